@@ -1,0 +1,83 @@
+"""Orpheus <-> SNAC token framing (integer-exact work).  Test infrastructure only.
+
+Restates, in numpy / plain Python:
+  * OrpheusTokens                      LlamaTTS.swift:20-30
+  * llamaDecodeAudioFromCodes (split)  LlamaTTS.swift:41-64   -> deinterleave()
+  * llamaEncodeAudioToCodes (merge)    LlamaTTS.swift:84-97   -> interleave()
+  * LlamaTTSModel.parseOutput          LlamaTTS.swift:383-434 -> parse_output()
+  * prompt wrapping of prepareInputIds LlamaTTS.swift:477-552 -> wrap_prompt()
+(paths relative to Sources/MLXAudioTTS/Models/Llama/).
+"""
+from __future__ import annotations
+
+import numpy as np
+
+START_OF_HUMAN = 128259
+END_OF_HUMAN = 128260
+END_OF_TEXT = 128009
+START_OF_SPEECH = 128257
+END_OF_SPEECH = 128258
+PAD_TOKEN = 128263
+AUDIO_START = 128261
+AUDIO_END = 128262
+AUDIO_TOKEN_OFFSET = 128266
+CODEBOOK = 4096
+
+
+def deinterleave(code_list):
+    """LlamaTTS.swift:41-58.  7-token frames -> (L0[G], L1[2G], L2[4G]).
+
+    numGroups = (count + 1) / 7 exactly as the reference (:46); callers hand in
+    lists already trimmed to a multiple of 7 (parseOutput :424)."""
+    code_list = [int(c) for c in code_list]
+    n_groups = (len(code_list) + 1) // 7
+    l1, l2, l3 = [], [], []
+    for i in range(n_groups):
+        b = 7 * i
+        l1.append(code_list[b])
+        l2.append(code_list[b + 1] - 4096)
+        l3.append(code_list[b + 2] - 2 * 4096)
+        l3.append(code_list[b + 3] - 3 * 4096)
+        l2.append(code_list[b + 4] - 4 * 4096)
+        l3.append(code_list[b + 5] - 5 * 4096)
+        l3.append(code_list[b + 6] - 6 * 4096)
+    return (np.asarray(l1, np.int32), np.asarray(l2, np.int32), np.asarray(l3, np.int32))
+
+
+def interleave(l1, l2, l3):
+    """LlamaTTS.swift:84-95 (exact inverse of deinterleave)."""
+    out = []
+    for i in range(len(l1)):
+        out += [int(l1[i]), int(l2[2 * i]) + 4096, int(l3[4 * i]) + 2 * 4096,
+                int(l3[4 * i + 1]) + 3 * 4096, int(l2[2 * i + 1]) + 4 * 4096,
+                int(l3[4 * i + 2]) + 5 * 4096, int(l3[4 * i + 3]) + 6 * 4096]
+    return np.asarray(out, np.int32)
+
+
+def parse_output_row(ids):
+    """parseOutput for ONE utterance (LlamaTTS.swift:383-434 with B = 1, which is the
+    only way the reference ever calls it, :749-752): crop after the LAST start-of-speech,
+    drop end-of-speech, trim to a multiple of 7, subtract the audio token offset."""
+    ids = [int(t) for t in ids]
+    last = None
+    for j, t in enumerate(ids):
+        if t == START_OF_SPEECH:
+            last = j
+    cropped = ids[last + 1:] if last is not None else ids
+    kept = [t for t in cropped if t != END_OF_SPEECH]
+    n = (len(kept) // 7) * 7
+    return np.asarray([t - AUDIO_TOKEN_OFFSET for t in kept[:n]], np.int32)
+
+
+def wrap_prompt(text_ids):
+    """[SOH] text [EOT][EOH]   (LlamaTTS.swift:478-482,533-537)."""
+    return np.asarray([START_OF_HUMAN] + [int(t) for t in text_ids] + [END_OF_TEXT, END_OF_HUMAN], np.int32)
+
+
+def left_pad_batch(rows):
+    """Left-pad with 128263 to the longest row; mask = ids != pad (LlamaTTS.swift:493-552)."""
+    m = max(len(r) for r in rows)
+    ids = np.full((len(rows), m), PAD_TOKEN, np.int32)
+    for i, r in enumerate(rows):
+        ids[i, m - len(r):] = r
+    return ids, ids != PAD_TOKEN

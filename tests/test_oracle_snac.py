@@ -1,0 +1,116 @@
+"""Pin the SNAC oracle against an independent implementation (torch.nn.functional) of the
+conv definitions the reference relies on, and against float64."""
+import math
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as Fn
+
+from oracle import snac
+
+
+@pytest.mark.parametrize("groups,dil,k,stride,pad", [(1, 1, 7, 1, 3), (8, 3, 7, 1, 9), (8, 9, 7, 1, 27),
+                                                     (1, 1, 1, 1, 0), (2, 1, 4, 2, 1), (1, 1, 16, 8, 4)])
+def test_conv1d_matches_torch(groups, dil, k, stride, pad):
+    rng = np.random.default_rng(0)
+    cin, cout = 8, 8
+    x = rng.standard_normal((2, cin, 50)).astype(np.float32)
+    w = rng.standard_normal((cout, k, cin // groups)).astype(np.float32)      # MLX layout
+    b = rng.standard_normal(cout).astype(np.float32)
+    y = snac.conv1d_nct(x, w, b, stride=stride, padding=pad, dilation=dil, groups=groups)
+    yt = Fn.conv1d(torch.from_numpy(x), torch.from_numpy(w).permute(0, 2, 1).contiguous(), torch.from_numpy(b),
+                   stride=stride, padding=pad, dilation=dil, groups=groups).numpy()
+    assert y.shape == yt.shape
+    np.testing.assert_allclose(y, yt, rtol=1e-4, atol=1e-4)
+
+
+@pytest.mark.parametrize("stride", [2, 3, 4, 7, 8])
+def test_conv_transpose_matches_torch_and_length(stride):
+    rng = np.random.default_rng(1)
+    cin, cout, T = 6, 4, 11
+    k, pad = 2 * stride, int(math.ceil(stride / 2))
+    x = rng.standard_normal((2, cin, T)).astype(np.float32)
+    w = rng.standard_normal((cin, k, cout)).astype(np.float32)                # reference layout [in,k,out]
+    b = rng.standard_normal(cout).astype(np.float32)
+    y = snac.conv_transpose1d_nct(x, w, b, stride=stride, padding=pad)
+    yt = Fn.conv_transpose1d(torch.from_numpy(x), torch.from_numpy(w).permute(0, 2, 1).contiguous(),
+                             torch.from_numpy(b), stride=stride, padding=pad).numpy()
+    np.testing.assert_allclose(y, yt, rtol=1e-4, atol=1e-4)
+    # s*T for even s, s*T - 1 for odd s (output_padding dropped, Layers.swift:169-176)
+    assert y.shape[2] == (stride * T if stride % 2 == 0 else stride * T - 1)
+
+
+def _torch_decode(cfg, W, codes, noises):
+    """Independent re-implementation of the module tree with torch functional ops (float64)."""
+    t = lambda a: torch.from_numpy(np.asarray(a, np.float64))
+
+    def wn(p):
+        v, g = t(W[p + ".weight_v"]), t(W[p + ".weight_g"])
+        return g * v / (v.pow(2).sum((1, 2), keepdim=True).sqrt() + 1e-12)
+
+    def conv(x, p, bias=True, **kw):
+        return Fn.conv1d(x, wn(p).permute(0, 2, 1).contiguous(), t(W[p + ".bias"]) if bias else None, **kw)
+
+    def snk(x, a):
+        a = t(W[a])
+        return x + (1.0 / (a + 1e-9)) * torch.sin(a * x) ** 2
+
+    zq = 0
+    for i, s in enumerate(cfg.vq_strides):
+        p = f"quantizer.quantizers.{i}"
+        z = t(W[p + ".codebook.weight"])[torch.from_numpy(codes[i]).long()].transpose(1, 2)
+        z = conv(z, p + ".out_proj")
+        zq = zq + z.repeat_interleave(s, dim=2)
+    p = "decoder.model.layers"
+    x = conv(zq, p + ".0", padding=3, groups=zq.shape[1])
+    x = conv(x, p + ".1")
+    for i, s in enumerate(cfg.decoder_rates):
+        b = f"{p}.{2 + i}.block.layers"
+        x = snk(x, b + ".0.alpha")
+        v, g = t(W[b + ".1.weight_v"]), t(W[b + ".1.weight_g"])
+        wt = g * v / v.pow(2).sum((1, 2), keepdim=True).sqrt()
+        x = Fn.conv_transpose1d(x, wt.permute(0, 2, 1).contiguous(), t(W[b + ".1.bias"]), stride=s,
+                                padding=int(math.ceil(s / 2)))
+        x = x + t(noises[i])[:, None, :] * conv(x, b + ".2.linear", bias=False)
+        for j, d in enumerate((1, 3, 9)):
+            r = f"{b}.{3 + j}.block.layers"
+            h = snk(x, r + ".0.alpha")
+            h = conv(h, r + ".1", padding=3 * d, dilation=d, groups=x.shape[1])
+            h = snk(h, r + ".2.alpha")
+            x = x + conv(h, r + ".3")
+    n = 2 + len(cfg.decoder_rates)
+    x = snk(x, f"{p}.{n}.alpha")
+    return torch.tanh(conv(x, f"{p}.{n + 1}", padding=3)).numpy()
+
+
+@pytest.mark.parametrize("cfgd,batch,groups", [(snac.TINY, 2, 5), ({}, 1, 2)])
+def test_full_decode_matches_independent_torch_float64(cfgd, batch, groups):
+    cfg = snac.SnacConfig(**cfgd)
+    W = snac.make_synthetic_weights(cfg)
+    codes = snac.synthetic_codes(cfg, batch, groups)
+    nz = snac.synthetic_noise(cfg, batch, groups)
+    y = snac.SnacOracle(cfg, W).decode(codes, nz)
+    assert y.shape == (batch, 1, groups * cfg.vq_strides[0] * int(np.prod(cfg.decoder_rates)))
+    ref = _torch_decode(cfg, W, codes, nz)
+    rms = float(np.sqrt(np.mean((y - ref) ** 2)))
+    assert rms < 2e-5, rms
+    assert np.all(np.abs(y) < 1.0)
+    # decoded waveform must not be degenerate (tanh neither dead nor saturated)
+    assert 0.05 < y.std() < 0.9
+
+
+def test_c1_shape_and_zero_noise_equals_no_noise():
+    # BASELINE config 1: G=12 -> 24576 samples; run on the tiny net for speed
+    cfg = snac.SnacConfig(**snac.TINY)
+    W = snac.make_synthetic_weights(cfg)
+    o = snac.SnacOracle(cfg, W)
+    codes = snac.synthetic_codes(cfg, 1, 12)
+    zeros = [np.zeros((1, t), np.float32) for t in o.noise_lengths(12)]
+    a = o.decode(codes, None)
+    b = o.decode(codes, zeros)
+    assert a.shape == (1, 1, 12 * 4 * 32)
+    assert np.array_equal(a, b)
+    full = snac.SnacConfig()
+    assert full.resolved_latent_dim == 768 and full.hop_length == 512
+    assert snac.SnacOracle(full, {}).noise_lengths(12) == [384, 3072, 12288, 24576]
