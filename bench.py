@@ -1,0 +1,215 @@
+#!/usr/bin/env python
+"""Headline benchmark (BASELINE.json): audio-seconds/sec, Orpheus-3B TTS generate + SNAC decode,
+batch 32 per GPU, bf16, synthetic weights + synthetic prompts (no checkpoints / datasets offline).
+
+A "step" = one full batched generate(): 32-token prompts -> prefill -> 672 decode steps with on-device
+sampling (T=0.6, top-p 0.8, repetition penalty 1.3 over 20 tokens; frame-constrained so that random
+weights emit valid SNAC frames - every vocabulary entry is still processed) -> parseOutput ->
+de-interleave -> SNAC 24 kHz decode of 96 frames per row -> PCM resident in HBM (+ one RCCL all-gather of
+the PCM when N > 1).  Inputs are resident in HBM/host-pinned-free: prompts are 4 KiB.
+
+  python bench.py --gpus 1 --steps 2 --warmup 1
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+         bench.py --gpus N --steps K --warmup W
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+ROWS_PER_GPU = 32
+PROMPT_LEN = 32
+NEW_TOKENS = 672            # 96 SNAC frames = 8.192 s per row
+HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.29 TB/s measured copy)
+
+
+def make_prompts(rows, row0, seed=1237):
+    rng = np.random.default_rng(seed)
+    allp = rng.integers(0, 128000, (row0 + rows, PROMPT_LEN - 4)).astype(np.int32)   # keyed by global row
+    out = []
+    for r in range(row0, row0 + rows):
+        out.append(np.concatenate([[128259], allp[r], [128009, 128260, 128257]]).astype(np.int32))
+    return out
+
+
+def cpu_baseline(snac_cfg_dict):
+    """Oracle (CPU restatement of the reference's MLX path) on a BOUNDED sample, rank 0 / N=1 only.
+    The reference is batch-1 (LlamaTTS.swift:683-688): one utterance, sequential.  Sample = 4 decode steps
+    of ONE Orpheus-3B-shaped layer + the lm_head at context 368 (x28 layers extrapolated) + SNAC decode of
+    12 frames (1.024 s)."""
+    import torch
+    from oracle import llama as ollama
+    from oracle import snac as osnac
+    cores = torch.get_num_threads()
+    full = ollama.ORPHEUS_3B
+    one = ollama.LlamaConfig(**{**full.__dict__, "num_hidden_layers": 1})
+    g = torch.Generator().manual_seed(0)
+    W = {}
+    d, ff, H, Hkv, D = one.hidden_size, one.intermediate_size, one.num_attention_heads, one.num_key_value_heads, 128
+
+    def rnd(*s):
+        return (torch.rand(*s, generator=g) - 0.5) * 0.05
+    W["model.embed_tokens.weight"] = rnd(one.vocab_size, d)
+    W["model.norm.weight"] = torch.ones(d)
+    p = "model.layers.0"
+    W[p + ".input_layernorm.weight"] = torch.ones(d); W[p + ".post_attention_layernorm.weight"] = torch.ones(d)
+    W[p + ".self_attn.q_proj.weight"] = rnd(H * D, d); W[p + ".self_attn.k_proj.weight"] = rnd(Hkv * D, d)
+    W[p + ".self_attn.v_proj.weight"] = rnd(Hkv * D, d); W[p + ".self_attn.o_proj.weight"] = rnd(d, H * D)
+    W[p + ".mlp.gate_proj.weight"] = rnd(ff, d); W[p + ".mlp.up_proj.weight"] = rnd(ff, d)
+    W[p + ".mlp.down_proj.weight"] = rnd(d, ff)
+    orc = ollama.LlamaOracle(one, W, round="bf16")
+    orc.reset(1)
+    orc.forward([np.arange(368) % 1000])                 # context
+    t0 = time.perf_counter()
+    steps = 4
+    for i in range(steps):
+        orc.forward([[i + 1]])
+    t_step_1layer = (time.perf_counter() - t0) / steps
+    # split: lm_head+embed part measured separately
+    h = torch.randn(1, d)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        orc.linear(h, orc.w["model.embed_tokens.weight"])
+    t_head = (time.perf_counter() - t0) / steps
+    t_layer = max(t_step_1layer - t_head, 1e-6)
+    t_token = 28 * t_layer + t_head
+    ocfg = osnac.SnacConfig(**snac_cfg_dict)
+    SW = osnac.make_synthetic_weights(ocfg, seed=1234)
+    so = osnac.SnacOracle(ocfg, SW)
+    codes = osnac.synthetic_codes(ocfg, 1, 12)
+    t0 = time.perf_counter()
+    so.decode(codes, None)
+    t_snac = time.perf_counter() - t0                     # 1.024 s of audio
+    tokens_per_audio_s = 7.0 * 24000.0 / 2048.0
+    cpu_s_per_audio_s = tokens_per_audio_s * t_token + t_snac / 1.024
+    return {"value": 1.0 / cpu_s_per_audio_s, "unit": "audio-s/s", "cores": int(cores), "kind": "port",
+            "sample": "oracle (CPU restatement, bf16-rounded fp32 torch/numpy), batch-1 like the reference: 4 decode "
+                      "steps of 1 Orpheus-3B layer + lm_head at context 368 (x28 layers extrapolated) + SNAC decode of "
+                      "12 frames; per-token %.3f s, SNAC %.3f s per 1.024 s" % (t_token, t_snac)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=2)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", rank=rank, world_size=world)      # nccl == RCCL on ROCm
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (no CPU fallback in the product path)")
+    device = local_rank if world > 1 else 0
+    torch.cuda.set_device(device)
+
+    import mlx_audio_swift_amd as mas
+    from mlx_audio_swift_amd.sharding import all_gather_pcm
+    from mlx_audio_swift_amd.synthetic import snac_synthetic_weights
+
+    snac_cfg = mas.SNACConfig()                                            # snac_24khz dims
+    codec = mas.SNAC.from_weights(snac_cfg, snac_synthetic_weights(snac_cfg, seed=1234), device=device)
+    lm_cfg = mas.LlamaTTSConfiguration(rope_theta=500000.0, rope_scaling={"factor": 32.0, "low_freq_factor": 1.0,
+                                       "high_freq_factor": 4.0, "original_max_position_embeddings": 8192,
+                                       "rope_type": "llama3"})            # Orpheus-3B = Llama-3.2-3B dims, vocab 156940
+    lm = mas.LlamaTTSModel.synthetic(lm_cfg, codec=codec, device=device, seed=4321)
+
+    n_rows = ROWS_PER_GPU * world
+    row0 = rank * ROWS_PER_GPU
+    prompts = make_prompts(ROWS_PER_GPU, row0)
+    flat, lens = lm._flatten(prompts)
+    gp = mas.GenerateParameters(max_tokens=NEW_TOKENS, temperature=0.6, top_p=0.8, repetition_penalty=1.3,
+                                repetition_context_size=20, seed=2024, frame_constrained=True, row_offset=row0)
+    gpc = gp.to_c()
+    import ctypes as C
+    n_samples = codec.num_samples(NEW_TOKENS // 7)
+    pcm = torch.zeros((ROWS_PER_GPU, n_samples), dtype=torch.float32, device=f"cuda:{device}")
+    plens = (C.c_int64 * ROWS_PER_GPU)()
+    ntok = (C.c_int32 * ROWS_PER_GPU)()
+    L = mas._lib.lib()
+
+    def step():
+        st = L.mis_tts_generate_device(lm._h, flat.ctypes.data, lens.ctypes.data, ROWS_PER_GPU, C.byref(gpc), None,
+                                       pcm.data_ptr(), n_samples, plens, ntok)
+        if st != 0:
+            raise RuntimeError(mas._lib.last_error())
+        lens_t = torch.tensor(list(plens), dtype=torch.int64, device=pcm.device)
+        return all_gather_pcm(pcm, lens_t, n_rows)
+
+    def sync():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        allp, alll = step()
+    sync()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=pcm.device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    audio_s = float(alll.sum().item()) / 24000.0 * args.steps
+    value = audio_s / elapsed
+    timing = lm.last_timing()
+
+    result = None
+    if rank == 0:
+        # roofline of the dominant kernel: the weight-streaming skinny GEMM (k_gemm_skinny); measured live with
+        # HIP events on the library's stream, rotating over the 28 layers so the 256 MB Infinity Cache cannot
+        # serve the weights.  Dominant instance by bytes/step: gate+up (42 % of the step's weight bytes).
+        names = ["qkv", "o_proj", "gate_up", "down", "lm_head"]
+        gemms = {}
+        for i, n in enumerate(names):
+            ms, by = lm.time_gemm(i, ROWS_PER_GPU, iters=56)
+            gemms[n] = {"ms": ms, "GBps": by / ms / 1e6, "bytes": by}
+        dom = gemms["gate_up"]
+        roofline = {"bound": "hbm", "kernel": "k_gemm_skinny<MT=2,R=2,silu_mul> (gate+up, 100.7 MB/launch)",
+                    "achieved": dom["GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": dom["GBps"] / HBM_PEAK_GBS,
+                    "traffic": None,
+                    "all_gemms_GBps": {k: round(v["GBps"], 1) for k, v in gemms.items()},
+                    "step": {"ms": timing["step_ms_avg"], "algorithmic_GB": timing["hbm_bytes_per_step"] / 1e9,
+                             "achieved_GBps": timing["hbm_bytes_per_step"] / max(timing["step_ms_avg"], 1e-9) / 1e6}}
+        cpu = None
+        if world == 1 and not args.no_cpu_baseline:
+            cpu = cpu_baseline({})
+        result = {
+            "metric": "audio-seconds/sec (TTS gen+codec decode), Orpheus-3B batch32 per GPU",
+            "value": value, "unit": "audio-s/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "config": {"workload": "Orpheus-3B bf16 TTS + SNAC 24 kHz decode, batch 32 per GPU (BASELINE configs[2]; "
+                                   "configs[1] Soprano not built yet), 32-token prompts, 672 new tokens/row = 8.192 s/row",
+                       "rows_per_gpu": ROWS_PER_GPU, "global_rows": n_rows, "prompt_len": PROMPT_LEN,
+                       "new_tokens": NEW_TOKENS, "parallelism": f"utterance-dp{world}", "sampler": "T0.6 top-p0.8 rep1.3"},
+            "value_per_gpu": value / world,
+            "phases_ms": {"prefill": timing["prefill_ms"], "decode": timing["decode_ms"], "codec": timing["codec_ms"]},
+            "roofline": roofline, "cpu_baseline": cpu,
+        }
+        print(json.dumps(result))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,234 @@
+/*
+ * mi_speech.h - C ABI of libmi_speech.so: MI355X-native (gfx950) kernels for the
+ * TTS generate()/generateStream() + neural-codec hot path of Blaizzy/mlx-audio-swift.
+ *
+ * The reference has NO FFI: its boundary is Swift protocol conformance
+ *   SpeechGenerationModel   Sources/MLXAudioTTS/Generation.swift:8-39
+ *   AudioCodecModel         Sources/MLXAudioCodecs/AudioCodecModel.swift:4-27
+ * implemented per model by classes whose arithmetic is MLX (un-vendored mlx-swift 0.31.4).
+ * This header is what a thin Swift class conforming to those protocols binds instead of MLX
+ * (see INTEGRATION.md for the Swift shim); every entry point cites the reference symbol it
+ * replaces.  Plain C types only: pointers + sizes, no torch / MLX types.
+ *
+ * Pointer convention: every data pointer may be HOST or DEVICE memory of the handle's GPU
+ * (copies use hipMemcpyDefault; unified addressing tells them apart).  Inputs are borrowed for
+ * the duration of the call.  Library-allocated outputs are pinned host memory released with
+ * mis_free().  No entry point aborts: failures return a status and set mis_last_error().
+ * Threading: one in-flight call per handle; distinct handles are independent.
+ */
+#ifndef MI_SPEECH_H
+#define MI_SPEECH_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MIS_ABI_VERSION 1
+
+/* <-> AudioGenerationError, Sources/MLXAudioCore/Generation/GenerationTypes.swift:66-87 */
+typedef enum {
+    MIS_OK = 0,
+    MIS_ERR_NOT_INITIALIZED = 1,   /* .modelNotInitialized */
+    MIS_ERR_GENERATION_FAILED = 2, /* .generationFailed    */
+    MIS_ERR_INVALID_INPUT = 3,     /* .invalidInput        */
+    MIS_ERR_AUDIO_DECODE = 4,      /* .audioDecodingFailed */
+    MIS_ERR_AUDIO_ENCODE = 5,      /* .audioEncodingFailed */
+    MIS_ERR_CANCELLED = 6,         /* Task cancellation, LlamaTTS.swift:715,911 */
+    MIS_ERR_DEVICE = 7             /* HIP runtime failure / no GPU */
+} mis_status;
+
+typedef enum { MIS_F32 = 0, MIS_F16 = 1, MIS_BF16 = 2, MIS_I32 = 3 } mis_dtype;
+
+const char* mis_last_error(void);          /* thread-local message of the last failing call */
+int         mis_abi_version(void);
+void        mis_free(void* p);             /* releases library-allocated (pinned host) outputs */
+int         mis_device_count(void);
+
+/* ------------------------------------------------------------------------------------------
+ * Orpheus <-> SNAC token framing (integer-exact).
+ * ---------------------------------------------------------------------------------------- */
+
+/* llamaDecodeAudioFromCodes, LlamaTTS.swift:41-64: split 7-token frames into the three SNAC
+ * levels.  codes7: [batch, 7*groups] values in [0, 7*4096); l0 [batch,groups], l1 [batch,2*groups],
+ * l2 [batch,4*groups], values in [0,4096).  Runs on the GPU `device`. */
+mis_status mis_orpheus_deinterleave(int device, const int32_t* codes7, int batch, int groups,
+                                    int32_t* l0, int32_t* l1, int32_t* l2);
+
+/* LlamaTTSModel.parseOutput, LlamaTTS.swift:383-434, per row (App. D.2 of SURVEY.md): crop after
+ * the last start-of-speech (128257), drop end-of-speech (128258), trim to a multiple of 7, subtract
+ * 128266.  ids: [batch, stride] with lens[batch] valid entries per row; codes_out: [batch, stride];
+ * n_codes_out: [batch]. */
+mis_status mis_orpheus_parse_output(int device, const int32_t* ids, const int32_t* lens, int batch,
+                                    int stride, int32_t* codes_out, int32_t* n_codes_out);
+
+/* ------------------------------------------------------------------------------------------
+ * SNAC codec (decode path).   Replaces class SNAC, Sources/MLXAudioCodecs/SNAC/SNACDecoder.swift.
+ * ---------------------------------------------------------------------------------------- */
+typedef struct mis_snac mis_snac;
+
+/* SNACConfig, SNAC/Config.swift:10-37 (decode-relevant fields) */
+typedef struct {
+    int32_t sampling_rate;
+    int32_t latent_dim;        /* = encoder_dim * 2^len(encoder_rates), SNACDecoder.swift:50 */
+    int32_t decoder_dim;
+    int32_t n_decoder_rates;   /* <= 8 */
+    int32_t decoder_rates[8];
+    int32_t codebook_size;
+    int32_t codebook_dim;
+    int32_t n_codebooks;       /* <= 8 */
+    int32_t vq_strides[8];
+    int32_t noise;             /* bool */
+    int32_t depthwise;         /* bool; only 1 is supported (24 kHz model) */
+    int32_t attn_window_size;  /* 0 = none; only 0 is supported (24 kHz model) */
+} mis_snac_config;
+
+/* SNAC.fromModelDirectory, SNACDecoder.swift:156-189: config.json + model.safetensors */
+mis_status mis_snac_load(const char* model_dir, int device, mis_snac** out);
+/* programmatic construction (tests / hosts that already hold the arrays) */
+mis_status mis_snac_create(const mis_snac_config* cfg, int device, mis_snac** out);
+/* one tensor in the reference's key layout, e.g.
+ * "decoder.model.layers.1.weight_v"; dtype F32/F16/BF16; shape as stored. */
+mis_status mis_snac_set_tensor(mis_snac*, const char* name, const void* data, mis_dtype dtype,
+                               const int64_t* shape, int ndim);
+/* update(parameters:verify:.all), SNACDecoder.swift:185: every decoder/quantizer key must be
+ * present; folds weight-norm (Layers.swift:35-42,102-103,166) and builds device tables. */
+mis_status mis_snac_finalize(mis_snac*);
+void       mis_snac_destroy(mis_snac*);
+/* number of samples decode() produces for t_coarse entries of codes[0] */
+int64_t    mis_snac_num_samples(const mis_snac*, int t_coarse);
+/* length of NoiseBlock i's input (i < n_decoder_rates) for t_coarse */
+int64_t    mis_snac_noise_len(const mis_snac*, int block, int t_coarse);
+
+/* NoiseBlock policy when a decode is given noise == NULL: null_noise_is_zero = 0 (default, the
+ * reference's behaviour: x + N(0,1)[B,1,T] * conv(x), Layers.swift:270-278) draws the noise on the
+ * device from the documented counter generator keyed by (seed, block, global row, t);
+ * null_noise_is_zero = 1 adds nothing (deterministic decode). */
+mis_status mis_snac_set_noise(mis_snac*, int null_noise_is_zero, uint64_t seed);
+
+/* SNAC.decode / decodeAudio, SNACDecoder.swift:127-131,201-203 (fromCodes VQ.swift:165-191 +
+ * Decoder Layers.swift:364-421).  codes[i]: int32 [batch, t_coarse * vq_strides[0]/vq_strides[i]];
+ * noise: NULL (see mis_snac_set_noise) or n_decoder_rates pointers to f32 [batch, noise_len(i)]
+ * standing in for MLXRandom.normal (Layers.swift:274); pcm_out: f32 [batch, num_samples]. */
+mis_status mis_snac_decode(mis_snac*, const int32_t* const* codes, int batch, int t_coarse,
+                           const float* const* noise, float* pcm_out);
+/* debug/parity taps: copy an intermediate ("zq","stem_dw","stem_pw","block0".."blockN") of the
+ * LAST decode into out (f32 [batch, C, T]); returns its C and T. */
+mis_status mis_snac_debug_tap(mis_snac*, const char* name, float* out, int64_t capacity,
+                              int32_t* channels, int64_t* length);
+
+/* ------------------------------------------------------------------------------------------
+ * Orpheus / Llama token LM + TTS generate.  Replaces LlamaTTSModel, LlamaTTS.swift:354-977.
+ * ---------------------------------------------------------------------------------------- */
+typedef struct mis_tts mis_tts;
+
+/* LlamaTTSConfiguration, LlamaTTSConfig.swift:15-61 */
+typedef struct {
+    int32_t hidden_size, num_hidden_layers, intermediate_size;
+    int32_t num_attention_heads, num_key_value_heads, head_dim;
+    int32_t vocab_size;
+    float   rms_norm_eps;
+    float   rope_theta;
+    /* llama3 rope scaling, LlamaTTS.swift:111-186 (defaults 32 / 1 / 4 / 8192) */
+    float   rope_factor, rope_low_freq_factor, rope_high_freq_factor, rope_original_max_pos;
+    int32_t tie_word_embeddings;
+    int32_t sample_rate;
+} mis_lm_config;
+
+/* GenerateParameters as used by LlamaTTS.swift:573-581,691-696 (mlx-swift-lm) */
+typedef struct {
+    int32_t  max_tokens;           /* default 1200 */
+    float    temperature;          /* 0 => greedy argmax */
+    float    top_p;                /* outside (0,1) => no nucleus cut */
+    float    repetition_penalty;   /* <= 0 or 1 => off */
+    int32_t  repetition_context;   /* default 20 */
+    uint64_t seed;                 /* mis-sampler-v1 RNG key (see csrc/lm_sampler.hip) */
+    int32_t  frame_constrained;    /* 0 normal. 1 (synthetic-weight benches): step i may only emit
+                                      128266 + (i%7)*4096 + [0,4096) - all vocab entries are still
+                                      processed; EOS can then never be sampled */
+    int64_t  row_offset;           /* global index of row 0 (RNG keyed by global row => sharding-invariant) */
+} mis_gen_params;
+
+/* AudioGeneration events, GenerationTypes.swift:50-61 */
+typedef enum { MIS_EVENT_TOKEN = 0, MIS_EVENT_INFO = 1, MIS_EVENT_AUDIO = 2 } mis_event_kind;
+/* AudioGenerationInfo, GenerationTypes.swift:14-45 */
+typedef struct {
+    int32_t prompt_token_count, generation_token_count;
+    double  prefill_time, generate_time, tokens_per_second, peak_memory_gb;
+} mis_gen_info;
+/* payload: TOKEN -> const int32_t* (n=1); INFO -> const mis_gen_info* (n=1); AUDIO -> const float* (n samples) */
+typedef void (*mis_event_cb)(void* user, int row, mis_event_kind kind, const void* payload, int64_t n);
+
+/* LlamaTTSModel.fromModelDirectory, LlamaTTS.swift:942-977: config.json + *.safetensors of the LM;
+ * codec is borrowed (post_load_hook loads SNAC separately, :595-602). */
+mis_status mis_tts_load(const char* model_dir, mis_snac* codec, int device, mis_tts** out);
+mis_status mis_tts_create(const mis_lm_config* cfg, mis_snac* codec /* may be NULL */, int device, mis_tts** out);
+/* HF/MLX key layout: model.embed_tokens.weight, model.layers.N.*, model.norm.weight, [lm_head.weight] */
+mis_status mis_tts_set_tensor(mis_tts*, const char* name, const void* data, mis_dtype dtype,
+                              const int64_t* shape, int ndim);
+/* fills every weight on the device with the documented generator "mis-synth-v1"
+ * (oracle/synth.py has the same formula); benches only - there are no checkpoints offline. */
+mis_status mis_tts_init_synthetic(mis_tts*, uint64_t seed);
+mis_status mis_tts_finalize(mis_tts*);     /* verify all keys present; pack weights for MFMA streaming */
+void       mis_tts_destroy(mis_tts*);
+
+/* LM-only taps (parity tests, teacher forcing).  reset: new batch, empty KV caches (makeCache,
+ * LlamaTTS.swift:604-608).  forward: ONE token per active row through the model
+ * (LlamaTTSModel.callAsFunction :557-567 with L=1 and cache), logits_out f32 [batch, vocab]
+ * (bf16 values, widened) or NULL. */
+mis_status mis_lm_reset(mis_tts*, int batch, int max_context);
+mis_status mis_lm_forward(mis_tts*, const int32_t* ids, const uint8_t* active, float* logits_out);
+/* processor + sampler of the generate loop (LlamaTTS.swift:717-721) on caller-provided logits:
+ * logits f32 [batch, vocab]; window [batch, ctx] (ids, right-aligned valid part = window_len[b]);
+ * lo/hi: optional allowed id range (hi<=0 => vocab); tokens_out [batch].  mis-sampler-v1. */
+mis_status mis_sample_logits(int device, const float* logits, int batch, int vocab,
+                             const int32_t* window, const int32_t* window_len, int ctx,
+                             const mis_gen_params* params, int step, int lo, int hi,
+                             int32_t* tokens_out);
+
+/* generate(text:voice:...) LlamaTTS.swift:658-765 for a BATCH of already-tokenised prompts
+ * (tokenisation stays on the host side: prepareInputIds :446-553 / swift-transformers).
+ * prompt_ids: concatenated rows; prompt_lens[batch].  snac_noise: NULL (N(0,1) drawn on the device,
+ * keyed by params->seed and the global row) or explicit noise as in mis_snac_decode (then every row
+ * must produce the same number of frames).  Outputs (library-allocated, mis_free):
+ * *pcm_out f32 [batch, *pcm_stride] with pcm_lens[batch] valid samples per row;
+ * *tokens_out (optional, may be NULL) int32 [batch, *tokens_stride] generated ids (EOS included
+ * when sampled, as in the .token stream :862-866), n_tokens[batch]. */
+mis_status mis_tts_generate(mis_tts*, const int32_t* prompt_ids, const int32_t* prompt_lens, int batch,
+                            const mis_gen_params* params, const float* const* snac_noise,
+                            float** pcm_out, int64_t* pcm_stride, int64_t* pcm_lens,
+                            int32_t** tokens_out, int64_t* tokens_stride, int32_t* n_tokens);
+/* Same, leaving PCM resident in HBM: pcm_dev f32 [batch, pcm_stride] caller-allocated DEVICE memory
+ * (pcm_stride >= num_samples for max_tokens/7 groups).  What bench.py times. */
+mis_status mis_tts_generate_device(mis_tts*, const int32_t* prompt_ids, const int32_t* prompt_lens, int batch,
+                                   const mis_gen_params* params, const float* const* snac_noise,
+                                   float* pcm_dev, int64_t pcm_stride, int64_t* pcm_lens, int32_t* n_tokens);
+/* generateStream(...) LlamaTTS.swift:777-913: .token per step and row, then per row .info and ONE
+ * final .audio (Orpheus does not stream audio chunks, :893-904).  cancel_flag polled per step. */
+mis_status mis_tts_generate_stream(mis_tts*, const int32_t* prompt_ids, const int32_t* prompt_lens, int batch,
+                                   const mis_gen_params* params, const float* const* snac_noise,
+                                   mis_event_cb on_event, void* user, const volatile int* cancel_flag);
+
+/* per-phase device timings of the last generate (ms): [0]=prefill [1]=decode loop [2]=parse+codec,
+ * plus average duration (ms) and launch count of the dominant GEMM kernel measured with HIP events
+ * on the library's own stream when profiling is enabled with mis_tts_set_profiling(ctx, 1). */
+typedef struct {
+    double prefill_ms, decode_ms, codec_ms;
+    double step_ms_avg;            /* decode_ms / steps */
+    int32_t steps;
+    double gemm_probe_ms;          /* avg duration of ONE lm_head GEMM launch (HIP events), 0 if off */
+    double gemm_probe_bytes;       /* algorithmic bytes of that launch */
+    double hbm_bytes_per_step;     /* algorithmic bytes per decode step: weights + KV read */
+} mis_tts_timing;
+mis_status mis_tts_set_profiling(mis_tts*, int enabled);
+mis_status mis_tts_last_timing(mis_tts*, mis_tts_timing* out);
+/* time `iters` launches of one weight-streaming GEMM of the decode step in isolation (HIP events on
+ * the library stream): which = 0 qkv, 1 o_proj, 2 gate_up, 3 down, 4 lm_head.  avg_ms and the
+ * algorithmic bytes of one launch are returned.  Used by bench.py for the roofline object. */
+mis_status mis_tts_time_gemm(mis_tts*, int which, int batch, int iters, double* avg_ms, double* bytes);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MI_SPEECH_H */

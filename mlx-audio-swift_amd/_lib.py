@@ -1,0 +1,118 @@
+"""ctypes binding of libmi_speech.so (include/mi_speech.h).  Fails loudly when the library is
+missing - there is no fallback path."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libmi_speech.so")
+
+MIS_OK = 0
+STATUS_NAMES = {0: "ok", 1: "modelNotInitialized", 2: "generationFailed", 3: "invalidInput",
+                4: "audioDecodingFailed", 5: "audioEncodingFailed", 6: "cancelled", 7: "device"}
+MIS_F32, MIS_F16, MIS_BF16, MIS_I32 = 0, 1, 2, 3
+EVENT_TOKEN, EVENT_INFO, EVENT_AUDIO = 0, 1, 2
+
+
+class SnacConfigC(C.Structure):
+    _fields_ = [("sampling_rate", C.c_int32), ("latent_dim", C.c_int32), ("decoder_dim", C.c_int32),
+                ("n_decoder_rates", C.c_int32), ("decoder_rates", C.c_int32 * 8), ("codebook_size", C.c_int32),
+                ("codebook_dim", C.c_int32), ("n_codebooks", C.c_int32), ("vq_strides", C.c_int32 * 8),
+                ("noise", C.c_int32), ("depthwise", C.c_int32), ("attn_window_size", C.c_int32)]
+
+
+class LmConfigC(C.Structure):
+    _fields_ = [("hidden_size", C.c_int32), ("num_hidden_layers", C.c_int32), ("intermediate_size", C.c_int32),
+                ("num_attention_heads", C.c_int32), ("num_key_value_heads", C.c_int32), ("head_dim", C.c_int32),
+                ("vocab_size", C.c_int32), ("rms_norm_eps", C.c_float), ("rope_theta", C.c_float),
+                ("rope_factor", C.c_float), ("rope_low_freq_factor", C.c_float), ("rope_high_freq_factor", C.c_float),
+                ("rope_original_max_pos", C.c_float), ("tie_word_embeddings", C.c_int32), ("sample_rate", C.c_int32)]
+
+
+class GenParamsC(C.Structure):
+    _fields_ = [("max_tokens", C.c_int32), ("temperature", C.c_float), ("top_p", C.c_float),
+                ("repetition_penalty", C.c_float), ("repetition_context", C.c_int32), ("seed", C.c_uint64),
+                ("frame_constrained", C.c_int32), ("row_offset", C.c_int64)]
+
+
+class GenInfoC(C.Structure):
+    _fields_ = [("prompt_token_count", C.c_int32), ("generation_token_count", C.c_int32),
+                ("prefill_time", C.c_double), ("generate_time", C.c_double), ("tokens_per_second", C.c_double),
+                ("peak_memory_gb", C.c_double)]
+
+
+class TimingC(C.Structure):
+    _fields_ = [("prefill_ms", C.c_double), ("decode_ms", C.c_double), ("codec_ms", C.c_double),
+                ("step_ms_avg", C.c_double), ("steps", C.c_int32), ("gemm_probe_ms", C.c_double),
+                ("gemm_probe_bytes", C.c_double), ("hbm_bytes_per_step", C.c_double)]
+
+
+EVENT_CB = C.CFUNCTYPE(None, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int64)
+
+_P = C.c_void_p
+# name -> (restype, argtypes): every symbol include/mi_speech.h declares
+SYMBOLS = {
+    "mis_last_error": (C.c_char_p, []),
+    "mis_abi_version": (C.c_int, []),
+    "mis_free": (None, [_P]),
+    "mis_device_count": (C.c_int, []),
+    "mis_orpheus_deinterleave": (C.c_int, [C.c_int, _P, C.c_int, C.c_int, _P, _P, _P]),
+    "mis_orpheus_parse_output": (C.c_int, [C.c_int, _P, _P, C.c_int, C.c_int, _P, _P]),
+    "mis_snac_load": (C.c_int, [C.c_char_p, C.c_int, C.POINTER(_P)]),
+    "mis_snac_create": (C.c_int, [C.POINTER(SnacConfigC), C.c_int, C.POINTER(_P)]),
+    "mis_snac_set_tensor": (C.c_int, [_P, C.c_char_p, _P, C.c_int, C.POINTER(C.c_int64), C.c_int]),
+    "mis_snac_finalize": (C.c_int, [_P]),
+    "mis_snac_destroy": (None, [_P]),
+    "mis_snac_num_samples": (C.c_int64, [_P, C.c_int]),
+    "mis_snac_noise_len": (C.c_int64, [_P, C.c_int, C.c_int]),
+    "mis_snac_set_noise": (C.c_int, [_P, C.c_int, C.c_uint64]),
+    "mis_snac_decode": (C.c_int, [_P, C.POINTER(_P), C.c_int, C.c_int, C.POINTER(_P), _P]),
+    "mis_snac_debug_tap": (C.c_int, [_P, C.c_char_p, _P, C.c_int64, C.POINTER(C.c_int32), C.POINTER(C.c_int64)]),
+    "mis_tts_load": (C.c_int, [C.c_char_p, _P, C.c_int, C.POINTER(_P)]),
+    "mis_tts_create": (C.c_int, [C.POINTER(LmConfigC), _P, C.c_int, C.POINTER(_P)]),
+    "mis_tts_set_tensor": (C.c_int, [_P, C.c_char_p, _P, C.c_int, C.POINTER(C.c_int64), C.c_int]),
+    "mis_tts_init_synthetic": (C.c_int, [_P, C.c_uint64]),
+    "mis_tts_finalize": (C.c_int, [_P]),
+    "mis_tts_destroy": (None, [_P]),
+    "mis_lm_reset": (C.c_int, [_P, C.c_int, C.c_int]),
+    "mis_lm_forward": (C.c_int, [_P, _P, _P, _P]),
+    "mis_sample_logits": (C.c_int, [C.c_int, _P, C.c_int, C.c_int, _P, _P, C.c_int, C.POINTER(GenParamsC), C.c_int,
+                                    C.c_int, C.c_int, _P]),
+    "mis_tts_generate": (C.c_int, [_P, _P, _P, C.c_int, C.POINTER(GenParamsC), C.POINTER(_P), C.POINTER(_P),
+                                   C.POINTER(C.c_int64), _P, C.POINTER(_P), C.POINTER(C.c_int64), _P]),
+    "mis_tts_generate_device": (C.c_int, [_P, _P, _P, C.c_int, C.POINTER(GenParamsC), C.POINTER(_P), _P, C.c_int64,
+                                          _P, _P]),
+    "mis_tts_generate_stream": (C.c_int, [_P, _P, _P, C.c_int, C.POINTER(GenParamsC), C.POINTER(_P), EVENT_CB, _P, _P]),
+    "mis_tts_set_profiling": (C.c_int, [_P, C.c_int]),
+    "mis_tts_last_timing": (C.c_int, [_P, C.POINTER(TimingC)]),
+    "mis_tts_time_gemm": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
+}
+
+_lib = None
+
+
+class MisLibraryMissing(RuntimeError):
+    pass
+
+
+def lib():
+    """The loaded shared library.  Raises (never falls back) when it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise MisLibraryMissing(
+                f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(hipcc --offload-arch=gfx950). There is no CPU fallback.")
+        l = C.CDLL(LIB_PATH)
+        for name, (res, args) in SYMBOLS.items():
+            fn = getattr(l, name)          # AttributeError if the ABI lost a symbol
+            fn.restype = res
+            fn.argtypes = args
+        _lib = l
+    return _lib
+
+
+def last_error() -> str:
+    m = lib().mis_last_error()
+    return m.decode("utf-8", "replace") if m else ""

@@ -1,0 +1,196 @@
+"""SNAC codec, host mirror of `class SNAC: Module, AudioCodecModel`
+(Sources/MLXAudioCodecs/SNAC/SNACDecoder.swift:11-205).  All arithmetic runs in libmi_speech.so."""
+from __future__ import annotations
+
+import ctypes as C
+import json
+import os
+from dataclasses import dataclass, field
+
+import numpy as np
+
+from . import _lib
+from .generation import AudioGenerationError, check
+
+
+@dataclass
+class SNACConfig:
+    """SNAC/Config.swift:10-37"""
+    sampling_rate: int = 24000
+    encoder_dim: int = 48
+    encoder_rates: list = field(default_factory=lambda: [2, 4, 8, 8])
+    latent_dim: int | None = None
+    decoder_dim: int = 1024
+    decoder_rates: list = field(default_factory=lambda: [8, 8, 4, 2])
+    attn_window_size: int | None = None
+    codebook_size: int = 4096
+    codebook_dim: int = 8
+    vq_strides: list = field(default_factory=lambda: [4, 2, 1])
+    noise: bool = True
+    depthwise: bool = True
+
+    @classmethod
+    def from_dict(cls, d: dict) -> "SNACConfig":
+        keys = cls.__dataclass_fields__.keys()
+        return cls(**{k: d[k] for k in keys if k in d})
+
+    def to_c(self) -> "_lib.SnacConfigC":
+        c = _lib.SnacConfigC()
+        c.sampling_rate = self.sampling_rate
+        c.latent_dim = self.latent_dim or self.encoder_dim * 2 ** len(self.encoder_rates)
+        c.decoder_dim = self.decoder_dim
+        c.n_decoder_rates = len(self.decoder_rates)
+        for i, r in enumerate(self.decoder_rates):
+            c.decoder_rates[i] = r
+        c.codebook_size, c.codebook_dim = self.codebook_size, self.codebook_dim
+        c.n_codebooks = len(self.vq_strides)
+        for i, s in enumerate(self.vq_strides):
+            c.vq_strides[i] = s
+        c.noise = 1 if self.noise else 0
+        c.depthwise = 1 if self.depthwise else 0
+        c.attn_window_size = self.attn_window_size or 0
+        return c
+
+
+_NP_DTYPES = {np.dtype(np.float32): _lib.MIS_F32, np.dtype(np.float16): _lib.MIS_F16}
+
+
+def _tensor_args(arr):
+    """numpy / torch tensor -> (keepalive, data pointer, mis dtype, shape)."""
+    try:
+        import torch
+        if isinstance(arr, torch.Tensor):
+            t = arr.detach().contiguous()
+            if t.dtype == torch.bfloat16:
+                return t, t.data_ptr(), _lib.MIS_BF16, tuple(t.shape)
+            if t.dtype == torch.float16:
+                return t, t.data_ptr(), _lib.MIS_F16, tuple(t.shape)
+            t = t.to(torch.float32).contiguous()
+            return t, t.data_ptr(), _lib.MIS_F32, tuple(t.shape)
+    except ImportError:
+        pass
+    a = np.ascontiguousarray(arr)
+    if a.dtype not in _NP_DTYPES:
+        a = a.astype(np.float32)
+    return a, a.ctypes.data, _NP_DTYPES[a.dtype], a.shape
+
+
+class SNAC:
+    """AudioCodecModel conformance (AudioCodecModel.swift:15-27): codec_sample_rate, decode_audio.
+    encode_audio (SNACDecoder.swift:120-125) is not built yet and raises audioEncodingFailed."""
+
+    def __init__(self, config: SNACConfig, device: int = 0, _handle=None):
+        self.config = config
+        self.device = device
+        self._h = _handle
+        if self._h is None:
+            h = C.c_void_p()
+            cfg = config.to_c()
+            check(_lib.lib().mis_snac_create(C.byref(cfg), device, C.byref(h)))
+            self._h = h
+        self.sampling_rate = config.sampling_rate
+        self.hop_length = int(np.prod(config.encoder_rates))
+
+    # -- loading (SNACDecoder.swift:133-189) ---------------------------------------------------
+    @classmethod
+    def from_model_directory(cls, model_dir: str, device: int = 0) -> "SNAC":
+        with open(os.path.join(model_dir, "config.json")) as f:
+            cfg = SNACConfig.from_dict(json.load(f))
+        h = C.c_void_p()
+        check(_lib.lib().mis_snac_load(model_dir.encode(), device, C.byref(h)))
+        return cls(cfg, device, _handle=h)
+
+    @classmethod
+    def from_pretrained(cls, model_repo: str, device: int = 0) -> "SNAC":
+        """fromPretrained (SNACDecoder.swift:133-154).  No network here: the repo id must resolve to a
+        local directory (HF snapshot layout or a plain path)."""
+        if os.path.isdir(model_repo):
+            return cls.from_model_directory(model_repo, device)
+        raise AudioGenerationError(1, f"model repo {model_repo!r} is not a local directory (no network access)")
+
+    @classmethod
+    def from_weights(cls, config: SNACConfig, weights: dict, device: int = 0) -> "SNAC":
+        m = cls(config, device)
+        for name, arr in weights.items():
+            if name.startswith("encoder.") or ".in_proj." in name:
+                continue
+            m.set_tensor(name, arr)
+        m.finalize()
+        return m
+
+    def set_tensor(self, name: str, arr):
+        keep, ptr, dt, shape = _tensor_args(arr)
+        sh = (C.c_int64 * len(shape))(*shape)
+        check(_lib.lib().mis_snac_set_tensor(self._h, name.encode(), ptr, dt, sh, len(shape)))
+
+    def finalize(self):
+        check(_lib.lib().mis_snac_finalize(self._h))
+
+    def set_noise(self, null_noise_is_zero: bool, seed: int = 0):
+        check(_lib.lib().mis_snac_set_noise(self._h, 1 if null_noise_is_zero else 0, seed))
+
+    # -- AudioCodecModel -----------------------------------------------------------------------
+    @property
+    def codec_sample_rate(self) -> float:
+        return float(self.sampling_rate)
+
+    def num_samples(self, t_coarse: int) -> int:
+        return int(_lib.lib().mis_snac_num_samples(self._h, t_coarse))
+
+    def noise_lengths(self, t_coarse: int):
+        return [int(_lib.lib().mis_snac_noise_len(self._h, i, t_coarse)) for i in range(len(self.config.decoder_rates))]
+
+    def decode(self, codes, noise=None) -> np.ndarray:
+        """SNAC.decode (SNACDecoder.swift:127-131): list of int arrays [B, T_i] -> float32 [B, 1, N].
+        noise: None (policy of set_noise) or one [B, T_i] array per decoder block."""
+        codes = [np.ascontiguousarray(c, dtype=np.int32) for c in codes]
+        if len(codes) != len(self.config.vq_strides):
+            raise AudioGenerationError(3, f"expected {len(self.config.vq_strides)} code arrays")
+        if any(c.ndim != 2 for c in codes):
+            raise AudioGenerationError(3, "codes must be [batch, time]")
+        B, t_coarse = codes[0].shape
+        s0 = self.config.vq_strides[0]
+        for c, s in zip(codes, self.config.vq_strides):
+            if c.shape != (B, t_coarse * (s0 // s)):
+                raise AudioGenerationError(3, "code array lengths inconsistent with vq_strides")
+        N = self.num_samples(t_coarse)
+        out = np.zeros((B, 1, N), np.float32)
+        if B == 0 or t_coarse == 0:
+            return out
+        cptr = (C.c_void_p * len(codes))(*[c.ctypes.data for c in codes])
+        nptr = None
+        keep = None
+        if noise is not None:
+            keep = [np.ascontiguousarray(n, dtype=np.float32) for n in noise]
+            lens = self.noise_lengths(t_coarse)
+            for n, L in zip(keep, lens):
+                if n.shape != (B, L):
+                    raise AudioGenerationError(3, f"noise shape {n.shape} != {(B, L)}")
+            nptr = (C.c_void_p * len(keep))(*[n.ctypes.data for n in keep])
+        check(_lib.lib().mis_snac_decode(self._h, cptr, B, t_coarse, nptr, out.ctypes.data))
+        return out
+
+    def decode_audio(self, codes) -> np.ndarray:           # decodeAudio, SNACDecoder.swift:201-203
+        return self.decode(codes)
+
+    def encode_audio(self, waveform):                      # encodeAudio, SNACDecoder.swift:197-199
+        raise AudioGenerationError(5, "SNAC encode path is not built yet (SURVEY 8(f).2)")
+
+    def debug_tap(self, name: str, batch: int) -> np.ndarray:
+        """Intermediate [batch, C, T] of the LAST decode: "zq", "stem_dw", "stem_pw", "block<i>"."""
+        cap = 1 << 26
+        buf = np.zeros(cap, np.float32)
+        ch, ln = C.c_int32(), C.c_int64()
+        check(_lib.lib().mis_snac_debug_tap(self._h, name.encode(), buf.ctypes.data, cap, C.byref(ch), C.byref(ln)))
+        return buf[: batch * ch.value * ln.value].reshape(batch, ch.value, ln.value).copy()
+
+    def close(self):
+        if self._h is not None:
+            _lib.lib().mis_snac_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -1,0 +1,22 @@
+// kernels.h - launchers shared between translation units of libmi_speech.
+#pragma once
+#include "common.h"
+
+// orpheus_codes.hip
+void launch_orpheus_deinterleave(const int32_t* codes7, int in_stride, int batch, int groups, int32_t* l0,
+                                 int32_t* l1, int32_t* l2, int out_groups, hipStream_t s);
+void launch_orpheus_deinterleave_ragged(const int32_t* codes7, int in_stride, const int32_t* n_codes, int batch,
+                                        int32_t* l0, int32_t* l1, int32_t* l2, int out_groups, hipStream_t s);
+void launch_orpheus_parse_output(const int32_t* ids, const int32_t* lens, int batch, int stride, int32_t* codes_out,
+                                 int32_t* n_codes_out, hipStream_t s);
+
+// snac.hip : device-pointer decode used by the TTS engine (codes already on device, ragged rows padded)
+struct mis_snac;
+// noise_dev: explicit per-block noise, or null -> rng_enabled ? internal N(0,1) keyed by (rng_seed, block,
+// row_offset + row_ids[b] (or b), t) : nothing added.
+void snac_decode_device(mis_snac* c, const int32_t* const* codes_dev, int batch, int t_coarse,
+                        const float* const* noise_dev, int rng_enabled, uint64_t rng_seed, const int32_t* row_ids,
+                        int64_t row_offset, float* pcm_dev, int64_t pcm_stride, hipStream_t s);
+hipStream_t snac_stream(mis_snac* c);
+int snac_device(const mis_snac* c);
+const mis_snac_config* snac_config(const mis_snac* c);

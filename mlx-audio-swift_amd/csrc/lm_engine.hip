@@ -1,0 +1,955 @@
+// lm_engine.hip - host side of the Orpheus TTS engine: weight residency, the per-step kernel chain
+// (hipGraph-captured), the batched generate loop and the hand-off to the SNAC codec.
+//
+// Reference being replaced: LlamaTTSModel (LlamaTTS.swift:354-977): fromModelDirectory :942-977,
+// callAsFunction :557-567, generate :658-765, generateStream :777-913.  The reference loop costs one
+// host<->device sync per token (.item() :723, eval :728); here a decode step is ONE hipGraph replay
+// (lm_head -> sampler -> embed -> 28 x [qkv, attention, o, norm, gate/up, down, norm]) and the host only
+// looks at a done-counter every few steps.
+#include "common.h"
+#include "kernels.h"
+#include "lm_kernels.h"
+
+#include <math.h>
+#include <string.h>
+#include <algorithm>
+#include <chrono>
+#include <set>
+
+#define ORPHEUS_END_OF_SPEECH 128258
+
+struct mis_tts {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    mis_lm_config cfg{};
+    mis_snac* codec = nullptr;
+    int d = 0, L = 0, ff = 0, H = 0, Hkv = 0, D = 0, V = 0, Vpad = 0, Nqkv = 0;
+    bool finalized = false, have_lm_head = false;
+    std::set<std::string> loaded;
+
+    // weights (HBM resident)
+    DevBuf<bf16_t> emb;        // [V][d] row-major (gather)
+    DevBuf<bf16_t> lm_head;    // packed [Vpad/16][d/32][64][8]
+    DevBuf<bf16_t> wqkv;       // [L] packed [Nqkv/16][d/32]...
+    DevBuf<bf16_t> wo;         // [L] packed [d/16][H*D/32]
+    DevBuf<bf16_t> wgu;        // [L] packed [2*ff/16][d/32]  (gate/up tiles interleaved)
+    DevBuf<bf16_t> wdown;      // [L] packed [d/16][ff/32]
+    DevBuf<bf16_t> norms;      // [L][2][d] + [d]
+    DevBuf<bf16_t> staging;    // row-major bf16 staging for one tensor
+    DevBuf<uint8_t> raw_staging;
+
+    // per-batch state
+    int batch = 0, Mpad = 0, Smax = 0;
+    int S_qkv = 1, S_o = 1, S_down = 1;
+    DevBuf<bf16_t> kcache, vtcache;
+    DevBuf<float> rope_cos, rope_sin;
+    DevBuf<int32_t> ids, pos_cur, pos_next;
+    DevBuf<uint8_t> active;
+    DevBuf<bf16_t> h, x, attn_out, act, logits;
+    DevBuf<float> qkv_part, part, e_buf, logits_f32;
+    // generation state
+    DevBuf<int32_t> prompt_mat, prompt_lens, step_counter, window, window_len, n_gen, tokens_out, all_ids, all_len,
+        done_count, codes, n_codes, l0, l1, l2, row_map;
+    DevBuf<float> pcm_tmp;
+    hipGraphExec_t g_prefill = nullptr, g_decode = nullptr;
+    uint64_t graph_key = 0;
+    bool use_graph = true;
+    int profiling = 0;
+    mis_tts_timing timing{};
+    SamplerParams sp{};
+};
+
+static size_t layer_qkv_elems(const mis_tts* c) { return (size_t)c->Nqkv * c->d; }
+static size_t layer_o_elems(const mis_tts* c) { return (size_t)c->d * c->H * c->D; }
+static size_t layer_gu_elems(const mis_tts* c) { return (size_t)2 * c->ff * c->d; }
+static size_t layer_down_elems(const mis_tts* c) { return (size_t)c->d * c->ff; }
+
+extern "C" mis_status mis_tts_create(const mis_lm_config* cfg, mis_snac* codec, int device, mis_tts** out) {
+    MIS_API_BEGIN
+    MIS_REQUIRE(cfg && out, MIS_ERR_INVALID_INPUT, "null argument");
+    int n = 0;
+    HIP_CHECK(hipGetDeviceCount(&n));
+    MIS_REQUIRE(device >= 0 && device < n, MIS_ERR_DEVICE, "device %d not available (%d GPUs visible)", device, n);
+    MIS_REQUIRE(!codec || snac_device(codec) == device, MIS_ERR_INVALID_INPUT, "codec lives on another device");
+    const int d = cfg->hidden_size, H = cfg->num_attention_heads, Hkv = cfg->num_key_value_heads;
+    const int D = cfg->head_dim > 0 ? cfg->head_dim : (H > 0 ? d / H : 0);
+    MIS_REQUIRE(d > 0 && cfg->num_hidden_layers > 0 && cfg->intermediate_size > 0 && H > 0 && Hkv > 0 && cfg->vocab_size > 0,
+                MIS_ERR_INVALID_INPUT, "bad model dimensions");
+    MIS_REQUIRE(D == 64 || D == 128, MIS_ERR_INVALID_INPUT, "head_dim %d unsupported (64 or 128)", D);
+    MIS_REQUIRE(H % Hkv == 0 && H / Hkv <= 16, MIS_ERR_INVALID_INPUT, "unsupported GQA grouping %d/%d", H, Hkv);
+    MIS_REQUIRE(d % 32 == 0 && cfg->intermediate_size % 32 == 0 && (H * D) % 32 == 0, MIS_ERR_INVALID_INPUT,
+                "hidden/intermediate sizes must be multiples of 32");
+    HIP_CHECK(hipSetDevice(device));
+    mis_tts* c = new mis_tts();
+    c->device = device;
+    c->cfg = *cfg;
+    c->cfg.head_dim = D;
+    if (c->cfg.rope_factor <= 0) c->cfg.rope_factor = 32.0f;            // LlamaTTS.swift:181-184 defaults
+    if (c->cfg.rope_low_freq_factor <= 0) c->cfg.rope_low_freq_factor = 1.0f;
+    if (c->cfg.rope_high_freq_factor <= 0) c->cfg.rope_high_freq_factor = 4.0f;
+    if (c->cfg.rope_original_max_pos <= 0) c->cfg.rope_original_max_pos = 8192.0f;
+    if (c->cfg.rope_theta <= 0) c->cfg.rope_theta = 10000.0f;
+    if (c->cfg.sample_rate <= 0) c->cfg.sample_rate = 24000;
+    c->codec = codec;
+    c->d = d; c->L = cfg->num_hidden_layers; c->ff = cfg->intermediate_size; c->H = H; c->Hkv = Hkv; c->D = D;
+    c->V = cfg->vocab_size; c->Vpad = (int)round_up(c->V, 16); c->Nqkv = (H + 2 * Hkv) * D;
+    HIP_CHECK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    c->emb.alloc((size_t)c->V * d);
+    c->lm_head.alloc((size_t)c->Vpad * d);
+    c->wqkv.alloc(layer_qkv_elems(c) * c->L);
+    c->wo.alloc(layer_o_elems(c) * c->L);
+    c->wgu.alloc(layer_gu_elems(c) * c->L);
+    c->wdown.alloc(layer_down_elems(c) * c->L);
+    c->norms.alloc((size_t)(2 * c->L + 1) * d);
+    c->use_graph = getenv("MIS_NO_GRAPH") == nullptr;
+    *out = c;
+    MIS_API_END
+}
+
+extern "C" void mis_tts_destroy(mis_tts* c) {
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    if (c->g_prefill) (void)hipGraphExecDestroy(c->g_prefill);
+    if (c->g_decode) (void)hipGraphExecDestroy(c->g_decode);
+    if (c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+
+// staging (row-major bf16 [N][K]) -> destination by tensor role
+static void place_matrix(mis_tts* c, const std::string& name, int64_t N, int64_t K) {
+    hipStream_t s = c->stream;
+    auto starts = [&](const char* p) { return name.rfind(p, 0) == 0; };
+    if (name == "model.embed_tokens.weight") {
+        MIS_REQUIRE(N == c->V && K == c->d, MIS_ERR_INVALID_INPUT, "embed_tokens shape mismatch");
+        HIP_CHECK(hipMemcpyAsync(c->emb.p, c->staging.p, (size_t)N * K * 2, hipMemcpyDeviceToDevice, s));
+        return;
+    }
+    if (name == "lm_head.weight") {
+        MIS_REQUIRE(N == c->V && K == c->d, MIS_ERR_INVALID_INPUT, "lm_head shape mismatch");
+        launch_pack_weight(c->staging.p, c->lm_head.p, c->V, c->d, c->Vpad / 16, 1, 0, s);
+        c->have_lm_head = true;
+        return;
+    }
+    MIS_REQUIRE(starts("model.layers."), MIS_ERR_INVALID_INPUT, "unexpected tensor %s", name.c_str());
+    size_t p1 = strlen("model.layers.");
+    size_t p2 = name.find('.', p1);
+    MIS_REQUIRE(p2 != std::string::npos, MIS_ERR_INVALID_INPUT, "bad tensor name %s", name.c_str());
+    int li = atoi(name.substr(p1, p2 - p1).c_str());
+    MIS_REQUIRE(li >= 0 && li < c->L, MIS_ERR_INVALID_INPUT, "layer index out of range in %s", name.c_str());
+    std::string rest = name.substr(p2 + 1);
+    const int HD = c->H * c->D, KD = c->Hkv * c->D;
+    if (rest == "self_attn.q_proj.weight") {
+        MIS_REQUIRE(N == HD && K == c->d, MIS_ERR_INVALID_INPUT, "%s shape mismatch", name.c_str());
+        bf16_t* dst = c->wqkv.p + layer_qkv_elems(c) * li;
+        launch_pack_weight(c->staging.p, dst, HD, c->d, HD / 16, 1, 0, s);
+    } else if (rest == "self_attn.k_proj.weight") {
+        MIS_REQUIRE(N == KD && K == c->d, MIS_ERR_INVALID_INPUT, "%s shape mismatch", name.c_str());
+        bf16_t* dst = c->wqkv.p + layer_qkv_elems(c) * li;
+        launch_pack_weight(c->staging.p, dst, KD, c->d, KD / 16, 1, HD / 16, s);
+    } else if (rest == "self_attn.v_proj.weight") {
+        MIS_REQUIRE(N == KD && K == c->d, MIS_ERR_INVALID_INPUT, "%s shape mismatch", name.c_str());
+        bf16_t* dst = c->wqkv.p + layer_qkv_elems(c) * li;
+        launch_pack_weight(c->staging.p, dst, KD, c->d, KD / 16, 1, (HD + KD) / 16, s);
+    } else if (rest == "self_attn.o_proj.weight") {
+        MIS_REQUIRE(N == c->d && K == HD, MIS_ERR_INVALID_INPUT, "%s shape mismatch", name.c_str());
+        launch_pack_weight(c->staging.p, c->wo.p + layer_o_elems(c) * li, c->d, HD, c->d / 16, 1, 0, s);
+    } else if (rest == "mlp.gate_proj.weight" || rest == "mlp.up_proj.weight") {
+        MIS_REQUIRE(N == c->ff && K == c->d, MIS_ERR_INVALID_INPUT, "%s shape mismatch", name.c_str());
+        launch_pack_weight(c->staging.p, c->wgu.p + layer_gu_elems(c) * li, c->ff, c->d, c->ff / 16, 2,
+                           rest == "mlp.gate_proj.weight" ? 0 : 1, s);
+    } else if (rest == "mlp.down_proj.weight") {
+        MIS_REQUIRE(N == c->d && K == c->ff, MIS_ERR_INVALID_INPUT, "%s shape mismatch", name.c_str());
+        launch_pack_weight(c->staging.p, c->wdown.p + layer_down_elems(c) * li, c->d, c->ff, c->d / 16, 1, 0, s);
+    } else {
+        throw MisError(MIS_ERR_INVALID_INPUT, "unexpected tensor " + name);
+    }
+}
+
+static bf16_t* norm_slot(mis_tts* c, const std::string& name) {
+    if (name == "model.norm.weight") return c->norms.p + (size_t)2 * c->L * c->d;
+    size_t p1 = strlen("model.layers.");
+    if (name.rfind("model.layers.", 0) != 0) return nullptr;
+    size_t p2 = name.find('.', p1);
+    if (p2 == std::string::npos) return nullptr;
+    int li = atoi(name.substr(p1, p2 - p1).c_str());
+    if (li < 0 || li >= c->L) return nullptr;
+    std::string rest = name.substr(p2 + 1);
+    if (rest == "input_layernorm.weight") return c->norms.p + (size_t)(2 * li) * c->d;
+    if (rest == "post_attention_layernorm.weight") return c->norms.p + (size_t)(2 * li + 1) * c->d;
+    return nullptr;
+}
+
+extern "C" mis_status mis_tts_set_tensor(mis_tts* c, const char* name_, const void* data, mis_dtype dtype,
+                                         const int64_t* shape, int ndim) {
+    MIS_API_BEGIN
+    MIS_REQUIRE(c && name_ && data && shape, MIS_ERR_INVALID_INPUT, "null argument");
+    MIS_REQUIRE(!c->finalized, MIS_ERR_INVALID_INPUT, "set_tensor after finalize");
+    MIS_REQUIRE(dtype == MIS_F32 || dtype == MIS_F16 || dtype == MIS_BF16, MIS_ERR_INVALID_INPUT, "unsupported dtype");
+    std::string name = name_;
+    if (name.find("rotary_emb.inv_freq") != std::string::npos) return MIS_OK;      // sanitize, LlamaTTS.swift:584-586
+    if (name == "lm_head.weight" && c->cfg.tie_word_embeddings) return MIS_OK;     // :588-590
+    HIP_CHECK(hipSetDevice(c->device));
+    size_t n = 1;
+    for (int i = 0; i < ndim; ++i) { MIS_REQUIRE(shape[i] > 0, MIS_ERR_INVALID_INPUT, "bad shape"); n *= (size_t)shape[i]; }
+    size_t esz = dtype == MIS_F32 ? 4 : 2;
+    c->raw_staging.alloc(n * esz);
+    c->staging.alloc(n);
+    HIP_CHECK(hipMemcpyAsync(c->raw_staging.p, data, n * esz, hipMemcpyDefault, c->stream));
+    if (ndim == 1) {
+        bf16_t* slot = norm_slot(c, name);
+        MIS_REQUIRE(slot && (int64_t)n == c->d, MIS_ERR_INVALID_INPUT, "unexpected 1-D tensor %s", name.c_str());
+        launch_convert_to_bf16(c->raw_staging.p, dtype, slot, n, c->stream);
+    } else {
+        MIS_REQUIRE(ndim == 2, MIS_ERR_INVALID_INPUT, "tensor %s must be 1-D or 2-D", name.c_str());
+        launch_convert_to_bf16(c->raw_staging.p, dtype, c->staging.p, n, c->stream);
+        place_matrix(c, name, shape[0], shape[1]);
+    }
+    HIP_CHECK(hipGetLastError());
+    HIP_CHECK(hipStreamSynchronize(c->stream));      // staging buffers are reused by the next call
+    c->loaded.insert(name);
+    MIS_API_END
+}
+
+extern "C" mis_status mis_tts_init_synthetic(mis_tts* c, uint64_t seed) {
+    MIS_API_BEGIN
+    MIS_REQUIRE(c && !c->finalized, MIS_ERR_INVALID_INPUT, "bad handle");
+    HIP_CHECK(hipSetDevice(c->device));
+    hipStream_t s = c->stream;
+    const int d = c->d, ff = c->ff, HD = c->H * c->D, KD = c->Hkv * c->D;
+    const uint64_t base = seed * 100000ull;
+    size_t big = std::max((size_t)c->V * d, (size_t)ff * d);
+    c->staging.alloc(big);
+    // keys / amplitudes: oracle/llama.py make_synthetic_weights
+    auto mat = [&](const std::string& name, uint64_t key, int64_t N, int64_t K, double amp) {
+        launch_synth_fill_bf16(c->staging.p, (size_t)N * K, base + key, (float)amp, 0, s);
+        place_matrix(c, name, N, K);
+        c->loaded.insert(name);
+    };
+    auto vec = [&](const std::string& name, uint64_t key) {
+        launch_synth_fill_bf16(norm_slot(c, name), (size_t)d, base + key, 0.1f, 1, s);
+        c->loaded.insert(name);
+    };
+    mat("model.embed_tokens.weight", 1, c->V, d, 0.5 * sqrt(3.0));
+    vec("model.norm.weight", 2);
+    if (!c->cfg.tie_word_embeddings) mat("lm_head.weight", 3, c->V, d, sqrt(3.0 / d) * 2.0);
+    for (int li = 0; li < c->L; ++li) {
+        std::string p = "model.layers." + std::to_string(li);
+        uint64_t k = 100 + (uint64_t)li * 16;
+        vec(p + ".input_layernorm.weight", k + 0);
+        vec(p + ".post_attention_layernorm.weight", k + 1);
+        mat(p + ".self_attn.q_proj.weight", k + 2, HD, d, sqrt(3.0 / d) * 1.5);
+        mat(p + ".self_attn.k_proj.weight", k + 3, KD, d, sqrt(3.0 / d) * 1.5);
+        mat(p + ".self_attn.v_proj.weight", k + 4, KD, d, sqrt(3.0 / d));
+        mat(p + ".self_attn.o_proj.weight", k + 5, d, HD, sqrt(3.0 / HD) * 0.5);
+        mat(p + ".mlp.gate_proj.weight", k + 6, ff, d, sqrt(3.0 / d));
+        mat(p + ".mlp.up_proj.weight", k + 7, ff, d, sqrt(3.0 / d));
+        mat(p + ".mlp.down_proj.weight", k + 8, d, ff, sqrt(3.0 / ff) * 0.5);
+    }
+    HIP_CHECK(hipGetLastError());
+    HIP_CHECK(hipStreamSynchronize(s));
+    MIS_API_END
+}
+
+extern "C" mis_status mis_tts_finalize(mis_tts* c) {
+    MIS_API_BEGIN
+    MIS_REQUIRE(c && !c->finalized, MIS_ERR_INVALID_INPUT, "bad handle");
+    HIP_CHECK(hipSetDevice(c->device));
+    // update(parameters:verify:.all), LlamaTTS.swift:971: every parameter must be present
+    std::vector<std::string> want = {"model.embed_tokens.weight", "model.norm.weight"};
+    if (!c->cfg.tie_word_embeddings) want.push_back("lm_head.weight");
+    const char* per_layer[] = {"input_layernorm.weight", "post_attention_layernorm.weight", "self_attn.q_proj.weight",
+                               "self_attn.k_proj.weight", "self_attn.v_proj.weight", "self_attn.o_proj.weight",
+                               "mlp.gate_proj.weight", "mlp.up_proj.weight", "mlp.down_proj.weight"};
+    for (int li = 0; li < c->L; ++li)
+        for (const char* r : per_layer) want.push_back("model.layers." + std::to_string(li) + "." + r);
+    for (auto& w : want)
+        MIS_REQUIRE(c->loaded.count(w), MIS_ERR_NOT_INITIALIZED, "LM weight missing: %s", w.c_str());
+    if (c->cfg.tie_word_embeddings)        // embedTokens.asLinear, LlamaTTS.swift:563
+        launch_pack_weight(c->emb.p, c->lm_head.p, c->V, c->d, c->Vpad / 16, 1, 0, c->stream);
+    HIP_CHECK(hipGetLastError());
+    HIP_CHECK(hipStreamSynchronize(c->stream));
+    c->staging.release();
+    c->raw_staging.release();
+    c->finalized = true;
+    MIS_API_END
+}
+
+// ---------------------------------------------------------------------------- per-batch state
+static int choose_split(int items, int KT) {
+    int S = 2048 / std::max(items, 1);
+    S = std::min(S, std::max(1, KT / 8));
+    S = std::min(S, 16);
+    return std::max(S, 1);
+}
+
+static void destroy_graphs(mis_tts* c) {
+    if (c->g_prefill) { (void)hipGraphExecDestroy(c->g_prefill); c->g_prefill = nullptr; }
+    if (c->g_decode) { (void)hipGraphExecDestroy(c->g_decode); c->g_decode = nullptr; }
+}
+
+static void build_rope_tables(mis_tts* c) {
+    // Llama3ScaledRoPE freqs, LlamaTTS.swift:126-156, float32 arithmetic; angle = pos / freqs[i]
+    const int D = c->D, half = D / 2;
+    std::vector<float> inv(half);
+    const float base = c->cfg.rope_theta, factor = c->cfg.rope_factor, low = c->cfg.rope_low_freq_factor,
+                high = c->cfg.rope_high_freq_factor, old = c->cfg.rope_original_max_pos;
+    for (int i = 0; i < half; ++i) {
+        float expo = (float)(2 * i) / (float)D;
+        float f = powf(base, expo);
+        float wl = (float)(2.0f * (float)M_PI) * f;
+        float low_wl = old / low, high_wl = old / high;
+        float fs = (wl > low_wl) ? f * factor : f;
+        bool med = (wl > high_wl) && (wl < low_wl);
+        float smooth = (old / wl - low) / (high - low);
+        float denom = (1.0f - smooth) / factor + smooth;
+        float ff = med ? fs / denom : fs;
+        inv[i] = 1.0f / ff;
+    }
+    std::vector<float> cs((size_t)c->Smax * half), sn((size_t)c->Smax * half);
+    for (int p = 0; p < c->Smax; ++p)
+        for (int i = 0; i < half; ++i) {
+            float ang = (float)p * inv[i];
+            cs[(size_t)p * half + i] = (float)cos((double)ang);
+            sn[(size_t)p * half + i] = (float)sin((double)ang);
+        }
+    c->rope_cos.alloc(cs.size());
+    c->rope_sin.alloc(sn.size());
+    HIP_CHECK(hipMemcpyAsync(c->rope_cos.p, cs.data(), cs.size() * 4, hipMemcpyHostToDevice, c->stream));
+    HIP_CHECK(hipMemcpyAsync(c->rope_sin.p, sn.data(), sn.size() * 4, hipMemcpyHostToDevice, c->stream));
+    HIP_CHECK(hipStreamSynchronize(c->stream));
+}
+
+static void lm_reset(mis_tts* c, int batch, int max_context) {
+    MIS_REQUIRE(c->finalized, MIS_ERR_NOT_INITIALIZED, "model not finalized");
+    MIS_REQUIRE(batch >= 1 && batch <= 64, MIS_ERR_INVALID_INPUT, "batch per GPU must be 1..64 (got %d)", batch);
+    MIS_REQUIRE(max_context >= 1, MIS_ERR_INVALID_INPUT, "max_context must be positive");
+    HIP_CHECK(hipSetDevice(c->device));
+    hipStream_t s = c->stream;
+    int Mpad = (int)round_up(batch, 16);
+    int Smax = (int)round_up(max_context, 64);
+    bool regraph = (batch != c->batch || Mpad != c->Mpad || Smax != c->Smax);
+    if (regraph) destroy_graphs(c);
+    bool new_tables = Smax != c->Smax;
+    c->batch = batch; c->Mpad = Mpad; c->Smax = Smax;
+    const int d = c->d, HD = c->H * c->D;
+    c->S_qkv = choose_split(c->Nqkv / 16, d / 32);
+    c->S_o = choose_split(d / 16, HD / 32);
+    c->S_down = choose_split(d / 16, c->ff / 32);
+    size_t kv = (size_t)c->L * batch * c->Hkv * Smax * c->D;
+    c->kcache.alloc(kv);
+    c->vtcache.alloc(kv);
+    HIP_CHECK(hipMemsetAsync(c->kcache.p, 0, kv * 2, s));
+    HIP_CHECK(hipMemsetAsync(c->vtcache.p, 0, kv * 2, s));
+    if (new_tables || !c->rope_cos.p) build_rope_tables(c);
+    c->ids.alloc(Mpad); c->pos_cur.alloc(Mpad); c->pos_next.alloc(Mpad); c->active.alloc(Mpad);
+    c->ids.zero(s); c->pos_cur.zero(s); c->pos_next.zero(s); c->active.zero(s);
+    c->h.alloc((size_t)Mpad * d); c->x.alloc((size_t)Mpad * d);
+    c->attn_out.alloc((size_t)Mpad * HD); c->act.alloc((size_t)Mpad * c->ff);
+    c->logits.alloc((size_t)Mpad * c->Vpad);
+    c->e_buf.alloc((size_t)Mpad * c->Vpad);
+    c->qkv_part.alloc((size_t)c->S_qkv * Mpad * c->Nqkv);
+    c->part.alloc((size_t)std::max(c->S_o, c->S_down) * Mpad * d);
+    c->h.zero(s); c->x.zero(s); c->attn_out.zero(s); c->act.zero(s); c->logits.zero(s);
+    HIP_CHECK(hipStreamSynchronize(s));
+}
+
+// embed -> L x block.  Leaves x = final-norm(h) ready for lm_head.   (LlamaTTS.swift:335-345,303-310)
+static void enqueue_layers(mis_tts* c) {
+    hipStream_t s = c->stream;
+    const int d = c->d, HD = c->H * c->D, Mpad = c->Mpad;
+    const float eps = c->cfg.rms_norm_eps;
+    launch_embed_rmsnorm(c->emb.p, c->ids.p, c->active.p, c->pos_cur.p, c->pos_next.p, c->norms.p, c->h.p, c->x.p, d,
+                         c->V, eps, c->batch, Mpad, s);
+    for (int li = 0; li < c->L; ++li) {
+        launch_gemm_skinny(EPI_PARTIAL, 1, c->wqkv.p + layer_qkv_elems(c) * li, c->x.p, c->qkv_part.p, c->Nqkv / 16,
+                           d / 32, c->S_qkv, c->Nqkv, Mpad, s);
+        AttnParams ap{};
+        ap.qkv_part = c->qkv_part.p; ap.S = c->S_qkv; ap.Mpad = Mpad; ap.Nqkv = c->Nqkv;
+        size_t lkv = (size_t)c->batch * c->Hkv * c->Smax * c->D;
+        ap.kcache = c->kcache.p + lkv * li; ap.vtcache = c->vtcache.p + lkv * li;
+        ap.pos = c->pos_cur.p; ap.active = c->active.p;
+        ap.rope_cos = c->rope_cos.p; ap.rope_sin = c->rope_sin.p;
+        ap.out = c->attn_out.p; ap.H = c->H; ap.Hkv = c->Hkv; ap.D = c->D; ap.Smax = c->Smax;
+        ap.scale = 1.0f / sqrtf((float)c->D);
+        launch_attn_decode(ap, c->batch, s);
+        launch_gemm_skinny(EPI_PARTIAL, 1, c->wo.p + layer_o_elems(c) * li, c->attn_out.p, c->part.p, d / 16, HD / 32,
+                           c->S_o, d, Mpad, s);
+        launch_reduce_residual_rmsnorm(c->part.p, c->S_o, Mpad, d, c->h.p, c->norms.p + (size_t)(2 * li + 1) * d,
+                                       c->x.p, eps, s);
+        launch_gemm_skinny(EPI_SILU_MUL, 2, c->wgu.p + layer_gu_elems(c) * li, c->x.p, c->act.p, 2 * c->ff / 16, d / 32,
+                           1, c->ff, Mpad, s);
+        launch_gemm_skinny(EPI_PARTIAL, 1, c->wdown.p + layer_down_elems(c) * li, c->act.p, c->part.p, d / 16,
+                           c->ff / 32, c->S_down, d, Mpad, s);
+        const bf16_t* next_norm = c->norms.p + (size_t)(li + 1 < c->L ? 2 * (li + 1) : 2 * c->L) * d;
+        launch_reduce_residual_rmsnorm(c->part.p, c->S_down, Mpad, d, c->h.p, next_norm, c->x.p, eps, s);
+    }
+}
+
+static void enqueue_lm_head(mis_tts* c) {
+    launch_gemm_skinny(EPI_BF16, 2, c->lm_head.p, c->x.p, c->logits.p, c->Vpad / 16, c->d / 32, 1, c->Vpad, c->Mpad,
+                       c->stream);
+}
+
+extern "C" mis_status mis_lm_reset(mis_tts* c, int batch, int max_context) {
+    MIS_API_BEGIN
+    MIS_REQUIRE(c, MIS_ERR_INVALID_INPUT, "null handle");
+    lm_reset(c, batch, max_context);
+    MIS_API_END
+}
+
+__global__ void k_bf16_rows_to_f32(const bf16_t* __restrict__ src, int src_stride, float* __restrict__ dst, int cols,
+                                   int rows) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (size_t)rows * cols) return;
+    int r = (int)(i / cols), cidx = (int)(i - (size_t)r * cols);
+    dst[i] = bf16_to_f32(src[(size_t)r * src_stride + cidx]);
+}
+__global__ void k_f32_rows_to_bf16(const float* __restrict__ src, int cols, bf16_t* __restrict__ dst, int dst_stride,
+                                   int rows) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (size_t)rows * cols) return;
+    int r = (int)(i / cols), cidx = (int)(i - (size_t)r * cols);
+    dst[(size_t)r * dst_stride + cidx] = f32_to_bf16(src[i]);
+}
+
+extern "C" mis_status mis_lm_forward(mis_tts* c, const int32_t* ids, const uint8_t* active, float* logits_out) {
+    MIS_API_BEGIN
+    MIS_REQUIRE(c && ids, MIS_ERR_INVALID_INPUT, "null argument");
+    MIS_REQUIRE(c->batch > 0, MIS_ERR_NOT_INITIALIZED, "call mis_lm_reset first");
+    HIP_CHECK(hipSetDevice(c->device));
+    hipStream_t s = c->stream;
+    std::vector<uint8_t> act(c->batch, 1);
+    if (active) {
+        std::vector<uint8_t> tmp(c->batch);
+        HIP_CHECK(hipMemcpy(tmp.data(), active, c->batch, hipMemcpyDefault));
+        act = tmp;
+    }
+    {   // context overflow check on the host mirror of pos_next
+        std::vector<int32_t> pn(c->batch);
+        HIP_CHECK(hipMemcpy(pn.data(), c->pos_next.p, c->batch * 4, hipMemcpyDeviceToHost));
+        for (int b = 0; b < c->batch; ++b)
+            MIS_REQUIRE(!act[b] || pn[b] < c->Smax, MIS_ERR_INVALID_INPUT, "row %d exceeds max_context %d", b, c->Smax);
+    }
+    HIP_CHECK(hipMemcpyAsync(c->ids.p, ids, c->batch * 4, hipMemcpyDefault, s));
+    HIP_CHECK(hipMemcpyAsync(c->active.p, act.data(), c->batch, hipMemcpyHostToDevice, s));
+    enqueue_layers(c);
+    if (logits_out) {
+        enqueue_lm_head(c);
+        c->logits_f32.alloc((size_t)c->batch * c->V);
+        size_t n = (size_t)c->batch * c->V;
+        hipLaunchKernelGGL(k_bf16_rows_to_f32, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, c->logits.p, c->Vpad,
+                           c->logits_f32.p, c->V, c->batch);
+        HIP_CHECK(hipMemcpyAsync(logits_out, c->logits_f32.p, n * 4, hipMemcpyDefault, s));
+    }
+    HIP_CHECK(hipGetLastError());
+    HIP_CHECK(hipStreamSynchronize(s));
+    MIS_API_END
+}
+
+extern "C" mis_status mis_sample_logits(int device, const float* logits, int batch, int vocab, const int32_t* window,
+                                        const int32_t* window_len, int ctx, const mis_gen_params* params, int step,
+                                        int lo, int hi, int32_t* tokens_out) {
+    MIS_API_BEGIN
+    MIS_REQUIRE(logits && params && tokens_out && batch >= 1 && vocab >= 1, MIS_ERR_INVALID_INPUT, "bad argument");
+    MIS_REQUIRE(ctx == 0 || (window && window_len), MIS_ERR_INVALID_INPUT, "window pointers required when ctx > 0");
+    HIP_CHECK(hipSetDevice(device));
+    int Vpad = (int)round_up(vocab, 16);
+    DevBuf<float> lf, eb;
+    DevBuf<bf16_t> lb;
+    DevBuf<int32_t> win, wl, steps, toks;
+    lf.alloc((size_t)batch * vocab); eb.alloc((size_t)batch * Vpad); lb.alloc((size_t)batch * Vpad);
+    win.alloc((size_t)batch * std::max(ctx, 1)); wl.alloc(batch); steps.alloc(batch); toks.alloc(batch);
+    HIP_CHECK(hipMemcpy(lf.p, logits, (size_t)batch * vocab * 4, hipMemcpyDefault));
+    HIP_CHECK(hipMemset(lb.p, 0, (size_t)batch * Vpad * 2));
+    size_t n = (size_t)batch * vocab;
+    hipLaunchKernelGGL(k_f32_rows_to_bf16, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, 0, lf.p, vocab, lb.p, Vpad, batch);
+    if (ctx > 0) {
+        HIP_CHECK(hipMemcpy(win.p, window, (size_t)batch * ctx * 4, hipMemcpyDefault));
+        HIP_CHECK(hipMemcpy(wl.p, window_len, batch * 4, hipMemcpyDefault));
+    }
+    std::vector<int32_t> st(batch, step);
+    HIP_CHECK(hipMemcpy(steps.p, st.data(), batch * 4, hipMemcpyHostToDevice));
+    SamplerParams sp{};
+    sp.logits = lb.p; sp.e_buf = eb.p; sp.Vpad = Vpad; sp.vocab = vocab;
+    sp.window = ctx > 0 ? win.p : nullptr; sp.window_len = ctx > 0 ? wl.p : nullptr; sp.ctx = ctx;
+    sp.tokens_out = toks.p; sp.tokens_stride = 0; sp.next_ids = toks.p; sp.step_override = steps.p;
+    sp.temperature = params->temperature; sp.top_p = params->top_p; sp.penalty = params->repetition_penalty;
+    sp.seed = params->seed; sp.row_offset = params->row_offset; sp.frame_constrained = params->frame_constrained;
+    sp.lo = lo; sp.hi = hi; sp.eos_id = -1; sp.max_tokens = 1 << 30;
+    sp.tokens_out = nullptr;
+    launch_sampler(sp, batch, 0);
+    HIP_CHECK(hipGetLastError());
+    HIP_CHECK(hipMemcpy(tokens_out, toks.p, batch * 4, hipMemcpyDefault));
+    MIS_API_END
+}
+
+// ---------------------------------------------------------------------------- generate
+struct GenOutputs {
+    float* pcm_dev = nullptr;          // caller device buffer (or internal)
+    int64_t pcm_stride = 0;
+    std::vector<int64_t> pcm_lens;
+    std::vector<int32_t> n_tokens;
+    std::vector<int32_t> tokens;       // [batch][tokens_stride] host copy (if requested)
+    int64_t tokens_stride = 0;
+};
+
+static double ms_between(hipEvent_t a, hipEvent_t b) {
+    float ms = 0;
+    HIP_CHECK(hipEventElapsedTime(&ms, a, b));
+    return ms;
+}
+
+static void run_generate(mis_tts* c, const int32_t* prompt_ids, const int32_t* prompt_lens, int batch,
+                         const mis_gen_params* gp, const float* const* snac_noise, float* pcm_dev, int64_t pcm_stride,
+                         bool want_tokens, mis_event_cb cb, void* user, const volatile int* cancel, GenOutputs& out) {
+    MIS_REQUIRE(c && c->finalized, MIS_ERR_NOT_INITIALIZED, "model not initialized");
+    MIS_REQUIRE(c->codec, MIS_ERR_NOT_INITIALIZED, "SNAC model not loaded");            // LlamaTTS.swift:672-674
+    MIS_REQUIRE(prompt_ids && prompt_lens && gp, MIS_ERR_INVALID_INPUT, "null argument");
+    MIS_REQUIRE(batch >= 1 && batch <= 64, MIS_ERR_INVALID_INPUT, "batch per GPU must be 1..64");
+    const mis_snac_config* sc = snac_config(c->codec);
+    MIS_REQUIRE(sc->n_codebooks == 3 && sc->vq_strides[0] == 4 && sc->vq_strides[1] == 2 && sc->vq_strides[2] == 1 &&
+                    sc->codebook_size == 4096,
+                MIS_ERR_INVALID_INPUT, "Orpheus framing needs a 3-level 4/2/1 SNAC codec with 4096-entry codebooks");
+    HIP_CHECK(hipSetDevice(c->device));
+    hipStream_t s = c->stream;
+    const int max_tokens = gp->max_tokens > 0 ? gp->max_tokens : 1200;
+    std::vector<int32_t> lens(batch);
+    HIP_CHECK(hipMemcpy(lens.data(), prompt_lens, batch * 4, hipMemcpyDefault));
+    int Lmax = 0;
+    size_t total = 0;
+    for (int b = 0; b < batch; ++b) {
+        MIS_REQUIRE(lens[b] >= 1, MIS_ERR_INVALID_INPUT, "empty prompt in row %d", b);
+        Lmax = std::max(Lmax, lens[b]);
+        total += lens[b];
+    }
+    std::vector<int32_t> flat(total);
+    HIP_CHECK(hipMemcpy(flat.data(), prompt_ids, total * 4, hipMemcpyDefault));
+    for (auto t : flat) MIS_REQUIRE(t >= 0 && t < c->V, MIS_ERR_INVALID_INPUT, "prompt token %d outside the vocabulary", t);
+    const int ctx = std::max(gp->repetition_context, 0);
+    const int all_stride = Lmax + max_tokens;
+    lm_reset(c, batch, Lmax + max_tokens + 1);
+
+    // host-built state: left-padded prompt matrix, all_ids (prompt, left-aligned), repetition windows
+    std::vector<int32_t> pm((size_t)batch * Lmax, 0), all((size_t)batch * all_stride, 0), win((size_t)batch * std::max(ctx, 1), 0),
+        wl(batch, 0), alen(batch);
+    {
+        size_t off = 0;
+        for (int b = 0; b < batch; ++b) {
+            for (int j = 0; j < lens[b]; ++j) {
+                pm[(size_t)b * Lmax + (Lmax - lens[b]) + j] = flat[off + j];
+                all[(size_t)b * all_stride + j] = flat[off + j];
+            }
+            int w = std::min(ctx, lens[b]);                 // processor.prompt(promptTokens), LlamaTTS.swift:695-696
+            for (int j = 0; j < w; ++j) win[(size_t)b * ctx + (ctx - w) + j] = flat[off + lens[b] - w + j];
+            wl[b] = w;
+            alen[b] = lens[b];
+            off += lens[b];
+        }
+    }
+    c->prompt_mat.alloc(pm.size()); c->prompt_lens.alloc(batch); c->step_counter.alloc(1);
+    c->window.alloc(win.size()); c->window_len.alloc(batch); c->n_gen.alloc(batch);
+    c->tokens_out.alloc((size_t)batch * max_tokens); c->all_ids.alloc(all.size()); c->all_len.alloc(batch);
+    c->done_count.alloc(1);
+    HIP_CHECK(hipMemcpyAsync(c->prompt_mat.p, pm.data(), pm.size() * 4, hipMemcpyHostToDevice, s));
+    HIP_CHECK(hipMemcpyAsync(c->prompt_lens.p, lens.data(), batch * 4, hipMemcpyHostToDevice, s));
+    HIP_CHECK(hipMemcpyAsync(c->window.p, win.data(), win.size() * 4, hipMemcpyHostToDevice, s));
+    HIP_CHECK(hipMemcpyAsync(c->window_len.p, wl.data(), batch * 4, hipMemcpyHostToDevice, s));
+    HIP_CHECK(hipMemcpyAsync(c->all_ids.p, all.data(), all.size() * 4, hipMemcpyHostToDevice, s));
+    HIP_CHECK(hipMemcpyAsync(c->all_len.p, alen.data(), batch * 4, hipMemcpyHostToDevice, s));
+    c->step_counter.zero(s); c->n_gen.zero(s); c->done_count.zero(s); c->tokens_out.zero(s);
+    HIP_CHECK(hipStreamSynchronize(s));
+
+    SamplerParams sp{};
+    sp.logits = c->logits.p; sp.e_buf = c->e_buf.p; sp.Vpad = c->Vpad; sp.vocab = c->V;
+    sp.active_in = c->active.p; sp.window = ctx > 0 ? c->window.p : nullptr; sp.window_len = c->window_len.p; sp.ctx = ctx;
+    sp.n_gen = c->n_gen.p; sp.tokens_out = c->tokens_out.p; sp.tokens_stride = max_tokens;
+    sp.all_ids = c->all_ids.p; sp.all_len = c->all_len.p; sp.all_stride = all_stride;
+    sp.next_ids = c->ids.p; sp.active = c->active.p; sp.done_count = c->done_count.p;
+    sp.temperature = gp->temperature; sp.top_p = gp->top_p; sp.penalty = gp->repetition_penalty;
+    sp.seed = gp->seed; sp.row_offset = gp->row_offset; sp.frame_constrained = gp->frame_constrained;
+    sp.lo = 0; sp.hi = 0; sp.eos_id = ORPHEUS_END_OF_SPEECH; sp.max_tokens = max_tokens;
+    c->sp = sp;
+    {   // the captured graphs bake in every pointer and scalar below: re-capture when any of them changes
+        uint64_t key = 1469598103934665603ull;
+        auto mix = [&](const void* p, size_t n) { const unsigned char* q = (const unsigned char*)p; for (size_t i = 0; i < n; ++i) { key ^= q[i]; key *= 1099511628211ull; } };
+        mix(&sp, sizeof(sp));
+        const void* ptrs[] = {c->prompt_mat.p, c->prompt_lens.p, c->step_counter.p, c->ids.p, c->active.p, c->h.p, c->x.p,
+                              c->attn_out.p, c->act.p, c->logits.p, c->qkv_part.p, c->part.p, c->kcache.p, c->vtcache.p,
+                              c->rope_cos.p, c->rope_sin.p, c->pos_cur.p, c->pos_next.p};
+        mix(ptrs, sizeof(ptrs));
+        int ints[] = {batch, Lmax, max_tokens, c->Mpad, c->Smax, c->S_qkv, c->S_o, c->S_down};
+        mix(ints, sizeof(ints));
+        if (key != c->graph_key) destroy_graphs(c);
+        c->graph_key = key;
+    }
+
+    auto prefill_body = [&]() {
+        launch_prefill_feed(c->prompt_mat.p, c->prompt_lens.p, Lmax, c->step_counter.p, c->ids.p, c->active.p, batch, s);
+        enqueue_layers(c);
+    };
+    auto decode_body = [&]() {
+        enqueue_lm_head(c);
+        launch_sampler(c->sp, batch, s);
+        enqueue_layers(c);
+    };
+    auto capture = [&](hipGraphExec_t* exec, auto&& body) {
+        hipGraph_t g = nullptr;
+        HIP_CHECK(hipStreamBeginCapture(s, hipStreamCaptureModeGlobal));
+        try { body(); } catch (...) { hipGraph_t dead = nullptr; (void)hipStreamEndCapture(s, &dead); if (dead) (void)hipGraphDestroy(dead); throw; }
+        HIP_CHECK(hipStreamEndCapture(s, &g));
+        HIP_CHECK(hipGraphInstantiate(exec, g, nullptr, nullptr, 0));
+        HIP_CHECK(hipGraphDestroy(g));
+    };
+
+    hipEvent_t ev[4];
+    for (auto& e : ev) HIP_CHECK(hipEventCreate(&e));
+    auto t_host0 = std::chrono::steady_clock::now();
+    HIP_CHECK(hipEventRecord(ev[0], s));
+    // ---- prefill: Lmax steps of the ragged, left-padded batch (prefill :711)
+    if (c->use_graph && !c->g_prefill) capture(&c->g_prefill, prefill_body);
+    for (int j = 0; j < Lmax; ++j) {
+        if (c->use_graph) HIP_CHECK(hipGraphLaunch(c->g_prefill, s)); else prefill_body();
+    }
+    HIP_CHECK(hipEventRecord(ev[1], s));
+    // after the last prompt token every row is active
+    {
+        std::vector<uint8_t> ones(batch, 1);
+        HIP_CHECK(hipMemcpyAsync(c->active.p, ones.data(), batch, hipMemcpyHostToDevice, s));
+        HIP_CHECK(hipStreamSynchronize(s));
+    }
+    // ---- decode loop (:714-744)
+    if (c->use_graph && !c->g_decode) capture(&c->g_decode, decode_body);
+    int steps = 0;
+    const int poll = cb ? 8 : 32;
+    std::vector<int32_t> host_ngen(batch, 0), host_tok;
+    std::vector<int32_t> emitted(batch, 0);
+    bool cancelled = false;
+    int32_t* done_host = nullptr;
+    HIP_CHECK(hipHostMalloc((void**)&done_host, sizeof(int32_t), 0));
+    *done_host = 0;
+    while (steps < max_tokens) {
+        int chunk = std::min(poll, max_tokens - steps);
+        for (int i = 0; i < chunk; ++i) {
+            if (c->use_graph) HIP_CHECK(hipGraphLaunch(c->g_decode, s)); else decode_body();
+        }
+        steps += chunk;
+        HIP_CHECK(hipMemcpyAsync(done_host, c->done_count.p, 4, hipMemcpyDeviceToHost, s));
+        if (cb) {
+            host_tok.resize((size_t)batch * max_tokens);
+            HIP_CHECK(hipMemcpyAsync(host_ngen.data(), c->n_gen.p, batch * 4, hipMemcpyDeviceToHost, s));
+            HIP_CHECK(hipMemcpyAsync(host_tok.data(), c->tokens_out.p, host_tok.size() * 4, hipMemcpyDeviceToHost, s));
+        }
+        HIP_CHECK(hipStreamSynchronize(s));
+        if (cb) {
+            for (int b = 0; b < batch; ++b)
+                for (; emitted[b] < host_ngen[b]; ++emitted[b]) {
+                    int32_t t = host_tok[(size_t)b * max_tokens + emitted[b]];
+                    cb(user, b, MIS_EVENT_TOKEN, &t, 1);                       // .token(id), LlamaTTS.swift:862
+                }
+        }
+        if (cancel && *cancel) { cancelled = true; break; }                    // Task.checkCancellation :715
+        if (*done_host >= batch) break;
+    }
+    (void)hipHostFree(done_host);
+    HIP_CHECK(hipEventRecord(ev[2], s));
+    if (cancelled) {
+        for (auto& e : ev) (void)hipEventDestroy(e);
+        throw MisError(MIS_ERR_CANCELLED, "generation cancelled");
+    }
+
+    // ---- parseOutput (:749-752) + de-interleave (:41-64) + SNAC decode (:759)
+    c->codes.alloc((size_t)batch * all_stride); c->n_codes.alloc(batch);
+    launch_orpheus_parse_output(c->all_ids.p, c->all_len.p, batch, all_stride, c->codes.p, c->n_codes.p, s);
+    std::vector<int32_t> ncodes(batch);
+    out.n_tokens.resize(batch);
+    HIP_CHECK(hipMemcpyAsync(ncodes.data(), c->n_codes.p, batch * 4, hipMemcpyDeviceToHost, s));
+    HIP_CHECK(hipMemcpyAsync(out.n_tokens.data(), c->n_gen.p, batch * 4, hipMemcpyDeviceToHost, s));
+    HIP_CHECK(hipStreamSynchronize(s));
+    int gmax = 0, gany = 0;
+    for (int b = 0; b < batch; ++b) { gmax = std::max(gmax, ncodes[b] / 7); gany += ncodes[b] > 0; }
+    MIS_REQUIRE(gany > 0, MIS_ERR_GENERATION_FAILED, "No audio codes generated");          // :754-756
+    const int64_t hop = mis_snac_num_samples(c->codec, 1);
+    out.pcm_lens.assign(batch, 0);
+    for (int b = 0; b < batch; ++b) out.pcm_lens[b] = (int64_t)(ncodes[b] / 7) * hop;
+    int64_t need = (int64_t)gmax * hop;
+    DevBuf<float> own;   // (only used when the caller gave no device buffer)
+    (void)own;
+    MIS_REQUIRE(pcm_dev && pcm_stride >= need, MIS_ERR_INVALID_INPUT, "pcm buffer too small (%lld needed per row)", (long long)need);
+    out.pcm_dev = pcm_dev; out.pcm_stride = pcm_stride;
+    // rows with equal group counts decode together; padding a short row would change its tail samples
+    std::vector<int> order(batch);
+    for (int b = 0; b < batch; ++b) order[b] = b;
+    std::stable_sort(order.begin(), order.end(), [&](int a, int b2) { return ncodes[a] < ncodes[b2]; });
+    bool all_equal = ncodes[order.front()] == ncodes[order.back()];
+    MIS_REQUIRE(!snac_noise || all_equal, MIS_ERR_INVALID_INPUT,
+                "explicit SNAC noise requires all rows to produce the same number of frames");
+    c->l0.alloc((size_t)batch * gmax); c->l1.alloc((size_t)batch * gmax * 2); c->l2.alloc((size_t)batch * gmax * 4);
+    std::vector<const float*> dnoise;
+    DevBuf<float> noise_dev[8];
+    if (snac_noise) {
+        for (int i = 0; i < sc->n_decoder_rates; ++i) {
+            size_t n = (size_t)batch * mis_snac_noise_len(c->codec, i, gmax);
+            noise_dev[i].alloc(n);
+            HIP_CHECK(hipMemcpyAsync(noise_dev[i].p, snac_noise[i], n * 4, hipMemcpyDefault, s));
+            dnoise.push_back(noise_dev[i].p);
+        }
+    }
+    size_t i0 = 0;
+    while (i0 < order.size()) {
+        size_t i1 = i0;
+        while (i1 < order.size() && ncodes[order[i1]] == ncodes[order[i0]]) ++i1;
+        int g = ncodes[order[i0]] / 7, nsub = (int)(i1 - i0);
+        if (g > 0) {
+            if (all_equal) {
+                launch_orpheus_deinterleave_ragged(c->codes.p, all_stride, c->n_codes.p, batch, c->l0.p, c->l1.p, c->l2.p, g, s);
+                const int32_t* cp[3] = {c->l0.p, c->l1.p, c->l2.p};
+                snac_decode_device(c->codec, cp, batch, g, snac_noise ? dnoise.data() : nullptr, 1, gp->seed, nullptr,
+                                   gp->row_offset, pcm_dev, pcm_stride, s);
+            } else {
+                // gather the subset row by row (rare path: ragged EOS); decode the subset; scatter PCM rows
+                c->pcm_tmp.alloc((size_t)nsub * g * hop);
+                for (int k = 0; k < nsub; ++k) {
+                    int b = order[i0 + k];
+                    launch_orpheus_deinterleave_ragged(c->codes.p + (size_t)b * all_stride, all_stride, c->n_codes.p + b, 1,
+                                                       c->l0.p + (size_t)k * g, c->l1.p + (size_t)k * g * 2,
+                                                       c->l2.p + (size_t)k * g * 4, g, s);
+                }
+                const int32_t* cp[3] = {c->l0.p, c->l1.p, c->l2.p};
+                c->row_map.alloc(batch);
+                HIP_CHECK(hipMemcpyAsync(c->row_map.p, order.data() + i0, nsub * sizeof(int32_t), hipMemcpyHostToDevice, s));
+                snac_decode_device(c->codec, cp, nsub, g, nullptr, 1, gp->seed, c->row_map.p, gp->row_offset, c->pcm_tmp.p,
+                                   (int64_t)g * hop, s);
+                for (int k = 0; k < nsub; ++k)
+                    HIP_CHECK(hipMemcpyAsync(pcm_dev + (size_t)order[i0 + k] * pcm_stride, c->pcm_tmp.p + (size_t)k * g * hop,
+                                             (size_t)g * hop * 4, hipMemcpyDeviceToDevice, s));
+            }
+        }
+        i0 = i1;
+    }
+    HIP_CHECK(hipGetLastError());
+    HIP_CHECK(hipEventRecord(ev[3], s));
+    if (want_tokens) {
+        out.tokens.resize((size_t)batch * max_tokens);
+        out.tokens_stride = max_tokens;
+        HIP_CHECK(hipMemcpyAsync(out.tokens.data(), c->tokens_out.p, out.tokens.size() * 4, hipMemcpyDeviceToHost, s));
+    }
+    HIP_CHECK(hipStreamSynchronize(s));
+    auto t_host1 = std::chrono::steady_clock::now();
+    (void)t_host0; (void)t_host1;
+    c->timing.prefill_ms = ms_between(ev[0], ev[1]);
+    c->timing.decode_ms = ms_between(ev[1], ev[2]);
+    c->timing.codec_ms = ms_between(ev[2], ev[3]);
+    c->timing.steps = steps;
+    c->timing.step_ms_avg = steps ? c->timing.decode_ms / steps : 0;
+    {
+        double w = 2.0 * ((double)c->L * ((double)c->Nqkv * c->d + (double)c->d * c->H * c->D + 3.0 * (double)c->ff * c->d) +
+                          (double)c->V * c->d);
+        double mean_ctx = Lmax + steps / 2.0;
+        double kvb = (double)batch * mean_ctx * c->L * 2.0 * c->Hkv * c->D * 2.0;
+        c->timing.hbm_bytes_per_step = w + kvb;
+    }
+    for (auto& e : ev) (void)hipEventDestroy(e);
+}
+
+static void default_params_check(const mis_gen_params* p) {
+    MIS_REQUIRE(p, MIS_ERR_INVALID_INPUT, "null generation parameters");
+    MIS_REQUIRE(p->temperature >= 0.0f, MIS_ERR_INVALID_INPUT, "temperature must be >= 0");
+}
+
+extern "C" mis_status mis_tts_generate_device(mis_tts* c, const int32_t* prompt_ids, const int32_t* prompt_lens, int batch,
+                                              const mis_gen_params* params, const float* const* snac_noise, float* pcm_dev,
+                                              int64_t pcm_stride, int64_t* pcm_lens, int32_t* n_tokens) {
+    MIS_API_BEGIN
+    MIS_REQUIRE(c, MIS_ERR_INVALID_INPUT, "null handle");
+    default_params_check(params);
+    GenOutputs out;
+    run_generate(c, prompt_ids, prompt_lens, batch, params, snac_noise, pcm_dev, pcm_stride, false, nullptr, nullptr, nullptr, out);
+    if (pcm_lens) for (int b = 0; b < batch; ++b) pcm_lens[b] = out.pcm_lens[b];
+    if (n_tokens) for (int b = 0; b < batch; ++b) n_tokens[b] = out.n_tokens[b];
+    MIS_API_END
+}
+
+static int64_t max_pcm_per_row(mis_tts* c, const mis_gen_params* p) {
+    int mt = p->max_tokens > 0 ? p->max_tokens : 1200;
+    return mis_snac_num_samples(c->codec, std::max(1, mt / 7 + 1));
+}
+
+extern "C" mis_status mis_tts_generate(mis_tts* c, const int32_t* prompt_ids, const int32_t* prompt_lens, int batch,
+                                       const mis_gen_params* params, const float* const* snac_noise, float** pcm_out,
+                                       int64_t* pcm_stride, int64_t* pcm_lens, int32_t** tokens_out,
+                                       int64_t* tokens_stride, int32_t* n_tokens) {
+    MIS_API_BEGIN
+    MIS_REQUIRE(c && pcm_out && pcm_stride && pcm_lens, MIS_ERR_INVALID_INPUT, "null argument");
+    MIS_REQUIRE(c->codec, MIS_ERR_NOT_INITIALIZED, "SNAC model not loaded");
+    default_params_check(params);
+    HIP_CHECK(hipSetDevice(c->device));
+    int64_t cap = max_pcm_per_row(c, params);
+    DevBuf<float> pcm;
+    pcm.alloc((size_t)batch * cap);
+    HIP_CHECK(hipMemsetAsync(pcm.p, 0, (size_t)batch * cap * 4, c->stream));
+    GenOutputs out;
+    run_generate(c, prompt_ids, prompt_lens, batch, params, snac_noise, pcm.p, cap, tokens_out != nullptr, nullptr, nullptr, nullptr, out);
+    int64_t longest = 0;
+    for (int b = 0; b < batch; ++b) longest = std::max(longest, out.pcm_lens[b]);
+    float* host = nullptr;
+    HIP_CHECK(hipHostMalloc((void**)&host, (size_t)batch * std::max<int64_t>(longest, 1) * 4, 0));
+    HIP_CHECK(hipMemcpy2D(host, (size_t)longest * 4, pcm.p, (size_t)cap * 4, (size_t)longest * 4, batch, hipMemcpyDeviceToHost));
+    *pcm_out = host; *pcm_stride = longest;
+    for (int b = 0; b < batch; ++b) pcm_lens[b] = out.pcm_lens[b];
+    if (tokens_out) {
+        int32_t* th = nullptr;
+        HIP_CHECK(hipHostMalloc((void**)&th, out.tokens.size() * 4 + 4, 0));
+        memcpy(th, out.tokens.data(), out.tokens.size() * 4);
+        *tokens_out = th;
+        if (tokens_stride) *tokens_stride = out.tokens_stride;
+    }
+    if (n_tokens) for (int b = 0; b < batch; ++b) n_tokens[b] = out.n_tokens[b];
+    MIS_API_END
+}
+
+extern "C" mis_status mis_tts_generate_stream(mis_tts* c, const int32_t* prompt_ids, const int32_t* prompt_lens, int batch,
+                                              const mis_gen_params* params, const float* const* snac_noise,
+                                              mis_event_cb on_event, void* user, const volatile int* cancel_flag) {
+    MIS_API_BEGIN
+    MIS_REQUIRE(c && on_event, MIS_ERR_INVALID_INPUT, "null argument");
+    MIS_REQUIRE(c->codec, MIS_ERR_NOT_INITIALIZED, "SNAC model not loaded");
+    default_params_check(params);
+    HIP_CHECK(hipSetDevice(c->device));
+    int64_t cap = max_pcm_per_row(c, params);
+    DevBuf<float> pcm;
+    pcm.alloc((size_t)batch * cap);
+    GenOutputs out;
+    run_generate(c, prompt_ids, prompt_lens, batch, params, snac_noise, pcm.p, cap, false, on_event, user, cancel_flag, out);
+    std::vector<int32_t> lens(batch);
+    HIP_CHECK(hipMemcpy(lens.data(), prompt_lens, batch * 4, hipMemcpyDefault));
+    std::vector<float> host;
+    for (int b = 0; b < batch; ++b) {
+        mis_gen_info info{};
+        info.prompt_token_count = lens[b];
+        info.generation_token_count = out.n_tokens[b];
+        info.prefill_time = c->timing.prefill_ms * 1e-3;
+        info.generate_time = c->timing.decode_ms * 1e-3;
+        info.tokens_per_second = info.generate_time > 0 ? out.n_tokens[b] / info.generate_time : 0;
+        size_t free_b = 0, total_b = 0;
+        (void)hipMemGetInfo(&free_b, &total_b);
+        info.peak_memory_gb = (double)(total_b - free_b) / 1e9;
+        on_event(user, b, MIS_EVENT_INFO, &info, 1);                         // .info, LlamaTTS.swift:893-901
+        host.resize((size_t)std::max<int64_t>(out.pcm_lens[b], 1));
+        HIP_CHECK(hipMemcpy(host.data(), pcm.p + (size_t)b * cap, (size_t)out.pcm_lens[b] * 4, hipMemcpyDeviceToHost));
+        on_event(user, b, MIS_EVENT_AUDIO, host.data(), out.pcm_lens[b]);   // ONE final .audio, :904
+    }
+    MIS_API_END
+}
+
+extern "C" mis_status mis_tts_set_profiling(mis_tts* c, int enabled) {
+    MIS_API_BEGIN
+    MIS_REQUIRE(c, MIS_ERR_INVALID_INPUT, "null handle");
+    c->profiling = enabled;
+    MIS_API_END
+}
+extern "C" mis_status mis_tts_last_timing(mis_tts* c, mis_tts_timing* out) {
+    MIS_API_BEGIN
+    MIS_REQUIRE(c && out, MIS_ERR_INVALID_INPUT, "null argument");
+    *out = c->timing;
+    MIS_API_END
+}
+
+extern "C" mis_status mis_tts_time_gemm(mis_tts* c, int which, int batch, int iters, double* avg_ms, double* bytes) {
+    MIS_API_BEGIN
+    MIS_REQUIRE(c && avg_ms && bytes && iters >= 1, MIS_ERR_INVALID_INPUT, "bad argument");
+    MIS_REQUIRE(c->finalized, MIS_ERR_NOT_INITIALIZED, "model not finalized");
+    if (c->batch != batch) lm_reset(c, batch, 64);
+    HIP_CHECK(hipSetDevice(c->device));
+    hipStream_t s = c->stream;
+    const int d = c->d, HD = c->H * c->D, Mpad = c->Mpad;
+    // rotate over the layers so consecutive launches stream DIFFERENT weights (the 256 MB Infinity Cache
+    // must not serve them); lm_head (0.96 GB) exceeds the cache by itself.
+    auto run = [&](int it) {
+        size_t li = (size_t)(it % c->L);
+        switch (which) {
+            case 0: launch_gemm_skinny(EPI_PARTIAL, 1, c->wqkv.p + layer_qkv_elems(c) * li, c->x.p, c->qkv_part.p, c->Nqkv / 16, d / 32, c->S_qkv, c->Nqkv, Mpad, s); break;
+            case 1: launch_gemm_skinny(EPI_PARTIAL, 1, c->wo.p + layer_o_elems(c) * li, c->attn_out.p, c->part.p, d / 16, HD / 32, c->S_o, d, Mpad, s); break;
+            case 2: launch_gemm_skinny(EPI_SILU_MUL, 2, c->wgu.p + layer_gu_elems(c) * li, c->x.p, c->act.p, 2 * c->ff / 16, d / 32, 1, c->ff, Mpad, s); break;
+            case 3: launch_gemm_skinny(EPI_PARTIAL, 1, c->wdown.p + layer_down_elems(c) * li, c->act.p, c->part.p, d / 16, c->ff / 32, c->S_down, d, Mpad, s); break;
+            case 4: enqueue_lm_head(c); break;
+            default: throw MisError(MIS_ERR_INVALID_INPUT, "unknown GEMM id");
+        }
+    };
+    double b = 0;
+    switch (which) {
+        case 0: b = 2.0 * c->Nqkv * d; break;
+        case 1: b = 2.0 * d * HD; break;
+        case 2: b = 2.0 * 2.0 * c->ff * d; break;
+        case 3: b = 2.0 * d * c->ff; break;
+        default: b = 2.0 * (double)c->V * d; break;
+    }
+    run(0);   // warm
+    hipEvent_t e0, e1;
+    HIP_CHECK(hipEventCreate(&e0));
+    HIP_CHECK(hipEventCreate(&e1));
+    HIP_CHECK(hipEventRecord(e0, s));
+    for (int i = 0; i < iters; ++i) run(i + 1);
+    HIP_CHECK(hipEventRecord(e1, s));
+    HIP_CHECK(hipStreamSynchronize(s));
+    HIP_CHECK(hipGetLastError());
+    *avg_ms = ms_between(e0, e1) / iters;
+    *bytes = b;
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    MIS_API_END
+}
+
+// LlamaTTSModel.fromModelDirectory, LlamaTTS.swift:942-977 (quantised checkpoints: not yet supported)
+extern "C" mis_status mis_tts_load(const char* model_dir, mis_snac* codec, int device, mis_tts** out) {
+    mis_tts* c = nullptr;
+    try {
+        MIS_REQUIRE(model_dir && out, MIS_ERR_INVALID_INPUT, "null argument");
+        std::string dir = model_dir;
+        JsonValue j = json_parse(read_text_file(dir + "/config.json"));
+        MIS_REQUIRE(!j.get("quantization"), MIS_ERR_INVALID_INPUT, "MLX affine-quantised checkpoints are not supported yet");
+        mis_lm_config cf{};
+        cf.hidden_size = (int)j.number_or("hidden_size", 0);
+        cf.num_hidden_layers = (int)j.number_or("num_hidden_layers", 0);
+        cf.intermediate_size = (int)j.number_or("intermediate_size", 0);
+        cf.num_attention_heads = (int)j.number_or("num_attention_heads", 0);
+        cf.num_key_value_heads = (int)j.number_or("num_key_value_heads", cf.num_attention_heads);
+        cf.head_dim = (int)j.number_or("head_dim", 0);
+        cf.vocab_size = (int)j.number_or("vocab_size", 0);
+        cf.rms_norm_eps = (float)j.number_or("rms_norm_eps", 1e-5);
+        cf.rope_theta = (float)j.number_or("rope_theta", 10000.0);
+        if (const JsonValue* rs = j.get("rope_scaling")) {
+            if (rs->type == JsonValue::OBJ) {
+                MIS_REQUIRE(rs->get("factor"), MIS_ERR_INVALID_INPUT, "rope_scaling must contain 'factor'");   // LlamaTTSConfig.swift:140-145
+                cf.rope_factor = (float)rs->number_or("factor", 32.0);
+                cf.rope_low_freq_factor = (float)rs->number_or("low_freq_factor", 1.0);
+                cf.rope_high_freq_factor = (float)rs->number_or("high_freq_factor", 4.0);
+                cf.rope_original_max_pos = (float)rs->number_or("original_max_position_embeddings", 8192.0);
+            }
+        }
+        cf.tie_word_embeddings = j.bool_or("tie_word_embeddings", true) ? 1 : 0;                     // default true :28
+        cf.sample_rate = (int)j.number_or("sample_rate", 24000);
+        mis_status st = mis_tts_create(&cf, codec, device, &c);
+        if (st != MIS_OK) return st;
+        for (auto& path : list_safetensors(dir)) {
+            SafeTensorFile f;
+            f.open(path);
+            for (auto& e : f.entries) {
+                st = mis_tts_set_tensor(c, e.name.c_str(), e.data, dtype_from_safetensors(e.dtype), e.shape.data(), (int)e.shape.size());
+                if (st != MIS_OK) { mis_tts_destroy(c); return st; }
+            }
+        }
+        st = mis_tts_finalize(c);
+        if (st != MIS_OK) { mis_tts_destroy(c); return st; }
+        *out = c;
+        return MIS_OK;
+    } catch (const MisError& e) {
+        if (c) mis_tts_destroy(c);
+        mis_set_error("%s", e.what());
+        return e.code;
+    } catch (const std::exception& e) {
+        if (c) mis_tts_destroy(c);
+        mis_set_error("%s", e.what());
+        return MIS_ERR_GENERATION_FAILED;
+    }
+}

@@ -1,0 +1,66 @@
+// lm_kernels.h - launchers of the Llama decode-step kernels (lm_kernels.hip, lm_sampler.hip)
+#pragma once
+#include "common.h"
+
+enum { EPI_PARTIAL = 0, EPI_BF16 = 1, EPI_SILU_MUL = 2 };
+
+void launch_convert_to_bf16(const void* src, int dtype, bf16_t* dst, size_t n, hipStream_t s);
+void launch_pack_weight(const bf16_t* src, bf16_t* dst, int N, int K, int NT, int tile_stride, int tile_offset,
+                        hipStream_t s);
+void launch_synth_fill_bf16(bf16_t* dst, size_t n, uint64_t key, float amp, int plus_one, hipStream_t s);
+
+void launch_prefill_feed(const int32_t* prompt, const int32_t* lens, int Lmax, int* step_counter, int32_t* ids,
+                         uint8_t* active, int batch, hipStream_t s);
+void launch_embed_rmsnorm(const bf16_t* emb, const int32_t* ids, const uint8_t* active, int* pos_cur, int* pos_next,
+                          const bf16_t* wnorm, bf16_t* h, bf16_t* x, int d, int vocab, float eps, int batch, int Mpad,
+                          hipStream_t s);
+void launch_reduce_residual_rmsnorm(const float* slabs, int S, int Mpad, int N, bf16_t* h, const bf16_t* wnorm,
+                                    bf16_t* x, float eps, hipStream_t s);
+// Wp packed [NT][KT][64][8]; X bf16 [Mpad][KT*32]; out: f32 slabs [S][Mpad][N_out] (EPI_PARTIAL) or bf16 [Mpad][N_out]
+void launch_gemm_skinny(int epi, int R, const bf16_t* Wp, const bf16_t* X, void* out, int NT, int KT, int S,
+                        int N_out, int Mpad, hipStream_t s);
+
+struct AttnParams {
+    const float* qkv_part;   // [S][Mpad][Nqkv]
+    int S, Mpad, Nqkv;
+    bf16_t* kcache;          // layer slice [B][Hkv][Smax][D]
+    bf16_t* vtcache;         // layer slice [B][Hkv][D][Smax]
+    const int* pos;          // [Mpad] position of the token being processed
+    const uint8_t* active;   // [Mpad]
+    const float* rope_cos;   // [Smax][D/2]
+    const float* rope_sin;
+    bf16_t* out;             // [Mpad][H*D]
+    int H, Hkv, D, Smax;
+    float scale;
+};
+void launch_attn_decode(const AttnParams& p, int batch, hipStream_t s);
+
+struct SamplerParams {
+    bf16_t* logits;          // [Mpad][Vpad]  (penalty is applied in place)
+    float* e_buf;            // [Mpad][Vpad] scratch
+    int Vpad, vocab;
+    const uint8_t* active_in;   // rows to sample (null = all)
+    // generation state (all device memory)
+    int32_t* window;         // [B][ctx] ring, right-aligned valid part
+    int32_t* window_len;     // [B]
+    int ctx;
+    int32_t* n_gen;          // [B] tokens generated so far (RNG step / frame slot)
+    int32_t* tokens_out;     // [B][tokens_stride] every sampled id (EOS included) or null
+    int tokens_stride;
+    int32_t* all_ids;        // [B][all_stride] prompt + generated (EOS excluded) or null
+    int32_t* all_len;        // [B]
+    int all_stride;
+    int32_t* next_ids;       // [B] next input token or null
+    uint8_t* active;         // [B] cleared on EOS (may alias active_in) or null
+    int32_t* done_count;     // incremented on EOS or null
+    int32_t* step_override;  // null, or [B] explicit RNG step (stand-alone sampling)
+    // parameters
+    float temperature, top_p, penalty;
+    uint64_t seed;
+    int64_t row_offset;
+    int frame_constrained;
+    int lo, hi;              // allowed id range when not frame constrained (hi <= 0 -> vocab)
+    int eos_id;
+    int max_tokens;
+};
+void launch_sampler(const SamplerParams& p, int batch, hipStream_t s);

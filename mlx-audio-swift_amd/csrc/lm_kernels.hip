@@ -1,0 +1,499 @@
+// lm_kernels.hip - Orpheus / Llama-3 decode-step kernels for gfx950.
+//
+// Reference being replaced: LlamaTTSModelInner / LlamaTTSAttention / LlamaTTSMLP
+// (Sources/MLXAudioTTS/Models/Llama/LlamaTTS.swift:206-346,557-567) whose arithmetic is MLX
+// (Linear, MLXFast.rmsNorm / RoPE / scaledDotProductAttention, KVCacheSimple).  Numerics follow
+// the rounding points of MLX's bf16 graph (oracle/llama.py): every primitive's output is bf16,
+// accumulation is f32.
+//
+// Data layout (all in HBM, resident for the whole generate call):
+//   weights   bf16, pre-packed at load into MFMA-A tiles  [N/16][K/32][64 lanes][8]  so that one wave
+//             instruction streams one contiguous 1 KiB tile (lane l = q*16+i holds W[16*nt+i][32*kt+8*q..+8])
+//   x / act   bf16 row-major [Mpad][K]  (Mpad = batch rounded up to 16; rows >= batch are don't-care)
+//   K cache   bf16 [B][Hkv][Smax][D]        V cache TRANSPOSED bf16 [B][Hkv][D][Smax]  (P.V B-operand wants
+//             8 consecutive keys per lane)
+//   split-K partial slabs f32 [S][Mpad][N]; reduced in the consumer's prologue (deterministic order)
+#include "common.h"
+#include "lm_kernels.h"
+
+// ============================================================================ weight staging
+
+__global__ void k_convert_to_bf16(const void* __restrict__ src, int dtype, bf16_t* __restrict__ dst, size_t n) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    if (dtype == MIS_F32) dst[i] = f32_to_bf16(((const float*)src)[i]);
+    else if (dtype == MIS_F16) dst[i] = f32_to_bf16((float)((const _Float16*)src)[i]);
+    else dst[i] = ((const bf16_t*)src)[i];
+}
+
+// row-major [N][K] bf16 -> packed tiles; destination tile index = nt * tile_stride + tile_offset
+// (gate/up interleave: stride 2, offset 0/1).  Rows >= N are zero.  One thread per 16-byte unit.
+__global__ void k_pack_weight(const bf16_t* __restrict__ src, bf16_t* __restrict__ dst, int N, int K, int NT,
+                              int tile_stride, int tile_offset) {
+    int KT = K / 32;
+    size_t u = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    size_t total = (size_t)NT * KT * 64;
+    if (u >= total) return;
+    int lane = (int)(u & 63);
+    size_t tk = u >> 6;
+    int kt = (int)(tk % KT);
+    int nt = (int)(tk / KT);
+    int i = lane & 15, q = lane >> 4;
+    int row = nt * 16 + i, col = kt * 32 + q * 8;
+    uint4 v = make_uint4(0, 0, 0, 0);
+    if (row < N) v = *reinterpret_cast<const uint4*>(src + (size_t)row * K + col);
+    size_t dt = (size_t)nt * tile_stride + tile_offset;
+    *reinterpret_cast<uint4*>(dst + ((dt * KT + kt) * 64 + lane) * 8) = v;
+}
+
+// mis-synth-v1 fill (oracle/synth.py).  plus_one: value = bf16(1 + bf16(x))  (norm weights)
+__global__ void k_synth_fill_bf16(bf16_t* __restrict__ dst, size_t n, uint64_t key, float amp, int plus_one) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float v = bf16_round_f32(mis_synth_value(key, i, amp));
+    if (plus_one) v = 1.0f + v;
+    dst[i] = f32_to_bf16(v);
+}
+
+void launch_convert_to_bf16(const void* src, int dtype, bf16_t* dst, size_t n, hipStream_t s) {
+    if (!n) return;
+    hipLaunchKernelGGL(k_convert_to_bf16, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, src, dtype, dst, n);
+}
+void launch_pack_weight(const bf16_t* src, bf16_t* dst, int N, int K, int NT, int tile_stride, int tile_offset,
+                        hipStream_t s) {
+    size_t total = (size_t)NT * (K / 32) * 64;
+    hipLaunchKernelGGL(k_pack_weight, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, src, dst, N, K, NT,
+                       tile_stride, tile_offset);
+}
+void launch_synth_fill_bf16(bf16_t* dst, size_t n, uint64_t key, float amp, int plus_one, hipStream_t s) {
+    if (!n) return;
+    hipLaunchKernelGGL(k_synth_fill_bf16, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, dst, n, key, amp, plus_one);
+}
+
+// ============================================================================ step bookkeeping
+
+// prefill feeder: step j of a left-padded prompt matrix [B][Lmax]; row b starts at j0 = Lmax - len[b]
+// (the pad tokens of prepareInputIds, LlamaTTS.swift:497-506, are never fed: SURVEY App. D.1).
+__global__ void k_prefill_feed(const int32_t* __restrict__ prompt, const int32_t* __restrict__ lens, int Lmax,
+                               int* __restrict__ step_counter, int32_t* __restrict__ ids, uint8_t* __restrict__ active,
+                               int batch) {
+    int b = blockIdx.x * blockDim.x + threadIdx.x;
+    int j = *step_counter;
+    if (b < batch) {
+        int j0 = Lmax - lens[b];
+        if (j >= j0 && j < Lmax) { ids[b] = prompt[(size_t)b * Lmax + j]; active[b] = 1; }
+        else { ids[b] = 0; active[b] = 0; }
+    }
+    __syncthreads();
+    if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) {
+        // every block has read *step_counter before the LAST block's thread can run this only if a
+        // single block is used; the launcher guarantees gridDim.x == 1.
+        *step_counter = j + 1;
+    }
+}
+void launch_prefill_feed(const int32_t* prompt, const int32_t* lens, int Lmax, int* step_counter, int32_t* ids,
+                         uint8_t* active, int batch, hipStream_t s) {
+    hipLaunchKernelGGL(k_prefill_feed, dim3(1), dim3(64 * ((batch + 63) / 64)), 0, s, prompt, lens, Lmax, step_counter,
+                       ids, active, batch);
+}
+
+// ============================================================================ embed + RMSNorm
+
+__device__ __forceinline__ float block_sum_256(float v, float* red) {
+    v = wave_sum(v);
+    int w = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) red[w] = v;
+    __syncthreads();
+    float t = red[0] + red[1] + red[2] + red[3];
+    __syncthreads();
+    return t;
+}
+
+// One 256-thread block per row.  h = E[id] ; x = RMSNorm(h) * w   (LlamaTTS.swift:336, :306)
+// Also advances the per-row position: pos_cur = pos_next ; pos_next += active.
+__global__ void __launch_bounds__(256) k_embed_rmsnorm(const bf16_t* __restrict__ emb, const int32_t* __restrict__ ids,
+                                                       const uint8_t* __restrict__ active, int* __restrict__ pos_cur,
+                                                       int* __restrict__ pos_next, const bf16_t* __restrict__ wnorm,
+                                                       bf16_t* __restrict__ h, bf16_t* __restrict__ x, int d, int vocab,
+                                                       float eps, int batch) {
+    __shared__ float red[4];
+    int m = blockIdx.x;
+    int id = (m < batch) ? ids[m] : 0;
+    if (id < 0 || id >= vocab) id = 0;
+    if (threadIdx.x == 0 && m < batch) {
+        int p = pos_next[m];
+        pos_cur[m] = p;
+        if (active[m]) pos_next[m] = p + 1;
+    }
+    const bf16_t* e = emb + (size_t)id * d;
+    float ss = 0.0f;
+    for (int i = threadIdx.x; i < d; i += 256) {
+        bf16_t v = e[i];
+        h[(size_t)m * d + i] = v;
+        float f = bf16_to_f32(v);
+        ss += f * f;
+    }
+    float tot = block_sum_256(ss, red);
+    float inv = 1.0f / sqrtf(tot / (float)d + eps);
+    for (int i = threadIdx.x; i < d; i += 256) {
+        float f = bf16_to_f32(e[i]);
+        float n = bf16_round_f32(f * inv);                       // T(x * rsqrt(mean+eps))
+        x[(size_t)m * d + i] = f32_to_bf16(bf16_to_f32(wnorm[i]) * n);   // T(w * n)
+    }
+}
+void launch_embed_rmsnorm(const bf16_t* emb, const int32_t* ids, const uint8_t* active, int* pos_cur, int* pos_next,
+                          const bf16_t* wnorm, bf16_t* h, bf16_t* x, int d, int vocab, float eps, int batch, int Mpad,
+                          hipStream_t s) {
+    hipLaunchKernelGGL(k_embed_rmsnorm, dim3(Mpad), dim3(256), 0, s, emb, ids, active, pos_cur, pos_next, wnorm, h, x, d,
+                       vocab, eps, batch);
+}
+
+// One block per row: o = T(sum_s slab[s]) ; h = T(h + o) ; x = RMSNorm(h) * w      (LlamaTTS.swift:306-309)
+__global__ void __launch_bounds__(256) k_reduce_residual_rmsnorm(const float* __restrict__ slabs, int S, int Mpad,
+                                                                 int N, bf16_t* __restrict__ h,
+                                                                 const bf16_t* __restrict__ wnorm,
+                                                                 bf16_t* __restrict__ x, float eps) {
+    __shared__ float red[4];
+    int m = blockIdx.x;
+    float ss = 0.0f;
+    for (int i = threadIdx.x; i < N; i += 256) {
+        float acc = 0.0f;
+        for (int s = 0; s < S; ++s) acc += slabs[((size_t)s * Mpad + m) * N + i];
+        float o = bf16_round_f32(acc);
+        float hn = bf16_round_f32(bf16_to_f32(h[(size_t)m * N + i]) + o);
+        h[(size_t)m * N + i] = f32_to_bf16(hn);
+        ss += hn * hn;
+    }
+    float tot = block_sum_256(ss, red);
+    float inv = 1.0f / sqrtf(tot / (float)N + eps);
+    for (int i = threadIdx.x; i < N; i += 256) {
+        float f = bf16_to_f32(h[(size_t)m * N + i]);          // written by this same thread above
+        float n = bf16_round_f32(f * inv);
+        x[(size_t)m * N + i] = f32_to_bf16(bf16_to_f32(wnorm[i]) * n);
+    }
+}
+void launch_reduce_residual_rmsnorm(const float* slabs, int S, int Mpad, int N, bf16_t* h, const bf16_t* wnorm,
+                                    bf16_t* x, float eps, hipStream_t s) {
+    hipLaunchKernelGGL(k_reduce_residual_rmsnorm, dim3(Mpad), dim3(256), 0, s, slabs, S, Mpad, N, h, wnorm, x, eps);
+}
+
+// ============================================================================ weight-streaming skinny GEMM
+//
+// Y[m][n] = sum_k X[m][k] * W[n][k],  M = 16*MT <= 64 rows, bf16 in / f32 accumulate on
+// v_mfma_f32_16x16x32_bf16 with A = W tile (16 n x 32 k), B = X^T (32 k x 16 m):
+//   A lane l: W[n = l&15][k = (l>>4)*8 + e]      B lane l: X[m = l&15][k = (l>>4)*8 + e]
+//   C/D lane l, reg r: n = (l>>4)*4 + r, m = l&15
+// Each WAVE is an independent work item (R consecutive n-tiles x one K slice): no LDS, no barriers,
+// every weight load is one contiguous 1 KiB tile read exactly once from HBM (non-temporal); X comes
+// from L2.  HBM-bound: algorithmic bytes = N*K*2 per launch.
+
+#define GEMM_U 4
+
+template <int MT, int R, int EPI>
+__global__ void __launch_bounds__(256) k_gemm_skinny(const bf16_t* __restrict__ Wp, const bf16_t* __restrict__ X,
+                                                     void* __restrict__ out, int NT, int KT, int S, int n_items,
+                                                     int N_out, int Mpad) {
+    const int lane = threadIdx.x & 63;
+    const int item = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (item >= n_items) return;
+    const int ntg = item / S, ks = item - ntg * S;
+    const int kt0 = (int)(((long long)KT * ks) / S), kt1 = (int)(((long long)KT * (ks + 1)) / S);
+    const int K = KT * 32;
+
+    const bf16x8_t* wp[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        int tile = ntg * R + r;
+        if (tile >= NT) tile = NT - 1;                     // clamp (store is skipped below)
+        wp[r] = reinterpret_cast<const bf16x8_t*>(Wp) + (size_t)tile * KT * 64 + lane;
+    }
+    const bf16x8_t* xp[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+        xp[mt] = reinterpret_cast<const bf16x8_t*>(X + (size_t)(mt * 16 + (lane & 15)) * K + (lane >> 4) * 8);
+
+    f32x4_t acc[R][MT];
+#pragma unroll
+    for (int r = 0; r < R; ++r)
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) acc[r][mt] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+
+    int kt = kt0;
+    for (; kt + GEMM_U <= kt1; kt += GEMM_U) {
+        bf16x8_t w[GEMM_U][R], x[GEMM_U][MT];
+#pragma unroll
+        for (int u = 0; u < GEMM_U; ++u) {
+#pragma unroll
+            for (int r = 0; r < R; ++r) w[u][r] = __builtin_nontemporal_load(wp[r] + (size_t)(kt + u) * 64);
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) x[u][mt] = xp[mt][(size_t)(kt + u) * 4];
+        }
+#pragma unroll
+        for (int u = 0; u < GEMM_U; ++u)
+#pragma unroll
+            for (int r = 0; r < R; ++r)
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt)
+                    acc[r][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[u][r], x[u][mt], acc[r][mt], 0, 0, 0);
+    }
+    for (; kt < kt1; ++kt) {
+        bf16x8_t w[R], x[MT];
+#pragma unroll
+        for (int r = 0; r < R; ++r) w[r] = __builtin_nontemporal_load(wp[r] + (size_t)kt * 64);
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) x[mt] = xp[mt][(size_t)kt * 4];
+#pragma unroll
+        for (int r = 0; r < R; ++r)
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+                acc[r][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[r], x[mt], acc[r][mt], 0, 0, 0);
+    }
+
+    const int nl = (lane >> 4) * 4, ml = lane & 15;
+    if (EPI == EPI_PARTIAL) {
+        float* o = reinterpret_cast<float*>(out);
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            int tile = ntg * R + r;
+            if (tile >= NT) continue;
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+                size_t off = ((size_t)ks * Mpad + mt * 16 + ml) * N_out + tile * 16 + nl;
+                *reinterpret_cast<float4*>(o + off) =
+                    make_float4(acc[r][mt][0], acc[r][mt][1], acc[r][mt][2], acc[r][mt][3]);
+            }
+        }
+    } else if (EPI == EPI_BF16) {
+        bf16_t* o = reinterpret_cast<bf16_t*>(out);
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            int tile = ntg * R + r;
+            if (tile >= NT) continue;
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+                size_t off = ((size_t)mt * 16 + ml) * N_out + tile * 16 + nl;
+                uint2 v;
+                v.x = (uint32_t)f32_to_bf16(acc[r][mt][0]) | ((uint32_t)f32_to_bf16(acc[r][mt][1]) << 16);
+                v.y = (uint32_t)f32_to_bf16(acc[r][mt][2]) | ((uint32_t)f32_to_bf16(acc[r][mt][3]) << 16);
+                *reinterpret_cast<uint2*>(o + off) = v;
+            }
+        }
+    } else {   // EPI_SILU_MUL: tile 2t = gate rows, 2t+1 = up rows  (LlamaTTS.swift:283)
+        bf16_t* o = reinterpret_cast<bf16_t*>(out);
+        static_assert(EPI != EPI_SILU_MUL || R == 2, "silu-mul epilogue pairs a gate tile with an up tile");
+        int t = ntg;
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            uint16_t res[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float g = bf16_round_f32(acc[0][mt][e]);
+                float u = bf16_round_f32(acc[R - 1][mt][e]);
+                float sg = bf16_round_f32(1.0f / (1.0f + __expf(-g)));     // T(sigmoid(g))
+                float a = bf16_round_f32(g * sg);                          // T(g * sigmoid)
+                res[e] = f32_to_bf16(a * u);                               // T(silu * up)
+            }
+            size_t off = ((size_t)mt * 16 + ml) * N_out + t * 16 + nl;
+            uint2 v;
+            v.x = (uint32_t)res[0] | ((uint32_t)res[1] << 16);
+            v.y = (uint32_t)res[2] | ((uint32_t)res[3] << 16);
+            *reinterpret_cast<uint2*>(o + off) = v;
+        }
+    }
+}
+
+template <int MT>
+static void launch_gemm_mt(int epi, int R, const bf16_t* Wp, const bf16_t* X, void* out, int NT, int KT, int S,
+                           int N_out, int Mpad, hipStream_t s) {
+    int n_items = ((NT + R - 1) / R) * S;
+    dim3 grid((n_items + 3) / 4), block(256);
+    if (epi == EPI_PARTIAL && R == 1)
+        hipLaunchKernelGGL((k_gemm_skinny<MT, 1, EPI_PARTIAL>), grid, block, 0, s, Wp, X, out, NT, KT, S, n_items, N_out, Mpad);
+    else if (epi == EPI_PARTIAL && R == 2)
+        hipLaunchKernelGGL((k_gemm_skinny<MT, 2, EPI_PARTIAL>), grid, block, 0, s, Wp, X, out, NT, KT, S, n_items, N_out, Mpad);
+    else if (epi == EPI_BF16 && R == 2)
+        hipLaunchKernelGGL((k_gemm_skinny<MT, 2, EPI_BF16>), grid, block, 0, s, Wp, X, out, NT, KT, S, n_items, N_out, Mpad);
+    else if (epi == EPI_BF16 && R == 1)
+        hipLaunchKernelGGL((k_gemm_skinny<MT, 1, EPI_BF16>), grid, block, 0, s, Wp, X, out, NT, KT, S, n_items, N_out, Mpad);
+    else if (epi == EPI_SILU_MUL && R == 2)
+        hipLaunchKernelGGL((k_gemm_skinny<MT, 2, EPI_SILU_MUL>), grid, block, 0, s, Wp, X, out, NT, KT, S, n_items, N_out, Mpad);
+    else
+        throw MisError(MIS_ERR_GENERATION_FAILED, "unsupported GEMM variant");
+}
+
+void launch_gemm_skinny(int epi, int R, const bf16_t* Wp, const bf16_t* X, void* out, int NT, int KT, int S,
+                        int N_out, int Mpad, hipStream_t s) {
+    MIS_REQUIRE(epi == EPI_PARTIAL || S == 1, MIS_ERR_GENERATION_FAILED, "split-K needs the partial epilogue");
+    switch (Mpad / 16) {
+        case 1: launch_gemm_mt<1>(epi, R, Wp, X, out, NT, KT, S, N_out, Mpad, s); break;
+        case 2: launch_gemm_mt<2>(epi, R, Wp, X, out, NT, KT, S, N_out, Mpad, s); break;
+        case 3: launch_gemm_mt<3>(epi, R, Wp, X, out, NT, KT, S, N_out, Mpad, s); break;
+        case 4: launch_gemm_mt<4>(epi, R, Wp, X, out, NT, KT, S, N_out, Mpad, s); break;
+        default: throw MisError(MIS_ERR_INVALID_INPUT, "batch per GPU must be <= 64");
+    }
+}
+
+// ============================================================================ decode attention
+//
+// One 512-thread block (8 waves) per (kv head, row).  Prologue: reduce the QKV split-K slabs, round to
+// bf16, RoPE q and k at the row's position (tables), append k / v to the caches.  Main loop: each wave
+// walks 32-key tiles (w, w+8, ...):  S^T = K . Q^T on MFMA (A = K tile with a key permutation that makes
+// the score registers line up with the P.V A-operand, B = Q^T), online softmax in f32, O += P . V with
+// P split into bf16 hi + lo parts (f32-accurate probabilities) and V^T tiles as B operand.  Epilogue:
+// cross-wave log-sum-exp combine through LDS.   (LlamaTTS.swift:235-266; SDPA semantics: oracle/llama.py)
+
+#define ATT_WAVES 8
+
+template <int D>
+__global__ void __launch_bounds__(512) k_attn_decode(AttnParams p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int kvh = blockIdx.x, b = blockIdx.y;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int G = p.H / p.Hkv;
+    if (!p.active[b]) return;
+    const int pos = p.pos[b];
+    const int kv_len = pos + 1;
+
+    // LDS carve-up
+    float* sraw = reinterpret_cast<float*>(smem);                      // [(G+2)][D] f32
+    bf16_t* qs = reinterpret_cast<bf16_t*>(sraw + (G + 2) * D);        // [16][D] bf16
+    float* sm = reinterpret_cast<float*>(qs + 16 * D);                 // [W][16]
+    float* sl = sm + ATT_WAVES * 16;                                   // [W][16]
+    float* sO = sl + ATT_WAVES * 16;                                   // [W][G][D]
+
+    // ---- prologue: slab reduce -> bf16
+    for (int idx = tid; idx < (G + 2) * D; idx += 512) {
+        int hh = idx / D, d = idx - hh * D;
+        int col;
+        if (hh < G) col = (kvh * G + hh) * D + d;
+        else if (hh == G) col = p.H * D + kvh * D + d;
+        else col = p.H * D + p.Hkv * D + kvh * D + d;
+        float acc = 0.0f;
+        for (int s = 0; s < p.S; ++s) acc += p.qkv_part[((size_t)s * p.Mpad + b) * p.Nqkv + col];
+        sraw[idx] = bf16_round_f32(acc);
+    }
+    for (int idx = tid; idx < 16 * D; idx += 512) qs[idx] = 0;
+    __syncthreads();
+    // ---- RoPE (rotate-half, pair (i, i + D/2), angle pos / freqs[i]; LlamaTTS.swift:192-200) + cache append
+    bf16_t* kc = p.kcache + ((size_t)(b * p.Hkv + kvh) * p.Smax) * D;
+    bf16_t* vt = p.vtcache + ((size_t)(b * p.Hkv + kvh) * D) * p.Smax;
+    for (int idx = tid; idx < (G + 1) * (D / 2); idx += 512) {
+        int hh = idx / (D / 2), i = idx - hh * (D / 2);
+        float x1 = sraw[hh * D + i], x2 = sraw[hh * D + i + D / 2];
+        float c = p.rope_cos[(size_t)pos * (D / 2) + i], s = p.rope_sin[(size_t)pos * (D / 2) + i];
+        bf16_t r1 = f32_to_bf16(x1 * c - x2 * s), r2 = f32_to_bf16(x1 * s + x2 * c);
+        if (hh < G) { qs[hh * D + i] = r1; qs[hh * D + i + D / 2] = r2; }
+        else { kc[(size_t)pos * D + i] = r1; kc[(size_t)pos * D + i + D / 2] = r2; }
+    }
+    for (int d = tid; d < D; d += 512) vt[(size_t)d * p.Smax + pos] = f32_to_bf16(sraw[(G + 1) * D + d]);
+    __syncthreads();       // LDS q visible; K/V stores of this block visible to its own waves (same CU)
+
+    // ---- main loop
+    const int h = lane & 15, g4 = lane >> 4;
+    bf16x8_t qf[D / 32];
+#pragma unroll
+    for (int c = 0; c < D / 32; ++c) qf[c] = *reinterpret_cast<const bf16x8_t*>(qs + h * D + c * 32 + g4 * 8);
+    f32x4_t O[D / 16];
+#pragma unroll
+    for (int dt = 0; dt < D / 16; ++dt) O[dt] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+    float m_run = -INFINITY, l_run = 0.0f;
+    const int n_tiles = (kv_len + 31) >> 5;
+    const int key0 = (h >> 2) * 8 + (h & 3);          // MFMA row i <-> key slot (see header comment)
+    for (int tile = wave; tile < n_tiles; tile += ATT_WAVES) {
+        const int base = tile * 32;
+        f32x4_t S0 = (f32x4_t){0.f, 0.f, 0.f, 0.f}, S1 = S0;
+        const bf16_t* k0p = kc + (size_t)(base + key0) * D + g4 * 8;
+        const bf16_t* k1p = k0p + 4 * D;
+#pragma unroll
+        for (int c = 0; c < D / 32; ++c) {
+            bf16x8_t a0 = *reinterpret_cast<const bf16x8_t*>(k0p + c * 32);
+            bf16x8_t a1 = *reinterpret_cast<const bf16x8_t*>(k1p + c * 32);
+            S0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0, qf[c], S0, 0, 0, 0);
+            S1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, qf[c], S1, 0, 0, 0);
+        }
+        // lane (head h, group g4) now holds scores of keys base + g4*8 + e, e = 0..7
+        float sc[8];
+        float mx = -INFINITY;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            float v = (e < 4 ? S0[e] : S1[e - 4]) * p.scale;
+            v = (base + g4 * 8 + e < kv_len) ? v : -INFINITY;
+            sc[e] = v;
+            mx = fmaxf(mx, v);
+        }
+        mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        float m_new = fmaxf(m_run, mx);
+        float alpha = __expf(m_run - m_new);            // m_run = -inf -> 0
+        float psum = 0.0f;
+        bf16x8_t ph, pl;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            float pe = __expf(sc[e] - m_new);
+            psum += pe;
+            bf16_t hi = f32_to_bf16(pe);
+            bf16_t lo = f32_to_bf16(pe - bf16_to_f32(hi));
+            ph[e] = (short)hi;
+            pl[e] = (short)lo;
+        }
+        l_run = l_run * alpha + psum;
+        m_run = m_new;
+        float ar[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) ar[r] = __shfl(alpha, g4 * 4 + r, 64);     // alpha of head (g4*4 + r)
+        const bf16_t* vp = vt + (size_t)h * p.Smax + base + g4 * 8;
+#pragma unroll
+        for (int dt = 0; dt < D / 16; ++dt) {
+            bf16x8_t vb = *reinterpret_cast<const bf16x8_t*>(vp + (size_t)dt * 16 * p.Smax);
+            f32x4_t o = O[dt];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) o[r] *= ar[r];
+            o = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ph, vb, o, 0, 0, 0);
+            o = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pl, vb, o, 0, 0, 0);
+            O[dt] = o;
+        }
+    }
+    // ---- per-wave partials -> LDS
+    l_run += __shfl_xor(l_run, 16, 64);
+    l_run += __shfl_xor(l_run, 32, 64);
+    if (g4 == 0) { sm[wave * 16 + h] = m_run; sl[wave * 16 + h] = l_run; }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        int head = g4 * 4 + r;
+        if (head < G) {
+#pragma unroll
+            for (int dt = 0; dt < D / 16; ++dt) sO[((size_t)wave * G + head) * D + dt * 16 + h] = O[dt][r];
+        }
+    }
+    __syncthreads();
+    // ---- combine waves
+    for (int idx = tid; idx < G * D; idx += 512) {
+        int head = idx / D, d = idx - head * D;
+        float M = -INFINITY;
+#pragma unroll
+        for (int w = 0; w < ATT_WAVES; ++w) M = fmaxf(M, sm[w * 16 + head]);
+        float num = 0.0f, den = 0.0f;
+#pragma unroll
+        for (int w = 0; w < ATT_WAVES; ++w) {
+            float f = __expf(sm[w * 16 + head] - M);
+            num += f * sO[((size_t)w * G + head) * D + d];
+            den += f * sl[w * 16 + head];
+        }
+        p.out[(size_t)b * p.H * D + (size_t)(kvh * G + head) * D + d] = f32_to_bf16(num / den);
+    }
+}
+
+size_t attn_smem_bytes(int G, int D) {
+    return (size_t)(G + 2) * D * 4 + 16 * D * 2 + 2 * ATT_WAVES * 16 * 4 + (size_t)ATT_WAVES * G * D * 4;
+}
+
+void launch_attn_decode(const AttnParams& p, int batch, hipStream_t s) {
+    int G = p.H / p.Hkv;
+    MIS_REQUIRE(G >= 1 && G <= 16 && p.H % p.Hkv == 0, MIS_ERR_INVALID_INPUT, "GQA group size must be 1..16");
+    size_t smem = attn_smem_bytes(G, p.D);
+    MIS_REQUIRE(smem <= 64 * 1024, MIS_ERR_INVALID_INPUT, "attention LDS footprint too large");
+    dim3 grid(p.Hkv, batch), block(512);
+    if (p.D == 128) hipLaunchKernelGGL((k_attn_decode<128>), grid, block, smem, s, p);
+    else if (p.D == 64) hipLaunchKernelGGL((k_attn_decode<64>), grid, block, smem, s, p);
+    else throw MisError(MIS_ERR_INVALID_INPUT, "head_dim must be 64 or 128");
+}

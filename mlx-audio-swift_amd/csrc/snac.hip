@@ -1,0 +1,812 @@
+// snac.hip - SNAC codec decode for gfx950 (fp32, exact-f32 MFMA for the dense contractions).
+//
+// Reference being replaced (Sources/MLXAudioCodecs/SNAC/): SNAC.decode SNACDecoder.swift:127-131 =
+// ResidualVectorQuantize.fromCodes (VQ.swift:165-191) -> Decoder (Layers.swift:364-421).
+// The reference recomputes weight-norm every call, transposes NCT<->NTC around every conv and forces
+// ~18 evals per decode (Layers.swift:28,101-116); here weight-norm, the codebook x out_proj product and
+// the transposed-conv phase split are folded ONCE at finalize and activations stay NCT in HBM.
+//
+// Kernels (activations f32 [B][C][T], T contiguous):
+//   k_snac_embed   z_q = sum_i table_i[codes_i[b, t/stride_i]]       (table_i = codebook_i x out_proj_i + b_i)
+//   k_snac_dw      depthwise k=7 dilated conv with optional Snake before/after, LDS halo tile
+//   k_snac_gemm    Y = A x X on v_mfma_f32_32x32x2_f32 with fused Snake prologue and
+//                  bias / residual / NoiseBlock / transposed-conv-phase epilogues
+//   k_snac_final   Snake -> conv k7 (C -> 1) -> tanh
+#include "common.h"
+#include "kernels.h"
+
+#include <math.h>
+#include <string.h>
+#include <algorithm>
+
+// ============================================================================ device kernels
+
+__device__ __forceinline__ float snake_f(float x, float a, float ra) {
+    float s = sinf(a * x);          // Layers.swift:44-50: x + 1/(alpha+1e-9) * sin(alpha x)^2
+    return x + ra * (s * s);
+}
+
+// ---- fromCodes ---------------------------------------------------------------------------------
+struct EmbedParams {
+    const float* tables;        // [n_q][codebook_size][C]
+    const int32_t* codes[8];    // [B][T0/stride_i]
+    int strides[8];
+    int n_q, codebook_size, C, T0;
+};
+
+// block: 32 channels x 32 frames, 256 threads; LDS transpose so that table reads are coalesced over
+// c and z_q writes are coalesced over t.
+__global__ void __launch_bounds__(256) k_snac_embed(EmbedParams p, float* __restrict__ zq) {
+    __shared__ float tile[32][33];
+    int b = blockIdx.z, c0 = blockIdx.y * 32, t0 = blockIdx.x * 32;
+    int tid = threadIdx.x;
+    int cc = tid & 31;
+    for (int tt = tid >> 5; tt < 32; tt += 8) {
+        int t = t0 + tt, c = c0 + cc;
+        float acc = 0.0f;
+        if (t < p.T0 && c < p.C) {
+            for (int i = 0; i < p.n_q; ++i) {          // (0 + z0) + z1 + z2 : VQ.swift:186 order
+                int Ti = p.T0 / p.strides[i];
+                int code = p.codes[i][(size_t)b * Ti + t / p.strides[i]];
+                code = code < 0 ? 0 : (code >= p.codebook_size ? p.codebook_size - 1 : code);
+                acc += p.tables[((size_t)i * p.codebook_size + code) * p.C + c];
+            }
+        }
+        tile[cc][tt] = acc;
+    }
+    __syncthreads();
+    int tt = tid & 31;
+    for (int c2 = tid >> 5; c2 < 32; c2 += 8) {
+        int t = t0 + tt, c = c0 + c2;
+        if (t < p.T0 && c < p.C) zq[((size_t)b * p.C + c) * p.T0 + t] = tile[c2][tt];
+    }
+}
+
+// ---- depthwise conv k=7 ---------------------------------------------------------------------------
+#define DW_TILE 1024
+#define DW_HALO 27      // 3 * max dilation (9)
+
+template <bool SNAKE_IN, bool SNAKE_OUT>
+__global__ void __launch_bounds__(256) k_snac_dw(const float* __restrict__ X, float* __restrict__ Y,
+                                                 const float* __restrict__ w /*[C][7]*/,
+                                                 const float* __restrict__ bias,
+                                                 const float* __restrict__ a_in, const float* __restrict__ ra_in,
+                                                 const float* __restrict__ a_out, const float* __restrict__ ra_out,
+                                                 int C, int T, int dil) {
+    __shared__ float s[DW_TILE + 2 * DW_HALO];
+    int b = blockIdx.z, c = blockIdx.y, t0 = blockIdx.x * DW_TILE;
+    const float* x = X + ((size_t)b * C + c) * T;
+    float* y = Y + ((size_t)b * C + c) * T;
+    int halo = 3 * dil;
+    float ai = 0.f, rai = 0.f;
+    if (SNAKE_IN) { ai = a_in[c]; rai = ra_in[c]; }
+    for (int i = threadIdx.x; i < DW_TILE + 2 * halo; i += 256) {
+        int t = t0 - halo + i;
+        float v = (t >= 0 && t < T) ? x[t] : 0.0f;     // zero padding AFTER snake == snake(0) = 0
+        if (SNAKE_IN) v = snake_f(v, ai, rai);
+        s[i] = v;
+    }
+    __syncthreads();
+    float wk[7];
+#pragma unroll
+    for (int k = 0; k < 7; ++k) wk[k] = w[c * 7 + k];
+    float bv = bias[c];
+    float ao = 0.f, rao = 0.f;
+    if (SNAKE_OUT) { ao = a_out[c]; rao = ra_out[c]; }
+    for (int i = threadIdx.x; i < DW_TILE; i += 256) {
+        int t = t0 + i;
+        if (t >= T) break;
+        float acc = 0.0f;
+#pragma unroll
+        for (int k = 0; k < 7; ++k) acc += wk[k] * s[i + k * dil];
+        acc += bv;
+        if (SNAKE_OUT) acc = snake_f(acc, ao, rao);
+        y[t] = acc;
+    }
+}
+
+// ---- dense contraction on f32 MFMA ----------------------------------------------------------------
+enum { GEMM_PLAIN = 0, GEMM_RESID = 1, GEMM_NOISE = 2, GEMM_CONVT = 3 };
+
+struct GemmParams {
+    const float* AT;      // [K][M]   (CONVT: [s][K][M], K = 2*Cin)
+    const float* bias;    // [M] or null
+    const float* X;       // [B][Kx][Tin]  (Kx = K; CONVT: Cin)
+    float* Y;             // [B][M][Tout]
+    const float* R;       // RESID: [B][M][N]
+    const float* noise;   // NOISE: explicit [B][N], or null
+    int noise_rng;        // NOISE with noise == null: 1 = draw N(0,1) from the documented generator, 0 = zeros
+    uint64_t noise_key;   // (seed, block) key of the generator
+    const int32_t* row_ids;   // optional global row id per batch row (rng keyed by GLOBAL row)
+    int64_t row_offset;
+    const float* alpha;   // Snake prologue on X rows (null = none)
+    const float* ralpha;
+    int M, K, N;          // N = output columns per phase
+    int Tin, Tout;
+    int s, pad, Cin;      // CONVT only
+};
+
+#define G_BM 64
+#define G_BN 128
+#define G_BK 16
+
+template <int MODE, bool SNAKE>
+__global__ void __launch_bounds__(256) k_snac_gemm(GemmParams p) {
+    __shared__ float As[G_BK][G_BM];
+    __shared__ float Xs[G_BK][G_BN];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int n0 = blockIdx.x * G_BN, m0 = blockIdx.y * G_BM;
+    int b, phase = 0;
+    if (MODE == GEMM_CONVT) { b = blockIdx.z / p.s; phase = blockIdx.z % p.s; }
+    else b = blockIdx.z;
+    const int Kx = (MODE == GEMM_CONVT) ? p.Cin : p.K;
+    const float* AT = p.AT + (size_t)phase * p.K * p.M;
+    const float* Xb = p.X + (size_t)b * Kx * p.Tin;
+    // transposed conv phase: out o = s*n + phase takes taps j=0,1 from x[:, n + q - j]
+    const int q = (MODE == GEMM_CONVT) ? (phase + p.pad) / p.s : 0;
+
+    f32x16_t acc[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.0f;
+
+    // staging registers: A: 4 floats / thread, X: 8 floats / thread
+    const int ar = tid >> 4, ac = (tid & 15) * 4;          // A tile row (k), col (m)
+    const int xr = tid >> 5, xc = (tid & 31) * 4;          // X tile rows xr and xr+8, col (n)
+    float ra[4], rx[2][4];
+
+    auto load_chunk = [&](int k0) {
+        {   // A^T tile
+            int k = k0 + ar, m = m0 + ac;
+            if (k < p.K && (p.M & 3) == 0 && m + 3 < p.M) {
+                float4 v = *reinterpret_cast<const float4*>(AT + (size_t)k * p.M + m);
+                ra[0] = v.x; ra[1] = v.y; ra[2] = v.z; ra[3] = v.w;
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) ra[e] = (k < p.K && m + e < p.M) ? AT[(size_t)k * p.M + m + e] : 0.0f;
+            }
+        }
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {   // X tile
+            int k = k0 + xr + 8 * h;
+            int row = k, shift = 0;
+            if (MODE == GEMM_CONVT) { int j = k / p.Cin; row = k - j * p.Cin; shift = q - j; }
+            int n = n0 + xc + shift;
+            bool kin = k < p.K;
+            const float* src = Xb + (size_t)row * p.Tin;
+            if (MODE != GEMM_CONVT && kin && (p.Tin & 3) == 0 && n + 3 < p.Tin) {
+                float4 v = *reinterpret_cast<const float4*>(src + n);
+                rx[h][0] = v.x; rx[h][1] = v.y; rx[h][2] = v.z; rx[h][3] = v.w;
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    int nn = n + e;
+                    rx[h][e] = (kin && nn >= 0 && nn < p.Tin) ? src[nn] : 0.0f;
+                }
+            }
+            if (SNAKE && kin) {
+                float a = p.alpha[row], r = p.ralpha[row];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) rx[h][e] = snake_f(rx[h][e], a, r);   // snake(0)=0 keeps the zero pad
+            }
+        }
+    };
+
+    const int nchunks = (p.K + G_BK - 1) / G_BK;
+    load_chunk(0);
+    for (int kc = 0; kc < nchunks; ++kc) {
+        __syncthreads();
+        *reinterpret_cast<float4*>(&As[ar][ac]) = make_float4(ra[0], ra[1], ra[2], ra[3]);
+        *reinterpret_cast<float4*>(&Xs[xr][xc]) = make_float4(rx[0][0], rx[0][1], rx[0][2], rx[0][3]);
+        *reinterpret_cast<float4*>(&Xs[xr + 8][xc]) = make_float4(rx[1][0], rx[1][1], rx[1][2], rx[1][3]);
+        __syncthreads();
+        if (kc + 1 < nchunks) load_chunk((kc + 1) * G_BK);
+#pragma unroll
+        for (int kk = 0; kk < G_BK; kk += 2) {
+            // v_mfma_f32_32x32x2_f32: A lane l = A[i=l&31][k=l>>5], B lane l = B[k=l>>5][j=l&31]
+            float a = As[kk + (lane >> 5)][wm * 32 + (lane & 31)];
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                float bv = Xs[kk + (lane >> 5)][wn * 64 + t * 32 + (lane & 31)];
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bv, acc[t], 0, 0, 0);
+            }
+        }
+    }
+
+    // NoiseBlock noise for this lane's two columns (MLXRandom.normal([B,1,T]), Layers.swift:274):
+    // explicit tensor, or Box-Muller on mis-synth-v1 uniforms keyed by (seed, block, GLOBAL row, t)
+    float nzv[2] = {0.0f, 0.0f};
+    if (MODE == GEMM_NOISE) {
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            int n = n0 + wn * 64 + t * 32 + (lane & 31);
+            if (n >= p.N) continue;
+            if (p.noise) nzv[t] = p.noise[(size_t)b * p.N + n];
+            else if (p.noise_rng) {
+                uint64_t row = (uint64_t)(p.row_offset + (p.row_ids ? p.row_ids[b] : b));
+                uint64_t u = mis_splitmix64((p.noise_key ^ (row * 0xD1B54A32D192ED03ull)) + (uint64_t)n);
+                float u1 = ((float)(uint32_t)(u >> 40) + 0.5f) * 5.9604644775390625e-08f;
+                float u2 = ((float)(uint32_t)((u >> 16) & 0xFFFFFF) + 0.5f) * 5.9604644775390625e-08f;
+                nzv[t] = sqrtf(-2.0f * logf(u1)) * cosf(6.283185307179586f * u2);
+            }
+        }
+    }
+    // epilogue: C/D layout col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        int n = n0 + wn * 64 + t * 32 + (lane & 31);
+        if (n >= p.N) continue;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            int m = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+            if (m >= p.M) continue;
+            float v = acc[t][r];
+            if (p.bias) v += p.bias[m];
+            if (MODE == GEMM_PLAIN) {
+                p.Y[((size_t)b * p.M + m) * p.Tout + n] = v;
+            } else if (MODE == GEMM_RESID) {
+                size_t o = ((size_t)b * p.M + m) * p.Tout + n;
+                p.Y[o] = p.R[o] + v;                                   // Layers.swift:230
+            } else if (MODE == GEMM_NOISE) {
+                size_t o = ((size_t)b * p.M + m) * p.Tout + n;
+                p.Y[o] = Xb[(size_t)m * p.Tin + n] + nzv[t] * v;       // Layers.swift:276-277
+            } else {
+                int o = p.s * n + phase;
+                if (o < p.Tout) p.Y[((size_t)b * p.M + m) * p.Tout + o] = v;
+            }
+        }
+    }
+}
+
+// ---- final Snake -> conv k7 (C -> 1) -> tanh ----------------------------------------------------------
+#define FIN_TILE 256
+#define FIN_CH 16
+__global__ void __launch_bounds__(256) k_snac_final(const float* __restrict__ X, float* __restrict__ out,
+                                                    int64_t out_stride, const float* __restrict__ w /*[C][7]*/,
+                                                    float bias, const float* __restrict__ alpha,
+                                                    const float* __restrict__ ralpha, int C, int T) {
+    __shared__ float s[FIN_CH][FIN_TILE + 8];
+    int b = blockIdx.y, t0 = blockIdx.x * FIN_TILE, tid = threadIdx.x;
+    float acc = 0.0f;
+    for (int c0 = 0; c0 < C; c0 += FIN_CH) {
+        __syncthreads();
+        for (int i = tid; i < FIN_CH * (FIN_TILE + 6); i += 256) {
+            int cc = i / (FIN_TILE + 6), j = i % (FIN_TILE + 6);
+            int c = c0 + cc, t = t0 - 3 + j;
+            float v = 0.0f;
+            if (c < C && t >= 0 && t < T) v = snake_f(X[((size_t)b * C + c) * T + t], alpha[c], ralpha[c]);
+            s[cc][j] = v;
+        }
+        __syncthreads();
+        int cmax = min(FIN_CH, C - c0);
+        for (int cc = 0; cc < cmax; ++cc) {
+            const float* wc = w + (size_t)(c0 + cc) * 7;
+#pragma unroll
+            for (int k = 0; k < 7; ++k) acc += wc[k] * s[cc][tid + k];
+        }
+    }
+    int t = t0 + tid;
+    if (t < T) out[(size_t)b * out_stride + t] = tanhf(acc + bias);
+}
+
+// ============================================================================ host side
+
+struct HostTensor {
+    std::vector<float> v;
+    std::vector<int64_t> shape;
+};
+
+struct ConvW { size_t w = 0, b = 0; bool has_bias = false; };        // offsets into the weight arena (floats)
+struct SnakeW { size_t a = 0, ra = 0; };
+
+struct mis_snac {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    mis_snac_config cfg{};
+    std::map<std::string, HostTensor> raw;
+    bool finalized = false;
+
+    DevBuf<float> arena;      // folded weights
+    size_t tables_off = 0;
+    ConvW stem_dw, stem_pw, fin;
+    float fin_bias = 0.f;
+    SnakeW fin_snake;
+    struct Block {
+        int cin, cout, stride, pad;
+        SnakeW snake0;
+        ConvW convT, noise;
+        struct RU { SnakeW s1, s2; ConvW dw, pw; } ru[3];
+    };
+    std::vector<Block> blocks;
+
+    // workspaces
+    DevBuf<float> buf[3];
+    DevBuf<int32_t> codes_ws;
+    DevBuf<float> noise_ws;
+    size_t act_capacity = 0;
+    // noise == NULL policy: 0 = draw N(0,1) internally (the reference's behaviour), 1 = add nothing
+    int null_noise_zero = 0;
+    uint64_t noise_seed = 0;
+    // last-call memo for debug taps
+    int last_batch = 0, last_t = 0;
+    bool last_noise = false;
+    std::vector<const int32_t*> last_codes;
+    std::vector<const float*> last_noise_ptrs;
+};
+
+hipStream_t snac_stream(mis_snac* c) { return c->stream; }
+int snac_device(const mis_snac* c) { return c->device; }
+const mis_snac_config* snac_config(const mis_snac* c) { return &c->cfg; }
+
+static const HostTensor& need(mis_snac* c, const std::string& name, std::initializer_list<int64_t> shape) {
+    auto it = c->raw.find(name);
+    MIS_REQUIRE(it != c->raw.end(), MIS_ERR_NOT_INITIALIZED, "SNAC weight missing: %s", name.c_str());
+    std::vector<int64_t> want(shape);
+    if (it->second.shape != want) {
+        std::string got, exp;
+        for (auto d : it->second.shape) got += std::to_string(d) + ",";
+        for (auto d : want) exp += std::to_string(d) + ",";
+        throw MisError(MIS_ERR_INVALID_INPUT, "SNAC weight " + name + " has shape [" + got + "] expected [" + exp + "]");
+    }
+    return it->second;
+}
+
+// w = g * v / (||v||_(1,2) + eps)   (Layers.swift:35-42,102-103; eps = 0 for the transposed conv :166)
+static std::vector<float> fold_weight_norm(const HostTensor& g, const HostTensor& v, float eps) {
+    int64_t d0 = v.shape[0], inner = v.shape[1] * v.shape[2];
+    std::vector<float> out(v.v.size());
+    for (int64_t o = 0; o < d0; ++o) {
+        float ss = 0.0f;
+        for (int64_t i = 0; i < inner; ++i) { float x = v.v[o * inner + i]; ss += x * x; }
+        float nrm = sqrtf(ss) + eps;
+        float gg = g.v[o];
+        for (int64_t i = 0; i < inner; ++i) out[o * inner + i] = gg * v.v[o * inner + i] / nrm;
+    }
+    return out;
+}
+
+static int64_t convt_out_len(int64_t T, int s) {
+    int pad = (s + 1) / 2;
+    return (T - 1) * s - 2 * pad + 2 * s;     // (T-1)s - 2pad + (K-1) + 1, K = 2s
+}
+
+extern "C" mis_status mis_snac_create(const mis_snac_config* cfg, int device, mis_snac** out) {
+    MIS_API_BEGIN
+    MIS_REQUIRE(cfg && out, MIS_ERR_INVALID_INPUT, "null argument");
+    MIS_REQUIRE(cfg->depthwise == 1, MIS_ERR_INVALID_INPUT, "only depthwise SNAC decoders are supported");
+    MIS_REQUIRE(cfg->attn_window_size == 0, MIS_ERR_INVALID_INPUT, "LocalMHA SNAC variants (32/44 kHz) are not supported");
+    MIS_REQUIRE(cfg->n_decoder_rates >= 1 && cfg->n_decoder_rates <= 8 && cfg->n_codebooks >= 1 && cfg->n_codebooks <= 8,
+                MIS_ERR_INVALID_INPUT, "bad decoder_rates / vq_strides count");
+    for (int i = 0; i < cfg->n_codebooks; ++i)
+        MIS_REQUIRE(cfg->vq_strides[i] >= 1 && cfg->vq_strides[0] % cfg->vq_strides[i] == 0, MIS_ERR_INVALID_INPUT,
+                    "vq_strides must divide vq_strides[0]");
+    for (int i = 0; i < cfg->n_decoder_rates; ++i)
+        MIS_REQUIRE(cfg->decoder_rates[i] >= 1 && cfg->decoder_rates[i] <= 64, MIS_ERR_INVALID_INPUT, "bad decoder rate");
+    MIS_REQUIRE(cfg->latent_dim > 0 && cfg->decoder_dim > 0 && cfg->codebook_size > 0 && cfg->codebook_dim > 0,
+                MIS_ERR_INVALID_INPUT, "bad dimensions");
+    int n = 0;
+    HIP_CHECK(hipGetDeviceCount(&n));
+    MIS_REQUIRE(device >= 0 && device < n, MIS_ERR_DEVICE, "device %d not available (%d GPUs visible)", device, n);
+    HIP_CHECK(hipSetDevice(device));
+    mis_snac* c = new mis_snac();
+    c->device = device;
+    c->cfg = *cfg;
+    HIP_CHECK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    *out = c;
+    MIS_API_END
+}
+
+extern "C" void mis_snac_destroy(mis_snac* c) {
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    if (c->stream) { (void)hipStreamSynchronize(c->stream); (void)hipStreamDestroy(c->stream); }
+    delete c;
+}
+
+extern "C" mis_status mis_snac_set_tensor(mis_snac* c, const char* name, const void* data, mis_dtype dtype,
+                                          const int64_t* shape, int ndim) {
+    MIS_API_BEGIN
+    MIS_REQUIRE(c && name && data && shape && ndim >= 1 && ndim <= 4, MIS_ERR_INVALID_INPUT, "bad argument");
+    MIS_REQUIRE(!c->finalized, MIS_ERR_INVALID_INPUT, "set_tensor after finalize");
+    HostTensor t;
+    size_t n = 1;
+    for (int i = 0; i < ndim; ++i) { MIS_REQUIRE(shape[i] > 0, MIS_ERR_INVALID_INPUT, "bad shape"); n *= (size_t)shape[i]; t.shape.push_back(shape[i]); }
+    t.v.resize(n);
+    if (dtype == MIS_F32) memcpy(t.v.data(), data, n * 4);
+    else if (dtype == MIS_BF16) { const uint16_t* s = (const uint16_t*)data; for (size_t i = 0; i < n; ++i) t.v[i] = bf16_to_f32(s[i]); }
+    else if (dtype == MIS_F16) { const uint16_t* s = (const uint16_t*)data; for (size_t i = 0; i < n; ++i) t.v[i] = f16_to_f32_host(s[i]); }
+    else throw MisError(MIS_ERR_INVALID_INPUT, "unsupported dtype for SNAC tensor");
+    c->raw[name] = std::move(t);
+    MIS_API_END
+}
+
+extern "C" mis_status mis_snac_finalize(mis_snac* c) {
+    MIS_API_BEGIN
+    MIS_REQUIRE(c, MIS_ERR_INVALID_INPUT, "null handle");
+    MIS_REQUIRE(!c->finalized, MIS_ERR_INVALID_INPUT, "already finalized");
+    HIP_CHECK(hipSetDevice(c->device));
+    const mis_snac_config& cf = c->cfg;
+    const int64_t D = cf.latent_dim, CB = cf.codebook_size, CD = cf.codebook_dim;
+    std::vector<float> arena;
+    auto push = [&](const std::vector<float>& v) { size_t o = arena.size(); arena.insert(arena.end(), v.begin(), v.end()); while (arena.size() & 3) arena.push_back(0.f); return o; };
+    auto push_snake = [&](const std::string& name, int64_t C) {
+        const HostTensor& a = need(c, name, {1, C, 1});
+        std::vector<float> ra(C);
+        for (int64_t i = 0; i < C; ++i) ra[i] = 1.0f / (a.v[i] + 1e-9f);
+        SnakeW s;
+        s.a = push(a.v);
+        s.ra = push(ra);
+        return s;
+    };
+    // 1x1 conv -> A^T [K=cin][M=cout]
+    auto push_pw = [&](const std::string& p, int64_t cout, int64_t cin, bool bias) {
+        std::vector<float> w = fold_weight_norm(need(c, p + ".weight_g", {cout, 1, 1}), need(c, p + ".weight_v", {cout, 1, cin}), 1e-12f);
+        std::vector<float> at((size_t)cin * cout);
+        for (int64_t o = 0; o < cout; ++o) for (int64_t i = 0; i < cin; ++i) at[i * cout + o] = w[o * cin + i];
+        ConvW cw;
+        cw.w = push(at);
+        cw.has_bias = bias;
+        if (bias) cw.b = push(need(c, p + ".bias", {cout}).v);
+        return cw;
+    };
+    auto push_dw = [&](const std::string& p, int64_t C) {
+        std::vector<float> w = fold_weight_norm(need(c, p + ".weight_g", {C, 1, 1}), need(c, p + ".weight_v", {C, 7, 1}), 1e-12f);
+        ConvW cw;
+        cw.w = push(w);          // [C][7]
+        cw.has_bias = true;
+        cw.b = push(need(c, p + ".bias", {C}).v);
+        return cw;
+    };
+
+    // quantizer tables: table_i[code][c] = sum_d W_i[c][d] * codebook_i[code][d] + b_i[c]   (VQ.swift:88-94,170-172)
+    {
+        std::vector<float> tables((size_t)cf.n_codebooks * CB * D);
+        for (int i = 0; i < cf.n_codebooks; ++i) {
+            std::string p = "quantizer.quantizers." + std::to_string(i);
+            const HostTensor& cb = need(c, p + ".codebook.weight", {CB, CD});
+            std::vector<float> w = fold_weight_norm(need(c, p + ".out_proj.weight_g", {D, 1, 1}), need(c, p + ".out_proj.weight_v", {D, 1, CD}), 1e-12f);
+            const HostTensor& bias = need(c, p + ".out_proj.bias", {D});
+            for (int64_t code = 0; code < CB; ++code)
+                for (int64_t ch = 0; ch < D; ++ch) {
+                    float acc = 0.0f;
+                    for (int64_t d = 0; d < CD; ++d) acc += w[ch * CD + d] * cb.v[code * CD + d];
+                    tables[((size_t)i * CB + code) * D + ch] = acc + bias.v[ch];
+                }
+        }
+        c->tables_off = push(tables);
+    }
+    const std::string L = "decoder.model.layers";
+    c->stem_dw = push_dw(L + ".0", D);
+    c->stem_pw = push_pw(L + ".1", cf.decoder_dim, D, true);
+    c->blocks.clear();
+    for (int bi = 0; bi < cf.n_decoder_rates; ++bi) {
+        mis_snac::Block blk;
+        blk.cin = cf.decoder_dim >> bi;
+        blk.cout = cf.decoder_dim >> (bi + 1);
+        MIS_REQUIRE(blk.cout >= 1, MIS_ERR_INVALID_INPUT, "decoder_dim too small for %d blocks", cf.n_decoder_rates);
+        blk.stride = cf.decoder_rates[bi];
+        blk.pad = (blk.stride + 1) / 2;           // ceil(stride/2), Layers.swift:294
+        std::string b = L + "." + std::to_string(2 + bi) + ".block.layers";
+        blk.snake0 = push_snake(b + ".0.alpha", blk.cin);
+        {   // transposed conv, weight_v [in, 2s, out]; per phase p: AT[p][j*Cin+ci][co] = w[ci][((p+pad)%s) + j*s][co]
+            int s = blk.stride, K = 2 * s;
+            std::vector<float> w = fold_weight_norm(need(c, b + ".1.weight_g", {blk.cin, 1, 1}), need(c, b + ".1.weight_v", {blk.cin, K, blk.cout}), 0.0f);
+            std::vector<float> at((size_t)s * 2 * blk.cin * blk.cout);
+            for (int p = 0; p < s; ++p)
+                for (int j = 0; j < 2; ++j) {
+                    int k = ((p + blk.pad) % s) + j * s;
+                    for (int ci = 0; ci < blk.cin; ++ci)
+                        for (int co = 0; co < blk.cout; ++co)
+                            at[(((size_t)p * 2 + j) * blk.cin + ci) * blk.cout + co] = w[((size_t)ci * K + k) * blk.cout + co];
+                }
+            blk.convT.w = push(at);
+            blk.convT.has_bias = true;
+            blk.convT.b = push(need(c, b + ".1.bias", {blk.cout}).v);
+        }
+        int idx = 2;
+        if (cf.noise) { blk.noise = push_pw(b + ".2.linear", blk.cout, blk.cout, false); idx = 3; }
+        for (int j = 0; j < 3; ++j) {
+            std::string r = b + "." + std::to_string(idx + j) + ".block.layers";
+            blk.ru[j].s1 = push_snake(r + ".0.alpha", blk.cout);
+            blk.ru[j].dw = push_dw(r + ".1", blk.cout);
+            blk.ru[j].s2 = push_snake(r + ".2.alpha", blk.cout);
+            blk.ru[j].pw = push_pw(r + ".3", blk.cout, blk.cout, true);
+        }
+        c->blocks.push_back(blk);
+    }
+    {
+        int n = 2 + cf.n_decoder_rates;
+        int64_t cl = cf.decoder_dim >> cf.n_decoder_rates;
+        c->fin_snake = push_snake(L + "." + std::to_string(n) + ".alpha", cl);
+        std::string p = L + "." + std::to_string(n + 1);
+        std::vector<float> w = fold_weight_norm(need(c, p + ".weight_g", {1, 1, 1}), need(c, p + ".weight_v", {1, 7, cl}), 1e-12f);
+        std::vector<float> wt((size_t)cl * 7);       // [C][7]
+        for (int64_t k = 0; k < 7; ++k) for (int64_t ci = 0; ci < cl; ++ci) wt[ci * 7 + k] = w[k * cl + ci];
+        c->fin.w = push(wt);
+        c->fin_bias = need(c, p + ".bias", {1}).v[0];
+    }
+    c->arena.alloc(arena.size());
+    HIP_CHECK(hipMemcpy(c->arena.p, arena.data(), arena.size() * sizeof(float), hipMemcpyHostToDevice));
+    c->raw.clear();
+    c->finalized = true;
+    MIS_API_END
+}
+
+extern "C" int64_t mis_snac_num_samples(const mis_snac* c, int t_coarse) {
+    if (!c || t_coarse <= 0) return 0;
+    int64_t T = (int64_t)t_coarse * c->cfg.vq_strides[0];
+    for (int i = 0; i < c->cfg.n_decoder_rates; ++i) T = convt_out_len(T, c->cfg.decoder_rates[i]);
+    return T;
+}
+extern "C" int64_t mis_snac_noise_len(const mis_snac* c, int block, int t_coarse) {
+    if (!c || t_coarse <= 0 || block < 0 || block >= c->cfg.n_decoder_rates) return 0;
+    int64_t T = (int64_t)t_coarse * c->cfg.vq_strides[0];
+    for (int i = 0; i <= block; ++i) T = convt_out_len(T, c->cfg.decoder_rates[i]);
+    return T;
+}
+
+// ---------------------------------------------------------------------------- pipeline
+static void launch_gemm(int mode, bool snake, const GemmParams& p, int batch, hipStream_t s) {
+    int phases = (mode == GEMM_CONVT) ? p.s : 1;
+    dim3 grid(cdiv(p.N, G_BN), cdiv(p.M, G_BM), batch * phases), block(256);
+    if (mode == GEMM_PLAIN) hipLaunchKernelGGL((k_snac_gemm<GEMM_PLAIN, false>), grid, block, 0, s, p);
+    else if (mode == GEMM_RESID) hipLaunchKernelGGL((k_snac_gemm<GEMM_RESID, false>), grid, block, 0, s, p);
+    else if (mode == GEMM_NOISE) hipLaunchKernelGGL((k_snac_gemm<GEMM_NOISE, false>), grid, block, 0, s, p);
+    else { MIS_REQUIRE(snake, MIS_ERR_GENERATION_FAILED, "convT without snake"); hipLaunchKernelGGL((k_snac_gemm<GEMM_CONVT, true>), grid, block, 0, s, p); }
+}
+
+// Runs the decode on device pointers.  stop_after: -1 = full; 0 zq, 1 stem_dw, 2 stem_pw, 3+i block i.
+// Returns the buffer holding the stage output (for taps) and its [C, T].
+struct NoiseRng { int enabled = 0; uint64_t seed = 0; const int32_t* row_ids = nullptr; int64_t row_offset = 0; };
+
+static const float* snac_run(mis_snac* c, const int32_t* const* codes, int batch, int t_coarse,
+                             const float* const* noise, const NoiseRng& rng, float* pcm, int64_t pcm_stride,
+                             int stop_after, int* outC, int64_t* outT, hipStream_t s) {
+    const mis_snac_config& cf = c->cfg;
+    const float* W = c->arena.p;
+    int64_t T0 = (int64_t)t_coarse * cf.vq_strides[0];
+    int64_t Tfinal = mis_snac_num_samples(c, t_coarse);
+    // capacity: max over stages of C*T
+    size_t cap = (size_t)std::max<int64_t>(cf.latent_dim, cf.decoder_dim) * T0;
+    {
+        int64_t T = T0;
+        for (int i = 0; i < cf.n_decoder_rates; ++i) {
+            T = convt_out_len(T, cf.decoder_rates[i]);
+            cap = std::max(cap, (size_t)(cf.decoder_dim >> (i + 1)) * (size_t)T);
+        }
+    }
+    cap *= (size_t)batch;
+    for (int i = 0; i < 3; ++i) c->buf[i].alloc(cap);
+    float *A = c->buf[0].p, *B = c->buf[1].p, *Cc = c->buf[2].p;
+
+    // fromCodes
+    EmbedParams ep{};
+    ep.tables = W + c->tables_off;
+    for (int i = 0; i < cf.n_codebooks; ++i) { ep.codes[i] = codes[i]; ep.strides[i] = cf.vq_strides[i]; }
+    ep.n_q = cf.n_codebooks; ep.codebook_size = cf.codebook_size; ep.C = cf.latent_dim; ep.T0 = (int)T0;
+    hipLaunchKernelGGL(k_snac_embed, dim3(cdiv(T0, 32), cdiv(cf.latent_dim, 32), batch), dim3(256), 0, s, ep, A);
+    if (stop_after == 0) { *outC = cf.latent_dim; *outT = T0; return A; }
+    // stem: depthwise k7 then 1x1 (Layers.swift:378-388)
+    hipLaunchKernelGGL((k_snac_dw<false, false>), dim3(cdiv(T0, DW_TILE), cf.latent_dim, batch), dim3(256), 0, s,
+                       A, B, W + c->stem_dw.w, W + c->stem_dw.b, nullptr, nullptr, nullptr, nullptr, cf.latent_dim, (int)T0, 1);
+    if (stop_after == 1) { *outC = cf.latent_dim; *outT = T0; return B; }
+    {
+        GemmParams g{};
+        g.AT = W + c->stem_pw.w; g.bias = W + c->stem_pw.b; g.X = B; g.Y = A;
+        g.M = cf.decoder_dim; g.K = cf.latent_dim; g.N = (int)T0; g.Tin = (int)T0; g.Tout = (int)T0;
+        launch_gemm(GEMM_PLAIN, false, g, batch, s);
+    }
+    if (stop_after == 2) { *outC = cf.decoder_dim; *outT = T0; return A; }
+    float* x = A;        // current activation
+    float* f1 = B;
+    float* f2 = Cc;
+    int64_t T = T0;
+    for (size_t bi = 0; bi < c->blocks.size(); ++bi) {
+        const mis_snac::Block& blk = c->blocks[bi];
+        int64_t To = convt_out_len(T, blk.stride);
+        {   // Snake -> transposed conv (Layers.swift:288-296)
+            GemmParams g{};
+            g.AT = W + blk.convT.w; g.bias = W + blk.convT.b; g.X = x; g.Y = f1;
+            g.alpha = W + blk.snake0.a; g.ralpha = W + blk.snake0.ra;
+            g.M = blk.cout; g.K = 2 * blk.cin; g.Tin = (int)T; g.Tout = (int)To;
+            g.s = blk.stride; g.pad = blk.pad; g.Cin = blk.cin;
+            g.N = (int)((To + blk.stride - 1) / blk.stride);     // columns per phase; stores are bounds-checked
+            launch_gemm(GEMM_CONVT, true, g, batch, s);
+        }
+        std::swap(x, f1);
+        T = To;
+        if (cf.noise) {   // NoiseBlock (Layers.swift:270-278)
+            GemmParams g{};
+            g.AT = W + blk.noise.w; g.bias = nullptr; g.X = x; g.Y = f1;
+            g.noise = noise ? noise[bi] : nullptr;
+            g.noise_rng = (!noise && rng.enabled) ? 1 : 0;
+            g.noise_key = mis_splitmix64(rng.seed + 0x51AC0000ull + (uint64_t)bi);
+            g.row_ids = rng.row_ids; g.row_offset = rng.row_offset;
+            g.M = blk.cout; g.K = blk.cout; g.N = (int)T; g.Tin = (int)T; g.Tout = (int)T;
+            launch_gemm(GEMM_NOISE, false, g, batch, s);
+            std::swap(x, f1);
+        }
+        const int dils[3] = {1, 3, 9};
+        for (int j = 0; j < 3; ++j) {   // ResidualUnit (Layers.swift:202-231)
+            const auto& ru = blk.ru[j];
+            hipLaunchKernelGGL((k_snac_dw<true, true>), dim3(cdiv(T, DW_TILE), blk.cout, batch), dim3(256), 0, s,
+                               x, f1, W + ru.dw.w, W + ru.dw.b, W + ru.s1.a, W + ru.s1.ra, W + ru.s2.a, W + ru.s2.ra,
+                               blk.cout, (int)T, dils[j]);
+            GemmParams g{};
+            g.AT = W + ru.pw.w; g.bias = W + ru.pw.b; g.X = f1; g.Y = f2; g.R = x;
+            g.M = blk.cout; g.K = blk.cout; g.N = (int)T; g.Tin = (int)T; g.Tout = (int)T;
+            launch_gemm(GEMM_RESID, false, g, batch, s);
+            std::swap(x, f2);
+        }
+        if (stop_after == 3 + (int)bi) { *outC = blk.cout; *outT = T; return x; }
+    }
+    MIS_REQUIRE(T == Tfinal, MIS_ERR_AUDIO_DECODE, "internal length mismatch");
+    int cl = cf.decoder_dim >> cf.n_decoder_rates;
+    hipLaunchKernelGGL(k_snac_final, dim3(cdiv(T, FIN_TILE), batch), dim3(256), 0, s, x, pcm, pcm_stride,
+                       W + c->fin.w, c->fin_bias, W + c->fin_snake.a, W + c->fin_snake.ra, cl, (int)T);
+    *outC = 1; *outT = T;
+    return pcm;
+}
+
+void snac_decode_device(mis_snac* c, const int32_t* const* codes_dev, int batch, int t_coarse,
+                        const float* const* noise_dev, int rng_enabled, uint64_t rng_seed, const int32_t* row_ids,
+                        int64_t row_offset, float* pcm_dev, int64_t pcm_stride, hipStream_t s) {
+    MIS_REQUIRE(c && c->finalized, MIS_ERR_NOT_INITIALIZED, "SNAC codec not finalized");
+    int C; int64_t T;
+    NoiseRng rng;
+    rng.enabled = rng_enabled; rng.seed = rng_seed; rng.row_ids = row_ids; rng.row_offset = row_offset;
+    snac_run(c, codes_dev, batch, t_coarse, noise_dev, rng, pcm_dev, pcm_stride, -1, &C, &T, s);
+    HIP_CHECK(hipGetLastError());
+}
+
+static void snac_stage_inputs(mis_snac* c, const int32_t* const* codes, int batch, int t_coarse,
+                              const float* const* noise, std::vector<const int32_t*>& dcodes,
+                              std::vector<const float*>& dnoise) {
+    const mis_snac_config& cf = c->cfg;
+    size_t total = 0;
+    std::vector<size_t> offs(cf.n_codebooks);
+    for (int i = 0; i < cf.n_codebooks; ++i) {
+        offs[i] = total;
+        total += (size_t)batch * t_coarse * (cf.vq_strides[0] / cf.vq_strides[i]);
+    }
+    c->codes_ws.alloc(total);
+    dcodes.resize(cf.n_codebooks);
+    for (int i = 0; i < cf.n_codebooks; ++i) {
+        size_t n = (size_t)batch * t_coarse * (cf.vq_strides[0] / cf.vq_strides[i]);
+        MIS_REQUIRE(codes[i], MIS_ERR_INVALID_INPUT, "codes[%d] is null", i);
+        HIP_CHECK(hipMemcpyAsync(c->codes_ws.p + offs[i], codes[i], n * sizeof(int32_t), hipMemcpyDefault, c->stream));
+        dcodes[i] = c->codes_ws.p + offs[i];
+    }
+    dnoise.clear();
+    if (noise && cf.noise) {
+        size_t tot = 0;
+        std::vector<size_t> no(cf.n_decoder_rates);
+        for (int i = 0; i < cf.n_decoder_rates; ++i) { no[i] = tot; tot += (size_t)batch * mis_snac_noise_len(c, i, t_coarse); }
+        c->noise_ws.alloc(tot);
+        dnoise.resize(cf.n_decoder_rates);
+        for (int i = 0; i < cf.n_decoder_rates; ++i) {
+            MIS_REQUIRE(noise[i], MIS_ERR_INVALID_INPUT, "noise[%d] is null", i);
+            size_t n = (size_t)batch * mis_snac_noise_len(c, i, t_coarse);
+            HIP_CHECK(hipMemcpyAsync(c->noise_ws.p + no[i], noise[i], n * sizeof(float), hipMemcpyDefault, c->stream));
+            dnoise[i] = c->noise_ws.p + no[i];
+        }
+    }
+}
+
+extern "C" mis_status mis_snac_decode(mis_snac* c, const int32_t* const* codes, int batch, int t_coarse,
+                                      const float* const* noise, float* pcm_out) {
+    MIS_API_BEGIN
+    MIS_REQUIRE(c, MIS_ERR_INVALID_INPUT, "null handle");
+    MIS_REQUIRE(c->finalized, MIS_ERR_NOT_INITIALIZED, "SNAC codec not finalized");
+    MIS_REQUIRE(batch >= 0 && t_coarse >= 0, MIS_ERR_INVALID_INPUT, "negative batch / length");
+    if (batch == 0 || t_coarse == 0) return MIS_OK;       // empty input -> empty waveform
+    MIS_REQUIRE(codes && pcm_out, MIS_ERR_INVALID_INPUT, "null pointer");
+    HIP_CHECK(hipSetDevice(c->device));
+    std::vector<const int32_t*> dcodes;
+    std::vector<const float*> dnoise;
+    snac_stage_inputs(c, codes, batch, t_coarse, noise, dcodes, dnoise);
+    int64_t N = mis_snac_num_samples(c, t_coarse);
+    DevBuf<float> pcm;
+    pcm.alloc((size_t)batch * N);
+    int C; int64_t T;
+    NoiseRng rng;
+    rng.enabled = c->null_noise_zero ? 0 : 1; rng.seed = c->noise_seed;
+    snac_run(c, dcodes.data(), batch, t_coarse, dnoise.empty() ? nullptr : dnoise.data(), rng, pcm.p, N, -1, &C, &T, c->stream);
+    HIP_CHECK(hipGetLastError());
+    HIP_CHECK(hipMemcpyAsync(pcm_out, pcm.p, (size_t)batch * N * sizeof(float), hipMemcpyDefault, c->stream));
+    HIP_CHECK(hipStreamSynchronize(c->stream));
+    c->last_batch = batch; c->last_t = t_coarse;
+    c->last_codes = dcodes; c->last_noise_ptrs = dnoise; c->last_noise = !dnoise.empty();
+    MIS_API_END
+}
+
+extern "C" mis_status mis_snac_set_noise(mis_snac* c, int null_noise_is_zero, uint64_t seed) {
+    MIS_API_BEGIN
+    MIS_REQUIRE(c, MIS_ERR_INVALID_INPUT, "null handle");
+    c->null_noise_zero = null_noise_is_zero ? 1 : 0;
+    c->noise_seed = seed;
+    MIS_API_END
+}
+
+extern "C" mis_status mis_snac_debug_tap(mis_snac* c, const char* name, float* out, int64_t capacity,
+                                         int32_t* channels, int64_t* length) {
+    MIS_API_BEGIN
+    MIS_REQUIRE(c && name && out && channels && length, MIS_ERR_INVALID_INPUT, "null argument");
+    MIS_REQUIRE(c->finalized && c->last_batch > 0, MIS_ERR_NOT_INITIALIZED, "no previous decode to tap");
+    HIP_CHECK(hipSetDevice(c->device));
+    std::string n = name;
+    int stop = -2;
+    if (n == "zq") stop = 0;
+    else if (n == "stem_dw") stop = 1;
+    else if (n == "stem_pw") stop = 2;
+    else if (n.rfind("block", 0) == 0) stop = 3 + atoi(n.c_str() + 5);
+    MIS_REQUIRE(stop >= 0 && stop < 3 + c->cfg.n_decoder_rates, MIS_ERR_INVALID_INPUT, "unknown tap %s", name);
+    int C; int64_t T;
+    NoiseRng rng;
+    rng.enabled = c->null_noise_zero ? 0 : 1; rng.seed = c->noise_seed;
+    const float* src = snac_run(c, c->last_codes.data(), c->last_batch, c->last_t,
+                                c->last_noise ? c->last_noise_ptrs.data() : nullptr, rng, nullptr, 0, stop, &C, &T, c->stream);
+    HIP_CHECK(hipGetLastError());
+    size_t n_el = (size_t)c->last_batch * C * T;
+    MIS_REQUIRE((int64_t)n_el <= capacity, MIS_ERR_INVALID_INPUT, "tap buffer too small (%zu needed)", n_el);
+    HIP_CHECK(hipMemcpyAsync(out, src, n_el * sizeof(float), hipMemcpyDefault, c->stream));
+    HIP_CHECK(hipStreamSynchronize(c->stream));
+    *channels = C; *length = T;
+    MIS_API_END
+}
+
+// SNAC.fromModelDirectory (SNACDecoder.swift:156-189)
+extern "C" mis_status mis_snac_load(const char* model_dir, int device, mis_snac** out) {
+    mis_snac* c = nullptr;
+    try {
+        MIS_REQUIRE(model_dir && out, MIS_ERR_INVALID_INPUT, "null argument");
+        std::string dir = model_dir;
+        JsonValue j = json_parse(read_text_file(dir + "/config.json"));
+        mis_snac_config cf{};
+        cf.sampling_rate = (int)j.number_or("sampling_rate", 24000);
+        const JsonValue* er = j.get("encoder_rates");
+        int enc_dim = (int)j.number_or("encoder_dim", 64);
+        const JsonValue* ld = j.get("latent_dim");
+        MIS_REQUIRE(er && er->type == JsonValue::ARR, MIS_ERR_INVALID_INPUT, "config.json: encoder_rates missing");
+        cf.latent_dim = (ld && ld->type == JsonValue::NUM) ? (int)ld->num : enc_dim << er->arr.size();
+        cf.decoder_dim = (int)j.number_or("decoder_dim", 1536);
+        const JsonValue* dr = j.get("decoder_rates");
+        MIS_REQUIRE(dr && dr->type == JsonValue::ARR && dr->arr.size() <= 8, MIS_ERR_INVALID_INPUT, "config.json: decoder_rates");
+        cf.n_decoder_rates = (int)dr->arr.size();
+        for (size_t i = 0; i < dr->arr.size(); ++i) cf.decoder_rates[i] = (int)dr->arr[i].num;
+        cf.codebook_size = (int)j.number_or("codebook_size", 4096);
+        cf.codebook_dim = (int)j.number_or("codebook_dim", 8);
+        const JsonValue* vs = j.get("vq_strides");
+        MIS_REQUIRE(vs && vs->type == JsonValue::ARR && vs->arr.size() <= 8, MIS_ERR_INVALID_INPUT, "config.json: vq_strides");
+        cf.n_codebooks = (int)vs->arr.size();
+        for (size_t i = 0; i < vs->arr.size(); ++i) cf.vq_strides[i] = (int)vs->arr[i].num;
+        cf.noise = j.bool_or("noise", true) ? 1 : 0;
+        cf.depthwise = j.bool_or("depthwise", true) ? 1 : 0;
+        const JsonValue* aw = j.get("attn_window_size");
+        cf.attn_window_size = (aw && aw->type == JsonValue::NUM) ? (int)aw->num : 0;
+        mis_status st = mis_snac_create(&cf, device, &c);
+        if (st != MIS_OK) return st;
+        SafeTensorFile f;
+        f.open(dir + "/model.safetensors");
+        for (auto& e : f.entries) {
+            if (e.name.rfind("encoder.", 0) == 0) continue;                       // encode path: not built yet
+            if (e.name.find(".in_proj.") != std::string::npos) continue;          // encode path
+            st = mis_snac_set_tensor(c, e.name.c_str(), e.data, dtype_from_safetensors(e.dtype), e.shape.data(), (int)e.shape.size());
+            if (st != MIS_OK) { mis_snac_destroy(c); return st; }
+        }
+        st = mis_snac_finalize(c);
+        if (st != MIS_OK) { mis_snac_destroy(c); return st; }
+        *out = c;
+        return MIS_OK;
+    } catch (const MisError& e) {
+        if (c) mis_snac_destroy(c);
+        mis_set_error("%s", e.what());
+        return e.code;
+    } catch (const std::exception& e) {
+        if (c) mis_snac_destroy(c);
+        mis_set_error("%s", e.what());
+        return MIS_ERR_GENERATION_FAILED;
+    }
+}

@@ -1,0 +1,287 @@
+"""Orpheus / Llama TTS, host mirror of `class LlamaTTSModel: SpeechGenerationModel`
+(Sources/MLXAudioTTS/Models/Llama/LlamaTTS.swift:354-977).  Tokenisation stays on the host, as in
+the reference (swift-transformers, LlamaTTS.swift:487); everything after token ids runs in
+libmi_speech.so."""
+from __future__ import annotations
+
+import ctypes as C
+import json
+import os
+from dataclasses import dataclass, field
+
+import numpy as np
+
+from . import _lib
+from .codecs import SNAC, _tensor_args
+from .generation import (AudioEvent, AudioGenerationError, AudioGenerationInfo, GenerateParameters, InfoEvent,
+                         TokenEvent, check)
+
+
+class OrpheusTokens:
+    """LlamaTTS.swift:20-30"""
+    start_of_human = 128259
+    end_of_human = 128260
+    end_of_text = 128009
+    start_of_speech = 128257
+    end_of_speech = 128258
+    pad_token = 128263
+    audio_start = 128261
+    audio_end = 128262
+    audio_token_offset = 128266
+
+
+@dataclass
+class LlamaTTSConfiguration:
+    """LlamaTTSConfig.swift:15-61 (CodingKeys = HF config.json names)."""
+    hidden_size: int = 3072
+    num_hidden_layers: int = 28
+    intermediate_size: int = 8192
+    num_attention_heads: int = 24
+    num_key_value_heads: int | None = 8
+    head_dim: int | None = 128
+    rms_norm_eps: float = 1e-5
+    vocab_size: int = 156940
+    rope_theta: float = 10000.0
+    rope_traditional: bool = False
+    rope_scaling: dict | None = None
+    tie_word_embeddings: bool = True
+    attention_bias: bool = False
+    mlp_bias: bool = False
+    sample_rate: int = 24000
+    max_position_embeddings: int | None = None
+
+    @classmethod
+    def from_dict(cls, d: dict) -> "LlamaTTSConfiguration":
+        cfg = cls(**{k: d[k] for k in cls.__dataclass_fields__ if k in d})
+        rs = cfg.rope_scaling
+        if rs is not None:                                   # validation of LlamaTTSConfig.swift:139-165
+            if "factor" not in rs:
+                raise AudioGenerationError(3, "rope_scaling must contain 'factor'")
+            if "type" not in rs and "rope_type" not in rs:
+                raise AudioGenerationError(3, "rope_scaling must contain either 'type' or 'rope_type'")
+        return cfg
+
+    def to_c(self) -> "_lib.LmConfigC":
+        if self.rope_traditional or self.attention_bias or self.mlp_bias:
+            raise AudioGenerationError(3, "rope_traditional / attention_bias / mlp_bias variants are not supported")
+        rs = self.rope_scaling or {}
+        return _lib.LmConfigC(self.hidden_size, self.num_hidden_layers, self.intermediate_size,
+                              self.num_attention_heads, self.num_key_value_heads or self.num_attention_heads,
+                              self.head_dim or 0, self.vocab_size, self.rms_norm_eps, self.rope_theta,
+                              float(rs.get("factor", 32.0)), float(rs.get("low_freq_factor", 1.0)),
+                              float(rs.get("high_freq_factor", 4.0)),
+                              float(rs.get("original_max_position_embeddings", 8192.0)),
+                              1 if self.tie_word_embeddings else 0, self.sample_rate)
+
+
+class LlamaTTSModel:
+    """SpeechGenerationModel conformance: sample_rate, default_generation_parameters, generate,
+    generate_stream (Generation.swift:8-39).  Batch methods (`generate_batch`) are the new capability
+    (the reference is batch-1, LlamaTTS.swift:683-688); row r of a batch equals the B=1 result."""
+
+    def __init__(self, config: LlamaTTSConfiguration, codec: SNAC | None = None, device: int = 0, _handle=None):
+        self.configuration = config
+        self.device = device
+        self._snac_model = codec
+        self.tokenizer = None
+        self._h = _handle
+        if self._h is None:
+            h = C.c_void_p()
+            cfg = config.to_c()
+            check(_lib.lib().mis_tts_create(C.byref(cfg), codec._h if codec else None, device, C.byref(h)))
+            self._h = h
+
+    # -- loading (LlamaTTS.swift:915-993) ---------------------------------------------------------
+    @classmethod
+    def from_model_directory(cls, model_dir: str, codec: SNAC | None = None, device: int = 0) -> "LlamaTTSModel":
+        with open(os.path.join(model_dir, "config.json")) as f:
+            cfg = LlamaTTSConfiguration.from_dict(json.load(f))
+        h = C.c_void_p()
+        check(_lib.lib().mis_tts_load(model_dir.encode(), codec._h if codec else None, device, C.byref(h)))
+        return cls(cfg, codec, device, _handle=h)
+
+    @classmethod
+    def from_pretrained(cls, model_repo: str, codec: SNAC | None = None, device: int = 0) -> "LlamaTTSModel":
+        if os.path.isdir(model_repo):
+            return cls.from_model_directory(model_repo, codec, device)
+        raise AudioGenerationError(1, f"model repo {model_repo!r} is not a local directory (no network access)")
+
+    @classmethod
+    def from_weights(cls, config, weights: dict, codec: SNAC | None = None, device: int = 0) -> "LlamaTTSModel":
+        m = cls(config, codec, device)
+        for name, arr in weights.items():
+            m.set_tensor(name, arr)
+        m.finalize()
+        return m
+
+    @classmethod
+    def synthetic(cls, config, codec: SNAC | None = None, device: int = 0, seed: int = 4321) -> "LlamaTTSModel":
+        """Random weights generated on the device (mis-synth-v1); there are no checkpoints offline."""
+        m = cls(config, codec, device)
+        check(_lib.lib().mis_tts_init_synthetic(m._h, seed))
+        m.finalize()
+        return m
+
+    def set_tensor(self, name: str, arr):
+        keep, ptr, dt, shape = _tensor_args(arr)
+        sh = (C.c_int64 * len(shape))(*shape)
+        check(_lib.lib().mis_tts_set_tensor(self._h, name.encode(), ptr, dt, sh, len(shape)))
+
+    def finalize(self):
+        check(_lib.lib().mis_tts_finalize(self._h))
+
+    # -- protocol surface --------------------------------------------------------------------------
+    @property
+    def sample_rate(self) -> int:
+        return self.configuration.sample_rate
+
+    @property
+    def default_generation_parameters(self) -> GenerateParameters:
+        return GenerateParameters()
+
+    def prepare_input_ids(self, prompts, voice=None):
+        """prepareInputIds (LlamaTTS.swift:446-553) without the voice-cloning branch: returns the list
+        of per-row id arrays [SOH] text [EOT][EOH]; needs `self.tokenizer` (any object with .encode)."""
+        if self.tokenizer is None:
+            raise AudioGenerationError(1, "Tokenizer not loaded")
+        rows = []
+        for p in prompts:
+            if voice is not None:
+                p = f"{voice}: {p}"
+            ids = list(self.tokenizer.encode(p))
+            rows.append(np.asarray([OrpheusTokens.start_of_human] + ids +
+                                   [OrpheusTokens.end_of_text, OrpheusTokens.end_of_human], np.int32))
+        return rows
+
+    def generate(self, text: str, voice=None, ref_audio=None, ref_text=None, language=None,
+                 generation_parameters: GenerateParameters | None = None, snac_noise=None) -> np.ndarray:
+        """generate(text:voice:...) -> 1-D float32 PCM (LlamaTTS.swift:658-765)."""
+        if ref_audio is not None:
+            raise AudioGenerationError(5, "voice cloning needs the SNAC encode path (not built yet)")
+        text = text.replace("\\n", "\n").replace("\\t", "\t")            # :680-681
+        rows = self.prepare_input_ids([text], voice)
+        return self.generate_batch(rows, generation_parameters, snac_noise)[0]
+
+    def generate_batch(self, prompt_rows, generation_parameters: GenerateParameters | None = None, snac_noise=None,
+                       return_tokens: bool = False):
+        """Batched generate on already-tokenised prompts: list of 1-D float32 arrays (one per row)."""
+        gp = generation_parameters or self.default_generation_parameters
+        flat, lens = self._flatten(prompt_rows)
+        B = len(lens)
+        gpc = gp.to_c()
+        pcm = C.c_void_p(); stride = C.c_int64(); plens = (C.c_int64 * B)()
+        toks = C.c_void_p(); tstride = C.c_int64(); ntok = (C.c_int32 * B)()
+        nptr, keep = self._noise_ptrs(snac_noise)
+        check(_lib.lib().mis_tts_generate(self._h, flat.ctypes.data, lens.ctypes.data, B, C.byref(gpc), nptr,
+                                          C.byref(pcm), C.byref(stride), plens,
+                                          C.byref(toks) if return_tokens else None, C.byref(tstride), ntok))
+        try:
+            arr = np.ctypeslib.as_array(C.cast(pcm, C.POINTER(C.c_float)), shape=(B, max(stride.value, 1)))
+            out = [arr[b, : plens[b]].copy() for b in range(B)]
+            if return_tokens:
+                t = np.ctypeslib.as_array(C.cast(toks, C.POINTER(C.c_int32)), shape=(B, max(tstride.value, 1)))
+                tok = [t[b, : ntok[b]].copy() for b in range(B)]
+        finally:
+            _lib.lib().mis_free(pcm)
+            if return_tokens and toks:
+                _lib.lib().mis_free(toks)
+        return (out, tok) if return_tokens else out
+
+    def generate_stream(self, text: str, voice=None, ref_audio=None, ref_text=None, language=None,
+                        generation_parameters: GenerateParameters | None = None, snac_noise=None):
+        """generateStream(...) (LlamaTTS.swift:777-913): yields TokenEvent per step, then InfoEvent and
+        ONE final AudioEvent (Orpheus does not stream audio chunks)."""
+        text = text.replace("\\n", "\n").replace("\\t", "\t")
+        rows = self.prepare_input_ids([text], voice)
+        yield from self.generate_stream_batch(rows, generation_parameters, snac_noise)
+
+    def generate_stream_batch(self, prompt_rows, generation_parameters=None, snac_noise=None, cancel_flag=None):
+        gp = generation_parameters or self.default_generation_parameters
+        flat, lens = self._flatten(prompt_rows)
+        B = len(lens)
+        gpc = gp.to_c()
+        events = []
+
+        def cb(user, row, kind, payload, n):
+            if kind == _lib.EVENT_TOKEN:
+                events.append(TokenEvent(row, C.cast(payload, C.POINTER(C.c_int32))[0]))
+            elif kind == _lib.EVENT_INFO:
+                i = C.cast(payload, C.POINTER(_lib.GenInfoC))[0]
+                events.append(InfoEvent(row, AudioGenerationInfo(i.prompt_token_count, i.generation_token_count,
+                                                                 i.prefill_time, i.generate_time, i.tokens_per_second,
+                                                                 i.peak_memory_gb)))
+            else:
+                a = np.ctypeslib.as_array(C.cast(payload, C.POINTER(C.c_float)), shape=(max(n, 1),))[:n].copy()
+                events.append(AudioEvent(row, a))
+
+        cbf = _lib.EVENT_CB(cb)
+        nptr, keep = self._noise_ptrs(snac_noise)
+        flag = cancel_flag if cancel_flag is not None else C.c_int(0)
+        check(_lib.lib().mis_tts_generate_stream(self._h, flat.ctypes.data, lens.ctypes.data, B, C.byref(gpc), nptr, cbf,
+                                                 None, C.addressof(flag)))
+        yield from events
+
+    # -- LM taps used by the parity tests ------------------------------------------------------------
+    def lm_reset(self, batch: int, max_context: int):
+        check(_lib.lib().mis_lm_reset(self._h, batch, max_context))
+
+    def lm_forward(self, ids, active=None, want_logits: bool = True):
+        ids = np.ascontiguousarray(ids, dtype=np.int32)
+        B = ids.shape[0]
+        act = None if active is None else np.ascontiguousarray(active, dtype=np.uint8)
+        out = np.zeros((B, self.configuration.vocab_size), np.float32) if want_logits else None
+        check(_lib.lib().mis_lm_forward(self._h, ids.ctypes.data, act.ctypes.data if act is not None else None,
+                                        out.ctypes.data if want_logits else None))
+        return out
+
+    def last_timing(self) -> dict:
+        t = _lib.TimingC()
+        check(_lib.lib().mis_tts_last_timing(self._h, C.byref(t)))
+        return {k: getattr(t, k) for k, _ in t._fields_}
+
+    def time_gemm(self, which: int, batch: int, iters: int = 20):
+        ms, by = C.c_double(), C.c_double()
+        check(_lib.lib().mis_tts_time_gemm(self._h, which, batch, iters, C.byref(ms), C.byref(by)))
+        return ms.value, by.value
+
+    # -- helpers ---------------------------------------------------------------------------------------
+    @staticmethod
+    def _flatten(rows):
+        rows = [np.ascontiguousarray(r, dtype=np.int32).ravel() for r in rows]
+        if not rows:
+            raise AudioGenerationError(3, "empty batch")
+        lens = np.asarray([len(r) for r in rows], np.int32)
+        return np.ascontiguousarray(np.concatenate(rows)), lens
+
+    @staticmethod
+    def _noise_ptrs(noise):
+        if noise is None:
+            return None, None
+        keep = [np.ascontiguousarray(n, dtype=np.float32) for n in noise]
+        return (C.c_void_p * len(keep))(*[n.ctypes.data for n in keep]), keep
+
+    def close(self):
+        if self._h is not None:
+            _lib.lib().mis_tts_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def sample_logits(logits, window, window_len, params: GenerateParameters, step: int, lo: int = 0, hi: int = 0,
+                  device: int = 0):
+    """Stand-alone processor+sampler (mis_sample_logits) for parity tests."""
+    l = np.ascontiguousarray(logits, dtype=np.float32)
+    B, V = l.shape
+    w = np.ascontiguousarray(window, dtype=np.int32)
+    ctx = w.shape[1] if w.size else 0
+    wl = np.ascontiguousarray(window_len, dtype=np.int32)
+    out = np.zeros(B, np.int32)
+    gpc = params.to_c()
+    check(_lib.lib().mis_sample_logits(device, l.ctypes.data, B, V, w.ctypes.data if ctx else None,
+                                       wl.ctypes.data if ctx else None, ctx, C.byref(gpc), step, lo, hi, out.ctypes.data))
+    return out

@@ -23,10 +23,13 @@ own sampler testable bit-for-bit we define a deterministic realisation of those 
   E_i   = trunc(e_i * 2^40)                    uint64 fixed point
   Z     = sum_i E_i                            exact integer => order independent
   thr   = uint64(double(float32(1) - topP) * double(Z))
-  e*    = min{ v : sum_{e_j <= v} E_j > thr }  (whole tie group kept; MLX's tie order is unspecified)
-  K     = { i : e_i >= e* }                    (topP outside (0,1): K = all unmasked)
+  key_i = bits(e_i) >> 16                      (e truncated to bf16: ties = equal keys; MLX's own
+                                                tie order inside argSort is unspecified anyway)
+  k*    = min{ k : sum_{key_j <= k} E_j > thr }
+  K     = { i : key_i >= k*, E_i > 0 }         (topP outside (0,1): k* = 0)
   r     = mulhi64(rand64(seed,row,step), Z_K)  Z_K = sum_{i in K} E_i
-  token = first i in K (index order) with prefix_K(E)_i > r          (inverse CDF, exact integers)
+  token = first i in K, in LANE-MAJOR order (i mod 512, i div 512) - the order the 512-lane
+          kernel walks the vocabulary - whose running sum of E exceeds r   (inverse CDF, exact)
   rand64(seed,row,step) = splitmix64(splitmix64(seed ^ 0xD1B54A32D192ED03*(row+1)) + step)
 `row` is the GLOBAL utterance index, so results do not depend on how a batch is sharded over GPUs.
 Optional frame constraint (bench / synthetic weights only): tokens outside [lo, hi) are masked.
@@ -38,6 +41,7 @@ import numpy as np
 from .synth import bf16_round, splitmix64
 
 F = np.float32
+LANES = 512          # threads of the sampling block (csrc/lm_sampler.hip SAMP_NT)
 _LOG2E = F(1.4426950408889634)
 # 2^f on [0,1): degree-6 polynomial (Horner, separate IEEE mul/add, no fma)
 _P = [F(1.0), F(0.6931471805599453), F(0.2402265069591007), F(0.05550410866482158),
@@ -99,31 +103,28 @@ def sample(logits: np.ndarray, temperature: float, top_p: float, seed: int, row:
     x = (l / F(temperature)).astype(F)
     m = np.max(np.where(allowed, x, F(-np.inf))).astype(F)
     e = det_exp(np.minimum((x - m).astype(F), F(0.0)))
-    e = np.where(allowed, e, F(0.0)).astype(F)
+    e = np.ascontiguousarray(np.where(allowed, e, F(0.0)).astype(F))
     E = (e.astype(np.float64) * float(2 ** 40)).astype(np.uint64)
     Z = int(E.sum(dtype=np.uint64))
+    key = (e.view(np.uint32) >> np.uint32(16)).astype(np.int64)
     if 0.0 < top_p < 1.0:
         thr = int(np.uint64(np.float64(F(1.0) - F(top_p)) * np.float64(Z)))
-        order = np.argsort(e, kind="stable")
-        es, Es = e[order], E[order]
-        cum = np.cumsum(Es, dtype=np.uint64)
-        # inclusive mass of each distinct value's whole tie group
-        last_of_group = np.r_[es[1:] != es[:-1], True]
-        grp_cum = cum[last_of_group]
-        grp_val = es[last_of_group]
-        gi = int(np.searchsorted(grp_cum, np.uint64(thr), side="right"))   # first group with cum > thr
-        e_star = grp_val[min(gi, len(grp_val) - 1)]
-        keep = (e >= e_star) & allowed & (E > 0)
+        mass = np.zeros(1 << 16, np.uint64)
+        np.add.at(mass, key, E)
+        cum = np.cumsum(mass, dtype=np.uint64)
+        k_star = int(np.searchsorted(cum, np.uint64(thr), side="right"))    # first key with cum > thr
+        k_star = min(k_star, (1 << 16) - 1)
     else:
-        keep = allowed & (E > 0)
-        e_star = F(0.0)
+        k_star = 0
+    keep = (key >= k_star) & (E > 0)
     Ek = np.where(keep, E, np.uint64(0))
     Zk = int(Ek.sum(dtype=np.uint64))
     r = (rand64(seed, row, step) * Zk) >> 64
-    pref = np.cumsum(Ek, dtype=np.uint64)
-    tok = int(np.searchsorted(pref, np.uint64(r), side="right"))
+    order = np.lexsort((np.arange(V) // LANES, np.arange(V) % LANES))   # lane-major walk
+    pref = np.cumsum(Ek[order], dtype=np.uint64)
+    tok = int(order[int(np.searchsorted(pref, np.uint64(r), side="right"))])
     if return_debug:
-        return tok, dict(Z=Z, Zk=Zk, r=r, e_star=float(e_star), n_keep=int(keep.sum()), keep=keep, e=e)
+        return tok, dict(Z=Z, Zk=Zk, r=r, k_star=k_star, n_keep=int(keep.sum()), keep=keep, e=e)
     return tok
 
 

@@ -1,0 +1,56 @@
+"""Helpers shared by the -m gpu parity tests (all calls go through the C ABI via the host mirror)."""
+import numpy as np
+import torch
+
+import mlx_audio_swift_amd as mas
+from oracle import llama as ollama
+from oracle import snac as osnac
+
+
+def rms(a, b):
+    a = np.asarray(a, np.float64); b = np.asarray(b, np.float64)
+    return float(np.sqrt(np.mean((a - b) ** 2)))
+
+
+def snac_pair(cfg_dict, seed=1234):
+    ocfg = osnac.SnacConfig(**cfg_dict)
+    W = osnac.make_synthetic_weights(ocfg, seed=seed)
+    oracle = osnac.SnacOracle(ocfg, W)
+    hcfg = mas.SNACConfig(**{k: getattr(ocfg, k) for k in mas.SNACConfig.__dataclass_fields__})
+    dev = mas.SNAC.from_weights(hcfg, W)
+    return ocfg, oracle, dev
+
+
+def lm_host_config(ocfg: ollama.LlamaConfig) -> mas.LlamaTTSConfiguration:
+    return mas.LlamaTTSConfiguration(
+        hidden_size=ocfg.hidden_size, num_hidden_layers=ocfg.num_hidden_layers, intermediate_size=ocfg.intermediate_size,
+        num_attention_heads=ocfg.num_attention_heads, num_key_value_heads=ocfg.num_key_value_heads,
+        head_dim=ocfg.head_dim, rms_norm_eps=ocfg.rms_norm_eps, vocab_size=ocfg.vocab_size, rope_theta=ocfg.rope_theta,
+        rope_scaling=dict(ocfg.rope_scaling) if ocfg.rope_scaling else None, tie_word_embeddings=ocfg.tie_word_embeddings)
+
+
+def lm_pair(ocfg: ollama.LlamaConfig, seed=4321, codec=None):
+    W = ollama.make_synthetic_weights(ocfg, seed=seed)        # bf16 tensors
+    oracle = ollama.LlamaOracle(ocfg, W, round="bf16")
+    dev = mas.LlamaTTSModel.from_weights(lm_host_config(ocfg), W, codec=codec)
+    return W, oracle, dev
+
+
+def teacher_forced(oracle, dev, rows, max_context=64):
+    """rows: list of 1-D id arrays (ragged).  Feeds them left-aligned one token per step through the
+    device engine (inactive once a row is exhausted) and all at once per row through the oracle.
+    Returns per-row (device_logits [L,V], oracle_logits [L,V])."""
+    B = len(rows)
+    Lmax = max(len(r) for r in rows)
+    dev.lm_reset(B, max_context)
+    got = [[] for _ in range(B)]
+    for t in range(Lmax):
+        ids = np.asarray([r[t] if t < len(r) else 0 for r in rows], np.int32)
+        act = np.asarray([1 if t < len(r) else 0 for r in rows], np.uint8)
+        lg = dev.lm_forward(ids, act)
+        for b in range(B):
+            if act[b]:
+                got[b].append(lg[b].copy())
+    oracle.reset(B)
+    ref = oracle.forward(rows)
+    return [(np.stack(got[b]), ref[b].numpy()) for b in range(B)]

@@ -1,0 +1,132 @@
+"""-m gpu: the batched generate()/generateStream() path end to end: prefill -> graph-replayed decode loop
+with on-device sampling -> parseOutput -> de-interleave -> SNAC, checked against the oracles.
+
+Free-running tokens cannot be compared one by one (a one-ulp bf16 difference flips an argmax and the
+sequences diverge), so parity is stated as: (1) every token the engine emitted, replayed through the
+oracle LM under teacher forcing, is the oracle's argmax up to the stated logit tolerance; (2) the
+waveform equals the oracle SNAC decode of the engine's own tokens within 1e-4 RMS; (3) integer framing
+is exact."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import mlx_audio_swift_amd as mas
+from gpu_util import lm_pair, rms, snac_pair
+from oracle import llama as ollama
+from oracle import orpheus_codes as oc
+from oracle import snac as osnac
+
+pytestmark = pytest.mark.gpu
+
+SNAC_SMALL = dict(encoder_dim=4, encoder_rates=[2, 4, 8, 8], decoder_dim=64, decoder_rates=[8, 8, 4, 2],
+                  codebook_size=4096, codebook_dim=8, vq_strides=[4, 2, 1])          # hop 512 like snac_24khz
+LM_SMALL = ollama.LlamaConfig(hidden_size=256, num_hidden_layers=2, intermediate_size=512, num_attention_heads=2,
+                              num_key_value_heads=1, head_dim=128, vocab_size=156940)
+
+
+@pytest.fixture(scope="module")
+def stack():
+    ocfg_s, osn, dsn = snac_pair(SNAC_SMALL)
+    W, olm, dlm = lm_pair(LM_SMALL, codec=dsn)
+    return ocfg_s, osn, dsn, olm, dlm
+
+
+def _prompts(rng, lens):
+    return [np.asarray([oc.START_OF_HUMAN] + list(rng.integers(0, 128000, n - 4)) +
+                       [oc.END_OF_TEXT, oc.END_OF_HUMAN, oc.START_OF_SPEECH], np.int32) for n in lens]
+
+
+def test_generate_greedy_constrained_parity(stack):
+    ocfg_s, osn, dsn, olm, dlm = stack
+    rng = np.random.default_rng(0)
+    prompts = _prompts(rng, [9, 5, 12])
+    gp = mas.GenerateParameters(max_tokens=21, temperature=0.0, top_p=0.8, repetition_penalty=1.3, seed=3,
+                                frame_constrained=True)
+    zeros = [np.zeros((3, n), np.float32) for n in dsn.noise_lengths(3)]
+    pcm, toks = dlm.generate_batch(prompts, gp, snac_noise=zeros, return_tokens=True)
+    assert [len(t) for t in toks] == [21, 21, 21] and [len(p) for p in pcm] == [3 * 2048] * 3
+    # (3) framing exact; (2) waveform vs oracle decode of the engine's tokens
+    for b in range(3):
+        slots = (toks[b] - oc.AUDIO_TOKEN_OFFSET) // 4096
+        assert np.array_equal(slots, np.arange(21) % 7)
+        codes = oc.parse_output_row(list(prompts[b]) + list(toks[b]))
+        assert np.array_equal(codes, toks[b] - oc.AUDIO_TOKEN_OFFSET)
+        l0, l1, l2 = oc.deinterleave(codes)
+        ref = osn.decode([l0[None], l1[None], l2[None]], None)[0, 0]
+        assert rms(pcm[b], ref) < 1e-4
+    # (1) teacher-forced oracle: engine's token is the oracle argmax (after the oracle's own penalty) within tolerance
+    from oracle import sampler as osamp
+    olm.reset(3)
+    for b in range(3):
+        seq = list(prompts[b]) + list(toks[b])
+        logits = olm._forward_row(b, __import__("torch").as_tensor(np.asarray(seq[:-1], np.int64))).numpy()
+        win = osamp.RepetitionWindow(20, prompts[b])
+        for i, t in enumerate(toks[b]):
+            l = osamp.apply_repetition_penalty(logits[len(prompts[b]) - 1 + i], win.ids, 1.3, bf16=True)
+            lo = oc.AUDIO_TOKEN_OFFSET + (i % 7) * 4096
+            seg = l[lo: lo + 4096]
+            tol = 0.04 * float(np.abs(logits).max())
+            assert seg[t - lo] >= seg.max() - tol, (b, i)
+            win.push(int(t))
+    # determinism + batch-vs-single parity on the token level
+    pcm2, toks2 = dlm.generate_batch(prompts, gp, snac_noise=zeros, return_tokens=True)
+    assert all(np.array_equal(a, b) for a, b in zip(toks, toks2)) and all(np.array_equal(a, b) for a, b in zip(pcm, pcm2))
+    one_pcm, one_tok = dlm.generate_batch(prompts[1:2], gp, snac_noise=[z[:1] for z in zeros], return_tokens=True)
+    assert np.array_equal(one_tok[0], toks[1]) and np.array_equal(one_pcm[0], pcm[1])
+
+
+def test_sampled_generation_is_seeded_and_stream_contract(stack):
+    ocfg_s, osn, dsn, olm, dlm = stack
+    rng = np.random.default_rng(1)
+    prompts = _prompts(rng, [8, 8])
+    gp = mas.GenerateParameters(max_tokens=14, temperature=0.6, top_p=0.8, repetition_penalty=1.3, seed=11,
+                                frame_constrained=True)
+    a = dlm.generate_batch(prompts, gp, return_tokens=True)
+    b = dlm.generate_batch(prompts, gp, return_tokens=True)
+    gp2 = mas.GenerateParameters(max_tokens=14, temperature=0.6, top_p=0.8, repetition_penalty=1.3, seed=12,
+                                 frame_constrained=True)
+    c = dlm.generate_batch(prompts, gp2, return_tokens=True)
+    assert all(np.array_equal(x, y) for x, y in zip(a[1], b[1])) and all(np.array_equal(x, y) for x, y in zip(a[0], b[0]))
+    assert not all(np.array_equal(x, y) for x, y in zip(a[1], c[1]))
+    # row_offset makes a shard reproduce the rows of the full batch (sharding invariance)
+    gp_shard = mas.GenerateParameters(max_tokens=14, temperature=0.6, top_p=0.8, repetition_penalty=1.3, seed=11,
+                                      frame_constrained=True, row_offset=1)
+    s = dlm.generate_batch(prompts[1:], gp_shard, return_tokens=True)
+    assert np.array_equal(s[1][0], a[1][1]) and np.array_equal(s[0][0], a[0][1])
+    # stream contract (LlamaTTS.swift:862,893-904): .token* then .info then ONE .audio per row
+    ev = list(dlm.generate_stream_batch(prompts, gp))
+    for row in (0, 1):
+        kinds = [type(e).__name__ for e in ev if e.row == row]
+        assert kinds == ["TokenEvent"] * 14 + ["InfoEvent", "AudioEvent"]
+        toks = [e.token for e in ev if e.row == row and isinstance(e, mas.TokenEvent)]
+        assert np.array_equal(toks, a[1][row])
+        audio = [e.audio for e in ev if e.row == row and isinstance(e, mas.AudioEvent)][0]
+        assert np.array_equal(audio, a[0][row])
+        info = [e.info for e in ev if e.row == row and isinstance(e, mas.InfoEvent)][0]
+        assert info.prompt_token_count == 8 and info.generation_token_count == 14 and info.tokens_per_second > 0
+
+
+def test_eos_ragged_rows_errors_and_cancel(stack):
+    ocfg_s, osn, dsn, olm, dlm = stack
+    rng = np.random.default_rng(2)
+    prompts = _prompts(rng, [6, 6])
+    # unconstrained greedy on random weights: tokens are arbitrary ids -> almost surely < 7 audio tokens
+    gp = mas.GenerateParameters(max_tokens=5, temperature=0.0, repetition_penalty=0.0, seed=1)
+    with pytest.raises(mas.AudioGenerationError) as e:
+        dlm.generate_batch(prompts, gp)
+    assert e.value.case == "generationFailed"                   # "No audio codes generated", LlamaTTS.swift:754-756
+    with pytest.raises(mas.AudioGenerationError) as e:
+        dlm.generate_batch([np.asarray([200000], np.int32)], gp)
+    assert e.value.case == "invalidInput"
+    flag = C.c_int(1)
+    gpc = mas.GenerateParameters(max_tokens=64, temperature=0.0, frame_constrained=True)
+    with pytest.raises(mas.AudioGenerationError) as e:
+        list(dlm.generate_stream_batch(prompts, gpc, cancel_flag=flag))
+    assert e.value.case == "cancelled"
+    no_codec = mas.LlamaTTSModel.synthetic(mas.LlamaTTSConfiguration(
+        hidden_size=64, num_hidden_layers=1, intermediate_size=64, num_attention_heads=1, num_key_value_heads=1,
+        head_dim=64, vocab_size=200))
+    with pytest.raises(mas.AudioGenerationError) as e:
+        no_codec.generate_batch([np.asarray([1, 2], np.int32)], gp)
+    assert e.value.case == "modelNotInitialized"                # "SNAC model not loaded", LlamaTTS.swift:672-674

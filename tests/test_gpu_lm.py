@@ -1,0 +1,101 @@
+"""-m gpu: Llama decode-step kernels (packed-weight MFMA GEMMs, fused attention, norms) vs the oracle.
+
+Tolerance (stated): the engine and the oracle both round to bf16 at every MLX primitive boundary but
+accumulate in different orders, so individual bf16 roundings may differ by one ulp and propagate.
+Teacher-forced logits must satisfy  max|dev - ref| <= 0.04 * max|ref|  and  rms(dev - ref) <=
+0.008 * rms(ref), and the greedy token must agree whenever the oracle's top-2 margin exceeds that
+error bound."""
+import numpy as np
+import pytest
+import torch
+
+import mlx_audio_swift_amd as mas
+from gpu_util import lm_host_config, lm_pair, rms, teacher_forced
+from oracle import llama as ollama
+
+pytestmark = pytest.mark.gpu
+
+
+def _check(pairs):
+    for dev_l, ref_l in pairs:
+        assert dev_l.shape == ref_l.shape
+        scale = float(np.abs(ref_l).max())
+        err = float(np.abs(dev_l - ref_l).max())
+        assert err <= 0.04 * scale, (err, scale)
+        assert rms(dev_l, ref_l) <= 0.008 * float(np.sqrt(np.mean(ref_l.astype(np.float64) ** 2)))
+        # bf16-valued logits
+        t = torch.from_numpy(dev_l)
+        assert torch.equal(t, t.to(torch.bfloat16).to(torch.float32))
+        top2 = np.sort(ref_l, axis=1)[:, -2:]
+        margin = top2[:, 1] - top2[:, 0]
+        sure = margin > 2 * err
+        assert sure.sum() > 0
+        assert np.array_equal(dev_l.argmax(1)[sure], ref_l.argmax(1)[sure])
+
+
+@pytest.mark.parametrize("cfg", [ollama.TINY, ollama.TINY64], ids=["d128-gqa3", "d64-mha"])
+def test_teacher_forced_logits_match_oracle(cfg):
+    W, oracle, dev = lm_pair(cfg)
+    rng = np.random.default_rng(1)
+    rows = [rng.integers(0, cfg.vocab_size, n).astype(np.int32) for n in (37, 5, 20)]   # ragged, > 32 keys
+    _check(teacher_forced(oracle, dev, rows, max_context=64))
+
+
+def test_untied_lm_head_and_long_context():
+    cfg = ollama.LlamaConfig(**{**ollama.TINY.__dict__, "tie_word_embeddings": False, "num_hidden_layers": 1})
+    W, oracle, dev = lm_pair(cfg)
+    rng = np.random.default_rng(2)
+    rows = [rng.integers(0, cfg.vocab_size, 300).astype(np.int32)]                     # 10 key tiles, all 8 waves busy
+    pairs = teacher_forced(oracle, dev, rows, max_context=320)
+    _check([(pairs[0][0][-40:], pairs[0][1][-40:])])
+
+
+def test_batch_row_equals_single_row_bitwise():
+    # Tests/ParakeetBatchParityTests.swift pattern: generateBatch(rows)[r] == generate(rows[r])
+    cfg = ollama.TINY
+    W, oracle, dev = lm_pair(cfg)
+    rng = np.random.default_rng(3)
+    rows = [rng.integers(0, cfg.vocab_size, 9).astype(np.int32) for _ in range(5)]
+    dev.lm_reset(5, 64)
+    batch_logits = [dev.lm_forward(np.asarray([r[t] for r in rows], np.int32)) for t in range(9)]
+    for r in (0, 4):
+        dev.lm_reset(1, 64)
+        for t in range(9):
+            one = dev.lm_forward(np.asarray([rows[r][t]], np.int32))
+            assert np.array_equal(one[0], batch_logits[t][r]), (r, t)
+    # 17 rows -> Mpad 32 (two MFMA column tiles): same numbers again
+    dev.lm_reset(17, 64)
+    rows17 = rows + [rows[0]] * 12
+    for t in range(9):
+        lg = dev.lm_forward(np.asarray([r[t] for r in rows17], np.int32))
+        assert np.array_equal(lg[:5], batch_logits[t])
+        assert np.array_equal(lg[16], batch_logits[t][0])
+
+
+def test_device_synthetic_init_equals_oracle_weights():
+    cfg = ollama.TINY
+    W, oracle, dev = lm_pair(cfg, seed=4321)
+    syn = mas.LlamaTTSModel.synthetic(lm_host_config(cfg), seed=4321)
+    ids = np.asarray([3, 999], np.int32)
+    dev.lm_reset(2, 64); syn.lm_reset(2, 64)
+    for _ in range(3):
+        a = dev.lm_forward(ids); b = syn.lm_forward(ids)
+        assert np.array_equal(a, b)          # identical weights => identical logits
+
+
+def test_inactive_rows_do_not_advance_and_errors():
+    cfg = ollama.TINY
+    W, oracle, dev = lm_pair(cfg)
+    dev.lm_reset(2, 64)
+    a0 = dev.lm_forward(np.asarray([5, 6], np.int32), np.asarray([1, 0], np.uint8))
+    a1 = dev.lm_forward(np.asarray([7, 6], np.int32), np.asarray([1, 1], np.uint8))
+    dev.lm_reset(1, 64)
+    b = dev.lm_forward(np.asarray([6], np.int32))
+    assert np.array_equal(a1[1], b[0])       # row 1 saw token 6 at position 0 exactly once
+    with pytest.raises(mas.AudioGenerationError):
+        dev.lm_reset(65, 64)
+    m = mas.LlamaTTSModel(lm_host_config(cfg))
+    with pytest.raises(mas.AudioGenerationError) as e:
+        m.finalize()
+    assert e.value.case == "modelNotInitialized"
+    del a0

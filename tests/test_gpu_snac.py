@@ -1,0 +1,107 @@
+"""-m gpu: SNAC decode (HIP, through the C ABI) vs the CPU oracle.
+Tolerance: waveform RMS error <= 1e-4 (BASELINE.json north_star), measured on outputs in (-1,1)."""
+import os
+
+import numpy as np
+import pytest
+
+from gpu_util import rms, snac_pair
+from oracle import snac as osnac
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-4
+G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+@pytest.mark.parametrize("cfgd,batch,groups", [
+    (osnac.TINY, 2, 5), (osnac.TINY, 1, 1), (osnac.TINY, 3, 40),
+    (dict(osnac.TINY, decoder_rates=[3, 2], decoder_dim=48), 2, 7),          # odd stride: length s*T-1
+    (dict(osnac.TINY, vq_strides=[2, 1], decoder_dim=128, codebook_size=4096), 1, 9),
+])
+def test_decode_matches_oracle_small(cfgd, batch, groups):
+    ocfg, oracle, dev = snac_pair(cfgd)
+    codes = osnac.synthetic_codes(ocfg, batch, groups)
+    noise = osnac.synthetic_noise(ocfg, batch, groups)
+    ref, inter = oracle.decoder(oracle.from_codes(codes), noise, return_intermediates=True)
+    got = dev.decode(codes, noise)
+    assert got.shape == ref.shape
+    # stage-by-stage diagnostics first (relative to the stage's own scale)
+    zq = dev.debug_tap("zq", batch)
+    assert rms(zq, oracle.from_codes(codes)) < 1e-5 * max(1.0, float(np.abs(zq).max()))
+    for name in ["stem_dw", "stem_pw"] + [f"block{i}" for i in range(len(ocfg.decoder_rates))]:
+        t = dev.debug_tap(name, batch)
+        assert t.shape == inter[name].shape, name
+        assert rms(t, inter[name]) < 2e-5 * float(np.abs(inter[name]).max()), name
+    assert rms(got, ref) < TOL
+    assert np.all(np.isfinite(got)) and np.abs(got).max() < 1.0
+
+
+def test_c1_full_24khz_matches_golden_and_oracle():
+    # BASELINE config 1: SNAC 24 kHz, 1 s of random codebook indices (12 groups -> 24576 samples)
+    z = np.load(os.path.join(G, "snac_c1.npz"))
+    ocfg, oracle, dev = snac_pair({})
+    codes = [z["l0"], z["l1"], z["l2"]]
+    noise = osnac.synthetic_noise(ocfg, 1, 12, seed=1236)
+    got = dev.decode(codes, noise)
+    assert got.shape == (1, 1, 24576)
+    assert rms(got[0, 0], z["pcm_noise"]) < TOL
+    dev.set_noise(True)
+    got0 = dev.decode(codes, None)
+    assert rms(got0[0, 0], z["pcm_zero_noise"]) < TOL
+    zeros = [np.zeros((1, n), np.float32) for n in dev.noise_lengths(12)]
+    assert np.array_equal(dev.decode(codes, zeros), got0)           # explicit zeros == "add nothing"
+    assert dev.noise_lengths(12) == [384, 3072, 12288, 24576] and dev.num_samples(12) == 24576
+
+
+def test_full_config_batch_and_internal_noise():
+    ocfg, oracle, dev = snac_pair({})
+    B, Gr = 3, 4
+    codes = osnac.synthetic_codes(ocfg, B, Gr, seed=77)
+    noise = osnac.synthetic_noise(ocfg, B, Gr, seed=78)
+    got = dev.decode(codes, noise)
+    assert rms(got, oracle.decode(codes, noise)) < TOL
+    # batch-vs-single parity (pattern of Tests/ParakeetBatchParityTests.swift): row r == the B=1 decode
+    for r in range(B):
+        one = dev.decode([c[r:r + 1] for c in codes], [n[r:r + 1] for n in noise])
+        assert np.array_equal(one[0], got[r])
+    # noise == None: N(0,1) drawn on the device (reference behaviour): reproducible per seed, differs per seed
+    dev.set_noise(False, seed=1)
+    a = dev.decode(codes, None); b = dev.decode(codes, None)
+    dev.set_noise(False, seed=2)
+    c = dev.decode(codes, None)
+    assert np.array_equal(a, b) and not np.array_equal(a, c)
+    dev.set_noise(True)
+    d = dev.decode(codes, None)
+    assert 0.01 < rms(a, d) < 1.0                                   # noise really is injected
+
+
+def test_large_batch_properties_at_bench_size():
+    # BASELINE config 3 codec leg: B = 32 rows x 96 groups (8.192 s each); the oracle is too slow here,
+    # so check size-independent properties: rows independent, finite, bounded, deterministic.
+    ocfg, oracle, dev = snac_pair({})
+    dev.set_noise(True)
+    B, Gr = 32, 96
+    codes = osnac.synthetic_codes(ocfg, B, Gr, seed=5)
+    got = dev.decode(codes, None)
+    assert got.shape == (B, 1, Gr * 2048)
+    assert np.all(np.isfinite(got)) and np.abs(got).max() < 1.0 and got.std() > 0.05
+    for r in (0, 17, 31):
+        one = dev.decode([c[r:r + 1] for c in codes], None)
+        assert np.array_equal(one[0], got[r])
+    # prefix property: the first groups of a row do not depend on codes far to the right
+    # (receptive field of the decoder is bounded): decode the first 8 groups alone
+    head = dev.decode([codes[0][:1, :8], codes[1][:1, :16], codes[2][:1, :32]], None)
+    assert rms(head[0, 0, : 4 * 2048], got[0, 0, : 4 * 2048]) < 1e-6
+
+
+def test_empty_and_invalid_inputs():
+    import mlx_audio_swift_amd as mas
+    ocfg, oracle, dev = snac_pair(osnac.TINY)
+    out = dev.decode([np.zeros((2, 0), np.int32)] * 3)
+    assert out.shape == (2, 1, 0)
+    with pytest.raises(mas.AudioGenerationError):
+        dev.decode([np.zeros((1, 4), np.int32), np.zeros((1, 7), np.int32), np.zeros((1, 16), np.int32)])
+    with pytest.raises(mas.AudioGenerationError) as e:
+        m = mas.SNAC(mas.SNACConfig(**{k: getattr(ocfg, k) for k in mas.SNACConfig.__dataclass_fields__}))
+        m.finalize()                                               # verify:.all -> missing keys
+    assert e.value.case == "modelNotInitialized"
