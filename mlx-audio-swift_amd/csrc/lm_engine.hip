@@ -41,6 +41,7 @@ struct mis_tts {
     // per-batch state
     int batch = 0, Mpad = 0, Smax = 0;
     int S_qkv = 1, S_o = 1, S_down = 1;
+    int ksb_part = 4, ksb_gu = 4, ksb_head = 1;     // waves per work item (in-block split-K), see k_gemm_skinny
     DevBuf<bf16_t> kcache, vtcache;
     DevBuf<float> rope_cos, rope_sin;
     DevBuf<int32_t> ids, pos_cur, pos_next;
@@ -51,6 +52,7 @@ struct mis_tts {
     DevBuf<int32_t> prompt_mat, prompt_lens, step_counter, window, window_len, n_gen, tokens_out, all_ids, all_len,
         done_count, codes, n_codes, l0, l1, l2, row_map;
     DevBuf<float> pcm_tmp;
+    DevBuf<SamplerScratch> samp_scratch;
     hipGraphExec_t g_prefill = nullptr, g_decode = nullptr;
     uint64_t graph_key = 0;
     bool use_graph = true;
@@ -276,11 +278,18 @@ extern "C" mis_status mis_tts_finalize(mis_tts* c) {
 }
 
 // ---------------------------------------------------------------------------- per-batch state
-static int choose_split(int items, int KT) {
-    int S = 2048 / std::max(items, 1);
-    S = std::min(S, std::max(1, KT / 8));
+static int env_int(const char* name, int dflt) {
+    const char* v = getenv(name);
+    return (v && *v) ? atoi(v) : dflt;
+}
+// inter-block split-K factor: aim at ~target waves in flight, keep >= 4 k-tiles per wave
+static int choose_split(int items, int KT, int ksb, const char* env) {
+    int target = env_int("MIS_GEMM_TARGET_WAVES", 3584);
+    int S = (target + items * ksb / 2) / std::max(items * ksb, 1);
+    S = std::min(S, std::max(1, KT / (4 * ksb)));
     S = std::min(S, 16);
-    return std::max(S, 1);
+    S = std::max(S, 1);
+    return env_int(env, S);
 }
 
 static void destroy_graphs(mis_tts* c) {
@@ -333,9 +342,12 @@ static void lm_reset(mis_tts* c, int batch, int max_context) {
     bool new_tables = Smax != c->Smax;
     c->batch = batch; c->Mpad = Mpad; c->Smax = Smax;
     const int d = c->d, HD = c->H * c->D;
-    c->S_qkv = choose_split(c->Nqkv / 16, d / 32);
-    c->S_o = choose_split(d / 16, HD / 32);
-    c->S_down = choose_split(d / 16, c->ff / 32);
+    c->ksb_part = env_int("MIS_KSB_PART", 4) == 1 ? 1 : 4;
+    c->ksb_gu = env_int("MIS_KSB_GU", 4) == 1 ? 1 : 4;
+    c->ksb_head = env_int("MIS_KSB_HEAD", 1) == 4 ? 4 : 1;
+    c->S_qkv = choose_split(c->Nqkv / 16, d / 32, c->ksb_part, "MIS_S_QKV");
+    c->S_o = choose_split(d / 16, HD / 32, c->ksb_part, "MIS_S_O");
+    c->S_down = choose_split(d / 16, c->ff / 32, c->ksb_part, "MIS_S_DOWN");
     size_t kv = (size_t)c->L * batch * c->Hkv * Smax * c->D;
     c->kcache.alloc(kv);
     c->vtcache.alloc(kv);
@@ -362,7 +374,7 @@ static void enqueue_layers(mis_tts* c) {
     launch_embed_rmsnorm(c->emb.p, c->ids.p, c->active.p, c->pos_cur.p, c->pos_next.p, c->norms.p, c->h.p, c->x.p, d,
                          c->V, eps, c->batch, Mpad, s);
     for (int li = 0; li < c->L; ++li) {
-        launch_gemm_skinny(EPI_PARTIAL, 1, c->wqkv.p + layer_qkv_elems(c) * li, c->x.p, c->qkv_part.p, c->Nqkv / 16,
+        launch_gemm_skinny(EPI_PARTIAL, 1, c->ksb_part, c->wqkv.p + layer_qkv_elems(c) * li, c->x.p, c->qkv_part.p, c->Nqkv / 16,
                            d / 32, c->S_qkv, c->Nqkv, Mpad, s);
         AttnParams ap{};
         ap.qkv_part = c->qkv_part.p; ap.S = c->S_qkv; ap.Mpad = Mpad; ap.Nqkv = c->Nqkv;
@@ -373,13 +385,13 @@ static void enqueue_layers(mis_tts* c) {
         ap.out = c->attn_out.p; ap.H = c->H; ap.Hkv = c->Hkv; ap.D = c->D; ap.Smax = c->Smax;
         ap.scale = 1.0f / sqrtf((float)c->D);
         launch_attn_decode(ap, c->batch, s);
-        launch_gemm_skinny(EPI_PARTIAL, 1, c->wo.p + layer_o_elems(c) * li, c->attn_out.p, c->part.p, d / 16, HD / 32,
+        launch_gemm_skinny(EPI_PARTIAL, 1, c->ksb_part, c->wo.p + layer_o_elems(c) * li, c->attn_out.p, c->part.p, d / 16, HD / 32,
                            c->S_o, d, Mpad, s);
         launch_reduce_residual_rmsnorm(c->part.p, c->S_o, Mpad, d, c->h.p, c->norms.p + (size_t)(2 * li + 1) * d,
                                        c->x.p, eps, s);
-        launch_gemm_skinny(EPI_SILU_MUL, 2, c->wgu.p + layer_gu_elems(c) * li, c->x.p, c->act.p, 2 * c->ff / 16, d / 32,
+        launch_gemm_skinny(EPI_SILU_MUL, 2, c->ksb_gu, c->wgu.p + layer_gu_elems(c) * li, c->x.p, c->act.p, 2 * c->ff / 16, d / 32,
                            1, c->ff, Mpad, s);
-        launch_gemm_skinny(EPI_PARTIAL, 1, c->wdown.p + layer_down_elems(c) * li, c->act.p, c->part.p, d / 16,
+        launch_gemm_skinny(EPI_PARTIAL, 1, c->ksb_part, c->wdown.p + layer_down_elems(c) * li, c->act.p, c->part.p, d / 16,
                            c->ff / 32, c->S_down, d, Mpad, s);
         const bf16_t* next_norm = c->norms.p + (size_t)(li + 1 < c->L ? 2 * (li + 1) : 2 * c->L) * d;
         launch_reduce_residual_rmsnorm(c->part.p, c->S_down, Mpad, d, c->h.p, next_norm, c->x.p, eps, s);
@@ -387,7 +399,7 @@ static void enqueue_layers(mis_tts* c) {
 }
 
 static void enqueue_lm_head(mis_tts* c) {
-    launch_gemm_skinny(EPI_BF16, 2, c->lm_head.p, c->x.p, c->logits.p, c->Vpad / 16, c->d / 32, 1, c->Vpad, c->Mpad,
+    launch_gemm_skinny(EPI_BF16, 2, c->ksb_head, c->lm_head.p, c->x.p, c->logits.p, c->Vpad / 16, c->d / 32, 1, c->Vpad, c->Mpad,
                        c->stream);
 }
 
@@ -470,7 +482,11 @@ extern "C" mis_status mis_sample_logits(int device, const float* logits, int bat
     }
     std::vector<int32_t> st(batch, step);
     HIP_CHECK(hipMemcpy(steps.p, st.data(), batch * 4, hipMemcpyHostToDevice));
+    DevBuf<SamplerScratch> scratch;
+    scratch.alloc(batch);
     SamplerParams sp{};
+    sp.scratch = scratch.p;
+    sampler_plan(vocab, &sp.n_chunks, &sp.chunk_w);
     sp.logits = lb.p; sp.e_buf = eb.p; sp.Vpad = Vpad; sp.vocab = vocab;
     sp.window = ctx > 0 ? win.p : nullptr; sp.window_len = ctx > 0 ? wl.p : nullptr; sp.ctx = ctx;
     sp.tokens_out = toks.p; sp.tokens_stride = 0; sp.next_ids = toks.p; sp.step_override = steps.p;
@@ -560,7 +576,10 @@ static void run_generate(mis_tts* c, const int32_t* prompt_ids, const int32_t* p
     c->step_counter.zero(s); c->n_gen.zero(s); c->done_count.zero(s); c->tokens_out.zero(s);
     HIP_CHECK(hipStreamSynchronize(s));
 
+    c->samp_scratch.alloc(batch);
     SamplerParams sp{};
+    sp.scratch = c->samp_scratch.p;
+    sampler_plan(c->V, &sp.n_chunks, &sp.chunk_w);
     sp.logits = c->logits.p; sp.e_buf = c->e_buf.p; sp.Vpad = c->Vpad; sp.vocab = c->V;
     sp.active_in = c->active.p; sp.window = ctx > 0 ? c->window.p : nullptr; sp.window_len = c->window_len.p; sp.ctx = ctx;
     sp.n_gen = c->n_gen.p; sp.tokens_out = c->tokens_out.p; sp.tokens_stride = max_tokens;
@@ -868,10 +887,10 @@ extern "C" mis_status mis_tts_time_gemm(mis_tts* c, int which, int batch, int it
     auto run = [&](int it) {
         size_t li = (size_t)(it % c->L);
         switch (which) {
-            case 0: launch_gemm_skinny(EPI_PARTIAL, 1, c->wqkv.p + layer_qkv_elems(c) * li, c->x.p, c->qkv_part.p, c->Nqkv / 16, d / 32, c->S_qkv, c->Nqkv, Mpad, s); break;
-            case 1: launch_gemm_skinny(EPI_PARTIAL, 1, c->wo.p + layer_o_elems(c) * li, c->attn_out.p, c->part.p, d / 16, HD / 32, c->S_o, d, Mpad, s); break;
-            case 2: launch_gemm_skinny(EPI_SILU_MUL, 2, c->wgu.p + layer_gu_elems(c) * li, c->x.p, c->act.p, 2 * c->ff / 16, d / 32, 1, c->ff, Mpad, s); break;
-            case 3: launch_gemm_skinny(EPI_PARTIAL, 1, c->wdown.p + layer_down_elems(c) * li, c->act.p, c->part.p, d / 16, c->ff / 32, c->S_down, d, Mpad, s); break;
+            case 0: launch_gemm_skinny(EPI_PARTIAL, 1, c->ksb_part, c->wqkv.p + layer_qkv_elems(c) * li, c->x.p, c->qkv_part.p, c->Nqkv / 16, d / 32, c->S_qkv, c->Nqkv, Mpad, s); break;
+            case 1: launch_gemm_skinny(EPI_PARTIAL, 1, c->ksb_part, c->wo.p + layer_o_elems(c) * li, c->attn_out.p, c->part.p, d / 16, HD / 32, c->S_o, d, Mpad, s); break;
+            case 2: launch_gemm_skinny(EPI_SILU_MUL, 2, c->ksb_gu, c->wgu.p + layer_gu_elems(c) * li, c->x.p, c->act.p, 2 * c->ff / 16, d / 32, 1, c->ff, Mpad, s); break;
+            case 3: launch_gemm_skinny(EPI_PARTIAL, 1, c->ksb_part, c->wdown.p + layer_down_elems(c) * li, c->act.p, c->part.p, d / 16, c->ff / 32, c->S_down, d, Mpad, s); break;
             case 4: enqueue_lm_head(c); break;
             default: throw MisError(MIS_ERR_INVALID_INPUT, "unknown GEMM id");
         }

@@ -17,7 +17,8 @@ void launch_embed_rmsnorm(const bf16_t* emb, const int32_t* ids, const uint8_t* 
 void launch_reduce_residual_rmsnorm(const float* slabs, int S, int Mpad, int N, bf16_t* h, const bf16_t* wnorm,
                                     bf16_t* x, float eps, hipStream_t s);
 // Wp packed [NT][KT][64][8]; X bf16 [Mpad][KT*32]; out: f32 slabs [S][Mpad][N_out] (EPI_PARTIAL) or bf16 [Mpad][N_out]
-void launch_gemm_skinny(int epi, int R, const bf16_t* Wp, const bf16_t* X, void* out, int NT, int KT, int S,
+// ksb = 1: each wave an independent item; ksb = 4: the block's 4 waves split the item's K range (LDS combine)
+void launch_gemm_skinny(int epi, int R, int ksb, const bf16_t* Wp, const bf16_t* X, void* out, int NT, int KT, int S,
                         int N_out, int Mpad, hipStream_t s);
 
 struct AttnParams {
@@ -35,7 +36,19 @@ struct AttnParams {
 };
 void launch_attn_decode(const AttnParams& p, int batch, hipStream_t s);
 
+#define SAMP_MAX_CHUNKS 64
+struct SamplerScratch {             // per row, device memory
+    unsigned long long hist1[256], hist2[256], cmass[SAMP_MAX_CHUNKS];
+    unsigned long long below1, Z, thr;
+    float pmax[SAMP_MAX_CHUNKS];
+    int pidx[SAMP_MAX_CHUNKS];
+    unsigned bin1, kstar;
+};
+void sampler_plan(int vocab, int* n_chunks, int* chunk_w);
+
 struct SamplerParams {
+    SamplerScratch* scratch; // [batch]
+    int n_chunks, chunk_w;   // vocabulary split (sampler_plan)
     bf16_t* logits;          // [Mpad][Vpad]  (penalty is applied in place)
     float* e_buf;            // [Mpad][Vpad] scratch
     int Vpad, vocab;

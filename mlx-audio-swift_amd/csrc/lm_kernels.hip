@@ -148,25 +148,65 @@ void launch_embed_rmsnorm(const bf16_t* emb, const int32_t* ids, const uint8_t* 
                        vocab, eps, batch);
 }
 
-// One block per row: o = T(sum_s slab[s]) ; h = T(h + o) ; x = RMSNorm(h) * w      (LlamaTTS.swift:306-309)
-__global__ void __launch_bounds__(256) k_reduce_residual_rmsnorm(const float* __restrict__ slabs, int S, int Mpad,
-                                                                 int N, bf16_t* __restrict__ h,
-                                                                 const bf16_t* __restrict__ wnorm,
-                                                                 bf16_t* __restrict__ x, float eps) {
-    __shared__ float red[4];
-    int m = blockIdx.x;
+// One 1024-thread block per row: o = T(sum_s slab[s]) ; h = T(h + o) ; x = RMSNorm(h) * w  (LlamaTTS.swift:306-309)
+// Each thread owns <= RR_MAXC columns; all S x RR_MAXC slab loads of a thread are independent, so one L2
+// round trip covers them (the v0 kernel chained 120 dependent loads: 34 us per call, 31 % of a step).
+#define RR_THREADS 1024
+#define RR_MAXC 4
+__device__ __forceinline__ float block_sum_1024(float v, float* red) {
+    v = wave_sum(v);
+    int w = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) red[w] = v;
+    __syncthreads();
+    float t = 0.0f;
+#pragma unroll
+    for (int i = 0; i < RR_THREADS / 64; ++i) t += red[i];
+    __syncthreads();
+    return t;
+}
+__global__ void __launch_bounds__(RR_THREADS) k_reduce_residual_rmsnorm(const float* __restrict__ slabs, int S,
+                                                                        int Mpad, int N, bf16_t* __restrict__ h,
+                                                                        const bf16_t* __restrict__ wnorm,
+                                                                        bf16_t* __restrict__ x, float eps) {
+    __shared__ float red[RR_THREADS / 64];
+    const int m = blockIdx.x, tid = threadIdx.x;
     float ss = 0.0f;
-    for (int i = threadIdx.x; i < N; i += 256) {
-        float acc = 0.0f;
-        for (int s = 0; s < S; ++s) acc += slabs[((size_t)s * Mpad + m) * N + i];
-        float o = bf16_round_f32(acc);
-        float hn = bf16_round_f32(bf16_to_f32(h[(size_t)m * N + i]) + o);
-        h[(size_t)m * N + i] = f32_to_bf16(hn);
-        ss += hn * hn;
+    for (int c0 = 0; c0 < N; c0 += RR_THREADS * RR_MAXC) {
+        float acc[RR_MAXC], hv[RR_MAXC];
+#pragma unroll
+        for (int k = 0; k < RR_MAXC; ++k) {
+            int i = c0 + tid + k * RR_THREADS;
+            acc[k] = 0.0f;
+            hv[k] = (i < N) ? bf16_to_f32(h[(size_t)m * N + i]) : 0.0f;
+        }
+        for (int s0 = 0; s0 < S; s0 += 4) {
+            float v[4][RR_MAXC];
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int k = 0; k < RR_MAXC; ++k) {
+                    int i = c0 + tid + k * RR_THREADS;
+                    v[j][k] = (s0 + j < S && i < N) ? slabs[((size_t)(s0 + j) * Mpad + m) * N + i] : 0.0f;
+                }
+#pragma unroll
+            for (int j = 0; j < 4; ++j)        // slab order s = 0,1,2,... (fixed => deterministic)
+#pragma unroll
+                for (int k = 0; k < RR_MAXC; ++k) acc[k] += v[j][k];
+        }
+#pragma unroll
+        for (int k = 0; k < RR_MAXC; ++k) {
+            int i = c0 + tid + k * RR_THREADS;
+            if (i < N) {
+                float o = bf16_round_f32(acc[k]);
+                float hn = bf16_round_f32(hv[k] + o);
+                h[(size_t)m * N + i] = f32_to_bf16(hn);
+                ss += hn * hn;
+            }
+        }
     }
-    float tot = block_sum_256(ss, red);
+    float tot = block_sum_1024(ss, red);
     float inv = 1.0f / sqrtf(tot / (float)N + eps);
-    for (int i = threadIdx.x; i < N; i += 256) {
+    for (int i = tid; i < N; i += RR_THREADS) {
         float f = bf16_to_f32(h[(size_t)m * N + i]);          // written by this same thread above
         float n = bf16_round_f32(f * inv);
         x[(size_t)m * N + i] = f32_to_bf16(bf16_to_f32(wnorm[i]) * n);
@@ -174,7 +214,7 @@ __global__ void __launch_bounds__(256) k_reduce_residual_rmsnorm(const float* __
 }
 void launch_reduce_residual_rmsnorm(const float* slabs, int S, int Mpad, int N, bf16_t* h, const bf16_t* wnorm,
                                     bf16_t* x, float eps, hipStream_t s) {
-    hipLaunchKernelGGL(k_reduce_residual_rmsnorm, dim3(Mpad), dim3(256), 0, s, slabs, S, Mpad, N, h, wnorm, x, eps);
+    hipLaunchKernelGGL(k_reduce_residual_rmsnorm, dim3(Mpad), dim3(RR_THREADS), 0, s, slabs, S, Mpad, N, h, wnorm, x, eps);
 }
 
 // ============================================================================ weight-streaming skinny GEMM
@@ -183,72 +223,19 @@ void launch_reduce_residual_rmsnorm(const float* slabs, int S, int Mpad, int N, 
 // v_mfma_f32_16x16x32_bf16 with A = W tile (16 n x 32 k), B = X^T (32 k x 16 m):
 //   A lane l: W[n = l&15][k = (l>>4)*8 + e]      B lane l: X[m = l&15][k = (l>>4)*8 + e]
 //   C/D lane l, reg r: n = (l>>4)*4 + r, m = l&15
-// Each WAVE is an independent work item (R consecutive n-tiles x one K slice): no LDS, no barriers,
-// every weight load is one contiguous 1 KiB tile read exactly once from HBM (non-temporal); X comes
-// from L2.  HBM-bound: algorithmic bytes = N*K*2 per launch.
+// Work item = R consecutive n-tiles x one K slice (S slices across blocks).  KSB = 1: every wave is an
+// independent item (no LDS, no barrier).  KSB = 4: the 4 waves of a block split their item's K range and
+// combine through LDS in a fixed order (deterministic) - 4x the waves in flight without 4x the partial
+// slabs.  Every weight load is one contiguous 1 KiB tile read exactly once from HBM (non-temporal); X
+// comes from L2.  The main loop is software pipelined over two static register buffers of GEMM_U k-tiles,
+// so 2*GEMM_U*(R+MT) KiB per wave are in flight while the MFMAs of the previous group run.
+// HBM-bound: algorithmic bytes = N*K*2 per launch.
 
 #define GEMM_U 4
 
 template <int MT, int R, int EPI>
-__global__ void __launch_bounds__(256) k_gemm_skinny(const bf16_t* __restrict__ Wp, const bf16_t* __restrict__ X,
-                                                     void* __restrict__ out, int NT, int KT, int S, int n_items,
-                                                     int N_out, int Mpad) {
-    const int lane = threadIdx.x & 63;
-    const int item = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (item >= n_items) return;
-    const int ntg = item / S, ks = item - ntg * S;
-    const int kt0 = (int)(((long long)KT * ks) / S), kt1 = (int)(((long long)KT * (ks + 1)) / S);
-    const int K = KT * 32;
-
-    const bf16x8_t* wp[R];
-#pragma unroll
-    for (int r = 0; r < R; ++r) {
-        int tile = ntg * R + r;
-        if (tile >= NT) tile = NT - 1;                     // clamp (store is skipped below)
-        wp[r] = reinterpret_cast<const bf16x8_t*>(Wp) + (size_t)tile * KT * 64 + lane;
-    }
-    const bf16x8_t* xp[MT];
-#pragma unroll
-    for (int mt = 0; mt < MT; ++mt)
-        xp[mt] = reinterpret_cast<const bf16x8_t*>(X + (size_t)(mt * 16 + (lane & 15)) * K + (lane >> 4) * 8);
-
-    f32x4_t acc[R][MT];
-#pragma unroll
-    for (int r = 0; r < R; ++r)
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt) acc[r][mt] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
-
-    int kt = kt0;
-    for (; kt + GEMM_U <= kt1; kt += GEMM_U) {
-        bf16x8_t w[GEMM_U][R], x[GEMM_U][MT];
-#pragma unroll
-        for (int u = 0; u < GEMM_U; ++u) {
-#pragma unroll
-            for (int r = 0; r < R; ++r) w[u][r] = __builtin_nontemporal_load(wp[r] + (size_t)(kt + u) * 64);
-#pragma unroll
-            for (int mt = 0; mt < MT; ++mt) x[u][mt] = xp[mt][(size_t)(kt + u) * 4];
-        }
-#pragma unroll
-        for (int u = 0; u < GEMM_U; ++u)
-#pragma unroll
-            for (int r = 0; r < R; ++r)
-#pragma unroll
-                for (int mt = 0; mt < MT; ++mt)
-                    acc[r][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[u][r], x[u][mt], acc[r][mt], 0, 0, 0);
-    }
-    for (; kt < kt1; ++kt) {
-        bf16x8_t w[R], x[MT];
-#pragma unroll
-        for (int r = 0; r < R; ++r) w[r] = __builtin_nontemporal_load(wp[r] + (size_t)kt * 64);
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt) x[mt] = xp[mt][(size_t)kt * 4];
-#pragma unroll
-        for (int r = 0; r < R; ++r)
-#pragma unroll
-            for (int mt = 0; mt < MT; ++mt)
-                acc[r][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[r], x[mt], acc[r][mt], 0, 0, 0);
-    }
-
+__device__ __forceinline__ void gemm_epilogue(const f32x4_t (&acc)[R][MT], void* __restrict__ out, int ntg, int ks,
+                                              int NT, int N_out, int Mpad, int lane, int mt_only) {
     const int nl = (lane >> 4) * 4, ml = lane & 15;
     if (EPI == EPI_PARTIAL) {
         float* o = reinterpret_cast<float*>(out);
@@ -258,6 +245,7 @@ __global__ void __launch_bounds__(256) k_gemm_skinny(const bf16_t* __restrict__ 
             if (tile >= NT) continue;
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) {
+                if (mt_only >= 0 && mt != mt_only) continue;
                 size_t off = ((size_t)ks * Mpad + mt * 16 + ml) * N_out + tile * 16 + nl;
                 *reinterpret_cast<float4*>(o + off) =
                     make_float4(acc[r][mt][0], acc[r][mt][1], acc[r][mt][2], acc[r][mt][3]);
@@ -271,6 +259,7 @@ __global__ void __launch_bounds__(256) k_gemm_skinny(const bf16_t* __restrict__ 
             if (tile >= NT) continue;
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) {
+                if (mt_only >= 0 && mt != mt_only) continue;
                 size_t off = ((size_t)mt * 16 + ml) * N_out + tile * 16 + nl;
                 uint2 v;
                 v.x = (uint32_t)f32_to_bf16(acc[r][mt][0]) | ((uint32_t)f32_to_bf16(acc[r][mt][1]) << 16);
@@ -280,10 +269,9 @@ __global__ void __launch_bounds__(256) k_gemm_skinny(const bf16_t* __restrict__ 
         }
     } else {   // EPI_SILU_MUL: tile 2t = gate rows, 2t+1 = up rows  (LlamaTTS.swift:283)
         bf16_t* o = reinterpret_cast<bf16_t*>(out);
-        static_assert(EPI != EPI_SILU_MUL || R == 2, "silu-mul epilogue pairs a gate tile with an up tile");
-        int t = ntg;
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
+            if (mt_only >= 0 && mt != mt_only) continue;
             uint16_t res[4];
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
@@ -293,7 +281,7 @@ __global__ void __launch_bounds__(256) k_gemm_skinny(const bf16_t* __restrict__ 
                 float a = bf16_round_f32(g * sg);                          // T(g * sigmoid)
                 res[e] = f32_to_bf16(a * u);                               // T(silu * up)
             }
-            size_t off = ((size_t)mt * 16 + ml) * N_out + t * 16 + nl;
+            size_t off = ((size_t)mt * 16 + ml) * N_out + ntg * 16 + nl;
             uint2 v;
             v.x = (uint32_t)res[0] | ((uint32_t)res[1] << 16);
             v.y = (uint32_t)res[2] | ((uint32_t)res[3] << 16);
@@ -302,33 +290,135 @@ __global__ void __launch_bounds__(256) k_gemm_skinny(const bf16_t* __restrict__ 
     }
 }
 
-template <int MT>
-static void launch_gemm_mt(int epi, int R, const bf16_t* Wp, const bf16_t* X, void* out, int NT, int KT, int S,
-                           int N_out, int Mpad, hipStream_t s) {
-    int n_items = ((NT + R - 1) / R) * S;
-    dim3 grid((n_items + 3) / 4), block(256);
-    if (epi == EPI_PARTIAL && R == 1)
-        hipLaunchKernelGGL((k_gemm_skinny<MT, 1, EPI_PARTIAL>), grid, block, 0, s, Wp, X, out, NT, KT, S, n_items, N_out, Mpad);
-    else if (epi == EPI_PARTIAL && R == 2)
-        hipLaunchKernelGGL((k_gemm_skinny<MT, 2, EPI_PARTIAL>), grid, block, 0, s, Wp, X, out, NT, KT, S, n_items, N_out, Mpad);
-    else if (epi == EPI_BF16 && R == 2)
-        hipLaunchKernelGGL((k_gemm_skinny<MT, 2, EPI_BF16>), grid, block, 0, s, Wp, X, out, NT, KT, S, n_items, N_out, Mpad);
-    else if (epi == EPI_BF16 && R == 1)
-        hipLaunchKernelGGL((k_gemm_skinny<MT, 1, EPI_BF16>), grid, block, 0, s, Wp, X, out, NT, KT, S, n_items, N_out, Mpad);
-    else if (epi == EPI_SILU_MUL && R == 2)
-        hipLaunchKernelGGL((k_gemm_skinny<MT, 2, EPI_SILU_MUL>), grid, block, 0, s, Wp, X, out, NT, KT, S, n_items, N_out, Mpad);
-    else
-        throw MisError(MIS_ERR_GENERATION_FAILED, "unsupported GEMM variant");
+template <int MT, int R, int EPI, int KSB>
+__global__ void __launch_bounds__(256) k_gemm_skinny(const bf16_t* __restrict__ Wp, const bf16_t* __restrict__ X,
+                                                     void* __restrict__ out, int NT, int KT, int S, int n_items,
+                                                     int N_out, int Mpad) {
+    static_assert(EPI != EPI_SILU_MUL || R == 2, "silu-mul epilogue pairs a gate tile with an up tile");
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int item = (KSB == 1) ? blockIdx.x * 4 + wave : blockIdx.x;
+    if (item >= n_items) return;                      // KSB > 1: uniform per block
+    const int ntg = item / S, ks = item - ntg * S;
+    int kt0 = (int)(((long long)KT * ks) / S), kt1 = (int)(((long long)KT * (ks + 1)) / S);
+    if (KSB > 1) {                                    // this wave's quarter of the item's K range
+        int len = kt1 - kt0;
+        int a = kt0 + (int)(((long long)len * wave) / KSB), b = kt0 + (int)(((long long)len * (wave + 1)) / KSB);
+        kt0 = a; kt1 = b;
+    }
+    const int K = KT * 32;
+
+    const bf16x8_t* wp[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        int tile = ntg * R + r;
+        if (tile >= NT) tile = NT - 1;                     // clamp (store is skipped in the epilogue)
+        wp[r] = reinterpret_cast<const bf16x8_t*>(Wp) + (size_t)tile * KT * 64 + lane;
+    }
+    const bf16x8_t* xp[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+        xp[mt] = reinterpret_cast<const bf16x8_t*>(X + (size_t)(mt * 16 + (lane & 15)) * K + (lane >> 4) * 8);
+
+    f32x4_t acc[R][MT];
+#pragma unroll
+    for (int r = 0; r < R; ++r)
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) acc[r][mt] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+
+    bf16x8_t wA[GEMM_U][R], xA[GEMM_U][MT], wB[GEMM_U][R], xB[GEMM_U][MT];
+    const int klast = kt1 - 1;
+#define GEMM_LOAD(WBUF, XBUF, KBASE)                                                              \
+    _Pragma("unroll") for (int u = 0; u < GEMM_U; ++u) {                                           \
+        int kk = (KBASE) + u;                                                                      \
+        kk = kk > klast ? klast : kk;               /* tail: redundant reload, MFMA is skipped */  \
+        _Pragma("unroll") for (int r = 0; r < R; ++r)                                              \
+            WBUF[u][r] = __builtin_nontemporal_load(wp[r] + (size_t)kk * 64);                      \
+        _Pragma("unroll") for (int mt = 0; mt < MT; ++mt) XBUF[u][mt] = xp[mt][(size_t)kk * 4];    \
+    }
+#define GEMM_MATH(WBUF, XBUF, KBASE)                                                              \
+    _Pragma("unroll") for (int u = 0; u < GEMM_U; ++u) {                                           \
+        if ((KBASE) + u < kt1) {                                                                   \
+            _Pragma("unroll") for (int r = 0; r < R; ++r)                                          \
+                _Pragma("unroll") for (int mt = 0; mt < MT; ++mt)                                  \
+                    acc[r][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(WBUF[u][r], XBUF[u][mt],  \
+                                                                         acc[r][mt], 0, 0, 0);     \
+        }                                                                                          \
+    }
+    if (kt0 < kt1) {
+        int kt = kt0;
+        GEMM_LOAD(wA, xA, kt)
+        while (true) {
+            if (kt + GEMM_U < kt1) { GEMM_LOAD(wB, xB, kt + GEMM_U) }
+            GEMM_MATH(wA, xA, kt)
+            kt += GEMM_U;
+            if (kt >= kt1) break;
+            if (kt + GEMM_U < kt1) { GEMM_LOAD(wA, xA, kt + GEMM_U) }
+            GEMM_MATH(wB, xB, kt)
+            kt += GEMM_U;
+            if (kt >= kt1) break;
+        }
+    }
+#undef GEMM_LOAD
+#undef GEMM_MATH
+
+    if (KSB == 1) {
+        gemm_epilogue<MT, R, EPI>(acc, out, ntg, ks, NT, N_out, Mpad, lane, -1);
+    } else {
+        __shared__ float4 red[KSB][R * MT][64];
+#pragma unroll
+        for (int r = 0; r < R; ++r)
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+                red[wave][r * MT + mt][lane] = make_float4(acc[r][mt][0], acc[r][mt][1], acc[r][mt][2], acc[r][mt][3]);
+        __syncthreads();
+        // wave w finishes the m-tiles mt = w, w+KSB, ...: sum the KSB partials in fixed order, then epilogue
+        for (int mt = wave; mt < MT; mt += KSB) {
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                float4 s0 = red[0][r * MT + mt][lane];
+#pragma unroll
+                for (int w = 1; w < KSB; ++w) {
+                    float4 t = red[w][r * MT + mt][lane];
+                    s0.x += t.x; s0.y += t.y; s0.z += t.z; s0.w += t.w;
+                }
+#pragma unroll
+                for (int m2 = 0; m2 < MT; ++m2)
+                    if (m2 == mt) acc[r][m2] = (f32x4_t){s0.x, s0.y, s0.z, s0.w};
+            }
+            gemm_epilogue<MT, R, EPI>(acc, out, ntg, ks, NT, N_out, Mpad, lane, mt);
+        }
+    }
 }
 
-void launch_gemm_skinny(int epi, int R, const bf16_t* Wp, const bf16_t* X, void* out, int NT, int KT, int S,
+template <int MT>
+static void launch_gemm_mt(int epi, int R, int ksb, const bf16_t* Wp, const bf16_t* X, void* out, int NT, int KT, int S,
+                           int N_out, int Mpad, hipStream_t s) {
+    int n_items = ((NT + R - 1) / R) * S;
+    dim3 grid(ksb == 1 ? (n_items + 3) / 4 : n_items), block(256);
+#define GEMM_CASE(E, RR, KS)                                                                                  \
+    if (epi == E && R == RR && ksb == KS) {                                                                   \
+        hipLaunchKernelGGL((k_gemm_skinny<MT, RR, E, KS>), grid, block, 0, s, Wp, X, out, NT, KT, S, n_items, \
+                           N_out, Mpad);                                                                      \
+        return;                                                                                               \
+    }
+    GEMM_CASE(EPI_PARTIAL, 1, 1)
+    GEMM_CASE(EPI_PARTIAL, 1, 4)
+    GEMM_CASE(EPI_BF16, 2, 1)
+    GEMM_CASE(EPI_BF16, 2, 4)
+    GEMM_CASE(EPI_SILU_MUL, 2, 1)
+    GEMM_CASE(EPI_SILU_MUL, 2, 4)
+#undef GEMM_CASE
+    throw MisError(MIS_ERR_GENERATION_FAILED, "unsupported GEMM variant");
+}
+
+void launch_gemm_skinny(int epi, int R, int ksb, const bf16_t* Wp, const bf16_t* X, void* out, int NT, int KT, int S,
                         int N_out, int Mpad, hipStream_t s) {
     MIS_REQUIRE(epi == EPI_PARTIAL || S == 1, MIS_ERR_GENERATION_FAILED, "split-K needs the partial epilogue");
     switch (Mpad / 16) {
-        case 1: launch_gemm_mt<1>(epi, R, Wp, X, out, NT, KT, S, N_out, Mpad, s); break;
-        case 2: launch_gemm_mt<2>(epi, R, Wp, X, out, NT, KT, S, N_out, Mpad, s); break;
-        case 3: launch_gemm_mt<3>(epi, R, Wp, X, out, NT, KT, S, N_out, Mpad, s); break;
-        case 4: launch_gemm_mt<4>(epi, R, Wp, X, out, NT, KT, S, N_out, Mpad, s); break;
+        case 1: launch_gemm_mt<1>(epi, R, ksb, Wp, X, out, NT, KT, S, N_out, Mpad, s); break;
+        case 2: launch_gemm_mt<2>(epi, R, ksb, Wp, X, out, NT, KT, S, N_out, Mpad, s); break;
+        case 3: launch_gemm_mt<3>(epi, R, ksb, Wp, X, out, NT, KT, S, N_out, Mpad, s); break;
+        case 4: launch_gemm_mt<4>(epi, R, ksb, Wp, X, out, NT, KT, S, N_out, Mpad, s); break;
         default: throw MisError(MIS_ERR_INVALID_INPUT, "batch per GPU must be <= 64");
     }
 }

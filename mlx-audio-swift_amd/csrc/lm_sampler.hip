@@ -2,21 +2,29 @@
 //
 // Replaces the per-token host round trip of the reference loop (LlamaTTS.swift:717-723:
 // processor.process -> sampler.sample -> .item()): repetition penalty, temperature, nucleus cut and the
-// categorical draw run in ONE kernel per step, one 512-thread block per utterance, and the sampled id
-// never leaves the GPU (it is written straight into next_ids for the following forward pass).
+// categorical draw run on the device and the sampled id never leaves the GPU (it is written straight
+// into next_ids for the following forward pass).
 //
+// v0 used one block per row and was latency bound (518 us per step).  Now every pass over the vocabulary
+// is spread over (chunks x rows) blocks, six small kernels inside the step's hipGraph:
+//   k_samp_prepare   repetition penalty in place (<= ctx ids per row) + scratch reset
+//   k_samp_max       per-chunk max over the allowed ids                      (greedy: max + first index)
+//   k_samp_exp       e_i = det_exp(fdiv(l_i,T) - max), E_i = trunc(e_i 2^40); 256-bin mass histogram of
+//                    key_i >> 8 (LDS u64 atomics, flushed with global u64 atomics: exact integers)
+//   k_samp_hist2     scan level-1 bins -> bin holding the nucleus boundary; 256-bin histogram of key & 255
+//   k_samp_mass      scan level-2 bins -> k*; kept mass per chunk
+//   k_samp_pick      r = mulhi64(rand64, Z_K); chunk, then token by inverse CDF in INDEX order; bookkeeping
 // Every quantity after e_i is an exact integer, so the result is independent of reduction order and
 // bit-identical to the numpy oracle:
-//   x_i = fdiv(l_i, T); y_i = x_i - max x; e_i = det_exp(y_i) (0 if masked); E_i = trunc(e_i * 2^40)
 //   key_i = bits(e_i) >> 16 ;  Z = sum E ; thr = u64(double(1 - topP) * double(Z))
 //   k* = min{k : sum_{key_j <= k} E_j > thr} ;  K = {i : key_i >= k*, E_i > 0}
-//   r = mulhi64(rand64(seed,row,step), Z_K) ; token = first i in K, in LANE-MAJOR order
-//   (i mod 512, i div 512), whose running sum exceeds r.
+//   token = first i in K (index order) with prefix_K(E)_i > r
 #include "common.h"
 #include "lm_kernels.h"
 
-#define SAMP_NT 512
+#define SAMP_NT 256
 #define ORPHEUS_AUDIO_OFFSET 128266
+#define E_SCALE 1099511627776.0f
 
 typedef unsigned long long u64;
 
@@ -38,67 +46,62 @@ __device__ __forceinline__ float det_exp_dev(float y) {
     return (n < -60.0f) ? 0.0f : r;
 }
 
-__device__ __forceinline__ u64 shfl_xor_u64(u64 v, int m) {
-    unsigned lo = (unsigned)v, hi = (unsigned)(v >> 32);
-    lo = __shfl_xor(lo, m, 64);
-    hi = __shfl_xor(hi, m, 64);
-    return ((u64)hi << 32) | lo;
-}
-__device__ __forceinline__ u64 block_sum_u64(u64 v, u64* red) {      // red[SAMP_NT/64]
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += shfl_xor_u64(v, o);
-    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
-    __syncthreads();
-    u64 t = 0;
-#pragma unroll
-    for (int w = 0; w < SAMP_NT / 64; ++w) t += red[w];
-    __syncthreads();
-    return t;
-}
-__device__ __forceinline__ float block_max_f32(float v, float* red) {
-    v = wave_max(v);
-    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
-    __syncthreads();
-    float t = red[0];
-#pragma unroll
-    for (int w = 1; w < SAMP_NT / 64; ++w) t = fmaxf(t, red[w]);
-    __syncthreads();
-    return t;
-}
-
-__global__ void __launch_bounds__(SAMP_NT) k_sampler(SamplerParams p) {
-    __shared__ u64 bins[8][SAMP_NT];       // 32 KiB: per-thread private mass bins / scan scratch
-    __shared__ u64 red64[SAMP_NT / 64];
-    __shared__ float redf[SAMP_NT / 64];
-    __shared__ int redi[SAMP_NT / 64];
-    __shared__ u64 s_cum;
-    __shared__ unsigned s_prefix;
-    __shared__ int s_token;
-
-    const int b = blockIdx.x, tid = threadIdx.x;
-    if (p.active_in && !p.active_in[b]) return;
-    bf16_t* logits = p.logits + (size_t)b * p.Vpad;
-    float* ebuf = p.e_buf + (size_t)b * p.Vpad;
+__device__ __forceinline__ void allowed_range(const SamplerParams& p, int step, int& lo, int& hi) {
     const int V = p.vocab;
-    const int step = p.step_override ? p.step_override[b] : p.n_gen[b];
-    if (!p.step_override && step >= p.max_tokens) return;
-
-    int lo = p.lo, hi = (p.hi <= 0 || p.hi > V) ? V : p.hi;
+    lo = p.lo;
+    hi = (p.hi <= 0 || p.hi > V) ? V : p.hi;
     if (p.frame_constrained) {
         lo = ORPHEUS_AUDIO_OFFSET + (step % 7) * 4096;
         hi = lo + 4096;
         if (hi > V) hi = V;
         if (lo > hi) lo = hi;
     }
+    if (lo < 0) lo = 0;
+}
+__device__ __forceinline__ int row_step(const SamplerParams& p, int b) {
+    return p.step_override ? p.step_override[b] : p.n_gen[b];
+}
+__device__ __forceinline__ bool row_skipped(const SamplerParams& p, int b) {
+    if (p.active_in && !p.active_in[b]) return true;
+    return !p.step_override && p.n_gen[b] >= p.max_tokens;
+}
+__device__ __forceinline__ void chunk_range(const SamplerParams& p, int c, int& i0, int& i1) {
+    i0 = c * p.chunk_w;
+    i1 = i0 + p.chunk_w;
+    if (i1 > p.vocab) i1 = p.vocab;
+    if (i0 > i1) i0 = i1;
+}
 
-    // ---- repetition penalty, once per unique id of the window (RepetitionContext.process)
+// inclusive scan of 256 u64 values held one per thread (Hillis-Steele through LDS)
+__device__ __forceinline__ u64 block_scan_incl_256(u64 v, u64* sh) {
+    const int tid = threadIdx.x;
+    sh[tid] = v;
+    __syncthreads();
+    for (int o = 1; o < SAMP_NT; o <<= 1) {
+        u64 t = (tid >= o) ? sh[tid - o] : 0;
+        __syncthreads();
+        sh[tid] += t;
+        __syncthreads();
+    }
+    u64 r = sh[tid];
+    __syncthreads();
+    return r;
+}
+
+// ---- 0: repetition penalty (RepetitionContext.process), once per unique id; scratch reset
+__global__ void __launch_bounds__(64) k_samp_prepare(SamplerParams p) {
+    const int b = blockIdx.x, tid = threadIdx.x;
+    SamplerScratch* sc = p.scratch + b;
+    for (int i = tid; i < 256; i += 64) { sc->hist1[i] = 0; sc->hist2[i] = 0; }
+    if (row_skipped(p, b)) return;
     if (p.penalty > 0.0f && p.penalty != 1.0f && p.window) {
+        bf16_t* logits = p.logits + (size_t)b * p.Vpad;
         int wl = p.window_len[b];
         const int32_t* win = p.window + (size_t)b * p.ctx + (p.ctx - wl);
-        if (tid < wl) {
-            int id = win[tid];
-            bool first = (id >= 0 && id < V);
-            for (int j = 0; j < tid; ++j) first = first && (win[j] != id);
+        for (int t = tid; t < wl; t += 64) {
+            int id = win[t];
+            bool first = (id >= 0 && id < p.vocab);
+            for (int j = 0; j < t; ++j) first = first && (win[j] != id);
             if (first) {
                 float pen = bf16_round_f32(p.penalty);            // scalar weakly typed to bf16
                 float l = bf16_to_f32(logits[id]);
@@ -106,135 +109,217 @@ __global__ void __launch_bounds__(SAMP_NT) k_sampler(SamplerParams p) {
                 logits[id] = f32_to_bf16(v);
             }
         }
-        __syncthreads();
     }
+}
 
-    int token;
-    if (p.temperature == 0.0f) {
-        // ---- greedy: argmax, first index on ties
-        float best = -INFINITY;
-        int bi = 0x7fffffff;
-        for (int i = tid; i < V; i += SAMP_NT) {
-            if (i < lo || i >= hi) continue;
-            float l = bf16_to_f32(logits[i]);
-            if (l > best || (l == best && i < bi)) { best = l; bi = i; }
-        }
+// ---- 1: per-chunk max (and first index of the max, for greedy)
+__global__ void __launch_bounds__(SAMP_NT) k_samp_max(SamplerParams p) {
+    __shared__ float redf[SAMP_NT / 64];
+    __shared__ int redi[SAMP_NT / 64];
+    const int c = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
+    if (row_skipped(p, b)) return;
+    int lo, hi, i0, i1;
+    allowed_range(p, row_step(p, b), lo, hi);
+    chunk_range(p, c, i0, i1);
+    if (i0 < lo) i0 = lo;
+    if (i1 > hi) i1 = hi;
+    const bf16_t* logits = p.logits + (size_t)b * p.Vpad;
+    float best = -INFINITY;
+    int bi = 0x7fffffff;
+    for (int i = i0 + tid; i < i1; i += SAMP_NT) {
+        float l = bf16_to_f32(logits[i]);
+        if (l > best) { best = l; bi = i; }               // ascending i per thread: first index kept on ties
+    }
 #pragma unroll
-        for (int o = 32; o > 0; o >>= 1) {
-            float ob = __shfl_xor(best, o, 64);
-            int oi = __shfl_xor(bi, o, 64);
-            if (ob > best || (ob == best && oi < bi)) { best = ob; bi = oi; }
+    for (int o = 32; o > 0; o >>= 1) {
+        float ob = __shfl_xor(best, o, 64);
+        int oi = __shfl_xor(bi, o, 64);
+        if (ob > best || (ob == best && oi < bi)) { best = ob; bi = oi; }
+    }
+    if ((tid & 63) == 0) { redf[tid >> 6] = best; redi[tid >> 6] = bi; }
+    __syncthreads();
+    if (tid == 0) {
+        for (int w = 1; w < SAMP_NT / 64; ++w)
+            if (redf[w] > best || (redf[w] == best && redi[w] < bi)) { best = redf[w]; bi = redi[w]; }
+        p.scratch[b].pmax[c] = best;
+        p.scratch[b].pidx[c] = bi;
+    }
+}
+
+__device__ __forceinline__ float row_max(const SamplerParams& p, int b) {
+    float m = -INFINITY;
+    for (int c = 0; c < p.n_chunks; ++c) m = fmaxf(m, p.scratch[b].pmax[c]);
+    return m;
+}
+
+// ---- 2: e, E, level-1 histogram.  Every vocabulary entry is visited; masked ones get e = 0.
+__global__ void __launch_bounds__(SAMP_NT) k_samp_exp(SamplerParams p) {
+    __shared__ u64 hist[256];
+    const int c = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
+    if (row_skipped(p, b)) return;
+    int lo, hi, i0, i1;
+    allowed_range(p, row_step(p, b), lo, hi);
+    chunk_range(p, c, i0, i1);
+    hist[tid] = 0;
+    __syncthreads();
+    const bf16_t* logits = p.logits + (size_t)b * p.Vpad;
+    float* ebuf = p.e_buf + (size_t)b * p.Vpad;
+    const float xmax = __fdiv_rn(row_max(p, b), p.temperature);      // fdiv is monotone: max x = fdiv(max l, T)
+    for (int i = i0 + tid; i < i1; i += SAMP_NT) {
+        float x = __fdiv_rn(bf16_to_f32(logits[i]), p.temperature);
+        float y = fminf(x - xmax, 0.0f);
+        float e = det_exp_dev(y);
+        if (i < lo || i >= hi) e = 0.0f;
+        ebuf[i] = e;
+        u64 E = (u64)(e * E_SCALE);
+        if (E) atomicAdd(&hist[__float_as_uint(e) >> 24], E);
+    }
+    __syncthreads();
+    if (hist[tid]) atomicAdd(&p.scratch[b].hist1[tid], hist[tid]);
+}
+
+// ---- 3: locate the level-1 bin of the nucleus boundary; level-2 histogram inside it
+__global__ void __launch_bounds__(SAMP_NT) k_samp_hist2(SamplerParams p) {
+    __shared__ u64 sh[SAMP_NT];
+    __shared__ u64 hist[256];
+    __shared__ unsigned s_bin;
+    __shared__ u64 s_below;
+    const int c = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
+    if (row_skipped(p, b)) return;
+    SamplerScratch* sc = p.scratch + b;
+    u64 mine = sc->hist1[tid];
+    u64 incl = block_scan_incl_256(mine, sh);
+    sh[tid] = incl;
+    __syncthreads();
+    const u64 Z = sh[SAMP_NT - 1];
+    const u64 thr = (u64)((double)(1.0f - p.top_p) * (double)Z);
+    if (tid == 0) { s_bin = 255; s_below = 0; }
+    __syncthreads();
+    if (incl > thr && incl - mine <= thr) { s_bin = (unsigned)tid; s_below = incl - mine; }   // unique crossing
+    hist[tid] = 0;
+    __syncthreads();
+    const unsigned bin1 = s_bin;
+    if (c == 0 && tid == 0) { sc->bin1 = bin1; sc->below1 = s_below; sc->Z = Z; sc->thr = thr; }
+    int i0, i1;
+    chunk_range(p, c, i0, i1);
+    const float* ebuf = p.e_buf + (size_t)b * p.Vpad;
+    for (int i = i0 + tid; i < i1; i += SAMP_NT) {
+        float e = ebuf[i];
+        unsigned key = __float_as_uint(e) >> 16;
+        if ((key >> 8) == bin1) {
+            u64 E = (u64)(e * E_SCALE);
+            if (E) atomicAdd(&hist[key & 255], E);
         }
-        if ((tid & 63) == 0) { redf[tid >> 6] = best; redi[tid >> 6] = bi; }
+    }
+    __syncthreads();
+    if (hist[tid]) atomicAdd(&sc->hist2[tid], hist[tid]);
+}
+
+// ---- 4: k* from the level-2 bins; kept mass of every chunk
+__global__ void __launch_bounds__(SAMP_NT) k_samp_mass(SamplerParams p, int nucleus) {
+    __shared__ u64 sh[SAMP_NT];
+    __shared__ u64 red[SAMP_NT / 64];
+    __shared__ unsigned s_bin;
+    const int c = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
+    if (row_skipped(p, b)) return;
+    SamplerScratch* sc = p.scratch + b;
+    unsigned kstar = 0;
+    if (nucleus) {
+        u64 mine = sc->hist2[tid];
+        u64 incl = block_scan_incl_256(mine, sh) + sc->below1;
+        if (tid == 0) s_bin = 255;
         __syncthreads();
+        if (incl > sc->thr && incl - mine <= sc->thr) s_bin = (unsigned)tid;
+        __syncthreads();
+        kstar = (sc->bin1 << 8) | s_bin;
+        if (c == 0 && tid == 0) sc->kstar = kstar;
+    } else if (c == 0 && tid == 0) sc->kstar = 0;
+    int i0, i1;
+    chunk_range(p, c, i0, i1);
+    const float* ebuf = p.e_buf + (size_t)b * p.Vpad;
+    u64 m = 0;
+    for (int i = i0 + tid; i < i1; i += SAMP_NT) {
+        float e = ebuf[i];
+        if ((__float_as_uint(e) >> 16) >= kstar) m += (u64)(e * E_SCALE);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        unsigned lo32 = __shfl_xor((unsigned)m, o, 64), hi32 = __shfl_xor((unsigned)(m >> 32), o, 64);
+        m += ((u64)hi32 << 32) | lo32;
+    }
+    if ((tid & 63) == 0) red[tid >> 6] = m;
+    __syncthreads();
+    if (tid == 0) {
+        u64 t = 0;
+        for (int w = 0; w < SAMP_NT / 64; ++w) t += red[w];
+        sc->cmass[c] = t;
+    }
+}
+
+// ---- 5: draw + bookkeeping (generate loop, LlamaTTS.swift:721-738).  One block per row.
+__global__ void __launch_bounds__(SAMP_NT) k_samp_pick(SamplerParams p, int greedy) {
+    __shared__ u64 sh[SAMP_NT];
+    __shared__ int s_token;
+    const int b = blockIdx.x, tid = threadIdx.x;
+    if (row_skipped(p, b)) return;
+    SamplerScratch* sc = p.scratch + b;
+    const int step = row_step(p, b);
+    int lo, hi;
+    allowed_range(p, step, lo, hi);
+    if (tid == 0) s_token = lo < p.vocab ? lo : 0;
+    __syncthreads();
+    if (greedy) {
         if (tid == 0) {
-            float bb = redf[0];
-            int ii = redi[0];
-            for (int w = 1; w < SAMP_NT / 64; ++w)
-                if (redf[w] > bb || (redf[w] == bb && redi[w] < ii)) { bb = redf[w]; ii = redi[w]; }
-            s_token = (ii == 0x7fffffff) ? lo : ii;
+            float best = -INFINITY;
+            int bi = 0x7fffffff;
+            for (int c = 0; c < p.n_chunks; ++c)              // chunks ascend in index: first max wins ties
+                if (sc->pmax[c] > best) { best = sc->pmax[c]; bi = sc->pidx[c]; }
+            if (bi != 0x7fffffff) s_token = bi;
         }
-        __syncthreads();
-        token = s_token;
     } else {
-        // ---- pass A: max logit over the allowed range (fdiv is monotone: max x = fdiv(max l, T))
-        float lmax = -INFINITY;
-        for (int i = tid; i < V; i += SAMP_NT)
-            if (i >= lo && i < hi) lmax = fmaxf(lmax, bf16_to_f32(logits[i]));
-        lmax = block_max_f32(lmax, redf);
-        const float xmax = __fdiv_rn(lmax, p.temperature);
-        // ---- pass B: e_i, Z  (every vocabulary entry is visited; masked ones get e = 0)
-        u64 zloc = 0;
-        for (int i = tid; i < V; i += SAMP_NT) {
-            float e = 0.0f;
-            float x = __fdiv_rn(bf16_to_f32(logits[i]), p.temperature);
-            float y = fminf(x - xmax, 0.0f);
-            float ee = det_exp_dev(y);
-            if (i >= lo && i < hi) e = ee;
-            ebuf[i] = e;
-            zloc += (u64)(e * 1099511627776.0f);
-        }
-        const u64 Z = block_sum_u64(zloc, red64);
-        // ---- nucleus threshold: 5 radix passes (3 bits each) over key = bits(e) >> 16
-        unsigned kstar = 0;
-        if (p.top_p > 0.0f && p.top_p < 1.0f) {
-            const u64 thr = (u64)((double)(1.0f - p.top_p) * (double)Z);
-            if (tid == 0) { s_cum = 0; s_prefix = 0; }
-            __syncthreads();
-            for (int pass = 0; pass < 5; ++pass) {
-                const int shift = 12 - 3 * pass;
-                const unsigned prefix = s_prefix;
-#pragma unroll
-                for (int q = 0; q < 8; ++q) bins[q][tid] = 0;
-                for (int i = tid; i < V; i += SAMP_NT) {
-                    float e = ebuf[i];
-                    unsigned key = __float_as_uint(e) >> 16;
-                    if ((key >> (shift + 3)) == prefix) {
-                        u64 E = (u64)(e * 1099511627776.0f);
-                        bins[(key >> shift) & 7][tid] += E;
-                    }
-                }
-                __syncthreads();
-                for (int st = SAMP_NT / 2; st > 0; st >>= 1) {
-                    if (tid < st) {
-#pragma unroll
-                        for (int q = 0; q < 8; ++q) bins[q][tid] += bins[q][tid + st];
-                    }
-                    __syncthreads();
-                }
-                if (tid == 0) {
-                    u64 cum = s_cum;
-                    int chosen = 7;
-                    for (int q = 0; q < 8; ++q) {
-                        if (cum + bins[q][0] > thr) { chosen = q; break; }
-                        cum += bins[q][0];
-                    }
-                    s_cum = cum;
-                    s_prefix = (prefix << 3) | (unsigned)chosen;
-                }
-                __syncthreads();
-            }
-            kstar = s_prefix;
-        }
-        // ---- kept mass per lane (lane-major order), exclusive scan over lanes, inverse CDF
-        u64 mine = 0;
-        for (int i = tid; i < V; i += SAMP_NT) {
-            float e = ebuf[i];
-            if ((__float_as_uint(e) >> 16) >= kstar) mine += (u64)(e * 1099511627776.0f);
-        }
-        u64* scan = &bins[0][0];
-        scan[tid] = mine;
-        __syncthreads();
-        for (int o = 1; o < SAMP_NT; o <<= 1) {
-            u64 t = (tid >= o) ? scan[tid - o] : 0;
-            __syncthreads();
-            scan[tid] += t;
-            __syncthreads();
-        }
-        const u64 Zk = scan[SAMP_NT - 1];
-        const u64 incl = scan[tid], excl = incl - mine;
+        // chunk selection (serial over <= 64 chunks), then in-chunk inverse CDF in index order
+        u64 Zk = 0;
+        for (int c = 0; c < p.n_chunks; ++c) Zk += sc->cmass[c];
         const u64 row = (u64)(p.row_offset + b);
         u64 a = p.seed ^ (0xD1B54A32D192ED03ull * (row + 1));
-        u64 rnd = mis_splitmix64(mis_splitmix64(a) + (u64)step);
+        const u64 rnd = mis_splitmix64(mis_splitmix64(a) + (u64)step);
         const u64 r = __umul64hi(rnd, Zk);
-        if (tid == 0) s_token = lo;
-        __syncthreads();
-        if (mine > 0 && r >= excl && r < incl) {
-            u64 run = excl;
-            for (int i = tid; i < V; i += SAMP_NT) {
+        int cs = -1;
+        u64 base = 0;
+        for (int c = 0; c < p.n_chunks; ++c) {
+            u64 cm = sc->cmass[c];
+            if (r < base + cm) { cs = c; break; }
+            base += cm;
+        }
+        if (cs >= 0) {
+            const unsigned kstar = sc->kstar;
+            int i0, i1;
+            chunk_range(p, cs, i0, i1);
+            const int per = (i1 - i0 + SAMP_NT - 1) / SAMP_NT;      // contiguous sub-range per thread
+            const int j0 = i0 + tid * per, j1 = min(i1, j0 + per);
+            const float* ebuf = p.e_buf + (size_t)b * p.Vpad;
+            u64 mine = 0;
+            for (int i = j0; i < j1; ++i) {
                 float e = ebuf[i];
-                if ((__float_as_uint(e) >> 16) >= kstar) {
-                    run += (u64)(e * 1099511627776.0f);
-                    if (run > r) { s_token = i; break; }
+                if ((__float_as_uint(e) >> 16) >= kstar) mine += (u64)(e * E_SCALE);
+            }
+            u64 incl = block_scan_incl_256(mine, sh) + base;
+            u64 excl = incl - mine;
+            if (mine > 0 && r >= excl && r < incl) {
+                u64 run = excl;
+                for (int i = j0; i < j1; ++i) {
+                    float e = ebuf[i];
+                    if ((__float_as_uint(e) >> 16) >= kstar) {
+                        run += (u64)(e * E_SCALE);
+                        if (run > r) { s_token = i; break; }
+                    }
                 }
             }
         }
-        __syncthreads();
-        token = s_token;
     }
-
-    // ---- bookkeeping (generate loop, LlamaTTS.swift:721-738)
+    __syncthreads();
     if (tid == 0) {
+        const int token = s_token;
         if (p.tokens_out && step < p.tokens_stride) p.tokens_out[(size_t)b * p.tokens_stride + step] = token;
         if (p.n_gen && !p.step_override) p.n_gen[b] = step + 1;
         if (p.window && p.ctx > 0) {       // didSample: slide the ring (kept right-aligned)
@@ -261,6 +346,29 @@ __global__ void __launch_bounds__(SAMP_NT) k_sampler(SamplerParams p) {
     }
 }
 
+void sampler_plan(int vocab, int* n_chunks, int* chunk_w) {
+    int nc = (vocab + 4095) / 4096;
+    if (nc > SAMP_MAX_CHUNKS) nc = SAMP_MAX_CHUNKS;
+    if (nc < 1) nc = 1;
+    int cw = (vocab + nc - 1) / nc;
+    cw = (cw + 7) / 8 * 8;
+    *n_chunks = (vocab + cw - 1) / cw;
+    *chunk_w = cw;
+}
+
 void launch_sampler(const SamplerParams& p, int batch, hipStream_t s) {
-    hipLaunchKernelGGL(k_sampler, dim3(batch), dim3(SAMP_NT), 0, s, p);
+    MIS_REQUIRE(p.scratch && p.n_chunks >= 1 && p.n_chunks <= SAMP_MAX_CHUNKS && p.chunk_w > 0, MIS_ERR_GENERATION_FAILED,
+                "sampler scratch not configured");
+    dim3 g2(p.n_chunks, batch);
+    hipLaunchKernelGGL(k_samp_prepare, dim3(batch), dim3(64), 0, s, p);
+    hipLaunchKernelGGL(k_samp_max, g2, dim3(SAMP_NT), 0, s, p);
+    if (p.temperature == 0.0f) {
+        hipLaunchKernelGGL(k_samp_pick, dim3(batch), dim3(SAMP_NT), 0, s, p, 1);
+        return;
+    }
+    hipLaunchKernelGGL(k_samp_exp, g2, dim3(SAMP_NT), 0, s, p);
+    int nucleus = (p.top_p > 0.0f && p.top_p < 1.0f) ? 1 : 0;
+    if (nucleus) hipLaunchKernelGGL(k_samp_hist2, g2, dim3(SAMP_NT), 0, s, p);
+    hipLaunchKernelGGL(k_samp_mass, g2, dim3(SAMP_NT), 0, s, p, nucleus);
+    hipLaunchKernelGGL(k_samp_pick, dim3(batch), dim3(SAMP_NT), 0, s, p, 0);
 }

@@ -28,8 +28,7 @@ own sampler testable bit-for-bit we define a deterministic realisation of those 
   k*    = min{ k : sum_{key_j <= k} E_j > thr }
   K     = { i : key_i >= k*, E_i > 0 }         (topP outside (0,1): k* = 0)
   r     = mulhi64(rand64(seed,row,step), Z_K)  Z_K = sum_{i in K} E_i
-  token = first i in K, in LANE-MAJOR order (i mod 512, i div 512) - the order the 512-lane
-          kernel walks the vocabulary - whose running sum of E exceeds r   (inverse CDF, exact)
+  token = first i in K (index order) whose running sum of E exceeds r      (inverse CDF, exact)
   rand64(seed,row,step) = splitmix64(splitmix64(seed ^ 0xD1B54A32D192ED03*(row+1)) + step)
 `row` is the GLOBAL utterance index, so results do not depend on how a batch is sharded over GPUs.
 Optional frame constraint (bench / synthetic weights only): tokens outside [lo, hi) are masked.
@@ -41,7 +40,6 @@ import numpy as np
 from .synth import bf16_round, splitmix64
 
 F = np.float32
-LANES = 512          # threads of the sampling block (csrc/lm_sampler.hip SAMP_NT)
 _LOG2E = F(1.4426950408889634)
 # 2^f on [0,1): degree-6 polynomial (Horner, separate IEEE mul/add, no fma)
 _P = [F(1.0), F(0.6931471805599453), F(0.2402265069591007), F(0.05550410866482158),
@@ -120,9 +118,8 @@ def sample(logits: np.ndarray, temperature: float, top_p: float, seed: int, row:
     Ek = np.where(keep, E, np.uint64(0))
     Zk = int(Ek.sum(dtype=np.uint64))
     r = (rand64(seed, row, step) * Zk) >> 64
-    order = np.lexsort((np.arange(V) // LANES, np.arange(V) % LANES))   # lane-major walk
-    pref = np.cumsum(Ek[order], dtype=np.uint64)
-    tok = int(order[int(np.searchsorted(pref, np.uint64(r), side="right"))])
+    pref = np.cumsum(Ek, dtype=np.uint64)
+    tok = int(np.searchsorted(pref, np.uint64(r), side="right"))
     if return_debug:
         return tok, dict(Z=Z, Zk=Zk, r=r, k_star=k_star, n_keep=int(keep.sum()), keep=keep, e=e)
     return tok
