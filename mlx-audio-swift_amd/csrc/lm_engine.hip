@@ -41,6 +41,7 @@ struct mis_tts {
     // per-batch state
     int batch = 0, Mpad = 0, Smax = 0;
     int S_qkv = 1, S_o = 1, S_down = 1;
+    int r_part = 1;                                 // n-tiles per work item of the split-K GEMMs
     int ksb_part = 4, ksb_gu = 4, ksb_head = 1;     // waves per work item (in-block split-K), see k_gemm_skinny
     DevBuf<bf16_t> kcache, vtcache;
     DevBuf<float> rope_cos, rope_sin;
@@ -282,11 +283,13 @@ static int env_int(const char* name, int dflt) {
     const char* v = getenv(name);
     return (v && *v) ? atoi(v) : dflt;
 }
-// inter-block split-K factor: aim at ~target waves in flight, keep >= 4 k-tiles per wave
+// inter-block split-K factor: aim at ~800 blocks (3 resident blocks per CU, one wave of blocks; measured
+// optimum of the R/KSB/S sweep, profiles/r01_v2_gemm_sweep.json), keep >= 2 k-tiles per wave
 static int choose_split(int items, int KT, int ksb, const char* env) {
-    int target = env_int("MIS_GEMM_TARGET_WAVES", 3584);
-    int S = (target + items * ksb / 2) / std::max(items * ksb, 1);
-    S = std::min(S, std::max(1, KT / (4 * ksb)));
+    int target = env_int("MIS_GEMM_TARGET_BLOCKS", 800);
+    int blocks_per_item = ksb == 1 ? 4 : 1;          // ksb == 1 packs 4 items into a block
+    int S = (target * blocks_per_item + items / 2) / std::max(items, 1);
+    S = std::min(S, std::max(1, KT / (2 * ksb)));
     S = std::min(S, 16);
     S = std::max(S, 1);
     return env_int(env, S);
@@ -345,9 +348,10 @@ static void lm_reset(mis_tts* c, int batch, int max_context) {
     c->ksb_part = env_int("MIS_KSB_PART", 4) == 1 ? 1 : 4;
     c->ksb_gu = env_int("MIS_KSB_GU", 4) == 1 ? 1 : 4;
     c->ksb_head = env_int("MIS_KSB_HEAD", 1) == 4 ? 4 : 1;
-    c->S_qkv = choose_split(c->Nqkv / 16, d / 32, c->ksb_part, "MIS_S_QKV");
-    c->S_o = choose_split(d / 16, HD / 32, c->ksb_part, "MIS_S_O");
-    c->S_down = choose_split(d / 16, c->ff / 32, c->ksb_part, "MIS_S_DOWN");
+    c->r_part = env_int("MIS_R_PART", 2) == 1 ? 1 : 2;
+    c->S_qkv = choose_split(c->Nqkv / 16 / c->r_part, d / 32, c->ksb_part, "MIS_S_QKV");
+    c->S_o = choose_split(d / 16 / c->r_part, HD / 32, c->ksb_part, "MIS_S_O");
+    c->S_down = choose_split(d / 16 / c->r_part, c->ff / 32, c->ksb_part, "MIS_S_DOWN");
     size_t kv = (size_t)c->L * batch * c->Hkv * Smax * c->D;
     c->kcache.alloc(kv);
     c->vtcache.alloc(kv);
@@ -374,7 +378,7 @@ static void enqueue_layers(mis_tts* c) {
     launch_embed_rmsnorm(c->emb.p, c->ids.p, c->active.p, c->pos_cur.p, c->pos_next.p, c->norms.p, c->h.p, c->x.p, d,
                          c->V, eps, c->batch, Mpad, s);
     for (int li = 0; li < c->L; ++li) {
-        launch_gemm_skinny(EPI_PARTIAL, 1, c->ksb_part, c->wqkv.p + layer_qkv_elems(c) * li, c->x.p, c->qkv_part.p, c->Nqkv / 16,
+        launch_gemm_skinny(EPI_PARTIAL, c->r_part, c->ksb_part, c->wqkv.p + layer_qkv_elems(c) * li, c->x.p, c->qkv_part.p, c->Nqkv / 16,
                            d / 32, c->S_qkv, c->Nqkv, Mpad, s);
         AttnParams ap{};
         ap.qkv_part = c->qkv_part.p; ap.S = c->S_qkv; ap.Mpad = Mpad; ap.Nqkv = c->Nqkv;
@@ -385,13 +389,13 @@ static void enqueue_layers(mis_tts* c) {
         ap.out = c->attn_out.p; ap.H = c->H; ap.Hkv = c->Hkv; ap.D = c->D; ap.Smax = c->Smax;
         ap.scale = 1.0f / sqrtf((float)c->D);
         launch_attn_decode(ap, c->batch, s);
-        launch_gemm_skinny(EPI_PARTIAL, 1, c->ksb_part, c->wo.p + layer_o_elems(c) * li, c->attn_out.p, c->part.p, d / 16, HD / 32,
+        launch_gemm_skinny(EPI_PARTIAL, c->r_part, c->ksb_part, c->wo.p + layer_o_elems(c) * li, c->attn_out.p, c->part.p, d / 16, HD / 32,
                            c->S_o, d, Mpad, s);
         launch_reduce_residual_rmsnorm(c->part.p, c->S_o, Mpad, d, c->h.p, c->norms.p + (size_t)(2 * li + 1) * d,
                                        c->x.p, eps, s);
         launch_gemm_skinny(EPI_SILU_MUL, 2, c->ksb_gu, c->wgu.p + layer_gu_elems(c) * li, c->x.p, c->act.p, 2 * c->ff / 16, d / 32,
                            1, c->ff, Mpad, s);
-        launch_gemm_skinny(EPI_PARTIAL, 1, c->ksb_part, c->wdown.p + layer_down_elems(c) * li, c->act.p, c->part.p, d / 16,
+        launch_gemm_skinny(EPI_PARTIAL, c->r_part, c->ksb_part, c->wdown.p + layer_down_elems(c) * li, c->act.p, c->part.p, d / 16,
                            c->ff / 32, c->S_down, d, Mpad, s);
         const bf16_t* next_norm = c->norms.p + (size_t)(li + 1 < c->L ? 2 * (li + 1) : 2 * c->L) * d;
         launch_reduce_residual_rmsnorm(c->part.p, c->S_down, Mpad, d, c->h.p, next_norm, c->x.p, eps, s);
@@ -887,10 +891,10 @@ extern "C" mis_status mis_tts_time_gemm(mis_tts* c, int which, int batch, int it
     auto run = [&](int it) {
         size_t li = (size_t)(it % c->L);
         switch (which) {
-            case 0: launch_gemm_skinny(EPI_PARTIAL, 1, c->ksb_part, c->wqkv.p + layer_qkv_elems(c) * li, c->x.p, c->qkv_part.p, c->Nqkv / 16, d / 32, c->S_qkv, c->Nqkv, Mpad, s); break;
-            case 1: launch_gemm_skinny(EPI_PARTIAL, 1, c->ksb_part, c->wo.p + layer_o_elems(c) * li, c->attn_out.p, c->part.p, d / 16, HD / 32, c->S_o, d, Mpad, s); break;
+            case 0: launch_gemm_skinny(EPI_PARTIAL, c->r_part, c->ksb_part, c->wqkv.p + layer_qkv_elems(c) * li, c->x.p, c->qkv_part.p, c->Nqkv / 16, d / 32, c->S_qkv, c->Nqkv, Mpad, s); break;
+            case 1: launch_gemm_skinny(EPI_PARTIAL, c->r_part, c->ksb_part, c->wo.p + layer_o_elems(c) * li, c->attn_out.p, c->part.p, d / 16, HD / 32, c->S_o, d, Mpad, s); break;
             case 2: launch_gemm_skinny(EPI_SILU_MUL, 2, c->ksb_gu, c->wgu.p + layer_gu_elems(c) * li, c->x.p, c->act.p, 2 * c->ff / 16, d / 32, 1, c->ff, Mpad, s); break;
-            case 3: launch_gemm_skinny(EPI_PARTIAL, 1, c->ksb_part, c->wdown.p + layer_down_elems(c) * li, c->act.p, c->part.p, d / 16, c->ff / 32, c->S_down, d, Mpad, s); break;
+            case 3: launch_gemm_skinny(EPI_PARTIAL, c->r_part, c->ksb_part, c->wdown.p + layer_down_elems(c) * li, c->act.p, c->part.p, d / 16, c->ff / 32, c->S_down, d, Mpad, s); break;
             case 4: enqueue_lm_head(c); break;
             default: throw MisError(MIS_ERR_INVALID_INPUT, "unknown GEMM id");
         }

@@ -9,12 +9,20 @@
 // Data layout (all in HBM, resident for the whole generate call):
 //   weights   bf16, pre-packed at load into MFMA-A tiles  [N/16][K/32][64 lanes][8]  so that one wave
 //             instruction streams one contiguous 1 KiB tile (lane l = q*16+i holds W[16*nt+i][32*kt+8*q..+8])
-//   x / act   bf16 row-major [Mpad][K]  (Mpad = batch rounded up to 16; rows >= batch are don't-care)
-//   K cache   bf16 [B][Hkv][Smax][D]        V cache TRANSPOSED bf16 [B][Hkv][D][Smax]  (P.V B-operand wants
-//             8 consecutive keys per lane)
+//   x / attn_out / act   bf16, PACKED as MFMA-B fragments [K/32][MT][64 lanes][8]: lane l = q*16+j of tile
+//             (kt, mt) holds X[m = 16*mt + j][k = 32*kt + 8*q .. +8]  (MT = Mpad/16, Mpad = batch rounded up to 16);
+//             one fragment load = one contiguous 1 KiB read (row-major X costs 16 x 64 B segments per load:
+//             measured -25 % on the big GEMMs).  The residual stream h stays row-major [Mpad][d].
+//   K cache   bf16 tiled as QK^T A-fragments  [B][Hkv][Smax/32][2][D/32][64][8]
+//   V cache   bf16 tiled as P.V  B-fragments  [B][Hkv][Smax/32][D/16][64][8]   (8 consecutive keys per lane)
 //   split-K partial slabs f32 [S][Mpad][N]; reduced in the consumer's prologue (deterministic order)
 #include "common.h"
 #include "lm_kernels.h"
+
+// element (m, k) of a packed activation [K/32][MT][64][8]
+__device__ __forceinline__ size_t xpk_index(int m, int k, int MT) {
+    return ((((size_t)(k >> 5) * MT + (m >> 4)) * 64) + (((k & 31) >> 3) << 4) + (m & 15)) * 8 + (k & 7);
+}
 
 // ============================================================================ weight staging
 
@@ -138,7 +146,7 @@ __global__ void __launch_bounds__(256) k_embed_rmsnorm(const bf16_t* __restrict_
     for (int i = threadIdx.x; i < d; i += 256) {
         float f = bf16_to_f32(e[i]);
         float n = bf16_round_f32(f * inv);                       // T(x * rsqrt(mean+eps))
-        x[(size_t)m * d + i] = f32_to_bf16(bf16_to_f32(wnorm[i]) * n);   // T(w * n)
+        x[xpk_index(m, i, gridDim.x >> 4)] = f32_to_bf16(bf16_to_f32(wnorm[i]) * n);   // T(w * n), packed
     }
 }
 void launch_embed_rmsnorm(const bf16_t* emb, const int32_t* ids, const uint8_t* active, int* pos_cur, int* pos_next,
@@ -170,7 +178,10 @@ __global__ void __launch_bounds__(RR_THREADS) k_reduce_residual_rmsnorm(const fl
                                                                         bf16_t* __restrict__ x, float eps) {
     __shared__ float red[RR_THREADS / 64];
     const int m = blockIdx.x, tid = threadIdx.x;
+    const int MT = gridDim.x >> 4;
     float ss = 0.0f;
+    float keep[RR_MAXC];                 // h_new of this thread's columns (valid when N <= RR_THREADS*RR_MAXC)
+    float wv[RR_MAXC];
     for (int c0 = 0; c0 < N; c0 += RR_THREADS * RR_MAXC) {
         float acc[RR_MAXC], hv[RR_MAXC];
 #pragma unroll
@@ -178,6 +189,7 @@ __global__ void __launch_bounds__(RR_THREADS) k_reduce_residual_rmsnorm(const fl
             int i = c0 + tid + k * RR_THREADS;
             acc[k] = 0.0f;
             hv[k] = (i < N) ? bf16_to_f32(h[(size_t)m * N + i]) : 0.0f;
+            wv[k] = (i < N) ? bf16_to_f32(wnorm[i]) : 0.0f;
         }
         for (int s0 = 0; s0 < S; s0 += 4) {
             float v[4][RR_MAXC];
@@ -196,20 +208,29 @@ __global__ void __launch_bounds__(RR_THREADS) k_reduce_residual_rmsnorm(const fl
 #pragma unroll
         for (int k = 0; k < RR_MAXC; ++k) {
             int i = c0 + tid + k * RR_THREADS;
+            keep[k] = 0.0f;
             if (i < N) {
                 float o = bf16_round_f32(acc[k]);
                 float hn = bf16_round_f32(hv[k] + o);
                 h[(size_t)m * N + i] = f32_to_bf16(hn);
+                keep[k] = hn;
                 ss += hn * hn;
             }
         }
     }
     float tot = block_sum_1024(ss, red);
     float inv = 1.0f / sqrtf(tot / (float)N + eps);
-    for (int i = tid; i < N; i += RR_THREADS) {
-        float f = bf16_to_f32(h[(size_t)m * N + i]);          // written by this same thread above
-        float n = bf16_round_f32(f * inv);
-        x[(size_t)m * N + i] = f32_to_bf16(bf16_to_f32(wnorm[i]) * n);
+    if (N <= RR_THREADS * RR_MAXC) {          // single pass: everything still in registers
+#pragma unroll
+        for (int k = 0; k < RR_MAXC; ++k) {
+            int i = tid + k * RR_THREADS;
+            if (i < N) x[xpk_index(m, i, MT)] = f32_to_bf16(wv[k] * bf16_round_f32(keep[k] * inv));
+        }
+    } else {
+        for (int i = tid; i < N; i += RR_THREADS) {
+            float f = bf16_to_f32(h[(size_t)m * N + i]);          // written by this same thread above
+            x[xpk_index(m, i, MT)] = f32_to_bf16(bf16_to_f32(wnorm[i]) * bf16_round_f32(f * inv));
+        }
     }
 }
 void launch_reduce_residual_rmsnorm(const float* slabs, int S, int Mpad, int N, bf16_t* h, const bf16_t* wnorm,
@@ -281,7 +302,8 @@ __device__ __forceinline__ void gemm_epilogue(const f32x4_t (&acc)[R][MT], void*
                 float a = bf16_round_f32(g * sg);                          // T(g * sigmoid)
                 res[e] = f32_to_bf16(a * u);                               // T(silu * up)
             }
-            size_t off = ((size_t)mt * 16 + ml) * N_out + ntg * 16 + nl;
+            // act is the down-projection's X operand: packed fragment layout (k = feature index)
+            size_t off = xpk_index(mt * 16 + ml, ntg * 16 + nl, MT);
             uint2 v;
             v.x = (uint32_t)res[0] | ((uint32_t)res[1] << 16);
             v.y = (uint32_t)res[2] | ((uint32_t)res[3] << 16);
@@ -293,7 +315,7 @@ __device__ __forceinline__ void gemm_epilogue(const f32x4_t (&acc)[R][MT], void*
 template <int MT, int R, int EPI, int KSB>
 __global__ void __launch_bounds__(256) k_gemm_skinny(const bf16_t* __restrict__ Wp, const bf16_t* __restrict__ X,
                                                      void* __restrict__ out, int NT, int KT, int S, int n_items,
-                                                     int N_out, int Mpad) {
+                                                     int N_out, int Mpad, int dbg_xfixed) {
     static_assert(EPI != EPI_SILU_MUL || R == 2, "silu-mul epilogue pairs a gate tile with an up tile");
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int item = (KSB == 1) ? blockIdx.x * 4 + wave : blockIdx.x;
@@ -305,8 +327,6 @@ __global__ void __launch_bounds__(256) k_gemm_skinny(const bf16_t* __restrict__ 
         int a = kt0 + (int)(((long long)len * wave) / KSB), b = kt0 + (int)(((long long)len * (wave + 1)) / KSB);
         kt0 = a; kt1 = b;
     }
-    const int K = KT * 32;
-
     const bf16x8_t* wp[R];
 #pragma unroll
     for (int r = 0; r < R; ++r) {
@@ -314,10 +334,9 @@ __global__ void __launch_bounds__(256) k_gemm_skinny(const bf16_t* __restrict__ 
         if (tile >= NT) tile = NT - 1;                     // clamp (store is skipped in the epilogue)
         wp[r] = reinterpret_cast<const bf16x8_t*>(Wp) + (size_t)tile * KT * 64 + lane;
     }
-    const bf16x8_t* xp[MT];
+    const bf16x8_t* xp[MT];                                // packed fragments: tile (kt, mt) at (kt*MT + mt)*64 + lane
 #pragma unroll
-    for (int mt = 0; mt < MT; ++mt)
-        xp[mt] = reinterpret_cast<const bf16x8_t*>(X + (size_t)(mt * 16 + (lane & 15)) * K + (lane >> 4) * 8);
+    for (int mt = 0; mt < MT; ++mt) xp[mt] = reinterpret_cast<const bf16x8_t*>(X) + mt * 64 + lane;
 
     f32x4_t acc[R][MT];
 #pragma unroll
@@ -333,7 +352,8 @@ __global__ void __launch_bounds__(256) k_gemm_skinny(const bf16_t* __restrict__ 
         kk = kk > klast ? klast : kk;               /* tail: redundant reload, MFMA is skipped */  \
         _Pragma("unroll") for (int r = 0; r < R; ++r)                                              \
             WBUF[u][r] = __builtin_nontemporal_load(wp[r] + (size_t)kk * 64);                      \
-        _Pragma("unroll") for (int mt = 0; mt < MT; ++mt) XBUF[u][mt] = xp[mt][(size_t)kk * 4];    \
+        _Pragma("unroll") for (int mt = 0; mt < MT; ++mt)                                          \
+            XBUF[u][mt] = xp[mt][(size_t)(dbg_xfixed ? (kk & 1) : kk) * (MT * 64)];                \
     }
 #define GEMM_MATH(WBUF, XBUF, KBASE)                                                              \
     _Pragma("unroll") for (int u = 0; u < GEMM_U; ++u) {                                           \
@@ -394,15 +414,18 @@ template <int MT>
 static void launch_gemm_mt(int epi, int R, int ksb, const bf16_t* Wp, const bf16_t* X, void* out, int NT, int KT, int S,
                            int N_out, int Mpad, hipStream_t s) {
     int n_items = ((NT + R - 1) / R) * S;
+    static const int dbg = getenv("MIS_GEMM_DEBUG_XFIXED") ? atoi(getenv("MIS_GEMM_DEBUG_XFIXED")) : 0;
     dim3 grid(ksb == 1 ? (n_items + 3) / 4 : n_items), block(256);
 #define GEMM_CASE(E, RR, KS)                                                                                  \
     if (epi == E && R == RR && ksb == KS) {                                                                   \
         hipLaunchKernelGGL((k_gemm_skinny<MT, RR, E, KS>), grid, block, 0, s, Wp, X, out, NT, KT, S, n_items, \
-                           N_out, Mpad);                                                                      \
+                           N_out, Mpad, dbg);                                                                 \
         return;                                                                                               \
     }
     GEMM_CASE(EPI_PARTIAL, 1, 1)
     GEMM_CASE(EPI_PARTIAL, 1, 4)
+    GEMM_CASE(EPI_PARTIAL, 2, 1)
+    GEMM_CASE(EPI_PARTIAL, 2, 4)
     GEMM_CASE(EPI_BF16, 2, 1)
     GEMM_CASE(EPI_BF16, 2, 4)
     GEMM_CASE(EPI_SILU_MUL, 2, 1)
@@ -467,15 +490,24 @@ __global__ void __launch_bounds__(512) k_attn_decode(AttnParams p) {
     // ---- RoPE (rotate-half, pair (i, i + D/2), angle pos / freqs[i]; LlamaTTS.swift:192-200) + cache append
     bf16_t* kc = p.kcache + ((size_t)(b * p.Hkv + kvh) * p.Smax) * D;
     bf16_t* vt = p.vtcache + ((size_t)(b * p.Hkv + kvh) * D) * p.Smax;
+    // tiled cache addressing of the new key `pos` (see header): 32-key tile, A-fragment row i, half hf
+    const int ptile = pos >> 5, pr = pos & 31;
+    const int prow = ((pr >> 3) << 2) | (pr & 3), phalf = (pr >> 2) & 1;
     for (int idx = tid; idx < (G + 1) * (D / 2); idx += 512) {
         int hh = idx / (D / 2), i = idx - hh * (D / 2);
         float x1 = sraw[hh * D + i], x2 = sraw[hh * D + i + D / 2];
         float c = p.rope_cos[(size_t)pos * (D / 2) + i], s = p.rope_sin[(size_t)pos * (D / 2) + i];
         bf16_t r1 = f32_to_bf16(x1 * c - x2 * s), r2 = f32_to_bf16(x1 * s + x2 * c);
         if (hh < G) { qs[hh * D + i] = r1; qs[hh * D + i + D / 2] = r2; }
-        else { kc[(size_t)pos * D + i] = r1; kc[(size_t)pos * D + i + D / 2] = r2; }
+        else {
+            int d1 = i, d2 = i + D / 2;
+            kc[((((size_t)ptile * 2 + phalf) * (D / 32) + (d1 >> 5)) * 64 + (((d1 & 31) >> 3) << 4) + prow) * 8 + (d1 & 7)] = r1;
+            kc[((((size_t)ptile * 2 + phalf) * (D / 32) + (d2 >> 5)) * 64 + (((d2 & 31) >> 3) << 4) + prow) * 8 + (d2 & 7)] = r2;
+        }
     }
-    for (int d = tid; d < D; d += 512) vt[(size_t)d * p.Smax + pos] = f32_to_bf16(sraw[(G + 1) * D + d]);
+    for (int d = tid; d < D; d += 512)
+        vt[(((size_t)ptile * (D / 16) + (d >> 4)) * 64 + ((pr >> 3) << 4) + (d & 15)) * 8 + (pr & 7)] =
+            f32_to_bf16(sraw[(G + 1) * D + d]);
     __syncthreads();       // LDS q visible; K/V stores of this block visible to its own waves (same CU)
 
     // ---- main loop
@@ -488,16 +520,16 @@ __global__ void __launch_bounds__(512) k_attn_decode(AttnParams p) {
     for (int dt = 0; dt < D / 16; ++dt) O[dt] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
     float m_run = -INFINITY, l_run = 0.0f;
     const int n_tiles = (kv_len + 31) >> 5;
-    const int key0 = (h >> 2) * 8 + (h & 3);          // MFMA row i <-> key slot (see header comment)
+    // MFMA row i <-> key base + (i>>2)*8 + (i&3) (+4 for the second half): baked into the cache tiling
     for (int tile = wave; tile < n_tiles; tile += ATT_WAVES) {
         const int base = tile * 32;
         f32x4_t S0 = (f32x4_t){0.f, 0.f, 0.f, 0.f}, S1 = S0;
-        const bf16_t* k0p = kc + (size_t)(base + key0) * D + g4 * 8;
-        const bf16_t* k1p = k0p + 4 * D;
+        const bf16x8_t* k0p = reinterpret_cast<const bf16x8_t*>(kc) + ((size_t)tile * 2) * (D / 32) * 64 + lane;
+        const bf16x8_t* k1p = k0p + (D / 32) * 64;
 #pragma unroll
         for (int c = 0; c < D / 32; ++c) {
-            bf16x8_t a0 = *reinterpret_cast<const bf16x8_t*>(k0p + c * 32);
-            bf16x8_t a1 = *reinterpret_cast<const bf16x8_t*>(k1p + c * 32);
+            bf16x8_t a0 = k0p[c * 64];                  // one contiguous 1 KiB fragment per load
+            bf16x8_t a1 = k1p[c * 64];
             S0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0, qf[c], S0, 0, 0, 0);
             S1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, qf[c], S1, 0, 0, 0);
         }
@@ -531,10 +563,10 @@ __global__ void __launch_bounds__(512) k_attn_decode(AttnParams p) {
         float ar[4];
 #pragma unroll
         for (int r = 0; r < 4; ++r) ar[r] = __shfl(alpha, g4 * 4 + r, 64);     // alpha of head (g4*4 + r)
-        const bf16_t* vp = vt + (size_t)h * p.Smax + base + g4 * 8;
+        const bf16x8_t* vp = reinterpret_cast<const bf16x8_t*>(vt) + (size_t)tile * (D / 16) * 64 + lane;
 #pragma unroll
         for (int dt = 0; dt < D / 16; ++dt) {
-            bf16x8_t vb = *reinterpret_cast<const bf16x8_t*>(vp + (size_t)dt * 16 * p.Smax);
+            bf16x8_t vb = vp[dt * 64];
             f32x4_t o = O[dt];
 #pragma unroll
             for (int r = 0; r < 4; ++r) o[r] *= ar[r];
@@ -569,7 +601,7 @@ __global__ void __launch_bounds__(512) k_attn_decode(AttnParams p) {
             num += f * sO[((size_t)w * G + head) * D + d];
             den += f * sl[w * 16 + head];
         }
-        p.out[(size_t)b * p.H * D + (size_t)(kvh * G + head) * D + d] = f32_to_bf16(num / den);
+        p.out[xpk_index(b, (kvh * G + head) * D + d, p.Mpad >> 4)] = f32_to_bf16(num / den);   // packed o_proj operand
     }
 }
 

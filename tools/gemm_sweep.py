@@ -28,9 +28,10 @@ def run(env, which):
     print(env, out, flush=True)
 
 
-for ksb in (1, 4):
-    for S in (1, 2, 3, 4, 6, 8, 12, 16):
-        run({"MIS_KSB_PART": ksb, "MIS_S_QKV": S, "MIS_S_O": S, "MIS_S_DOWN": S}, [0, 1, 3])
+for R in (1, 2):
+    for ksb in (1, 4):
+        for S in (1, 2, 3, 4, 6, 8, 12):
+            run({"MIS_R_PART": R, "MIS_KSB_PART": ksb, "MIS_S_QKV": S, "MIS_S_O": S, "MIS_S_DOWN": S}, [0, 1, 3])
 for ksb in (1, 4):
     run({"MIS_KSB_GU": ksb}, [2])
     run({"MIS_KSB_HEAD": ksb}, [4])
