@@ -160,7 +160,7 @@ void launch_embed_rmsnorm(const bf16_t* emb, const int32_t* ids, const uint8_t* 
 // Each thread owns <= RR_MAXC columns; all S x RR_MAXC slab loads of a thread are independent, so one L2
 // round trip covers them (the v0 kernel chained 120 dependent loads: 34 us per call, 31 % of a step).
 #define RR_THREADS 1024
-#define RR_MAXC 4
+#define RR_MAXC 3
 __device__ __forceinline__ float block_sum_1024(float v, float* red) {
     v = wave_sum(v);
     int w = threadIdx.x >> 6;
@@ -191,17 +191,17 @@ __global__ void __launch_bounds__(RR_THREADS) k_reduce_residual_rmsnorm(const fl
             hv[k] = (i < N) ? bf16_to_f32(h[(size_t)m * N + i]) : 0.0f;
             wv[k] = (i < N) ? bf16_to_f32(wnorm[i]) : 0.0f;
         }
-        for (int s0 = 0; s0 < S; s0 += 4) {
-            float v[4][RR_MAXC];
+        for (int s0 = 0; s0 < S; s0 += 8) {     // 8 slabs x RR_MAXC columns: one round trip (slabs come from HBM/MALL:
+            float v[8][RR_MAXC];                // the producer's L2 lines were written back at the kernel boundary)
 #pragma unroll
-            for (int j = 0; j < 4; ++j)
+            for (int j = 0; j < 8; ++j)
 #pragma unroll
                 for (int k = 0; k < RR_MAXC; ++k) {
                     int i = c0 + tid + k * RR_THREADS;
                     v[j][k] = (s0 + j < S && i < N) ? slabs[((size_t)(s0 + j) * Mpad + m) * N + i] : 0.0f;
                 }
 #pragma unroll
-            for (int j = 0; j < 4; ++j)        // slab order s = 0,1,2,... (fixed => deterministic)
+            for (int j = 0; j < 8; ++j)        // slab order s = 0,1,2,... (fixed => deterministic)
 #pragma unroll
                 for (int k = 0; k < RR_MAXC; ++k) acc[k] += v[j][k];
         }
@@ -482,7 +482,14 @@ __global__ void __launch_bounds__(512) k_attn_decode(AttnParams p) {
         else if (hh == G) col = p.H * D + kvh * D + d;
         else col = p.H * D + p.Hkv * D + kvh * D + d;
         float acc = 0.0f;
-        for (int s = 0; s < p.S; ++s) acc += p.qkv_part[((size_t)s * p.Mpad + b) * p.Nqkv + col];
+        for (int s0 = 0; s0 < p.S; s0 += 8) {        // up to 8 independent loads in flight, summed in slab order
+            float v[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+                v[j] = (s0 + j < p.S) ? p.qkv_part[((size_t)(s0 + j) * p.Mpad + b) * p.Nqkv + col] : 0.0f;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc += v[j];
+        }
         sraw[idx] = bf16_round_f32(acc);
     }
     for (int idx = tid; idx < 16 * D; idx += 512) qs[idx] = 0;
@@ -520,18 +527,19 @@ __global__ void __launch_bounds__(512) k_attn_decode(AttnParams p) {
     for (int dt = 0; dt < D / 16; ++dt) O[dt] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
     float m_run = -INFINITY, l_run = 0.0f;
     const int n_tiles = (kv_len + 31) >> 5;
-    // MFMA row i <-> key base + (i>>2)*8 + (i&3) (+4 for the second half): baked into the cache tiling
-    for (int tile = wave; tile < n_tiles; tile += ATT_WAVES) {
+    // MFMA row i <-> key base + (i>>2)*8 + (i&3) (+4 for the second half): baked into the cache tiling.
+    // Each wave owns tiles (wave + 8j); they are processed in PAIRS with all K and V fragments of both tiles
+    // (32 KiB per wave) requested before the first MFMA, so a typical context (<= 512 keys) costs one memory
+    // round trip per wave instead of four dependent ones.
+    const bf16x8_t* kbase = reinterpret_cast<const bf16x8_t*>(kc) + lane;
+    const bf16x8_t* vbase = reinterpret_cast<const bf16x8_t*>(vt) + lane;
+    auto process = [&](int tile, const bf16x8_t (&ka)[2][D / 32], const bf16x8_t (&vb)[D / 16]) {
         const int base = tile * 32;
         f32x4_t S0 = (f32x4_t){0.f, 0.f, 0.f, 0.f}, S1 = S0;
-        const bf16x8_t* k0p = reinterpret_cast<const bf16x8_t*>(kc) + ((size_t)tile * 2) * (D / 32) * 64 + lane;
-        const bf16x8_t* k1p = k0p + (D / 32) * 64;
 #pragma unroll
         for (int c = 0; c < D / 32; ++c) {
-            bf16x8_t a0 = k0p[c * 64];                  // one contiguous 1 KiB fragment per load
-            bf16x8_t a1 = k1p[c * 64];
-            S0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0, qf[c], S0, 0, 0, 0);
-            S1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, qf[c], S1, 0, 0, 0);
+            S0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ka[0][c], qf[c], S0, 0, 0, 0);
+            S1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ka[1][c], qf[c], S1, 0, 0, 0);
         }
         // lane (head h, group g4) now holds scores of keys base + g4*8 + e, e = 0..7
         float sc[8];
@@ -563,17 +571,37 @@ __global__ void __launch_bounds__(512) k_attn_decode(AttnParams p) {
         float ar[4];
 #pragma unroll
         for (int r = 0; r < 4; ++r) ar[r] = __shfl(alpha, g4 * 4 + r, 64);     // alpha of head (g4*4 + r)
-        const bf16x8_t* vp = reinterpret_cast<const bf16x8_t*>(vt) + (size_t)tile * (D / 16) * 64 + lane;
 #pragma unroll
         for (int dt = 0; dt < D / 16; ++dt) {
-            bf16x8_t vb = vp[dt * 64];
             f32x4_t o = O[dt];
 #pragma unroll
             for (int r = 0; r < 4; ++r) o[r] *= ar[r];
-            o = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ph, vb, o, 0, 0, 0);
-            o = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pl, vb, o, 0, 0, 0);
+            o = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ph, vb[dt], o, 0, 0, 0);
+            o = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pl, vb[dt], o, 0, 0, 0);
             O[dt] = o;
         }
+    };
+    for (int tile = wave; tile < n_tiles; tile += 2 * ATT_WAVES) {
+        const int tile2 = tile + ATT_WAVES;
+        const bool has2 = tile2 < n_tiles;
+        const int t2 = has2 ? tile2 : tile;                    // clamp: redundant reload, result unused
+        bf16x8_t kA[2][D / 32], kB[2][D / 32], vA[D / 16], vB[D / 16];
+#pragma unroll
+        for (int c = 0; c < D / 32; ++c) {
+            kA[0][c] = kbase[((size_t)tile * 2) * (D / 32) * 64 + c * 64];
+            kA[1][c] = kbase[((size_t)tile * 2 + 1) * (D / 32) * 64 + c * 64];
+        }
+#pragma unroll
+        for (int c = 0; c < D / 32; ++c) {
+            kB[0][c] = kbase[((size_t)t2 * 2) * (D / 32) * 64 + c * 64];
+            kB[1][c] = kbase[((size_t)t2 * 2 + 1) * (D / 32) * 64 + c * 64];
+        }
+#pragma unroll
+        for (int dt = 0; dt < D / 16; ++dt) vA[dt] = vbase[((size_t)tile * (D / 16) + dt) * 64];
+#pragma unroll
+        for (int dt = 0; dt < D / 16; ++dt) vB[dt] = vbase[((size_t)t2 * (D / 16) + dt) * 64];
+        process(tile, kA, vA);
+        if (has2) process(tile2, kB, vB);
     }
     // ---- per-wave partials -> LDS
     l_run += __shfl_xor(l_run, 16, 64);
