@@ -183,9 +183,14 @@ def main():
             ms, by = lm.time_gemm(i, ROWS_PER_GPU, iters=56)
             gemms[n] = {"ms": ms, "GBps": by / ms / 1e6, "bytes": by}
         dom = gemms["gate_up"]
-        roofline = {"bound": "hbm", "kernel": "k_gemm_skinny<MT=2,R=2,silu_mul> (gate+up, 100.7 MB/launch)",
+        traffic = None      # HBM bytes per launch from the committed PMC pass (profiles/r01_pmc/traffic.json)
+        try:
+            traffic = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc", "traffic.json")))["gate_up"]["hbm_bytes_per_launch"]
+        except Exception:
+            pass
+        roofline = {"bound": "hbm", "kernel": "k_gemm_skinny<MT=2,R=2,silu_mul,KSB=4> (gate+up, 100.7 MB/launch)",
                     "achieved": dom["GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": dom["GBps"] / HBM_PEAK_GBS,
-                    "traffic": None,
+                    "traffic": traffic, "algorithmic_bytes": dom["bytes"],
                     "all_gemms_GBps": {k: round(v["GBps"], 1) for k, v in gemms.items()},
                     "step": {"ms": timing["step_ms_avg"], "algorithmic_GB": timing["hbm_bytes_per_step"] / 1e9,
                              "achieved_GBps": timing["hbm_bytes_per_step"] / max(timing["step_ms_avg"], 1e-9) / 1e6}}

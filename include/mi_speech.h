@@ -228,6 +228,10 @@ mis_status mis_tts_last_timing(mis_tts*, mis_tts_timing* out);
  * algorithmic bytes of one launch are returned.  Used by bench.py for the roofline object. */
 mis_status mis_tts_time_gemm(mis_tts*, int which, int batch, int iters, double* avg_ms, double* bytes);
 
+/* diagnostics: microseconds per dependent kernel boundary in a replayed hipGraph of n trivial kernels
+ * (mode 0: 1 block x 64 threads, 1: 32 x 1024, 2: 1024 x 256).  DESIGN.md quotes it as the launch floor. */
+mis_status mis_debug_launch_floor(int device, int n_kernels, int mode, int reps, double* us_per_kernel);
+
 #ifdef __cplusplus
 }
 #endif

@@ -87,6 +87,7 @@ SYMBOLS = {
     "mis_tts_set_profiling": (C.c_int, [_P, C.c_int]),
     "mis_tts_last_timing": (C.c_int, [_P, C.POINTER(TimingC)]),
     "mis_tts_time_gemm": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
+    "mis_debug_launch_floor": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_double)]),
 }
 
 _lib = None

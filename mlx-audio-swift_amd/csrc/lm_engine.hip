@@ -976,3 +976,48 @@ extern "C" mis_status mis_tts_load(const char* model_dir, mis_snac* codec, int d
         return MIS_ERR_GENERATION_FAILED;
     }
 }
+
+// ---------------------------------------------------------------------------- diagnostics
+// Cost of a dependent kernel boundary on this machine: a hipGraph of n trivial kernels (mode 0: one
+// 64-thread block doing one load + one store; mode 1: 32 blocks x 1024 threads, each thread one load +
+// one store; mode 2: 1024 blocks x 256 threads) replayed `reps` times.  Returns microseconds per kernel.
+__global__ void k_floor_probe(const float* __restrict__ a, float* __restrict__ b, int n) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) b[i] = a[i] + 1.0f;
+}
+extern "C" mis_status mis_debug_launch_floor(int device, int n_kernels, int mode, int reps, double* us_per_kernel) {
+    MIS_API_BEGIN
+    MIS_REQUIRE(us_per_kernel && n_kernels >= 1 && reps >= 1, MIS_ERR_INVALID_INPUT, "bad argument");
+    HIP_CHECK(hipSetDevice(device));
+    hipStream_t s;
+    HIP_CHECK(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+    DevBuf<float> a, b;
+    const int n = 1 << 18;
+    a.alloc(n); b.alloc(n);
+    HIP_CHECK(hipMemset(a.p, 0, n * 4));
+    dim3 grid(mode == 0 ? 1 : (mode == 1 ? 32 : 1024)), block(mode == 0 ? 64 : (mode == 1 ? 1024 : 256));
+    hipGraph_t g = nullptr;
+    hipGraphExec_t ge = nullptr;
+    HIP_CHECK(hipStreamBeginCapture(s, hipStreamCaptureModeGlobal));
+    for (int i = 0; i < n_kernels; ++i) {
+        const float* src = (i & 1) ? b.p : a.p;
+        float* dst = (i & 1) ? a.p : b.p;
+        hipLaunchKernelGGL(k_floor_probe, grid, block, 0, s, src, dst, n);
+    }
+    HIP_CHECK(hipStreamEndCapture(s, &g));
+    HIP_CHECK(hipGraphInstantiate(&ge, g, nullptr, nullptr, 0));
+    HIP_CHECK(hipGraphLaunch(ge, s));
+    HIP_CHECK(hipStreamSynchronize(s));
+    hipEvent_t e0, e1;
+    HIP_CHECK(hipEventCreate(&e0));
+    HIP_CHECK(hipEventCreate(&e1));
+    HIP_CHECK(hipEventRecord(e0, s));
+    for (int r = 0; r < reps; ++r) HIP_CHECK(hipGraphLaunch(ge, s));
+    HIP_CHECK(hipEventRecord(e1, s));
+    HIP_CHECK(hipStreamSynchronize(s));
+    *us_per_kernel = ms_between(e0, e1) * 1e3 / ((double)reps * n_kernels);
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    (void)hipGraphExecDestroy(ge); (void)hipGraphDestroy(g);
+    (void)hipStreamDestroy(s);
+    MIS_API_END
+}
