@@ -228,6 +228,28 @@ mis_status mis_tts_last_timing(mis_tts*, mis_tts_timing* out);
  * algorithmic bytes of one launch are returned.  Used by bench.py for the roofline object. */
 mis_status mis_tts_time_gemm(mis_tts*, int which, int batch, int iters, double* avg_ms, double* bytes);
 
+/* ------------------------------------------------------------------------------------------
+ * Log-mel / STFT front end.  Replaces WhisperAudio.logMelSpectrogram / encoderFeatures
+ * (Sources/MLXAudioSTT/Models/Whisper/WhisperAudio.swift:38-87) and computeMelSpectrogram
+ * (Sources/MLXAudioCore/DSP.swift:230-273): reflect pad, window, rfft, |.|^2, mel filterbank
+ * (melFilters DSP.swift:76-168), log10, clamp to (max - 8), (x + 4) / 4.
+ * ---------------------------------------------------------------------------------------- */
+typedef struct {
+    int32_t sample_rate, n_fft /* even, <= 512 */, hop_length, n_mels /* <= 256 */;
+    int32_t window;           /* 0 periodic Hann (WhisperAudio.swift:42-43), 1 symmetric Hann (DSP.swift:15-22) */
+    int32_t mel_scale;        /* 0 HTK (DSP default), 1 Slaney (Whisper) */
+    int32_t slaney_norm;      /* 1 = area normalisation (DSP.swift:155-162) */
+    int32_t drop_last_frame;  /* 1 = Whisper (WhisperAudio.swift:65-67) */
+} mis_mel_config;
+int64_t    mis_mel_num_frames(const mis_mel_config*, int64_t n_samples);
+/* pcm f32 [batch, n_samples] -> out f32 [batch, n_frames, n_mels]; every row is normalised by its own max */
+mis_status mis_mel_spectrogram(int device, const mis_mel_config*, const float* pcm, int batch, int64_t n_samples,
+                               float* out, int64_t* n_frames_out);
+/* WhisperAudio.encoderFeatures: rows of `stride` samples with lens[b] valid (NULL = stride) are zero-padded /
+ * trimmed to 480000 samples; out f32 [batch, 3000, n_mels], n_mels in {80, 128}. */
+mis_status mis_whisper_encoder_features(int device, const float* pcm, const int64_t* lens, int batch, int64_t stride,
+                                        int n_mels, float* out);
+
 /* diagnostics: microseconds per dependent kernel boundary in a replayed hipGraph of n trivial kernels
  * (mode 0: 1 block x 64 threads, 1: 32 x 1024, 2: 1024 x 256).  DESIGN.md quotes it as the launch floor. */
 mis_status mis_debug_launch_floor(int device, int n_kernels, int mode, int reps, double* us_per_kernel);

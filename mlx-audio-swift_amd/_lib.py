@@ -42,6 +42,11 @@ class GenInfoC(C.Structure):
                 ("peak_memory_gb", C.c_double)]
 
 
+class MelConfigC(C.Structure):
+    _fields_ = [("sample_rate", C.c_int32), ("n_fft", C.c_int32), ("hop_length", C.c_int32), ("n_mels", C.c_int32),
+                ("window", C.c_int32), ("mel_scale", C.c_int32), ("slaney_norm", C.c_int32), ("drop_last_frame", C.c_int32)]
+
+
 class TimingC(C.Structure):
     _fields_ = [("prefill_ms", C.c_double), ("decode_ms", C.c_double), ("codec_ms", C.c_double),
                 ("step_ms_avg", C.c_double), ("steps", C.c_int32), ("gemm_probe_ms", C.c_double),
@@ -87,6 +92,9 @@ SYMBOLS = {
     "mis_tts_set_profiling": (C.c_int, [_P, C.c_int]),
     "mis_tts_last_timing": (C.c_int, [_P, C.POINTER(TimingC)]),
     "mis_tts_time_gemm": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
+    "mis_mel_num_frames": (C.c_int64, [C.POINTER(MelConfigC), C.c_int64]),
+    "mis_mel_spectrogram": (C.c_int, [C.c_int, C.POINTER(MelConfigC), _P, C.c_int, C.c_int64, _P, C.POINTER(C.c_int64)]),
+    "mis_whisper_encoder_features": (C.c_int, [C.c_int, _P, _P, C.c_int, C.c_int64, C.c_int, _P]),
     "mis_debug_launch_floor": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_double)]),
 }
 

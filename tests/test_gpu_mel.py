@@ -1,0 +1,80 @@
+"""-m gpu: log-mel front end (HIP) vs the oracle.  Tolerance: max-abs 1e-4 in the normalised log domain
+ - relaxed to 2e-3 on the few bins whose power sits at the 1e-10 floor of a
+near-silent frame, where log10 amplifies f32 round-off of a cancelling DFT sum."""
+import numpy as np
+import pytest
+
+import mlx_audio_swift_amd as mas
+from oracle import mel as omel
+
+pytestmark = pytest.mark.gpu
+
+
+def _speechlike(n, seed=0):
+    rng = np.random.default_rng(seed)
+    t = np.arange(n) / 16000.0
+    x = 0.3 * np.sin(2 * np.pi * 220 * t) * (1 + 0.5 * np.sin(2 * np.pi * 3 * t)) + 0.05 * rng.standard_normal(n)
+    x[: n // 7] *= 0.01
+    return x.astype(np.float32)
+
+
+def _close(got, ref):
+    d = np.abs(got - ref)
+    assert d.max() < 2e-3, d.max()
+    assert np.mean(d > 1e-4) < 1e-3, np.mean(d > 1e-4)
+    assert float(np.sqrt(np.mean(d.astype(np.float64) ** 2))) < 2e-5
+
+
+@pytest.mark.parametrize("n_mels", [80, 128])
+def test_whisper_encoder_features_match_oracle(n_mels):
+    rows = [_speechlike(16000 * 7, 1), _speechlike(16000 * 3, 2), _speechlike(1000, 3)]
+    stride = max(len(r) for r in rows)
+    batch = np.zeros((3, stride), np.float32)
+    for i, r in enumerate(rows):
+        batch[i, : len(r)] = r
+    got = mas.dsp.whisper_encoder_features(batch, n_mels, lens=[len(r) for r in rows])
+    assert got.shape == (3, 3000, n_mels)
+    for i, r in enumerate(rows):
+        _close(got[i], omel.encoder_features(r, n_mels)[0])
+
+
+def test_reference_known_answers_on_device():
+    # Tests/MLXAudioSTTTests.swift:4416-4422: zeros(5 s), 80 mels -> [1,3000,80], all (log10(1e-10)+4)/4
+    f = mas.dsp.whisper_encoder_features(np.zeros(16000 * 5, np.float32), 80)
+    assert f.shape == (1, 3000, 80) and np.abs(f + 1.5).max() < 1e-6
+
+
+def test_long_input_is_trimmed_and_short_unpadded_variant():
+    x = _speechlike(16000 * 31, 4)
+    got = mas.dsp.whisper_encoder_features(x, 80)
+    _close(got[0], omel.encoder_features(x, 80)[0])
+    y = _speechlike(16000 * 2 + 37, 5)
+    _close(mas.dsp.log_mel_spectrogram(y, 80), omel.log_mel_spectrogram(y, 80))
+    assert mas.dsp.log_mel_spectrogram(np.zeros(0, np.float32), 80).shape == (80, 0)
+    z = _speechlike(330, 8)[:170] * 3             # shorter than the reflect pad (200): zero-filled edges (:89-112)
+    ref = omel.log_mel_spectrogram(z, 80)
+    assert ref.shape == (80, 1)
+    _close(mas.dsp.log_mel_spectrogram(z, 80), ref)
+    assert mas.dsp.log_mel_spectrogram(np.float32([0.5, -0.25, 0.125]), 80).shape == (80, 0)
+
+
+def test_generic_dsp_path():
+    x = _speechlike(16000, 6)
+    got = mas.dsp.compute_mel_spectrogram(x, 16000, 400, 160, 64)
+    ref = omel.compute_mel_spectrogram(x, 16000, 400, 160, 64)
+    assert got.shape == ref.shape == (101, 64)
+    _close(got, ref)
+    got2 = mas.dsp.compute_mel_spectrogram(np.stack([x, x[::-1].copy()]), 16000, 256, 64, 40)
+    ref2 = omel.compute_mel_spectrogram(x[::-1].copy(), 16000, 256, 64, 40)
+    _close(got2[1], ref2)
+
+
+def test_batch64_at_bench_size_properties():
+    # BASELINE config 4 front end: 64 x 30 s.  Rows independent, bounded, deterministic.
+    rng = np.random.default_rng(7)
+    x = (rng.standard_normal((64, 480000)) * 0.1).astype(np.float32)
+    f = mas.dsp.whisper_encoder_features(x, 128)
+    assert f.shape == (64, 3000, 128) and np.isfinite(f).all()
+    assert np.all(f.reshape(64, -1).max(1) - f.reshape(64, -1).min(1) <= 2.0 + 1e-5)
+    one = mas.dsp.whisper_encoder_features(x[17], 128)
+    assert np.array_equal(one[0], f[17])
