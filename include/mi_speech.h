@@ -250,6 +250,52 @@ mis_status mis_mel_spectrogram(int device, const mis_mel_config*, const float* p
 mis_status mis_whisper_encoder_features(int device, const float* pcm, const int64_t* lens, int batch, int64_t stride,
                                         int n_mels, float* out);
 
+/* ------------------------------------------------------------------------------------------
+ * Whisper STT.  Replaces WhisperModel / WhisperEncoder / WhisperDecoder
+ * (Sources/MLXAudioSTT/Models/Whisper/WhisperModel.swift:36-309, WhisperLayers.swift:110-328).
+ * bf16 compute (fp16 checkpoints are converted at load).  Tokenisation / prompt construction /
+ * text decoding stay on the host (WhisperTokenizer.swift), as in the reference.
+ * ---------------------------------------------------------------------------------------- */
+typedef struct mis_whisper mis_whisper;
+/* WhisperConfig, WhisperConfig.swift:3-22 */
+typedef struct {
+    int32_t vocab_size, num_mel_bins, d_model;
+    int32_t encoder_layers, encoder_attention_heads, encoder_ffn_dim, max_source_positions;
+    int32_t decoder_layers, decoder_attention_heads, decoder_ffn_dim, max_target_positions;
+} mis_whisper_config;
+/* generation knobs of transcribeChunk (WhisperModel.swift:213-236) + WhisperGenerationConfig suppress lists */
+typedef struct {
+    int32_t max_tokens;            /* STTGenerateParameters.maxTokens */
+    float   temperature;           /* <= 0: greedy argmax (:284-287) */
+    uint64_t seed;
+    int32_t eot_id;                /* tokenizer.endOfTextId: ends a row, not emitted */
+    int32_t timestamp_begin;       /* suppressFromIndex(:300-309): ids >= this are never sampled (0 = off) */
+    const int32_t* suppress;       /* suppress_tokens, every step */
+    int32_t n_suppress;
+    const int32_t* begin_suppress; /* begin_suppress_tokens, first step only (default [eot]) */
+    int32_t n_begin_suppress;
+} mis_stt_params;
+mis_status mis_whisper_create(const mis_whisper_config*, int device, mis_whisper** out);
+/* HF transformers key layout (model.encoder.* / model.decoder.*; conv weights [out, in, k]; proj_out ignored: tied) */
+mis_status mis_whisper_set_tensor(mis_whisper*, const char* name, const void* data, mis_dtype dtype,
+                                  const int64_t* shape, int ndim);
+mis_status mis_whisper_init_synthetic(mis_whisper*, uint64_t seed);
+mis_status mis_whisper_finalize(mis_whisper*);
+void       mis_whisper_destroy(mis_whisper*);
+/* WhisperEncoder (+ the cross-attention K/V of every decoder layer): features f32 [batch, 3000, n_mels];
+ * enc_out f32 [batch, 1500, d_model] or NULL.  Resets the decoder state. */
+mis_status mis_whisper_encode(mis_whisper*, const float* features, int batch, float* enc_out);
+mis_status mis_whisper_decoder_reset(mis_whisper*);
+/* one decoder token per active row through the KV caches (WhisperDecoder.callAsFunction with Tnew = 1);
+ * logits_out f32 [batch, vocab] (tied projection) or NULL */
+mis_status mis_whisper_decoder_forward(mis_whisper*, const int32_t* tokens, const uint8_t* active, float* logits_out);
+/* transcribeChunk for a batch of <= 30 s windows: pcm f32 [batch, stride] (lens[b] valid samples, NULL = stride),
+ * prompt_ids = buildPromptTokens(...) shared by all rows.  *tokens_out (mis_free) int32 [batch, *tokens_stride],
+ * n_tokens[batch] generated ids per row (EOT excluded). */
+mis_status mis_stt_whisper_generate(mis_whisper*, const float* pcm, const int64_t* lens, int batch, int64_t stride,
+                                    const int32_t* prompt_ids, int n_prompt, const mis_stt_params*,
+                                    int32_t** tokens_out, int64_t* tokens_stride, int32_t* n_tokens);
+
 /* diagnostics: microseconds per dependent kernel boundary in a replayed hipGraph of n trivial kernels
  * (mode 0: 1 block x 64 threads, 1: 32 x 1024, 2: 1024 x 256).  DESIGN.md quotes it as the launch floor. */
 mis_status mis_debug_launch_floor(int device, int n_kernels, int mode, int reps, double* us_per_kernel);

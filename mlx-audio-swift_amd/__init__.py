@@ -8,6 +8,7 @@ the Swift shim a maintainer would add):
 
     codecs.SNAC            <-> class SNAC : AudioCodecModel       (MLXAudioCodecs/SNAC/SNACDecoder.swift)
     tts.LlamaTTSModel      <-> class LlamaTTSModel : SpeechGenerationModel  (MLXAudioTTS/Models/Llama/LlamaTTS.swift)
+    stt.WhisperModel       <-> class WhisperModel : STTGenerationModel   (MLXAudioSTT/Models/Whisper/WhisperModel.swift)
     dsp.*                  <-> computeMelSpectrogram (MLXAudioCore/DSP.swift) / WhisperAudio.encoderFeatures
     generation.*           <-> AudioGeneration / AudioGenerationInfo / AudioGenerationError /
                                GenerateParameters                (MLXAudioCore/Generation/GenerationTypes.swift)
@@ -22,6 +23,7 @@ from .codecs import SNAC, SNACConfig  # noqa: F401
 from .tts import LlamaTTSModel, LlamaTTSConfiguration, OrpheusTokens  # noqa: F401
 from .orpheus import deinterleave, parse_output  # noqa: F401
 from . import dsp  # noqa: F401
+from .stt import WhisperModel, WhisperConfig, STTGenerateParameters, STTOutput  # noqa: F401
 
 __all__ = ["SNAC", "SNACConfig", "LlamaTTSModel", "LlamaTTSConfiguration", "OrpheusTokens", "GenerateParameters",
            "AudioGenerationError", "AudioGenerationInfo", "TokenEvent", "InfoEvent", "AudioEvent", "deinterleave",

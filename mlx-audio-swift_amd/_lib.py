@@ -47,6 +47,19 @@ class MelConfigC(C.Structure):
                 ("window", C.c_int32), ("mel_scale", C.c_int32), ("slaney_norm", C.c_int32), ("drop_last_frame", C.c_int32)]
 
 
+class WhisperConfigC(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ("vocab_size", "num_mel_bins", "d_model", "encoder_layers",
+                                         "encoder_attention_heads", "encoder_ffn_dim", "max_source_positions",
+                                         "decoder_layers", "decoder_attention_heads", "decoder_ffn_dim",
+                                         "max_target_positions")]
+
+
+class SttParamsC(C.Structure):
+    _fields_ = [("max_tokens", C.c_int32), ("temperature", C.c_float), ("seed", C.c_uint64), ("eot_id", C.c_int32),
+                ("timestamp_begin", C.c_int32), ("suppress", C.c_void_p), ("n_suppress", C.c_int32),
+                ("begin_suppress", C.c_void_p), ("n_begin_suppress", C.c_int32)]
+
+
 class TimingC(C.Structure):
     _fields_ = [("prefill_ms", C.c_double), ("decode_ms", C.c_double), ("codec_ms", C.c_double),
                 ("step_ms_avg", C.c_double), ("steps", C.c_int32), ("gemm_probe_ms", C.c_double),
@@ -95,6 +108,16 @@ SYMBOLS = {
     "mis_mel_num_frames": (C.c_int64, [C.POINTER(MelConfigC), C.c_int64]),
     "mis_mel_spectrogram": (C.c_int, [C.c_int, C.POINTER(MelConfigC), _P, C.c_int, C.c_int64, _P, C.POINTER(C.c_int64)]),
     "mis_whisper_encoder_features": (C.c_int, [C.c_int, _P, _P, C.c_int, C.c_int64, C.c_int, _P]),
+    "mis_whisper_create": (C.c_int, [C.POINTER(WhisperConfigC), C.c_int, C.POINTER(_P)]),
+    "mis_whisper_set_tensor": (C.c_int, [_P, C.c_char_p, _P, C.c_int, C.POINTER(C.c_int64), C.c_int]),
+    "mis_whisper_init_synthetic": (C.c_int, [_P, C.c_uint64]),
+    "mis_whisper_finalize": (C.c_int, [_P]),
+    "mis_whisper_destroy": (None, [_P]),
+    "mis_whisper_encode": (C.c_int, [_P, _P, C.c_int, _P]),
+    "mis_whisper_decoder_reset": (C.c_int, [_P]),
+    "mis_whisper_decoder_forward": (C.c_int, [_P, _P, _P, _P]),
+    "mis_stt_whisper_generate": (C.c_int, [_P, _P, _P, C.c_int, C.c_int64, _P, C.c_int, C.POINTER(SttParamsC),
+                                           C.POINTER(_P), C.POINTER(C.c_int64), _P]),
     "mis_debug_launch_floor": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_double)]),
 }
 

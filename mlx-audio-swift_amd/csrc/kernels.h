@@ -20,3 +20,6 @@ void snac_decode_device(mis_snac* c, const int32_t* const* codes_dev, int batch,
 hipStream_t snac_stream(mis_snac* c);
 int snac_device(const mis_snac* c);
 const mis_snac_config* snac_config(const mis_snac* c);
+
+// mel.hip
+void whisper_features_device(int device, const float* pcm_dev, int batch, int n_mels, float* out_dev, hipStream_t s);

@@ -2,7 +2,7 @@
 #pragma once
 #include "common.h"
 
-enum { EPI_PARTIAL = 0, EPI_BF16 = 1, EPI_SILU_MUL = 2 };
+enum { EPI_PARTIAL = 0, EPI_BF16 = 1, EPI_SILU_MUL = 2, EPI_GELU_PACKED = 3 };
 
 void launch_convert_to_bf16(const void* src, int dtype, bf16_t* dst, size_t n, hipStream_t s);
 void launch_pack_weight(const bf16_t* src, bf16_t* dst, int N, int K, int NT, int tile_stride, int tile_offset,
@@ -14,12 +14,15 @@ void launch_prefill_feed(const int32_t* prompt, const int32_t* lens, int Lmax, i
 void launch_embed_rmsnorm(const bf16_t* emb, const int32_t* ids, const uint8_t* active, int* pos_cur, int* pos_next,
                           const bf16_t* wnorm, bf16_t* h, bf16_t* x, int d, int vocab, float eps, int batch, int Mpad,
                           hipStream_t s);
+// ln_bias == nullptr: RMSNorm; otherwise LayerNorm(weight wnorm, bias ln_bias)
 void launch_reduce_residual_rmsnorm(const float* slabs, int S, int Mpad, int N, bf16_t* h, const bf16_t* wnorm,
-                                    bf16_t* x, float eps, hipStream_t s);
+                                    bf16_t* x, float eps, hipStream_t s, const bf16_t* ln_bias = nullptr);
 // Wp packed [NT][KT][64][8]; X bf16 [Mpad][KT*32]; out: f32 slabs [S][Mpad][N_out] (EPI_PARTIAL) or bf16 [Mpad][N_out]
 // ksb = 1: each wave an independent item; ksb = 4: the block's 4 waves split the item's K range (LDS combine)
+// bias (bf16 [N], optional): added once (slab 0 / final epilogue).  EPI_GELU_PACKED: T(gelu(T(xW+b))) written
+// in the packed fragment layout (it is the next GEMM's X operand).
 void launch_gemm_skinny(int epi, int R, int ksb, const bf16_t* Wp, const bf16_t* X, void* out, int NT, int KT, int S,
-                        int N_out, int Mpad, hipStream_t s);
+                        int N_out, int Mpad, hipStream_t s, const bf16_t* bias = nullptr);
 
 struct AttnParams {
     const float* qkv_part;   // [S][Mpad][Nqkv]
@@ -28,8 +31,10 @@ struct AttnParams {
     bf16_t* vtcache;         // layer slice [B][Hkv][D][Smax]
     const int* pos;          // [Mpad] position of the token being processed
     const uint8_t* active;   // [Mpad]
-    const float* rope_cos;   // [Smax][D/2]
+    const float* rope_cos;   // [Smax][D/2]; null = no rotary (Whisper)
     const float* rope_sin;
+    int cross;               // 1: cross attention - queries only, no append, keys 0..cross_len-1 of the given caches
+    int cross_len;
     bf16_t* out;             // [Mpad][H*D]
     int H, Hkv, D, Smax;
     float scale;

@@ -58,7 +58,8 @@ __global__ void k_pack_weight(const bf16_t* __restrict__ src, bf16_t* __restrict
 __global__ void k_synth_fill_bf16(bf16_t* __restrict__ dst, size_t n, uint64_t key, float amp, int plus_one) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    float v = bf16_round_f32(mis_synth_value(key, i, amp));
+    float v = mis_synth_value(key, i, amp);
+    if (plus_one != 2) v = bf16_round_f32(v);        // plus_one: 1 = bf16(1 + bf16(x)), 2 = bf16(1 + x)
     if (plus_one) v = 1.0f + v;
     dst[i] = f32_to_bf16(v);
 }
@@ -175,7 +176,10 @@ __device__ __forceinline__ float block_sum_1024(float v, float* red) {
 __global__ void __launch_bounds__(RR_THREADS) k_reduce_residual_rmsnorm(const float* __restrict__ slabs, int S,
                                                                         int Mpad, int N, bf16_t* __restrict__ h,
                                                                         const bf16_t* __restrict__ wnorm,
-                                                                        bf16_t* __restrict__ x, float eps) {
+                                                                        bf16_t* __restrict__ x, float eps,
+                                                                        const bf16_t* __restrict__ ln_bias) {
+    // ln_bias == nullptr: RMSNorm (Llama).  Otherwise LayerNorm with weight wnorm and bias ln_bias (Whisper,
+    // WhisperLayers.swift:90-107): f32 statistics, one rounding at the output.
     __shared__ float red[RR_THREADS / 64];
     const int m = blockIdx.x, tid = threadIdx.x;
     const int MT = gridDim.x >> 4;
@@ -218,6 +222,32 @@ __global__ void __launch_bounds__(RR_THREADS) k_reduce_residual_rmsnorm(const fl
             }
         }
     }
+    if (ln_bias) {
+        float sum = 0.0f;
+        if (N <= RR_THREADS * RR_MAXC) {
+#pragma unroll
+            for (int k = 0; k < RR_MAXC; ++k) sum += keep[k];
+        } else {
+            for (int i = tid; i < N; i += RR_THREADS) sum += bf16_to_f32(h[(size_t)m * N + i]);
+        }
+        const float mean = block_sum_1024(sum, red) / (float)N;
+        float sq = 0.0f;
+        if (N <= RR_THREADS * RR_MAXC) {
+#pragma unroll
+            for (int k = 0; k < RR_MAXC; ++k) {
+                int i = tid + k * RR_THREADS;
+                if (i < N) { float dlt = keep[k] - mean; sq += dlt * dlt; }
+            }
+        } else {
+            for (int i = tid; i < N; i += RR_THREADS) { float dlt = bf16_to_f32(h[(size_t)m * N + i]) - mean; sq += dlt * dlt; }
+        }
+        const float rstd = 1.0f / sqrtf(block_sum_1024(sq, red) / (float)N + eps);
+        for (int i = tid; i < N; i += RR_THREADS) {
+            float f = bf16_to_f32(h[(size_t)m * N + i]);
+            x[xpk_index(m, i, MT)] = f32_to_bf16((f - mean) * rstd * bf16_to_f32(wnorm[i]) + bf16_to_f32(ln_bias[i]));
+        }
+        return;
+    }
     float tot = block_sum_1024(ss, red);
     float inv = 1.0f / sqrtf(tot / (float)N + eps);
     if (N <= RR_THREADS * RR_MAXC) {          // single pass: everything still in registers
@@ -234,8 +264,9 @@ __global__ void __launch_bounds__(RR_THREADS) k_reduce_residual_rmsnorm(const fl
     }
 }
 void launch_reduce_residual_rmsnorm(const float* slabs, int S, int Mpad, int N, bf16_t* h, const bf16_t* wnorm,
-                                    bf16_t* x, float eps, hipStream_t s) {
-    hipLaunchKernelGGL(k_reduce_residual_rmsnorm, dim3(Mpad), dim3(RR_THREADS), 0, s, slabs, S, Mpad, N, h, wnorm, x, eps);
+                                    bf16_t* x, float eps, hipStream_t s, const bf16_t* ln_bias) {
+    hipLaunchKernelGGL(k_reduce_residual_rmsnorm, dim3(Mpad), dim3(RR_THREADS), 0, s, slabs, S, Mpad, N, h, wnorm, x, eps,
+                       ln_bias);
 }
 
 // ============================================================================ weight-streaming skinny GEMM
@@ -254,9 +285,12 @@ void launch_reduce_residual_rmsnorm(const float* slabs, int S, int Mpad, int N, 
 
 #define GEMM_U 4
 
+__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
+
 template <int MT, int R, int EPI>
 __device__ __forceinline__ void gemm_epilogue(const f32x4_t (&acc)[R][MT], void* __restrict__ out, int ntg, int ks,
-                                              int NT, int N_out, int Mpad, int lane, int mt_only) {
+                                              int NT, int N_out, int Mpad, int lane, int mt_only,
+                                              const bf16_t* __restrict__ bias) {
     const int nl = (lane >> 4) * 4, ml = lane & 15;
     if (EPI == EPI_PARTIAL) {
         float* o = reinterpret_cast<float*>(out);
@@ -264,27 +298,45 @@ __device__ __forceinline__ void gemm_epilogue(const f32x4_t (&acc)[R][MT], void*
         for (int r = 0; r < R; ++r) {
             int tile = ntg * R + r;
             if (tile >= NT) continue;
+            float bv[4] = {0.f, 0.f, 0.f, 0.f};
+            if (bias && ks == 0) {                 // Linear bias rides on slab 0 (addMM: T(acc + b) after the slab sum)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) bv[e] = bf16_to_f32(bias[tile * 16 + nl + e]);
+            }
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) {
                 if (mt_only >= 0 && mt != mt_only) continue;
                 size_t off = ((size_t)ks * Mpad + mt * 16 + ml) * N_out + tile * 16 + nl;
                 *reinterpret_cast<float4*>(o + off) =
-                    make_float4(acc[r][mt][0], acc[r][mt][1], acc[r][mt][2], acc[r][mt][3]);
+                    make_float4(acc[r][mt][0] + bv[0], acc[r][mt][1] + bv[1], acc[r][mt][2] + bv[2], acc[r][mt][3] + bv[3]);
             }
         }
-    } else if (EPI == EPI_BF16) {
+    } else if (EPI == EPI_BF16 || EPI == EPI_GELU_PACKED) {
         bf16_t* o = reinterpret_cast<bf16_t*>(out);
 #pragma unroll
         for (int r = 0; r < R; ++r) {
             int tile = ntg * R + r;
             if (tile >= NT) continue;
+            float bv[4] = {0.f, 0.f, 0.f, 0.f};
+            if (bias) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) bv[e] = bf16_to_f32(bias[tile * 16 + nl + e]);
+            }
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) {
                 if (mt_only >= 0 && mt != mt_only) continue;
-                size_t off = ((size_t)mt * 16 + ml) * N_out + tile * 16 + nl;
+                uint16_t res[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    float v = acc[r][mt][e] + bv[e];
+                    if (EPI == EPI_GELU_PACKED) v = gelu_erf(bf16_round_f32(v));       // T(gelu(T(xW + b)))
+                    res[e] = f32_to_bf16(v);
+                }
+                size_t off = (EPI == EPI_GELU_PACKED) ? xpk_index(mt * 16 + ml, tile * 16 + nl, MT)
+                                                      : ((size_t)mt * 16 + ml) * N_out + tile * 16 + nl;
                 uint2 v;
-                v.x = (uint32_t)f32_to_bf16(acc[r][mt][0]) | ((uint32_t)f32_to_bf16(acc[r][mt][1]) << 16);
-                v.y = (uint32_t)f32_to_bf16(acc[r][mt][2]) | ((uint32_t)f32_to_bf16(acc[r][mt][3]) << 16);
+                v.x = (uint32_t)res[0] | ((uint32_t)res[1] << 16);
+                v.y = (uint32_t)res[2] | ((uint32_t)res[3] << 16);
                 *reinterpret_cast<uint2*>(o + off) = v;
             }
         }
@@ -315,7 +367,8 @@ __device__ __forceinline__ void gemm_epilogue(const f32x4_t (&acc)[R][MT], void*
 template <int MT, int R, int EPI, int KSB>
 __global__ void __launch_bounds__(256) k_gemm_skinny(const bf16_t* __restrict__ Wp, const bf16_t* __restrict__ X,
                                                      void* __restrict__ out, int NT, int KT, int S, int n_items,
-                                                     int N_out, int Mpad, int dbg_xfixed) {
+                                                     int N_out, int Mpad, int dbg_xfixed,
+                                                     const bf16_t* __restrict__ bias) {
     static_assert(EPI != EPI_SILU_MUL || R == 2, "silu-mul epilogue pairs a gate tile with an up tile");
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int item = (KSB == 1) ? blockIdx.x * 4 + wave : blockIdx.x;
@@ -382,7 +435,7 @@ __global__ void __launch_bounds__(256) k_gemm_skinny(const bf16_t* __restrict__ 
 #undef GEMM_MATH
 
     if (KSB == 1) {
-        gemm_epilogue<MT, R, EPI>(acc, out, ntg, ks, NT, N_out, Mpad, lane, -1);
+        gemm_epilogue<MT, R, EPI>(acc, out, ntg, ks, NT, N_out, Mpad, lane, -1, bias);
     } else {
         __shared__ float4 red[KSB][R * MT][64];
 #pragma unroll
@@ -405,21 +458,21 @@ __global__ void __launch_bounds__(256) k_gemm_skinny(const bf16_t* __restrict__ 
                 for (int m2 = 0; m2 < MT; ++m2)
                     if (m2 == mt) acc[r][m2] = (f32x4_t){s0.x, s0.y, s0.z, s0.w};
             }
-            gemm_epilogue<MT, R, EPI>(acc, out, ntg, ks, NT, N_out, Mpad, lane, mt);
+            gemm_epilogue<MT, R, EPI>(acc, out, ntg, ks, NT, N_out, Mpad, lane, mt, bias);
         }
     }
 }
 
 template <int MT>
 static void launch_gemm_mt(int epi, int R, int ksb, const bf16_t* Wp, const bf16_t* X, void* out, int NT, int KT, int S,
-                           int N_out, int Mpad, hipStream_t s) {
+                           int N_out, int Mpad, const bf16_t* bias, hipStream_t s) {
     int n_items = ((NT + R - 1) / R) * S;
     static const int dbg = getenv("MIS_GEMM_DEBUG_XFIXED") ? atoi(getenv("MIS_GEMM_DEBUG_XFIXED")) : 0;
     dim3 grid(ksb == 1 ? (n_items + 3) / 4 : n_items), block(256);
 #define GEMM_CASE(E, RR, KS)                                                                                  \
     if (epi == E && R == RR && ksb == KS) {                                                                   \
         hipLaunchKernelGGL((k_gemm_skinny<MT, RR, E, KS>), grid, block, 0, s, Wp, X, out, NT, KT, S, n_items, \
-                           N_out, Mpad, dbg);                                                                 \
+                           N_out, Mpad, dbg, bias);                                                           \
         return;                                                                                               \
     }
     GEMM_CASE(EPI_PARTIAL, 1, 1)
@@ -430,18 +483,21 @@ static void launch_gemm_mt(int epi, int R, int ksb, const bf16_t* Wp, const bf16
     GEMM_CASE(EPI_BF16, 2, 4)
     GEMM_CASE(EPI_SILU_MUL, 2, 1)
     GEMM_CASE(EPI_SILU_MUL, 2, 4)
+    GEMM_CASE(EPI_GELU_PACKED, 2, 4)
+    GEMM_CASE(EPI_GELU_PACKED, 1, 4)
+    GEMM_CASE(EPI_BF16, 1, 4)
 #undef GEMM_CASE
     throw MisError(MIS_ERR_GENERATION_FAILED, "unsupported GEMM variant");
 }
 
 void launch_gemm_skinny(int epi, int R, int ksb, const bf16_t* Wp, const bf16_t* X, void* out, int NT, int KT, int S,
-                        int N_out, int Mpad, hipStream_t s) {
+                        int N_out, int Mpad, hipStream_t s, const bf16_t* bias) {
     MIS_REQUIRE(epi == EPI_PARTIAL || S == 1, MIS_ERR_GENERATION_FAILED, "split-K needs the partial epilogue");
     switch (Mpad / 16) {
-        case 1: launch_gemm_mt<1>(epi, R, ksb, Wp, X, out, NT, KT, S, N_out, Mpad, s); break;
-        case 2: launch_gemm_mt<2>(epi, R, ksb, Wp, X, out, NT, KT, S, N_out, Mpad, s); break;
-        case 3: launch_gemm_mt<3>(epi, R, ksb, Wp, X, out, NT, KT, S, N_out, Mpad, s); break;
-        case 4: launch_gemm_mt<4>(epi, R, ksb, Wp, X, out, NT, KT, S, N_out, Mpad, s); break;
+        case 1: launch_gemm_mt<1>(epi, R, ksb, Wp, X, out, NT, KT, S, N_out, Mpad, bias, s); break;
+        case 2: launch_gemm_mt<2>(epi, R, ksb, Wp, X, out, NT, KT, S, N_out, Mpad, bias, s); break;
+        case 3: launch_gemm_mt<3>(epi, R, ksb, Wp, X, out, NT, KT, S, N_out, Mpad, bias, s); break;
+        case 4: launch_gemm_mt<4>(epi, R, ksb, Wp, X, out, NT, KT, S, N_out, Mpad, bias, s); break;
         default: throw MisError(MIS_ERR_INVALID_INPUT, "batch per GPU must be <= 64");
     }
 }
@@ -464,8 +520,8 @@ __global__ void __launch_bounds__(512) k_attn_decode(AttnParams p) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int G = p.H / p.Hkv;
     if (!p.active[b]) return;
-    const int pos = p.pos[b];
-    const int kv_len = pos + 1;
+    const int pos = p.cross ? 0 : p.pos[b];
+    const int kv_len = p.cross ? p.cross_len : pos + 1;
 
     // LDS carve-up
     float* sraw = reinterpret_cast<float*>(smem);                      // [(G+2)][D] f32
@@ -475,7 +531,8 @@ __global__ void __launch_bounds__(512) k_attn_decode(AttnParams p) {
     float* sO = sl + ATT_WAVES * 16;                                   // [W][G][D]
 
     // ---- prologue: slab reduce -> bf16
-    for (int idx = tid; idx < (G + 2) * D; idx += 512) {
+    const int n_pro = p.cross ? G : G + 2;          // cross attention: queries only (K/V cached once per utterance)
+    for (int idx = tid; idx < n_pro * D; idx += 512) {
         int hh = idx / D, d = idx - hh * D;
         int col;
         if (hh < G) col = (kvh * G + hh) * D + d;
@@ -500,11 +557,15 @@ __global__ void __launch_bounds__(512) k_attn_decode(AttnParams p) {
     // tiled cache addressing of the new key `pos` (see header): 32-key tile, A-fragment row i, half hf
     const int ptile = pos >> 5, pr = pos & 31;
     const int prow = ((pr >> 3) << 2) | (pr & 3), phalf = (pr >> 2) & 1;
-    for (int idx = tid; idx < (G + 1) * (D / 2); idx += 512) {
+    const int n_rot = p.cross ? G : G + 1;
+    for (int idx = tid; idx < n_rot * (D / 2); idx += 512) {
         int hh = idx / (D / 2), i = idx - hh * (D / 2);
         float x1 = sraw[hh * D + i], x2 = sraw[hh * D + i + D / 2];
-        float c = p.rope_cos[(size_t)pos * (D / 2) + i], s = p.rope_sin[(size_t)pos * (D / 2) + i];
-        bf16_t r1 = f32_to_bf16(x1 * c - x2 * s), r2 = f32_to_bf16(x1 * s + x2 * c);
+        bf16_t r1, r2;
+        if (p.rope_cos) {
+            float c = p.rope_cos[(size_t)pos * (D / 2) + i], s = p.rope_sin[(size_t)pos * (D / 2) + i];
+            r1 = f32_to_bf16(x1 * c - x2 * s); r2 = f32_to_bf16(x1 * s + x2 * c);
+        } else { r1 = f32_to_bf16(x1); r2 = f32_to_bf16(x2); }      // Whisper: learned positions, no rotary
         if (hh < G) { qs[hh * D + i] = r1; qs[hh * D + i + D / 2] = r2; }
         else {
             int d1 = i, d2 = i + D / 2;
@@ -512,9 +573,10 @@ __global__ void __launch_bounds__(512) k_attn_decode(AttnParams p) {
             kc[((((size_t)ptile * 2 + phalf) * (D / 32) + (d2 >> 5)) * 64 + (((d2 & 31) >> 3) << 4) + prow) * 8 + (d2 & 7)] = r2;
         }
     }
-    for (int d = tid; d < D; d += 512)
-        vt[(((size_t)ptile * (D / 16) + (d >> 4)) * 64 + ((pr >> 3) << 4) + (d & 15)) * 8 + (pr & 7)] =
-            f32_to_bf16(sraw[(G + 1) * D + d]);
+    if (!p.cross)
+        for (int d = tid; d < D; d += 512)
+            vt[(((size_t)ptile * (D / 16) + (d >> 4)) * 64 + ((pr >> 3) << 4) + (d & 15)) * 8 + (pr & 7)] =
+                f32_to_bf16(sraw[(G + 1) * D + d]);
     __syncthreads();       // LDS q visible; K/V stores of this block visible to its own waves (same CU)
 
     // ---- main loop

@@ -261,6 +261,14 @@ static void run_mel(int device, const mis_mel_config& c, const float* pcm_dev, i
     HIP_CHECK(hipStreamSynchronize(s));        // rmax is freed on return
 }
 
+// device-pointer entry used by the Whisper engine: pcm_dev [batch][480000] (already padded) -> out_dev [batch][3000][n_mels]
+void whisper_features_device(int device, const float* pcm_dev, int batch, int n_mels, float* out_dev, hipStream_t s) {
+    mis_mel_config c{};
+    c.sample_rate = 16000; c.n_fft = 400; c.hop_length = 160; c.n_mels = n_mels;
+    c.window = 0; c.mel_scale = 1; c.slaney_norm = 1; c.drop_last_frame = 1;
+    run_mel(device, c, pcm_dev, batch, 480000, out_dev, s);
+}
+
 extern "C" mis_status mis_mel_spectrogram(int device, const mis_mel_config* cfg, const float* pcm, int batch,
                                           int64_t n_samples, float* out, int64_t* n_frames_out) {
     MIS_API_BEGIN

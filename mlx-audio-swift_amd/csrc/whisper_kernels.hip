@@ -1,0 +1,377 @@
+// whisper_kernels.hip - Whisper encoder kernels (compute-bound side of the STT path) for gfx950.
+//
+// Reference being replaced: WhisperEncoder / WhisperEncoderLayer / WhisperAttention
+// (Sources/MLXAudioSTT/Models/Whisper/WhisperLayers.swift:11-156) whose arithmetic is MLX (Conv1d, Linear,
+// LayerNorm, gelu, MLXFast.scaledDotProductAttention).  The decoder's per-token path reuses the
+// weight-streaming kernels of lm_kernels.hip.  bf16 storage, f32 accumulation, rounding at every MLX
+// primitive boundary (oracle/whisper.py).
+//
+//   k_gemm_big      C[M][N] = X[M][K] W[N][K]^T on v_mfma_f32_16x16x32_bf16, 128x128x32 LDS tiles, fused
+//                   bias / exact-erf GELU / residual / positional-embedding epilogues (M = batch*1500 rows)
+//   k_layernorm     row LayerNorm (f32 statistics)
+//   k_im2col3       k=3 convolution patches (stride 1 / 2) so both stem convs run on k_gemm_big
+//   k_scatter_kv    [M][*] K and V columns -> the tiled MFMA-fragment cache layouts of lm_kernels.hip
+//   k_attn_prefill  non-causal flash attention over the tiled K/V, 16 query rows per wave
+#include "common.h"
+#include "whisper_kernels.h"
+
+__device__ __forceinline__ float gelu_erf_w(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
+
+// ============================================================================ big GEMM
+#define BG_BM 128
+#define BG_BN 128
+#define BG_BK 32
+#define BG_LD 40          // padded LDS row (bf16 elements): 80 B rows keep 16-B fragments aligned
+
+template <int EPI>
+__global__ void __launch_bounds__(256) k_gemm_big(BigGemmParams p) {
+    __shared__ __attribute__((aligned(16))) bf16_t Ws[BG_BN][BG_LD];
+    __shared__ __attribute__((aligned(16))) bf16_t Xs[BG_BM][BG_LD];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int n0 = blockIdx.x * BG_BN, m0 = blockIdx.y * BG_BM;
+    const int wn = wave >> 1, wm = wave & 1;            // wave tile: 64 n x 64 m
+    f32x4_t acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+    // staging: 128 rows x 32 k = 512 chunks of 16 B per operand, two per thread
+    const int r0 = tid >> 2, c0 = (tid & 3) * 8;
+    uint4 wreg[2], xreg[2];
+    auto load = [&](int k0) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            int row = r0 + 64 * h;
+            int n = n0 + row, m = m0 + row;
+            wreg[h] = (n < p.N) ? *reinterpret_cast<const uint4*>(p.W + (size_t)n * p.K + k0 + c0) : make_uint4(0, 0, 0, 0);
+            xreg[h] = (m < p.M) ? *reinterpret_cast<const uint4*>(p.X + (size_t)m * p.ldx + k0 + c0) : make_uint4(0, 0, 0, 0);
+        }
+    };
+    load(0);
+    for (int k0 = 0; k0 < p.K; k0 += BG_BK) {
+        __syncthreads();
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            *reinterpret_cast<uint4*>(&Ws[r0 + 64 * h][c0]) = wreg[h];
+            *reinterpret_cast<uint4*>(&Xs[r0 + 64 * h][c0]) = xreg[h];
+        }
+        __syncthreads();
+        if (k0 + BG_BK < p.K) load(k0 + BG_BK);
+        bf16x8_t a[4], b[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            a[i] = *reinterpret_cast<const bf16x8_t*>(&Ws[wn * 64 + i * 16 + (lane & 15)][(lane >> 4) * 8]);
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            b[j] = *reinterpret_cast<const bf16x8_t*>(&Xs[wm * 64 + j * 16 + (lane & 15)][(lane >> 4) * 8]);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+    }
+    // epilogue: C/D lane l, reg r: n = (l>>4)*4 + r (A rows), m = l&15 (B cols) -> 4 consecutive n per lane
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        int n = n0 + wn * 64 + i * 16 + (lane >> 4) * 4;
+        if (n >= p.N) continue;
+        float bv[4] = {0.f, 0.f, 0.f, 0.f};
+        if (p.bias) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) bv[e] = (n + e < p.N) ? bf16_to_f32(p.bias[n + e]) : 0.0f;
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            int m = m0 + wm * 64 + j * 16 + (lane & 15);
+            if (m >= p.M) continue;
+            uint16_t res[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float v = bf16_round_f32(acc[i][j][e] + bv[e]);                       // T(xW^T + b)
+                if (EPI == BG_GELU || EPI == BG_GELU_POS) v = bf16_round_f32(gelu_erf_w(v));
+                if (EPI == BG_RESID) v = bf16_round_f32(v + bf16_to_f32(p.R[(size_t)m * p.N + n + e]));
+                if (EPI == BG_GELU_POS) v = bf16_round_f32(v + bf16_to_f32(p.R[(size_t)(m % p.pos_rows) * p.N + n + e]));
+                res[e] = f32_to_bf16(v);
+            }
+            bf16_t* o = p.C + (size_t)m * p.N + n;
+            if (n + 3 < p.N) {
+                uint2 v;
+                v.x = (uint32_t)res[0] | ((uint32_t)res[1] << 16);
+                v.y = (uint32_t)res[2] | ((uint32_t)res[3] << 16);
+                *reinterpret_cast<uint2*>(o) = v;
+            } else {
+                for (int e = 0; e < 4 && n + e < p.N; ++e) o[e] = res[e];
+            }
+        }
+    }
+}
+
+void launch_gemm_big(int epi, const BigGemmParams& p, hipStream_t s) {
+    MIS_REQUIRE(p.K % BG_BK == 0 && p.ldx % 8 == 0 && p.N % 4 == 0, MIS_ERR_INVALID_INPUT, "big GEMM needs K % 32 == 0");
+    dim3 grid(cdiv(p.N, BG_BN), cdiv(p.M, BG_BM)), block(256);
+    switch (epi) {
+        case BG_NONE: hipLaunchKernelGGL((k_gemm_big<BG_NONE>), grid, block, 0, s, p); break;
+        case BG_GELU: hipLaunchKernelGGL((k_gemm_big<BG_GELU>), grid, block, 0, s, p); break;
+        case BG_RESID: hipLaunchKernelGGL((k_gemm_big<BG_RESID>), grid, block, 0, s, p); break;
+        case BG_GELU_POS: hipLaunchKernelGGL((k_gemm_big<BG_GELU_POS>), grid, block, 0, s, p); break;
+        default: throw MisError(MIS_ERR_GENERATION_FAILED, "unknown big GEMM epilogue");
+    }
+}
+
+// ============================================================================ LayerNorm over rows
+__global__ void __launch_bounds__(256) k_layernorm(const bf16_t* __restrict__ x, bf16_t* __restrict__ y,
+                                                   const bf16_t* __restrict__ w, const bf16_t* __restrict__ bias, int d,
+                                                   float eps) {
+    __shared__ float red[4];
+    const size_t row = blockIdx.x;
+    const bf16_t* xr = x + row * d;
+    float s = 0.0f;
+    for (int i = threadIdx.x; i < d; i += 256) s += bf16_to_f32(xr[i]);
+    s = wave_sum(s);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    const float mean = (red[0] + red[1] + red[2] + red[3]) / (float)d;
+    __syncthreads();
+    float q = 0.0f;
+    for (int i = threadIdx.x; i < d; i += 256) { float t = bf16_to_f32(xr[i]) - mean; q += t * t; }
+    q = wave_sum(q);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = q;
+    __syncthreads();
+    const float rstd = 1.0f / sqrtf((red[0] + red[1] + red[2] + red[3]) / (float)d + eps);
+    for (int i = threadIdx.x; i < d; i += 256)
+        y[row * d + i] = f32_to_bf16((bf16_to_f32(xr[i]) - mean) * rstd * bf16_to_f32(w[i]) + bf16_to_f32(bias[i]));
+}
+void launch_layernorm(const bf16_t* x, bf16_t* y, const bf16_t* w, const bf16_t* b, int rows, int d, float eps, hipStream_t s) {
+    if (rows > 0) hipLaunchKernelGGL(k_layernorm, dim3(rows), dim3(256), 0, s, x, y, w, b, d, eps);
+}
+
+// ============================================================================ conv stem patches
+// out[(b*Tout + t)][k*C + c] = in[b][t*stride + k - 1][c]  (zero outside), k = 0..2   (Conv1d k3 p1, NLC)
+template <typename TIN>
+__global__ void k_im2col3(const TIN* __restrict__ in, bf16_t* __restrict__ out, int B, int Tin, int C, int Tout, int stride) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    size_t total = (size_t)B * Tout * 3 * C;
+    if (i >= total) return;
+    int c = (int)(i % C);
+    size_t r = i / C;
+    int k = (int)(r % 3);
+    r /= 3;
+    int t = (int)(r % Tout);
+    int b = (int)(r / Tout);
+    int ti = t * stride + k - 1;
+    float v = 0.0f;
+    if (ti >= 0 && ti < Tin) {
+        TIN raw = in[((size_t)b * Tin + ti) * C + c];
+        if constexpr (sizeof(TIN) == 4) v = (float)raw; else v = bf16_to_f32((bf16_t)raw);
+    }
+    out[i] = f32_to_bf16(v);
+}
+void launch_im2col3_f32(const float* in, bf16_t* out, int B, int Tin, int C, int Tout, int stride, hipStream_t s) {
+    size_t total = (size_t)B * Tout * 3 * C;
+    hipLaunchKernelGGL((k_im2col3<float>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, in, out, B, Tin, C, Tout, stride);
+}
+void launch_im2col3_bf16(const bf16_t* in, bf16_t* out, int B, int Tin, int C, int Tout, int stride, hipStream_t s) {
+    size_t total = (size_t)B * Tout * 3 * C;
+    hipLaunchKernelGGL((k_im2col3<bf16_t>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, in, out, B, Tin, C, Tout, stride);
+}
+
+// ============================================================================ K / V -> tiled fragment caches
+// src rows [B*T][ld]; K columns at kcol0 + h*D + d, V columns at vcol0 + h*D + d.
+// kcache [B][H][Spad/32][2][D/32][64][8],  vcache [B][H][Spad/32][D/16][64][8]   (layouts of lm_kernels.hip)
+__global__ void k_scatter_kv(const bf16_t* __restrict__ src, int ld, int kcol0, int vcol0, bf16_t* __restrict__ kc,
+                             bf16_t* __restrict__ vc, int B, int T, int H, int D, int Spad) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    size_t total = (size_t)B * T * H * D;
+    if (i >= total) return;
+    int d = (int)(i % D);
+    size_t r = i / D;
+    int h = (int)(r % H);
+    r /= H;
+    int t = (int)(r % T);
+    int b = (int)(r / T);
+    const bf16_t* row = src + ((size_t)b * T + t) * ld;
+    bf16_t kv = row[kcol0 + h * D + d], vv = row[vcol0 + h * D + d];
+    size_t base = ((size_t)b * H + h) * (size_t)Spad * D;
+    int tile = t >> 5, pr = t & 31;
+    int prow = ((pr >> 3) << 2) | (pr & 3), phalf = (pr >> 2) & 1;
+    kc[base + ((((size_t)tile * 2 + phalf) * (D / 32) + (d >> 5)) * 64 + (((d & 31) >> 3) << 4) + prow) * 8 + (d & 7)] = kv;
+    vc[base + (((size_t)tile * (D / 16) + (d >> 4)) * 64 + ((pr >> 3) << 4) + (d & 15)) * 8 + (pr & 7)] = vv;
+}
+void launch_scatter_kv(const bf16_t* src, int ld, int kcol0, int vcol0, bf16_t* kc, bf16_t* vc, int B, int T, int H, int D,
+                       int Spad, hipStream_t s) {
+    size_t total = (size_t)B * T * H * D;
+    hipLaunchKernelGGL(k_scatter_kv, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, src, ld, kcol0, vcol0, kc, vc, B, T,
+                       H, D, Spad);
+}
+
+// ============================================================================ encoder self attention (non causal)
+// grid (ceil(T/64), H, B), 4 waves x 16 query rows.  S^T = K Q^T (A = K fragment, B = Q^T): lane (q row j, group g4)
+// holds the scores of keys base + g4*8 + e; online softmax per query row; O += P V with P split into bf16 hi + lo.
+template <int D>
+__global__ void __launch_bounds__(256) k_attn_prefill(const bf16_t* __restrict__ q, int ldq, const bf16_t* __restrict__ kc,
+                                                      const bf16_t* __restrict__ vc, bf16_t* __restrict__ out, int ldo,
+                                                      int T, int H, int Spad, float scale) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int b = blockIdx.z, h = blockIdx.y, t0 = blockIdx.x * 64 + wave * 16;
+    if (t0 >= T) return;
+    const int j = lane & 15, g4 = lane >> 4;
+    const int tq = t0 + j;
+    bf16x8_t qf[D / 32];
+#pragma unroll
+    for (int c = 0; c < D / 32; ++c) {
+        if (tq < T) qf[c] = *reinterpret_cast<const bf16x8_t*>(q + ((size_t)b * T + tq) * ldq + h * D + c * 32 + g4 * 8);
+        else qf[c] = (bf16x8_t){0, 0, 0, 0, 0, 0, 0, 0};
+    }
+    const size_t base = ((size_t)b * H + h) * (size_t)Spad * D;
+    const bf16x8_t* kbase = reinterpret_cast<const bf16x8_t*>(kc + base) + lane;
+    const bf16x8_t* vbase = reinterpret_cast<const bf16x8_t*>(vc + base) + lane;
+    f32x4_t O[D / 16];
+#pragma unroll
+    for (int dt = 0; dt < D / 16; ++dt) O[dt] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+    float m_run = -INFINITY, l_run = 0.0f;
+    const int n_tiles = (T + 31) >> 5;
+    for (int tile = 0; tile < n_tiles; ++tile) {
+        const int kb = tile * 32;
+        f32x4_t S0 = (f32x4_t){0.f, 0.f, 0.f, 0.f}, S1 = S0;
+#pragma unroll
+        for (int c = 0; c < D / 32; ++c) {
+            bf16x8_t a0 = kbase[((size_t)tile * 2) * (D / 32) * 64 + c * 64];
+            bf16x8_t a1 = kbase[((size_t)tile * 2 + 1) * (D / 32) * 64 + c * 64];
+            S0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0, qf[c], S0, 0, 0, 0);
+            S1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, qf[c], S1, 0, 0, 0);
+        }
+        float sc[8], mx = -INFINITY;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            float v = (e < 4 ? S0[e] : S1[e - 4]) * scale;
+            v = (kb + g4 * 8 + e < T) ? v : -INFINITY;
+            sc[e] = v;
+            mx = fmaxf(mx, v);
+        }
+        mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        float m_new = fmaxf(m_run, mx);
+        float alpha = __expf(m_run - m_new);
+        float psum = 0.0f;
+        bf16x8_t ph, pl;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            float pe = __expf(sc[e] - m_new);
+            psum += pe;
+            bf16_t hi = f32_to_bf16(pe);
+            bf16_t lo = f32_to_bf16(pe - bf16_to_f32(hi));
+            ph[e] = (short)hi;
+            pl[e] = (short)lo;
+        }
+        l_run = l_run * alpha + psum;
+        m_run = m_new;
+        float ar[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) ar[r] = __shfl(alpha, g4 * 4 + r, 64);
+#pragma unroll
+        for (int dt = 0; dt < D / 16; ++dt) {
+            bf16x8_t vb = vbase[((size_t)tile * (D / 16) + dt) * 64];
+            f32x4_t o = O[dt];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) o[r] *= ar[r];
+            o = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ph, vb, o, 0, 0, 0);
+            o = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pl, vb, o, 0, 0, 0);
+            O[dt] = o;
+        }
+    }
+    l_run += __shfl_xor(l_run, 16, 64);
+    l_run += __shfl_xor(l_run, 32, 64);
+    // O[dt][r]: row = query (g4*4 + r), col = d (dt*16 + j); the row's normaliser lives in lane (g4*4 + r)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        float lr = __shfl(l_run, g4 * 4 + r, 64);
+        int tr = t0 + g4 * 4 + r;
+        if (tr < T) {
+#pragma unroll
+            for (int dt = 0; dt < D / 16; ++dt)
+                out[((size_t)b * T + tr) * ldo + h * D + dt * 16 + j] = f32_to_bf16(O[dt][r] / lr);
+        }
+    }
+}
+void launch_attn_prefill(const bf16_t* q, int ldq, const bf16_t* kc, const bf16_t* vc, bf16_t* out, int ldo, int B, int T,
+                         int H, int D, int Spad, hipStream_t s) {
+    dim3 grid(cdiv(T, 64), H, B), block(256);
+    float scale = 1.0f / sqrtf((float)D);
+    if (D == 64) hipLaunchKernelGGL((k_attn_prefill<64>), grid, block, 0, s, q, ldq, kc, vc, out, ldo, T, H, Spad, scale);
+    else if (D == 128) hipLaunchKernelGGL((k_attn_prefill<128>), grid, block, 0, s, q, ldq, kc, vc, out, ldo, T, H, Spad, scale);
+    else throw MisError(MIS_ERR_INVALID_INPUT, "head_dim must be 64 or 128");
+}
+
+// ============================================================================ decoder step helpers
+// h = T(E[tok] + P[pos]) ; x = LayerNorm(h) packed ; advances positions like k_embed_rmsnorm
+__global__ void __launch_bounds__(256) k_whisper_embed_ln(const bf16_t* __restrict__ emb, const bf16_t* __restrict__ pos_emb,
+                                                          const int32_t* __restrict__ ids, const uint8_t* __restrict__ active,
+                                                          int* __restrict__ pos_cur, int* __restrict__ pos_next,
+                                                          const bf16_t* __restrict__ lw, const bf16_t* __restrict__ lb,
+                                                          bf16_t* __restrict__ h, bf16_t* __restrict__ x, int d, int vocab,
+                                                          int max_pos, int batch) {
+    __shared__ float red[4];
+    const int m = blockIdx.x, MT = gridDim.x >> 4;
+    int id = (m < batch) ? ids[m] : 0;
+    if (id < 0 || id >= vocab) id = 0;
+    int p = (m < batch) ? pos_next[m] : 0;
+    if (threadIdx.x == 0 && m < batch) {
+        pos_cur[m] = p;
+        if (active[m]) pos_next[m] = p + 1;
+    }
+    if (p >= max_pos) p = max_pos - 1;
+    float s = 0.0f;
+    for (int i = threadIdx.x; i < d; i += 256) {
+        float v = bf16_round_f32(bf16_to_f32(emb[(size_t)id * d + i]) + bf16_to_f32(pos_emb[(size_t)p * d + i]));
+        h[(size_t)m * d + i] = f32_to_bf16(v);
+        s += v;
+    }
+    s = wave_sum(s);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    const float mean = (red[0] + red[1] + red[2] + red[3]) / (float)d;
+    __syncthreads();
+    float q = 0.0f;
+    for (int i = threadIdx.x; i < d; i += 256) { float t = bf16_to_f32(h[(size_t)m * d + i]) - mean; q += t * t; }
+    q = wave_sum(q);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = q;
+    __syncthreads();
+    const float rstd = 1.0f / sqrtf((red[0] + red[1] + red[2] + red[3]) / (float)d + 1e-5f);
+    for (int i = threadIdx.x; i < d; i += 256) {
+        float f = bf16_to_f32(h[(size_t)m * d + i]);
+        size_t off = ((((size_t)(i >> 5) * MT + (m >> 4)) * 64) + (((i & 31) >> 3) << 4) + (m & 15)) * 8 + (i & 7);
+        x[off] = f32_to_bf16((f - mean) * rstd * bf16_to_f32(lw[i]) + bf16_to_f32(lb[i]));
+    }
+}
+void launch_whisper_embed_ln(const bf16_t* emb, const bf16_t* pos_emb, const int32_t* ids, const uint8_t* active, int* pos_cur,
+                             int* pos_next, const bf16_t* lw, const bf16_t* lb, bf16_t* h, bf16_t* x, int d, int vocab,
+                             int max_pos, int batch, int Mpad, hipStream_t s) {
+    hipLaunchKernelGGL(k_whisper_embed_ln, dim3(Mpad), dim3(256), 0, s, emb, pos_emb, ids, active, pos_cur, pos_next, lw, lb, h,
+                       x, d, vocab, max_pos, batch);
+}
+
+// suppress masks of the greedy loop (WhisperModel.swift:228-236,293-309): logits += -1e9 on the listed ids
+// (begin list only while the row has generated nothing); ids >= timestamp_begin are excluded via the sampler range.
+__global__ void k_whisper_suppress(bf16_t* __restrict__ logits, int Vpad, int vocab, const int32_t* __restrict__ sup, int n_sup,
+                                   const int32_t* __restrict__ bsup, int n_bsup, const int32_t* __restrict__ n_gen,
+                                   const uint8_t* __restrict__ active) {
+    const int b = blockIdx.x;
+    if (active && !active[b]) return;
+    bf16_t* l = logits + (size_t)b * Vpad;
+    for (int i = threadIdx.x; i < n_sup; i += blockDim.x) {
+        int id = sup[i];
+        if (id >= 0 && id < vocab) l[id] = f32_to_bf16(bf16_to_f32(l[id]) + -1e9f);
+    }
+    if (n_gen[b] == 0)
+        for (int i = threadIdx.x; i < n_bsup; i += blockDim.x) {
+            int id = bsup[i];
+            bool dup = false;
+            for (int k = 0; k < n_sup; ++k) dup = dup || (sup[k] == id);
+            if (id >= 0 && id < vocab && !dup) l[id] = f32_to_bf16(bf16_to_f32(l[id]) + -1e9f);
+        }
+}
+void launch_whisper_suppress(bf16_t* logits, int Vpad, int vocab, const int32_t* sup, int n_sup, const int32_t* bsup, int n_bsup,
+                             const int32_t* n_gen, const uint8_t* active, int batch, hipStream_t s) {
+    if (n_sup + n_bsup == 0) return;
+    hipLaunchKernelGGL(k_whisper_suppress, dim3(batch), dim3(128), 0, s, logits, Vpad, vocab, sup, n_sup, bsup, n_bsup, n_gen, active);
+}

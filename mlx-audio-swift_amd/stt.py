@@ -1,0 +1,226 @@
+"""Whisper STT, host mirror of `WhisperModel: STTGenerationModel`
+(Sources/MLXAudioSTT/Models/Whisper/WhisperModel.swift:6-309; protocol Sources/MLXAudioSTT/Generation.swift:52-64;
+STTOutput Sources/MLXAudioSTT/Models/GLMASR/STTOutput.swift:80-125).  Tokenisation, prompt construction and text
+decoding stay on the host, as in the reference (WhisperTokenizer.swift); everything else runs in libmi_speech.so."""
+from __future__ import annotations
+
+import ctypes as C
+import json
+import os
+import time
+from dataclasses import dataclass, field
+
+import numpy as np
+
+from . import _lib
+from .codecs import _tensor_args
+from .generation import AudioGenerationError, check
+
+SAMPLE_RATE, CHUNK_SAMPLES = 16000, 480000          # WhisperAudioConfig, WhisperConfig.swift:188-193
+
+
+@dataclass
+class WhisperConfig:
+    """WhisperConfig.swift:3-22 (both the HF and the OpenAI / mlx-whisper key spellings, :26-55,93-129)."""
+    vocab_size: int = 51865
+    num_mel_bins: int = 80
+    d_model: int = 384
+    encoder_layers: int = 4
+    encoder_attention_heads: int = 6
+    encoder_ffn_dim: int | None = None
+    max_source_positions: int = 1500
+    decoder_layers: int = 4
+    decoder_attention_heads: int = 6
+    decoder_ffn_dim: int | None = None
+    max_target_positions: int = 448
+
+    @classmethod
+    def from_dict(cls, d: dict) -> "WhisperConfig":
+        alias = {"n_vocab": "vocab_size", "n_mels": "num_mel_bins", "n_audio_state": "d_model",
+                 "n_audio_layer": "encoder_layers", "n_audio_head": "encoder_attention_heads",
+                 "n_audio_ctx": "max_source_positions", "n_text_layer": "decoder_layers",
+                 "n_text_head": "decoder_attention_heads", "n_text_ctx": "max_target_positions"}
+        kw = {}
+        for k, v in d.items():
+            k = alias.get(k, k)
+            if k in cls.__dataclass_fields__ and k not in kw:
+                kw[k] = v
+        return cls(**kw)
+
+    def to_c(self) -> "_lib.WhisperConfigC":
+        return _lib.WhisperConfigC(self.vocab_size, self.num_mel_bins, self.d_model, self.encoder_layers,
+                                   self.encoder_attention_heads, self.encoder_ffn_dim or 4 * self.d_model,
+                                   self.max_source_positions, self.decoder_layers, self.decoder_attention_heads,
+                                   self.decoder_ffn_dim or 4 * self.d_model, self.max_target_positions)
+
+
+@dataclass
+class STTGenerateParameters:
+    """Sources/MLXAudioSTT/Generation.swift:3-50 (fields the Whisper loop reads) + WhisperGenerationConfig lists."""
+    max_tokens: int = 432
+    temperature: float = 0.0
+    language: str | None = None
+    seed: int = 0
+    eot_id: int = 50257
+    timestamp_begin: int = 0
+    suppress_tokens: list = field(default_factory=list)
+    begin_suppress_tokens: list | None = None       # default [eot] (WhisperModel.swift:218)
+
+
+@dataclass
+class STTOutput:
+    """STTOutput.swift:80-125"""
+    text: str
+    segments: list | None
+    language: str | None
+    prompt_tokens: int
+    generation_tokens: int
+    total_tokens: int
+    prompt_tps: float
+    generation_tps: float
+    total_time: float
+    peak_memory_usage: float
+    token_ids: list = field(default_factory=list)   # per chunk (the engine's raw output; text needs a tokenizer)
+
+
+class WhisperModel:
+    """STTGenerationModel conformance: default_generation_parameters, generate(audio, generation_parameters)."""
+
+    def __init__(self, config: WhisperConfig, device: int = 0):
+        self.config = config
+        self.device = device
+        self.tokenizer = None            # any object with decode(list[int]) -> str and build_prompt_tokens(language, task)
+        h = C.c_void_p()
+        cfg = config.to_c()
+        check(_lib.lib().mis_whisper_create(C.byref(cfg), device, C.byref(h)))
+        self._h = h
+
+    @classmethod
+    def from_weights(cls, config, weights: dict, device: int = 0) -> "WhisperModel":
+        m = cls(config, device)
+        for name, arr in weights.items():
+            m.set_tensor(name, arr)
+        m.finalize()
+        return m
+
+    @classmethod
+    def synthetic(cls, config, device: int = 0, seed: int = 777) -> "WhisperModel":
+        m = cls(config, device)
+        check(_lib.lib().mis_whisper_init_synthetic(m._h, seed))
+        m.finalize()
+        return m
+
+    @classmethod
+    def from_model_directory(cls, model_dir: str, device: int = 0) -> "WhisperModel":
+        """fromDirectory: config.json + *.safetensors in the HF transformers layout (WhisperModel.swift:337-363)."""
+        from safetensors import safe_open
+        with open(os.path.join(model_dir, "config.json")) as f:
+            cfg = WhisperConfig.from_dict(json.load(f))
+        m = cls(cfg, device)
+        for fn in sorted(os.listdir(model_dir)):
+            if fn.endswith(".safetensors"):
+                with safe_open(os.path.join(model_dir, fn), framework="pt") as sf:
+                    for k in sf.keys():
+                        if ".blocks." in k:
+                            raise AudioGenerationError(3, "mlx-whisper key layout is not supported yet (HF layout only)")
+                        m.set_tensor(k, sf.get_tensor(k))
+        m.finalize()
+        return m
+
+    def set_tensor(self, name: str, arr):
+        keep, ptr, dt, shape = _tensor_args(arr)
+        sh = (C.c_int64 * len(shape))(*shape)
+        check(_lib.lib().mis_whisper_set_tensor(self._h, name.encode(), ptr, dt, sh, len(shape)))
+
+    def finalize(self):
+        check(_lib.lib().mis_whisper_finalize(self._h))
+
+    @property
+    def default_generation_parameters(self) -> STTGenerateParameters:      # WhisperModel.swift:21-34
+        return STTGenerateParameters(max_tokens=self.config.max_target_positions - 16)
+
+    # -- taps for parity tests -----------------------------------------------------------------------
+    def encode(self, features: np.ndarray, want_output: bool = True):
+        f = np.ascontiguousarray(features, dtype=np.float32)
+        B = f.shape[0]
+        out = np.zeros((B, 1500, self.config.d_model), np.float32) if want_output else None
+        check(_lib.lib().mis_whisper_encode(self._h, f.ctypes.data, B, out.ctypes.data if want_output else None))
+        return out
+
+    def decoder_reset(self):
+        check(_lib.lib().mis_whisper_decoder_reset(self._h))
+
+    def decoder_forward(self, tokens, active=None, want_logits: bool = True):
+        t = np.ascontiguousarray(tokens, dtype=np.int32)
+        B = t.shape[0]
+        act = None if active is None else np.ascontiguousarray(active, dtype=np.uint8)
+        out = np.zeros((B, self.config.vocab_size), np.float32) if want_logits else None
+        check(_lib.lib().mis_whisper_decoder_forward(self._h, t.ctypes.data, act.ctypes.data if act is not None else None,
+                                                     out.ctypes.data if want_logits else None))
+        return out
+
+    # -- generate ------------------------------------------------------------------------------------
+    def transcribe_windows(self, windows, prompt_ids, params: STTGenerateParameters):
+        """transcribeChunk for a batch of <= 30 s windows: list of 1-D float arrays -> list of token-id lists."""
+        B = len(windows)
+        stride = max(1, max(len(w) for w in windows))
+        pcm = np.zeros((B, stride), np.float32)
+        lens = np.zeros(B, np.int64)
+        for i, w in enumerate(windows):
+            w = np.asarray(w, np.float32).reshape(-1)
+            pcm[i, : len(w)] = w
+            lens[i] = len(w)
+        prompt = np.ascontiguousarray(prompt_ids, dtype=np.int32)
+        sup = np.ascontiguousarray(params.suppress_tokens or [], dtype=np.int32)
+        bs = params.begin_suppress_tokens if params.begin_suppress_tokens is not None else [params.eot_id]
+        bsup = np.ascontiguousarray(bs, dtype=np.int32)
+        sp = _lib.SttParamsC(int(params.max_tokens), float(params.temperature), int(params.seed), int(params.eot_id),
+                             int(params.timestamp_begin), sup.ctypes.data if len(sup) else None, len(sup),
+                             bsup.ctypes.data if len(bsup) else None, len(bsup))
+        toks = C.c_void_p(); ts = C.c_int64(); nt = (C.c_int32 * B)()
+        check(_lib.lib().mis_stt_whisper_generate(self._h, pcm.ctypes.data, lens.ctypes.data, B, stride, prompt.ctypes.data,
+                                                  len(prompt), C.byref(sp), C.byref(toks), C.byref(ts), nt))
+        try:
+            arr = np.ctypeslib.as_array(C.cast(toks, C.POINTER(C.c_int32)), shape=(B, max(ts.value, 1)))
+            return [arr[b, : nt[b]].tolist() for b in range(B)]
+        finally:
+            _lib.lib().mis_free(toks)
+
+    def generate(self, audio, generation_parameters: STTGenerateParameters | None = None, prompt_ids=None,
+                 max_batch: int = 64) -> STTOutput:
+        """generate(audio:generationParameters:) (WhisperModel.swift:36-90): mono mix, hard 30 s chunking (:165-182),
+        every chunk transcribed (here: batched on the device), texts joined with spaces."""
+        gp = generation_parameters or self.default_generation_parameters
+        t0 = time.time()
+        a = np.asarray(audio, np.float32)
+        mono = a.mean(axis=-1) if a.ndim > 1 else a
+        chunks = [mono] if len(mono) <= CHUNK_SAMPLES else [mono[i:i + CHUNK_SAMPLES] for i in range(0, len(mono), CHUNK_SAMPLES)]
+        if prompt_ids is None:
+            if self.tokenizer is None:
+                raise AudioGenerationError(1, "WhisperTokenizer not loaded")
+            prompt_ids = self.tokenizer.build_prompt_tokens(language=gp.language, task="transcribe")
+        ids = []
+        for i in range(0, len(chunks), max_batch):
+            ids += self.transcribe_windows(chunks[i:i + max_batch], prompt_ids, gp)
+        texts, segments = [], []
+        for ci, tok in enumerate(ids):
+            text = self.tokenizer.decode(tok).strip() if self.tokenizer is not None else ""
+            if text:
+                texts.append(text)
+                start = ci * CHUNK_SAMPLES / SAMPLE_RATE
+                segments.append({"text": text, "start": start, "end": start + len(chunks[ci]) / SAMPLE_RATE})
+        el = time.time() - t0
+        n_prompt, n_gen = len(prompt_ids) * len(chunks), sum(len(t) for t in ids)
+        return STTOutput(" ".join(texts), segments or None, gp.language, n_prompt, n_gen, n_prompt + n_gen,
+                         n_prompt / el if el > 0 else 0.0, n_gen / el if el > 0 else 0.0, el, 0.0, ids)
+
+    def close(self):
+        if self._h is not None:
+            _lib.lib().mis_whisper_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
