@@ -136,6 +136,10 @@ def lib():
             raise MisLibraryMissing(
                 f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                 "(hipcc --offload-arch=gfx950). There is no CPU fallback.")
+        try:        # if torch is installed, let ITS bundled ROCm runtime load first (one libamdhip64 per process)
+            import torch  # noqa: F401
+        except Exception:
+            pass
         l = C.CDLL(LIB_PATH)
         for name, (res, args) in SYMBOLS.items():
             fn = getattr(l, name)          # AttributeError if the ABI lost a symbol

@@ -3,6 +3,13 @@ import sys
 
 import pytest
 
+# torch FIRST: its wheel bundles its own ROCm runtime; if libmi_speech.so (linked against /opt/rocm) were loaded
+# before it, torch would bind to the wrong libamdhip64 and report "no GPU" (every -m gpu test silently skipped).
+try:
+    import torch  # noqa: F401
+except Exception:  # pragma: no cover
+    torch = None
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
@@ -13,9 +20,16 @@ def pytest_configure(config):
 
 
 def _has_gpu():
+    if not os.path.exists("/dev/kfd"):
+        return False
     try:
-        import torch
-        return torch.cuda.is_available()
+        if torch is not None and torch.cuda.is_available():
+            return True
+    except Exception:
+        pass
+    try:                                   # ask the HIP library itself
+        import mlx_audio_swift_amd as mas
+        return mas._lib.lib().mis_device_count() > 0
     except Exception:
         return False
 
