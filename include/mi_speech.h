@@ -134,6 +134,11 @@ typedef struct {
     float   rope_factor, rope_low_freq_factor, rope_high_freq_factor, rope_original_max_pos;
     int32_t tie_word_embeddings;
     int32_t sample_rate;
+    /* Qwen3-style variants (Soprano Soprano.swift:24-97, VyvoTTS Qwen3.swift:204-205): per-head RMSNorm of q and k
+     * before RoPE (weights model.layers.N.self_attn.{q,k}_norm.weight [head_dim]) and plain RoPE(base) without the
+     * llama3 rescale.  Both 0 for Orpheus (LlamaTTS.swift always builds Llama3ScaledRoPE, :161-186). */
+    int32_t qk_norm;
+    int32_t rope_plain;
 } mis_lm_config;
 
 /* GenerateParameters as used by LlamaTTS.swift:573-581,691-696 (mlx-swift-lm) */
@@ -148,6 +153,11 @@ typedef struct {
                                       128266 + (i%7)*4096 + [0,4096) - all vocab entries are still
                                       processed; EOS can then never be sampled */
     int64_t  row_offset;           /* global index of row 0 (RNG keyed by global row => sharding-invariant) */
+    int32_t  sampler_flavor;       /* 0 mlx-lm processor/sampler (Orpheus).  1 Soprano streamGenerate (Soprano.swift:801-901):
+                                      penalty window = generated tokens only, applied per occurrence in float32; the reference's
+                                      TopPSampler thresholds UNNORMALISED exp(logit) sums (:1003-1036) and so only ever drops
+                                      tokens of vanishing mass - this flavour keeps them (top_p is ignored) */
+    int32_t  reserved;
 } mis_gen_params;
 
 /* AudioGeneration events, GenerationTypes.swift:50-61 */
@@ -179,6 +189,9 @@ void       mis_tts_destroy(mis_tts*);
  * (bf16 values, widened) or NULL. */
 mis_status mis_lm_reset(mis_tts*, int batch, int max_context);
 mis_status mis_lm_forward(mis_tts*, const int32_t* ids, const uint8_t* active, float* logits_out);
+/* same, also returning model.norm(h) of the fed token: hidden_out f32 [batch, hidden_size] (Soprano decodes these,
+ * Soprano.swift:254-275); either output may be NULL */
+mis_status mis_lm_forward_hidden(mis_tts*, const int32_t* ids, const uint8_t* active, float* logits_out, float* hidden_out);
 /* processor + sampler of the generate loop (LlamaTTS.swift:717-721) on caller-provided logits:
  * logits f32 [batch, vocab]; window [batch, ctx] (ids, right-aligned valid part = window_len[b]);
  * lo/hi: optional allowed id range (hi<=0 => vocab); tokens_out [batch].  mis-sampler-v1. */
@@ -227,6 +240,35 @@ mis_status mis_tts_last_timing(mis_tts*, mis_tts_timing* out);
  * the library stream): which = 0 qkv, 1 o_proj, 2 gate_up, 3 down, 4 lm_head.  avg_ms and the
  * algorithmic bytes of one launch are returned.  Used by bench.py for the roofline object. */
 mis_status mis_tts_time_gemm(mis_tts*, int which, int batch, int iters, double* avg_ms, double* bytes);
+
+/* ------------------------------------------------------------------------------------------
+ * Soprano TTS.  Replaces SopranoModel / SopranoDecoder (Sources/MLXAudioTTS/Models/Soprano/Soprano.swift:201-690,
+ * SopranoDecoder.swift:225-284, Vocos backbone Sources/MLXAudioCodecs/Vocos/VocosBackbone.swift:109-204).
+ * Text splitting / cleaning / tokenisation stay on the host (TextUtils.swift).
+ * ---------------------------------------------------------------------------------------- */
+typedef struct mis_soprano mis_soprano;
+/* SopranoConfiguration, SopranoConfig.swift:103-167 */
+typedef struct {
+    mis_lm_config lm;              /* qk_norm / rope_plain are forced on (SopranoAttention) */
+    int32_t decoder_num_layers, decoder_dim, decoder_intermediate_dim;
+    int32_t hop_length, n_fft, upscale, input_kernel, dw_kernel, token_size;
+    int32_t stop_token_id;         /* "[STOP]" (Soprano.swift:855) */
+} mis_soprano_config;
+mis_status mis_soprano_create(const mis_soprano_config*, int device, mis_soprano** out);
+/* checkpoint keys as stored; SopranoModel.sanitize (Soprano.swift:314-361) is applied: "decoder.*" -> float32 decoder
+ * weights, everything else -> the token LM (model.* / lm_head.weight) */
+mis_status mis_soprano_set_tensor(mis_soprano*, const char* name, const void* data, mis_dtype dtype,
+                                  const int64_t* shape, int ndim);
+mis_status mis_soprano_finalize(mis_soprano*);
+void       mis_soprano_destroy(mis_soprano*);
+mis_tts*   mis_soprano_lm(mis_soprano*);                 /* borrowed handle of the token LM (taps, synthetic init) */
+int64_t    mis_soprano_num_samples(const mis_soprano*, int n_hidden);   /* (upscale*(n-1)) * hop_length */
+/* SopranoDecoder.callAsFunction: hidden f32 [batch, L, hidden_size] -> audio f32 [batch, num_samples(L)] */
+mis_status mis_soprano_decode(mis_soprano*, const float* hidden, int batch, int L, float* audio_out);
+/* generate for a batch of tokenised sentences: outputs as mis_tts_generate (pcm rows padded to the longest) */
+mis_status mis_soprano_generate(mis_soprano*, const int32_t* prompt_ids, const int32_t* prompt_lens, int batch,
+                                const mis_gen_params* params, float** pcm_out, int64_t* pcm_stride, int64_t* pcm_lens,
+                                int32_t** tokens_out, int64_t* tokens_stride, int32_t* n_tokens);
 
 /* ------------------------------------------------------------------------------------------
  * Log-mel / STFT front end.  Replaces WhisperAudio.logMelSpectrogram / encoderFeatures

@@ -8,6 +8,7 @@ the Swift shim a maintainer would add):
 
     codecs.SNAC            <-> class SNAC : AudioCodecModel       (MLXAudioCodecs/SNAC/SNACDecoder.swift)
     tts.LlamaTTSModel      <-> class LlamaTTSModel : SpeechGenerationModel  (MLXAudioTTS/Models/Llama/LlamaTTS.swift)
+    soprano.SopranoModel   <-> class SopranoModel : SpeechGenerationModel  (MLXAudioTTS/Models/Soprano/Soprano.swift)
     stt.WhisperModel       <-> class WhisperModel : STTGenerationModel   (MLXAudioSTT/Models/Whisper/WhisperModel.swift)
     dsp.*                  <-> computeMelSpectrogram (MLXAudioCore/DSP.swift) / WhisperAudio.encoderFeatures
     generation.*           <-> AudioGeneration / AudioGenerationInfo / AudioGenerationError /
@@ -22,6 +23,7 @@ from .generation import (AudioGenerationError, AudioGenerationInfo, GeneratePara
 from .codecs import SNAC, SNACConfig  # noqa: F401
 from .tts import LlamaTTSModel, LlamaTTSConfiguration, OrpheusTokens  # noqa: F401
 from .orpheus import deinterleave, parse_output  # noqa: F401
+from .soprano import SopranoModel, SopranoConfiguration  # noqa: F401
 from . import dsp  # noqa: F401
 from .stt import WhisperModel, WhisperConfig, STTGenerateParameters, STTOutput  # noqa: F401
 

@@ -27,19 +27,28 @@ class LmConfigC(C.Structure):
                 ("num_attention_heads", C.c_int32), ("num_key_value_heads", C.c_int32), ("head_dim", C.c_int32),
                 ("vocab_size", C.c_int32), ("rms_norm_eps", C.c_float), ("rope_theta", C.c_float),
                 ("rope_factor", C.c_float), ("rope_low_freq_factor", C.c_float), ("rope_high_freq_factor", C.c_float),
-                ("rope_original_max_pos", C.c_float), ("tie_word_embeddings", C.c_int32), ("sample_rate", C.c_int32)]
+                ("rope_original_max_pos", C.c_float), ("tie_word_embeddings", C.c_int32), ("sample_rate", C.c_int32),
+                ("qk_norm", C.c_int32), ("rope_plain", C.c_int32)]
 
 
 class GenParamsC(C.Structure):
     _fields_ = [("max_tokens", C.c_int32), ("temperature", C.c_float), ("top_p", C.c_float),
                 ("repetition_penalty", C.c_float), ("repetition_context", C.c_int32), ("seed", C.c_uint64),
-                ("frame_constrained", C.c_int32), ("row_offset", C.c_int64)]
+                ("frame_constrained", C.c_int32), ("row_offset", C.c_int64),
+                ("sampler_flavor", C.c_int32), ("reserved", C.c_int32)]
 
 
 class GenInfoC(C.Structure):
     _fields_ = [("prompt_token_count", C.c_int32), ("generation_token_count", C.c_int32),
                 ("prefill_time", C.c_double), ("generate_time", C.c_double), ("tokens_per_second", C.c_double),
                 ("peak_memory_gb", C.c_double)]
+
+
+class SopranoConfigC(C.Structure):
+    _fields_ = [("lm", LmConfigC), ("decoder_num_layers", C.c_int32), ("decoder_dim", C.c_int32),
+                ("decoder_intermediate_dim", C.c_int32), ("hop_length", C.c_int32), ("n_fft", C.c_int32),
+                ("upscale", C.c_int32), ("input_kernel", C.c_int32), ("dw_kernel", C.c_int32),
+                ("token_size", C.c_int32), ("stop_token_id", C.c_int32)]
 
 
 class MelConfigC(C.Structure):
@@ -95,6 +104,7 @@ SYMBOLS = {
     "mis_tts_destroy": (None, [_P]),
     "mis_lm_reset": (C.c_int, [_P, C.c_int, C.c_int]),
     "mis_lm_forward": (C.c_int, [_P, _P, _P, _P]),
+    "mis_lm_forward_hidden": (C.c_int, [_P, _P, _P, _P, _P]),
     "mis_sample_logits": (C.c_int, [C.c_int, _P, C.c_int, C.c_int, _P, _P, C.c_int, C.POINTER(GenParamsC), C.c_int,
                                     C.c_int, C.c_int, _P]),
     "mis_tts_generate": (C.c_int, [_P, _P, _P, C.c_int, C.POINTER(GenParamsC), C.POINTER(_P), C.POINTER(_P),
@@ -118,6 +128,15 @@ SYMBOLS = {
     "mis_whisper_decoder_forward": (C.c_int, [_P, _P, _P, _P]),
     "mis_stt_whisper_generate": (C.c_int, [_P, _P, _P, C.c_int, C.c_int64, _P, C.c_int, C.POINTER(SttParamsC),
                                            C.POINTER(_P), C.POINTER(C.c_int64), _P]),
+    "mis_soprano_create": (C.c_int, [C.POINTER(SopranoConfigC), C.c_int, C.POINTER(_P)]),
+    "mis_soprano_set_tensor": (C.c_int, [_P, C.c_char_p, _P, C.c_int, C.POINTER(C.c_int64), C.c_int]),
+    "mis_soprano_finalize": (C.c_int, [_P]),
+    "mis_soprano_destroy": (None, [_P]),
+    "mis_soprano_lm": (_P, [_P]),
+    "mis_soprano_num_samples": (C.c_int64, [_P, C.c_int]),
+    "mis_soprano_decode": (C.c_int, [_P, _P, C.c_int, C.c_int, _P]),
+    "mis_soprano_generate": (C.c_int, [_P, _P, _P, C.c_int, C.POINTER(GenParamsC), C.POINTER(_P), C.POINTER(C.c_int64),
+                                       _P, C.POINTER(_P), C.POINTER(C.c_int64), _P]),
     "mis_debug_launch_floor": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_double)]),
 }
 

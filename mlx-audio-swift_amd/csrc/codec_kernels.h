@@ -1,0 +1,28 @@
+// codec_kernels.h - f32 kernels shared by the codec back ends (SNAC decoder, Soprano / Vocos decoder); defined in snac.hip
+#pragma once
+#include "common.h"
+
+enum { GEMM_PLAIN = 0, GEMM_RESID = 1, GEMM_NOISE = 2, GEMM_CONVT = 3, GEMM_GELU = 4 };
+
+// Y[b][m][n] = sum_k A[m][k] X[b][k][n] on v_mfma_f32_32x32x2_f32 (activations NCT, time contiguous)
+struct GemmParams {
+    const float* AT;      // [K][M]   (CONVT: [s][K][M], K = 2*Cin)
+    const float* bias;    // [M] or null
+    const float* X;       // [B][Kx][Tin]  (Kx = K; CONVT: Cin)
+    float* Y;             // [B][M][Tout]
+    const float* R;       // RESID: [B][M][N]
+    const float* scale;   // RESID: optional per-row scale of (acc + bias)  (ConvNeXt gamma)
+    const float* noise;   // NOISE: explicit [B][N], or null
+    int noise_rng;        // NOISE with noise == null: 1 = draw N(0,1) from the documented generator, 0 = zeros
+    uint64_t noise_key;   // (seed, block) key of the generator
+    const int32_t* row_ids;   // optional global row id per batch row (rng keyed by GLOBAL row)
+    int64_t row_offset;
+    const float* alpha;   // Snake prologue on X rows (null = none)
+    const float* ralpha;
+    int M, K, N;          // N = output columns per phase
+    int Tin, Tout;
+    int s, pad, Cin;      // CONVT only
+};
+void launch_gemm(int mode, bool snake, const GemmParams& p, int batch, hipStream_t s);
+// depthwise 7-tap conv (zero padded, dilation dil): shorter odd kernels ride in centred 7-tap weights
+void launch_dw7(const float* X, float* Y, const float* w7 /*[C][7]*/, const float* bias, int batch, int C, int T, int dil, hipStream_t s);

@@ -23,3 +23,13 @@ const mis_snac_config* snac_config(const mis_snac* c);
 
 // mel.hip
 void whisper_features_device(int device, const float* pcm_dev, int batch, int n_mels, float* out_dev, hipStream_t s);
+
+// lm_engine.hip hooks used by soprano.hip
+struct mis_tts;
+hipStream_t tts_stream(mis_tts* c);
+int tts_hidden_size(const mis_tts* c);
+int tts_device(const mis_tts* c);
+// generate collecting model.norm(h) per step (row b: n_hidden[b] states, first = last prompt token), stop token ends a row
+void tts_generate_hidden(mis_tts* c, const int32_t* prompt_ids, const int32_t* prompt_lens, int batch, const mis_gen_params* gp,
+                         int stop_id, DevBuf<float>& hidden, std::vector<int32_t>& n_hidden, std::vector<int32_t>& n_tokens,
+                         std::vector<int32_t>& tokens, int64_t& tokens_stride);

@@ -35,6 +35,7 @@ struct mis_tts {
     DevBuf<bf16_t> wgu;        // [L] packed [2*ff/16][d/32]  (gate/up tiles interleaved)
     DevBuf<bf16_t> wdown;      // [L] packed [d/16][ff/32]
     DevBuf<bf16_t> norms;      // [L][2][d] + [d]
+    DevBuf<bf16_t> qknorm;     // [L][2][D] (qk_norm models)
     DevBuf<bf16_t> staging;    // row-major bf16 staging for one tensor
     DevBuf<uint8_t> raw_staging;
 
@@ -48,7 +49,7 @@ struct mis_tts {
     DevBuf<int32_t> ids, pos_cur, pos_next;
     DevBuf<uint8_t> active;
     DevBuf<bf16_t> h, x, attn_out, act, logits;
-    DevBuf<float> qkv_part, part, e_buf, logits_f32;
+    DevBuf<float> qkv_part, part, e_buf, logits_f32, samp_l32;
     // generation state
     DevBuf<int32_t> prompt_mat, prompt_lens, step_counter, window, window_len, n_gen, tokens_out, all_ids, all_len,
         done_count, codes, n_codes, l0, l1, l2, row_map;
@@ -104,6 +105,7 @@ extern "C" mis_status mis_tts_create(const mis_lm_config* cfg, mis_snac* codec, 
     c->wgu.alloc(layer_gu_elems(c) * c->L);
     c->wdown.alloc(layer_down_elems(c) * c->L);
     c->norms.alloc((size_t)(2 * c->L + 1) * d);
+    if (c->cfg.qk_norm) c->qknorm.alloc((size_t)2 * c->L * D);
     c->use_graph = getenv("MIS_NO_GRAPH") == nullptr;
     *out = c;
     MIS_API_END
@@ -178,6 +180,8 @@ static bf16_t* norm_slot(mis_tts* c, const std::string& name) {
     int li = atoi(name.substr(p1, p2 - p1).c_str());
     if (li < 0 || li >= c->L) return nullptr;
     std::string rest = name.substr(p2 + 1);
+    if (c->cfg.qk_norm && rest == "self_attn.q_norm.weight") return c->qknorm.p + (size_t)(2 * li) * c->D;
+    if (c->cfg.qk_norm && rest == "self_attn.k_norm.weight") return c->qknorm.p + (size_t)(2 * li + 1) * c->D;
     if (rest == "input_layernorm.weight") return c->norms.p + (size_t)(2 * li) * c->d;
     if (rest == "post_attention_layernorm.weight") return c->norms.p + (size_t)(2 * li + 1) * c->d;
     return nullptr;
@@ -201,7 +205,8 @@ extern "C" mis_status mis_tts_set_tensor(mis_tts* c, const char* name_, const vo
     HIP_CHECK(hipMemcpyAsync(c->raw_staging.p, data, n * esz, hipMemcpyDefault, c->stream));
     if (ndim == 1) {
         bf16_t* slot = norm_slot(c, name);
-        MIS_REQUIRE(slot && (int64_t)n == c->d, MIS_ERR_INVALID_INPUT, "unexpected 1-D tensor %s", name.c_str());
+        bool is_qk = name.find("_norm.weight") != std::string::npos && name.find("self_attn.") != std::string::npos;
+        MIS_REQUIRE(slot && (int64_t)n == (is_qk ? c->D : c->d), MIS_ERR_INVALID_INPUT, "unexpected 1-D tensor %s", name.c_str());
         launch_convert_to_bf16(c->raw_staging.p, dtype, slot, n, c->stream);
     } else {
         MIS_REQUIRE(ndim == 2, MIS_ERR_INVALID_INPUT, "tensor %s must be 1-D or 2-D", name.c_str());
@@ -230,7 +235,8 @@ extern "C" mis_status mis_tts_init_synthetic(mis_tts* c, uint64_t seed) {
         c->loaded.insert(name);
     };
     auto vec = [&](const std::string& name, uint64_t key) {
-        launch_synth_fill_bf16(norm_slot(c, name), (size_t)d, base + key, 0.1f, 1, s);
+        bool is_qk = name.find("self_attn.") != std::string::npos;
+        launch_synth_fill_bf16(norm_slot(c, name), (size_t)(is_qk ? c->D : d), base + key, 0.1f, 1, s);
         c->loaded.insert(name);
     };
     mat("model.embed_tokens.weight", 1, c->V, d, 0.5 * sqrt(3.0));
@@ -248,6 +254,7 @@ extern "C" mis_status mis_tts_init_synthetic(mis_tts* c, uint64_t seed) {
         mat(p + ".mlp.gate_proj.weight", k + 6, ff, d, sqrt(3.0 / d));
         mat(p + ".mlp.up_proj.weight", k + 7, ff, d, sqrt(3.0 / d));
         mat(p + ".mlp.down_proj.weight", k + 8, d, ff, sqrt(3.0 / ff) * 0.5);
+        if (c->cfg.qk_norm) { vec(p + ".self_attn.q_norm.weight", k + 9); vec(p + ".self_attn.k_norm.weight", k + 10); }
     }
     HIP_CHECK(hipGetLastError());
     HIP_CHECK(hipStreamSynchronize(s));
@@ -264,8 +271,13 @@ extern "C" mis_status mis_tts_finalize(mis_tts* c) {
     const char* per_layer[] = {"input_layernorm.weight", "post_attention_layernorm.weight", "self_attn.q_proj.weight",
                                "self_attn.k_proj.weight", "self_attn.v_proj.weight", "self_attn.o_proj.weight",
                                "mlp.gate_proj.weight", "mlp.up_proj.weight", "mlp.down_proj.weight"};
-    for (int li = 0; li < c->L; ++li)
+    for (int li = 0; li < c->L; ++li) {
         for (const char* r : per_layer) want.push_back("model.layers." + std::to_string(li) + "." + r);
+        if (c->cfg.qk_norm) {
+            want.push_back("model.layers." + std::to_string(li) + ".self_attn.q_norm.weight");
+            want.push_back("model.layers." + std::to_string(li) + ".self_attn.k_norm.weight");
+        }
+    }
     for (auto& w : want)
         MIS_REQUIRE(c->loaded.count(w), MIS_ERR_NOT_INITIALIZED, "LM weight missing: %s", w.c_str());
     if (c->cfg.tie_word_embeddings)        // embedTokens.asLinear, LlamaTTS.swift:563
@@ -316,6 +328,7 @@ static void build_rope_tables(mis_tts* c) {
         float smooth = (old / wl - low) / (high - low);
         float denom = (1.0f - smooth) / factor + smooth;
         float ff = med ? fs / denom : fs;
+        if (c->cfg.rope_plain) ff = f;                 // MLXNN.RoPE(dimensions, base): no rescale (Soprano.swift:56-61)
         inv[i] = 1.0f / ff;
     }
     std::vector<float> cs((size_t)c->Smax * half), sn((size_t)c->Smax * half);
@@ -388,6 +401,11 @@ static void enqueue_layers(mis_tts* c) {
         ap.rope_cos = c->rope_cos.p; ap.rope_sin = c->rope_sin.p;
         ap.out = c->attn_out.p; ap.H = c->H; ap.Hkv = c->Hkv; ap.D = c->D; ap.Smax = c->Smax;
         ap.scale = 1.0f / sqrtf((float)c->D);
+        if (c->cfg.qk_norm) {
+            ap.qnorm_w = c->qknorm.p + (size_t)(2 * li) * c->D;
+            ap.knorm_w = c->qknorm.p + (size_t)(2 * li + 1) * c->D;
+            ap.qk_eps = c->cfg.rms_norm_eps;
+        }
         launch_attn_decode(ap, c->batch, s);
         launch_gemm_skinny(EPI_PARTIAL, c->r_part, c->ksb_part, c->wo.p + layer_o_elems(c) * li, c->attn_out.p, c->part.p, d / 16, HD / 32,
                            c->S_o, d, Mpad, s);
@@ -429,7 +447,22 @@ __global__ void k_f32_rows_to_bf16(const float* __restrict__ src, int cols, bf16
     dst[(size_t)r * dst_stride + cidx] = f32_to_bf16(src[i]);
 }
 
+__global__ void k_unpack_x_f32(const bf16_t* __restrict__ x, float* __restrict__ out, int d, int batch, int MT) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (size_t)batch * d) return;
+    int m = (int)(i / d), k = (int)(i - (size_t)m * d);
+    size_t off = ((((size_t)(k >> 5) * MT + (m >> 4)) * 64) + (((k & 31) >> 3) << 4) + (m & 15)) * 8 + (k & 7);
+    out[i] = bf16_to_f32(x[off]);
+}
+
+extern "C" mis_status mis_lm_forward_hidden(mis_tts* c, const int32_t* ids, const uint8_t* active, float* logits_out,
+                                            float* hidden_out);
 extern "C" mis_status mis_lm_forward(mis_tts* c, const int32_t* ids, const uint8_t* active, float* logits_out) {
+    return mis_lm_forward_hidden(c, ids, active, logits_out, nullptr);
+}
+
+extern "C" mis_status mis_lm_forward_hidden(mis_tts* c, const int32_t* ids, const uint8_t* active, float* logits_out,
+                                            float* hidden_out) {
     MIS_API_BEGIN
     MIS_REQUIRE(c && ids, MIS_ERR_INVALID_INPUT, "null argument");
     MIS_REQUIRE(c->batch > 0, MIS_ERR_NOT_INITIALIZED, "call mis_lm_reset first");
@@ -450,6 +483,14 @@ extern "C" mis_status mis_lm_forward(mis_tts* c, const int32_t* ids, const uint8
     HIP_CHECK(hipMemcpyAsync(c->ids.p, ids, c->batch * 4, hipMemcpyDefault, s));
     HIP_CHECK(hipMemcpyAsync(c->active.p, act.data(), c->batch, hipMemcpyHostToDevice, s));
     enqueue_layers(c);
+    if (hidden_out) {
+        size_t n = (size_t)c->batch * c->d;
+        c->logits_f32.alloc(std::max(n, c->logits_f32.n));
+        hipLaunchKernelGGL(k_unpack_x_f32, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, c->x.p, c->logits_f32.p, c->d,
+                           c->batch, c->Mpad / 16);
+        HIP_CHECK(hipMemcpyAsync(hidden_out, c->logits_f32.p, n * 4, hipMemcpyDefault, s));
+        HIP_CHECK(hipStreamSynchronize(s));
+    }
     if (logits_out) {
         enqueue_lm_head(c);
         c->logits_f32.alloc((size_t)c->batch * c->V);
@@ -498,6 +539,11 @@ extern "C" mis_status mis_sample_logits(int device, const float* logits, int bat
     sp.seed = params->seed; sp.row_offset = params->row_offset; sp.frame_constrained = params->frame_constrained;
     sp.lo = lo; sp.hi = hi; sp.eos_id = -1; sp.max_tokens = 1 << 30;
     sp.tokens_out = nullptr;
+    DevBuf<float> l32;
+    if (params->sampler_flavor == 1) {                  // Soprano: f32 per-occurrence penalty, no nucleus cut (see header)
+        l32.alloc((size_t)batch * Vpad);
+        sp.penalty_flavor = 1; sp.top_p = 1.0f; sp.logits32 = l32.p;
+    }
     launch_sampler(sp, batch, 0);
     HIP_CHECK(hipGetLastError());
     HIP_CHECK(hipMemcpy(tokens_out, toks.p, batch * 4, hipMemcpyDefault));
@@ -520,16 +566,44 @@ static double ms_between(hipEvent_t a, hipEvent_t b) {
     return ms;
 }
 
+// one block per row: hidden[b][slot][:] = unpack(x[b]); prefill: slot 0 (every step overwrites, the last one stays);
+// decode: rows still active after the sampler append at hid_count[b]++
+__global__ void k_collect_hidden(const bf16_t* __restrict__ x, const uint8_t* __restrict__ active, int32_t* __restrict__ hid_count,
+                                 float* __restrict__ out, int64_t stride_rows, int d, int MT, int prefill) {
+    const int b = blockIdx.x;
+    int slot = 0;
+    if (!prefill) {
+        if (!active[b]) return;
+        slot = hid_count[b];
+        if (slot >= stride_rows) return;
+    }
+    for (int k = threadIdx.x; k < d; k += blockDim.x) {
+        size_t off = ((((size_t)(k >> 5) * MT + (b >> 4)) * 64) + (((k & 31) >> 3) << 4) + (b & 15)) * 8 + (k & 7);
+        out[((size_t)b * stride_rows + slot) * d + k] = bf16_to_f32(x[off]);
+    }
+    __syncthreads();
+    if (!prefill && threadIdx.x == 0) hid_count[b] = slot + 1;
+}
+
+struct HiddenMode {            // Soprano: collect model.norm(h) per step instead of decoding SNAC frames
+    bool on = false;
+    int stop_id = -1;
+    DevBuf<float>* hidden = nullptr;      // [batch][max_tokens + 1][d]
+    std::vector<int32_t> n_hidden;
+};
+
 static void run_generate(mis_tts* c, const int32_t* prompt_ids, const int32_t* prompt_lens, int batch,
                          const mis_gen_params* gp, const float* const* snac_noise, float* pcm_dev, int64_t pcm_stride,
-                         bool want_tokens, mis_event_cb cb, void* user, const volatile int* cancel, GenOutputs& out) {
+                         bool want_tokens, mis_event_cb cb, void* user, const volatile int* cancel, GenOutputs& out,
+                         HiddenMode* hm = nullptr) {
     MIS_REQUIRE(c && c->finalized, MIS_ERR_NOT_INITIALIZED, "model not initialized");
-    MIS_REQUIRE(c->codec, MIS_ERR_NOT_INITIALIZED, "SNAC model not loaded");            // LlamaTTS.swift:672-674
+    const bool hidden_mode = hm && hm->on;
+    MIS_REQUIRE(hidden_mode || c->codec, MIS_ERR_NOT_INITIALIZED, "SNAC model not loaded");            // LlamaTTS.swift:672-674
     MIS_REQUIRE(prompt_ids && prompt_lens && gp, MIS_ERR_INVALID_INPUT, "null argument");
     MIS_REQUIRE(batch >= 1 && batch <= 64, MIS_ERR_INVALID_INPUT, "batch per GPU must be 1..64");
-    const mis_snac_config* sc = snac_config(c->codec);
-    MIS_REQUIRE(sc->n_codebooks == 3 && sc->vq_strides[0] == 4 && sc->vq_strides[1] == 2 && sc->vq_strides[2] == 1 &&
-                    sc->codebook_size == 4096,
+    const mis_snac_config* sc = hidden_mode ? nullptr : snac_config(c->codec);
+    MIS_REQUIRE(hidden_mode || (sc->n_codebooks == 3 && sc->vq_strides[0] == 4 && sc->vq_strides[1] == 2 &&
+                                sc->vq_strides[2] == 1 && sc->codebook_size == 4096),
                 MIS_ERR_INVALID_INPUT, "Orpheus framing needs a 3-level 4/2/1 SNAC codec with 4096-entry codebooks");
     HIP_CHECK(hipSetDevice(c->device));
     hipStream_t s = c->stream;
@@ -561,6 +635,7 @@ static void run_generate(mis_tts* c, const int32_t* prompt_ids, const int32_t* p
                 all[(size_t)b * all_stride + j] = flat[off + j];
             }
             int w = std::min(ctx, lens[b]);                 // processor.prompt(promptTokens), LlamaTTS.swift:695-696
+            if (gp->sampler_flavor == 1) w = 0;             // Soprano penalises generated tokens only (Soprano.swift:833-848)
             for (int j = 0; j < w; ++j) win[(size_t)b * ctx + (ctx - w) + j] = flat[off + lens[b] - w + j];
             wl[b] = w;
             alen[b] = lens[b];
@@ -591,7 +666,20 @@ static void run_generate(mis_tts* c, const int32_t* prompt_ids, const int32_t* p
     sp.next_ids = c->ids.p; sp.active = c->active.p; sp.done_count = c->done_count.p;
     sp.temperature = gp->temperature; sp.top_p = gp->top_p; sp.penalty = gp->repetition_penalty;
     sp.seed = gp->seed; sp.row_offset = gp->row_offset; sp.frame_constrained = gp->frame_constrained;
-    sp.lo = 0; sp.hi = 0; sp.eos_id = ORPHEUS_END_OF_SPEECH; sp.max_tokens = max_tokens;
+    sp.lo = 0; sp.hi = 0; sp.eos_id = hidden_mode ? hm->stop_id : ORPHEUS_END_OF_SPEECH; sp.max_tokens = max_tokens;
+    if (gp->sampler_flavor == 1) {
+        c->samp_l32.alloc((size_t)c->Mpad * c->Vpad);
+        sp.penalty_flavor = 1; sp.top_p = 1.0f; sp.logits32 = c->samp_l32.p;
+    }
+    DevBuf<int32_t> hid_count;
+    int64_t hid_rows = max_tokens + 1;
+    if (hidden_mode) {
+        hm->hidden->alloc((size_t)batch * hid_rows * c->d);
+        hid_count.alloc(batch);
+        std::vector<int32_t> ones_i(batch, 1);           // slot 0 = last prompt token (Soprano.swift:824-825)
+        HIP_CHECK(hipMemcpyAsync(hid_count.p, ones_i.data(), batch * 4, hipMemcpyHostToDevice, s));
+        HIP_CHECK(hipStreamSynchronize(s));
+    }
     c->sp = sp;
     {   // the captured graphs bake in every pointer and scalar below: re-capture when any of them changes
         uint64_t key = 1469598103934665603ull;
@@ -601,20 +689,29 @@ static void run_generate(mis_tts* c, const int32_t* prompt_ids, const int32_t* p
                               c->attn_out.p, c->act.p, c->logits.p, c->qkv_part.p, c->part.p, c->kcache.p, c->vtcache.p,
                               c->rope_cos.p, c->rope_sin.p, c->pos_cur.p, c->pos_next.p};
         mix(ptrs, sizeof(ptrs));
-        int ints[] = {batch, Lmax, max_tokens, c->Mpad, c->Smax, c->S_qkv, c->S_o, c->S_down};
+        int ints[] = {batch, Lmax, max_tokens, c->Mpad, c->Smax, c->S_qkv, c->S_o, c->S_down, hidden_mode ? 1 : 0};
         mix(ints, sizeof(ints));
+        const void* hp[] = {hidden_mode ? (const void*)hm->hidden->p : nullptr, hidden_mode ? (const void*)hid_count.p : nullptr};
+        mix(hp, sizeof(hp));
         if (key != c->graph_key) destroy_graphs(c);
         c->graph_key = key;
     }
 
+    auto collect = [&](int prefill) {
+        if (hidden_mode)
+            hipLaunchKernelGGL(k_collect_hidden, dim3(batch), dim3(256), 0, s, c->x.p, c->active.p, hid_count.p, hm->hidden->p,
+                               hid_rows, c->d, c->Mpad / 16, prefill);
+    };
     auto prefill_body = [&]() {
         launch_prefill_feed(c->prompt_mat.p, c->prompt_lens.p, Lmax, c->step_counter.p, c->ids.p, c->active.p, batch, s);
         enqueue_layers(c);
+        collect(1);
     };
     auto decode_body = [&]() {
         enqueue_lm_head(c);
         launch_sampler(c->sp, batch, s);
         enqueue_layers(c);
+        collect(0);
     };
     auto capture = [&](hipGraphExec_t* exec, auto&& body) {
         hipGraph_t g = nullptr;
@@ -681,6 +778,28 @@ static void run_generate(mis_tts* c, const int32_t* prompt_ids, const int32_t* p
         throw MisError(MIS_ERR_CANCELLED, "generation cancelled");
     }
 
+    if (hidden_mode) {
+        hm->n_hidden.resize(batch);
+        out.n_tokens.resize(batch);
+        HIP_CHECK(hipMemcpyAsync(hm->n_hidden.data(), hid_count.p, batch * 4, hipMemcpyDeviceToHost, s));
+        HIP_CHECK(hipMemcpyAsync(out.n_tokens.data(), c->n_gen.p, batch * 4, hipMemcpyDeviceToHost, s));
+        if (want_tokens) {
+            out.tokens.resize((size_t)batch * max_tokens);
+            out.tokens_stride = max_tokens;
+            HIP_CHECK(hipMemcpyAsync(out.tokens.data(), c->tokens_out.p, out.tokens.size() * 4, hipMemcpyDeviceToHost, s));
+        }
+        HIP_CHECK(hipStreamSynchronize(s));
+        // the graphs reference hid_count / hidden: never reuse them after this call
+        destroy_graphs(c);
+        c->graph_key = 0;
+        c->timing.prefill_ms = ms_between(ev[0], ev[1]);
+        c->timing.decode_ms = ms_between(ev[1], ev[2]);
+        c->timing.codec_ms = 0;
+        c->timing.steps = steps;
+        c->timing.step_ms_avg = steps ? c->timing.decode_ms / steps : 0;
+        for (auto& e2 : ev) (void)hipEventDestroy(e2);
+        return;
+    }
     // ---- parseOutput (:749-752) + de-interleave (:41-64) + SNAC decode (:759)
     c->codes.alloc((size_t)batch * all_stride); c->n_codes.alloc(batch);
     launch_orpheus_parse_output(c->all_ids.p, c->all_len.p, batch, all_stride, c->codes.p, c->n_codes.p, s);
@@ -952,6 +1071,10 @@ extern "C" mis_status mis_tts_load(const char* model_dir, mis_snac* codec, int d
         }
         cf.tie_word_embeddings = j.bool_or("tie_word_embeddings", true) ? 1 : 0;                     // default true :28
         cf.sample_rate = (int)j.number_or("sample_rate", 24000);
+        {   // Qwen3-style checkpoints (VyvoTTS): model_type "qwen3" => q/k norm + plain rope
+            const JsonValue* mt = j.get("model_type");
+            if (mt && mt->type == JsonValue::STR && mt->str.find("qwen3") != std::string::npos) { cf.qk_norm = 1; cf.rope_plain = 1; }
+        }
         mis_status st = mis_tts_create(&cf, codec, device, &c);
         if (st != MIS_OK) return st;
         for (auto& path : list_safetensors(dir)) {
@@ -1020,4 +1143,18 @@ extern "C" mis_status mis_debug_launch_floor(int device, int n_kernels, int mode
     (void)hipGraphExecDestroy(ge); (void)hipGraphDestroy(g);
     (void)hipStreamDestroy(s);
     MIS_API_END
+}
+
+// ---------------------------------------------------------------------------- Soprano hooks (soprano.hip)
+hipStream_t tts_stream(mis_tts* c) { return c->stream; }
+int tts_hidden_size(const mis_tts* c) { return c->d; }
+int tts_device(const mis_tts* c) { return c->device; }
+void tts_generate_hidden(mis_tts* c, const int32_t* prompt_ids, const int32_t* prompt_lens, int batch, const mis_gen_params* gp,
+                         int stop_id, DevBuf<float>& hidden, std::vector<int32_t>& n_hidden, std::vector<int32_t>& n_tokens,
+                         std::vector<int32_t>& tokens, int64_t& tokens_stride) {
+    HiddenMode hm;
+    hm.on = true; hm.stop_id = stop_id; hm.hidden = &hidden;
+    GenOutputs out;
+    run_generate(c, prompt_ids, prompt_lens, batch, gp, nullptr, nullptr, 0, true, nullptr, nullptr, nullptr, out, &hm);
+    n_hidden = hm.n_hidden; n_tokens = out.n_tokens; tokens = out.tokens; tokens_stride = out.tokens_stride;
 }

@@ -33,6 +33,9 @@ struct AttnParams {
     const uint8_t* active;   // [Mpad]
     const float* rope_cos;   // [Smax][D/2]; null = no rotary (Whisper)
     const float* rope_sin;
+    const bf16_t* qnorm_w;   // [D] per-head q RMSNorm weight (Qwen3-style), null = none
+    const bf16_t* knorm_w;   // [D]
+    float qk_eps;
     int cross;               // 1: cross attention - queries only, no append, keys 0..cross_len-1 of the given caches
     int cross_len;
     bf16_t* out;             // [Mpad][H*D]
@@ -56,6 +59,7 @@ struct SamplerParams {
     int n_chunks, chunk_w;   // vocabulary split (sampler_plan)
     bf16_t* logits;          // [Mpad][Vpad]  (penalty is applied in place)
     float* e_buf;            // [Mpad][Vpad] scratch
+    float* logits32;         // [Mpad][Vpad] float32 processed logits (penalty_flavor 1), else null
     int Vpad, vocab;
     const uint8_t* active_in;   // rows to sample (null = all)
     // generation state (all device memory)
@@ -74,6 +78,7 @@ struct SamplerParams {
     int32_t* step_override;  // null, or [B] explicit RNG step (stand-alone sampling)
     // parameters
     float temperature, top_p, penalty;
+    int penalty_flavor;      // 0 mlx-lm RepetitionContext (unique ids, bf16); 1 Soprano (per occurrence, f32, sign rule > 0)
     uint64_t seed;
     int64_t row_offset;
     int frame_constrained;

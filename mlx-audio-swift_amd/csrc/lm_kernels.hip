@@ -551,6 +551,20 @@ __global__ void __launch_bounds__(512) k_attn_decode(AttnParams p) {
     }
     for (int idx = tid; idx < 16 * D; idx += 512) qs[idx] = 0;
     __syncthreads();
+    if (p.qnorm_w) {
+        // Qwen3-style per-head RMSNorm of q and k BEFORE RoPE (Soprano.swift:75-76): n = T(x rsqrt(mean x^2 + eps)), T(w n)
+        const int n_rows = p.cross ? G : G + 1;
+        for (int row = wave; row < n_rows; row += ATT_WAVES) {
+            float ss = 0.0f;
+            for (int d = lane; d < D; d += 64) { float v = sraw[row * D + d]; ss += v * v; }
+            ss = wave_sum(ss);
+            const float inv = 1.0f / sqrtf(ss / (float)D + p.qk_eps);
+            const bf16_t* w = (row < G) ? p.qnorm_w : p.knorm_w;
+            for (int d = lane; d < D; d += 64)
+                sraw[row * D + d] = bf16_round_f32(bf16_to_f32(w[d]) * bf16_round_f32(sraw[row * D + d] * inv));
+        }
+        __syncthreads();
+    }
     // ---- RoPE (rotate-half, pair (i, i + D/2), angle pos / freqs[i]; LlamaTTS.swift:192-200) + cache append
     bf16_t* kc = p.kcache + ((size_t)(b * p.Hkv + kvh) * p.Smax) * D;
     bf16_t* vt = p.vtcache + ((size_t)(b * p.Hkv + kvh) * D) * p.Smax;

@@ -94,6 +94,12 @@ __global__ void __launch_bounds__(64) k_samp_prepare(SamplerParams p) {
     SamplerScratch* sc = p.scratch + b;
     for (int i = tid; i < 256; i += 64) { sc->hist1[i] = 0; sc->hist2[i] = 0; }
     if (row_skipped(p, b)) return;
+    if (p.logits32) {                                   // Soprano flavour: the processed logits are float32
+        const bf16_t* src = p.logits + (size_t)b * p.Vpad;
+        float* dst = p.logits32 + (size_t)b * p.Vpad;
+        for (int i = tid; i < p.vocab; i += 64) dst[i] = bf16_to_f32(src[i]);
+        __syncthreads();
+    }
     if (p.penalty > 0.0f && p.penalty != 1.0f && p.window) {
         bf16_t* logits = p.logits + (size_t)b * p.Vpad;
         int wl = p.window_len[b];
@@ -103,10 +109,20 @@ __global__ void __launch_bounds__(64) k_samp_prepare(SamplerParams p) {
             bool first = (id >= 0 && id < p.vocab);
             for (int j = 0; j < t; ++j) first = first && (win[j] != id);
             if (first) {
-                float pen = bf16_round_f32(p.penalty);            // scalar weakly typed to bf16
                 float l = bf16_to_f32(logits[id]);
-                float v = (l < 0.0f) ? l * pen : __fdiv_rn(l, pen);
-                logits[id] = f32_to_bf16(v);
+                float v;
+                if (p.penalty_flavor == 0) {
+                    float pen = bf16_round_f32(p.penalty);        // scalar weakly typed to bf16
+                    v = (l < 0.0f) ? l * pen : __fdiv_rn(l, pen);
+                } else {
+                    // Soprano applyRepetitionPenalty (Soprano.swift:888-901): float32, once PER OCCURRENCE in the window
+                    int mult = 0;
+                    for (int j = 0; j < wl; ++j) mult += (win[j] == id);
+                    v = l;
+                    for (int k = 0; k < mult; ++k) v = (v > 0.0f) ? __fdiv_rn(v, p.penalty) : v * p.penalty;
+                }
+                if (p.logits32) p.logits32[(size_t)b * p.Vpad + id] = v;
+                else logits[id] = f32_to_bf16(v);
             }
         }
     }
@@ -124,10 +140,11 @@ __global__ void __launch_bounds__(SAMP_NT) k_samp_max(SamplerParams p) {
     if (i0 < lo) i0 = lo;
     if (i1 > hi) i1 = hi;
     const bf16_t* logits = p.logits + (size_t)b * p.Vpad;
+    const float* l32 = p.logits32 ? p.logits32 + (size_t)b * p.Vpad : nullptr;
     float best = -INFINITY;
     int bi = 0x7fffffff;
     for (int i = i0 + tid; i < i1; i += SAMP_NT) {
-        float l = bf16_to_f32(logits[i]);
+        float l = l32 ? l32[i] : bf16_to_f32(logits[i]);
         if (l > best) { best = l; bi = i; }               // ascending i per thread: first index kept on ties
     }
 #pragma unroll
@@ -163,10 +180,11 @@ __global__ void __launch_bounds__(SAMP_NT) k_samp_exp(SamplerParams p) {
     hist[tid] = 0;
     __syncthreads();
     const bf16_t* logits = p.logits + (size_t)b * p.Vpad;
+    const float* l32 = p.logits32 ? p.logits32 + (size_t)b * p.Vpad : nullptr;
     float* ebuf = p.e_buf + (size_t)b * p.Vpad;
     const float xmax = __fdiv_rn(row_max(p, b), p.temperature);      // fdiv is monotone: max x = fdiv(max l, T)
     for (int i = i0 + tid; i < i1; i += SAMP_NT) {
-        float x = __fdiv_rn(bf16_to_f32(logits[i]), p.temperature);
+        float x = __fdiv_rn(l32 ? l32[i] : bf16_to_f32(logits[i]), p.temperature);
         float y = fminf(x - xmax, 0.0f);
         float e = det_exp_dev(y);
         if (i < lo || i >= hi) e = 0.0f;
@@ -339,7 +357,8 @@ __global__ void __launch_bounds__(SAMP_NT) k_samp_pick(SamplerParams p, int gree
                 if (n < p.all_stride) { p.all_ids[(size_t)b * p.all_stride + n] = token; p.all_len[b] = n + 1; }
             }
             if (p.n_gen && !p.step_override && step + 1 >= p.max_tokens) {
-                if (p.active) p.active[b] = 0;            // budget exhausted (LlamaTTS.swift:714)
+                // budget exhausted (LlamaTTS.swift:714): the row stays active for the forward pass of this last
+                // token (Soprano needs its hidden state, Soprano.swift:871-876); later sampler calls skip the row
                 if (p.done_count) atomicAdd(p.done_count, 1);
             }
         }

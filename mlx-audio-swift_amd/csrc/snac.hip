@@ -14,6 +14,7 @@
 //   k_snac_final   Snake -> conv k7 (C -> 1) -> tanh
 #include "common.h"
 #include "kernels.h"
+#include "codec_kernels.h"
 
 #include <math.h>
 #include <string.h>
@@ -106,26 +107,6 @@ __global__ void __launch_bounds__(256) k_snac_dw(const float* __restrict__ X, fl
 }
 
 // ---- dense contraction on f32 MFMA ----------------------------------------------------------------
-enum { GEMM_PLAIN = 0, GEMM_RESID = 1, GEMM_NOISE = 2, GEMM_CONVT = 3 };
-
-struct GemmParams {
-    const float* AT;      // [K][M]   (CONVT: [s][K][M], K = 2*Cin)
-    const float* bias;    // [M] or null
-    const float* X;       // [B][Kx][Tin]  (Kx = K; CONVT: Cin)
-    float* Y;             // [B][M][Tout]
-    const float* R;       // RESID: [B][M][N]
-    const float* noise;   // NOISE: explicit [B][N], or null
-    int noise_rng;        // NOISE with noise == null: 1 = draw N(0,1) from the documented generator, 0 = zeros
-    uint64_t noise_key;   // (seed, block) key of the generator
-    const int32_t* row_ids;   // optional global row id per batch row (rng keyed by GLOBAL row)
-    int64_t row_offset;
-    const float* alpha;   // Snake prologue on X rows (null = none)
-    const float* ralpha;
-    int M, K, N;          // N = output columns per phase
-    int Tin, Tout;
-    int s, pad, Cin;      // CONVT only
-};
-
 #define G_BM 64
 #define G_BN 128
 #define G_BK 16
@@ -246,8 +227,11 @@ __global__ void __launch_bounds__(256) k_snac_gemm(GemmParams p) {
             if (p.bias) v += p.bias[m];
             if (MODE == GEMM_PLAIN) {
                 p.Y[((size_t)b * p.M + m) * p.Tout + n] = v;
+            } else if (MODE == GEMM_GELU) {                            // exact-erf GELU (VocosBackbone.swift:89)
+                p.Y[((size_t)b * p.M + m) * p.Tout + n] = 0.5f * v * (1.0f + erff(v * 0.70710678118654752f));
             } else if (MODE == GEMM_RESID) {
                 size_t o = ((size_t)b * p.M + m) * p.Tout + n;
+                if (p.scale) v *= p.scale[m];                          // ConvNeXt layer scale gamma (VocosBackbone.swift:92-95)
                 p.Y[o] = p.R[o] + v;                                   // Layers.swift:230
             } else if (MODE == GEMM_NOISE) {
                 size_t o = ((size_t)b * p.M + m) * p.Tout + n;
@@ -548,10 +532,16 @@ extern "C" int64_t mis_snac_noise_len(const mis_snac* c, int block, int t_coarse
 }
 
 // ---------------------------------------------------------------------------- pipeline
-static void launch_gemm(int mode, bool snake, const GemmParams& p, int batch, hipStream_t s) {
+void launch_dw7(const float* X, float* Y, const float* w7, const float* bias, int batch, int C, int T, int dil, hipStream_t s) {
+    hipLaunchKernelGGL((k_snac_dw<false, false>), dim3(cdiv(T, DW_TILE), C, batch), dim3(256), 0, s, X, Y, w7, bias, nullptr,
+                       nullptr, nullptr, nullptr, C, T, dil);
+}
+
+void launch_gemm(int mode, bool snake, const GemmParams& p, int batch, hipStream_t s) {
     int phases = (mode == GEMM_CONVT) ? p.s : 1;
     dim3 grid(cdiv(p.N, G_BN), cdiv(p.M, G_BM), batch * phases), block(256);
     if (mode == GEMM_PLAIN) hipLaunchKernelGGL((k_snac_gemm<GEMM_PLAIN, false>), grid, block, 0, s, p);
+    else if (mode == GEMM_GELU) hipLaunchKernelGGL((k_snac_gemm<GEMM_GELU, false>), grid, block, 0, s, p);
     else if (mode == GEMM_RESID) hipLaunchKernelGGL((k_snac_gemm<GEMM_RESID, false>), grid, block, 0, s, p);
     else if (mode == GEMM_NOISE) hipLaunchKernelGGL((k_snac_gemm<GEMM_NOISE, false>), grid, block, 0, s, p);
     else { MIS_REQUIRE(snake, MIS_ERR_GENERATION_FAILED, "convT without snake"); hipLaunchKernelGGL((k_snac_gemm<GEMM_CONVT, true>), grid, block, 0, s, p); }

@@ -1,0 +1,374 @@
+// soprano.hip - Soprano TTS: Qwen3-style token LM (lm_engine.hip, q/k-norm variant) whose per-token hidden states
+// are decoded by a Vocos / ConvNeXt backbone + ISTFT head, all in float32 on the GPU.
+//
+// Reference being replaced: SopranoModel / SopranoDecoder / ISTFTHead / interpolate1d
+// (Sources/MLXAudioTTS/Models/Soprano/Soprano.swift:201-690,801-901, SopranoDecoder.swift:22-284) and
+// VocosBackbone / ConvNeXtBlock (Sources/MLXAudioCodecs/Vocos/VocosBackbone.swift:18-204).  The reference runs
+// the ISTFT overlap-add as a Swift host loop over asArray copies (SopranoDecoder.swift:161-186); here the irfft is
+// an exact-f32 MFMA contraction against a host-built inverse-DFT table and the overlap-add is one gather kernel.
+// Activations are NCT ([B][C][T], time contiguous) so the f32 codec kernels of snac.hip are reused unchanged.
+#include "common.h"
+#include "kernels.h"
+#include "codec_kernels.h"
+
+#include <math.h>
+#include <string.h>
+#include <algorithm>
+
+struct mis_soprano {
+    int device = 0;
+    mis_soprano_config cfg{};
+    mis_tts* lm = nullptr;
+    std::map<std::string, std::vector<float>> raw;
+    std::map<std::string, std::vector<int64_t>> raw_shape;
+    bool finalized = false;
+    DevBuf<float> arena;
+    size_t embed_w = 0, embed_b = 0, norm_w = 0, norm_b = 0, fin_w = 0, fin_b = 0, head_w = 0, head_b = 0, idft = 0, window = 0;
+    struct Blk { size_t dw, dwb, lnw, lnb, p1, b1, p2, b2, gamma; };
+    std::vector<Blk> blocks;
+    DevBuf<float> buf[4];
+    DevBuf<float> hidden;
+};
+
+// ---------------------------------------------------------------------------- kernels
+// hidden [B][L][C] -> x [B][C][T], T = up*(L-1)+1, linear interpolation with align_corners (SopranoDecoder.swift:22-80)
+__global__ void k_sop_interp(const float* __restrict__ hid, int64_t hid_row_stride, float* __restrict__ x, int L, int C, int T) {
+    int t = blockIdx.x * blockDim.x + threadIdx.x, c = blockIdx.y, b = blockIdx.z;
+    if (t >= T) return;
+    float v;
+    const float* hb = hid + (size_t)b * hid_row_stride * C;
+    if (L == 1 || T == L) v = hb[(size_t)(L == 1 ? 0 : t) * C + c];
+    else {
+        float pos = (float)t * ((float)(L - 1) / (float)(T - 1));
+        int lo = (int)floorf(pos);
+        int hi = min(lo + 1, L - 1);
+        float fr = pos - (float)lo;
+        v = hb[(size_t)lo * C + c] * (1.0f - fr) + hb[(size_t)hi * C + c] * fr;
+    }
+    x[((size_t)b * C + c) * T + t] = v;
+}
+
+// [B][C][T] -> [B][k*C][T]: row kk*C + c holds x[c][t + kk - k/2] (zero outside)   (Conv1d padding k/2)
+__global__ void k_sop_im2col(const float* __restrict__ x, float* __restrict__ y, int C, int T, int k) {
+    int t = blockIdx.x * blockDim.x + threadIdx.x, r = blockIdx.y, b = blockIdx.z;
+    if (t >= T) return;
+    int kk = r / C, c = r - kk * C;
+    int ts = t + kk - k / 2;
+    y[((size_t)b * k * C + r) * T + t] = (ts >= 0 && ts < T) ? x[((size_t)b * C + c) * T + ts] : 0.0f;
+}
+
+// LayerNorm over the CHANNEL axis of NCT data (eps 1e-6): thread = one time step, loops over C (coalesced over t)
+__global__ void k_sop_ln_ct(const float* __restrict__ x, float* __restrict__ y, const float* __restrict__ w,
+                            const float* __restrict__ bias, int C, int T, float eps) {
+    int t = blockIdx.x * blockDim.x + threadIdx.x, b = blockIdx.y;
+    if (t >= T) return;
+    const float* xb = x + (size_t)b * C * T + t;
+    float s = 0.0f;
+    for (int c = 0; c < C; ++c) s += xb[(size_t)c * T];
+    float mean = s / (float)C, q = 0.0f;
+    for (int c = 0; c < C; ++c) { float d = xb[(size_t)c * T] - mean; q += d * d; }
+    float rstd = 1.0f / sqrtf(q / (float)C + eps);
+    float* yb = y + (size_t)b * C * T + t;
+    for (int c = 0; c < C; ++c) yb[(size_t)c * T] = (xb[(size_t)c * T] - mean) * rstd * w[c] + bias[c];
+}
+
+// head output hh [B][n_fft+2][T] -> spec [B][2*bins][T]: rows 0..bins-1 = mag*cos(phase), bins.. = mag*sin(phase),
+// mag = min(exp(.), 100)   (SopranoDecoder.swift:109-122)
+__global__ void k_sop_spec(const float* __restrict__ hh, float* __restrict__ spec, int bins, int T) {
+    int t = blockIdx.x * blockDim.x + threadIdx.x, k = blockIdx.y, b = blockIdx.z;
+    if (t >= T) return;
+    const float* hb = hh + (size_t)b * 2 * bins * T;
+    float mag = fminf(expf(hb[(size_t)k * T + t]), 100.0f);
+    float ph = hb[(size_t)(bins + k) * T + t];
+    float* sb = spec + (size_t)b * 2 * bins * T;
+    sb[(size_t)k * T + t] = mag * cosf(ph);
+    sb[(size_t)(bins + k) * T + t] = mag * sinf(ph);
+}
+
+// frames [B][n_fft][T] -> audio [B][out_stride]: windowed overlap-add normalised by the window SUM, trimmed by n_fft/2
+// at both ends (SopranoDecoder.swift:155-195)
+__global__ void k_sop_ola(const float* __restrict__ frames, const float* __restrict__ window, float* __restrict__ audio,
+                          int64_t out_stride, int n_fft, int hop, int T) {
+    int s = blockIdx.x * blockDim.x + threadIdx.x, b = blockIdx.y;
+    int n_out = (T - 1) * hop;
+    if (s >= n_out) return;
+    int sp = s + n_fft / 2;
+    int i1 = min(sp / hop, T - 1);
+    int i0 = max(0, (sp - n_fft + hop) / hop);
+    const float* fb = frames + (size_t)b * n_fft * T;
+    float acc = 0.0f, ws = 0.0f;
+    for (int i = i0; i <= i1; ++i) {
+        int j = sp - i * hop;
+        if (j < 0 || j >= n_fft) continue;
+        float w = window[j];
+        acc += fb[(size_t)j * T + i] * w;
+        ws += w;
+    }
+    audio[(size_t)b * out_stride + s] = (ws != 0.0f) ? acc / ws : acc;
+}
+
+// ---------------------------------------------------------------------------- host
+static std::string sop_sanitize(const std::string& key) {          // SopranoModel.sanitize, Soprano.swift:314-361
+    std::string k = key;
+    if (k.rfind("model.", 0) == 0) k = k.substr(6);
+    if (k.rfind("decoder.", 0) == 0) return k;
+    if (k.rfind("language_model.lm_head", 0) == 0) return k.substr(strlen("language_model."));
+    if (k.rfind("language_model.", 0) == 0) return "model." + k.substr(strlen("language_model."));
+    if (k.rfind("lm_head", 0) == 0) return k;
+    return "model." + k;
+}
+
+extern "C" mis_status mis_soprano_create(const mis_soprano_config* cfg, int device, mis_soprano** out) {
+    MIS_API_BEGIN
+    MIS_REQUIRE(cfg && out, MIS_ERR_INVALID_INPUT, "null argument");
+    MIS_REQUIRE(cfg->decoder_num_layers >= 0 && cfg->decoder_dim > 0 && cfg->decoder_intermediate_dim > 0, MIS_ERR_INVALID_INPUT, "bad decoder dims");
+    MIS_REQUIRE(cfg->n_fft >= 8 && cfg->n_fft % 2 == 0 && cfg->hop_length >= 1 && cfg->upscale >= 1, MIS_ERR_INVALID_INPUT, "bad ISTFT config");
+    MIS_REQUIRE(cfg->input_kernel >= 1 && cfg->input_kernel % 2 == 1 && cfg->dw_kernel >= 1 && cfg->dw_kernel <= 7 && cfg->dw_kernel % 2 == 1,
+                MIS_ERR_INVALID_INPUT, "input_kernel must be odd, dw_kernel odd and <= 7");
+    mis_lm_config lmc = cfg->lm;
+    lmc.qk_norm = 1;                                   // SopranoAttention: q_norm / k_norm, plain RoPE (Soprano.swift:38-61)
+    lmc.rope_plain = 1;
+    mis_tts* lm = nullptr;
+    mis_status st = mis_tts_create(&lmc, nullptr, device, &lm);
+    if (st != MIS_OK) return st;
+    mis_soprano* c = new mis_soprano();
+    c->device = device; c->cfg = *cfg; c->cfg.lm = lmc; c->lm = lm;
+    *out = c;
+    MIS_API_END
+}
+extern "C" void mis_soprano_destroy(mis_soprano* c) {
+    if (!c) return;
+    if (c->lm) mis_tts_destroy(c->lm);
+    (void)hipSetDevice(c->device);
+    delete c;
+}
+extern "C" mis_tts* mis_soprano_lm(mis_soprano* c) { return c ? c->lm : nullptr; }
+
+extern "C" mis_status mis_soprano_set_tensor(mis_soprano* c, const char* name_, const void* data, mis_dtype dtype,
+                                             const int64_t* shape, int ndim) {
+    MIS_API_BEGIN
+    MIS_REQUIRE(c && name_ && data && shape && ndim >= 1 && ndim <= 3, MIS_ERR_INVALID_INPUT, "bad argument");
+    MIS_REQUIRE(!c->finalized, MIS_ERR_INVALID_INPUT, "set_tensor after finalize");
+    std::string name = sop_sanitize(name_);
+    if (name.rfind("decoder.", 0) != 0) return mis_tts_set_tensor(c->lm, name.c_str(), data, dtype, shape, ndim);
+    size_t n = 1;
+    std::vector<int64_t> sh;
+    for (int i = 0; i < ndim; ++i) { MIS_REQUIRE(shape[i] > 0, MIS_ERR_INVALID_INPUT, "bad shape"); n *= (size_t)shape[i]; sh.push_back(shape[i]); }
+    HIP_CHECK(hipSetDevice(c->device));
+    size_t esz = dtype == MIS_F32 ? 4 : 2;
+    std::vector<uint8_t> host(n * esz);
+    HIP_CHECK(hipMemcpy(host.data(), data, n * esz, hipMemcpyDefault));
+    std::vector<float> v(n);                                         // decoder weights are float32 (Soprano.swift:332-339)
+    if (dtype == MIS_F32) memcpy(v.data(), host.data(), n * 4);
+    else if (dtype == MIS_BF16) for (size_t i = 0; i < n; ++i) v[i] = bf16_to_f32(((uint16_t*)host.data())[i]);
+    else if (dtype == MIS_F16) for (size_t i = 0; i < n; ++i) v[i] = f16_to_f32_host(((uint16_t*)host.data())[i]);
+    else throw MisError(MIS_ERR_INVALID_INPUT, "unsupported dtype");
+    c->raw[name] = std::move(v);
+    c->raw_shape[name] = sh;
+    MIS_API_END
+}
+
+static const std::vector<float>& sneed(mis_soprano* c, const std::string& name, std::initializer_list<int64_t> shape) {
+    auto it = c->raw.find(name);
+    MIS_REQUIRE(it != c->raw.end(), MIS_ERR_NOT_INITIALIZED, "Soprano weight missing: %s", name.c_str());
+    MIS_REQUIRE(c->raw_shape[name] == std::vector<int64_t>(shape), MIS_ERR_INVALID_INPUT, "Soprano weight %s has the wrong shape", name.c_str());
+    return it->second;
+}
+
+extern "C" mis_status mis_soprano_finalize(mis_soprano* c) {
+    MIS_API_BEGIN
+    MIS_REQUIRE(c && !c->finalized, MIS_ERR_INVALID_INPUT, "bad handle");
+    mis_status st = mis_tts_finalize(c->lm);
+    if (st != MIS_OK) return st;
+    HIP_CHECK(hipSetDevice(c->device));
+    const mis_soprano_config& cf = c->cfg;
+    const int64_t C = cf.lm.hidden_size, d = cf.decoder_dim, inter = cf.decoder_intermediate_dim, nf = cf.n_fft, bins = nf / 2 + 1;
+    const int64_t ik = cf.input_kernel, dk = cf.dw_kernel;
+    std::vector<float> arena;
+    auto push = [&](const std::vector<float>& v) { size_t o = arena.size(); arena.insert(arena.end(), v.begin(), v.end()); while (arena.size() & 3) arena.push_back(0.f); return o; };
+    auto transpose = [&](const std::vector<float>& w, int64_t out_f, int64_t in_f) {       // [out][in] -> A^T [in][out]
+        std::vector<float> at((size_t)in_f * out_f);
+        for (int64_t o = 0; o < out_f; ++o) for (int64_t i = 0; i < in_f; ++i) at[i * out_f + o] = w[o * in_f + i];
+        return at;
+    };
+    const std::string P = "decoder.decoder";
+    {   // embed conv: weight [d][ik][C] (MLX Conv1d) == [d][ik*C] row-major with column kk*C + c
+        const auto& w = sneed(c, P + ".embed.weight", {d, ik, C});
+        c->embed_w = push(transpose(w, d, ik * C));
+        c->embed_b = push(sneed(c, P + ".embed.bias", {d}));
+    }
+    c->norm_w = push(sneed(c, P + ".norm.weight", {d})); c->norm_b = push(sneed(c, P + ".norm.bias", {d}));
+    c->blocks.clear();
+    for (int i = 0; i < cf.decoder_num_layers; ++i) {
+        std::string q = P + ".convnext." + std::to_string(i);
+        mis_soprano::Blk b{};
+        const auto& dw = sneed(c, q + ".dwconv.weight", {d, dk, 1});
+        std::vector<float> w7((size_t)d * 7, 0.0f);                    // centre the dk taps in a 7-tap kernel
+        for (int64_t ch = 0; ch < d; ++ch) for (int64_t j = 0; j < dk; ++j) w7[ch * 7 + (3 - dk / 2) + j] = dw[ch * dk + j];
+        b.dw = push(w7); b.dwb = push(sneed(c, q + ".dwconv.bias", {d}));
+        b.lnw = push(sneed(c, q + ".norm.weight", {d})); b.lnb = push(sneed(c, q + ".norm.bias", {d}));
+        b.p1 = push(transpose(sneed(c, q + ".pwconv1.weight", {inter, d}), inter, d)); b.b1 = push(sneed(c, q + ".pwconv1.bias", {inter}));
+        b.p2 = push(transpose(sneed(c, q + ".pwconv2.weight", {d, inter}), d, inter)); b.b2 = push(sneed(c, q + ".pwconv2.bias", {d}));
+        b.gamma = push(sneed(c, q + ".gamma", {d}));
+        c->blocks.push_back(b);
+    }
+    c->fin_w = push(sneed(c, P + ".final_layer_norm.weight", {d})); c->fin_b = push(sneed(c, P + ".final_layer_norm.bias", {d}));
+    c->head_w = push(transpose(sneed(c, "decoder.head.out.weight", {nf + 2, d}), nf + 2, d));
+    c->head_b = push(sneed(c, "decoder.head.out.bias", {nf + 2}));
+    {   // irfft as a contraction: frames[n] = (1/N) sum_k c_k (Re_k cos(2 pi k n / N) - Im_k sin(2 pi k n / N)),
+        // c_0 = c_{N/2} = 1, else 2; imaginary parts of DC / Nyquist are ignored (MLXFFT.irfft semantics)
+        std::vector<float> at((size_t)2 * bins * nf);
+        for (int64_t k = 0; k < bins; ++k) {
+            double ck = (k == 0 || k == nf / 2) ? 1.0 : 2.0;
+            for (int64_t n = 0; n < nf; ++n) {
+                double ang = 2.0 * M_PI * (double)((k * n) % nf) / (double)nf;
+                at[(size_t)k * nf + n] = (float)(ck * cos(ang) / (double)nf);
+                at[(size_t)(bins + k) * nf + n] = (k == 0 || k == nf / 2) ? 0.0f : (float)(-ck * sin(ang) / (double)nf);
+            }
+        }
+        c->idft = push(at);
+        std::vector<float> win(nf);
+        float factor = (float)M_PI / (float)(nf - 1);                   // hanningWindow, SopranoDecoder.swift:209-217
+        for (int64_t n = 0; n < nf; ++n) win[n] = 0.5f - 0.5f * cosf(2.0f * factor * (float)n);
+        if (nf == 1) win[0] = 1.0f;
+        c->window = push(win);
+    }
+    c->arena.alloc(arena.size());
+    HIP_CHECK(hipMemcpy(c->arena.p, arena.data(), arena.size() * 4, hipMemcpyHostToDevice));
+    c->raw.clear(); c->raw_shape.clear();
+    c->finalized = true;
+    MIS_API_END
+}
+
+extern "C" int64_t mis_soprano_num_samples(const mis_soprano* c, int n_hidden) {
+    if (!c || n_hidden < 1) return 0;
+    int64_t T = (int64_t)c->cfg.upscale * (n_hidden - 1) + 1;
+    return (T - 1) * c->cfg.hop_length;
+}
+
+// hidden_dev [B][row_stride][C] (first L rows used) -> audio_dev [B][out_stride]
+static void soprano_decode_device(mis_soprano* c, const float* hidden_dev, int64_t row_stride, int batch, int L, float* audio_dev,
+                                  int64_t out_stride, hipStream_t s) {
+    MIS_REQUIRE(c->finalized, MIS_ERR_NOT_INITIALIZED, "Soprano model not finalized");
+    const mis_soprano_config& cf = c->cfg;
+    const int C = cf.lm.hidden_size, d = cf.decoder_dim, inter = cf.decoder_intermediate_dim, nf = cf.n_fft, bins = nf / 2 + 1;
+    const int T = cf.upscale * (L - 1) + 1;
+    if (T < 2) return;                                                 // (T-1)*hop == 0 samples
+    const float* W = c->arena.p;
+    size_t rows = (size_t)std::max({(int)(cf.input_kernel * C), d, inter, nf + 2, 2 * bins, nf});
+    for (int i = 0; i < 4; ++i) c->buf[i].alloc((size_t)batch * rows * T);
+    float *a = c->buf[0].p, *b = c->buf[1].p, *t1 = c->buf[2].p, *t2 = c->buf[3].p;
+    dim3 tb(128), tg(cdiv(T, 128));
+    hipLaunchKernelGGL(k_sop_interp, dim3(tg.x, C, batch), tb, 0, s, hidden_dev, row_stride, a, L, C, T);
+    const float* xin = a;
+    int Kin = C;
+    if (cf.input_kernel > 1) {
+        hipLaunchKernelGGL(k_sop_im2col, dim3(tg.x, cf.input_kernel * C, batch), tb, 0, s, a, t1, C, T, cf.input_kernel);
+        xin = t1; Kin = cf.input_kernel * C;
+    }
+    GemmParams g{};
+    g.AT = W + c->embed_w; g.bias = W + c->embed_b; g.X = xin; g.Y = b; g.M = d; g.K = Kin; g.N = T; g.Tin = T; g.Tout = T;
+    launch_gemm(GEMM_PLAIN, false, g, batch, s);
+    hipLaunchKernelGGL(k_sop_ln_ct, dim3(tg.x, batch), tb, 0, s, b, a, W + c->norm_w, W + c->norm_b, d, T, 1e-6f);
+    float* h = a;       // residual stream
+    float* o = b;
+    for (const auto& blk : c->blocks) {                                // ConvNeXtBlock, VocosBackbone.swift:64-99
+        launch_dw7(h, t1, W + blk.dw, W + blk.dwb, batch, d, T, 1, s);
+        hipLaunchKernelGGL(k_sop_ln_ct, dim3(tg.x, batch), tb, 0, s, t1, t2, W + blk.lnw, W + blk.lnb, d, T, 1e-6f);
+        g = GemmParams{};
+        g.AT = W + blk.p1; g.bias = W + blk.b1; g.X = t2; g.Y = t1; g.M = inter; g.K = d; g.N = T; g.Tin = T; g.Tout = T;
+        launch_gemm(GEMM_GELU, false, g, batch, s);
+        g = GemmParams{};
+        g.AT = W + blk.p2; g.bias = W + blk.b2; g.X = t1; g.Y = o; g.R = h; g.scale = W + blk.gamma;
+        g.M = d; g.K = inter; g.N = T; g.Tin = T; g.Tout = T;
+        launch_gemm(GEMM_RESID, false, g, batch, s);
+        std::swap(h, o);
+    }
+    hipLaunchKernelGGL(k_sop_ln_ct, dim3(tg.x, batch), tb, 0, s, h, o, W + c->fin_w, W + c->fin_b, d, T, 1e-6f);
+    g = GemmParams{};
+    g.AT = W + c->head_w; g.bias = W + c->head_b; g.X = o; g.Y = t1; g.M = nf + 2; g.K = d; g.N = T; g.Tin = T; g.Tout = T;
+    launch_gemm(GEMM_PLAIN, false, g, batch, s);
+    hipLaunchKernelGGL(k_sop_spec, dim3(tg.x, bins, batch), tb, 0, s, t1, t2, bins, T);
+    g = GemmParams{};
+    g.AT = W + c->idft; g.X = t2; g.Y = t1; g.M = nf; g.K = 2 * bins; g.N = T; g.Tin = T; g.Tout = T;
+    launch_gemm(GEMM_PLAIN, false, g, batch, s);
+    int n_out = (T - 1) * cf.hop_length;
+    hipLaunchKernelGGL(k_sop_ola, dim3(cdiv(n_out, 256), batch), dim3(256), 0, s, t1, W + c->window, audio_dev, out_stride, nf,
+                       cf.hop_length, T);
+    HIP_CHECK(hipGetLastError());
+}
+
+extern "C" mis_status mis_soprano_decode(mis_soprano* c, const float* hidden, int batch, int L, float* audio_out) {
+    MIS_API_BEGIN
+    MIS_REQUIRE(c, MIS_ERR_INVALID_INPUT, "null handle");
+    MIS_REQUIRE(c->finalized, MIS_ERR_NOT_INITIALIZED, "Soprano model not finalized");
+    MIS_REQUIRE(batch >= 0 && L >= 0, MIS_ERR_INVALID_INPUT, "negative size");
+    int64_t n = mis_soprano_num_samples(c, L);
+    if (batch == 0 || n == 0) return MIS_OK;
+    MIS_REQUIRE(hidden && audio_out, MIS_ERR_INVALID_INPUT, "null pointer");
+    HIP_CHECK(hipSetDevice(c->device));
+    hipStream_t s = tts_stream(c->lm);
+    const int C = c->cfg.lm.hidden_size;
+    DevBuf<float> hd, ad;
+    hd.alloc((size_t)batch * L * C); ad.alloc((size_t)batch * n);
+    HIP_CHECK(hipMemcpyAsync(hd.p, hidden, (size_t)batch * L * C * 4, hipMemcpyDefault, s));
+    soprano_decode_device(c, hd.p, L, batch, L, ad.p, n, s);
+    HIP_CHECK(hipMemcpyAsync(audio_out, ad.p, (size_t)batch * n * 4, hipMemcpyDefault, s));
+    HIP_CHECK(hipStreamSynchronize(s));
+    MIS_API_END
+}
+
+// SopranoModel.generate for already-tokenised sentences (Soprano.swift:577-690 per prompt chunk): LM loop with the
+// Soprano sampler flavour collecting hidden states until the stop token, then SopranoDecoder on each row.
+extern "C" mis_status mis_soprano_generate(mis_soprano* c, const int32_t* prompt_ids, const int32_t* prompt_lens, int batch,
+                                           const mis_gen_params* params, float** pcm_out, int64_t* pcm_stride, int64_t* pcm_lens,
+                                           int32_t** tokens_out, int64_t* tokens_stride, int32_t* n_tokens) {
+    MIS_API_BEGIN
+    MIS_REQUIRE(c && prompt_ids && prompt_lens && params && pcm_out && pcm_stride && pcm_lens, MIS_ERR_INVALID_INPUT, "null argument");
+    MIS_REQUIRE(c->finalized, MIS_ERR_NOT_INITIALIZED, "Soprano model not finalized");
+    HIP_CHECK(hipSetDevice(c->device));
+    hipStream_t s = tts_stream(c->lm);
+    mis_gen_params gp = *params;
+    gp.sampler_flavor = 1;
+    gp.frame_constrained = 0;
+    if (gp.max_tokens <= 0) gp.max_tokens = 512;                       // parameters.maxTokens ?? 512 (:635)
+    std::vector<int32_t> n_hidden, ntok, toks;
+    int64_t tstride = 0;
+    tts_generate_hidden(c->lm, prompt_ids, prompt_lens, batch, &gp, c->cfg.stop_token_id, c->hidden, n_hidden, ntok, toks, tstride);
+    const int C = c->cfg.lm.hidden_size;
+    const int64_t hid_rows = gp.max_tokens + 1;
+    int64_t longest = 0;
+    for (int b = 0; b < batch; ++b) { pcm_lens[b] = mis_soprano_num_samples(c, n_hidden[b]); longest = std::max(longest, pcm_lens[b]); }
+    MIS_REQUIRE(longest > 0, MIS_ERR_GENERATION_FAILED, "No audio generated");             // Soprano.swift:684-686
+    DevBuf<float> audio;
+    audio.alloc((size_t)batch * longest);
+    HIP_CHECK(hipMemsetAsync(audio.p, 0, (size_t)batch * longest * 4, s));
+    for (int b = 0; b < batch; ++b)                                     // rows end at different steps: decode one by one
+        if (pcm_lens[b] > 0)
+            soprano_decode_device(c, c->hidden.p + (size_t)b * hid_rows * C, hid_rows, 1, n_hidden[b], audio.p + (size_t)b * longest, longest, s);
+    float* host = nullptr;
+    HIP_CHECK(hipHostMalloc((void**)&host, (size_t)batch * longest * 4, 0));
+    HIP_CHECK(hipMemcpyAsync(host, audio.p, (size_t)batch * longest * 4, hipMemcpyDeviceToHost, s));
+    HIP_CHECK(hipStreamSynchronize(s));
+    for (int b = 0; b < batch; ++b) {                                   // audio[0, (-audioLength)...], Soprano.swift:666-671
+        int64_t want = (int64_t)(n_hidden[b] - 1) * c->cfg.token_size;
+        if (want > 0 && want < pcm_lens[b]) {
+            memmove(host + (size_t)b * longest, host + (size_t)b * longest + (pcm_lens[b] - want), (size_t)want * 4);
+            pcm_lens[b] = want;
+        }
+    }
+    *pcm_out = host; *pcm_stride = longest;
+    if (tokens_out) {
+        int32_t* th = nullptr;
+        HIP_CHECK(hipHostMalloc((void**)&th, toks.size() * 4 + 4, 0));
+        memcpy(th, toks.data(), toks.size() * 4);
+        *tokens_out = th;
+        if (tokens_stride) *tokens_stride = tstride;
+    }
+    if (n_tokens) for (int b = 0; b < batch; ++b) {
+        int n = ntok[b];                                                // the stop token is not a generated token (:855-857)
+        if (n > 0 && toks[(size_t)b * tstride + n - 1] == c->cfg.stop_token_id) n -= 1;
+        n_tokens[b] = n;
+    }
+    MIS_API_END
+}

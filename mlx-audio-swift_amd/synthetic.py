@@ -86,3 +86,29 @@ def snac_synthetic_weights(cfg, seed: int = 1234) -> dict:
     alpha(f"{p}.{n}.alpha", cl)
     wn_conv(f"{p}.{n + 1}", 1, 7, cl, gain=0.12)
     return W
+
+
+def soprano_decoder_synthetic_weights(cfg, seed: int = 99) -> dict:
+    """cfg: soprano.SopranoConfiguration.  Keys as stored in the checkpoint ("decoder.*", float32)."""
+    W, key = {}, [seed * 100000]
+
+    def t(shape, amp):
+        key[0] += 1
+        return synth_tensor(key[0], shape, amp)
+
+    F = np.float32
+    p, d, inter = "decoder.decoder", cfg.decoder_dim, cfg.decoder_intermediate_dim
+    W[p + ".embed.weight"] = t((d, cfg.input_kernel, cfg.hidden_size), math.sqrt(3.0 / (cfg.input_kernel * cfg.hidden_size)))
+    W[p + ".embed.bias"] = t((d,), 0.05)
+    W[p + ".norm.weight"] = (1.0 + t((d,), 0.1)).astype(F); W[p + ".norm.bias"] = t((d,), 0.05)
+    for i in range(cfg.decoder_num_layers):
+        q = f"{p}.convnext.{i}"
+        W[q + ".dwconv.weight"] = t((d, cfg.dw_kernel, 1), math.sqrt(3.0 / cfg.dw_kernel)); W[q + ".dwconv.bias"] = t((d,), 0.05)
+        W[q + ".norm.weight"] = (1.0 + t((d,), 0.1)).astype(F); W[q + ".norm.bias"] = t((d,), 0.05)
+        W[q + ".pwconv1.weight"] = t((inter, d), math.sqrt(3.0 / d)); W[q + ".pwconv1.bias"] = t((inter,), 0.05)
+        W[q + ".pwconv2.weight"] = t((d, inter), math.sqrt(3.0 / inter)); W[q + ".pwconv2.bias"] = t((d,), 0.05)
+        W[q + ".gamma"] = (0.5 + t((d,), 0.3)).astype(F)
+    W[p + ".final_layer_norm.weight"] = (1.0 + t((d,), 0.1)).astype(F); W[p + ".final_layer_norm.bias"] = t((d,), 0.05)
+    W["decoder.head.out.weight"] = t((cfg.n_fft + 2, d), 0.6 * math.sqrt(3.0 / d))
+    W["decoder.head.out.bias"] = t((cfg.n_fft + 2,), 0.05)
+    return W

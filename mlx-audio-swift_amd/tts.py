@@ -49,6 +49,8 @@ class LlamaTTSConfiguration:
     mlp_bias: bool = False
     sample_rate: int = 24000
     max_position_embeddings: int | None = None
+    qk_norm: bool = False          # Qwen3-style LMs (Soprano, VyvoTTS): per-head q/k RMSNorm ...
+    rope_plain: bool = False       # ... and RoPE(base) without the llama3 rescale
 
     @classmethod
     def from_dict(cls, d: dict) -> "LlamaTTSConfiguration":
@@ -71,7 +73,8 @@ class LlamaTTSConfiguration:
                               float(rs.get("factor", 32.0)), float(rs.get("low_freq_factor", 1.0)),
                               float(rs.get("high_freq_factor", 4.0)),
                               float(rs.get("original_max_position_embeddings", 8192.0)),
-                              1 if self.tie_word_embeddings else 0, self.sample_rate)
+                              1 if self.tie_word_embeddings else 0, self.sample_rate,
+                              1 if self.qk_norm else 0, 1 if self.rope_plain else 0)
 
 
 class LlamaTTSModel:
@@ -225,14 +228,16 @@ class LlamaTTSModel:
     def lm_reset(self, batch: int, max_context: int):
         check(_lib.lib().mis_lm_reset(self._h, batch, max_context))
 
-    def lm_forward(self, ids, active=None, want_logits: bool = True):
+    def lm_forward(self, ids, active=None, want_logits: bool = True, want_hidden: bool = False):
         ids = np.ascontiguousarray(ids, dtype=np.int32)
         B = ids.shape[0]
         act = None if active is None else np.ascontiguousarray(active, dtype=np.uint8)
         out = np.zeros((B, self.configuration.vocab_size), np.float32) if want_logits else None
-        check(_lib.lib().mis_lm_forward(self._h, ids.ctypes.data, act.ctypes.data if act is not None else None,
-                                        out.ctypes.data if want_logits else None))
-        return out
+        hid = np.zeros((B, self.configuration.hidden_size), np.float32) if want_hidden else None
+        check(_lib.lib().mis_lm_forward_hidden(self._h, ids.ctypes.data, act.ctypes.data if act is not None else None,
+                                               out.ctypes.data if want_logits else None,
+                                               hid.ctypes.data if want_hidden else None))
+        return (out, hid) if want_hidden else out
 
     def last_timing(self) -> dict:
         t = _lib.TimingC()
@@ -262,7 +267,8 @@ class LlamaTTSModel:
 
     def close(self):
         if self._h is not None:
-            _lib.lib().mis_tts_destroy(self._h)
+            if not getattr(self, "_borrowed", False):      # SopranoModel owns its LM handle
+                _lib.lib().mis_tts_destroy(self._h)
             self._h = None
 
     def __del__(self):

@@ -53,6 +53,10 @@ class LlamaConfig:
         original_max_position_embeddings=8192, rope_type="llama3"))
     tie_word_embeddings: bool = True
     max_position_embeddings: int = 131072
+    # Qwen3-style variants: per-head RMSNorm of q/k before RoPE and plain RoPE(base)
+    # (SopranoAttention Soprano.swift:24-97; VyvoTTS Qwen3.swift:204-205)
+    qk_norm: bool = False
+    rope_plain: bool = False
 
     @property
     def resolved_head_dim(self) -> int:
@@ -75,6 +79,9 @@ class LlamaConfig:
 ORPHEUS_3B = LlamaConfig()
 TINY = LlamaConfig(hidden_size=768, num_hidden_layers=2, intermediate_size=1024, num_attention_heads=6,
                    num_key_value_heads=2, head_dim=128, vocab_size=1000 + 7 * 64)
+TINY_QWEN3 = LlamaConfig(hidden_size=512, num_hidden_layers=2, intermediate_size=768, num_attention_heads=4,
+                         num_key_value_heads=2, head_dim=128, vocab_size=1200, rope_theta=10000.0, rope_scaling=None,
+                         tie_word_embeddings=False, qk_norm=True, rope_plain=True, rms_norm_eps=1e-6)
 TINY64 = LlamaConfig(hidden_size=256, num_hidden_layers=3, intermediate_size=512, num_attention_heads=4,
                      num_key_value_heads=4, head_dim=64, vocab_size=777)
 
@@ -93,6 +100,8 @@ def llama3_freqs(cfg: LlamaConfig) -> np.ndarray:
     low = f32(rs.get("low_freq_factor", 1.0))
     high = f32(rs.get("high_freq_factor", 4.0))
     old = f32(rs.get("original_max_position_embeddings", 8192.0))
+    if cfg.rope_plain:                       # MLXNN.RoPE(dimensions, traditional: false, base) [3P]
+        return freqs
     wavelens = f32(2.0 * np.float32(np.pi)) * freqs
     low_wl = old / low
     high_wl = old / high
@@ -163,6 +172,9 @@ class LlamaOracle:
             q = self.linear(x, self.w[p + ".self_attn.q_proj.weight"]).view(L, H, D).transpose(0, 1)
             k = self.linear(x, self.w[p + ".self_attn.k_proj.weight"]).view(L, Hkv, D).transpose(0, 1)
             v = self.linear(x, self.w[p + ".self_attn.v_proj.weight"]).view(L, Hkv, D).transpose(0, 1)
+            if cfg.qk_norm:                  # Soprano.swift:75-76
+                q = self.rmsnorm(q, self.w[p + ".self_attn.q_norm.weight"])
+                k = self.rmsnorm(k, self.w[p + ".self_attn.k_norm.weight"])
             q = self.rope(q, pos)
             k = self.rope(k, pos)
             if self.k_cache[row][li] is not None:
@@ -189,6 +201,7 @@ class LlamaOracle:
             h = self.r(h + self.linear(act, self.w[p + ".mlp.down_proj.weight"]))
         self.offset[row] = off + L
         h = self.rmsnorm(h, self.w["model.norm.weight"])
+        self.last_hidden = h                          # model.norm(h): what Soprano's decoder consumes (Soprano.swift:264)
         head = self.w.get("lm_head.weight") if not cfg.tie_word_embeddings else None
         if head is None:
             head = self.w["model.embed_tokens.weight"]
@@ -233,4 +246,7 @@ def make_synthetic_weights(cfg: LlamaConfig, seed: int = 4321, dtype=torch.bfloa
         W[p + ".mlp.gate_proj.weight"] = mat(k + 6, (ff, d), math.sqrt(3.0 / d))
         W[p + ".mlp.up_proj.weight"] = mat(k + 7, (ff, d), math.sqrt(3.0 / d))
         W[p + ".mlp.down_proj.weight"] = mat(k + 8, (d, ff), math.sqrt(3.0 / ff) * 0.5)
+        if cfg.qk_norm:
+            W[p + ".self_attn.q_norm.weight"] = (1.0 + mat(k + 9, (D,), 0.1).float()).to(dtype)
+            W[p + ".self_attn.k_norm.weight"] = (1.0 + mat(k + 10, (D,), 0.1).float()).to(dtype)
     return W

@@ -26,7 +26,8 @@ def lm_host_config(ocfg: ollama.LlamaConfig) -> mas.LlamaTTSConfiguration:
         hidden_size=ocfg.hidden_size, num_hidden_layers=ocfg.num_hidden_layers, intermediate_size=ocfg.intermediate_size,
         num_attention_heads=ocfg.num_attention_heads, num_key_value_heads=ocfg.num_key_value_heads,
         head_dim=ocfg.head_dim, rms_norm_eps=ocfg.rms_norm_eps, vocab_size=ocfg.vocab_size, rope_theta=ocfg.rope_theta,
-        rope_scaling=dict(ocfg.rope_scaling) if ocfg.rope_scaling else None, tie_word_embeddings=ocfg.tie_word_embeddings)
+        rope_scaling=dict(ocfg.rope_scaling) if ocfg.rope_scaling else None, tie_word_embeddings=ocfg.tie_word_embeddings,
+        qk_norm=ocfg.qk_norm, rope_plain=ocfg.rope_plain)
 
 
 def lm_pair(ocfg: ollama.LlamaConfig, seed=4321, codec=None):

@@ -33,7 +33,7 @@ def _check(pairs):
         assert np.array_equal(dev_l.argmax(1)[sure], ref_l.argmax(1)[sure])
 
 
-@pytest.mark.parametrize("cfg", [ollama.TINY, ollama.TINY64], ids=["d128-gqa3", "d64-mha"])
+@pytest.mark.parametrize("cfg", [ollama.TINY, ollama.TINY64, ollama.TINY_QWEN3], ids=["d128-gqa3", "d64-mha", "qwen3-qknorm"])
 def test_teacher_forced_logits_match_oracle(cfg):
     W, oracle, dev = lm_pair(cfg)
     rng = np.random.default_rng(1)
@@ -99,3 +99,18 @@ def test_inactive_rows_do_not_advance_and_errors():
         m.finalize()
     assert e.value.case == "modelNotInitialized"
     del a0
+
+
+def test_hidden_state_tap_matches_oracle():
+    # forwardWithHiddenStates (Soprano.swift:254-275): model.norm(h) of the fed token
+    cfg = ollama.TINY_QWEN3
+    W, oracle, dev = lm_pair(cfg)
+    rng = np.random.default_rng(6)
+    ids = rng.integers(0, cfg.vocab_size, 12).astype(np.int32)
+    dev.lm_reset(1, 64)
+    oracle.reset(1)
+    for t in range(12):
+        lg, hid = dev.lm_forward(ids[t:t + 1], want_hidden=True)
+        oracle.forward([ids[t:t + 1]])
+        ref = oracle.last_hidden.numpy()[-1]
+        assert np.abs(hid[0] - ref).max() <= 0.04 * np.abs(ref).max()

@@ -1,0 +1,164 @@
+"""-m gpu: Soprano (a21): Vocos/ISTFT decoder against oracle/soprano.py, the Soprano sampler flavour against the
+oracle sampler, and generate() end to end (hidden-state collection, [STOP] handling, ragged rows).
+Decoder tolerance: float32 chain with exp/cos/sin and a 2*(n_fft/2+1)-term inverse DFT: max |err| <= 2e-4 * max |ref|."""
+import numpy as np
+import pytest
+import torch
+
+import mlx_audio_swift_amd as mas
+from gpu_util import lm_host_config
+from oracle import llama as ollama
+from oracle import sampler as osamp
+from oracle import soprano as osop
+
+pytestmark = pytest.mark.gpu
+
+LM = ollama.TINY_QWEN3
+
+
+def _cfg(**dec):
+    base = dict(decoder_num_layers=2, decoder_dim=96, decoder_intermediate_dim=160, hop_length=32, n_fft=128, upscale=4,
+                input_kernel=3, dw_kernel=3, token_size=128)
+    base.update(dec)
+    h = lm_host_config(LM)
+    cfg = mas.SopranoConfiguration(hidden_size=LM.hidden_size, num_hidden_layers=LM.num_hidden_layers,
+                                   intermediate_size=LM.intermediate_size, num_attention_heads=LM.num_attention_heads,
+                                   num_key_value_heads=LM.num_key_value_heads, head_dim=LM.head_dim, vocab_size=LM.vocab_size,
+                                   rms_norm_eps=LM.rms_norm_eps, rope_theta=LM.rope_theta, tie_word_embeddings=False,
+                                   stop_token_id=3, **base)
+    ocfg = osop.SopranoDecoderConfig(hidden_size=LM.hidden_size, **base)
+    return cfg, ocfg
+
+
+def _pair(stop_token_id=3, **dec):
+    cfg, ocfg = _cfg(**dec)
+    cfg.stop_token_id = stop_token_id
+    Wd = osop.make_synthetic_weights(ocfg, seed=99)
+    Wl = ollama.make_synthetic_weights(LM, seed=4321)
+    # checkpoint naming: LM keys without the "model." prefix exercise sanitize (Soprano.swift:314-361)
+    W = {(k[len("model."):] if k.startswith("model.") else k): v for k, v in Wl.items()}
+    W.update(Wd)
+    dev = mas.SopranoModel.from_weights(cfg, W)
+    return cfg, dev, osop.SopranoDecoderOracle(ocfg, Wd), ollama.LlamaOracle(LM, Wl, round="bf16")
+
+
+@pytest.mark.parametrize("dec", [dict(), dict(input_kernel=1, dw_kernel=7, n_fft=64, hop_length=16, upscale=2, token_size=32)],
+                         ids=["k3-dw3-up4", "k1-dw7-up2"])
+def test_decoder_matches_oracle(dec):
+    cfg, dev, odec, _ = _pair(**dec)
+    rng = np.random.default_rng(0)
+    for B, L in [(2, 9), (1, 2), (3, 33)]:
+        hid = rng.standard_normal((B, L, cfg.hidden_size)).astype(np.float32)
+        ref = odec.decode(hid)
+        got = dev.decode(hid)
+        assert got.shape == ref.shape == (B, cfg.upscale * (L - 1) * cfg.hop_length)
+        assert np.abs(got - ref).max() <= 2e-4 * np.abs(ref).max(), (B, L)
+    assert dev.decode(rng.standard_normal((2, 1, cfg.hidden_size)).astype(np.float32)).shape == (2, 0)   # one hidden state: no audio
+    # product synthetic generator == oracle generator (shared mis-synth-v1)
+    from mlx_audio_swift_amd.synthetic import soprano_decoder_synthetic_weights
+    Wp = soprano_decoder_synthetic_weights(cfg, 99)
+    Wo = osop.make_synthetic_weights(_cfg(**dec)[1], seed=99)
+    assert Wp.keys() == Wo.keys() and all(np.array_equal(Wp[k], Wo[k]) for k in Wp)
+
+
+def test_soprano_sampler_flavour_matches_oracle():
+    rng = np.random.default_rng(1)
+    V, B, ctx = 1200, 4, 30
+    logits = osamp.bf16_round((rng.standard_normal((B, V)) * 3).astype(np.float32)) if hasattr(osamp, "bf16_round") else None
+    if logits is None:
+        logits = torch.as_tensor((rng.standard_normal((B, V)) * 3).astype(np.float32)).bfloat16().float().numpy()
+    win = np.zeros((B, ctx), np.int32)
+    wl = np.asarray([0, 5, 30, 12], np.int32)
+    gen = []
+    for b in range(B):
+        ids = rng.integers(0, V, wl[b])
+        if wl[b] >= 5:
+            ids[1] = ids[3] = ids[4]                       # repeated ids: the penalty applies once per occurrence
+        ids[: min(2, wl[b])] = np.argsort(logits[b])[-2:][: min(2, wl[b])]   # penalise the top logits so it matters
+        gen.append(ids)
+        win[b, ctx - wl[b]:] = ids
+    for temp in (0.0, 0.7):
+        gp = mas.GenerateParameters(temperature=temp, top_p=0.95, repetition_penalty=1.5, repetition_context_size=ctx, seed=5,
+                                    sampler_flavor=1)
+        got = mas.tts.sample_logits(logits, win, wl, gp, step=7)
+        for b in range(B):
+            l = osop.soprano_repetition_penalty(logits[b], gen[b], 1.5)
+            ref = osamp.sample(l, temp, 1.0, 5, b, 7)
+            assert got[b] == ref, (temp, b)
+
+
+def _teacher_hidden(dev, prompt, toks):
+    """Hidden states the engine's own LM produces for prompt + tokens (B = 1), via the lm_forward tap."""
+    dev.lm.lm_reset(1, 128)
+    out = []
+    for i, t in enumerate(list(prompt) + list(toks)):
+        _, hid = dev.lm.lm_forward(np.asarray([t], np.int32), want_hidden=True)
+        if i >= len(prompt) - 1:
+            out.append(hid[0].copy())
+    return np.stack(out)[None]
+
+
+def test_generate_greedy_hidden_collection_stop_and_ragged_rows():
+    cfg, dev, odec, olm = _pair()
+    rng = np.random.default_rng(2)
+    prompts = [rng.integers(4, LM.vocab_size, n).astype(np.int32) for n in (7, 12, 5)]
+    gp = mas.GenerateParameters(max_tokens=12, temperature=0.0, top_p=0.95, repetition_penalty=1.5, repetition_context_size=30,
+                                seed=1, sampler_flavor=1)
+    pcm, toks = dev.generate_batch(prompts, gp, return_tokens=True)
+    assert [len(t) for t in toks] == [12, 12, 12]
+    # (1) engine tokens are the oracle's greedy choice under teacher forcing (Soprano penalty on generated tokens only)
+    olm.reset(3)
+    for b in range(3):
+        seq = list(prompts[b]) + list(toks[b])
+        lg = olm._forward_row(b, torch.as_tensor(np.asarray(seq[:-1], np.int64))).numpy()
+        tol = 0.04 * float(np.abs(lg).max())
+        for i, t in enumerate(toks[b]):
+            l = osop.soprano_repetition_penalty(lg[len(prompts[b]) - 1 + i], list(toks[b][:i])[-30:], 1.5)
+            assert l[t] >= l.max() - tol, (b, i)
+    # (2) audio == oracle decoder applied to the hidden states of (last prompt token, each generated token)
+    for b in range(3):
+        hid = _teacher_hidden(dev, prompts[b], toks[b])
+        assert hid.shape[1] == 13
+        ref = odec.decode(hid)[0]
+        assert pcm[b].shape == ref.shape == (12 * cfg.token_size,)
+        assert np.abs(pcm[b] - ref).max() <= 2e-4 * np.abs(ref).max(), b
+    # (3) determinism and batch == single
+    pcm2, toks2 = dev.generate_batch(prompts, gp, return_tokens=True)
+    assert all(np.array_equal(a, c) for a, c in zip(toks, toks2)) and all(np.array_equal(a, c) for a, c in zip(pcm, pcm2))
+    p1, t1 = dev.generate_batch(prompts[1:2], gp, return_tokens=True)
+    assert np.array_equal(t1[0], toks[1]) and np.array_equal(p1[0], pcm[1])
+    # (4) [STOP]: choose row 0's 5th token as the stop id -> row 0 ends there, the others run on (ragged batch)
+    stop = int(toks[0][4])
+    assert stop not in toks[0][:4]
+    cfg_s, dev_s, _, _ = _pair(stop_token_id=stop)
+    pcm_s, toks_s = dev_s.generate_batch(prompts, gp, return_tokens=True)
+    assert np.array_equal(toks_s[0], toks[0][:4])                      # the stop token is not emitted (Soprano.swift:855-857)
+    ref0 = odec.decode(_teacher_hidden(dev_s, prompts[0], toks_s[0]))[0]
+    assert np.abs(pcm_s[0] - ref0).max() <= 2e-4 * np.abs(ref0).max()
+    assert len(pcm_s[0]) == 4 * cfg.token_size
+    for b in (1, 2):
+        k = list(toks[b]).index(stop) if stop in toks[b] else 12
+        assert np.array_equal(toks_s[b], toks[b][:k]) and len(pcm_s[b]) == k * cfg.token_size
+
+
+def test_generate_sampled_is_seeded_and_text_front_end():
+    cfg, dev, _, _ = _pair()
+
+    class Tok:                                                         # stand-in tokenizer: one id per character
+        def encode(self, s):
+            return {"[STOP]": [3], "[TEXT]": [1], "[START]": [2]}.get(s, [10 + (ord(ch) % 500) for ch in s])
+
+    dev.tokenizer = Tok()
+    cfg.space_token_id = 9
+    ids = dev.tokenize("[STOP][TEXT]ab  c.[START]")
+    assert list(ids) == [3, 1, 10 + ord("a"), 10 + ord("b"), 9, 9, 10 + ord("c"), 10 + ord("."), 2]
+    gp = mas.GenerateParameters(max_tokens=6, temperature=0.7, top_p=0.95, repetition_penalty=1.5, repetition_context_size=30,
+                                seed=21, sampler_flavor=1)
+    a = dev.generate("Hello there. This sentence is long enough to stand alone, yes.\nSecond line here.", generation_parameters=gp)
+    b = dev.generate("Hello there. This sentence is long enough to stand alone, yes.\nSecond line here.", generation_parameters=gp)
+    assert a.shape == (2 * 6 * cfg.token_size,) and np.array_equal(a, b)    # 2 sentence prompts (short one merged), 6 tokens each
+    gp.seed = 22
+    c = dev.generate("Hello there. This sentence is long enough to stand alone, yes.\nSecond line here.", generation_parameters=gp)
+    assert not np.array_equal(a, c)
+    with pytest.raises(mas.AudioGenerationError):
+        dev.generate("   ", generation_parameters=gp)

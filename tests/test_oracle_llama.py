@@ -78,3 +78,30 @@ def test_bf16_mode_stays_close_to_fp32_and_is_bf16_valued():
         assert err < 0.05, err
     # rows are independent: ragged lengths, separate offsets
     assert a.offset == [6, 3]
+
+
+def test_qwen3_style_variant_matches_hf_qwen3():
+    """q/k per-head RMSNorm + plain RoPE (Soprano / VyvoTTS LM) vs HF Qwen3ForCausalLM, float32."""
+    from transformers import Qwen3Config, Qwen3ForCausalLM
+    cfg = llama.TINY_QWEN3
+    W = llama.make_synthetic_weights(cfg, dtype=torch.float32)
+    hc = Qwen3Config(hidden_size=cfg.hidden_size, num_hidden_layers=cfg.num_hidden_layers,
+                     intermediate_size=cfg.intermediate_size, num_attention_heads=cfg.num_attention_heads,
+                     num_key_value_heads=cfg.num_key_value_heads, head_dim=cfg.head_dim, rms_norm_eps=cfg.rms_norm_eps,
+                     vocab_size=cfg.vocab_size, rope_theta=cfg.rope_theta, tie_word_embeddings=False,
+                     max_position_embeddings=4096, attention_bias=False, attn_implementation="eager",
+                     use_sliding_window=False)
+    m = Qwen3ForCausalLM(hc).to(torch.float32).eval()
+    missing, unexpected = m.load_state_dict({k: v.to(torch.float32) for k, v in W.items()}, strict=False)
+    assert not unexpected and not [k for k in missing if "rotary" not in k], (missing, unexpected)
+    rng = np.random.default_rng(5)
+    ids = rng.integers(0, cfg.vocab_size, (1, 11))
+    with torch.no_grad():
+        out = m(torch.from_numpy(ids), output_hidden_states=True)
+        ref = out.logits.numpy()[0]
+    o = llama.LlamaOracle(cfg, W, round=None)
+    o.reset(1)
+    a = o.forward([ids[0, :6]])[0].numpy()
+    b = np.concatenate([o.forward([ids[0, t:t + 1]])[0].numpy() for t in range(6, 11)])
+    np.testing.assert_allclose(np.concatenate([a, b]), ref, rtol=3e-4, atol=3e-4)
+    np.testing.assert_allclose(o.last_hidden.numpy()[-1], out.hidden_states[-1].numpy()[0, -1], rtol=3e-4, atol=3e-4)
