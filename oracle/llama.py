@@ -57,6 +57,9 @@ class LlamaConfig:
     # (SopranoAttention Soprano.swift:24-97; VyvoTTS Qwen3.swift:204-205)
     qk_norm: bool = False
     rope_plain: bool = False
+    # Qwen3-TTS talker / code predictor: RoPE written out as array ops in the model dtype,
+    # q*cos + rotate_half(q)*sin with cos/sin cast to T (Qwen3TTSTalker.swift:15-24,92-95)
+    rope_ops_in_dtype: bool = False
 
     @property
     def resolved_head_dim(self) -> int:
@@ -155,16 +158,24 @@ class LlamaOracle:
         ang = positions.to(torch.float32)[:, None] * self.inv_freqs[None, :]       # [L, D/2]
         c, s = torch.cos(ang), torch.sin(ang)
         x1, x2 = x[..., : D // 2], x[..., D // 2:]
+        if self.cfg.rope_ops_in_dtype:       # every array op rounds to T: T(T(x*cos) + T(rotate_half(x)*sin))
+            c, s = self.r(c), self.r(s)
+            return self.r(torch.cat([self.r(x1 * c) + self.r(-x2 * s), self.r(x2 * c) + self.r(x1 * s)], dim=-1))
         return self.r(torch.cat([x1 * c - x2 * s, x1 * s + x2 * c], dim=-1))
 
     # -- one row, L new tokens --------------------------------------------------
     def _forward_row(self, row: int, ids: torch.Tensor):
+        return self.forward_embeds(row, self.w["model.embed_tokens.weight"][ids])   # [L, d]
+
+    def forward_embeds(self, row: int, h: torch.Tensor, head: torch.Tensor | None = None):
+        """L new positions given as input embeddings [L, d] (Qwen3TTSTalkerModel.callAsFunction takes
+        inputsEmbeds, Qwen3TTSTalker.swift:274-305).  `head` overrides the output projection."""
         cfg = self.cfg
         H, Hkv, D = cfg.num_attention_heads, cfg.num_key_value_heads, cfg.resolved_head_dim
-        L = ids.shape[0]
+        h = torch.as_tensor(h, dtype=torch.float32)
+        L = h.shape[0]
         off = self.offset[row]
         pos = torch.arange(off, off + L)
-        h = self.w["model.embed_tokens.weight"][ids]                                # [L, d]
         scale = float(D) ** -0.5
         for li in range(cfg.num_hidden_layers):
             p = f"model.layers.{li}"
@@ -202,9 +213,10 @@ class LlamaOracle:
         self.offset[row] = off + L
         h = self.rmsnorm(h, self.w["model.norm.weight"])
         self.last_hidden = h                          # model.norm(h): what Soprano's decoder consumes (Soprano.swift:264)
-        head = self.w.get("lm_head.weight") if not cfg.tie_word_embeddings else None
         if head is None:
-            head = self.w["model.embed_tokens.weight"]
+            head = self.w.get("lm_head.weight") if not cfg.tie_word_embeddings else None
+            if head is None:
+                head = self.w["model.embed_tokens.weight"]
         return self.linear(h, head)                                                 # [L, V]
 
     def forward(self, ids_per_row):
