@@ -139,6 +139,9 @@ typedef struct {
      * llama3 rescale.  Both 0 for Orpheus (LlamaTTS.swift always builds Llama3ScaledRoPE, :161-186). */
     int32_t qk_norm;
     int32_t rope_plain;
+    /* Qwen3-TTS talker / code predictor write the rotation as array ops in the model dtype (cos/sin cast to bf16,
+     * T(T(x*cos) + T(rotate_half(x)*sin)), Qwen3TTSTalker.swift:15-24,92-95) instead of MLXFast.RoPE */
+    int32_t rope_ops_in_dtype;
 } mis_lm_config;
 
 /* GenerateParameters as used by LlamaTTS.swift:573-581,691-696 (mlx-swift-lm) */
@@ -269,6 +272,70 @@ mis_status mis_soprano_decode(mis_soprano*, const float* hidden, int batch, int 
 mis_status mis_soprano_generate(mis_soprano*, const int32_t* prompt_ids, const int32_t* prompt_lens, int batch,
                                 const mis_gen_params* params, float** pcm_out, int64_t* pcm_stride, int64_t* pcm_lens,
                                 int32_t** tokens_out, int64_t* tokens_stride, int32_t* n_tokens);
+
+/* ------------------------------------------------------------------------------------------
+ * Qwen3-TTS.  Replaces Qwen3TTSModel.generate / generateStream -> generateVoiceDesign
+ * (Sources/MLXAudioTTS/Models/Qwen3TTS/Qwen3TTS.swift:60-133,306-569), the talker and code predictor LMs
+ * (Qwen3TTSTalker.swift, Qwen3TTSCodePredictor.swift), sampleToken (:1003-1118) and the speech-tokenizer decoder
+ * (Qwen3TTSSpeechTokenizer.swift:888-1006).  Tokenisation and the ChatML prompt text stay on the host.
+ * ---------------------------------------------------------------------------------------- */
+typedef struct mis_qwen3tts mis_qwen3tts;
+typedef struct {
+    mis_lm_config talker;          /* Qwen3TTSTalkerConfig (:200-305): vocab_size = codec vocabulary (3072) */
+    mis_lm_config predictor;       /* Qwen3TTSTalkerCodePredictorConfig (:6-67): vocab_size 2048 */
+    int32_t num_code_groups;       /* 16 */
+    int32_t text_hidden_size, text_vocab_size;
+    int32_t codec_eos_token_id;    /* 2150 */
+    int32_t tts_pad_token_id;      /* 151671 */
+    /* Qwen3TTSTokenizerDecoderConfig (:307-385) */
+    int32_t dec_latent_dim, dec_codebook_dim, dec_codebook_size, dec_decoder_dim, dec_hidden_size, dec_intermediate_size;
+    int32_t dec_head_dim, dec_num_heads, dec_num_layers, dec_num_kv_heads, dec_num_quantizers, dec_num_semantic_quantizers;
+    float   dec_rms_norm_eps, dec_rope_theta;
+    int32_t n_upsample_rates;    int32_t upsample_rates[8];      /* [8,5,4,3] */
+    int32_t n_upsampling_ratios; int32_t upsampling_ratios[8];   /* [2,2] */
+    int32_t sample_rate;           /* 24000 */
+} mis_qwen3tts_config;
+/* sampleToken parameters (VoiceDesignGenerationSettings, Qwen3TTS.swift:651-664; defaults 0.9 / 1.0 / - / 1.05 / 0) */
+typedef struct {
+    int32_t  max_frames;           /* maxTokens (4096); per-row caps via row_max_frames = min(maxTokens, max(75, 6 * text tokens)) (:383) */
+    float    temperature, top_p;
+    int32_t  top_k;                /* 0 = off */
+    float    repetition_penalty, min_p;
+    uint64_t seed;
+    int64_t  row_offset;
+} mis_qwen3tts_params;
+mis_status mis_qwen3tts_create(const mis_qwen3tts_config*, int device, mis_qwen3tts** out);
+/* keys after the reference's sanitize steps: talker tensors with or without the "talker." prefix
+ * (model.*, codec_head.weight, text_projection.*, code_predictor.*), speech-tokenizer decoder tensors as "decoder.*"
+ * with the module-tree names Qwen3TTSSpeechTokenizer.sanitize produces */
+mis_status mis_qwen3tts_set_tensor(mis_qwen3tts*, const char* name, const void* data, mis_dtype dtype,
+                                   const int64_t* shape, int ndim);
+mis_status mis_qwen3tts_finalize(mis_qwen3tts*);
+void       mis_qwen3tts_destroy(mis_qwen3tts*);
+mis_tts*   mis_qwen3tts_talker(mis_qwen3tts*);            /* borrowed handle (parity taps) */
+int        mis_qwen3tts_samples_per_frame(const mis_qwen3tts*);   /* 1920 */
+/* Prompts as prepareGenerationInputs builds them (:883-1000): prefill position p of row b is
+ * text_projection(text_embedding[text_ids[b,p]]) (text id >= 0) plus codec_embedding[codec_ids[b,p]] (codec id >= 0);
+ * trailing_ids = the text ids added to the generated frames' embeddings (then tts_pad).  int32 [batch, P] / [batch, Tt].
+ * *codes_out (mis_free) int32 [batch, *codes_stride, num_code_groups]; n_frames[batch]. */
+mis_status mis_qwen3tts_generate_codes(mis_qwen3tts*, const int32_t* text_ids, const int32_t* codec_ids,
+                                       const int32_t* prefill_lens, int P, const int32_t* trailing_ids,
+                                       const int32_t* trailing_lens, int Tt, int batch, const mis_qwen3tts_params* params,
+                                       const int32_t* row_max_frames, int32_t** codes_out, int64_t* codes_stride,
+                                       int32_t* n_frames);
+mis_status mis_qwen3tts_decode(mis_qwen3tts*, const int32_t* codes, int batch, int T, float* wav_out);
+mis_status mis_qwen3tts_decoder_tap(mis_qwen3tts*, const int32_t* codes, int batch, int T, int stage, float* out,
+                                    int64_t capacity, int32_t* channels, int64_t* length);
+mis_status mis_qwen3tts_generate(mis_qwen3tts*, const int32_t* text_ids, const int32_t* codec_ids, const int32_t* prefill_lens,
+                                 int P, const int32_t* trailing_ids, const int32_t* trailing_lens, int Tt, int batch,
+                                 const mis_qwen3tts_params* params, const int32_t* row_max_frames, float** pcm_out,
+                                 int64_t* pcm_stride, int64_t* pcm_lens, int32_t** codes_out, int64_t* codes_stride,
+                                 int32_t* n_frames, int chunk_frames, mis_event_cb on_event, void* user,
+                                 const volatile int* cancel_flag);
+/* stand-alone sampleToken (parity tests): logits f32 [batch, vocab], seen u8 [batch, vocab] or NULL */
+mis_status mis_qwen3tts_sample_logits(int device, const float* logits, int batch, int vocab, const uint8_t* seen,
+                                      const mis_qwen3tts_params* params, int suppress_lo, int suppress_hi, int eos_id, int step,
+                                      int32_t* tokens_out);
 
 /* ------------------------------------------------------------------------------------------
  * Log-mel / STFT front end.  Replaces WhisperAudio.logMelSpectrogram / encoderFeatures

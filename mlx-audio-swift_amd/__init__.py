@@ -9,6 +9,7 @@ the Swift shim a maintainer would add):
     codecs.SNAC            <-> class SNAC : AudioCodecModel       (MLXAudioCodecs/SNAC/SNACDecoder.swift)
     tts.LlamaTTSModel      <-> class LlamaTTSModel : SpeechGenerationModel  (MLXAudioTTS/Models/Llama/LlamaTTS.swift)
     soprano.SopranoModel   <-> class SopranoModel : SpeechGenerationModel  (MLXAudioTTS/Models/Soprano/Soprano.swift)
+    qwen3tts.Qwen3TTSModel <-> class Qwen3TTSModel : SpeechGenerationModel  (MLXAudioTTS/Models/Qwen3TTS/Qwen3TTS.swift)
     stt.WhisperModel       <-> class WhisperModel : STTGenerationModel   (MLXAudioSTT/Models/Whisper/WhisperModel.swift)
     dsp.*                  <-> computeMelSpectrogram (MLXAudioCore/DSP.swift) / WhisperAudio.encoderFeatures
     generation.*           <-> AudioGeneration / AudioGenerationInfo / AudioGenerationError /
@@ -24,6 +25,8 @@ from .codecs import SNAC, SNACConfig  # noqa: F401
 from .tts import LlamaTTSModel, LlamaTTSConfiguration, OrpheusTokens  # noqa: F401
 from .orpheus import deinterleave, parse_output  # noqa: F401
 from .soprano import SopranoModel, SopranoConfiguration  # noqa: F401
+from .qwen3tts import (Qwen3TTSModel, Qwen3TTSConfiguration, Qwen3TTSDecoderConfiguration, Qwen3TTSGenerateParameters,  # noqa: F401
+                       PreparedPrompt)
 from . import dsp  # noqa: F401
 from .stt import WhisperModel, WhisperConfig, STTGenerateParameters, STTOutput  # noqa: F401
 

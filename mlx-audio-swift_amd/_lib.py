@@ -28,7 +28,7 @@ class LmConfigC(C.Structure):
                 ("vocab_size", C.c_int32), ("rms_norm_eps", C.c_float), ("rope_theta", C.c_float),
                 ("rope_factor", C.c_float), ("rope_low_freq_factor", C.c_float), ("rope_high_freq_factor", C.c_float),
                 ("rope_original_max_pos", C.c_float), ("tie_word_embeddings", C.c_int32), ("sample_rate", C.c_int32),
-                ("qk_norm", C.c_int32), ("rope_plain", C.c_int32)]
+                ("qk_norm", C.c_int32), ("rope_plain", C.c_int32), ("rope_ops_in_dtype", C.c_int32)]
 
 
 class GenParamsC(C.Structure):
@@ -49,6 +49,24 @@ class SopranoConfigC(C.Structure):
                 ("decoder_intermediate_dim", C.c_int32), ("hop_length", C.c_int32), ("n_fft", C.c_int32),
                 ("upscale", C.c_int32), ("input_kernel", C.c_int32), ("dw_kernel", C.c_int32),
                 ("token_size", C.c_int32), ("stop_token_id", C.c_int32)]
+
+
+class Qwen3TTSConfigC(C.Structure):
+    _fields_ = [("talker", LmConfigC), ("predictor", LmConfigC), ("num_code_groups", C.c_int32),
+                ("text_hidden_size", C.c_int32), ("text_vocab_size", C.c_int32), ("codec_eos_token_id", C.c_int32),
+                ("tts_pad_token_id", C.c_int32),
+                ("dec_latent_dim", C.c_int32), ("dec_codebook_dim", C.c_int32), ("dec_codebook_size", C.c_int32),
+                ("dec_decoder_dim", C.c_int32), ("dec_hidden_size", C.c_int32), ("dec_intermediate_size", C.c_int32),
+                ("dec_head_dim", C.c_int32), ("dec_num_heads", C.c_int32), ("dec_num_layers", C.c_int32),
+                ("dec_num_kv_heads", C.c_int32), ("dec_num_quantizers", C.c_int32), ("dec_num_semantic_quantizers", C.c_int32),
+                ("dec_rms_norm_eps", C.c_float), ("dec_rope_theta", C.c_float),
+                ("n_upsample_rates", C.c_int32), ("upsample_rates", C.c_int32 * 8),
+                ("n_upsampling_ratios", C.c_int32), ("upsampling_ratios", C.c_int32 * 8), ("sample_rate", C.c_int32)]
+
+
+class Qwen3TTSParamsC(C.Structure):
+    _fields_ = [("max_frames", C.c_int32), ("temperature", C.c_float), ("top_p", C.c_float), ("top_k", C.c_int32),
+                ("repetition_penalty", C.c_float), ("min_p", C.c_float), ("seed", C.c_uint64), ("row_offset", C.c_int64)]
 
 
 class MelConfigC(C.Structure):
@@ -137,6 +155,22 @@ SYMBOLS = {
     "mis_soprano_decode": (C.c_int, [_P, _P, C.c_int, C.c_int, _P]),
     "mis_soprano_generate": (C.c_int, [_P, _P, _P, C.c_int, C.POINTER(GenParamsC), C.POINTER(_P), C.POINTER(C.c_int64),
                                        _P, C.POINTER(_P), C.POINTER(C.c_int64), _P]),
+    "mis_qwen3tts_create": (C.c_int, [C.POINTER(Qwen3TTSConfigC), C.c_int, C.POINTER(_P)]),
+    "mis_qwen3tts_set_tensor": (C.c_int, [_P, C.c_char_p, _P, C.c_int, C.POINTER(C.c_int64), C.c_int]),
+    "mis_qwen3tts_finalize": (C.c_int, [_P]),
+    "mis_qwen3tts_destroy": (None, [_P]),
+    "mis_qwen3tts_talker": (_P, [_P]),
+    "mis_qwen3tts_samples_per_frame": (C.c_int, [_P]),
+    "mis_qwen3tts_generate_codes": (C.c_int, [_P, _P, _P, _P, C.c_int, _P, _P, C.c_int, C.c_int, C.POINTER(Qwen3TTSParamsC), _P,
+                                              C.POINTER(_P), C.POINTER(C.c_int64), _P]),
+    "mis_qwen3tts_decode": (C.c_int, [_P, _P, C.c_int, C.c_int, _P]),
+    "mis_qwen3tts_decoder_tap": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, _P, C.c_int64, C.POINTER(C.c_int32),
+                                           C.POINTER(C.c_int64)]),
+    "mis_qwen3tts_generate": (C.c_int, [_P, _P, _P, _P, C.c_int, _P, _P, C.c_int, C.c_int, C.POINTER(Qwen3TTSParamsC), _P,
+                                        C.POINTER(_P), C.POINTER(C.c_int64), _P, C.POINTER(_P), C.POINTER(C.c_int64), _P,
+                                        C.c_int, EVENT_CB, _P, _P]),
+    "mis_qwen3tts_sample_logits": (C.c_int, [C.c_int, _P, C.c_int, C.c_int, _P, C.POINTER(Qwen3TTSParamsC), C.c_int, C.c_int,
+                                             C.c_int, C.c_int, _P]),
     "mis_debug_launch_floor": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_double)]),
 }
 

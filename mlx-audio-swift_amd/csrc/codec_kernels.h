@@ -2,7 +2,7 @@
 #pragma once
 #include "common.h"
 
-enum { GEMM_PLAIN = 0, GEMM_RESID = 1, GEMM_NOISE = 2, GEMM_CONVT = 3, GEMM_GELU = 4 };
+enum { GEMM_PLAIN = 0, GEMM_RESID = 1, GEMM_NOISE = 2, GEMM_CONVT = 3, GEMM_GELU = 4, GEMM_TAPS = 5 };
 
 // Y[b][m][n] = sum_k A[m][k] X[b][k][n] on v_mfma_f32_32x32x2_f32 (activations NCT, time contiguous)
 struct GemmParams {
@@ -21,8 +21,10 @@ struct GemmParams {
     const float* ralpha;
     int M, K, N;          // N = output columns per phase
     int Tin, Tout;
-    int s, pad, Cin;      // CONVT only
+    int s, pad, Cin;      // CONVT only (Cin also TAPS)
+    int taps, dil;        // TAPS: causal dense conv, K = taps*Cin, tap j reads x[:, n - (taps-1-j)*dil] (zero before 0); A^T row j*Cin + c
 };
+// snake: Snake prologue on the X rows (CONVT and TAPS always run it: pass alpha = ralpha = zeros for identity)
 void launch_gemm(int mode, bool snake, const GemmParams& p, int batch, hipStream_t s);
 // depthwise 7-tap conv (zero padded, dilation dil): shorter odd kernels ride in centred 7-tap weights
 void launch_dw7(const float* X, float* Y, const float* w7 /*[C][7]*/, const float* bias, int batch, int C, int T, int dil, hipStream_t s);

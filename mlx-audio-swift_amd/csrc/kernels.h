@@ -33,3 +33,23 @@ int tts_device(const mis_tts* c);
 void tts_generate_hidden(mis_tts* c, const int32_t* prompt_ids, const int32_t* prompt_lens, int batch, const mis_gen_params* gp,
                          int stop_id, DevBuf<float>& hidden, std::vector<int32_t>& n_hidden, std::vector<int32_t>& n_tokens,
                          std::vector<int32_t>& tokens, int64_t& tokens_stride);
+
+// hooks for composite engines built on the LM step chain (qwen3tts.hip); defined in lm_engine.hip
+struct TtsView { bf16_t *x, *h, *logits, *emb; int32_t *ids, *pos_next; uint8_t* active; int d, Mpad, V, Vpad, batch, finalized, L; hipStream_t stream; };
+void tts_internal_reset(mis_tts* c, int batch, int max_context);
+void tts_internal_use_stream(mis_tts* c, hipStream_t s);
+// one token position per active row: embedding rows gathered from `table` ([table_rows][d] bf16) by `ids` (device), through all
+// layers and the final norm (result: packed x of the view).  table == nullptr: the model's own embedding / id buffer.
+void tts_internal_enqueue_layers(mis_tts* c, const bf16_t* table, int table_rows, const int32_t* ids);
+void tts_internal_enqueue_head(mis_tts* c, const bf16_t* head_packed);      // logits of the view; nullptr = own lm_head
+TtsView tts_internal_view(mis_tts* c);
+
+// Qwen3-TTS speech-tokenizer decoder (q3_codec.hip)
+struct mis_q3dec;
+mis_status mis_q3dec_create(const mis_qwen3tts_config* cfg, int device, mis_q3dec** out);
+mis_status mis_q3dec_set_tensor(mis_q3dec*, const char* name, const void* data, mis_dtype dtype, const int64_t* shape, int ndim);
+mis_status mis_q3dec_finalize(mis_q3dec*);
+void mis_q3dec_destroy(mis_q3dec*);
+int q3dec_total_upsample(const mis_q3dec*);
+void q3dec_decode_device(mis_q3dec*, const int32_t* codes_dev /*[B][nq][T]*/, int batch, int T, float* wav_dev, int64_t wav_stride, hipStream_t s);
+void q3dec_decode_host(mis_q3dec*, const int32_t* codes, int batch, int T, float* out, int stop_after, int* outC, int64_t* outT, hipStream_t s);

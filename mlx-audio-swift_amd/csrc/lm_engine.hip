@@ -58,6 +58,7 @@ struct mis_tts {
     hipGraphExec_t g_prefill = nullptr, g_decode = nullptr;
     uint64_t graph_key = 0;
     bool use_graph = true;
+    bool borrowed_stream = false;
     int profiling = 0;
     mis_tts_timing timing{};
     SamplerParams sp{};
@@ -117,7 +118,7 @@ extern "C" void mis_tts_destroy(mis_tts* c) {
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     if (c->g_prefill) (void)hipGraphExecDestroy(c->g_prefill);
     if (c->g_decode) (void)hipGraphExecDestroy(c->g_decode);
-    if (c->stream) (void)hipStreamDestroy(c->stream);
+    if (c->stream && !c->borrowed_stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }
 
@@ -384,12 +385,13 @@ static void lm_reset(mis_tts* c, int batch, int max_context) {
 }
 
 // embed -> L x block.  Leaves x = final-norm(h) ready for lm_head.   (LlamaTTS.swift:335-345,303-310)
-static void enqueue_layers(mis_tts* c) {
+// table/rows/ids: embedding source override (composite engines feed input embeddings as a [rows][d] table)
+static void enqueue_layers(mis_tts* c, const bf16_t* table = nullptr, int table_rows = 0, const int32_t* ids = nullptr) {
     hipStream_t s = c->stream;
     const int d = c->d, HD = c->H * c->D, Mpad = c->Mpad;
     const float eps = c->cfg.rms_norm_eps;
-    launch_embed_rmsnorm(c->emb.p, c->ids.p, c->active.p, c->pos_cur.p, c->pos_next.p, c->norms.p, c->h.p, c->x.p, d,
-                         c->V, eps, c->batch, Mpad, s);
+    launch_embed_rmsnorm(table ? table : c->emb.p, ids ? ids : c->ids.p, c->active.p, c->pos_cur.p, c->pos_next.p, c->norms.p,
+                         c->h.p, c->x.p, d, table ? table_rows : c->V, eps, c->batch, Mpad, s);
     for (int li = 0; li < c->L; ++li) {
         launch_gemm_skinny(EPI_PARTIAL, c->r_part, c->ksb_part, c->wqkv.p + layer_qkv_elems(c) * li, c->x.p, c->qkv_part.p, c->Nqkv / 16,
                            d / 32, c->S_qkv, c->Nqkv, Mpad, s);
@@ -406,6 +408,7 @@ static void enqueue_layers(mis_tts* c) {
             ap.knorm_w = c->qknorm.p + (size_t)(2 * li + 1) * c->D;
             ap.qk_eps = c->cfg.rms_norm_eps;
         }
+        ap.rope_in_dtype = c->cfg.rope_ops_in_dtype;
         launch_attn_decode(ap, c->batch, s);
         launch_gemm_skinny(EPI_PARTIAL, c->r_part, c->ksb_part, c->wo.p + layer_o_elems(c) * li, c->attn_out.p, c->part.p, d / 16, HD / 32,
                            c->S_o, d, Mpad, s);
@@ -420,9 +423,9 @@ static void enqueue_layers(mis_tts* c) {
     }
 }
 
-static void enqueue_lm_head(mis_tts* c) {
-    launch_gemm_skinny(EPI_BF16, 2, c->ksb_head, c->lm_head.p, c->x.p, c->logits.p, c->Vpad / 16, c->d / 32, 1, c->Vpad, c->Mpad,
-                       c->stream);
+static void enqueue_lm_head(mis_tts* c, const bf16_t* head = nullptr) {
+    launch_gemm_skinny(EPI_BF16, 2, c->ksb_head, head ? head : c->lm_head.p, c->x.p, c->logits.p, c->Vpad / 16, c->d / 32, 1,
+                       c->Vpad, c->Mpad, c->stream);
 }
 
 extern "C" mis_status mis_lm_reset(mis_tts* c, int batch, int max_context) {
@@ -1157,4 +1160,20 @@ void tts_generate_hidden(mis_tts* c, const int32_t* prompt_ids, const int32_t* p
     GenOutputs out;
     run_generate(c, prompt_ids, prompt_lens, batch, gp, nullptr, nullptr, 0, true, nullptr, nullptr, nullptr, out, &hm);
     n_hidden = hm.n_hidden; n_tokens = out.n_tokens; tokens = out.tokens; tokens_stride = out.tokens_stride;
+}
+
+// ---------------------------------------------------------------------------- hooks for composite engines (qwen3tts.hip)
+void tts_internal_reset(mis_tts* c, int batch, int max_context) { lm_reset(c, batch, max_context); }
+void tts_internal_use_stream(mis_tts* c, hipStream_t s) {
+    if (c->stream && !c->borrowed_stream && c->stream != s) { (void)hipStreamSynchronize(c->stream); (void)hipStreamDestroy(c->stream); }
+    c->stream = s; c->borrowed_stream = true;
+}
+void tts_internal_enqueue_layers(mis_tts* c, const bf16_t* table, int table_rows, const int32_t* ids) { enqueue_layers(c, table, table_rows, ids); }
+void tts_internal_enqueue_head(mis_tts* c, const bf16_t* head_packed) { enqueue_lm_head(c, head_packed); }
+TtsView tts_internal_view(mis_tts* c) {
+    TtsView v{};
+    v.x = c->x.p; v.h = c->h.p; v.logits = c->logits.p; v.emb = c->emb.p; v.ids = c->ids.p; v.pos_next = c->pos_next.p;
+    v.active = c->active.p; v.d = c->d; v.Mpad = c->Mpad; v.V = c->V; v.Vpad = c->Vpad; v.batch = c->batch; v.stream = c->stream;
+    v.finalized = c->finalized ? 1 : 0; v.L = c->L;
+    return v;
 }

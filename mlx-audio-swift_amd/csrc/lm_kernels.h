@@ -2,7 +2,12 @@
 #pragma once
 #include "common.h"
 
-enum { EPI_PARTIAL = 0, EPI_BF16 = 1, EPI_SILU_MUL = 2, EPI_GELU_PACKED = 3 };
+// element (m, k) of a packed activation [K/32][MT][64][8] (MFMA-B fragments: a wave's operand is one contiguous 1 KiB load)
+__host__ __device__ __forceinline__ size_t xpk_index(int m, int k, int MT) {
+    return ((((size_t)(k >> 5) * MT + (m >> 4)) * 64) + (((k & 31) >> 3) << 4) + (m & 15)) * 8 + (k & 7);
+}
+
+enum { EPI_PARTIAL = 0, EPI_BF16 = 1, EPI_SILU_MUL = 2, EPI_GELU_PACKED = 3, EPI_SILU_PACKED = 4 };
 
 void launch_convert_to_bf16(const void* src, int dtype, bf16_t* dst, size_t n, hipStream_t s);
 void launch_pack_weight(const bf16_t* src, bf16_t* dst, int N, int K, int NT, int tile_stride, int tile_offset,
@@ -20,7 +25,7 @@ void launch_reduce_residual_rmsnorm(const float* slabs, int S, int Mpad, int N, 
 // Wp packed [NT][KT][64][8]; X bf16 [Mpad][KT*32]; out: f32 slabs [S][Mpad][N_out] (EPI_PARTIAL) or bf16 [Mpad][N_out]
 // ksb = 1: each wave an independent item; ksb = 4: the block's 4 waves split the item's K range (LDS combine)
 // bias (bf16 [N], optional): added once (slab 0 / final epilogue).  EPI_GELU_PACKED: T(gelu(T(xW+b))) written
-// in the packed fragment layout (it is the next GEMM's X operand).
+// in the packed fragment layout (it is the next GEMM's X operand).  EPI_SILU_PACKED: h = T(xW+b), T(h * T(sigmoid(h))) packed.
 void launch_gemm_skinny(int epi, int R, int ksb, const bf16_t* Wp, const bf16_t* X, void* out, int NT, int KT, int S,
                         int N_out, int Mpad, hipStream_t s, const bf16_t* bias = nullptr);
 
@@ -36,6 +41,7 @@ struct AttnParams {
     const bf16_t* qnorm_w;   // [D] per-head q RMSNorm weight (Qwen3-style), null = none
     const bf16_t* knorm_w;   // [D]
     float qk_eps;
+    int rope_in_dtype;       // 1: T(T(x cos) + T(rot(x) sin)) with cos/sin rounded to bf16 (Qwen3-TTS)
     int cross;               // 1: cross attention - queries only, no append, keys 0..cross_len-1 of the given caches
     int cross_len;
     bf16_t* out;             // [Mpad][H*D]

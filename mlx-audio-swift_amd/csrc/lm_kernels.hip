@@ -19,10 +19,6 @@
 #include "common.h"
 #include "lm_kernels.h"
 
-// element (m, k) of a packed activation [K/32][MT][64][8]
-__device__ __forceinline__ size_t xpk_index(int m, int k, int MT) {
-    return ((((size_t)(k >> 5) * MT + (m >> 4)) * 64) + (((k & 31) >> 3) << 4) + (m & 15)) * 8 + (k & 7);
-}
 
 // ============================================================================ weight staging
 
@@ -311,7 +307,7 @@ __device__ __forceinline__ void gemm_epilogue(const f32x4_t (&acc)[R][MT], void*
                     make_float4(acc[r][mt][0] + bv[0], acc[r][mt][1] + bv[1], acc[r][mt][2] + bv[2], acc[r][mt][3] + bv[3]);
             }
         }
-    } else if (EPI == EPI_BF16 || EPI == EPI_GELU_PACKED) {
+    } else if (EPI == EPI_BF16 || EPI == EPI_GELU_PACKED || EPI == EPI_SILU_PACKED) {
         bf16_t* o = reinterpret_cast<bf16_t*>(out);
 #pragma unroll
         for (int r = 0; r < R; ++r) {
@@ -330,9 +326,13 @@ __device__ __forceinline__ void gemm_epilogue(const f32x4_t (&acc)[R][MT], void*
                 for (int e = 0; e < 4; ++e) {
                     float v = acc[r][mt][e] + bv[e];
                     if (EPI == EPI_GELU_PACKED) v = gelu_erf(bf16_round_f32(v));       // T(gelu(T(xW + b)))
+                    if (EPI == EPI_SILU_PACKED) {                                        // h = T(xW + b); T(h * T(sigmoid(h)))
+                        float hh = bf16_round_f32(v);
+                        v = hh * bf16_round_f32(1.0f / (1.0f + __expf(-hh)));
+                    }
                     res[e] = f32_to_bf16(v);
                 }
-                size_t off = (EPI == EPI_GELU_PACKED) ? xpk_index(mt * 16 + ml, tile * 16 + nl, MT)
+                size_t off = (EPI == EPI_GELU_PACKED || EPI == EPI_SILU_PACKED) ? xpk_index(mt * 16 + ml, tile * 16 + nl, MT)
                                                       : ((size_t)mt * 16 + ml) * N_out + tile * 16 + nl;
                 uint2 v;
                 v.x = (uint32_t)res[0] | ((uint32_t)res[1] << 16);
@@ -486,6 +486,7 @@ static void launch_gemm_mt(int epi, int R, int ksb, const bf16_t* Wp, const bf16
     GEMM_CASE(EPI_GELU_PACKED, 2, 4)
     GEMM_CASE(EPI_GELU_PACKED, 1, 4)
     GEMM_CASE(EPI_BF16, 1, 4)
+    GEMM_CASE(EPI_SILU_PACKED, 2, 4)
 #undef GEMM_CASE
     throw MisError(MIS_ERR_GENERATION_FAILED, "unsupported GEMM variant");
 }
@@ -578,7 +579,11 @@ __global__ void __launch_bounds__(512) k_attn_decode(AttnParams p) {
         bf16_t r1, r2;
         if (p.rope_cos) {
             float c = p.rope_cos[(size_t)pos * (D / 2) + i], s = p.rope_sin[(size_t)pos * (D / 2) + i];
-            r1 = f32_to_bf16(x1 * c - x2 * s); r2 = f32_to_bf16(x1 * s + x2 * c);
+            if (p.rope_in_dtype) {
+                c = bf16_round_f32(c); s = bf16_round_f32(s);
+                r1 = f32_to_bf16(bf16_round_f32(x1 * c) + bf16_round_f32(-x2 * s));
+                r2 = f32_to_bf16(bf16_round_f32(x2 * c) + bf16_round_f32(x1 * s));
+            } else { r1 = f32_to_bf16(x1 * c - x2 * s); r2 = f32_to_bf16(x1 * s + x2 * c); }
         } else { r1 = f32_to_bf16(x1); r2 = f32_to_bf16(x2); }      // Whisper: learned positions, no rotary
         if (hh < G) { qs[hh * D + i] = r1; qs[hh * D + i + D / 2] = r2; }
         else {

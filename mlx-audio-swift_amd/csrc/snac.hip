@@ -121,7 +121,7 @@ __global__ void __launch_bounds__(256) k_snac_gemm(GemmParams p) {
     int b, phase = 0;
     if (MODE == GEMM_CONVT) { b = blockIdx.z / p.s; phase = blockIdx.z % p.s; }
     else b = blockIdx.z;
-    const int Kx = (MODE == GEMM_CONVT) ? p.Cin : p.K;
+    const int Kx = (MODE == GEMM_CONVT || MODE == GEMM_TAPS) ? p.Cin : p.K;
     const float* AT = p.AT + (size_t)phase * p.K * p.M;
     const float* Xb = p.X + (size_t)b * Kx * p.Tin;
     // transposed conv phase: out o = s*n + phase takes taps j=0,1 from x[:, n + q - j]
@@ -154,10 +154,11 @@ __global__ void __launch_bounds__(256) k_snac_gemm(GemmParams p) {
             int k = k0 + xr + 8 * h;
             int row = k, shift = 0;
             if (MODE == GEMM_CONVT) { int j = k / p.Cin; row = k - j * p.Cin; shift = q - j; }
+            if (MODE == GEMM_TAPS) { int j = k / p.Cin; row = k - j * p.Cin; shift = (j - (p.taps - 1)) * p.dil; }
             int n = n0 + xc + shift;
             bool kin = k < p.K;
             const float* src = Xb + (size_t)row * p.Tin;
-            if (MODE != GEMM_CONVT && kin && (p.Tin & 3) == 0 && n + 3 < p.Tin) {
+            if (MODE != GEMM_CONVT && MODE != GEMM_TAPS && kin && (p.Tin & 3) == 0 && n + 3 < p.Tin) {
                 float4 v = *reinterpret_cast<const float4*>(src + n);
                 rx[h][0] = v.x; rx[h][1] = v.y; rx[h][2] = v.z; rx[h][3] = v.w;
             } else {
@@ -225,7 +226,7 @@ __global__ void __launch_bounds__(256) k_snac_gemm(GemmParams p) {
             if (m >= p.M) continue;
             float v = acc[t][r];
             if (p.bias) v += p.bias[m];
-            if (MODE == GEMM_PLAIN) {
+            if (MODE == GEMM_PLAIN || MODE == GEMM_TAPS) {
                 p.Y[((size_t)b * p.M + m) * p.Tout + n] = v;
             } else if (MODE == GEMM_GELU) {                            // exact-erf GELU (VocosBackbone.swift:89)
                 p.Y[((size_t)b * p.M + m) * p.Tout + n] = 0.5f * v * (1.0f + erff(v * 0.70710678118654752f));
@@ -542,7 +543,9 @@ void launch_gemm(int mode, bool snake, const GemmParams& p, int batch, hipStream
     dim3 grid(cdiv(p.N, G_BN), cdiv(p.M, G_BM), batch * phases), block(256);
     if (mode == GEMM_PLAIN) hipLaunchKernelGGL((k_snac_gemm<GEMM_PLAIN, false>), grid, block, 0, s, p);
     else if (mode == GEMM_GELU) hipLaunchKernelGGL((k_snac_gemm<GEMM_GELU, false>), grid, block, 0, s, p);
+    else if (mode == GEMM_RESID && snake) hipLaunchKernelGGL((k_snac_gemm<GEMM_RESID, true>), grid, block, 0, s, p);
     else if (mode == GEMM_RESID) hipLaunchKernelGGL((k_snac_gemm<GEMM_RESID, false>), grid, block, 0, s, p);
+    else if (mode == GEMM_TAPS) { MIS_REQUIRE(p.alpha && p.ralpha, MIS_ERR_GENERATION_FAILED, "taps GEMM needs snake arrays"); hipLaunchKernelGGL((k_snac_gemm<GEMM_TAPS, true>), grid, block, 0, s, p); }
     else if (mode == GEMM_NOISE) hipLaunchKernelGGL((k_snac_gemm<GEMM_NOISE, false>), grid, block, 0, s, p);
     else { MIS_REQUIRE(snake, MIS_ERR_GENERATION_FAILED, "convT without snake"); hipLaunchKernelGGL((k_snac_gemm<GEMM_CONVT, true>), grid, block, 0, s, p); }
 }

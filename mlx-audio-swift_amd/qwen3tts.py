@@ -1,0 +1,285 @@
+"""Host mirror of Qwen3TTSModel : SpeechGenerationModel (Sources/MLXAudioTTS/Models/Qwen3TTS/Qwen3TTS.swift:12-133).
+
+Device work (talker + code-predictor frame loop, sampleToken, speech-tokenizer decoder) is behind mis_qwen3tts_* in
+libmi_speech.so.  Host logic mirrored here: the ChatML prompt template and the (text id, codec id) layout of
+prepareGenerationInputs (Qwen3TTS.swift:883-1000), the per-utterance frame cap (:383) and the stream contract."""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass, field
+
+import numpy as np
+
+from . import _lib
+from .codecs import _tensor_args
+from .generation import AudioEvent, AudioGenerationError, InfoEvent, TokenEvent, check  # noqa: F401
+from .tts import LlamaTTSConfiguration
+
+
+def _lm(hidden, layers, ff, heads, kv, hd, vocab):
+    return LlamaTTSConfiguration(hidden_size=hidden, num_hidden_layers=layers, intermediate_size=ff, num_attention_heads=heads,
+                                 num_key_value_heads=kv, head_dim=hd, vocab_size=vocab, rms_norm_eps=1e-6, rope_theta=1e6,
+                                 rope_scaling=None, tie_word_embeddings=False, qk_norm=True, rope_plain=True, rope_ops_in_dtype=True)
+
+
+@dataclass
+class Qwen3TTSDecoderConfiguration:
+    """Qwen3TTSTokenizerDecoderConfig (Qwen3TTSConfig.swift:307-385)"""
+    latent_dim: int = 1024
+    codebook_dim: int = 512
+    codebook_size: int = 2048
+    decoder_dim: int = 1536
+    hidden_size: int = 512
+    intermediate_size: int = 1024
+    head_dim: int = 64
+    num_attention_heads: int = 16
+    num_hidden_layers: int = 8
+    num_key_value_heads: int = 16
+    num_quantizers: int = 16
+    num_semantic_quantizers: int = 1
+    rms_norm_eps: float = 1e-5
+    rope_theta: float = 10000.0
+    upsample_rates: tuple = (8, 5, 4, 3)
+    upsampling_ratios: tuple = (2, 2)
+
+
+@dataclass
+class Qwen3TTSConfiguration:
+    """Qwen3TTSModelConfig + Qwen3TTSTalkerConfig (Qwen3TTSConfig.swift:200-305,532-583)"""
+    talker: LlamaTTSConfiguration = field(default_factory=lambda: _lm(1024, 28, 3072, 16, 8, 128, 3072))
+    predictor: LlamaTTSConfiguration = field(default_factory=lambda: _lm(1024, 5, 3072, 16, 8, 128, 2048))
+    num_code_groups: int = 16
+    text_hidden_size: int = 2048
+    text_vocab_size: int = 151936
+    codec_eos_token_id: int = 2150
+    codec_think_id: int = 2154
+    codec_nothink_id: int = 2155
+    codec_think_bos_id: int = 2156
+    codec_think_eos_id: int = 2157
+    codec_pad_id: int = 2148
+    codec_bos_id: int = 2149
+    codec_language_id: dict | None = None
+    tts_pad_token_id: int = 151671
+    tts_bos_token_id: int = 151672
+    tts_eos_token_id: int = 151673
+    sample_rate: int = 24000
+    decoder: Qwen3TTSDecoderConfiguration = field(default_factory=Qwen3TTSDecoderConfiguration)
+
+    def to_c(self) -> "_lib.Qwen3TTSConfigC":
+        d = self.decoder
+        ur = (C.c_int32 * 8)(*d.upsample_rates)
+        up = (C.c_int32 * 8)(*d.upsampling_ratios)
+        return _lib.Qwen3TTSConfigC(self.talker.to_c(), self.predictor.to_c(), self.num_code_groups, self.text_hidden_size,
+                                    self.text_vocab_size, self.codec_eos_token_id, self.tts_pad_token_id, d.latent_dim,
+                                    d.codebook_dim, d.codebook_size, d.decoder_dim, d.hidden_size, d.intermediate_size, d.head_dim,
+                                    d.num_attention_heads, d.num_hidden_layers, d.num_key_value_heads, d.num_quantizers,
+                                    d.num_semantic_quantizers, d.rms_norm_eps, d.rope_theta, len(d.upsample_rates), ur,
+                                    len(d.upsampling_ratios), up, self.sample_rate)
+
+
+@dataclass
+class Qwen3TTSGenerateParameters:
+    """defaultGenerationParameters / resolveVoiceDesignGenerationSettings (Qwen3TTS.swift:30-37,651-664)"""
+    max_tokens: int = 4096
+    temperature: float = 0.9
+    top_p: float = 1.0
+    top_k: int = 0
+    repetition_penalty: float = 1.05
+    min_p: float = 0.0
+    seed: int = 0
+    row_offset: int = 0
+
+    def to_c(self):
+        return _lib.Qwen3TTSParamsC(int(self.max_tokens), float(self.temperature), float(self.top_p), int(self.top_k),
+                                    float(self.repetition_penalty), float(self.min_p), int(self.seed), int(self.row_offset))
+
+
+@dataclass
+class PreparedPrompt:
+    """One utterance as prepareGenerationInputs lays it out: prefill positions as (text id | -1, codec id | -1) pairs, the
+    trailing text ids added to the generated frames, and the number of text tokens (frame cap, Qwen3TTS.swift:381-383)."""
+    text_ids: np.ndarray
+    codec_ids: np.ndarray
+    trailing_ids: np.ndarray
+    target_token_count: int = 0
+
+
+class Qwen3TTSModel:
+    def __init__(self, config: Qwen3TTSConfiguration, device: int = 0):
+        self.configuration = config
+        self.device = device
+        self.tokenizer = None
+        self._h = C.c_void_p()
+        cc = config.to_c()
+        check(_lib.lib().mis_qwen3tts_create(C.byref(cc), device, C.byref(self._h)))
+
+    def __del__(self):
+        h, self._h = getattr(self, "_h", None), None
+        if h:
+            _lib.lib().mis_qwen3tts_destroy(h)
+
+    @classmethod
+    def from_weights(cls, config, weights: dict, device: int = 0) -> "Qwen3TTSModel":
+        m = cls(config, device)
+        for k, v in weights.items():
+            m.set_tensor(k, v)
+        m.finalize()
+        return m
+
+    def set_tensor(self, name: str, arr):
+        keep, ptr, dt, shape = _tensor_args(arr)
+        sh = (C.c_int64 * len(shape))(*shape)
+        check(_lib.lib().mis_qwen3tts_set_tensor(self._h, name.encode(), ptr, dt, sh, len(shape)))
+
+    def finalize(self):
+        check(_lib.lib().mis_qwen3tts_finalize(self._h))
+
+    # -- protocol surface ------------------------------------------------------------------------------
+    @property
+    def sample_rate(self) -> int:
+        return self.configuration.sample_rate
+
+    @property
+    def default_generation_parameters(self) -> Qwen3TTSGenerateParameters:
+        return Qwen3TTSGenerateParameters()
+
+    @property
+    def samples_per_frame(self) -> int:
+        return int(_lib.lib().mis_qwen3tts_samples_per_frame(self._h))
+
+    def prepare_generation_inputs(self, text: str, language: str = "auto", instruct: str | None = None) -> PreparedPrompt:
+        """prepareGenerationInputs (Qwen3TTS.swift:883-1000) without the CustomVoice speaker branch."""
+        if self.tokenizer is None:
+            raise AudioGenerationError(1, "Qwen3TTS requires the text tokenizer to be loaded")
+        cfg = self.configuration
+        ids = list(self.tokenizer.encode(f"<|im_start|>assistant\n{text}<|im_end|>\n<|im_start|>assistant\n"))
+        lang = None
+        if language.lower() != "auto" and cfg.codec_language_id:
+            lang = cfg.codec_language_id.get(language.lower())
+        prefix = ([cfg.codec_think_id, cfg.codec_think_bos_id, lang, cfg.codec_think_eos_id] if lang is not None
+                  else [cfg.codec_nothink_id, cfg.codec_think_bos_id, cfg.codec_think_eos_id])
+        codec = prefix + [cfg.codec_pad_id, cfg.codec_bos_id]
+        t, c = [], []
+        if instruct:
+            ins = list(self.tokenizer.encode(f"<|im_start|>user\n{instruct}<|im_end|>\n"))
+            t += ins; c += [-1] * len(ins)
+        t += ids[:3]; c += [-1, -1, -1]                                  # role: <|im_start|>assistant\n
+        pad_count = len(codec) - 2
+        t += [cfg.tts_pad_token_id] * pad_count + [cfg.tts_bos_token_id]  # (pad..., bos) + codec[:-1]
+        c += codec[:-1]
+        t += [ids[3]]; c += [codec[-1]]                                   # first text token + codec_bos
+        trailing = ids[4:len(ids) - 5] + [cfg.tts_eos_token_id]
+        return PreparedPrompt(np.asarray(t, np.int32), np.asarray(c, np.int32), np.asarray(trailing, np.int32),
+                              len(self.tokenizer.encode(text)))
+
+    def _marshal(self, prompts):
+        B = len(prompts)
+        if B == 0:
+            raise AudioGenerationError(3, "empty batch")
+        P = max(len(p.text_ids) for p in prompts)
+        Tt = max(max(len(p.trailing_ids) for p in prompts), 1)
+        t = np.full((B, P), -1, np.int32); c = np.full((B, P), -1, np.int32); tr = np.zeros((B, Tt), np.int32)
+        pl = np.zeros(B, np.int32); tl = np.zeros(B, np.int32)
+        for b, p in enumerate(prompts):
+            n = len(p.text_ids)
+            t[b, :n] = p.text_ids; c[b, :n] = p.codec_ids; pl[b] = n
+            tl[b] = len(p.trailing_ids); tr[b, :tl[b]] = p.trailing_ids
+        return t, c, pl, P, tr, tl, Tt
+
+    def _row_caps(self, prompts, gp):
+        caps = np.asarray([min(gp.max_tokens, max(75, p.target_token_count * 6)) if p.target_token_count > 0 else gp.max_tokens
+                           for p in prompts], np.int32)                  # effectiveMaxTokens (:383)
+        return caps
+
+    def generate_codes(self, prompts, generation_parameters: Qwen3TTSGenerateParameters | None = None):
+        """Frame loop only: list of [n_frames, num_code_groups] int32 arrays."""
+        gp = generation_parameters or self.default_generation_parameters
+        t, c, pl, P, tr, tl, Tt = self._marshal(prompts)
+        B = len(prompts)
+        caps = self._row_caps(prompts, gp)
+        gpc = gp.to_c()
+        gpc.max_frames = int(caps.max())
+        out = C.c_void_p(); stride = C.c_int64(); nf = (C.c_int32 * B)()
+        check(_lib.lib().mis_qwen3tts_generate_codes(self._h, t.ctypes.data, c.ctypes.data, pl.ctypes.data, P, tr.ctypes.data,
+                                                     tl.ctypes.data, Tt, B, C.byref(gpc), caps.ctypes.data, C.byref(out),
+                                                     C.byref(stride), nf))
+        try:
+            G = self.configuration.num_code_groups
+            arr = np.ctypeslib.as_array(C.cast(out, C.POINTER(C.c_int32)), shape=(B, max(stride.value, 1), G))
+            return [arr[b, : nf[b]].copy() for b in range(B)]
+        finally:
+            _lib.lib().mis_free(out)
+
+    def decode_codes(self, codes) -> np.ndarray:
+        """speechTokenizer.decoder over whole sequences: codes [B, num_quantizers, T] -> [B, T * samples_per_frame]."""
+        cd = np.ascontiguousarray(codes, dtype=np.int32)
+        B, nq, T = cd.shape
+        out = np.zeros((B, T * self.samples_per_frame), np.float32)
+        check(_lib.lib().mis_qwen3tts_decode(self._h, cd.ctypes.data, B, T, out.ctypes.data))
+        return out
+
+    def decoder_tap(self, codes, stage: int) -> np.ndarray:
+        cd = np.ascontiguousarray(codes, dtype=np.int32)
+        B, nq, T = cd.shape
+        d = self.configuration.decoder
+        cap = B * max(d.decoder_dim, d.latent_dim, d.codebook_dim) * T * self.samples_per_frame
+        buf = np.zeros(cap, np.float32)
+        ch = C.c_int32(); ln = C.c_int64()
+        check(_lib.lib().mis_qwen3tts_decoder_tap(self._h, cd.ctypes.data, B, T, stage, buf.ctypes.data, cap, C.byref(ch), C.byref(ln)))
+        return buf[: B * ch.value * ln.value].reshape(B, ch.value, ln.value).copy()
+
+    def generate_batch(self, prompts, generation_parameters: Qwen3TTSGenerateParameters | None = None, return_codes: bool = False,
+                       streaming_interval: float | None = None, on_audio=None):
+        """generateVoiceDesign for a batch of prepared prompts: list of 1-D float32 PCM arrays.  With `on_audio` the decoded
+        audio is also delivered in chunks of streaming_interval * 12.5 frames (Qwen3TTS.swift:394-395)."""
+        gp = generation_parameters or self.default_generation_parameters
+        t, c, pl, P, tr, tl, Tt = self._marshal(prompts)
+        B = len(prompts)
+        caps = self._row_caps(prompts, gp)
+        gpc = gp.to_c()
+        gpc.max_frames = int(caps.max())
+        pcm = C.c_void_p(); stride = C.c_int64(); plens = (C.c_int64 * B)()
+        codes = C.c_void_p(); cstride = C.c_int64(); nf = (C.c_int32 * B)()
+        chunk = max(1, int((streaming_interval or 2.0) * 12.5))
+        keep = []
+
+        def cb(user, row, kind, payload, n):
+            if kind == _lib.EVENT_AUDIO and on_audio is not None:
+                on_audio(row, np.ctypeslib.as_array(C.cast(payload, C.POINTER(C.c_float)), shape=(n,)).copy())
+        cbc = _lib.EVENT_CB(cb) if on_audio is not None else C.cast(None, _lib.EVENT_CB)
+        keep.append(cbc)
+        check(_lib.lib().mis_qwen3tts_generate(self._h, t.ctypes.data, c.ctypes.data, pl.ctypes.data, P, tr.ctypes.data, tl.ctypes.data,
+                                               Tt, B, C.byref(gpc), caps.ctypes.data, C.byref(pcm), C.byref(stride), plens,
+                                               C.byref(codes), C.byref(cstride), nf, chunk, cbc, None, None))
+        try:
+            arr = np.ctypeslib.as_array(C.cast(pcm, C.POINTER(C.c_float)), shape=(B, max(stride.value, 1)))
+            out = [arr[b, : plens[b]].copy() for b in range(B)]
+            G = self.configuration.num_code_groups
+            ca = np.ctypeslib.as_array(C.cast(codes, C.POINTER(C.c_int32)), shape=(B, max(cstride.value, 1), G))
+            cl = [ca[b, : nf[b]].copy() for b in range(B)]
+        finally:
+            _lib.lib().mis_free(pcm)
+            _lib.lib().mis_free(codes)
+        return (out, cl) if return_codes else out
+
+    def generate(self, text: str, voice: str | None = None, ref_audio=None, ref_text=None, language: str | None = None,
+                 generation_parameters: Qwen3TTSGenerateParameters | None = None) -> np.ndarray:
+        """generate(text:voice:refAudio:refText:language:generationParameters:) (Qwen3TTS.swift:60-82); `voice` is the
+        VoiceDesign instruction."""
+        if ref_audio is not None:
+            raise AudioGenerationError(5, "in-context voice cloning needs the speech-tokenizer encoder (not built)")
+        p = self.prepare_generation_inputs(text, language or "auto", voice)
+        out = self.generate_batch([p], generation_parameters)[0]
+        return out if len(out) else np.zeros(1, np.float32)              # generatedCodes.isEmpty -> zeros([1]) (:520-522)
+
+    def generate_stream(self, text: str, voice: str | None = None, language: str | None = None,
+                        generation_parameters: Qwen3TTSGenerateParameters | None = None, streaming_interval: float = 2.0):
+        """generateStream (:84-133): yields TokenEvent (code 0 of each frame), then AudioEvent chunks."""
+        p = self.prepare_generation_inputs(text, language or "auto", voice)
+        chunks = []
+        pcm, codes = self.generate_batch([p], generation_parameters, return_codes=True, streaming_interval=streaming_interval,
+                                         on_audio=lambda row, a: chunks.append(a))
+        for f in codes[0]:
+            yield TokenEvent(0, int(f[0]))
+        for a in chunks:
+            yield AudioEvent(0, a)

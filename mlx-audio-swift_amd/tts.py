@@ -51,6 +51,7 @@ class LlamaTTSConfiguration:
     max_position_embeddings: int | None = None
     qk_norm: bool = False          # Qwen3-style LMs (Soprano, VyvoTTS): per-head q/k RMSNorm ...
     rope_plain: bool = False       # ... and RoPE(base) without the llama3 rescale
+    rope_ops_in_dtype: bool = False  # Qwen3-TTS: rotation as bf16 array ops (Qwen3TTSTalker.swift:15-24)
 
     @classmethod
     def from_dict(cls, d: dict) -> "LlamaTTSConfiguration":
@@ -74,7 +75,7 @@ class LlamaTTSConfiguration:
                               float(rs.get("high_freq_factor", 4.0)),
                               float(rs.get("original_max_position_embeddings", 8192.0)),
                               1 if self.tie_word_embeddings else 0, self.sample_rate,
-                              1 if self.qk_norm else 0, 1 if self.rope_plain else 0)
+                              1 if self.qk_norm else 0, 1 if self.rope_plain else 0, 1 if self.rope_ops_in_dtype else 0)
 
 
 class LlamaTTSModel:

@@ -94,9 +94,10 @@ def _tiny_lm(layers, vocab, hidden=256, ff=384):
 
 
 TINY = Qwen3TTSConfig(
-    talker=_tiny_lm(2, 1280), predictor=_tiny_lm(2, 96), num_code_groups=4, text_hidden_size=128, text_vocab_size=500,
-    codec_eos_token_id=1190, codec_think_id=1194, codec_nothink_id=1195, codec_think_bos_id=1196, codec_think_eos_id=1197,
-    codec_pad_id=1188, codec_bos_id=1189, tts_pad_token_id=491, tts_bos_token_id=492, tts_eos_token_id=493,
+    # talker vocabulary = 96 audio codes (== decoder codebook_size) + 1024 suppressed special ids
+    talker=_tiny_lm(2, 1120), predictor=_tiny_lm(2, 96), num_code_groups=4, text_hidden_size=128, text_vocab_size=500,
+    codec_eos_token_id=1030, codec_think_id=1034, codec_nothink_id=1035, codec_think_bos_id=1036, codec_think_eos_id=1037,
+    codec_pad_id=1028, codec_bos_id=1029, tts_pad_token_id=491, tts_bos_token_id=492, tts_eos_token_id=493,
     decoder=DecoderConfig(latent_dim=64, codebook_dim=32, codebook_size=96, decoder_dim=96, hidden_size=64,
                           intermediate_size=96, head_dim=16, num_attention_heads=4, num_hidden_layers=2,
                           num_key_value_heads=4, num_quantizers=4, num_semantic_quantizers=1, upsample_rates=(3, 2),

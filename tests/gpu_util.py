@@ -27,7 +27,7 @@ def lm_host_config(ocfg: ollama.LlamaConfig) -> mas.LlamaTTSConfiguration:
         num_attention_heads=ocfg.num_attention_heads, num_key_value_heads=ocfg.num_key_value_heads,
         head_dim=ocfg.head_dim, rms_norm_eps=ocfg.rms_norm_eps, vocab_size=ocfg.vocab_size, rope_theta=ocfg.rope_theta,
         rope_scaling=dict(ocfg.rope_scaling) if ocfg.rope_scaling else None, tie_word_embeddings=ocfg.tie_word_embeddings,
-        qk_norm=ocfg.qk_norm, rope_plain=ocfg.rope_plain)
+        qk_norm=ocfg.qk_norm, rope_plain=ocfg.rope_plain, rope_ops_in_dtype=ocfg.rope_ops_in_dtype)
 
 
 def lm_pair(ocfg: ollama.LlamaConfig, seed=4321, codec=None):

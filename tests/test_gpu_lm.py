@@ -33,7 +33,12 @@ def _check(pairs):
         assert np.array_equal(dev_l.argmax(1)[sure], ref_l.argmax(1)[sure])
 
 
-@pytest.mark.parametrize("cfg", [ollama.TINY, ollama.TINY64, ollama.TINY_QWEN3], ids=["d128-gqa3", "d64-mha", "qwen3-qknorm"])
+TINY_Q3TTS = ollama.LlamaConfig(**{**ollama.TINY_QWEN3.__dict__, "rope_theta": 1e6, "rope_ops_in_dtype": True, "head_dim": 64,
+                                    "num_attention_heads": 8, "num_key_value_heads": 4})
+
+
+@pytest.mark.parametrize("cfg", [ollama.TINY, ollama.TINY64, ollama.TINY_QWEN3, TINY_Q3TTS],
+                         ids=["d128-gqa3", "d64-mha", "qwen3-qknorm", "qwen3tts-rope-ops"])
 def test_teacher_forced_logits_match_oracle(cfg):
     W, oracle, dev = lm_pair(cfg)
     rng = np.random.default_rng(1)
