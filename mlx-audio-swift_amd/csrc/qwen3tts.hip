@@ -584,25 +584,36 @@ extern "C" mis_status mis_qwen3tts_generate(mis_qwen3tts* c, const int32_t* text
     try {
         DevBuf<float> wav;
         DevBuf<int32_t> cd;
-        for (int b = 0; b < batch; ++b) {
-            const int n = nf[b];
-            if (n == 0) continue;                                       // generatedCodes.isEmpty -> zeros([1]) (:520-522): length 0 here
-            std::vector<int32_t> row((size_t)G * n);                    // [frames][G] -> [G][frames]
-            for (int f = 0; f < n; ++f) for (int g = 0; g < G; ++g) row[(size_t)g * n + f] = codes[((size_t)b * stride + f) * G + g];
-            cd.alloc(row.size()); wav.alloc((size_t)n * up);
-            HIP_CHECK(hipMemcpyAsync(cd.p, row.data(), row.size() * 4, hipMemcpyHostToDevice, c->s));
-            q3dec_decode_device(c->dec, cd.p, 1, n, wav.p, (int64_t)n * up, c->s);
-            HIP_CHECK(hipMemcpyAsync(host + (size_t)b * longest, wav.p, (size_t)n * up * 4, hipMemcpyDeviceToHost, c->s));
+        // rows with the same frame count decode together (bounded by ~16 GB of activations); ragged rows one by one
+        std::vector<char> done_row(batch, 0);
+        for (int b0 = 0; b0 < batch; ++b0) {
+            const int n = nf[b0];
+            if (done_row[b0] || n == 0) continue;                       // generatedCodes.isEmpty -> zeros([1]) (:520-522): length 0 here
+            const size_t per_row = (size_t)4 * 4 * 96 * (size_t)n * up;            // 4 buffers x f32 x widest stage (approx.)
+            const int cap = (int)std::max<size_t>(1, std::min<size_t>(64, ((size_t)16 << 30) / std::max<size_t>(per_row, 1)));
+            std::vector<int> grp;
+            for (int b = b0; b < batch && (int)grp.size() < cap; ++b) if (!done_row[b] && nf[b] == n) { grp.push_back(b); done_row[b] = 1; }
+            const int gb = (int)grp.size();
+            std::vector<int32_t> rows((size_t)gb * G * n);              // [frames][G] -> [G][frames] per row
+            for (int r = 0; r < gb; ++r)
+                for (int f = 0; f < n; ++f) for (int g = 0; g < G; ++g)
+                    rows[((size_t)r * G + g) * n + f] = codes[((size_t)grp[r] * stride + f) * G + g];
+            cd.alloc(rows.size()); wav.alloc((size_t)gb * n * up);
+            HIP_CHECK(hipMemcpyAsync(cd.p, rows.data(), rows.size() * 4, hipMemcpyHostToDevice, c->s));
+            q3dec_decode_device(c->dec, cd.p, gb, n, wav.p, (int64_t)n * up, c->s);
+            for (int r = 0; r < gb; ++r)
+                HIP_CHECK(hipMemcpyAsync(host + (size_t)grp[r] * longest, wav.p + (size_t)r * n * up, (size_t)n * up * 4, hipMemcpyDeviceToHost, c->s));
             HIP_CHECK(hipStreamSynchronize(c->s));
-            if (on_event) {
-                const int step = chunk_frames > 0 ? chunk_frames : n;
+            if (cancel_flag && *cancel_flag) throw MisError(MIS_ERR_CANCELLED, "generation cancelled");
+        }
+        if (on_event)
+            for (int b = 0; b < batch; ++b) {
+                const int n = nf[b], step = chunk_frames > 0 ? chunk_frames : std::max(n, 1);
                 for (int f0 = 0; f0 < n; f0 += step) {
                     const int fn = std::min(step, n - f0);
                     on_event(user, b, MIS_EVENT_AUDIO, host + (size_t)b * longest + (size_t)f0 * up, (int64_t)fn * up);
                 }
             }
-            if (cancel_flag && *cancel_flag) throw MisError(MIS_ERR_CANCELLED, "generation cancelled");
-        }
     } catch (...) { (void)hipHostFree(host); throw; }
     *pcm_out = host; *pcm_stride = longest;
     if (codes_out) {

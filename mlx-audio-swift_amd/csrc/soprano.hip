@@ -343,9 +343,15 @@ extern "C" mis_status mis_soprano_generate(mis_soprano* c, const int32_t* prompt
     DevBuf<float> audio;
     audio.alloc((size_t)batch * longest);
     HIP_CHECK(hipMemsetAsync(audio.p, 0, (size_t)batch * longest * 4, s));
-    for (int b = 0; b < batch; ++b)                                     // rows end at different steps: decode one by one
-        if (pcm_lens[b] > 0)
-            soprano_decode_device(c, c->hidden.p + (size_t)b * hid_rows * C, hid_rows, 1, n_hidden[b], audio.p + (size_t)b * longest, longest, s);
+    bool same = true;
+    for (int b = 1; b < batch; ++b) same = same && n_hidden[b] == n_hidden[0];
+    if (same && pcm_lens[0] > 0) {                                      // all rows ended at the same step: one batched decode
+        soprano_decode_device(c, c->hidden.p, hid_rows, batch, n_hidden[0], audio.p, longest, s);
+    } else {
+        for (int b = 0; b < batch; ++b)                                 // ragged rows: decode one by one
+            if (pcm_lens[b] > 0)
+                soprano_decode_device(c, c->hidden.p + (size_t)b * hid_rows * C, hid_rows, 1, n_hidden[b], audio.p + (size_t)b * longest, longest, s);
+    }
     float* host = nullptr;
     HIP_CHECK(hipHostMalloc((void**)&host, (size_t)batch * longest * 4, 0));
     HIP_CHECK(hipMemcpyAsync(host, audio.p, (size_t)batch * longest * 4, hipMemcpyDeviceToHost, s));

@@ -112,3 +112,114 @@ def soprano_decoder_synthetic_weights(cfg, seed: int = 99) -> dict:
     W["decoder.head.out.weight"] = t((cfg.n_fft + 2, d), 0.6 * math.sqrt(3.0 / d))
     W["decoder.head.out.bias"] = t((cfg.n_fft + 2,), 0.05)
     return W
+
+
+def qwen3tts_synthetic_weights(cfg, seed: int = 515):
+    """cfg: qwen3tts.Qwen3TTSConfiguration.  Yields (name, array) pairs (bf16-valued float32 for the LMs would double the host
+    footprint, so LM tensors are produced as float32 and converted by the loader; decoder tensors float32)."""
+    key = [seed * 100000]
+
+    def t(shape, amp, offset=0.0):
+        key[0] += 1
+        a = synth_tensor(key[0], shape, amp)
+        return a + np.float32(offset) if offset else a
+
+    def lm(prefix, c):
+        d, ff, H, Hkv, D = c.hidden_size, c.intermediate_size, c.num_attention_heads, c.num_key_value_heads, c.head_dim
+        yield prefix + "model.norm.weight", t((d,), 0.1, 1.0)
+        for li in range(c.num_hidden_layers):
+            p = f"{prefix}model.layers.{li}"
+            yield p + ".input_layernorm.weight", t((d,), 0.1, 1.0)
+            yield p + ".post_attention_layernorm.weight", t((d,), 0.1, 1.0)
+            yield p + ".self_attn.q_proj.weight", t((H * D, d), math.sqrt(3.0 / d) * 1.5)
+            yield p + ".self_attn.k_proj.weight", t((Hkv * D, d), math.sqrt(3.0 / d) * 1.5)
+            yield p + ".self_attn.v_proj.weight", t((Hkv * D, d), math.sqrt(3.0 / d))
+            yield p + ".self_attn.o_proj.weight", t((d, H * D), math.sqrt(3.0 / (H * D)) * 0.5)
+            yield p + ".mlp.gate_proj.weight", t((ff, d), math.sqrt(3.0 / d))
+            yield p + ".mlp.up_proj.weight", t((ff, d), math.sqrt(3.0 / d))
+            yield p + ".mlp.down_proj.weight", t((d, ff), math.sqrt(3.0 / ff) * 0.5)
+            yield p + ".self_attn.q_norm.weight", t((D,), 0.1, 1.0)
+            yield p + ".self_attn.k_norm.weight", t((D,), 0.1, 1.0)
+
+    tk, pr, dc = cfg.talker, cfg.predictor, cfg.decoder
+    d, dp, th = tk.hidden_size, pr.hidden_size, cfg.text_hidden_size
+    yield "model.codec_embedding.weight", t((tk.vocab_size, d), 0.5 * math.sqrt(3.0))
+    yield "codec_head.weight", t((tk.vocab_size, d), math.sqrt(3.0 / d) * 2.0)
+    yield "model.text_embedding.weight", t((cfg.text_vocab_size, th), 0.5 * math.sqrt(3.0))
+    yield "text_projection.linear_fc1.weight", t((th, th), math.sqrt(3.0 / th) * 2.0)
+    yield "text_projection.linear_fc1.bias", t((th,), 0.1)
+    yield "text_projection.linear_fc2.weight", t((d, th), math.sqrt(3.0 / th) * 2.0)
+    yield "text_projection.linear_fc2.bias", t((d,), 0.1)
+    yield from lm("", tk)
+    yield from lm("code_predictor.", pr)
+    for i in range(cfg.num_code_groups - 1):
+        yield f"code_predictor.model.codec_embedding.{i}.weight", t((pr.vocab_size, d), 0.5 * math.sqrt(3.0))
+        yield f"code_predictor.lm_head.{i}.weight", t((pr.vocab_size, dp), math.sqrt(3.0 / dp) * 2.0)
+    if d != dp:
+        yield "code_predictor.small_to_mtp_projection.weight", t((dp, d), math.sqrt(3.0 / d))
+        yield "code_predictor.small_to_mtp_projection.bias", t((dp,), 0.1)
+    # speech-tokenizer decoder (float32)
+    half = dc.codebook_dim // 2
+    for name, n in (("rvq_first", dc.num_semantic_quantizers), ("rvq_rest", dc.num_quantizers - dc.num_semantic_quantizers)):
+        for i in range(n):
+            p = f"decoder.quantizer.{name}.vq.layers.{i}.codebook"
+            yield p + ".cluster_usage", t((dc.codebook_size,), 0.5, 1.0)
+            yield p + ".embedding_sum", t((dc.codebook_size, half), math.sqrt(3.0) / math.sqrt(n))
+        yield f"decoder.quantizer.{name}.output_proj.weight", t((dc.codebook_dim, 1, half), math.sqrt(3.0 / half))
+
+    def conv(p, co, k, ci, gain=1.0):
+        yield p + ".weight", t((co, k, ci), gain * math.sqrt(3.0 / (k * ci)))
+        yield p + ".bias", t((co,), 0.05)
+
+    def lin(p, co, ci, bias=True, gain=1.0):
+        yield p + ".weight", t((co, ci), gain * math.sqrt(3.0 / ci))
+        if bias:
+            yield p + ".bias", t((co,), 0.05)
+
+    yield from conv("decoder.pre_conv.conv", dc.latent_dim, 3, dc.codebook_dim)
+    P, hs = "decoder.pre_transformer", dc.hidden_size
+    yield from lin(P + ".input_proj", hs, dc.latent_dim)
+    yield from lin(P + ".output_proj", dc.latent_dim, hs)
+    yield P + ".norm.weight", t((hs,), 0.1, 1.0)
+    for i in range(dc.num_hidden_layers):
+        p = f"{P}.layers.{i}"
+        yield p + ".input_layernorm.weight", t((hs,), 0.1, 1.0)
+        yield p + ".post_attention_layernorm.weight", t((hs,), 0.1, 1.0)
+        yield from lin(p + ".self_attn.q_proj", dc.num_attention_heads * dc.head_dim, hs, False, 1.5)
+        yield from lin(p + ".self_attn.k_proj", dc.num_key_value_heads * dc.head_dim, hs, False, 1.5)
+        yield from lin(p + ".self_attn.v_proj", dc.num_key_value_heads * dc.head_dim, hs, False)
+        yield from lin(p + ".self_attn.o_proj", hs, dc.num_attention_heads * dc.head_dim, False)
+        yield from lin(p + ".mlp.gate_proj", dc.intermediate_size, hs, False)
+        yield from lin(p + ".mlp.up_proj", dc.intermediate_size, hs, False)
+        yield from lin(p + ".mlp.down_proj", hs, dc.intermediate_size, False)
+        yield p + ".self_attn_layer_scale.scale", t((hs,), 0.2, 0.5)
+        yield p + ".mlp_layer_scale.scale", t((hs,), 0.2, 0.5)
+    ld = dc.latent_dim
+    for i, f in enumerate(dc.upsampling_ratios):
+        p = f"decoder.upsample.{i}.layers"
+        yield from conv(p + ".0.conv", ld, f, ld, math.sqrt(f))
+        yield from conv(p + ".1.dwconv.conv", ld, 7, 1)
+        yield p + ".1.norm.weight", t((ld,), 0.1, 1.0)
+        yield p + ".1.norm.bias", t((ld,), 0.05)
+        yield from lin(p + ".1.pwconv1", 4 * ld, ld)
+        yield from lin(p + ".1.pwconv2", ld, 4 * ld)
+        yield p + ".1.gamma", t((ld,), 0.2, 0.4)
+    yield from conv("decoder.decoder.0.conv", dc.decoder_dim, 7, ld)
+    for bi, rate in enumerate(dc.upsample_rates):
+        cin, cout = dc.decoder_dim >> bi, dc.decoder_dim >> (bi + 1)
+        p = f"decoder.decoder.{bi + 1}.block"
+        yield p + ".0.alpha", t((cin,), 0.5)
+        yield p + ".0.beta", t((cin,), 0.5)
+        yield from conv(p + ".1.conv", cout, 2 * rate, cin, math.sqrt(rate) * 0.8)
+        for ri in range(3):
+            q = f"{p}.{ri + 2}"
+            yield q + ".act1.alpha", t((cout,), 0.5)
+            yield q + ".act1.beta", t((cout,), 0.5)
+            yield from conv(q + ".conv1.conv", cout, 7, cout, 0.7)
+            yield q + ".act2.alpha", t((cout,), 0.5)
+            yield q + ".act2.beta", t((cout,), 0.5)
+            yield from conv(q + ".conv2.conv", cout, 1, cout, 0.3)
+    n, cl = len(dc.upsample_rates), dc.decoder_dim >> len(dc.upsample_rates)
+    yield f"decoder.decoder.{n + 1}.alpha", t((cl,), 0.5)
+    yield f"decoder.decoder.{n + 1}.beta", t((cl,), 0.5)
+    yield from conv(f"decoder.decoder.{n + 2}.conv", 1, 7, cl, 0.5)
