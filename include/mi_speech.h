@@ -182,6 +182,12 @@ mis_status mis_tts_set_tensor(mis_tts*, const char* name, const void* data, mis_
                               const int64_t* shape, int ndim);
 /* fills every weight on the device with the documented generator "mis-synth-v1"
  * (oracle/synth.py has the same formula); benches only - there are no checkpoints offline. */
+/* Linear / Embedding in MLX's affine-quantised form (mlx quantize [3P]): wq uint32 [N, K*bits/32] (element i of a row =
+ * (word[i / (32/bits)] >> (bits * (i % (32/bits)))) & mask), scales / biases [N, K/group_size] of dtype sb_dtype;
+ * w = scale * q + bias.  Dequantised once at load into the engine's bf16 layout (the reference keeps QuantizedLinear,
+ * LlamaTTS.swift:958-968, and dequantises inside every matmul in f32: a stated bf16-rounding deviation). */
+mis_status mis_tts_set_tensor_quantized(mis_tts*, const char* name, const uint32_t* wq, const void* scales, const void* biases,
+                                        mis_dtype sb_dtype, int64_t N, int64_t K, int group_size, int bits);
 mis_status mis_tts_init_synthetic(mis_tts*, uint64_t seed);
 mis_status mis_tts_finalize(mis_tts*);     /* verify all keys present; pack weights for MFMA streaming */
 void       mis_tts_destroy(mis_tts*);

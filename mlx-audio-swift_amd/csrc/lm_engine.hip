@@ -6,6 +6,8 @@
 // host<->device sync per token (.item() :723, eval :728); here a decode step is ONE hipGraph replay
 // (lm_head -> sampler -> embed -> 28 x [qkv, attention, o, norm, gate/up, down, norm]) and the host only
 // looks at a done-counter every few steps.
+#include <deque>
+#include <map>
 #include "common.h"
 #include "kernels.h"
 #include "lm_kernels.h"
@@ -216,6 +218,40 @@ extern "C" mis_status mis_tts_set_tensor(mis_tts* c, const char* name_, const vo
     }
     HIP_CHECK(hipGetLastError());
     HIP_CHECK(hipStreamSynchronize(c->stream));      // staging buffers are reused by the next call
+    c->loaded.insert(name);
+    MIS_API_END
+}
+
+// A Linear / Embedding stored in MLX's affine-quantised form (`weight` uint32 [N, K*bits/32], `scales` / `biases` [N, K/group],
+// written by mlx quantize; the reference re-creates QuantizedLinear modules for every path that has `.scales`,
+// LlamaTTS.swift:958-968).  The matrix is dequantised once at load into the engine's bf16 layouts.
+extern "C" mis_status mis_tts_set_tensor_quantized(mis_tts* c, const char* name_, const uint32_t* wq, const void* scales,
+                                                   const void* biases, mis_dtype sb_dtype, int64_t N, int64_t K, int group_size,
+                                                   int bits) {
+    MIS_API_BEGIN
+    MIS_REQUIRE(c && name_ && wq && scales && biases, MIS_ERR_INVALID_INPUT, "null argument");
+    MIS_REQUIRE(!c->finalized, MIS_ERR_INVALID_INPUT, "set_tensor after finalize");
+    MIS_REQUIRE(bits == 2 || bits == 4 || bits == 8, MIS_ERR_INVALID_INPUT, "unsupported quantisation width %d (2, 4 or 8 bits)", bits);
+    MIS_REQUIRE(group_size >= 1 && N >= 1 && K >= 1 && K % group_size == 0 && K % (32 / bits) == 0, MIS_ERR_INVALID_INPUT,
+                "bad quantised shape for %s", name_);
+    MIS_REQUIRE(sb_dtype == MIS_F32 || sb_dtype == MIS_F16 || sb_dtype == MIS_BF16, MIS_ERR_INVALID_INPUT, "unsupported scale dtype");
+    std::string name = name_;
+    if (name == "lm_head.weight" && c->cfg.tie_word_embeddings) return MIS_OK;
+    HIP_CHECK(hipSetDevice(c->device));
+    const size_t words = (size_t)N * K * bits / 32, ng = (size_t)N * (K / group_size), esz = sb_dtype == MIS_F32 ? 4 : 2;
+    const size_t wb = round_up(words * 4, 16), sb = round_up(ng * esz, 16);
+    c->raw_staging.alloc(wb + 2 * sb);
+    uint8_t* p = c->raw_staging.p;
+    uint8_t* ps = p + wb;
+    uint8_t* pb = ps + sb;
+    HIP_CHECK(hipMemcpyAsync(p, wq, words * 4, hipMemcpyDefault, c->stream));
+    HIP_CHECK(hipMemcpyAsync(ps, scales, ng * esz, hipMemcpyDefault, c->stream));
+    HIP_CHECK(hipMemcpyAsync(pb, biases, ng * esz, hipMemcpyDefault, c->stream));
+    c->staging.alloc((size_t)N * K);
+    launch_dequant_affine((const uint32_t*)p, ps, pb, (int)sb_dtype, c->staging.p, (int)N, (int)K, group_size, bits, c->stream);
+    place_matrix(c, name, N, K);
+    HIP_CHECK(hipGetLastError());
+    HIP_CHECK(hipStreamSynchronize(c->stream));
     c->loaded.insert(name);
     MIS_API_END
 }
@@ -1045,14 +1081,13 @@ extern "C" mis_status mis_tts_time_gemm(mis_tts* c, int which, int batch, int it
     MIS_API_END
 }
 
-// LlamaTTSModel.fromModelDirectory, LlamaTTS.swift:942-977 (quantised checkpoints: not yet supported)
+// LlamaTTSModel.fromModelDirectory, LlamaTTS.swift:942-977 (bf16 / f16 / f32 and MLX affine-quantised checkpoints)
 extern "C" mis_status mis_tts_load(const char* model_dir, mis_snac* codec, int device, mis_tts** out) {
     mis_tts* c = nullptr;
     try {
         MIS_REQUIRE(model_dir && out, MIS_ERR_INVALID_INPUT, "null argument");
         std::string dir = model_dir;
         JsonValue j = json_parse(read_text_file(dir + "/config.json"));
-        MIS_REQUIRE(!j.get("quantization"), MIS_ERR_INVALID_INPUT, "MLX affine-quantised checkpoints are not supported yet");
         mis_lm_config cf{};
         cf.hidden_size = (int)j.number_or("hidden_size", 0);
         cf.num_hidden_layers = (int)j.number_or("num_hidden_layers", 0);
@@ -1080,13 +1115,40 @@ extern "C" mis_status mis_tts_load(const char* model_dir, mis_snac* codec, int d
         }
         mis_status st = mis_tts_create(&cf, codec, device, &c);
         if (st != MIS_OK) return st;
-        for (auto& path : list_safetensors(dir)) {
-            SafeTensorFile f;
-            f.open(path);
-            for (auto& e : f.entries) {
-                st = mis_tts_set_tensor(c, e.name.c_str(), e.data, dtype_from_safetensors(e.dtype), e.shape.data(), (int)e.shape.size());
-                if (st != MIS_OK) { mis_tts_destroy(c); return st; }
+        // MLX affine-quantised checkpoints: "quantization": {"group_size": g, "bits": b, "<module path>": {...} | false, ...}
+        // (BaseConfiguration.perLayerQuantization; a module is quantised iff "<path>.scales" exists, LlamaTTS.swift:958-968)
+        const JsonValue* qz = j.get("quantization");
+        if (!qz) qz = j.get("quantization_config");
+        int q_group = qz ? (int)qz->number_or("group_size", 64) : 0, q_bits = qz ? (int)qz->number_or("bits", 4) : 0;
+        std::deque<SafeTensorFile> files;                       // deque: no relocation (the files own their mappings)
+        for (auto& path : list_safetensors(dir)) { files.emplace_back(); files.back().open(path); }
+        std::map<std::string, const SafeTensorEntry*> index;
+        for (auto& f : files) for (auto& e : f.entries) index[e.name] = &e;
+        for (auto& kv : index) {
+            const SafeTensorEntry& e = *kv.second;
+            const std::string& nm = e.name;
+            auto ends = [&](const char* suf) { size_t l = strlen(suf); return nm.size() > l && nm.compare(nm.size() - l, l, suf) == 0; };
+            if (ends(".scales") || ends(".biases")) {
+                MIS_REQUIRE(qz, MIS_ERR_INVALID_INPUT, "%s present but config.json has no quantization entry", nm.c_str());
+                continue;
             }
+            const std::string base = ends(".weight") ? nm.substr(0, nm.size() - 7) : std::string();
+            auto sc = base.empty() ? index.end() : index.find(base + ".scales");
+            if (sc != index.end()) {
+                auto bi = index.find(base + ".biases");
+                MIS_REQUIRE(bi != index.end() && e.dtype == "U32" && e.shape.size() == 2 && sc->second->shape.size() == 2, MIS_ERR_INVALID_INPUT,
+                            "malformed quantised tensor %s", nm.c_str());
+                int g = q_group, b = q_bits;
+                if (const JsonValue* ov = qz ? qz->get(base) : nullptr)
+                    if (ov->type == JsonValue::OBJ) { g = (int)ov->number_or("group_size", g); b = (int)ov->number_or("bits", b); }
+                const int64_t N = e.shape[0], K = sc->second->shape[1] * g;
+                MIS_REQUIRE(b > 0 && e.shape[1] * 32 / b == K, MIS_ERR_INVALID_INPUT, "quantised tensor %s: packed width does not match bits/group_size", nm.c_str());
+                st = mis_tts_set_tensor_quantized(c, nm.c_str(), (const uint32_t*)e.data, sc->second->data, bi->second->data,
+                                                  dtype_from_safetensors(sc->second->dtype), N, K, g, b);
+            } else {
+                st = mis_tts_set_tensor(c, nm.c_str(), e.data, dtype_from_safetensors(e.dtype), e.shape.data(), (int)e.shape.size());
+            }
+            if (st != MIS_OK) { mis_tts_destroy(c); return st; }
         }
         st = mis_tts_finalize(c);
         if (st != MIS_OK) { mis_tts_destroy(c); return st; }

@@ -10,6 +10,9 @@ __host__ __device__ __forceinline__ size_t xpk_index(int m, int k, int MT) {
 enum { EPI_PARTIAL = 0, EPI_BF16 = 1, EPI_SILU_MUL = 2, EPI_GELU_PACKED = 3, EPI_SILU_PACKED = 4 };
 
 void launch_convert_to_bf16(const void* src, int dtype, bf16_t* dst, size_t n, hipStream_t s);
+// MLX affine-quantised matrix (uint32 words, per-group scales / biases of dtype sb_dtype = mis_dtype) -> bf16 [N][K]
+void launch_dequant_affine(const uint32_t* wq, const void* scales, const void* biases, int sb_dtype, bf16_t* dst, int N, int K,
+                           int group, int bits, hipStream_t s);
 void launch_pack_weight(const bf16_t* src, bf16_t* dst, int N, int K, int NT, int tile_stride, int tile_offset,
                         hipStream_t s);
 void launch_synth_fill_bf16(bf16_t* dst, size_t n, uint64_t key, float amp, int plus_one, hipStream_t s);

@@ -16,6 +16,7 @@
 //   K cache   bf16 tiled as QK^T A-fragments  [B][Hkv][Smax/32][2][D/32][64][8]
 //   V cache   bf16 tiled as P.V  B-fragments  [B][Hkv][Smax/32][D/16][64][8]   (8 consecutive keys per lane)
 //   split-K partial slabs f32 [S][Mpad][N]; reduced in the consumer's prologue (deterministic order)
+#include <hip/hip_fp16.h>
 #include "common.h"
 #include "lm_kernels.h"
 
@@ -58,6 +59,29 @@ __global__ void k_synth_fill_bf16(bf16_t* __restrict__ dst, size_t n, uint64_t k
     if (plus_one != 2) v = bf16_round_f32(v);        // plus_one: 1 = bf16(1 + bf16(x)), 2 = bf16(1 + x)
     if (plus_one) v = 1.0f + v;
     dst[i] = f32_to_bf16(v);
+}
+
+// MLX affine quantisation (mlx quantize / dequantize [3P]): element i of row o is (wq[o][i / epw] >> (bits * (i % epw))) & mask,
+// epw = 32 / bits; w = scale[o][i / group] * q + bias[o][i / group].  Output bf16 row-major [N][K].
+__global__ void k_dequant_affine(const uint32_t* __restrict__ wq, const void* __restrict__ scales, const void* __restrict__ biases,
+                                 int sb_dtype, bf16_t* __restrict__ dst, int N, int K, int group, int bits) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (size_t)N * K) return;
+    const int o = (int)(i / K), k = (int)(i - (size_t)o * K);
+    const int epw = 32 / bits;
+    const uint32_t word = wq[(size_t)o * (K / epw) + k / epw];
+    const float q = (float)((word >> (bits * (k % epw))) & ((1u << bits) - 1u));
+    const size_t g = (size_t)o * (K / group) + k / group;
+    float sc, bi;
+    if (sb_dtype == 0) { sc = ((const float*)scales)[g]; bi = ((const float*)biases)[g]; }
+    else if (sb_dtype == 2) { sc = bf16_to_f32(((const bf16_t*)scales)[g]); bi = bf16_to_f32(((const bf16_t*)biases)[g]); }
+    else { sc = __half2float(((const __half*)scales)[g]); bi = __half2float(((const __half*)biases)[g]); }
+    dst[i] = f32_to_bf16(sc * q + bi);
+}
+void launch_dequant_affine(const uint32_t* wq, const void* scales, const void* biases, int sb_dtype, bf16_t* dst, int N, int K,
+                           int group, int bits, hipStream_t s) {
+    size_t n = (size_t)N * K;
+    hipLaunchKernelGGL(k_dequant_affine, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, wq, scales, biases, sb_dtype, dst, N, K, group, bits);
 }
 
 void launch_convert_to_bf16(const void* src, int dtype, bf16_t* dst, size_t n, hipStream_t s) {

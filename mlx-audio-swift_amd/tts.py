@@ -131,6 +131,16 @@ class LlamaTTSModel:
         sh = (C.c_int64 * len(shape))(*shape)
         check(_lib.lib().mis_tts_set_tensor(self._h, name.encode(), ptr, dt, sh, len(shape)))
 
+    def set_quantized_tensor(self, name: str, wq, scales, biases, group_size: int = 64, bits: int = 4):
+        """A matrix in MLX's affine-quantised form: wq uint32 [N, K*bits/32], scales / biases [N, K/group_size]."""
+        wq = np.ascontiguousarray(wq, dtype=np.uint32)
+        ks, ps, ds, ss = _tensor_args(scales)
+        kb, pb, db, sb = _tensor_args(biases)
+        if ds != db or tuple(ss) != tuple(sb):
+            raise AudioGenerationError(3, "scales and biases must share dtype and shape")
+        N, K = int(ss[0]), int(ss[1]) * group_size
+        check(_lib.lib().mis_tts_set_tensor_quantized(self._h, name.encode(), wq.ctypes.data, ps, pb, ds, N, K, group_size, bits))
+
     def finalize(self):
         check(_lib.lib().mis_tts_finalize(self._h))
 
