@@ -202,8 +202,8 @@ def main():
             "value": value, "unit": "audio-s/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
-            "config": {"workload": "Orpheus-3B bf16 TTS + SNAC 24 kHz decode, batch 32 per GPU (BASELINE configs[2]; "
-                                   "configs[1] Soprano not built yet), 32-token prompts, 672 new tokens/row = 8.192 s/row",
+            "config": {"workload": "Orpheus-3B bf16 TTS + SNAC 24 kHz decode, batch 32 per GPU (BASELINE configs[2], the configuration the "
+                                   "metric is quoted on), 32-token prompts, 672 new tokens/row = 8.192 s/row",
                        "rows_per_gpu": ROWS_PER_GPU, "global_rows": n_rows, "prompt_len": PROMPT_LEN,
                        "new_tokens": NEW_TOKENS, "parallelism": f"utterance-dp{world}", "sampler": "T0.6 top-p0.8 rep1.3"},
             "value_per_gpu": value / world,

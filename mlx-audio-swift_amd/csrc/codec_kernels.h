@@ -22,9 +22,10 @@ struct GemmParams {
     int M, K, N;          // N = output columns per phase
     int Tin, Tout;
     int s, pad, Cin;      // CONVT only (Cin also TAPS)
-    int taps, dil;        // TAPS: causal dense conv, K = taps*Cin, tap j reads x[:, n - (taps-1-j)*dil] (zero before 0); A^T row j*Cin + c
+    int taps, dil;        // TAPS: dense conv, K = taps*Cin, tap j reads x[:, n - pad + j*dil] (zero outside); A^T row j*Cin + c;
+                          // pad = (taps-1)*dil: causal, (taps-1)*dil/2: "same"; optional R (+scale) residual epilogue
 };
-// snake: Snake prologue on the X rows (CONVT and TAPS always run it: pass alpha = ralpha = zeros for identity)
+// snake: Snake prologue on the X rows (CONVT always runs it: pass alpha = ralpha = zeros for identity)
 void launch_gemm(int mode, bool snake, const GemmParams& p, int batch, hipStream_t s);
 // depthwise 7-tap conv (zero padded, dilation dil): shorter odd kernels ride in centred 7-tap weights
 void launch_dw7(const float* X, float* Y, const float* w7 /*[C][7]*/, const float* bias, int batch, int C, int T, int dil, hipStream_t s);

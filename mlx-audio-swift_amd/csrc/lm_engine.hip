@@ -1047,7 +1047,8 @@ extern "C" mis_status mis_tts_time_gemm(mis_tts* c, int which, int batch, int it
     // rotate over the layers so consecutive launches stream DIFFERENT weights (the 256 MB Infinity Cache
     // must not serve them); lm_head (0.96 GB) exceeds the cache by itself.
     auto run = [&](int it) {
-        size_t li = (size_t)(it % c->L);
+        static const int fixed = env_int("MIS_TIME_GEMM_FIXED_LAYER", -1);      // experiment: weights stay in the Infinity Cache
+        size_t li = fixed >= 0 ? (size_t)fixed : (size_t)(it % c->L);
         switch (which) {
             case 0: launch_gemm_skinny(EPI_PARTIAL, c->r_part, c->ksb_part, c->wqkv.p + layer_qkv_elems(c) * li, c->x.p, c->qkv_part.p, c->Nqkv / 16, d / 32, c->S_qkv, c->Nqkv, Mpad, s); break;
             case 1: launch_gemm_skinny(EPI_PARTIAL, c->r_part, c->ksb_part, c->wo.p + layer_o_elems(c) * li, c->attn_out.p, c->part.p, d / 16, HD / 32, c->S_o, d, Mpad, s); break;

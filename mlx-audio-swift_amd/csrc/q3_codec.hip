@@ -427,7 +427,7 @@ static const float* q3dec_run(mis_q3dec* d, const int32_t* codes_dev, int batch,
     if (stop_after == 1) { *outC = Cd; *outT = T; return a; }
     {   // pre_conv: causal k3
         GemmParams g = gemm(GEMM_TAPS, true, d->pre_conv, a, b, T, T, T, nullptr, nullptr, Z, Z);
-        g.Cin = Cd; g.taps = 3; g.dil = 1;
+        g.Cin = Cd; g.taps = 3; g.dil = 1; g.pad = 2;
         launch_gemm(GEMM_TAPS, true, g, batch, s);
     }
     // ---- transformer (NCT: channels x time), x in `a`
@@ -469,7 +469,7 @@ static const float* q3dec_run(mis_q3dec* d, const int32_t* codes_dev, int batch,
     if (stop_after == 3) { *outC = ld; *outT = Tc; return x; }
     {   // decoder.0: causal k7
         GemmParams g = gemm(GEMM_TAPS, true, d->dec0, x, y, Tc, Tc, Tc, nullptr, nullptr, Z, Z);
-        g.Cin = ld; g.taps = 7; g.dil = 1;
+        g.Cin = ld; g.taps = 7; g.dil = 1; g.pad = 6;
         launch_gemm(GEMM_TAPS, true, g, batch, s);
         std::swap(x, y);
     }
@@ -483,7 +483,7 @@ static const float* q3dec_run(mis_q3dec* d, const int32_t* codes_dev, int batch,
         for (int ri = 0; ri < 3; ++ri) {
             const auto& R = B.ru[ri];
             GemmParams g1 = gemm(GEMM_TAPS, true, R.c1, x, t1, Tc, Tc, Tc, nullptr, nullptr, W + R.a1, W + R.ra1);
-            g1.Cin = B.cout; g1.taps = 7; g1.dil = R.dil;
+            g1.Cin = B.cout; g1.taps = 7; g1.dil = R.dil; g1.pad = 6 * R.dil;
             launch_gemm(GEMM_TAPS, true, g1, batch, s);
             launch_gemm(GEMM_RESID, true, gemm(GEMM_RESID, true, R.c2, t1, y, Tc, Tc, Tc, x, nullptr, W + R.a2, W + R.ra2), batch, s);
             std::swap(x, y);

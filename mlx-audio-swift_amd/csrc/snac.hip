@@ -245,6 +245,118 @@ __global__ void __launch_bounds__(256) k_snac_gemm(GemmParams p) {
     }
 }
 
+// ---- dense k-tap conv on f32 MFMA (Qwen3-TTS / DAC-style decoders: dilated k7 convs with Cin = Cout up to 1536) ---------
+// y[m][n] = bias[m] + sum_{j < taps} sum_c W[m][j][c] * act(x[c][n - pad_left + j*dil]),  zero outside [0, Tin).
+// Loop order (channel chunk outer, tap inner): the activation tile WITH its halo is staged once per 16 channels (aligned
+// float4 loads, Snake applied on the way in) and every tap reads it from LDS at a column offset, so x is fetched once instead
+// of `taps` times and never with scalar loads; the `taps` weight tiles of the chunk are staged together (2 barriers per chunk
+// for taps*16 MFMA steps).  A^T row (j*Cin + c), as for the other modes.
+#define CT_XS 224                     // staged columns per row: G_BN + halo (<= 92) + alignment slack (<= 3)
+#define CT_MAXT 7
+template <bool RESID>
+__global__ void __launch_bounds__(256) k_conv_taps(GemmParams p) {
+    __shared__ float As[CT_MAXT][G_BK][G_BM];
+    __shared__ float Xs[G_BK][CT_XS];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int n0 = blockIdx.x * G_BN, m0 = blockIdx.y * G_BM, b = blockIdx.z;
+    const float* Xb = p.X + (size_t)b * p.Cin * p.Tin;
+    const int halo = (p.taps - 1) * p.dil;
+    const int c_lo = n0 - p.pad;                       // first needed input column (may be negative)
+    const int a0 = (c_lo >= 0 ? c_lo : c_lo - 3) / 4 * 4;     // aligned-down staging origin
+    const int off = c_lo - a0;                         // 0..3
+    const int ncols = off + G_BN + halo;               // staged columns
+    const bool vec = (p.Tin & 3) == 0;
+    f32x16_t acc[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.0f;
+    // staging registers: A: taps float4 per thread (row tid>>4, cols (tid&15)*4); X: 4 float4 per thread
+    const int ar = tid >> 4, ac = (tid & 15) * 4;
+    float4 ra[CT_MAXT], rx[4];
+    auto load_chunk = [&](int c0) {
+#pragma unroll
+        for (int j = 0; j < CT_MAXT; ++j) {
+            if (j >= p.taps) break;
+            const int k = j * p.Cin + c0 + ar, m = m0 + ac;
+            if (c0 + ar < p.Cin && (p.M & 3) == 0 && m + 3 < p.M) ra[j] = *reinterpret_cast<const float4*>(p.AT + (size_t)k * p.M + m);
+            else {
+                float v[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = (c0 + ar < p.Cin && m + e < p.M) ? p.AT[(size_t)k * p.M + m + e] : 0.0f;
+                ra[j] = make_float4(v[0], v[1], v[2], v[3]);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {                    // 16 rows x 56 float4
+            const int idx = tid + i * 256;
+            const int row = idx / (CT_XS / 4), c4 = (idx - row * (CT_XS / 4)) * 4;
+            float v[4] = {0.f, 0.f, 0.f, 0.f};
+            if (row < G_BK && c0 + row < p.Cin && c4 < ncols) {
+                const float* src = Xb + (size_t)(c0 + row) * p.Tin;
+                const int g = a0 + c4;
+                if (vec && g >= 0 && g + 3 < p.Tin) { float4 t = *reinterpret_cast<const float4*>(src + g); v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w; }
+                else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = (g + e >= 0 && g + e < p.Tin) ? src[g + e] : 0.0f;
+                }
+                if (p.alpha) {
+                    const float al = p.alpha[c0 + row], ra_ = p.ralpha[c0 + row];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = snake_f(v[e], al, ra_);      // snake(0) = 0 keeps the zero padding
+                }
+            }
+            rx[i] = make_float4(v[0], v[1], v[2], v[3]);
+        }
+    };
+    const int nchunks = (p.Cin + G_BK - 1) / G_BK;
+    load_chunk(0);
+    for (int cc = 0; cc < nchunks; ++cc) {
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < CT_MAXT; ++j) {
+            if (j >= p.taps) break;
+            *reinterpret_cast<float4*>(&As[j][ar][ac]) = ra[j];
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int idx = tid + i * 256;
+            const int row = idx / (CT_XS / 4), c4 = (idx - row * (CT_XS / 4)) * 4;
+            if (row < G_BK) *reinterpret_cast<float4*>(&Xs[row][c4]) = rx[i];
+        }
+        __syncthreads();
+        if (cc + 1 < nchunks) load_chunk((cc + 1) * G_BK);
+        for (int j = 0; j < p.taps; ++j) {
+            const int xo = off + j * p.dil + wn * 64 + (lane & 31);
+#pragma unroll
+            for (int kk = 0; kk < G_BK; kk += 2) {
+                float a = As[j][kk + (lane >> 5)][wm * 32 + (lane & 31)];
+#pragma unroll
+                for (int t = 0; t < 2; ++t) {
+                    float bv = Xs[kk + (lane >> 5)][xo + t * 32];
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bv, acc[t], 0, 0, 0);
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        int n = n0 + wn * 64 + t * 32 + (lane & 31);
+        if (n >= p.N) continue;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            int m = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+            if (m >= p.M) continue;
+            float v = acc[t][r];
+            if (p.bias) v += p.bias[m];
+            size_t o = ((size_t)b * p.M + m) * p.Tout + n;
+            if (RESID) { if (p.scale) v *= p.scale[m]; v += p.R[o]; }
+            p.Y[o] = v;
+        }
+    }
+}
+
 // ---- final Snake -> conv k7 (C -> 1) -> tanh ----------------------------------------------------------
 #define FIN_TILE 256
 #define FIN_CH 16
@@ -545,7 +657,14 @@ void launch_gemm(int mode, bool snake, const GemmParams& p, int batch, hipStream
     else if (mode == GEMM_GELU) hipLaunchKernelGGL((k_snac_gemm<GEMM_GELU, false>), grid, block, 0, s, p);
     else if (mode == GEMM_RESID && snake) hipLaunchKernelGGL((k_snac_gemm<GEMM_RESID, true>), grid, block, 0, s, p);
     else if (mode == GEMM_RESID) hipLaunchKernelGGL((k_snac_gemm<GEMM_RESID, false>), grid, block, 0, s, p);
-    else if (mode == GEMM_TAPS) { MIS_REQUIRE(p.alpha && p.ralpha, MIS_ERR_GENERATION_FAILED, "taps GEMM needs snake arrays"); hipLaunchKernelGGL((k_snac_gemm<GEMM_TAPS, true>), grid, block, 0, s, p); }
+    else if (mode == GEMM_TAPS) {
+        MIS_REQUIRE(p.taps >= 1 && p.taps <= CT_MAXT && (p.taps - 1) * p.dil + 3 + G_BN <= CT_XS, MIS_ERR_INVALID_INPUT,
+                    "dense conv: %d taps with dilation %d exceed the staged halo", p.taps, p.dil);
+        GemmParams q = p;
+        if (!snake) { q.alpha = nullptr; q.ralpha = nullptr; }
+        if (q.R) hipLaunchKernelGGL((k_conv_taps<true>), grid, block, 0, s, q);
+        else hipLaunchKernelGGL((k_conv_taps<false>), grid, block, 0, s, q);
+    }
     else if (mode == GEMM_NOISE) hipLaunchKernelGGL((k_snac_gemm<GEMM_NOISE, false>), grid, block, 0, s, p);
     else { MIS_REQUIRE(snake, MIS_ERR_GENERATION_FAILED, "convT without snake"); hipLaunchKernelGGL((k_snac_gemm<GEMM_CONVT, true>), grid, block, 0, s, p); }
 }

@@ -563,18 +563,40 @@ extern "C" mis_status mis_stt_whisper_generate(mis_whisper* c, const float* pcm,
     int32_t* done_host = nullptr;
     HIP_CHECK(hipHostMalloc((void**)&done_host, 4, 0));
     *done_host = 0;
-    for (int step = 0; step < max_tokens; ++step) {
+    // one decode step = logits GEMM -> suppress masks -> argmax / sampler -> next token through the decoder: every argument
+    // is a device pointer that stays put, so the step is captured once and replayed (≈430 kernel nodes per step)
+    auto step_body = [&]() {
         enqueue_vocab(c);
         launch_whisper_suppress(c->logits.p, c->Vpad, c->V, c->sup.p, sp->n_suppress, c->bsup.p, sp->n_begin_suppress, c->n_gen.p,
                                 c->active.p, batch, s);
         launch_sampler(q, batch, s);
         enqueue_decoder_step(c);
-        if ((step & 7) == 7 || step + 1 == max_tokens) {
-            HIP_CHECK(hipMemcpyAsync(done_host, c->done_count.p, 4, hipMemcpyDeviceToHost, s));
-            HIP_CHECK(hipStreamSynchronize(s));
-            if (*done_host >= batch) break;
+    };
+    hipGraphExec_t gexec = nullptr;
+    const bool use_graph = getenv("MIS_NO_GRAPH") == nullptr;
+    try {
+        if (use_graph) {
+            hipGraph_t g = nullptr;
+            HIP_CHECK(hipStreamBeginCapture(s, hipStreamCaptureModeGlobal));
+            try { step_body(); } catch (...) { hipGraph_t dead = nullptr; (void)hipStreamEndCapture(s, &dead); if (dead) (void)hipGraphDestroy(dead); throw; }
+            HIP_CHECK(hipStreamEndCapture(s, &g));
+            HIP_CHECK(hipGraphInstantiate(&gexec, g, nullptr, nullptr, 0));
+            HIP_CHECK(hipGraphDestroy(g));
         }
+        for (int step = 0; step < max_tokens; ++step) {
+            if (use_graph) HIP_CHECK(hipGraphLaunch(gexec, s)); else step_body();
+            if ((step & 7) == 7 || step + 1 == max_tokens) {
+                HIP_CHECK(hipMemcpyAsync(done_host, c->done_count.p, 4, hipMemcpyDeviceToHost, s));
+                HIP_CHECK(hipStreamSynchronize(s));
+                if (*done_host >= batch) break;
+            }
+        }
+    } catch (...) {
+        if (gexec) (void)hipGraphExecDestroy(gexec);
+        (void)hipHostFree(done_host);
+        throw;
     }
+    if (gexec) (void)hipGraphExecDestroy(gexec);
     (void)hipHostFree(done_host);
     HIP_CHECK(hipGetLastError());
     std::vector<int32_t> ng(batch), toks((size_t)batch * max_tokens);
