@@ -344,6 +344,28 @@ mis_status mis_qwen3tts_sample_logits(int device, const float* logits, int batch
                                       int32_t* tokens_out);
 
 /* ------------------------------------------------------------------------------------------
+ * Descript DAC decoder.  Replaces DescriptDAC.decodeFromCodes / decode (Sources/MLXAudioCodecs/Descript/DescriptDAC.swift:
+ * 103-160,235-242) and DescriptResidualVectorQuantize.fromCodes (DescriptQuantization.swift:150-163).  Encoder tensors
+ * ("encoder.*", "*.in_proj.*") are accepted and ignored (the encode path is not built).
+ * ---------------------------------------------------------------------------------------- */
+typedef struct mis_dac mis_dac;
+typedef struct {                   /* DescriptDACConfig.swift:3-34; latent_dim resolved (encoder_dim * 2^len(encoder_rates)) */
+    int32_t latent_dim, decoder_dim;
+    int32_t n_decoder_rates; int32_t decoder_rates[8];
+    int32_t n_codebooks, codebook_size, codebook_dim;
+    int32_t sample_rate;
+} mis_dac_config;
+mis_status mis_dac_create(const mis_dac_config*, int device, mis_dac** out);
+/* checkpoint keys as stored; DescriptDAC.sanitize (:274-286) is applied */
+mis_status mis_dac_set_tensor(mis_dac*, const char* name, const void* data, mis_dtype dtype, const int64_t* shape, int ndim);
+mis_status mis_dac_finalize(mis_dac*);
+void       mis_dac_destroy(mis_dac*);
+int64_t    mis_dac_num_samples(const mis_dac*, int n_frames);    /* 250 frames @ [8,5,4,2] -> 80 043 (output_padding 1 per block) */
+mis_status mis_dac_decode_codes(mis_dac*, const int32_t* codes, int batch, int T, float* wav_out);
+mis_status mis_dac_debug_tap(mis_dac*, const int32_t* codes, int batch, int T, int block, float* out, int64_t capacity,
+                             int32_t* channels, int64_t* length);
+
+/* ------------------------------------------------------------------------------------------
  * Log-mel / STFT front end.  Replaces WhisperAudio.logMelSpectrogram / encoderFeatures
  * (Sources/MLXAudioSTT/Models/Whisper/WhisperAudio.swift:38-87) and computeMelSpectrogram
  * (Sources/MLXAudioCore/DSP.swift:230-273): reflect pad, window, rfft, |.|^2, mel filterbank

@@ -69,6 +69,12 @@ class Qwen3TTSParamsC(C.Structure):
                 ("repetition_penalty", C.c_float), ("min_p", C.c_float), ("seed", C.c_uint64), ("row_offset", C.c_int64)]
 
 
+class DacConfigC(C.Structure):
+    _fields_ = [("latent_dim", C.c_int32), ("decoder_dim", C.c_int32), ("n_decoder_rates", C.c_int32),
+                ("decoder_rates", C.c_int32 * 8), ("n_codebooks", C.c_int32), ("codebook_size", C.c_int32),
+                ("codebook_dim", C.c_int32), ("sample_rate", C.c_int32)]
+
+
 class MelConfigC(C.Structure):
     _fields_ = [("sample_rate", C.c_int32), ("n_fft", C.c_int32), ("hop_length", C.c_int32), ("n_mels", C.c_int32),
                 ("window", C.c_int32), ("mel_scale", C.c_int32), ("slaney_norm", C.c_int32), ("drop_last_frame", C.c_int32)]
@@ -172,6 +178,13 @@ SYMBOLS = {
                                         C.c_int, EVENT_CB, _P, _P]),
     "mis_qwen3tts_sample_logits": (C.c_int, [C.c_int, _P, C.c_int, C.c_int, _P, C.POINTER(Qwen3TTSParamsC), C.c_int, C.c_int,
                                              C.c_int, C.c_int, _P]),
+    "mis_dac_create": (C.c_int, [C.POINTER(DacConfigC), C.c_int, C.POINTER(_P)]),
+    "mis_dac_set_tensor": (C.c_int, [_P, C.c_char_p, _P, C.c_int, C.POINTER(C.c_int64), C.c_int]),
+    "mis_dac_finalize": (C.c_int, [_P]),
+    "mis_dac_destroy": (None, [_P]),
+    "mis_dac_num_samples": (C.c_int64, [_P, C.c_int]),
+    "mis_dac_decode_codes": (C.c_int, [_P, _P, C.c_int, C.c_int, _P]),
+    "mis_dac_debug_tap": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, _P, C.c_int64, C.POINTER(C.c_int32), C.POINTER(C.c_int64)]),
     "mis_debug_launch_floor": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_double)]),
 }
 

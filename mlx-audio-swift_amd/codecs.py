@@ -194,3 +194,79 @@ class SNAC:
             self.close()
         except Exception:
             pass
+
+
+@dataclass
+class DescriptDACConfig:
+    """DescriptDACConfig (Sources/MLXAudioCodecs/Descript/DescriptDACConfig.swift:3-34)"""
+    encoder_dim: int = 64
+    encoder_rates: tuple = (2, 4, 5, 8)
+    latent_dim: int | None = None
+    decoder_dim: int = 1536
+    decoder_rates: tuple = (8, 5, 4, 2)
+    n_codebooks: int = 12
+    codebook_size: int = 1024
+    codebook_dim: int = 8
+    sample_rate: int = 16000
+
+    @property
+    def resolved_latent(self) -> int:
+        return self.latent_dim or self.encoder_dim * 2 ** len(self.encoder_rates)
+
+    def to_c(self) -> "_lib.DacConfigC":
+        return _lib.DacConfigC(self.resolved_latent, self.decoder_dim, len(self.decoder_rates), (C.c_int32 * 8)(*self.decoder_rates),
+                               self.n_codebooks, self.codebook_size, self.codebook_dim, self.sample_rate)
+
+
+class DescriptDAC:
+    """Decode side of class DescriptDAC (Descript/DescriptDAC.swift:172-245): decode_from_codes.  encode() is not built."""
+
+    def __init__(self, config: DescriptDACConfig, device: int = 0):
+        self.config = config
+        self._h = C.c_void_p()
+        cc = config.to_c()
+        check(_lib.lib().mis_dac_create(C.byref(cc), device, C.byref(self._h)))
+
+    def __del__(self):
+        h, self._h = getattr(self, "_h", None), None
+        if h:
+            _lib.lib().mis_dac_destroy(h)
+
+    @classmethod
+    def from_weights(cls, config, weights: dict, device: int = 0) -> "DescriptDAC":
+        m = cls(config, device)
+        for k, v in weights.items():
+            keep, ptr, dt, shape = _tensor_args(v)
+            sh = (C.c_int64 * len(shape))(*shape)
+            check(_lib.lib().mis_dac_set_tensor(m._h, k.encode(), ptr, dt, sh, len(shape)))
+        check(_lib.lib().mis_dac_finalize(m._h))
+        return m
+
+    @property
+    def codec_sample_rate(self) -> float:
+        return float(self.config.sample_rate)
+
+    def num_samples(self, n_frames: int) -> int:
+        return int(_lib.lib().mis_dac_num_samples(self._h, n_frames))
+
+    def decode_from_codes(self, codes) -> np.ndarray:
+        """codes int [B, n_codebooks, T] -> waveform float32 [B, num_samples(T)]"""
+        cd = np.ascontiguousarray(codes, dtype=np.int32)
+        B, ncb, T = cd.shape
+        if ncb != self.config.n_codebooks:
+            raise AudioGenerationError(3, "wrong number of codebooks")
+        out = np.zeros((B, self.num_samples(T)), np.float32)
+        check(_lib.lib().mis_dac_decode_codes(self._h, cd.ctypes.data, B, T, out.ctypes.data))
+        return out
+
+    def debug_tap(self, codes, block: int) -> np.ndarray:
+        cd = np.ascontiguousarray(codes, dtype=np.int32)
+        B, ncb, T = cd.shape
+        cap = B * self.config.decoder_dim * self.num_samples(T)
+        buf = np.zeros(cap, np.float32)
+        ch = C.c_int32(); ln = C.c_int64()
+        check(_lib.lib().mis_dac_debug_tap(self._h, cd.ctypes.data, B, T, block, buf.ctypes.data, cap, C.byref(ch), C.byref(ln)))
+        return buf[: B * ch.value * ln.value].reshape(B, ch.value, ln.value).copy()
+
+    def encode(self, audio):
+        raise AudioGenerationError(5, "DAC encode path is not built")
