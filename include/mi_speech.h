@@ -387,6 +387,18 @@ mis_status mis_mel_spectrogram(int device, const mis_mel_config*, const float* p
 mis_status mis_whisper_encoder_features(int device, const float* pcm, const int64_t* lens, int batch, int64_t stride,
                                         int n_mels, float* out);
 
+/* Streaming front end: IncrementalMelSpectrogram (Sources/MLXAudioSTT/Streaming/IncrementalMelSpectrogram.swift:17-215).
+ * One handle per audio session; overlap-save framing and the running log-maximum are carried between calls.
+ * out f32 [capacity_frames, n_mels]; *n_frames = frames produced by this call (0 while a frame is incomplete). */
+typedef struct mis_mel_stream mis_mel_stream;
+mis_status mis_mel_stream_create(int device, int sample_rate, int n_fft, int hop_length, int n_mels, mis_mel_stream** out);
+mis_status mis_mel_stream_process(mis_mel_stream*, const float* samples, int64_t n, float* out, int64_t capacity_frames,
+                                  int64_t* n_frames);
+mis_status mis_mel_stream_flush(mis_mel_stream*, float* out, int64_t capacity_frames, int64_t* n_frames);
+mis_status mis_mel_stream_reset(mis_mel_stream*);
+int64_t    mis_mel_stream_total_frames(const mis_mel_stream*);
+void       mis_mel_stream_destroy(mis_mel_stream*);
+
 /* ------------------------------------------------------------------------------------------
  * Whisper STT.  Replaces WhisperModel / WhisperEncoder / WhisperDecoder
  * (Sources/MLXAudioSTT/Models/Whisper/WhisperModel.swift:36-309, WhisperLayers.swift:110-328).

@@ -185,6 +185,12 @@ SYMBOLS = {
     "mis_dac_num_samples": (C.c_int64, [_P, C.c_int]),
     "mis_dac_decode_codes": (C.c_int, [_P, _P, C.c_int, C.c_int, _P]),
     "mis_dac_debug_tap": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, _P, C.c_int64, C.POINTER(C.c_int32), C.POINTER(C.c_int64)]),
+    "mis_mel_stream_create": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(_P)]),
+    "mis_mel_stream_process": (C.c_int, [_P, _P, C.c_int64, _P, C.c_int64, C.POINTER(C.c_int64)]),
+    "mis_mel_stream_flush": (C.c_int, [_P, _P, C.c_int64, C.POINTER(C.c_int64)]),
+    "mis_mel_stream_reset": (C.c_int, [_P]),
+    "mis_mel_stream_total_frames": (C.c_int64, [_P]),
+    "mis_mel_stream_destroy": (None, [_P]),
     "mis_debug_launch_floor": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_double)]),
 }
 

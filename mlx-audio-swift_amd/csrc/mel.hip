@@ -57,6 +57,7 @@ struct MelParams {
     const float* filt;       // [nfp][nmp]
     long long n_samples;
     int n_fft, hop, n_mels, nfp, nmp, frames_total, frames_out;
+    int raw;                 // 1: frames taken from the signal as given (no centre padding): streaming overlap-save
 };
 
 __global__ void __launch_bounds__(256) k_mel_tile(MelParams p) {
@@ -71,7 +72,10 @@ __global__ void __launch_bounds__(256) k_mel_tile(MelParams p) {
         int f = idx / p.n_fft, k = idx - f * p.n_fft;
         int fr = f0 + f;
         float v = 0.0f;
-        if (fr < p.frames_total) v = padded_sample(a, p.n_samples, (long long)fr * p.hop + k, pad) * p.window[k];
+        if (fr < p.frames_total) {
+            const long long q = (long long)fr * p.hop + k;
+            v = (p.raw ? (q < p.n_samples ? a[q] : 0.0f) : padded_sample(a, p.n_samples, q, pad)) * p.window[k];
+        }
         lds[f * FS + k] = v;
     }
     __syncthreads();
@@ -314,5 +318,137 @@ extern "C" mis_status mis_whisper_encoder_features(int device, const float* pcm,
     }
     run_mel(device, c, din.p, batch, W, dout.p, 0);
     HIP_CHECK(hipMemcpy(out, dout.p, (size_t)batch * 3000 * n_mels * 4, hipMemcpyDefault));
+    MIS_API_END
+}
+
+// ---------------------------------------------------------------------------- streaming front end
+// IncrementalMelSpectrogram (Sources/MLXAudioSTT/Streaming/IncrementalMelSpectrogram.swift:17-215): overlap-save framing across
+// chunk boundaries (n_fft - hop samples carried), reflected prefix on the first chunk, log10 clamp against the RUNNING maximum of
+// the session.  The chunk bookkeeping is host state exactly as in the reference; framing, DFT, filterbank, log and normalisation
+// run in k_mel_tile / k_mel_normalize (raw mode, row_max seeded with the running maximum).
+struct mis_mel_stream {
+    int device = 0;
+    mis_mel_config cfg{};
+    std::vector<float> overlap;
+    bool first = true;
+    float running_max = -INFINITY;
+    int64_t total_frames = 0;
+    hipStream_t stream = nullptr;
+    DevBuf<float> sig, out, rmax;
+};
+
+extern "C" mis_status mis_mel_stream_create(int device, int sample_rate, int n_fft, int hop_length, int n_mels, mis_mel_stream** out) {
+    MIS_API_BEGIN
+    MIS_REQUIRE(out && n_fft >= 2 && hop_length >= 1 && hop_length <= n_fft && n_mels >= 1 && sample_rate >= 1, MIS_ERR_INVALID_INPUT, "bad argument");
+    int n = 0;
+    HIP_CHECK(hipGetDeviceCount(&n));
+    MIS_REQUIRE(device >= 0 && device < n, MIS_ERR_DEVICE, "device %d not available (%d GPUs visible)", device, n);
+    HIP_CHECK(hipSetDevice(device));
+    mis_mel_stream* h = new mis_mel_stream();
+    h->device = device;
+    h->cfg.sample_rate = sample_rate; h->cfg.n_fft = n_fft; h->cfg.hop_length = hop_length; h->cfg.n_mels = n_mels;
+    h->cfg.window = 1; h->cfg.mel_scale = 0; h->cfg.slaney_norm = 1; h->cfg.drop_last_frame = 0;      // hanningWindow + melFilters(norm: "slaney") (:54-60)
+    HIP_CHECK(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
+    h->rmax.alloc(1);
+    *out = h;
+    MIS_API_END
+}
+extern "C" void mis_mel_stream_destroy(mis_mel_stream* h) {
+    if (!h) return;
+    (void)hipSetDevice(h->device);
+    if (h->stream) { (void)hipStreamSynchronize(h->stream); (void)hipStreamDestroy(h->stream); }
+    delete h;
+}
+extern "C" mis_status mis_mel_stream_reset(mis_mel_stream* h) {
+    MIS_API_BEGIN
+    MIS_REQUIRE(h, MIS_ERR_INVALID_INPUT, "null handle");
+    h->overlap.clear(); h->first = true; h->running_max = -INFINITY; h->total_frames = 0;
+    MIS_API_END
+}
+extern "C" int64_t mis_mel_stream_total_frames(const mis_mel_stream* h) { return h ? h->total_frames : 0; }
+
+static int64_t mel_stream_frames(mis_mel_stream* h, const std::vector<float>& signal, int64_t n_frames, float* out_host) {
+    HIP_CHECK(hipSetDevice(h->device));
+    const mis_mel_config& c = h->cfg;
+    MelPlan* pl = get_plan(h->device, c);
+    hipStream_t s = h->stream;
+    h->sig.alloc(signal.size());
+    h->out.alloc((size_t)n_frames * c.n_mels);
+    HIP_CHECK(hipMemcpyAsync(h->sig.p, signal.data(), signal.size() * 4, hipMemcpyHostToDevice, s));
+    HIP_CHECK(hipMemcpyAsync(h->rmax.p, &h->running_max, 4, hipMemcpyHostToDevice, s));
+    MelParams mp{};
+    mp.pcm = h->sig.p; mp.out = h->out.p; mp.row_max = h->rmax.p;
+    mp.window = pl->window.p; mp.cosT = pl->cosT.p; mp.sinT = pl->sinT.p; mp.filt = pl->filt.p;
+    mp.n_samples = (long long)signal.size(); mp.n_fft = c.n_fft; mp.hop = c.hop_length; mp.n_mels = c.n_mels;
+    mp.nfp = pl->nfp; mp.nmp = pl->nmp; mp.frames_total = (int)n_frames; mp.frames_out = (int)n_frames; mp.raw = 1;
+    size_t smem = (size_t)MEL_FRAMES * (std::max(c.n_fft, pl->nfp) + 1) * sizeof(float);
+    MIS_REQUIRE(smem <= 64 * 1024, MIS_ERR_INVALID_INPUT, "mel tile does not fit LDS");
+    hipLaunchKernelGGL(k_mel_tile, dim3(cdiv(n_frames, MEL_FRAMES), 1), dim3(256), smem, s, mp);
+    size_t per_row = (size_t)n_frames * c.n_mels;
+    hipLaunchKernelGGL(k_mel_normalize, dim3((unsigned)((per_row + 255) / 256), 1), dim3(256), 0, s, h->out.p, h->rmax.p, per_row, 1);
+    HIP_CHECK(hipGetLastError());
+    HIP_CHECK(hipMemcpyAsync(out_host, h->out.p, per_row * 4, hipMemcpyDeviceToHost, s));
+    HIP_CHECK(hipMemcpyAsync(&h->running_max, h->rmax.p, 4, hipMemcpyDeviceToHost, s));
+    HIP_CHECK(hipStreamSynchronize(s));
+    h->total_frames += n_frames;
+    return n_frames;
+}
+
+// process(samples:) (:68-147): out f32 [capacity_frames, n_mels]; *n_frames = 0 when the chunk does not complete a frame
+extern "C" mis_status mis_mel_stream_process(mis_mel_stream* h, const float* samples, int64_t n, float* out, int64_t capacity_frames,
+                                             int64_t* n_frames) {
+    MIS_API_BEGIN
+    MIS_REQUIRE(h && n_frames && n >= 0, MIS_ERR_INVALID_INPUT, "bad argument");
+    *n_frames = 0;
+    if (n == 0) return MIS_OK;
+    MIS_REQUIRE(samples, MIS_ERR_INVALID_INPUT, "null samples");
+    const int nfft = h->cfg.n_fft, hop = h->cfg.hop_length, ov = nfft - hop;
+    std::vector<float> sm((size_t)n);
+    HIP_CHECK(hipMemcpy(sm.data(), samples, (size_t)n * 4, hipMemcpyDefault));
+    std::vector<float> signal;
+    if (h->first) {
+        const int pad = nfft / 2;
+        std::vector<float> prefix;
+        if (n > 1) {
+            const int64_t rl = std::min<int64_t>(pad, n - 1);
+            for (int64_t i = rl; i >= 1; --i) prefix.push_back(sm[(size_t)i]);
+        }
+        if (prefix.empty()) prefix.assign(pad, sm[0]);
+        else while ((int)prefix.size() < pad) {
+            size_t need = (size_t)pad - prefix.size(), have = prefix.size();
+            for (size_t i = 0; i < std::min(need, have); ++i) prefix.push_back(prefix[i]);
+        }
+        signal = prefix;
+        signal.insert(signal.end(), sm.begin(), sm.end());
+        h->first = false;
+    } else {
+        signal = h->overlap;
+        signal.insert(signal.end(), sm.begin(), sm.end());
+    }
+    const int64_t nf = std::max<int64_t>(0, ((int64_t)signal.size() - nfft) / hop + 1);
+    if ((int64_t)signal.size() < nfft || nf <= 0) { h->overlap = signal; return MIS_OK; }
+    MIS_REQUIRE(out && nf <= capacity_frames, MIS_ERR_INVALID_INPUT, "output buffer holds %lld frames, chunk produces %lld", (long long)capacity_frames, (long long)nf);
+    const int64_t consumed = (nf - 1) * hop + nfft;
+    if (consumed < (int64_t)signal.size()) h->overlap.assign(signal.begin() + (consumed - ov), signal.end());
+    else h->overlap.assign(signal.end() - ov, signal.end());
+    *n_frames = mel_stream_frames(h, signal, nf, out);
+    MIS_API_END
+}
+// flush() (:150-200)
+extern "C" mis_status mis_mel_stream_flush(mis_mel_stream* h, float* out, int64_t capacity_frames, int64_t* n_frames) {
+    MIS_API_BEGIN
+    MIS_REQUIRE(h && n_frames, MIS_ERR_INVALID_INPUT, "bad argument");
+    *n_frames = 0;
+    if (h->overlap.empty()) return MIS_OK;
+    const int nfft = h->cfg.n_fft, hop = h->cfg.hop_length;
+    std::vector<float> signal = h->overlap;
+    if ((int)signal.size() < nfft) signal.resize(nfft, 0.0f);
+    const int64_t len = (int64_t)signal.size(), rl = std::min<int64_t>(nfft / 2, len - 1);
+    for (int64_t i = len - 2; i >= len - 1 - rl; --i) signal.push_back(signal[(size_t)i]);
+    h->overlap.clear();
+    const int64_t nf = std::max<int64_t>(0, ((int64_t)signal.size() - nfft) / hop + 1);
+    if (nf <= 0) return MIS_OK;
+    MIS_REQUIRE(out && nf <= capacity_frames, MIS_ERR_INVALID_INPUT, "output buffer too small");
+    *n_frames = mel_stream_frames(h, signal, nf, out);
     MIS_API_END
 }

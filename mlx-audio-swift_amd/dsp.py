@@ -55,3 +55,42 @@ def whisper_encoder_features(audio, n_mels: int, lens=None, device: int = 0) -> 
     check(_lib.lib().mis_whisper_encoder_features(device, a.ctypes.data if stride else None, lp, B, stride, n_mels,
                                                   out.ctypes.data))
     return out
+
+
+class IncrementalMelSpectrogram:
+    """class IncrementalMelSpectrogram (Sources/MLXAudioSTT/Streaming/IncrementalMelSpectrogram.swift:17-215):
+    process(samples) -> [new_frames, n_mels] or None; flush(); reset(); total_frames."""
+
+    def __init__(self, sample_rate: int = 16000, n_fft: int = 400, hop_length: int = 160, n_mels: int = 128, device: int = 0):
+        self.n_fft, self.hop_length, self.n_mels = n_fft, hop_length, n_mels
+        self._h = C.c_void_p()
+        check(_lib.lib().mis_mel_stream_create(device, sample_rate, n_fft, hop_length, n_mels, C.byref(self._h)))
+
+    def __del__(self):
+        h, self._h = getattr(self, "_h", None), None
+        if h:
+            _lib.lib().mis_mel_stream_destroy(h)
+
+    @property
+    def total_frames(self) -> int:
+        return int(_lib.lib().mis_mel_stream_total_frames(self._h))
+
+    def process(self, samples):
+        a = np.ascontiguousarray(samples, dtype=np.float32).reshape(-1)
+        if a.size == 0:
+            return None
+        cap = (a.size + self.n_fft) // self.hop_length + 2
+        out = np.zeros((cap, self.n_mels), np.float32)
+        n = C.c_int64()
+        check(_lib.lib().mis_mel_stream_process(self._h, a.ctypes.data, a.size, out.ctypes.data, cap, C.byref(n)))
+        return out[: n.value].copy() if n.value else None
+
+    def flush(self):
+        cap = (2 * self.n_fft) // self.hop_length + 4
+        out = np.zeros((cap, self.n_mels), np.float32)
+        n = C.c_int64()
+        check(_lib.lib().mis_mel_stream_flush(self._h, out.ctypes.data, cap, C.byref(n)))
+        return out[: n.value].copy() if n.value else None
+
+    def reset(self):
+        check(_lib.lib().mis_mel_stream_reset(self._h))

@@ -144,3 +144,73 @@ def compute_mel_spectrogram(audio: np.ndarray, sample_rate: int, n_fft: int, hop
     mel = np.log10(np.maximum(mel, F(1e-10))).astype(F)
     mel = np.maximum(mel, mel.max() - F(8.0))
     return ((mel + F(4.0)) / F(4.0)).astype(F)
+
+
+class IncrementalMelOracle:
+    """IncrementalMelSpectrogram (Sources/MLXAudioSTT/Streaming/IncrementalMelSpectrogram.swift:17-215): overlap-save framing
+    with a reflected prefix on the first chunk, symmetric Hann window, HTK-scale / Slaney-norm filters, log10 with a RUNNING
+    maximum (grows monotonically over the session), (x + 4) / 4."""
+
+    def __init__(self, sample_rate=16000, n_fft=400, hop_length=160, n_mels=128):
+        self.n_fft, self.hop, self.n_mels = n_fft, hop_length, n_mels
+        self.overlap_size = n_fft - hop_length
+        self.window = hanning_window(n_fft)
+        self.filters = mel_filters(sample_rate, n_fft, n_mels, norm="slaney", mel_scale="htk")
+        self.reset()
+
+    def reset(self):
+        self.overlap = np.zeros(0, F)
+        self.first = True
+        self.running_max = -np.inf
+        self.total_frames = 0
+
+    def _frames(self, signal, n):
+        idx = np.arange(n)[:, None] * self.hop + np.arange(self.n_fft)[None, :]
+        spec = np.fft.rfft((signal[idx] * self.window).astype(F), axis=1)
+        power = (np.abs(spec).astype(F) ** 2).astype(F)
+        mel = np.log10(np.maximum((power @ self.filters).astype(F), F(1e-10))).astype(F)
+        self.running_max = max(self.running_max, float(mel.max()))
+        mel = np.maximum(mel, F(self.running_max - 8.0))
+        self.total_frames += n
+        return ((mel + F(4.0)) / F(4.0)).astype(F)
+
+    def process(self, samples):
+        samples = np.asarray(samples, F)
+        if samples.size == 0:
+            return None
+        if self.first:                                         # :77-99
+            pad = self.n_fft // 2
+            prefix = np.zeros(0, F)
+            if samples.size > 1:
+                rl = min(pad, samples.size - 1)
+                if rl > 0:
+                    prefix = samples[1:rl + 1][::-1]
+            if prefix.size == 0:
+                prefix = np.full(pad, samples[0], F)
+            else:
+                while prefix.size < pad:
+                    prefix = np.concatenate([prefix, prefix[: pad - prefix.size]])
+            signal = np.concatenate([prefix, samples]).astype(F)
+            self.first = False
+        else:
+            signal = np.concatenate([self.overlap, samples]).astype(F)
+        n = max(0, (signal.size - self.n_fft) // self.hop + 1)
+        if n <= 0:
+            self.overlap = signal
+            return None
+        consumed = (n - 1) * self.hop + self.n_fft
+        self.overlap = signal[consumed - self.overlap_size:] if consumed < signal.size else signal[signal.size - self.overlap_size:]
+        return self._frames(signal, n)
+
+    def flush(self):                                          # :150-200
+        if self.overlap.size == 0:
+            return None
+        signal = self.overlap
+        if signal.size < self.n_fft:
+            signal = np.concatenate([signal, np.zeros(self.n_fft - signal.size, F)])
+        pad = self.n_fft // 2
+        rl = min(pad, signal.size - 1)
+        signal = np.concatenate([signal, signal[signal.size - 1 - rl: signal.size - 1][::-1]]).astype(F)
+        self.overlap = np.zeros(0, F)
+        n = max(0, (signal.size - self.n_fft) // self.hop + 1)
+        return self._frames(signal, n) if n > 0 else None

@@ -78,3 +78,26 @@ def test_batch64_at_bench_size_properties():
     assert np.all(f.reshape(64, -1).max(1) - f.reshape(64, -1).min(1) <= 2.0 + 1e-5)
     one = mas.dsp.whisper_encoder_features(x[17], 128)
     assert np.array_equal(one[0], f[17])
+
+
+def test_incremental_mel_matches_oracle_chunk_by_chunk():
+    from oracle.mel import IncrementalMelOracle
+    rng = np.random.default_rng(9)
+    audio = (0.2 * rng.standard_normal(24000) * np.linspace(0.05, 1.0, 24000)).astype(np.float32)
+    for n_mels, sizes in ((128, (4000, 4000, 16000)), (80, (100, 7, 333, 1, 399, 23160)), (128, (1,)), (80, (250, 100))):
+        dev = mas.dsp.IncrementalMelSpectrogram(n_mels=n_mels)
+        orc = IncrementalMelOracle(n_mels=n_mels)
+        pos = 0
+        for n in sizes:
+            g, r = dev.process(audio[pos:pos + n]), orc.process(audio[pos:pos + n])
+            pos += n
+            assert (g is None) == (r is None)
+            if r is not None:
+                assert g.shape == r.shape and np.abs(g - r).max() < 1e-4          # normalised log domain
+        g, r = dev.flush(), orc.flush()
+        assert (g is None) == (r is None)
+        if r is not None:
+            assert g.shape == r.shape and np.abs(g - r).max() < 1e-4
+        assert dev.total_frames == orc.total_frames
+        dev.reset()
+        assert dev.total_frames == 0 and dev.process(audio[:10]) is None

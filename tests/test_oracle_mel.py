@@ -55,3 +55,29 @@ def test_generic_dsp_path_shapes():
     m = mel.compute_mel_spectrogram(x, 16000, 400, 160, 64)
     assert m.shape == (101, 64) and np.isfinite(m).all()
     assert m.max() - m.min() <= 2.0 + 1e-6          # dynamic range clamp: 8 dB-decades / 4
+
+
+def test_incremental_mel_frames_do_not_depend_on_chunking():
+    # overlap-save: before the running-max clamp bites, chunked processing yields the frames of one-shot processing
+    from oracle.mel import IncrementalMelOracle
+    rng = np.random.default_rng(5)
+    audio = (0.1 * rng.standard_normal(16000)).astype(np.float32)
+    one = IncrementalMelOracle(n_mels=80)
+    full = np.concatenate([x for x in (one.process(audio), one.flush()) if x is not None])
+    # (the reflected prefix is built from the FIRST chunk, :77-99, so that chunk must cover n_fft/2 + 1 samples for equality)
+    for sizes in ((4000, 4000, 8000), (300, 7, 333, 15360), (401, 1, 15598)):
+        inc = IncrementalMelOracle(n_mels=80)
+        parts, pos = [], 0
+        for n in sizes:
+            r = inc.process(audio[pos:pos + n]); pos += n
+            if r is not None:
+                parts.append(r)
+        r = inc.flush()
+        if r is not None:
+            parts.append(r)
+        got = np.concatenate(parts)
+        assert got.shape == full.shape == (one.total_frames, 80) and inc.total_frames == one.total_frames
+        # white noise: every chunk's maximum is within 8 of the session maximum only approximately -> compare where unclamped
+        floor = (one.running_max - 8.0 + 4.0) / 4.0
+        ok = (full > floor + 1e-3) & (got > floor + 1e-3)
+        assert ok.mean() > 0.9 and np.abs(got - full)[ok].max() < 2e-4
