@@ -115,6 +115,13 @@ mis_status mis_snac_decode(mis_snac*, const int32_t* const* codes, int batch, in
                            const float* const* noise, float* pcm_out);
 /* debug/parity taps: copy an intermediate ("zq","stem_dw","stem_pw","block0".."blockN") of the
  * LAST decode into out (f32 [batch, C, T]); returns its C and T. */
+/* encode path (SNAC.encode, SNACDecoder.swift:86-125: preprocess right-pad -> Encoder (Layers.swift:319-360) -> residual VQ with
+ * nearest normalised code, VQ.swift:47-163).  Available when the checkpoint's "encoder.*" tensors were loaded (depthwise
+ * configs without LocalMHA, i.e. snac_24khz).  padded_length = n rounded up to hop * lcm(vq_strides). */
+int64_t    mis_snac_padded_length(const mis_snac*, int64_t n_samples);
+/* audio f32 [batch, n_samples]; codes_out[i] int32 [batch, padded / hop / vq_strides[i]]; z_out (nullable) f32
+ * [batch, latent_dim, padded / hop] = encoder output before quantisation */
+mis_status mis_snac_encode(mis_snac*, const float* audio, int batch, int64_t n_samples, int32_t* const* codes_out, float* z_out);
 mis_status mis_snac_debug_tap(mis_snac*, const char* name, float* out, int64_t capacity,
                               int32_t* channels, int64_t* length);
 

@@ -119,6 +119,8 @@ SYMBOLS = {
     "mis_snac_noise_len": (C.c_int64, [_P, C.c_int, C.c_int]),
     "mis_snac_set_noise": (C.c_int, [_P, C.c_int, C.c_uint64]),
     "mis_snac_decode": (C.c_int, [_P, C.POINTER(_P), C.c_int, C.c_int, C.POINTER(_P), _P]),
+    "mis_snac_padded_length": (C.c_int64, [_P, C.c_int64]),
+    "mis_snac_encode": (C.c_int, [_P, _P, C.c_int, C.c_int64, _P, _P]),
     "mis_snac_debug_tap": (C.c_int, [_P, C.c_char_p, _P, C.c_int64, C.POINTER(C.c_int32), C.POINTER(C.c_int64)]),
     "mis_tts_load": (C.c_int, [C.c_char_p, _P, C.c_int, C.POINTER(_P)]),
     "mis_tts_create": (C.c_int, [C.POINTER(LmConfigC), _P, C.c_int, C.POINTER(_P)]),

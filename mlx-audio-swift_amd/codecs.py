@@ -112,9 +112,7 @@ class SNAC:
     def from_weights(cls, config: SNACConfig, weights: dict, device: int = 0) -> "SNAC":
         m = cls(config, device)
         for name, arr in weights.items():
-            if name.startswith("encoder.") or ".in_proj." in name:
-                continue
-            m.set_tensor(name, arr)
+            m.set_tensor(name, arr)                  # "encoder.*" / "*.in_proj.*" enable the encode path when present
         m.finalize()
         return m
 
@@ -173,8 +171,27 @@ class SNAC:
     def decode_audio(self, codes) -> np.ndarray:           # decodeAudio, SNACDecoder.swift:201-203
         return self.decode(codes)
 
+    def padded_length(self, n_samples: int) -> int:
+        return int(_lib.lib().mis_snac_padded_length(self._h, n_samples))
+
+    def encode(self, audio, return_latent: bool = False):
+        """SNAC.encode (SNACDecoder.swift:120-125): audio [B, samples] (or [samples]) -> list of int32 codes [B, T_i]."""
+        a = np.ascontiguousarray(audio, dtype=np.float32)
+        if a.ndim == 1:
+            a = a[None]
+        if a.ndim == 3 and a.shape[1] == 1:
+            a = np.ascontiguousarray(a[:, 0])
+        B, n = a.shape
+        Tl = self.padded_length(n) // self.hop_length
+        outs = [np.zeros((B, Tl // s), np.int32) for s in self.config.vq_strides]
+        ptrs = (C.c_void_p * len(outs))(*[o.ctypes.data for o in outs])
+        latent = self.config.latent_dim or self.config.encoder_dim * 2 ** len(self.config.encoder_rates)
+        z = np.zeros((B, latent, Tl), np.float32) if return_latent else None
+        check(_lib.lib().mis_snac_encode(self._h, a.ctypes.data, B, n, ptrs, z.ctypes.data if return_latent else None))
+        return (outs, z) if return_latent else outs
+
     def encode_audio(self, waveform):                      # encodeAudio, SNACDecoder.swift:197-199
-        raise AudioGenerationError(5, "SNAC encode path is not built yet (SURVEY 8(f).2)")
+        return self.encode(waveform)
 
     def debug_tap(self, name: str, batch: int) -> np.ndarray:
         """Intermediate [batch, C, T] of the LAST decode: "zq", "stem_dw", "stem_pw", "block<i>"."""

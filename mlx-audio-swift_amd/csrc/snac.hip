@@ -245,6 +245,84 @@ __global__ void __launch_bounds__(256) k_snac_gemm(GemmParams p) {
     }
 }
 
+// ---- encoder kernels (Layers.swift:319-360, VQ.swift:47-120) ---------------------------------------------------------
+// first layer: conv k7 "same", 1 -> C
+__global__ void k_enc_first(const float* __restrict__ audio, float* __restrict__ y, const float* __restrict__ w /*[C][7]*/,
+                            const float* __restrict__ bias, int C, int T) {
+    int t = blockIdx.x * blockDim.x + threadIdx.x, c = blockIdx.y, b = blockIdx.z;
+    if (t >= T) return;
+    const float* a = audio + (size_t)b * T;
+    float acc = bias[c];
+#pragma unroll
+    for (int j = 0; j < 7; ++j) {
+        int ts = t + j - 3;
+        if (ts >= 0 && ts < T) acc += w[c * 7 + j] * a[ts];
+    }
+    y[((size_t)b * C + c) * T + t] = acc;
+}
+// Snake, then phase split for a stride-s conv: y[(c*s + r)][m] = snake(x[c][s*m + r])   (T = s*Tm)
+__global__ void k_enc_phase_split(const float* __restrict__ x, float* __restrict__ y, const float* __restrict__ a, const float* __restrict__ ra,
+                                  int C, int T, int s) {
+    int t = blockIdx.x * blockDim.x + threadIdx.x, c = blockIdx.y, b = blockIdx.z;
+    if (t >= T) return;
+    const int Tm = T / s, m = t / s, r = t - m * s;
+    float v = snake_f(x[((size_t)b * C + c) * T + t], a[c], ra[c]);
+    y[((size_t)b * C * s + (size_t)c * s + r) * Tm + m] = v;
+}
+// average pool over `stride` consecutive samples (VQ.swift:47-57)
+__global__ void k_vq_pool(const float* __restrict__ x, float* __restrict__ y, int C, int T, int stride) {
+    int m = blockIdx.x * blockDim.x + threadIdx.x, c = blockIdx.y, b = blockIdx.z;
+    const int Tm = T / stride;
+    if (m >= Tm) return;
+    const float* xr = x + ((size_t)b * C + c) * T + (size_t)m * stride;
+    float acc = 0.0f;
+    for (int j = 0; j < stride; ++j) acc += xr[j];
+    y[((size_t)b * C + c) * Tm + m] = acc / (float)stride;
+}
+// nearest codebook entry of the L2-normalised latent (VQ.swift:96-120): dist = |e|^2 - 2 e.c + |c|^2 on normalised vectors,
+// argmax(-dist) with the first index on ties.  One block per (b, t); ze [B][CD][Tm]; codes [B][Tm].
+__global__ void __launch_bounds__(256) k_vq_nearest(const float* __restrict__ ze, const float* __restrict__ cn, const float* __restrict__ cn2,
+                                                    int32_t* __restrict__ codes, int CD, int CB, int Tm) {
+    __shared__ float e[64];
+    __shared__ float redv[4];
+    __shared__ int redi[4];
+    const int t = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
+    if (tid < CD) e[tid] = ze[((size_t)b * CD + tid) * Tm + t];
+    __syncthreads();
+    float n2 = 0.0f;
+    for (int d = 0; d < CD; ++d) n2 += e[d] * e[d];
+    const float inv = 1.0f / fmaxf(sqrtf(n2), 1e-12f);
+    float en2 = 0.0f;
+    for (int d = 0; d < CD; ++d) { float v = e[d] * inv; en2 += v * v; }
+    float best = INFINITY;
+    int bi = 0x7fffffff;
+    for (int k = tid; k < CB; k += 256) {
+        float dot = 0.0f;
+        for (int d = 0; d < CD; ++d) dot += (e[d] * inv) * cn[(size_t)k * CD + d];
+        float dist = en2 - 2.0f * dot + cn2[k];
+        if (dist < best) { best = dist; bi = k; }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        float ob = __shfl_xor(best, o, 64);
+        int oi = __shfl_xor(bi, o, 64);
+        if (ob < best || (ob == best && oi < bi)) { best = ob; bi = oi; }
+    }
+    if ((tid & 63) == 0) { redv[tid >> 6] = best; redi[tid >> 6] = bi; }
+    __syncthreads();
+    if (tid == 0) {
+        for (int w = 1; w < 4; ++w) if (redv[w] < best || (redv[w] == best && redi[w] < bi)) { best = redv[w]; bi = redi[w]; }
+        codes[(size_t)b * Tm + t] = bi;
+    }
+}
+// residual -= repeat_interleave(out_proj(codebook[code]), stride)   (VQ.swift:60-80,151-158); table [CB][C]
+__global__ void k_vq_residual(float* __restrict__ r, const int32_t* __restrict__ codes, const float* __restrict__ table, int C, int T, int stride) {
+    int t = blockIdx.x * blockDim.x + threadIdx.x, c = blockIdx.y, b = blockIdx.z;
+    if (t >= T) return;
+    int code = codes[(size_t)b * (T / stride) + t / stride];
+    r[((size_t)b * C + c) * T + t] -= table[(size_t)code * C + c];
+}
+
 // ---- dense k-tap conv on f32 MFMA (Qwen3-TTS / DAC-style decoders: dilated k7 convs with Cin = Cout up to 1536) ---------
 // y[m][n] = bias[m] + sum_{j < taps} sum_c W[m][j][c] * act(x[c][n - pad_left + j*dil]),  zero outside [0, Tin).
 // Loop order (channel chunk outer, tap inner): the activation tile WITH its halo is staged once per 16 channels (aligned
@@ -417,6 +495,21 @@ struct mis_snac {
         struct RU { SnakeW s1, s2; ConvW dw, pw; } ru[3];
     };
     std::vector<Block> blocks;
+    // encoder (built when "encoder.*" tensors were provided): Layers.swift:236-259,319-360
+    struct EncBlock {
+        int cin, cout, stride;
+        struct RU { SnakeW s1, s2; ConvW dw, pw; } ru[3];
+        SnakeW snake;
+        ConvW down;                       // strided conv as a 3-tap conv over the phase-split tensor: A^T [3*s*cin][cout]
+    };
+    bool has_encoder = false;
+    int enc_dim = 0;
+    ConvW enc_first, enc_last;            // first: [d][7] (Cin = 1); last: depthwise [C][7]
+    std::vector<EncBlock> enc_blocks;
+    struct VqEnc { ConvW in_proj; size_t cn = 0, cn2 = 0; };    // normalised codebook [CB][CD] and its squared norms
+    std::vector<VqEnc> vq_enc;
+    DevBuf<float> enc_buf[3], vq_pool, vq_ze;
+    DevBuf<int32_t> enc_codes;
 
     // workspaces
     DevBuf<float> buf[3];
@@ -624,10 +717,181 @@ extern "C" mis_status mis_snac_finalize(mis_snac* c) {
         c->fin.w = push(wt);
         c->fin_bias = need(c, p + ".bias", {1}).v[0];
     }
+    // ---- encoder (optional): dimensions are read off the tensors (encoder_dim / encoder_rates are not part of mis_snac_config)
+    c->has_encoder = false;
+    const std::string E = "encoder.block.layers";
+    auto e0 = c->raw.find(E + ".0.weight_v");
+    if (e0 != c->raw.end()) {
+        MIS_REQUIRE(cf.depthwise, MIS_ERR_INVALID_INPUT, "SNAC encoder: only depthwise residual units are built");
+        MIS_REQUIRE(cf.attn_window_size <= 0, MIS_ERR_INVALID_INPUT, "SNAC encoder: LocalMHA (attn_window_size) is not built");
+        MIS_REQUIRE(e0->second.shape.size() == 3 && e0->second.shape[1] == 7 && e0->second.shape[2] == 1, MIS_ERR_INVALID_INPUT, "bad encoder stem");
+        int64_t ch = e0->second.shape[0];
+        c->enc_dim = (int)ch;
+        {
+            std::vector<float> w = fold_weight_norm(need(c, E + ".0.weight_g", {ch, 1, 1}), need(c, E + ".0.weight_v", {ch, 7, 1}), 1e-12f);
+            c->enc_first.w = push(w); c->enc_first.has_bias = true; c->enc_first.b = push(need(c, E + ".0.bias", {ch}).v);
+        }
+        c->enc_blocks.clear();
+        int li = 1;
+        for (;; ++li) {
+            const std::string b = E + "." + std::to_string(li) + ".block.layers";
+            auto dn = c->raw.find(b + ".4.weight_v");
+            if (dn == c->raw.end()) break;
+            mis_snac::EncBlock eb;
+            eb.cin = (int)ch;
+            MIS_REQUIRE(dn->second.shape.size() == 3 && dn->second.shape[2] == ch && dn->second.shape[1] % 2 == 0, MIS_ERR_INVALID_INPUT, "bad encoder block %d", li);
+            eb.cout = (int)dn->second.shape[0];
+            eb.stride = (int)dn->second.shape[1] / 2;
+            for (int j = 0; j < 3; ++j) {
+                const std::string r = b + "." + std::to_string(j) + ".block.layers";
+                eb.ru[j].s1 = push_snake(r + ".0.alpha", ch);
+                eb.ru[j].dw = push_dw(r + ".1", ch);
+                eb.ru[j].s2 = push_snake(r + ".2.alpha", ch);
+                eb.ru[j].pw = push_pw(r + ".3", ch, ch, true);
+            }
+            eb.snake = push_snake(b + ".3.alpha", ch);
+            {   // WNConv1d(k = 2s, stride s, pad ceil(s/2)) (Layers.swift:248-254) over the phase-split input [ch*s][T/s]:
+                // y[n] = sum_{q in -1..1} sum_{c,r} W[co][s*q + r + pad][c] * xph[c*s + r][n + q]
+                const int sdn = eb.stride, K = 2 * sdn, pad = (sdn + 1) / 2;
+                std::vector<float> w = fold_weight_norm(need(c, b + ".4.weight_g", {eb.cout, 1, 1}), need(c, b + ".4.weight_v", {eb.cout, K, ch}), 1e-12f);
+                std::vector<float> at((size_t)3 * sdn * ch * eb.cout, 0.0f);
+                for (int qi = 0; qi < 3; ++qi)
+                    for (int64_t ci = 0; ci < ch; ++ci)
+                        for (int r = 0; r < sdn; ++r) {
+                            const int j = sdn * (qi - 1) + r + pad;
+                            if (j < 0 || j >= K) continue;
+                            for (int co = 0; co < eb.cout; ++co)
+                                at[(((size_t)qi * ch * sdn) + (size_t)ci * sdn + r) * eb.cout + co] = w[((size_t)co * K + j) * ch + ci];
+                        }
+                eb.down.w = push(at); eb.down.has_bias = true; eb.down.b = push(need(c, b + ".4.bias", {eb.cout}).v);
+            }
+            ch = eb.cout;
+            c->enc_blocks.push_back(eb);
+        }
+        MIS_REQUIRE(!c->enc_blocks.empty() && ch == D, MIS_ERR_INVALID_INPUT, "SNAC encoder output width %lld != latent_dim %lld", (long long)ch, (long long)D);
+        c->enc_last = push_dw(E + "." + std::to_string(li), D);
+        c->vq_enc.clear();
+        for (int i = 0; i < cf.n_codebooks; ++i) {
+            const std::string p = "quantizer.quantizers." + std::to_string(i);
+            mis_snac::VqEnc v;
+            v.in_proj = push_pw(p + ".in_proj", CD, D, true);
+            const HostTensor& cb = need(c, p + ".codebook.weight", {CB, CD});
+            std::vector<float> cn((size_t)CB * CD), cn2(CB);
+            for (int64_t k = 0; k < CB; ++k) {
+                float n2 = 0.0f;
+                for (int64_t d = 0; d < CD; ++d) n2 += cb.v[k * CD + d] * cb.v[k * CD + d];
+                const float inv = 1.0f / std::max(sqrtf(n2), 1e-12f);
+                float s2 = 0.0f;
+                for (int64_t d = 0; d < CD; ++d) { float x = cb.v[k * CD + d] * inv; cn[k * CD + d] = x; s2 += x * x; }
+                cn2[k] = s2;
+            }
+            v.cn = push(cn); v.cn2 = push(cn2);
+            c->vq_enc.push_back(v);
+        }
+        c->has_encoder = true;
+    }
     c->arena.alloc(arena.size());
     HIP_CHECK(hipMemcpy(c->arena.p, arena.data(), arena.size() * sizeof(float), hipMemcpyHostToDevice));
     c->raw.clear();
     c->finalized = true;
+    MIS_API_END
+}
+
+// ---------------------------------------------------------------------------- encode (SNACDecoder.swift:86-125)
+extern "C" int64_t mis_snac_padded_length(const mis_snac* c, int64_t n_samples) {
+    if (!c || n_samples < 0) return 0;
+    int64_t l = 1;
+    auto lcm = [](int64_t a, int64_t b) { int64_t x = a, y = b; while (y) { int64_t t = x % y; x = y; y = t; } return a / x * b; };
+    for (int i = 0; i < c->cfg.n_codebooks; ++i) l = lcm(l, c->cfg.vq_strides[i]);
+    if (c->cfg.attn_window_size > 0) l = lcm(l, c->cfg.attn_window_size);
+    int64_t hop = 1;
+    for (int i = 0; i < c->cfg.n_decoder_rates; ++i) hop *= c->cfg.decoder_rates[i];      // == prod(encoder_rates) for every published config
+    if (c->has_encoder) { hop = 1; for (auto& b : c->enc_blocks) hop *= b.stride; }
+    const int64_t pad_to = hop * l;
+    return (n_samples + pad_to - 1) / pad_to * pad_to;
+}
+
+// audio f32 [batch, n_samples] (host or device) -> codes_out[i] int32 [batch, T_i], T_i = padded / hop / vq_strides[i];
+// z_out (optional) f32 [batch, latent, padded / hop] = encoder output before quantisation (parity taps)
+extern "C" mis_status mis_snac_encode(mis_snac* c, const float* audio, int batch, int64_t n_samples, int32_t* const* codes_out, float* z_out) {
+    MIS_API_BEGIN
+    MIS_REQUIRE(c && audio && codes_out && batch >= 1 && n_samples >= 1, MIS_ERR_INVALID_INPUT, "bad argument");
+    MIS_REQUIRE(c->finalized, MIS_ERR_NOT_INITIALIZED, "SNAC model not finalized");
+    MIS_REQUIRE(c->has_encoder, MIS_ERR_AUDIO_ENCODE, "this SNAC handle was loaded without encoder weights");
+    HIP_CHECK(hipSetDevice(c->device));
+    hipStream_t s = c->stream;
+    const mis_snac_config& cf = c->cfg;
+    const float* W = c->arena.p;
+    const int64_t Tp = mis_snac_padded_length(c, n_samples);
+    const int D = cf.latent_dim;
+    size_t cap = (size_t)c->enc_dim * Tp;
+    {
+        int64_t T = Tp;
+        for (auto& b : c->enc_blocks) { cap = std::max(cap, (size_t)b.cin * T); T /= b.stride; cap = std::max(cap, (size_t)b.cout * T); }
+    }
+    cap *= (size_t)batch;
+    for (int i = 0; i < 3; ++i) c->enc_buf[i].alloc(cap);
+    DevBuf<float> ain;
+    ain.alloc((size_t)batch * Tp);
+    HIP_CHECK(hipMemsetAsync(ain.p, 0, (size_t)batch * Tp * 4, s));
+    HIP_CHECK(hipMemcpy2DAsync(ain.p, (size_t)Tp * 4, audio, (size_t)n_samples * 4, (size_t)n_samples * 4, batch, hipMemcpyDefault, s));
+    float *x = c->enc_buf[0].p, *f1 = c->enc_buf[1].p, *f2 = c->enc_buf[2].p;
+    int64_t T = Tp;
+    hipLaunchKernelGGL(k_enc_first, dim3(cdiv(T, 256), c->enc_dim, batch), dim3(256), 0, s, ain.p, x, W + c->enc_first.w, W + c->enc_first.b, c->enc_dim, (int)T);
+    const int dils[3] = {1, 3, 9};
+    DevBuf<float> zeros;
+    for (auto& eb : c->enc_blocks) {
+        for (int j = 0; j < 3; ++j) {
+            const auto& ru = eb.ru[j];
+            hipLaunchKernelGGL((k_snac_dw<true, true>), dim3(cdiv(T, DW_TILE), eb.cin, batch), dim3(256), 0, s, x, f1, W + ru.dw.w, W + ru.dw.b,
+                               W + ru.s1.a, W + ru.s1.ra, W + ru.s2.a, W + ru.s2.ra, eb.cin, (int)T, dils[j]);
+            GemmParams g{};
+            g.AT = W + ru.pw.w; g.bias = W + ru.pw.b; g.X = f1; g.Y = f2; g.R = x;
+            g.M = eb.cin; g.K = eb.cin; g.N = (int)T; g.Tin = (int)T; g.Tout = (int)T;
+            launch_gemm(GEMM_RESID, false, g, batch, s);
+            std::swap(x, f2);
+        }
+        MIS_REQUIRE(T % eb.stride == 0, MIS_ERR_AUDIO_ENCODE, "internal: length not divisible by the stride");
+        hipLaunchKernelGGL(k_enc_phase_split, dim3(cdiv(T, 256), eb.cin, batch), dim3(256), 0, s, x, f1, W + eb.snake.a, W + eb.snake.ra, eb.cin, (int)T, eb.stride);
+        T /= eb.stride;
+        GemmParams g{};
+        g.AT = W + eb.down.w; g.bias = W + eb.down.b; g.X = f1; g.Y = f2;
+        g.M = eb.cout; g.K = 3 * eb.stride * eb.cin; g.N = (int)T; g.Tin = (int)T; g.Tout = (int)T;
+        g.Cin = eb.stride * eb.cin; g.taps = 3; g.dil = 1; g.pad = 1;
+        launch_gemm(GEMM_TAPS, false, g, batch, s);
+        std::swap(x, f2);
+    }
+    hipLaunchKernelGGL((k_snac_dw<false, false>), dim3(cdiv(T, DW_TILE), D, batch), dim3(256), 0, s, x, f1, W + c->enc_last.w, W + c->enc_last.b,
+                       nullptr, nullptr, nullptr, nullptr, D, (int)T, 1);
+    float* resid = f1;                                                    // z [B][D][T]
+    if (z_out) HIP_CHECK(hipMemcpyAsync(z_out, resid, (size_t)batch * D * T * 4, hipMemcpyDefault, s));
+    // ---- residual VQ (VQ.swift:141-161)
+    c->vq_pool.alloc((size_t)batch * D * T);
+    c->vq_ze.alloc((size_t)batch * cf.codebook_dim * T);
+    c->enc_codes.alloc((size_t)batch * T);
+    for (int i = 0; i < cf.n_codebooks; ++i) {
+        const int st = cf.vq_strides[i];
+        MIS_REQUIRE(T % st == 0, MIS_ERR_AUDIO_ENCODE, "internal: latent length not divisible by vq stride");
+        const int Tm = (int)(T / st);
+        const float* pooled = resid;
+        if (st > 1) {
+            hipLaunchKernelGGL(k_vq_pool, dim3(cdiv(Tm, 128), D, batch), dim3(128), 0, s, resid, c->vq_pool.p, D, (int)T, st);
+            pooled = c->vq_pool.p;
+        }
+        GemmParams g{};
+        g.AT = W + c->vq_enc[i].in_proj.w; g.bias = W + c->vq_enc[i].in_proj.b; g.X = pooled; g.Y = c->vq_ze.p;
+        g.M = cf.codebook_dim; g.K = D; g.N = Tm; g.Tin = Tm; g.Tout = Tm;
+        launch_gemm(GEMM_PLAIN, false, g, batch, s);
+        MIS_REQUIRE(cf.codebook_dim <= 64, MIS_ERR_INVALID_INPUT, "codebook_dim > 64 unsupported by the nearest-code kernel");
+        hipLaunchKernelGGL(k_vq_nearest, dim3(Tm, batch), dim3(256), 0, s, c->vq_ze.p, W + c->vq_enc[i].cn, W + c->vq_enc[i].cn2, c->enc_codes.p,
+                           cf.codebook_dim, cf.codebook_size, Tm);
+        HIP_CHECK(hipMemcpyAsync(codes_out[i], c->enc_codes.p, (size_t)batch * Tm * 4, hipMemcpyDefault, s));
+        if (i + 1 < cf.n_codebooks)
+            hipLaunchKernelGGL(k_vq_residual, dim3(cdiv(T, 256), D, batch), dim3(256), 0, s, resid, c->enc_codes.p,
+                               W + c->tables_off + (size_t)i * cf.codebook_size * D, D, (int)T, st);
+        HIP_CHECK(hipStreamSynchronize(s));                                // enc_codes is reused by the next level
+    }
+    HIP_CHECK(hipGetLastError());
     MIS_API_END
 }
 
@@ -903,7 +1167,6 @@ extern "C" mis_status mis_snac_load(const char* model_dir, int device, mis_snac*
         SafeTensorFile f;
         f.open(dir + "/model.safetensors");
         for (auto& e : f.entries) {
-            if (e.name.rfind("encoder.", 0) == 0) continue;                       // encode path: not built yet
             if (e.name.find(".in_proj.") != std::string::npos) continue;          // encode path
             st = mis_snac_set_tensor(c, e.name.c_str(), e.data, dtype_from_safetensors(e.dtype), e.shape.data(), (int)e.shape.size());
             if (st != MIS_OK) { mis_snac_destroy(c); return st; }

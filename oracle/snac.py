@@ -228,6 +228,72 @@ class SnacOracle:
         """SNAC.decode (SNACDecoder.swift:127-131): codes = 3 int arrays [B,T_i] -> [B,1,N]."""
         return self.decoder(self.from_codes(codes), noises)
 
+    # -- encoder + RVQ encode (Layers.swift:236-259,319-360; VQ.swift:47-163; SNACDecoder.swift:86-125) ----
+    def preprocess(self, audio):
+        """Right-pad to a multiple of hop_length * lcm(vq_strides [, attn_window_size]) (SNACDecoder.swift:86-104)."""
+        cfg = self.cfg
+        l = 1
+        for s in cfg.vq_strides:
+            l = l * s // math.gcd(l, s)
+        if cfg.attn_window_size:
+            l = l * cfg.attn_window_size // math.gcd(l, cfg.attn_window_size)
+        pad_to = cfg.hop_length * l
+        n = audio.shape[-1]
+        right = int(math.ceil(n / pad_to)) * pad_to - n
+        return np.pad(audio, [(0, 0)] * (audio.ndim - 1) + [(0, right)])
+
+    def encoder(self, audio):
+        """audio [B, 1, T] -> z [B, latent, T / hop]."""
+        cfg = self.cfg
+        assert not cfg.attn_window_size, "LocalMHA encoder layer is not restated"
+        p = "encoder.block.layers"
+        w, b = self._wn(p + ".0")
+        x = conv1d_nct(np.asarray(audio, self.dtype), w, b, padding=3)
+        for i, s in enumerate(cfg.encoder_rates):
+            q = f"{p}.{1 + i}.block.layers"
+            for j, dil in enumerate((1, 3, 9)):
+                x = self._residual_unit(x, f"{q}.{j}", dil) if cfg.depthwise else self._residual_unit_dense(x, f"{q}.{j}", dil)
+            x = snake(x, self.w[q + ".3.alpha"])
+            w, b = self._wn(q + ".4")
+            x = conv1d_nct(x, w, b, stride=s, padding=int(math.ceil(s / 2.0)))
+        n = 1 + len(cfg.encoder_rates)
+        w, b = self._wn(f"{p}.{n}")
+        return conv1d_nct(x, w, b, padding=3, groups=x.shape[1] if cfg.depthwise else 1)
+
+    def quantize(self, z, return_details=False):
+        """ResidualVectorQuantize.callAsFunction (VQ.swift:141-161): codes per level + per-level distance tables (details)."""
+        t = self.dtype.type
+        residual = np.array(z, self.dtype)
+        codes, details = [], []
+        for i, stride in enumerate(self.cfg.vq_strides):
+            p = f"quantizer.quantizers.{i}"
+            r = residual
+            if stride > 1:                                                   # avg pool, kernel = stride (:47-57)
+                B, C, T = r.shape
+                r = r[:, :, : (T // stride) * stride].reshape(B, C, T // stride, stride).sum(-1, dtype=self.dtype) / t(stride)
+            w, b = self._wn(p + ".in_proj")
+            ze = conv1d_nct(r.astype(self.dtype), w, b)                      # [B, 8, T_i]
+            B, D, Ti = ze.shape
+            e = np.transpose(ze, (0, 2, 1)).reshape(B * Ti, D)
+            cb = self.w[p + ".codebook.weight"]
+            en = e / np.maximum(np.sqrt((e * e).sum(1, keepdims=True)), t(1e-12))
+            cn = cb / np.maximum(np.sqrt((cb * cb).sum(1, keepdims=True)), t(1e-12))
+            dist = (en * en).sum(1, keepdims=True) - t(2.0) * (en @ cn.T) + (cn * cn).sum(1, keepdims=True).T
+            idx = np.argmax(-dist, axis=1).reshape(B, Ti)                    # first index on ties
+            codes.append(idx.astype(np.int32))
+            details.append(dist.reshape(B, Ti, -1))
+            zq = np.transpose(cb[idx], (0, 2, 1))
+            w, b = self._wn(p + ".out_proj")
+            zqi = conv1d_nct(zq.astype(self.dtype), w, b)
+            if stride > 1:
+                zqi = np.repeat(zqi, stride, axis=2)
+            residual = (residual - zqi).astype(self.dtype)
+        return (codes, details) if return_details else codes
+
+    def encode(self, audio, return_details=False):
+        """SNAC.encode (SNACDecoder.swift:120-125): audio [B, 1, T] -> [codes_i [B, T_i]]."""
+        return self.quantize(self.encoder(self.preprocess(np.asarray(audio, self.dtype))), return_details)
+
     def noise_lengths(self, groups: int):
         """Time length of each NoiseBlock's input for `groups` Orpheus frames
         (T0 = 4*groups... in general lcm-based; here vq_strides[0]*groups)."""
@@ -242,7 +308,7 @@ class SnacOracle:
 
 # ----------------------------------------------------------------------------- synthetic weights
 
-def make_synthetic_weights(cfg: SnacConfig, seed: int = 1234) -> dict:
+def make_synthetic_weights(cfg: SnacConfig, seed: int = 1234, with_encoder: bool = False) -> dict:
     """Seeded synthetic weights in the reference's safetensors key layout,
     weight_v ~ U(+-gain*sqrt(3/fan_in)) (variance-preserving, so the random network keeps O(1)
     activations and the final tanh is exercised off saturation), weight_g = ||v|| * U(0.5,1.5),
@@ -304,6 +370,22 @@ def make_synthetic_weights(cfg: SnacConfig, seed: int = 1234) -> dict:
     cl = cfg.decoder_dim // 2 ** len(cfg.decoder_rates)
     alpha(f"{p}.{n}.alpha", cl)
     wn_conv(f"{p}.{n + 1}", 1, 7, cl, cl, gain=0.12)
+    if with_encoder:                      # appended after every decoder key: the decoder tensors keep their generator keys
+        e = "encoder.block.layers"
+        wn_conv(e + ".0", cfg.encoder_dim, 7, 1, 1, gain=3.0)
+        c = cfg.encoder_dim
+        for i, st in enumerate(cfg.encoder_rates):
+            b = f"{e}.{1 + i}.block.layers"
+            for j in range(3):
+                r = f"{b}.{j}.block.layers"
+                alpha(r + ".0.alpha", c)
+                wn_conv(r + ".1", c, 7, 1 if cfg.depthwise else c, c)
+                alpha(r + ".2.alpha", c)
+                wn_conv(r + ".3", c, 1, c, c, gain=0.2)
+            alpha(b + ".3.alpha", c)
+            wn_conv(b + ".4", 2 * c, 2 * st, c, c)
+            c *= 2
+        wn_conv(f"{e}.{1 + len(cfg.encoder_rates)}", c, 7, 1 if cfg.depthwise else c, c)
     return W
 
 

@@ -105,3 +105,41 @@ def test_empty_and_invalid_inputs():
         m = mas.SNAC(mas.SNACConfig(**{k: getattr(ocfg, k) for k in mas.SNACConfig.__dataclass_fields__}))
         m.finalize()                                               # verify:.all -> missing keys
     assert e.value.case == "modelNotInitialized"
+
+
+def test_encode_matches_oracle():
+    # (f)2: SNAC.encode (SNACDecoder.swift:120-125): encoder latent within fp tolerance, codes equal wherever the oracle's
+    # nearest-code decision has a margin (a tie within float rounding may legitimately go either way)
+    import mlx_audio_swift_amd as mas
+    from oracle import snac as osnac
+    ocfg = osnac.SnacConfig(**osnac.TINY)
+    W = osnac.make_synthetic_weights(ocfg, with_encoder=True)
+    orc = osnac.SnacOracle(ocfg, W)
+    hcfg = mas.SNACConfig(**{k: getattr(ocfg, k) for k in mas.SNACConfig.__dataclass_fields__})
+    dev = mas.SNAC.from_weights(hcfg, W)
+    rng = np.random.default_rng(4)
+    for B, n in ((2, 1000), (1, 64), (3, 4133)):
+        audio = (0.3 * rng.standard_normal((B, n))).astype(np.float32)
+        assert dev.padded_length(n) == orc.preprocess(audio[:, None]).shape[-1]
+        codes, z = dev.encode(audio, return_latent=True)
+        zr = orc.encoder(orc.preprocess(audio[:, None]))
+        assert z.shape == zr.shape and np.abs(z - zr).max() <= 2e-4 * np.abs(zr).max()
+        rcodes, dist = orc.encode(audio[:, None], return_details=True)
+        for lvl, (g, r, d) in enumerate(zip(codes, rcodes, dist)):
+            assert g.shape == r.shape
+            ds = np.sort(d, -1)
+            sure = (ds[..., 1] - ds[..., 0]) > 1e-4
+            assert np.array_equal(g[sure], r[sure]), lvl
+            # where they differ the engine's choice is as close as the oracle's
+            pick = np.take_along_axis(d, g[..., None].astype(np.int64), -1)[..., 0]
+            assert np.all(pick <= ds[..., 0] + 1e-4)
+            if lvl == 0:
+                assert sure.mean() > 0.9
+    # round trip through the engine's own decoder runs (AudioCodecModel: decodeAudio(encodeAudio(x)))
+    wav = dev.decode(dev.encode_audio((0.3 * rng.standard_normal((1, 2048))).astype(np.float32)), noise=None)
+    assert wav.shape[-1] == 2048 // 16 * 32          # TINY: encoder hop 16, decoder hop 32
+    # a handle without encoder tensors raises audioEncodingFailed
+    dec_only = mas.SNAC.from_weights(hcfg, osnac.make_synthetic_weights(ocfg))
+    with pytest.raises(mas.AudioGenerationError) as e:
+        dec_only.encode(np.zeros((1, 64), np.float32))
+    assert e.value.case == "audioEncodingFailed"

@@ -114,3 +114,38 @@ def test_c1_shape_and_zero_noise_equals_no_noise():
     full = snac.SnacConfig()
     assert full.resolved_latent_dim == 768 and full.hop_length == 512
     assert snac.SnacOracle(full, {}).noise_lengths(12) == [384, 3072, 12288, 24576]
+
+
+def test_encode_path_strided_conv_and_nearest_code():
+    import torch
+    import torch.nn.functional as TF
+    cfg = snac.SnacConfig(**snac.TINY)
+    W = snac.make_synthetic_weights(cfg, with_encoder=True)
+    W0 = snac.make_synthetic_weights(cfg)
+    assert all(np.array_equal(W[k], W0[k]) for k in W0)               # decoder tensors keep their generator keys
+    orc = snac.SnacOracle(cfg, W)
+    rng = np.random.default_rng(3)
+    # strided WNConv1d against torch
+    x = rng.standard_normal((2, 8, 40)).astype(np.float32)
+    w = rng.standard_normal((16, 4, 8)).astype(np.float32)
+    ref = TF.conv1d(torch.from_numpy(x), torch.from_numpy(w).permute(0, 2, 1), stride=2, padding=1).numpy()
+    assert np.abs(snac.conv1d_nct(x, w, stride=2, padding=1) - ref).max() < 1e-5
+    # preprocess pads to hop * lcm(vq_strides)
+    audio = (0.3 * rng.standard_normal((2, 1, 1000))).astype(np.float32)
+    assert orc.preprocess(audio).shape[-1] == 1024 and cfg.hop_length * 4 == 64
+    codes, details = orc.encode(audio, return_details=True)
+    assert [c.shape for c in codes] == [(2, 16), (2, 32), (2, 64)]
+    # nearest code == cosine-similarity argmax in float64
+    z = orc.encoder(orc.preprocess(audio)).astype(np.float64)
+    pooled = z.reshape(2, z.shape[1], 16, 4).mean(-1)
+    wi, bi = orc._wn("quantizer.quantizers.0.in_proj")
+    e = np.einsum("oc,bct->bto", wi[:, 0, :].astype(np.float64), pooled) + bi
+    cb = W["quantizer.quantizers.0.codebook.weight"].astype(np.float64)
+    cos = (e / np.linalg.norm(e, axis=-1, keepdims=True)) @ (cb / np.linalg.norm(cb, axis=-1, keepdims=True)).T
+    best = cos.argmax(-1)
+    agree = (best == codes[0])
+    margin = np.sort(cos, -1)[..., -1] - np.sort(cos, -1)[..., -2]
+    assert agree[margin > 1e-5].all() and agree.mean() > 0.9
+    # codes decode back through fromCodes to the sum of the per-level quantised vectors
+    zq = orc.from_codes(codes)
+    assert zq.shape == z.shape
