@@ -153,27 +153,49 @@ class LlamaTTSModel:
     def default_generation_parameters(self) -> GenerateParameters:
         return GenerateParameters()
 
-    def prepare_input_ids(self, prompts, voice=None):
-        """prepareInputIds (LlamaTTS.swift:446-553) without the voice-cloning branch: returns the list
-        of per-row id arrays [SOH] text [EOT][EOH]; needs `self.tokenizer` (any object with .encode)."""
+    def encode_audio_to_codes(self, audio) -> np.ndarray:
+        """llamaEncodeAudioToCodes (LlamaTTS.swift:72-98): SNAC-encode a reference waveform and interleave the three code
+        levels into 7-token frames with the k*4096 slot offsets (inverse of the decode-side de-interleave, :41-64)."""
+        if self._snac_model is None:
+            raise AudioGenerationError(1, "SNAC model not loaded")
+        l1, l2, l3 = [c[0].astype(np.int64) for c in self._snac_model.encode(np.asarray(audio, np.float32).reshape(1, -1))]
+        g = len(l1)
+        out = np.empty((g, 7), np.int64)
+        out[:, 0] = l1
+        out[:, 1] = l2[0::2] + 4096
+        out[:, 2] = l3[0::4] + 2 * 4096
+        out[:, 3] = l3[1::4] + 3 * 4096
+        out[:, 4] = l2[1::2] + 4 * 4096
+        out[:, 5] = l3[2::4] + 5 * 4096
+        out[:, 6] = l3[3::4] + 6 * 4096
+        return out.reshape(-1).astype(np.int32)
+
+    def prepare_input_ids(self, prompts, voice=None, ref_audio=None, ref_text=None):
+        """prepareInputIds (LlamaTTS.swift:446-553): the list of per-row id arrays
+        [SOH transcript EOT EOH AUDIO_START START_OF_SPEECH ref-audio-tokens END_OF_SPEECH AUDIO_END]? [SOH] text [EOT][EOH];
+        rows are left-padded by the engine, so the reference's explicit pad tokens are not materialised.  Needs
+        `self.tokenizer` (any object with .encode)."""
         if self.tokenizer is None:
             raise AudioGenerationError(1, "Tokenizer not loaded")
+        T = OrpheusTokens
+        ref = []
+        if ref_audio is not None and ref_text is not None:                # voice cloning branch (:457-469,505-528)
+            audio_ids = self.encode_audio_to_codes(ref_audio).astype(np.int64) + T.audio_token_offset
+            ref = ([T.start_of_human] + list(self.tokenizer.encode(ref_text)) + [T.end_of_text, T.end_of_human] +
+                   [T.audio_start, T.start_of_speech] + list(audio_ids) + [T.end_of_speech, T.audio_end])
         rows = []
         for p in prompts:
             if voice is not None:
                 p = f"{voice}: {p}"
             ids = list(self.tokenizer.encode(p))
-            rows.append(np.asarray([OrpheusTokens.start_of_human] + ids +
-                                   [OrpheusTokens.end_of_text, OrpheusTokens.end_of_human], np.int32))
+            rows.append(np.asarray(ref + [T.start_of_human] + ids + [T.end_of_text, T.end_of_human], np.int32))
         return rows
 
     def generate(self, text: str, voice=None, ref_audio=None, ref_text=None, language=None,
                  generation_parameters: GenerateParameters | None = None, snac_noise=None) -> np.ndarray:
         """generate(text:voice:...) -> 1-D float32 PCM (LlamaTTS.swift:658-765)."""
-        if ref_audio is not None:
-            raise AudioGenerationError(5, "voice cloning needs the SNAC encode path (not built yet)")
         text = text.replace("\\n", "\n").replace("\\t", "\t")            # :680-681
-        rows = self.prepare_input_ids([text], voice)
+        rows = self.prepare_input_ids([text], voice, ref_audio, ref_text)
         return self.generate_batch(rows, generation_parameters, snac_noise)[0]
 
     def generate_batch(self, prompt_rows, generation_parameters: GenerateParameters | None = None, snac_noise=None,

@@ -143,3 +143,36 @@ def test_encode_matches_oracle():
     with pytest.raises(mas.AudioGenerationError) as e:
         dec_only.encode(np.zeros((1, 64), np.float32))
     assert e.value.case == "audioEncodingFailed"
+
+
+def test_orpheus_voice_cloning_prompt_uses_the_encode_path():
+    # llamaEncodeAudioToCodes + the refAudio/refText branch of prepareInputIds (LlamaTTS.swift:72-98,457-528)
+    import mlx_audio_swift_amd as mas
+    from oracle import orpheus_codes as oc
+    from oracle import snac as osnac
+    small = dict(encoder_dim=4, encoder_rates=[2, 4, 8, 8], decoder_dim=64, decoder_rates=[8, 8, 4, 2], codebook_size=4096,
+                 codebook_dim=8, vq_strides=[4, 2, 1])
+    ocfg = osnac.SnacConfig(**small)
+    codec = mas.SNAC.from_weights(mas.SNACConfig(**{k: getattr(ocfg, k) for k in mas.SNACConfig.__dataclass_fields__}),
+                                  osnac.make_synthetic_weights(ocfg, with_encoder=True))
+    lm = mas.LlamaTTSModel.synthetic(mas.LlamaTTSConfiguration(hidden_size=64, num_hidden_layers=1, intermediate_size=64,
+                                                               num_attention_heads=1, num_key_value_heads=1, head_dim=64,
+                                                               vocab_size=156940), codec=codec)
+
+    class Tok:
+        def encode(self, s):
+            return [1000 + (ord(ch) % 97) for ch in s]
+    lm.tokenizer = Tok()
+    rng = np.random.default_rng(5)
+    ref = (0.3 * rng.standard_normal(5000)).astype(np.float32)          # padded to 3 groups of 2048 samples
+    flat = lm.encode_audio_to_codes(ref)
+    levels = codec.encode(ref)
+    assert flat.shape == (21,) and np.array_equal(flat, oc.interleave(levels[0][0], levels[1][0], levels[2][0]))
+    l0, l1, l2 = oc.deinterleave(flat)                                   # decode-side framing is the exact inverse
+    assert np.array_equal(l0, levels[0][0]) and np.array_equal(l1, levels[1][0]) and np.array_equal(l2, levels[2][0])
+    row = lm.prepare_input_ids(["hi"], voice="tara", ref_audio=ref, ref_text="ok")[0]
+    T = mas.OrpheusTokens
+    want = ([T.start_of_human] + Tok().encode("ok") + [T.end_of_text, T.end_of_human, T.audio_start, T.start_of_speech] +
+            list(flat + T.audio_token_offset) + [T.end_of_speech, T.audio_end, T.start_of_human] + Tok().encode("tara: hi") +
+            [T.end_of_text, T.end_of_human])
+    assert row.tolist() == want
