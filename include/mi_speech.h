@@ -373,6 +373,34 @@ mis_status mis_dac_debug_tap(mis_dac*, const int32_t* codes, int batch, int T, i
                              int32_t* channels, int64_t* length);
 
 /* ------------------------------------------------------------------------------------------
+ * EnCodec decoder.  Replaces Encodec.decodeFrame / EncodecDecoder (Sources/MLXAudioCodecs/Encodec/Encodec.swift:94-170,295-302)
+ * incl. the 2-layer LSTM (EncodecLayers.swift:15-80) and EncodecResidualVectorQuantizer.decode (EncodecQuantization.swift:117-133).
+ * norm_type "weight_norm" models (no GroupNorm), mono, causal.  Chunked decode = decode_frame per chunk + the host
+ * linearOverlapAdd of the reference (Encodec.swift:304-355; mirrored in the Python host layer).
+ * ---------------------------------------------------------------------------------------- */
+typedef struct mis_encodec mis_encodec;
+typedef struct {                   /* EncodecConfig.swift:64-89 */
+    int32_t audio_channels, num_filters, kernel_size, num_residual_layers, dilation_growth_rate;
+    int32_t codebook_size, codebook_dim, hidden_size, num_lstm_layers, residual_kernel_size;
+    int32_t use_causal_conv, pad_reflect, last_kernel_size, compress, use_conv_shortcut;
+    float   trim_right_ratio;
+    int32_t n_upsampling_ratios; int32_t upsampling_ratios[8];
+    int32_t n_quantizers;          /* EncodecQuantization.swift:60-64 */
+    int32_t sampling_rate;
+} mis_encodec_config;
+mis_status mis_encodec_create(const mis_encodec_config*, int device, mis_encodec** out);
+/* module-tree keys: quantizer.layers.N.codebook.embed, decoder.layers.N.conv.{weight [out,k,in],bias},
+ * decoder.layers.1.lstm.N.{Wx,Wh,bias}, decoder.layers.N.{block.1,block.3,shortcut}.conv.*; "encoder.*" ignored */
+mis_status mis_encodec_set_tensor(mis_encodec*, const char* name, const void* data, mis_dtype dtype, const int64_t* shape, int ndim);
+mis_status mis_encodec_finalize(mis_encodec*);
+void       mis_encodec_destroy(mis_encodec*);
+int        mis_encodec_hop_length(const mis_encodec*);
+mis_status mis_encodec_decode_frame(mis_encodec*, const int32_t* codes, int batch, int n_q, int T, const float* scales, float* wav_out);
+/* stage 1 conv0, 2 LSTM block, 3 + i upsampling block i: out f32 [batch, C, T'] */
+mis_status mis_encodec_debug_tap(mis_encodec*, const int32_t* codes, int batch, int n_q, int T, int stage, float* out, int64_t capacity,
+                                 int32_t* channels, int64_t* length);
+
+/* ------------------------------------------------------------------------------------------
  * Log-mel / STFT front end.  Replaces WhisperAudio.logMelSpectrogram / encoderFeatures
  * (Sources/MLXAudioSTT/Models/Whisper/WhisperAudio.swift:38-87) and computeMelSpectrogram
  * (Sources/MLXAudioCore/DSP.swift:230-273): reflect pad, window, rfft, |.|^2, mel filterbank

@@ -8,6 +8,7 @@ the Swift shim a maintainer would add):
 
     codecs.SNAC            <-> class SNAC : AudioCodecModel       (MLXAudioCodecs/SNAC/SNACDecoder.swift)
     codecs.DescriptDAC     <-> class DescriptDAC (decode side)         (MLXAudioCodecs/Descript/DescriptDAC.swift)
+    codecs.Encodec         <-> class Encodec (decode side)             (MLXAudioCodecs/Encodec/Encodec.swift)
     tts.LlamaTTSModel      <-> class LlamaTTSModel : SpeechGenerationModel  (MLXAudioTTS/Models/Llama/LlamaTTS.swift)
     soprano.SopranoModel   <-> class SopranoModel : SpeechGenerationModel  (MLXAudioTTS/Models/Soprano/Soprano.swift)
     qwen3tts.Qwen3TTSModel <-> class Qwen3TTSModel : SpeechGenerationModel  (MLXAudioTTS/Models/Qwen3TTS/Qwen3TTS.swift)
@@ -22,7 +23,7 @@ compute entry point raises if the HIP library or a GPU is missing.
 from . import _lib  # noqa: F401
 from .generation import (AudioGenerationError, AudioGenerationInfo, GenerateParameters, TokenEvent, InfoEvent,  # noqa: F401
                          AudioEvent)
-from .codecs import SNAC, SNACConfig, DescriptDAC, DescriptDACConfig  # noqa: F401
+from .codecs import SNAC, SNACConfig, DescriptDAC, DescriptDACConfig, Encodec, EncodecConfig  # noqa: F401
 from .tts import LlamaTTSModel, LlamaTTSConfiguration, OrpheusTokens  # noqa: F401
 from .orpheus import deinterleave, parse_output  # noqa: F401
 from .soprano import SopranoModel, SopranoConfiguration  # noqa: F401

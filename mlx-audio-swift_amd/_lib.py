@@ -75,6 +75,16 @@ class DacConfigC(C.Structure):
                 ("codebook_dim", C.c_int32), ("sample_rate", C.c_int32)]
 
 
+class EncodecConfigC(C.Structure):
+    _fields_ = [("audio_channels", C.c_int32), ("num_filters", C.c_int32), ("kernel_size", C.c_int32),
+                ("num_residual_layers", C.c_int32), ("dilation_growth_rate", C.c_int32), ("codebook_size", C.c_int32),
+                ("codebook_dim", C.c_int32), ("hidden_size", C.c_int32), ("num_lstm_layers", C.c_int32),
+                ("residual_kernel_size", C.c_int32), ("use_causal_conv", C.c_int32), ("pad_reflect", C.c_int32),
+                ("last_kernel_size", C.c_int32), ("compress", C.c_int32), ("use_conv_shortcut", C.c_int32),
+                ("trim_right_ratio", C.c_float), ("n_upsampling_ratios", C.c_int32), ("upsampling_ratios", C.c_int32 * 8),
+                ("n_quantizers", C.c_int32), ("sampling_rate", C.c_int32)]
+
+
 class MelConfigC(C.Structure):
     _fields_ = [("sample_rate", C.c_int32), ("n_fft", C.c_int32), ("hop_length", C.c_int32), ("n_mels", C.c_int32),
                 ("window", C.c_int32), ("mel_scale", C.c_int32), ("slaney_norm", C.c_int32), ("drop_last_frame", C.c_int32)]
@@ -193,6 +203,14 @@ SYMBOLS = {
     "mis_mel_stream_reset": (C.c_int, [_P]),
     "mis_mel_stream_total_frames": (C.c_int64, [_P]),
     "mis_mel_stream_destroy": (None, [_P]),
+    "mis_encodec_create": (C.c_int, [C.POINTER(EncodecConfigC), C.c_int, C.POINTER(_P)]),
+    "mis_encodec_set_tensor": (C.c_int, [_P, C.c_char_p, _P, C.c_int, C.POINTER(C.c_int64), C.c_int]),
+    "mis_encodec_finalize": (C.c_int, [_P]),
+    "mis_encodec_destroy": (None, [_P]),
+    "mis_encodec_hop_length": (C.c_int, [_P]),
+    "mis_encodec_decode_frame": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, _P, _P]),
+    "mis_encodec_debug_tap": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, C.c_int, _P, C.c_int64, C.POINTER(C.c_int32),
+                                        C.POINTER(C.c_int64)]),
     "mis_debug_launch_floor": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_double)]),
 }
 

@@ -287,3 +287,141 @@ class DescriptDAC:
 
     def encode(self, audio):
         raise AudioGenerationError(5, "DAC encode path is not built")
+
+
+@dataclass
+class EncodecConfig:
+    """EncodecConfig (Sources/MLXAudioCodecs/Encodec/EncodecConfig.swift:64-89)"""
+    audio_channels: int = 1
+    num_filters: int = 32
+    kernel_size: int = 7
+    num_residual_layers: int = 1
+    dilation_growth_rate: int = 2
+    codebook_size: int = 1024
+    codebook_dim: int = 128
+    hidden_size: int = 128
+    num_lstm_layers: int = 2
+    residual_kernel_size: int = 3
+    use_causal_conv: bool = True
+    pad_mode: str = "reflect"
+    norm_type: str = "weight_norm"
+    last_kernel_size: int = 7
+    trim_right_ratio: float = 1.0
+    compress: int = 2
+    upsampling_ratios: tuple = (8, 5, 4, 2)
+    target_bandwidths: tuple = (1.5, 3.0, 6.0, 12.0, 24.0)
+    sampling_rate: int = 24000
+    chunk_length_s: float | None = None
+    overlap: float | None = None
+    use_conv_shortcut: bool = True
+
+    @property
+    def hop_length(self) -> int:
+        return int(np.prod(self.upsampling_ratios))
+
+    @property
+    def num_quantizers(self) -> int:              # EncodecQuantization.swift:60-64
+        import math
+        frame_rate = int(math.ceil(self.sampling_rate / self.hop_length))
+        return int(1000 * max(self.target_bandwidths) / (frame_rate * 10))
+
+    @property
+    def chunk_length(self):                       # Encodec.swift:196-201
+        return None if self.chunk_length_s is None else int(self.chunk_length_s * self.sampling_rate)
+
+    @property
+    def chunk_stride(self):                       # Encodec.swift:203-208
+        if self.chunk_length_s is None or self.overlap is None:
+            return None
+        return max(1, int((1.0 - self.overlap) * self.chunk_length))
+
+    def to_c(self) -> "_lib.EncodecConfigC":
+        if self.norm_type != "weight_norm":
+            raise AudioGenerationError(3, "only norm_type 'weight_norm' Encodec models are built (no GroupNorm)")
+        return _lib.EncodecConfigC(self.audio_channels, self.num_filters, self.kernel_size, self.num_residual_layers,
+                                   self.dilation_growth_rate, self.codebook_size, self.codebook_dim, self.hidden_size,
+                                   self.num_lstm_layers, self.residual_kernel_size, 1 if self.use_causal_conv else 0,
+                                   1 if self.pad_mode == "reflect" else 0, self.last_kernel_size, self.compress,
+                                   1 if self.use_conv_shortcut else 0, float(self.trim_right_ratio), len(self.upsampling_ratios),
+                                   (C.c_int32 * 8)(*self.upsampling_ratios), self.num_quantizers, self.sampling_rate)
+
+
+class Encodec:
+    """Decode side of class Encodec (Encodec/Encodec.swift:179-398): decode(audio_codes, audio_scales)."""
+
+    def __init__(self, config: EncodecConfig, device: int = 0):
+        self.config = config
+        self._h = C.c_void_p()
+        cc = config.to_c()
+        check(_lib.lib().mis_encodec_create(C.byref(cc), device, C.byref(self._h)))
+
+    def __del__(self):
+        h, self._h = getattr(self, "_h", None), None
+        if h:
+            _lib.lib().mis_encodec_destroy(h)
+
+    @classmethod
+    def from_weights(cls, config, weights: dict, device: int = 0) -> "Encodec":
+        m = cls(config, device)
+        for k, v in weights.items():
+            keep, ptr, dt, shape = _tensor_args(v)
+            sh = (C.c_int64 * len(shape))(*shape)
+            check(_lib.lib().mis_encodec_set_tensor(m._h, k.encode(), ptr, dt, sh, len(shape)))
+        check(_lib.lib().mis_encodec_finalize(m._h))
+        return m
+
+    @property
+    def codec_sample_rate(self) -> float:
+        return float(self.config.sampling_rate)
+
+    def decode_frame(self, codes, scale=None) -> np.ndarray:
+        """decodeFrame (Encodec.swift:295-302): codes int [B, n_q, T] -> [B, T * hop]"""
+        cd = np.ascontiguousarray(codes, dtype=np.int32)
+        B, nq, T = cd.shape
+        out = np.zeros((B, T * self.config.hop_length), np.float32)
+        sc = None if scale is None else np.ascontiguousarray(np.broadcast_to(np.asarray(scale, np.float32).reshape(-1), (B,)))
+        check(_lib.lib().mis_encodec_decode_frame(self._h, cd.ctypes.data, B, nq, T, None if sc is None else sc.ctypes.data,
+                                                  out.ctypes.data))
+        return out
+
+    @staticmethod
+    def linear_overlap_add(frames, hop_stride: int) -> np.ndarray:
+        """Encodec.linearOverlapAdd (Encodec.swift:304-355); host arithmetic in the reference as well."""
+        L = frames[0].shape[1]
+        total = hop_stride * (len(frames) - 1) + frames[-1].shape[1]
+        tv = (np.arange(L, dtype=np.float32) + np.float32(1)) / np.float32(L + 1)
+        wv = (np.float32(0.5) - np.abs(tv - np.float32(0.5))).astype(np.float32)
+        out = np.zeros((frames[0].shape[0], total), np.float32)
+        sw = np.zeros(total, np.float32)
+        off = 0
+        for f in frames:
+            n = f.shape[1]
+            out[:, off:off + n] += wv[:n] * f
+            sw[off:off + n] += wv[:n]
+            off += hop_stride
+        nz = sw != 0
+        out[:, nz] /= sw[nz]
+        return out
+
+    def decode(self, audio_codes, audio_scales=None, padding_mask=None) -> np.ndarray:
+        """decode (Encodec.swift:357-398): audio_codes [n_chunks, B, n_q, frames] -> [B, samples]"""
+        ac = np.asarray(audio_codes)
+        scales = audio_scales if audio_scales is not None else [None] * ac.shape[0]
+        if self.config.chunk_length is None:
+            if ac.shape[0] != 1:
+                raise AudioGenerationError(3, f"Expected one frame, got {ac.shape[0]}")
+            out = self.decode_frame(ac[0], scales[0])
+        else:
+            out = self.linear_overlap_add([self.decode_frame(ac[i], scales[i]) for i in range(ac.shape[0])], self.config.chunk_stride or 1)
+        if padding_mask is not None and np.asarray(padding_mask).shape[1] < out.shape[1]:
+            out = out[:, : np.asarray(padding_mask).shape[1]]
+        return out
+
+    def debug_tap(self, codes, stage: int) -> np.ndarray:
+        cd = np.ascontiguousarray(codes, dtype=np.int32)
+        B, nq, T = cd.shape
+        cap = B * max(self.config.num_filters << len(self.config.upsampling_ratios), 4) * (T + 8) * self.config.hop_length
+        buf = np.zeros(cap, np.float32)
+        ch = C.c_int32(); ln = C.c_int64()
+        check(_lib.lib().mis_encodec_debug_tap(self._h, cd.ctypes.data, B, nq, T, stage, buf.ctypes.data, cap, C.byref(ch), C.byref(ln)))
+        return buf[: B * ch.value * ln.value].reshape(B, ch.value, ln.value).copy()
