@@ -460,7 +460,9 @@ typedef struct {
     int32_t n_begin_suppress;
 } mis_stt_params;
 mis_status mis_whisper_create(const mis_whisper_config*, int device, mis_whisper** out);
-/* HF transformers key layout (model.encoder.* / model.decoder.*; conv weights [out, in, k]; proj_out ignored: tied) */
+/* HF transformers key layout (model.encoder.* / model.decoder.*; conv weights [out, in, k]; proj_out ignored: tied) or the
+ * mlx-whisper layout (encoder.blocks.N.attn.query.*, conv weights [out, k, in], encoder positional embedding synthesised):
+ * WhisperModel.sanitize, WhisperModel.swift:321-478 */
 mis_status mis_whisper_set_tensor(mis_whisper*, const char* name, const void* data, mis_dtype dtype,
                                   const int64_t* shape, int ndim);
 mis_status mis_whisper_init_synthetic(mis_whisper*, uint64_t seed);

@@ -84,6 +84,47 @@ extern "C" void mis_whisper_destroy(mis_whisper* c) {
     delete c;
 }
 
+// mlx-whisper checkpoint keys ("encoder.blocks.N.attn.query.weight", ...) -> the HF names the engine indexes by
+// (WhisperModel.remapMlxWhisperKey / remapBlockSuffix / remapAttnSuffix, WhisperModel.swift:393-478).  false = not an mlx key.
+static bool whisper_remap_mlx_key(const std::string& raw, std::string* out) {
+    auto starts = [&](const std::string& s, const char* p) { return s.rfind(p, 0) == 0; };
+    if (raw == "encoder.positional_embedding") { *out = "model.encoder.embed_positions.weight"; return true; }
+    if (raw == "decoder.positional_embedding") { *out = "model.decoder.embed_positions.weight"; return true; }
+    if (starts(raw, "decoder.token_embedding.")) { *out = "model.decoder.embed_tokens." + raw.substr(strlen("decoder.token_embedding.")); return true; }
+    if (starts(raw, "encoder.ln_post.")) { *out = "model.encoder.layer_norm." + raw.substr(strlen("encoder.ln_post.")); return true; }
+    if (starts(raw, "decoder.ln.")) { *out = "model.decoder.layer_norm." + raw.substr(strlen("decoder.ln.")); return true; }
+    for (const char* stem : {"encoder", "decoder"}) {
+        const std::string pre = std::string(stem) + ".blocks.";
+        if (!starts(raw, pre.c_str())) continue;
+        const std::string rest = raw.substr(pre.size());
+        const size_t dot = rest.find('.');
+        if (dot == std::string::npos) return false;
+        const std::string idx = rest.substr(0, dot), suf = rest.substr(dot + 1);
+        const bool dec = std::string(stem) == "decoder";
+        auto attn = [&](const std::string& s2, const char* container, std::string* m) {
+            const size_t d2 = s2.find('.');
+            if (d2 == std::string::npos) return false;
+            const std::string proj = s2.substr(0, d2), tail = s2.substr(d2 + 1);
+            const char* mp = proj == "query" ? "q_proj" : proj == "key" ? "k_proj" : proj == "value" ? "v_proj" : proj == "out" ? "out_proj" : nullptr;
+            if (!mp) return false;
+            *m = std::string(container) + "." + mp + "." + tail;
+            return true;
+        };
+        std::string m;
+        if (starts(suf, "attn_ln.")) m = "self_attn_layer_norm." + suf.substr(8);
+        else if (dec && starts(suf, "cross_attn_ln.")) m = "encoder_attn_layer_norm." + suf.substr(14);
+        else if (starts(suf, "mlp_ln.")) m = "final_layer_norm." + suf.substr(7);
+        else if (starts(suf, "mlp1.")) m = "fc1." + suf.substr(5);
+        else if (starts(suf, "mlp2.")) m = "fc2." + suf.substr(5);
+        else if (starts(suf, "attn.")) { if (!attn(suf.substr(5), "self_attn", &m)) return false; }
+        else if (dec && starts(suf, "cross_attn.")) { if (!attn(suf.substr(11), "encoder_attn", &m)) return false; }
+        else return false;
+        *out = std::string("model.") + stem + ".layers." + idx + "." + m;
+        return true;
+    }
+    return false;
+}
+
 extern "C" mis_status mis_whisper_set_tensor(mis_whisper* c, const char* name_, const void* data, mis_dtype dtype,
                                              const int64_t* shape, int ndim) {
     MIS_API_BEGIN
@@ -92,6 +133,11 @@ extern "C" mis_status mis_whisper_set_tensor(mis_whisper* c, const char* name_, 
     MIS_REQUIRE(dtype == MIS_F32 || dtype == MIS_F16 || dtype == MIS_BF16, MIS_ERR_INVALID_INPUT, "unsupported dtype");
     std::string name = name_;
     if (name == "proj_out.weight" || name == "model.proj_out.weight") return MIS_OK;          // tied, WhisperModel.swift:343-346
+    if (name == "alignment_heads") return MIS_OK;                                              // mlx-whisper extra (:371)
+    {   // mlx-whisper key layout -> HF names (WhisperModel.remapMlxWhisperKey / remapBlockSuffix, :393-478)
+        std::string mapped;
+        if (whisper_remap_mlx_key(name, &mapped)) name = mapped;
+    }
     if (name.rfind("model.", 0) != 0 && (name.rfind("encoder.", 0) == 0 || name.rfind("decoder.", 0) == 0)) name = "model." + name;
     HIP_CHECK(hipSetDevice(c->device));
     size_t n = 1;
@@ -101,6 +147,19 @@ extern "C" mis_status mis_whisper_set_tensor(mis_whisper* c, const char* name_, 
     DevBuf<uint8_t> rawb;
     rawb.alloc(n * esz);
     t->buf.alloc(n);
+    std::vector<uint8_t> permuted;
+    if ((name == "model.encoder.conv1.weight" || name == "model.encoder.conv2.weight") && ndim == 3 && shape[1] == 3 && shape[2] != 3) {
+        // MLX Conv1d layout [out, k, in] (mlx-whisper checkpoints; the reference transposes HF's [out, in, k] INTO this, :354-358):
+        // the engine keeps HF's order, so bring it back
+        std::vector<uint8_t> host(n * esz);
+        HIP_CHECK(hipMemcpy(host.data(), data, n * esz, hipMemcpyDefault));
+        permuted.resize(n * esz);
+        const int64_t O = shape[0], K = shape[1], I = shape[2];
+        for (int64_t o = 0; o < O; ++o) for (int64_t k = 0; k < K; ++k) for (int64_t i = 0; i < I; ++i)
+            memcpy(&permuted[((o * I + i) * K + k) * esz], &host[((o * K + k) * I + i) * esz], esz);
+        data = permuted.data();
+        t->shape = {O, I, K};
+    }
     HIP_CHECK(hipMemcpyAsync(rawb.p, data, n * esz, hipMemcpyDefault, c->stream));
     launch_convert_to_bf16(rawb.p, dtype, t->buf.p, n, c->stream);
     HIP_CHECK(hipGetLastError());
@@ -160,7 +219,21 @@ extern "C" mis_status mis_whisper_finalize(mis_whisper* c) {
                        wneed(c, E + ".conv2.weight", {d, d, 3})->buf.p, c->conv2w, (int)d, (int)d, (int)(3 * d));
     c->conv2b = vec(E + ".conv2.bias", d);
     c->enc_pos = take((size_t)1500 * d);
-    copy(c->enc_pos, wneed(c, E + ".embed_positions.weight", {1500, d}));
+    if (!c->raw.count(E + ".embed_positions.weight")) {
+        // mlx-whisper checkpoints omit the fixed sinusoid (WhisperModel.swift:376-392 synthesises it): [sin | cos] halves
+        const int64_t half = d / 2;
+        const double inc = log(10000.0) / (double)std::max<int64_t>(half - 1, 1);
+        std::vector<bf16_t> pe((size_t)1500 * d);
+        for (int64_t pos = 0; pos < 1500; ++pos)
+            for (int64_t i = 0; i < half; ++i) {
+                const double st = (double)pos * exp(-inc * (double)i);
+                pe[pos * d + i] = f32_to_bf16((float)sin(st));
+                pe[pos * d + half + i] = f32_to_bf16((float)cos(st));
+            }
+        HIP_CHECK(hipMemcpyAsync(c->enc_pos, pe.data(), pe.size() * 2, hipMemcpyHostToDevice, s));
+        HIP_CHECK(hipStreamSynchronize(s));
+    } else
+        copy(c->enc_pos, wneed(c, E + ".embed_positions.weight", {1500, d}));
     c->enc.resize(Le);
     for (int li = 0; li < Le; ++li) {
         std::string q = E + ".layers." + std::to_string(li);

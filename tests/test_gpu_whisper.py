@@ -119,3 +119,57 @@ def test_errors():
     assert e.value.case == "modelNotInitialized"
     with pytest.raises(mas.AudioGenerationError):
         mas.WhisperModel(mas.WhisperConfig(d_model=100))
+
+
+def test_mlx_whisper_key_layout_loads_to_the_same_model():
+    # WhisperModel.sanitize: the mlx-whisper layout ("encoder.blocks.N.attn.query.weight", conv weights [out, k, in], no encoder
+    # positional embedding) must give the model the HF layout gives (WhisperModel.swift:321-478)
+    import torch
+    cfg = ow.TINY
+    W = ow.make_synthetic_weights(cfg, seed=31)
+    d = cfg.d_model
+    half = d // 2
+    inc = np.log(10000.0) / max(half - 1, 1)
+    pos = np.arange(1500)[:, None] * np.exp(-inc * np.arange(half))[None]
+    W["model.encoder.embed_positions.weight"] = torch.from_numpy(np.concatenate([np.sin(pos), np.cos(pos)], 1).astype(np.float32)).bfloat16()
+    hf = mas.WhisperModel.from_weights(_host_cfg(cfg), W)
+    attn = {"q_proj": "query", "k_proj": "key", "v_proj": "value", "out_proj": "out"}
+    M = {}
+    for k, v in W.items():
+        k2 = k[len("model."):]
+        if k2 == "encoder.embed_positions.weight":
+            continue                                                     # omitted by mlx-whisper
+        if k2 == "decoder.embed_positions.weight":
+            M["decoder.positional_embedding"] = v; continue
+        if k2.startswith("decoder.embed_tokens."):
+            M["decoder.token_embedding." + k2.split(".", 2)[2]] = v; continue
+        if k2 in ("encoder.conv1.weight", "encoder.conv2.weight"):
+            M[k2] = v.permute(0, 2, 1).contiguous(); continue             # [out, in, k] -> MLX [out, k, in]
+        if k2.startswith("encoder.conv"):
+            M[k2] = v; continue
+        if k2.startswith("encoder.layer_norm."):
+            M["encoder.ln_post." + k2.split(".", 2)[2]] = v; continue
+        if k2.startswith("decoder.layer_norm."):
+            M["decoder.ln." + k2.split(".", 2)[2]] = v; continue
+        stem, _, idx, rest = k2.split(".", 3)
+        head, tail = rest.split(".", 1)
+        if head == "self_attn_layer_norm":
+            r = "attn_ln." + tail
+        elif head == "encoder_attn_layer_norm":
+            r = "cross_attn_ln." + tail
+        elif head == "final_layer_norm":
+            r = "mlp_ln." + tail
+        elif head in ("fc1", "fc2"):
+            r = ("mlp1." if head == "fc1" else "mlp2.") + tail
+        else:
+            proj, t2 = tail.split(".", 1)
+            r = ("attn." if head == "self_attn" else "cross_attn.") + attn[proj] + "." + t2
+        M[f"{stem}.blocks.{idx}.{r}"] = v
+    M["alignment_heads"] = torch.zeros(2, 2)
+    mlx = mas.WhisperModel.from_weights(_host_cfg(cfg), M)
+    f = _feats(2, cfg.num_mel_bins, 3)
+    a, b = hf.encode(f), mlx.encode(f)
+    assert np.array_equal(a, b)
+    toks = np.asarray([3, 5], np.int32)
+    hf.decoder_reset(); mlx.decoder_reset()
+    assert np.array_equal(hf.decoder_forward(toks), mlx.decoder_forward(toks))
