@@ -399,7 +399,7 @@ static void lm_reset(mis_tts* c, int batch, int max_context) {
     c->ksb_gu = env_int("MIS_KSB_GU", 4) == 1 ? 1 : 4;
     c->ksb_head = env_int("MIS_KSB_HEAD", 1) == 4 ? 4 : 1;
     c->r_part = env_int("MIS_R_PART", 2) == 1 ? 1 : 2;
-    c->S_qkv = choose_split(c->Nqkv / 16 / c->r_part, d / 32, c->ksb_part, "MIS_S_QKV");
+    c->S_qkv = std::min(8, choose_split(c->Nqkv / 16 / c->r_part, d / 32, c->ksb_part, "MIS_S_QKV"));   // attention prologue: <= 8 slabs
     c->S_o = choose_split(d / 16 / c->r_part, HD / 32, c->ksb_part, "MIS_S_O");
     c->S_down = choose_split(d / 16 / c->r_part, c->ff / 32, c->ksb_part, "MIS_S_DOWN");
     size_t kv = (size_t)c->L * batch * c->Hkv * Smax * c->D;

@@ -538,7 +538,7 @@ void launch_gemm_skinny(int epi, int R, int ksb, const bf16_t* Wp, const bf16_t*
 
 #define ATT_WAVES 8
 
-template <int D>
+template <int D, int NIT>
 __global__ void __launch_bounds__(512) k_attn_decode(AttnParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int kvh = blockIdx.x, b = blockIdx.y;
@@ -555,24 +555,81 @@ __global__ void __launch_bounds__(512) k_attn_decode(AttnParams p) {
     float* sl = sm + ATT_WAVES * 16;                                   // [W][16]
     float* sO = sl + ATT_WAVES * 16;                                   // [W][G][D]
 
-    // ---- prologue: slab reduce -> bf16
+    // ---- cache pointers and the first pair of key tiles of this wave.  Tiles that do not hold the NEW key are independent of
+    // this step's q/k/v, so their K and V fragments (32 KiB per wave) are requested BEFORE the prologue consumes its slab loads:
+    // the KV stream of the step overlaps the slab reduce / norm / RoPE instead of starting after it.
+    bf16_t* kc = p.kcache + ((size_t)(b * p.Hkv + kvh) * p.Smax) * D;
+    bf16_t* vt = p.vtcache + ((size_t)(b * p.Hkv + kvh) * D) * p.Smax;
+    const bf16x8_t* kbase = reinterpret_cast<const bf16x8_t*>(kc) + lane;
+    const bf16x8_t* vbase = reinterpret_cast<const bf16x8_t*>(vt) + lane;
+    const int n_tiles = (kv_len + 31) >> 5;
+    const int new_tile = p.cross ? -1 : (pos >> 5);
+    bf16x8_t kA[2][D / 32], kB[2][D / 32], vA[D / 16], vB[D / 16];
+    auto load_tile = [&](int tile, bf16x8_t (&ka)[2][D / 32], bf16x8_t (&vb)[D / 16]) {
+#pragma unroll
+        for (int c = 0; c < D / 32; ++c) {
+            ka[0][c] = kbase[((size_t)tile * 2) * (D / 32) * 64 + c * 64];
+            ka[1][c] = kbase[((size_t)tile * 2 + 1) * (D / 32) * 64 + c * 64];
+        }
+#pragma unroll
+        for (int dt = 0; dt < D / 16; ++dt) vb[dt] = vbase[((size_t)tile * (D / 16) + dt) * 64];
+    };
+    // ---- prologue: slab reduce -> bf16.  The first 8 slabs of this thread's (up to 2) elements are requested first, then the
+    // KV prefetch, then the values are consumed (loads retire in order, so the consumer only waits for the slab loads).
     const int n_pro = p.cross ? G : G + 2;          // cross attention: queries only (K/V cached once per utterance)
-    for (int idx = tid; idx < n_pro * D; idx += 512) {
+    const int n_el = n_pro * D;
+    float pv[NIT][8];                                // NIT * 512 >= (G + 2) * D
+    int pcol[NIT];
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+        const int idx = tid + it * 512;
         int hh = idx / D, d = idx - hh * D;
         int col;
         if (hh < G) col = (kvh * G + hh) * D + d;
         else if (hh == G) col = p.H * D + kvh * D + d;
         else col = p.H * D + p.Hkv * D + kvh * D + d;
-        float acc = 0.0f;
-        for (int s0 = 0; s0 < p.S; s0 += 8) {        // up to 8 independent loads in flight, summed in slab order
-            float v[8];
+        pcol[it] = col;
 #pragma unroll
-            for (int j = 0; j < 8; ++j)
-                v[j] = (s0 + j < p.S) ? p.qkv_part[((size_t)(s0 + j) * p.Mpad + b) * p.Nqkv + col] : 0.0f;
+        for (int j = 0; j < 8; ++j)
+            pv[it][j] = (idx < n_el && j < p.S) ? p.qkv_part[((size_t)j * p.Mpad + b) * p.Nqkv + col] : 0.0f;
+    }
+    // RoPE table entries and q/k-norm weights this thread will need: also requested before the KV prefetch (a load issued after
+    // it could only be consumed once the whole prefetch has landed - loads retire in order).  Null tables read a dummy address.
+    const int n_rot_el = (p.cross ? G : G + 1) * (D / 2);
+    float rc[NIT], rs[NIT];
+    {
+        const float* ct = p.rope_cos ? p.rope_cos + (size_t)pos * (D / 2) : p.qkv_part;
+        const float* st = p.rope_cos ? p.rope_sin + (size_t)pos * (D / 2) : p.qkv_part;
 #pragma unroll
-            for (int j = 0; j < 8; ++j) acc += v[j];
+        for (int it = 0; it < NIT; ++it) {
+            const int idx = tid + it * 512;
+            const int i = idx % (D / 2);
+            rc[it] = (idx < n_rot_el) ? ct[p.rope_cos ? i : 0] : 1.0f;
+            rs[it] = (idx < n_rot_el) ? st[p.rope_cos ? i : 0] : 0.0f;
         }
-        sraw[idx] = bf16_round_f32(acc);
+    }
+    float qw[D / 64], kw[D / 64];
+    {
+        const bf16_t* qp = p.qnorm_w ? p.qnorm_w : reinterpret_cast<const bf16_t*>(p.qkv_part);
+        const bf16_t* kp = p.qnorm_w ? p.knorm_w : reinterpret_cast<const bf16_t*>(p.qkv_part);
+#pragma unroll
+        for (int j = 0; j < D / 64; ++j) { qw[j] = bf16_to_f32(qp[p.qnorm_w ? lane + 64 * j : 0]); kw[j] = bf16_to_f32(kp[p.qnorm_w ? lane + 64 * j : 0]); }
+    }
+    const bool preA = wave < n_tiles && wave != new_tile;
+    const bool preB = wave + ATT_WAVES < n_tiles && wave + ATT_WAVES != new_tile;
+    // unconditional (straight-line code keeps the s_waitcnt bookkeeping exact: a conditional prefetch makes the compiler wait
+    // for vmcnt(0) at the join); a wave without an old tile re-reads a clamped one and discards it
+    load_tile(min(wave, n_tiles - 1), kA, vA);
+    load_tile(min(wave + ATT_WAVES, n_tiles - 1), kB, vB);
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+        const int idx = tid + it * 512;
+        if (idx < n_el) {
+            float acc = 0.0f;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc += pv[it][j];                // slab order 0..7 (S <= 8, checked by the launcher)
+            sraw[idx] = bf16_round_f32(acc);
+        }
     }
     for (int idx = tid; idx < 16 * D; idx += 512) qs[idx] = 0;
     __syncthreads();
@@ -584,25 +641,27 @@ __global__ void __launch_bounds__(512) k_attn_decode(AttnParams p) {
             for (int d = lane; d < D; d += 64) { float v = sraw[row * D + d]; ss += v * v; }
             ss = wave_sum(ss);
             const float inv = 1.0f / sqrtf(ss / (float)D + p.qk_eps);
-            const bf16_t* w = (row < G) ? p.qnorm_w : p.knorm_w;
-            for (int d = lane; d < D; d += 64)
-                sraw[row * D + d] = bf16_round_f32(bf16_to_f32(w[d]) * bf16_round_f32(sraw[row * D + d] * inv));
+#pragma unroll
+            for (int j = 0; j < D / 64; ++j) {
+                const int d = lane + 64 * j;
+                sraw[row * D + d] = bf16_round_f32((row < G ? qw[j] : kw[j]) * bf16_round_f32(sraw[row * D + d] * inv));
+            }
         }
         __syncthreads();
     }
     // ---- RoPE (rotate-half, pair (i, i + D/2), angle pos / freqs[i]; LlamaTTS.swift:192-200) + cache append
-    bf16_t* kc = p.kcache + ((size_t)(b * p.Hkv + kvh) * p.Smax) * D;
-    bf16_t* vt = p.vtcache + ((size_t)(b * p.Hkv + kvh) * D) * p.Smax;
     // tiled cache addressing of the new key `pos` (see header): 32-key tile, A-fragment row i, half hf
     const int ptile = pos >> 5, pr = pos & 31;
     const int prow = ((pr >> 3) << 2) | (pr & 3), phalf = (pr >> 2) & 1;
-    const int n_rot = p.cross ? G : G + 1;
-    for (int idx = tid; idx < n_rot * (D / 2); idx += 512) {
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+        const int idx = tid + it * 512;
+        if (idx >= n_rot_el) continue;
         int hh = idx / (D / 2), i = idx - hh * (D / 2);
         float x1 = sraw[hh * D + i], x2 = sraw[hh * D + i + D / 2];
         bf16_t r1, r2;
         if (p.rope_cos) {
-            float c = p.rope_cos[(size_t)pos * (D / 2) + i], s = p.rope_sin[(size_t)pos * (D / 2) + i];
+            float c = rc[it], s = rs[it];
             if (p.rope_in_dtype) {
                 c = bf16_round_f32(c); s = bf16_round_f32(s);
                 r1 = f32_to_bf16(bf16_round_f32(x1 * c) + bf16_round_f32(-x2 * s));
@@ -631,13 +690,10 @@ __global__ void __launch_bounds__(512) k_attn_decode(AttnParams p) {
 #pragma unroll
     for (int dt = 0; dt < D / 16; ++dt) O[dt] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
     float m_run = -INFINITY, l_run = 0.0f;
-    const int n_tiles = (kv_len + 31) >> 5;
     // MFMA row i <-> key base + (i>>2)*8 + (i&3) (+4 for the second half): baked into the cache tiling.
     // Each wave owns tiles (wave + 8j); they are processed in PAIRS with all K and V fragments of both tiles
     // (32 KiB per wave) requested before the first MFMA, so a typical context (<= 512 keys) costs one memory
     // round trip per wave instead of four dependent ones.
-    const bf16x8_t* kbase = reinterpret_cast<const bf16x8_t*>(kc) + lane;
-    const bf16x8_t* vbase = reinterpret_cast<const bf16x8_t*>(vt) + lane;
     auto process = [&](int tile, const bf16x8_t (&ka)[2][D / 32], const bf16x8_t (&vb)[D / 16]) {
         const int base = tile * 32;
         f32x4_t S0 = (f32x4_t){0.f, 0.f, 0.f, 0.f}, S1 = S0;
@@ -689,22 +745,9 @@ __global__ void __launch_bounds__(512) k_attn_decode(AttnParams p) {
     for (int tile = wave; tile < n_tiles; tile += 2 * ATT_WAVES) {
         const int tile2 = tile + ATT_WAVES;
         const bool has2 = tile2 < n_tiles;
-        const int t2 = has2 ? tile2 : tile;                    // clamp: redundant reload, result unused
-        bf16x8_t kA[2][D / 32], kB[2][D / 32], vA[D / 16], vB[D / 16];
-#pragma unroll
-        for (int c = 0; c < D / 32; ++c) {
-            kA[0][c] = kbase[((size_t)tile * 2) * (D / 32) * 64 + c * 64];
-            kA[1][c] = kbase[((size_t)tile * 2 + 1) * (D / 32) * 64 + c * 64];
-        }
-#pragma unroll
-        for (int c = 0; c < D / 32; ++c) {
-            kB[0][c] = kbase[((size_t)t2 * 2) * (D / 32) * 64 + c * 64];
-            kB[1][c] = kbase[((size_t)t2 * 2 + 1) * (D / 32) * 64 + c * 64];
-        }
-#pragma unroll
-        for (int dt = 0; dt < D / 16; ++dt) vA[dt] = vbase[((size_t)tile * (D / 16) + dt) * 64];
-#pragma unroll
-        for (int dt = 0; dt < D / 16; ++dt) vB[dt] = vbase[((size_t)t2 * (D / 16) + dt) * 64];
+        const bool first = tile == wave;
+        if (!(first && preA)) load_tile(tile, kA, vA);                  // the tile with the new key (or a later pair)
+        if (has2 && !(first && preB)) load_tile(tile2, kB, vB);
         process(tile, kA, vA);
         if (has2) process(tile2, kB, vB);
     }
@@ -747,8 +790,12 @@ void launch_attn_decode(const AttnParams& p, int batch, hipStream_t s) {
     MIS_REQUIRE(G >= 1 && G <= 16 && p.H % p.Hkv == 0, MIS_ERR_INVALID_INPUT, "GQA group size must be 1..16");
     size_t smem = attn_smem_bytes(G, p.D);
     MIS_REQUIRE(smem <= 64 * 1024, MIS_ERR_INVALID_INPUT, "attention LDS footprint too large");
+    MIS_REQUIRE(p.S >= 1 && p.S <= 8, MIS_ERR_GENERATION_FAILED, "attention prologue reduces at most 8 split-K slabs (got %d)", p.S);
     dim3 grid(p.Hkv, batch), block(512);
-    if (p.D == 128) hipLaunchKernelGGL((k_attn_decode<128>), grid, block, smem, s, p);
-    else if (p.D == 64) hipLaunchKernelGGL((k_attn_decode<64>), grid, block, smem, s, p);
+    const int n_el = (G + 2) * p.D;
+    if (p.D == 128 && n_el <= 1024) hipLaunchKernelGGL((k_attn_decode<128, 2>), grid, block, smem, s, p);
+    else if (p.D == 128) hipLaunchKernelGGL((k_attn_decode<128, 5>), grid, block, smem, s, p);
+    else if (p.D == 64 && n_el <= 1024) hipLaunchKernelGGL((k_attn_decode<64, 2>), grid, block, smem, s, p);
+    else if (p.D == 64) hipLaunchKernelGGL((k_attn_decode<64, 3>), grid, block, smem, s, p);
     else throw MisError(MIS_ERR_INVALID_INPUT, "head_dim must be 64 or 128");
 }
