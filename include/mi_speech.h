@@ -60,6 +60,9 @@ mis_status mis_orpheus_deinterleave(int device, const int32_t* codes7, int batch
  * the last start-of-speech (128257), drop end-of-speech (128258), trim to a multiple of 7, subtract
  * 128266.  ids: [batch, stride] with lens[batch] valid entries per row; codes_out: [batch, stride];
  * n_codes_out: [batch]. */
+mis_status mis_speech_parse_output(int device, const int32_t* ids, const int32_t* lens, int batch, int stride, int32_t* codes_out,
+                                   int32_t* n_codes_out, int start_of_speech, int end_of_speech, int audio_token_offset,
+                                   int start_of_ai);     /* explicit ids (VyvoTTS); start_of_ai < 0: no fallback */
 mis_status mis_orpheus_parse_output(int device, const int32_t* ids, const int32_t* lens, int batch,
                                     int stride, int32_t* codes_out, int32_t* n_codes_out);
 
@@ -149,6 +152,10 @@ typedef struct {
     /* Qwen3-TTS talker / code predictor write the rotation as array ops in the model dtype (cos/sin cast to bf16,
      * T(T(x*cos) + T(rotate_half(x)*sin)), Qwen3TTSTalker.swift:15-24,92-95) instead of MLXFast.RoPE */
     int32_t rope_ops_in_dtype;
+    /* speech token ids of the generate loop (0 = Orpheus: 128257 / 128258 / 128266, LlamaTTS.swift:20-30).  VyvoTTS
+     * (Qwen3.swift:19-29): start_of_speech 151670, end_of_speech 151671, audio_token_offset 151679, start_of_ai 151674
+     * (parse fallback, :332-358; 0 = none) */
+    int32_t start_of_speech_id, end_of_speech_id, audio_token_offset, start_of_ai_id;
 } mis_lm_config;
 
 /* GenerateParameters as used by LlamaTTS.swift:573-581,691-696 (mlx-swift-lm) */

@@ -28,7 +28,9 @@ class LmConfigC(C.Structure):
                 ("vocab_size", C.c_int32), ("rms_norm_eps", C.c_float), ("rope_theta", C.c_float),
                 ("rope_factor", C.c_float), ("rope_low_freq_factor", C.c_float), ("rope_high_freq_factor", C.c_float),
                 ("rope_original_max_pos", C.c_float), ("tie_word_embeddings", C.c_int32), ("sample_rate", C.c_int32),
-                ("qk_norm", C.c_int32), ("rope_plain", C.c_int32), ("rope_ops_in_dtype", C.c_int32)]
+                ("qk_norm", C.c_int32), ("rope_plain", C.c_int32), ("rope_ops_in_dtype", C.c_int32),
+                ("start_of_speech_id", C.c_int32), ("end_of_speech_id", C.c_int32), ("audio_token_offset", C.c_int32),
+                ("start_of_ai_id", C.c_int32)]
 
 
 class GenParamsC(C.Structure):
@@ -119,6 +121,7 @@ SYMBOLS = {
     "mis_free": (None, [_P]),
     "mis_device_count": (C.c_int, []),
     "mis_orpheus_deinterleave": (C.c_int, [C.c_int, _P, C.c_int, C.c_int, _P, _P, _P]),
+    "mis_speech_parse_output": (C.c_int, [C.c_int, _P, _P, C.c_int, C.c_int, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int]),
     "mis_orpheus_parse_output": (C.c_int, [C.c_int, _P, _P, C.c_int, C.c_int, _P, _P]),
     "mis_snac_load": (C.c_int, [C.c_char_p, C.c_int, C.POINTER(_P)]),
     "mis_snac_create": (C.c_int, [C.POINTER(SnacConfigC), C.c_int, C.POINTER(_P)]),

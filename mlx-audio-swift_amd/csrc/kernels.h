@@ -7,8 +7,9 @@ void launch_orpheus_deinterleave(const int32_t* codes7, int in_stride, int batch
                                  int32_t* l1, int32_t* l2, int out_groups, hipStream_t s);
 void launch_orpheus_deinterleave_ragged(const int32_t* codes7, int in_stride, const int32_t* n_codes, int batch,
                                         int32_t* l0, int32_t* l1, int32_t* l2, int out_groups, hipStream_t s);
+struct SpeechTokenIds { int start_of_speech, end_of_speech, audio_offset, start_of_ai; };   // nullptr = Orpheus (LlamaTTS.swift:20-30)
 void launch_orpheus_parse_output(const int32_t* ids, const int32_t* lens, int batch, int stride, int32_t* codes_out,
-                                 int32_t* n_codes_out, hipStream_t s);
+                                 int32_t* n_codes_out, hipStream_t s, const SpeechTokenIds* tk = nullptr);
 
 // snac.hip : device-pointer decode used by the TTS engine (codes already on device, ragged rows padded)
 struct mis_snac;

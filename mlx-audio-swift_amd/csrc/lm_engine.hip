@@ -705,7 +705,9 @@ static void run_generate(mis_tts* c, const int32_t* prompt_ids, const int32_t* p
     sp.next_ids = c->ids.p; sp.active = c->active.p; sp.done_count = c->done_count.p;
     sp.temperature = gp->temperature; sp.top_p = gp->top_p; sp.penalty = gp->repetition_penalty;
     sp.seed = gp->seed; sp.row_offset = gp->row_offset; sp.frame_constrained = gp->frame_constrained;
-    sp.lo = 0; sp.hi = 0; sp.eos_id = hidden_mode ? hm->stop_id : ORPHEUS_END_OF_SPEECH; sp.max_tokens = max_tokens;
+    sp.lo = 0; sp.hi = 0; sp.max_tokens = max_tokens;
+    sp.eos_id = hidden_mode ? hm->stop_id : (c->cfg.end_of_speech_id > 0 ? c->cfg.end_of_speech_id : ORPHEUS_END_OF_SPEECH);
+    sp.audio_offset = c->cfg.audio_token_offset;
     if (gp->sampler_flavor == 1) {
         c->samp_l32.alloc((size_t)c->Mpad * c->Vpad);
         sp.penalty_flavor = 1; sp.top_p = 1.0f; sp.logits32 = c->samp_l32.p;
@@ -841,7 +843,11 @@ static void run_generate(mis_tts* c, const int32_t* prompt_ids, const int32_t* p
     }
     // ---- parseOutput (:749-752) + de-interleave (:41-64) + SNAC decode (:759)
     c->codes.alloc((size_t)batch * all_stride); c->n_codes.alloc(batch);
-    launch_orpheus_parse_output(c->all_ids.p, c->all_len.p, batch, all_stride, c->codes.p, c->n_codes.p, s);
+    {
+        SpeechTokenIds tk{c->cfg.start_of_speech_id, c->cfg.end_of_speech_id, c->cfg.audio_token_offset, c->cfg.start_of_ai_id > 0 ? c->cfg.start_of_ai_id : -1};
+        launch_orpheus_parse_output(c->all_ids.p, c->all_len.p, batch, all_stride, c->codes.p, c->n_codes.p, s,
+                                    c->cfg.start_of_speech_id > 0 ? &tk : nullptr);
+    }
     std::vector<int32_t> ncodes(batch);
     out.n_tokens.resize(batch);
     HIP_CHECK(hipMemcpyAsync(ncodes.data(), c->n_codes.p, batch * 4, hipMemcpyDeviceToHost, s));
@@ -1112,7 +1118,10 @@ extern "C" mis_status mis_tts_load(const char* model_dir, mis_snac* codec, int d
         cf.sample_rate = (int)j.number_or("sample_rate", 24000);
         {   // Qwen3-style checkpoints (VyvoTTS): model_type "qwen3" => q/k norm + plain rope
             const JsonValue* mt = j.get("model_type");
-            if (mt && mt->type == JsonValue::STR && mt->str.find("qwen3") != std::string::npos) { cf.qk_norm = 1; cf.rope_plain = 1; }
+            if (mt && mt->type == JsonValue::STR && mt->str.find("qwen3") != std::string::npos) {
+                cf.qk_norm = 1; cf.rope_plain = 1;
+                cf.start_of_speech_id = 151670; cf.end_of_speech_id = 151671; cf.audio_token_offset = 151679; cf.start_of_ai_id = 151674;   // Qwen3.swift:19-29
+            }
         }
         mis_status st = mis_tts_create(&cf, codec, device, &c);
         if (st != MIS_OK) return st;

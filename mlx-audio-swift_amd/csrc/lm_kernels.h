@@ -91,6 +91,7 @@ struct SamplerParams {
     uint64_t seed;
     int64_t row_offset;
     int frame_constrained;
+    int audio_offset;        // first audio token id (frame-constrained range): 0 = Orpheus 128266
     int lo, hi;              // allowed id range when not frame constrained (hi <= 0 -> vocab)
     int eos_id;
     int max_tokens;

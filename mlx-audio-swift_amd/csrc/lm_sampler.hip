@@ -51,7 +51,7 @@ __device__ __forceinline__ void allowed_range(const SamplerParams& p, int step, 
     lo = p.lo;
     hi = (p.hi <= 0 || p.hi > V) ? V : p.hi;
     if (p.frame_constrained) {
-        lo = ORPHEUS_AUDIO_OFFSET + (step % 7) * 4096;
+        lo = (p.audio_offset > 0 ? p.audio_offset : ORPHEUS_AUDIO_OFFSET) + (step % 7) * 4096;
         hi = lo + 4096;
         if (hi > V) hi = V;
         if (lo > hi) lo = hi;

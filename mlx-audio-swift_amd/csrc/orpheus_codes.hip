@@ -67,11 +67,16 @@ __global__ void k_orpheus_deinterleave_ragged(const int32_t* __restrict__ codes7
 
 // One 256-thread block per row.  parseOutput (LlamaTTS.swift:383-434) per row:
 //   last = last index of 128257 (or -1) ; keep ids[last+1:] != 128258 ; trim to 7k ; -128266.
+// Token ids are parameters: Orpheus (128257 / 128258 / 128266, LlamaTTS.swift:20-30) or VyvoTTS (151670 / 151671 / 151679 and the
+// START_OF_AI fallback of Qwen3.swift:332-358: without a start-of-speech token, cropping starts at the first audio token after
+// the last START_OF_AI).
 __global__ void __launch_bounds__(256) k_orpheus_parse_output(const int32_t* __restrict__ ids,
                                                               const int32_t* __restrict__ lens, int stride,
                                                               int32_t* __restrict__ codes_out,
-                                                              int32_t* __restrict__ n_codes_out) {
+                                                              int32_t* __restrict__ n_codes_out, int sos_id, int eos_id,
+                                                              int audio_offset, int soa_id) {
     __shared__ int s_last;
+    __shared__ int s_soa, s_first;
     __shared__ int s_scan[256];
     __shared__ int s_base;
     int b = blockIdx.x, tid = threadIdx.x;
@@ -79,19 +84,31 @@ __global__ void __launch_bounds__(256) k_orpheus_parse_output(const int32_t* __r
     int32_t* out = codes_out + (size_t)b * stride;
     int len = lens[b];
     if (len > stride) len = stride;
-    if (tid == 0) { s_last = -1; s_base = 0; }
+    if (tid == 0) { s_last = -1; s_base = 0; s_soa = -1; s_first = 0x7fffffff; }
     __syncthreads();
-    int my_last = -1;
-    for (int j = tid; j < len; j += 256)
-        if (row[j] == ORPHEUS_START_OF_SPEECH) my_last = j;
+    int my_last = -1, my_soa = -1;
+    for (int j = tid; j < len; j += 256) {
+        if (row[j] == sos_id) my_last = j;
+        if (soa_id >= 0 && row[j] == soa_id) my_soa = j;
+    }
     if (my_last >= 0) atomicMax(&s_last, my_last);
+    if (my_soa >= 0) atomicMax(&s_soa, my_soa);
     __syncthreads();
+    if (s_last < 0 && s_soa >= 0) {                      // fallback: first audio token after the last START_OF_AI
+        int my_first = 0x7fffffff;
+        for (int j = s_soa + 1 + tid; j < len; j += 256)
+            if (row[j] >= audio_offset) { my_first = j; break; }
+        if (my_first != 0x7fffffff) atomicMin(&s_first, my_first);
+        __syncthreads();
+        if (tid == 0 && s_first != 0x7fffffff) s_last = s_first - 1;
+        __syncthreads();
+    }
     int start = s_last + 1;
     // ordered stream compaction, 256 elements per round
     for (int base = start; base < len; base += 256) {
         int j = base + tid;
-        int v = (j < len) ? row[j] : ORPHEUS_END_OF_SPEECH;
-        int keep = (j < len && v != ORPHEUS_END_OF_SPEECH) ? 1 : 0;
+        int v = (j < len) ? row[j] : eos_id;
+        int keep = (j < len && v != eos_id) ? 1 : 0;
         s_scan[tid] = keep;
         __syncthreads();
         for (int o = 1; o < 256; o <<= 1) {   // Hillis-Steele inclusive scan
@@ -101,7 +118,7 @@ __global__ void __launch_bounds__(256) k_orpheus_parse_output(const int32_t* __r
             __syncthreads();
         }
         int pos = s_base + s_scan[tid] - keep;
-        if (keep) out[pos] = v - ORPHEUS_AUDIO_OFFSET;
+        if (keep) out[pos] = v - audio_offset;
         __syncthreads();
         if (tid == 255) s_base += s_scan[255];
         __syncthreads();
@@ -123,9 +140,11 @@ void launch_orpheus_deinterleave_ragged(const int32_t* codes7, int in_stride, co
                        out_groups);
 }
 void launch_orpheus_parse_output(const int32_t* ids, const int32_t* lens, int batch, int stride, int32_t* codes_out,
-                                 int32_t* n_codes_out, hipStream_t s) {
+                                 int32_t* n_codes_out, hipStream_t s, const SpeechTokenIds* tk) {
     if (batch <= 0) return;
-    hipLaunchKernelGGL(k_orpheus_parse_output, dim3(batch), dim3(256), 0, s, ids, lens, stride, codes_out, n_codes_out);
+    SpeechTokenIds t = tk ? *tk : SpeechTokenIds{ORPHEUS_START_OF_SPEECH, ORPHEUS_END_OF_SPEECH, ORPHEUS_AUDIO_OFFSET, -1};
+    hipLaunchKernelGGL(k_orpheus_parse_output, dim3(batch), dim3(256), 0, s, ids, lens, stride, codes_out, n_codes_out, t.start_of_speech,
+                       t.end_of_speech, t.audio_offset, t.start_of_ai);
 }
 
 // ---------------------------------------------------------------------------- C ABI
@@ -148,8 +167,21 @@ extern "C" mis_status mis_orpheus_deinterleave(int device, const int32_t* codes7
     MIS_API_END
 }
 
+static mis_status parse_output_host(int device, const int32_t* ids, const int32_t* lens, int batch, int stride, int32_t* codes_out,
+                                    int32_t* n_codes_out, const SpeechTokenIds* tk);
 extern "C" mis_status mis_orpheus_parse_output(int device, const int32_t* ids, const int32_t* lens, int batch,
                                                int stride, int32_t* codes_out, int32_t* n_codes_out) {
+    return parse_output_host(device, ids, lens, batch, stride, codes_out, n_codes_out, nullptr);
+}
+// same with explicit token ids (VyvoTTS: Qwen3.swift:19-29,332-358); start_of_ai < 0 disables the fallback
+extern "C" mis_status mis_speech_parse_output(int device, const int32_t* ids, const int32_t* lens, int batch, int stride,
+                                              int32_t* codes_out, int32_t* n_codes_out, int start_of_speech, int end_of_speech,
+                                              int audio_token_offset, int start_of_ai) {
+    SpeechTokenIds t{start_of_speech, end_of_speech, audio_token_offset, start_of_ai};
+    return parse_output_host(device, ids, lens, batch, stride, codes_out, n_codes_out, &t);
+}
+static mis_status parse_output_host(int device, const int32_t* ids, const int32_t* lens, int batch, int stride, int32_t* codes_out,
+                                    int32_t* n_codes_out, const SpeechTokenIds* tk) {
     MIS_API_BEGIN
     MIS_REQUIRE(batch >= 0 && stride >= 0, MIS_ERR_INVALID_INPUT, "negative batch/stride");
     if (batch == 0) return MIS_OK;
@@ -161,7 +193,7 @@ extern "C" mis_status mis_orpheus_parse_output(int device, const int32_t* ids, c
     if (stride) HIP_CHECK(hipMemcpy(din.p, ids, (size_t)batch * stride * sizeof(int32_t), hipMemcpyDefault));
     HIP_CHECK(hipMemcpy(dl.p, lens, batch * sizeof(int32_t), hipMemcpyDefault));
     HIP_CHECK(hipMemset(dout.p, 0, n * sizeof(int32_t)));
-    launch_orpheus_parse_output(din.p, dl.p, batch, stride, dout.p, dn.p, 0);
+    launch_orpheus_parse_output(din.p, dl.p, batch, stride, dout.p, dn.p, 0, tk);
     HIP_CHECK(hipGetLastError());
     if (stride) HIP_CHECK(hipMemcpy(codes_out, dout.p, (size_t)batch * stride * sizeof(int32_t), hipMemcpyDefault));
     HIP_CHECK(hipMemcpy(n_codes_out, dn.p, batch * sizeof(int32_t), hipMemcpyDefault));

@@ -30,6 +30,21 @@ class OrpheusTokens:
     audio_token_offset = 128266
 
 
+class VyvoTokens:
+    """VyvoTTS (Qwen3 + SNAC) token ids, Sources/MLXAudioTTS/Models/Qwen3/Qwen3.swift:19-29"""
+    tokenizer_length = 151669
+    start_of_text = 151643
+    end_of_text = 151645
+    start_of_speech = 151670
+    end_of_speech = 151671
+    start_of_human = 151672
+    end_of_human = 151673
+    start_of_ai = 151674
+    end_of_ai = 151675
+    pad_token = 151676
+    audio_token_offset = 151679
+
+
 @dataclass
 class LlamaTTSConfiguration:
     """LlamaTTSConfig.swift:15-61 (CodingKeys = HF config.json names)."""
@@ -52,6 +67,11 @@ class LlamaTTSConfiguration:
     qk_norm: bool = False          # Qwen3-style LMs (Soprano, VyvoTTS): per-head q/k RMSNorm ...
     rope_plain: bool = False       # ... and RoPE(base) without the llama3 rescale
     rope_ops_in_dtype: bool = False  # Qwen3-TTS: rotation as bf16 array ops (Qwen3TTSTalker.swift:15-24)
+    # speech token ids of the generate loop; 0 = Orpheus (OrpheusTokens).  VyvoTTS: VyvoTokens
+    start_of_speech_id: int = 0
+    end_of_speech_id: int = 0
+    audio_token_offset: int = 0
+    start_of_ai_id: int = 0
 
     @classmethod
     def from_dict(cls, d: dict) -> "LlamaTTSConfiguration":
@@ -75,7 +95,8 @@ class LlamaTTSConfiguration:
                               float(rs.get("high_freq_factor", 4.0)),
                               float(rs.get("original_max_position_embeddings", 8192.0)),
                               1 if self.tie_word_embeddings else 0, self.sample_rate,
-                              1 if self.qk_norm else 0, 1 if self.rope_plain else 0, 1 if self.rope_ops_in_dtype else 0)
+                              1 if self.qk_norm else 0, 1 if self.rope_plain else 0, 1 if self.rope_ops_in_dtype else 0,
+                              self.start_of_speech_id, self.end_of_speech_id, self.audio_token_offset, self.start_of_ai_id)
 
 
 class LlamaTTSModel:

@@ -81,3 +81,26 @@ def left_pad_batch(rows):
     for i, r in enumerate(rows):
         ids[i, m - len(r):] = r
     return ids, ids != PAD_TOKEN
+
+
+# ---- VyvoTTS (Qwen3 LM + SNAC), Sources/MLXAudioTTS/Models/Qwen3/Qwen3.swift:19-29
+VYVO_START_OF_SPEECH, VYVO_END_OF_SPEECH, VYVO_START_OF_AI, VYVO_AUDIO_OFFSET = 151670, 151671, 151674, 151679
+
+
+def parse_output_row_vyvo(tokens):
+    """Qwen3Model.parseOutputRow (Qwen3.swift:332-358): crop after the last START_OF_SPEECH, else after the token before the
+    first audio token that follows the last START_OF_AI, else nothing cropped; drop END_OF_SPEECH; trim to 7k; subtract."""
+    t = [int(x) for x in tokens]
+    start = None
+    if VYVO_START_OF_SPEECH in t:
+        start = len(t) - 1 - t[::-1].index(VYVO_START_OF_SPEECH)
+    elif VYVO_START_OF_AI in t:
+        soa = len(t) - 1 - t[::-1].index(VYVO_START_OF_AI)
+        for j in range(soa + 1, len(t)):
+            if t[j] >= VYVO_AUDIO_OFFSET:
+                start = j - 1
+                break
+    sl = t[start + 1:] if start is not None else t
+    f = [x for x in sl if x != VYVO_END_OF_SPEECH]
+    n = (len(f) // 7) * 7
+    return np.asarray([x - VYVO_AUDIO_OFFSET for x in f[:n]], np.int32)

@@ -54,3 +54,33 @@ def test_parse_output_edge_cases_and_long_rows():
     got = mas.parse_output(ids, [len(c) for c in cases])
     for i, c in enumerate(cases):
         assert np.array_equal(got[i], oc.parse_output_row(c)), i
+
+
+def test_vyvotts_parse_output_with_start_of_ai_fallback():
+    # Qwen3.swift:332-358 through mis_speech_parse_output (explicit token ids)
+    import ctypes as C
+    from mlx_audio_swift_amd import _lib
+    from mlx_audio_swift_amd.generation import check
+    from oracle import orpheus_codes as oc
+    rng = np.random.default_rng(11)
+    A, SOS, EOS, SOA = oc.VYVO_AUDIO_OFFSET, oc.VYVO_START_OF_SPEECH, oc.VYVO_END_OF_SPEECH, oc.VYVO_START_OF_AI
+    audio = lambda n: list(A + rng.integers(0, 7 * 4096, n))
+    rows = [
+        [5, 6, SOS] + audio(15) + [EOS],                                   # normal
+        [5, SOS, 9, SOS] + audio(9) + [EOS, A + 3],                        # last start-of-speech wins; EOS dropped mid-stream
+        [5, SOA, 7, 8] + audio(16),                                        # fallback: crop at the first audio token after START_OF_AI
+        [5, 6, 7] + audio(3),                                              # nothing to crop, fewer than 7 -> empty
+        [SOA, 3, 4],                                                       # START_OF_AI but no audio token -> whole row, trimmed to 0
+        [],
+    ]
+    stride = max(len(r) for r in rows)
+    ids = np.zeros((len(rows), stride), np.int32)
+    lens = np.asarray([len(r) for r in rows], np.int32)
+    for i, r in enumerate(rows):
+        ids[i, :len(r)] = r
+    out = np.zeros_like(ids); n = np.zeros(len(rows), np.int32)
+    check(_lib.lib().mis_speech_parse_output(0, ids.ctypes.data, lens.ctypes.data, len(rows), stride, out.ctypes.data, n.ctypes.data,
+                                             SOS, EOS, A, SOA))
+    for i, r in enumerate(rows):
+        ref = oc.parse_output_row_vyvo(r)
+        assert n[i] == len(ref) and np.array_equal(out[i, :n[i]], ref), i

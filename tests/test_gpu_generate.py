@@ -130,3 +130,26 @@ def test_eos_ragged_rows_errors_and_cancel(stack):
     with pytest.raises(mas.AudioGenerationError) as e:
         no_codec.generate_batch([np.asarray([1, 2], np.int32)], gp)
     assert e.value.case == "modelNotInitialized"                # "SNAC model not loaded", LlamaTTS.swift:672-674
+
+
+def test_vyvotts_token_ids_drive_the_same_loop():
+    # VyvoTTS = Qwen3-style LM + SNAC with its own token ids (Qwen3.swift:19-29): EOS, frame-constrained range and parse use them
+    ocfg_s, osn, dsn = snac_pair(SNAC_SMALL)
+    V = mas.VyvoTokens
+    lcfg = ollama.LlamaConfig(hidden_size=256, num_hidden_layers=1, intermediate_size=512, num_attention_heads=2, num_key_value_heads=1,
+                              head_dim=128, vocab_size=V.audio_token_offset + 7 * 4096, rope_theta=1e6, rope_scaling=None,
+                              tie_word_embeddings=True, qk_norm=True, rope_plain=True, rms_norm_eps=1e-6)
+    from gpu_util import lm_host_config
+    hc = lm_host_config(lcfg)
+    hc.start_of_speech_id, hc.end_of_speech_id, hc.audio_token_offset, hc.start_of_ai_id = (V.start_of_speech, V.end_of_speech,
+                                                                                           V.audio_token_offset, V.start_of_ai)
+    lm = mas.LlamaTTSModel.synthetic(hc, codec=dsn, seed=99)
+    prompt = np.asarray([V.start_of_human, 11, 12, V.end_of_text, V.end_of_human, V.start_of_ai, V.start_of_speech], np.int32)
+    gp = mas.GenerateParameters(max_tokens=14, temperature=0.0, repetition_penalty=0.0, frame_constrained=True)
+    zeros = [np.zeros((1, n), np.float32) for n in dsn.noise_lengths(2)]
+    pcm, toks = lm.generate_batch([prompt], gp, snac_noise=zeros, return_tokens=True)
+    slots = (toks[0] - V.audio_token_offset) // 4096
+    assert len(toks[0]) == 14 and np.array_equal(slots, np.arange(14) % 7) and len(pcm[0]) == 2 * 2048
+    l0, l1, l2 = oc.deinterleave(oc.parse_output_row_vyvo(list(prompt) + list(toks[0])))
+    ref = osn.decode([l0[None], l1[None], l2[None]], None)[0, 0]
+    assert rms(pcm[0], ref) < 1e-4
