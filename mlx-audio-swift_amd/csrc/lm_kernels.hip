@@ -460,7 +460,7 @@ __device__ void glue_row_256(const GlueFuse& g, int m, float* rowbuf, float* red
     __syncthreads();                                  // rowbuf is reused by the next row of this block
 }
 
-template <int MT, int R, int EPI, int KSB>
+template <int MT, int R, int EPI, int KSB, bool FUSED>
 __global__ void __launch_bounds__(256) k_gemm_skinny(const bf16_t* __restrict__ Wp, const bf16_t* __restrict__ X,
                                                      void* __restrict__ out, int NT, int KT, int S, int n_items,
                                                      int N_out, int Mpad, int dbg_xfixed,
@@ -469,8 +469,8 @@ __global__ void __launch_bounds__(256) k_gemm_skinny(const bf16_t* __restrict__ 
     extern __shared__ __attribute__((aligned(16))) float glue_lds[];       // [N + 8] only when a producer is fused
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     // fused producer: the first glue.rows blocks are pure producers (one row each) and leave after signalling
-    const int pblocks = glue.flag ? glue.rows : 0;
-    if ((int)blockIdx.x < pblocks) {
+    const int pblocks = FUSED ? glue.rows : 0;       // (FUSED = false compiles the producer, the wait and the idle waves out)
+    if (FUSED && (int)blockIdx.x < pblocks) {
         glue_row_256(glue, blockIdx.x, glue_lds, glue_lds + glue.N);     // ends with vmcnt(0) + barrier: x is in memory
         if (threadIdx.x == 0) __hip_atomic_fetch_add(glue.flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         return;
@@ -478,7 +478,7 @@ __global__ void __launch_bounds__(256) k_gemm_skinny(const bf16_t* __restrict__ 
     const int gblock = blockIdx.x - pblocks;
     int item = (KSB == 1) ? gblock * 4 + wave : gblock;
     const bool idle = item >= n_items;                // (KSB == 1: a wave of the last block may have no item)
-    if (idle && !glue.flag) return;
+    if (idle && !FUSED) return;
     if (idle) item = n_items - 1;                     // keeps the address arithmetic valid; the epilogue is skipped
     const int ntg = item / S, ks = item - ntg * S;
     int kt0 = (int)(((long long)KT * ks) / S), kt1 = (int)(((long long)KT * (ks + 1)) / S);
@@ -532,7 +532,7 @@ __global__ void __launch_bounds__(256) k_gemm_skinny(const bf16_t* __restrict__ 
     }
     const bool has_k = kt0 < kt1;
     if (has_k) { GEMM_LOAD_W(wA, kt0) }               // weights do not depend on the producer: in flight while it runs
-    if (glue.flag) {                                  // wait for the fused producer's rows (acquire)
+    if (FUSED) {                                      // wait for the fused producer's rows (acquire)
         if (threadIdx.x < 64) {
             if (threadIdx.x == 0) {
                 // hundreds of blocks wait on ONE word: poll sparsely (a hot address serialises at its memory channel)
@@ -565,7 +565,7 @@ __global__ void __launch_bounds__(256) k_gemm_skinny(const bf16_t* __restrict__ 
 #undef GEMM_LOAD_W
 #undef GEMM_LOAD_X
 #undef GEMM_MATH
-    if (idle) return;
+    if (FUSED && idle) return;
 
     if (KSB == 1) {
         gemm_epilogue<MT, R, EPI>(acc, out, ntg, ks, NT, N_out, Mpad, lane, -1, bias);
@@ -612,9 +612,15 @@ static void launch_gemm_mt(int epi, int R, int ksb, const bf16_t* Wp, const bf16
     }
     dim3 grid((ksb == 1 ? (n_items + 3) / 4 : n_items) + (glue ? gf.rows : 0)), block(256);
 #define GEMM_CASE(E, RR, KS)                                                                                  \
-    if (epi == E && R == RR && ksb == KS) {                                                                   \
-        hipLaunchKernelGGL((k_gemm_skinny<MT, RR, E, KS>), grid, block, smem, s, Wp, X, out, NT, KT, S, n_items, \
-                           N_out, Mpad, dbg, bias, gf);                                                          \
+    if (epi == E && R == RR && ksb == KS && !glue) {                                                          \
+        hipLaunchKernelGGL((k_gemm_skinny<MT, RR, E, KS, false>), grid, block, 0, s, Wp, X, out, NT, KT, S,       \
+                           n_items, N_out, Mpad, dbg, bias, gf);                                                  \
+        return;                                                                                               \
+    }
+#define GEMM_CASE_FUSED(E, RR, KS)                                                                            \
+    if (epi == E && R == RR && ksb == KS && glue) {                                                           \
+        hipLaunchKernelGGL((k_gemm_skinny<MT, RR, E, KS, true>), grid, block, smem, s, Wp, X, out, NT, KT, S,     \
+                           n_items, N_out, Mpad, dbg, bias, gf);                                                  \
         return;                                                                                               \
     }
     GEMM_CASE(EPI_PARTIAL, 1, 1)
@@ -629,7 +635,16 @@ static void launch_gemm_mt(int epi, int R, int ksb, const bf16_t* Wp, const bf16
     GEMM_CASE(EPI_GELU_PACKED, 1, 4)
     GEMM_CASE(EPI_BF16, 1, 4)
     GEMM_CASE(EPI_SILU_PACKED, 2, 4)
+    GEMM_CASE_FUSED(EPI_PARTIAL, 1, 1)              // the fused producer feeds qkv (partial / bf16) and gate+up (silu-mul) only
+    GEMM_CASE_FUSED(EPI_PARTIAL, 1, 4)
+    GEMM_CASE_FUSED(EPI_PARTIAL, 2, 1)
+    GEMM_CASE_FUSED(EPI_PARTIAL, 2, 4)
+    GEMM_CASE_FUSED(EPI_BF16, 2, 1)
+    GEMM_CASE_FUSED(EPI_BF16, 2, 4)
+    GEMM_CASE_FUSED(EPI_SILU_MUL, 2, 1)
+    GEMM_CASE_FUSED(EPI_SILU_MUL, 2, 4)
 #undef GEMM_CASE
+#undef GEMM_CASE_FUSED
     throw MisError(MIS_ERR_GENERATION_FAILED, "unsupported GEMM variant");
 }
 
