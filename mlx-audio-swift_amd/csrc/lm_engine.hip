@@ -54,12 +54,6 @@ struct mis_tts {
     DevBuf<float> qkv_part, part, e_buf, logits_f32, samp_l32;
     DevBuf<int32_t> glue_flags;                     // [2L] arrival counters of the fused producers (zeroed every step) + [1] error
     bool fuse_glue = false;
-    // residual stream kept in the GEMMs (NormFuse, lm_kernels.h): packed h, per-group sums of squares, tile arrival counters
-    bool resid_in_gemm = false;
-    int ksb_resid = 4;
-    DevBuf<bf16_t> hp;
-    DevBuf<float> ssq;
-    DevBuf<int32_t> tile_ctr;
     // generation state
     DevBuf<int32_t> prompt_mat, prompt_lens, step_counter, window, window_len, n_gen, tokens_out, all_ids, all_len,
         done_count, codes, n_codes, l0, l1, l2, row_map;
@@ -403,10 +397,7 @@ static void lm_reset(mis_tts* c, int batch, int max_context) {
     bool new_tables = Smax != c->Smax;
     c->batch = batch; c->Mpad = Mpad; c->Smax = Smax;
     const int d = c->d, HD = c->H * c->D;
-    c->ksb_part = env_int("MIS_KSB_PART", 4);
-    if (c->ksb_part != 1 && c->ksb_part != 8 && !(c->ksb_part == 16 && Mpad <= 32)) c->ksb_part = 4;
-    c->ksb_resid = env_int("MIS_KSB_RESID", c->ksb_part);
-    if (c->ksb_resid != 1 && c->ksb_resid != 8 && !(c->ksb_resid == 16 && Mpad <= 32)) c->ksb_resid = 4;
+    c->ksb_part = env_int("MIS_KSB_PART", 4) == 1 ? 1 : 4;
     c->ksb_gu = env_int("MIS_KSB_GU", 4) == 1 ? 1 : 4;
     c->ksb_head = env_int("MIS_KSB_HEAD", 1) == 4 ? 4 : 1;
     c->r_part = env_int("MIS_R_PART", 2) == 1 ? 1 : 2;
@@ -424,13 +415,6 @@ static void lm_reset(mis_tts* c, int batch, int max_context) {
     // experimental, off by default: measured slower at the bench shape ("Fused producer experiment")
     c->fuse_glue = env_int("MIS_FUSED_GLUE", 0) == 1 && d <= 12 * 1024 && d % 2 == 0;
     c->ids.zero(s); c->pos_cur.zero(s); c->pos_next.zero(s); c->active.zero(s);
-    c->resid_in_gemm = env_int("MIS_RESID_IN_GEMM", 0) == 1 && !c->fuse_glue;
-    {
-        const int groups = (d / 16 + c->r_part - 1) / c->r_part;
-        c->hp.alloc((size_t)Mpad * d); c->hp.zero(s);
-        c->ssq.alloc((size_t)groups * Mpad); c->ssq.zero(s);
-        c->tile_ctr.alloc((size_t)groups * (Mpad / 16)); c->tile_ctr.zero(s);
-    }
     c->h.alloc((size_t)Mpad * d); c->x.alloc((size_t)Mpad * d);
     c->attn_out.alloc((size_t)Mpad * HD); c->act.alloc((size_t)Mpad * c->ff);
     c->logits.alloc((size_t)Mpad * c->Vpad);
@@ -439,34 +423,6 @@ static void lm_reset(mis_tts* c, int batch, int max_context) {
     c->part.alloc((size_t)std::max(c->S_o, c->S_down) * Mpad * d);
     c->h.zero(s); c->x.zero(s); c->attn_out.zero(s); c->act.zero(s); c->logits.zero(s);
     HIP_CHECK(hipStreamSynchronize(s));
-}
-
-// the four projections of a block in the residual-in-GEMM arrangement (also what mis_tts_time_gemm times)
-static int resid_groups(const mis_tts* c) { return (c->d / 16 + c->r_part - 1) / c->r_part; }
-static void resid_gemm_qkv(mis_tts* c, int li, bool x_is_normed) {
-    NormFuse nq{};
-    nq.ssq = c->ssq.p; nq.G = resid_groups(c); nq.wnorm = c->norms.p + (size_t)(2 * li) * c->d; nq.eps = c->cfg.rms_norm_eps;
-    launch_gemm_skinny(EPI_PARTIAL, c->r_part, c->ksb_part, c->wqkv.p + layer_qkv_elems(c) * li, x_is_normed ? c->x.p : c->hp.p,
-                       c->qkv_part.p, c->Nqkv / 16, c->d / 32, c->S_qkv, c->Nqkv, c->Mpad, c->stream, nullptr, nullptr,
-                       x_is_normed ? nullptr : &nq);
-}
-static void resid_gemm_o(mis_tts* c, int li, bool h_rowmajor) {
-    NormFuse ro{};
-    ro.h_in = h_rowmajor ? c->h.p : c->hp.p; ro.h_in_rowmajor = h_rowmajor; ro.h_out = c->hp.p; ro.ssq_out = c->ssq.p; ro.ctr = c->tile_ctr.p;
-    launch_gemm_skinny(EPI_RESID, c->r_part, c->ksb_resid, c->wo.p + layer_o_elems(c) * li, c->attn_out.p, c->part.p, c->d / 16,
-                       c->H * c->D / 32, c->S_o, c->d, c->Mpad, c->stream, nullptr, nullptr, &ro);
-}
-static void resid_gemm_gate_up(mis_tts* c, int li) {
-    NormFuse ng{};
-    ng.ssq = c->ssq.p; ng.G = resid_groups(c); ng.wnorm = c->norms.p + (size_t)(2 * li + 1) * c->d; ng.eps = c->cfg.rms_norm_eps;
-    launch_gemm_skinny(EPI_SILU_MUL, 2, c->ksb_gu, c->wgu.p + layer_gu_elems(c) * li, c->hp.p, c->act.p, 2 * c->ff / 16, c->d / 32,
-                       1, c->ff, c->Mpad, c->stream, nullptr, nullptr, &ng);
-}
-static void resid_gemm_down(mis_tts* c, int li) {
-    NormFuse rd{};
-    rd.h_in = c->hp.p; rd.h_in_rowmajor = 0; rd.h_out = c->hp.p; rd.ssq_out = c->ssq.p; rd.ctr = c->tile_ctr.p;
-    launch_gemm_skinny(EPI_RESID, c->r_part, c->ksb_resid, c->wdown.p + layer_down_elems(c) * li, c->act.p, c->part.p, c->d / 16,
-                       c->ff / 32, c->S_down, c->d, c->Mpad, c->stream, nullptr, nullptr, &rd);
 }
 
 // embed -> L x block.  Leaves x = final-norm(h) ready for lm_head.   (LlamaTTS.swift:335-345,303-310)
@@ -481,34 +437,6 @@ static void enqueue_layers(mis_tts* c, const bf16_t* table = nullptr, int table_
     if (fuse) HIP_CHECK(hipMemsetAsync(flags, 0, (size_t)2 * c->L * sizeof(int), s));
     launch_embed_rmsnorm(table ? table : c->emb.p, ids ? ids : c->ids.p, c->active.p, c->pos_cur.p, c->pos_next.p, c->norms.p,
                          c->h.p, c->x.p, d, table ? table_rows : c->V, eps, c->batch, Mpad, s);
-    if (c->resid_in_gemm) {
-        // 5 launches per block: qkv -> attention -> o_proj (residual epilogue) -> gate+up (norm operand) -> down (residual
-        // epilogue).  The embedding kernel wrote x for layer 0 and the row-major h its o_proj adds to; from there on the residual
-        // stream lives packed in hp and the norms are applied to the GEMM operands in registers.
-        for (int li = 0; li < c->L; ++li) {
-            resid_gemm_qkv(c, li, li == 0);
-            AttnParams ap{};
-            ap.qkv_part = c->qkv_part.p; ap.S = c->S_qkv; ap.Mpad = Mpad; ap.Nqkv = c->Nqkv;
-            size_t lkv = (size_t)c->batch * c->Hkv * c->Smax * c->D;
-            ap.kcache = c->kcache.p + lkv * li; ap.vtcache = c->vtcache.p + lkv * li;
-            ap.pos = c->pos_cur.p; ap.active = c->active.p;
-            ap.rope_cos = c->rope_cos.p; ap.rope_sin = c->rope_sin.p;
-            ap.out = c->attn_out.p; ap.H = c->H; ap.Hkv = c->Hkv; ap.D = c->D; ap.Smax = c->Smax;
-            ap.scale = 1.0f / sqrtf((float)c->D);
-            if (c->cfg.qk_norm) {
-                ap.qnorm_w = c->qknorm.p + (size_t)(2 * li) * c->D;
-                ap.knorm_w = c->qknorm.p + (size_t)(2 * li + 1) * c->D;
-                ap.qk_eps = c->cfg.rms_norm_eps;
-            }
-            ap.rope_in_dtype = c->cfg.rope_ops_in_dtype;
-            launch_attn_decode(ap, c->batch, s);
-            resid_gemm_o(c, li, li == 0);
-            resid_gemm_gate_up(c, li);
-            resid_gemm_down(c, li);
-        }
-        launch_norm_from_ssq(c->hp.p, c->ssq.p, resid_groups(c), Mpad, d, c->norms.p + (size_t)(2 * c->L) * d, eps, c->x.p, s);
-        return;
-    }
     for (int li = 0; li < c->L; ++li) {
         // the residual add + input_layernorm that follows the previous layer's down projection runs as the fused producer of
         // this layer's qkv GEMM (layer 0: the embedding kernel already wrote x)
@@ -1159,15 +1087,6 @@ extern "C" mis_status mis_tts_time_gemm(mis_tts* c, int which, int batch, int it
     auto run = [&](int it) {
         static const int fixed = env_int("MIS_TIME_GEMM_FIXED_LAYER", -1);      // experiment: weights stay in the Infinity Cache
         size_t li = fixed >= 0 ? (size_t)fixed : (size_t)(it % c->L);
-        if (c->resid_in_gemm && which < 4) {        // the variants the step chain launches (residual stream in the GEMMs)
-            switch (which) {
-                case 0: resid_gemm_qkv(c, (int)li, false); break;
-                case 1: resid_gemm_o(c, (int)li, false); break;
-                case 2: resid_gemm_gate_up(c, (int)li); break;
-                default: resid_gemm_down(c, (int)li); break;
-            }
-            return;
-        }
         switch (which) {
             case 0: launch_gemm_skinny(EPI_PARTIAL, c->r_part, c->ksb_part, c->wqkv.p + layer_qkv_elems(c) * li, c->x.p, c->qkv_part.p, c->Nqkv / 16, d / 32, c->S_qkv, c->Nqkv, Mpad, s); break;
             case 1: launch_gemm_skinny(EPI_PARTIAL, c->r_part, c->ksb_part, c->wo.p + layer_o_elems(c) * li, c->attn_out.p, c->part.p, d / 16, HD / 32, c->S_o, d, Mpad, s); break;

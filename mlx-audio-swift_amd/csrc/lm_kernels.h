@@ -7,7 +7,7 @@ __host__ __device__ __forceinline__ size_t xpk_index(int m, int k, int MT) {
     return ((((size_t)(k >> 5) * MT + (m >> 4)) * 64) + (((k & 31) >> 3) << 4) + (m & 15)) * 8 + (k & 7);
 }
 
-enum { EPI_PARTIAL = 0, EPI_BF16 = 1, EPI_SILU_MUL = 2, EPI_GELU_PACKED = 3, EPI_SILU_PACKED = 4, EPI_RESID = 5 };
+enum { EPI_PARTIAL = 0, EPI_BF16 = 1, EPI_SILU_MUL = 2, EPI_GELU_PACKED = 3, EPI_SILU_PACKED = 4 };
 
 void launch_convert_to_bf16(const void* src, int dtype, bf16_t* dst, size_t n, hipStream_t s);
 // MLX affine-quantised matrix (uint32 words, per-group scales / biases of dtype sb_dtype = mis_dtype) -> bf16 [N][K]
@@ -46,31 +46,8 @@ struct GlueFuse {
     int spin_limit;          // polls before giving up
     int pre_sleep;           // s_sleep(127) periods (~3.4 us each at 2.4 GHz) before the first poll
 };
-// Residual stream kept in the GEMMs (no separate residual-add / RMSNorm launches between the projections of a Llama block):
-//   producer side, EPI_RESID (o_proj, down_proj): the S split-K blocks of an (n-tile group, m-tile) write their f32 partials
-//     write-through and arrive on a counter; the LAST one to arrive sums the S partials in slab order (deterministic), rounds
-//     o = T(sum), updates the residual stream h = T(h + o) (h kept in the packed operand layout) and writes the tile's per-row sum
-//     of squares.  Wait-free: nobody spins; the counter resets itself for the next launch.
-//   consumer side, NORM (qkv, gate+up): the X operand IS the packed residual stream; every wave derives rsqrt(mean h^2 + eps) of
-//     its rows from the per-group sums and applies x = T(w * T(h * inv)) to each fragment in registers before the MFMA
-//     (v_pk_mul_f32 + v_cvt_pk_bf16_f32) - same rounding points as k_reduce_residual_rmsnorm.
-struct NormFuse {
-    const float* ssq;        // consumer: [G][Mpad] sums of squares of the rows of X over column group g
-    int G;
-    const bf16_t* wnorm;     // consumer: [K] norm weight
-    float eps;
-    const bf16_t* h_in;      // producer: residual stream in (packed, or row-major [Mpad][N] when h_in_rowmajor)
-    int h_in_rowmajor;
-    bf16_t* h_out;           // producer: residual stream out, packed (may alias a packed h_in)
-    float* ssq_out;          // producer: [ceil(NT/R)][Mpad]
-    int* ctr;                // producer: [ceil(NT/R) * Mpad/16] arrival counters, zero between launches
-};
 void launch_gemm_skinny(int epi, int R, int ksb, const bf16_t* Wp, const bf16_t* X, void* out, int NT, int KT, int S,
-                        int N_out, int Mpad, hipStream_t s, const bf16_t* bias = nullptr, const GlueFuse* glue = nullptr,
-                        const NormFuse* norm = nullptr);
-// x (packed) = T(w * T(h * rsqrt(mean h^2 + eps))) from the packed residual stream and its per-group sums of squares
-void launch_norm_from_ssq(const bf16_t* h_packed, const float* ssq, int G, int Mpad, int N, const bf16_t* wnorm, float eps,
-                          bf16_t* x, hipStream_t s);
+                        int N_out, int Mpad, hipStream_t s, const bf16_t* bias = nullptr, const GlueFuse* glue = nullptr);
 
 struct AttnParams {
     const float* qkv_part;   // [S][Mpad][Nqkv]

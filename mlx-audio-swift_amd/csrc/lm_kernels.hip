@@ -388,141 +388,6 @@ __device__ __forceinline__ void gemm_epilogue(const f32x4_t (&acc)[R][MT], void*
     }
 }
 
-// ---- residual stream in the GEMMs (NormFuse, lm_kernels.h)
-typedef float f32x2_t __attribute__((ext_vector_type(2)));
-typedef __bf16 bf16v2_t __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ uint32_t pack_bf16x2_rne(f32x2_t v) {          // v_cvt_pk_bf16_f32 (round to nearest even)
-    bf16v2_t b = __builtin_convertvector(v, bf16v2_t);
-    return __builtin_bit_cast(uint32_t, b);
-}
-__device__ __forceinline__ f32x2_t unpack_bf16x2(uint32_t u) {
-    return (f32x2_t){__uint_as_float(u << 16), __uint_as_float(u & 0xffff0000u)};
-}
-// x fragment = T(w * T(h * inv)) for the 8 k-consecutive elements a lane holds
-__device__ __forceinline__ bf16x8_t norm_fragment(bf16x8_t hv, float inv, const f32x2_t (&wf)[4]) {
-    union { bf16x8_t v; uint32_t u[4]; } in, out;
-    in.v = hv;
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        f32x2_t a = unpack_bf16x2(in.u[q]) * inv;
-        f32x2_t t = unpack_bf16x2(pack_bf16x2_rne(a));
-        out.u[q] = pack_bf16x2_rne(t * wf[q]);
-    }
-    return out.v;
-}
-// sum of the G per-group sums of squares of row m, in a fixed order: lane group g (= lane >> 4) adds groups g, g+4, ...; then
-// (g0 + g1) + (g2 + g3).  All four lane groups end with the same bits.
-__device__ __forceinline__ float ssq_row_total(const float* __restrict__ ssq, int G, int Mpad, int m, int lane) {
-    float sa = 0.0f;
-    for (int j0 = lane >> 4; j0 < G; j0 += 4 * 32) {       // 32 independent loads per round trip (G <= 128: one trip)
-        float v[32];
-#pragma unroll
-        for (int u = 0; u < 32; ++u) { const int j = j0 + 4 * u; v[u] = j < G ? ssq[(size_t)j * Mpad + m] : 0.0f; }
-#pragma unroll
-        for (int u = 0; u < 32; ++u) sa += v[u];
-    }
-    sa += __shfl_xor(sa, 16, 64);
-    sa += __shfl_xor(sa, 32, 64);
-    return sa;
-}
-// EPI_RESID tail of one (n-tile group, m-tile): a[r] = this block's f32 partial of tile ntg*R + r (K slice ks of S).
-template <int MT, int R>
-__device__ __forceinline__ void gemm_resid_finish(f32x4_t (&a)[R], int mt, int ntg, int ks, int S, int NT, int N_out, int Mpad,
-                                                  int lane, float* __restrict__ slabs, const bf16_t* __restrict__ bias,
-                                                  const NormFuse& nf) {
-    const int nl = (lane >> 4) * 4, ml = lane & 15, m = mt * 16 + ml;
-    if (bias && ks == 0) {                           // Linear bias rides on slab 0, as in the partial epilogue
-#pragma unroll
-        for (int r = 0; r < R; ++r) {
-            const int tile = ntg * R + r;
-            if (tile >= NT) continue;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) a[r][e] += bf16_to_f32(bias[tile * 16 + nl + e]);
-        }
-    }
-    if (S > 1) {
-        // partials go straight to memory (write-through): the finishing block may sit on another XCD, whose L2 is not coherent
-#pragma unroll
-        for (int r = 0; r < R; ++r) {
-            const int tile = ntg * R + r;
-            if (tile >= NT) continue;
-            uint64_t* dst = reinterpret_cast<uint64_t*>(slabs + ((size_t)ks * Mpad + m) * N_out + tile * 16 + nl);
-            const uint64_t lo = (uint64_t)__float_as_uint(a[r][0]) | ((uint64_t)__float_as_uint(a[r][1]) << 32);
-            const uint64_t hi = (uint64_t)__float_as_uint(a[r][2]) | ((uint64_t)__float_as_uint(a[r][3]) << 32);
-            __hip_atomic_store(dst, lo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_store(dst + 1, hi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                 // the whole wave's partials are written before it arrives
-        int* ctr = nf.ctr + ntg * MT + mt;
-        int old = 0;
-        if (lane == 0) old = __hip_atomic_fetch_add(ctr, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        old = __builtin_amdgcn_readfirstlane(old);
-        if (old != S - 1) return;                                         // somebody else finishes this tile
-        if (lane == 0) __hip_atomic_store(ctr, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);     // ready for the next launch
-        __atomic_signal_fence(__ATOMIC_SEQ_CST);
-#pragma unroll
-        for (int r = 0; r < R; ++r) {
-            const int tile = ntg * R + r;
-            if (tile >= NT) continue;
-            float sum[4] = {0.f, 0.f, 0.f, 0.f};
-            for (int s0 = 0; s0 < S; s0 += 8) {                           // slab order 0, 1, 2, ... (whoever arrives last);
-                uint64_t lo[8], hi[8];                                    // 8 slabs per round trip
-#pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    const int sl = s0 + j < S ? s0 + j : S - 1;
-                    const uint64_t* src = reinterpret_cast<const uint64_t*>(slabs + ((size_t)sl * Mpad + m) * N_out + tile * 16 + nl);
-                    lo[j] = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    hi[j] = __hip_atomic_load(src + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                }
-#pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    if (s0 + j >= S) break;
-                    sum[0] += __uint_as_float((uint32_t)lo[j]); sum[1] += __uint_as_float((uint32_t)(lo[j] >> 32));
-                    sum[2] += __uint_as_float((uint32_t)hi[j]); sum[3] += __uint_as_float((uint32_t)(hi[j] >> 32));
-                }
-            }
-            a[r] = (f32x4_t){sum[0], sum[1], sum[2], sum[3]};
-        }
-    }
-    float ss = 0.0f;
-#pragma unroll
-    for (int r = 0; r < R; ++r) {
-        const int tile = ntg * R + r;
-        if (tile >= NT) continue;
-        const int n0 = tile * 16 + nl;
-        const size_t ip = xpk_index(m, n0, MT);
-        const size_t ii = nf.h_in_rowmajor ? (size_t)m * N_out + n0 : ip;
-        const uint2 hv = *reinterpret_cast<const uint2*>(nf.h_in + ii);
-        const f32x2_t h01 = unpack_bf16x2(hv.x), h23 = unpack_bf16x2(hv.y);
-        const f32x2_t o01 = unpack_bf16x2(pack_bf16x2_rne((f32x2_t){a[r][0], a[r][1]}));        // o = T(sum of slabs)
-        const f32x2_t o23 = unpack_bf16x2(pack_bf16x2_rne((f32x2_t){a[r][2], a[r][3]}));
-        uint2 hn;
-        hn.x = pack_bf16x2_rne(h01 + o01);                                                        // h = T(h + o)
-        hn.y = pack_bf16x2_rne(h23 + o23);
-        *reinterpret_cast<uint2*>(nf.h_out + ip) = hn;
-        const f32x2_t n01 = unpack_bf16x2(hn.x), n23 = unpack_bf16x2(hn.y);
-        ss += n01[0] * n01[0]; ss += n01[1] * n01[1]; ss += n23[0] * n23[0]; ss += n23[1] * n23[1];
-    }
-    ss += __shfl_xor(ss, 16, 64);
-    ss += __shfl_xor(ss, 32, 64);
-    if (lane < 16) nf.ssq_out[(size_t)ntg * Mpad + m] = ss;
-}
-
-__global__ void __launch_bounds__(256) k_norm_from_ssq(const bf16_t* __restrict__ hp, const float* __restrict__ ssq, int G,
-                                                       int Mpad, int N, const bf16_t* __restrict__ wnorm, float eps,
-                                                       bf16_t* __restrict__ x) {
-    const int m = blockIdx.x, MT = Mpad >> 4;
-    const float inv = 1.0f / sqrtf(ssq_row_total(ssq, G, Mpad, m, threadIdx.x & 63) / (float)N + eps);
-    for (int i = threadIdx.x; i < N; i += 256) {
-        const size_t ip = xpk_index(m, i, MT);
-        x[ip] = f32_to_bf16(bf16_to_f32(wnorm[i]) * bf16_round_f32(bf16_to_f32(hp[ip]) * inv));
-    }
-}
-void launch_norm_from_ssq(const bf16_t* h_packed, const float* ssq, int G, int Mpad, int N, const bf16_t* wnorm, float eps,
-                          bf16_t* x, hipStream_t s) {
-    hipLaunchKernelGGL(k_norm_from_ssq, dim3(Mpad), dim3(256), 0, s, h_packed, ssq, G, Mpad, N, wnorm, eps, x);
-}
-
 // One row of the fused producer, executed by a whole 256-thread block (see GlueFuse).  Arithmetic and rounding points are those of
 // k_reduce_residual_rmsnorm: o = T(sum_s slab_s) in slab order, h = T(h + o), x = T(w * T(h * rsqrt(mean h^2 + eps))) (or LayerNorm).
 // The f32 statistics are summed in an order that depends on N only, so a row's result does not depend on the batch it sits in.
@@ -595,11 +460,11 @@ __device__ void glue_row_256(const GlueFuse& g, int m, float* rowbuf, float* red
     __syncthreads();                                  // rowbuf is reused by the next row of this block
 }
 
-template <int MT, int R, int EPI, int KSB, bool FUSED, bool NORM>
-__global__ void __launch_bounds__(KSB > 4 ? 64 * KSB : 256) k_gemm_skinny(const bf16_t* __restrict__ Wp, const bf16_t* __restrict__ X,
+template <int MT, int R, int EPI, int KSB, bool FUSED>
+__global__ void __launch_bounds__(256) k_gemm_skinny(const bf16_t* __restrict__ Wp, const bf16_t* __restrict__ X,
                                                      void* __restrict__ out, int NT, int KT, int S, int n_items,
                                                      int N_out, int Mpad, int dbg_xfixed,
-                                                     const bf16_t* __restrict__ bias, GlueFuse glue, NormFuse nf) {
+                                                     const bf16_t* __restrict__ bias, GlueFuse glue) {
     static_assert(EPI != EPI_SILU_MUL || R == 2, "silu-mul epilogue pairs a gate tile with an up tile");
     extern __shared__ __attribute__((aligned(16))) float glue_lds[];       // [N + 8] only when a producer is fused
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -640,8 +505,6 @@ __global__ void __launch_bounds__(KSB > 4 ? 64 * KSB : 256) k_gemm_skinny(const 
         for (int mt = 0; mt < MT; ++mt) acc[r][mt] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
 
     bf16x8_t wA[GEMM_U][R], xA[GEMM_U][MT], wB[GEMM_U][R], xB[GEMM_U][MT];
-    bf16x8_t nA[NORM ? GEMM_U : 1], nB[NORM ? GEMM_U : 1];       // NORM: norm-weight fragments of the same k-tiles
-    const bf16x8_t* np = reinterpret_cast<const bf16x8_t*>(nf.wnorm) + (lane >> 4);      // k = kt*32 + (lane>>4)*8 + e
     const int klast = kt1 - 1;
 #define GEMM_LOAD_W(WBUF, KBASE)                                                                  \
     _Pragma("unroll") for (int u = 0; u < GEMM_U; ++u) {                                           \
@@ -650,26 +513,17 @@ __global__ void __launch_bounds__(KSB > 4 ? 64 * KSB : 256) k_gemm_skinny(const 
         _Pragma("unroll") for (int r = 0; r < R; ++r)                                              \
             WBUF[u][r] = __builtin_nontemporal_load(wp[r] + (size_t)kk * 64);                      \
     }
-#define GEMM_LOAD_X(XBUF, NBUF, KBASE)                                                            \
+#define GEMM_LOAD_X(XBUF, KBASE)                                                                  \
     _Pragma("unroll") for (int u = 0; u < GEMM_U; ++u) {                                           \
         int kk = (KBASE) + u;                                                                      \
         kk = kk > klast ? klast : kk;                                                              \
         _Pragma("unroll") for (int mt = 0; mt < MT; ++mt)                                          \
             XBUF[u][mt] = xp[mt][(size_t)(dbg_xfixed ? (kk & 1) : kk) * (MT * 64)];                \
-        if (NORM) NBUF[u] = np[(size_t)kk * 4];                                                    \
     }
-#define GEMM_LOAD(WBUF, XBUF, NBUF, KBASE) GEMM_LOAD_W(WBUF, KBASE) GEMM_LOAD_X(XBUF, NBUF, KBASE)
-#define GEMM_MATH(WBUF, XBUF, NBUF, KBASE)                                                        \
+#define GEMM_LOAD(WBUF, XBUF, KBASE) GEMM_LOAD_W(WBUF, KBASE) GEMM_LOAD_X(XBUF, KBASE)
+#define GEMM_MATH(WBUF, XBUF, KBASE)                                                              \
     _Pragma("unroll") for (int u = 0; u < GEMM_U; ++u) {                                           \
         if ((KBASE) + u < kt1) {                                                                   \
-            if (NORM) {                               /* x = T(w * T(h * inv)) in registers */     \
-                union { bf16x8_t v; uint32_t q[4]; } wn;                                           \
-                wn.v = NBUF[u];                                                                    \
-                const f32x2_t wf[4] = {unpack_bf16x2(wn.q[0]), unpack_bf16x2(wn.q[1]),             \
-                                       unpack_bf16x2(wn.q[2]), unpack_bf16x2(wn.q[3])};            \
-                _Pragma("unroll") for (int mt = 0; mt < MT; ++mt)                                  \
-                    XBUF[u][mt] = norm_fragment(XBUF[u][mt], inv_rms[mt], wf);                     \
-            }                                                                                      \
             _Pragma("unroll") for (int r = 0; r < R; ++r)                                          \
                 _Pragma("unroll") for (int mt = 0; mt < MT; ++mt)                                  \
                     acc[r][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(WBUF[u][r], XBUF[u][mt],  \
@@ -678,11 +532,6 @@ __global__ void __launch_bounds__(KSB > 4 ? 64 * KSB : 256) k_gemm_skinny(const 
     }
     const bool has_k = kt0 < kt1;
     if (has_k) { GEMM_LOAD_W(wA, kt0) }               // weights do not depend on the producer: in flight while it runs
-    float inv_rms[MT];
-#pragma unroll
-    for (int mt = 0; mt < MT; ++mt)
-        inv_rms[mt] = NORM ? 1.0f / sqrtf(ssq_row_total(nf.ssq, nf.G, Mpad, mt * 16 + (lane & 15), lane) / (float)(KT * 32) + nf.eps)
-                           : 1.0f;
     if (FUSED) {                                      // wait for the fused producer's rows (acquire)
         if (threadIdx.x < 64) {
             if (threadIdx.x == 0) {
@@ -700,14 +549,14 @@ __global__ void __launch_bounds__(KSB > 4 ? 64 * KSB : 256) k_gemm_skinny(const 
     }
     if (has_k) {
         int kt = kt0;
-        GEMM_LOAD_X(xA, nA, kt)
+        GEMM_LOAD_X(xA, kt)
         while (true) {
-            if (kt + GEMM_U < kt1) { GEMM_LOAD(wB, xB, nB, kt + GEMM_U) }
-            GEMM_MATH(wA, xA, nA, kt)
+            if (kt + GEMM_U < kt1) { GEMM_LOAD(wB, xB, kt + GEMM_U) }
+            GEMM_MATH(wA, xA, kt)
             kt += GEMM_U;
             if (kt >= kt1) break;
-            if (kt + GEMM_U < kt1) { GEMM_LOAD(wA, xA, nA, kt + GEMM_U) }
-            GEMM_MATH(wB, xB, nB, kt)
+            if (kt + GEMM_U < kt1) { GEMM_LOAD(wA, xA, kt + GEMM_U) }
+            GEMM_MATH(wB, xB, kt)
             kt += GEMM_U;
             if (kt >= kt1) break;
         }
@@ -719,17 +568,7 @@ __global__ void __launch_bounds__(KSB > 4 ? 64 * KSB : 256) k_gemm_skinny(const 
     if (FUSED && idle) return;
 
     if (KSB == 1) {
-        if constexpr (EPI == EPI_RESID) {
-#pragma unroll
-            for (int mt = 0; mt < MT; ++mt) {
-                f32x4_t a[R];
-#pragma unroll
-                for (int r = 0; r < R; ++r) a[r] = acc[r][mt];
-                gemm_resid_finish<MT, R>(a, mt, ntg, ks, S, NT, N_out, Mpad, lane, reinterpret_cast<float*>(out), bias, nf);
-            }
-        } else {
-            gemm_epilogue<MT, R, EPI>(acc, out, ntg, ks, NT, N_out, Mpad, lane, -1, bias);
-        }
+        gemm_epilogue<MT, R, EPI>(acc, out, ntg, ks, NT, N_out, Mpad, lane, -1, bias);
     } else {
         __shared__ float4 red[KSB][R * MT][64];
 #pragma unroll
@@ -740,7 +579,6 @@ __global__ void __launch_bounds__(KSB > 4 ? 64 * KSB : 256) k_gemm_skinny(const 
         __syncthreads();
         // wave w finishes the m-tiles mt = w, w+KSB, ...: sum the KSB partials in fixed order, then epilogue
         for (int mt = wave; mt < MT; mt += KSB) {
-            f32x4_t fin[R];
 #pragma unroll
             for (int r = 0; r < R; ++r) {
                 float4 s0 = red[0][r * MT + mt][lane];
@@ -749,26 +587,19 @@ __global__ void __launch_bounds__(KSB > 4 ? 64 * KSB : 256) k_gemm_skinny(const 
                     float4 t = red[w][r * MT + mt][lane];
                     s0.x += t.x; s0.y += t.y; s0.z += t.z; s0.w += t.w;
                 }
-                fin[r] = (f32x4_t){s0.x, s0.y, s0.z, s0.w};
 #pragma unroll
                 for (int m2 = 0; m2 < MT; ++m2)
-                    if (m2 == mt) acc[r][m2] = fin[r];
+                    if (m2 == mt) acc[r][m2] = (f32x4_t){s0.x, s0.y, s0.z, s0.w};
             }
-            if constexpr (EPI == EPI_RESID)
-                gemm_resid_finish<MT, R>(fin, mt, ntg, ks, S, NT, N_out, Mpad, lane, reinterpret_cast<float*>(out), bias, nf);
-            else
-                gemm_epilogue<MT, R, EPI>(acc, out, ntg, ks, NT, N_out, Mpad, lane, mt, bias);
+            gemm_epilogue<MT, R, EPI>(acc, out, ntg, ks, NT, N_out, Mpad, lane, mt, bias);
         }
     }
 }
 
 template <int MT>
 static void launch_gemm_mt(int epi, int R, int ksb, const bf16_t* Wp, const bf16_t* X, void* out, int NT, int KT, int S,
-                           int N_out, int Mpad, const bf16_t* bias, hipStream_t s, const GlueFuse* glue, const NormFuse* norm) {
+                           int N_out, int Mpad, const bf16_t* bias, hipStream_t s, const GlueFuse* glue) {
     int n_items = ((NT + R - 1) / R) * S;
-    NormFuse nf{};
-    if (norm) nf = *norm;
-    const bool normx = norm && norm->ssq;
     static const int dbg = getenv("MIS_GEMM_DEBUG_XFIXED") ? atoi(getenv("MIS_GEMM_DEBUG_XFIXED")) : 0;
     GlueFuse gf{};
     size_t smem = 0;
@@ -779,23 +610,17 @@ static void launch_gemm_mt(int epi, int R, int ksb, const bf16_t* Wp, const bf16
         static const int pre = getenv("MIS_GLUE_PRESLEEP") ? atoi(getenv("MIS_GLUE_PRESLEEP")) : 1;
         gf.pre_sleep = pre;
     }
-    dim3 grid((ksb == 1 ? (n_items + 3) / 4 : n_items) + (glue ? gf.rows : 0)), block(ksb > 4 ? 64 * ksb : 256);
+    dim3 grid((ksb == 1 ? (n_items + 3) / 4 : n_items) + (glue ? gf.rows : 0)), block(256);
 #define GEMM_CASE(E, RR, KS)                                                                                  \
-    if (epi == E && R == RR && ksb == KS && !glue && !normx) {                                                \
-        hipLaunchKernelGGL((k_gemm_skinny<MT, RR, E, KS, false, false>), grid, block, 0, s, Wp, X, out, NT, KT, S, \
-                           n_items, N_out, Mpad, dbg, bias, gf, nf);                                              \
-        return;                                                                                               \
-    }
-#define GEMM_CASE_NORM(E, RR, KS)                                                                             \
-    if (epi == E && R == RR && ksb == KS && !glue && normx) {                                                 \
-        hipLaunchKernelGGL((k_gemm_skinny<MT, RR, E, KS, false, true>), grid, block, 0, s, Wp, X, out, NT, KT, S, \
-                           n_items, N_out, Mpad, dbg, bias, gf, nf);                                              \
+    if (epi == E && R == RR && ksb == KS && !glue) {                                                          \
+        hipLaunchKernelGGL((k_gemm_skinny<MT, RR, E, KS, false>), grid, block, 0, s, Wp, X, out, NT, KT, S,       \
+                           n_items, N_out, Mpad, dbg, bias, gf);                                                  \
         return;                                                                                               \
     }
 #define GEMM_CASE_FUSED(E, RR, KS)                                                                            \
-    if (epi == E && R == RR && ksb == KS && glue && !normx) {                                                           \
-        hipLaunchKernelGGL((k_gemm_skinny<MT, RR, E, KS, true, false>), grid, block, smem, s, Wp, X, out, NT, KT, S, \
-                           n_items, N_out, Mpad, dbg, bias, gf, nf);                                              \
+    if (epi == E && R == RR && ksb == KS && glue) {                                                           \
+        hipLaunchKernelGGL((k_gemm_skinny<MT, RR, E, KS, true>), grid, block, smem, s, Wp, X, out, NT, KT, S,     \
+                           n_items, N_out, Mpad, dbg, bias, gf);                                                  \
         return;                                                                                               \
     }
     GEMM_CASE(EPI_PARTIAL, 1, 1)
@@ -818,48 +643,21 @@ static void launch_gemm_mt(int epi, int R, int ksb, const bf16_t* Wp, const bf16
     GEMM_CASE_FUSED(EPI_BF16, 2, 4)
     GEMM_CASE_FUSED(EPI_SILU_MUL, 2, 1)
     GEMM_CASE_FUSED(EPI_SILU_MUL, 2, 4)
-    GEMM_CASE_NORM(EPI_PARTIAL, 1, 1)               // residual stream as X operand: qkv (partial) and gate+up (silu-mul)
-    GEMM_CASE_NORM(EPI_PARTIAL, 1, 4)
-    GEMM_CASE_NORM(EPI_PARTIAL, 2, 1)
-    GEMM_CASE_NORM(EPI_PARTIAL, 2, 4)
-    GEMM_CASE_NORM(EPI_SILU_MUL, 2, 1)
-    GEMM_CASE_NORM(EPI_SILU_MUL, 2, 4)
-    GEMM_CASE(EPI_RESID, 1, 1)                      // residual-stream epilogue: o_proj, down_proj
-    GEMM_CASE(EPI_RESID, 1, 4)
-    GEMM_CASE(EPI_RESID, 2, 1)
-    GEMM_CASE(EPI_RESID, 2, 4)
-    // wide in-block K split (512 / 1024 threads): the whole K range of a tile group inside one block, no slabs to reduce
-    if constexpr (MT <= 4) {
-        GEMM_CASE(EPI_RESID, 1, 8)
-        GEMM_CASE(EPI_PARTIAL, 1, 8)
-        GEMM_CASE(EPI_RESID, 2, 8)
-        GEMM_CASE(EPI_PARTIAL, 2, 8)
-    }
-    if constexpr (MT <= 2) {
-        GEMM_CASE(EPI_RESID, 1, 16)
-        GEMM_CASE(EPI_PARTIAL, 1, 16)
-        GEMM_CASE(EPI_RESID, 2, 16)
-        GEMM_CASE(EPI_PARTIAL, 2, 16)
-    }
 #undef GEMM_CASE
 #undef GEMM_CASE_FUSED
-#undef GEMM_CASE_NORM
     throw MisError(MIS_ERR_GENERATION_FAILED, "unsupported GEMM variant");
 }
 
 void launch_gemm_skinny(int epi, int R, int ksb, const bf16_t* Wp, const bf16_t* X, void* out, int NT, int KT, int S,
-                        int N_out, int Mpad, hipStream_t s, const bf16_t* bias, const GlueFuse* glue, const NormFuse* norm) {
-    MIS_REQUIRE(epi == EPI_PARTIAL || epi == EPI_RESID || S == 1, MIS_ERR_GENERATION_FAILED, "split-K needs the partial epilogue");
-    MIS_REQUIRE(epi != EPI_RESID || (norm && norm->h_in && norm->h_out && norm->ssq_out && norm->ctr && out),
-                MIS_ERR_GENERATION_FAILED, "residual epilogue without its buffers");
-    MIS_REQUIRE(!(norm && norm->ssq) || (norm->wnorm && norm->G >= 1 && !glue), MIS_ERR_GENERATION_FAILED, "bad norm-operand arguments");
+                        int N_out, int Mpad, hipStream_t s, const bf16_t* bias, const GlueFuse* glue) {
+    MIS_REQUIRE(epi == EPI_PARTIAL || S == 1, MIS_ERR_GENERATION_FAILED, "split-K needs the partial epilogue");
     MIS_REQUIRE(!glue || (glue->flag && glue->error && glue->rows == Mpad && glue->N == KT * 32 && glue->N <= 12 * 1024 && glue->x == X),
                 MIS_ERR_GENERATION_FAILED, "bad fused-producer arguments");
     switch (Mpad / 16) {
-        case 1: launch_gemm_mt<1>(epi, R, ksb, Wp, X, out, NT, KT, S, N_out, Mpad, bias, s, glue, norm); break;
-        case 2: launch_gemm_mt<2>(epi, R, ksb, Wp, X, out, NT, KT, S, N_out, Mpad, bias, s, glue, norm); break;
-        case 3: launch_gemm_mt<3>(epi, R, ksb, Wp, X, out, NT, KT, S, N_out, Mpad, bias, s, glue, norm); break;
-        case 4: launch_gemm_mt<4>(epi, R, ksb, Wp, X, out, NT, KT, S, N_out, Mpad, bias, s, glue, norm); break;
+        case 1: launch_gemm_mt<1>(epi, R, ksb, Wp, X, out, NT, KT, S, N_out, Mpad, bias, s, glue); break;
+        case 2: launch_gemm_mt<2>(epi, R, ksb, Wp, X, out, NT, KT, S, N_out, Mpad, bias, s, glue); break;
+        case 3: launch_gemm_mt<3>(epi, R, ksb, Wp, X, out, NT, KT, S, N_out, Mpad, bias, s, glue); break;
+        case 4: launch_gemm_mt<4>(epi, R, ksb, Wp, X, out, NT, KT, S, N_out, Mpad, bias, s, glue); break;
         default: throw MisError(MIS_ERR_INVALID_INPUT, "batch per GPU must be <= 64");
     }
 }
