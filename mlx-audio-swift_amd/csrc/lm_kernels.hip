@@ -209,11 +209,15 @@ __global__ void __launch_bounds__(RR_THREADS) k_reduce_residual_rmsnorm(const fl
     for (int c0 = 0; c0 < N; c0 += RR_THREADS * RR_MAXC) {
         float acc[RR_MAXC], hv[RR_MAXC];
 #pragma unroll
+        // every load below is UNCONDITIONAL (out-of-range columns / slabs read a clamped address and are masked afterwards):
+        // a guarded load compiles to a branch with its own s_waitcnt vmcnt(0), i.e. one dependent memory round trip per
+        // guard - four in a row here before this was straight-line code, against the single one the data flow needs.
         for (int k = 0; k < RR_MAXC; ++k) {
             int i = c0 + tid + k * RR_THREADS;
+            const int ic = i < N ? i : N - 1;
             acc[k] = 0.0f;
-            hv[k] = (i < N) ? bf16_to_f32(h[(size_t)m * N + i]) : 0.0f;
-            wv[k] = (i < N) ? bf16_to_f32(wnorm[i]) : 0.0f;
+            hv[k] = bf16_to_f32(h[(size_t)m * N + ic]);
+            wv[k] = bf16_to_f32(wnorm[ic]);
         }
         for (int s0 = 0; s0 < S; s0 += 8) {     // 8 slabs x RR_MAXC columns: one round trip (slabs come from HBM/MALL:
             float v[8][RR_MAXC];                // the producer's L2 lines were written back at the kernel boundary)
@@ -222,13 +226,19 @@ __global__ void __launch_bounds__(RR_THREADS) k_reduce_residual_rmsnorm(const fl
 #pragma unroll
                 for (int k = 0; k < RR_MAXC; ++k) {
                     int i = c0 + tid + k * RR_THREADS;
-                    v[j][k] = (s0 + j < S && i < N) ? slabs[((size_t)(s0 + j) * Mpad + m) * N + i] : 0.0f;
+                    const int ic = i < N ? i : N - 1;
+                    const int sj = s0 + j < S ? s0 + j : S - 1;
+                    v[j][k] = slabs[((size_t)sj * Mpad + m) * N + ic];
                 }
 #pragma unroll
             for (int j = 0; j < 8; ++j)        // slab order s = 0,1,2,... (fixed => deterministic)
 #pragma unroll
-                for (int k = 0; k < RR_MAXC; ++k) acc[k] += v[j][k];
+                for (int k = 0; k < RR_MAXC; ++k) acc[k] += (s0 + j < S) ? v[j][k] : 0.0f;
         }
+        // pin the norm-weight loads here (they were issued ahead of the slab loads, so they have landed): left alone the compiler
+        // sinks them to their use after the block reduction - one more dependent round trip at the tail of the kernel
+#pragma unroll
+        for (int k = 0; k < RR_MAXC; ++k) asm volatile("" : "+v"(wv[k]));
 #pragma unroll
         for (int k = 0; k < RR_MAXC; ++k) {
             int i = c0 + tid + k * RR_THREADS;
@@ -684,8 +694,8 @@ __global__ void __launch_bounds__(512) k_attn_decode(AttnParams p) {
     const int kv_len = p.cross ? p.cross_len : pos + 1;
 
     // LDS carve-up
-    float* sraw = reinterpret_cast<float*>(smem);                      // [(G+2)][D] f32
-    bf16_t* qs = reinterpret_cast<bf16_t*>(sraw + (G + 2) * D);        // [16][D] bf16
+    float* sraw = reinterpret_cast<float*>(smem);                      // [(G+2)][D] f32, padded to NIT*512 (see the slab sum)
+    bf16_t* qs = reinterpret_cast<bf16_t*>(sraw + NIT * 512);          // [16][D] bf16
     float* sm = reinterpret_cast<float*>(qs + 16 * D);                 // [W][16]
     float* sl = sm + ATT_WAVES * 16;                                   // [W][16]
     float* sO = sl + ATT_WAVES * 16;                                   // [W][G][D]
@@ -719,14 +729,17 @@ __global__ void __launch_bounds__(512) k_attn_decode(AttnParams p) {
     for (int it = 0; it < NIT; ++it) {
         const int idx = tid + it * 512;
         int hh = idx / D, d = idx - hh * D;
+        if (idx >= n_el) { hh = 0; d = 0; }          // clamped: loaded, never used
         int col;
         if (hh < G) col = (kvh * G + hh) * D + d;
         else if (hh == G) col = p.H * D + kvh * D + d;
         else col = p.H * D + p.Hkv * D + kvh * D + d;
         pcol[it] = col;
+        // unconditional loads (clamped slab index, masked at the sum): a guarded load becomes a branch with its own
+        // s_waitcnt vmcnt(0) - a dependent memory round trip per guard ahead of the KV prefetch
 #pragma unroll
         for (int j = 0; j < 8; ++j)
-            pv[it][j] = (idx < n_el && j < p.S) ? p.qkv_part[((size_t)j * p.Mpad + b) * p.Nqkv + col] : 0.0f;
+            pv[it][j] = p.qkv_part[((size_t)(j < p.S ? j : p.S - 1) * p.Mpad + b) * p.Nqkv + col];
     }
     // RoPE table entries and q/k-norm weights this thread will need: also requested before the KV prefetch (a load issued after
     // it could only be consumed once the whole prefetch has landed - loads retire in order).  Null tables read a dummy address.
@@ -739,8 +752,8 @@ __global__ void __launch_bounds__(512) k_attn_decode(AttnParams p) {
         for (int it = 0; it < NIT; ++it) {
             const int idx = tid + it * 512;
             const int i = idx % (D / 2);
-            rc[it] = (idx < n_rot_el) ? ct[p.rope_cos ? i : 0] : 1.0f;
-            rs[it] = (idx < n_rot_el) ? st[p.rope_cos ? i : 0] : 0.0f;
+            rc[it] = ct[p.rope_cos ? i : 0];          // unconditional; entries past n_rot_el are never used
+            rs[it] = st[p.rope_cos ? i : 0];
         }
     }
     float qw[D / 64], kw[D / 64];
@@ -754,17 +767,25 @@ __global__ void __launch_bounds__(512) k_attn_decode(AttnParams p) {
     const bool preB = wave + ATT_WAVES < n_tiles && wave + ATT_WAVES != new_tile;
     // unconditional (straight-line code keeps the s_waitcnt bookkeeping exact: a conditional prefetch makes the compiler wait
     // for vmcnt(0) at the join); a wave without an old tile re-reads a clamped one and discards it
+    __builtin_amdgcn_sched_barrier(0);          // the prologue's own loads go out FIRST (vmcnt retires in issue order)
     load_tile(min(wave, n_tiles - 1), kA, vA);
     load_tile(min(wave + ATT_WAVES, n_tiles - 1), kB, vB);
+    __builtin_amdgcn_sched_barrier(0);
+    // pin the slab values here: without this the compiler folds "(j < S) ? loaded : 0" into a guarded load placed after the
+    // prefetch, whose s_waitcnt vmcnt(0) then waits for the whole KV stream
+#pragma unroll
+    for (int it = 0; it < NIT; ++it)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) asm volatile("" : "+v"(pv[it][j]));
 #pragma unroll
     for (int it = 0; it < NIT; ++it) {
         const int idx = tid + it * 512;
-        if (idx < n_el) {
-            float acc = 0.0f;
+        // unconditional (sraw is padded to NIT*512 entries; entries >= n_el hold clamped-address garbage nobody reads): a guard
+        // here lets the compiler sink the slab loads into the guarded block, BEHIND the KV prefetch - and wait for all of it
+        float acc = 0.0f;
 #pragma unroll
-            for (int j = 0; j < 8; ++j) acc += pv[it][j];                // slab order 0..7 (S <= 8, checked by the launcher)
-            sraw[idx] = bf16_round_f32(acc);
-        }
+        for (int j = 0; j < 8; ++j) acc += (j < p.S) ? pv[it][j] : 0.0f;       // slab order 0..7 (S <= 8, checked by the launcher)
+        sraw[idx] = bf16_round_f32(acc);
     }
     for (int idx = tid; idx < 16 * D; idx += 512) qs[idx] = 0;
     __syncthreads();
@@ -916,8 +937,12 @@ __global__ void __launch_bounds__(512) k_attn_decode(AttnParams p) {
     }
 }
 
+static int attn_nit(int G, int D) {                  // prologue elements per thread: NIT * 512 >= (G + 2) * D
+    const int n_el = (G + 2) * D;
+    return n_el <= 1024 ? 2 : (D == 128 ? 5 : 3);
+}
 size_t attn_smem_bytes(int G, int D) {
-    return (size_t)(G + 2) * D * 4 + 16 * D * 2 + 2 * ATT_WAVES * 16 * 4 + (size_t)ATT_WAVES * G * D * 4;
+    return (size_t)attn_nit(G, D) * 512 * 4 + 16 * D * 2 + 2 * ATT_WAVES * 16 * 4 + (size_t)ATT_WAVES * G * D * 4;
 }
 
 void launch_attn_decode(const AttnParams& p, int batch, hipStream_t s) {
