@@ -531,7 +531,17 @@ __global__ void __launch_bounds__(256) k_gemm_skinny(const bf16_t* __restrict__ 
             XBUF[u][mt] = xp[mt][(size_t)(dbg_xfixed ? (kk & 1) : kk) * (MT * 64)];                \
     }
 #define GEMM_LOAD(WBUF, XBUF, KBASE) GEMM_LOAD_W(WBUF, KBASE) GEMM_LOAD_X(XBUF, KBASE)
-#define GEMM_MATH(WBUF, XBUF, KBASE)                                                              \
+/* FULL: every k-tile of the group is inside the wave's range (no guard).  TAIL: the last group(s) of the range, guarded.       */
+/* The main loop below uses FULL and unconditional loads only: with a guard inside the loop the waitcnt pass has to assume the   */
+/* no-load path at the join and drains vmcnt far enough to stall the group just requested - one group in flight per wave.        */
+#define GEMM_MATH_FULL(WBUF, XBUF)                                                                \
+    _Pragma("unroll") for (int u = 0; u < GEMM_U; ++u) {                                           \
+        _Pragma("unroll") for (int r = 0; r < R; ++r)                                              \
+            _Pragma("unroll") for (int mt = 0; mt < MT; ++mt)                                      \
+                acc[r][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(WBUF[u][r], XBUF[u][mt],      \
+                                                                     acc[r][mt], 0, 0, 0);         \
+    }
+#define GEMM_MATH_TAIL(WBUF, XBUF, KBASE)                                                         \
     _Pragma("unroll") for (int u = 0; u < GEMM_U; ++u) {                                           \
         if ((KBASE) + u < kt1) {                                                                   \
             _Pragma("unroll") for (int r = 0; r < R; ++r)                                          \
@@ -560,21 +570,42 @@ __global__ void __launch_bounds__(256) k_gemm_skinny(const bf16_t* __restrict__ 
     if (has_k) {
         int kt = kt0;
         GEMM_LOAD_X(xA, kt)
-        while (true) {
-            if (kt + GEMM_U < kt1) { GEMM_LOAD(wB, xB, kt + GEMM_U) }
-            GEMM_MATH(wA, xA, kt)
-            kt += GEMM_U;
-            if (kt >= kt1) break;
-            if (kt + GEMM_U < kt1) { GEMM_LOAD(wA, xA, kt + GEMM_U) }
-            GEMM_MATH(wB, xB, kt)
-            kt += GEMM_U;
-            if (kt >= kt1) break;
+        // steady state: groups kt and kt + U are full and both following loads exist
+        // (sched barriers: the next group is REQUESTED before the current one is waited for - left alone the scheduler sinks
+        // the loads in between the MFMAs, i.e. behind the wait for the current group)
+        while (kt + 3 * GEMM_U <= kt1) {
+            GEMM_LOAD(wB, xB, kt + GEMM_U)
+            __builtin_amdgcn_sched_barrier(0);
+            GEMM_MATH_FULL(wA, xA)
+            __builtin_amdgcn_sched_barrier(0);
+            GEMM_LOAD(wA, xA, kt + 2 * GEMM_U)
+            __builtin_amdgcn_sched_barrier(0);
+            GEMM_MATH_FULL(wB, xB)
+            __builtin_amdgcn_sched_barrier(0);
+            kt += 2 * GEMM_U;
+        }
+        // tail: one to three (partial) groups left, the first of them already in buffer A
+        if (kt + GEMM_U < kt1) {
+            GEMM_LOAD(wB, xB, kt + GEMM_U)
+            __builtin_amdgcn_sched_barrier(0);
+            GEMM_MATH_TAIL(wA, xA, kt)
+            if (kt + 2 * GEMM_U < kt1) {
+                GEMM_LOAD(wA, xA, kt + 2 * GEMM_U)
+                __builtin_amdgcn_sched_barrier(0);
+                GEMM_MATH_TAIL(wB, xB, kt + GEMM_U)
+                GEMM_MATH_TAIL(wA, xA, kt + 2 * GEMM_U)
+            } else {
+                GEMM_MATH_TAIL(wB, xB, kt + GEMM_U)
+            }
+        } else {
+            GEMM_MATH_TAIL(wA, xA, kt)
         }
     }
 #undef GEMM_LOAD
 #undef GEMM_LOAD_W
 #undef GEMM_LOAD_X
-#undef GEMM_MATH
+#undef GEMM_MATH_FULL
+#undef GEMM_MATH_TAIL
     if (FUSED && idle) return;
 
     if (KSB == 1) {
