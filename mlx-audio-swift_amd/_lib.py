@@ -6,7 +6,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libmi_speech.so")
+# MIS_LIB_PATH: load a diagnostics build of the same library instead (e.g. `make timing`, tools/attn_phases.py)
+LIB_PATH = os.environ.get("MIS_LIB_PATH") or os.path.join(_HERE, "libmi_speech.so")
 
 MIS_OK = 0
 STATUS_NAMES = {0: "ok", 1: "modelNotInitialized", 2: "generationFailed", 3: "invalidInput",

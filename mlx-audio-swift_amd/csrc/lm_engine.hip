@@ -989,9 +989,16 @@ extern "C" mis_status mis_tts_generate_device(mis_tts* c, const int32_t* prompt_
     MIS_API_END
 }
 
-static int64_t max_pcm_per_row(mis_tts* c, const mis_gen_params* p) {
+// Upper bound of the audio one row can decode to.  parseOutput (LlamaTTS.swift:749-752) keeps everything after the LAST
+// start-of-speech marker - or the whole sequence, prompt included, when the prompt carries none - so the prompt length counts.
+static int64_t max_pcm_per_row(mis_tts* c, const mis_gen_params* p, const int32_t* prompt_lens, int batch) {
+    MIS_REQUIRE(prompt_lens && batch >= 1, MIS_ERR_INVALID_INPUT, "null argument");
+    std::vector<int32_t> lens(batch);
+    HIP_CHECK(hipMemcpy(lens.data(), prompt_lens, (size_t)batch * 4, hipMemcpyDefault));
+    int lmax = 0;
+    for (int b = 0; b < batch; ++b) lmax = std::max(lmax, lens[b]);
     int mt = p->max_tokens > 0 ? p->max_tokens : 1200;
-    return mis_snac_num_samples(c->codec, std::max(1, mt / 7 + 1));
+    return mis_snac_num_samples(c->codec, std::max(1, (mt + lmax) / 7 + 1));
 }
 
 extern "C" mis_status mis_tts_generate(mis_tts* c, const int32_t* prompt_ids, const int32_t* prompt_lens, int batch,
@@ -1003,7 +1010,7 @@ extern "C" mis_status mis_tts_generate(mis_tts* c, const int32_t* prompt_ids, co
     MIS_REQUIRE(c->codec, MIS_ERR_NOT_INITIALIZED, "SNAC model not loaded");
     default_params_check(params);
     HIP_CHECK(hipSetDevice(c->device));
-    int64_t cap = max_pcm_per_row(c, params);
+    int64_t cap = max_pcm_per_row(c, params, prompt_lens, batch);
     DevBuf<float> pcm;
     pcm.alloc((size_t)batch * cap);
     HIP_CHECK(hipMemsetAsync(pcm.p, 0, (size_t)batch * cap * 4, c->stream));
@@ -1035,7 +1042,7 @@ extern "C" mis_status mis_tts_generate_stream(mis_tts* c, const int32_t* prompt_
     MIS_REQUIRE(c->codec, MIS_ERR_NOT_INITIALIZED, "SNAC model not loaded");
     default_params_check(params);
     HIP_CHECK(hipSetDevice(c->device));
-    int64_t cap = max_pcm_per_row(c, params);
+    int64_t cap = max_pcm_per_row(c, params, prompt_lens, batch);
     DevBuf<float> pcm;
     pcm.alloc((size_t)batch * cap);
     GenOutputs out;

@@ -67,6 +67,7 @@ struct AttnParams {
     bf16_t* out;             // [Mpad][H*D]
     int H, Hkv, D, Smax;
     float scale;
+    unsigned long long* dbg; // phase timestamps (MIS_ATTN_TIMING builds only), else null
 };
 void launch_attn_decode(const AttnParams& p, int batch, hipStream_t s);
 

@@ -714,26 +714,71 @@ void launch_gemm_skinny(int epi, int R, int ksb, const bf16_t* Wp, const bf16_t*
 
 #define ATT_WAVES 8
 
+// phase timestamps of block (0, 0) for tools/attn_phases.py (compiled in with -DMIS_ATTN_TIMING only)
+#ifdef MIS_ATTN_TIMING
+#define ATT_STAMP(i) do { if (p.dbg && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) p.dbg[i] = __builtin_readcyclecounter(); } while (0)
+#else
+#define ATT_STAMP(i) do { } while (0)
+#endif
+
 template <int D, int NIT>
 __global__ void __launch_bounds__(512) k_attn_decode(AttnParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int kvh = blockIdx.x, b = blockIdx.y;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int G = p.H / p.Hkv;
-    if (!p.active[b]) return;
-    const int pos = p.cross ? 0 : p.pos[b];
-    const int kv_len = p.cross ? p.cross_len : pos + 1;
+    ATT_STAMP(0);
 
     // LDS carve-up
     float* sraw = reinterpret_cast<float*>(smem);                      // [(G+2)][D] f32, padded to NIT*512 (see the slab sum)
     bf16_t* qs = reinterpret_cast<bf16_t*>(sraw + NIT * 512);          // [16][D] bf16
-    float* sm = reinterpret_cast<float*>(qs + 16 * D);                 // [W][16]
+    bf16_t* ksh = qs + 16 * D;                                         // [D] bf16: the new key after RoPE (patched into its tile)
+    float* sm = reinterpret_cast<float*>(ksh + D);                     // [W][16]
     float* sl = sm + ATT_WAVES * 16;                                   // [W][16]
     float* sO = sl + ATT_WAVES * 16;                                   // [W][G][D]
 
-    // ---- cache pointers and the first pair of key tiles of this wave.  Tiles that do not hold the NEW key are independent of
-    // this step's q/k/v, so their K and V fragments (32 KiB per wave) are requested BEFORE the prologue consumes its slab loads:
-    // the KV stream of the step overlaps the slab reduce / norm / RoPE instead of starting after it.
+    // ---- memory round trip 1: everything that does not depend on the row's position goes out together - the row's state
+    // (active, pos), the split-K slabs of this (row, kv head) and the q/k-norm weights.  All loads are unconditional (clamped
+    // addresses, masked at use): a guarded load compiles to a branch with its own s_waitcnt vmcnt(0), i.e. one more dependent
+    // round trip per guard.
+    const int n_pro = p.cross ? G : G + 2;          // cross attention: queries only (K/V cached once per utterance)
+    const int n_el = n_pro * D;
+    float pv[NIT][8];                                // NIT * 512 >= (G + 2) * D
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+        const int idx = tid + it * 512;
+        int hh = idx / D, d = idx - hh * D;
+        if (idx >= n_el) { hh = 0; d = 0; }          // clamped: loaded, never used
+        int col;
+        if (hh < G) col = (kvh * G + hh) * D + d;
+        else if (hh == G) col = p.H * D + kvh * D + d;
+        else col = p.H * D + p.Hkv * D + kvh * D + d;
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+            pv[it][j] = p.qkv_part[((size_t)(j < p.S ? j : p.S - 1) * p.Mpad + b) * p.Nqkv + col];
+    }
+    float qw[D / 64], kw[D / 64];
+    {
+        const bf16_t* qp = p.qnorm_w ? p.qnorm_w : reinterpret_cast<const bf16_t*>(p.qkv_part);
+        const bf16_t* kp = p.qnorm_w ? p.knorm_w : reinterpret_cast<const bf16_t*>(p.qkv_part);
+#pragma unroll
+        for (int j = 0; j < D / 64; ++j) { qw[j] = bf16_to_f32(qp[p.qnorm_w ? lane + 64 * j : 0]); kw[j] = bf16_to_f32(kp[p.qnorm_w ? lane + 64 * j : 0]); }
+    }
+    const unsigned char row_active = p.active[b];
+    const int pos = p.cross ? 0 : p.pos[b];
+    // the slab values are pinned here (the compiler would otherwise sink the loads behind the early return, i.e. behind the
+    // wait for `active`): one wait covers the whole round trip
+#pragma unroll
+    for (int it = 0; it < NIT; ++it)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) asm volatile("" : "+v"(pv[it][j]));
+    if (!row_active) return;
+    ATT_STAMP(1);
+    const int kv_len = p.cross ? p.cross_len : pos + 1;
+
+    // ---- memory round trip 2: RoPE table rows of this position, then the wave's first pair of K/V tiles (32 KiB per wave) -
+    // INCLUDING the tile the new key belongs to: its slot is patched in registers from LDS below, so no load ever waits for
+    // this step's own cache append.  The stream overlaps the slab reduce / norm / RoPE.
     bf16_t* kc = p.kcache + ((size_t)(b * p.Hkv + kvh) * p.Smax) * D;
     bf16_t* vt = p.vtcache + ((size_t)(b * p.Hkv + kvh) * D) * p.Smax;
     const bf16x8_t* kbase = reinterpret_cast<const bf16x8_t*>(kc) + lane;
@@ -750,30 +795,6 @@ __global__ void __launch_bounds__(512) k_attn_decode(AttnParams p) {
 #pragma unroll
         for (int dt = 0; dt < D / 16; ++dt) vb[dt] = vbase[((size_t)tile * (D / 16) + dt) * 64];
     };
-    // ---- prologue: slab reduce -> bf16.  The first 8 slabs of this thread's (up to 2) elements are requested first, then the
-    // KV prefetch, then the values are consumed (loads retire in order, so the consumer only waits for the slab loads).
-    const int n_pro = p.cross ? G : G + 2;          // cross attention: queries only (K/V cached once per utterance)
-    const int n_el = n_pro * D;
-    float pv[NIT][8];                                // NIT * 512 >= (G + 2) * D
-    int pcol[NIT];
-#pragma unroll
-    for (int it = 0; it < NIT; ++it) {
-        const int idx = tid + it * 512;
-        int hh = idx / D, d = idx - hh * D;
-        if (idx >= n_el) { hh = 0; d = 0; }          // clamped: loaded, never used
-        int col;
-        if (hh < G) col = (kvh * G + hh) * D + d;
-        else if (hh == G) col = p.H * D + kvh * D + d;
-        else col = p.H * D + p.Hkv * D + kvh * D + d;
-        pcol[it] = col;
-        // unconditional loads (clamped slab index, masked at the sum): a guarded load becomes a branch with its own
-        // s_waitcnt vmcnt(0) - a dependent memory round trip per guard ahead of the KV prefetch
-#pragma unroll
-        for (int j = 0; j < 8; ++j)
-            pv[it][j] = p.qkv_part[((size_t)(j < p.S ? j : p.S - 1) * p.Mpad + b) * p.Nqkv + col];
-    }
-    // RoPE table entries and q/k-norm weights this thread will need: also requested before the KV prefetch (a load issued after
-    // it could only be consumed once the whole prefetch has landed - loads retire in order).  Null tables read a dummy address.
     const int n_rot_el = (p.cross ? G : G + 1) * (D / 2);
     float rc[NIT], rs[NIT];
     {
@@ -787,32 +808,15 @@ __global__ void __launch_bounds__(512) k_attn_decode(AttnParams p) {
             rs[it] = st[p.rope_cos ? i : 0];
         }
     }
-    float qw[D / 64], kw[D / 64];
-    {
-        const bf16_t* qp = p.qnorm_w ? p.qnorm_w : reinterpret_cast<const bf16_t*>(p.qkv_part);
-        const bf16_t* kp = p.qnorm_w ? p.knorm_w : reinterpret_cast<const bf16_t*>(p.qkv_part);
-#pragma unroll
-        for (int j = 0; j < D / 64; ++j) { qw[j] = bf16_to_f32(qp[p.qnorm_w ? lane + 64 * j : 0]); kw[j] = bf16_to_f32(kp[p.qnorm_w ? lane + 64 * j : 0]); }
-    }
-    const bool preA = wave < n_tiles && wave != new_tile;
-    const bool preB = wave + ATT_WAVES < n_tiles && wave + ATT_WAVES != new_tile;
-    // unconditional (straight-line code keeps the s_waitcnt bookkeeping exact: a conditional prefetch makes the compiler wait
-    // for vmcnt(0) at the join); a wave without an old tile re-reads a clamped one and discards it
-    __builtin_amdgcn_sched_barrier(0);          // the prologue's own loads go out FIRST (vmcnt retires in issue order)
-    load_tile(min(wave, n_tiles - 1), kA, vA);
+    __builtin_amdgcn_sched_barrier(0);          // the table rows go out FIRST (vmcnt retires in issue order)
+    load_tile(min(wave, n_tiles - 1), kA, vA);  // unconditional; a wave without a tile re-reads a clamped one and discards it
     load_tile(min(wave + ATT_WAVES, n_tiles - 1), kB, vB);
     __builtin_amdgcn_sched_barrier(0);
-    // pin the slab values here: without this the compiler folds "(j < S) ? loaded : 0" into a guarded load placed after the
-    // prefetch, whose s_waitcnt vmcnt(0) then waits for the whole KV stream
-#pragma unroll
-    for (int it = 0; it < NIT; ++it)
-#pragma unroll
-        for (int j = 0; j < 8; ++j) asm volatile("" : "+v"(pv[it][j]));
+    ATT_STAMP(2);
 #pragma unroll
     for (int it = 0; it < NIT; ++it) {
         const int idx = tid + it * 512;
-        // unconditional (sraw is padded to NIT*512 entries; entries >= n_el hold clamped-address garbage nobody reads): a guard
-        // here lets the compiler sink the slab loads into the guarded block, BEHIND the KV prefetch - and wait for all of it
+        // unconditional (sraw is padded to NIT*512 entries; entries >= n_el hold clamped-address garbage nobody reads)
         float acc = 0.0f;
 #pragma unroll
         for (int j = 0; j < 8; ++j) acc += (j < p.S) ? pv[it][j] : 0.0f;       // slab order 0..7 (S <= 8, checked by the launcher)
@@ -820,6 +824,7 @@ __global__ void __launch_bounds__(512) k_attn_decode(AttnParams p) {
     }
     for (int idx = tid; idx < 16 * D; idx += 512) qs[idx] = 0;
     __syncthreads();
+    ATT_STAMP(3);
     if (p.qnorm_w) {
         // Qwen3-style per-head RMSNorm of q and k BEFORE RoPE (Soprano.swift:75-76): n = T(x rsqrt(mean x^2 + eps)), T(w n)
         const int n_rows = p.cross ? G : G + 1;
@@ -858,6 +863,7 @@ __global__ void __launch_bounds__(512) k_attn_decode(AttnParams p) {
         if (hh < G) { qs[hh * D + i] = r1; qs[hh * D + i + D / 2] = r2; }
         else {
             int d1 = i, d2 = i + D / 2;
+            ksh[d1] = r1; ksh[d2] = r2;        // for the register patch of the new key's tile; the cache append is fire-and-forget
             kc[((((size_t)ptile * 2 + phalf) * (D / 32) + (d1 >> 5)) * 64 + (((d1 & 31) >> 3) << 4) + prow) * 8 + (d1 & 7)] = r1;
             kc[((((size_t)ptile * 2 + phalf) * (D / 32) + (d2 >> 5)) * 64 + (((d2 & 31) >> 3) << 4) + prow) * 8 + (d2 & 7)] = r2;
         }
@@ -866,7 +872,27 @@ __global__ void __launch_bounds__(512) k_attn_decode(AttnParams p) {
         for (int d = tid; d < D; d += 512)
             vt[(((size_t)ptile * (D / 16) + (d >> 4)) * 64 + ((pr >> 3) << 4) + (d & 15)) * 8 + (pr & 7)] =
                 f32_to_bf16(sraw[(G + 1) * D + d]);
-    __syncthreads();       // LDS q visible; K/V stores of this block visible to its own waves (same CU)
+    __syncthreads();       // LDS q / new key visible (nobody reads this step's K/V append back from memory)
+    ATT_STAMP(4);
+    // the new key (position pos) inside its tile's fragments: K row `prow` of half `phalf`, V^T column pr (see the cache tiling)
+    auto patch_new_key = [&](bf16x8_t (&ka)[2][D / 32], bf16x8_t (&vb)[D / 16]) {
+        if ((lane & 15) == prow) {
+#pragma unroll
+            for (int c = 0; c < D / 32; ++c) {
+                const bf16x8_t kn = *reinterpret_cast<const bf16x8_t*>(ksh + c * 32 + (lane >> 4) * 8);
+                if (phalf) ka[1][c] = kn; else ka[0][c] = kn;
+            }
+        }
+        if ((lane >> 4) == (pr >> 3)) {
+#pragma unroll
+            for (int dt = 0; dt < D / 16; ++dt) {
+                const short vn = (short)f32_to_bf16(sraw[(G + 1) * D + dt * 16 + (lane & 15)]);
+#pragma unroll
+                for (int e = 0; e < 8; ++e)
+                    if (e == (pr & 7)) vb[dt][e] = vn;
+            }
+        }
+    };
 
     // ---- main loop
     const int h = lane & 15, g4 = lane >> 4;
@@ -932,12 +958,18 @@ __global__ void __launch_bounds__(512) k_attn_decode(AttnParams p) {
     for (int tile = wave; tile < n_tiles; tile += 2 * ATT_WAVES) {
         const int tile2 = tile + ATT_WAVES;
         const bool has2 = tile2 < n_tiles;
-        const bool first = tile == wave;
-        if (!(first && preA)) load_tile(tile, kA, vA);                  // the tile with the new key (or a later pair)
-        if (has2 && !(first && preB)) load_tile(tile2, kB, vB);
+        if (tile != wave) {                                             // later pairs (the first one was requested up front)
+            load_tile(tile, kA, vA);
+            if (has2) load_tile(tile2, kB, vB);
+        }
+        if (tile == new_tile) patch_new_key(kA, vA);
         process(tile, kA, vA);
-        if (has2) process(tile2, kB, vB);
+        if (has2) {
+            if (tile2 == new_tile) patch_new_key(kB, vB);
+            process(tile2, kB, vB);
+        }
     }
+    ATT_STAMP(5);
     // ---- per-wave partials -> LDS
     l_run += __shfl_xor(l_run, 16, 64);
     l_run += __shfl_xor(l_run, 32, 64);
@@ -951,6 +983,7 @@ __global__ void __launch_bounds__(512) k_attn_decode(AttnParams p) {
         }
     }
     __syncthreads();
+    ATT_STAMP(6);
     // ---- combine waves
     for (int idx = tid; idx < G * D; idx += 512) {
         int head = idx / D, d = idx - head * D;
@@ -966,14 +999,33 @@ __global__ void __launch_bounds__(512) k_attn_decode(AttnParams p) {
         }
         p.out[xpk_index(b, (kvh * G + head) * D + d, p.Mpad >> 4)] = f32_to_bf16(num / den);   // packed o_proj operand
     }
+    ATT_STAMP(7);
 }
 
+#ifdef MIS_ATTN_TIMING
+#include <string.h>
+static unsigned long long* g_attn_dbg = nullptr;
+static int g_attn_slot = 0;
+extern "C" int mis_debug_attn_timing_init() {          // outside any stream capture
+    if (!g_attn_dbg) {
+        if (hipHostMalloc((void**)&g_attn_dbg, 4096 * 16 * sizeof(unsigned long long), 0) != hipSuccess) return 1;
+        memset(g_attn_dbg, 0, 4096 * 16 * 8);
+    }
+    g_attn_slot = 0;
+    return 0;
+}
+extern "C" int mis_debug_attn_timing(unsigned long long* out, int max_slots) {      // copies [slots][16] stamps, returns slots used
+    int n = g_attn_slot < max_slots ? g_attn_slot : max_slots;
+    if (g_attn_dbg) memcpy(out, g_attn_dbg, (size_t)n * 16 * 8);
+    return n;
+}
+#endif
 static int attn_nit(int G, int D) {                  // prologue elements per thread: NIT * 512 >= (G + 2) * D
     const int n_el = (G + 2) * D;
     return n_el <= 1024 ? 2 : (D == 128 ? 5 : 3);
 }
 size_t attn_smem_bytes(int G, int D) {
-    return (size_t)attn_nit(G, D) * 512 * 4 + 16 * D * 2 + 2 * ATT_WAVES * 16 * 4 + (size_t)ATT_WAVES * G * D * 4;
+    return (size_t)attn_nit(G, D) * 512 * 4 + 16 * D * 2 + D * 2 + 2 * ATT_WAVES * 16 * 4 + (size_t)ATT_WAVES * G * D * 4;
 }
 
 void launch_attn_decode(const AttnParams& p, int batch, hipStream_t s) {
@@ -984,9 +1036,17 @@ void launch_attn_decode(const AttnParams& p, int batch, hipStream_t s) {
     MIS_REQUIRE(p.S >= 1 && p.S <= 8, MIS_ERR_GENERATION_FAILED, "attention prologue reduces at most 8 split-K slabs (got %d)", p.S);
     dim3 grid(p.Hkv, batch), block(512);
     const int n_el = (G + 2) * p.D;
-    if (p.D == 128 && n_el <= 1024) hipLaunchKernelGGL((k_attn_decode<128, 2>), grid, block, smem, s, p);
-    else if (p.D == 128) hipLaunchKernelGGL((k_attn_decode<128, 5>), grid, block, smem, s, p);
-    else if (p.D == 64 && n_el <= 1024) hipLaunchKernelGGL((k_attn_decode<64, 2>), grid, block, smem, s, p);
-    else if (p.D == 64) hipLaunchKernelGGL((k_attn_decode<64, 3>), grid, block, smem, s, p);
+#ifdef MIS_ATTN_TIMING
+    // one 16-stamp slot per enqueued launch (graph replays rewrite their slot); dumped by mis_debug_attn_timing()
+    AttnParams pt = p;
+    pt.dbg = g_attn_dbg ? g_attn_dbg + (size_t)(g_attn_slot++ % 4096) * 16 : nullptr;   // mis_debug_attn_timing_init() first
+    const AttnParams& p2 = pt;
+#else
+    const AttnParams& p2 = p;
+#endif
+    if (p.D == 128 && n_el <= 1024) hipLaunchKernelGGL((k_attn_decode<128, 2>), grid, block, smem, s, p2);
+    else if (p.D == 128) hipLaunchKernelGGL((k_attn_decode<128, 5>), grid, block, smem, s, p2);
+    else if (p.D == 64 && n_el <= 1024) hipLaunchKernelGGL((k_attn_decode<64, 2>), grid, block, smem, s, p2);
+    else if (p.D == 64) hipLaunchKernelGGL((k_attn_decode<64, 3>), grid, block, smem, s, p2);
     else throw MisError(MIS_ERR_INVALID_INPUT, "head_dim must be 64 or 128");
 }

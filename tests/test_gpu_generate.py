@@ -132,6 +132,22 @@ def test_eos_ragged_rows_errors_and_cancel(stack):
     assert e.value.case == "modelNotInitialized"                # "SNAC model not loaded", LlamaTTS.swift:672-674
 
 
+def test_prompt_without_speech_marker_counts_towards_the_audio(stack):
+    """parseOutput keeps the WHOLE sequence when the prompt has no start-of-speech marker (LlamaTTS.swift:749-752 ->
+    :383-434), so prompt tokens that are audio codes are decoded too: the PCM bound must include the prompt length."""
+    ocfg_s, osn, dsn, olm, dlm = stack
+    rng = np.random.default_rng(5)
+    frames = 3
+    prompt = np.asarray([oc.AUDIO_TOKEN_OFFSET + (j % 7) * 4096 + int(rng.integers(0, 4096)) for j in range(7 * frames)], np.int32)
+    gp = mas.GenerateParameters(max_tokens=7, temperature=0.0, repetition_penalty=0.0, frame_constrained=True)
+    pcm, toks = dlm.generate_batch([prompt], gp, return_tokens=True)
+    assert len(toks[0]) == 7
+    codes = oc.parse_output_row(np.concatenate([prompt, toks[0]]))
+    assert len(codes) == 7 * (frames + 1)
+    hop = int(np.prod(SNAC_SMALL["decoder_rates"])) * SNAC_SMALL["vq_strides"][0]
+    assert len(pcm[0]) == (frames + 1) * hop
+
+
 def test_vyvotts_token_ids_drive_the_same_loop():
     # VyvoTTS = Qwen3-style LM + SNAC with its own token ids (Qwen3.swift:19-29): EOS, frame-constrained range and parse use them
     ocfg_s, osn, dsn = snac_pair(SNAC_SMALL)
