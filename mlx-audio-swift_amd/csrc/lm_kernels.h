@@ -49,6 +49,9 @@ struct GlueFuse {
 void launch_gemm_skinny(int epi, int R, int ksb, const bf16_t* Wp, const bf16_t* X, void* out, int NT, int KT, int S,
                         int N_out, int Mpad, hipStream_t s, const bf16_t* bias = nullptr, const GlueFuse* glue = nullptr);
 
+// split-K factor of a weight-streaming GEMM (items = n-tile groups, KT = k-tiles, ksb = waves per item), see the definition
+int gemm_choose_split(int items, int KT, int ksb, int s_max);
+
 struct AttnParams {
     const float* qkv_part;   // [S][Mpad][Nqkv]
     int S, Mpad, Nqkv;

@@ -18,6 +18,7 @@
 //   split-K partial slabs f32 [S][Mpad][N]; reduced in the consumer's prologue (deterministic order)
 #include <hip/hip_fp16.h>
 #include "common.h"
+#include <algorithm>
 #include "lm_kernels.h"
 
 
@@ -701,6 +702,36 @@ void launch_gemm_skinny(int epi, int R, int ksb, const bf16_t* Wp, const bf16_t*
         case 4: launch_gemm_mt<4>(epi, R, ksb, Wp, X, out, NT, KT, S, N_out, Mpad, bias, s, glue); break;
         default: throw MisError(MIS_ERR_INVALID_INPUT, "batch per GPU must be <= 64");
     }
+}
+
+// Inter-block split-K factor of a weight-streaming GEMM with `items` n-tile groups and KT k-tiles.  All blocks of a launch are
+// co-resident and share their CU's load bandwidth, so the launch takes as long as the most loaded CU needs:
+//   time ~ ceil(blocks / CUs) / blocks            (the share of the weight bytes behind the busiest CU)
+//        x loaded / needed k-tiles                (waves load whole groups of GEMM_U = 4 k-tiles; a ragged range re-reads its tail)
+//        x (1 + 1 % per slab)                     (partial slabs written here and summed by the consumer).
+// This reproduces the measured optimum of every shape in profiles/r01_v1..v5 gemm sweeps (Orpheus-3B, batch 32: qkv S = 3,
+// o_proj S = 2, down S = 8); the former "about 800 blocks" rule picked S = 5 for qkv (4.8 k-tiles per wave: 67 % extra loads).
+int gemm_choose_split(int items, int KT, int ksb, int s_max) {
+    static const int n_cu = [] {
+        hipDeviceProp_t prop{};
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess || prop.multiProcessorCount <= 0) return 256;
+        return prop.multiProcessorCount;
+    }();
+    const int U = 4;                                  // GEMM_U (lm_kernels.hip)
+    int best = 1;
+    double best_cost = 1e30;
+    const int limit = std::max(1, std::min(std::min(s_max, 16), KT / (2 * ksb)));
+    for (int S = 1; S <= limit; ++S) {
+        const long blocks = ksb == 1 ? ((long)items * S + 3) / 4 : (long)items * S;
+        const int waves_per_item = ksb == 1 ? 1 : ksb;
+        const int kw = (KT + S * waves_per_item - 1) / (S * waves_per_item);      // k-tiles of the longest wave range
+        const int loaded = (kw + U - 1) / U * U;
+        const double cost = (double)((blocks + n_cu - 1) / n_cu) / (double)blocks * ((double)loaded * S * waves_per_item / KT) *
+                            (1.0 + 0.01 * S);
+        if (cost < best_cost * (1.0 - 1e-9)) { best_cost = cost; best = S; }
+    }
+    return best;
 }
 
 // ============================================================================ decode attention

@@ -353,18 +353,14 @@ extern "C" mis_status mis_whisper_init_synthetic(mis_whisper* c, uint64_t seed) 
 }
 
 // ---------------------------------------------------------------------------- encoder
-static int split_for(int items, int KT) {
-    int S = (800 + items / 2) / std::max(items, 1);
-    S = std::min(S, std::max(1, KT / 8));
-    return std::max(1, std::min(S, 16));
-}
+static int split_for(int items, int KT, int s_max = 16) { return gemm_choose_split(items, KT, 4, s_max); }   // R = 2, KSB = 4 launches below
 
 static void whisper_alloc_state(mis_whisper* c, int batch) {
     const int d = c->d, Ld = c->cfg.decoder_layers;
     int Mpad = (int)round_up(batch, 16);
     int Smax = (int)round_up(c->cfg.max_target_positions, 64);
     c->batch = batch; c->Mpad = Mpad; c->Smax = Smax;
-    c->S_qkv = split_for(3 * d / 16 / 2, d / 32);
+    c->S_qkv = split_for(3 * d / 16 / 2, d / 32, 8);      // attention prologue: <= 8 slabs
     c->S_o = split_for(d / 16 / 2, d / 32);
     c->S_cq = c->S_o;
     c->S_fc2 = split_for(d / 16 / 2, c->cfg.decoder_ffn_dim / 32);
