@@ -314,7 +314,9 @@ void launch_reduce_residual_rmsnorm(const float* slabs, int S, int Mpad, int N, 
 // so 2*GEMM_U*(R+MT) KiB per wave are in flight while the MFMAs of the previous group run.
 // HBM-bound: algorithmic bytes = N*K*2 per launch.
 
+#ifndef GEMM_U
 #define GEMM_U 4
+#endif
 
 __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
 

@@ -27,6 +27,7 @@
 #define E_SCALE 1099511627776.0f
 
 typedef unsigned long long u64;
+static_assert(SAMP_MAX_CHUNKS <= 64, "per-chunk quantities are reduced one per lane");
 
 __device__ __forceinline__ float det_exp_dev(float y) {
 #pragma clang fp contract(off)
@@ -72,20 +73,36 @@ __device__ __forceinline__ void chunk_range(const SamplerParams& p, int c, int& 
     if (i0 > i1) i0 = i1;
 }
 
-// inclusive scan of 256 u64 values held one per thread (Hillis-Steele through LDS)
-__device__ __forceinline__ u64 block_scan_incl_256(u64 v, u64* sh) {
-    const int tid = threadIdx.x;
-    sh[tid] = v;
-    __syncthreads();
-    for (int o = 1; o < SAMP_NT; o <<= 1) {
-        u64 t = (tid >= o) ? sh[tid - o] : 0;
-        __syncthreads();
-        sh[tid] += t;
-        __syncthreads();
+__device__ __forceinline__ u64 shfl_up_u64(u64 v, int o) {
+    unsigned lo = __shfl_up((unsigned)v, o, 64), hi = __shfl_up((unsigned)(v >> 32), o, 64);
+    return ((u64)hi << 32) | lo;
+}
+__device__ __forceinline__ u64 shfl_u64(u64 v, int src) {
+    unsigned lo = __shfl((unsigned)v, src, 64), hi = __shfl((unsigned)(v >> 32), src, 64);
+    return ((u64)hi << 32) | lo;
+}
+// inclusive scan over the 64 lanes of a wave (integers: the result does not depend on the association order)
+__device__ __forceinline__ u64 wave_scan_incl(u64 v) {
+    const int lane = threadIdx.x & 63;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        u64 t = shfl_up_u64(v, o);
+        if (lane >= o) v += t;
     }
-    u64 r = sh[tid];
+    return v;
+}
+// inclusive scan of 256 u64 values held one per thread: wave scans in registers + the 4 wave totals through LDS
+// (two barriers instead of the seventeen of a Hillis-Steele scan through LDS)
+__device__ __forceinline__ u64 block_scan_incl_256(u64 v, u64* sh) {
+    const int tid = threadIdx.x, w = tid >> 6;
+    u64 incl = wave_scan_incl(v);
+    if ((tid & 63) == 63) sh[w] = incl;
     __syncthreads();
-    return r;
+    u64 base = 0;
+#pragma unroll
+    for (int i = 0; i < SAMP_NT / 64; ++i) base += (i < w) ? sh[i] : 0;
+    __syncthreads();
+    return incl + base;
 }
 
 // ---- 0: repetition penalty (RepetitionContext.process), once per unique id; scratch reset
@@ -163,9 +180,13 @@ __global__ void __launch_bounds__(SAMP_NT) k_samp_max(SamplerParams p) {
     }
 }
 
+// max over the per-chunk maxima: one load per lane + a wave reduction (n_chunks <= SAMP_MAX_CHUNKS = 64), every wave for itself
 __device__ __forceinline__ float row_max(const SamplerParams& p, int b) {
-    float m = -INFINITY;
-    for (int c = 0; c < p.n_chunks; ++c) m = fmaxf(m, p.scratch[b].pmax[c]);
+    const int lane = threadIdx.x & 63;
+    float m = p.scratch[b].pmax[lane < p.n_chunks ? lane : 0];
+    m = lane < p.n_chunks ? m : -INFINITY;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
     return m;
 }
 
@@ -296,19 +317,19 @@ __global__ void __launch_bounds__(SAMP_NT) k_samp_pick(SamplerParams p, int gree
         }
     } else {
         // chunk selection (serial over <= 64 chunks), then in-chunk inverse CDF in index order
-        u64 Zk = 0;
-        for (int c = 0; c < p.n_chunks; ++c) Zk += sc->cmass[c];
+        // chunk selection: lane c holds the kept mass of chunk c; inclusive wave scan; first chunk whose prefix exceeds r
+        const int lane = tid & 63;
+        u64 cm = sc->cmass[lane < p.n_chunks ? lane : 0];
+        cm = lane < p.n_chunks ? cm : 0;
+        const u64 cincl = wave_scan_incl(cm);
+        const u64 Zk = shfl_u64(cincl, 63);
         const u64 row = (u64)(p.row_offset + b);
         u64 a = p.seed ^ (0xD1B54A32D192ED03ull * (row + 1));
         const u64 rnd = mis_splitmix64(mis_splitmix64(a) + (u64)step);
         const u64 r = __umul64hi(rnd, Zk);
-        int cs = -1;
-        u64 base = 0;
-        for (int c = 0; c < p.n_chunks; ++c) {
-            u64 cm = sc->cmass[c];
-            if (r < base + cm) { cs = c; break; }
-            base += cm;
-        }
+        const unsigned long long hit = __ballot(lane < p.n_chunks && r < cincl);
+        const int cs = hit ? __ffsll((long long)hit) - 1 : -1;
+        const u64 base = cs >= 0 ? shfl_u64(cincl - cm, cs) : 0;
         if (cs >= 0) {
             const unsigned kstar = sc->kstar;
             int i0, i1;
