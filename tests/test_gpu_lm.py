@@ -55,6 +55,28 @@ def test_untied_lm_head_and_long_context():
     _check([(pairs[0][0][-40:], pairs[0][1][-40:])])
 
 
+def test_context_beyond_the_first_tile_pair():
+    # > 512 keys: the waves go round their tile loop a second time (in-loop loads), and the tile holding the new key - patched in
+    # registers, never read back from the cache - is one of those later tiles
+    cfg = ollama.LlamaConfig(**{**ollama.TINY.__dict__, "num_hidden_layers": 1})
+    W, oracle, dev = lm_pair(cfg)
+    rng = np.random.default_rng(12)
+    rows = [rng.integers(0, cfg.vocab_size, 560).astype(np.int32)]                     # 18 key tiles at the end
+    pairs = teacher_forced(oracle, dev, rows, max_context=576)
+    _check([(pairs[0][0][-48:], pairs[0][1][-48:])])                                   # positions 512..559
+
+
+@pytest.mark.parametrize("batch", [33, 64], ids=["mt3", "mt4"])
+def test_wide_batches(batch):
+    # 33 rows -> 3 MFMA column tiles, 64 -> 4 (the widest the weight-streaming GEMM takes)
+    cfg = ollama.LlamaConfig(**{**ollama.TINY.__dict__, "num_hidden_layers": 2})
+    W, oracle, dev = lm_pair(cfg)
+    rng = np.random.default_rng(13)
+    rows = [rng.integers(0, cfg.vocab_size, 6).astype(np.int32) for _ in range(batch)]
+    pairs = teacher_forced(oracle, dev, rows, max_context=64)
+    _check([pairs[0], pairs[batch // 2], pairs[batch - 1]])
+
+
 def test_batch_row_equals_single_row_bitwise():
     # Tests/ParakeetBatchParityTests.swift pattern: generateBatch(rows)[r] == generate(rows[r])
     cfg = ollama.TINY
