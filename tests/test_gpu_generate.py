@@ -132,6 +132,35 @@ def test_eos_ragged_rows_errors_and_cancel(stack):
     assert e.value.case == "modelNotInitialized"                # "SNAC model not loaded", LlamaTTS.swift:672-674
 
 
+def test_full_size_orpheus_3b_properties():
+    """BASELINE configs[2] at its real size (Orpheus-3B dims, snac_24khz, batch 32, synthetic weights) through size-independent
+    properties: seeded determinism, shard / batch-width invariance of tokens AND waveform (a row computed in a 32-row batch equals
+    the same row computed alone with its global row offset), exact integer framing, waveform range."""
+    from mlx_audio_swift_amd.synthetic import snac_synthetic_weights
+    snac_cfg = mas.SNACConfig()
+    codec = mas.SNAC.from_weights(snac_cfg, snac_synthetic_weights(snac_cfg, seed=1234))
+    cfg = mas.LlamaTTSConfiguration(rope_theta=500000.0, rope_scaling={"factor": 32.0, "low_freq_factor": 1.0, "high_freq_factor": 4.0,
+                                                                    "original_max_position_embeddings": 8192, "rope_type": "llama3"})
+    lm = mas.LlamaTTSModel.synthetic(cfg, codec=codec, seed=4321)
+    rng = np.random.default_rng(9)
+    prompts = _prompts(rng, [32] * 32)
+    gp = mas.GenerateParameters(max_tokens=21, temperature=0.6, top_p=0.8, repetition_penalty=1.3, seed=2024, frame_constrained=True)
+    pcm, toks = lm.generate_batch(prompts, gp, return_tokens=True)
+    pcm2, toks2 = lm.generate_batch(prompts, gp, return_tokens=True)
+    hop = 2048
+    for r in range(32):
+        assert np.array_equal(toks[r], toks2[r]) and np.array_equal(pcm[r], pcm2[r])
+        assert len(toks[r]) == 21 and len(pcm[r]) == 3 * hop
+        codes = oc.parse_output_row(np.concatenate([prompts[r], toks[r]]))
+        assert len(codes) == 21 and codes.min() >= 0 and codes.max() < 7 * 4096
+        assert np.isfinite(pcm[r]).all() and np.abs(pcm[r]).max() <= 1.0
+    for r in (0, 17, 31):
+        gp1 = mas.GenerateParameters(max_tokens=21, temperature=0.6, top_p=0.8, repetition_penalty=1.3, seed=2024, frame_constrained=True,
+                                     row_offset=r)
+        p1, t1 = lm.generate_batch([prompts[r]], gp1, return_tokens=True)
+        assert np.array_equal(t1[0], toks[r]) and np.array_equal(p1[0], pcm[r])
+
+
 def test_prompt_without_speech_marker_counts_towards_the_audio(stack):
     """parseOutput keeps the WHOLE sequence when the prompt has no start-of-speech marker (LlamaTTS.swift:749-752 ->
     :383-434), so prompt tokens that are audio codes are decoded too: the PCM bound must include the prompt length."""
