@@ -156,6 +156,10 @@ typedef struct {
      * (Qwen3.swift:19-29): start_of_speech 151670, end_of_speech 151671, audio_token_offset 151679, start_of_ai 151674
      * (parse fallback, :332-358; 0 = none) */
     int32_t start_of_speech_id, end_of_speech_id, audio_token_offset, start_of_ai_id;
+    /* SNAC decode granularity of generate(): 0 = the whole utterance in one decode (LlamaTTS.swift:759).  VyvoTTS decodes
+     * INDEPENDENT chunks of 50 code groups and concatenates the samples (decodeAudioFromCodes, Qwen3.swift:47-83; nothing is
+     * carried across a chunk boundary, so the waveform differs from a single decode near every boundary) */
+    int32_t codec_chunk_groups;
 } mis_lm_config;
 
 /* GenerateParameters as used by LlamaTTS.swift:573-581,691-696 (mlx-swift-lm) */

@@ -31,7 +31,7 @@ class LmConfigC(C.Structure):
                 ("rope_original_max_pos", C.c_float), ("tie_word_embeddings", C.c_int32), ("sample_rate", C.c_int32),
                 ("qk_norm", C.c_int32), ("rope_plain", C.c_int32), ("rope_ops_in_dtype", C.c_int32),
                 ("start_of_speech_id", C.c_int32), ("end_of_speech_id", C.c_int32), ("audio_token_offset", C.c_int32),
-                ("start_of_ai_id", C.c_int32)]
+                ("start_of_ai_id", C.c_int32), ("codec_chunk_groups", C.c_int32)]
 
 
 class GenParamsC(C.Structure):

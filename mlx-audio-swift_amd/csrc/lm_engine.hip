@@ -908,6 +908,62 @@ static void run_generate(mis_tts* c, const int32_t* prompt_ids, const int32_t* p
             dnoise.push_back(noise_dev[i].p);
         }
     }
+    const int chunk = c->cfg.codec_chunk_groups;
+    if (chunk > 0 && gmax > chunk) {
+        // VyvoTTS decodeAudioFromCodes (Qwen3.swift:47-83): rows longer than `chunk` groups are decoded as INDEPENDENT chunks of
+        // `chunk` groups (the last one shorter) whose samples are concatenated; shorter rows are a single chunk.  Per chunk index
+        // the rows are grouped by their chunk length, gathered, decoded together and scattered to sample offset ci*chunk*hop.
+        // Explicit noise: the caller's per-row tensors (sized for the whole utterance) are sliced at the same offsets; internal
+        // noise: the chunk index is folded into the seed (the reference draws fresh noise per chunk).
+        DevBuf<float> noise_stage[8];
+        const int n_ch = (gmax + chunk - 1) / chunk;
+        for (int ci = 0; ci < n_ch; ++ci) {
+            std::vector<std::pair<int, int>> part;                      // (chunk length in groups, row)
+            for (int b = 0; b < batch; ++b) {
+                int g = ncodes[b] / 7;
+                if (g > ci * chunk) part.push_back({std::min(chunk, g - ci * chunk), b});
+            }
+            std::stable_sort(part.begin(), part.end());
+            size_t j0 = 0;
+            while (j0 < part.size()) {
+                size_t j1 = j0;
+                while (j1 < part.size() && part[j1].first == part[j0].first) ++j1;
+                const int gc = part[j0].first, nsub = (int)(j1 - j0);
+                c->pcm_tmp.alloc((size_t)nsub * gc * hop);
+                std::vector<int32_t> rows(nsub);
+                for (int k = 0; k < nsub; ++k) {
+                    const int b = part[j0 + k].second;
+                    rows[k] = b;
+                    launch_orpheus_deinterleave(c->codes.p + (size_t)b * all_stride + (size_t)ci * chunk * 7, 7 * gc, 1, gc,
+                                                c->l0.p + (size_t)k * gc, c->l1.p + (size_t)k * gc * 2, c->l2.p + (size_t)k * gc * 4, gc, s);
+                }
+                const int32_t* cp[3] = {c->l0.p, c->l1.p, c->l2.p};
+                std::vector<const float*> nz;
+                if (snac_noise) {                                       // all rows have gmax groups here (checked above)
+                    for (int i = 0; i < sc->n_decoder_rates; ++i) {
+                        const size_t full = mis_snac_noise_len(c->codec, i, gmax), per_group = full / gmax, len = per_group * gc;
+                        noise_stage[i].alloc((size_t)nsub * len);
+                        for (int k = 0; k < nsub; ++k)
+                            HIP_CHECK(hipMemcpyAsync(noise_stage[i].p + (size_t)k * len,
+                                                     noise_dev[i].p + (size_t)rows[k] * full + (size_t)ci * chunk * per_group, len * 4,
+                                                     hipMemcpyDeviceToDevice, s));
+                        nz.push_back(noise_stage[i].p);
+                    }
+                }
+                c->row_map.alloc(batch);
+                HIP_CHECK(hipMemcpyAsync(c->row_map.p, rows.data(), nsub * sizeof(int32_t), hipMemcpyHostToDevice, s));
+                snac_decode_device(c->codec, cp, nsub, gc, snac_noise ? nz.data() : nullptr, 1,
+                                   gp->seed + 0x9E3779B97F4A7C15ull * (uint64_t)ci, c->row_map.p, gp->row_offset, c->pcm_tmp.p,
+                                   (int64_t)gc * hop, s);
+                for (int k = 0; k < nsub; ++k)
+                    HIP_CHECK(hipMemcpyAsync(pcm_dev + (size_t)rows[k] * pcm_stride + (size_t)ci * chunk * hop,
+                                             c->pcm_tmp.p + (size_t)k * gc * hop, (size_t)gc * hop * 4, hipMemcpyDeviceToDevice, s));
+                HIP_CHECK(hipStreamSynchronize(s));                     // `rows` / staging are reused by the next sub-batch
+                j0 = j1;
+            }
+        }
+        order.clear();                                                  // the whole-utterance path below has nothing left to do
+    }
     size_t i0 = 0;
     while (i0 < order.size()) {
         size_t i1 = i0;
@@ -1154,6 +1210,7 @@ extern "C" mis_status mis_tts_load(const char* model_dir, mis_snac* codec, int d
             if (mt && mt->type == JsonValue::STR && mt->str.find("qwen3") != std::string::npos) {
                 cf.qk_norm = 1; cf.rope_plain = 1;
                 cf.start_of_speech_id = 151670; cf.end_of_speech_id = 151671; cf.audio_token_offset = 151679; cf.start_of_ai_id = 151674;   // Qwen3.swift:19-29
+                cf.codec_chunk_groups = 50;                                                                                              // Qwen3.swift:47
             }
         }
         mis_status st = mis_tts_create(&cf, codec, device, &c);

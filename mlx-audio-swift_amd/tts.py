@@ -43,6 +43,7 @@ class VyvoTokens:
     end_of_ai = 151675
     pad_token = 151676
     audio_token_offset = 151679
+    codec_chunk_groups = 50          # decodeAudioFromCodes(chunkSize:), Qwen3.swift:47
 
 
 @dataclass
@@ -72,6 +73,7 @@ class LlamaTTSConfiguration:
     end_of_speech_id: int = 0
     audio_token_offset: int = 0
     start_of_ai_id: int = 0
+    codec_chunk_groups: int = 0    # VyvoTTS: 50 (independent SNAC chunks, Qwen3.swift:47-83); 0 = one decode per utterance
 
     @classmethod
     def from_dict(cls, d: dict) -> "LlamaTTSConfiguration":
@@ -96,7 +98,8 @@ class LlamaTTSConfiguration:
                               float(rs.get("original_max_position_embeddings", 8192.0)),
                               1 if self.tie_word_embeddings else 0, self.sample_rate,
                               1 if self.qk_norm else 0, 1 if self.rope_plain else 0, 1 if self.rope_ops_in_dtype else 0,
-                              self.start_of_speech_id, self.end_of_speech_id, self.audio_token_offset, self.start_of_ai_id)
+                              self.start_of_speech_id, self.end_of_speech_id, self.audio_token_offset, self.start_of_ai_id,
+                              self.codec_chunk_groups)
 
 
 class LlamaTTSModel:

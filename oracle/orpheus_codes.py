@@ -104,3 +104,32 @@ def parse_output_row_vyvo(tokens):
     f = [x for x in sl if x != VYVO_END_OF_SPEECH]
     n = (len(f) // 7) * 7
     return np.asarray([x - VYVO_AUDIO_OFFSET for x in f[:n]], np.int32)
+
+
+def decode_audio_from_codes_chunked(code_list, snac_oracle, chunk_groups=50, noises=None):
+    """VyvoTTS decodeAudioFromCodes (Qwen3.swift:47-83): at most `chunk_groups` groups -> one SNAC decode; otherwise the groups are
+    decoded chunk by chunk, every chunk an INDEPENDENT decode (decodeAudioChunk :85-114 = de-interleave + snacModel.decode), and
+    the samples are concatenated.  `noises` (optional, one [1, T_i] array per decoder block, sized for the whole utterance) is
+    sliced at the chunk's offset so that a test can inject the same noise on both sides."""
+    code_list = [int(c) for c in code_list]
+    n_groups = (len(code_list) + 1) // 7                                   # :48
+
+    def one(codes, nz):
+        l0, l1, l2 = deinterleave(codes)
+        return snac_oracle.decode([l0[None], l1[None], l2[None]], nz)[0, 0]
+
+    if n_groups <= chunk_groups:                                           # :51-55
+        return one(code_list, noises)
+    out = []
+    start = 0
+    while start < n_groups:                                                # :63-80
+        end = min(start + chunk_groups, n_groups)
+        nz = None
+        if noises is not None:
+            nz = []
+            for z in noises:
+                per_group = z.shape[-1] // n_groups
+                nz.append(z[..., start * per_group: end * per_group])
+        out.append(one(code_list[7 * start: min(7 * end, len(code_list))], nz))
+        start = end
+    return np.concatenate(out)

@@ -34,7 +34,7 @@ def test_abi_version_and_struct_layouts():
     assert _lib.lib().mis_abi_version() == 1
     assert C.sizeof(_lib.SnacConfigC) == 4 * (4 + 8 + 3 + 8 + 3)
     assert C.sizeof(_lib.GenParamsC) == 56
-    assert C.sizeof(_lib.LmConfigC) == 22 * 4
+    assert C.sizeof(_lib.LmConfigC) == 23 * 4
 
 
 @pytest.mark.skipif(_lib.lib().mis_device_count() > 0, reason="GPU present")

@@ -198,3 +198,38 @@ def test_vyvotts_token_ids_drive_the_same_loop():
     l0, l1, l2 = oc.deinterleave(oc.parse_output_row_vyvo(list(prompt) + list(toks[0])))
     ref = osn.decode([l0[None], l1[None], l2[None]], None)[0, 0]
     assert rms(pcm[0], ref) < 1e-4
+
+
+def test_vyvotts_decodes_snac_in_independent_chunks():
+    # decodeAudioFromCodes (Qwen3.swift:47-83): utterances longer than codec_chunk_groups are decoded chunk by chunk, every chunk
+    # an independent SNAC decode; explicit noise is sliced at the chunk offsets
+    ocfg_s, osn, dsn = snac_pair(SNAC_SMALL)
+    V = mas.VyvoTokens
+    lcfg = ollama.LlamaConfig(hidden_size=256, num_hidden_layers=1, intermediate_size=512, num_attention_heads=2, num_key_value_heads=1,
+                              head_dim=128, vocab_size=V.audio_token_offset + 7 * 4096, rope_theta=1e6, rope_scaling=None,
+                              tie_word_embeddings=True, qk_norm=True, rope_plain=True, rms_norm_eps=1e-6)
+    from gpu_util import lm_host_config
+    hc = lm_host_config(lcfg)
+    hc.start_of_speech_id, hc.end_of_speech_id, hc.audio_token_offset, hc.start_of_ai_id = (V.start_of_speech, V.end_of_speech,
+                                                                                           V.audio_token_offset, V.start_of_ai)
+    hc.codec_chunk_groups = 3
+    lm = mas.LlamaTTSModel.synthetic(hc, codec=dsn, seed=99)
+    rng = np.random.default_rng(21)
+    prompts = [np.asarray([V.start_of_human, 11 + r, 12, V.end_of_text, V.end_of_human, V.start_of_ai, V.start_of_speech], np.int32)
+               for r in range(2)]
+    groups = 7                                                                  # chunks of 3, 3 and 1 groups
+    gp = mas.GenerateParameters(max_tokens=7 * groups, temperature=0.0, repetition_penalty=0.0, frame_constrained=True)
+    noise = [rng.standard_normal((2, n)).astype(np.float32) for n in dsn.noise_lengths(groups)]
+    pcm, toks = lm.generate_batch(prompts, gp, snac_noise=noise, return_tokens=True)
+    whole = []
+    for r in range(2):
+        assert len(toks[r]) == 7 * groups and len(pcm[r]) == groups * 2048
+        codes = oc.parse_output_row_vyvo(list(prompts[r]) + list(toks[r]))
+        ref = oc.decode_audio_from_codes_chunked(codes, osn, chunk_groups=3, noises=[z[r:r + 1] for z in noise])
+        assert rms(pcm[r], ref) < 1e-4
+        whole.append(oc.decode_audio_from_codes_chunked(codes, osn, chunk_groups=50, noises=[z[r:r + 1] for z in noise]))
+    assert rms(pcm[0], whole[0]) > 1e-3                                         # NOT the single-decode waveform
+    # internal noise: runs, deterministic, and rows of different length (EOS) take the ragged sub-batches
+    a = lm.generate_batch(prompts, gp)
+    b = lm.generate_batch(prompts, gp)
+    assert all(np.array_equal(x, y) for x, y in zip(a, b)) and len(a[0]) == groups * 2048

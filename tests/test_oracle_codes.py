@@ -61,3 +61,35 @@ def test_wrap_and_left_pad():
     assert ids.shape == (2, 6)
     assert ids[1].tolist() == [128263, 128263, 128259, 7, 128009, 128260]
     assert mask[1].tolist() == [False, False, True, True, True, True]
+
+
+def test_vyvotts_chunked_decode_is_a_concatenation_of_independent_decodes():
+    """decodeAudioFromCodes (Qwen3.swift:47-83): <= chunk groups -> one decode; else independent chunk decodes, concatenated."""
+    from oracle import snac as osnac
+    cfg = osnac.SnacConfig(**osnac.TINY)
+    so = osnac.SnacOracle(cfg, osnac.make_synthetic_weights(cfg, seed=5))
+    rng = np.random.default_rng(4)
+    groups = 7
+    codes = []
+    for _ in range(groups):
+        codes += [int(rng.integers(0, cfg.codebook_size)) + k * 4096 for k in range(7)]
+    hop = 1
+    for r in cfg.decoder_rates:
+        hop *= r
+    hop *= cfg.vq_strides[0]
+    whole = oc.decode_audio_from_codes_chunked(codes, so, chunk_groups=50)
+    l0, l1, l2 = oc.deinterleave(codes)
+    assert np.array_equal(whole, so.decode([l0[None], l1[None], l2[None]], None)[0, 0]) and len(whole) == groups * hop
+    ch = oc.decode_audio_from_codes_chunked(codes, so, chunk_groups=3)          # chunks of 3, 3, 1 groups
+    assert len(ch) == groups * hop
+    for a, b in ((0, 3), (3, 6), (6, 7)):
+        m0, m1, m2 = oc.deinterleave(codes[7 * a: 7 * b])
+        assert np.array_equal(ch[a * hop: b * hop], so.decode([m0[None], m1[None], m2[None]], None)[0, 0])
+    assert not np.allclose(ch, whole, atol=1e-6)                                # nothing is carried across the boundaries
+    # explicit noise is sliced per chunk
+    nz = [rng.standard_normal((1, n)).astype(np.float32) for n in so.noise_lengths(groups)]
+    chn = oc.decode_audio_from_codes_chunked(codes, so, chunk_groups=3, noises=nz)
+    m0, m1, m2 = oc.deinterleave(codes[21:42])
+    per = [z.shape[-1] // groups for z in nz]
+    ref = so.decode([m0[None], m1[None], m2[None]], [z[..., 3 * p_: 6 * p_] for z, p_ in zip(nz, per)])[0, 0]
+    assert np.array_equal(chn[3 * hop: 6 * hop], ref)
