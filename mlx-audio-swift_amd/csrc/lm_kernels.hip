@@ -147,33 +147,72 @@ __global__ void __launch_bounds__(256) k_embed_rmsnorm(const bf16_t* __restrict_
                                                        bf16_t* __restrict__ h, bf16_t* __restrict__ x, int d, int vocab,
                                                        float eps, int batch) {
     __shared__ float red[4];
-    int m = blockIdx.x;
-    int id = (m < batch) ? ids[m] : 0;
-    if (id < 0 || id >= vocab) id = 0;
+    const int m = blockIdx.x;
+    // two memory round trips: (ids, positions, norm weights) then the embedding row.  8 columns (16 B) per thread and slot,
+    // EMB_SLOTS slots of 256 threads; loads unconditional on clamped addresses, everything kept in registers (no second pass).
+    constexpr int EMB_SLOTS = 6;                                        // d <= 6 * 256 * 8 = 12288
+    const int nch = d >> 3;                                             // 16-byte chunks per row (d % 8 == 0, checked at launch)
+    int id = ids[m < batch ? m : 0];
+    uint4 wq[EMB_SLOTS];
+#pragma unroll
+    for (int k = 0; k < EMB_SLOTS; ++k) {
+        const int ch = threadIdx.x + 256 * k;
+        wq[k] = reinterpret_cast<const uint4*>(wnorm)[ch < nch ? ch : 0];
+    }
+    if (m >= batch || id < 0 || id >= vocab) id = 0;
     if (threadIdx.x == 0 && m < batch) {
         int p = pos_next[m];
         pos_cur[m] = p;
         if (active[m]) pos_next[m] = p + 1;
     }
-    const bf16_t* e = emb + (size_t)id * d;
+    const uint4* e = reinterpret_cast<const uint4*>(emb + (size_t)id * d);
+    uint4 eq[EMB_SLOTS];
+#pragma unroll
+    for (int k = 0; k < EMB_SLOTS; ++k) {
+        const int ch = threadIdx.x + 256 * k;
+        eq[k] = e[ch < nch ? ch : 0];
+    }
     float ss = 0.0f;
-    for (int i = threadIdx.x; i < d; i += 256) {
-        bf16_t v = e[i];
-        h[(size_t)m * d + i] = v;
-        float f = bf16_to_f32(v);
-        ss += f * f;
+#pragma unroll
+    for (int k = 0; k < EMB_SLOTS; ++k) {
+        const int ch = threadIdx.x + 256 * k;
+        if (ch < nch) {
+            reinterpret_cast<uint4*>(h + (size_t)m * d)[ch] = eq[k];
+            const uint32_t q[4] = {eq[k].x, eq[k].y, eq[k].z, eq[k].w};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float f0 = bf16_to_f32((bf16_t)(q[j] & 0xffffu)), f1 = bf16_to_f32((bf16_t)(q[j] >> 16));
+                ss += f0 * f0; ss += f1 * f1;
+            }
+        }
     }
     float tot = block_sum_256(ss, red);
     float inv = 1.0f / sqrtf(tot / (float)d + eps);
-    for (int i = threadIdx.x; i < d; i += 256) {
-        float f = bf16_to_f32(e[i]);
-        float n = bf16_round_f32(f * inv);                       // T(x * rsqrt(mean+eps))
-        x[xpk_index(m, i, gridDim.x >> 4)] = f32_to_bf16(bf16_to_f32(wnorm[i]) * n);   // T(w * n), packed
+    const int MT = gridDim.x >> 4;
+#pragma unroll
+    for (int k = 0; k < EMB_SLOTS; ++k) {
+        const int ch = threadIdx.x + 256 * k;
+        if (ch < nch) {
+            const uint32_t q[4] = {eq[k].x, eq[k].y, eq[k].z, eq[k].w};
+            const uint32_t w[4] = {wq[k].x, wq[k].y, wq[k].z, wq[k].w};
+            uint32_t o[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float f0 = bf16_to_f32((bf16_t)(q[j] & 0xffffu)), f1 = bf16_to_f32((bf16_t)(q[j] >> 16));
+                const float w0 = bf16_to_f32((bf16_t)(w[j] & 0xffffu)), w1 = bf16_to_f32((bf16_t)(w[j] >> 16));
+                const bf16_t r0 = f32_to_bf16(w0 * bf16_round_f32(f0 * inv));      // T(w * T(x * rsqrt(mean + eps)))
+                const bf16_t r1 = f32_to_bf16(w1 * bf16_round_f32(f1 * inv));
+                o[j] = (uint32_t)r0 | ((uint32_t)r1 << 16);
+            }
+            // 8 consecutive columns of one row are one 16-byte element of the packed operand layout
+            *reinterpret_cast<uint4*>(x + xpk_index(m, ch * 8, MT)) = make_uint4(o[0], o[1], o[2], o[3]);
+        }
     }
 }
 void launch_embed_rmsnorm(const bf16_t* emb, const int32_t* ids, const uint8_t* active, int* pos_cur, int* pos_next,
                           const bf16_t* wnorm, bf16_t* h, bf16_t* x, int d, int vocab, float eps, int batch, int Mpad,
                           hipStream_t s) {
+    MIS_REQUIRE(d % 8 == 0 && d <= 6 * 256 * 8, MIS_ERR_INVALID_INPUT, "hidden size must be a multiple of 8 and <= 12288");
     hipLaunchKernelGGL(k_embed_rmsnorm, dim3(Mpad), dim3(256), 0, s, emb, ids, active, pos_cur, pos_next, wnorm, h, x, d,
                        vocab, eps, batch);
 }
