@@ -38,3 +38,60 @@ def test_decode_shapes_and_range():
     codes = np.random.default_rng(1).integers(0, cfg.codebook_size, (2, cfg.n_codebooks, 6))
     wav = m.decode_from_codes(codes)
     assert wav.shape == (2, od.num_samples(cfg, 6)) and np.abs(wav).max() <= 1.0 and wav.std() > 1e-3
+
+
+def test_decoder_matches_hf_transformers_away_from_the_right_edge():
+    """Independent implementation: HF transformers' DacModel decoder / quantizer with the oracle's (weight-norm folded) weights.
+    HF's ConvTranspose1d has no output_padding, the reference passes output_padding = 1 (one more sample on the RIGHT of every
+    block, pinned by the reference's own length tests), so the two agree sample by sample except near the right edge."""
+    from transformers import DacConfig as HFC, DacModel
+    cfg = od.DacConfig(encoder_dim=4, encoder_rates=(3, 5), latent_dim=24, decoder_dim=48, decoder_rates=(5, 3), n_codebooks=3,
+                       codebook_size=32, codebook_dim=8)
+    hc = HFC(encoder_hidden_size=4, downsampling_ratios=[3, 5], decoder_hidden_size=48, upsampling_ratios=[5, 3], n_codebooks=3,
+             codebook_size=32, codebook_dim=8, hidden_size=24, sampling_rate=16000)
+    hf = DacModel(hc).eval()
+    W = od.make_synthetic_weights(cfg, seed=11)
+    o = od.DacOracle(cfg, W)
+    sd = hf.state_dict()
+
+    def eff(p, transposed=False):                       # effective weight in torch layout
+        w = od._wn(o.w[p + ".weight_g"], o.w[p + ".weight_v"], 2 if transposed else 0)
+        return (w.permute(2, 0, 1) if transposed else w.permute(0, 2, 1)).contiguous()
+
+    def put(hf_name, p, transposed=False):
+        assert sd[hf_name + ".weight"].shape == eff(p, transposed).shape, (hf_name, p)
+        sd[hf_name + ".weight"] = eff(p, transposed)
+        sd[hf_name + ".bias"] = o.w[p + ".bias"]
+
+    put("decoder.conv1", "decoder.model.0")
+    for bi in range(2):
+        p = f"decoder.model.{bi + 1}.block"
+        sd[f"decoder.block.{bi}.snake1.alpha"] = o.w[p + ".0.alpha"].reshape(1, -1, 1)
+        put(f"decoder.block.{bi}.conv_t1", p + ".1", transposed=True)
+        for ri in range(3):
+            q = f"{p}.{ri + 2}.block"
+            h = f"decoder.block.{bi}.res_unit{ri + 1}"
+            sd[h + ".snake1.alpha"] = o.w[q + ".0.alpha"].reshape(1, -1, 1)
+            put(h + ".conv1", q + ".1")
+            sd[h + ".snake2.alpha"] = o.w[q + ".2.alpha"].reshape(1, -1, 1)
+            put(h + ".conv2", q + ".3")
+    sd["decoder.snake1.alpha"] = o.w["decoder.model.3.alpha"].reshape(1, -1, 1)
+    put("decoder.conv2", "decoder.model.4")
+    for i in range(3):
+        p = f"quantizer.quantizers.{i}"
+        sd[f"{p}.codebook.weight"] = o.w[p + ".codebook.weight"]
+        put(f"{p}.out_proj", p + ".outProj")
+    hf.load_state_dict(sd)
+    rng = np.random.default_rng(2)
+    T = 40
+    codes = rng.integers(0, 32, (2, 3, T))
+    with torch.no_grad():
+        z_hf = hf.quantizer.from_codes(torch.from_numpy(codes))[0]
+        y_hf = hf.decoder(z_hf)[:, 0].numpy()
+    z = o.from_codes(codes)
+    assert torch.allclose(z, z_hf, atol=1e-5)
+    y = o.decode_from_codes(codes)
+    assert y.shape[1] == od.num_samples(cfg, T) and y_hf.shape[1] < y.shape[1]      # the reference keeps one more sample per block
+    n = y_hf.shape[1] - 260                                                          # right-edge influence of the missing samples
+    assert n > 300
+    np.testing.assert_allclose(y[:, :n], y_hf[:, :n], rtol=1e-4, atol=2e-5)
