@@ -79,3 +79,46 @@ def test_frame_loop_is_deterministic_and_teacher_forcing_reproduces_logits():
         assert a[:, 0].max() < cfg.talker.vocab_size - 1024 and a[:, 1:].max() < cfg.predictor.vocab_size
         c, lc = m.generate_row(text_ids, codec_ids, [11, 12, cfg.tts_eos_token_id], params, max_frames=5, forced_codes=a)
         assert np.array_equal(c, a) and all(np.array_equal(x, y) for x, y in zip(la, lc[:5]))
+
+
+def test_decoder_building_blocks_match_hf_code2wav_modules():
+    """Independent implementation of the shared building blocks: HF transformers' Qwen3-Omni Code2Wav (the same vocoder family:
+    SnakeBeta, causal conv, ConvNeXt block, residual unit).  NOT compared: the transposed conv - HF trims kernel - stride samples
+    on BOTH sides, the reference on the right only (Qwen3TTSSpeechTokenizer.swift:533-551,732-749), which is what the oracle
+    restates and test_causal_transposed_conv_matches_naive_scatter pins."""
+    from transformers.models.qwen3_omni_moe import modeling_qwen3_omni_moe as hf
+    rng = np.random.default_rng(5)
+    C, T = 12, 37
+    x = torch.from_numpy(rng.standard_normal((2, C, T)).astype(np.float32))
+
+    def r(*shape, s=0.3):
+        return torch.from_numpy((rng.standard_normal(shape) * s).astype(np.float32))
+
+    with torch.no_grad():
+        # SnakeBeta
+        sb = hf.Qwen3OmniMoeSnakeBeta(C)
+        sb.alpha.copy_(r(C)); sb.beta.copy_(r(C))
+        assert torch.allclose(oq.snake_beta(x, sb.alpha, sb.beta), sb(x), atol=1e-6)
+        # causal (dilated) conv
+        for k, dil in ((7, 1), (7, 3), (7, 9), (1, 1)):
+            cc = hf.Qwen3OmniMoeCausalConvNet(C, C, k, dilation=dil)
+            w = cc.conv.weight.permute(0, 2, 1).contiguous()                                   # oracle layout [Co, k, Ci]
+            assert torch.allclose(oq.causal_conv1d(x, w, cc.conv.bias, dilation=dil), cc(x), atol=1e-5)
+        # ConvNeXt block
+        cn = hf.Qwen3OmniMoeConvNeXtBlock(C)
+        cn.gamma.copy_(r(C, s=1.0)); cn.norm.weight.copy_(1.0 + r(C)); cn.norm.bias.copy_(r(C))
+        W = {"p.dwconv.conv.weight": cn.dwconv.conv.weight.permute(0, 2, 1).contiguous(), "p.dwconv.conv.bias": cn.dwconv.conv.bias,
+             "p.norm.weight": cn.norm.weight, "p.norm.bias": cn.norm.bias, "p.pwconv1.weight": cn.pwconv1.weight,
+             "p.pwconv1.bias": cn.pwconv1.bias, "p.pwconv2.weight": cn.pwconv2.weight, "p.pwconv2.bias": cn.pwconv2.bias,
+             "p.gamma": cn.gamma}
+        o = oq.SpeechDecoderOracle(oq.DecoderConfig(), {k: v.detach().numpy() for k, v in W.items()})
+        assert torch.allclose(o.convnext(x, "p"), cn(x), atol=1e-5)
+        # residual unit (act1 -> conv k7 dilated -> act2 -> conv k1, + x), as inlined in SpeechDecoderOracle.decode
+        ru = hf.Qwen3OmniMoeCode2WavDecoderResidualUnit(C, dilation=3)
+        for a in (ru.act1, ru.act2):
+            a.alpha.copy_(r(C)); a.beta.copy_(r(C))
+        t = oq.snake_beta(x, ru.act1.alpha, ru.act1.beta)
+        t = oq.causal_conv1d(t, ru.conv1.conv.weight.permute(0, 2, 1).contiguous(), ru.conv1.conv.bias, dilation=3)
+        t = oq.snake_beta(t, ru.act2.alpha, ru.act2.beta)
+        y = x + oq.causal_conv1d(t, ru.conv2.conv.weight.permute(0, 2, 1).contiguous(), ru.conv2.conv.bias)
+        assert torch.allclose(y, ru(x), atol=1e-5)
