@@ -881,8 +881,12 @@ __global__ void __launch_bounds__(512) k_attn_decode(AttnParams p) {
         }
     }
     __builtin_amdgcn_sched_barrier(0);          // the table rows go out FIRST (vmcnt retires in issue order)
-    load_tile(min(wave, n_tiles - 1), kA, vA);  // unconditional; a wave without a tile re-reads a clamped one and discards it
-    load_tile(min(wave + ATT_WAVES, n_tiles - 1), kB, vB);
+    // wave-uniform guards: a wave without a tile requests nothing (at short contexts seven of eight waves would otherwise each
+    // pull a redundant 32 KB pair through the CU's 64 B/clk return path - 2-3 us per launch on the small models).  The price is a
+    // conservative vmcnt at the join: the prologue below then waits for the wave's own first pair as well, which measured the
+    // same as the unconditional form at long contexts (the kernel is paced by the KV stream either way).
+    if (wave < n_tiles) load_tile(wave, kA, vA);
+    if (wave + ATT_WAVES < n_tiles) load_tile(wave + ATT_WAVES, kB, vB);
     __builtin_amdgcn_sched_barrier(0);
     ATT_STAMP(2);
 #pragma unroll
