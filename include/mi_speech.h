@@ -496,6 +496,10 @@ mis_status mis_stt_whisper_generate(mis_whisper*, const float* pcm, const int64_
 /* diagnostics: microseconds per dependent kernel boundary in a replayed hipGraph of n trivial kernels
  * (mode 0: 1 block x 64 threads, 1: 32 x 1024, 2: 1024 x 256).  DESIGN.md quotes it as the launch floor. */
 mis_status mis_debug_launch_floor(int device, int n_kernels, int mode, int reps, double* us_per_kernel);
+/* diagnostics: the inter-block split-K factor the engines pick for a weight-streaming GEMM with `items` n-tile groups, `k_tiles`
+ * 32-wide k-tiles and `waves_per_item` waves per work item ("Split-K factor from a cost model"); no GPU needed
+ * (falls back to 256 CUs when no device is visible). */
+int32_t mis_debug_choose_split(int32_t items, int32_t k_tiles, int32_t waves_per_item, int32_t s_max);
 
 #ifdef __cplusplus
 }

@@ -1273,6 +1273,11 @@ __global__ void k_floor_probe(const float* __restrict__ a, float* __restrict__ b
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) b[i] = a[i] + 1.0f;
 }
+extern "C" int32_t mis_debug_choose_split(int32_t items, int32_t k_tiles, int32_t waves_per_item, int32_t s_max) {
+    if (items < 1 || k_tiles < 1 || (waves_per_item != 1 && waves_per_item != 4) || s_max < 1) return 0;
+    return gemm_choose_split(items, k_tiles, waves_per_item, s_max);
+}
+
 extern "C" mis_status mis_debug_launch_floor(int device, int n_kernels, int mode, int reps, double* us_per_kernel) {
     MIS_API_BEGIN
     MIS_REQUIRE(us_per_kernel && n_kernels >= 1 && reps >= 1, MIS_ERR_INVALID_INPUT, "bad argument");

@@ -77,3 +77,15 @@ def test_config_mirrors():
     p = mas.GenerateParameters()
     assert (p.max_tokens, p.temperature, p.top_p, p.repetition_penalty, p.repetition_context_size) == (1200, 0.6, 0.8, 1.3, 20)
     assert (mas.OrpheusTokens.start_of_speech, mas.OrpheusTokens.audio_token_offset) == (128257, 128266)
+
+
+def test_split_k_cost_model_picks_the_measured_optima():
+    """gemm_choose_split: busiest CU's share x whole-group load waste x slab overhead.  Orpheus-3B at batch 32
+    (R = 2 n-tiles per item, 4 waves per item, 256 CUs): qkv 160 items x 96 k-tiles -> S = 3 (8 k-tiles per wave, 480 blocks),
+    o_proj 96 x 96 -> S = 2, down 96 x 256 -> S = 8 - the optima of every sweep in profiles/r01_v{1,2,5}_gemm_sweep.json."""
+    L = _lib.lib()
+    assert L.mis_debug_choose_split(160, 96, 4, 8) == 3
+    assert L.mis_debug_choose_split(96, 96, 4, 16) == 2
+    assert L.mis_debug_choose_split(96, 256, 4, 16) == 8
+    assert L.mis_debug_choose_split(4, 2, 4, 16) == 1                 # tiny model: K too short to split
+    assert L.mis_debug_choose_split(0, 96, 4, 8) == 0                 # invalid arguments
