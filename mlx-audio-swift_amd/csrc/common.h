@@ -1,6 +1,7 @@
 // common.h - shared helpers for libmi_speech (gfx950 only).
 #pragma once
 #include <hip/hip_runtime.h>
+#include <algorithm>
 #include <stdint.h>
 #include <stdio.h>
 #include <stdarg.h>
@@ -69,6 +70,22 @@ struct DevBuf {
     }
     void zero(hipStream_t s) { if (p && n) HIP_CHECK(hipMemsetAsync(p, 0, n * sizeof(T), s)); }
     size_t bytes() const { return n * sizeof(T); }
+};
+
+// pinned host memory with scope lifetime; release() hands the pointer to the caller (freed later with mis_free)
+template <typename T>
+struct PinnedBuf {
+    T* p = nullptr;
+    PinnedBuf() = default;
+    explicit PinnedBuf(size_t n) { alloc(n); }
+    PinnedBuf(const PinnedBuf&) = delete;
+    PinnedBuf& operator=(const PinnedBuf&) = delete;
+    ~PinnedBuf() { if (p) (void)hipHostFree(p); }
+    void alloc(size_t n) {
+        if (p) { (void)hipHostFree(p); p = nullptr; }
+        HIP_CHECK(hipHostMalloc((void**)&p, std::max<size_t>(n, 1) * sizeof(T), 0));
+    }
+    T* release() { T* q = p; p = nullptr; return q; }
 };
 
 static inline size_t round_up(size_t a, size_t b) { return (a + b - 1) / b * b; }

@@ -811,8 +811,8 @@ static void run_generate(mis_tts* c, const int32_t* prompt_ids, const int32_t* p
     std::vector<int32_t> host_ngen(batch, 0), host_tok;
     std::vector<int32_t> emitted(batch, 0);
     bool cancelled = false;
-    int32_t* done_host = nullptr;
-    HIP_CHECK(hipHostMalloc((void**)&done_host, sizeof(int32_t), 0));
+    PinnedBuf<int32_t> done_pin(1);
+    int32_t* done_host = done_pin.p;
     *done_host = 0;
     while (steps < max_tokens) {
         int chunk = std::min(poll, max_tokens - steps);
@@ -837,7 +837,6 @@ static void run_generate(mis_tts* c, const int32_t* prompt_ids, const int32_t* p
         if (cancel && *cancel) { cancelled = true; break; }                    // Task.checkCancellation :715
         if (*done_host >= batch) break;
     }
-    (void)hipHostFree(done_host);
     check_glue_error(c);
     HIP_CHECK(hipEventRecord(ev[2], s));
     if (cancelled) {
@@ -1068,18 +1067,16 @@ extern "C" mis_status mis_tts_generate(mis_tts* c, const int32_t* prompt_ids, co
     run_generate(c, prompt_ids, prompt_lens, batch, params, snac_noise, pcm.p, cap, tokens_out != nullptr, nullptr, nullptr, nullptr, out);
     int64_t longest = 0;
     for (int b = 0; b < batch; ++b) longest = std::max(longest, out.pcm_lens[b]);
-    float* host = nullptr;
-    HIP_CHECK(hipHostMalloc((void**)&host, (size_t)batch * std::max<int64_t>(longest, 1) * 4, 0));
-    HIP_CHECK(hipMemcpy2D(host, (size_t)longest * 4, pcm.p, (size_t)cap * 4, (size_t)longest * 4, batch, hipMemcpyDeviceToHost));
-    *pcm_out = host; *pcm_stride = longest;
-    for (int b = 0; b < batch; ++b) pcm_lens[b] = out.pcm_lens[b];
+    PinnedBuf<float> host((size_t)batch * std::max<int64_t>(longest, 1));
+    HIP_CHECK(hipMemcpy2D(host.p, (size_t)longest * 4, pcm.p, (size_t)cap * 4, (size_t)longest * 4, batch, hipMemcpyDeviceToHost));
     if (tokens_out) {
-        int32_t* th = nullptr;
-        HIP_CHECK(hipHostMalloc((void**)&th, out.tokens.size() * 4 + 4, 0));
-        memcpy(th, out.tokens.data(), out.tokens.size() * 4);
-        *tokens_out = th;
+        PinnedBuf<int32_t> th(out.tokens.size() + 1);
+        memcpy(th.p, out.tokens.data(), out.tokens.size() * 4);
+        *tokens_out = th.release();
         if (tokens_stride) *tokens_stride = out.tokens_stride;
     }
+    *pcm_out = host.release(); *pcm_stride = longest;
+    for (int b = 0; b < batch; ++b) pcm_lens[b] = out.pcm_lens[b];
     if (n_tokens) for (int b = 0; b < batch; ++b) n_tokens[b] = out.n_tokens[b];
     MIS_API_END
 }

@@ -451,8 +451,8 @@ void q3_generate_codes(mis_qwen3tts* c, const int32_t* text_ids, const int32_t* 
             tts_internal_enqueue_layers(c->talker, c->in_emb.p, Mpad, c->iota.p);
         };
         if (use_graph) capture(&g_frame, frame_body);
-        int32_t* done_host = nullptr;
-        HIP_CHECK(hipHostMalloc((void**)&done_host, 4, 0));
+        PinnedBuf<int32_t> done_pin(1);
+        int32_t* done_host = done_pin.p;
         *done_host = 0;
         int f = 0;
         const int poll = 8;
@@ -463,9 +463,8 @@ void q3_generate_codes(mis_qwen3tts* c, const int32_t* text_ids, const int32_t* 
             HIP_CHECK(hipMemcpyAsync(done_host, c->done.p, 4, hipMemcpyDeviceToHost, s));
             HIP_CHECK(hipStreamSynchronize(s));
             if (*done_host >= batch) break;
-            if (cancel && *cancel) { (void)hipHostFree(done_host); throw MisError(MIS_ERR_CANCELLED, "generation cancelled"); }
+            if (cancel && *cancel) throw MisError(MIS_ERR_CANCELLED, "generation cancelled");
         }
-        (void)hipHostFree(done_host);
         HIP_CHECK(hipGetLastError());
         tts_internal_check(c->talker); tts_internal_check(c->pred);
     } catch (...) {
@@ -496,10 +495,9 @@ extern "C" mis_status mis_qwen3tts_generate_codes(mis_qwen3tts* c, const int32_t
     int stride = 0;
     q3_generate_codes(c, text_ids, codec_ids, prefill_lens, P, trailing_ids, trailing_lens, Tt, batch, params, row_max_frames, codes, nf,
                       &stride, nullptr);
-    int32_t* host = nullptr;
-    HIP_CHECK(hipHostMalloc((void**)&host, codes.size() * 4 + 4, 0));
-    memcpy(host, codes.data(), codes.size() * 4);
-    *codes_out = host; *codes_stride = stride;
+    PinnedBuf<int32_t> host(codes.size() + 1);
+    memcpy(host.p, codes.data(), codes.size() * 4);
+    *codes_out = host.release(); *codes_stride = stride;
     for (int b = 0; b < batch; ++b) n_frames[b] = nf[b];
     MIS_API_END
 }
@@ -579,10 +577,10 @@ extern "C" mis_status mis_qwen3tts_generate(mis_qwen3tts* c, const int32_t* text
     const int G = c->G, up = q3dec_total_upsample(c->dec);
     int64_t longest = 0;
     for (int b = 0; b < batch; ++b) { pcm_lens[b] = (int64_t)nf[b] * up; longest = std::max(longest, pcm_lens[b]); }
-    float* host = nullptr;
-    HIP_CHECK(hipHostMalloc((void**)&host, (size_t)std::max<int64_t>(longest, 1) * batch * 4, 0));
+    PinnedBuf<float> host_pin((size_t)std::max<int64_t>(longest, 1) * batch);
+    float* host = host_pin.p;
     memset(host, 0, (size_t)std::max<int64_t>(longest, 1) * batch * 4);
-    try {
+    {
         DevBuf<float> wav;
         DevBuf<int32_t> cd;
         // rows with the same frame count decode together (bounded by ~16 GB of activations); ragged rows one by one
@@ -615,15 +613,14 @@ extern "C" mis_status mis_qwen3tts_generate(mis_qwen3tts* c, const int32_t* text
                     on_event(user, b, MIS_EVENT_AUDIO, host + (size_t)b * longest + (size_t)f0 * up, (int64_t)fn * up);
                 }
             }
-    } catch (...) { (void)hipHostFree(host); throw; }
-    *pcm_out = host; *pcm_stride = longest;
+    }
     if (codes_out) {
-        int32_t* ch = nullptr;
-        HIP_CHECK(hipHostMalloc((void**)&ch, codes.size() * 4 + 4, 0));
-        memcpy(ch, codes.data(), codes.size() * 4);
-        *codes_out = ch;
+        PinnedBuf<int32_t> ch(codes.size() + 1);
+        memcpy(ch.p, codes.data(), codes.size() * 4);
+        *codes_out = ch.release();
         if (codes_stride) *codes_stride = stride;
     }
+    *pcm_out = host_pin.release(); *pcm_stride = longest;
     if (n_frames) for (int b = 0; b < batch; ++b) n_frames[b] = nf[b];
     MIS_API_END
 }

@@ -352,8 +352,8 @@ extern "C" mis_status mis_soprano_generate(mis_soprano* c, const int32_t* prompt
             if (pcm_lens[b] > 0)
                 soprano_decode_device(c, c->hidden.p + (size_t)b * hid_rows * C, hid_rows, 1, n_hidden[b], audio.p + (size_t)b * longest, longest, s);
     }
-    float* host = nullptr;
-    HIP_CHECK(hipHostMalloc((void**)&host, (size_t)batch * longest * 4, 0));
+    PinnedBuf<float> host_pin((size_t)batch * longest);
+    float* host = host_pin.p;
     HIP_CHECK(hipMemcpyAsync(host, audio.p, (size_t)batch * longest * 4, hipMemcpyDeviceToHost, s));
     HIP_CHECK(hipStreamSynchronize(s));
     for (int b = 0; b < batch; ++b) {                                   // audio[0, (-audioLength)...], Soprano.swift:666-671
@@ -363,14 +363,13 @@ extern "C" mis_status mis_soprano_generate(mis_soprano* c, const int32_t* prompt
             pcm_lens[b] = want;
         }
     }
-    *pcm_out = host; *pcm_stride = longest;
     if (tokens_out) {
-        int32_t* th = nullptr;
-        HIP_CHECK(hipHostMalloc((void**)&th, toks.size() * 4 + 4, 0));
-        memcpy(th, toks.data(), toks.size() * 4);
-        *tokens_out = th;
+        PinnedBuf<int32_t> th(toks.size() + 1);
+        memcpy(th.p, toks.data(), toks.size() * 4);
+        *tokens_out = th.release();
         if (tokens_stride) *tokens_stride = tstride;
     }
+    *pcm_out = host_pin.release(); *pcm_stride = longest;
     if (n_tokens) for (int b = 0; b < batch; ++b) {
         int n = ntok[b];                                                // the stop token is not a generated token (:855-857)
         if (n > 0 && toks[(size_t)b * tstride + n - 1] == c->cfg.stop_token_id) n -= 1;

@@ -629,8 +629,8 @@ extern "C" mis_status mis_stt_whisper_generate(mis_whisper* c, const float* pcm,
     q.temperature = sp->temperature > 0 ? sp->temperature : 0.0f; q.top_p = 1.0f; q.penalty = 0.0f; q.seed = sp->seed;
     q.lo = 0; q.hi = (sp->timestamp_begin > 0 && sp->timestamp_begin < c->V) ? sp->timestamp_begin : c->V;   // suppressFromIndex
     q.eos_id = sp->eot_id; q.max_tokens = max_tokens;
-    int32_t* done_host = nullptr;
-    HIP_CHECK(hipHostMalloc((void**)&done_host, 4, 0));
+    PinnedBuf<int32_t> done_pin(1);
+    int32_t* done_host = done_pin.p;
     *done_host = 0;
     // one decode step = logits GEMM -> suppress masks -> argmax / sampler -> next token through the decoder: every argument
     // is a device pointer that stays put, so the step is captured once and replayed (≈430 kernel nodes per step)
@@ -662,19 +662,16 @@ extern "C" mis_status mis_stt_whisper_generate(mis_whisper* c, const float* pcm,
         }
     } catch (...) {
         if (gexec) (void)hipGraphExecDestroy(gexec);
-        (void)hipHostFree(done_host);
         throw;
     }
     if (gexec) (void)hipGraphExecDestroy(gexec);
-    (void)hipHostFree(done_host);
     HIP_CHECK(hipGetLastError());
     std::vector<int32_t> ng(batch), toks((size_t)batch * max_tokens);
     HIP_CHECK(hipMemcpy(ng.data(), c->n_gen.p, batch * 4, hipMemcpyDeviceToHost));
     HIP_CHECK(hipMemcpy(toks.data(), c->tokens_out.p, toks.size() * 4, hipMemcpyDeviceToHost));
-    int32_t* th = nullptr;
-    HIP_CHECK(hipHostMalloc((void**)&th, toks.size() * 4 + 4, 0));
-    memcpy(th, toks.data(), toks.size() * 4);
-    *tokens_out = th; *tokens_stride = max_tokens;
+    PinnedBuf<int32_t> th(toks.size() + 1);
+    memcpy(th.p, toks.data(), toks.size() * 4);
+    *tokens_out = th.release(); *tokens_stride = max_tokens;
     for (int b = 0; b < batch; ++b) {
         // the EOT token ends the row and is not part of `generated` (:238-240)
         int n = ng[b];
