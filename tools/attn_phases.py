@@ -34,6 +34,7 @@ for new_tokens in [int(a) for a in sys.argv[1:]] or [7, 399]:
     last = a[-28:]                                  # the decode graph's 28 launches, as of the last replay
     d = np.diff(last[:, :8], axis=1).astype(np.float64)
     tot = (last[:, 7] - last[:, 0]).mean()
-    print(f"new_tokens={new_tokens}: ticks start->end mean {tot:.0f} (s_memtime ticks; 100 MHz => {tot / 100:.2f} us)")
+    print(f"new_tokens={new_tokens}: s_memtime ticks start->end, mean over the layers: {tot:.0f}  (about 2.0 ticks/ns on MI355X - calibrate "
+          f"against the kernel duration in a rocprofv3 trace; roughly {tot / 2000:.1f} us)")
     for i, nm in enumerate(names):
         print(f"   {nm:24s} {d[:, i].mean():8.1f} ticks")
