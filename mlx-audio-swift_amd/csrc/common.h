@@ -100,6 +100,12 @@ __host__ __device__ static inline float bf16_to_f32(bf16_t v) {
     return c.f;
 }
 __host__ __device__ static inline bf16_t f32_to_bf16(float f) {   // round-to-nearest-even
+#if defined(__HIP_DEVICE_COMPILE__)
+    // gfx950 has the conversion in hardware (v_cvt_pk_bf16_f32, RNE, quiet NaN): one instruction instead of the six of the
+    // integer formulation below - the step chain's kernels round at every MLX primitive boundary, so this is a large share
+    // of their VALU instruction count
+    return __builtin_bit_cast(unsigned short, (__bf16)f);
+#endif
     union { uint32_t u; float f; } c;
     c.f = f;
     uint32_t u = c.u;
