@@ -122,3 +122,44 @@ def test_decoder_building_blocks_match_hf_code2wav_modules():
         t = oq.snake_beta(t, ru.act2.alpha, ru.act2.beta)
         y = x + oq.causal_conv1d(t, ru.conv2.conv.weight.permute(0, 2, 1).contiguous(), ru.conv2.conv.bias)
         assert torch.allclose(y, ru(x), atol=1e-5)
+
+
+def test_decoder_transformer_matches_hf_code2wav_transformer_inside_the_window():
+    """The speech-tokenizer's pre-transformer (RMSNorm, RoPE, causal attention, layer scale, SwiGLU) against HF transformers'
+    Qwen3-Omni Code2Wav transformer with the same weights.  HF masks with a 72-frame sliding window, the reference with a plain
+    causal mask (Qwen3TTSSpeechTokenizer.swift:449-503: createAdditiveCausalMask), so the comparison uses T < 72; the oracle's
+    input / output projections (which HF's module does not have) are set to the identity."""
+    from transformers.models.qwen3_omni_moe import configuration_qwen3_omni_moe as hc, modeling_qwen3_omni_moe as hf
+    D, H, hd, ff, L, T = 32, 4, 8, 48, 2, 40
+    cfg = hc.Qwen3OmniMoeCode2WavConfig(hidden_size=D, num_attention_heads=H, num_key_value_heads=H, intermediate_size=ff,
+                                        num_hidden_layers=L, sliding_window=72, rms_norm_eps=1e-5, layer_scale_initial_scale=0.01,
+                                        max_position_embeddings=128, rope_parameters={"rope_type": "default", "rope_theta": 10000.0})
+    cfg._attn_implementation = "eager"
+    tm = hf.Qwen3OmniMoeCode2WavTransformerModel(cfg).eval()
+    rng = np.random.default_rng(8)
+    with torch.no_grad():
+        for prm in tm.parameters():
+            prm.copy_(torch.from_numpy((rng.standard_normal(tuple(prm.shape)) * (0.3 if prm.ndim > 1 else 1.0)).astype(np.float32))
+                      + (1.0 if prm.ndim == 1 else 0.0))
+    P = "decoder.pre_transformer"
+    W = {P + ".input_proj.weight": np.eye(D, dtype=np.float32), P + ".input_proj.bias": np.zeros(D, np.float32),
+         P + ".output_proj.weight": np.eye(D, dtype=np.float32), P + ".output_proj.bias": np.zeros(D, np.float32),
+         P + ".norm.weight": tm.norm.weight.detach().numpy()}
+    for i, lyr in enumerate(tm.layers):
+        p = f"{P}.layers.{i}"
+        for nm in ("q_proj", "k_proj", "v_proj", "o_proj"):
+            W[f"{p}.self_attn.{nm}.weight"] = getattr(lyr.self_attn, nm).weight.detach().numpy()
+        for nm in ("gate_proj", "up_proj", "down_proj"):
+            W[f"{p}.mlp.{nm}.weight"] = getattr(lyr.mlp, nm).weight.detach().numpy()
+        W[p + ".input_layernorm.weight"] = lyr.input_layernorm.weight.detach().numpy()
+        W[p + ".post_attention_layernorm.weight"] = lyr.post_attention_layernorm.weight.detach().numpy()
+        W[p + ".self_attn_layer_scale.scale"] = lyr.self_attn_layer_scale.scale.detach().numpy()
+        W[p + ".mlp_layer_scale.scale"] = lyr.mlp_layer_scale.scale.detach().numpy()
+    dc = oq.DecoderConfig(latent_dim=D, hidden_size=D, intermediate_size=ff, head_dim=hd, num_attention_heads=H, num_hidden_layers=L,
+                          num_key_value_heads=H, rms_norm_eps=1e-5, rope_theta=10000.0)
+    o = oq.SpeechDecoderOracle(dc, W)
+    x = torch.from_numpy(rng.standard_normal((2, T, D)).astype(np.float32))
+    with torch.no_grad():
+        ref = tm(inputs_embeds=x).last_hidden_state
+        got = o.transformer(x)
+    assert torch.allclose(got, ref, rtol=1e-4, atol=1e-4), float((got - ref).abs().max())
