@@ -44,7 +44,6 @@ void tts_internal_use_stream(mis_tts* c, hipStream_t s);
 void tts_internal_enqueue_layers(mis_tts* c, const bf16_t* table, int table_rows, const int32_t* ids);
 void tts_internal_enqueue_head(mis_tts* c, const bf16_t* head_packed);      // logits of the view; nullptr = own lm_head
 TtsView tts_internal_view(mis_tts* c);
-void tts_internal_check(mis_tts* c);            // throws if a fused-producer barrier of the step chain timed out
 
 // Qwen3-TTS speech-tokenizer decoder (q3_codec.hip)
 struct mis_q3dec;

@@ -52,8 +52,6 @@ struct mis_tts {
     DevBuf<uint8_t> active;
     DevBuf<bf16_t> h, x, attn_out, act, logits;
     DevBuf<float> qkv_part, part, e_buf, logits_f32, samp_l32;
-    DevBuf<int32_t> glue_flags;                     // [2L] arrival counters of the fused producers (zeroed every step) + [1] error
-    bool fuse_glue = false;
     // generation state
     DevBuf<int32_t> prompt_mat, prompt_lens, step_counter, window, window_len, n_gen, tokens_out, all_ids, all_len,
         done_count, codes, n_codes, l0, l1, l2, row_map;
@@ -405,9 +403,6 @@ static void lm_reset(mis_tts* c, int batch, int max_context) {
     HIP_CHECK(hipMemsetAsync(c->vtcache.p, 0, kv * 2, s));
     if (new_tables || !c->rope_cos.p) build_rope_tables(c);
     c->ids.alloc(Mpad); c->pos_cur.alloc(Mpad); c->pos_next.alloc(Mpad); c->active.alloc(Mpad);
-    c->glue_flags.alloc((size_t)2 * c->L + 1); c->glue_flags.zero(s);
-    // experimental, off by default: measured slower at the bench shape ("Fused producer experiment")
-    c->fuse_glue = env_int("MIS_FUSED_GLUE", 0) == 1 && d <= 12 * 1024 && d % 2 == 0;
     c->ids.zero(s); c->pos_cur.zero(s); c->pos_next.zero(s); c->active.zero(s);
     c->h.alloc((size_t)Mpad * d); c->x.alloc((size_t)Mpad * d);
     c->attn_out.alloc((size_t)Mpad * HD); c->act.alloc((size_t)Mpad * c->ff);
@@ -425,22 +420,11 @@ static void enqueue_layers(mis_tts* c, const bf16_t* table = nullptr, int table_
     hipStream_t s = c->stream;
     const int d = c->d, HD = c->H * c->D, Mpad = c->Mpad;
     const float eps = c->cfg.rms_norm_eps;
-    const bool fuse = c->fuse_glue;
-    int* flags = c->glue_flags.p;
-    int* err = flags + 2 * c->L;
-    if (fuse) HIP_CHECK(hipMemsetAsync(flags, 0, (size_t)2 * c->L * sizeof(int), s));
     launch_embed_rmsnorm(table ? table : c->emb.p, ids ? ids : c->ids.p, c->active.p, c->pos_cur.p, c->pos_next.p, c->norms.p,
                          c->h.p, c->x.p, d, table ? table_rows : c->V, eps, c->batch, Mpad, s);
     for (int li = 0; li < c->L; ++li) {
-        // the residual add + input_layernorm that follows the previous layer's down projection runs as the fused producer of
-        // this layer's qkv GEMM (layer 0: the embedding kernel already wrote x)
-        GlueFuse g1{};
-        if (fuse && li > 0) {
-            g1.slabs = c->part.p; g1.S = c->S_down; g1.N = d; g1.rows = Mpad; g1.h = c->h.p; g1.wnorm = c->norms.p + (size_t)(2 * li) * d;
-            g1.eps = eps; g1.x = c->x.p; g1.flag = flags + 2 * li; g1.error = err;
-        }
         launch_gemm_skinny(EPI_PARTIAL, c->r_part, c->ksb_part, c->wqkv.p + layer_qkv_elems(c) * li, c->x.p, c->qkv_part.p, c->Nqkv / 16,
-                           d / 32, c->S_qkv, c->Nqkv, Mpad, s, nullptr, (fuse && li > 0) ? &g1 : nullptr);
+                           d / 32, c->S_qkv, c->Nqkv, Mpad, s);
         AttnParams ap{};
         ap.qkv_part = c->qkv_part.p; ap.S = c->S_qkv; ap.Mpad = Mpad; ap.Nqkv = c->Nqkv;
         size_t lkv = (size_t)c->batch * c->Hkv * c->Smax * c->D;
@@ -458,30 +442,14 @@ static void enqueue_layers(mis_tts* c, const bf16_t* table = nullptr, int table_
         launch_attn_decode(ap, c->batch, s);
         launch_gemm_skinny(EPI_PARTIAL, c->r_part, c->ksb_part, c->wo.p + layer_o_elems(c) * li, c->attn_out.p, c->part.p, d / 16, HD / 32,
                            c->S_o, d, Mpad, s);
-        // residual add + post_attention_layernorm: fused producer of the gate/up GEMM
-        GlueFuse g2{};
-        if (fuse) {
-            g2.slabs = c->part.p; g2.S = c->S_o; g2.N = d; g2.rows = Mpad; g2.h = c->h.p; g2.wnorm = c->norms.p + (size_t)(2 * li + 1) * d;
-            g2.eps = eps; g2.x = c->x.p; g2.flag = flags + 2 * li + 1; g2.error = err;
-        } else {
-            launch_reduce_residual_rmsnorm(c->part.p, c->S_o, Mpad, d, c->h.p, c->norms.p + (size_t)(2 * li + 1) * d, c->x.p, eps, s);
-        }
+        launch_reduce_residual_rmsnorm(c->part.p, c->S_o, Mpad, d, c->h.p, c->norms.p + (size_t)(2 * li + 1) * d, c->x.p, eps, s);
         launch_gemm_skinny(EPI_SILU_MUL, 2, c->ksb_gu, c->wgu.p + layer_gu_elems(c) * li, c->x.p, c->act.p, 2 * c->ff / 16, d / 32,
-                           1, c->ff, Mpad, s, nullptr, fuse ? &g2 : nullptr);
+                           1, c->ff, Mpad, s);
         launch_gemm_skinny(EPI_PARTIAL, c->r_part, c->ksb_part, c->wdown.p + layer_down_elems(c) * li, c->act.p, c->part.p, d / 16,
                            c->ff / 32, c->S_down, d, Mpad, s);
-        if (!fuse || li + 1 == c->L) {
-            const bf16_t* next_norm = c->norms.p + (size_t)(li + 1 < c->L ? 2 * (li + 1) : 2 * c->L) * d;
-            launch_reduce_residual_rmsnorm(c->part.p, c->S_down, Mpad, d, c->h.p, next_norm, c->x.p, eps, s);
-        }
+        const bf16_t* next_norm = c->norms.p + (size_t)(li + 1 < c->L ? 2 * (li + 1) : 2 * c->L) * d;
+        launch_reduce_residual_rmsnorm(c->part.p, c->S_down, Mpad, d, c->h.p, next_norm, c->x.p, eps, s);
     }
-}
-// a fused producer's bounded spin gave up (should never happen: the producer blocks are the launch's lowest block ids)
-static void check_glue_error(mis_tts* c) {
-    if (!c->fuse_glue || !c->glue_flags.p) return;
-    int32_t e = 0;
-    HIP_CHECK(hipMemcpy(&e, c->glue_flags.p + 2 * c->L, 4, hipMemcpyDeviceToHost));
-    if (e) { (void)hipMemset(c->glue_flags.p + 2 * c->L, 0, 4); throw MisError(MIS_ERR_GENERATION_FAILED, "fused producer barrier timed out"); }
 }
 static void enqueue_lm_head(mis_tts* c, const bf16_t* head = nullptr) {
     launch_gemm_skinny(EPI_BF16, 2, c->ksb_head, head ? head : c->lm_head.p, c->x.p, c->logits.p, c->Vpad / 16, c->d / 32, 1,
@@ -564,7 +532,6 @@ extern "C" mis_status mis_lm_forward_hidden(mis_tts* c, const int32_t* ids, cons
     }
     HIP_CHECK(hipGetLastError());
     HIP_CHECK(hipStreamSynchronize(s));
-    check_glue_error(c);
     MIS_API_END
 }
 
@@ -837,7 +804,6 @@ static void run_generate(mis_tts* c, const int32_t* prompt_ids, const int32_t* p
         if (cancel && *cancel) { cancelled = true; break; }                    // Task.checkCancellation :715
         if (*done_host >= batch) break;
     }
-    check_glue_error(c);
     HIP_CHECK(hipEventRecord(ev[2], s));
     if (cancelled) {
         for (auto& e : ev) (void)hipEventDestroy(e);
@@ -1341,4 +1307,3 @@ TtsView tts_internal_view(mis_tts* c) {
     v.finalized = c->finalized ? 1 : 0; v.L = c->L;
     return v;
 }
-void tts_internal_check(mis_tts* c) { check_glue_error(c); }

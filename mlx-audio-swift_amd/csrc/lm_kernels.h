@@ -29,25 +29,8 @@ void launch_reduce_residual_rmsnorm(const float* slabs, int S, int Mpad, int N, 
 // ksb = 1: each wave an independent item; ksb = 4: the block's 4 waves split the item's K range (LDS combine)
 // bias (bf16 [N], optional): added once (slab 0 / final epilogue).  EPI_GELU_PACKED: T(gelu(T(xW+b))) written
 // in the packed fragment layout (it is the next GEMM's X operand).  EPI_SILU_PACKED: h = T(xW+b), T(h * T(sigmoid(h))) packed.
-// Optional fused producer ("glue role"): the GEMM's lowest blocks first compute the GEMM's OWN X operand - split-K slab reduce of
-// the previous GEMM + residual add + RMSNorm / LayerNorm (what k_reduce_residual_rmsnorm does as a separate launch) - while every
-// block already has its first weight tiles in flight; the blocks then meet on an arrival counter (release fence -> atomic arrive;
-// agent-scope poll -> acquire fence; bounded spin) and stream on.  One launch and one cold-start memory latency less per pair.
-struct GlueFuse {
-    const float* slabs;      // [S][rows][N] partials of the previous GEMM
-    int S, N, rows;          // N = hidden size (= K of this GEMM), rows = Mpad
-    bf16_t* h;               // residual stream [rows][N], updated in place
-    const bf16_t* wnorm;     // [N]
-    const bf16_t* ln_bias;   // null: RMSNorm; else LayerNorm bias
-    float eps;
-    bf16_t* x;               // packed output (the X operand of the launch)
-    int* flag;               // arrival counter, zero before the launch; null = no fused producer
-    int* error;              // set to 1 when a bounded spin gives up
-    int spin_limit;          // polls before giving up
-    int pre_sleep;           // s_sleep(127) periods (~3.4 us each at 2.4 GHz) before the first poll
-};
 void launch_gemm_skinny(int epi, int R, int ksb, const bf16_t* Wp, const bf16_t* X, void* out, int NT, int KT, int S,
-                        int N_out, int Mpad, hipStream_t s, const bf16_t* bias = nullptr, const GlueFuse* glue = nullptr);
+                        int N_out, int Mpad, hipStream_t s, const bf16_t* bias = nullptr);
 
 // split-K factor of a weight-streaming GEMM (items = n-tile groups, KT = k-tiles, ksb = waves per item), see the definition
 int gemm_choose_split(int items, int KT, int ksb, int s_max);

@@ -440,98 +440,15 @@ __device__ __forceinline__ void gemm_epilogue(const f32x4_t (&acc)[R][MT], void*
     }
 }
 
-// One row of the fused producer, executed by a whole 256-thread block (see GlueFuse).  Arithmetic and rounding points are those of
-// k_reduce_residual_rmsnorm: o = T(sum_s slab_s) in slab order, h = T(h + o), x = T(w * T(h * rsqrt(mean h^2 + eps))) (or LayerNorm).
-// The f32 statistics are summed in an order that depends on N only, so a row's result does not depend on the batch it sits in.
-__device__ __forceinline__ float glue_block_sum(float v, float* red) {
-    v = wave_sum(v);
-    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
-    __syncthreads();
-    float t = red[0] + red[1] + red[2] + red[3];
-    __syncthreads();
-    return t;
-}
-__device__ void glue_row_256(const GlueFuse& g, int m, float* rowbuf, float* red) {
-    const int tid = threadIdx.x, N = g.N, MTt = g.rows >> 4;
-    float ss = 0.0f, sum = 0.0f;
-    for (int c0 = 0; c0 < N; c0 += 256 * 4) {
-        float acc[4], hv[4];
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const int i = c0 + tid + k * 256;
-            acc[k] = 0.0f;
-            hv[k] = (i < N) ? bf16_to_f32(g.h[(size_t)m * N + i]) : 0.0f;
-        }
-        for (int s0 = 0; s0 < g.S; s0 += 8) {
-            float v[8][4];
-#pragma unroll
-            for (int j = 0; j < 8; ++j)
-#pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    const int i = c0 + tid + k * 256;
-                    v[j][k] = (s0 + j < g.S && i < N) ? g.slabs[((size_t)(s0 + j) * g.rows + m) * N + i] : 0.0f;
-                }
-#pragma unroll
-            for (int j = 0; j < 8; ++j)
-#pragma unroll
-                for (int k = 0; k < 4; ++k) acc[k] += v[j][k];
-        }
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const int i = c0 + tid + k * 256;
-            if (i < N) {
-                const float hn = bf16_round_f32(hv[k] + bf16_round_f32(acc[k]));
-                g.h[(size_t)m * N + i] = f32_to_bf16(hn);
-                rowbuf[i] = hn;
-                ss += hn * hn;
-                sum += hn;
-            }
-        }
-    }
-    // x is consumed by the other blocks of this SAME launch: written through to memory with agent-scope (sc1) 32-bit stores so
-    // that no L2 write-back fence is needed (a full release fence per wave cost ~60 us per launch here); N is even.
-    auto put2 = [&](int i, float a, float b) {
-        const unsigned v = (unsigned)f32_to_bf16(a) | ((unsigned)f32_to_bf16(b) << 16);
-        __hip_atomic_store(reinterpret_cast<unsigned*>(g.x + xpk_index(m, i, MTt)), v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    };
-    __syncthreads();                                  // rowbuf complete
-    if (g.ln_bias) {
-        const float mean = glue_block_sum(sum, red) / (float)N;
-        float sq = 0.0f;
-        for (int i = tid; i < N; i += 256) { const float d = rowbuf[i] - mean; sq += d * d; }
-        const float rstd = 1.0f / sqrtf(glue_block_sum(sq, red) / (float)N + g.eps);
-        for (int i = tid * 2; i < N; i += 512)
-            put2(i, (rowbuf[i] - mean) * rstd * bf16_to_f32(g.wnorm[i]) + bf16_to_f32(g.ln_bias[i]),
-                 (rowbuf[i + 1] - mean) * rstd * bf16_to_f32(g.wnorm[i + 1]) + bf16_to_f32(g.ln_bias[i + 1]));
-    } else {
-        const float inv = 1.0f / sqrtf(glue_block_sum(ss, red) / (float)N + g.eps);
-        for (int i = tid * 2; i < N; i += 512)
-            put2(i, bf16_to_f32(g.wnorm[i]) * bf16_round_f32(rowbuf[i] * inv), bf16_to_f32(g.wnorm[i + 1]) * bf16_round_f32(rowbuf[i + 1] * inv));
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this thread's write-through stores are performed
-    __syncthreads();                                  // rowbuf is reused by the next row of this block
-}
-
-template <int MT, int R, int EPI, int KSB, bool FUSED>
+template <int MT, int R, int EPI, int KSB>
 __global__ void __launch_bounds__(256) k_gemm_skinny(const bf16_t* __restrict__ Wp, const bf16_t* __restrict__ X,
                                                      void* __restrict__ out, int NT, int KT, int S, int n_items,
                                                      int N_out, int Mpad, int dbg_xfixed,
-                                                     const bf16_t* __restrict__ bias, GlueFuse glue) {
+                                                     const bf16_t* __restrict__ bias) {
     static_assert(EPI != EPI_SILU_MUL || R == 2, "silu-mul epilogue pairs a gate tile with an up tile");
-    extern __shared__ __attribute__((aligned(16))) float glue_lds[];       // [N + 8] only when a producer is fused
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    // fused producer: the first glue.rows blocks are pure producers (one row each) and leave after signalling
-    const int pblocks = FUSED ? glue.rows : 0;       // (FUSED = false compiles the producer, the wait and the idle waves out)
-    if (FUSED && (int)blockIdx.x < pblocks) {
-        glue_row_256(glue, blockIdx.x, glue_lds, glue_lds + glue.N);     // ends with vmcnt(0) + barrier: x is in memory
-        if (threadIdx.x == 0) __hip_atomic_fetch_add(glue.flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        return;
-    }
-    const int gblock = blockIdx.x - pblocks;
-    int item = (KSB == 1) ? gblock * 4 + wave : gblock;
-    const bool idle = item >= n_items;                // (KSB == 1: a wave of the last block may have no item)
-    if (idle && !FUSED) return;
-    if (idle) item = n_items - 1;                     // keeps the address arithmetic valid; the epilogue is skipped
+    const int item = (KSB == 1) ? blockIdx.x * 4 + wave : blockIdx.x;
+    if (item >= n_items) return;                      // (KSB == 1: a wave of the last block may have no item)
     const int ntg = item / S, ks = item - ntg * S;
     int kt0 = (int)(((long long)KT * ks) / S), kt1 = (int)(((long long)KT * (ks + 1)) / S);
     if (KSB > 1) {                                    // this wave's quarter of the item's K range
@@ -593,25 +510,9 @@ __global__ void __launch_bounds__(256) k_gemm_skinny(const bf16_t* __restrict__ 
         }                                                                                          \
     }
     const bool has_k = kt0 < kt1;
-    if (has_k) { GEMM_LOAD_W(wA, kt0) }               // weights do not depend on the producer: in flight while it runs
-    if (FUSED) {                                      // wait for the fused producer's rows (acquire)
-        if (threadIdx.x < 64) {
-            if (threadIdx.x == 0) {
-                // hundreds of blocks wait on ONE word: poll sparsely (a hot address serialises at its memory channel)
-                for (int i = 0; i < glue.pre_sleep; ++i) __builtin_amdgcn_s_sleep(127);
-                int spins = 0;
-                while (__hip_atomic_load(glue.flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < glue.rows) {
-                    __builtin_amdgcn_s_sleep(20);
-                    if (++spins > glue.spin_limit) { *glue.error = 1; break; }
-                }
-            }
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");      // one wave: invalidates this CU's L1 / the XCD's stale x lines
-        }
-        __syncthreads();
-    }
     if (has_k) {
         int kt = kt0;
-        GEMM_LOAD_X(xA, kt)
+        GEMM_LOAD(wA, xA, kt)
         // steady state: groups kt and kt + U are full and both following loads exist
         // (sched barriers: the next group is REQUESTED before the current one is waited for - left alone the scheduler sinks
         // the loads in between the MFMAs, i.e. behind the wait for the current group)
@@ -648,7 +549,6 @@ __global__ void __launch_bounds__(256) k_gemm_skinny(const bf16_t* __restrict__ 
 #undef GEMM_LOAD_X
 #undef GEMM_MATH_FULL
 #undef GEMM_MATH_TAIL
-    if (FUSED && idle) return;
 
     if (KSB == 1) {
         gemm_epilogue<MT, R, EPI>(acc, out, ntg, ks, NT, N_out, Mpad, lane, -1, bias);
@@ -681,29 +581,14 @@ __global__ void __launch_bounds__(256) k_gemm_skinny(const bf16_t* __restrict__ 
 
 template <int MT>
 static void launch_gemm_mt(int epi, int R, int ksb, const bf16_t* Wp, const bf16_t* X, void* out, int NT, int KT, int S,
-                           int N_out, int Mpad, const bf16_t* bias, hipStream_t s, const GlueFuse* glue) {
+                           int N_out, int Mpad, const bf16_t* bias, hipStream_t s) {
     int n_items = ((NT + R - 1) / R) * S;
     static const int dbg = getenv("MIS_GEMM_DEBUG_XFIXED") ? atoi(getenv("MIS_GEMM_DEBUG_XFIXED")) : 0;
-    GlueFuse gf{};
-    size_t smem = 0;
-    if (glue) {
-        gf = *glue; smem = ((size_t)gf.N + 8) * sizeof(float);
-        static const int lim = getenv("MIS_GLUE_SPIN") ? atoi(getenv("MIS_GLUE_SPIN")) : (1 << 20);
-        gf.spin_limit = lim;
-        static const int pre = getenv("MIS_GLUE_PRESLEEP") ? atoi(getenv("MIS_GLUE_PRESLEEP")) : 1;
-        gf.pre_sleep = pre;
-    }
-    dim3 grid((ksb == 1 ? (n_items + 3) / 4 : n_items) + (glue ? gf.rows : 0)), block(256);
+    dim3 grid(ksb == 1 ? (n_items + 3) / 4 : n_items), block(256);
 #define GEMM_CASE(E, RR, KS)                                                                                  \
-    if (epi == E && R == RR && ksb == KS && !glue) {                                                          \
-        hipLaunchKernelGGL((k_gemm_skinny<MT, RR, E, KS, false>), grid, block, 0, s, Wp, X, out, NT, KT, S,       \
-                           n_items, N_out, Mpad, dbg, bias, gf);                                                  \
-        return;                                                                                               \
-    }
-#define GEMM_CASE_FUSED(E, RR, KS)                                                                            \
-    if (epi == E && R == RR && ksb == KS && glue) {                                                           \
-        hipLaunchKernelGGL((k_gemm_skinny<MT, RR, E, KS, true>), grid, block, smem, s, Wp, X, out, NT, KT, S,     \
-                           n_items, N_out, Mpad, dbg, bias, gf);                                                  \
+    if (epi == E && R == RR && ksb == KS) {                                                                   \
+        hipLaunchKernelGGL((k_gemm_skinny<MT, RR, E, KS>), grid, block, 0, s, Wp, X, out, NT, KT, S, n_items,     \
+                           N_out, Mpad, dbg, bias);                                                               \
         return;                                                                                               \
     }
     GEMM_CASE(EPI_PARTIAL, 1, 1)
@@ -718,29 +603,18 @@ static void launch_gemm_mt(int epi, int R, int ksb, const bf16_t* Wp, const bf16
     GEMM_CASE(EPI_GELU_PACKED, 1, 4)
     GEMM_CASE(EPI_BF16, 1, 4)
     GEMM_CASE(EPI_SILU_PACKED, 2, 4)
-    GEMM_CASE_FUSED(EPI_PARTIAL, 1, 1)              // the fused producer feeds qkv (partial / bf16) and gate+up (silu-mul) only
-    GEMM_CASE_FUSED(EPI_PARTIAL, 1, 4)
-    GEMM_CASE_FUSED(EPI_PARTIAL, 2, 1)
-    GEMM_CASE_FUSED(EPI_PARTIAL, 2, 4)
-    GEMM_CASE_FUSED(EPI_BF16, 2, 1)
-    GEMM_CASE_FUSED(EPI_BF16, 2, 4)
-    GEMM_CASE_FUSED(EPI_SILU_MUL, 2, 1)
-    GEMM_CASE_FUSED(EPI_SILU_MUL, 2, 4)
 #undef GEMM_CASE
-#undef GEMM_CASE_FUSED
     throw MisError(MIS_ERR_GENERATION_FAILED, "unsupported GEMM variant");
 }
 
 void launch_gemm_skinny(int epi, int R, int ksb, const bf16_t* Wp, const bf16_t* X, void* out, int NT, int KT, int S,
-                        int N_out, int Mpad, hipStream_t s, const bf16_t* bias, const GlueFuse* glue) {
+                        int N_out, int Mpad, hipStream_t s, const bf16_t* bias) {
     MIS_REQUIRE(epi == EPI_PARTIAL || S == 1, MIS_ERR_GENERATION_FAILED, "split-K needs the partial epilogue");
-    MIS_REQUIRE(!glue || (glue->flag && glue->error && glue->rows == Mpad && glue->N == KT * 32 && glue->N <= 12 * 1024 && glue->x == X),
-                MIS_ERR_GENERATION_FAILED, "bad fused-producer arguments");
     switch (Mpad / 16) {
-        case 1: launch_gemm_mt<1>(epi, R, ksb, Wp, X, out, NT, KT, S, N_out, Mpad, bias, s, glue); break;
-        case 2: launch_gemm_mt<2>(epi, R, ksb, Wp, X, out, NT, KT, S, N_out, Mpad, bias, s, glue); break;
-        case 3: launch_gemm_mt<3>(epi, R, ksb, Wp, X, out, NT, KT, S, N_out, Mpad, bias, s, glue); break;
-        case 4: launch_gemm_mt<4>(epi, R, ksb, Wp, X, out, NT, KT, S, N_out, Mpad, bias, s, glue); break;
+        case 1: launch_gemm_mt<1>(epi, R, ksb, Wp, X, out, NT, KT, S, N_out, Mpad, bias, s); break;
+        case 2: launch_gemm_mt<2>(epi, R, ksb, Wp, X, out, NT, KT, S, N_out, Mpad, bias, s); break;
+        case 3: launch_gemm_mt<3>(epi, R, ksb, Wp, X, out, NT, KT, S, N_out, Mpad, bias, s); break;
+        case 4: launch_gemm_mt<4>(epi, R, ksb, Wp, X, out, NT, KT, S, N_out, Mpad, bias, s); break;
         default: throw MisError(MIS_ERR_INVALID_INPUT, "batch per GPU must be <= 64");
     }
 }

@@ -466,7 +466,6 @@ void q3_generate_codes(mis_qwen3tts* c, const int32_t* text_ids, const int32_t* 
             if (cancel && *cancel) throw MisError(MIS_ERR_CANCELLED, "generation cancelled");
         }
         HIP_CHECK(hipGetLastError());
-        tts_internal_check(c->talker); tts_internal_check(c->pred);
     } catch (...) {
         if (g_prefill) (void)hipGraphExecDestroy(g_prefill);
         if (g_frame) (void)hipGraphExecDestroy(g_frame);

@@ -107,7 +107,7 @@ __global__ void __launch_bounds__(256) k_gemm_big(BigGemmParams p) {
 }
 
 void launch_gemm_big(int epi, const BigGemmParams& p, hipStream_t s) {
-    MIS_REQUIRE(p.K % BG_BK == 0 && p.ldx % 8 == 0 && p.N % 4 == 0, MIS_ERR_INVALID_INPUT, "big GEMM needs K % 32 == 0");
+    MIS_REQUIRE(p.K % BG_BK == 0 && p.ldx % 8 == 0 && p.N % 4 == 0, MIS_ERR_INVALID_INPUT, "big GEMM needs K %% 32 == 0");
     dim3 grid(cdiv(p.N, BG_BN), cdiv(p.M, BG_BM)), block(256);
     switch (epi) {
         case BG_NONE: hipLaunchKernelGGL((k_gemm_big<BG_NONE>), grid, block, 0, s, p); break;

@@ -71,3 +71,57 @@ class InfoEvent:
 class AudioEvent:
     row: int
     audio: np.ndarray
+
+
+def stream_events(start_call, decode_event, cancel_flag=None):
+    """Run a blocking `mis_*_generate_stream` C call on a worker thread and yield its events as the callback fires
+    (the Swift shim does the same hop into an AsyncThrowingStream continuation, LlamaTTS.swift:792-911).
+    start_call(cb, cancel_flag_address) -> status runs the C call; decode_event(row, kind, payload, n) -> event object.
+    Closing the generator early sets the cancel flag (continuation.onTermination -> task.cancel()); `cancel_flag` (a
+    ctypes.c_int the caller may set from another thread) is used instead of a private flag when given."""
+    import ctypes as C
+    import queue
+    import threading
+
+    q: "queue.Queue" = queue.Queue()
+    flag = cancel_flag if cancel_flag is not None else C.c_int(0)
+    DONE = object()
+
+    def cb(user, row, kind, payload, n):
+        q.put(decode_event(row, kind, payload, n))
+
+    cbf = _lib.EVENT_CB(cb)
+
+    def run():
+        try:
+            st = start_call(cbf, C.addressof(flag))
+            q.put((DONE, st, _lib.last_error() if st != _lib.MIS_OK else ""))     # last_error is thread-local: read it here
+        except BaseException as e:  # pragma: no cover
+            q.put((DONE, -1, repr(e)))
+
+    th = threading.Thread(target=run, daemon=True)
+    th.start()
+    try:
+        while True:
+            ev = q.get()
+            if isinstance(ev, tuple) and len(ev) == 3 and ev[0] is DONE:
+                if ev[1] != _lib.MIS_OK:
+                    raise AudioGenerationError(ev[1] if ev[1] >= 0 else 2, ev[2])
+                return
+            yield ev
+    finally:
+        flag.value = 1
+        th.join()
+
+
+def decode_audio_event(row, kind, payload, n):
+    """payload of the three AudioGeneration cases (GenerationTypes.swift:50-61) -> host events"""
+    import ctypes as C
+    if kind == _lib.EVENT_TOKEN:
+        return TokenEvent(row, C.cast(payload, C.POINTER(C.c_int32))[0])
+    if kind == _lib.EVENT_INFO:
+        i = C.cast(payload, C.POINTER(_lib.GenInfoC))[0]
+        return InfoEvent(row, AudioGenerationInfo(i.prompt_token_count, i.generation_token_count, i.prefill_time,
+                                                  i.generate_time, i.tokens_per_second, i.peak_memory_gb))
+    a = np.ctypeslib.as_array(C.cast(payload, C.POINTER(C.c_float)), shape=(max(n, 1),))[:n].copy()
+    return AudioEvent(row, a)

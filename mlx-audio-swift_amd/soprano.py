@@ -16,7 +16,7 @@ import numpy as np
 from . import _lib
 from .codecs import _tensor_args
 from .generation import AudioGenerationError, GenerateParameters, check
-from .tts import LlamaTTSConfiguration, LlamaTTSModel
+from .tts import MAX_BATCH, LlamaTTSConfiguration, LlamaTTSModel
 
 
 @dataclass
@@ -225,8 +225,20 @@ class SopranoModel:
 
     def generate_batch(self, prompt_rows, generation_parameters: GenerateParameters | None = None,
                        return_tokens: bool = False):
-        """One generate per tokenised sentence prompt, batched: list of 1-D float32 arrays."""
+        """One generate per tokenised sentence prompt, batched: list of 1-D float32 arrays.  More rows than the engine's
+        per-call maximum run in slices of MAX_BATCH (the reference loops sentence by sentence, Soprano.swift:637-676);
+        the RNG is keyed by the global row index, so slicing does not change any row."""
         gp = generation_parameters or self.default_generation_parameters
+        if len(prompt_rows) > MAX_BATCH:
+            from dataclasses import replace
+            outs, toks_all = [], []
+            for i in range(0, len(prompt_rows), MAX_BATCH):
+                r = self.generate_batch(prompt_rows[i:i + MAX_BATCH], replace(gp, row_offset=gp.row_offset + i), return_tokens)
+                if return_tokens:
+                    outs += r[0]; toks_all += r[1]
+                else:
+                    outs += r
+            return (outs, toks_all) if return_tokens else outs
         flat, lens = LlamaTTSModel._flatten(prompt_rows)
         B = len(lens)
         gpc = gp.to_c()
@@ -250,8 +262,8 @@ class SopranoModel:
 
     def generate(self, text: str, voice=None, split_pattern: str = "\n",
                  generation_parameters: GenerateParameters | None = None) -> np.ndarray:
-        """generate(text:voice:splitPattern:parameters:) (Soprano.swift:577-690).  All sentence prompts of the
-        text run as ONE batch (the reference loops over them); parts are concatenated in order."""
+        """generate(text:voice:splitPattern:parameters:) (Soprano.swift:577-690).  The sentence prompts of the text run
+        batched, up to MAX_BATCH per engine call (the reference loops over them); parts are concatenated in order."""
         if self.tokenizer is None:
             raise AudioGenerationError(1, "Tokenizer not loaded")
         gp = generation_parameters or self.default_generation_parameters

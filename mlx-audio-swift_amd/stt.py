@@ -61,10 +61,12 @@ class STTGenerateParameters:
     temperature: float = 0.0
     language: str | None = None
     seed: int = 0
-    eot_id: int = 50257
-    timestamp_begin: int = 0
-    suppress_tokens: list = field(default_factory=list)
-    begin_suppress_tokens: list | None = None       # default [eot] (WhisperModel.swift:218)
+    # tokenizer-owned ids: None = take them from the attached tokenizer (tokenizer.endOfTextId / timestampBeginId,
+    # WhisperModel.swift:218,236,238); generate() raises when neither the tokenizer nor the parameters provide them
+    eot_id: int | None = None
+    timestamp_begin: int | None = None
+    suppress_tokens: list | None = None             # None = generationConfig?.suppressTokens ?? [] (:219)
+    begin_suppress_tokens: list | None = None       # None = generationConfig?.beginSuppressTokens ?? [eot] (:218)
 
 
 @dataclass
@@ -89,7 +91,10 @@ class WhisperModel:
     def __init__(self, config: WhisperConfig, device: int = 0):
         self.config = config
         self.device = device
-        self.tokenizer = None            # any object with decode(list[int]) -> str and build_prompt_tokens(language, task)
+        # any object with decode(list[int]) -> str, build_prompt_tokens(language, task) and the attributes end_of_text_id,
+        # timestamp_begin_id, is_multilingual, language_to_id (WhisperTokenizer.swift)
+        self.tokenizer = None
+        self.generation_config = None    # optional dict: suppress_tokens / begin_suppress_tokens (generation_config.json)
         h = C.c_void_p()
         cfg = config.to_c()
         check(_lib.lib().mis_whisper_create(C.byref(cfg), device, C.byref(h)))
@@ -112,7 +117,9 @@ class WhisperModel:
 
     @classmethod
     def from_model_directory(cls, model_dir: str, device: int = 0) -> "WhisperModel":
-        """fromDirectory: config.json + *.safetensors in the HF transformers layout (WhisperModel.swift:337-363)."""
+        """fromDirectory: config.json + *.safetensors (WhisperModel.swift:337-363) in either key layout - HF transformers
+        ("model.encoder.layers.N.self_attn.q_proj.*") or OpenAI / mlx-whisper ("encoder.blocks.N.attn.query.*", MLX conv
+        layout, no encoder positional embedding); the engine's set_tensor applies WhisperModel.sanitize (:321-478)."""
         from safetensors import safe_open
         with open(os.path.join(model_dir, "config.json")) as f:
             cfg = WhisperConfig.from_dict(json.load(f))
@@ -121,10 +128,12 @@ class WhisperModel:
             if fn.endswith(".safetensors"):
                 with safe_open(os.path.join(model_dir, fn), framework="pt") as sf:
                     for k in sf.keys():
-                        if ".blocks." in k:
-                            raise AudioGenerationError(3, "mlx-whisper key layout is not supported yet (HF layout only)")
                         m.set_tensor(k, sf.get_tensor(k))
         m.finalize()
+        gc = os.path.join(model_dir, "generation_config.json")
+        if os.path.exists(gc):
+            with open(gc) as f:
+                m.generation_config = json.load(f)
         return m
 
     def set_tensor(self, name: str, arr):
@@ -170,6 +179,7 @@ class WhisperModel:
             w = np.asarray(w, np.float32).reshape(-1)
             pcm[i, : len(w)] = w
             lens[i] = len(w)
+        params = self._resolve_parameters(params)
         prompt = np.ascontiguousarray(prompt_ids, dtype=np.int32)
         sup = np.ascontiguousarray(params.suppress_tokens or [], dtype=np.int32)
         bs = params.begin_suppress_tokens if params.begin_suppress_tokens is not None else [params.eot_id]
@@ -186,11 +196,34 @@ class WhisperModel:
         finally:
             _lib.lib().mis_free(toks)
 
+    def _resolve_parameters(self, gp: STTGenerateParameters) -> STTGenerateParameters:
+        """transcribeChunk reads the end-of-text id, the first timestamp id and the default suppress lists from the tokenizer /
+        generation config (WhisperModel.swift:218-219,236-238), never from the caller: fill what the parameters leave open."""
+        from dataclasses import replace
+        tk, gc = self.tokenizer, (self.generation_config or {})
+        eot = gp.eot_id if gp.eot_id is not None else getattr(tk, "end_of_text_id", None)
+        tsb = gp.timestamp_begin if gp.timestamp_begin is not None else getattr(tk, "timestamp_begin_id", None)
+        if eot is None or tsb is None:
+            raise AudioGenerationError(3, "end-of-text / timestamp-begin ids unknown: attach a tokenizer (end_of_text_id, "
+                                          "timestamp_begin_id) or set eot_id and timestamp_begin in STTGenerateParameters")
+        sup = gp.suppress_tokens if gp.suppress_tokens is not None else list(gc.get("suppress_tokens") or [])
+        bsup = gp.begin_suppress_tokens if gp.begin_suppress_tokens is not None else list(gc.get("begin_suppress_tokens") or [eot])
+        return replace(gp, eot_id=int(eot), timestamp_begin=int(tsb), suppress_tokens=sup, begin_suppress_tokens=bsup)
+
+    def _prompt_language(self, prompt_ids, fallback):
+        """The language token sits at prompt index 1 for multilingual models (WhisperModel.swift:271-280)."""
+        tk = self.tokenizer
+        if tk is not None and getattr(tk, "is_multilingual", False) and len(prompt_ids) > 1:
+            for code, tid in getattr(tk, "language_to_id", {}).items():
+                if tid == int(prompt_ids[1]):
+                    return code
+        return fallback
+
     def generate(self, audio, generation_parameters: STTGenerateParameters | None = None, prompt_ids=None,
                  max_batch: int = 64) -> STTOutput:
         """generate(audio:generationParameters:) (WhisperModel.swift:36-90): mono mix, hard 30 s chunking (:165-182),
         every chunk transcribed (here: batched on the device), texts joined with spaces."""
-        gp = generation_parameters or self.default_generation_parameters
+        gp = self._resolve_parameters(generation_parameters or self.default_generation_parameters)
         t0 = time.time()
         a = np.asarray(audio, np.float32)
         mono = a.mean(axis=-1) if a.ndim > 1 else a
@@ -211,7 +244,7 @@ class WhisperModel:
                 segments.append({"text": text, "start": start, "end": start + len(chunks[ci]) / SAMPLE_RATE})
         el = time.time() - t0
         n_prompt, n_gen = len(prompt_ids) * len(chunks), sum(len(t) for t in ids)
-        return STTOutput(" ".join(texts), segments or None, gp.language, n_prompt, n_gen, n_prompt + n_gen,
+        return STTOutput(" ".join(texts), segments or None, self._prompt_language(prompt_ids, gp.language), n_prompt, n_gen, n_prompt + n_gen,
                          n_prompt / el if el > 0 else 0.0, n_gen / el if el > 0 else 0.0, el, 0.0, ids)
 
     def close(self):

@@ -14,7 +14,10 @@ import numpy as np
 from . import _lib
 from .codecs import SNAC, _tensor_args
 from .generation import (AudioEvent, AudioGenerationError, AudioGenerationInfo, GenerateParameters, InfoEvent,
-                         TokenEvent, check)
+                         TokenEvent, check, decode_audio_event, stream_events)
+
+
+MAX_BATCH = 64          # rows per engine call ("batch per GPU must be 1..64", csrc/lm_engine.hip)
 
 
 class OrpheusTokens:
@@ -224,8 +227,21 @@ class LlamaTTSModel:
 
     def generate_batch(self, prompt_rows, generation_parameters: GenerateParameters | None = None, snac_noise=None,
                        return_tokens: bool = False):
-        """Batched generate on already-tokenised prompts: list of 1-D float32 arrays (one per row)."""
+        """Batched generate on already-tokenised prompts: list of 1-D float32 arrays (one per row).  More than MAX_BATCH
+        rows run in slices (RNG keyed by the global row index: slicing changes no row)."""
         gp = generation_parameters or self.default_generation_parameters
+        if len(prompt_rows) > MAX_BATCH:
+            if snac_noise is not None:
+                raise AudioGenerationError(3, f"explicit SNAC noise is limited to {MAX_BATCH} rows per call")
+            from dataclasses import replace
+            outs, toks_all = [], []
+            for i in range(0, len(prompt_rows), MAX_BATCH):
+                r = self.generate_batch(prompt_rows[i:i + MAX_BATCH], replace(gp, row_offset=gp.row_offset + i), None, return_tokens)
+                if return_tokens:
+                    outs += r[0]; toks_all += r[1]
+                else:
+                    outs += r
+            return (outs, toks_all) if return_tokens else outs
         flat, lens = self._flatten(prompt_rows)
         B = len(lens)
         gpc = gp.to_c()
@@ -252,34 +268,22 @@ class LlamaTTSModel:
         """generateStream(...) (LlamaTTS.swift:777-913): yields TokenEvent per step, then InfoEvent and
         ONE final AudioEvent (Orpheus does not stream audio chunks)."""
         text = text.replace("\\n", "\n").replace("\\t", "\t")
-        rows = self.prepare_input_ids([text], voice)
+        rows = self.prepare_input_ids([text], voice, ref_audio, ref_text)        # :806-811 passes refAudio / refText too
         yield from self.generate_stream_batch(rows, generation_parameters, snac_noise)
 
     def generate_stream_batch(self, prompt_rows, generation_parameters=None, snac_noise=None, cancel_flag=None):
+        """Events are yielded while the engine is still generating (the C call runs on a worker thread); closing the
+        generator cancels the generation at the next poll of the decode loop."""
         gp = generation_parameters or self.default_generation_parameters
         flat, lens = self._flatten(prompt_rows)
         B = len(lens)
         gpc = gp.to_c()
-        events = []
-
-        def cb(user, row, kind, payload, n):
-            if kind == _lib.EVENT_TOKEN:
-                events.append(TokenEvent(row, C.cast(payload, C.POINTER(C.c_int32))[0]))
-            elif kind == _lib.EVENT_INFO:
-                i = C.cast(payload, C.POINTER(_lib.GenInfoC))[0]
-                events.append(InfoEvent(row, AudioGenerationInfo(i.prompt_token_count, i.generation_token_count,
-                                                                 i.prefill_time, i.generate_time, i.tokens_per_second,
-                                                                 i.peak_memory_gb)))
-            else:
-                a = np.ctypeslib.as_array(C.cast(payload, C.POINTER(C.c_float)), shape=(max(n, 1),))[:n].copy()
-                events.append(AudioEvent(row, a))
-
-        cbf = _lib.EVENT_CB(cb)
         nptr, keep = self._noise_ptrs(snac_noise)
-        flag = cancel_flag if cancel_flag is not None else C.c_int(0)
-        check(_lib.lib().mis_tts_generate_stream(self._h, flat.ctypes.data, lens.ctypes.data, B, C.byref(gpc), nptr, cbf,
-                                                 None, C.addressof(flag)))
-        yield from events
+
+        def start(cbf, flag_addr):
+            return _lib.lib().mis_tts_generate_stream(self._h, flat.ctypes.data, lens.ctypes.data, B, C.byref(gpc), nptr, cbf,
+                                                      None, flag_addr)
+        yield from stream_events(start, decode_audio_event, cancel_flag)
 
     # -- LM taps used by the parity tests ------------------------------------------------------------
     def lm_reset(self, batch: int, max_context: int):

@@ -137,21 +137,14 @@ def snake(x, alpha):
 
 # ----------------------------------------------------------------------------- model
 
-def decoder_layer_plan(cfg: SnacConfig):
-    """Layer list of Decoder (Layers.swift:376-413) as (name, kind, params) used by both the
-    synthetic-weight generator and the forward pass.  attn_window_size must be None
-    (LocalMHA is not on the 24 kHz path, Layers.swift:395-397)."""
-    assert cfg.attn_window_size is None, "LocalMHA variant (32/44 kHz) not restated"
-    assert cfg.depthwise, "non-depthwise decoder stem not restated"
-    return None
-
-
 class SnacOracle:
     def __init__(self, cfg: SnacConfig, weights: dict, dtype=np.float32):
         self.cfg = cfg
         self.dtype = np.dtype(dtype)
         self.w = {k: np.asarray(v, dtype=self.dtype) for k, v in weights.items()}
-        decoder_layer_plan(cfg)
+        # LocalMHA (32/44 kHz) and the non-depthwise stem are not on the 24 kHz path (Layers.swift:376-397) and not restated
+        assert cfg.attn_window_size is None, "LocalMHA variant (32/44 kHz) not restated"
+        assert cfg.depthwise, "non-depthwise decoder stem not restated"
 
     # -- weight helpers ------------------------------------------------------
     def _wn(self, prefix, bias=True):
