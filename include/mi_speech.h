@@ -296,6 +296,13 @@ mis_status mis_soprano_decode(mis_soprano*, const float* hidden, int batch, int 
 mis_status mis_soprano_generate(mis_soprano*, const int32_t* prompt_ids, const int32_t* prompt_lens, int batch,
                                 const mis_gen_params* params, float** pcm_out, int64_t* pcm_stride, int64_t* pcm_lens,
                                 int32_t** tokens_out, int64_t* tokens_stride, int32_t* n_tokens);
+/* generateStream (Soprano.swift:693-800) for a batch of tokenised sentences: MIS_EVENT_TOKEN per sampled id while the loop runs
+ * (the [STOP] token is not announced, :855-857), then per row MIS_EVENT_INFO (SopranoGenerationInfo :771-779: prompt count and
+ * prefill time 0, generation count = hidden states decoded) and ONE MIS_EVENT_AUDIO (:781).  cancel_flag polled every 8 steps
+ * (continuation.onTermination -> task.cancel(), :798) -> MIS_ERR_CANCELLED. */
+mis_status mis_soprano_generate_stream(mis_soprano*, const int32_t* prompt_ids, const int32_t* prompt_lens, int batch,
+                                       const mis_gen_params* params, mis_event_cb on_event, void* user,
+                                       const volatile int* cancel_flag);
 
 /* ------------------------------------------------------------------------------------------
  * Qwen3-TTS.  Replaces Qwen3TTSModel.generate / generateStream -> generateVoiceDesign
@@ -492,6 +499,14 @@ mis_status mis_whisper_decoder_forward(mis_whisper*, const int32_t* tokens, cons
 mis_status mis_stt_whisper_generate(mis_whisper*, const float* pcm, const int64_t* lens, int batch, int64_t stride,
                                     const int32_t* prompt_ids, int n_prompt, const mis_stt_params*,
                                     int32_t** tokens_out, int64_t* tokens_stride, int32_t* n_tokens);
+/* generateStream (WhisperModel.swift:92-160): same work, announcing every sampled id as MIS_EVENT_TOKEN (row, id) while the loop
+ * runs (every 4 steps; EOT is never announced) - the host turns ids into the reference's text deltas (decode-and-diff,
+ * onTokenDelta :186-250) - then one MIS_EVENT_INFO per row (prompt_token_count, generation_token_count of the final .result).
+ * cancel_flag polled at the same cadence -> MIS_ERR_CANCELLED.  tokens_out / tokens_stride / n_tokens may be NULL. */
+mis_status mis_stt_whisper_generate_stream(mis_whisper*, const float* pcm, const int64_t* lens, int batch, int64_t stride,
+                                           const int32_t* prompt_ids, int n_prompt, const mis_stt_params*,
+                                           mis_event_cb on_event, void* user, const volatile int* cancel_flag,
+                                           int32_t** tokens_out, int64_t* tokens_stride, int32_t* n_tokens);
 
 /* diagnostics: microseconds per dependent kernel boundary in a replayed hipGraph of n trivial kernels
  * (mode 0: 1 block x 64 threads, 1: 32 x 1024, 2: 1024 x 256).  DESIGN.md quotes it as the launch floor. */

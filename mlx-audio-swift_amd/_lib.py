@@ -169,6 +169,8 @@ SYMBOLS = {
     "mis_whisper_decoder_forward": (C.c_int, [_P, _P, _P, _P]),
     "mis_stt_whisper_generate": (C.c_int, [_P, _P, _P, C.c_int, C.c_int64, _P, C.c_int, C.POINTER(SttParamsC),
                                            C.POINTER(_P), C.POINTER(C.c_int64), _P]),
+    "mis_stt_whisper_generate_stream": (C.c_int, [_P, _P, _P, C.c_int, C.c_int64, _P, C.c_int, C.POINTER(SttParamsC), EVENT_CB, _P, _P,
+                                                  C.POINTER(_P), C.POINTER(C.c_int64), _P]),
     "mis_soprano_create": (C.c_int, [C.POINTER(SopranoConfigC), C.c_int, C.POINTER(_P)]),
     "mis_soprano_set_tensor": (C.c_int, [_P, C.c_char_p, _P, C.c_int, C.POINTER(C.c_int64), C.c_int]),
     "mis_soprano_finalize": (C.c_int, [_P]),
@@ -178,6 +180,7 @@ SYMBOLS = {
     "mis_soprano_decode": (C.c_int, [_P, _P, C.c_int, C.c_int, _P]),
     "mis_soprano_generate": (C.c_int, [_P, _P, _P, C.c_int, C.POINTER(GenParamsC), C.POINTER(_P), C.POINTER(C.c_int64),
                                        _P, C.POINTER(_P), C.POINTER(C.c_int64), _P]),
+    "mis_soprano_generate_stream": (C.c_int, [_P, _P, _P, C.c_int, C.POINTER(GenParamsC), EVENT_CB, _P, _P]),
     "mis_qwen3tts_create": (C.c_int, [C.POINTER(Qwen3TTSConfigC), C.c_int, C.POINTER(_P)]),
     "mis_qwen3tts_set_tensor": (C.c_int, [_P, C.c_char_p, _P, C.c_int, C.POINTER(C.c_int64), C.c_int]),
     "mis_qwen3tts_finalize": (C.c_int, [_P]),

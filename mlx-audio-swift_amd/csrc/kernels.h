@@ -33,7 +33,9 @@ int tts_device(const mis_tts* c);
 // generate collecting model.norm(h) per step (row b: n_hidden[b] states, first = last prompt token), stop token ends a row
 void tts_generate_hidden(mis_tts* c, const int32_t* prompt_ids, const int32_t* prompt_lens, int batch, const mis_gen_params* gp,
                          int stop_id, DevBuf<float>& hidden, std::vector<int32_t>& n_hidden, std::vector<int32_t>& n_tokens,
-                         std::vector<int32_t>& tokens, int64_t& tokens_stride);
+                         std::vector<int32_t>& tokens, int64_t& tokens_stride, mis_event_cb cb = nullptr, void* user = nullptr,
+                         const volatile int* cancel = nullptr);
+double tts_last_decode_ms(const mis_tts* c);
 
 // hooks for composite engines built on the LM step chain (qwen3tts.hip); defined in lm_engine.hip
 struct TtsView { bf16_t *x, *h, *logits, *emb; int32_t *ids, *pos_next; uint8_t* active; int d, Mpad, V, Vpad, batch, finalized, L; hipStream_t stream; };

@@ -798,6 +798,7 @@ static void run_generate(mis_tts* c, const int32_t* prompt_ids, const int32_t* p
             for (int b = 0; b < batch; ++b)
                 for (; emitted[b] < host_ngen[b]; ++emitted[b]) {
                     int32_t t = host_tok[(size_t)b * max_tokens + emitted[b]];
+                    if (hidden_mode && t == hm->stop_id) continue;             // Soprano: [STOP] ends the row unannounced (Soprano.swift:855-857)
                     cb(user, b, MIS_EVENT_TOKEN, &t, 1);                       // .token(id), LlamaTTS.swift:862
                 }
         }
@@ -1281,14 +1282,15 @@ extern "C" mis_status mis_debug_launch_floor(int device, int n_kernels, int mode
 // ---------------------------------------------------------------------------- Soprano hooks (soprano.hip)
 hipStream_t tts_stream(mis_tts* c) { return c->stream; }
 int tts_hidden_size(const mis_tts* c) { return c->d; }
+double tts_last_decode_ms(const mis_tts* c) { return c->timing.prefill_ms + c->timing.decode_ms; }
 int tts_device(const mis_tts* c) { return c->device; }
 void tts_generate_hidden(mis_tts* c, const int32_t* prompt_ids, const int32_t* prompt_lens, int batch, const mis_gen_params* gp,
                          int stop_id, DevBuf<float>& hidden, std::vector<int32_t>& n_hidden, std::vector<int32_t>& n_tokens,
-                         std::vector<int32_t>& tokens, int64_t& tokens_stride) {
+                         std::vector<int32_t>& tokens, int64_t& tokens_stride, mis_event_cb cb, void* user, const volatile int* cancel) {
     HiddenMode hm;
     hm.on = true; hm.stop_id = stop_id; hm.hidden = &hidden;
     GenOutputs out;
-    run_generate(c, prompt_ids, prompt_lens, batch, gp, nullptr, nullptr, 0, true, nullptr, nullptr, nullptr, out, &hm);
+    run_generate(c, prompt_ids, prompt_lens, batch, gp, nullptr, nullptr, 0, true, cb, user, cancel, out, &hm);
     n_hidden = hm.n_hidden; n_tokens = out.n_tokens; tokens = out.tokens; tokens_stride = out.tokens_stride;
 }
 

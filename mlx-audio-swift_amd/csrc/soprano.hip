@@ -318,13 +318,15 @@ extern "C" mis_status mis_soprano_decode(mis_soprano* c, const float* hidden, in
     MIS_API_END
 }
 
-// SopranoModel.generate for already-tokenised sentences (Soprano.swift:577-690 per prompt chunk): LM loop with the
-// Soprano sampler flavour collecting hidden states until the stop token, then SopranoDecoder on each row.
-extern "C" mis_status mis_soprano_generate(mis_soprano* c, const int32_t* prompt_ids, const int32_t* prompt_lens, int batch,
-                                           const mis_gen_params* params, float** pcm_out, int64_t* pcm_stride, int64_t* pcm_lens,
-                                           int32_t** tokens_out, int64_t* tokens_stride, int32_t* n_tokens) {
-    MIS_API_BEGIN
-    MIS_REQUIRE(c && prompt_ids && prompt_lens && params && pcm_out && pcm_stride && pcm_lens, MIS_ERR_INVALID_INPUT, "null argument");
+// SopranoModel.generate / generateStream for already-tokenised sentences (Soprano.swift:577-690 / :693-800 per prompt chunk): LM
+// loop with the Soprano sampler flavour collecting hidden states until the stop token, then SopranoDecoder on each row.
+// on_event (stream form): .token per sampled id while the loop runs (the stop token is not announced, :855-857), then per row
+// .info and ONE .audio (:771-787).
+static void soprano_generate_impl(mis_soprano* c, const int32_t* prompt_ids, const int32_t* prompt_lens, int batch,
+                                  const mis_gen_params* params, float** pcm_out, int64_t* pcm_stride, int64_t* pcm_lens,
+                                  int32_t** tokens_out, int64_t* tokens_stride, int32_t* n_tokens, mis_event_cb on_event, void* user,
+                                  const volatile int* cancel_flag) {
+    MIS_REQUIRE(c && prompt_ids && prompt_lens && params, MIS_ERR_INVALID_INPUT, "null argument");
     MIS_REQUIRE(c->finalized, MIS_ERR_NOT_INITIALIZED, "Soprano model not finalized");
     HIP_CHECK(hipSetDevice(c->device));
     hipStream_t s = tts_stream(c->lm);
@@ -334,22 +336,24 @@ extern "C" mis_status mis_soprano_generate(mis_soprano* c, const int32_t* prompt
     if (gp.max_tokens <= 0) gp.max_tokens = 512;                       // parameters.maxTokens ?? 512 (:635)
     std::vector<int32_t> n_hidden, ntok, toks;
     int64_t tstride = 0;
-    tts_generate_hidden(c->lm, prompt_ids, prompt_lens, batch, &gp, c->cfg.stop_token_id, c->hidden, n_hidden, ntok, toks, tstride);
+    tts_generate_hidden(c->lm, prompt_ids, prompt_lens, batch, &gp, c->cfg.stop_token_id, c->hidden, n_hidden, ntok, toks, tstride,
+                        on_event, user, cancel_flag);
     const int C = c->cfg.lm.hidden_size;
     const int64_t hid_rows = gp.max_tokens + 1;
     int64_t longest = 0;
-    for (int b = 0; b < batch; ++b) { pcm_lens[b] = mis_soprano_num_samples(c, n_hidden[b]); longest = std::max(longest, pcm_lens[b]); }
+    std::vector<int64_t> plens(batch);
+    for (int b = 0; b < batch; ++b) { plens[b] = mis_soprano_num_samples(c, n_hidden[b]); longest = std::max(longest, plens[b]); }
     MIS_REQUIRE(longest > 0, MIS_ERR_GENERATION_FAILED, "No audio generated");             // Soprano.swift:684-686
     DevBuf<float> audio;
     audio.alloc((size_t)batch * longest);
     HIP_CHECK(hipMemsetAsync(audio.p, 0, (size_t)batch * longest * 4, s));
     bool same = true;
     for (int b = 1; b < batch; ++b) same = same && n_hidden[b] == n_hidden[0];
-    if (same && pcm_lens[0] > 0) {                                      // all rows ended at the same step: one batched decode
+    if (same && plens[0] > 0) {                                         // all rows ended at the same step: one batched decode
         soprano_decode_device(c, c->hidden.p, hid_rows, batch, n_hidden[0], audio.p, longest, s);
     } else {
         for (int b = 0; b < batch; ++b)                                 // ragged rows: decode one by one
-            if (pcm_lens[b] > 0)
+            if (plens[b] > 0)
                 soprano_decode_device(c, c->hidden.p + (size_t)b * hid_rows * C, hid_rows, 1, n_hidden[b], audio.p + (size_t)b * longest, longest, s);
     }
     PinnedBuf<float> host_pin((size_t)batch * longest);
@@ -358,9 +362,29 @@ extern "C" mis_status mis_soprano_generate(mis_soprano* c, const int32_t* prompt
     HIP_CHECK(hipStreamSynchronize(s));
     for (int b = 0; b < batch; ++b) {                                   // audio[0, (-audioLength)...], Soprano.swift:666-671
         int64_t want = (int64_t)(n_hidden[b] - 1) * c->cfg.token_size;
-        if (want > 0 && want < pcm_lens[b]) {
-            memmove(host + (size_t)b * longest, host + (size_t)b * longest + (pcm_lens[b] - want), (size_t)want * 4);
-            pcm_lens[b] = want;
+        if (want > 0 && want < plens[b]) {
+            memmove(host + (size_t)b * longest, host + (size_t)b * longest + (plens[b] - want), (size_t)want * 4);
+            plens[b] = want;
+        }
+    }
+    std::vector<int32_t> ngen(batch);
+    for (int b = 0; b < batch; ++b) {
+        int n = ntok[b];                                                // the stop token is not a generated token (:855-857)
+        if (n > 0 && toks[(size_t)b * tstride + n - 1] == c->cfg.stop_token_id) n -= 1;
+        ngen[b] = n;
+    }
+    if (on_event) {
+        const double secs = tts_last_decode_ms(c->lm) * 1e-3;
+        for (int b = 0; b < batch; ++b) {
+            mis_gen_info info{};                                        // SopranoGenerationInfo (:771-779): prompt count / prefill time are 0
+            info.generation_token_count = n_hidden[b];                  // totalTokens += tokenCount (hidden states, :752)
+            info.generate_time = secs;
+            info.tokens_per_second = secs > 0 ? n_hidden[b] / secs : 0;
+            size_t free_b = 0, total_b = 0;
+            (void)hipMemGetInfo(&free_b, &total_b);
+            info.peak_memory_gb = (double)(total_b - free_b) / 1e9;
+            on_event(user, b, MIS_EVENT_INFO, &info, 1);
+            on_event(user, b, MIS_EVENT_AUDIO, host + (size_t)b * longest, plens[b]);
         }
     }
     if (tokens_out) {
@@ -369,11 +393,27 @@ extern "C" mis_status mis_soprano_generate(mis_soprano* c, const int32_t* prompt
         *tokens_out = th.release();
         if (tokens_stride) *tokens_stride = tstride;
     }
-    *pcm_out = host_pin.release(); *pcm_stride = longest;
-    if (n_tokens) for (int b = 0; b < batch; ++b) {
-        int n = ntok[b];                                                // the stop token is not a generated token (:855-857)
-        if (n > 0 && toks[(size_t)b * tstride + n - 1] == c->cfg.stop_token_id) n -= 1;
-        n_tokens[b] = n;
-    }
+    if (pcm_out) { *pcm_out = host_pin.release(); *pcm_stride = longest; }
+    if (pcm_lens) for (int b = 0; b < batch; ++b) pcm_lens[b] = plens[b];
+    if (n_tokens) for (int b = 0; b < batch; ++b) n_tokens[b] = ngen[b];
+}
+
+extern "C" mis_status mis_soprano_generate(mis_soprano* c, const int32_t* prompt_ids, const int32_t* prompt_lens, int batch,
+                                           const mis_gen_params* params, float** pcm_out, int64_t* pcm_stride, int64_t* pcm_lens,
+                                           int32_t** tokens_out, int64_t* tokens_stride, int32_t* n_tokens) {
+    MIS_API_BEGIN
+    MIS_REQUIRE(pcm_out && pcm_stride && pcm_lens, MIS_ERR_INVALID_INPUT, "null argument");
+    soprano_generate_impl(c, prompt_ids, prompt_lens, batch, params, pcm_out, pcm_stride, pcm_lens, tokens_out, tokens_stride, n_tokens,
+                          nullptr, nullptr, nullptr);
+    MIS_API_END
+}
+
+extern "C" mis_status mis_soprano_generate_stream(mis_soprano* c, const int32_t* prompt_ids, const int32_t* prompt_lens, int batch,
+                                                  const mis_gen_params* params, mis_event_cb on_event, void* user,
+                                                  const volatile int* cancel_flag) {
+    MIS_API_BEGIN
+    MIS_REQUIRE(on_event, MIS_ERR_INVALID_INPUT, "null callback");
+    soprano_generate_impl(c, prompt_ids, prompt_lens, batch, params, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, on_event, user,
+                          cancel_flag);
     MIS_API_END
 }

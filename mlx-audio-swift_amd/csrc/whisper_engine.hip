@@ -575,11 +575,11 @@ extern "C" mis_status mis_whisper_decoder_forward(mis_whisper* c, const int32_t*
 
 // transcribeChunk for a batch of <= 30 s windows (WhisperModel.swift:186-282): mel -> encoder -> prompt prefill ->
 // greedy / temperature loop with the suppress masks, until EOT or max_tokens.  Token ids only; text stays host side.
-extern "C" mis_status mis_stt_whisper_generate(mis_whisper* c, const float* pcm, const int64_t* lens, int batch, int64_t stride,
-                                               const int32_t* prompt_ids, int n_prompt, const mis_stt_params* sp,
-                                               int32_t** tokens_out, int64_t* tokens_stride, int32_t* n_tokens) {
-    MIS_API_BEGIN
-    MIS_REQUIRE(c && prompt_ids && sp && tokens_out && tokens_stride && n_tokens, MIS_ERR_INVALID_INPUT, "null argument");
+static void whisper_generate_impl(mis_whisper* c, const float* pcm, const int64_t* lens, int batch, int64_t stride,
+                                  const int32_t* prompt_ids, int n_prompt, const mis_stt_params* sp,
+                                  int32_t** tokens_out, int64_t* tokens_stride, int32_t* n_tokens, mis_event_cb on_event, void* user,
+                                  const volatile int* cancel_flag) {
+    MIS_REQUIRE(c && prompt_ids && sp, MIS_ERR_INVALID_INPUT, "null argument");
     MIS_REQUIRE(c->finalized, MIS_ERR_NOT_INITIALIZED, "model not finalized");
     MIS_REQUIRE(batch >= 1 && batch <= 64 && n_prompt >= 1 && stride >= 0, MIS_ERR_INVALID_INPUT, "bad sizes");
     MIS_REQUIRE(stride == 0 || pcm, MIS_ERR_INVALID_INPUT, "null audio");
@@ -652,11 +652,27 @@ extern "C" mis_status mis_stt_whisper_generate(mis_whisper* c, const float* pcm,
             HIP_CHECK(hipGraphInstantiate(&gexec, g, nullptr, nullptr, 0));
             HIP_CHECK(hipGraphDestroy(g));
         }
+        // stream form: the ids sampled since the last poll are announced in step order per row (the reference decodes them to a
+        // text delta per step, WhisperModel.swift:242-254; detokenisation stays with the host); EOT is never announced (:238)
+        std::vector<int32_t> emitted(batch, 0), h_ng(batch), h_tok;
+        const int poll = on_event ? 3 : 7;
         for (int step = 0; step < max_tokens; ++step) {
             if (use_graph) HIP_CHECK(hipGraphLaunch(gexec, s)); else step_body();
-            if ((step & 7) == 7 || step + 1 == max_tokens) {
+            if ((step & poll) == poll || step + 1 == max_tokens) {
                 HIP_CHECK(hipMemcpyAsync(done_host, c->done_count.p, 4, hipMemcpyDeviceToHost, s));
+                if (on_event) {
+                    h_tok.resize((size_t)batch * max_tokens);
+                    HIP_CHECK(hipMemcpyAsync(h_ng.data(), c->n_gen.p, batch * 4, hipMemcpyDeviceToHost, s));
+                    HIP_CHECK(hipMemcpyAsync(h_tok.data(), c->tokens_out.p, h_tok.size() * 4, hipMemcpyDeviceToHost, s));
+                }
                 HIP_CHECK(hipStreamSynchronize(s));
+                if (on_event)
+                    for (int b = 0; b < batch; ++b)
+                        for (; emitted[b] < h_ng[b]; ++emitted[b]) {
+                            int32_t t = h_tok[(size_t)b * max_tokens + emitted[b]];
+                            if (t != sp->eot_id) on_event(user, b, MIS_EVENT_TOKEN, &t, 1);
+                        }
+                if (cancel_flag && *cancel_flag) throw MisError(MIS_ERR_CANCELLED, "transcription cancelled");
                 if (*done_host >= batch) break;
             }
         }
@@ -669,14 +685,43 @@ extern "C" mis_status mis_stt_whisper_generate(mis_whisper* c, const float* pcm,
     std::vector<int32_t> ng(batch), toks((size_t)batch * max_tokens);
     HIP_CHECK(hipMemcpy(ng.data(), c->n_gen.p, batch * 4, hipMemcpyDeviceToHost));
     HIP_CHECK(hipMemcpy(toks.data(), c->tokens_out.p, toks.size() * 4, hipMemcpyDeviceToHost));
-    PinnedBuf<int32_t> th(toks.size() + 1);
-    memcpy(th.p, toks.data(), toks.size() * 4);
-    *tokens_out = th.release(); *tokens_stride = max_tokens;
+    if (tokens_out) {
+        PinnedBuf<int32_t> th(toks.size() + 1);
+        memcpy(th.p, toks.data(), toks.size() * 4);
+        *tokens_out = th.release();
+        if (tokens_stride) *tokens_stride = max_tokens;
+    }
     for (int b = 0; b < batch; ++b) {
         // the EOT token ends the row and is not part of `generated` (:238-240)
         int n = ng[b];
         if (n > 0 && toks[(size_t)b * max_tokens + n - 1] == sp->eot_id) n -= 1;
-        n_tokens[b] = n;
+        if (n_tokens) n_tokens[b] = n;
+        if (on_event) {                                   // per-row counts of the final .result (STTOutput promptTokens / generationTokens)
+            mis_gen_info info{};
+            info.prompt_token_count = n_prompt; info.generation_token_count = n;
+            on_event(user, b, MIS_EVENT_INFO, &info, 1);
+        }
     }
+}
+
+extern "C" mis_status mis_stt_whisper_generate(mis_whisper* c, const float* pcm, const int64_t* lens, int batch, int64_t stride,
+                                               const int32_t* prompt_ids, int n_prompt, const mis_stt_params* sp,
+                                               int32_t** tokens_out, int64_t* tokens_stride, int32_t* n_tokens) {
+    MIS_API_BEGIN
+    MIS_REQUIRE(tokens_out && tokens_stride && n_tokens, MIS_ERR_INVALID_INPUT, "null argument");
+    whisper_generate_impl(c, pcm, lens, batch, stride, prompt_ids, n_prompt, sp, tokens_out, tokens_stride, n_tokens, nullptr, nullptr, nullptr);
+    MIS_API_END
+}
+
+// generateStream (WhisperModel.swift:92-160) for a batch of windows: MIS_EVENT_TOKEN (row, id) while the greedy loop runs - the
+// host turns ids into text deltas (onTokenDelta :186-250) - then one MIS_EVENT_INFO per row; cancel_flag is polled every few steps.
+// tokens_out / tokens_stride / n_tokens may be NULL.
+extern "C" mis_status mis_stt_whisper_generate_stream(mis_whisper* c, const float* pcm, const int64_t* lens, int batch, int64_t stride,
+                                                      const int32_t* prompt_ids, int n_prompt, const mis_stt_params* sp,
+                                                      mis_event_cb on_event, void* user, const volatile int* cancel_flag,
+                                                      int32_t** tokens_out, int64_t* tokens_stride, int32_t* n_tokens) {
+    MIS_API_BEGIN
+    MIS_REQUIRE(on_event, MIS_ERR_INVALID_INPUT, "null callback");
+    whisper_generate_impl(c, pcm, lens, batch, stride, prompt_ids, n_prompt, sp, tokens_out, tokens_stride, n_tokens, on_event, user, cancel_flag);
     MIS_API_END
 }

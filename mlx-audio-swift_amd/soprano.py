@@ -15,7 +15,8 @@ import numpy as np
 
 from . import _lib
 from .codecs import _tensor_args
-from .generation import AudioGenerationError, GenerateParameters, check
+from .generation import (AudioEvent, AudioGenerationError, AudioGenerationInfo, GenerateParameters, InfoEvent, TokenEvent, check,
+                         decode_audio_event, stream_events)
 from .tts import MAX_BATCH, LlamaTTSConfiguration, LlamaTTSModel
 
 
@@ -276,3 +277,43 @@ class SopranoModel:
             raise AudioGenerationError(6, "No audio generated")
         parts = self.generate_batch(rows, gp)
         return np.concatenate(parts) if len(parts) > 1 else parts[0]
+
+    def generate_stream_batch(self, prompt_rows, generation_parameters: GenerateParameters | None = None, cancel_flag=None):
+        """mis_soprano_generate_stream on tokenised sentence prompts: TokenEvent while the engine generates, then per row
+        InfoEvent and one AudioEvent."""
+        gp = generation_parameters or GenerateParameters(max_tokens=512, temperature=0.3, top_p=0.95, repetition_penalty=1.5,
+                                                         repetition_context_size=30)          # generateStream defaults (:696-702)
+        flat, lens = LlamaTTSModel._flatten(prompt_rows)
+        B = len(lens)
+        if B > MAX_BATCH:
+            raise AudioGenerationError(3, f"at most {MAX_BATCH} sentence prompts per streamed call")
+        gpc = gp.to_c()
+        gpc.sampler_flavor = 1
+
+        def start(cbf, flag_addr):
+            return _lib.lib().mis_soprano_generate_stream(self._h, flat.ctypes.data, lens.ctypes.data, B, C.byref(gpc), cbf, None,
+                                                          flag_addr)
+        yield from stream_events(start, decode_audio_event, cancel_flag)
+
+    def generate_stream(self, text: str, voice=None, generation_parameters: GenerateParameters | None = None):
+        """generateStream(text:voice:parameters:) (Soprano.swift:693-800): .token per sampled id (all sentences of the text, in
+        sentence order), then ONE .info and ONE .audio = the sentences' audio concatenated (:760-787).  The sentences run
+        sequentially like the reference's loop so that the token order is the reference's."""
+        if self.tokenizer is None:
+            raise AudioGenerationError(1, "Tokenizer not loaded")
+        text = text.replace("\\n", "\n").replace("\\t", "\t")
+        rows = [self.tokenize(p) for p, _, _ in preprocess_text([text], clean_text=self.clean_text)]
+        parts, total, secs = [], 0, 0.0
+        for row in rows:
+            for ev in self.generate_stream_batch([row], generation_parameters):
+                if isinstance(ev, TokenEvent):
+                    yield TokenEvent(0, ev.token)
+                elif isinstance(ev, InfoEvent):
+                    total += ev.info.generation_token_count
+                    secs += ev.info.generate_time
+                elif isinstance(ev, AudioEvent):
+                    parts.append(ev.audio)
+        if not parts:
+            raise AudioGenerationError(2, "No audio generated")
+        yield InfoEvent(0, AudioGenerationInfo(0, total, 0.0, secs, total / secs if secs > 0 else 0.0, 0.0))
+        yield AudioEvent(0, np.concatenate(parts) if len(parts) > 1 else parts[0])

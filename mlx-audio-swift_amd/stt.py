@@ -14,7 +14,7 @@ import numpy as np
 
 from . import _lib
 from .codecs import _tensor_args
-from .generation import AudioGenerationError, check
+from .generation import AudioGenerationError, InfoEvent, TokenEvent, check, decode_audio_event, stream_events
 
 SAMPLE_RATE, CHUNK_SAMPLES = 16000, 480000          # WhisperAudioConfig, WhisperConfig.swift:188-193
 
@@ -246,6 +246,64 @@ class WhisperModel:
         n_prompt, n_gen = len(prompt_ids) * len(chunks), sum(len(t) for t in ids)
         return STTOutput(" ".join(texts), segments or None, self._prompt_language(prompt_ids, gp.language), n_prompt, n_gen, n_prompt + n_gen,
                          n_prompt / el if el > 0 else 0.0, n_gen / el if el > 0 else 0.0, el, 0.0, ids)
+
+    def transcribe_windows_stream(self, windows, prompt_ids, params: STTGenerateParameters, cancel_flag=None):
+        """mis_stt_whisper_generate_stream: yields TokenEvent(row, id) while the greedy loop runs, then InfoEvent per row."""
+        B = len(windows)
+        stride = max(1, max(len(w) for w in windows))
+        pcm = np.zeros((B, stride), np.float32)
+        lens = np.zeros(B, np.int64)
+        for i, w in enumerate(windows):
+            w = np.asarray(w, np.float32).reshape(-1)
+            pcm[i, : len(w)] = w
+            lens[i] = len(w)
+        params = self._resolve_parameters(params)
+        prompt = np.ascontiguousarray(prompt_ids, dtype=np.int32)
+        sup = np.ascontiguousarray(params.suppress_tokens or [], dtype=np.int32)
+        bsup = np.ascontiguousarray(params.begin_suppress_tokens, dtype=np.int32)
+        sp = _lib.SttParamsC(int(params.max_tokens), float(params.temperature), int(params.seed), int(params.eot_id),
+                             int(params.timestamp_begin), sup.ctypes.data if len(sup) else None, len(sup),
+                             bsup.ctypes.data if len(bsup) else None, len(bsup))
+
+        def start(cbf, flag_addr):
+            return _lib.lib().mis_stt_whisper_generate_stream(self._h, pcm.ctypes.data, lens.ctypes.data, B, stride, prompt.ctypes.data,
+                                                              len(prompt), C.byref(sp), cbf, None, flag_addr, None, None, None)
+        yield from stream_events(start, decode_audio_event, cancel_flag)
+
+    def generate_stream(self, audio, generation_parameters: STTGenerateParameters | None = None, prompt_ids=None):
+        """generateStream(audio:generationParameters:) (WhisperModel.swift:92-160): chunk by chunk, yields ("token", text delta)
+        per step whose decoded text changed (decode-and-diff, :242-254) and finally ("result", STTOutput)."""
+        gp = self._resolve_parameters(generation_parameters or self.default_generation_parameters)
+        if self.tokenizer is None:
+            raise AudioGenerationError(1, "WhisperTokenizer not loaded")
+        t0 = time.time()
+        a = np.asarray(audio, np.float32)
+        mono = a.mean(axis=-1) if a.ndim > 1 else a
+        chunks = [mono] if len(mono) <= CHUNK_SAMPLES else [mono[i:i + CHUNK_SAMPLES] for i in range(0, len(mono), CHUNK_SAMPLES)]
+        if prompt_ids is None:
+            prompt_ids = self.tokenizer.build_prompt_tokens(language=gp.language, task="transcribe")
+        texts, segments, ids = [], [], []
+        for ci, chunk in enumerate(chunks):                       # the reference streams chunk after chunk (:107-121)
+            generated, previous = [], ""
+            for ev in self.transcribe_windows_stream([chunk], prompt_ids, gp):
+                if isinstance(ev, TokenEvent):
+                    generated.append(ev.token)
+                    so_far = self.tokenizer.decode(generated)
+                    if so_far != previous:
+                        delta = so_far[len(previous):] if so_far.startswith(previous) else so_far
+                        previous = so_far
+                        if delta:
+                            yield ("token", delta)
+            ids.append(generated)
+            text = self.tokenizer.decode(generated).strip()
+            if text:
+                texts.append(text)
+                start = ci * CHUNK_SAMPLES / SAMPLE_RATE
+                segments.append({"text": text, "start": start, "end": start + len(chunk) / SAMPLE_RATE})
+        el = time.time() - t0
+        n_prompt, n_gen = len(prompt_ids) * len(chunks), sum(len(t) for t in ids)
+        yield ("result", STTOutput(" ".join(texts), segments or None, self._prompt_language(prompt_ids, gp.language), n_prompt, n_gen,
+                                   n_prompt + n_gen, n_prompt / el if el > 0 else 0.0, n_gen / el if el > 0 else 0.0, el, 0.0, ids))
 
     def close(self):
         if self._h is not None:

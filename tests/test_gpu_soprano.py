@@ -162,3 +162,39 @@ def test_generate_sampled_is_seeded_and_text_front_end():
     assert not np.array_equal(a, c)
     with pytest.raises(mas.AudioGenerationError):
         dev.generate("   ", generation_parameters=gp)
+
+
+def test_generate_stream_event_order_and_cancel():
+    # generateStream (Soprano.swift:693-800): .token* while generating (no [STOP]), then per row .info and ONE .audio whose
+    # samples equal generate()'s; closing the stream cancels the engine
+    cfg, dev, odec, olm = _pair()
+    rng = np.random.default_rng(5)
+    prompts = [rng.integers(4, LM.vocab_size, n).astype(np.int32) for n in (6, 9)]
+    gp = mas.GenerateParameters(max_tokens=20, temperature=0.0, top_p=0.95, repetition_penalty=1.5, repetition_context_size=30,
+                                seed=3, sampler_flavor=1)
+    pcm, toks = dev.generate_batch(prompts, gp, return_tokens=True)
+    ev = list(dev.generate_stream_batch(prompts, gp))
+    for row in (0, 1):
+        kinds = [type(e).__name__ for e in ev if e.row == row]
+        assert kinds == ["TokenEvent"] * len(toks[row]) + ["InfoEvent", "AudioEvent"]
+        assert np.array_equal([e.token for e in ev if e.row == row and isinstance(e, mas.TokenEvent)], toks[row])
+        audio = [e.audio for e in ev if e.row == row and isinstance(e, mas.AudioEvent)][0]
+        assert np.array_equal(audio, pcm[row])
+        info = [e.info for e in ev if e.row == row and isinstance(e, mas.InfoEvent)][0]
+        assert info.prompt_token_count == 0 and info.generation_token_count == len(toks[row]) + 1      # hidden states (:752)
+    # every token precedes every info/audio event (tokens are delivered while the loop runs)
+    last_tok = max(i for i, e in enumerate(ev) if isinstance(e, mas.TokenEvent))
+    first_end = min(i for i, e in enumerate(ev) if not isinstance(e, mas.TokenEvent))
+    assert last_tok < first_end
+    # early close: the engine is cancelled, no error surfaces, and the model stays usable
+    long_gp = mas.GenerateParameters(max_tokens=400, temperature=0.0, repetition_penalty=1.5, repetition_context_size=30, sampler_flavor=1)
+    g = dev.generate_stream_batch(prompts, long_gp)
+    first = next(g)
+    assert isinstance(first, mas.TokenEvent)
+    g.close()
+    pcm2, toks2 = dev.generate_batch(prompts, gp, return_tokens=True)
+    assert all(np.array_equal(a, b) for a, b in zip(toks, toks2))
+    import ctypes as C
+    with pytest.raises(mas.AudioGenerationError) as e:
+        list(dev.generate_stream_batch(prompts, long_gp, cancel_flag=C.c_int(1)))
+    assert e.value.case == "cancelled"

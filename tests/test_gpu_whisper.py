@@ -173,3 +173,100 @@ def test_mlx_whisper_key_layout_loads_to_the_same_model():
     toks = np.asarray([3, 5], np.int32)
     hf.decoder_reset(); mlx.decoder_reset()
     assert np.array_equal(hf.decoder_forward(toks), mlx.decoder_forward(toks))
+
+
+def test_generate_stream_tokens_then_result_and_mlx_directory_loader(tmp_path):
+    # generateStream (WhisperModel.swift:92-160): token events while the loop runs, ids equal to generate()'s; text deltas are the
+    # host's decode-and-diff (:242-254).  Also the directory loader on an mlx-whisper key layout (fromDirectory + sanitize).
+    import json
+    import torch
+    from safetensors.torch import save_file
+    cfg = ow.TINY
+    W = ow.make_synthetic_weights(cfg, seed=777)
+    dev = mas.WhisperModel.from_weights(_host_cfg(cfg), W)
+    rng = np.random.default_rng(9)
+    wins = [(0.1 * rng.standard_normal(16000 * 3)).astype(np.float32), (0.05 * rng.standard_normal(16000)).astype(np.float32)]
+    prompt = [590, 591, 592, 593]
+    gp = mas.STTGenerateParameters(max_tokens=14, temperature=0.0, eot_id=599, timestamp_begin=560, suppress_tokens=[1, 2, 3])
+    ids = dev.transcribe_windows(wins, prompt, gp)
+    ev = list(dev.transcribe_windows_stream(wins, prompt, gp))
+    for row in (0, 1):
+        toks = [e.token for e in ev if e.row == row and isinstance(e, mas.TokenEvent)]
+        assert toks == ids[row] and 599 not in toks
+        info = [e.info for e in ev if e.row == row and isinstance(e, mas.InfoEvent)]
+        assert len(info) == 1 and info[0].prompt_token_count == 4 and info[0].generation_token_count == len(ids[row])
+    assert max(i for i, e in enumerate(ev) if isinstance(e, mas.TokenEvent)) < min(i for i, e in enumerate(ev) if isinstance(e, mas.InfoEvent))
+
+    class Tok:                                             # stand-in tokenizer: an id is one letter; ids the reference would read from it
+        end_of_text_id, timestamp_begin_id, is_multilingual = 599, 560, True
+        language_to_id = {"en": 591, "fr": 594}
+
+        def decode(self, ids):
+            return "".join(chr(97 + (i % 26)) for i in ids)
+
+        def build_prompt_tokens(self, language=None, task="transcribe"):
+            return prompt
+
+    dev.tokenizer = Tok()
+    gp2 = mas.STTGenerateParameters(max_tokens=14, temperature=0.0, suppress_tokens=[1, 2, 3])     # ids come from the tokenizer
+    out = dev.generate(wins[0], gp2)
+    assert out.token_ids == [ids[0]] and out.language == "en" and out.text == Tok().decode(ids[0])
+    stream = list(dev.generate_stream(wins[0], gp2))
+    assert [k for k, _ in stream] == ["token"] * len(ids[0]) + ["result"]
+    assert "".join(v for k, v in stream if k == "token") == out.text and stream[-1][1].text == out.text
+    dev.tokenizer = None
+    with pytest.raises(mas.AudioGenerationError):
+        dev.generate(wins[0], mas.STTGenerateParameters(max_tokens=4), prompt_ids=prompt)              # no tokenizer, no ids: loud
+    # ---- fromDirectory on the mlx-whisper layout (the guard that rejected ".blocks." keys is gone)
+    attn = {"q_proj": "query", "k_proj": "key", "v_proj": "value", "out_proj": "out"}
+    M = {}
+    for k, v in W.items():
+        k2 = k[len("model."):]
+        if k2 == "encoder.embed_positions.weight":
+            continue
+        if k2 == "decoder.embed_positions.weight":
+            M["decoder.positional_embedding"] = v; continue
+        if k2.startswith("decoder.embed_tokens."):
+            M["decoder.token_embedding." + k2.split(".", 2)[2]] = v; continue
+        if k2 in ("encoder.conv1.weight", "encoder.conv2.weight"):
+            M[k2] = v.permute(0, 2, 1).contiguous(); continue
+        if k2.startswith("encoder.conv"):
+            M[k2] = v; continue
+        if k2.startswith("encoder.layer_norm."):
+            M["encoder.ln_post." + k2.split(".", 2)[2]] = v; continue
+        if k2.startswith("decoder.layer_norm."):
+            M["decoder.ln." + k2.split(".", 2)[2]] = v; continue
+        stem, _, idx, rest = k2.split(".", 3)
+        head, tail = rest.split(".", 1)
+        if head == "self_attn_layer_norm":
+            r = "attn_ln." + tail
+        elif head == "encoder_attn_layer_norm":
+            r = "cross_attn_ln." + tail
+        elif head == "final_layer_norm":
+            r = "mlp_ln." + tail
+        elif head in ("fc1", "fc2"):
+            r = ("mlp1." if head == "fc1" else "mlp2.") + tail
+        else:
+            proj, t2 = tail.split(".", 1)
+            r = ("attn." if head == "self_attn" else "cross_attn.") + attn[proj] + "." + t2
+        M[f"{stem}.blocks.{idx}.{r}"] = v
+    d = tmp_path / "whisper-mlx"
+    d.mkdir()
+    save_file({k: v.contiguous() for k, v in M.items()}, str(d / "weights.safetensors"))
+    hc = _host_cfg(cfg)
+    (d / "config.json").write_text(json.dumps({"n_vocab": hc.vocab_size, "n_mels": hc.num_mel_bins, "n_audio_state": hc.d_model,
+                                               "n_audio_layer": hc.encoder_layers, "n_audio_head": hc.encoder_attention_heads,
+                                               "n_audio_ctx": 1500, "n_text_layer": hc.decoder_layers,
+                                               "n_text_head": hc.decoder_attention_heads, "n_text_ctx": hc.max_target_positions}))
+    (d / "generation_config.json").write_text(json.dumps({"suppress_tokens": [1, 2, 3], "begin_suppress_tokens": [599]}))
+    loaded = mas.WhisperModel.from_model_directory(str(d))
+    assert loaded.generation_config["suppress_tokens"] == [1, 2, 3]
+    # the mlx layout synthesises the encoder sinusoid; compare against the HF-layout model with that same table
+    half = cfg.d_model // 2
+    inc = np.log(10000.0) / max(half - 1, 1)
+    pos = np.arange(1500)[:, None] * np.exp(-inc * np.arange(half))[None]
+    W2 = dict(W)
+    W2["model.encoder.embed_positions.weight"] = torch.from_numpy(np.concatenate([np.sin(pos), np.cos(pos)], 1).astype(np.float32)).bfloat16()
+    hf = mas.WhisperModel.from_weights(hc, W2)
+    gp3 = mas.STTGenerateParameters(max_tokens=10, temperature=0.0, eot_id=599, timestamp_begin=560, suppress_tokens=[1, 2, 3])
+    assert loaded.transcribe_windows(wins, prompt, gp3) == hf.transcribe_windows(wins, prompt, gp3)
