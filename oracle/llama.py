@@ -164,12 +164,14 @@ class LlamaOracle:
         return self.r(torch.cat([x1 * c - x2 * s, x1 * s + x2 * c], dim=-1))
 
     # -- one row, L new tokens --------------------------------------------------
-    def _forward_row(self, row: int, ids: torch.Tensor):
-        return self.forward_embeds(row, self.w["model.embed_tokens.weight"][ids])   # [L, d]
+    def _forward_row(self, row: int, ids: torch.Tensor, logit_positions=None):
+        return self.forward_embeds(row, self.w["model.embed_tokens.weight"][ids], logit_positions=logit_positions)   # [L, d]
 
-    def forward_embeds(self, row: int, h: torch.Tensor, head: torch.Tensor | None = None):
+    def forward_embeds(self, row: int, h: torch.Tensor, head: torch.Tensor | None = None, logit_positions=None):
         """L new positions given as input embeddings [L, d] (Qwen3TTSTalkerModel.callAsFunction takes
-        inputsEmbeds, Qwen3TTSTalker.swift:274-305).  `head` overrides the output projection."""
+        inputsEmbeds, Qwen3TTSTalker.swift:274-305).  `head` overrides the output projection.
+        logit_positions (test economy at full vocabulary width): indices among the L new positions whose logits are
+        wanted - the output projection is a per-position Linear, so skipping positions changes no value."""
         cfg = self.cfg
         H, Hkv, D = cfg.num_attention_heads, cfg.num_key_value_heads, cfg.resolved_head_dim
         h = torch.as_tensor(h, dtype=torch.float32)
@@ -213,19 +215,23 @@ class LlamaOracle:
         self.offset[row] = off + L
         h = self.rmsnorm(h, self.w["model.norm.weight"])
         self.last_hidden = h                          # model.norm(h): what Soprano's decoder consumes (Soprano.swift:264)
+        if logit_positions is not None:
+            h = h[torch.as_tensor(list(logit_positions), dtype=torch.long)]
         if head is None:
             head = self.w.get("lm_head.weight") if not cfg.tie_word_embeddings else None
             if head is None:
                 head = self.w["model.embed_tokens.weight"]
         return self.linear(h, head)                                                 # [L, V]
 
-    def forward(self, ids_per_row):
+    def forward(self, ids_per_row, logit_positions=None):
         """ids_per_row: list (len = batch) of 1-D int sequences (may differ in length).
-        Returns list of logits [L_r, V] float32 (bf16-rounded values when round='bf16')."""
+        Returns list of logits [L_r, V] float32 (bf16-rounded values when round='bf16'); with logit_positions (one
+        index list per row) only those positions' logits."""
         out = []
         with torch.no_grad():
             for r, ids in enumerate(ids_per_row):
-                out.append(self._forward_row(r, torch.as_tensor(np.asarray(ids, dtype=np.int64))))
+                out.append(self._forward_row(r, torch.as_tensor(np.asarray(ids, dtype=np.int64)),
+                                             None if logit_positions is None else logit_positions[r]))
         return out
 
 

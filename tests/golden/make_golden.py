@@ -16,7 +16,36 @@ from oracle import snac  # noqa: E402
 OUT = os.path.dirname(os.path.abspath(__file__))
 
 
+def reference_fixture():
+    """Pins that do NOT come from this repo's oracle: the reference's own speech fixture Tests/media/intention.wav (used by its codec /
+    STT / smoke tests, e.g. Tests/MLXAudioSmokeTests.swift:78-110) run through an INDEPENDENT implementation of the Whisper front
+    end (HF transformers' WhisperFeatureExtractor).  Needs /root/reference (build container only); the outputs are committed."""
+    import shutil
+    import wave
+    from math import gcd
+
+    from scipy.signal import resample_poly
+    from transformers import WhisperFeatureExtractor
+    src = "/root/reference/Tests/media/intention.wav"
+    dst = os.path.join(OUT, "intention.wav")
+    shutil.copyfile(src, dst)
+    os.chmod(dst, 0o644)
+    w = wave.open(dst)
+    sr, n = w.getframerate(), w.getnframes()
+    pcm = np.frombuffer(w.readframes(n), dtype="<i2").astype(np.float32) / 32768.0
+    g = gcd(sr, 16000)
+    pcm16 = resample_poly(pcm.astype(np.float64), 16000 // g, sr // g).astype(np.float32)        # 24 kHz -> 16 kHz
+    out = {"sr": np.int32(sr), "pcm16k": pcm16}
+    for n_mels in (80, 128):
+        fe = WhisperFeatureExtractor(feature_size=n_mels)
+        m = fe(pcm16, sampling_rate=16000, return_tensors="np")["input_features"][0]            # [n_mels, 3000]
+        out[f"hf_mel{n_mels}"] = m.astype(np.float32)
+    np.savez_compressed(os.path.join(OUT, "intention_whisper_features.npz"), **out)
+
+
 def main():
+    if os.path.exists("/root/reference/Tests/media/intention.wav"):
+        reference_fixture()
     # C1: SNAC 24 kHz, 12 groups = 1.024 s, B = 1, seeded synthetic weights / codes / noise
     cfg = snac.SnacConfig()
     W = snac.make_synthetic_weights(cfg, seed=1234)

@@ -55,3 +55,31 @@ def teacher_forced(oracle, dev, rows, max_context=64):
     oracle.reset(B)
     ref = oracle.forward(rows)
     return [(np.stack(got[b]), ref[b].numpy()) for b in range(B)]
+
+
+def record(name: str, **metrics):
+    """Observed parity errors, printed (pytest -s / -rP) and appended to gpurun_out/parity_observed.jsonl so that the
+    tolerances written in the tests can be compared with what the hardware actually delivers (profiles/rNN_parity_observed.json)."""
+    import json
+    import os
+    row = {"test": name, **{k: (float(v) if isinstance(v, (int, float, np.floating, np.integer)) else v) for k, v in metrics.items()}}
+    print("PARITY", json.dumps(row))
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = os.path.join(root, "gpurun_out")
+    try:
+        os.makedirs(out, exist_ok=True)
+        with open(os.path.join(out, "parity_observed.jsonl"), "a") as f:
+            f.write(json.dumps(row) + "\n")
+    except OSError:
+        pass
+
+
+def logits_errors(dev_l, ref_l):
+    """(max abs err / max |ref|, rms err / rms ref, greedy agreement on rows whose oracle top-2 margin exceeds 2x the max error)"""
+    scale = float(np.abs(ref_l).max())
+    err = float(np.abs(dev_l - ref_l).max())
+    r = rms(dev_l, ref_l) / float(np.sqrt(np.mean(ref_l.astype(np.float64) ** 2)))
+    top2 = np.sort(ref_l, axis=-1)[..., -2:]
+    sure = (top2[..., 1] - top2[..., 0]) > 2 * err
+    agree = bool(np.array_equal(dev_l.argmax(-1)[sure], ref_l.argmax(-1)[sure]))
+    return err / scale, r, int(sure.sum()), agree

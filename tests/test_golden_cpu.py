@@ -44,3 +44,35 @@ def test_product_synthetic_generator_equals_oracle_generator():
         assert a.keys() == b.keys()
         for k in a:
             assert np.array_equal(a[k], b[k]), k
+
+
+def _intention():
+    z = np.load(os.path.join(G, "intention_whisper_features.npz"))
+    return z
+
+
+def test_reference_fixture_intention_wav_pins_the_mel_oracle():
+    """Tests/media/intention.wav is the reference's own speech fixture (Tests/MLXAudioSmokeTests.swift:78-110, MLXAudioSTTTests.swift:61).
+    The committed features come from HF transformers' WhisperFeatureExtractor - an implementation independent of oracle/mel.py -
+    so this pins the oracle on real speech, not on this repo's own outputs.  Tolerance 2e-4 in the normalised log domain
+    (HF computes the STFT in float64 numpy, the oracle in float32)."""
+    import wave
+    from math import gcd
+
+    from scipy.signal import resample_poly
+
+    from oracle import mel
+    z = _intention()
+    w = wave.open(os.path.join(G, "intention.wav"))
+    assert (w.getframerate(), w.getnchannels(), w.getnframes()) == (24000, 1, 36480) and int(z["sr"]) == 24000
+    pcm = np.frombuffer(w.readframes(w.getnframes()), dtype="<i2").astype(np.float32) / 32768.0
+    g = gcd(24000, 16000)
+    pcm16 = resample_poly(pcm.astype(np.float64), 16000 // g, 24000 // g).astype(np.float32)
+    assert pcm16.shape == z["pcm16k"].shape == (24320,) and np.abs(pcm16 - z["pcm16k"]).max() < 1e-6
+    for n_mels in (80, 128):
+        got = mel.encoder_features(z["pcm16k"], n_mels)[0].T              # [n_mels, 3000]
+        ref = z[f"hf_mel{n_mels}"]
+        assert got.shape == ref.shape == (n_mels, 3000)
+        d = np.abs(got - ref)
+        assert d.max() < 2e-4, (n_mels, d.max())
+        assert ref[:, :152].std() > 0.2                                   # real speech: the compared region is not a constant floor

@@ -101,3 +101,37 @@ def test_incremental_mel_matches_oracle_chunk_by_chunk():
         assert dev.total_frames == orc.total_frames
         dev.reset()
         assert dev.total_frames == 0 and dev.process(audio[:10]) is None
+
+
+def test_reference_fixture_intention_wav_on_device():
+    """The reference's own speech fixture (Tests/media/intention.wav) through the device front end, against features computed by
+    HF transformers' WhisperFeatureExtractor (independent of this repo's oracle; committed by tests/golden/make_golden.py) and
+    against the oracle; then the streaming front end chunk by chunk over the same audio."""
+    import os
+    from gpu_util import record
+    from oracle.mel import IncrementalMelOracle
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "intention_whisper_features.npz"))
+    pcm = z["pcm16k"]
+    for n_mels in (80, 128):
+        got = mas.dsp.whisper_encoder_features(pcm, n_mels)[0]             # [3000, n_mels]
+        hf = z[f"hf_mel{n_mels}"].T
+        orc = omel.encoder_features(pcm, n_mels)[0]
+        d_hf, d_or = np.abs(got - hf), np.abs(got - orc)
+        record(f"intention_wav_mel{n_mels}", max_vs_hf=d_hf.max(), max_vs_oracle=d_or.max(), frac_over_1e4_vs_hf=float(np.mean(d_hf > 1e-4)),
+               tol_max=2e-3, tol_frac=1e-3)
+        _close(got, orc)
+        assert d_hf.max() < 2e-3 and np.mean(d_hf > 2e-4) < 1e-3, (n_mels, d_hf.max())
+    dev, orc = mas.dsp.IncrementalMelSpectrogram(n_mels=128), IncrementalMelOracle(n_mels=128)
+    pos, worst = 0, 0.0
+    for n in (1600, 37, 4000, 8000, 10683):                               # 24 320 samples in uneven chunks
+        g, r = dev.process(pcm[pos:pos + n]), orc.process(pcm[pos:pos + n])
+        pos += n
+        assert (g is None) == (r is None)
+        if r is not None:
+            assert g.shape == r.shape
+            worst = max(worst, float(np.abs(g - r).max()))
+    g, r = dev.flush(), orc.flush()
+    if r is not None:
+        worst = max(worst, float(np.abs(g - r).max()))
+    assert pos == len(pcm) and dev.total_frames == orc.total_frames and worst < 1e-4, worst
+    record("intention_wav_incremental_mel128", max_vs_oracle=worst, tol=1e-4)

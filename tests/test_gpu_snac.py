@@ -176,3 +176,37 @@ def test_orpheus_voice_cloning_prompt_uses_the_encode_path():
             list(flat + T.audio_token_offset) + [T.end_of_speech, T.audio_end, T.start_of_human] + Tok().encode("tara: hi") +
             [T.end_of_text, T.end_of_human])
     assert row.tolist() == want
+
+
+def test_snac_encode_decode_cycle_on_the_reference_fixture():
+    """Mirror of the reference's snacEncodeDecodeCycle smoke test (Tests/MLXAudioSmokeTests.swift:78-110): intention.wav (24 kHz)
+    -> SNAC.encode -> SNAC.decode, full snac_24khz dimensions, synthetic seeded weights (no checkpoints offline).  The reference
+    only expects a non-empty reconstruction; here the codes and the waveform are also compared with the oracle."""
+    import wave
+    import mlx_audio_swift_amd as mas
+    from gpu_util import record
+    w = wave.open(os.path.join(G, "intention.wav"))
+    pcm = np.frombuffer(w.readframes(w.getnframes()), dtype="<i2").astype(np.float32) / 32768.0
+    assert w.getframerate() == 24000
+    ocfg = osnac.SnacConfig()
+    W = osnac.make_synthetic_weights(ocfg, seed=1234, with_encoder=True)
+    orc = osnac.SnacOracle(ocfg, W)
+    hcfg = mas.SNACConfig(**{k: getattr(ocfg, k) for k in mas.SNACConfig.__dataclass_fields__})
+    dev = mas.SNAC.from_weights(hcfg, W)
+    audio = pcm[None]                                                    # [1, 36480]
+    codes = dev.encode_audio(audio)                                      # AudioCodecModel.encodeAudio
+    rcodes, dist = orc.encode(audio[:, None], return_details=True)
+    padded = dev.padded_length(audio.shape[1])
+    assert padded == 36864 and [c.shape for c in codes] == [(1, 18), (1, 36), (1, 72)]       # hop 512 x lcm(4,2,1): 72 latent frames
+    agree = []
+    for g, r, d in zip(codes, rcodes, dist):
+        ds = np.sort(d, -1)
+        sure = (ds[..., 1] - ds[..., 0]) > 1e-4
+        assert np.array_equal(g[sure], r[sure])
+        agree.append(float(np.mean(g == r)))
+    noise = osnac.synthetic_noise(ocfg, 1, 18, seed=3)
+    wav = dev.decode(codes, noise)                                       # AudioCodecModel.decodeAudio
+    ref = orc.decode([np.asarray(c) for c in codes], noise)
+    e = rms(wav, ref)
+    assert wav.shape == ref.shape == (1, 1, 36864) and wav.shape[-1] > 0 and e < TOL, e
+    record("intention_wav_snac_cycle", code_agreement=agree, wave_rms=e, tol_rms=TOL)
