@@ -263,9 +263,10 @@ typedef struct {
 } mis_tts_timing;
 mis_status mis_tts_set_profiling(mis_tts*, int enabled);
 mis_status mis_tts_last_timing(mis_tts*, mis_tts_timing* out);
-/* time `iters` launches of one weight-streaming GEMM of the decode step in isolation (HIP events on
- * the library stream): which = 0 qkv, 1 o_proj, 2 gate_up, 3 down, 4 lm_head.  avg_ms and the
- * algorithmic bytes of one launch are returned.  Used by bench.py for the roofline object. */
+/* time `iters` launches of one kernel of the decode step in isolation (HIP events on the library stream), rotating over the
+ * layers so the Infinity Cache cannot serve the operands: which = 0 qkv, 1 o_proj, 2 gate_up, 3 down, 4 lm_head (weight-streaming
+ * GEMMs), 5 decode attention at context 368 (the C3 mean; bytes = K/V rows read), 6 the slab-reduce + residual + RMSNorm kernel.
+ * avg_ms and the algorithmic bytes of one launch are returned.  Used by bench.py for the roofline object. */
 mis_status mis_tts_time_gemm(mis_tts*, int which, int batch, int iters, double* avg_ms, double* bytes);
 
 /* ------------------------------------------------------------------------------------------

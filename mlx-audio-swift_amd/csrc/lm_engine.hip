@@ -1099,10 +1099,19 @@ extern "C" mis_status mis_tts_time_gemm(mis_tts* c, int which, int batch, int it
     MIS_API_BEGIN
     MIS_REQUIRE(c && avg_ms && bytes && iters >= 1, MIS_ERR_INVALID_INPUT, "bad argument");
     MIS_REQUIRE(c->finalized, MIS_ERR_NOT_INITIALIZED, "model not finalized");
-    if (c->batch != batch) lm_reset(c, batch, 64);
+    static const int attn_ctx = std::max(1, env_int("MIS_TIME_ATTN_CTX", 368));      // mean context of the C3 workload
+    if (c->batch != batch || (which == 5 && c->Smax < attn_ctx + 1)) lm_reset(c, batch, which == 5 ? attn_ctx + 1 : 64);
     HIP_CHECK(hipSetDevice(c->device));
     hipStream_t s = c->stream;
     const int d = c->d, HD = c->H * c->D, Mpad = c->Mpad;
+    if (which == 5) {           // decode attention of every row at context attn_ctx (positions / active flags set once)
+        std::vector<int32_t> pos(Mpad, attn_ctx);
+        std::vector<uint8_t> act(Mpad, 0);
+        for (int b = 0; b < batch; ++b) act[b] = 1;
+        HIP_CHECK(hipMemcpyAsync(c->pos_cur.p, pos.data(), Mpad * 4, hipMemcpyHostToDevice, s));
+        HIP_CHECK(hipMemcpyAsync(c->active.p, act.data(), Mpad, hipMemcpyHostToDevice, s));
+        HIP_CHECK(hipStreamSynchronize(s));
+    }
     // rotate over the layers so consecutive launches stream DIFFERENT weights (the 256 MB Infinity Cache
     // must not serve them); lm_head (0.96 GB) exceeds the cache by itself.
     auto run = [&](int it) {
@@ -1114,7 +1123,20 @@ extern "C" mis_status mis_tts_time_gemm(mis_tts* c, int which, int batch, int it
             case 2: launch_gemm_skinny(EPI_SILU_MUL, 2, c->ksb_gu, c->wgu.p + layer_gu_elems(c) * li, c->x.p, c->act.p, 2 * c->ff / 16, d / 32, 1, c->ff, Mpad, s); break;
             case 3: launch_gemm_skinny(EPI_PARTIAL, c->r_part, c->ksb_part, c->wdown.p + layer_down_elems(c) * li, c->act.p, c->part.p, d / 16, c->ff / 32, c->S_down, d, Mpad, s); break;
             case 4: enqueue_lm_head(c); break;
-            default: throw MisError(MIS_ERR_INVALID_INPUT, "unknown GEMM id");
+            case 5: {
+                AttnParams ap{};
+                ap.qkv_part = c->qkv_part.p; ap.S = c->S_qkv; ap.Mpad = Mpad; ap.Nqkv = c->Nqkv;
+                size_t lkv = (size_t)c->batch * c->Hkv * c->Smax * c->D;
+                ap.kcache = c->kcache.p + lkv * li; ap.vtcache = c->vtcache.p + lkv * li;
+                ap.pos = c->pos_cur.p; ap.active = c->active.p; ap.rope_cos = c->rope_cos.p; ap.rope_sin = c->rope_sin.p;
+                ap.out = c->attn_out.p; ap.H = c->H; ap.Hkv = c->Hkv; ap.D = c->D; ap.Smax = c->Smax; ap.scale = 1.0f / sqrtf((float)c->D);
+                if (c->cfg.qk_norm) { ap.qnorm_w = c->qknorm.p + (size_t)(2 * li) * c->D; ap.knorm_w = c->qknorm.p + (size_t)(2 * li + 1) * c->D; ap.qk_eps = c->cfg.rms_norm_eps; }
+                ap.rope_in_dtype = c->cfg.rope_ops_in_dtype;
+                launch_attn_decode(ap, c->batch, s);
+                break;
+            }
+            case 6: launch_reduce_residual_rmsnorm(c->part.p, c->S_down, Mpad, d, c->h.p, c->norms.p + (size_t)(2 * li) * d, c->x.p, c->cfg.rms_norm_eps, s); break;
+            default: throw MisError(MIS_ERR_INVALID_INPUT, "unknown kernel id");
         }
     };
     double b = 0;
@@ -1123,6 +1145,8 @@ extern "C" mis_status mis_tts_time_gemm(mis_tts* c, int which, int batch, int it
         case 1: b = 2.0 * d * HD; break;
         case 2: b = 2.0 * 2.0 * c->ff * d; break;
         case 3: b = 2.0 * d * c->ff; break;
+        case 5: b = (double)batch * (attn_ctx + 1) * 2.0 * c->Hkv * c->D * 2.0; break;      // K and V rows of every cached key, bf16
+        case 6: b = (double)c->S_down * Mpad * d * 4.0 + 2.0 * (double)Mpad * d * 2.0; break;  // slabs + residual stream (cache resident)
         default: b = 2.0 * (double)c->V * d; break;
     }
     run(0);   // warm
