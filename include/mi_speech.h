@@ -250,6 +250,49 @@ mis_status mis_tts_generate_stream(mis_tts*, const int32_t* prompt_ids, const in
                                    const mis_gen_params* params, const float* const* snac_noise,
                                    mis_event_cb on_event, void* user, const volatile int* cancel_flag);
 
+/* ------------------------------------------------------------------------------------------
+ * Multi-GPU: utterance-batch data parallelism behind the boundary (the reference is single-device and has
+ * no counterpart).  Rows are independent units; every GPU holds a full replica of the weights (the host loads one mis_tts per
+ * device, exactly as it loads one); a batch is cut into contiguous row blocks (mis_shard_rows); the sampler / codec-noise RNG is
+ * keyed by the GLOBAL row index (row_offset), so every row's tokens and samples are independent of the number of shards; the only
+ * exchange is ONE all-gather of the decoded PCM (+ lengths) at the end.
+ * ---------------------------------------------------------------------------------------- */
+/* contiguous block [*lo, *hi) of `rank` among `world` shards; block sizes differ by at most one row */
+void mis_shard_rows(int n_rows, int rank, int world, int* lo, int* hi);
+
+/* (1) SINGLE PROCESS, N devices (a Swift host): a group of replicas - one finalized mis_tts (with its own codec) per device;
+ * devices may repeat (logical shards of one GPU).  The group borrows the handles. */
+typedef struct mis_group mis_group;
+typedef struct { int32_t n_shards; double generate_ms, slowest_shard_ms, gather_ms; } mis_group_timing;
+mis_status mis_tts_group_create(mis_tts* const* replicas, int n, mis_group** out);
+void       mis_tts_group_destroy(mis_group*);
+int        mis_tts_group_size(const mis_group*);
+/* mis_tts_generate over the group: one worker thread + stream per replica, each generating its block with row_offset advanced by
+ * the block start; outputs as mis_tts_generate (rows in batch order, one pinned host buffer) - identical, bit for bit, to the
+ * single-handle call. */
+mis_status mis_tts_group_generate(mis_group*, const int32_t* prompt_ids, const int32_t* prompt_lens, int batch,
+                                  const mis_gen_params* params, float** pcm_out, int64_t* pcm_stride, int64_t* pcm_lens,
+                                  int32_t** tokens_out, int64_t* tokens_stride, int32_t* n_tokens);
+/* PCM left in HBM and all-gathered: pcm_dev[i] = replica i's DEVICE buffer [batch, pcm_stride] on its own GPU; on return every
+ * buffer holds every row (each replica writes its block into every peer's buffer over xGMI: direct peer copies). */
+mis_status mis_tts_group_generate_device(mis_group*, const int32_t* prompt_ids, const int32_t* prompt_lens, int batch,
+                                         const mis_gen_params* params, float* const* pcm_dev, int64_t pcm_stride,
+                                         int64_t* pcm_lens, int32_t* n_tokens);
+mis_status mis_tts_group_last_timing(mis_group*, mis_group_timing* out);
+
+/* (2) ONE PROCESS PER GPU (any launcher; what bench.py --gpus N runs): an RCCL communicator behind the ABI.  Rank 0 obtains a
+ * 128-byte id (ncclUniqueId), the host distributes it to the other ranks by whatever means it has, every rank creates its
+ * communicator, generates its block with mis_tts_generate_device(row_offset = block start) and calls the all-gather:
+ * pcm_local_dev [rows_local, stride] -> pcm_all_dev [world * rows_local, stride] (device), lens (host) likewise; RCCL
+ * ncclAllGather over xGMI on the communicator's stream; *gather_ms (nullable) = device time of the exchange. */
+typedef struct mis_comm mis_comm;
+#define MIS_COMM_ID_BYTES 128
+mis_status mis_comm_unique_id(void* id_out /* MIS_COMM_ID_BYTES */);
+mis_status mis_comm_create(int device, int rank, int world, const void* unique_id, mis_comm** out);
+void       mis_comm_destroy(mis_comm*);
+mis_status mis_comm_all_gather_pcm(mis_comm*, const float* pcm_local_dev, const int64_t* lens_local, int rows_local,
+                                   int64_t stride, float* pcm_all_dev, int64_t* lens_all, double* gather_ms);
+
 /* per-phase device timings of the last generate (ms): [0]=prefill [1]=decode loop [2]=parse+codec,
  * plus average duration (ms) and launch count of the dominant GEMM kernel measured with HIP events
  * on the library's own stream when profiling is enabled with mis_tts_set_profiling(ctx, 1). */

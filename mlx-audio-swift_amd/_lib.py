@@ -106,6 +106,10 @@ class SttParamsC(C.Structure):
                 ("begin_suppress", C.c_void_p), ("n_begin_suppress", C.c_int32)]
 
 
+class GroupTimingC(C.Structure):
+    _fields_ = [("n_shards", C.c_int32), ("generate_ms", C.c_double), ("slowest_shard_ms", C.c_double), ("gather_ms", C.c_double)]
+
+
 class TimingC(C.Structure):
     _fields_ = [("prefill_ms", C.c_double), ("decode_ms", C.c_double), ("codec_ms", C.c_double),
                 ("step_ms_avg", C.c_double), ("steps", C.c_int32), ("gemm_probe_ms", C.c_double),
@@ -156,6 +160,18 @@ SYMBOLS = {
     "mis_tts_set_profiling": (C.c_int, [_P, C.c_int]),
     "mis_tts_last_timing": (C.c_int, [_P, C.POINTER(TimingC)]),
     "mis_tts_time_gemm": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
+    "mis_shard_rows": (None, [C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "mis_tts_group_create": (C.c_int, [C.POINTER(_P), C.c_int, C.POINTER(_P)]),
+    "mis_tts_group_destroy": (None, [_P]),
+    "mis_tts_group_size": (C.c_int, [_P]),
+    "mis_tts_group_generate": (C.c_int, [_P, _P, _P, C.c_int, C.POINTER(GenParamsC), C.POINTER(_P), C.POINTER(C.c_int64), _P,
+                                         C.POINTER(_P), C.POINTER(C.c_int64), _P]),
+    "mis_tts_group_generate_device": (C.c_int, [_P, _P, _P, C.c_int, C.POINTER(GenParamsC), C.POINTER(_P), C.c_int64, _P, _P]),
+    "mis_tts_group_last_timing": (C.c_int, [_P, C.POINTER(GroupTimingC)]),
+    "mis_comm_unique_id": (C.c_int, [_P]),
+    "mis_comm_create": (C.c_int, [C.c_int, C.c_int, C.c_int, _P, C.POINTER(_P)]),
+    "mis_comm_destroy": (None, [_P]),
+    "mis_comm_all_gather_pcm": (C.c_int, [_P, _P, _P, C.c_int, C.c_int64, _P, _P, C.POINTER(C.c_double)]),
     "mis_mel_num_frames": (C.c_int64, [C.POINTER(MelConfigC), C.c_int64]),
     "mis_mel_spectrogram": (C.c_int, [C.c_int, C.POINTER(MelConfigC), _P, C.c_int, C.c_int64, _P, C.POINTER(C.c_int64)]),
     "mis_whisper_encoder_features": (C.c_int, [C.c_int, _P, _P, C.c_int, C.c_int64, C.c_int, _P]),

@@ -1,0 +1,321 @@
+// group.hip - utterance data parallelism BEHIND the C ABI: the rows of a batch are independent units, every
+// GPU holds a full weight replica, rows are sharded in contiguous blocks, the RNG is keyed by the GLOBAL row (mis_gen_params.
+// row_offset) so results do not depend on the shard count, and the only exchange is ONE all-gather of the decoded PCM at the end.
+// The reference has no counterpart (single device); a Swift host cannot call torch.distributed, so both forms live here:
+//   mis_group  single process, N replicas (one per device): one worker thread + stream per GPU inside mis_tts_group_generate*,
+//              all-gather by direct peer writes over xGMI (hipMemcpyPeerAsync: every rank writes its block into every peer's
+//              buffer - xGMI is point-to-point, 7 links per GPU, so the direct form uses all links at once where a ring all-gather is
+//              bound by one);
+//   mis_comm   one process per GPU (the bench contract: torchrun / any launcher): RCCL communicator created from a broadcast
+//              ncclUniqueId, ncclAllGather of the PCM blocks and lengths on the library's stream.  librccl is dlopen'ed so that the
+//              library still loads on hosts without RCCL.
+#include "common.h"
+#include "kernels.h"
+
+#include <dlfcn.h>
+#include <string.h>
+#include <chrono>
+#include <thread>
+
+// ---------------------------------------------------------------------------- RCCL (dlopen)
+namespace {
+typedef struct { char internal[128]; } rccl_unique_id;            // ncclUniqueId (rccl.h: NCCL_UNIQUE_ID_BYTES = 128)
+typedef void* rccl_comm_t;
+enum { RCCL_INT64 = 4, RCCL_FLOAT32 = 7 };                        // ncclDataType_t values used here (rccl.h)
+struct RcclApi {
+    void* handle = nullptr;
+    int (*GetUniqueId)(rccl_unique_id*) = nullptr;
+    int (*CommInitRank)(rccl_comm_t*, int, rccl_unique_id, int) = nullptr;
+    int (*AllGather)(const void*, void*, size_t, int, rccl_comm_t, hipStream_t) = nullptr;
+    int (*CommDestroy)(rccl_comm_t) = nullptr;
+    const char* (*GetErrorString)(int) = nullptr;
+};
+RcclApi* rccl() {
+    static RcclApi api;
+    static bool tried = false;
+    if (tried) return api.handle ? &api : nullptr;
+    tried = true;
+    std::vector<std::string> names;
+    if (const char* p = getenv("MIS_RCCL_PATH")) names.push_back(p);
+    names.push_back("librccl.so.1");
+    names.push_back("librccl.so");
+    names.push_back("/opt/rocm/lib/librccl.so.1");
+    void* h = nullptr;
+    for (auto& n : names) if ((h = dlopen(n.c_str(), RTLD_NOW | RTLD_NOLOAD))) break;      // a copy the host already loaded (torch bundles one)
+    if (!h) for (auto& n : names) if ((h = dlopen(n.c_str(), RTLD_NOW | RTLD_GLOBAL))) break;
+    if (!h) return nullptr;
+    api.GetUniqueId = (int (*)(rccl_unique_id*))dlsym(h, "ncclGetUniqueId");
+    api.CommInitRank = (int (*)(rccl_comm_t*, int, rccl_unique_id, int))dlsym(h, "ncclCommInitRank");
+    api.AllGather = (int (*)(const void*, void*, size_t, int, rccl_comm_t, hipStream_t))dlsym(h, "ncclAllGather");
+    api.CommDestroy = (int (*)(rccl_comm_t))dlsym(h, "ncclCommDestroy");
+    api.GetErrorString = (const char* (*)(int))dlsym(h, "ncclGetErrorString");
+    if (!api.GetUniqueId || !api.CommInitRank || !api.AllGather || !api.CommDestroy) return nullptr;
+    api.handle = h;
+    return &api;
+}
+#define RCCL_CHECK(expr)                                                                                     \
+    do {                                                                                                     \
+        int _r = (expr);                                                                                     \
+        if (_r != 0) {                                                                                       \
+            char _b[256];                                                                                    \
+            snprintf(_b, sizeof(_b), "%s failed: %s", #expr, rccl()->GetErrorString ? rccl()->GetErrorString(_r) : "rccl error"); \
+            throw MisError(MIS_ERR_DEVICE, _b);                                                              \
+        }                                                                                                    \
+    } while (0)
+}   // namespace
+
+struct mis_comm {
+    int device = 0, rank = 0, world = 1;
+    rccl_comm_t comm = nullptr;
+    hipStream_t stream = nullptr;
+    DevBuf<int64_t> lens_local, lens_all;
+    double last_gather_ms = 0;
+};
+
+extern "C" mis_status mis_comm_unique_id(void* id_out) {
+    MIS_API_BEGIN
+    MIS_REQUIRE(id_out, MIS_ERR_INVALID_INPUT, "null argument");
+    MIS_REQUIRE(rccl(), MIS_ERR_DEVICE, "librccl could not be loaded (set MIS_RCCL_PATH)");
+    rccl_unique_id id;
+    RCCL_CHECK(rccl()->GetUniqueId(&id));
+    memcpy(id_out, &id, sizeof(id));
+    MIS_API_END
+}
+
+extern "C" mis_status mis_comm_create(int device, int rank, int world, const void* unique_id, mis_comm** out) {
+    MIS_API_BEGIN
+    MIS_REQUIRE(out && unique_id && world >= 1 && rank >= 0 && rank < world, MIS_ERR_INVALID_INPUT, "bad communicator arguments");
+    MIS_REQUIRE(rccl(), MIS_ERR_DEVICE, "librccl could not be loaded (set MIS_RCCL_PATH)");
+    int n = 0;
+    HIP_CHECK(hipGetDeviceCount(&n));
+    MIS_REQUIRE(device >= 0 && device < n, MIS_ERR_DEVICE, "device %d not available (%d GPUs visible)", device, n);
+    HIP_CHECK(hipSetDevice(device));
+    mis_comm* c = new mis_comm();
+    c->device = device; c->rank = rank; c->world = world;
+    try {
+        rccl_unique_id id;
+        memcpy(&id, unique_id, sizeof(id));
+        RCCL_CHECK(rccl()->CommInitRank(&c->comm, world, id, rank));
+        HIP_CHECK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    } catch (...) { delete c; throw; }
+    *out = c;
+    MIS_API_END
+}
+
+extern "C" void mis_comm_destroy(mis_comm* c) {
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    if (c->stream) { (void)hipStreamSynchronize(c->stream); (void)hipStreamDestroy(c->stream); }
+    if (c->comm && rccl()) (void)rccl()->CommDestroy(c->comm);
+    delete c;
+}
+
+// The exchange step of SURVEY 8(e): every rank contributes rows_local rows of `stride` samples (device memory, the output of
+// mis_tts_generate_device) and their lengths; every rank receives all world * rows_local rows in rank order.  Fixed-size blocks
+// (weak scaling: the same number of rows per GPU).  Runs on the communicator's stream and returns when the data has landed.
+extern "C" mis_status mis_comm_all_gather_pcm(mis_comm* c, const float* pcm_local_dev, const int64_t* lens_local, int rows_local,
+                                              int64_t stride, float* pcm_all_dev, int64_t* lens_all, double* gather_ms) {
+    MIS_API_BEGIN
+    MIS_REQUIRE(c && pcm_local_dev && lens_local && pcm_all_dev && lens_all && rows_local >= 1 && stride >= 1, MIS_ERR_INVALID_INPUT, "bad argument");
+    HIP_CHECK(hipSetDevice(c->device));
+    hipStream_t s = c->stream;
+    c->lens_local.alloc(rows_local); c->lens_all.alloc((size_t)rows_local * c->world);
+    HIP_CHECK(hipMemcpyAsync(c->lens_local.p, lens_local, (size_t)rows_local * 8, hipMemcpyDefault, s));
+    hipEvent_t e0, e1;
+    HIP_CHECK(hipEventCreate(&e0)); HIP_CHECK(hipEventCreate(&e1));
+    HIP_CHECK(hipEventRecord(e0, s));
+    RCCL_CHECK(rccl()->AllGather(pcm_local_dev, pcm_all_dev, (size_t)rows_local * stride, RCCL_FLOAT32, c->comm, s));
+    RCCL_CHECK(rccl()->AllGather(c->lens_local.p, c->lens_all.p, (size_t)rows_local, RCCL_INT64, c->comm, s));
+    HIP_CHECK(hipEventRecord(e1, s));
+    HIP_CHECK(hipMemcpyAsync(lens_all, c->lens_all.p, (size_t)rows_local * c->world * 8, hipMemcpyDefault, s));
+    HIP_CHECK(hipStreamSynchronize(s));
+    float ms = 0;
+    HIP_CHECK(hipEventElapsedTime(&ms, e0, e1));
+    c->last_gather_ms = ms;
+    if (gather_ms) *gather_ms = ms;
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    MIS_API_END
+}
+
+// ---------------------------------------------------------------------------- single-process device group
+struct mis_group {
+    std::vector<mis_tts*> reps;
+    mis_group_timing timing{};
+};
+
+extern "C" mis_status mis_tts_group_create(mis_tts* const* replicas, int n, mis_group** out) {
+    MIS_API_BEGIN
+    MIS_REQUIRE(replicas && out && n >= 1 && n <= 64, MIS_ERR_INVALID_INPUT, "a group needs 1..64 replicas");
+    mis_group* g = new mis_group();
+    for (int i = 0; i < n; ++i) {
+        if (!replicas[i]) { delete g; throw MisError(MIS_ERR_INVALID_INPUT, "null replica handle"); }
+        for (int j = 0; j < i; ++j)
+            if (replicas[j] == replicas[i]) { delete g; throw MisError(MIS_ERR_INVALID_INPUT, "a handle may appear only once in a group (one in-flight call per handle)"); }
+        g->reps.push_back(replicas[i]);
+    }
+    *out = g;
+    MIS_API_END
+}
+extern "C" void mis_tts_group_destroy(mis_group* g) { delete g; }     // the replicas stay with their owner
+extern "C" int mis_tts_group_size(const mis_group* g) { return g ? (int)g->reps.size() : 0; }
+
+static void shard_block(int n_rows, int r, int world, int* lo, int* hi) {
+    const int base = n_rows / world, rem = n_rows % world;
+    *lo = r * base + std::min(r, rem);
+    *hi = *lo + base + (r < rem ? 1 : 0);
+}
+extern "C" void mis_shard_rows(int n_rows, int rank, int world, int* lo, int* hi) {
+    int a = 0, b = 0;
+    if (world >= 1 && rank >= 0 && rank < world && n_rows >= 0) shard_block(n_rows, rank, world, &a, &b);
+    if (lo) *lo = a;
+    if (hi) *hi = b;
+}
+
+namespace {
+struct ShardResult { mis_status st = MIS_OK; std::string err; double ms = 0; };
+struct HostPrompts { std::vector<int32_t> lens, flat; std::vector<size_t> off; };
+HostPrompts fetch_prompts(const int32_t* prompt_ids, const int32_t* prompt_lens, int batch) {
+    HostPrompts h;
+    h.lens.resize(batch);
+    HIP_CHECK(hipMemcpy(h.lens.data(), prompt_lens, (size_t)batch * 4, hipMemcpyDefault));
+    h.off.assign(batch + 1, 0);
+    for (int b = 0; b < batch; ++b) { MIS_REQUIRE(h.lens[b] >= 1, MIS_ERR_INVALID_INPUT, "empty prompt in row %d", b); h.off[b + 1] = h.off[b] + h.lens[b]; }
+    h.flat.resize(h.off[batch]);
+    HIP_CHECK(hipMemcpy(h.flat.data(), prompt_ids, h.off[batch] * 4, hipMemcpyDefault));
+    return h;
+}
+}   // namespace
+
+// generate for a batch sharded over the group's replicas, PCM left in HBM and ALL-GATHERED: pcm_dev[i] is replica i's buffer
+// [batch, pcm_stride] on its own device; on return every buffer holds every row.  One worker thread per replica runs
+// mis_tts_generate_device on that replica's rows with row_offset advanced by the block start (RNG keyed by the global row), then
+// writes its block into every peer's buffer (peer copies).  snac noise: drawn on the device (explicit noise is a single-device
+// test facility).
+extern "C" mis_status mis_tts_group_generate_device(mis_group* g, const int32_t* prompt_ids, const int32_t* prompt_lens, int batch,
+                                                    const mis_gen_params* params, float* const* pcm_dev, int64_t pcm_stride,
+                                                    int64_t* pcm_lens, int32_t* n_tokens) {
+    MIS_API_BEGIN
+    MIS_REQUIRE(g && prompt_ids && prompt_lens && params && pcm_dev && pcm_lens, MIS_ERR_INVALID_INPUT, "null argument");
+    const int W = (int)g->reps.size();
+    MIS_REQUIRE(batch >= W, MIS_ERR_INVALID_INPUT, "batch %d smaller than the group (%d replicas)", batch, W);
+    for (int r = 0; r < W; ++r) MIS_REQUIRE(pcm_dev[r], MIS_ERR_INVALID_INPUT, "null PCM buffer for replica %d", r);
+    HostPrompts hp = fetch_prompts(prompt_ids, prompt_lens, batch);
+    std::vector<ShardResult> res(W);
+    std::vector<int32_t> ntok(batch, 0);
+    std::vector<int64_t> plens(batch, 0);
+    auto t0 = std::chrono::steady_clock::now();
+    std::vector<std::thread> th;
+    for (int r = 0; r < W; ++r)
+        th.emplace_back([&, r]() {
+            int lo, hi;
+            shard_block(batch, r, W, &lo, &hi);
+            mis_gen_params p = *params;
+            p.row_offset += lo;
+            auto a = std::chrono::steady_clock::now();
+            res[r].st = mis_tts_generate_device(g->reps[r], hp.flat.data() + hp.off[lo], hp.lens.data() + lo, hi - lo, &p, nullptr,
+                                                pcm_dev[r] + (size_t)lo * pcm_stride, pcm_stride, plens.data() + lo, ntok.data() + lo);
+            if (res[r].st != MIS_OK) res[r].err = mis_last_error();      // thread-local message: capture it on this thread
+            res[r].ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - a).count();
+        });
+    for (auto& t : th) t.join();
+    auto t1 = std::chrono::steady_clock::now();
+    for (int r = 0; r < W; ++r)
+        if (res[r].st != MIS_OK) throw MisError(res[r].st, "shard " + std::to_string(r) + ": " + res[r].err);
+    // ---- all-gather by direct peer writes: rank r's block -> every other replica's buffer, issued on r's own stream
+    for (int r = 0; r < W; ++r) {
+        int lo, hi;
+        shard_block(batch, r, W, &lo, &hi);
+        const int dr = tts_device(g->reps[r]);
+        HIP_CHECK(hipSetDevice(dr));
+        hipStream_t s = tts_stream(g->reps[r]);
+        const size_t bytes = (size_t)(hi - lo) * pcm_stride * 4;
+        for (int q = 0; q < W; ++q) {
+            if (q == r || pcm_dev[q] == pcm_dev[r]) continue;
+            const int dq = tts_device(g->reps[q]);
+            if (dq == dr) HIP_CHECK(hipMemcpyAsync(pcm_dev[q] + (size_t)lo * pcm_stride, pcm_dev[r] + (size_t)lo * pcm_stride, bytes, hipMemcpyDeviceToDevice, s));
+            else HIP_CHECK(hipMemcpyPeerAsync(pcm_dev[q] + (size_t)lo * pcm_stride, dq, pcm_dev[r] + (size_t)lo * pcm_stride, dr, bytes, s));
+        }
+    }
+    for (int r = 0; r < W; ++r) { HIP_CHECK(hipSetDevice(tts_device(g->reps[r]))); HIP_CHECK(hipStreamSynchronize(tts_stream(g->reps[r]))); }
+    auto t2 = std::chrono::steady_clock::now();
+    g->timing.n_shards = W;
+    g->timing.generate_ms = std::chrono::duration<double, std::milli>(t1 - t0).count();
+    g->timing.gather_ms = std::chrono::duration<double, std::milli>(t2 - t1).count();
+    g->timing.slowest_shard_ms = 0;
+    for (int r = 0; r < W; ++r) g->timing.slowest_shard_ms = std::max(g->timing.slowest_shard_ms, res[r].ms);
+    for (int b = 0; b < batch; ++b) pcm_lens[b] = plens[b];
+    if (n_tokens) for (int b = 0; b < batch; ++b) n_tokens[b] = ntok[b];
+    MIS_API_END
+}
+
+// Same, gathering to HOST memory (what a Swift host hands back as MLXArrays): each shard's rows are copied device -> pinned host
+// straight into their place of one [batch, *pcm_stride] buffer (no peer traffic is needed for a host-side gather).
+extern "C" mis_status mis_tts_group_generate(mis_group* g, const int32_t* prompt_ids, const int32_t* prompt_lens, int batch,
+                                             const mis_gen_params* params, float** pcm_out, int64_t* pcm_stride, int64_t* pcm_lens,
+                                             int32_t** tokens_out, int64_t* tokens_stride, int32_t* n_tokens) {
+    MIS_API_BEGIN
+    MIS_REQUIRE(g && prompt_ids && prompt_lens && params && pcm_out && pcm_stride && pcm_lens, MIS_ERR_INVALID_INPUT, "null argument");
+    const int W = (int)g->reps.size();
+    MIS_REQUIRE(batch >= W, MIS_ERR_INVALID_INPUT, "batch %d smaller than the group (%d replicas)", batch, W);
+    HostPrompts hp = fetch_prompts(prompt_ids, prompt_lens, batch);
+    struct Part { float* pcm = nullptr; int64_t stride = 0; int32_t* tok = nullptr; int64_t tstride = 0; };
+    std::vector<Part> part(W);
+    std::vector<ShardResult> res(W);
+    std::vector<int32_t> ntok(batch, 0);
+    std::vector<int64_t> plens(batch, 0);
+    auto t0 = std::chrono::steady_clock::now();
+    std::vector<std::thread> th;
+    for (int r = 0; r < W; ++r)
+        th.emplace_back([&, r]() {
+            int lo, hi;
+            shard_block(batch, r, W, &lo, &hi);
+            mis_gen_params p = *params;
+            p.row_offset += lo;
+            auto a = std::chrono::steady_clock::now();
+            res[r].st = mis_tts_generate(g->reps[r], hp.flat.data() + hp.off[lo], hp.lens.data() + lo, hi - lo, &p, nullptr, &part[r].pcm,
+                                         &part[r].stride, plens.data() + lo, tokens_out ? &part[r].tok : nullptr, &part[r].tstride,
+                                         ntok.data() + lo);
+            if (res[r].st != MIS_OK) res[r].err = mis_last_error();
+            res[r].ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - a).count();
+        });
+    for (auto& t : th) t.join();
+    auto t1 = std::chrono::steady_clock::now();
+    auto free_parts = [&]() { for (auto& p : part) { if (p.pcm) mis_free(p.pcm); if (p.tok) mis_free(p.tok); p.pcm = nullptr; p.tok = nullptr; } };
+    for (int r = 0; r < W; ++r)
+        if (res[r].st != MIS_OK) { free_parts(); throw MisError(res[r].st, "shard " + std::to_string(r) + ": " + res[r].err); }
+    int64_t longest = 1, tlongest = 1;
+    for (int r = 0; r < W; ++r) { longest = std::max(longest, part[r].stride); tlongest = std::max(tlongest, part[r].tstride); }
+    try {
+        PinnedBuf<float> host((size_t)batch * longest);
+        memset(host.p, 0, (size_t)batch * longest * 4);
+        PinnedBuf<int32_t> thost;
+        if (tokens_out) { thost.alloc((size_t)batch * tlongest); memset(thost.p, 0, (size_t)batch * tlongest * 4); }
+        for (int r = 0; r < W; ++r) {
+            int lo, hi;
+            shard_block(batch, r, W, &lo, &hi);
+            for (int b = lo; b < hi; ++b) {
+                memcpy(host.p + (size_t)b * longest, part[r].pcm + (size_t)(b - lo) * part[r].stride, (size_t)plens[b] * 4);
+                if (tokens_out) memcpy(thost.p + (size_t)b * tlongest, part[r].tok + (size_t)(b - lo) * part[r].tstride, (size_t)part[r].tstride * 4);
+            }
+        }
+        *pcm_out = host.release(); *pcm_stride = longest;
+        if (tokens_out) { *tokens_out = thost.release(); if (tokens_stride) *tokens_stride = tlongest; }
+    } catch (...) { free_parts(); throw; }
+    free_parts();
+    auto t2 = std::chrono::steady_clock::now();
+    g->timing.n_shards = W;
+    g->timing.generate_ms = std::chrono::duration<double, std::milli>(t1 - t0).count();
+    g->timing.gather_ms = std::chrono::duration<double, std::milli>(t2 - t1).count();
+    g->timing.slowest_shard_ms = 0;
+    for (int r = 0; r < W; ++r) g->timing.slowest_shard_ms = std::max(g->timing.slowest_shard_ms, res[r].ms);
+    for (int b = 0; b < batch; ++b) pcm_lens[b] = plens[b];
+    if (n_tokens) for (int b = 0; b < batch; ++b) n_tokens[b] = ntok[b];
+    MIS_API_END
+}
+
+extern "C" mis_status mis_tts_group_last_timing(mis_group* g, mis_group_timing* out) {
+    MIS_API_BEGIN
+    MIS_REQUIRE(g && out, MIS_ERR_INVALID_INPUT, "null argument");
+    *out = g->timing;
+    MIS_API_END
+}

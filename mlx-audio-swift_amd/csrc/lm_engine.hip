@@ -748,7 +748,7 @@ static void run_generate(mis_tts* c, const int32_t* prompt_ids, const int32_t* p
     };
     auto capture = [&](hipGraphExec_t* exec, auto&& body) {
         hipGraph_t g = nullptr;
-        HIP_CHECK(hipStreamBeginCapture(s, hipStreamCaptureModeGlobal));
+        HIP_CHECK(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
         try { body(); } catch (...) { hipGraph_t dead = nullptr; (void)hipStreamEndCapture(s, &dead); if (dead) (void)hipGraphDestroy(dead); throw; }
         HIP_CHECK(hipStreamEndCapture(s, &g));
         HIP_CHECK(hipGraphInstantiate(exec, g, nullptr, nullptr, 0));
@@ -1279,7 +1279,7 @@ extern "C" mis_status mis_debug_launch_floor(int device, int n_kernels, int mode
     dim3 grid(mode == 0 ? 1 : (mode == 1 ? 32 : 1024)), block(mode == 0 ? 64 : (mode == 1 ? 1024 : 256));
     hipGraph_t g = nullptr;
     hipGraphExec_t ge = nullptr;
-    HIP_CHECK(hipStreamBeginCapture(s, hipStreamCaptureModeGlobal));
+    HIP_CHECK(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
     for (int i = 0; i < n_kernels; ++i) {
         const float* src = (i & 1) ? b.p : a.p;
         float* dst = (i & 1) ? a.p : b.p;

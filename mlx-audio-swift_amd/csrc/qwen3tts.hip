@@ -383,7 +383,7 @@ void q3_generate_codes(mis_qwen3tts* c, const int32_t* text_ids, const int32_t* 
 
     auto capture = [&](hipGraphExec_t* exec, auto&& body) {
         hipGraph_t g = nullptr;
-        HIP_CHECK(hipStreamBeginCapture(s, hipStreamCaptureModeGlobal));
+        HIP_CHECK(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
         try { body(); } catch (...) { hipGraph_t dead = nullptr; (void)hipStreamEndCapture(s, &dead); if (dead) (void)hipGraphDestroy(dead); throw; }
         HIP_CHECK(hipStreamEndCapture(s, &g));
         HIP_CHECK(hipGraphInstantiate(exec, g, nullptr, nullptr, 0));

@@ -646,7 +646,7 @@ static void whisper_generate_impl(mis_whisper* c, const float* pcm, const int64_
     try {
         if (use_graph) {
             hipGraph_t g = nullptr;
-            HIP_CHECK(hipStreamBeginCapture(s, hipStreamCaptureModeGlobal));
+            HIP_CHECK(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
             try { step_body(); } catch (...) { hipGraph_t dead = nullptr; (void)hipStreamEndCapture(s, &dead); if (dead) (void)hipGraphDestroy(dead); throw; }
             HIP_CHECK(hipStreamEndCapture(s, &g));
             HIP_CHECK(hipGraphInstantiate(&gexec, g, nullptr, nullptr, 0));

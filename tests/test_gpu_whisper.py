@@ -257,7 +257,8 @@ def test_generate_stream_tokens_then_result_and_mlx_directory_loader(tmp_path):
     (d / "config.json").write_text(json.dumps({"n_vocab": hc.vocab_size, "n_mels": hc.num_mel_bins, "n_audio_state": hc.d_model,
                                                "n_audio_layer": hc.encoder_layers, "n_audio_head": hc.encoder_attention_heads,
                                                "n_audio_ctx": 1500, "n_text_layer": hc.decoder_layers,
-                                               "n_text_head": hc.decoder_attention_heads, "n_text_ctx": hc.max_target_positions}))
+                                               "n_text_head": hc.decoder_attention_heads, "n_text_ctx": hc.max_target_positions,
+                                               "encoder_ffn_dim": hc.encoder_ffn_dim, "decoder_ffn_dim": hc.decoder_ffn_dim}))
     (d / "generation_config.json").write_text(json.dumps({"suppress_tokens": [1, 2, 3], "begin_suppress_tokens": [599]}))
     loaded = mas.WhisperModel.from_model_directory(str(d))
     assert loaded.generation_config["suppress_tokens"] == [1, 2, 3]
