@@ -6,7 +6,7 @@ A "step" = one full batched generate(): 32-token prompts -> prefill -> 672 decod
 sampling (T=0.6, top-p 0.8, repetition penalty 1.3 over 20 tokens; frame-constrained so that random
 weights emit valid SNAC frames - every vocabulary entry is still processed) -> parseOutput ->
 de-interleave -> SNAC 24 kHz decode of 96 frames per row -> PCM resident in HBM (+ one RCCL all-gather of
-the PCM when N > 1).  Inputs are resident in HBM/host-pinned-free: prompts are 4 KiB.
+the PCM when N > 1, inside the library: mis_comm_all_gather_pcm).  Inputs are resident in HBM/host-pinned-free: prompts are 4 KiB.
 
   python bench.py --gpus 1 --steps 2 --warmup 1
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
@@ -163,7 +163,7 @@ def main():
     torch.cuda.set_device(device)
 
     import mlx_audio_swift_amd as mas
-    from mlx_audio_swift_amd.sharding import all_gather_pcm
+    from mlx_audio_swift_amd.sharding import Communicator
     from mlx_audio_swift_amd.synthetic import snac_synthetic_weights
 
     snac_cfg = mas.SNACConfig()                                            # snac_24khz dims
@@ -187,13 +187,28 @@ def main():
     ntok = (C.c_int32 * ROWS_PER_GPU)()
     L = mas._lib.lib()
 
+    # N > 1: the one exchange of the path - an all-gather of the decoded PCM - runs INSIDE the library (mis_comm_*: RCCL
+    # ncclAllGather over xGMI on the library's stream); torch.distributed only ships the 128-byte communicator id (bootstrap)
+    # and provides the barrier / max-over-ranks of the timing contract
+    comm, pcm_all, gather_ms = None, None, []
+    if world > 1:
+        def bcast(raw):
+            obj = [raw]
+            dist.broadcast_object_list(obj, src=0)
+            return obj[0]
+        comm = Communicator(device, rank, world, bcast)
+        pcm_all = torch.zeros((n_rows, n_samples), dtype=torch.float32, device=f"cuda:{device}")
+
     def step():
         st = L.mis_tts_generate_device(lm._h, flat.ctypes.data, lens.ctypes.data, ROWS_PER_GPU, C.byref(gpc), None,
                                        pcm.data_ptr(), n_samples, plens, ntok)
         if st != 0:
             raise RuntimeError(mas._lib.last_error())
-        lens_t = torch.tensor(list(plens), dtype=torch.int64, device=pcm.device)
-        return all_gather_pcm(pcm, lens_t, n_rows)
+        if comm is None:
+            return pcm, np.asarray(list(plens), np.int64)
+        lens_all, ms = comm.all_gather_pcm(pcm.data_ptr(), list(plens), ROWS_PER_GPU, n_samples, pcm_all.data_ptr())
+        gather_ms.append(ms)
+        return pcm_all, lens_all
 
     def sync():
         torch.cuda.synchronize()
@@ -213,7 +228,7 @@ def main():
         t = torch.tensor([elapsed], dtype=torch.float64, device=pcm.device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-    audio_s = float(alll.sum().item()) / 24000.0 * args.steps
+    audio_s = float(alll.sum()) / 24000.0 * args.steps
     value = audio_s / elapsed
     timing = lm.last_timing()
 
@@ -268,7 +283,8 @@ def main():
                        "rows_per_gpu": ROWS_PER_GPU, "global_rows": n_rows, "prompt_len": PROMPT_LEN,
                        "new_tokens": NEW_TOKENS, "parallelism": f"utterance-dp{world}", "sampler": "T0.6 top-p0.8 rep1.3"},
             "value_per_gpu": value / world,
-            "phases_ms": {"prefill": timing["prefill_ms"], "decode": timing["decode_ms"], "codec": timing["codec_ms"]},
+            "phases_ms": {"prefill": timing["prefill_ms"], "decode": timing["decode_ms"], "codec": timing["codec_ms"],
+                          "all_gather_rccl": (float(np.mean(gather_ms[-args.steps:])) if gather_ms else 0.0)},
             "roofline": roofline, "cpu_baseline": cpu,
         }
         print(json.dumps(result))

@@ -683,10 +683,19 @@ __global__ void __launch_bounds__(512) k_attn_decode(AttnParams p) {
     float* sl = sm + ATT_WAVES * 16;                                   // [W][16]
     float* sO = sl + ATT_WAVES * 16;                                   // [W][G][D]
 
-    // ---- memory round trip 1: everything that does not depend on the row's position goes out together - the row's state
-    // (active, pos), the split-K slabs of this (row, kv head) and the q/k-norm weights.  All loads are unconditional (clamped
-    // addresses, masked at use): a guarded load compiles to a branch with its own s_waitcnt vmcnt(0), i.e. one more dependent
-    // round trip per guard.
+    // ---- scalar round trip: the row's state.  Both addresses are wave-uniform, so these are s_load (scalar cache, lgkmcnt) - they
+    // neither queue behind nor hold up the vector loads below.  `active` is read as the aligned 32-bit word holding byte b (there is
+    // no sub-dword scalar load on gfx950).  With pos known up front, the RoPE table rows join round trip 1 and nothing after it
+    // depends on memory any more - which is what lets the K/V stream overlap the whole prologue (see below).
+    const uint32_t active_word = reinterpret_cast<const uint32_t*>(p.active)[b >> 2];
+    const unsigned char row_active = (unsigned char)((active_word >> (8 * (b & 3))) & 0xffu);
+    const int pos = p.cross ? 0 : p.pos[b];
+    if (!row_active) return;
+    const int kv_len = p.cross ? p.cross_len : pos + 1;
+
+    // ---- memory round trip 1 (vector): the split-K slabs of this (row, kv head), the q/k-norm weights and the RoPE table rows of
+    // this position.  All loads are unconditional (clamped addresses, masked at use): a guarded load compiles to a branch with its
+    // own s_waitcnt vmcnt(0), i.e. one more dependent round trip per guard.
     const int n_pro = p.cross ? G : G + 2;          // cross attention: queries only (K/V cached once per utterance)
     const int n_el = n_pro * D;
     float pv[NIT][8];                                // NIT * 512 >= (G + 2) * D
@@ -710,21 +719,37 @@ __global__ void __launch_bounds__(512) k_attn_decode(AttnParams p) {
 #pragma unroll
         for (int j = 0; j < D / 64; ++j) { qw[j] = bf16_to_f32(qp[p.qnorm_w ? lane + 64 * j : 0]); kw[j] = bf16_to_f32(kp[p.qnorm_w ? lane + 64 * j : 0]); }
     }
-    const unsigned char row_active = p.active[b];
-    const int pos = p.cross ? 0 : p.pos[b];
-    // the slab values are pinned here (the compiler would otherwise sink the loads behind the early return, i.e. behind the
-    // wait for `active`): one wait covers the whole round trip
+    const int n_rot_el = (p.cross ? G : G + 1) * (D / 2);
+    float rc[NIT], rs[NIT];
+    {
+        const float* ct = p.rope_cos ? p.rope_cos + (size_t)pos * (D / 2) : p.qkv_part;
+        const float* st = p.rope_cos ? p.rope_sin + (size_t)pos * (D / 2) : p.qkv_part;
 #pragma unroll
-    for (int it = 0; it < NIT; ++it)
+        for (int it = 0; it < NIT; ++it) {
+            const int idx = tid + it * 512;
+            const int i = idx % (D / 2);
+            rc[it] = ct[p.rope_cos ? i : 0];          // unconditional; entries past n_rot_el are never used
+            rs[it] = st[p.rope_cos ? i : 0];
+        }
+    }
+    // one wait covers the whole round trip: everything is pinned here, BEFORE the K/V stream is requested, so that no later use of
+    // these values has to wait behind 32 KiB of K/V per wave (vmcnt retires in issue order, and the wave-uniform guards around the
+    // tile loads make the compiler's waitcnt at the join conservative - before this ordering the RoPE step waited for the wave's
+    // whole first tile pair, i.e. at contexts <= 512 for the entire KV stream of the launch)
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
 #pragma unroll
         for (int j = 0; j < 8; ++j) asm volatile("" : "+v"(pv[it][j]));
-    if (!row_active) return;
+        asm volatile("" : "+v"(rc[it]));
+        asm volatile("" : "+v"(rs[it]));
+    }
+#pragma unroll
+    for (int j = 0; j < D / 64; ++j) { asm volatile("" : "+v"(qw[j])); asm volatile("" : "+v"(kw[j])); }
     ATT_STAMP(1);
-    const int kv_len = p.cross ? p.cross_len : pos + 1;
 
-    // ---- memory round trip 2: RoPE table rows of this position, then the wave's first pair of K/V tiles (32 KiB per wave) -
-    // INCLUDING the tile the new key belongs to: its slot is patched in registers from LDS below, so no load ever waits for
-    // this step's own cache append.  The stream overlaps the slab reduce / norm / RoPE.
+    // ---- the K/V stream: the wave's first pair of tiles (32 KiB per wave) is requested now and lands while the prologue below
+    // (slab reduce, q/k norm, RoPE, cache append, LDS staging, two barriers) runs - INCLUDING the tile the new key belongs to: its
+    // slot is patched in registers from LDS below, so no load ever waits for this step's own cache append.
     bf16_t* kc = p.kcache + ((size_t)(b * p.Hkv + kvh) * p.Smax) * D;
     bf16_t* vt = p.vtcache + ((size_t)(b * p.Hkv + kvh) * D) * p.Smax;
     const bf16x8_t* kbase = reinterpret_cast<const bf16x8_t*>(kc) + lane;
@@ -741,24 +766,9 @@ __global__ void __launch_bounds__(512) k_attn_decode(AttnParams p) {
 #pragma unroll
         for (int dt = 0; dt < D / 16; ++dt) vb[dt] = vbase[((size_t)tile * (D / 16) + dt) * 64];
     };
-    const int n_rot_el = (p.cross ? G : G + 1) * (D / 2);
-    float rc[NIT], rs[NIT];
-    {
-        const float* ct = p.rope_cos ? p.rope_cos + (size_t)pos * (D / 2) : p.qkv_part;
-        const float* st = p.rope_cos ? p.rope_sin + (size_t)pos * (D / 2) : p.qkv_part;
-#pragma unroll
-        for (int it = 0; it < NIT; ++it) {
-            const int idx = tid + it * 512;
-            const int i = idx % (D / 2);
-            rc[it] = ct[p.rope_cos ? i : 0];          // unconditional; entries past n_rot_el are never used
-            rs[it] = st[p.rope_cos ? i : 0];
-        }
-    }
-    __builtin_amdgcn_sched_barrier(0);          // the table rows go out FIRST (vmcnt retires in issue order)
+    __builtin_amdgcn_sched_barrier(0);
     // wave-uniform guards: a wave without a tile requests nothing (at short contexts seven of eight waves would otherwise each
-    // pull a redundant 32 KB pair through the CU's 64 B/clk return path - 2-3 us per launch on the small models).  The price is a
-    // conservative vmcnt at the join: the prologue below then waits for the wave's own first pair as well, which measured the
-    // same as the unconditional form at long contexts (the kernel is paced by the KV stream either way).
+    // pull a redundant 32 KB pair through the CU's 64 B/clk return path - 2-3 us per launch on the small models)
     if (wave < n_tiles) load_tile(wave, kA, vA);
     if (wave + ATT_WAVES < n_tiles) load_tile(wave + ATT_WAVES, kB, vB);
     __builtin_amdgcn_sched_barrier(0);
@@ -984,6 +994,7 @@ void launch_attn_decode(const AttnParams& p, int batch, hipStream_t s) {
     size_t smem = attn_smem_bytes(G, p.D);
     MIS_REQUIRE(smem <= 64 * 1024, MIS_ERR_INVALID_INPUT, "attention LDS footprint too large");
     MIS_REQUIRE(p.S >= 1 && p.S <= 8, MIS_ERR_GENERATION_FAILED, "attention prologue reduces at most 8 split-K slabs (got %d)", p.S);
+    MIS_REQUIRE(((uintptr_t)p.active & 3) == 0, MIS_ERR_GENERATION_FAILED, "attention: the active-flag array must be 4-byte aligned");
     dim3 grid(p.Hkv, batch), block(512);
     const int n_el = (G + 2) * p.D;
 #ifdef MIS_ATTN_TIMING

@@ -233,3 +233,65 @@ def test_vyvotts_decodes_snac_in_independent_chunks():
     a = lm.generate_batch(prompts, gp)
     b = lm.generate_batch(prompts, gp)
     assert all(np.array_equal(x, y) for x, y in zip(a, b)) and len(a[0]) == groups * 2048
+
+
+def test_device_group_two_logical_shards_equal_the_unsharded_call_bitwise(stack):
+    """Multi-GPU behind the C ABI on ONE GPU: a group of two replicas (two LM + codec handles on device 0, each
+    with its own stream and worker thread inside mis_tts_group_generate*) must reproduce the single-handle call bit for bit -
+    tokens and waveform - because the RNG is keyed by the global row.  Host gather and device all-gather forms."""
+    import torch
+    from gpu_util import snac_pair
+    from mlx_audio_swift_amd.sharding import TTSGroup
+    ocfg_s, osn, dsn, olm, dlm = stack
+    rng = np.random.default_rng(31)
+    prompts = _prompts(rng, [6, 9, 7, 8, 6])
+    gp = mas.GenerateParameters(max_tokens=21, temperature=0.6, top_p=0.8, repetition_penalty=1.3, seed=17, frame_constrained=True)
+    ref_pcm, ref_tok = dlm.generate_batch(prompts, gp, return_tokens=True)
+    # two fresh replicas with the same weights (what a host does per device: load the checkpoint once per GPU)
+    from gpu_util import lm_pair
+    reps = []
+    for _ in range(2):
+        _, _, codec = snac_pair(SNAC_SMALL)
+        _, _, lm = lm_pair(LM_SMALL, codec=codec)
+        reps.append(lm)
+    grp = TTSGroup(reps)
+    assert len(grp) == 2
+    pcm, tok = grp.generate_batch(prompts, gp, return_tokens=True)
+    for b in range(5):
+        assert np.array_equal(tok[b], ref_tok[b]) and np.array_equal(pcm[b], ref_pcm[b]), b
+    t = grp.last_timing()
+    assert t["n_shards"] == 2 and t["generate_ms"] > 0 and t["slowest_shard_ms"] <= t["generate_ms"] + 1.0
+    # device form: both replicas' buffers hold ALL rows afterwards (all-gather by peer copies)
+    n = dsn.num_samples(3)
+    bufs = [torch.zeros((5, n), dtype=torch.float32, device="cuda:0") for _ in range(2)]
+    lens, ntok = grp.generate_device(prompts, gp, [b.data_ptr() for b in bufs], n)
+    torch.cuda.synchronize()
+    assert lens == [n] * 5 and ntok == [21] * 5
+    for buf in bufs:
+        got = buf.cpu().numpy()
+        for b in range(5):
+            assert np.array_equal(got[b], ref_pcm[b]), b
+    # a failing shard surfaces as an error naming the shard, and the group stays usable
+    bad = [p.copy() for p in prompts]
+    bad[4][0] = 10 ** 6
+    with pytest.raises(mas.AudioGenerationError) as e:
+        grp.generate_batch(bad, gp)
+    assert e.value.case == "invalidInput" and "shard 1" in str(e.value)
+    pcm2 = grp.generate_batch(prompts, gp)
+    assert all(np.array_equal(a, b) for a, b in zip(pcm2, ref_pcm))
+    with pytest.raises(mas.AudioGenerationError):
+        TTSGroup([reps[0], reps[0]])                       # one in-flight call per handle
+
+
+def test_rccl_communicator_world1_all_gather_is_the_identity():
+    """mis_comm_* (one process per GPU): with a single rank the RCCL all-gather must return the local block - exercises librccl
+    loading, ncclCommInitRank from a unique id and ncclAllGather on the library stream (N > 1 needs more GPUs than a test box has)."""
+    import torch
+    from mlx_audio_swift_amd.sharding import Communicator
+    comm = Communicator(0, 0, 1)
+    x = torch.arange(3 * 1000, dtype=torch.float32, device="cuda:0").reshape(3, 1000)
+    out = torch.zeros_like(x)
+    lens, ms = comm.all_gather_pcm(x.data_ptr(), [1000, 7, 0], 3, 1000, out.data_ptr())
+    torch.cuda.synchronize()
+    assert torch.equal(out, x) and lens.tolist() == [1000, 7, 0] and ms >= 0.0
+    comm.close()

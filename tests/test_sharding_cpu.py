@@ -57,3 +57,22 @@ def test_all_gather_pcm_world2_gloo():
         assert allp.shape == (n_rows, 64)
         assert np.array_equal(allp, ref)
         assert alll.tolist() == [10 + 3 * r for r in range(n_rows)]
+
+
+def test_c_abi_shard_rows_equals_host_mirror_and_comm_fails_loudly_without_gpu():
+    import ctypes as C
+    import pytest
+    import mlx_audio_swift_amd as mas
+    from mlx_audio_swift_amd import _lib
+    L = _lib.lib()
+    for n in (0, 1, 7, 32, 33, 256):
+        for w in (1, 2, 3, 8):
+            for r in range(w):
+                lo, hi = C.c_int(-1), C.c_int(-1)
+                L.mis_shard_rows(n, r, w, C.byref(lo), C.byref(hi))
+                assert (lo.value, hi.value) == shard_rows(n, r, w)
+    if L.mis_device_count() == 0:                      # no GPU here: the communicator must refuse, not fall back
+        from mlx_audio_swift_amd.sharding import Communicator
+        with pytest.raises(mas.AudioGenerationError) as e:
+            Communicator(0, 0, 1)
+        assert e.value.case == "device"
