@@ -202,10 +202,19 @@ mis_status mis_tts_set_tensor(mis_tts*, const char* name, const void* data, mis_
  * (oracle/synth.py has the same formula); benches only - there are no checkpoints offline. */
 /* Linear / Embedding in MLX's affine-quantised form (mlx quantize [3P]): wq uint32 [N, K*bits/32] (element i of a row =
  * (word[i / (32/bits)] >> (bits * (i % (32/bits)))) & mask), scales / biases [N, K/group_size] of dtype sb_dtype;
- * w = scale * q + bias.  Dequantised once at load into the engine's bf16 layout (the reference keeps QuantizedLinear,
- * LlamaTTS.swift:958-968, and dequantises inside every matmul in f32: a stated bf16-rounding deviation). */
+ * w = scale * q + bias.  The reference keeps QuantizedLinear (LlamaTTS.swift:958-968, Qwen3TTS.swift:1157-1170) and never
+ * materialises the weight: quantizedMatmul applies scale and bias to float32 group sums.  So does the engine for a role
+ * (q|k|v, o_proj, gate|up, down_proj, lm_head) whose matrices ALL arrive with 8 or 4 bits, group size 64 and bf16 scales: the
+ * codes are streamed as stored (0.53x / 0.28x of the bf16 bytes) and dequantised in registers (csrc/lm_qgemm.hip).  Any other
+ * combination (2 bit, other groups, f16 / f32 scales, per-layer overrides inside a role, MIS_QUANT_NATIVE=0) is dequantised once at
+ * load into the bf16 layout, which rounds s*q+b to bf16 per weight - a stated deviation for those cases only.  The embedding
+ * (QuantizedEmbedding: a gather of dequantised rows in the model dtype) is always dequantised at load. */
 mis_status mis_tts_set_tensor_quantized(mis_tts*, const char* name, const uint32_t* wq, const void* scales, const void* biases,
                                         mis_dtype sb_dtype, int64_t N, int64_t K, int group_size, int bits);
+/* after finalize: bits of the quantised form a role is streamed in (0 = dense bf16); role 0 q|k|v, 1 o_proj, 2 gate|up, 3 down, 4 lm_head */
+int        mis_tts_native_quant_bits(const mis_tts*, int role);
+/* benches: every Linear as a synthetic MLX-quantised matrix (bits 8 or 4, group 64, bf16 scales) - no checkpoints offline */
+mis_status mis_tts_init_synthetic_quantized(mis_tts*, uint64_t seed, int bits);
 mis_status mis_tts_init_synthetic(mis_tts*, uint64_t seed);
 mis_status mis_tts_finalize(mis_tts*);     /* verify all keys present; pack weights for MFMA streaming */
 void       mis_tts_destroy(mis_tts*);
@@ -385,6 +394,11 @@ mis_status mis_qwen3tts_create(const mis_qwen3tts_config*, int device, mis_qwen3
  * with the module-tree names Qwen3TTSSpeechTokenizer.sanitize produces */
 mis_status mis_qwen3tts_set_tensor(mis_qwen3tts*, const char* name, const void* data, mis_dtype dtype,
                                    const int64_t* shape, int ndim);
+/* the same keys in MLX's affine-quantised form (the published Qwen3-TTS checkpoints are 8 bit, Qwen3TTS.swift:1157-1170): the
+ * Linear layers of the talker and the code predictor are streamed as codes (see mis_tts_set_tensor_quantized); embeddings,
+ * text projection, predictor tables / heads are dequantised at load (gathered or folded tensors) */
+mis_status mis_qwen3tts_set_tensor_quantized(mis_qwen3tts*, const char* name, const uint32_t* wq, const void* scales,
+                                             const void* biases, mis_dtype sb_dtype, int64_t N, int64_t K, int group_size, int bits);
 mis_status mis_qwen3tts_finalize(mis_qwen3tts*);
 void       mis_qwen3tts_destroy(mis_qwen3tts*);
 mis_tts*   mis_qwen3tts_talker(mis_qwen3tts*);            /* borrowed handle (parity taps) */
@@ -401,6 +415,25 @@ mis_status mis_qwen3tts_generate_codes(mis_qwen3tts*, const int32_t* text_ids, c
 mis_status mis_qwen3tts_decode(mis_qwen3tts*, const int32_t* codes, int batch, int T, float* wav_out);
 mis_status mis_qwen3tts_decoder_tap(mis_qwen3tts*, const int32_t* codes, int batch, int T, int stage, float* out,
                                     int64_t capacity, int32_t* channels, int64_t* length);
+/* streamingStep / resetStreamingState (Qwen3TTSSpeechTokenizer.swift:948-1006) as a session on the handle: carried conv
+ * inputs (CausalConv1d.step :199-227, k7 conv steps :655-667,:710-722), transposed-conv overlap (:553-576) and the decoder
+ * transformer's K/V cache live on the device between steps; a step computes only the new frames.
+ * begin: batch rows, at most max_frames frames in the session, at most max_chunk_frames per step.
+ * step:  codes int32 [batch, num_quantizers, n_frames] (host or device) = the NEXT n_frames frames of every row ->
+ *        wav_out f32 [batch, n_frames * samples_per_frame] (host or device).
+ * set_stream_exact(1): chunked decode bitwise equal to mis_qwen3tts_decode of the whole sequence.  Default 0 = the
+ * reference's arithmetic: its overlap-add sums two biased transposed-conv outputs, so the first `stride` samples of each
+ * decoder block after a chunk boundary carry that block's bias twice. */
+mis_status mis_qwen3tts_set_stream_exact(mis_qwen3tts*, int exact);
+mis_status mis_qwen3tts_decode_stream_begin(mis_qwen3tts*, int batch, int max_frames, int max_chunk_frames);
+mis_status mis_qwen3tts_decode_stream_step(mis_qwen3tts*, const int32_t* codes, int n_frames, float* wav_out);
+mis_status mis_qwen3tts_decode_stream_end(mis_qwen3tts*);
+/* generateVoiceDesign for a batch of prepared prompts (Qwen3TTS.swift:306-569).  *pcm_out (mis_free) f32 [batch, *pcm_stride].
+ * on_event == NULL or chunk_frames <= 0: all frames, then one whole-sequence decode (one MIS_EVENT_AUDIO per row if on_event).
+ * on_event != NULL and chunk_frames > 0 = generateStream (chunk_frames = streamingInterval * 12.5, :394-395): every
+ * chunk_frames frames a streaming step of the whole batch runs on a second stream WHILE the frame loop continues; each
+ * row's new samples arrive as MIS_EVENT_AUDIO as soon as they are on the host (:492-505), the frames after the last full
+ * chunk when the loop ends (:537-546).  A row's pcm is the concatenation of its chunks (see set_stream_exact). */
 mis_status mis_qwen3tts_generate(mis_qwen3tts*, const int32_t* text_ids, const int32_t* codec_ids, const int32_t* prefill_lens,
                                  int P, const int32_t* trailing_ids, const int32_t* trailing_lens, int Tt, int batch,
                                  const mis_qwen3tts_params* params, const int32_t* row_max_frames, float** pcm_out,

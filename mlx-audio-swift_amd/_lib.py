@@ -143,6 +143,8 @@ SYMBOLS = {
     "mis_tts_load": (C.c_int, [C.c_char_p, _P, C.c_int, C.POINTER(_P)]),
     "mis_tts_create": (C.c_int, [C.POINTER(LmConfigC), _P, C.c_int, C.POINTER(_P)]),
     "mis_tts_set_tensor": (C.c_int, [_P, C.c_char_p, _P, C.c_int, C.POINTER(C.c_int64), C.c_int]),
+    "mis_tts_native_quant_bits": (C.c_int, [_P, C.c_int]),
+    "mis_tts_init_synthetic_quantized": (C.c_int, [_P, C.c_uint64, C.c_int]),
     "mis_tts_set_tensor_quantized": (C.c_int, [_P, C.c_char_p, _P, _P, _P, C.c_int, C.c_int64, C.c_int64, C.c_int, C.c_int]),
     "mis_tts_init_synthetic": (C.c_int, [_P, C.c_uint64]),
     "mis_tts_finalize": (C.c_int, [_P]),
@@ -199,6 +201,7 @@ SYMBOLS = {
     "mis_soprano_generate_stream": (C.c_int, [_P, _P, _P, C.c_int, C.POINTER(GenParamsC), EVENT_CB, _P, _P]),
     "mis_qwen3tts_create": (C.c_int, [C.POINTER(Qwen3TTSConfigC), C.c_int, C.POINTER(_P)]),
     "mis_qwen3tts_set_tensor": (C.c_int, [_P, C.c_char_p, _P, C.c_int, C.POINTER(C.c_int64), C.c_int]),
+    "mis_qwen3tts_set_tensor_quantized": (C.c_int, [_P, C.c_char_p, _P, _P, _P, C.c_int, C.c_int64, C.c_int64, C.c_int, C.c_int]),
     "mis_qwen3tts_finalize": (C.c_int, [_P]),
     "mis_qwen3tts_destroy": (None, [_P]),
     "mis_qwen3tts_talker": (_P, [_P]),
@@ -206,6 +209,10 @@ SYMBOLS = {
     "mis_qwen3tts_generate_codes": (C.c_int, [_P, _P, _P, _P, C.c_int, _P, _P, C.c_int, C.c_int, C.POINTER(Qwen3TTSParamsC), _P,
                                               C.POINTER(_P), C.POINTER(C.c_int64), _P]),
     "mis_qwen3tts_decode": (C.c_int, [_P, _P, C.c_int, C.c_int, _P]),
+    "mis_qwen3tts_set_stream_exact": (C.c_int, [_P, C.c_int]),
+    "mis_qwen3tts_decode_stream_begin": (C.c_int, [_P, C.c_int, C.c_int, C.c_int]),
+    "mis_qwen3tts_decode_stream_step": (C.c_int, [_P, _P, C.c_int, _P]),
+    "mis_qwen3tts_decode_stream_end": (C.c_int, [_P]),
     "mis_qwen3tts_decoder_tap": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, _P, C.c_int64, C.POINTER(C.c_int32),
                                            C.POINTER(C.c_int64)]),
     "mis_qwen3tts_generate": (C.c_int, [_P, _P, _P, _P, C.c_int, _P, _P, C.c_int, C.c_int, C.POINTER(Qwen3TTSParamsC), _P,

@@ -22,6 +22,10 @@ struct GemmParams {
     int M, K, N;          // N = output columns per phase
     int Tin, Tout;
     int s, pad, Cin;      // CONVT only (Cin also TAPS)
+    int ldx, ldy;         // row strides of X and of Y / R in floats; 0 = dense (Tin, Tout)
+    int x_lo;             // lowest valid X column (<= 0): columns [x_lo, 0) hold carried history (streaming decode), zero below
+    int dup_bias_n0;      // CONVT: add the bias a second time to output frame n = 0 - the reference's streaming overlap-add sums
+                          // two biased outputs there (DecoderBlockUpsample.step, Qwen3TTSSpeechTokenizer.swift:553-576)
     int taps, dil;        // TAPS: dense conv, K = taps*Cin, tap j reads x[:, n - pad + j*dil] (zero outside); A^T row j*Cin + c;
                           // pad = (taps-1)*dil: causal, (taps-1)*dil/2: "same"; optional R (+scale) residual epilogue
 };

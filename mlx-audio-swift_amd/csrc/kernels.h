@@ -56,3 +56,12 @@ void mis_q3dec_destroy(mis_q3dec*);
 int q3dec_total_upsample(const mis_q3dec*);
 void q3dec_decode_device(mis_q3dec*, const int32_t* codes_dev /*[B][nq][T]*/, int batch, int T, float* wav_dev, int64_t wav_stride, hipStream_t s);
 void q3dec_decode_host(mis_q3dec*, const int32_t* codes, int batch, int T, float* out, int stop_after, int* outC, int64_t* outT, hipStream_t s);
+void q3dec_decode_strided(mis_q3dec*, const int32_t* codes_dev, int64_t cs_b, int64_t cs_q, int64_t cs_t, int batch, int T, float* wav_dev,
+                          int64_t wav_stride, hipStream_t s);
+// streaming session (resetStreamingState / streamingStep): code (b, q, t) of a step at codes_dev[b*cs_b + q*cs_q + t*cs_t]
+void q3dec_stream_begin(mis_q3dec*, int batch, int cap_frames, int chunk_cap, bool dup_bias, hipStream_t s);
+void q3dec_stream_step(mis_q3dec*, const int32_t* codes_dev, int64_t cs_b, int64_t cs_q, int64_t cs_t, int Tn, float* wav_dev,
+                       int64_t wav_stride, hipStream_t s);
+void q3dec_stream_step_host(mis_q3dec*, const int32_t* codes /*[B][nq][Tn]*/, int Tn, float* out, hipStream_t s);
+void q3dec_stream_end(mis_q3dec*);
+int q3dec_stream_pos(const mis_q3dec*);

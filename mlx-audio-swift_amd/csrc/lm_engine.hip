@@ -40,6 +40,15 @@ struct mis_tts {
     DevBuf<bf16_t> qknorm;     // [L][2][D] (qk_norm models)
     DevBuf<bf16_t> staging;    // row-major bf16 staging for one tensor
     DevBuf<uint8_t> raw_staging;
+    // MLX affine-quantised checkpoints (8 / 4 bit, group 64, bf16 scales): a role whose every matrix arrived quantised the same way
+    // is streamed in that form by k_gemm_skinny_q (lm_qgemm.hip) and its bf16 copy is dropped at finalize
+    struct QRole {
+        DevBuf<uint8_t> q;     // [L] packed codes, layer stride q_layer bytes
+        DevBuf<bf16_t> sb;     // [L] packed scale / bias pairs, layer stride sb_layer elements
+        size_t q_layer = 0, sb_layer = 0;
+        int bits = 0, placed = 0;
+        bool bad = false, on = false;
+    } q_qkv, q_o, q_gu, q_down, q_head;
 
     // per-batch state
     int batch = 0, Mpad = 0, Smax = 0;
@@ -174,6 +183,41 @@ static void place_matrix(mis_tts* c, const std::string& name, int64_t N, int64_t
     }
 }
 
+// the same matrix in its quantised form (device pointers: MLX layout) -> the role's packed code / scale buffers
+static void place_qmatrix(mis_tts* c, const std::string& name, int64_t N, int64_t K, int bits, const uint32_t* wq, const bf16_t* sc,
+                          const bf16_t* bi) {
+    hipStream_t s = c->stream;
+    const int HD = c->H * c->D, KD = c->Hkv * c->D;
+    auto put = [&](mis_tts::QRole& R, int li, int n_layers, int64_t Ntot, int tile_stride, int tile_offset) {
+        if (R.bits && R.bits != bits) { R.bad = true; return; }
+        const size_t NTtot = round_up(Ntot, 16) / 16, KT = K / 32, G = K / 64;
+        const size_t q_layer = NTtot * KT * 64 * bits, sb_layer = NTtot * G * 32;
+        if (!R.bits) {
+            R.bits = bits; R.q_layer = q_layer; R.sb_layer = sb_layer;
+            R.q.alloc(q_layer * n_layers); R.sb.alloc(sb_layer * n_layers);
+            HIP_CHECK(hipMemsetAsync(R.q.p, 0, q_layer * n_layers, s));          // rows past N (vocabulary padding) decode to 0
+            HIP_CHECK(hipMemsetAsync(R.sb.p, 0, sb_layer * n_layers * 2, s));
+        }
+        if (R.q_layer != q_layer) { R.bad = true; return; }
+        launch_pack_qweight(bits, wq, sc, bi, R.q.p + q_layer * li, R.sb.p + sb_layer * li, (int)N, (int)K, tile_stride, tile_offset, s);
+        R.placed += 1;
+    };
+    if (name == "lm_head.weight") { put(c->q_head, 0, 1, c->V, 1, 0); return; }
+    if (name.rfind("model.layers.", 0) != 0) return;
+    size_t p1 = strlen("model.layers."), p2 = name.find('.', p1);
+    if (p2 == std::string::npos) return;
+    const int li = atoi(name.substr(p1, p2 - p1).c_str());
+    if (li < 0 || li >= c->L) return;
+    const std::string rest = name.substr(p2 + 1);
+    if (rest == "self_attn.q_proj.weight") put(c->q_qkv, li, c->L, c->Nqkv, 1, 0);
+    else if (rest == "self_attn.k_proj.weight") put(c->q_qkv, li, c->L, c->Nqkv, 1, HD / 16);
+    else if (rest == "self_attn.v_proj.weight") put(c->q_qkv, li, c->L, c->Nqkv, 1, (HD + KD) / 16);
+    else if (rest == "self_attn.o_proj.weight") put(c->q_o, li, c->L, c->d, 1, 0);
+    else if (rest == "mlp.gate_proj.weight") put(c->q_gu, li, c->L, 2 * c->ff, 2, 0);
+    else if (rest == "mlp.up_proj.weight") put(c->q_gu, li, c->L, 2 * c->ff, 2, 1);
+    else if (rest == "mlp.down_proj.weight") put(c->q_down, li, c->L, c->d, 1, 0);
+}
+
 static bf16_t* norm_slot(mis_tts* c, const std::string& name) {
     if (name == "model.norm.weight") return c->norms.p + (size_t)2 * c->L * c->d;
     size_t p1 = strlen("model.layers.");
@@ -225,18 +269,13 @@ extern "C" mis_status mis_tts_set_tensor(mis_tts* c, const char* name_, const vo
 // A Linear / Embedding stored in MLX's affine-quantised form (`weight` uint32 [N, K*bits/32], `scales` / `biases` [N, K/group],
 // written by mlx quantize; the reference re-creates QuantizedLinear modules for every path that has `.scales`,
 // LlamaTTS.swift:958-968).  The matrix is dequantised once at load into the engine's bf16 layouts.
-extern "C" mis_status mis_tts_set_tensor_quantized(mis_tts* c, const char* name_, const uint32_t* wq, const void* scales,
-                                                   const void* biases, mis_dtype sb_dtype, int64_t N, int64_t K, int group_size,
-                                                   int bits) {
-    MIS_API_BEGIN
-    MIS_REQUIRE(c && name_ && wq && scales && biases, MIS_ERR_INVALID_INPUT, "null argument");
-    MIS_REQUIRE(!c->finalized, MIS_ERR_INVALID_INPUT, "set_tensor after finalize");
+static void set_quantized_any(mis_tts* c, const std::string& name, const uint32_t* wq, const void* scales, const void* biases,
+                              mis_dtype sb_dtype, int64_t N, int64_t K, int group_size, int bits) {
     MIS_REQUIRE(bits == 2 || bits == 4 || bits == 8, MIS_ERR_INVALID_INPUT, "unsupported quantisation width %d (2, 4 or 8 bits)", bits);
     MIS_REQUIRE(group_size >= 1 && N >= 1 && K >= 1 && K % group_size == 0 && K % (32 / bits) == 0, MIS_ERR_INVALID_INPUT,
-                "bad quantised shape for %s", name_);
+                "bad quantised shape for %s", name.c_str());
     MIS_REQUIRE(sb_dtype == MIS_F32 || sb_dtype == MIS_F16 || sb_dtype == MIS_BF16, MIS_ERR_INVALID_INPUT, "unsupported scale dtype");
-    std::string name = name_;
-    if (name == "lm_head.weight" && c->cfg.tie_word_embeddings) return MIS_OK;
+    if (name == "lm_head.weight" && c->cfg.tie_word_embeddings) return;
     HIP_CHECK(hipSetDevice(c->device));
     const size_t words = (size_t)N * K * bits / 32, ng = (size_t)N * (K / group_size), esz = sb_dtype == MIS_F32 ? 4 : 2;
     const size_t wb = round_up(words * 4, 16), sb = round_up(ng * esz, 16);
@@ -250,9 +289,87 @@ extern "C" mis_status mis_tts_set_tensor_quantized(mis_tts* c, const char* name_
     c->staging.alloc((size_t)N * K);
     launch_dequant_affine((const uint32_t*)p, ps, pb, (int)sb_dtype, c->staging.p, (int)N, (int)K, group_size, bits, c->stream);
     place_matrix(c, name, N, K);
+    // native form (see QRole): bf16 scales are exact in the kernel's float32 arithmetic; anything else keeps the bf16 copy only
+    static const bool native = !(getenv("MIS_QUANT_NATIVE") && atoi(getenv("MIS_QUANT_NATIVE")) == 0);
+    if (native && (bits == 8 || bits == 4) && group_size == 64 && sb_dtype == MIS_BF16 && K % 64 == 0 && (N % 16 == 0 || name == "lm_head.weight"))
+        place_qmatrix(c, name, N, K, bits, (const uint32_t*)p, (const bf16_t*)ps, (const bf16_t*)pb);
     HIP_CHECK(hipGetLastError());
     HIP_CHECK(hipStreamSynchronize(c->stream));
     c->loaded.insert(name);
+}
+
+extern "C" mis_status mis_tts_set_tensor_quantized(mis_tts* c, const char* name_, const uint32_t* wq, const void* scales,
+                                                   const void* biases, mis_dtype sb_dtype, int64_t N, int64_t K, int group_size,
+                                                   int bits) {
+    MIS_API_BEGIN
+    MIS_REQUIRE(c && name_ && wq && scales && biases, MIS_ERR_INVALID_INPUT, "null argument");
+    MIS_REQUIRE(!c->finalized, MIS_ERR_INVALID_INPUT, "set_tensor after finalize");
+    set_quantized_any(c, name_, wq, scales, biases, sb_dtype, N, K, group_size, bits);
+    MIS_API_END
+}
+
+// bits of the quantised form a role is streamed in after finalize (0 = dense bf16): role 0 qkv, 1 o_proj, 2 gate/up, 3 down, 4 lm_head
+extern "C" int mis_tts_native_quant_bits(const mis_tts* c, int role) {
+    if (!c) return 0;
+    const mis_tts::QRole* R[5] = {&c->q_qkv, &c->q_o, &c->q_gu, &c->q_down, &c->q_head};
+    return (role >= 0 && role < 5 && R[role]->on) ? R[role]->bits : 0;
+}
+
+// benches: every Linear as a synthetic MLX-quantised matrix (random codes, group scale ~ 2 amp / (2^bits - 1), bias ~ -amp), group 64,
+// bf16 scales - there are no checkpoints offline.  The embedding stays dense.
+__global__ void k_synth_quant(uint32_t* __restrict__ wq, bf16_t* __restrict__ sc, bf16_t* __restrict__ bi, size_t words, size_t groups,
+                              uint64_t key, float amp, int bits) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < words) wq[i] = (uint32_t)(mis_splitmix64(key * 0x9E3779B97F4A7C15ull + i) >> 16);
+    if (i < groups) {
+        const float jitter = 1.0f + 0.25f * mis_synth_value(key ^ 0x5bd1e995ull, i, 1.0f);
+        sc[i] = f32_to_bf16(2.0f * amp * jitter / (float)((1 << bits) - 1));
+        bi[i] = f32_to_bf16(-amp * jitter);
+    }
+}
+extern "C" mis_status mis_tts_init_synthetic_quantized(mis_tts* c, uint64_t seed, int bits) {
+    MIS_API_BEGIN
+    MIS_REQUIRE(c && !c->finalized && (bits == 4 || bits == 8), MIS_ERR_INVALID_INPUT, "bad argument");
+    HIP_CHECK(hipSetDevice(c->device));
+    hipStream_t s = c->stream;
+    const int d = c->d, ff = c->ff, HD = c->H * c->D, KD = c->Hkv * c->D;
+    const uint64_t base = seed * 100000ull;
+    DevBuf<uint32_t> wq; DevBuf<bf16_t> sc, bi;
+    auto mat = [&](const std::string& name, uint64_t key, int64_t N, int64_t K, double amp) {
+        const size_t words = (size_t)N * K * bits / 32, groups = (size_t)N * (K / 64);
+        wq.alloc(words); sc.alloc(groups); bi.alloc(groups);
+        hipLaunchKernelGGL(k_synth_quant, dim3((unsigned)((words + 255) / 256)), dim3(256), 0, s, wq.p, sc.p, bi.p, words, groups, base + key, (float)amp, bits);
+        HIP_CHECK(hipStreamSynchronize(s));
+        set_quantized_any(c, name, wq.p, sc.p, bi.p, MIS_BF16, N, K, 64, bits);
+    };
+    auto vec = [&](const std::string& name, uint64_t key) {
+        bool is_qk = name.find("self_attn.") != std::string::npos;
+        launch_synth_fill_bf16(norm_slot(c, name), (size_t)(is_qk ? c->D : d), base + key, 0.1f, 1, s);
+        c->loaded.insert(name);
+    };
+    c->staging.alloc((size_t)c->V * d);
+    launch_synth_fill_bf16(c->staging.p, (size_t)c->V * d, base + 1, (float)(0.5 * sqrt(3.0)), 0, s);
+    place_matrix(c, "model.embed_tokens.weight", c->V, d);
+    c->loaded.insert("model.embed_tokens.weight");
+    HIP_CHECK(hipStreamSynchronize(s));
+    vec("model.norm.weight", 2);
+    if (!c->cfg.tie_word_embeddings) mat("lm_head.weight", 3, c->V, d, sqrt(3.0 / d) * 2.0);
+    for (int li = 0; li < c->L; ++li) {
+        std::string p = "model.layers." + std::to_string(li);
+        uint64_t k = 100 + (uint64_t)li * 16;
+        vec(p + ".input_layernorm.weight", k + 0);
+        vec(p + ".post_attention_layernorm.weight", k + 1);
+        mat(p + ".self_attn.q_proj.weight", k + 2, HD, d, sqrt(3.0 / d) * 1.5);
+        mat(p + ".self_attn.k_proj.weight", k + 3, KD, d, sqrt(3.0 / d) * 1.5);
+        mat(p + ".self_attn.v_proj.weight", k + 4, KD, d, sqrt(3.0 / d));
+        mat(p + ".self_attn.o_proj.weight", k + 5, d, HD, sqrt(3.0 / HD) * 0.5);
+        mat(p + ".mlp.gate_proj.weight", k + 6, ff, d, sqrt(3.0 / d));
+        mat(p + ".mlp.up_proj.weight", k + 7, ff, d, sqrt(3.0 / d));
+        mat(p + ".mlp.down_proj.weight", k + 8, d, ff, sqrt(3.0 / ff) * 0.5);
+        if (c->cfg.qk_norm) { vec(p + ".self_attn.q_norm.weight", k + 9); vec(p + ".self_attn.k_norm.weight", k + 10); }
+    }
+    HIP_CHECK(hipGetLastError());
+    HIP_CHECK(hipStreamSynchronize(s));
     MIS_API_END
 }
 
@@ -321,6 +438,19 @@ extern "C" mis_status mis_tts_finalize(mis_tts* c) {
         launch_pack_weight(c->emb.p, c->lm_head.p, c->V, c->d, c->Vpad / 16, 1, 0, c->stream);
     HIP_CHECK(hipGetLastError());
     HIP_CHECK(hipStreamSynchronize(c->stream));
+    {   // quantised roles: complete and uniform -> stream the codes, drop the bf16 copy
+        auto decide = [&](mis_tts::QRole& R, int expected, DevBuf<bf16_t>& dense) {
+            R.on = R.bits != 0 && !R.bad && R.placed == expected;
+            if (R.on) dense.release();
+            else { R.q.release(); R.sb.release(); R.bits = 0; }
+        };
+        decide(c->q_qkv, 3 * c->L, c->wqkv);
+        decide(c->q_o, c->L, c->wo);
+        decide(c->q_gu, 2 * c->L, c->wgu);
+        decide(c->q_down, c->L, c->wdown);
+        if (c->cfg.tie_word_embeddings) { c->q_head.on = false; c->q_head.q.release(); c->q_head.sb.release(); }
+        else decide(c->q_head, 1, c->lm_head);
+    }
     c->staging.release();
     c->raw_staging.release();
     c->finalized = true;
@@ -414,6 +544,32 @@ static void lm_reset(mis_tts* c, int batch, int max_context) {
     HIP_CHECK(hipStreamSynchronize(s));
 }
 
+// the step chain's five GEMMs: dense bf16 tiles or, for a quantised role, codes + scales (lm_qgemm.hip)
+static void gemm_qkv(mis_tts* c, size_t li, hipStream_t s) {
+    if (c->q_qkv.on) launch_gemm_skinny_q(c->q_qkv.bits, EPI_PARTIAL, c->r_part, c->ksb_part, c->q_qkv.q.p + c->q_qkv.q_layer * li, c->q_qkv.sb.p + c->q_qkv.sb_layer * li,
+                                          c->x.p, c->qkv_part.p, c->Nqkv / 16, c->d / 64, c->S_qkv, c->Nqkv, c->Mpad, s);
+    else launch_gemm_skinny(EPI_PARTIAL, c->r_part, c->ksb_part, c->wqkv.p + layer_qkv_elems(c) * li, c->x.p, c->qkv_part.p, c->Nqkv / 16, c->d / 32, c->S_qkv,
+                            c->Nqkv, c->Mpad, s);
+}
+static void gemm_o(mis_tts* c, size_t li, hipStream_t s) {
+    const int HD = c->H * c->D;
+    if (c->q_o.on) launch_gemm_skinny_q(c->q_o.bits, EPI_PARTIAL, c->r_part, c->ksb_part, c->q_o.q.p + c->q_o.q_layer * li, c->q_o.sb.p + c->q_o.sb_layer * li,
+                                        c->attn_out.p, c->part.p, c->d / 16, HD / 64, c->S_o, c->d, c->Mpad, s);
+    else launch_gemm_skinny(EPI_PARTIAL, c->r_part, c->ksb_part, c->wo.p + layer_o_elems(c) * li, c->attn_out.p, c->part.p, c->d / 16, HD / 32, c->S_o, c->d,
+                            c->Mpad, s);
+}
+static void gemm_gate_up(mis_tts* c, size_t li, hipStream_t s) {
+    if (c->q_gu.on) launch_gemm_skinny_q(c->q_gu.bits, EPI_SILU_MUL, 2, c->ksb_gu, c->q_gu.q.p + c->q_gu.q_layer * li, c->q_gu.sb.p + c->q_gu.sb_layer * li, c->x.p,
+                                         c->act.p, 2 * c->ff / 16, c->d / 64, 1, c->ff, c->Mpad, s);
+    else launch_gemm_skinny(EPI_SILU_MUL, 2, c->ksb_gu, c->wgu.p + layer_gu_elems(c) * li, c->x.p, c->act.p, 2 * c->ff / 16, c->d / 32, 1, c->ff, c->Mpad, s);
+}
+static void gemm_down(mis_tts* c, size_t li, hipStream_t s) {
+    if (c->q_down.on) launch_gemm_skinny_q(c->q_down.bits, EPI_PARTIAL, c->r_part, c->ksb_part, c->q_down.q.p + c->q_down.q_layer * li,
+                                           c->q_down.sb.p + c->q_down.sb_layer * li, c->act.p, c->part.p, c->d / 16, c->ff / 64, c->S_down, c->d, c->Mpad, s);
+    else launch_gemm_skinny(EPI_PARTIAL, c->r_part, c->ksb_part, c->wdown.p + layer_down_elems(c) * li, c->act.p, c->part.p, c->d / 16, c->ff / 32, c->S_down,
+                            c->d, c->Mpad, s);
+}
+
 // embed -> L x block.  Leaves x = final-norm(h) ready for lm_head.   (LlamaTTS.swift:335-345,303-310)
 // table/rows/ids: embedding source override (composite engines feed input embeddings as a [rows][d] table)
 static void enqueue_layers(mis_tts* c, const bf16_t* table = nullptr, int table_rows = 0, const int32_t* ids = nullptr) {
@@ -423,8 +579,7 @@ static void enqueue_layers(mis_tts* c, const bf16_t* table = nullptr, int table_
     launch_embed_rmsnorm(table ? table : c->emb.p, ids ? ids : c->ids.p, c->active.p, c->pos_cur.p, c->pos_next.p, c->norms.p,
                          c->h.p, c->x.p, d, table ? table_rows : c->V, eps, c->batch, Mpad, s);
     for (int li = 0; li < c->L; ++li) {
-        launch_gemm_skinny(EPI_PARTIAL, c->r_part, c->ksb_part, c->wqkv.p + layer_qkv_elems(c) * li, c->x.p, c->qkv_part.p, c->Nqkv / 16,
-                           d / 32, c->S_qkv, c->Nqkv, Mpad, s);
+        gemm_qkv(c, li, s);
         AttnParams ap{};
         ap.qkv_part = c->qkv_part.p; ap.S = c->S_qkv; ap.Mpad = Mpad; ap.Nqkv = c->Nqkv;
         size_t lkv = (size_t)c->batch * c->Hkv * c->Smax * c->D;
@@ -440,18 +595,20 @@ static void enqueue_layers(mis_tts* c, const bf16_t* table = nullptr, int table_
         }
         ap.rope_in_dtype = c->cfg.rope_ops_in_dtype;
         launch_attn_decode(ap, c->batch, s);
-        launch_gemm_skinny(EPI_PARTIAL, c->r_part, c->ksb_part, c->wo.p + layer_o_elems(c) * li, c->attn_out.p, c->part.p, d / 16, HD / 32,
-                           c->S_o, d, Mpad, s);
+        gemm_o(c, li, s);
         launch_reduce_residual_rmsnorm(c->part.p, c->S_o, Mpad, d, c->h.p, c->norms.p + (size_t)(2 * li + 1) * d, c->x.p, eps, s);
-        launch_gemm_skinny(EPI_SILU_MUL, 2, c->ksb_gu, c->wgu.p + layer_gu_elems(c) * li, c->x.p, c->act.p, 2 * c->ff / 16, d / 32,
-                           1, c->ff, Mpad, s);
-        launch_gemm_skinny(EPI_PARTIAL, c->r_part, c->ksb_part, c->wdown.p + layer_down_elems(c) * li, c->act.p, c->part.p, d / 16,
-                           c->ff / 32, c->S_down, d, Mpad, s);
+        gemm_gate_up(c, li, s);
+        gemm_down(c, li, s);
         const bf16_t* next_norm = c->norms.p + (size_t)(li + 1 < c->L ? 2 * (li + 1) : 2 * c->L) * d;
         launch_reduce_residual_rmsnorm(c->part.p, c->S_down, Mpad, d, c->h.p, next_norm, c->x.p, eps, s);
     }
 }
 static void enqueue_lm_head(mis_tts* c, const bf16_t* head = nullptr) {
+    if (!head && c->q_head.on) {
+        launch_gemm_skinny_q(c->q_head.bits, EPI_BF16, 2, c->ksb_head, c->q_head.q.p, c->q_head.sb.p, c->x.p, c->logits.p, c->Vpad / 16, c->d / 64, 1, c->Vpad,
+                             c->Mpad, c->stream);
+        return;
+    }
     launch_gemm_skinny(EPI_BF16, 2, c->ksb_head, head ? head : c->lm_head.p, c->x.p, c->logits.p, c->Vpad / 16, c->d / 32, 1,
                        c->Vpad, c->Mpad, c->stream);
 }
@@ -1118,10 +1275,10 @@ extern "C" mis_status mis_tts_time_gemm(mis_tts* c, int which, int batch, int it
         static const int fixed = env_int("MIS_TIME_GEMM_FIXED_LAYER", -1);      // experiment: weights stay in the Infinity Cache
         size_t li = fixed >= 0 ? (size_t)fixed : (size_t)(it % c->L);
         switch (which) {
-            case 0: launch_gemm_skinny(EPI_PARTIAL, c->r_part, c->ksb_part, c->wqkv.p + layer_qkv_elems(c) * li, c->x.p, c->qkv_part.p, c->Nqkv / 16, d / 32, c->S_qkv, c->Nqkv, Mpad, s); break;
-            case 1: launch_gemm_skinny(EPI_PARTIAL, c->r_part, c->ksb_part, c->wo.p + layer_o_elems(c) * li, c->attn_out.p, c->part.p, d / 16, HD / 32, c->S_o, d, Mpad, s); break;
-            case 2: launch_gemm_skinny(EPI_SILU_MUL, 2, c->ksb_gu, c->wgu.p + layer_gu_elems(c) * li, c->x.p, c->act.p, 2 * c->ff / 16, d / 32, 1, c->ff, Mpad, s); break;
-            case 3: launch_gemm_skinny(EPI_PARTIAL, c->r_part, c->ksb_part, c->wdown.p + layer_down_elems(c) * li, c->act.p, c->part.p, d / 16, c->ff / 32, c->S_down, d, Mpad, s); break;
+            case 0: gemm_qkv(c, li, s); break;
+            case 1: gemm_o(c, li, s); break;
+            case 2: gemm_gate_up(c, li, s); break;
+            case 3: gemm_down(c, li, s); break;
             case 4: enqueue_lm_head(c); break;
             case 5: {
                 AttnParams ap{};
@@ -1140,14 +1297,16 @@ extern "C" mis_status mis_tts_time_gemm(mis_tts* c, int which, int batch, int it
         }
     };
     double b = 0;
+    // algorithmic bytes of a weight matrix: dense bf16, or codes + one bf16 scale/bias pair per 64 inputs
+    auto wbytes = [&](const mis_tts::QRole& R, double N, double K) { return R.on ? N * K * R.bits / 8.0 + N * (K / 64.0) * 4.0 : 2.0 * N * K; };
     switch (which) {
-        case 0: b = 2.0 * c->Nqkv * d; break;
-        case 1: b = 2.0 * d * HD; break;
-        case 2: b = 2.0 * 2.0 * c->ff * d; break;
-        case 3: b = 2.0 * d * c->ff; break;
+        case 0: b = wbytes(c->q_qkv, c->Nqkv, d); break;
+        case 1: b = wbytes(c->q_o, d, HD); break;
+        case 2: b = wbytes(c->q_gu, 2.0 * c->ff, d); break;
+        case 3: b = wbytes(c->q_down, d, c->ff); break;
         case 5: b = (double)batch * (attn_ctx + 1) * 2.0 * c->Hkv * c->D * 2.0; break;      // K and V rows of every cached key, bf16
         case 6: b = (double)c->S_down * Mpad * d * 4.0 + 2.0 * (double)Mpad * d * 2.0; break;  // slabs + residual stream (cache resident)
-        default: b = 2.0 * (double)c->V * d; break;
+        default: b = wbytes(c->q_head, c->V, d); break;
     }
     run(0);   // warm
     hipEvent_t e0, e1;

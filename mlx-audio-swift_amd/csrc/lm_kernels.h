@@ -32,6 +32,12 @@ void launch_reduce_residual_rmsnorm(const float* slabs, int S, int Mpad, int N, 
 void launch_gemm_skinny(int epi, int R, int ksb, const bf16_t* Wp, const bf16_t* X, void* out, int NT, int KT, int S,
                         int N_out, int Mpad, hipStream_t s, const bf16_t* bias = nullptr);
 
+// the same on MLX affine-quantised weights (lm_qgemm.hip): Qp packed codes, SB packed bf16 scale/bias pairs, G = K/64 scale groups
+void launch_gemm_skinny_q(int bits, int epi, int R, int ksb, const void* Qp, const bf16_t* SB, const bf16_t* X, void* out, int NT, int G,
+                          int S, int N_out, int Mpad, hipStream_t s, const bf16_t* bias = nullptr);
+void launch_pack_qweight(int bits, const uint32_t* wq, const bf16_t* scales, const bf16_t* biases, void* qdst, bf16_t* sbdst, int N, int K,
+                         int tile_stride, int tile_offset, hipStream_t s);
+
 // split-K factor of a weight-streaming GEMM (items = n-tile groups, KT = k-tiles, ksb = waves per item), see the definition
 int gemm_choose_split(int items, int KT, int ksb, int s_max);
 

@@ -1,0 +1,351 @@
+// lm_qgemm.hip - weight-streaming skinny GEMM on MLX affine-quantised weights (8 / 4 bit, group size 64), dequantised in registers.
+//
+// Reference being replaced: QuantizedLinear -> quantizedMatmul(x, w, scales, biases, transpose: true, groupSize, bits)
+// (created for every path with `.scales`, Sources/MLXAudioTTS/Models/Llama/LlamaTTS.swift:958-968,
+// Sources/MLXAudioTTS/Models/Qwen3TTS/Qwen3TTS.swift:1157-1170; arithmetic in mlx [3P]: per group of `group_size` inputs
+// y += scale * sum_k(x_k * q_k) + bias * sum_k(x_k), float32 accumulation, output in x's dtype).
+//
+// Here: the integer codes q in [0, 2^bits) are exact in bf16, so sum_k x_k q_k runs on v_mfma_f32_16x16x32_bf16 with exact
+// products and float32 accumulation, one accumulator per 64-wide scale group (= 2 k-tiles); sum_k x_k comes from one more MFMA
+// against an all-ones A tile; the group's scale and bias (bf16 in the checkpoint, exact in float32) are applied to those two
+// float32 sums.  Nothing is rounded that the reference does not round - the dequantise-at-load path rounds s*q+b to bf16 per
+// weight.  HBM bytes per launch: N*K*bits/8 codes + N*(K/64)*4 scale/bias bytes (8 bit: 0.53x, 4 bit: 0.28x of bf16).
+//
+// Layouts (written by k_pack_qweight at load):
+//   codes   [NT][KT][64 lanes][8 codes]: lane l = q*16 + i holds W[16nt + i][32kt + 8q .. +8) - the bf16 pack of lm_kernels.hip with
+//           codes instead of values: 8 bytes (uint2) per lane at 8 bit, 4 bytes at 4 bit (code e in bits [bits*e, bits*(e+1)))
+//   scales  [NT][G][2][16] bf16: scale then bias of rows 16nt .. 16nt+15 for scale group g (a lane reads its 4 C/D rows as 8 bytes)
+// Work decomposition, epilogues and the in-block split-K combine are those of k_gemm_skinny; K ranges are cut at scale groups.
+#include "common.h"
+#include "lm_kernels.h"
+
+
+typedef unsigned int u32x2_t __attribute__((ext_vector_type(2)));
+template <int BITS> struct QTile;
+template <> struct QTile<8> { typedef u32x2_t type; };
+template <> struct QTile<4> { typedef unsigned int type; };
+
+// 8 codes -> 8 bf16 values (exact).  (float)(byte) is v_cvt_f32_ubyteN; the pair conversion is v_cvt_pk_bf16_f32.
+__device__ __forceinline__ bf16x8_t dq_codes(u32x2_t w) {
+    bf16x8_t r;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        r[e] = (short)f32_to_bf16((float)((w.x >> (8 * e)) & 0xffu));
+        r[4 + e] = (short)f32_to_bf16((float)((w.y >> (8 * e)) & 0xffu));
+    }
+    return r;
+}
+__device__ __forceinline__ bf16x8_t dq_codes(unsigned int w) {
+    bf16x8_t r;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) r[e] = (short)f32_to_bf16((float)((w >> (4 * e)) & 0xfu));
+    return r;
+}
+__device__ __forceinline__ void unpack_bf16x4(uint2 v, float (&o)[4]) {
+    o[0] = __uint_as_float(v.x << 16); o[1] = __uint_as_float(v.x & 0xffff0000u);
+    o[2] = __uint_as_float(v.y << 16); o[3] = __uint_as_float(v.y & 0xffff0000u);
+}
+
+// epilogues: identical arithmetic to gemm_epilogue of lm_kernels.hip (kept in step with it)
+template <int MT, int R, int EPI>
+__device__ __forceinline__ void qgemm_epilogue(const f32x4_t (&acc)[R][MT], void* __restrict__ out, int ntg, int ks, int NT, int N_out,
+                                               int Mpad, int lane, int mt_only, const bf16_t* __restrict__ bias) {
+    const int nl = (lane >> 4) * 4, ml = lane & 15;
+    if (EPI == EPI_PARTIAL) {
+        float* o = reinterpret_cast<float*>(out);
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            int tile = ntg * R + r;
+            if (tile >= NT) continue;
+            float bv[4] = {0.f, 0.f, 0.f, 0.f};
+            if (bias && ks == 0) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) bv[e] = bf16_to_f32(bias[tile * 16 + nl + e]);
+            }
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+                if (mt_only >= 0 && mt != mt_only) continue;
+                size_t off = ((size_t)ks * Mpad + mt * 16 + ml) * N_out + tile * 16 + nl;
+                *reinterpret_cast<float4*>(o + off) =
+                    make_float4(acc[r][mt][0] + bv[0], acc[r][mt][1] + bv[1], acc[r][mt][2] + bv[2], acc[r][mt][3] + bv[3]);
+            }
+        }
+    } else if (EPI == EPI_BF16) {
+        bf16_t* o = reinterpret_cast<bf16_t*>(out);
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            int tile = ntg * R + r;
+            if (tile >= NT) continue;
+            float bv[4] = {0.f, 0.f, 0.f, 0.f};
+            if (bias) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) bv[e] = bf16_to_f32(bias[tile * 16 + nl + e]);
+            }
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+                if (mt_only >= 0 && mt != mt_only) continue;
+                uint16_t res[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) res[e] = f32_to_bf16(acc[r][mt][e] + bv[e]);
+                size_t off = ((size_t)mt * 16 + ml) * N_out + tile * 16 + nl;
+                uint2 v;
+                v.x = (uint32_t)res[0] | ((uint32_t)res[1] << 16);
+                v.y = (uint32_t)res[2] | ((uint32_t)res[3] << 16);
+                *reinterpret_cast<uint2*>(o + off) = v;
+            }
+        }
+    } else {   // EPI_SILU_MUL: tile 2t = gate rows, 2t+1 = up rows  (LlamaTTS.swift:283)
+        bf16_t* o = reinterpret_cast<bf16_t*>(out);
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            if (mt_only >= 0 && mt != mt_only) continue;
+            uint16_t res[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float g = bf16_round_f32(acc[0][mt][e]);
+                float u = bf16_round_f32(acc[R - 1][mt][e]);
+                float sg = bf16_round_f32(1.0f / (1.0f + __expf(-g)));
+                float a = bf16_round_f32(g * sg);
+                res[e] = f32_to_bf16(a * u);
+            }
+            size_t off = xpk_index(mt * 16 + ml, ntg * 16 + nl, MT);
+            uint2 v;
+            v.x = (uint32_t)res[0] | ((uint32_t)res[1] << 16);
+            v.y = (uint32_t)res[2] | ((uint32_t)res[3] << 16);
+            *reinterpret_cast<uint2*>(o + off) = v;
+        }
+    }
+}
+
+// QGEMM_U = scale groups per register buffer: 2 (= 4 k-tiles, 196 VGPRs at MT = 2, two blocks per CU) or 1 (four blocks per CU; the
+// only one that fits without spills at MT >= 3)
+template <int MT, int R, int EPI, int KSB, int BITS, int QGEMM_U>
+__global__ void __launch_bounds__(256, 2) k_gemm_skinny_q(const void* __restrict__ Qp, const bf16_t* __restrict__ SB, const bf16_t* __restrict__ X,
+                                                       void* __restrict__ out, int NT, int G, int S, int n_items, int N_out, int Mpad,
+                                                       const bf16_t* __restrict__ bias) {
+    static_assert(EPI != EPI_SILU_MUL || R == 2, "silu-mul epilogue pairs a gate tile with an up tile");
+    typedef typename QTile<BITS>::type WT;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int item = (KSB == 1) ? blockIdx.x * 4 + wave : blockIdx.x;
+    if (item >= n_items) return;
+    const int ntg = item / S, ks = item - ntg * S;
+    const int KT = 2 * G;
+    int g0 = (int)(((long long)G * ks) / S), g1 = (int)(((long long)G * (ks + 1)) / S);          // this item's scale groups
+    if (KSB > 1) {
+        int len = g1 - g0;
+        int a = g0 + (int)(((long long)len * wave) / KSB), b = g0 + (int)(((long long)len * (wave + 1)) / KSB);
+        g0 = a; g1 = b;
+    }
+    const WT* wp[R];
+    const uint2* sp[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        int tile = ntg * R + r;
+        if (tile >= NT) tile = NT - 1;                     // clamp (store is skipped in the epilogue)
+        wp[r] = reinterpret_cast<const WT*>(Qp) + (size_t)tile * KT * 64 + lane;
+        sp[r] = reinterpret_cast<const uint2*>(SB) + (size_t)tile * G * 8 + (lane >> 4);       // group g: + g*8 (scale), + g*8 + 4 (bias)
+    }
+    const bf16x8_t* xp[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) xp[mt] = reinterpret_cast<const bf16x8_t*>(X) + mt * 64 + lane;
+
+    f32x4_t acc[R][MT];
+#pragma unroll
+    for (int r = 0; r < R; ++r)
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) acc[r][mt] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+    bf16x8_t ones;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) ones[e] = (short)0x3F80;               // bf16 1.0
+
+    WT wA[QGEMM_U][2][R], wB[QGEMM_U][2][R];
+    bf16x8_t xA[QGEMM_U][2][MT], xB[QGEMM_U][2][MT];
+    uint2 sA[QGEMM_U][R][2], sB[QGEMM_U][R][2];
+    const int glast = g1 - 1;
+#define QG_LOAD(WBUF, XBUF, SBUF, GBASE)                                                            \
+    _Pragma("unroll") for (int u = 0; u < QGEMM_U; ++u) {                                           \
+        int gg = (GBASE) + u;                                                                       \
+        gg = gg > glast ? glast : gg;               /* tail: redundant reload, math is skipped */   \
+        _Pragma("unroll") for (int j = 0; j < 2; ++j) {                                             \
+            _Pragma("unroll") for (int r = 0; r < R; ++r)                                           \
+                WBUF[u][j][r] = __builtin_nontemporal_load(wp[r] + (size_t)(2 * gg + j) * 64);      \
+            _Pragma("unroll") for (int mt = 0; mt < MT; ++mt)                                       \
+                XBUF[u][j][mt] = xp[mt][(size_t)(2 * gg + j) * (MT * 64)];                          \
+        }                                                                                           \
+        _Pragma("unroll") for (int r = 0; r < R; ++r) {                                             \
+            SBUF[u][r][0] = sp[r][(size_t)gg * 8];                                                  \
+            SBUF[u][r][1] = sp[r][(size_t)gg * 8 + 4];                                              \
+        }                                                                                           \
+    }
+#define QG_GROUP(WBUF, XBUF, SBUF, U)                                                               \
+    {                                                                                               \
+        f32x4_t ag[R][MT], sx[MT];                                                                  \
+        _Pragma("unroll") for (int mt = 0; mt < MT; ++mt) {                                         \
+            sx[mt] = (f32x4_t){0.f, 0.f, 0.f, 0.f};                                                 \
+            _Pragma("unroll") for (int r = 0; r < R; ++r) ag[r][mt] = (f32x4_t){0.f, 0.f, 0.f, 0.f}; \
+        }                                                                                           \
+        _Pragma("unroll") for (int j = 0; j < 2; ++j) {                                             \
+            bf16x8_t fr[R];                                                                         \
+            _Pragma("unroll") for (int r = 0; r < R; ++r) fr[r] = dq_codes(WBUF[U][j][r]);          \
+            _Pragma("unroll") for (int mt = 0; mt < MT; ++mt) {                                     \
+                sx[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, XBUF[U][j][mt], sx[mt], 0, 0, 0); \
+                _Pragma("unroll") for (int r = 0; r < R; ++r)                                       \
+                    ag[r][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fr[r], XBUF[U][j][mt], ag[r][mt], 0, 0, 0); \
+            }                                                                                       \
+        }                                                                                           \
+        _Pragma("unroll") for (int r = 0; r < R; ++r) {                                             \
+            float sc[4], bi[4];                                                                     \
+            unpack_bf16x4(SBUF[U][r][0], sc);                                                       \
+            unpack_bf16x4(SBUF[U][r][1], bi);                                                       \
+            _Pragma("unroll") for (int mt = 0; mt < MT; ++mt)                                       \
+                _Pragma("unroll") for (int e = 0; e < 4; ++e)                                       \
+                    acc[r][mt][e] += sc[e] * ag[r][mt][e] + bi[e] * sx[mt][e];                      \
+        }                                                                                           \
+    }
+#define QG_MATH_FULL(WBUF, XBUF, SBUF)                                                              \
+    _Pragma("unroll") for (int u = 0; u < QGEMM_U; ++u) QG_GROUP(WBUF, XBUF, SBUF, u)
+#define QG_MATH_TAIL(WBUF, XBUF, SBUF, GBASE)                                                       \
+    _Pragma("unroll") for (int u = 0; u < QGEMM_U; ++u) {                                           \
+        if ((GBASE) + u < g1) QG_GROUP(WBUF, XBUF, SBUF, u)                                         \
+    }
+    if (g0 < g1) {
+        int g = g0;
+        QG_LOAD(wA, xA, sA, g)
+        while (g + 3 * QGEMM_U <= g1) {                    // steady state: unguarded loads and math (see k_gemm_skinny)
+            QG_LOAD(wB, xB, sB, g + QGEMM_U)
+            __builtin_amdgcn_sched_barrier(0);
+            QG_MATH_FULL(wA, xA, sA)
+            __builtin_amdgcn_sched_barrier(0);
+            QG_LOAD(wA, xA, sA, g + 2 * QGEMM_U)
+            __builtin_amdgcn_sched_barrier(0);
+            QG_MATH_FULL(wB, xB, sB)
+            __builtin_amdgcn_sched_barrier(0);
+            g += 2 * QGEMM_U;
+        }
+        if (g + QGEMM_U < g1) {
+            QG_LOAD(wB, xB, sB, g + QGEMM_U)
+            __builtin_amdgcn_sched_barrier(0);
+            QG_MATH_TAIL(wA, xA, sA, g)
+            if (g + 2 * QGEMM_U < g1) {
+                QG_LOAD(wA, xA, sA, g + 2 * QGEMM_U)
+                __builtin_amdgcn_sched_barrier(0);
+                QG_MATH_TAIL(wB, xB, sB, g + QGEMM_U)
+                QG_MATH_TAIL(wA, xA, sA, g + 2 * QGEMM_U)
+            } else {
+                QG_MATH_TAIL(wB, xB, sB, g + QGEMM_U)
+            }
+        } else {
+            QG_MATH_TAIL(wA, xA, sA, g)
+        }
+    }
+#undef QG_LOAD
+#undef QG_GROUP
+#undef QG_MATH_FULL
+#undef QG_MATH_TAIL
+
+    if (KSB == 1) {
+        qgemm_epilogue<MT, R, EPI>(acc, out, ntg, ks, NT, N_out, Mpad, lane, -1, bias);
+    } else {
+        __shared__ float4 red[KSB][R * MT][64];
+#pragma unroll
+        for (int r = 0; r < R; ++r)
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+                red[wave][r * MT + mt][lane] = make_float4(acc[r][mt][0], acc[r][mt][1], acc[r][mt][2], acc[r][mt][3]);
+        __syncthreads();
+        for (int mt = wave; mt < MT; mt += KSB) {
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                float4 s0 = red[0][r * MT + mt][lane];
+#pragma unroll
+                for (int w = 1; w < KSB; ++w) {
+                    float4 t = red[w][r * MT + mt][lane];
+                    s0.x += t.x; s0.y += t.y; s0.z += t.z; s0.w += t.w;
+                }
+#pragma unroll
+                for (int m2 = 0; m2 < MT; ++m2)
+                    if (m2 == mt) acc[r][m2] = (f32x4_t){s0.x, s0.y, s0.z, s0.w};
+            }
+            qgemm_epilogue<MT, R, EPI>(acc, out, ntg, ks, NT, N_out, Mpad, lane, mt, bias);
+        }
+    }
+}
+
+template <int MT, int BITS, int U>
+static void launch_qgemm_mt(int epi, int R, int ksb, const void* Qp, const bf16_t* SB, const bf16_t* X, void* out, int NT, int G, int S,
+                            int N_out, int Mpad, const bf16_t* bias, hipStream_t s) {
+    int n_items = ((NT + R - 1) / R) * S;
+    dim3 grid(ksb == 1 ? (n_items + 3) / 4 : n_items), block(256);
+#define QGEMM_CASE(E, RR, KS)                                                                                       \
+    if (epi == E && R == RR && ksb == KS) {                                                                         \
+        hipLaunchKernelGGL((k_gemm_skinny_q<MT, RR, E, KS, BITS, U>), grid, block, 0, s, Qp, SB, X, out, NT, G, S, n_items, \
+                           N_out, Mpad, bias);                                                                      \
+        return;                                                                                                     \
+    }
+    QGEMM_CASE(EPI_PARTIAL, 1, 4)
+    QGEMM_CASE(EPI_PARTIAL, 2, 1)
+    QGEMM_CASE(EPI_PARTIAL, 2, 4)
+    QGEMM_CASE(EPI_BF16, 2, 1)
+    QGEMM_CASE(EPI_BF16, 2, 4)
+    QGEMM_CASE(EPI_SILU_MUL, 2, 1)
+    QGEMM_CASE(EPI_SILU_MUL, 2, 4)
+#undef QGEMM_CASE
+    throw MisError(MIS_ERR_GENERATION_FAILED, "unsupported quantised GEMM variant");
+}
+
+// Qp / SB: packed codes and scale/bias pairs (see the file header); G = K / 64 scale groups; otherwise as launch_gemm_skinny
+void launch_gemm_skinny_q(int bits, int epi, int R, int ksb, const void* Qp, const bf16_t* SB, const bf16_t* X, void* out, int NT, int G,
+                          int S, int N_out, int Mpad, hipStream_t s, const bf16_t* bias) {
+    MIS_REQUIRE(epi == EPI_PARTIAL || S == 1, MIS_ERR_GENERATION_FAILED, "split-K needs the partial epilogue");
+    MIS_REQUIRE(bits == 8 || bits == 4, MIS_ERR_GENERATION_FAILED, "quantised GEMM: 8 or 4 bits");
+    MIS_REQUIRE(S >= 1 && S <= G, MIS_ERR_GENERATION_FAILED, "quantised GEMM: %d K slices for %d scale groups", S, G);   // a wave may get none
+    static const int u_env = getenv("MIS_QGEMM_U") ? atoi(getenv("MIS_QGEMM_U")) : 2;
+#define QGEMM_MT(M, UU)                                                                                              \
+    if (bits == 8) launch_qgemm_mt<M, 8, UU>(epi, R, ksb, Qp, SB, X, out, NT, G, S, N_out, Mpad, bias, s);           \
+    else launch_qgemm_mt<M, 4, UU>(epi, R, ksb, Qp, SB, X, out, NT, G, S, N_out, Mpad, bias, s);
+    switch (Mpad / 16) {
+        case 1: if (u_env == 1) { QGEMM_MT(1, 1) } else { QGEMM_MT(1, 2) } break;
+        case 2: if (u_env == 1) { QGEMM_MT(2, 1) } else { QGEMM_MT(2, 2) } break;
+        case 3: { QGEMM_MT(3, 1) } break;
+        case 4: { QGEMM_MT(4, 1) } break;
+        default: throw MisError(MIS_ERR_INVALID_INPUT, "batch per GPU must be <= 64");
+    }
+#undef QGEMM_MT
+}
+
+// ---- load-time packing: MLX layout (wq uint32 [N][K*bits/32], scales / biases bf16 [N][K/64]) -> the layouts above.
+// Tile placement as launch_pack_weight: source n-tile t lands at tile t*tile_stride + tile_offset of a matrix with KT = K/32.
+template <int BITS>
+__global__ void k_pack_qweight(const uint32_t* __restrict__ wq, const bf16_t* __restrict__ scales, const bf16_t* __restrict__ biases,
+                               void* __restrict__ qdst, bf16_t* __restrict__ sbdst, int N, int K, int tile_stride, int tile_offset) {
+    const int KT = K / 32, G = K / 64;
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;          // one thread per (n, kt, q)
+    const size_t total = (size_t)N * KT * 4;
+    if (idx < total) {
+        const int q = (int)(idx & 3);
+        const int kt = (int)((idx >> 2) % KT);
+        const int n = (int)(idx / ((size_t)4 * KT));
+        const int tile = (n >> 4) * tile_stride + tile_offset, lane = q * 16 + (n & 15);
+        const int k0 = kt * 32 + q * 8;
+        if (BITS == 8) {
+            const uint32_t* src = wq + (size_t)n * (K / 4) + k0 / 4;
+            reinterpret_cast<uint2*>(qdst)[((size_t)tile * KT + kt) * 64 + lane] = make_uint2(src[0], src[1]);
+        } else {
+            reinterpret_cast<uint32_t*>(qdst)[((size_t)tile * KT + kt) * 64 + lane] = wq[(size_t)n * (K / 8) + k0 / 8];
+        }
+    }
+    if (idx < (size_t)N * G) {                                                  // one thread per (n, g): scale and bias
+        const int g = (int)(idx % G), n = (int)(idx / G);
+        const int tile = (n >> 4) * tile_stride + tile_offset;
+        sbdst[(((size_t)tile * G + g) * 2 + 0) * 16 + (n & 15)] = scales[(size_t)n * G + g];
+        sbdst[(((size_t)tile * G + g) * 2 + 1) * 16 + (n & 15)] = biases[(size_t)n * G + g];
+    }
+}
+void launch_pack_qweight(int bits, const uint32_t* wq, const bf16_t* scales, const bf16_t* biases, void* qdst, bf16_t* sbdst, int N, int K,
+                         int tile_stride, int tile_offset, hipStream_t s) {
+    MIS_REQUIRE((bits == 8 || bits == 4) && N >= 1 && K % 64 == 0, MIS_ERR_INVALID_INPUT, "quantised pack: bad shape");
+    const size_t total = (size_t)N * (K / 32) * 4;
+    dim3 grid((unsigned)((total + 255) / 256)), block(256);
+    if (bits == 8) hipLaunchKernelGGL((k_pack_qweight<8>), grid, block, 0, s, wq, scales, biases, qdst, sbdst, N, K, tile_stride, tile_offset);
+    else hipLaunchKernelGGL((k_pack_qweight<4>), grid, block, 0, s, wq, scales, biases, qdst, sbdst, N, K, tile_stride, tile_offset);
+}

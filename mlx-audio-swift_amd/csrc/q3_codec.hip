@@ -5,9 +5,17 @@
 // -> CausalConv1d k3 (:132-196) -> DecoderTransformer (:449-503: RMSNorm, RoPE, causal SDPA, SwiGLU, LayerScale) -> 2 x
 // [CausalTransposeConv1d (:732-749) + ConvNeXtBlock (:257-299)] -> conv k7 -> 4 x DecoderBlock (:583-637: SnakeBeta,
 // transposed conv k=2s with right trim, 3 residual units with dilations 1/3/9) -> SnakeBeta -> conv k7 -> clip.
-// Because every layer is causal, `streamingStep` over chunks (carried conv buffers, transposed-conv overflow, KV cache)
-// computes exactly the full-sequence result; the GPU decodes whole sequences, and streams by re-decoding a window with enough
-// left context (see q3dec_receptive_frames).
+// Two ways through the same kernels:
+//  * whole sequences (callAsFunction :926-946): dense [B][C][T] buffers;
+//  * `streamingStep` (:971-1006): only the NEW frames of a chunk are computed.  Carried state per session: the last
+//    (k-1)*dilation input columns of every causal conv (CausalConv1d.step :199-227 and the k7 convs :655-667,:710-722), the last
+//    input column of every 2s-tap transposed conv (the reference carries the equivalent `overflow` of the OUTPUT, :553-576) and
+//    the transformer's K/V cache.  Work buffers then have HP columns of head room in front of every row ([B][C][HP + T']): a
+//    tiny kernel drops the carried columns there before the conv runs, so the conv kernels need no second code path - only a
+//    row stride and a lowest valid column (GemmParams.ldx / x_lo).  Every output column is computed by the same instruction
+//    sequence in both modes (same K order, same 64-key attention tiles counted from key 0), so chunked decode is BITWISE equal
+//    to the whole-sequence decode - except where the reference itself differs: its overlap-add sums two biased transposed-conv
+//    outputs, so the first `stride` samples after every chunk boundary carry the bias twice (`dup_bias`, on by default).
 // Activations are NCT ([B][C][T], time contiguous); dense convs are exact-f32 MFMA contractions over (tap, channel)
 // (k_snac_gemm modes TAPS / CONVT of snac.hip) with the SnakeBeta activation fused into the operand load.
 #include "common.h"
@@ -42,29 +50,63 @@ struct mis_q3dec {
     int fin_c = 0;
     DevBuf<float> buf[4];
     DevBuf<int32_t> codes_dev;
+    // streaming session (resetStreamingState / streamingStep)
+    struct Stream {
+        bool open = false, dup_bias = true;
+        int batch = 0, cap_frames = 0, pos = 0, steps = 0;
+        size_t hist_n = 0;
+        DevBuf<float> hist;               // carried conv inputs of every layer, in call order: [layer][B][C][H]
+        DevBuf<float> kv;                 // [layers][B][2 Hkv D][cap_frames]: K rows (unrotated), then V rows
+    } st;
 };
+#define Q3_HP 64                           // head-room columns in front of every work-buffer row (>= 6*9 = longest history)
 
 // ---------------------------------------------------------------------------- kernels
 // codes [B][nq][T] -> h [B][C][T]: sum over quantizers of the folded tables [nq][bins][C]
-__global__ void k_q3_rvq(const int32_t* __restrict__ codes, const float* __restrict__ tables, float* __restrict__ h, int nq, int bins,
-                         int C, int T) {
+// code (b, q, t) at codes[b*cs_b + q*cs_q + t*cs_t]: [B][nq][T] arrays and the generate loop's [B][frames][nq] store alike
+__global__ void k_q3_rvq(const int32_t* __restrict__ codes, int64_t cs_b, int64_t cs_q, int64_t cs_t, const float* __restrict__ tables,
+                         float* __restrict__ h, int nq, int bins, int C, int ld) {
     const int t = blockIdx.x, b = blockIdx.y;
     for (int c = threadIdx.x; c < C; c += blockDim.x) {
         float acc = 0.0f;
         for (int q = 0; q < nq; ++q) {
-            int code = codes[((size_t)b * nq + q) * T + t];
+            int code = codes[(size_t)b * cs_b + (size_t)q * cs_q + (size_t)t * cs_t];
             code = min(max(code, 0), bins - 1);
             acc += tables[((size_t)q * bins + code) * C + c];
         }
-        h[((size_t)b * C + c) * T + t] = acc;
+        h[((size_t)b * C + c) * ld + t] = acc;
     }
+}
+
+// streaming: history columns in and out.  st [B][C][H] holds the last H columns this layer's input had before this chunk; x points
+// at column 0 of the chunk's [B][C][ld] input (Tn new columns).  Columns [-H, 0) of x <- st, then st <- the last H columns of
+// [st | new]  (CausalConv1d.step :201-210).  One block per row, H <= 64.
+__global__ void __launch_bounds__(64) k_q3_hist(float* __restrict__ st, float* __restrict__ x, int C, int ld, int H, int Tn) {
+    const int c = blockIdx.x, b = blockIdx.y, i = threadIdx.x;
+    float* sr = st + ((size_t)b * C + c) * H;
+    float* xr = x + ((size_t)b * C + c) * ld;
+    float old = 0.0f, nw = 0.0f;
+    if (i < H) {
+        old = sr[i];
+        const int src = Tn - H + i;
+        nw = src >= 0 ? xr[src] : sr[i + Tn];
+    }
+    __syncthreads();
+    if (i < H) { xr[i - H] = old; sr[i] = nw; }
+}
+// streaming: K and V rows of the fused q|k|v output (columns [0, Tn)) -> cache columns [pos0, pos0 + Tn)
+__global__ void k_q3_kv_append(const float* __restrict__ qkv, int64_t q_bs, int q_ld, int row0, float* __restrict__ kv, int64_t kv_bs,
+                               int kv_ld, int rows, int pos0, int Tn) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x, r = blockIdx.y, b = blockIdx.z;
+    if (t >= Tn) return;
+    kv[(size_t)b * kv_bs + (size_t)r * kv_ld + pos0 + t] = qkv[(size_t)b * q_bs + (size_t)(row0 + r) * q_ld + t];
 }
 
 // normalisation over the CHANNEL axis of NCT data; rms = 1: w * x * rsqrt(mean(x^2) + eps), else LayerNorm(w, bias)
 __global__ void k_q3_norm_ct(const float* __restrict__ x, float* __restrict__ y, const float* __restrict__ w, const float* __restrict__ bias,
-                             int C, int T, float eps, int rms) {
+                             int C, int Tn, int T /*row stride*/, float eps, int rms) {
     int t = blockIdx.x * blockDim.x + threadIdx.x, b = blockIdx.y;
-    if (t >= T) return;
+    if (t >= Tn) return;
     const float* xb = x + (size_t)b * C * T + t;
     float* yb = y + (size_t)b * C * T + t;
     if (rms) {
@@ -84,68 +126,79 @@ __global__ void k_q3_norm_ct(const float* __restrict__ x, float* __restrict__ y,
 
 // causal depthwise conv, k taps (CausalConv1d with groups = C, :132-196): y[c][t] = b[c] + sum_j w[c][j] x[c][t - (k-1-j)]
 __global__ void k_q3_dw_causal(const float* __restrict__ x, float* __restrict__ y, const float* __restrict__ w, const float* __restrict__ bias,
-                               int C, int T, int k) {
+                               int C, int T, int ld, int x_lo, int k) {
     int t = blockIdx.x * blockDim.x + threadIdx.x, c = blockIdx.y, b = blockIdx.z;
     if (t >= T) return;
-    const float* xr = x + ((size_t)b * C + c) * T;
+    const float* xr = x + ((size_t)b * C + c) * ld;
     float acc = bias[c];
     for (int j = 0; j < k; ++j) {
         int ts = t - (k - 1 - j);
-        if (ts >= 0) acc += w[c * k + j] * xr[ts];
+        if (ts >= x_lo) acc += w[c * k + j] * xr[ts];
     }
-    y[((size_t)b * C + c) * T + t] = acc;
+    y[((size_t)b * C + c) * ld + t] = acc;
 }
 
 // gu [B][2I][T] (gate rows then up rows) -> act [B][I][T] = silu(gate) * up
-__global__ void k_q3_swiglu(const float* __restrict__ gu, float* __restrict__ act, int I, int T) {
+__global__ void k_q3_swiglu(const float* __restrict__ gu, float* __restrict__ act, int I, int Tn, int T /*row stride*/) {
     int t = blockIdx.x * blockDim.x + threadIdx.x, i = blockIdx.y, b = blockIdx.z;
-    if (t >= T) return;
+    if (t >= Tn) return;
     float g = gu[((size_t)b * 2 * I + i) * T + t], u = gu[((size_t)b * 2 * I + I + i) * T + t];
     act[((size_t)b * I + i) * T + t] = (g / (1.0f + expf(-g))) * u;
 }
 
-// causal attention with rotate-half RoPE, f32.  qkv [B][(H + 2 Hkv) D][T]; out [B][H D][T].  One thread per query, 64 queries per
-// block; K/V tiles of 64 keys staged (K rotated) in LDS and read by all threads at the same address (broadcast).
+// causal attention with rotate-half RoPE, f32.  Queries: Tq columns of q (row stride q_ld, batch stride q_bs) at absolute
+// positions pos0 + t; keys / values: columns [0, pos0 + Tq) of k / v (row stride kv_ld, batch stride kv_bs) - the same q|k|v
+// tensor for whole sequences (pos0 = 0), the session's cache when streaming.  One thread per query, 64 queries per block; K/V
+// tiles of 64 keys counted from key 0 are staged (K rotated) in LDS and read by all threads at the same address (broadcast), so
+// a query sees the same operation order whichever chunk it arrives in.
+struct Q3AttnArgs {
+    const float* q; int64_t q_bs; int q_ld;
+    const float* k; const float* v; int64_t kv_bs; int kv_ld;
+    float* out; int64_t o_bs; int o_ld;
+    int H, Hkv, Tq, pos0;
+    float theta, scale;
+};
 template <int D>
-__global__ void __launch_bounds__(64) k_q3_attn(const float* __restrict__ qkv, float* __restrict__ out, int H, int Hkv, int T, float theta,
-                                                float scale) {
+__global__ void __launch_bounds__(64) k_q3_attn(Q3AttnArgs a) {
     __shared__ float Ks[D][64];
     __shared__ float Vs[D][64];
     const int h = blockIdx.y, b = blockIdx.z, tid = threadIdx.x;
-    const int t = blockIdx.x * 64 + tid;
-    const int kvh = h / (H / Hkv);
-    const float* qb = qkv + ((size_t)b * (H + 2 * Hkv) * D + (size_t)h * D) * T;
-    const float* kb = qkv + ((size_t)b * (H + 2 * Hkv) * D + (size_t)(H + kvh) * D) * T;
-    const float* vb = qkv + ((size_t)b * (H + 2 * Hkv) * D + (size_t)(H + Hkv + kvh) * D) * T;
+    const int tq = blockIdx.x * 64 + tid;
+    const int t = a.pos0 + tq;                                        // absolute position of this thread's query
+    const int kvh = h / (a.H / a.Hkv);
+    const int Tk = a.pos0 + a.Tq;
+    const float* qb = a.q + (size_t)b * a.q_bs + (size_t)h * D * a.q_ld;
+    const float* kb = a.k + (size_t)b * a.kv_bs + (size_t)kvh * D * a.kv_ld;
+    const float* vb = a.v + (size_t)b * a.kv_bs + (size_t)kvh * D * a.kv_ld;
     float q[D], o[D];
-    const bool valid = t < T;
+    const bool valid = tq < a.Tq;
 #pragma unroll
     for (int i = 0; i < D / 2; ++i) {
-        float inv = 1.0f / powf(theta, (float)(2 * i) / (float)D);
+        float inv = 1.0f / powf(a.theta, (float)(2 * i) / (float)D);
         float ang = (float)t * inv, c = cosf(ang), s = sinf(ang);
-        float x1 = valid ? qb[(size_t)i * T + t] : 0.0f, x2 = valid ? qb[(size_t)(i + D / 2) * T + t] : 0.0f;
-        q[i] = (x1 * c - x2 * s) * scale;
-        q[i + D / 2] = (x2 * c + x1 * s) * scale;
+        float x1 = valid ? qb[(size_t)i * a.q_ld + tq] : 0.0f, x2 = valid ? qb[(size_t)(i + D / 2) * a.q_ld + tq] : 0.0f;
+        q[i] = (x1 * c - x2 * s) * a.scale;
+        q[i + D / 2] = (x2 * c + x1 * s) * a.scale;
     }
 #pragma unroll
     for (int d = 0; d < D; ++d) o[d] = 0.0f;
     float m = -INFINITY, l = 0.0f;
-    const int t_hi = min(blockIdx.x * 64 + 63, T - 1);
+    const int t_hi = a.pos0 + min(blockIdx.x * 64 + 63, a.Tq - 1);
     for (int j0 = 0; j0 <= t_hi; j0 += 64) {
         __syncthreads();
         {   // thread tid stages key j0 + tid
             const int j = j0 + tid;
-            const bool kin = j < T;
+            const bool kin = j < Tk;
 #pragma unroll
             for (int i = 0; i < D / 2; ++i) {
-                float inv = 1.0f / powf(theta, (float)(2 * i) / (float)D);
+                float inv = 1.0f / powf(a.theta, (float)(2 * i) / (float)D);
                 float ang = (float)j * inv, c = cosf(ang), s = sinf(ang);
-                float x1 = kin ? kb[(size_t)i * T + j] : 0.0f, x2 = kin ? kb[(size_t)(i + D / 2) * T + j] : 0.0f;
+                float x1 = kin ? kb[(size_t)i * a.kv_ld + j] : 0.0f, x2 = kin ? kb[(size_t)(i + D / 2) * a.kv_ld + j] : 0.0f;
                 Ks[i][tid] = x1 * c - x2 * s;
                 Ks[i + D / 2][tid] = x2 * c + x1 * s;
             }
 #pragma unroll
-            for (int d = 0; d < D; ++d) Vs[d][tid] = kin ? vb[(size_t)d * T + j] : 0.0f;
+            for (int d = 0; d < D; ++d) Vs[d][tid] = kin ? vb[(size_t)d * a.kv_ld + j] : 0.0f;
         }
         __syncthreads();
         const int jn = min(64, t_hi - j0 + 1);
@@ -163,25 +216,25 @@ __global__ void __launch_bounds__(64) k_q3_attn(const float* __restrict__ qkv, f
         }
     }
     if (valid) {
-        float* ob = out + ((size_t)b * H * D + (size_t)h * D) * T;
+        float* ob = a.out + (size_t)b * a.o_bs + (size_t)h * D * a.o_ld;
         float rl = 1.0f / l;
 #pragma unroll
-        for (int d = 0; d < D; ++d) ob[(size_t)d * T + t] = o[d] * rl;
+        for (int d = 0; d < D; ++d) ob[(size_t)d * a.o_ld + tq] = o[d] * rl;
     }
 }
 
 // SnakeBeta -> causal conv k (C -> 1) -> clip(-1, 1)   (DecoderOutputSnake / DecoderOutputConv :676-730, clip :945)
 __global__ void k_q3_final(const float* __restrict__ x, float* __restrict__ out, int64_t out_stride, const float* __restrict__ w /*[k][C]*/,
-                           float bias, const float* __restrict__ a, const float* __restrict__ ra, int C, int T, int k) {
+                           float bias, const float* __restrict__ a, const float* __restrict__ ra, int C, int T, int ld, int x_lo, int k) {
     int t = blockIdx.x * blockDim.x + threadIdx.x, b = blockIdx.y;
     if (t >= T) return;
     float acc = bias;
     for (int c = 0; c < C; ++c) {
-        const float* xr = x + ((size_t)b * C + c) * T;
+        const float* xr = x + ((size_t)b * C + c) * ld;
         const float ac = a[c], rc = ra[c];
         for (int j = 0; j < k; ++j) {
             int ts = t - (k - 1 - j);
-            if (ts < 0) continue;
+            if (ts < x_lo) continue;
             float v = xr[ts];
             float s = sinf(ac * v);
             acc += w[j * C + c] * (v + rc * s * s);
@@ -394,115 +447,218 @@ mis_status mis_q3dec_finalize(mis_q3dec* d) {
 }
 
 // ---------------------------------------------------------------------------- decode
-// stop_after (debug taps): 0 full; 1 quantizer; 2 transformer; 3 upsample; 4.. block (stop_after - 4).  Returns the stage buffer.
-static const float* q3dec_run(mis_q3dec* d, const int32_t* codes_dev, int batch, int T, float* wav_dev, int64_t wav_stride, int stop_after,
-                              int* outC, int64_t* outT, hipStream_t s) {
+// history floats one batch row carries through a streaming session (layers in call order of q3dec_run)
+static size_t q3dec_hist_floats(const mis_q3dec* d) {
+    const mis_qwen3tts_config& cf = d->cfg;
+    size_t n = (size_t)cf.dec_codebook_dim * 2;                                 // pre_conv k3
+    n += (size_t)d->ups.size() * cf.dec_latent_dim * 6;                         // ConvNeXt depthwise k7
+    n += (size_t)cf.dec_latent_dim * 6;                                         // decoder.0 k7
+    for (auto& B : d->blocks) n += (size_t)B.cin + (size_t)B.cout * (6 + 18 + 54);
+    n += (size_t)d->fin_c * 6;                                                  // output conv k7
+    return n;
+}
+
+// codes: element (b, q, t) at codes_dev[b*cs_b + q*cs_q + t*cs_t].  st == nullptr: whole sequence of T frames.  st != nullptr: the
+// next T frames of an open streaming session (positions st->pos ..).
+// stop_after (debug taps, whole-sequence mode only): 0 full; 1 quantizer; 2 transformer; 3 upsample; 4.. block (stop_after - 4).
+static const float* q3dec_run(mis_q3dec* d, const int32_t* codes_dev, int64_t cs_b, int64_t cs_q, int64_t cs_t, int batch, int T,
+                              float* wav_dev, int64_t wav_stride, int stop_after, int* outC, int64_t* outT, hipStream_t s,
+                              mis_q3dec::Stream* st) {
     MIS_REQUIRE(d->finalized, MIS_ERR_NOT_INITIALIZED, "speech tokenizer not finalized");
+    MIS_REQUIRE(!st || stop_after == 0, MIS_ERR_INVALID_INPUT, "decoder taps are a whole-sequence facility");
     const mis_qwen3tts_config& cf = d->cfg;
     const float* W = d->arena.p;
     const int Cd = cf.dec_codebook_dim, ld = cf.dec_latent_dim, hs = cf.dec_hidden_size, I = cf.dec_intermediate_size, H = cf.dec_num_heads,
               Hkv = cf.dec_num_kv_heads, D = cf.dec_head_dim;
     const int up = q3dec_total_upsample(d);
+    const int HP = st ? Q3_HP : 0;
+    auto LD = [&](int64_t Tc) { return (int)(HP ? HP + round_up(Tc, 4) : Tc); };          // row stride of a work buffer
     // buffer sizing: the largest [C][T'] along the pipeline
-    size_t need_elems = (size_t)std::max({Cd, ld, (H + 2 * Hkv) * D, 2 * I, hs}) * T;
+    size_t need_elems = (size_t)std::max({Cd, ld, (H + 2 * Hkv) * D, 2 * I, hs}) * LD(T);
     {
         int64_t Tc = T;
-        for (auto& U : d->ups) { Tc *= U.f; need_elems = std::max(need_elems, (size_t)4 * ld * Tc); }
-        need_elems = std::max(need_elems, (size_t)cf.dec_decoder_dim * Tc);
-        for (auto& B : d->blocks) { need_elems = std::max(need_elems, (size_t)B.cin * Tc); Tc *= B.s; need_elems = std::max(need_elems, (size_t)B.cout * Tc); }
+        for (auto& U : d->ups) { Tc *= U.f; need_elems = std::max(need_elems, (size_t)4 * ld * LD(Tc)); }
+        need_elems = std::max(need_elems, (size_t)cf.dec_decoder_dim * LD(Tc));
+        for (auto& B : d->blocks) { need_elems = std::max(need_elems, (size_t)B.cin * LD(Tc)); Tc *= B.s; need_elems = std::max(need_elems, (size_t)B.cout * LD(Tc)); }
     }
-    for (int i = 0; i < 4; ++i) d->buf[i].alloc((size_t)batch * need_elems);
-    float *a = d->buf[0].p, *b = d->buf[1].p, *t1 = d->buf[2].p, *t2 = d->buf[3].p;
-    auto gemm = [&](int mode, bool snake, const mis_q3dec::Lin& L, const float* X, float* Y, int N, int Tin, int Tout, const float* R = nullptr,
+    for (int i = 0; i < 4; ++i) d->buf[i].alloc((size_t)batch * need_elems + 2 * Q3_HP);
+    float *a = d->buf[0].p + HP, *b = d->buf[1].p + HP, *t1 = d->buf[2].p + HP, *t2 = d->buf[3].p + HP;     // column 0 of row 0
+    auto gemm = [&](const mis_q3dec::Lin& L, const float* X, float* Y, int N, int Tin, int Tout, const float* R = nullptr,
                     const float* scale = nullptr, const float* al = nullptr, const float* ral = nullptr) {
         GemmParams g{};
         g.AT = W + L.w; g.bias = L.b == (size_t)-1 ? nullptr : W + L.b; g.X = X; g.Y = Y; g.R = R; g.scale = scale; g.alpha = al; g.ralpha = ral;
         g.M = L.M; g.K = L.K; g.N = N; g.Tin = Tin; g.Tout = Tout;
+        g.ldx = LD(Tin); g.ldy = LD(Tout); g.x_lo = -HP;
         return g;
+    };
+    // streaming: carried input columns of the conv about to run on x (C channels, H = (k-1)*dilation columns, Tn new columns)
+    size_t hist_cur = 0;
+    auto hist = [&](float* x, int C, int Tn, int Hc) {
+        if (!st) return;
+        MIS_REQUIRE(Hc <= Q3_HP && hist_cur + (size_t)batch * C * Hc <= st->hist_n, MIS_ERR_GENERATION_FAILED, "streaming history overflow");
+        hipLaunchKernelGGL(k_q3_hist, dim3(C, batch), dim3(64), 0, s, st->hist.p + hist_cur, x, C, LD(Tn), Hc, Tn);
+        hist_cur += (size_t)batch * C * Hc;
     };
     const float* Z = W + d->zeros;
     dim3 tb(128);
     int Tc = T;
-    hipLaunchKernelGGL(k_q3_rvq, dim3(T, batch), dim3(256), 0, s, codes_dev, W + d->rvq_tables, a, cf.dec_num_quantizers, cf.dec_codebook_size, Cd, T);
+    const int pos0 = st ? st->pos : 0;
+    hipLaunchKernelGGL(k_q3_rvq, dim3(T, batch), dim3(256), 0, s, codes_dev, cs_b, cs_q, cs_t, W + d->rvq_tables, a, cf.dec_num_quantizers,
+                       cf.dec_codebook_size, Cd, LD(T));
     if (stop_after == 1) { *outC = Cd; *outT = T; return a; }
     {   // pre_conv: causal k3
-        GemmParams g = gemm(GEMM_TAPS, true, d->pre_conv, a, b, T, T, T, nullptr, nullptr, Z, Z);
+        hist(a, Cd, T, 2);
+        GemmParams g = gemm(d->pre_conv, a, b, T, T, T, nullptr, nullptr, Z, Z);
         g.Cin = Cd; g.taps = 3; g.dil = 1; g.pad = 2;
         launch_gemm(GEMM_TAPS, true, g, batch, s);
     }
     // ---- transformer (NCT: channels x time), x in `a`
-    launch_gemm(GEMM_PLAIN, false, gemm(GEMM_PLAIN, false, d->in_proj, b, a, T, T, T), batch, s);
+    launch_gemm(GEMM_PLAIN, false, gemm(d->in_proj, b, a, T, T, T), batch, s);
     float* x = a; float* y = b;
+    const int ldT = LD(T);
+    int li = 0;
     for (auto& L : d->layers) {
-        hipLaunchKernelGGL(k_q3_norm_ct, dim3(cdiv(T, 128), batch), tb, 0, s, x, t1, W + L.ln1, nullptr, hs, T, cf.dec_rms_norm_eps, 1);
-        launch_gemm(GEMM_PLAIN, false, gemm(GEMM_PLAIN, false, L.qkv, t1, t2, T, T, T), batch, s);
+        hipLaunchKernelGGL(k_q3_norm_ct, dim3(cdiv(T, 128), batch), tb, 0, s, x, t1, W + L.ln1, nullptr, hs, T, ldT, cf.dec_rms_norm_eps, 1);
+        launch_gemm(GEMM_PLAIN, false, gemm(L.qkv, t1, t2, T, T, T), batch, s);
+        Q3AttnArgs aa{};
+        aa.q = t2; aa.q_bs = (int64_t)(H + 2 * Hkv) * D * ldT; aa.q_ld = ldT;
+        aa.out = t1; aa.o_bs = (int64_t)H * D * ldT; aa.o_ld = ldT;
+        aa.H = H; aa.Hkv = Hkv; aa.Tq = T; aa.pos0 = pos0; aa.theta = cf.dec_rope_theta; aa.scale = 1.0f / sqrtf((float)D);
+        if (st) {
+            const int64_t kv_bs = (int64_t)2 * Hkv * D * st->cap_frames;
+            float* cache = st->kv.p + (size_t)li * batch * kv_bs;
+            hipLaunchKernelGGL(k_q3_kv_append, dim3(cdiv(T, 64), 2 * Hkv * D, batch), dim3(64), 0, s, t2, aa.q_bs, ldT, H * D, cache, kv_bs,
+                               st->cap_frames, 2 * Hkv * D, pos0, T);
+            aa.k = cache; aa.v = cache + (size_t)Hkv * D * st->cap_frames; aa.kv_bs = kv_bs; aa.kv_ld = st->cap_frames;
+        } else {
+            aa.k = t2 + (size_t)H * D * ldT; aa.v = t2 + (size_t)(H + Hkv) * D * ldT; aa.kv_bs = aa.q_bs; aa.kv_ld = ldT;
+        }
         dim3 ag(cdiv(T, 64), H, batch);
-        const float sc = 1.0f / sqrtf((float)D);
-        if (D == 64) hipLaunchKernelGGL((k_q3_attn<64>), ag, dim3(64), 0, s, t2, t1, H, Hkv, T, cf.dec_rope_theta, sc);
-        else if (D == 32) hipLaunchKernelGGL((k_q3_attn<32>), ag, dim3(64), 0, s, t2, t1, H, Hkv, T, cf.dec_rope_theta, sc);
-        else hipLaunchKernelGGL((k_q3_attn<16>), ag, dim3(64), 0, s, t2, t1, H, Hkv, T, cf.dec_rope_theta, sc);
-        launch_gemm(GEMM_RESID, false, gemm(GEMM_RESID, false, L.o, t1, y, T, T, T, x, W + L.ls1), batch, s);
+        if (D == 64) hipLaunchKernelGGL((k_q3_attn<64>), ag, dim3(64), 0, s, aa);
+        else if (D == 32) hipLaunchKernelGGL((k_q3_attn<32>), ag, dim3(64), 0, s, aa);
+        else hipLaunchKernelGGL((k_q3_attn<16>), ag, dim3(64), 0, s, aa);
+        launch_gemm(GEMM_RESID, false, gemm(L.o, t1, y, T, T, T, x, W + L.ls1), batch, s);
         std::swap(x, y);
-        hipLaunchKernelGGL(k_q3_norm_ct, dim3(cdiv(T, 128), batch), tb, 0, s, x, t1, W + L.ln2, nullptr, hs, T, cf.dec_rms_norm_eps, 1);
-        launch_gemm(GEMM_PLAIN, false, gemm(GEMM_PLAIN, false, L.gu, t1, t2, T, T, T), batch, s);
-        hipLaunchKernelGGL(k_q3_swiglu, dim3(cdiv(T, 128), I, batch), tb, 0, s, t2, t1, I, T);
-        launch_gemm(GEMM_RESID, false, gemm(GEMM_RESID, false, L.down, t1, y, T, T, T, x, W + L.ls2), batch, s);
+        hipLaunchKernelGGL(k_q3_norm_ct, dim3(cdiv(T, 128), batch), tb, 0, s, x, t1, W + L.ln2, nullptr, hs, T, ldT, cf.dec_rms_norm_eps, 1);
+        launch_gemm(GEMM_PLAIN, false, gemm(L.gu, t1, t2, T, T, T), batch, s);
+        hipLaunchKernelGGL(k_q3_swiglu, dim3(cdiv(T, 128), I, batch), tb, 0, s, t2, t1, I, T, ldT);
+        launch_gemm(GEMM_RESID, false, gemm(L.down, t1, y, T, T, T, x, W + L.ls2), batch, s);
         std::swap(x, y);
+        ++li;
     }
-    hipLaunchKernelGGL(k_q3_norm_ct, dim3(cdiv(T, 128), batch), tb, 0, s, x, t1, W + d->tnorm, nullptr, hs, T, cf.dec_rms_norm_eps, 1);
-    launch_gemm(GEMM_PLAIN, false, gemm(GEMM_PLAIN, false, d->out_proj, t1, y, T, T, T), batch, s);
+    hipLaunchKernelGGL(k_q3_norm_ct, dim3(cdiv(T, 128), batch), tb, 0, s, x, t1, W + d->tnorm, nullptr, hs, T, ldT, cf.dec_rms_norm_eps, 1);
+    launch_gemm(GEMM_PLAIN, false, gemm(d->out_proj, t1, y, T, T, T), batch, s);
     std::swap(x, y);                                                   // x: [B][ld][T]
     if (stop_after == 2) { *outC = ld; *outT = T; return x; }
-    // ---- upsample layers: transposed conv (k = stride = f) + ConvNeXt
+    // ---- upsample layers: transposed conv (k = stride = f: no overlap, nothing carried) + ConvNeXt
     for (auto& U : d->ups) {
-        GemmParams g = gemm(GEMM_CONVT, true, U.ct, x, y, Tc, Tc, Tc * U.f, nullptr, nullptr, Z, Z);
+        GemmParams g = gemm(U.ct, x, y, Tc, Tc, Tc * U.f, nullptr, nullptr, Z, Z);
         g.s = U.f; g.pad = 0; g.Cin = ld;
         launch_gemm(GEMM_CONVT, true, g, batch, s);
         Tc *= U.f;
         std::swap(x, y);
-        hipLaunchKernelGGL(k_q3_dw_causal, dim3(cdiv(Tc, 128), ld, batch), tb, 0, s, x, t1, W + U.dw, W + U.dwb, ld, Tc, 7);
-        hipLaunchKernelGGL(k_q3_norm_ct, dim3(cdiv(Tc, 128), batch), tb, 0, s, t1, t2, W + U.lnw, W + U.lnb, ld, Tc, 1e-6f, 0);
-        launch_gemm(GEMM_GELU, false, gemm(GEMM_GELU, false, U.p1, t2, t1, Tc, Tc, Tc), batch, s);
-        launch_gemm(GEMM_RESID, false, gemm(GEMM_RESID, false, U.p2, t1, y, Tc, Tc, Tc, x, W + U.gamma), batch, s);
+        const int ldc = LD(Tc);
+        hist(x, ld, Tc, 6);
+        hipLaunchKernelGGL(k_q3_dw_causal, dim3(cdiv(Tc, 128), ld, batch), tb, 0, s, x, t1, W + U.dw, W + U.dwb, ld, Tc, ldc, -HP, 7);
+        hipLaunchKernelGGL(k_q3_norm_ct, dim3(cdiv(Tc, 128), batch), tb, 0, s, t1, t2, W + U.lnw, W + U.lnb, ld, Tc, ldc, 1e-6f, 0);
+        launch_gemm(GEMM_GELU, false, gemm(U.p1, t2, t1, Tc, Tc, Tc), batch, s);
+        launch_gemm(GEMM_RESID, false, gemm(U.p2, t1, y, Tc, Tc, Tc, x, W + U.gamma), batch, s);
         std::swap(x, y);
     }
     if (stop_after == 3) { *outC = ld; *outT = Tc; return x; }
     {   // decoder.0: causal k7
-        GemmParams g = gemm(GEMM_TAPS, true, d->dec0, x, y, Tc, Tc, Tc, nullptr, nullptr, Z, Z);
+        hist(x, ld, Tc, 6);
+        GemmParams g = gemm(d->dec0, x, y, Tc, Tc, Tc, nullptr, nullptr, Z, Z);
         g.Cin = ld; g.taps = 7; g.dil = 1; g.pad = 6;
         launch_gemm(GEMM_TAPS, true, g, batch, s);
         std::swap(x, y);
     }
     int bi = 0;
     for (auto& B : d->blocks) {
-        GemmParams g = gemm(GEMM_CONVT, true, B.ct, x, y, Tc, Tc, Tc * B.s, nullptr, nullptr, W + B.a, W + B.ra);
+        hist(x, B.cin, Tc, 1);                                          // tap p + s of output frame n reads input column n - 1
+        GemmParams g = gemm(B.ct, x, y, Tc, Tc, Tc * B.s, nullptr, nullptr, W + B.a, W + B.ra);
         g.s = B.s; g.pad = 0; g.Cin = B.cin;
+        g.dup_bias_n0 = (st && st->dup_bias && st->steps > 0) ? 1 : 0;
         launch_gemm(GEMM_CONVT, true, g, batch, s);
         Tc *= B.s;
         std::swap(x, y);
         for (int ri = 0; ri < 3; ++ri) {
             const auto& R = B.ru[ri];
-            GemmParams g1 = gemm(GEMM_TAPS, true, R.c1, x, t1, Tc, Tc, Tc, nullptr, nullptr, W + R.a1, W + R.ra1);
+            hist(x, B.cout, Tc, 6 * R.dil);
+            GemmParams g1 = gemm(R.c1, x, t1, Tc, Tc, Tc, nullptr, nullptr, W + R.a1, W + R.ra1);
             g1.Cin = B.cout; g1.taps = 7; g1.dil = R.dil; g1.pad = 6 * R.dil;
             launch_gemm(GEMM_TAPS, true, g1, batch, s);
-            launch_gemm(GEMM_RESID, true, gemm(GEMM_RESID, true, R.c2, t1, y, Tc, Tc, Tc, x, nullptr, W + R.a2, W + R.ra2), batch, s);
+            launch_gemm(GEMM_RESID, true, gemm(R.c2, t1, y, Tc, Tc, Tc, x, nullptr, W + R.a2, W + R.ra2), batch, s);
             std::swap(x, y);
         }
         if (stop_after == 4 + bi) { *outC = B.cout; *outT = Tc; return x; }
         ++bi;
     }
     MIS_REQUIRE(Tc == (int64_t)T * up, MIS_ERR_GENERATION_FAILED, "internal length mismatch");
+    hist(x, d->fin_c, Tc, 6);
     hipLaunchKernelGGL(k_q3_final, dim3(cdiv(Tc, 128), batch), tb, 0, s, x, wav_dev, wav_stride, W + d->fin_w, d->fin_b, W + d->fin_a,
-                       W + d->fin_ra, d->fin_c, Tc, 7);
+                       W + d->fin_ra, d->fin_c, Tc, LD(Tc), -HP, 7);
     HIP_CHECK(hipGetLastError());
+    if (st) {
+        MIS_REQUIRE(hist_cur == st->hist_n, MIS_ERR_GENERATION_FAILED, "streaming history bookkeeping mismatch");
+        st->pos += T; st->steps += 1;
+    }
     *outC = 1; *outT = Tc;
     return wav_dev;
 }
 
 void q3dec_decode_device(mis_q3dec* d, const int32_t* codes_dev, int batch, int T, float* wav_dev, int64_t wav_stride, hipStream_t s) {
     int C; int64_t Tt;
-    q3dec_run(d, codes_dev, batch, T, wav_dev, wav_stride, 0, &C, &Tt, s);
+    q3dec_run(d, codes_dev, (int64_t)d->cfg.dec_num_quantizers * T, T, 1, batch, T, wav_dev, wav_stride, 0, &C, &Tt, s, nullptr);
 }
+
+// whole sequences straight from a strided code store (element (b, q, t) at codes_dev[b*cs_b + q*cs_q + t*cs_t])
+void q3dec_decode_strided(mis_q3dec* d, const int32_t* codes_dev, int64_t cs_b, int64_t cs_q, int64_t cs_t, int batch, int T, float* wav_dev,
+                          int64_t wav_stride, hipStream_t s) {
+    int C; int64_t Tt;
+    q3dec_run(d, codes_dev, cs_b, cs_q, cs_t, batch, T, wav_dev, wav_stride, 0, &C, &Tt, s, nullptr);
+}
+
+// ---- streaming session: resetStreamingState (:948-968) + streamingStep (:971-1006)
+// cap_frames bounds the session length (K/V cache columns); chunk_cap the frames of one step (work buffers are sized up front so
+// no allocation happens between steps).  dup_bias: reproduce the reference's double bias at chunk boundaries (see header).
+void q3dec_stream_begin(mis_q3dec* d, int batch, int cap_frames, int chunk_cap, bool dup_bias, hipStream_t s) {
+    MIS_REQUIRE(d->finalized, MIS_ERR_NOT_INITIALIZED, "speech tokenizer not finalized");
+    MIS_REQUIRE(batch >= 1 && cap_frames >= 1 && chunk_cap >= 1, MIS_ERR_INVALID_INPUT, "bad streaming session sizes");
+    HIP_CHECK(hipSetDevice(d->device));
+    const mis_qwen3tts_config& cf = d->cfg;
+    auto& st = d->st;
+    st.open = true; st.dup_bias = dup_bias; st.batch = batch; st.cap_frames = cap_frames; st.pos = 0; st.steps = 0;
+    st.hist_n = (size_t)batch * q3dec_hist_floats(d);
+    st.hist.alloc(st.hist_n);
+    st.kv.alloc((size_t)cf.dec_num_layers * batch * 2 * cf.dec_num_kv_heads * cf.dec_head_dim * cap_frames);
+    HIP_CHECK(hipMemsetAsync(st.hist.p, 0, st.hist_n * 4, s));             // no history = the causal zero padding (:206)
+    {   // size the work buffers for the largest chunk now
+        const int up = q3dec_total_upsample(d);
+        const int Cd = cf.dec_codebook_dim, ld = cf.dec_latent_dim, hs = cf.dec_hidden_size, I = cf.dec_intermediate_size, H = cf.dec_num_heads,
+                  Hkv = cf.dec_num_kv_heads, D = cf.dec_head_dim;
+        auto LD = [&](int64_t Tc) { return (size_t)(Q3_HP + round_up(Tc, 4)); };
+        size_t need = (size_t)std::max({Cd, ld, (H + 2 * Hkv) * D, 2 * I, hs}) * LD(chunk_cap);
+        int64_t Tc = chunk_cap;
+        for (auto& U : d->ups) { Tc *= U.f; need = std::max(need, (size_t)4 * ld * LD(Tc)); }
+        need = std::max(need, (size_t)cf.dec_decoder_dim * LD(Tc));
+        for (auto& B : d->blocks) { need = std::max(need, (size_t)B.cin * LD(Tc)); Tc *= B.s; need = std::max(need, (size_t)B.cout * LD(Tc)); }
+        (void)up;
+        for (int i = 0; i < 4; ++i) d->buf[i].alloc((size_t)batch * need + 2 * Q3_HP);
+    }
+}
+// the next Tn frames of every row: wav_dev [batch][wav_stride], Tn * samples_per_frame new samples per row
+void q3dec_stream_step(mis_q3dec* d, const int32_t* codes_dev, int64_t cs_b, int64_t cs_q, int64_t cs_t, int Tn, float* wav_dev,
+                       int64_t wav_stride, hipStream_t s) {
+    auto& st = d->st;
+    MIS_REQUIRE(st.open, MIS_ERR_NOT_INITIALIZED, "no streaming session is open");
+    MIS_REQUIRE(Tn >= 1 && st.pos + Tn <= st.cap_frames, MIS_ERR_INVALID_INPUT, "streaming step of %d frames at position %d exceeds the session capacity %d",
+                Tn, st.pos, st.cap_frames);
+    int C; int64_t Tt;
+    q3dec_run(d, codes_dev, cs_b, cs_q, cs_t, st.batch, Tn, wav_dev, wav_stride, 0, &C, &Tt, s, &st);
+}
+void q3dec_stream_end(mis_q3dec* d) { d->st.open = false; }
+int q3dec_stream_pos(const mis_q3dec* d) { return d->st.open ? d->st.pos : -1; }
 
 // host entry used by mis_qwen3tts_decode / debug taps: codes host or device [B][nq][T]
 void q3dec_decode_host(mis_q3dec* d, const int32_t* codes, int batch, int T, float* out, int stop_after, int* outC, int64_t* outT, hipStream_t s) {
@@ -514,9 +670,23 @@ void q3dec_decode_host(mis_q3dec* d, const int32_t* codes, int batch, int T, flo
     DevBuf<float> wav;
     wav.alloc((size_t)batch * n);
     int C = 0; int64_t Tt = 0;
-    const float* res = q3dec_run(d, d->codes_dev.p, batch, T, wav.p, n, stop_after, &C, &Tt, s);
+    const float* res = q3dec_run(d, d->codes_dev.p, (int64_t)nq * T, T, 1, batch, T, wav.p, n, stop_after, &C, &Tt, s, nullptr);
     if (out) HIP_CHECK(hipMemcpyAsync(out, res, (size_t)batch * C * Tt * 4, hipMemcpyDefault, s));
     HIP_CHECK(hipStreamSynchronize(s));
     if (outC) *outC = C;
     if (outT) *outT = Tt;
+}
+// streamingStep from host or device codes [B][nq][Tn] -> out (host or device) [B][Tn * samples_per_frame]
+void q3dec_stream_step_host(mis_q3dec* d, const int32_t* codes, int Tn, float* out, hipStream_t s) {
+    HIP_CHECK(hipSetDevice(d->device));
+    const int nq = d->cfg.dec_num_quantizers, batch = d->st.batch;
+    MIS_REQUIRE(d->st.open, MIS_ERR_NOT_INITIALIZED, "no streaming session is open");
+    d->codes_dev.alloc((size_t)batch * nq * Tn);
+    HIP_CHECK(hipMemcpyAsync(d->codes_dev.p, codes, (size_t)batch * nq * Tn * 4, hipMemcpyDefault, s));
+    const int64_t n = (int64_t)Tn * q3dec_total_upsample(d);
+    DevBuf<float> wav;
+    wav.alloc((size_t)batch * n);
+    q3dec_stream_step(d, d->codes_dev.p, (int64_t)nq * Tn, Tn, 1, Tn, wav.p, n, s);
+    HIP_CHECK(hipMemcpyAsync(out, wav.p, (size_t)batch * n * 4, hipMemcpyDefault, s));
+    HIP_CHECK(hipStreamSynchronize(s));
 }

@@ -15,6 +15,10 @@
 #include <math.h>
 #include <string.h>
 #include <algorithm>
+#include <chrono>
+#include <deque>
+#include <functional>
+#include <memory>
 #include <set>
 
 struct mis_qwen3tts {
@@ -24,7 +28,8 @@ struct mis_qwen3tts {
     mis_tts* pred = nullptr;
     mis_q3dec* dec = nullptr;
     hipStream_t s = nullptr;
-    bool proj = false, finalized = false;
+    hipStream_t s_dec = nullptr;            // speech-tokenizer decoder stream while the frame loop keeps running on s (generateStream)
+    bool proj = false, finalized = false, stream_exact = false;
     int G = 0, d = 0, dp = 0, th = 0, Vt = 0, Vc = 0, Vp = 0, VpPad = 0;
     std::set<std::string> loaded;
     DevBuf<uint8_t> raw;
@@ -157,6 +162,8 @@ extern "C" mis_status mis_qwen3tts_create(const mis_qwen3tts_config* cfg, int de
     c->cfg.talker = tc; c->cfg.predictor = pc;
     c->s = tts_stream(c->talker);
     tts_internal_use_stream(c->pred, c->s);
+    HIP_CHECK(hipSetDevice(device));
+    HIP_CHECK(hipStreamCreateWithFlags(&c->s_dec, hipStreamNonBlocking));
     c->G = cfg->num_code_groups; c->d = tc.hidden_size; c->dp = pc.hidden_size; c->th = cfg->text_hidden_size;
     c->Vt = cfg->text_vocab_size; c->Vc = tc.vocab_size; c->Vp = pc.vocab_size; c->VpPad = (int)round_up(c->Vp, 16);
     c->proj = c->d != c->dp;
@@ -182,6 +189,7 @@ extern "C" void mis_qwen3tts_destroy(mis_qwen3tts* c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
     if (c->s) (void)hipStreamSynchronize(c->s);
+    if (c->s_dec) { (void)hipStreamSynchronize(c->s_dec); (void)hipStreamDestroy(c->s_dec); }
     if (c->dec) mis_q3dec_destroy(c->dec);
     if (c->pred) mis_tts_destroy(c->pred);          // borrows the talker's stream (or still owns its own if create failed early)
     if (c->talker) mis_tts_destroy(c->talker);
@@ -261,6 +269,45 @@ extern "C" mis_status mis_qwen3tts_set_tensor(mis_qwen3tts* c, const char* name_
     MIS_API_END
 }
 
+// A tensor of a quantised checkpoint (mlx quantize: uint32 words + scales + biases, Qwen3TTS.swift:1157-1170).  The Linear layers of
+// the two LMs (q/k/v/o/gate/up/down, codec_head) keep their quantised form and are streamed as codes (mis_tts_set_tensor_quantized);
+// everything that is gathered or folded at load (embeddings, text projection, predictor tables and heads, mtp projection) is
+// dequantised here to bf16 rows - for the embeddings that IS the reference's arithmetic (QuantizedEmbedding returns model-dtype rows).
+extern "C" mis_status mis_qwen3tts_set_tensor_quantized(mis_qwen3tts* c, const char* name_, const uint32_t* wq, const void* scales,
+                                                        const void* biases, mis_dtype sb_dtype, int64_t N, int64_t K, int group_size,
+                                                        int bits) {
+    MIS_API_BEGIN
+    MIS_REQUIRE(c && name_ && wq && scales && biases, MIS_ERR_INVALID_INPUT, "null argument");
+    MIS_REQUIRE(!c->finalized, MIS_ERR_INVALID_INPUT, "set_tensor after finalize");
+    std::string name = name_;
+    if (name.rfind("talker.", 0) == 0) name = name.substr(7);
+    const bool pred_lm = name.rfind("code_predictor.model.layers.", 0) == 0;
+    const bool talker_lm = name.rfind("model.layers.", 0) == 0 || name == "codec_head.weight";
+    if (pred_lm || talker_lm) {
+        const std::string inner = pred_lm ? name.substr(strlen("code_predictor.")) : (name == "codec_head.weight" ? "lm_head.weight" : name);
+        mis_status st = mis_tts_set_tensor_quantized(pred_lm ? c->pred : c->talker, inner.c_str(), wq, scales, biases, sb_dtype, N, K, group_size, bits);
+        if (st != MIS_OK) return st;
+        c->loaded.insert(name);
+        return MIS_OK;
+    }
+    MIS_REQUIRE(bits == 2 || bits == 4 || bits == 8, MIS_ERR_INVALID_INPUT, "unsupported quantisation width %d", bits);
+    MIS_REQUIRE(group_size >= 1 && N >= 1 && K >= 1 && K % group_size == 0 && K % (32 / bits) == 0, MIS_ERR_INVALID_INPUT, "bad quantised shape for %s", name_);
+    HIP_CHECK(hipSetDevice(c->device));
+    const size_t words = (size_t)N * K * bits / 32, ng = (size_t)N * (K / group_size), esz = sb_dtype == MIS_F32 ? 4 : 2;
+    DevBuf<uint8_t> raw;
+    DevBuf<bf16_t> rows;
+    const size_t wb = round_up(words * 4, 16), sb = round_up(ng * esz, 16);
+    raw.alloc(wb + 2 * sb); rows.alloc((size_t)N * K);
+    HIP_CHECK(hipMemcpyAsync(raw.p, wq, words * 4, hipMemcpyDefault, c->s));
+    HIP_CHECK(hipMemcpyAsync(raw.p + wb, scales, ng * esz, hipMemcpyDefault, c->s));
+    HIP_CHECK(hipMemcpyAsync(raw.p + wb + sb, biases, ng * esz, hipMemcpyDefault, c->s));
+    launch_dequant_affine((const uint32_t*)raw.p, raw.p + wb, raw.p + wb + sb, (int)sb_dtype, rows.p, (int)N, (int)K, group_size, bits, c->s);
+    HIP_CHECK(hipStreamSynchronize(c->s));
+    const int64_t shape[2] = {N, K};
+    return mis_qwen3tts_set_tensor(c, name_, rows.p, MIS_BF16, shape, 2);
+    MIS_API_END
+}
+
 // out[rows][dp] = T(table[rows][d] . Wp^T + b): the mtp projection applied once to every embedding table (identical per row to
 // projecting after the gather, Qwen3TTSCodePredictor.swift:231-234)
 static void project_table(mis_qwen3tts* c, const bf16_t* table, int rows, DevBuf<bf16_t>& out) {
@@ -302,7 +349,15 @@ extern "C" mis_status mis_qwen3tts_finalize(mis_qwen3tts* c) {
 }
 
 // ---------------------------------------------------------------------------- generate (codes)
-struct Q3Run { int batch, P, Tt, Lmax, max_frames; };
+// generateStream: the frame loop tells the caller whenever another `chunk_frames` frames of every row are final on the loop's
+// stream (Qwen3TTS.swift:492-505), and lets it look for finished work after every host synchronisation.
+struct Q3StreamHook {
+    int chunk_frames = 0;
+    std::function<void(int f0, int fn)> on_boundary;    // frames [f0, f0 + fn) were just enqueued on c->s
+    std::function<void(int f)> pre_sync;                // f frames enqueued; the loop is about to synchronise with the host
+    std::function<void(int f)> poll;                    // ... and has
+    std::function<void()> loop_done;                    // every row has ended (before the frames after the last full chunk go out)
+};
 
 static void q3_text_projection(mis_qwen3tts* c, const std::vector<int32_t>& text_ids) {
     // textProjection(textEmbedding(ids)) for every text id of the call (ResizeMLP, Qwen3TTSTalker.swift:212-225), 64 rows a time
@@ -324,7 +379,7 @@ static void q3_text_projection(mis_qwen3tts* c, const std::vector<int32_t>& text
 void q3_generate_codes(mis_qwen3tts* c, const int32_t* text_ids, const int32_t* codec_ids, const int32_t* prefill_lens, int P,
                        const int32_t* trailing_ids, const int32_t* trailing_lens, int Tt, int batch, const mis_qwen3tts_params* gp,
                        const int32_t* row_max_frames, std::vector<int32_t>& codes_host, std::vector<int32_t>& n_frames_host,
-                       int* stride_out, const volatile int* cancel) {
+                       int* stride_out, const volatile int* cancel, Q3StreamHook* hook = nullptr) {
     MIS_REQUIRE(c->finalized, MIS_ERR_NOT_INITIALIZED, "Qwen3-TTS model not finalized");
     MIS_REQUIRE(batch >= 1 && batch <= 64 && P >= 1 && Tt >= 0, MIS_ERR_INVALID_INPUT, "bad batch / prompt sizes");
     MIS_REQUIRE(gp->max_frames >= 1, MIS_ERR_INVALID_INPUT, "max_frames must be positive");
@@ -454,18 +509,31 @@ void q3_generate_codes(mis_qwen3tts* c, const int32_t* text_ids, const int32_t* 
         PinnedBuf<int32_t> done_pin(1);
         int32_t* done_host = done_pin.p;
         *done_host = 0;
-        int f = 0;
+        int f = 0, last_boundary = 0;
         const int poll = 8;
         while (f < max_frames) {
             int chunk = std::min(poll, max_frames - f);
+            if (hook) chunk = std::min(chunk, last_boundary + hook->chunk_frames - f);
             for (int i = 0; i < chunk; ++i) { if (use_graph) HIP_CHECK(hipGraphLaunch(g_frame, s)); else frame_body(); }
             f += chunk;
+            if (hook && f - last_boundary == hook->chunk_frames) { hook->on_boundary(last_boundary, f - last_boundary); last_boundary = f; }
             HIP_CHECK(hipMemcpyAsync(done_host, c->done.p, 4, hipMemcpyDeviceToHost, s));
+            if (hook) hook->pre_sync(f);
             HIP_CHECK(hipStreamSynchronize(s));
+            if (hook) hook->poll(f);
             if (*done_host >= batch) break;
             if (cancel && *cancel) throw MisError(MIS_ERR_CANCELLED, "generation cancelled");
         }
         HIP_CHECK(hipGetLastError());
+        if (hook) {   // the frames after the last full chunk (:537-546): rows still running there have <= f - last_boundary of them
+            n_frames_host.resize(batch);
+            HIP_CHECK(hipMemcpyAsync(n_frames_host.data(), c->n_frames.p, batch * 4, hipMemcpyDeviceToHost, s));
+            HIP_CHECK(hipStreamSynchronize(s));
+            int longest = 0;
+            for (int b = 0; b < batch; ++b) longest = std::max(longest, n_frames_host[b]);
+            hook->loop_done();
+            if (longest > last_boundary) hook->on_boundary(last_boundary, longest - last_boundary);
+        }
     } catch (...) {
         if (g_prefill) (void)hipGraphExecDestroy(g_prefill);
         if (g_frame) (void)hipGraphExecDestroy(g_frame);
@@ -557,9 +625,45 @@ extern "C" mis_status mis_qwen3tts_decoder_tap(mis_qwen3tts* c, const int32_t* c
     MIS_API_END
 }
 
-// generateVoiceDesign for a batch of prepared prompts (Qwen3TTS.swift:306-569): codes, then the speech tokenizer per row.
-// on_event (nullable): MIS_EVENT_AUDIO chunks of `chunk_frames` frames per row while decoding (streamingInterval * 12.5,
-// :394-395,492-505), emitted after generation in row order; the concatenation of a row's chunks equals its pcm row.
+// ---- streamingStep / resetStreamingState as a session on the handle (Qwen3TTSSpeechTokenizer.swift:948-1006)
+// exact = 1: chunked decode bitwise equal to the whole-sequence decode; 0 (default): the reference's streaming arithmetic, whose
+// overlap-add counts the transposed-conv bias twice on the first `stride` samples after every chunk boundary (:553-576).
+extern "C" mis_status mis_qwen3tts_set_stream_exact(mis_qwen3tts* c, int exact) {
+    MIS_API_BEGIN
+    MIS_REQUIRE(c, MIS_ERR_INVALID_INPUT, "null handle");
+    c->stream_exact = exact != 0;
+    MIS_API_END
+}
+extern "C" mis_status mis_qwen3tts_decode_stream_begin(mis_qwen3tts* c, int batch, int max_frames, int max_chunk_frames) {
+    MIS_API_BEGIN
+    MIS_REQUIRE(c && batch >= 1 && max_frames >= 1 && max_chunk_frames >= 1, MIS_ERR_INVALID_INPUT, "bad argument");
+    MIS_REQUIRE(c->finalized, MIS_ERR_NOT_INITIALIZED, "Qwen3-TTS model not finalized");
+    q3dec_stream_begin(c->dec, batch, max_frames, max_chunk_frames, !c->stream_exact, c->s);
+    HIP_CHECK(hipStreamSynchronize(c->s));
+    MIS_API_END
+}
+// codes int32 [batch, num_quantizers, n_frames] (host or device): the NEXT n_frames frames of every row of the session ->
+// wav_out f32 [batch, n_frames * samples_per_frame] (host or device)
+extern "C" mis_status mis_qwen3tts_decode_stream_step(mis_qwen3tts* c, const int32_t* codes, int n_frames, float* wav_out) {
+    MIS_API_BEGIN
+    MIS_REQUIRE(c && codes && wav_out && n_frames >= 1, MIS_ERR_INVALID_INPUT, "bad argument");
+    q3dec_stream_step_host(c->dec, codes, n_frames, wav_out, c->s);
+    MIS_API_END
+}
+extern "C" mis_status mis_qwen3tts_decode_stream_end(mis_qwen3tts* c) {
+    MIS_API_BEGIN
+    MIS_REQUIRE(c, MIS_ERR_INVALID_INPUT, "null handle");
+    q3dec_stream_end(c->dec);
+    MIS_API_END
+}
+
+// generateVoiceDesign for a batch of prepared prompts (Qwen3TTS.swift:306-569).
+// on_event == NULL or chunk_frames <= 0: codes first, then ONE whole-sequence decode of the batch (rows right-padded to the
+// longest: every layer is causal, so a row's samples do not depend on what follows them).
+// on_event != NULL and chunk_frames > 0 (generateStream, streamingInterval * 12.5 frames, :394-395): whenever another chunk_frames
+// frames exist, a streamingStep of the whole batch runs on a second stream WHILE the frame loop continues, and each row's new samples
+// are delivered as MIS_EVENT_AUDIO as soon as they are on the host (:492-505); the frames after the last full chunk follow when the
+// loop ends (:537-546).  A row's pcm is the concatenation of its chunks.
 extern "C" mis_status mis_qwen3tts_generate(mis_qwen3tts* c, const int32_t* text_ids, const int32_t* codec_ids, const int32_t* prefill_lens,
                                             int P, const int32_t* trailing_ids, const int32_t* trailing_lens, int Tt, int batch,
                                             const mis_qwen3tts_params* params, const int32_t* row_max_frames, float** pcm_out,
@@ -571,47 +675,147 @@ extern "C" mis_status mis_qwen3tts_generate(mis_qwen3tts* c, const int32_t* text
                 MIS_ERR_INVALID_INPUT, "null argument");
     std::vector<int32_t> codes, nf;
     int stride = 0;
-    q3_generate_codes(c, text_ids, codec_ids, prefill_lens, P, trailing_ids, trailing_lens, Tt, batch, params, row_max_frames, codes, nf,
-                      &stride, cancel_flag);
     const int G = c->G, up = q3dec_total_upsample(c->dec);
+    const bool streaming = on_event && chunk_frames > 0;
+    MIS_REQUIRE(G == c->cfg.dec_num_quantizers, MIS_ERR_INVALID_INPUT, "num_code_groups (%d) != decoder quantizers (%d)", G, c->cfg.dec_num_quantizers);
+
+    struct Chunk { int f0, fn; PinnedBuf<float> wav; PinnedBuf<int32_t> nf; hipEvent_t done = nullptr; bool emitted = false; };
+    std::deque<std::unique_ptr<Chunk>> chunks;
+    DevBuf<float> wav_dev;
+    hipEvent_t ev_lm = nullptr;
+    auto cleanup = [&]() {
+        if (ev_lm) { (void)hipEventDestroy(ev_lm); ev_lm = nullptr; }
+        for (auto& ch : chunks) if (ch->done) { (void)hipEventDestroy(ch->done); ch->done = nullptr; }
+        q3dec_stream_end(c->dec);
+    };
+    auto emit_ready = [&](bool wait) {
+        for (auto& ch : chunks) {
+            if (ch->emitted) continue;
+            if (wait) HIP_CHECK(hipEventSynchronize(ch->done));
+            else if (hipEventQuery(ch->done) != hipSuccess) { (void)hipGetLastError(); break; }     // chunks finish in order
+            for (int b = 0; b < batch; ++b) {
+                const int valid = std::min(std::max(ch->nf.p[b] - ch->f0, 0), ch->fn);
+                if (valid > 0) on_event(user, b, MIS_EVENT_AUDIO, ch->wav.p + (size_t)b * ch->fn * up, (int64_t)valid * up);
+            }
+            ch->emitted = true;
+        }
+    };
+    Q3StreamHook hook;
+    // MIS_EVENT_TOKEN: code 0 of every frame as the host learns of it (onToken, :484), the EOS id included when a row ends on it
+    PinnedBuf<int32_t> tok_codes, tok_nf;
+    std::vector<char> eos_sent(batch, 0);
+    int tok_f = 0, tok_pending_f = 0;
+    const auto t_start = std::chrono::steady_clock::now();
+    try {
+        if (streaming) {
+            HIP_CHECK(hipSetDevice(c->device));
+            const int cap = params->max_frames;
+            MIS_REQUIRE(cap >= 1, MIS_ERR_INVALID_INPUT, "max_frames must be positive");
+            q3dec_stream_begin(c->dec, batch, cap, std::min(chunk_frames, cap), !c->stream_exact, c->s_dec);
+            wav_dev.alloc((size_t)batch * std::min(chunk_frames, cap) * up);
+            HIP_CHECK(hipEventCreateWithFlags(&ev_lm, hipEventDisableTiming));
+            hook.chunk_frames = chunk_frames;
+            hook.on_boundary = [&](int f0, int fn) {
+                auto ch = std::make_unique<Chunk>();
+                ch->f0 = f0; ch->fn = fn;
+                ch->wav.alloc((size_t)batch * fn * up);
+                ch->nf.alloc(batch);
+                HIP_CHECK(hipEventCreateWithFlags(&ch->done, hipEventDisableTiming));
+                HIP_CHECK(hipEventRecord(ev_lm, c->s));                  // frames < f0 + fn are final once this fires
+                HIP_CHECK(hipStreamWaitEvent(c->s_dec, ev_lm, 0));
+                // the loop's code store is [B][max_frames][G]: no transposition, the quantizer kernel takes the strides
+                q3dec_stream_step(c->dec, c->codes.p + (size_t)f0 * G, (int64_t)params->max_frames * G, 1, G, fn, wav_dev.p, (int64_t)fn * up,
+                                  c->s_dec);
+                HIP_CHECK(hipMemcpyAsync(ch->wav.p, wav_dev.p, (size_t)batch * fn * up * 4, hipMemcpyDeviceToHost, c->s_dec));
+                // rows that ended inside / before this chunk keep their count; running rows have >= f0 + fn (clipped at emission)
+                HIP_CHECK(hipMemcpyAsync(ch->nf.p, c->n_frames.p, (size_t)batch * 4, hipMemcpyDeviceToHost, c->s_dec));
+                HIP_CHECK(hipEventRecord(ch->done, c->s_dec));
+                chunks.push_back(std::move(ch));
+            };
+            tok_codes.alloc((size_t)batch * 8 * G);
+            tok_nf.alloc(batch);
+            hook.pre_sync = [&](int f) {
+                MIS_REQUIRE(f - tok_f <= 8, MIS_ERR_GENERATION_FAILED, "token window");
+                if (f > tok_f)
+                    HIP_CHECK(hipMemcpy2DAsync(tok_codes.p, (size_t)8 * G * 4, c->codes.p + (size_t)tok_f * G, (size_t)params->max_frames * G * 4,
+                                               (size_t)(f - tok_f) * G * 4, batch, hipMemcpyDeviceToHost, c->s));
+                HIP_CHECK(hipMemcpyAsync(tok_nf.p, c->n_frames.p, (size_t)batch * 4, hipMemcpyDeviceToHost, c->s));
+                tok_pending_f = f;
+            };
+            hook.poll = [&](int f) {
+                for (int b = 0; b < batch; ++b) {
+                    const int cap = row_max_frames ? std::max(1, std::min(row_max_frames[b], params->max_frames)) : params->max_frames;
+                    for (int i = tok_f; i < std::min(tok_nf.p[b], tok_pending_f); ++i)
+                        on_event(user, b, MIS_EVENT_TOKEN, &tok_codes.p[((size_t)b * 8 + (i - tok_f)) * G], 1);
+                    if (!eos_sent[b] && tok_nf.p[b] < std::min(tok_pending_f, cap)) {
+                        const int32_t eos = c->cfg.codec_eos_token_id;
+                        on_event(user, b, MIS_EVENT_TOKEN, &eos, 1);
+                        eos_sent[b] = 1;
+                    }
+                }
+                tok_f = tok_pending_f;
+                (void)f;
+                emit_ready(false);
+            };
+            hook.loop_done = [&]() {                                   // AudioGenerationInfo (:524-534): one per row
+                const double secs = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count();
+                size_t free_b = 0, total_b = 0;
+                (void)hipMemGetInfo(&free_b, &total_b);
+                for (int b = 0; b < batch; ++b) {
+                    mis_gen_info info{};
+                    info.generation_token_count = tok_nf.p[b];
+                    info.generate_time = secs;
+                    info.tokens_per_second = secs > 0 ? tok_nf.p[b] / secs : 0;
+                    info.peak_memory_gb = (double)(total_b - free_b) / 1e9;
+                    on_event(user, b, MIS_EVENT_INFO, &info, 1);
+                }
+            };
+        }
+        q3_generate_codes(c, text_ids, codec_ids, prefill_lens, P, trailing_ids, trailing_lens, Tt, batch, params, row_max_frames, codes, nf,
+                          &stride, cancel_flag, streaming ? &hook : nullptr);
+        if (streaming) emit_ready(true);
+    } catch (...) {
+        (void)hipStreamSynchronize(c->s_dec);
+        cleanup();
+        throw;
+    }
     int64_t longest = 0;
     for (int b = 0; b < batch; ++b) { pcm_lens[b] = (int64_t)nf[b] * up; longest = std::max(longest, pcm_lens[b]); }
     PinnedBuf<float> host_pin((size_t)std::max<int64_t>(longest, 1) * batch);
     float* host = host_pin.p;
     memset(host, 0, (size_t)std::max<int64_t>(longest, 1) * batch * 4);
-    {
-        DevBuf<float> wav;
-        DevBuf<int32_t> cd;
-        // rows with the same frame count decode together (bounded by ~16 GB of activations); ragged rows one by one
-        std::vector<char> done_row(batch, 0);
-        for (int b0 = 0; b0 < batch; ++b0) {
-            const int n = nf[b0];
-            if (done_row[b0] || n == 0) continue;                       // generatedCodes.isEmpty -> zeros([1]) (:520-522): length 0 here
-            const size_t per_row = (size_t)4 * 4 * 96 * (size_t)n * up;            // 4 buffers x f32 x widest stage (approx.)
-            const int cap = (int)std::max<size_t>(1, std::min<size_t>(64, ((size_t)16 << 30) / std::max<size_t>(per_row, 1)));
-            std::vector<int> grp;
-            for (int b = b0; b < batch && (int)grp.size() < cap; ++b) if (!done_row[b] && nf[b] == n) { grp.push_back(b); done_row[b] = 1; }
-            const int gb = (int)grp.size();
-            std::vector<int32_t> rows((size_t)gb * G * n);              // [frames][G] -> [G][frames] per row
-            for (int r = 0; r < gb; ++r)
-                for (int f = 0; f < n; ++f) for (int g = 0; g < G; ++g)
-                    rows[((size_t)r * G + g) * n + f] = codes[((size_t)grp[r] * stride + f) * G + g];
-            cd.alloc(rows.size()); wav.alloc((size_t)gb * n * up);
-            HIP_CHECK(hipMemcpyAsync(cd.p, rows.data(), rows.size() * 4, hipMemcpyHostToDevice, c->s));
-            q3dec_decode_device(c->dec, cd.p, gb, n, wav.p, (int64_t)n * up, c->s);
-            for (int r = 0; r < gb; ++r)
-                HIP_CHECK(hipMemcpyAsync(host + (size_t)grp[r] * longest, wav.p + (size_t)r * n * up, (size_t)n * up * 4, hipMemcpyDeviceToHost, c->s));
-            HIP_CHECK(hipStreamSynchronize(c->s));
-            if (cancel_flag && *cancel_flag) throw MisError(MIS_ERR_CANCELLED, "generation cancelled");
-        }
-        if (on_event)
+    if (streaming) {
+        for (auto& ch : chunks)
             for (int b = 0; b < batch; ++b) {
-                const int n = nf[b], step = chunk_frames > 0 ? chunk_frames : std::max(n, 1);
-                for (int f0 = 0; f0 < n; f0 += step) {
-                    const int fn = std::min(step, n - f0);
-                    on_event(user, b, MIS_EVENT_AUDIO, host + (size_t)b * longest + (size_t)f0 * up, (int64_t)fn * up);
-                }
+                const int valid = std::min(std::max(nf[b] - ch->f0, 0), ch->fn);
+                if (valid > 0) memcpy(host + (size_t)b * longest + (size_t)ch->f0 * up, ch->wav.p + (size_t)b * ch->fn * up, (size_t)valid * up * 4);
             }
+        cleanup();
+        chunks.clear();
+    } else {
+        DevBuf<float> wav;
+        // consecutive rows decode together, right-padded to the slice's longest row (bounded by ~16 GB of activations)
+        int b0 = 0;
+        while (b0 < batch) {
+            int n = nf[b0], b1 = b0 + 1;
+            auto fits = [&](int rows, int frames) { return (size_t)4 * 4 * 96 * (size_t)frames * up * rows <= ((size_t)16 << 30); };
+            while (b1 < batch && b1 - b0 < 64 && fits(b1 - b0 + 1, std::max(n, nf[b1]))) { n = std::max(n, nf[b1]); ++b1; }
+            const int gb = b1 - b0;
+            if (n > 0) {                                                // generatedCodes.isEmpty -> zeros([1]) (:520-522): length 0 here
+                wav.alloc((size_t)gb * n * up);
+                q3dec_decode_strided(c->dec, c->codes.p + (size_t)b0 * stride * G, (int64_t)stride * G, 1, G, gb, n, wav.p, (int64_t)n * up, c->s);
+                for (int r = 0; r < gb; ++r)
+                    if (nf[b0 + r] > 0)
+                        HIP_CHECK(hipMemcpyAsync(host + (size_t)(b0 + r) * longest, wav.p + (size_t)r * n * up, (size_t)nf[b0 + r] * up * 4,
+                                                 hipMemcpyDeviceToHost, c->s));
+                HIP_CHECK(hipStreamSynchronize(c->s));
+            }
+            if (cancel_flag && *cancel_flag) throw MisError(MIS_ERR_CANCELLED, "generation cancelled");
+            b0 = b1;
+        }
+        if (on_event)                                                   // no chunking requested: one AUDIO event per row
+            for (int b = 0; b < batch; ++b)
+                if (nf[b] > 0) on_event(user, b, MIS_EVENT_AUDIO, host + (size_t)b * longest, (int64_t)nf[b] * up);
     }
     if (codes_out) {
         PinnedBuf<int32_t> ch(codes.size() + 1);

@@ -123,7 +123,7 @@ __global__ void __launch_bounds__(256) k_snac_gemm(GemmParams p) {
     else b = blockIdx.z;
     const int Kx = (MODE == GEMM_CONVT || MODE == GEMM_TAPS) ? p.Cin : p.K;
     const float* AT = p.AT + (size_t)phase * p.K * p.M;
-    const float* Xb = p.X + (size_t)b * Kx * p.Tin;
+    const float* Xb = p.X + (size_t)b * Kx * p.ldx;
     // transposed conv phase: out o = s*n + phase takes taps j=0,1 from x[:, n + q - j]
     const int q = (MODE == GEMM_CONVT) ? (phase + p.pad) / p.s : 0;
 
@@ -157,15 +157,15 @@ __global__ void __launch_bounds__(256) k_snac_gemm(GemmParams p) {
             if (MODE == GEMM_TAPS) { int j = k / p.Cin; row = k - j * p.Cin; shift = (j - (p.taps - 1)) * p.dil; }
             int n = n0 + xc + shift;
             bool kin = k < p.K;
-            const float* src = Xb + (size_t)row * p.Tin;
-            if (MODE != GEMM_CONVT && MODE != GEMM_TAPS && kin && (p.Tin & 3) == 0 && n + 3 < p.Tin) {
+            const float* src = Xb + (size_t)row * p.ldx;
+            if (MODE != GEMM_CONVT && MODE != GEMM_TAPS && kin && (p.ldx & 3) == 0 && n + 3 < p.Tin) {
                 float4 v = *reinterpret_cast<const float4*>(src + n);
                 rx[h][0] = v.x; rx[h][1] = v.y; rx[h][2] = v.z; rx[h][3] = v.w;
             } else {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     int nn = n + e;
-                    rx[h][e] = (kin && nn >= 0 && nn < p.Tin) ? src[nn] : 0.0f;
+                    rx[h][e] = (kin && nn >= p.x_lo && nn < p.Tin) ? src[nn] : 0.0f;
                 }
             }
             if (SNAKE && kin) {
@@ -227,19 +227,20 @@ __global__ void __launch_bounds__(256) k_snac_gemm(GemmParams p) {
             float v = acc[t][r];
             if (p.bias) v += p.bias[m];
             if (MODE == GEMM_PLAIN || MODE == GEMM_TAPS) {
-                p.Y[((size_t)b * p.M + m) * p.Tout + n] = v;
+                p.Y[((size_t)b * p.M + m) * p.ldy + n] = v;
             } else if (MODE == GEMM_GELU) {                            // exact-erf GELU (VocosBackbone.swift:89)
-                p.Y[((size_t)b * p.M + m) * p.Tout + n] = 0.5f * v * (1.0f + erff(v * 0.70710678118654752f));
+                p.Y[((size_t)b * p.M + m) * p.ldy + n] = 0.5f * v * (1.0f + erff(v * 0.70710678118654752f));
             } else if (MODE == GEMM_RESID) {
-                size_t o = ((size_t)b * p.M + m) * p.Tout + n;
+                size_t o = ((size_t)b * p.M + m) * p.ldy + n;
                 if (p.scale) v *= p.scale[m];                          // ConvNeXt layer scale gamma (VocosBackbone.swift:92-95)
                 p.Y[o] = p.R[o] + v;                                   // Layers.swift:230
             } else if (MODE == GEMM_NOISE) {
-                size_t o = ((size_t)b * p.M + m) * p.Tout + n;
-                p.Y[o] = Xb[(size_t)m * p.Tin + n] + nzv[t] * v;       // Layers.swift:276-277
+                size_t o = ((size_t)b * p.M + m) * p.ldy + n;
+                p.Y[o] = Xb[(size_t)m * p.ldx + n] + nzv[t] * v;       // Layers.swift:276-277
             } else {
                 int o = p.s * n + phase;
-                if (o < p.Tout) p.Y[((size_t)b * p.M + m) * p.Tout + o] = v;
+                if (n == 0 && p.dup_bias_n0 && p.bias) v += p.bias[m];   // streaming overlap-add counts the bias twice (GemmParams)
+                if (o < p.Tout) p.Y[((size_t)b * p.M + m) * p.ldy + o] = v;
             }
         }
     }
@@ -338,13 +339,13 @@ __global__ void __launch_bounds__(256) k_conv_taps(GemmParams p) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
     const int n0 = blockIdx.x * G_BN, m0 = blockIdx.y * G_BM, b = blockIdx.z;
-    const float* Xb = p.X + (size_t)b * p.Cin * p.Tin;
+    const float* Xb = p.X + (size_t)b * p.Cin * p.ldx;
     const int halo = (p.taps - 1) * p.dil;
     const int c_lo = n0 - p.pad;                       // first needed input column (may be negative)
     const int a0 = (c_lo >= 0 ? c_lo : c_lo - 3) / 4 * 4;     // aligned-down staging origin
     const int off = c_lo - a0;                         // 0..3
     const int ncols = off + G_BN + halo;               // staged columns
-    const bool vec = (p.Tin & 3) == 0;
+    const bool vec = (p.ldx & 3) == 0;
     f32x16_t acc[2];
 #pragma unroll
     for (int t = 0; t < 2; ++t)
@@ -372,12 +373,12 @@ __global__ void __launch_bounds__(256) k_conv_taps(GemmParams p) {
             const int row = idx / (CT_XS / 4), c4 = (idx - row * (CT_XS / 4)) * 4;
             float v[4] = {0.f, 0.f, 0.f, 0.f};
             if (row < G_BK && c0 + row < p.Cin && c4 < ncols) {
-                const float* src = Xb + (size_t)(c0 + row) * p.Tin;
+                const float* src = Xb + (size_t)(c0 + row) * p.ldx;
                 const int g = a0 + c4;
-                if (vec && g >= 0 && g + 3 < p.Tin) { float4 t = *reinterpret_cast<const float4*>(src + g); v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w; }
+                if (vec && g >= p.x_lo && g + 3 < p.Tin) { float4 t = *reinterpret_cast<const float4*>(src + g); v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w; }
                 else {
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] = (g + e >= 0 && g + e < p.Tin) ? src[g + e] : 0.0f;
+                    for (int e = 0; e < 4; ++e) v[e] = (g + e >= p.x_lo && g + e < p.Tin) ? src[g + e] : 0.0f;
                 }
                 if (p.alpha) {
                     const float al = p.alpha[c0 + row], ra_ = p.ralpha[c0 + row];
@@ -428,7 +429,7 @@ __global__ void __launch_bounds__(256) k_conv_taps(GemmParams p) {
             if (m >= p.M) continue;
             float v = acc[t][r];
             if (p.bias) v += p.bias[m];
-            size_t o = ((size_t)b * p.M + m) * p.Tout + n;
+            size_t o = ((size_t)b * p.M + m) * p.ldy + n;
             if (RESID) { if (p.scale) v *= p.scale[m]; v += p.R[o]; }
             p.Y[o] = v;
         }
@@ -914,7 +915,11 @@ void launch_dw7(const float* X, float* Y, const float* w7, const float* bias, in
                        nullptr, nullptr, nullptr, C, T, dil);
 }
 
-void launch_gemm(int mode, bool snake, const GemmParams& p, int batch, hipStream_t s) {
+void launch_gemm(int mode, bool snake, const GemmParams& p_in, int batch, hipStream_t s) {
+    GemmParams p = p_in;
+    if (!p.ldx) p.ldx = p.Tin;                                          // dense [B][C][T] tensors unless the caller says otherwise
+    if (!p.ldy) p.ldy = p.Tout;
+    MIS_REQUIRE(p.x_lo <= 0 && p.ldx >= p.Tin, MIS_ERR_GENERATION_FAILED, "bad codec GEMM strides");
     int phases = (mode == GEMM_CONVT) ? p.s : 1;
     dim3 grid(cdiv(p.N, G_BN), cdiv(p.M, G_BM), batch * phases), block(256);
     if (mode == GEMM_PLAIN) hipLaunchKernelGGL((k_snac_gemm<GEMM_PLAIN, false>), grid, block, 0, s, p);

@@ -12,7 +12,8 @@ import numpy as np
 
 from . import _lib
 from .codecs import _tensor_args
-from .generation import AudioEvent, AudioGenerationError, InfoEvent, TokenEvent, check  # noqa: F401
+from .generation import (AudioEvent, AudioGenerationError, InfoEvent, TokenEvent, check, decode_audio_event,  # noqa: F401
+                         stream_events)
 from .tts import LlamaTTSConfiguration
 
 
@@ -130,6 +131,16 @@ class Qwen3TTSModel:
         keep, ptr, dt, shape = _tensor_args(arr)
         sh = (C.c_int64 * len(shape))(*shape)
         check(_lib.lib().mis_qwen3tts_set_tensor(self._h, name.encode(), ptr, dt, sh, len(shape)))
+
+    def set_quantized_tensor(self, name: str, wq, scales, biases, group_size: int = 64, bits: int = 8):
+        """A tensor of a quantised checkpoint: wq uint32 [N, K*bits/32], scales / biases [N, K/group_size]."""
+        wq = np.ascontiguousarray(wq, dtype=np.uint32)
+        ks, ps, ds, ss = _tensor_args(scales)
+        kb, pb, db, sb = _tensor_args(biases)
+        if ds != db or tuple(ss) != tuple(sb):
+            raise AudioGenerationError(3, "scales and biases must share dtype and shape")
+        N, K = int(ss[0]), int(ss[1]) * group_size
+        check(_lib.lib().mis_qwen3tts_set_tensor_quantized(self._h, name.encode(), wq.ctypes.data, ps, pb, ds, N, K, group_size, bits))
 
     def finalize(self):
         check(_lib.lib().mis_qwen3tts_finalize(self._h))
@@ -272,14 +283,55 @@ class Qwen3TTSModel:
         out = self.generate_batch([p], generation_parameters)[0]
         return out if len(out) else np.zeros(1, np.float32)              # generatedCodes.isEmpty -> zeros([1]) (:520-522)
 
+    # -- streamingStep / resetStreamingState (Qwen3TTSSpeechTokenizer.swift:948-1006) --------------------------------------
+    def set_stream_exact(self, exact: bool):
+        """False (default): the reference's streaming arithmetic (bias counted twice after chunk boundaries, :556-559);
+        True: chunked decode bitwise equal to decode_codes of the whole sequence."""
+        check(_lib.lib().mis_qwen3tts_set_stream_exact(self._h, 1 if exact else 0))
+
+    def reset_streaming_state(self, batch: int = 1, max_frames: int = 4096, max_chunk_frames: int = 64):
+        check(_lib.lib().mis_qwen3tts_decode_stream_begin(self._h, batch, max_frames, max_chunk_frames))
+        self._stream_batch = batch
+
+    def streaming_step(self, codes) -> np.ndarray:
+        """codes [B, num_quantizers, Tn] = only the new frames -> [B, Tn * samples_per_frame]; state stays on the device."""
+        cd = np.ascontiguousarray(codes, dtype=np.int32)
+        B, nq, T = cd.shape
+        if B != getattr(self, "_stream_batch", None):
+            raise AudioGenerationError(3, "streaming_step: batch differs from reset_streaming_state")
+        out = np.zeros((B, T * self.samples_per_frame), np.float32)
+        check(_lib.lib().mis_qwen3tts_decode_stream_step(self._h, cd.ctypes.data, T, out.ctypes.data))
+        return out
+
+    def end_streaming(self):
+        check(_lib.lib().mis_qwen3tts_decode_stream_end(self._h))
+
+    def generate_stream_batch(self, prompts, generation_parameters: Qwen3TTSGenerateParameters | None = None,
+                              streaming_interval: float = 2.0, cancel_flag=None):
+        """mis_qwen3tts_generate in streaming mode for a batch of prepared prompts: TokenEvent (code 0 of each frame) and
+        AudioEvent chunks of streaming_interval * 12.5 frames WHILE the engine generates, InfoEvent per row when the frame loop
+        ends, then the frames after the last full chunk."""
+        gp = generation_parameters or self.default_generation_parameters
+        t, c, pl, P, tr, tl, Tt = self._marshal(prompts)
+        B = len(prompts)
+        caps = self._row_caps(prompts, gp)
+        gpc = gp.to_c()
+        gpc.max_frames = int(caps.max())
+        chunk = max(1, int(streaming_interval * 12.5))                  # streamingChunkSize (:394-395)
+        pcm = C.c_void_p(); stride = C.c_int64(); plens = (C.c_int64 * B)()
+
+        def start(cbf, flag_addr):
+            st = _lib.lib().mis_qwen3tts_generate(self._h, t.ctypes.data, c.ctypes.data, pl.ctypes.data, P, tr.ctypes.data, tl.ctypes.data,
+                                                  Tt, B, C.byref(gpc), caps.ctypes.data, C.byref(pcm), C.byref(stride), plens,
+                                                  None, None, None, chunk, cbf, None, flag_addr)
+            if pcm.value:
+                _lib.lib().mis_free(pcm)
+            return st
+        yield from stream_events(start, decode_audio_event, cancel_flag)
+
     def generate_stream(self, text: str, voice: str | None = None, language: str | None = None,
                         generation_parameters: Qwen3TTSGenerateParameters | None = None, streaming_interval: float = 2.0):
-        """generateStream (:84-133): yields TokenEvent (code 0 of each frame), then AudioEvent chunks."""
+        """generateStream (:84-133): .token per frame and .audio chunks while generating, .info when the loop ends, then the
+        remaining samples."""
         p = self.prepare_generation_inputs(text, language or "auto", voice)
-        chunks = []
-        pcm, codes = self.generate_batch([p], generation_parameters, return_codes=True, streaming_interval=streaming_interval,
-                                         on_audio=lambda row, a: chunks.append(a))
-        for f in codes[0]:
-            yield TokenEvent(0, int(f[0]))
-        for a in chunks:
-            yield AudioEvent(0, a)
+        yield from self.generate_stream_batch([p], generation_parameters, streaming_interval)

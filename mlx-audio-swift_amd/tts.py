@@ -146,12 +146,21 @@ class LlamaTTSModel:
         return m
 
     @classmethod
-    def synthetic(cls, config, codec: SNAC | None = None, device: int = 0, seed: int = 4321) -> "LlamaTTSModel":
-        """Random weights generated on the device (mis-synth-v1); there are no checkpoints offline."""
+    def synthetic(cls, config, codec: SNAC | None = None, device: int = 0, seed: int = 4321, quant_bits: int | None = None) -> "LlamaTTSModel":
+        """Random weights generated on the device (mis-synth-v1); there are no checkpoints offline.  quant_bits 8 / 4: every
+        Linear as a synthetic MLX affine-quantised matrix (group 64), streamed in that form."""
         m = cls(config, codec, device)
-        check(_lib.lib().mis_tts_init_synthetic(m._h, seed))
+        if quant_bits:
+            check(_lib.lib().mis_tts_init_synthetic_quantized(m._h, seed, int(quant_bits)))
+        else:
+            check(_lib.lib().mis_tts_init_synthetic(m._h, seed))
         m.finalize()
         return m
+
+    @property
+    def native_quant_bits(self) -> dict:
+        """Per role, the bit width of the quantised form it is streamed in (0 = dense bf16)."""
+        return {r: int(_lib.lib().mis_tts_native_quant_bits(self._h, i)) for i, r in enumerate(("qkv", "o", "gate_up", "down", "lm_head"))}
 
     def set_tensor(self, name: str, arr):
         keep, ptr, dt, shape = _tensor_args(arr)

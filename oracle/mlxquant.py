@@ -42,3 +42,27 @@ def dequantize(wq: np.ndarray, scales: np.ndarray, biases: np.ndarray, group_siz
     s = np.repeat(np.asarray(scales, np.float32), group_size, axis=1)
     b = np.repeat(np.asarray(biases, np.float32), group_size, axis=1)
     return (s * q + b).astype(np.float32)
+
+
+def quantized_matmul(x: np.ndarray, wq: np.ndarray, scales: np.ndarray, biases: np.ndarray, group_size: int = 64, bits: int = 4) -> np.ndarray:
+    """mlx quantized_matmul(x, w, scales, biases, transpose=True) [3P: mlx 0.31 qmm kernels], the arithmetic behind
+    QuantizedLinear (LlamaTTS.swift:958-968, Qwen3TTS.swift:1157-1170): the weight is never materialised; per group
+        y[m, n] += scale[n, g] * sum_k x[m, k] q[n, k]  +  bias[n, g] * sum_k x[m, k],
+    everything in float32 (x, scales, biases converted to float32 first; the caller rounds y to x's dtype).
+    x [M, K] float32 (holding bf16 values), returns float32 [M, N]."""
+    x = np.asarray(x, np.float32)
+    wq = np.asarray(wq, np.uint32)
+    N = wq.shape[0]
+    epw = 32 // bits
+    K = wq.shape[1] * epw
+    q = np.zeros((N, K), np.float32)
+    for j in range(epw):
+        q[:, j::epw] = ((wq >> np.uint32(bits * j)) & np.uint32(2 ** bits - 1)).astype(np.float32)
+    G = K // group_size
+    s = np.asarray(scales, np.float32).reshape(N, G)
+    b = np.asarray(biases, np.float32).reshape(N, G)
+    xg = x.reshape(x.shape[0], G, group_size)
+    qg = q.reshape(N, G, group_size)
+    dots = np.einsum("mgk,ngk->mng", xg, qg).astype(np.float32)           # exact products (8-bit codes x bf16), f32 sums
+    sums = xg.sum(-1, dtype=np.float32)                                    # [M, G]
+    return (dots * s[None] + sums[:, None, :] * b[None]).sum(-1, dtype=np.float32)

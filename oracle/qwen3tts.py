@@ -396,6 +396,115 @@ class SpeechDecoderOracle:
             return torch.clamp(h, -1.0, 1.0)[:, 0].numpy()
 
 
+    # -------------------------------------------------------------------------------------------- streaming (carried state)
+    def reset_streaming_state(self):
+        """resetStreamingState (Qwen3TTSSpeechTokenizer.swift:948-968)."""
+        self._sb = {}            # CausalConv1d.streamBuffer / DecoderInitialConv / DecoderOutputConv buffers, by layer name
+        self._ov = {}            # DecoderBlockUpsample.overflow, by layer name
+        self._kv = None          # transformerCache: per layer (k [B,Hkv,T,D] rotated, v)
+
+    def _conv_step(self, name, x, w, b, dilation=1, groups=1):
+        """CausalConv1d.step (:199-227) and the k7 conv steps (:655-667,:710-722): prepend the carried buffer (zeros on the first
+        chunk), keep the last `padding` columns, run the unpadded conv."""
+        k = w.shape[1]
+        pad = (k - 1) * dilation
+        if pad > 0:
+            buf = self._sb.get(name)
+            x = torch.cat([buf, x], -1) if buf is not None else TF.pad(x, (pad, 0))
+            self._sb[name] = x[..., max(0, x.shape[-1] - pad):]
+        return TF.conv1d(x, w.permute(0, 2, 1).contiguous(), b, dilation=dilation, groups=groups)
+
+    def _upsample_step(self, name, x, w, b, stride):
+        """DecoderBlockUpsample.step (:553-576): full transposed conv, add the carried overflow to the head, split off the last
+        k - stride outputs as the next overflow.  Both summands carry the bias - the reference counts it twice there."""
+        k = w.shape[1]
+        h = TF.conv_transpose1d(x, w.permute(2, 0, 1).contiguous(), b, stride=stride)
+        ov = self._ov.get(name)
+        if ov is not None:
+            n = ov.shape[-1]
+            head = h[..., :n] + ov
+            h = torch.cat([head, h[..., n:]], -1) if n < h.shape[-1] else head
+        trim = k - stride
+        if trim > 0:
+            split = max(0, h.shape[-1] - trim)
+            self._ov[name] = h[..., split:]
+            h = h[..., :split]
+        else:
+            self._ov[name] = None
+        return h
+
+    def _transformer_step(self, x):
+        """DecoderTransformer with a KVCacheSimple per layer (:470-496): positions continue at the cache offset, the new queries
+        see every cached key plus the causal part of the chunk."""
+        cfg, w, P = self.cfg, self.w, "decoder.pre_transformer"
+        B, T, _ = x.shape
+        H, Hkv, D = cfg.num_attention_heads, cfg.num_key_value_heads, cfg.head_dim
+        if self._kv is None:
+            self._kv = [None] * cfg.num_hidden_layers
+        off = 0 if self._kv[0] is None else self._kv[0][0].shape[2]
+        x = x @ w[P + ".input_proj.weight"].t() + w[P + ".input_proj.bias"]
+        inv = 1.0 / (cfg.rope_theta ** (torch.arange(0, D, 2, dtype=torch.float32) / D))
+        ang = torch.arange(off, off + T, dtype=torch.float32)[:, None] * inv[None]
+        cos, sin = torch.cat([torch.cos(ang)] * 2, -1), torch.cat([torch.sin(ang)] * 2, -1)
+
+        def rot(t):
+            return torch.cat([-t[..., D // 2:], t[..., : D // 2]], -1)
+        mask = torch.full((T, off + T), float("-inf")).triu(off + 1)
+        for i in range(cfg.num_hidden_layers):
+            p = f"{P}.layers.{i}"
+            h = self.rmsnorm(x, w[p + ".input_layernorm.weight"])
+            q = (h @ w[p + ".self_attn.q_proj.weight"].t()).view(B, T, H, D).transpose(1, 2)
+            k = (h @ w[p + ".self_attn.k_proj.weight"].t()).view(B, T, Hkv, D).transpose(1, 2)
+            v = (h @ w[p + ".self_attn.v_proj.weight"].t()).view(B, T, Hkv, D).transpose(1, 2)
+            q, k = q * cos + rot(q) * sin, k * cos + rot(k) * sin
+            if self._kv[i] is not None:
+                k, v = torch.cat([self._kv[i][0], k], 2), torch.cat([self._kv[i][1], v], 2)
+            self._kv[i] = (k, v)
+            g = H // Hkv
+            kk, vv = k.repeat_interleave(g, 1), v.repeat_interleave(g, 1)
+            a = torch.softmax((q * D ** -0.5) @ kk.transpose(-1, -2) + mask, -1) @ vv
+            a = a.transpose(1, 2).reshape(B, T, H * D) @ w[p + ".self_attn.o_proj.weight"].t()
+            x = x + w[p + ".self_attn_layer_scale.scale"] * a
+            h = self.rmsnorm(x, w[p + ".post_attention_layernorm.weight"])
+            m = (TF.silu(h @ w[p + ".mlp.gate_proj.weight"].t()) * (h @ w[p + ".mlp.up_proj.weight"].t())) @ w[p + ".mlp.down_proj.weight"].t()
+            x = x + w[p + ".mlp_layer_scale.scale"] * m
+        x = self.rmsnorm(x, w[P + ".norm.weight"])
+        return x @ w[P + ".output_proj.weight"].t() + w[P + ".output_proj.bias"]
+
+    def streaming_step(self, codes):
+        """streamingStep (:971-1006): codes [B, nq, Tn] = only the NEW frames -> wav [B, Tn * total_upsample].  Call
+        reset_streaming_state() first."""
+        cfg, w = self.cfg, self.w
+        with torch.no_grad():
+            h = self.quantizer_decode(codes)
+            h = self._conv_step("pre_conv", h, w["decoder.pre_conv.conv.weight"], w["decoder.pre_conv.conv.bias"])
+            h = self._transformer_step(h.transpose(1, 2)).transpose(1, 2)
+            for i, f in enumerate(cfg.upsampling_ratios):
+                p = f"decoder.upsample.{i}.layers"
+                h = causal_conv_transpose1d(h, w[p + ".0.conv.weight"], w[p + ".0.conv.bias"], f)     # k == stride: stateless (:772-779)
+                q = p + ".1"
+                t = self._conv_step(q, h, w[q + ".dwconv.conv.weight"], w[q + ".dwconv.conv.bias"], groups=h.shape[1]).transpose(1, 2)
+                t = TF.layer_norm(t, (t.shape[-1],), w[q + ".norm.weight"], w[q + ".norm.bias"], 1e-6)
+                t = TF.gelu(t @ w[q + ".pwconv1.weight"].t() + w[q + ".pwconv1.bias"])
+                t = w[q + ".gamma"] * (t @ w[q + ".pwconv2.weight"].t() + w[q + ".pwconv2.bias"])
+                h = h + t.transpose(1, 2)
+            h = self._conv_step("dec0", h, w["decoder.decoder.0.conv.weight"], w["decoder.decoder.0.conv.bias"])
+            for bi, rate in enumerate(cfg.upsample_rates):
+                p = f"decoder.decoder.{bi + 1}.block"
+                h = snake_beta(h, w[p + ".0.alpha"], w[p + ".0.beta"])
+                h = self._upsample_step(p + ".1", h, w[p + ".1.conv.weight"], w[p + ".1.conv.bias"], rate)
+                for ri, dil in enumerate((1, 3, 9)):
+                    q = f"{p}.{ri + 2}"
+                    t = snake_beta(h, w[q + ".act1.alpha"], w[q + ".act1.beta"])
+                    t = self._conv_step(q + ".conv1", t, w[q + ".conv1.conv.weight"], w[q + ".conv1.conv.bias"], dilation=dil)
+                    t = snake_beta(t, w[q + ".act2.alpha"], w[q + ".act2.beta"])
+                    h = h + self._conv_step(q + ".conv2", t, w[q + ".conv2.conv.weight"], w[q + ".conv2.conv.bias"])
+            n = len(cfg.upsample_rates)
+            h = snake_beta(h, w[f"decoder.decoder.{n + 1}.alpha"], w[f"decoder.decoder.{n + 1}.beta"])
+            h = self._conv_step("out", h, w[f"decoder.decoder.{n + 2}.conv.weight"], w[f"decoder.decoder.{n + 2}.conv.bias"])
+            return torch.clamp(h, -1.0, 1.0)[:, 0].numpy()
+
+
 # ------------------------------------------------------------------------------------------------ synthetic weights
 def make_synthetic_weights(cfg: Qwen3TTSConfig, seed: int = 515) -> dict:
     """Talker-side weights, bf16 tensors, keys after sanitize.  LM stacks reuse oracle.llama's generator (mis-synth-v1)."""

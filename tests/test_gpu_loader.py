@@ -83,3 +83,68 @@ def test_plain_and_quantised_directories(tmp_path):
         (bad / "config.json").write_text(json.dumps(CFG.to_json_dict()))
         save_file({"model.norm.weight": W["model.norm.weight"].contiguous()}, str(bad / "model.safetensors"))
         mas.LlamaTTSModel.from_model_directory(str(bad))                 # update(verify: .all): missing parameters
+
+
+QCFG = ollama.LlamaConfig(hidden_size=1024, num_hidden_layers=2, intermediate_size=3072, num_attention_heads=16, num_key_value_heads=8,
+                          head_dim=128, vocab_size=3072, tie_word_embeddings=False, rope_scaling=None, rope_plain=True, qk_norm=True,
+                          rms_norm_eps=1e-6)
+
+
+@pytest.mark.parametrize("bits,batch", [(8, 32), (4, 32), (8, 40), (4, 5)], ids=["8bit-b32", "4bit-b32", "8bit-b40", "4bit-b5"])
+def test_native_quantised_streaming_matches_the_float32_dequant_oracle(bits, batch):
+    """QuantizedLinear / quantizedMatmul (LlamaTTS.swift:958-968, Qwen3TTS.swift:1157-1170): uniformly quantised checkpoints (group
+    64, bf16 scales) are streamed as codes and dequantised in registers (csrc/lm_qgemm.hip).  Oracle = the LM on the float32
+    weights s*q+b, NOT rounded to bf16 - what quantized_matmul computes (tests/test_oracle_mlxquant.py) - at Qwen3-TTS-0.6B talker
+    widths (1024 / 3072, 16/8 heads): K = 1024 -> 16 scale groups (split-K S, 4 waves per item), K = 3072 -> 48; batch 32 / 40 / 5
+    -> MT = 2 / 3 / 1 (both register-buffer depths).  Tolerance as test_gpu_lm.py: logits max <= 0.04 max|ref|, rms <= 0.008."""
+    from gpu_util import logits_errors, record
+    W = ollama.make_synthetic_weights(QCFG, seed=99)
+    m = mas.LlamaTTSModel(lm_host_config(QCFG))
+    W32, W16 = {}, {}
+    for k, v in W.items():
+        if v.ndim == 2:
+            wq, s, bia = mq.quantize(v.float().numpy(), 64, bits)
+            s16, b16 = torch.from_numpy(s).bfloat16(), torch.from_numpy(bia).bfloat16()
+            m.set_quantized_tensor(k, wq, s16, b16, 64, bits)
+            d32 = torch.from_numpy(mq.dequantize(wq, s16.float().numpy(), b16.float().numpy(), 64, bits))
+            W16[k] = d32.bfloat16()
+            W32[k] = W16[k] if k == "model.embed_tokens.weight" else d32       # QuantizedEmbedding yields model-dtype rows
+        else:
+            m.set_tensor(k, v); W32[k] = v; W16[k] = v
+    m.finalize()
+    assert m.native_quant_bits == {"qkv": bits, "o": bits, "gate_up": bits, "down": bits, "lm_head": bits}
+    rng = np.random.default_rng(7)
+    rows = [rng.integers(0, QCFG.vocab_size, 3 + (b % 4)).astype(np.int32) for b in range(batch)]
+    pairs = teacher_forced(ollama.LlamaOracle(QCFG, W32, round="bf16"), m, rows)
+    ref16 = teacher_forced(ollama.LlamaOracle(QCFG, W16, round="bf16"), m, rows[:4])
+    worst = (0.0, 0.0)
+    for dev_l, ref_l in pairs:
+        e_max, e_rms, n_sure, agree = logits_errors(dev_l, ref_l)
+        worst = (max(worst[0], e_max), max(worst[1], e_rms))
+        assert e_max <= 0.04 and e_rms <= 0.008 and agree, (e_max, e_rms)
+    # how far the dequantise-at-load arithmetic (bf16-rounded weights) sits from the same device logits, for the record
+    r16 = max(logits_errors(d, r)[1] for d, r in ref16)
+    record(f"native_quant_{bits}bit_b{batch}", logits_max_rel=worst[0], logits_rms_rel=worst[1], rms_vs_bf16_rounded_weights=r16,
+           tol_max=0.04, tol_rms=0.008)
+
+
+def test_quantised_role_with_a_per_layer_override_falls_back_to_the_dense_copy():
+    """One matrix of a role quantised differently (config.json per-layer override) -> that role is dequantised at load, the others
+    stream natively; results stay within tolerance of the oracle either way."""
+    W = ollama.make_synthetic_weights(CFG, seed=78)
+    m = mas.LlamaTTSModel(lm_host_config(CFG))
+    Wd = {}
+    for k, v in W.items():
+        if v.ndim == 2:
+            g, b = (32, 8) if k == "model.layers.1.mlp.down_proj.weight" else (64, 4)
+            wq, s, bia = mq.quantize(v.float().numpy(), g, b)
+            s16, b16 = torch.from_numpy(s).bfloat16(), torch.from_numpy(bia).bfloat16()
+            m.set_quantized_tensor(k, wq, s16, b16, g, b)
+            Wd[k] = torch.from_numpy(mq.dequantize(wq, s16.float().numpy(), b16.float().numpy(), g, b)).bfloat16()
+        else:
+            m.set_tensor(k, v); Wd[k] = v
+    m.finalize()
+    assert m.native_quant_bits == {"qkv": 4, "o": 4, "gate_up": 4, "down": 0, "lm_head": 4}
+    rng = np.random.default_rng(1)
+    rows = [rng.integers(0, CFG.vocab_size, n).astype(np.int32) for n in (9, 5)]
+    _check(teacher_forced(ollama.LlamaOracle(CFG, Wd, round="bf16"), m, rows))

@@ -23,11 +23,33 @@ def _host_cfg(o: oq.Qwen3TTSConfig) -> mas.Qwen3TTSConfiguration:
         tts_pad_token_id=o.tts_pad_token_id, tts_bos_token_id=o.tts_bos_token_id, tts_eos_token_id=o.tts_eos_token_id, decoder=dec)
 
 
-def _pair(ocfg=oq.TINY, eos=None):
+def _pair(ocfg=oq.TINY, eos=None, quant_bits=None):
     if eos is not None:
         ocfg = oq.Qwen3TTSConfig(**{**ocfg.__dict__, "codec_eos_token_id": eos})
     W = oq.make_synthetic_weights(ocfg)
     Wd = oq.make_synthetic_decoder_weights(ocfg.decoder)
+    if quant_bits:
+        # a quantised checkpoint (Qwen3TTS.swift:1157-1170): every 2-D talker tensor as uint32 words + bf16 scales / biases.  Oracle
+        # weights: the float32 s*q+b for the Linear layers of the two LMs (quantizedMatmul never rounds the weight), model-dtype
+        # rows for everything gathered or folded (QuantizedEmbedding, text projection, predictor tables / heads)
+        from oracle import mlxquant as mq
+        dev = mas.Qwen3TTSModel(_host_cfg(ocfg))
+        Wo = {}
+        for k, v in W.items():
+            v = torch.as_tensor(v)
+            if v.ndim == 2 and v.shape[1] % 64 == 0:
+                wq, s, bia = mq.quantize(v.float().numpy(), 64, quant_bits)
+                s16, b16 = torch.from_numpy(s).bfloat16(), torch.from_numpy(bia).bfloat16()
+                dev.set_quantized_tensor("talker." + k, wq, s16, b16, 64, quant_bits)
+                d32 = torch.from_numpy(mq.dequantize(wq, s16.float().numpy(), b16.float().numpy(), 64, quant_bits))
+                lm_linear = ("model.layers." in k and k.endswith("_proj.weight")) or k == "codec_head.weight"
+                Wo[k] = d32 if lm_linear else d32.bfloat16()
+            else:
+                dev.set_tensor("talker." + k, v); Wo[k] = v
+        for k, v in Wd.items():
+            dev.set_tensor(k, v)
+        dev.finalize()
+        return ocfg, dev, oq.Qwen3TTSOracle(ocfg, Wo), oq.SpeechDecoderOracle(ocfg.decoder, Wd)
     allw = {("talker." + k): v for k, v in W.items()}          # checkpoint naming: sanitize strips the prefix
     allw.update(Wd)
     dev = mas.Qwen3TTSModel.from_weights(_host_cfg(ocfg), allw)
@@ -107,9 +129,13 @@ def test_decoder_stages_and_waveform_match_oracle():
     assert np.abs(part - full[:, : 5 * d.total_upsample]).max() < 1e-5
 
 
-@pytest.mark.parametrize("ocfg", [oq.TINY, oq.TINY_PROJ], ids=["same-width", "mtp-projection"])
-def test_frame_loop_greedy_under_teacher_forcing(ocfg):
-    cfg, dev, olm, _ = _pair(ocfg)
+@pytest.mark.parametrize("ocfg,quant", [(oq.TINY, None), (oq.TINY_PROJ, None), (oq.TINY, 8), (oq.TINY_PROJ, 4)],
+                         ids=["same-width", "mtp-projection", "8bit-checkpoint", "4bit-checkpoint-mtp"])
+def test_frame_loop_greedy_under_teacher_forcing(ocfg, quant):
+    cfg, dev, olm, _ = _pair(ocfg, quant_bits=quant)
+    if quant:                                                                    # the talker streams every role as codes
+        lib = mas._lib.lib()
+        assert [lib.mis_tts_native_quant_bits(lib.mis_qwen3tts_talker(dev._h), r) for r in range(5)] == [quant] * 5
     rng = np.random.default_rng(2)
     prompts = [_prompt(cfg, rng, 9, 3), _prompt(cfg, rng, 4, 1), _prompt(cfg, rng, 6, 5)]
     gp = mas.Qwen3TTSGenerateParameters(max_tokens=6, temperature=0.0, repetition_penalty=1.05, seed=1)
@@ -171,13 +197,105 @@ def test_sampled_generation_eos_ragged_rows_and_end_to_end_audio():
     assert np.array_equal(g2[0], g[0][:3])
     k = list(g[1][:, 0]).index(eos) if eos in g[1][:, 0] else 8
     assert np.array_equal(g2[1], g[1][:k])
-    # end to end: pcm == speech-tokenizer oracle applied to the engine's codes; chunks concatenate to the pcm
-    chunks = {0: [], 1: []}
-    pcm, codes = dev.generate_batch(prompts, gp, return_codes=True, streaming_interval=0.2, on_audio=lambda r, x: chunks[r].append(x))
+    # end to end, no streaming: pcm == speech-tokenizer oracle applied to the engine's codes (rows decode together, right-padded)
+    pcm, codes = dev.generate_batch(prompts, gp, return_codes=True)
     for r in range(2):
         assert np.array_equal(codes[r], a[r])
         ref = odec.decode(codes[r].T[None])[0]
         assert pcm[r].shape == ref.shape == (8 * cfg.decoder.total_upsample,)
         assert np.abs(pcm[r] - ref).max() <= 5e-4 * max(np.abs(ref).max(), 1e-3)
-        assert [len(x) for x in chunks[r]] == [2 * cfg.decoder.total_upsample] * 4      # 0.2 s * 12.5 Hz = 2 frames per chunk
-        assert np.array_equal(np.concatenate(chunks[r]), pcm[r])
+    # ragged rows in one padded decode: row 0 stops after 3 frames (EOS), row 1 runs on
+    pr, cr = dev2.generate_batch(prompts, mas.Qwen3TTSGenerateParameters(max_tokens=8, temperature=0.0), return_codes=True)
+    for r in range(2):
+        assert len(pr[r]) == len(cr[r]) * cfg.decoder.total_upsample
+        if len(cr[r]):
+            ref = odec.decode(cr[r].T[None])[0]
+            assert np.abs(pr[r] - ref).max() <= 5e-4 * max(np.abs(ref).max(), 1e-3)
+
+
+def _oracle_stream(odec, codes_bqt, cuts):
+    odec.reset_streaming_state()
+    out, a0 = [], 0
+    for b in list(cuts) + [codes_bqt.shape[-1]]:
+        if b > a0:
+            out.append(odec.streaming_step(codes_bqt[:, :, a0:b]))
+        a0 = b
+    return np.concatenate(out, -1)
+
+
+def test_streaming_step_carried_state_matches_oracle_and_exact_mode_is_bitwise():
+    """streamingStep (Qwen3TTSSpeechTokenizer.swift:971-1006): only the new frames are computed, conv history / transposed-conv
+    overlap / K/V cache stay on the device.  exact mode: any chunking is BITWISE the whole-sequence decode.  Default mode: the
+    reference's arithmetic (bias twice after a boundary), compared with the oracle's literal restatement of the step functions."""
+    cfg, dev, _, odec = _pair()
+    d = cfg.decoder
+    up = d.total_upsample
+    rng = np.random.default_rng(11)
+    B, T = 2, 13
+    codes = rng.integers(0, d.codebook_size, (B, d.num_quantizers, T)).astype(np.int32)
+    whole = dev.decode_codes(codes)
+    for cuts in ([5], [1, 2, 3, 4], [4, 5, 12], list(range(1, T))):
+        bounds = [0] + list(cuts) + [T]
+        dev.set_stream_exact(True)
+        dev.reset_streaming_state(batch=B, max_frames=T, max_chunk_frames=max(b - a for a, b in zip(bounds, bounds[1:])))
+        got = np.concatenate([dev.streaming_step(codes[:, :, a:b]) for a, b in zip(bounds, bounds[1:])], -1)
+        assert np.array_equal(got, whole), ("exact", cuts, float(np.abs(got - whole).max()))
+        dev.set_stream_exact(False)
+        dev.reset_streaming_state(batch=B, max_frames=T, max_chunk_frames=T)
+        got = np.concatenate([dev.streaming_step(codes[:, :, a:b]) for a, b in zip(bounds, bounds[1:])], -1)
+        ref = _oracle_stream(odec, codes, cuts)
+        err = float(np.abs(got - ref).max())
+        print(f"PARITY q3 streaming cuts={cuts}: max err {err:.2e} (max |ref| {np.abs(ref).max():.3f})")
+        assert err <= 5e-4 * max(np.abs(ref).max(), 1e-3), cuts
+        assert np.array_equal(got[:, : cuts[0] * up], whole[:, : cuts[0] * up])          # identical up to the first boundary
+        assert np.abs(got - whole).max() > 1e-5                                           # ... and the doubled bias after it
+    dev.end_streaming()
+    with pytest.raises(mas.AudioGenerationError):
+        dev.streaming_step(codes[:, :, :1])                                               # no session open
+
+
+def test_generate_stream_delivers_audio_while_the_frame_loop_runs():
+    """generateStream (Qwen3TTS.swift:101-133,492-505,537-546): audio chunks come out of streaming steps that run while the
+    talker keeps generating; their concatenation is the row's pcm; the first AUDIO event precedes the last TOKEN event."""
+    cfg, dev, olm, odec = _pair()
+    rng = np.random.default_rng(3)
+    prompts = [_prompt(cfg, rng, 7, 2), _prompt(cfg, rng, 5, 4)]
+    up = cfg.decoder.total_upsample
+    gp = mas.Qwen3TTSGenerateParameters(max_tokens=21, temperature=0.9, top_k=50, repetition_penalty=1.05, seed=5)
+    codes = dev.generate_codes(prompts, gp)
+    events = list(dev.generate_stream_batch(prompts, gp, streaming_interval=0.4))         # 5 frames per chunk: 5,5,5,5,1
+    for r in range(2):
+        toks = [e.token for e in events if isinstance(e, mas.TokenEvent) and e.row == r]
+        assert toks == list(codes[r][:, 0])                                              # code 0 of every frame, in order
+        chunks = [e.audio for e in events if isinstance(e, mas.AudioEvent) and e.row == r]
+        assert [len(x) for x in chunks] == [5 * up] * 4 + [up]
+        ref = _oracle_stream(odec, codes[r].T[None], [5, 10, 15, 20])[0]
+        got = np.concatenate(chunks)
+        assert np.abs(got - ref).max() <= 5e-4 * max(np.abs(ref).max(), 1e-3)
+        infos = [e for e in events if isinstance(e, mas.InfoEvent) and e.row == r]
+        assert len(infos) == 1 and infos[0].info.generation_token_count == 21
+    kinds = ["A" if isinstance(e, mas.AudioEvent) else "T" if isinstance(e, mas.TokenEvent) else "I" for e in events]
+    first_audio, last_token = kinds.index("A"), len(kinds) - 1 - kinds[::-1].index("T")
+    assert first_audio < last_token, "".join(kinds)                                       # audio while the loop was still sampling
+    assert kinds.index("I") > last_token and "A" in kinds[kinds.index("I"):]              # info, then the remaining frames
+    # the blocking call with a chunk callback returns the same samples as pcm; exact mode equals the whole-sequence decode bitwise
+    got_chunks = {0: [], 1: []}
+    pcm = dev.generate_batch(prompts, gp, streaming_interval=0.4, on_audio=lambda r, x: got_chunks[r].append(x))
+    plain = dev.generate_batch(prompts, gp)
+    for r in range(2):
+        assert np.array_equal(np.concatenate(got_chunks[r]), pcm[r])
+        assert not np.array_equal(pcm[r], plain[r])
+    dev.set_stream_exact(True)
+    pcm_x = dev.generate_batch(prompts, gp, streaming_interval=0.4, on_audio=lambda r, x: None)
+    for r in range(2):
+        assert np.array_equal(pcm_x[r], plain[r])
+    # EOS mid-chunk: the row's last chunk is short, nothing follows it
+    g = dev.generate_codes(prompts, mas.Qwen3TTSGenerateParameters(max_tokens=12, temperature=0.0))
+    eos = int(g[0][7, 0])
+    if eos not in g[0][:7, 0]:
+        cfg2, dev2, _, _ = _pair(eos=eos)
+        ev = list(dev2.generate_stream_batch(prompts, mas.Qwen3TTSGenerateParameters(max_tokens=12, temperature=0.0), streaming_interval=0.4))
+        lens0 = [len(e.audio) for e in ev if isinstance(e, mas.AudioEvent) and e.row == 0]
+        assert lens0 == [5 * up, 2 * up]
+        t0 = [e.token for e in ev if isinstance(e, mas.TokenEvent) and e.row == 0]
+        assert t0 == list(g[0][:7, 0]) + [eos]                                           # onToken fires for the EOS id too (:484-487)

@@ -39,6 +39,42 @@ def test_decoder_is_causal_so_streaming_equals_full_decode():
     assert np.abs(alt - full).max() > 1e-4
 
 
+def _stream(dec, codes, cuts):
+    dec.reset_streaming_state()
+    out, a = [], 0
+    for b in list(cuts) + [codes.shape[-1]]:
+        if b > a:
+            out.append(dec.streaming_step(codes[:, :, a:b]))
+        a = b
+    return np.concatenate(out, -1)
+
+
+def test_streaming_step_restates_the_reference_step_functions():
+    """streamingStep (Qwen3TTSSpeechTokenizer.swift:971-1006) with carried conv buffers, transposed-conv overflow and KV cache.
+    (1) One chunk is the whole-sequence decode.  (2) With the transposed-conv biases of the decoder blocks zeroed, ANY chunking is
+    the whole-sequence decode (carried state is exact).  (3) With the biases, the reference's overlap-add sums two biased
+    outputs (:556-559): the difference to the whole-sequence decode starts exactly at the first chunk boundary."""
+    cfg = oq.TINY.decoder
+    W = oq.make_synthetic_decoder_weights(cfg)
+    rng = np.random.default_rng(5)
+    codes = rng.integers(0, cfg.codebook_size, (2, cfg.num_quantizers, 11))
+    up = cfg.total_upsample
+    dec = oq.SpeechDecoderOracle(cfg, W)
+    full = dec.decode(codes)
+    assert np.abs(_stream(dec, codes, []) - full).max() < 2e-5
+    W0 = dict(W)
+    for bi in range(len(cfg.upsample_rates)):
+        W0[f"decoder.decoder.{bi + 1}.block.1.conv.bias"] = np.zeros_like(W[f"decoder.decoder.{bi + 1}.block.1.conv.bias"])
+    dec0 = oq.SpeechDecoderOracle(cfg, W0)
+    full0 = dec0.decode(codes)
+    for cuts in ([4], [1, 2, 3], [5, 6, 10], list(range(1, 11))):
+        assert np.abs(_stream(dec0, codes, cuts) - full0).max() < 3e-5, cuts
+    got = _stream(dec, codes, [4, 9])
+    assert got.shape == full.shape
+    assert np.abs(got[:, : 4 * up] - full[:, : 4 * up]).max() < 2e-5          # nothing differs before the first boundary
+    assert np.abs(got[:, 4 * up: 4 * up + up] - full[:, 4 * up: 4 * up + up]).max() > 1e-4     # the doubled bias right after it
+
+
 def test_sample_token_set_semantics():
     rng = np.random.default_rng(2)
     V = 300
