@@ -440,8 +440,13 @@ __device__ __forceinline__ void gemm_epilogue(const f32x4_t (&acc)[R][MT], void*
     }
 }
 
+// Two register buffers of GEMM_U k-tiles per wave (one group in flight while one is consumed).  A ring of THREE (two groups in
+// flight, 238 VGPRs, still two blocks per CU) was measured and is slower: gate+up 19.0 -> 19.7 us, step 165.0 -> 161.3 audio-s/s
+// (profiles/r02_gemm_nbuf_ab.json) - and the same kernel streams weights that already sit in the Infinity Cache only 3.5 % faster
+// than from HBM (profiles/r02_mall_probe.txt), so neither the memory nor the bytes in flight bound this launch; what is left is
+// its ramp-up and tail (the lm_head instance, 8x longer, reaches 5.8 TB/s with the same loop).
 template <int MT, int R, int EPI, int KSB>
-__global__ void __launch_bounds__(256) k_gemm_skinny(const bf16_t* __restrict__ Wp, const bf16_t* __restrict__ X,
+__global__ void __launch_bounds__(256, 2) k_gemm_skinny(const bf16_t* __restrict__ Wp, const bf16_t* __restrict__ X,
                                                      void* __restrict__ out, int NT, int KT, int S, int n_items,
                                                      int N_out, int Mpad, int dbg_xfixed,
                                                      const bf16_t* __restrict__ bias) {

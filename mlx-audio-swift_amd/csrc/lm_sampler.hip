@@ -386,6 +386,184 @@ __global__ void __launch_bounds__(SAMP_NT) k_samp_pick(SamplerParams p, int gree
     }
 }
 
+// ---- the whole sampler in ONE launch when the allowed id range holds <= 4096 entries (frame-constrained Orpheus / VyvoTTS steps,
+// any [lo, hi) that narrow): one 1024-thread block per row, four CONSECUTIVE ids per thread, every quantity of the spec above in
+// registers / LDS.  Same integers as the six-kernel path (E, Z, thr, k*, Z_K, r are exact), so the token is bit-identical; what
+// goes away is five dependent kernel boundaries and four passes over a [rows][Vpad] float scratch per step.
+#define SN_NT 1024
+#define SN_W 4096
+__device__ __forceinline__ u64 block_scan_incl_1024(u64 v, u64* sh /*[16]*/, u64* total) {
+    const int tid = threadIdx.x, w = tid >> 6;
+    u64 incl = wave_scan_incl(v);
+    if ((tid & 63) == 63) sh[w] = incl;
+    __syncthreads();
+    u64 base = 0, tot = 0;
+#pragma unroll
+    for (int i = 0; i < SN_NT / 64; ++i) { const u64 t = sh[i]; base += (i < w) ? t : 0; tot += t; }
+    __syncthreads();
+    if (total) *total = tot;
+    return incl + base;
+}
+__global__ void __launch_bounds__(SN_NT) k_samp_narrow(SamplerParams p) {
+    __shared__ float sl[SN_W];
+    __shared__ u64 hist[256];
+    __shared__ u64 sh[SN_NT / 64];
+    __shared__ float redf[SN_NT / 64];
+    __shared__ int redi[SN_NT / 64];
+    __shared__ unsigned s_bin, s_bin2;
+    __shared__ u64 s_below;
+    __shared__ int s_token;
+    const int b = blockIdx.x, tid = threadIdx.x;
+    if (row_skipped(p, b)) return;
+    const int step = row_step(p, b);
+    int lo, hi;
+    allowed_range(p, step, lo, hi);
+    bf16_t* logits = p.logits + (size_t)b * p.Vpad;
+    // ---- the allowed window of the row -> LDS (ids >= hi: -inf)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int i = lo + tid + j * SN_NT;
+        sl[tid + j * SN_NT] = (i < hi) ? bf16_to_f32(logits[i]) : -INFINITY;
+    }
+    if (tid < 256) hist[tid] = 0;
+    if (tid == 0) { s_token = lo < p.vocab ? lo : 0; s_bin = 255; s_bin2 = 255; s_below = 0; }
+    __syncthreads();
+    // ---- repetition penalty (RepetitionContext.process): once per unique id of the window, bf16 arithmetic; in place in
+    // memory like the multi-kernel path, and in the staged window for the ids this step can sample
+    if (p.penalty > 0.0f && p.penalty != 1.0f && p.window) {
+        const int wl = p.window_len[b];
+        const int32_t* win = p.window + (size_t)b * p.ctx + (p.ctx - wl);
+        const float pen = bf16_round_f32(p.penalty);
+        for (int t = tid; t < wl; t += SN_NT) {
+            const int id = win[t];
+            bool first = (id >= 0 && id < p.vocab);
+            for (int j = 0; j < t; ++j) first = first && (win[j] != id);
+            if (first) {
+                const float l = bf16_to_f32(logits[id]);
+                const bf16_t v = f32_to_bf16((l < 0.0f) ? l * pen : __fdiv_rn(l, pen));
+                logits[id] = v;
+                if (id >= lo && id < hi) sl[id - lo] = bf16_to_f32(v);
+            }
+        }
+        __syncthreads();
+    }
+    // ---- this thread's four consecutive ids
+    float l[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) l[j] = sl[4 * tid + j];
+    const int i_base = lo + 4 * tid;
+    // ---- max (first index on ties)
+    float best = -INFINITY;
+    int bi = 0x7fffffff;
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+        if (i_base + j < hi && l[j] > best) { best = l[j]; bi = i_base + j; }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const float ob = __shfl_xor(best, o, 64);
+        const int oi = __shfl_xor(bi, o, 64);
+        if (ob > best || (ob == best && oi < bi)) { best = ob; bi = oi; }
+    }
+    if ((tid & 63) == 0) { redf[tid >> 6] = best; redi[tid >> 6] = bi; }
+    __syncthreads();
+    best = redf[0]; bi = redi[0];
+#pragma unroll
+    for (int w = 1; w < SN_NT / 64; ++w)
+        if (redf[w] > best || (redf[w] == best && redi[w] < bi)) { best = redf[w]; bi = redi[w]; }
+    if (p.temperature == 0.0f) {
+        if (tid == 0 && bi != 0x7fffffff) s_token = bi;
+    } else {
+        // ---- e, E, keys
+        const float xmax = __fdiv_rn(best, p.temperature);
+        float e[4];
+        u64 E[4];
+        unsigned key[4];
+        u64 zsum = 0;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float x = __fdiv_rn(l[j], p.temperature);
+            const float y = fminf(x - xmax, 0.0f);
+            e[j] = (i_base + j < hi) ? det_exp_dev(y) : 0.0f;
+            E[j] = (u64)(e[j] * E_SCALE);
+            key[j] = __float_as_uint(e[j]) >> 16;
+            zsum += E[j];
+        }
+        unsigned kstar = 0;
+        if (p.top_p > 0.0f && p.top_p < 1.0f) {
+            // level 1: mass per key >> 8
+#pragma unroll
+            for (int j = 0; j < 4; ++j) if (E[j]) atomicAdd(&hist[key[j] >> 8], E[j]);
+            __syncthreads();
+            u64 Z = 0;
+            u64 mine = tid < 256 ? hist[tid] : 0;
+            u64 incl = block_scan_incl_1024(mine, sh, &Z);
+            const u64 thr = (u64)((double)(1.0f - p.top_p) * (double)Z);
+            if (tid < 256 && incl > thr && incl - mine <= thr) { s_bin = (unsigned)tid; s_below = incl - mine; }   // unique crossing
+            __syncthreads();
+            const unsigned bin1 = s_bin;
+            const u64 below1 = s_below;
+            if (tid < 256) hist[tid] = 0;
+            __syncthreads();
+            // level 2: mass per key & 255 inside bin1
+#pragma unroll
+            for (int j = 0; j < 4; ++j) if (E[j] && (key[j] >> 8) == bin1) atomicAdd(&hist[key[j] & 255], E[j]);
+            __syncthreads();
+            mine = tid < 256 ? hist[tid] : 0;
+            incl = block_scan_incl_1024(mine, sh, nullptr) + below1;
+            if (tid < 256 && incl > thr && incl - mine <= thr) s_bin2 = (unsigned)tid;
+            __syncthreads();
+            kstar = (bin1 << 8) | s_bin2;
+        }
+        // ---- kept mass in index order, draw, inverse CDF
+        u64 Ek[4];
+        u64 mine = 0;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { Ek[j] = (key[j] >= kstar) ? E[j] : 0; mine += Ek[j]; }
+        u64 Zk = 0;
+        const u64 incl = block_scan_incl_1024(mine, sh, &Zk);
+        const u64 excl = incl - mine;
+        const u64 row = (u64)(p.row_offset + b);
+        const u64 a = p.seed ^ (0xD1B54A32D192ED03ull * (row + 1));
+        const u64 rnd = mis_splitmix64(mis_splitmix64(a) + (u64)step);
+        const u64 r = __umul64hi(rnd, Zk);
+        if (mine > 0 && r >= excl && r < incl) {
+            u64 run = excl;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                run += Ek[j];
+                if (Ek[j] && run > r) { s_token = i_base + j; break; }
+            }
+        }
+        (void)zsum;
+    }
+    __syncthreads();
+    if (tid == 0) {      // bookkeeping of the generate loop (LlamaTTS.swift:721-738), as k_samp_pick
+        const int token = s_token;
+        if (p.tokens_out && step < p.tokens_stride) p.tokens_out[(size_t)b * p.tokens_stride + step] = token;
+        if (p.n_gen && !p.step_override) p.n_gen[b] = step + 1;
+        if (p.window && p.ctx > 0) {
+            int32_t* win = p.window + (size_t)b * p.ctx;
+            int wl = p.window_len[b];
+            if (wl < p.ctx) { wl++; p.window_len[b] = wl; }
+            for (int j = p.ctx - wl; j < p.ctx - 1; ++j) win[j] = win[j + 1];
+            win[p.ctx - 1] = token;
+        }
+        if (p.next_ids) p.next_ids[b] = token;
+        if (token == p.eos_id) {
+            if (p.active) p.active[b] = 0;
+            if (p.done_count) atomicAdd(p.done_count, 1);
+        } else {
+            if (p.all_ids) {
+                int n = p.all_len[b];
+                if (n < p.all_stride) { p.all_ids[(size_t)b * p.all_stride + n] = token; p.all_len[b] = n + 1; }
+            }
+            if (p.n_gen && !p.step_override && step + 1 >= p.max_tokens) {
+                if (p.done_count) atomicAdd(p.done_count, 1);
+            }
+        }
+    }
+}
+
 void sampler_plan(int vocab, int* n_chunks, int* chunk_w) {
     int nc = (vocab + 4095) / 4096;
     if (nc > SAMP_MAX_CHUNKS) nc = SAMP_MAX_CHUNKS;
@@ -399,6 +577,15 @@ void sampler_plan(int vocab, int* n_chunks, int* chunk_w) {
 void launch_sampler(const SamplerParams& p, int batch, hipStream_t s) {
     MIS_REQUIRE(p.scratch && p.n_chunks >= 1 && p.n_chunks <= SAMP_MAX_CHUNKS && p.chunk_w > 0, MIS_ERR_GENERATION_FAILED,
                 "sampler scratch not configured");
+    {   // narrow allowed range (every frame-constrained step; any static [lo, hi) of <= 4096 ids): the single-launch sampler
+        static const bool wide_only = getenv("MIS_SAMPLER_WIDE") && atoi(getenv("MIS_SAMPLER_WIDE")) != 0;      // A/B and parity tests
+        const int hi = (p.hi <= 0 || p.hi > p.vocab) ? p.vocab : p.hi, lo = p.lo < 0 ? 0 : p.lo;
+        const bool narrow = p.frame_constrained || (hi - lo <= SN_W);
+        if (narrow && !wide_only && !p.logits32 && p.penalty_flavor == 0) {
+            hipLaunchKernelGGL(k_samp_narrow, dim3(batch), dim3(SN_NT), 0, s, p);
+            return;
+        }
+    }
     dim3 g2(p.n_chunks, batch);
     hipLaunchKernelGGL(k_samp_prepare, dim3(batch), dim3(64), 0, s, p);
     hipLaunchKernelGGL(k_samp_max, g2, dim3(SAMP_NT), 0, s, p);

@@ -106,9 +106,128 @@ __global__ void __launch_bounds__(256) k_gemm_big(BigGemmParams p) {
     }
 }
 
+// ---- the same contraction with direct global -> LDS staging (global_load_lds_dwordx4), BK = 64, two LDS buffers, ONE barrier per
+// k-step: tile kt+1 is in flight while the 32 MFMAs per wave of tile kt run.  A wave's LDS-DMA writes 64 lanes x 16 B = 1 KiB
+// contiguously (lane-linear destination), i.e. 8 rows x 128 B of the [128][64] bf16 tile; bank conflicts of the fragment reads are
+// avoided on the SOURCE side: LDS position (row r, 16-B chunk c) holds global chunk c ^ ((r >> 1) & 7), and a fragment read of
+// chunk kc of row r goes to position kc ^ ((r >> 1) & 7).  With ds_read_b128's 16-lane service groups ({0-3,12-15,20-27}, ...: every
+// group touches the 16 rows of a fragment once, at two neighbouring kc) the 16 lanes of a group land on 16 distinct 16-B slots of
+// the 256-B bank row.  Rows past M / N are loaded clamped and masked in the epilogue.
+#define BG2_BK 64
+template <int EPI>
+__global__ void __launch_bounds__(256, 2) k_gemm_big2(BigGemmParams p) {
+    __shared__ __attribute__((aligned(1024))) bf16_t Ws[2][BG_BN * BG2_BK];
+    __shared__ __attribute__((aligned(1024))) bf16_t Xs[2][BG_BM * BG2_BK];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int n0 = blockIdx.x * BG_BN, m0 = blockIdx.y * BG_BM;
+    const int wn = wave >> 1, wm = wave & 1;            // wave tile: 64 n x 64 m
+    f32x4_t acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+    // staging: instruction q (0..3) of wave w moves rows (w*4 + q)*8 .. +8 of each operand tile; lane l -> row + (l >> 3), position l & 7
+    const bf16_t* wsrc[4];
+    const bf16_t* xsrc[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int r = (wave * 4 + q) * 8 + (lane >> 3);
+        const int chunk = (lane & 7) ^ ((r >> 1) & 7);
+        const int n = min(n0 + r, p.N - 1), m = min(m0 + r, p.M - 1);
+        wsrc[q] = p.W + (size_t)n * p.K + chunk * 8;
+        xsrc[q] = p.X + (size_t)m * p.ldx + chunk * 8;
+    }
+    auto stage = [&](int buf, int k0) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int row0 = (wave * 4 + q) * 8;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wsrc[q] + k0),
+                                             (__attribute__((address_space(3))) void*)&Ws[buf][row0 * BG2_BK], 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(xsrc[q] + k0),
+                                             (__attribute__((address_space(3))) void*)&Xs[buf][row0 * BG2_BK], 16, 0, 0);
+        }
+    };
+    const int sw = (lane >> 1) & 7;                      // ((row >> 1) & 7) of this lane's fragment rows (row = 16*t + (lane & 15))
+    const int KT = p.K / BG2_BK;
+    stage(0, 0);
+    for (int kt = 0; kt < KT; ++kt) {
+        __syncthreads();                                 // waits for this wave's LDS-DMA (vmcnt(0)), then the block: tile kt is complete
+        const bf16_t* wt = Ws[kt & 1];
+        const bf16_t* xt = Xs[kt & 1];
+        // all fragment reads of the tile FIRST, then the next tile's DMA: hipcc puts a vmcnt(0) in front of any ds_read that follows an
+        // LDS-DMA in program order (it cannot prove the read does not alias the DMA's destination), which would serialise the
+        // prefetch with the reads; issued after them, the DMA runs under the 32 MFMAs of this tile
+        bf16x8_t a[2][4], b[2][4];
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            const int pos = ((ks * 4 + (lane >> 4)) ^ sw) * 8;
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                a[ks][i] = *reinterpret_cast<const bf16x8_t*>(wt + (wn * 64 + i * 16 + (lane & 15)) * BG2_BK + pos);
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                b[ks][j] = *reinterpret_cast<const bf16x8_t*>(xt + (wm * 64 + j * 16 + (lane & 15)) * BG2_BK + pos);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if (kt + 1 < KT) stage((kt + 1) & 1, (kt + 1) * BG2_BK);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[ks][i], b[ks][j], acc[i][j], 0, 0, 0);
+    }
+    // epilogue: as k_gemm_big
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        int n = n0 + wn * 64 + i * 16 + (lane >> 4) * 4;
+        if (n >= p.N) continue;
+        float bv[4] = {0.f, 0.f, 0.f, 0.f};
+        if (p.bias) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) bv[e] = (n + e < p.N) ? bf16_to_f32(p.bias[n + e]) : 0.0f;
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            int m = m0 + wm * 64 + j * 16 + (lane & 15);
+            if (m >= p.M) continue;
+            uint16_t res[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float v = bf16_round_f32(acc[i][j][e] + bv[e]);                       // T(xW^T + b)
+                if (EPI == BG_GELU || EPI == BG_GELU_POS) v = bf16_round_f32(gelu_erf_w(v));
+                if (EPI == BG_RESID) v = bf16_round_f32(v + bf16_to_f32(p.R[(size_t)m * p.N + n + e]));
+                if (EPI == BG_GELU_POS) v = bf16_round_f32(v + bf16_to_f32(p.R[(size_t)(m % p.pos_rows) * p.N + n + e]));
+                res[e] = f32_to_bf16(v);
+            }
+            bf16_t* o = p.C + (size_t)m * p.N + n;
+            if (n + 3 < p.N) {
+                uint2 v;
+                v.x = (uint32_t)res[0] | ((uint32_t)res[1] << 16);
+                v.y = (uint32_t)res[2] | ((uint32_t)res[3] << 16);
+                *reinterpret_cast<uint2*>(o) = v;
+            } else {
+                for (int e = 0; e < 4 && n + e < p.N; ++e) o[e] = res[e];
+            }
+        }
+    }
+}
+
 void launch_gemm_big(int epi, const BigGemmParams& p, hipStream_t s) {
     MIS_REQUIRE(p.K % BG_BK == 0 && p.ldx % 8 == 0 && p.N % 4 == 0, MIS_ERR_INVALID_INPUT, "big GEMM needs K %% 32 == 0");
     dim3 grid(cdiv(p.N, BG_BN), cdiv(p.M, BG_BM)), block(256);
+    static const bool v1 = getenv("MIS_GEMM_BIG_V1") && atoi(getenv("MIS_GEMM_BIG_V1")) != 0;     // A/B: the register-staged kernel
+    if (!v1 && p.K % BG2_BK == 0 && p.K >= 2 * BG2_BK) {
+        switch (epi) {
+            case BG_NONE: hipLaunchKernelGGL((k_gemm_big2<BG_NONE>), grid, block, 0, s, p); return;
+            case BG_GELU: hipLaunchKernelGGL((k_gemm_big2<BG_GELU>), grid, block, 0, s, p); return;
+            case BG_RESID: hipLaunchKernelGGL((k_gemm_big2<BG_RESID>), grid, block, 0, s, p); return;
+            case BG_GELU_POS: hipLaunchKernelGGL((k_gemm_big2<BG_GELU_POS>), grid, block, 0, s, p); return;
+            default: throw MisError(MIS_ERR_GENERATION_FAILED, "unknown big GEMM epilogue");
+        }
+    }
     switch (epi) {
         case BG_NONE: hipLaunchKernelGGL((k_gemm_big<BG_NONE>), grid, block, 0, s, p); break;
         case BG_GELU: hipLaunchKernelGGL((k_gemm_big<BG_GELU>), grid, block, 0, s, p); break;

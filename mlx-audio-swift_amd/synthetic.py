@@ -223,3 +223,29 @@ def qwen3tts_synthetic_weights(cfg, seed: int = 515):
     yield f"decoder.decoder.{n + 1}.alpha", t((cl,), 0.5)
     yield f"decoder.decoder.{n + 1}.beta", t((cl,), 0.5)
     yield from conv(f"decoder.decoder.{n + 2}.conv", 1, 7, cl, 0.5)
+
+
+def mlx_affine_quantize(w, group_size: int = 64, bits: int = 8):
+    """A [N, K] float matrix in MLX's affine-quantised checkpoint form (mlx.core.quantize [3P]): uint32 words [N, K*bits/32]
+    (element i of a row in word i // (32/bits) at bit bits * (i % (32/bits))), bf16 scales and biases [N, K/group_size] as torch
+    tensors.  Host utility for the synthetic quantised benches (there are no checkpoints offline); the arithmetic follows mlx:
+    scale = (max - min) / (2^bits - 1) signed so that the group's larger-magnitude extreme is a code point."""
+    import torch
+    w = np.asarray(w, np.float32)
+    N, K = w.shape
+    n_bins = float(2 ** bits - 1)
+    g = w.reshape(N, K // group_size, group_size)
+    w_max, w_min = g.max(-1), g.min(-1)
+    mask = np.abs(w_min) > np.abs(w_max)
+    scales = np.maximum((w_max - w_min) / n_bins, 1e-7).astype(np.float32)
+    scales = np.where(mask, scales, -scales)
+    edge = np.where(mask, w_min, w_max)
+    q0 = np.round(edge / scales)
+    scales = np.where(q0 != 0, edge / np.where(q0 != 0, q0, 1), scales).astype(np.float32)
+    biases = np.where(q0 == 0, 0.0, edge).astype(np.float32)
+    q = np.clip(np.round((g - biases[..., None]) / scales[..., None]), 0, n_bins).astype(np.uint32).reshape(N, K)
+    epw = 32 // bits
+    words = np.zeros((N, K // epw), np.uint32)
+    for j in range(epw):
+        words |= q[:, j::epw] << np.uint32(bits * j)
+    return words, torch.from_numpy(scales).bfloat16(), torch.from_numpy(biases).bfloat16()

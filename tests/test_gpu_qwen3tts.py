@@ -262,18 +262,21 @@ def test_generate_stream_delivers_audio_while_the_frame_loop_runs():
     prompts = [_prompt(cfg, rng, 7, 2), _prompt(cfg, rng, 5, 4)]
     up = cfg.decoder.total_upsample
     gp = mas.Qwen3TTSGenerateParameters(max_tokens=21, temperature=0.9, top_k=50, repetition_penalty=1.05, seed=5)
-    codes = dev.generate_codes(prompts, gp)
-    events = list(dev.generate_stream_batch(prompts, gp, streaming_interval=0.4))         # 5 frames per chunk: 5,5,5,5,1
+    codes = dev.generate_codes(prompts, gp)                                               # (this seed: row 1 samples EOS after 18 frames)
+    events = list(dev.generate_stream_batch(prompts, gp, streaming_interval=0.4))         # 5 frames per chunk
     for r in range(2):
+        n = len(codes[r])
+        ended_on_eos = n < 21
         toks = [e.token for e in events if isinstance(e, mas.TokenEvent) and e.row == r]
-        assert toks == list(codes[r][:, 0])                                              # code 0 of every frame, in order
+        # code 0 of every frame, in order; onToken fires for the EOS id too (Qwen3TTS.swift:484-487)
+        assert toks == list(codes[r][:, 0]) + ([cfg.codec_eos_token_id] if ended_on_eos else [])
         chunks = [e.audio for e in events if isinstance(e, mas.AudioEvent) and e.row == r]
-        assert [len(x) for x in chunks] == [5 * up] * 4 + [up]
-        ref = _oracle_stream(odec, codes[r].T[None], [5, 10, 15, 20])[0]
+        assert [len(x) for x in chunks] == [5 * up] * (n // 5) + ([(n % 5) * up] if n % 5 else [])
+        ref = _oracle_stream(odec, codes[r].T[None], list(range(5, n, 5)))[0]
         got = np.concatenate(chunks)
         assert np.abs(got - ref).max() <= 5e-4 * max(np.abs(ref).max(), 1e-3)
         infos = [e for e in events if isinstance(e, mas.InfoEvent) and e.row == r]
-        assert len(infos) == 1 and infos[0].info.generation_token_count == 21
+        assert len(infos) == 1 and infos[0].info.generation_token_count == n
     kinds = ["A" if isinstance(e, mas.AudioEvent) else "T" if isinstance(e, mas.TokenEvent) else "I" for e in events]
     first_audio, last_token = kinds.index("A"), len(kinds) - 1 - kinds[::-1].index("T")
     assert first_audio < last_token, "".join(kinds)                                       # audio while the loop was still sampling

@@ -54,3 +54,34 @@ def test_range_constraint_and_peaked_distribution():
         g = sample_logits(logits, np.zeros((3, 0), np.int32), np.zeros(3, np.int32), pc, step)
         s = step % 7
         assert np.all((g >= 128266 + s * 4096) & (g < 128266 + (s + 1) * 4096))
+
+
+@pytest.mark.parametrize("temp,top_p,pen", [(0.6, 0.8, 1.3), (0.0, 0.8, 1.3), (1.0, 1.0, 0.0), (0.9, 0.3, 1.1), (0.6, 0.999, 1.3)])
+def test_single_launch_sampler_on_narrow_ranges_bit_exact(temp, top_p, pen):
+    """Allowed ranges of <= 4096 ids (every frame-constrained step, the bench's case) run k_samp_narrow: one launch instead of
+    six, same integers.  Frame slots 0..6 of two frames, penalty windows holding ids inside AND outside the allowed range,
+    duplicate ids, a ragged range [lo, hi) whose width is not a multiple of 4, and a range clipped by the vocabulary end."""
+    rng = np.random.default_rng(int(temp * 100) + int(top_p * 1000))
+    V, B, ctx = 156940, 6, 24
+    logits = bf16_round((rng.standard_normal((B, V)) * 2.5).astype(np.float32))
+    wl = np.asarray([24, 24, 7, 0, 1, 24], np.int32)
+    pc = mas.GenerateParameters(temperature=temp, top_p=top_p, repetition_penalty=pen, seed=99, row_offset=3, frame_constrained=True)
+    for step in (0, 1, 5, 6, 7, 13):
+        lo = 128266 + (step % 7) * 4096
+        window = rng.integers(lo, lo + 4096, (B, ctx)).astype(np.int32)
+        window[:, ::5] = rng.integers(0, V, (B, len(range(0, ctx, 5))))        # some ids outside the range
+        window[:, -3] = window[:, -1]
+        # the strongest candidates sit in the window so the penalty decides the outcome
+        for b in range(B):
+            logits[b, window[b, -1]] = 9.0
+            logits[b, window[b, -2]] = 8.5
+        logits = bf16_round(logits)
+        got = sample_logits(logits, window, wl, pc, step)
+        ref = _oracle_tokens(logits, window, wl, pc, step, lo, lo + 4096)
+        assert np.array_equal(got, ref), (step, got, ref)
+    p = mas.GenerateParameters(temperature=temp, top_p=top_p, repetition_penalty=pen, seed=5, row_offset=0)
+    window = rng.integers(0, V, (B, ctx)).astype(np.int32)
+    for lo, hi in ((1000, 1000 + 1447), (V - 301, V), (70000, 70001)):
+        got = sample_logits(logits, window, wl, p, 2, lo, hi)
+        ref = _oracle_tokens(logits, window, wl, p, 2, lo, hi)
+        assert np.array_equal(got, ref), (lo, hi, got, ref)

@@ -1,6 +1,8 @@
-"""Secondary bench (BASELINE configs[4] / SURVEY §8d C5, one GPU's share): Qwen3-TTS-0.6B-shaped synthetic model (bf16 weights; the
-8-bit checkpoint format dequantises to this), batch 32, 100 frames (8 s) per row, EOS out of reach, chunked audio delivery every
-25 frames.  argv[1] = batch (default 32), argv[2] = frames (default 100)."""
+"""Secondary bench (BASELINE configs[4] / SURVEY §8d C5, one GPU's share): Qwen3-TTS-0.6B-shaped synthetic model, batch 32, 100 frames
+(8 s) per row, EOS out of reach.  Three measurements: the frame loop alone, generate with one whole-sequence decode, and
+generateStream (streaming_interval 2.0 s = 25 frames: streaming steps on a second stream while the loop runs) with the time to the
+first audio chunk.  argv[1] = batch (default 32), argv[2] = frames (default 100), argv[3] = 16 (bf16 weights, default) | 8 | 4 (every
+2-D talker tensor as an MLX affine-quantised matrix, the published checkpoint's form)."""
 import json, os, sys, time
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -13,9 +15,17 @@ F = int(sys.argv[2]) if len(sys.argv) > 2 else 100
 cfg = mas.Qwen3TTSConfiguration(codec_eos_token_id=3071)            # inside the suppressed range but exempt: never the argmax in practice
 t0 = time.perf_counter()
 m = mas.Qwen3TTSModel(cfg)
+BITS = int(sys.argv[3]) if len(sys.argv) > 3 else 16
 for name, arr in qwen3tts_synthetic_weights(cfg):
-    m.set_tensor(name, arr)
+    if BITS != 16 and arr.ndim == 2 and not name.startswith("decoder.") and arr.shape[1] % 64 == 0:
+        from mlx_audio_swift_amd.synthetic import mlx_affine_quantize
+        wq, sc, bi = mlx_affine_quantize(arr, 64, BITS)
+        m.set_quantized_tensor(name, wq, sc, bi, 64, BITS)
+    else:
+        m.set_tensor(name, arr)
 m.finalize()
+lib = mas._lib.lib()
+native = [lib.mis_tts_native_quant_bits(lib.mis_qwen3tts_talker(m._h), r) for r in range(5)]
 t_load = time.perf_counter() - t0
 rng = np.random.default_rng(1238)
 prompts = []
@@ -30,8 +40,19 @@ res = {}
 for rep in range(2):
     t0 = time.perf_counter(); codes = m.generate_codes(prompts, gp); t_codes = time.perf_counter() - t0
     t0 = time.perf_counter(); pcm = m.generate_batch(prompts, gp); t_all = time.perf_counter() - t0
+# generateStream: first-audio latency and total time with the decoder overlapped with the frame loop
+for rep in range(2):
+    t0 = time.perf_counter(); t_first = None; n_audio = 0; samples = 0
+    for ev in m.generate_stream_batch(prompts, gp, streaming_interval=2.0):
+        if isinstance(ev, mas.AudioEvent):
+            if t_first is None:
+                t_first = time.perf_counter() - t0
+            n_audio += 1; samples += len(ev.audio)
+    t_stream = time.perf_counter() - t0
 audio_s = sum(len(p) for p in pcm) / cfg.sample_rate
-print(json.dumps({"workload": f"Qwen3-TTS-0.6B-shaped bf16, batch {B}, {F} frames/row, 16 code groups, speech-tokenizer decode per row",
+print(json.dumps({"workload": f"Qwen3-TTS-0.6B-shaped, weights {BITS} bit (native roles {native}), batch {B}, {F} frames/row, 16 code groups",
+                  "stream_total_ms": t_stream * 1e3, "stream_first_audio_ms": (t_first or 0) * 1e3, "stream_audio_events": n_audio,
+                  "stream_audio_s_per_s": samples / cfg.sample_rate / t_stream,
                   "load_s": t_load, "frames": [len(c) for c in codes][:4], "codes_ms": t_codes * 1e3,
                   "ms_per_frame": t_codes * 1e3 / F, "generate_ms": t_all * 1e3, "decode_ms": (t_all - t_codes) * 1e3,
                   "audio_s_per_s": audio_s / t_all, "audio_s": audio_s}))
