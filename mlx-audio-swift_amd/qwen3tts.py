@@ -66,6 +66,31 @@ class Qwen3TTSConfiguration:
     sample_rate: int = 24000
     decoder: Qwen3TTSDecoderConfiguration = field(default_factory=Qwen3TTSDecoderConfiguration)
 
+    @classmethod
+    def from_dict(cls, d: dict, tokenizer: dict | None = None) -> "Qwen3TTSConfiguration":
+        """Qwen3TTSModelConfig (config.json: talker_config { code_predictor_config }, tts_*_token_id, sample_rate) plus the speech
+        tokenizer's decoder_config (speech_tokenizer/config.json); defaults as Qwen3TTSConfig.swift:47-63,267-295,362-385,582-587."""
+        t = d.get("talker_config") or {}
+        cp = t.get("code_predictor_config") or {}
+
+        def lm(c, layers, vocab):
+            return _lm(c.get("hidden_size", 1024), c.get("num_hidden_layers", layers), c.get("intermediate_size", 3072),
+                       c.get("num_attention_heads", 16), c.get("num_key_value_heads", 8), c.get("head_dim", 128), c.get("vocab_size", vocab))
+        talker, pred = lm(t, 28, 3072), lm(cp, 5, 2048)
+        talker.rms_norm_eps = t.get("rms_norm_eps", 1e-6); talker.rope_theta = t.get("rope_theta", 1e6)
+        pred.rms_norm_eps = cp.get("rms_norm_eps", 1e-6); pred.rope_theta = cp.get("rope_theta", 1e6)
+        dc = (tokenizer or {}).get("decoder_config") or {}
+        dec = Qwen3TTSDecoderConfiguration(**{k: (tuple(dc[k]) if isinstance(dc[k], list) else dc[k])
+                                              for k in Qwen3TTSDecoderConfiguration.__dataclass_fields__ if k in dc})
+        return cls(talker=talker, predictor=pred, num_code_groups=t.get("num_code_groups", 16),
+                   text_hidden_size=t.get("text_hidden_size", 2048), text_vocab_size=t.get("text_vocab_size", 151936),
+                   codec_eos_token_id=t.get("codec_eos_token_id", 2150), codec_think_id=t.get("codec_think_id", 2154),
+                   codec_nothink_id=t.get("codec_nothink_id", 2155), codec_think_bos_id=t.get("codec_think_bos_id", 2156),
+                   codec_think_eos_id=t.get("codec_think_eos_id", 2157), codec_pad_id=t.get("codec_pad_id", 2148),
+                   codec_bos_id=t.get("codec_bos_id", 2149), codec_language_id=t.get("codec_language_id"),
+                   tts_pad_token_id=d.get("tts_pad_token_id", 151671), tts_bos_token_id=d.get("tts_bos_token_id", 151672),
+                   tts_eos_token_id=d.get("tts_eos_token_id", 151673), sample_rate=d.get("sample_rate", 24000), decoder=dec)
+
     def to_c(self) -> "_lib.Qwen3TTSConfigC":
         d = self.decoder
         ur = (C.c_int32 * 8)(*d.upsample_rates)
@@ -93,6 +118,77 @@ class Qwen3TTSGenerateParameters:
     def to_c(self):
         return _lib.Qwen3TTSParamsC(int(self.max_tokens), float(self.temperature), float(self.top_p), int(self.top_k),
                                     float(self.repetition_penalty), float(self.min_p), int(self.seed), int(self.row_offset))
+
+
+def read_safetensors(path: str) -> dict:
+    """name -> torch tensor (bf16 / f16 / f32 as stored) or numpy uint32 array (quantised words).  MLX writes U32 for packed weights."""
+    import json
+    import torch
+    out = {}
+    with open(path, "rb") as f:
+        n = int.from_bytes(f.read(8), "little")
+        hdr = json.loads(f.read(n))
+        blob = f.read()
+    kinds = {"BF16": torch.bfloat16, "F16": torch.float16, "F32": torch.float32}
+    for k, e in hdr.items():
+        if k == "__metadata__":
+            continue
+        a, b = e["data_offsets"]
+        raw = np.frombuffer(blob, np.uint8, b - a, a)
+        if e["dtype"] in kinds:
+            out[k] = torch.frombuffer(bytearray(raw.tobytes()), dtype=kinds[e["dtype"]]).reshape(e["shape"]) if b > a else torch.zeros(e["shape"], dtype=kinds[e["dtype"]])
+        elif e["dtype"] in ("U32", "I32"):
+            out[k] = raw.view(np.uint32).reshape(e["shape"]).copy()
+        elif e["dtype"] in ("I64", "BOOL", "U8"):
+            continue                                                     # bookkeeping tensors (codebook `initialized`, ...)
+        else:
+            raise AudioGenerationError(3, f"unsupported safetensors dtype {e['dtype']} for {k}")
+    return out
+
+
+def _mlx_conv_shape(shape) -> bool:
+    """checkArrayShapeQwen3 (Qwen3TTSSpeechTokenizer.swift:1445-1455): does a 3-D conv weight already look like MLX's [out, k, in]?"""
+    if len(shape) != 3:
+        return False
+    _, d2, d3 = shape
+    if d2 == 1:
+        return d3 > 64
+    if d3 == 1:
+        return d2 <= 64
+    return d2 < d3
+
+
+def sanitize_speech_tokenizer(weights: dict) -> dict:
+    """Qwen3TTSSpeechTokenizer.sanitize (:1093-1440), decoder side: strip the speech_tokenizer./decoder_model. prefixes, keep the
+    decoder codebooks' cluster_usage / embedding_sum (`_codebook.` -> `.codebook.`), transpose PyTorch conv weights to MLX's layout
+    when the shape heuristic says they are not already (transposed convs [in, out, k] -> [out, k, in], convs [out, in, k] ->
+    [out, k, in]), rename upsample.X.Y -> upsample.X.layers.Y.  Encoder / speaker-encoder keys are dropped (not built)."""
+    import re
+    out = {}
+    for raw, v in weights.items():
+        k = raw
+        stripped = True
+        while stripped:
+            stripped = False
+            for pre in ("speech_tokenizer.", "encoder_model.", "decoder_model."):
+                if k.startswith(pre):
+                    k = k[len(pre):]; stripped = True; break
+        if not k or k.startswith("encoder.") or "speaker_encoder" in k or "initialized" in k:
+            continue
+        if "_codebook.cluster_usage" in k or "_codebook.embedding_sum" in k:
+            base, leaf = k.rsplit("._codebook.", 1)
+            out[f"{base}.codebook.{leaf}"] = v
+            continue
+        shape = tuple(v.shape)
+        is_tconv = ("upsample" in k and ".0.conv.weight" in k) or ("decoder.decoder" in k and "block.1.conv.weight" in k)
+        if len(shape) == 3 and not _mlx_conv_shape(shape):
+            if is_tconv:
+                v = v.permute(1, 2, 0).contiguous()
+            elif "conv.weight" in k or "_proj.weight" in k:
+                v = v.permute(0, 2, 1).contiguous()
+        k = re.sub(r"upsample\.(\d+)\.(\d+)", r"upsample.\1.layers.\2", k)
+        out[k] = v
+    return out
 
 
 @dataclass
@@ -126,6 +222,58 @@ class Qwen3TTSModel:
             m.set_tensor(k, v)
         m.finalize()
         return m
+
+    # -- fromModelDirectory / fromPretrained (Qwen3TTS.swift:1122-1275) -----------------------------------------------------------
+    @classmethod
+    def from_model_directory(cls, model_dir: str, device: int = 0) -> "Qwen3TTSModel":
+        """config.json + *.safetensors (talker, `talker.` prefix stripped by sanitize :357-365; quantised paths = those with a
+        `.scales` companion, group size / bits from `quantization` and its per-layer overrides :1157-1170) + speech_tokenizer/
+        (config.json, *.safetensors through `sanitize_speech_tokenizer`).  Speaker-encoder / tokenizer-encoder tensors are skipped
+        (voice cloning is not built)."""
+        import json
+        import os
+        with open(os.path.join(model_dir, "config.json")) as f:
+            cj = json.load(f)
+        st_dir = os.path.join(model_dir, "speech_tokenizer")
+        tj = {}
+        if os.path.isdir(st_dir) and os.path.exists(os.path.join(st_dir, "config.json")):
+            with open(os.path.join(st_dir, "config.json")) as f:
+                tj = json.load(f)
+        m = cls(Qwen3TTSConfiguration.from_dict(cj, tj), device)
+        weights = {}
+        for fn in sorted(os.listdir(model_dir)):
+            if fn.endswith(".safetensors"):
+                weights.update(read_safetensors(os.path.join(model_dir, fn)))
+        talker = {k[len("talker."):]: v for k, v in weights.items() if k.startswith("talker.")}
+        quant = cj.get("quantization") or cj.get("quantization_config") or {}
+        for name, arr in talker.items():
+            if name.endswith(".scales") or name.endswith(".biases"):
+                continue
+            base = name[: -len(".weight")] if name.endswith(".weight") else name
+            if base + ".scales" in talker:
+                per = quant.get("talker." + base) or quant.get(base) or {}
+                gs, bits = int(per.get("group_size", quant.get("group_size", 64))), int(per.get("bits", quant.get("bits", 4)))
+                m.set_quantized_tensor(name, np.asarray(arr).view(np.uint32), talker[base + ".scales"], talker[base + ".biases"], gs, bits)
+            else:
+                m.set_tensor(name, arr)
+        if not os.path.isdir(st_dir):
+            raise AudioGenerationError(1, "speech_tokenizer directory not found: speech decoding unavailable")
+        tw = {}
+        for fn in sorted(os.listdir(st_dir)):
+            if fn.endswith(".safetensors"):
+                tw.update(read_safetensors(os.path.join(st_dir, fn)))
+        for name, arr in sanitize_speech_tokenizer(tw).items():
+            if name.startswith("decoder."):
+                m.set_tensor(name, arr)
+        m.finalize()
+        return m
+
+    @classmethod
+    def from_pretrained(cls, model_repo: str, device: int = 0) -> "Qwen3TTSModel":
+        import os
+        if os.path.isdir(model_repo):
+            return cls.from_model_directory(model_repo, device)
+        raise AudioGenerationError(1, f"model repo {model_repo!r} is not a local directory (no network access)")
 
     def set_tensor(self, name: str, arr):
         keep, ptr, dt, shape = _tensor_args(arr)

@@ -302,3 +302,82 @@ def test_generate_stream_delivers_audio_while_the_frame_loop_runs():
         assert lens0 == [5 * up, 2 * up]
         t0 = [e.token for e in ev if isinstance(e, mas.TokenEvent) and e.row == 0]
         assert t0 == list(g[0][:7, 0]) + [eos]                                           # onToken fires for the EOS id too (:484-487)
+
+
+def test_from_model_directory_quantised_checkpoint_and_pytorch_layout_tokenizer(tmp_path):
+    """fromModelDirectory (Qwen3TTS.swift:1136-1275): config.json (talker_config, quantization), talker tensors under `talker.` with
+    8-bit packed weights + scales / biases, speech_tokenizer/ in the PyTorch layout the published checkpoints use ([out, in, k] convs,
+    [in, out, k] transposed convs, `_codebook.` statistics) -> the same model as building it tensor by tensor (codes and waveform
+    bitwise).  codebook_dim 160 / decoder_dim 288 keep the reference's conv-layout heuristic (checkArrayShapeQwen3 :1445-1455: it reads
+    [*, 1, <=64] and [*, <=64, 1] the wrong way round) on its valid side, as the published dimensions do."""
+    import json
+    import os
+    from safetensors.torch import save_file
+    from oracle import mlxquant as mq
+    dcfg = oq.DecoderConfig(**{**oq.TINY.decoder.__dict__, "codebook_dim": 160, "decoder_dim": 288})    # 1x1 convs wider than 64 too
+    ocfg = oq.Qwen3TTSConfig(**{**oq.TINY.__dict__, "decoder": dcfg})
+    W = oq.make_synthetic_weights(ocfg)
+    Wd = oq.make_synthetic_decoder_weights(dcfg)
+    ref = mas.Qwen3TTSModel(_host_cfg(ocfg))
+    tens = {}
+    for k, v in W.items():
+        v = torch.as_tensor(v)
+        if v.ndim == 2 and v.shape[1] % 64 == 0:
+            wq, s_, b_ = mq.quantize(v.float().numpy(), 64, 8)
+            s16, b16 = torch.from_numpy(s_).bfloat16(), torch.from_numpy(b_).bfloat16()
+            ref.set_quantized_tensor("talker." + k, wq, s16, b16, 64, 8)
+            base = "talker." + k[: -len(".weight")]
+            tens[base + ".weight"] = torch.from_numpy(wq.view(np.int32)).view(torch.int32)
+            tens[base + ".scales"], tens[base + ".biases"] = s16, b16
+        else:
+            ref.set_tensor("talker." + k, v); tens["talker." + k] = v.contiguous()
+    for k, v in Wd.items():
+        ref.set_tensor(k, v)
+    ref.finalize()
+    d = tmp_path / "q3"; (d / "speech_tokenizer").mkdir(parents=True)
+    lmj = lambda c: dict(hidden_size=c.hidden_size, num_hidden_layers=c.num_hidden_layers, intermediate_size=c.intermediate_size,
+                         num_attention_heads=c.num_attention_heads, num_key_value_heads=c.num_key_value_heads, head_dim=c.head_dim,
+                         vocab_size=c.vocab_size, rms_norm_eps=c.rms_norm_eps, rope_theta=c.rope_theta)
+    tj = {**lmj(ocfg.talker), "code_predictor_config": lmj(ocfg.predictor), "num_code_groups": ocfg.num_code_groups,
+          "text_hidden_size": ocfg.text_hidden_size, "text_vocab_size": ocfg.text_vocab_size}
+    for f in ("codec_eos_token_id", "codec_think_id", "codec_nothink_id", "codec_think_bos_id", "codec_think_eos_id", "codec_pad_id", "codec_bos_id"):
+        tj[f] = getattr(ocfg, f)
+    (d / "config.json").write_text(json.dumps({"model_type": "qwen3_tts", "talker_config": tj, "quantization": {"group_size": 64, "bits": 8},
+                                                "tts_pad_token_id": ocfg.tts_pad_token_id, "tts_bos_token_id": ocfg.tts_bos_token_id,
+                                                "tts_eos_token_id": ocfg.tts_eos_token_id}))
+    path = str(d / "model.safetensors")
+    save_file(tens, path)
+    raw = open(path, "rb").read()                                            # MLX writes the packed words as U32
+    n = int.from_bytes(raw[:8], "little")
+    hdr = json.loads(raw[8:8 + n])
+    for k in hdr:
+        if k != "__metadata__" and hdr[k]["dtype"] == "I32":
+            hdr[k]["dtype"] = "U32"
+    hb = json.dumps(hdr, separators=(",", ":")).encode()
+    hb += b" " * ((8 - len(hb) % 8) % 8)
+    open(path, "wb").write(len(hb).to_bytes(8, "little") + hb + raw[8 + n:])
+    # speech tokenizer as a PyTorch-layout checkpoint
+    pt = {}
+    for k, v in Wd.items():
+        v = torch.as_tensor(v)
+        if ".codebook." in k:
+            k = k.replace(".codebook.", "._codebook.")
+        elif v.ndim == 3:
+            tconv = ("upsample" in k and ".0.conv.weight" in k) or ("decoder.decoder" in k and "block.1.conv.weight" in k)
+            v = v.permute(2, 0, 1) if tconv else v.permute(0, 2, 1)           # MLX [out,k,in] -> torch [in,out,k] / [out,in,k]
+        k = k.replace(".layers.0.", ".0.").replace(".layers.1.", ".1.") if k.startswith("decoder.upsample.") else k
+        pt[k] = v.contiguous()
+    save_file(pt, str(d / "speech_tokenizer" / "model.safetensors"))
+    dj = {f: (list(getattr(dcfg, f)) if isinstance(getattr(dcfg, f), tuple) else getattr(dcfg, f)) for f in mas.Qwen3TTSDecoderConfiguration.__dataclass_fields__}
+    (d / "speech_tokenizer" / "config.json").write_text(json.dumps({"decoder_config": dj}))
+    dev = mas.Qwen3TTSModel.from_pretrained(str(d))
+    lib = mas._lib.lib()
+    assert [lib.mis_tts_native_quant_bits(lib.mis_qwen3tts_talker(dev._h), r) for r in range(5)] == [8] * 5
+    rng = np.random.default_rng(8)
+    prompts = [_prompt(ocfg, rng, 6, 3), _prompt(ocfg, rng, 5, 1)]
+    gp = mas.Qwen3TTSGenerateParameters(max_tokens=5, temperature=0.9, top_k=20, seed=3)
+    a, b = ref.generate_batch(prompts, gp, return_codes=True), dev.generate_batch(prompts, gp, return_codes=True)
+    for r in range(2):
+        assert np.array_equal(a[1][r], b[1][r]) and np.array_equal(a[0][r], b[0][r])
+    with pytest.raises(mas.AudioGenerationError):
+        mas.Qwen3TTSModel.from_pretrained("mlx-community/Qwen3-TTS-12Hz-0.6B-Base-8bit")          # no network: local directories only

@@ -37,3 +37,34 @@ def test_prompt_layout_matches_reference_construction():
     t, c, pl, P, tr, tl, Tt = m._marshal([p, q])
     assert t.shape == (2, P) and pl.tolist() == [len(p.text_ids), len(q.text_ids)] and tl.tolist() == [len(p.trailing_ids)] * 2
     assert m._row_caps([p, q], q3.Qwen3TTSGenerateParameters(max_tokens=4096)).tolist() == [75, 75]
+
+
+def test_speech_tokenizer_sanitize_and_safetensors_reader_round_trip(tmp_path):
+    """Qwen3TTSSpeechTokenizer.sanitize (Qwen3TTSSpeechTokenizer.swift:1093-1440), decoder side: a PyTorch-layout checkpoint
+    ([out, in, k] convs, [in, out, k] transposed convs, `_codebook.` statistics, upsample.X.Y names, encoder keys) comes back as the
+    module-tree tensors the engine takes; the U32 words of quantised tensors survive the reader."""
+    import torch
+    from safetensors.torch import save_file
+    from mlx_audio_swift_amd.qwen3tts import read_safetensors, sanitize_speech_tokenizer, Qwen3TTSConfiguration
+    from oracle import qwen3tts as oq
+    dcfg = oq.DecoderConfig(**{**oq.TINY.decoder.__dict__, "codebook_dim": 160, "decoder_dim": 288})
+    Wd = oq.make_synthetic_decoder_weights(dcfg)
+    pt = {"encoder.encoder.layers.0.conv.weight": torch.zeros(4, 1, 7), "decoder.quantizer.rvq_first.vq.layers.0._codebook.initialized": torch.ones(1)}
+    for k, v in Wd.items():
+        v = torch.as_tensor(v)
+        if ".codebook." in k:
+            k = k.replace(".codebook.", "._codebook.")
+        elif v.ndim == 3:
+            tconv = ("upsample" in k and ".0.conv.weight" in k) or ("decoder.decoder" in k and "block.1.conv.weight" in k)
+            v = v.permute(2, 0, 1) if tconv else v.permute(0, 2, 1)
+        k = k.replace(".layers.0.", ".0.").replace(".layers.1.", ".1.") if k.startswith("decoder.upsample.") else k
+        pt["speech_tokenizer." + k if "quantizer" in k else k] = v.contiguous()
+    save_file(pt, str(tmp_path / "m.safetensors"))
+    back = sanitize_speech_tokenizer(read_safetensors(str(tmp_path / "m.safetensors")))
+    assert set(back) == set(Wd)
+    for k, v in Wd.items():
+        assert tuple(back[k].shape) == tuple(np.asarray(v).shape) and np.array_equal(back[k].float().numpy(), torch.as_tensor(v).float().numpy()), k
+    cfg = Qwen3TTSConfiguration.from_dict({"talker_config": {"hidden_size": 256, "code_predictor_config": {"num_hidden_layers": 3}}, "tts_pad_token_id": 7},
+                                          {"decoder_config": {"upsample_rates": [3, 2], "codebook_dim": 160}})
+    assert (cfg.talker.hidden_size, cfg.talker.num_hidden_layers, cfg.predictor.num_hidden_layers, cfg.predictor.vocab_size) == (256, 28, 3, 2048)
+    assert cfg.tts_pad_token_id == 7 and cfg.decoder.upsample_rates == (3, 2) and cfg.decoder.codebook_dim == 160 and cfg.decoder.latent_dim == 1024
