@@ -65,6 +65,11 @@ struct mis_tts {
     DevBuf<int32_t> prompt_mat, prompt_lens, step_counter, window, window_len, n_gen, tokens_out, all_ids, all_len,
         done_count, codes, n_codes, l0, l1, l2, row_map;
     DevBuf<float> pcm_tmp;
+    // batched prefill (lm_prefill.hip): one chunk of positions x rows
+    DevBuf<bf16_t> pf_h, pf_x, pf_attn, pf_act;
+    DevBuf<float> pf_qkv;
+    DevBuf<int32_t> pf_pos;
+    DevBuf<uint8_t> pf_on;
     DevBuf<SamplerScratch> samp_scratch;
     hipGraphExec_t g_prefill = nullptr, g_decode = nullptr;
     uint64_t graph_key = 0;
@@ -613,6 +618,67 @@ static void enqueue_lm_head(mis_tts* c, const bf16_t* head = nullptr) {
                        c->Vpad, c->Mpad, c->stream);
 }
 
+// ---- the prompt in one pass per chunk of positions (LlamaTTS.swift:711; kernels and layout: lm_prefill.hip).  On return the K/V
+// caches hold every prompt position, c->x is the packed final-norm hidden state of every row's LAST prompt token (the operand of the
+// first lm_head) and the position counters stand behind the prompts - the state the position-by-position prefill leaves.
+static bool prefill_batched_ok(const mis_tts* c, int Lmax) {
+    const bool off = getenv("MIS_PREFILL_SEQ") && atoi(getenv("MIS_PREFILL_SEQ")) != 0;             // A/B and parity tests (read per call)
+    const int HD = c->H * c->D;
+    return !off && Lmax >= 2 && !c->q_qkv.on && !c->q_o.on && !c->q_gu.on && !c->q_down.on && c->d % 64 == 0 && HD % 64 == 0 &&
+           c->ff % 64 == 0 && c->d >= 128 && HD >= 128 && c->ff >= 128;
+}
+static void prefill_batched(mis_tts* c, const int32_t* prompt_mat_dev, const int32_t* lens_dev, const std::vector<int32_t>& lens, int Lmax) {
+    hipStream_t s = c->stream;
+    const int d = c->d, HD = c->H * c->D, Mpad = c->Mpad, batch = c->batch;
+    const float eps = c->cfg.rms_norm_eps;
+    const int Tc = std::min(Lmax, std::max(1, 4096 / Mpad));                 // positions per chunk: <= 4096 rows of activations
+    const size_t Mc = (size_t)Tc * Mpad;
+    c->pf_h.alloc(Mc * d); c->pf_x.alloc(Mc * d); c->pf_attn.alloc(Mc * HD); c->pf_act.alloc(Mc * c->ff);
+    c->pf_qkv.alloc(Mc * c->Nqkv); c->pf_pos.alloc(Mc); c->pf_on.alloc(Mc);
+    HIP_CHECK(hipMemsetAsync(c->pf_attn.p, 0, Mc * HD * 2, s));             // rows of padded positions are never written by the attention
+    const size_t lkv = (size_t)batch * c->Hkv * c->Smax * c->D;
+    int t0 = 0;
+    for (; t0 < Lmax; t0 += Tc) {
+        const int tc = std::min(Tc, Lmax - t0);
+        const int M = tc * Mpad;
+        launch_pf_embed_rmsnorm(c->emb.p, prompt_mat_dev, lens_dev, Lmax, t0, tc, batch, Mpad, c->V, c->norms.p, c->pf_h.p, c->pf_x.p,
+                                c->pf_pos.p, c->pf_on.p, d, eps, s);
+        for (int li = 0; li < c->L; ++li) {
+            launch_gemm_pf(PF_F32, c->pf_x.p, c->wqkv.p + layer_qkv_elems(c) * li, c->pf_qkv.p, M, c->Nqkv, d, s);
+            for (int tl = 0; tl < tc; ++tl) {
+                AttnParams ap{};
+                ap.qkv_part = c->pf_qkv.p + (size_t)tl * Mpad * c->Nqkv; ap.S = 1; ap.Mpad = Mpad; ap.Nqkv = c->Nqkv;
+                ap.kcache = c->kcache.p + lkv * li; ap.vtcache = c->vtcache.p + lkv * li;
+                ap.pos = c->pf_pos.p + (size_t)tl * Mpad; ap.active = c->pf_on.p + (size_t)tl * Mpad;
+                ap.rope_cos = c->rope_cos.p; ap.rope_sin = c->rope_sin.p;
+                ap.out = c->pf_attn.p + (size_t)tl * Mpad * HD; ap.out_ld = HD;
+                ap.H = c->H; ap.Hkv = c->Hkv; ap.D = c->D; ap.Smax = c->Smax; ap.scale = 1.0f / sqrtf((float)c->D);
+                if (c->cfg.qk_norm) {
+                    ap.qnorm_w = c->qknorm.p + (size_t)(2 * li) * c->D;
+                    ap.knorm_w = c->qknorm.p + (size_t)(2 * li + 1) * c->D;
+                    ap.qk_eps = c->cfg.rms_norm_eps;
+                }
+                ap.rope_in_dtype = c->cfg.rope_ops_in_dtype;
+                launch_attn_decode(ap, batch, s);
+            }
+            launch_gemm_pf(PF_RESID, c->pf_attn.p, c->wo.p + layer_o_elems(c) * li, c->pf_h.p, M, d, HD, s);
+            launch_pf_rmsnorm(c->pf_h.p, c->norms.p + (size_t)(2 * li + 1) * d, c->pf_x.p, M, d, eps, s);
+            launch_gemm_pf(PF_SILU, c->pf_x.p, c->wgu.p + layer_gu_elems(c) * li, c->pf_act.p, M, 2 * c->ff, d, s);
+            launch_gemm_pf(PF_RESID, c->pf_act.p, c->wdown.p + layer_down_elems(c) * li, c->pf_h.p, M, d, c->ff, s);
+            const bf16_t* next_norm = c->norms.p + (size_t)(li + 1 < c->L ? 2 * (li + 1) : 2 * c->L) * d;
+            launch_pf_rmsnorm(c->pf_h.p, next_norm, c->pf_x.p, M, d, eps, s);
+        }
+        if (t0 + tc >= Lmax)                                                 // left-padded prompts: every row's last token is position Lmax - 1
+            launch_pf_pack_rows(c->pf_x.p + (size_t)(tc - 1) * Mpad * d, c->x.p, Mpad, d, s);
+    }
+    std::vector<int32_t> pn(Mpad, 0), pc(Mpad, 0);
+    for (int b = 0; b < batch; ++b) { pn[b] = lens[b]; pc[b] = lens[b] - 1; }
+    HIP_CHECK(hipMemcpyAsync(c->pos_next.p, pn.data(), (size_t)Mpad * 4, hipMemcpyHostToDevice, s));
+    HIP_CHECK(hipMemcpyAsync(c->pos_cur.p, pc.data(), (size_t)Mpad * 4, hipMemcpyHostToDevice, s));
+    HIP_CHECK(hipGetLastError());
+    HIP_CHECK(hipStreamSynchronize(s));                                      // pn / pc are host stack memory
+}
+
 extern "C" mis_status mis_lm_reset(mis_tts* c, int batch, int max_context) {
     MIS_API_BEGIN
     MIS_REQUIRE(c, MIS_ERR_INVALID_INPUT, "null handle");
@@ -685,6 +751,65 @@ extern "C" mis_status mis_lm_forward_hidden(mis_tts* c, const int32_t* ids, cons
         size_t n = (size_t)c->batch * c->V;
         hipLaunchKernelGGL(k_bf16_rows_to_f32, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, c->logits.p, c->Vpad,
                            c->logits_f32.p, c->V, c->batch);
+        HIP_CHECK(hipMemcpyAsync(logits_out, c->logits_f32.p, n * 4, hipMemcpyDefault, s));
+    }
+    HIP_CHECK(hipGetLastError());
+    HIP_CHECK(hipStreamSynchronize(s));
+    MIS_API_END
+}
+
+// The prefill call of the reference loop as an entry point (`model(inputIds, cache:)`, LlamaTTS.swift:711): prompts (ragged, flat
+// + lens) through the model with empty caches; logits_out f32 [batch, vocab] (nullable) = logits of the NEXT token of every row.
+// The caches then hold the prompts and mis_lm_forward continues behind them.  Runs the batched path when the model allows it
+// (dense weights, dimensions multiples of 64), else position by position; MIS_PREFILL_SEQ=1 forces the latter.
+extern "C" mis_status mis_lm_prefill(mis_tts* c, const int32_t* prompt_ids, const int32_t* prompt_lens, int batch, int max_context,
+                                     float* logits_out) {
+    MIS_API_BEGIN
+    MIS_REQUIRE(c && prompt_ids && prompt_lens && batch >= 1, MIS_ERR_INVALID_INPUT, "bad argument");
+    MIS_REQUIRE(c->finalized, MIS_ERR_NOT_INITIALIZED, "model not finalized");
+    HIP_CHECK(hipSetDevice(c->device));
+    hipStream_t s = c->stream;
+    std::vector<int32_t> lens(batch);
+    HIP_CHECK(hipMemcpy(lens.data(), prompt_lens, batch * 4, hipMemcpyDefault));
+    int Lmax = 0;
+    size_t total = 0;
+    for (int b = 0; b < batch; ++b) {
+        MIS_REQUIRE(lens[b] >= 1, MIS_ERR_INVALID_INPUT, "empty prompt in row %d", b);
+        Lmax = std::max(Lmax, lens[b]); total += lens[b];
+    }
+    std::vector<int32_t> flat(total);
+    HIP_CHECK(hipMemcpy(flat.data(), prompt_ids, total * 4, hipMemcpyDefault));
+    for (auto t : flat) MIS_REQUIRE(t >= 0 && t < c->V, MIS_ERR_INVALID_INPUT, "prompt token %d outside the vocabulary", t);
+    lm_reset(c, batch, std::max(max_context, Lmax + 1));
+    std::vector<int32_t> pm((size_t)batch * Lmax, 0);
+    {
+        size_t off = 0;
+        for (int b = 0; b < batch; ++b) {
+            for (int j = 0; j < lens[b]; ++j) pm[(size_t)b * Lmax + (Lmax - lens[b]) + j] = flat[off + j];
+            off += lens[b];
+        }
+    }
+    c->prompt_mat.alloc(pm.size()); c->prompt_lens.alloc(batch); c->step_counter.alloc(1);
+    HIP_CHECK(hipMemcpyAsync(c->prompt_mat.p, pm.data(), pm.size() * 4, hipMemcpyHostToDevice, s));
+    HIP_CHECK(hipMemcpyAsync(c->prompt_lens.p, lens.data(), batch * 4, hipMemcpyHostToDevice, s));
+    c->step_counter.zero(s);
+    HIP_CHECK(hipStreamSynchronize(s));
+    if (prefill_batched_ok(c, Lmax)) prefill_batched(c, c->prompt_mat.p, c->prompt_lens.p, lens, Lmax);
+    else
+        for (int j = 0; j < Lmax; ++j) {
+            launch_prefill_feed(c->prompt_mat.p, c->prompt_lens.p, Lmax, c->step_counter.p, c->ids.p, c->active.p, batch, s);
+            enqueue_layers(c);
+        }
+    {
+        std::vector<uint8_t> ones(batch, 1);
+        HIP_CHECK(hipMemcpyAsync(c->active.p, ones.data(), batch, hipMemcpyHostToDevice, s));
+        HIP_CHECK(hipStreamSynchronize(s));
+    }
+    if (logits_out) {
+        enqueue_lm_head(c);
+        const size_t n = (size_t)batch * c->V;
+        c->logits_f32.alloc(n);
+        hipLaunchKernelGGL(k_bf16_rows_to_f32, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, c->logits.p, c->Vpad, c->logits_f32.p, c->V, batch);
         HIP_CHECK(hipMemcpyAsync(logits_out, c->logits_f32.p, n * 4, hipMemcpyDefault, s));
     }
     HIP_CHECK(hipGetLastError());
@@ -917,9 +1042,14 @@ static void run_generate(mis_tts* c, const int32_t* prompt_ids, const int32_t* p
     auto t_host0 = std::chrono::steady_clock::now();
     HIP_CHECK(hipEventRecord(ev[0], s));
     // ---- prefill: Lmax steps of the ragged, left-padded batch (prefill :711)
-    if (c->use_graph && !c->g_prefill) capture(&c->g_prefill, prefill_body);
-    for (int j = 0; j < Lmax; ++j) {
-        if (c->use_graph) HIP_CHECK(hipGraphLaunch(c->g_prefill, s)); else prefill_body();
+    if (prefill_batched_ok(c, Lmax)) {
+        prefill_batched(c, c->prompt_mat.p, c->prompt_lens.p, lens, Lmax);
+        collect(1);
+    } else {
+        if (c->use_graph && !c->g_prefill) capture(&c->g_prefill, prefill_body);
+        for (int j = 0; j < Lmax; ++j) {
+            if (c->use_graph) HIP_CHECK(hipGraphLaunch(c->g_prefill, s)); else prefill_body();
+        }
     }
     HIP_CHECK(hipEventRecord(ev[1], s));
     // after the last prompt token every row is active

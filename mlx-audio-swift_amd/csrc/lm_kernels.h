@@ -38,6 +38,14 @@ void launch_gemm_skinny_q(int bits, int epi, int R, int ksb, const void* Qp, con
 void launch_pack_qweight(int bits, const uint32_t* wq, const bf16_t* scales, const bf16_t* biases, void* qdst, bf16_t* sbdst, int N, int K,
                          int tile_stride, int tile_offset, hipStream_t s);
 
+// batched prefill (lm_prefill.hip): M = positions x rows
+enum { PF_F32 = 0, PF_RESID = 1, PF_SILU = 2 };
+void launch_gemm_pf(int epi, const bf16_t* X, const bf16_t* Wp, void* C, int M, int N, int K, hipStream_t s);
+void launch_pf_embed_rmsnorm(const bf16_t* emb, const int32_t* prompt, const int32_t* lens, int Lmax, int t0, int Tc, int batch, int Mpad, int vocab,
+                             const bf16_t* wnorm, bf16_t* h, bf16_t* x, int32_t* pos_tab, uint8_t* act_tab, int d, float eps, hipStream_t s);
+void launch_pf_rmsnorm(const bf16_t* h, const bf16_t* wnorm, bf16_t* x, int rows, int d, float eps, hipStream_t s);
+void launch_pf_pack_rows(const bf16_t* rows, bf16_t* xpk, int Mpad, int d, hipStream_t s);
+
 // split-K factor of a weight-streaming GEMM (items = n-tile groups, KT = k-tiles, ksb = waves per item), see the definition
 int gemm_choose_split(int items, int KT, int ksb, int s_max);
 
@@ -56,7 +64,8 @@ struct AttnParams {
     int rope_in_dtype;       // 1: T(T(x cos) + T(rot(x) sin)) with cos/sin rounded to bf16 (Qwen3-TTS)
     int cross;               // 1: cross attention - queries only, no append, keys 0..cross_len-1 of the given caches
     int cross_len;
-    bf16_t* out;             // [Mpad][H*D]
+    bf16_t* out;             // [Mpad][H*D] as packed MFMA-B fragments (out_ld == 0) or row-major with row stride out_ld
+    int out_ld;
     int H, Hkv, D, Smax;
     float scale;
     unsigned long long* dbg; // phase timestamps (MIS_ATTN_TIMING builds only), else null

@@ -233,6 +233,9 @@ __device__ __forceinline__ float block_sum_1024(float v, float* red) {
     __syncthreads();
     return t;
 }
+// SG = slabs fetched per round trip (2, 4 or 8 >= S where possible): the loads are unconditional on clamped slab indices, so a
+// fixed 8 cost the S = 2 launches (o_proj) 18 redundant load instructions per thread
+template <int SG>
 __global__ void __launch_bounds__(RR_THREADS) k_reduce_residual_rmsnorm(const float* __restrict__ slabs, int S,
                                                                         int Mpad, int N, bf16_t* __restrict__ h,
                                                                         const bf16_t* __restrict__ wnorm,
@@ -259,10 +262,10 @@ __global__ void __launch_bounds__(RR_THREADS) k_reduce_residual_rmsnorm(const fl
             hv[k] = bf16_to_f32(h[(size_t)m * N + ic]);
             wv[k] = bf16_to_f32(wnorm[ic]);
         }
-        for (int s0 = 0; s0 < S; s0 += 8) {     // 8 slabs x RR_MAXC columns: one round trip (slabs come from HBM/MALL:
-            float v[8][RR_MAXC];                // the producer's L2 lines were written back at the kernel boundary)
+        for (int s0 = 0; s0 < S; s0 += SG) {    // SG slabs x RR_MAXC columns: one round trip (slabs come from HBM/MALL:
+            float v[SG][RR_MAXC];               // the producer's L2 lines were written back at the kernel boundary)
 #pragma unroll
-            for (int j = 0; j < 8; ++j)
+            for (int j = 0; j < SG; ++j)
 #pragma unroll
                 for (int k = 0; k < RR_MAXC; ++k) {
                     int i = c0 + tid + k * RR_THREADS;
@@ -271,7 +274,7 @@ __global__ void __launch_bounds__(RR_THREADS) k_reduce_residual_rmsnorm(const fl
                     v[j][k] = slabs[((size_t)sj * Mpad + m) * N + ic];
                 }
 #pragma unroll
-            for (int j = 0; j < 8; ++j)        // slab order s = 0,1,2,... (fixed => deterministic)
+            for (int j = 0; j < SG; ++j)       // slab order s = 0,1,2,... (fixed => deterministic)
 #pragma unroll
                 for (int k = 0; k < RR_MAXC; ++k) acc[k] += (s0 + j < S) ? v[j][k] : 0.0f;
         }
@@ -335,8 +338,9 @@ __global__ void __launch_bounds__(RR_THREADS) k_reduce_residual_rmsnorm(const fl
 }
 void launch_reduce_residual_rmsnorm(const float* slabs, int S, int Mpad, int N, bf16_t* h, const bf16_t* wnorm,
                                     bf16_t* x, float eps, hipStream_t s, const bf16_t* ln_bias) {
-    hipLaunchKernelGGL(k_reduce_residual_rmsnorm, dim3(Mpad), dim3(RR_THREADS), 0, s, slabs, S, Mpad, N, h, wnorm, x, eps,
-                       ln_bias);
+    if (S <= 2) hipLaunchKernelGGL((k_reduce_residual_rmsnorm<2>), dim3(Mpad), dim3(RR_THREADS), 0, s, slabs, S, Mpad, N, h, wnorm, x, eps, ln_bias);
+    else if (S <= 4) hipLaunchKernelGGL((k_reduce_residual_rmsnorm<4>), dim3(Mpad), dim3(RR_THREADS), 0, s, slabs, S, Mpad, N, h, wnorm, x, eps, ln_bias);
+    else hipLaunchKernelGGL((k_reduce_residual_rmsnorm<8>), dim3(Mpad), dim3(RR_THREADS), 0, s, slabs, S, Mpad, N, h, wnorm, x, eps, ln_bias);
 }
 
 // ============================================================================ weight-streaming skinny GEMM
@@ -962,7 +966,9 @@ __global__ void __launch_bounds__(512) k_attn_decode(AttnParams p) {
             num += f * sO[((size_t)w * G + head) * D + d];
             den += f * sl[w * 16 + head];
         }
-        p.out[xpk_index(b, (kvh * G + head) * D + d, p.Mpad >> 4)] = f32_to_bf16(num / den);   // packed o_proj operand
+        const bf16_t ov = f32_to_bf16(num / den);
+        if (p.out_ld) p.out[(size_t)b * p.out_ld + (kvh * G + head) * D + d] = ov;            // row-major (batched prefill)
+        else p.out[xpk_index(b, (kvh * G + head) * D + d, p.Mpad >> 4)] = ov;                 // packed o_proj operand
     }
     ATT_STAMP(7);
 }
