@@ -226,10 +226,12 @@ void       mis_tts_destroy(mis_tts*);
 mis_status mis_lm_reset(mis_tts*, int batch, int max_context);
 /* the prefill call of the reference loop, `model(inputIds, cache:)` (LlamaTTS.swift:711): ragged prompts (flat ids + lens) through
  * the model with empty caches as ONE [positions x rows] pass of MFMA GEMMs (csrc/lm_prefill.hip) - position by position only for
- * natively quantised roles or MIS_PREFILL_SEQ=1.  logits_out f32 [batch, vocab] (nullable): the next-token logits of every row.
- * The caches then hold the prompts; mis_lm_forward continues behind them.  mis_tts_generate* prefill the same way. */
+ * natively quantised roles or MIS_PREFILL_SEQ=1.  logits_out f32 [batch, vocab] (nullable): the next-token logits of every row;
+ * hidden_out f32 [batch, hidden] (nullable): model.norm(h) of every row's last prompt token (Soprano's first decoder input,
+ * Soprano.swift:824-825).  The caches then hold the prompts; mis_lm_forward continues behind them.  mis_tts_generate* prefill the
+ * same way. */
 mis_status mis_lm_prefill(mis_tts*, const int32_t* prompt_ids, const int32_t* prompt_lens, int batch, int max_context,
-                          float* logits_out);
+                          float* logits_out, float* hidden_out);
 mis_status mis_lm_forward(mis_tts*, const int32_t* ids, const uint8_t* active, float* logits_out);
 /* same, also returning model.norm(h) of the fed token: hidden_out f32 [batch, hidden_size] (Soprano decodes these,
  * Soprano.swift:254-275); either output may be NULL */

@@ -143,7 +143,7 @@ SYMBOLS = {
     "mis_tts_load": (C.c_int, [C.c_char_p, _P, C.c_int, C.POINTER(_P)]),
     "mis_tts_create": (C.c_int, [C.POINTER(LmConfigC), _P, C.c_int, C.POINTER(_P)]),
     "mis_tts_set_tensor": (C.c_int, [_P, C.c_char_p, _P, C.c_int, C.POINTER(C.c_int64), C.c_int]),
-    "mis_lm_prefill": (C.c_int, [_P, _P, _P, C.c_int, C.c_int, _P]),
+    "mis_lm_prefill": (C.c_int, [_P, _P, _P, C.c_int, C.c_int, _P, _P]),
     "mis_tts_native_quant_bits": (C.c_int, [_P, C.c_int]),
     "mis_tts_init_synthetic_quantized": (C.c_int, [_P, C.c_uint64, C.c_int]),
     "mis_tts_set_tensor_quantized": (C.c_int, [_P, C.c_char_p, _P, _P, _P, C.c_int, C.c_int64, C.c_int64, C.c_int, C.c_int]),

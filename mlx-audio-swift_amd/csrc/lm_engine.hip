@@ -763,7 +763,7 @@ extern "C" mis_status mis_lm_forward_hidden(mis_tts* c, const int32_t* ids, cons
 // The caches then hold the prompts and mis_lm_forward continues behind them.  Runs the batched path when the model allows it
 // (dense weights, dimensions multiples of 64), else position by position; MIS_PREFILL_SEQ=1 forces the latter.
 extern "C" mis_status mis_lm_prefill(mis_tts* c, const int32_t* prompt_ids, const int32_t* prompt_lens, int batch, int max_context,
-                                     float* logits_out) {
+                                     float* logits_out, float* hidden_out) {
     MIS_API_BEGIN
     MIS_REQUIRE(c && prompt_ids && prompt_lens && batch >= 1, MIS_ERR_INVALID_INPUT, "bad argument");
     MIS_REQUIRE(c->finalized, MIS_ERR_NOT_INITIALIZED, "model not finalized");
@@ -803,6 +803,13 @@ extern "C" mis_status mis_lm_prefill(mis_tts* c, const int32_t* prompt_ids, cons
     {
         std::vector<uint8_t> ones(batch, 1);
         HIP_CHECK(hipMemcpyAsync(c->active.p, ones.data(), batch, hipMemcpyHostToDevice, s));
+        HIP_CHECK(hipStreamSynchronize(s));
+    }
+    if (hidden_out) {                                                        // model.norm(h) of every row's last prompt token
+        const size_t n = (size_t)batch * c->d;
+        c->logits_f32.alloc(std::max(n, c->logits_f32.n));
+        hipLaunchKernelGGL(k_unpack_x_f32, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, c->x.p, c->logits_f32.p, c->d, batch, c->Mpad / 16);
+        HIP_CHECK(hipMemcpyAsync(hidden_out, c->logits_f32.p, n * 4, hipMemcpyDefault, s));
         HIP_CHECK(hipStreamSynchronize(s));
     }
     if (logits_out) {

@@ -410,6 +410,7 @@ __global__ void __launch_bounds__(SN_NT) k_samp_narrow(SamplerParams p) {
     __shared__ u64 sh[SN_NT / 64];
     __shared__ float redf[SN_NT / 64];
     __shared__ int redi[SN_NT / 64];
+    __shared__ int swin[SN_NT];
     __shared__ unsigned s_bin, s_bin2;
     __shared__ u64 s_below;
     __shared__ int s_token;
@@ -434,10 +435,16 @@ __global__ void __launch_bounds__(SN_NT) k_samp_narrow(SamplerParams p) {
         const int wl = p.window_len[b];
         const int32_t* win = p.window + (size_t)b * p.ctx + (p.ctx - wl);
         const float pen = bf16_round_f32(p.penalty);
+        // the window goes through LDS first: the first-occurrence test below is O(wl) reads per id, and as dependent GLOBAL loads it
+        // was half of this kernel's time (17 us -> see profiles/r02_final_bench_kernel_stats.csv)
+        const bool staged = wl <= SN_NT;
+        if (staged && tid < wl) swin[tid] = win[tid];
+        __syncthreads();
         for (int t = tid; t < wl; t += SN_NT) {
-            const int id = win[t];
+            const int id = staged ? swin[t] : win[t];
             bool first = (id >= 0 && id < p.vocab);
-            for (int j = 0; j < t; ++j) first = first && (win[j] != id);
+            if (staged) { for (int j = 0; j < t; ++j) first = first && (swin[j] != id); }
+            else { for (int j = 0; j < t; ++j) first = first && (win[j] != id); }
             if (first) {
                 const float l = bf16_to_f32(logits[id]);
                 const bf16_t v = f32_to_bf16((l < 0.0f) ? l * pen : __fdiv_rn(l, pen));

@@ -109,7 +109,10 @@ __global__ void __launch_bounds__(256) k_snac_dw(const float* __restrict__ X, fl
 // ---- dense contraction on f32 MFMA ----------------------------------------------------------------
 #define G_BM 64
 #define G_BN 128
-#define G_BK 16
+#define G_BK 16                       // k rows per staged chunk.  32 (twice the MFMA steps per barrier pair, twice the staging registers) was
+                                      // measured and is SLOWER: SNAC decode of the bench 48.6 -> 53.8 ms (profiles/r02_codec_bk_ab.json)
+#define G_AH (G_BK / 16)              // staged A float4 per thread: rows ar + 16 h
+#define G_XH (G_BK / 8)               // staged X float4 per thread: rows xr + 8 h
 
 template <int MODE, bool SNAKE>
 __global__ void __launch_bounds__(256) k_snac_gemm(GemmParams p) {
@@ -133,24 +136,25 @@ __global__ void __launch_bounds__(256) k_snac_gemm(GemmParams p) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[t][r] = 0.0f;
 
-    // staging registers: A: 4 floats / thread, X: 8 floats / thread
-    const int ar = tid >> 4, ac = (tid & 15) * 4;          // A tile row (k), col (m)
-    const int xr = tid >> 5, xc = (tid & 31) * 4;          // X tile rows xr and xr+8, col (n)
-    float ra[4], rx[2][4];
+    // staging registers: A: G_AH float4 / thread, X: G_XH float4 / thread
+    const int ar = tid >> 4, ac = (tid & 15) * 4;          // A tile rows ar + 16 h (k), col (m)
+    const int xr = tid >> 5, xc = (tid & 31) * 4;          // X tile rows xr + 8 h, col (n)
+    float ra[G_AH][4], rx[G_XH][4];
 
     auto load_chunk = [&](int k0) {
-        {   // A^T tile
-            int k = k0 + ar, m = m0 + ac;
+#pragma unroll
+        for (int h = 0; h < G_AH; ++h) {   // A^T tile
+            int k = k0 + ar + 16 * h, m = m0 + ac;
             if (k < p.K && (p.M & 3) == 0 && m + 3 < p.M) {
                 float4 v = *reinterpret_cast<const float4*>(AT + (size_t)k * p.M + m);
-                ra[0] = v.x; ra[1] = v.y; ra[2] = v.z; ra[3] = v.w;
+                ra[h][0] = v.x; ra[h][1] = v.y; ra[h][2] = v.z; ra[h][3] = v.w;
             } else {
 #pragma unroll
-                for (int e = 0; e < 4; ++e) ra[e] = (k < p.K && m + e < p.M) ? AT[(size_t)k * p.M + m + e] : 0.0f;
+                for (int e = 0; e < 4; ++e) ra[h][e] = (k < p.K && m + e < p.M) ? AT[(size_t)k * p.M + m + e] : 0.0f;
             }
         }
 #pragma unroll
-        for (int h = 0; h < 2; ++h) {   // X tile
+        for (int h = 0; h < G_XH; ++h) {   // X tile
             int k = k0 + xr + 8 * h;
             int row = k, shift = 0;
             if (MODE == GEMM_CONVT) { int j = k / p.Cin; row = k - j * p.Cin; shift = q - j; }
@@ -180,9 +184,12 @@ __global__ void __launch_bounds__(256) k_snac_gemm(GemmParams p) {
     load_chunk(0);
     for (int kc = 0; kc < nchunks; ++kc) {
         __syncthreads();
-        *reinterpret_cast<float4*>(&As[ar][ac]) = make_float4(ra[0], ra[1], ra[2], ra[3]);
-        *reinterpret_cast<float4*>(&Xs[xr][xc]) = make_float4(rx[0][0], rx[0][1], rx[0][2], rx[0][3]);
-        *reinterpret_cast<float4*>(&Xs[xr + 8][xc]) = make_float4(rx[1][0], rx[1][1], rx[1][2], rx[1][3]);
+#pragma unroll
+        for (int h = 0; h < G_AH; ++h)
+            *reinterpret_cast<float4*>(&As[ar + 16 * h][ac]) = make_float4(ra[h][0], ra[h][1], ra[h][2], ra[h][3]);
+#pragma unroll
+        for (int h = 0; h < G_XH; ++h)
+            *reinterpret_cast<float4*>(&Xs[xr + 8 * h][xc]) = make_float4(rx[h][0], rx[h][1], rx[h][2], rx[h][3]);
         __syncthreads();
         if (kc + 1 < nchunks) load_chunk((kc + 1) * G_BK);
 #pragma unroll
@@ -332,10 +339,11 @@ __global__ void k_vq_residual(float* __restrict__ r, const int32_t* __restrict__
 // for taps*16 MFMA steps).  A^T row (j*Cin + c), as for the other modes.
 #define CT_XS 224                     // staged columns per row: G_BN + halo (<= 92) + alignment slack (<= 3)
 #define CT_MAXT 7
+#define CT_BK 16                      // input channels per staged chunk (7 tap tiles of 16 x 64 + the halo tile: 43 KB of LDS)
 template <bool RESID>
 __global__ void __launch_bounds__(256) k_conv_taps(GemmParams p) {
-    __shared__ float As[CT_MAXT][G_BK][G_BM];
-    __shared__ float Xs[G_BK][CT_XS];
+    __shared__ float As[CT_MAXT][CT_BK][G_BM];
+    __shared__ float Xs[CT_BK][CT_XS];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
     const int n0 = blockIdx.x * G_BN, m0 = blockIdx.y * G_BM, b = blockIdx.z;
@@ -372,7 +380,7 @@ __global__ void __launch_bounds__(256) k_conv_taps(GemmParams p) {
             const int idx = tid + i * 256;
             const int row = idx / (CT_XS / 4), c4 = (idx - row * (CT_XS / 4)) * 4;
             float v[4] = {0.f, 0.f, 0.f, 0.f};
-            if (row < G_BK && c0 + row < p.Cin && c4 < ncols) {
+            if (row < CT_BK && c0 + row < p.Cin && c4 < ncols) {
                 const float* src = Xb + (size_t)(c0 + row) * p.ldx;
                 const int g = a0 + c4;
                 if (vec && g >= p.x_lo && g + 3 < p.Tin) { float4 t = *reinterpret_cast<const float4*>(src + g); v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w; }
@@ -389,7 +397,7 @@ __global__ void __launch_bounds__(256) k_conv_taps(GemmParams p) {
             rx[i] = make_float4(v[0], v[1], v[2], v[3]);
         }
     };
-    const int nchunks = (p.Cin + G_BK - 1) / G_BK;
+    const int nchunks = (p.Cin + CT_BK - 1) / CT_BK;
     load_chunk(0);
     for (int cc = 0; cc < nchunks; ++cc) {
         __syncthreads();
@@ -402,14 +410,14 @@ __global__ void __launch_bounds__(256) k_conv_taps(GemmParams p) {
         for (int i = 0; i < 4; ++i) {
             const int idx = tid + i * 256;
             const int row = idx / (CT_XS / 4), c4 = (idx - row * (CT_XS / 4)) * 4;
-            if (row < G_BK) *reinterpret_cast<float4*>(&Xs[row][c4]) = rx[i];
+            if (row < CT_BK) *reinterpret_cast<float4*>(&Xs[row][c4]) = rx[i];
         }
         __syncthreads();
-        if (cc + 1 < nchunks) load_chunk((cc + 1) * G_BK);
+        if (cc + 1 < nchunks) load_chunk((cc + 1) * CT_BK);
         for (int j = 0; j < p.taps; ++j) {
             const int xo = off + j * p.dil + wn * 64 + (lane & 31);
 #pragma unroll
-            for (int kk = 0; kk < G_BK; kk += 2) {
+            for (int kk = 0; kk < CT_BK; kk += 2) {
                 float a = As[j][kk + (lane >> 5)][wm * 32 + (lane & 31)];
 #pragma unroll
                 for (int t = 0; t < 2; ++t) {

@@ -314,15 +314,16 @@ class LlamaTTSModel:
         check(_lib.lib().mis_tts_last_timing(self._h, C.byref(t)))
         return {k: getattr(t, k) for k, _ in t._fields_}
 
-    def lm_prefill(self, rows, max_context: int = 0, want_logits: bool = True):
-        """The prefill call `model(inputIds, cache:)` (LlamaTTS.swift:711) for ragged prompts: next-token logits [B, V] (or None);
-        the caches then hold the prompts and lm_forward continues behind them."""
+    def lm_prefill(self, rows, max_context: int = 0, want_logits: bool = True, want_hidden: bool = False):
+        """The prefill call `model(inputIds, cache:)` (LlamaTTS.swift:711) for ragged prompts: next-token logits [B, V] (and / or
+        model.norm(h) of every row's last prompt token [B, d]); the caches then hold the prompts and lm_forward continues behind them."""
         flat, lens = self._flatten(rows)
         B = len(lens)
         out = np.zeros((B, self.configuration.vocab_size), np.float32) if want_logits else None
+        hid = np.zeros((B, self.configuration.hidden_size), np.float32) if want_hidden else None
         check(_lib.lib().mis_lm_prefill(self._h, flat.ctypes.data, lens.ctypes.data, B, int(max_context),
-                                        out.ctypes.data if want_logits else None))
-        return out
+                                        out.ctypes.data if want_logits else None, hid.ctypes.data if want_hidden else None))
+        return (out, hid) if want_hidden else out
 
     def time_gemm(self, which: int, batch: int, iters: int = 20):
         ms, by = C.c_double(), C.c_double()

@@ -88,13 +88,13 @@ def test_soprano_sampler_flavour_matches_oracle():
 
 
 def _teacher_hidden(dev, prompt, toks):
-    """Hidden states the engine's own LM produces for prompt + tokens (B = 1), via the lm_forward tap."""
-    dev.lm.lm_reset(1, 128)
-    out = []
-    for i, t in enumerate(list(prompt) + list(toks)):
+    """Hidden states the engine's own LM produces for prompt + tokens (B = 1): the prompt through the prefill entry (what generate
+    runs: a row's result does not depend on the rows beside it), then one decode step per token via the lm_forward tap."""
+    _, hid0 = dev.lm.lm_prefill([np.asarray(prompt, np.int32)], max_context=128, want_logits=False, want_hidden=True)
+    out = [hid0[0].copy()]
+    for t in toks:
         _, hid = dev.lm.lm_forward(np.asarray([t], np.int32), want_hidden=True)
-        if i >= len(prompt) - 1:
-            out.append(hid[0].copy())
+        out.append(hid[0].copy())
     return np.stack(out)[None]
 
 
