@@ -666,6 +666,10 @@ int gemm_choose_split(int items, int KT, int ksb, int s_max) {
 // the score registers line up with the P.V A-operand, B = Q^T), online softmax in f32, O += P . V with
 // P split into bf16 hi + lo parts (f32-accurate probabilities) and V^T tiles as B operand.  Epilogue:
 // cross-wave log-sum-exp combine through LDS.   (LlamaTTS.swift:235-266; SDPA semantics: oracle/llama.py)
+// Measured alternative (round 2, removed again): waves 1..7 request their first tile at once while WAVE 0 ALONE runs the whole
+// prologue barrier-free, the second tile of a pair requested after the single barrier (counted wait in front of the first tile's
+// math).  Parity-green (103 GPU tests) and slower: 14.24 -> 14.58 us at context 368, bench 173.9 -> 171.1 audio-s/s
+// (profiles/r02_attn_w0_ab.json): the 512-thread prologue is NOT what the K/V stream waits for.
 
 #define ATT_WAVES 8
 
