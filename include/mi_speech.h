@@ -455,8 +455,8 @@ mis_status mis_qwen3tts_sample_logits(int device, const float* logits, int batch
 
 /* ------------------------------------------------------------------------------------------
  * Descript DAC decoder.  Replaces DescriptDAC.decodeFromCodes / decode (Sources/MLXAudioCodecs/Descript/DescriptDAC.swift:
- * 103-160,235-242) and DescriptResidualVectorQuantize.fromCodes (DescriptQuantization.swift:150-163).  Encoder tensors
- * ("encoder.*", "*.in_proj.*") are accepted and ignored (the encode path is not built).
+ * 103-160,235-242), DescriptResidualVectorQuantize.fromCodes (DescriptQuantization.swift:150-163) and, when the checkpoint
+ * carries the encoder tensors ("encoder.*", "*.in_proj.*"), DescriptDAC.encode / encodeAudio (:40-95,216-233,340-345).
  * ---------------------------------------------------------------------------------------- */
 typedef struct mis_dac mis_dac;
 typedef struct {                   /* DescriptDACConfig.swift:3-34; latent_dim resolved (encoder_dim * 2^len(encoder_rates)) */
@@ -472,6 +472,12 @@ mis_status mis_dac_finalize(mis_dac*);
 void       mis_dac_destroy(mis_dac*);
 int64_t    mis_dac_num_samples(const mis_dac*, int n_frames);    /* 250 frames @ [8,5,4,2] -> 80 043 (output_padding 1 per block) */
 mis_status mis_dac_decode_codes(mis_dac*, const int32_t* codes, int batch, int T, float* wav_out);
+/* encode / encodeAudio (DescriptDAC.swift:216-233,340-345; needs the checkpoint's encoder.* and in_proj tensors, else
+ * MIS_ERR_AUDIO_ENCODE): audio f32 [batch, n_samples] is right-padded to the hop length (prod of the encoder strides) ->
+ * codes int32 [batch, nq, padded / hop] with nq = n_quantizers (0 = all; the reference's nQuantizers); z_out (nullable) f32 [batch, latent, T] = the encoder output before the RVQ.
+ * Codebook lookup = nearest L2-normalised code, first index on ties (DescriptQuantization.swift:76-94). */
+int64_t    mis_dac_padded_length(const mis_dac*, int64_t n_samples);
+mis_status mis_dac_encode(mis_dac*, const float* audio, int batch, int64_t n_samples, int n_quantizers, int32_t* codes_out, float* z_out);
 mis_status mis_dac_debug_tap(mis_dac*, const int32_t* codes, int batch, int T, int block, float* out, int64_t capacity,
                              int32_t* channels, int64_t* length);
 

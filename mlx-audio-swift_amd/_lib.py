@@ -226,6 +226,8 @@ SYMBOLS = {
     "mis_dac_finalize": (C.c_int, [_P]),
     "mis_dac_destroy": (None, [_P]),
     "mis_dac_num_samples": (C.c_int64, [_P, C.c_int]),
+    "mis_dac_padded_length": (C.c_int64, [_P, C.c_int64]),
+    "mis_dac_encode": (C.c_int, [_P, _P, C.c_int, C.c_int64, C.c_int, _P, _P]),
     "mis_dac_decode_codes": (C.c_int, [_P, _P, C.c_int, C.c_int, _P]),
     "mis_dac_debug_tap": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, _P, C.c_int64, C.POINTER(C.c_int32), C.POINTER(C.c_int64)]),
     "mis_mel_stream_create": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(_P)]),

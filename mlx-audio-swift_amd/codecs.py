@@ -236,7 +236,8 @@ class DescriptDACConfig:
 
 
 class DescriptDAC:
-    """Decode side of class DescriptDAC (Descript/DescriptDAC.swift:172-245): decode_from_codes.  encode() is not built."""
+    """class DescriptDAC (Descript/DescriptDAC.swift:172-245,334-352): preprocess / encode / encode_audio / decode_from_codes /
+    decode_audio.  The encoder needs the checkpoint's encoder.* and in_proj tensors (error 5 otherwise)."""
 
     def __init__(self, config: DescriptDACConfig, device: int = 0):
         self.config = config
@@ -285,8 +286,44 @@ class DescriptDAC:
         check(_lib.lib().mis_dac_debug_tap(self._h, cd.ctypes.data, B, T, block, buf.ctypes.data, cap, C.byref(ch), C.byref(ln)))
         return buf[: B * ch.value * ln.value].reshape(B, ch.value, ln.value).copy()
 
-    def encode(self, audio):
-        raise AudioGenerationError(5, "DAC encode path is not built")
+    @property
+    def hop_length(self) -> int:
+        return int(np.prod(self.config.encoder_rates))
+
+    def preprocess(self, audio, sample_rate: int | None = None) -> np.ndarray:
+        """DescriptDAC.preprocess (:216-228): right-pad [B, n] to a multiple of the hop length"""
+        if sample_rate is not None and sample_rate != self.config.sample_rate:
+            raise AudioGenerationError(3, f"Sample rate mismatch: {sample_rate} != {self.config.sample_rate}")
+        a = np.ascontiguousarray(audio, dtype=np.float32)
+        pad = -a.shape[1] % self.hop_length
+        return np.pad(a, ((0, 0), (0, pad))) if pad else a
+
+    def encode(self, audio, n_quantizers: int | None = None, return_latent: bool = False):
+        """DescriptDAC.encode (:230-233) on preprocess()ed audio [B, n]: codes int32 [B, nq, n / hop] (+ the encoder output
+        [B, latent, T] before the RVQ when return_latent).  Un-padded input is padded as preprocess() does."""
+        a = np.ascontiguousarray(audio, dtype=np.float32)
+        if a.ndim != 2 or a.shape[1] < 1:
+            raise AudioGenerationError(3, "audio must be [batch, samples]")
+        B, n = a.shape
+        nq = self.config.n_codebooks if n_quantizers is None else int(n_quantizers)
+        if not 1 <= nq <= self.config.n_codebooks:
+            raise AudioGenerationError(3, "n_quantizers out of range")
+        T = int(_lib.lib().mis_dac_padded_length(self._h, n)) // self.hop_length
+        if T < 1:
+            raise AudioGenerationError(5, "this DAC model was loaded without encoder weights")
+        codes = np.zeros((B, nq, T), np.int32)
+        z = np.zeros((B, self.config.resolved_latent, T), np.float32) if return_latent else None
+        check(_lib.lib().mis_dac_encode(self._h, a.ctypes.data, B, n, nq, codes.ctypes.data, z.ctypes.data if return_latent else None))
+        return (codes, z) if return_latent else codes
+
+    def encode_audio(self, waveform) -> dict:
+        """AudioCodecModel.encodeAudio (:340-345): {"codes", "original_length"}"""
+        w = np.ascontiguousarray(waveform, dtype=np.float32)
+        return {"codes": self.encode(self.preprocess(w, self.config.sample_rate)), "original_length": int(w.shape[1])}
+
+    def decode_audio(self, encoded: dict) -> np.ndarray:
+        """AudioCodecModel.decodeAudio (:347-350): decode and trim to the original length"""
+        return self.decode_from_codes(encoded["codes"])[:, : encoded["original_length"]]
 
 
 @dataclass

@@ -33,3 +33,10 @@ struct GemmParams {
 void launch_gemm(int mode, bool snake, const GemmParams& p, int batch, hipStream_t s);
 // depthwise 7-tap conv (zero padded, dilation dil): shorter odd kernels ride in centred 7-tap weights
 void launch_dw7(const float* X, float* Y, const float* w7 /*[C][7]*/, const float* bias, int batch, int C, int T, int dil, hipStream_t s);
+// encoder pieces (SNAC / DAC): first conv k7 "same" 1 -> C (w [C][7]); Snake + phase split for a stride-s conv
+// (y[(c*s + r)][m] = snake(x[c][s*m + r])); nearest code of the L2-normalised latent (first index on ties; cn = normalised codebook
+// [CB][CD], cn2 = its squared norms); residual -= table[code] (table [CB][C], code index t / stride)
+void launch_enc_first(const float* audio, float* y, const float* w, const float* bias, int batch, int C, int T, hipStream_t s);
+void launch_enc_phase_split(const float* x, float* y, const float* a, const float* ra, int batch, int C, int T, int stride, hipStream_t s);
+void launch_vq_nearest(const float* ze, const float* cn, const float* cn2, int32_t* codes, int batch, int CD, int CB, int Tm, hipStream_t s);
+void launch_vq_residual(float* r, const int32_t* codes, const float* table, int batch, int C, int T, int stride, hipStream_t s);

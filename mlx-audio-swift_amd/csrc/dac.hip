@@ -1,4 +1,4 @@
-// dac.hip - Descript DAC decoder (residual-VQ codes -> waveform), float32.
+// dac.hip - Descript DAC codec: decoder (residual-VQ codes -> waveform) and encoder (waveform -> codes), float32.
 //
 // Reference being replaced: DescriptDAC.decodeFromCodes / decode (Sources/MLXAudioCodecs/Descript/DescriptDAC.swift:235-242),
 // DescriptDecoder / DescriptDecoderBlock / DescriptResidualUnit (:7-32,103-160), DescriptResidualVectorQuantize.fromCodes
@@ -6,6 +6,10 @@
 // activations and recomputes the weight norm on every call; here weights are folded once (A^T per tap / per transposed-conv
 // phase, codebook x out_proj tables) and activations stay NCT.  Dense k7 dilated convs run on k_conv_taps, 1x1 convs and the
 // transposed convs on k_snac_gemm (exact-f32 MFMA), Snake fused into the operand loads.
+// Encode (DescriptEncoder / DescriptEncoderBlock :40-95, preprocess + encode :216-233, DescriptVectorQuantize / residual loop
+// DescriptQuantization.swift:54-147): first conv k7, per block 3 residual units (the decoder's: dense dilated k7 on k_conv_taps + 1x1
+// with residual epilogue) then Snake + the stride-s conv (k = 2s, pad ceil(s/2)) as a 3-tap conv over the phase-split tensor, last
+// conv k3; residual VQ: in_proj GEMM, nearest code of the L2-normalised latent (first index on ties), residual -= the decode table row.
 #include "common.h"
 #include "kernels.h"
 #include "codec_kernels.h"
@@ -35,6 +39,18 @@ struct mis_dac {
     int fin_c = 0;
     DevBuf<float> buf[3];
     DevBuf<int32_t> codes_dev;
+    // encoder (optional: built when the checkpoint carries encoder.* / in_proj tensors)
+    bool has_encoder = false;
+    int enc_dim = 0, hop = 1;
+    size_t enc_first_w = 0, enc_first_b = 0;
+    struct EncBlk { RU ru[3]; size_t a, ra; Lin down; int cin, cout, stride; };
+    std::vector<EncBlk> enc_blocks;
+    size_t enc_fin_a = 0, enc_fin_ra = 0;
+    Lin enc_last;
+    struct VqEnc { Lin in_proj; size_t cn, cn2; };
+    std::vector<VqEnc> vq_enc;
+    DevBuf<float> ebuf[3], vq_ze;
+    DevBuf<int32_t> enc_codes;
 };
 
 __global__ void k_dac_embed(const int32_t* __restrict__ codes, const float* __restrict__ tables, float* __restrict__ z, int ncb, int bins,
@@ -108,7 +124,6 @@ extern "C" mis_status mis_dac_set_tensor(mis_dac* c, const char* name_, const vo
         size_t pos;
         while ((pos = name.find(rep.first)) != std::string::npos) name.replace(pos, strlen(rep.first), rep.second);
     }
-    if (name.rfind("encoder.", 0) == 0 || name.find(".inProj.") != std::string::npos) return MIS_OK;     // encode path: not built
     size_t n = 1;
     std::vector<int64_t> sh;
     for (int i = 0; i < ndim; ++i) { MIS_REQUIRE(shape[i] > 0, MIS_ERR_INVALID_INPUT, "bad shape"); n *= (size_t)shape[i]; sh.push_back(shape[i]); }
@@ -219,10 +234,167 @@ extern "C" mis_status mis_dac_finalize(mis_dac* c) {
         c->fin_w = push(w);                                              // [1][7][C] == [7][C]
         c->fin_b = dneed(c, "decoder.model." + std::to_string(n + 2) + ".bias", {1})[0];
     }
+    // ---- encoder (optional): dimensions are read off the tensors
+    c->has_encoder = false;
+    {
+        auto e0 = c->raw_shape.find("encoder.block.0.weight_v");
+        if (e0 != c->raw_shape.end()) {
+            MIS_REQUIRE(e0->second.size() == 3 && e0->second[1] == 7 && e0->second[2] == 1, MIS_ERR_INVALID_INPUT, "bad DAC encoder stem");
+            int64_t ch = e0->second[0];
+            c->enc_dim = (int)ch;
+            {
+                std::vector<float> w = wn("encoder.block.0", ch, 7, 1, 0);          // [C][7][1] == [C][7]
+                c->enc_first_w = push(w); c->enc_first_b = push(dneed(c, "encoder.block.0.bias", {ch}));
+            }
+            c->enc_blocks.clear();
+            c->hop = 1;
+            int li = 1;
+            const int dils[3] = {1, 3, 9};
+            for (;; ++li) {
+                const std::string p = "encoder.block." + std::to_string(li) + ".block";
+                auto dn = c->raw_shape.find(p + ".4.weight_v");
+                if (dn == c->raw_shape.end()) break;
+                MIS_REQUIRE(dn->second.size() == 3 && dn->second[2] == ch && dn->second[1] % 2 == 0, MIS_ERR_INVALID_INPUT, "bad DAC encoder block %d", li);
+                mis_dac::EncBlk E{};
+                E.cin = (int)ch; E.cout = (int)dn->second[0]; E.stride = (int)dn->second[1] / 2;
+                for (int ri = 0; ri < 3; ++ri) {
+                    const std::string q = p + "." + std::to_string(ri) + ".block";
+                    snake(q + ".0.alpha", ch, E.ru[ri].a1, E.ru[ri].ra1);
+                    E.ru[ri].c1 = conv(q + ".1", ch, 7, ch);
+                    snake(q + ".2.alpha", ch, E.ru[ri].a2, E.ru[ri].ra2);
+                    E.ru[ri].c2 = conv(q + ".3", ch, 1, ch);
+                    E.ru[ri].dil = dils[ri];
+                }
+                snake(p + ".3.alpha", ch, E.a, E.ra);
+                {   // WNConv1d(k = 2s, stride s, pad ceil(s/2)) over the phase-split input [ch*s][T/s]:
+                    // y[n] = sum_{q in -1..1} sum_{c,r} W[co][s*q + r + pad][c] * xph[c*s + r][n + q]
+                    const int sdn = E.stride, K = 2 * sdn, pad = (sdn + 1) / 2;
+                    std::vector<float> w = wn(p + ".4", E.cout, K, ch, 0);
+                    std::vector<float> at((size_t)3 * sdn * ch * E.cout, 0.0f);
+                    for (int qi = 0; qi < 3; ++qi)
+                        for (int64_t ci = 0; ci < ch; ++ci)
+                            for (int r = 0; r < sdn; ++r) {
+                                const int j = sdn * (qi - 1) + r + pad;
+                                if (j < 0 || j >= K) continue;
+                                for (int co = 0; co < E.cout; ++co)
+                                    at[(((size_t)qi * ch * sdn) + (size_t)ci * sdn + r) * E.cout + co] = w[((size_t)co * K + j) * ch + ci];
+                            }
+                    E.down.M = E.cout; E.down.K = 3 * sdn * (int)ch; E.down.w = push(at); E.down.b = push(dneed(c, p + ".4.bias", {E.cout}));
+                }
+                c->hop *= E.stride;
+                ch = E.cout;
+                c->enc_blocks.push_back(E);
+            }
+            MIS_REQUIRE(!c->enc_blocks.empty(), MIS_ERR_INVALID_INPUT, "DAC encoder has no blocks");
+            snake("encoder.block." + std::to_string(li) + ".alpha", ch, c->enc_fin_a, c->enc_fin_ra);
+            c->enc_last = conv("encoder.block." + std::to_string(li + 1), D, 3, ch);
+            c->vq_enc.clear();
+            for (int q = 0; q < cf.n_codebooks; ++q) {
+                const std::string p = "quantizer.quantizers." + std::to_string(q);
+                mis_dac::VqEnc v{};
+                v.in_proj = conv(p + ".inProj", cd, 1, D);
+                const auto& cb = dneed(c, p + ".codebook.weight", {bins, cd});
+                std::vector<float> cn((size_t)bins * cd), cn2(bins);
+                for (int64_t k = 0; k < bins; ++k) {                         // descriptNormalize (DescriptQuantization.swift:8-11)
+                    float n2 = 0.0f;
+                    for (int64_t d2 = 0; d2 < cd; ++d2) n2 += cb[k * cd + d2] * cb[k * cd + d2];
+                    const float inv = 1.0f / std::max(sqrtf(n2), 1e-12f);
+                    float s2 = 0.0f;
+                    for (int64_t d2 = 0; d2 < cd; ++d2) { const float x = cb[k * cd + d2] * inv; cn[k * cd + d2] = x; s2 += x * x; }
+                    cn2[k] = s2;
+                }
+                v.cn = push(cn); v.cn2 = push(cn2);
+                c->vq_enc.push_back(v);
+            }
+            c->has_encoder = true;
+        }
+    }
     c->arena.alloc(arena.size());
     HIP_CHECK(hipMemcpy(c->arena.p, arena.data(), arena.size() * 4, hipMemcpyHostToDevice));
     c->raw.clear(); c->raw_shape.clear();
     c->finalized = true;
+    MIS_API_END
+}
+
+// ---- encode: preprocess (right-pad to the hop length, :216-228) + encode (:230-233)
+extern "C" int64_t mis_dac_padded_length(const mis_dac* c, int64_t n_samples) {
+    if (!c || !c->has_encoder || n_samples < 0) return 0;
+    return (n_samples + c->hop - 1) / c->hop * c->hop;
+}
+// audio f32 [batch, n_samples] (host or device) -> codes int32 [batch, nq, T], T = padded_length / hop (host or device), nq = n_quantizers
+// (0 = all codebooks; the reference's nQuantizers, DescriptQuantization.swift:120-147);
+// z_out (nullable) f32 [batch, latent, T]: the encoder output before quantisation
+extern "C" mis_status mis_dac_encode(mis_dac* c, const float* audio, int batch, int64_t n_samples, int n_quantizers, int32_t* codes_out, float* z_out) {
+    MIS_API_BEGIN
+    MIS_REQUIRE(c && audio && codes_out && batch >= 1 && n_samples >= 1, MIS_ERR_INVALID_INPUT, "bad argument");
+    MIS_REQUIRE(c->finalized, MIS_ERR_NOT_INITIALIZED, "DAC model not finalized");
+    MIS_REQUIRE(c->has_encoder, MIS_ERR_AUDIO_ENCODE, "this DAC handle was loaded without encoder weights");
+    MIS_REQUIRE(n_quantizers >= 0 && n_quantizers <= c->cfg.n_codebooks, MIS_ERR_INVALID_INPUT, "n_quantizers out of range");
+    const int nq = n_quantizers ? n_quantizers : c->cfg.n_codebooks;
+    HIP_CHECK(hipSetDevice(c->device));
+    hipStream_t s = c->stream;
+    const mis_dac_config& cf = c->cfg;
+    const float* W = c->arena.p;
+    const int64_t Tp = mis_dac_padded_length(c, n_samples);
+    const int D = c->latent;
+    size_t cap = (size_t)c->enc_dim * Tp;
+    {
+        int64_t T = Tp;
+        for (auto& b : c->enc_blocks) { cap = std::max(cap, (size_t)b.cin * T); T /= b.stride; cap = std::max(cap, (size_t)b.cout * T); }
+        cap = std::max(cap, (size_t)D * T);
+    }
+    cap *= (size_t)batch;
+    for (int i = 0; i < 3; ++i) c->ebuf[i].alloc(cap);
+    DevBuf<float> ain;
+    ain.alloc((size_t)batch * Tp);
+    HIP_CHECK(hipMemsetAsync(ain.p, 0, (size_t)batch * Tp * 4, s));
+    HIP_CHECK(hipMemcpy2DAsync(ain.p, (size_t)Tp * 4, audio, (size_t)n_samples * 4, (size_t)n_samples * 4, batch, hipMemcpyDefault, s));
+    float *x = c->ebuf[0].p, *f1 = c->ebuf[1].p, *f2 = c->ebuf[2].p;
+    int64_t T = Tp;
+    launch_enc_first(ain.p, x, W + c->enc_first_w, W + c->enc_first_b, batch, c->enc_dim, (int)T, s);
+    auto gp = [&](const mis_dac::Lin& L, const float* X, float* Y, int N) {
+        GemmParams g{};
+        g.AT = W + L.w; g.bias = W + L.b; g.X = X; g.Y = Y; g.M = L.M; g.K = L.K; g.N = N; g.Tin = N; g.Tout = N;
+        return g;
+    };
+    for (auto& E : c->enc_blocks) {
+        for (int ri = 0; ri < 3; ++ri) {
+            const auto& R = E.ru[ri];
+            GemmParams g1 = gp(R.c1, x, f1, (int)T);
+            g1.Cin = E.cin; g1.taps = 7; g1.dil = R.dil; g1.pad = 3 * R.dil; g1.alpha = W + R.a1; g1.ralpha = W + R.ra1;
+            launch_gemm(GEMM_TAPS, true, g1, batch, s);
+            GemmParams g2 = gp(R.c2, f1, f2, (int)T);
+            g2.R = x; g2.alpha = W + R.a2; g2.ralpha = W + R.ra2;
+            launch_gemm(GEMM_RESID, true, g2, batch, s);
+            std::swap(x, f2);
+        }
+        MIS_REQUIRE(T % E.stride == 0, MIS_ERR_AUDIO_ENCODE, "internal: length not divisible by the stride");
+        launch_enc_phase_split(x, f1, W + E.a, W + E.ra, batch, E.cin, (int)T, E.stride, s);
+        T /= E.stride;
+        GemmParams g = gp(E.down, f1, f2, (int)T);
+        g.Cin = E.stride * E.cin; g.taps = 3; g.dil = 1; g.pad = 1;
+        launch_gemm(GEMM_TAPS, false, g, batch, s);
+        std::swap(x, f2);
+    }
+    {
+        GemmParams g = gp(c->enc_last, x, f1, (int)T);
+        g.Cin = c->enc_blocks.back().cout; g.taps = 3; g.dil = 1; g.pad = 1; g.alpha = W + c->enc_fin_a; g.ralpha = W + c->enc_fin_ra;
+        launch_gemm(GEMM_TAPS, true, g, batch, s);
+    }
+    float* resid = f1;                                                    // z [B][D][T]
+    if (z_out) HIP_CHECK(hipMemcpyAsync(z_out, resid, (size_t)batch * D * T * 4, hipMemcpyDefault, s));
+    c->vq_ze.alloc((size_t)batch * cf.codebook_dim * T);
+    c->enc_codes.alloc((size_t)batch * T);
+    for (int q = 0; q < nq; ++q) {
+        launch_gemm(GEMM_PLAIN, false, gp(c->vq_enc[q].in_proj, resid, c->vq_ze.p, (int)T), batch, s);
+        launch_vq_nearest(c->vq_ze.p, W + c->vq_enc[q].cn, W + c->vq_enc[q].cn2, c->enc_codes.p, batch, cf.codebook_dim, cf.codebook_size, (int)T, s);
+        HIP_CHECK(hipMemcpy2DAsync(codes_out + (size_t)q * T, (size_t)nq * T * 4, c->enc_codes.p, (size_t)T * 4, (size_t)T * 4, batch,
+                                   hipMemcpyDefault, s));
+        if (q + 1 < nq)                                                    // residual -= out_proj(codebook[code]) (+ bias): the decode table row
+            launch_vq_residual(resid, c->enc_codes.p, W + c->tables + (size_t)q * cf.codebook_size * D, batch, D, (int)T, 1, s);
+        HIP_CHECK(hipStreamSynchronize(s));                                // enc_codes is reused by the next quantizer
+    }
+    HIP_CHECK(hipGetLastError());
     MIS_API_END
 }
 

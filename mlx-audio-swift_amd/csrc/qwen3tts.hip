@@ -163,7 +163,11 @@ extern "C" mis_status mis_qwen3tts_create(const mis_qwen3tts_config* cfg, int de
     c->s = tts_stream(c->talker);
     tts_internal_use_stream(c->pred, c->s);
     HIP_CHECK(hipSetDevice(device));
-    HIP_CHECK(hipStreamCreateWithFlags(&c->s_dec, hipStreamNonBlocking));
+    {   // the decoder stream yields to the frame loop: its kernels fill the gaps of the latency-bound LM chain instead of delaying it
+        int lo = 0, hi = 0;
+        HIP_CHECK(hipDeviceGetStreamPriorityRange(&lo, &hi));           // lo = least priority (numerically largest)
+        HIP_CHECK(hipStreamCreateWithPriority(&c->s_dec, hipStreamNonBlocking, lo));
+    }
     c->G = cfg->num_code_groups; c->d = tc.hidden_size; c->dp = pc.hidden_size; c->th = cfg->text_hidden_size;
     c->Vt = cfg->text_vocab_size; c->Vc = tc.vocab_size; c->Vp = pc.vocab_size; c->VpPad = (int)round_up(c->Vp, 16);
     c->proj = c->d != c->dp;

@@ -923,6 +923,21 @@ void launch_dw7(const float* X, float* Y, const float* w7, const float* bias, in
                        nullptr, nullptr, nullptr, C, T, dil);
 }
 
+// encoder pieces shared with the Descript DAC encoder (dac.hip)
+void launch_enc_first(const float* audio, float* y, const float* w, const float* bias, int batch, int C, int T, hipStream_t s) {
+    hipLaunchKernelGGL(k_enc_first, dim3(cdiv(T, 256), C, batch), dim3(256), 0, s, audio, y, w, bias, C, T);
+}
+void launch_enc_phase_split(const float* x, float* y, const float* a, const float* ra, int batch, int C, int T, int stride, hipStream_t s) {
+    hipLaunchKernelGGL(k_enc_phase_split, dim3(cdiv(T, 256), C, batch), dim3(256), 0, s, x, y, a, ra, C, T, stride);
+}
+void launch_vq_nearest(const float* ze, const float* cn, const float* cn2, int32_t* codes, int batch, int CD, int CB, int Tm, hipStream_t s) {
+    MIS_REQUIRE(CD <= 64, MIS_ERR_INVALID_INPUT, "codebook_dim > 64 unsupported by the nearest-code kernel");
+    hipLaunchKernelGGL(k_vq_nearest, dim3(Tm, batch), dim3(256), 0, s, ze, cn, cn2, codes, CD, CB, Tm);
+}
+void launch_vq_residual(float* r, const int32_t* codes, const float* table, int batch, int C, int T, int stride, hipStream_t s) {
+    hipLaunchKernelGGL(k_vq_residual, dim3(cdiv(T, 256), C, batch), dim3(256), 0, s, r, codes, table, C, T, stride);
+}
+
 void launch_gemm(int mode, bool snake, const GemmParams& p_in, int batch, hipStream_t s) {
     GemmParams p = p_in;
     if (!p.ldx) p.ldx = p.Tin;                                          // dense [B][C][T] tensors unless the caller says otherwise

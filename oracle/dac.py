@@ -1,4 +1,4 @@
-"""Descript DAC decoder (codes -> waveform): CPU restatement of the reference.  Test infrastructure only.
+"""Descript DAC codec (codes -> waveform, and waveform -> codes): CPU restatement of the reference.  Test infrastructure only.
 
 Follows Sources/MLXAudioCodecs/Descript/DescriptDAC.swift:7-160,172-245 (DescriptResidualUnit, DescriptDecoderBlock,
 DescriptDecoder, DescriptDAC.decodeFromCodes), DescriptQuantization.swift:13-24,74-81,150-163 (Snake, decodeCode, fromCodes) and
@@ -108,6 +108,60 @@ class DacOracle:
         with torch.no_grad():
             return self.decode(self.from_codes(codes), stop_after)
 
+    # ---- encode (DescriptDAC.swift:40-95 DescriptEncoderBlock / DescriptEncoder, :216-233 preprocess + encode;
+    # DescriptQuantization.swift:54-94 VectorQuantize: in_proj -> nearest L2-normalised code -> out_proj, :121-147 residual loop)
+    def preprocess(self, audio):
+        """right-pad to a multiple of the hop length (prod(encoder_rates)); audio [B, n] -> [B, 1, n']"""
+        a = torch.as_tensor(np.asarray(audio, F))
+        hop = int(np.prod(self.cfg.encoder_rates))
+        n = a.shape[1]
+        return TF.pad(a, (0, (-n) % hop))[:, None, :]
+
+    def encoder(self, x):
+        cfg = self.cfg
+        h = self.conv("encoder.block.0", x, 3)
+        for bi, s in enumerate(cfg.encoder_rates):
+            p = f"encoder.block.{bi + 1}.block"
+            for ri, dil in enumerate((1, 3, 9)):
+                q = f"{p}.{ri}.block"
+                t = self.conv(q + ".1", _snake(h, self.w[q + ".0.alpha"]), 3 * dil, dil)
+                h = h + self.conv(q + ".3", _snake(t, self.w[q + ".2.alpha"]), 0)
+            w = _wn(self.w[p + ".4.weight_g"], self.w[p + ".4.weight_v"], 0)
+            h = TF.conv1d(_snake(h, self.w[p + ".3.alpha"]), w.permute(0, 2, 1).contiguous(), self.w[p + ".4.bias"], stride=s,
+                          padding=math.ceil(s / 2))
+        n = len(cfg.encoder_rates)
+        return self.conv(f"encoder.block.{n + 2}", _snake(h, self.w[f"encoder.block.{n + 1}.alpha"]), 1)
+
+    def encode(self, audio, n_quantizers=None, return_latent=False, return_margins=False):
+        """audio [B, n] -> codes [B, n_cb, T] int64 (and z [B, latent, T] before quantisation; margins = per (b, q, t) gap between the
+        best and the second-best code's distance: a device may legitimately differ where it is at float32 rounding level)."""
+        with torch.no_grad():
+            z = self.encoder(self.preprocess(audio))
+            resid, codes, margins = z, [], []
+            for i in range(n_quantizers or self.cfg.n_codebooks):
+                p = f"quantizer.quantizers.{i}"
+                ze = self.conv(p + ".inProj", resid, 0)                                   # [B, cd, T]
+                B, cd, T = ze.shape
+                enc = ze.transpose(1, 2).reshape(B * T, cd)
+                cb = self.w[p + ".codebook.weight"]
+                en = enc / torch.clamp(torch.sqrt((enc * enc).sum(1, keepdim=True)), min=1e-12)
+                cn = cb / torch.clamp(torch.sqrt((cb * cb).sum(1, keepdim=True)), min=1e-12)
+                dist = (en * en).sum(1, keepdim=True) - 2 * en @ cn.t() + (cn * cn).sum(1, keepdim=True).t()
+                idx = torch.argmax(-dist, dim=1)
+                top2 = torch.topk(-dist, 2, dim=1).values
+                margins.append((top2[:, 0] - top2[:, 1]).reshape(B, T))
+                idx = idx.reshape(B, T)
+                codes.append(idx)
+                zq = self.conv(p + ".outProj", cb[idx].transpose(1, 2), 0)
+                resid = resid - zq
+            out = torch.stack(codes, 1).numpy()
+            res = [out]
+            if return_latent:
+                res.append(z.numpy())
+            if return_margins:
+                res.append(torch.stack(margins, 1).numpy())
+            return res[0] if len(res) == 1 else tuple(res)
+
 
 def make_synthetic_weights(cfg: DacConfig, seed: int = 808) -> dict:
     from . import synth
@@ -147,4 +201,23 @@ def make_synthetic_weights(cfg: DacConfig, seed: int = 808) -> dict:
     n, cl = len(cfg.decoder_rates), cfg.decoder_dim >> len(cfg.decoder_rates)
     W[f"decoder.model.{n + 1}.alpha"] = t((1, 1, cl), 0.75, 1.25)
     wn(f"decoder.model.{n + 2}", 1, 7, cl, gain=0.5)
+    # encoder + in_proj (keys after DescriptDAC.sanitize)
+    ch = cfg.encoder_dim
+    wn("encoder.block.0", ch, 7, 1, gain=1.5)
+    for bi, s in enumerate(cfg.encoder_rates):
+        p = f"encoder.block.{bi + 1}.block"
+        for ri in range(3):
+            q = f"{p}.{ri}.block"
+            W[q + ".0.alpha"] = t((1, 1, ch), 0.75, 1.25)
+            wn(q + ".1", ch, 7, ch, gain=0.7)
+            W[q + ".2.alpha"] = t((1, 1, ch), 0.75, 1.25)
+            wn(q + ".3", ch, 1, ch, gain=0.3)
+        W[p + ".3.alpha"] = t((1, 1, ch), 0.75, 1.25)
+        wn(p + ".4", 2 * ch, 2 * s, ch, gain=1.2)
+        ch *= 2
+    m = len(cfg.encoder_rates)
+    W[f"encoder.block.{m + 1}.alpha"] = t((1, 1, ch), 0.75, 1.25)
+    wn(f"encoder.block.{m + 2}", D, 3, ch, gain=1.5)
+    for i in range(cfg.n_codebooks):
+        wn(f"quantizer.quantizers.{i}.inProj", cfg.codebook_dim, 1, D, gain=1.5)
     return W

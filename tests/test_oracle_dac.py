@@ -95,3 +95,66 @@ def test_decoder_matches_hf_transformers_away_from_the_right_edge():
     n = y_hf.shape[1] - 260                                                          # right-edge influence of the missing samples
     assert n > 300
     np.testing.assert_allclose(y[:, :n], y_hf[:, :n], rtol=1e-4, atol=2e-5)
+
+
+def test_encoder_and_rvq_encode_match_hf_transformers():
+    """Independent implementation for the encode side: HF DacModel.encoder / quantizer with the oracle's weights.  The encoder output
+    agrees to float tolerance; codes agree wherever the oracle's top-2 distance margin is not a rounding-level tie."""
+    from transformers import DacConfig as HFC, DacModel
+    cfg = od.DacConfig(encoder_dim=4, encoder_rates=(3, 5), latent_dim=24, decoder_dim=48, decoder_rates=(5, 3), n_codebooks=3,
+                       codebook_size=32, codebook_dim=8)
+    hc = HFC(encoder_hidden_size=4, downsampling_ratios=[3, 5], decoder_hidden_size=48, upsampling_ratios=[5, 3], n_codebooks=3,
+             codebook_size=32, codebook_dim=8, hidden_size=24, sampling_rate=16000)
+    hf = DacModel(hc).eval()
+    W = od.make_synthetic_weights(cfg, seed=5)
+    o = od.DacOracle(cfg, W)
+    sd = hf.state_dict()
+
+    def put(hf_name, p):
+        w = od._wn(o.w[p + ".weight_g"], o.w[p + ".weight_v"], 0).permute(0, 2, 1).contiguous()
+        assert sd[hf_name + ".weight"].shape == w.shape, (hf_name, p)
+        sd[hf_name + ".weight"] = w
+        sd[hf_name + ".bias"] = o.w[p + ".bias"]
+
+    put("encoder.conv1", "encoder.block.0")
+    for bi in range(2):
+        p = f"encoder.block.{bi + 1}.block"
+        for ri in range(3):
+            q, h = f"{p}.{ri}.block", f"encoder.block.{bi}.res_unit{ri + 1}"
+            sd[h + ".snake1.alpha"] = o.w[q + ".0.alpha"].reshape(1, -1, 1)
+            put(h + ".conv1", q + ".1")
+            sd[h + ".snake2.alpha"] = o.w[q + ".2.alpha"].reshape(1, -1, 1)
+            put(h + ".conv2", q + ".3")
+        sd[f"encoder.block.{bi}.snake1.alpha"] = o.w[p + ".3.alpha"].reshape(1, -1, 1)
+        put(f"encoder.block.{bi}.conv1", p + ".4")
+    sd["encoder.snake1.alpha"] = o.w["encoder.block.3.alpha"].reshape(1, -1, 1)
+    put("encoder.conv2", "encoder.block.4")
+    for i in range(3):
+        p = f"quantizer.quantizers.{i}"
+        sd[f"{p}.codebook.weight"] = o.w[p + ".codebook.weight"]
+        put(f"{p}.in_proj", p + ".inProj")
+        put(f"{p}.out_proj", p + ".outProj")
+    hf.load_state_dict(sd)
+    rng = np.random.default_rng(3)
+    audio = (0.3 * rng.standard_normal((2, 15 * 40))).astype(np.float32)
+    codes, z, margins = o.encode(audio, return_latent=True, return_margins=True)
+    with torch.no_grad():
+        z_hf = hf.encoder(torch.from_numpy(audio)[:, None])
+        codes_hf = hf.quantizer(z_hf)[1].numpy()
+    assert z.shape == z_hf.shape == (2, 24, 40)
+    np.testing.assert_allclose(z, z_hf.numpy(), rtol=1e-4, atol=1e-5)
+    assert codes.shape == codes_hf.shape == (2, 3, 40)
+    # a near-tie in an early codebook changes the residual of the later ones: compare up to the first near-tie per frame
+    ok = np.cumprod(margins > 1e-4, axis=1).astype(bool)
+    assert ok.mean() > 0.9 and (codes[ok] == codes_hf[ok]).all()
+
+
+def test_encode_audio_pads_to_the_hop_and_round_trips_shapes():
+    cfg = od.TINY
+    o = od.DacOracle(cfg, od.make_synthetic_weights(cfg))
+    audio = np.random.default_rng(4).standard_normal((2, 37)).astype(np.float32) * 0.2
+    assert o.preprocess(audio).shape == (2, 1, 40)                                   # hop = 4
+    codes = o.encode(audio)
+    assert codes.shape == (2, cfg.n_codebooks, 10) and codes.min() >= 0 and codes.max() < cfg.codebook_size
+    assert o.encode(audio, n_quantizers=2).shape == (2, 2, 10)
+    np.testing.assert_array_equal(o.encode(audio, n_quantizers=2), codes[:, :2])
