@@ -1,0 +1,357 @@
+// codec_bf3.hip - split-bf16 dense contractions for the codec decoders (SNAC / DAC / Qwen3-TTS speech tokenizer / Vocos / EnCodec).
+//
+// The codec weights and activations are f32 (SNAC ships f32 checkpoints; the waveform gate is 1e-4 RMS), and gfx950 has no TF32-like
+// MFMA: exact-f32 MFMA runs at 1/16 of the bf16 rate.  Here every f32 operand is split into two bf16 halves, x = xh + xl with
+// xh = bf16(x), xl = bf16(x - xh) (relative error of the pair <= 2^-18), and a product becomes three bf16 MFMAs accumulated in f32:
+// xh.wh + xh.wl + xl.wh (the lo.lo term, <= 2^-16 of the product, is dropped).  Measured on the CPU emulation of exactly this
+// arithmetic inside the SNAC oracle (tools/bf16x3_emulation.py, profiles/r02_bf16x3_emulation.json): 1.06e-5 RMS on the 24 kHz decode
+// against the 1e-4 gate (plain bf16: 5.7e-3).  The exact-f32 kernels of snac.hip stay: encoders (codebook decisions), small or
+// memory-bound shapes, and MIS_CODEC_EXACT_F32=1.
+//
+// Three kernels:
+//   k_bf3_pack_w   A^T f32 [taps][Cin][M] -> MFMA-A fragments of v_mfma_f32_32x32x16_bf16, hi and lo, [tap][M/32][Cp/16][hl][64][8]
+//                  (once per weight matrix, cached per model in CodecPack)
+//   k_bf3_split    activation pre-pass: (Snake) -> split -> transpose to time-major planes xh, xl [B][Tp][Cp] with zero pads, so that a
+//                  B fragment (8 consecutive channels of one time column) is one aligned 16-byte piece; Snake runs ONCE per element
+//                  (the staged f32 kernels re-run it per 64-row block and per transposed-conv phase)
+//   k_bf3_gemm     128 x 128 output tile per block: 4 MFMA waves (64 x 64 each) + 1 loader wave.  The loader streams the activation
+//                  tile (with its tap halo) by LDS-DMA into an NBUF-deep ring, chunk = 32 channels, running NBUF-1 chunks ahead on its
+//                  OWN vmcnt counter; the MFMA waves take the packed weight fragments straight from L2 into registers (prefetched two
+//                  steps ahead) and the activation fragments from LDS (XOR-swizzled at the DMA source, conflict-free ds_read_b128).
+//                  One s_barrier per chunk.  Taps (dense k-tap convs), transposed-conv phases and 1x1 convs share the tile code:
+//                  tap j reads the staged tile at a column offset.
+#include "common.h"
+#include "codec_kernels.h"
+
+#define B3_BM 128
+#define B3_BN 128
+#define B3_KC 32
+#define B3_THREADS 320
+
+typedef __attribute__((address_space(1))) const void* gptr_t;
+typedef __attribute__((address_space(3))) void* lptr_t;
+
+struct Bf3Params {
+    GemmParams g;
+    const uint16_t* wp;
+    const uint16_t* xh;
+    const uint16_t* xl;
+    int mode, ntaps, MT32, KS, Cp, Tp, t_org;
+};
+
+__device__ __forceinline__ float bf3_snake(float x, float a, float ra) {
+    float s = sinf(a * x);
+    return x + ra * (s * s);
+}
+
+// ---- weights: A^T [ntaps][Cin][M] f32 -> fragments --------------------------------------------------------------------------------
+__global__ void k_bf3_pack_w(const float* __restrict__ AT, uint16_t* __restrict__ wp, int ntaps, int Cin, int M, int MT32, int KS) {
+    const size_t total = (size_t)ntaps * MT32 * KS * 512;
+    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x) {
+        const int j = (int)(e & 7), lane = (int)((e >> 3) & 63);
+        size_t r = e >> 9;
+        const int ks = (int)(r % KS); r /= KS;
+        const int mt = (int)(r % MT32);
+        const int tap = (int)(r / MT32);
+        const int m = mt * 32 + (lane & 31), c = ks * 16 + (lane >> 5) * 8 + j;
+        float v = (m < M && c < Cin) ? AT[((size_t)tap * Cin + c) * M + m] : 0.0f;
+        const uint16_t h = f32_to_bf16(v);
+        const uint16_t l = f32_to_bf16(v - bf16_to_f32(h));
+        const size_t o = ((((size_t)tap * MT32 + mt) * KS + ks) * 2) * 512 + (size_t)lane * 8 + j;
+        wp[o] = h;
+        wp[o + 512] = l;
+    }
+}
+
+// ---- activations: x f32 [B][C][ldx] -> planes [B][Tp][Cp] (column t' holds input column t' + t_org; zero outside [x_lo, Tin)) ---------
+__global__ void __launch_bounds__(256) k_bf3_split(const float* __restrict__ X, uint16_t* __restrict__ xh, uint16_t* __restrict__ xl,
+                                                   const float* __restrict__ alpha, const float* __restrict__ ralpha,
+                                                   int C, int ldx, int x_lo, int Tin, int Cp, int Tp, int t_org) {
+    const int tl = threadIdx.x & 63, cg = threadIdx.x >> 6;
+    const int tp = blockIdx.x * 64 + tl, c0 = blockIdx.y * 32 + cg * 8, b = blockIdx.z;
+    if (tp >= Tp) return;
+    const int t = tp + t_org;
+    const bool tin = t >= x_lo && t < Tin;
+    uint32_t hp[4], lp[4];
+#pragma unroll
+    for (int j = 0; j < 8; j += 2) {
+        float v[2];
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            const int c = c0 + j + e;
+            float x = 0.0f;
+            if (tin && c < C) {
+                x = X[((int64_t)b * C + c) * ldx + t];
+                if (alpha) x = bf3_snake(x, alpha[c], ralpha[c]);
+            }
+            v[e] = x;
+        }
+        const uint16_t h0 = f32_to_bf16(v[0]), h1 = f32_to_bf16(v[1]);
+        const uint16_t l0 = f32_to_bf16(v[0] - bf16_to_f32(h0)), l1 = f32_to_bf16(v[1] - bf16_to_f32(h1));
+        hp[j >> 1] = (uint32_t)h0 | ((uint32_t)h1 << 16);
+        lp[j >> 1] = (uint32_t)l0 | ((uint32_t)l1 << 16);
+    }
+    const size_t o = ((size_t)b * Tp + tp) * Cp + c0;
+    *reinterpret_cast<uint4*>(xh + o) = make_uint4(hp[0], hp[1], hp[2], hp[3]);
+    *reinterpret_cast<uint4*>(xl + o) = make_uint4(lp[0], lp[1], lp[2], lp[3]);
+}
+
+// ---- the contraction -----------------------------------------------------------------------------------------------------------------
+struct Bf3A { bf16x8_t v[2][2]; };     // [m tile][hi, lo]
+struct Bf3B { bf16x8_t v[2][2]; };     // [n tile][hi, lo]
+
+template <int NQ, int NBUF, int NTAPS>
+__global__ void __launch_bounds__(B3_THREADS) k_bf3_gemm(Bf3Params P) {
+    constexpr int PLANE = NQ * 512;                       // bf16 per plane: NQ DMA instructions of 1 KiB (16 columns x 32 channels)
+    constexpr int BUF = 2 * PLANE;
+    __shared__ __attribute__((aligned(1024))) uint16_t lds[NBUF * BUF];
+    const GemmParams& p = P.g;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int n0 = blockIdx.x * B3_BN;
+    int b = blockIdx.z, phase = 0, sh0 = 0, dsh = 0, tapbase = 0;
+    if (P.mode == GEMM_CONVT) { b = blockIdx.z / p.s; phase = blockIdx.z - b * p.s; sh0 = (phase + p.pad) / p.s; dsh = -1; tapbase = phase * NTAPS; }
+    else if (P.mode == GEMM_TAPS) { sh0 = -p.pad; dsh = p.dil; }
+    constexpr int ntaps = NTAPS;
+    const int shmin = min(sh0, sh0 + (ntaps - 1) * dsh);
+    const int nchunks = P.Cp / B3_KC;
+
+    if (wave == 4) {
+        // ---- loader: tile column i = input column n0 + shmin + i.  DMA instruction q moves columns 16q .. 16q+15, four lanes per column;
+        // lane slot gs holds channel group gs ^ ((i >> 2) & 3) (the swizzle is on the SOURCE address, the LDS side of a DMA is lane-linear)
+        const int il = lane >> 2, grp = (lane & 3) ^ ((il >> 2) & 3);
+        const size_t col0 = ((size_t)b * P.Tp + (size_t)(n0 + shmin - P.t_org + il)) * P.Cp + grp * 8;
+        const uint16_t* sh = P.xh + col0;
+        const uint16_t* sl = P.xl + col0;
+        const size_t qstride = (size_t)16 * P.Cp;
+        auto issue = [&](int cc, int buf) {
+            const uint16_t* h = sh + cc * B3_KC;
+            const uint16_t* l = sl + cc * B3_KC;
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) {
+                __builtin_amdgcn_global_load_lds((gptr_t)(h + q * qstride), (lptr_t)&lds[buf * BUF + q * 512], 16, 0, 0);
+                __builtin_amdgcn_global_load_lds((gptr_t)(l + q * qstride), (lptr_t)&lds[buf * BUF + PLANE + q * 512], 16, 0, 0);
+            }
+        };
+        for (int c = 0; c < NBUF - 1 && c < nchunks; ++c) issue(c, c);
+        for (int cc = 0; cc < nchunks; ++cc) {
+            // chunk cc must have landed; up to NBUF-2 younger chunks stay in flight
+            if (nchunks - 1 - cc >= NBUF - 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NBUF - 2) * 2 * NQ) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            if (cc + NBUF - 1 < nchunks) issue(cc + NBUF - 1, (cc + NBUF - 1) % NBUF);
+        }
+        return;
+    }
+
+    // ---- MFMA waves: 2 x 2, wave tile 64 rows x 64 columns = 2 x 2 tiles of 32 x 32
+    const int wm = wave >> 1, wn = wave & 1;
+    const int mt0 = blockIdx.y * 4 + wm * 2;
+    if (mt0 >= P.MT32) {                                   // no rows for this wave (M <= 64 in this block row): keep the barrier count
+        for (int cc = 0; cc < nchunks; ++cc) __builtin_amdgcn_s_barrier();
+        return;
+    }
+    f32x16_t acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+
+    // weight stream: step (chunk, tap, ks) -> fragments of both row tiles, hi and lo.  It runs two steps ahead of the MFMAs, across
+    // chunk boundaries (it does not depend on the staged tile).  A second row tile past M re-reads the first (its rows are never
+    // stored).  The body below is three chunks (3 * NST steps) of straight-line code: the weight registers rotate with period 3,
+    // the tile-fragment registers with period 2, every index is a compile-time constant and there is no branch between the MFMAs,
+    // so the waitcnt pass keeps exactly the two younger weight loads in flight (with branches in the body it fell back to vmcnt(0)).
+    constexpr int NST = 2 * NTAPS;
+    const size_t tap_stride = (size_t)P.MT32 * P.KS * 1024, mt_stride = (size_t)P.KS * 1024;
+    const uint16_t* wbase = P.wp + (size_t)lane * 8 + (size_t)tapbase * tap_stride + (size_t)mt0 * mt_stride;
+    const size_t mt1 = (mt0 + 1 < P.MT32) ? mt_stride : 0;
+    const int ncol = wn * 64 + (lane & 31), kgrp = lane >> 5;
+    Bf3A aq[3];
+    Bf3B bq[2];
+    auto loadA = [&](Bf3A& f, int chunk, int tap, int ks) {
+        const uint16_t* q = wbase + (size_t)tap * tap_stride + (size_t)(min(chunk, nchunks - 1) * 2 + ks) * 1024;
+        f.v[0][0] = *reinterpret_cast<const bf16x8_t*>(q);
+        f.v[0][1] = *reinterpret_cast<const bf16x8_t*>(q + 512);
+        f.v[1][0] = *reinterpret_cast<const bf16x8_t*>(q + mt1);
+        f.v[1][1] = *reinterpret_cast<const bf16x8_t*>(q + mt1 + 512);
+    };
+    auto readB = [&](Bf3B& f, const uint16_t* tile, int tap, int ks) {
+        const int toff = sh0 + tap * dsh - shmin;
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni) {
+            const int i = ncol + ni * 32 + toff;
+            const uint16_t* q = tile + i * 32 + (((ks * 2 + kgrp) ^ ((i >> 2) & 3)) * 8);
+            f.v[ni][0] = *reinterpret_cast<const bf16x8_t*>(q);
+            f.v[ni][1] = *reinterpret_cast<const bf16x8_t*>(q + PLANE);
+        }
+    };
+    // three products per tile pair: hi.hi, hi.lo, lo.hi; four independent accumulators between dependent MFMAs
+    auto mfma12 = [&](const Bf3A& A, const Bf3B& B) {
+#pragma unroll
+        for (int term = 0; term < 3; ++term) {
+            const int ta = term == 2 ? 1 : 0, tb = term == 1 ? 1 : 0;
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < 2; ++ni)
+                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A.v[mi][ta], B.v[ni][tb], acc[mi][ni], 0, 0, 0);
+        }
+    };
+    loadA(aq[0], 0, 0, 0);
+    loadA(aq[1], 0, 0, 1);
+    const uint16_t* tile = lds;
+    int cc = 0;
+    for (; cc + 3 <= nchunks; cc += 3) {
+#pragma unroll
+        for (int I = 0; I < 3 * NST; ++I) {
+            const int cg = I / NST, t = I % NST;
+            if (t == 0) {
+                __builtin_amdgcn_s_barrier();
+                tile = lds + ((cc + cg) % NBUF) * BUF;
+                readB(bq[I & 1], tile, 0, 0);
+            }
+            if (t + 1 < NST) readB(bq[(I + 1) & 1], tile, (t + 1) >> 1, (t + 1) & 1);
+            const int J = I + 2;
+            loadA(aq[J % 3], cc + J / NST, (J % NST) >> 1, J & 1);
+            __builtin_amdgcn_sched_barrier(0);              // keep the prefetches HERE: the scheduler otherwise sinks them to their use
+            mfma12(aq[I % 3], bq[I & 1]);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    // tail: one or two chunks, same schedule with a runtime bound (the rotation phase is 0 again here: 3 * NST steps per group)
+    if (cc < nchunks) {
+        const int rem = (nchunks - cc) * NST;
+#pragma unroll
+        for (int I = 0; I < 2 * NST; ++I) {
+            if (I < rem) {
+                const int cg = I / NST, t = I % NST;
+                if (t == 0) {
+                    __builtin_amdgcn_s_barrier();
+                    tile = lds + ((cc + cg) % NBUF) * BUF;
+                    readB(bq[I & 1], tile, 0, 0);
+                }
+                if (t + 1 < NST) readB(bq[(I + 1) & 1], tile, (t + 1) >> 1, (t + 1) & 1);
+                const int J = I + 2;
+                loadA(aq[J % 3], cc + J / NST, (J % NST) >> 1, J & 1);
+                __builtin_amdgcn_sched_barrier(0);
+                mfma12(aq[I % 3], bq[I & 1]);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+    }
+
+    // ---- epilogue (the modes of k_snac_gemm / k_conv_taps).  C/D layout: col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)
+    const float* Xb = p.X + (size_t)b * p.Cin * p.ldx;
+    const bool convt = P.mode == GEMM_CONVT, gelu = P.mode == GEMM_GELU, noise = P.mode == GEMM_NOISE;
+    const float* Rr = (convt || gelu || noise) ? nullptr : p.R;
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni) {
+        const int n = n0 + wn * 64 + ni * 32 + (lane & 31);
+        if (n >= p.N) continue;
+        float nz = 0.0f;
+        if (noise) {
+            if (p.noise) nz = p.noise[(size_t)b * p.N + n];
+            else if (p.noise_rng) {
+                uint64_t row = (uint64_t)(p.row_offset + (p.row_ids ? p.row_ids[b] : b));
+                uint64_t u = mis_splitmix64((p.noise_key ^ (row * 0xD1B54A32D192ED03ull)) + (uint64_t)n);
+                float u1 = ((float)(uint32_t)(u >> 40) + 0.5f) * 5.9604644775390625e-08f;
+                float u2 = ((float)(uint32_t)((u >> 16) & 0xFFFFFF) + 0.5f) * 5.9604644775390625e-08f;
+                nz = sqrtf(-2.0f * logf(u1)) * cosf(6.283185307179586f * u2);
+            }
+        }
+        const int o = convt ? p.s * n + phase : n;
+        if (o >= p.Tout) continue;
+        const bool dupb = convt && n == 0 && p.dup_bias_n0;
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = (mt0 + mi) * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                if (m >= p.M) continue;
+                float v = acc[mi][ni][r];
+                const float bm = p.bias ? p.bias[m] : 0.0f;
+                v += bm;
+                if (dupb) v += bm;
+                const size_t rowo = ((size_t)b * p.M + m) * p.ldy;
+                if (gelu) v = 0.5f * v * (1.0f + erff(v * 0.70710678118654752f));
+                if (Rr) { if (p.scale) v *= p.scale[m]; v += Rr[rowo + n]; }
+                if (noise) v = Xb[(size_t)m * p.ldx + n] + nz * v;
+                p.Y[rowo + o] = v;
+            }
+        }
+    }
+}
+
+// ---- host side ------------------------------------------------------------------------------------------------------------------------
+CodecPack::~CodecPack() {
+    for (auto& e : entries) if (e.wp) (void)hipFree(e.wp);
+}
+
+const CodecPack::Entry& CodecPack::get(const float* at, int ntaps, int Cin, int M, hipStream_t s) {
+    for (auto& e : entries)
+        if (e.at == at && e.ntaps == ntaps && e.Cin == Cin && e.M == M) return e;
+    Entry e{};
+    e.at = at; e.ntaps = ntaps; e.Cin = Cin; e.M = M;
+    e.Cp = (Cin + B3_KC - 1) / B3_KC * B3_KC;
+    e.KS = e.Cp / 16;
+    e.MT32 = (M + 31) / 32;
+    const size_t n = (size_t)ntaps * e.MT32 * e.KS * 1024;
+    HIP_CHECK(hipMalloc((void**)&e.wp, n * sizeof(uint16_t)));
+    hipLaunchKernelGGL(k_bf3_pack_w, dim3((unsigned)std::min<size_t>((n / 2 + 255) / 256, 8192)), dim3(256), 0, s, at, e.wp, ntaps, Cin, M, e.MT32, e.KS);
+    entries.push_back(e);
+    return entries.back();
+}
+
+static thread_local CodecPack* tl_pack = nullptr;
+CodecPackScope::CodecPackScope(CodecPack* p) : prev(tl_pack) { tl_pack = p; }
+CodecPackScope::~CodecPackScope() { tl_pack = prev; }
+
+static int bf3_env(const char* name, int dflt) {
+    const char* v = getenv(name);
+    return v ? atoi(v) : dflt;
+}
+
+bool launch_gemm_bf3(int mode, bool snake, const GemmParams& p_in, int batch, hipStream_t s) {
+    GemmParams p = p_in;
+    if (!p.pack) p.pack = tl_pack;
+    if (!p.pack || bf3_env("MIS_CODEC_EXACT_F32", 0)) return false;
+    const bool one = mode == GEMM_PLAIN || mode == GEMM_GELU || mode == GEMM_RESID || mode == GEMM_NOISE;
+    int ntaps = 1, Cin = p.K, span = 0, t_org = 0, wtaps = 1;
+    if (mode == GEMM_TAPS) { ntaps = p.taps; Cin = p.Cin; span = (p.taps - 1) * p.dil; t_org = -p.pad; wtaps = ntaps; }
+    else if (mode == GEMM_CONVT) {
+        if (p.Cin <= 0 || p.K % p.Cin || p.K / p.Cin > 2) return false;
+        ntaps = p.K / p.Cin;                                         // 2: kernel 2s (overlap-add); 1: kernel = stride (A^T holds one tap)
+        Cin = p.Cin; span = ntaps - 1; wtaps = ntaps * p.s;
+        t_org = p.pad / p.s - (ntaps - 1);                           // phase 0 has the smallest q = (phase + pad) / s
+        if ((p.s - 1 + p.pad) / p.s - p.pad / p.s > 1) return false;
+    } else if (!one) return false;
+    // what pays: MFMA-bound shapes.  A 1x1 conv over few channels is HBM-bound and the pre-pass would only add traffic
+    const int min_k1 = bf3_env("MIS_BF3_MIN_K1", 256), min_k = bf3_env("MIS_BF3_MIN_K", 32);
+    if (one ? Cin < min_k1 : Cin < min_k) return false;
+    if (p.M < 32 || span > 64 || (ntaps != 1 && ntaps != 2 && ntaps != 7)) return false;
+    const CodecPack::Entry& e = p.pack->get(p.AT, wtaps, Cin, p.M, s);
+
+    const int nbx = (p.N + B3_BN - 1) / B3_BN;
+    const int nq = span <= 16 ? 9 : 12;
+    // the transposed conv's phases share one pre-pass: columns from the smallest shift of any phase to the largest
+    const int extra = mode == GEMM_CONVT ? ((p.s - 1 + p.pad) / p.s - p.pad / p.s) : 0;
+    const int Tp = (nbx - 1) * B3_BN + nq * 16 + extra;
+    p.pack->xh.alloc((size_t)batch * Tp * e.Cp);
+    p.pack->xl.alloc((size_t)batch * Tp * e.Cp);
+    const bool sn = snake && p.alpha;
+    hipLaunchKernelGGL(k_bf3_split, dim3((Tp + 63) / 64, e.Cp / 32, batch), dim3(256), 0, s, p.X, p.pack->xh.p, p.pack->xl.p,
+                       sn ? p.alpha : nullptr, sn ? p.ralpha : nullptr, Cin, p.ldx, p.x_lo, p.Tin, e.Cp, Tp, t_org);
+    Bf3Params P{};
+    P.g = p; P.g.Cin = Cin;
+    P.wp = e.wp; P.xh = p.pack->xh.p; P.xl = p.pack->xl.p;
+    P.mode = mode; P.ntaps = ntaps; P.MT32 = e.MT32; P.KS = e.KS; P.Cp = e.Cp; P.Tp = Tp; P.t_org = t_org;
+    const int phases = mode == GEMM_CONVT ? p.s : 1;
+    dim3 grid(nbx, (p.M + B3_BM - 1) / B3_BM, batch * phases), block(B3_THREADS);
+    if (ntaps == 1) hipLaunchKernelGGL((k_bf3_gemm<9, 4, 1>), grid, block, 0, s, P);
+    else if (ntaps == 2) hipLaunchKernelGGL((k_bf3_gemm<9, 4, 2>), grid, block, 0, s, P);
+    else if (nq == 9) hipLaunchKernelGGL((k_bf3_gemm<9, 4, 7>), grid, block, 0, s, P);
+    else hipLaunchKernelGGL((k_bf3_gemm<12, 3, 7>), grid, block, 0, s, P);
+    return true;
+}

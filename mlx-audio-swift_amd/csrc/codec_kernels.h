@@ -1,11 +1,34 @@
 // codec_kernels.h - f32 kernels shared by the codec back ends (SNAC decoder, Soprano / Vocos decoder); defined in snac.hip
 #pragma once
 #include "common.h"
+#include <vector>
 
 enum { GEMM_PLAIN = 0, GEMM_RESID = 1, GEMM_NOISE = 2, GEMM_CONVT = 3, GEMM_GELU = 4, GEMM_TAPS = 5 };
 
 // Y[b][m][n] = sum_k A[m][k] X[b][k][n] on v_mfma_f32_32x32x2_f32 (activations NCT, time contiguous)
+// Per-model state of the split-bf16 path (codec_bf3.hip): packed hi/lo weight fragments keyed by the A^T pointer (packed on first use,
+// on the calling stream) and the split-activation scratch planes.  One in-flight call per model handle, as for the rest of the engine.
+struct CodecPack {
+    struct Entry { const float* at; int ntaps, Cin, M, Cp, KS, MT32; uint16_t* wp; };
+    std::vector<Entry> entries;
+    DevBuf<uint16_t> xh, xl;
+    CodecPack() {}
+    CodecPack(const CodecPack&) = delete;
+    CodecPack& operator=(const CodecPack&) = delete;
+    ~CodecPack();
+    const Entry& get(const float* at, int ntaps, int Cin, int M, hipStream_t s);
+};
+
+// Decoders open a scope around their launches: launch_gemm picks the scope's CodecPack up when GemmParams.pack is null.  Encoders
+// (codebook decisions) do not, and stay on the exact-f32 kernels.
+struct CodecPackScope {
+    CodecPack* prev;
+    explicit CodecPackScope(CodecPack* p);
+    ~CodecPackScope();
+};
+
 struct GemmParams {
+    CodecPack* pack;      // non-null: MFMA-bound shapes run as split-bf16 contractions (codec_bf3.hip); null: exact-f32 kernels only
     const float* AT;      // [K][M]   (CONVT: [s][K][M], K = 2*Cin)
     const float* bias;    // [M] or null
     const float* X;       // [B][Kx][Tin]  (Kx = K; CONVT: Cin)
@@ -31,6 +54,8 @@ struct GemmParams {
 };
 // snake: Snake prologue on the X rows (CONVT always runs it: pass alpha = ralpha = zeros for identity)
 void launch_gemm(int mode, bool snake, const GemmParams& p, int batch, hipStream_t s);
+// split-bf16 path; false = shape not eligible (or MIS_CODEC_EXACT_F32=1), nothing launched.  p must have ldx / ldy resolved
+bool launch_gemm_bf3(int mode, bool snake, const GemmParams& p, int batch, hipStream_t s);
 // depthwise 7-tap conv (zero padded, dilation dil): shorter odd kernels ride in centred 7-tap weights
 void launch_dw7(const float* X, float* Y, const float* w7 /*[C][7]*/, const float* bias, int batch, int C, int T, int dil, hipStream_t s);
 // encoder pieces (SNAC / DAC): first conv k7 "same" 1 -> C (w [C][7]); Snake + phase split for a stride-s conv

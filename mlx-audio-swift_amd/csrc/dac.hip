@@ -38,6 +38,7 @@ struct mis_dac {
     float fin_b = 0.0f;
     int fin_c = 0;
     DevBuf<float> buf[3];
+    CodecPack pack;                      // split-bf16 weight fragments + activation scratch (codec_bf3.hip)
     DevBuf<int32_t> codes_dev;
     // encoder (optional: built when the checkpoint carries encoder.* / in_proj tensors)
     bool has_encoder = false;
@@ -401,6 +402,7 @@ extern "C" mis_status mis_dac_encode(mis_dac* c, const float* audio, int batch, 
 // stage 0: waveform; 1 + i: output of decoder block i (tap)
 static const float* dac_run(mis_dac* c, const int32_t* codes_dev, int batch, int T, float* wav_dev, int64_t wav_stride, int stage, int* outC,
                             int64_t* outT) {
+    CodecPackScope pack_scope(&c->pack);
     MIS_REQUIRE(c->finalized, MIS_ERR_NOT_INITIALIZED, "DAC model not finalized");
     const mis_dac_config& cf = c->cfg;
     hipStream_t s = c->stream;

@@ -35,6 +35,7 @@ struct mis_encodec {
     struct Up { Lin ct; int s, cin, cout; std::vector<Res> res; };
     std::vector<Up> ups;
     DevBuf<float> buf[4], hstate;
+    CodecPack pack;                      // split-bf16 weight fragments + activation scratch (codec_bf3.hip)
     DevBuf<int32_t> codes_dev, sync;
 };
 
@@ -296,6 +297,7 @@ extern "C" mis_status mis_encodec_finalize(mis_encodec* c) {
 
 // stage: 0 waveform; 1 conv0; 2 lstm block; 3 + i upsampling block i
 static const float* encodec_run(mis_encodec* c, const int32_t* codes_dev, int nq, int batch, int T, float* wav_dev, int stage, int* outC, int64_t* outT) {
+    CodecPackScope pack_scope(&c->pack);
     MIS_REQUIRE(c->finalized, MIS_ERR_NOT_INITIALIZED, "Encodec model not finalized");
     const mis_encodec_config& cf = c->cfg;
     hipStream_t s = c->stream;

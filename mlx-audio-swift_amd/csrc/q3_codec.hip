@@ -49,6 +49,7 @@ struct mis_q3dec {
     float fin_b = 0.0f;
     int fin_c = 0;
     DevBuf<float> buf[4];
+    CodecPack pack;                      // split-bf16 weight fragments + activation scratch (codec_bf3.hip)
     DevBuf<int32_t> codes_dev;
     // streaming session (resetStreamingState / streamingStep)
     struct Stream {
@@ -464,6 +465,7 @@ static size_t q3dec_hist_floats(const mis_q3dec* d) {
 static const float* q3dec_run(mis_q3dec* d, const int32_t* codes_dev, int64_t cs_b, int64_t cs_q, int64_t cs_t, int batch, int T,
                               float* wav_dev, int64_t wav_stride, int stop_after, int* outC, int64_t* outT, hipStream_t s,
                               mis_q3dec::Stream* st) {
+    CodecPackScope pack_scope(&d->pack);
     MIS_REQUIRE(d->finalized, MIS_ERR_NOT_INITIALIZED, "speech tokenizer not finalized");
     MIS_REQUIRE(!st || stop_after == 0, MIS_ERR_INVALID_INPUT, "decoder taps are a whole-sequence facility");
     const mis_qwen3tts_config& cf = d->cfg;

@@ -522,6 +522,7 @@ struct mis_snac {
 
     // workspaces
     DevBuf<float> buf[3];
+    CodecPack pack;                      // split-bf16 weight fragments + activation scratch (codec_bf3.hip)
     DevBuf<int32_t> codes_ws;
     DevBuf<float> noise_ws;
     size_t act_capacity = 0;
@@ -943,6 +944,7 @@ void launch_gemm(int mode, bool snake, const GemmParams& p_in, int batch, hipStr
     if (!p.ldx) p.ldx = p.Tin;                                          // dense [B][C][T] tensors unless the caller says otherwise
     if (!p.ldy) p.ldy = p.Tout;
     MIS_REQUIRE(p.x_lo <= 0 && p.ldx >= p.Tin, MIS_ERR_GENERATION_FAILED, "bad codec GEMM strides");
+    if (launch_gemm_bf3(mode, snake, p, batch, s)) return;
     int phases = (mode == GEMM_CONVT) ? p.s : 1;
     dim3 grid(cdiv(p.N, G_BN), cdiv(p.M, G_BM), batch * phases), block(256);
     if (mode == GEMM_PLAIN) hipLaunchKernelGGL((k_snac_gemm<GEMM_PLAIN, false>), grid, block, 0, s, p);
@@ -968,6 +970,7 @@ struct NoiseRng { int enabled = 0; uint64_t seed = 0; const int32_t* row_ids = n
 static const float* snac_run(mis_snac* c, const int32_t* const* codes, int batch, int t_coarse,
                              const float* const* noise, const NoiseRng& rng, float* pcm, int64_t pcm_stride,
                              int stop_after, int* outC, int64_t* outT, hipStream_t s) {
+    CodecPackScope pack_scope(&c->pack);
     const mis_snac_config& cf = c->cfg;
     const float* W = c->arena.p;
     int64_t T0 = (int64_t)t_coarse * cf.vq_strides[0];

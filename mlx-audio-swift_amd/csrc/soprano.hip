@@ -27,6 +27,7 @@ struct mis_soprano {
     struct Blk { size_t dw, dwb, lnw, lnb, p1, b1, p2, b2, gamma; };
     std::vector<Blk> blocks;
     DevBuf<float> buf[4];
+    CodecPack pack;                      // split-bf16 weight fragments + activation scratch (codec_bf3.hip)
     DevBuf<float> hidden;
 };
 
@@ -249,6 +250,7 @@ extern "C" int64_t mis_soprano_num_samples(const mis_soprano* c, int n_hidden) {
 // hidden_dev [B][row_stride][C] (first L rows used) -> audio_dev [B][out_stride]
 static void soprano_decode_device(mis_soprano* c, const float* hidden_dev, int64_t row_stride, int batch, int L, float* audio_dev,
                                   int64_t out_stride, hipStream_t s) {
+    CodecPackScope pack_scope(&c->pack);
     MIS_REQUIRE(c->finalized, MIS_ERR_NOT_INITIALIZED, "Soprano model not finalized");
     const mis_soprano_config& cf = c->cfg;
     const int C = cf.lm.hidden_size, d = cf.decoder_dim, inter = cf.decoder_intermediate_dim, nf = cf.n_fft, bins = nf / 2 + 1;

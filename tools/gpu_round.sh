@@ -1,5 +1,5 @@
 set -x
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out
-timeout 600 python -m pytest tests/test_gpu_dac.py tests/test_gpu_qwen3tts.py tests/test_gpu_snac.py -m gpu -q -x 2>&1 | grep -v "^PARITY" | tail -25
-timeout 300 python tools/bench_qwen3tts.py 32 100 16 > gpurun_out/q3_lowprio.log 2>&1; tail -3 gpurun_out/q3_lowprio.log
+timeout 300 python tools/bf3_debug.py > gpurun_out/bf3_debug.txt 2>&1; grep -v "first bad" gpurun_out/bf3_debug.txt | tail -14
+timeout 900 python -m pytest tests/test_gpu_snac.py tests/test_gpu_dac.py tests/test_gpu_encodec.py tests/test_gpu_soprano.py tests/test_gpu_qwen3tts.py tests/test_gpu_fullwidth.py -m gpu -q 2>&1 | grep -v "^PARITY" | tail -12
