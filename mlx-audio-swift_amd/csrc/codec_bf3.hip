@@ -36,13 +36,10 @@ struct Bf3Params {
     const uint16_t* wp;
     const uint16_t* xh;
     const uint16_t* xl;
-    int mode, ntaps, MT32, KS, Cp, Tp, t_org;
+    int mode, ntaps, MT32, KS, Cp, Tp, t_org, nbx, tpb;
 };
 
-__device__ __forceinline__ float bf3_snake(float x, float a, float ra) {
-    float s = sinf(a * x);
-    return x + ra * (s * s);
-}
+__device__ __forceinline__ float bf3_snake(float x, float a, float ra) { return fmaf(ra, mis_sin_sq(a * x), x); }
 
 // ---- weights: A^T [ntaps][Cin][M] f32 -> fragments --------------------------------------------------------------------------------
 __global__ void k_bf3_pack_w(const float* __restrict__ AT, uint16_t* __restrict__ wp, int ntaps, int Cin, int M, int MT32, int KS) {
@@ -64,81 +61,98 @@ __global__ void k_bf3_pack_w(const float* __restrict__ AT, uint16_t* __restrict_
 }
 
 // ---- activations: x f32 [B][C][ldx] -> planes [B][Tp][Cp] (column t' holds input column t' + t_org; zero outside [x_lo, Tin)) ---------
+// Block: 64 columns x SP_CB channels.  Loads are coalesced along time (a wave reads 64 consecutive columns of one channel), the split
+// halves go through an LDS transpose, stores are coalesced along channels (16-byte pieces, a full SP_CB-channel row per 16 threads)
+#define SP_CB 128
+#define SP_LD (SP_CB + 8)             // LDS row stride in bf16 (272 B: 16-byte aligned rows; the 2-byte transposing writes of a wave hit
+                                      // rows 68 dwords apart: 4 | 68 only by 4, so the 64 lanes spread over 16 banks x 2 ways at worst)
 __global__ void __launch_bounds__(256) k_bf3_split(const float* __restrict__ X, uint16_t* __restrict__ xh, uint16_t* __restrict__ xl,
                                                    const float* __restrict__ alpha, const float* __restrict__ ralpha,
                                                    int C, int ldx, int x_lo, int Tin, int Cp, int Tp, int t_org) {
+    __shared__ __attribute__((aligned(16))) uint16_t sh[64 * SP_LD], sl[64 * SP_LD];
     const int tl = threadIdx.x & 63, cg = threadIdx.x >> 6;
-    const int tp = blockIdx.x * 64 + tl, c0 = blockIdx.y * 32 + cg * 8, b = blockIdx.z;
-    if (tp >= Tp) return;
-    const int t = tp + t_org;
-    const bool tin = t >= x_lo && t < Tin;
-    uint32_t hp[4], lp[4];
-#pragma unroll
-    for (int j = 0; j < 8; j += 2) {
-        float v[2];
-#pragma unroll
-        for (int e = 0; e < 2; ++e) {
-            const int c = c0 + j + e;
-            float x = 0.0f;
-            if (tin && c < C) {
-                x = X[((int64_t)b * C + c) * ldx + t];
-                if (alpha) x = bf3_snake(x, alpha[c], ralpha[c]);
-            }
-            v[e] = x;
+    const int tp0 = blockIdx.x * 64, c0 = blockIdx.y * SP_CB, b = blockIdx.z;
+    const int cw = min(SP_CB, Cp - c0);                         // channels of this block (multiple of 32)
+    const int t = tp0 + tl + t_org;
+    const bool tin = tp0 + tl < Tp && t >= x_lo && t < Tin;
+    for (int cc = cg; cc < cw; cc += 4) {
+        const int c = c0 + cc;
+        float x = 0.0f;
+        if (tin && c < C) {
+            x = X[((int64_t)b * C + c) * ldx + t];
+            if (alpha) x = bf3_snake(x, alpha[c], ralpha[c]);
         }
-        const uint16_t h0 = f32_to_bf16(v[0]), h1 = f32_to_bf16(v[1]);
-        const uint16_t l0 = f32_to_bf16(v[0] - bf16_to_f32(h0)), l1 = f32_to_bf16(v[1] - bf16_to_f32(h1));
-        hp[j >> 1] = (uint32_t)h0 | ((uint32_t)h1 << 16);
-        lp[j >> 1] = (uint32_t)l0 | ((uint32_t)l1 << 16);
+        const uint16_t h = f32_to_bf16(x);
+        sh[tl * SP_LD + cc] = h;
+        sl[tl * SP_LD + cc] = f32_to_bf16(x - bf16_to_f32(h));
     }
-    const size_t o = ((size_t)b * Tp + tp) * Cp + c0;
-    *reinterpret_cast<uint4*>(xh + o) = make_uint4(hp[0], hp[1], hp[2], hp[3]);
-    *reinterpret_cast<uint4*>(xl + o) = make_uint4(lp[0], lp[1], lp[2], lp[3]);
+    __syncthreads();
+    const int pieces = cw / 8;                                  // 16-byte pieces per row
+    for (int i = threadIdx.x; i < 64 * pieces; i += 256) {
+        const int r = i / pieces, pc = i - r * pieces;
+        if (tp0 + r >= Tp) continue;
+        const size_t o = ((size_t)b * Tp + tp0 + r) * Cp + c0 + pc * 8;
+        *reinterpret_cast<uint4*>(xh + o) = *reinterpret_cast<const uint4*>(sh + r * SP_LD + pc * 8);
+        *reinterpret_cast<uint4*>(xl + o) = *reinterpret_cast<const uint4*>(sl + r * SP_LD + pc * 8);
+    }
 }
 
 // ---- the contraction -----------------------------------------------------------------------------------------------------------------
 struct Bf3A { bf16x8_t v[2][2]; };     // [m tile][hi, lo]
 struct Bf3B { bf16x8_t v[2][2]; };     // [n tile][hi, lo]
 
-template <int NQ, int NBUF, int NTAPS>
-__global__ void __launch_bounds__(B3_THREADS) k_bf3_gemm(Bf3Params P) {
+// sched_group_barrier masks: 0x008 MFMA, 0x002 VALU, 0x020 VMEM read, 0x100 DS read
+#define B3_IL_V __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x002, 3, 0); __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+#define B3_IL_D __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x002, 3, 0); __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+#define B3_IL_M __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);
+#define B3_INTERLEAVE B3_IL_V B3_IL_V B3_IL_V B3_IL_V B3_IL_D B3_IL_D B3_IL_D B3_IL_D B3_IL_M B3_IL_M B3_IL_M B3_IL_M
+
+template <int NQ, int NBUF, int NTAPS, int MINW>
+__global__ void __launch_bounds__(B3_THREADS, MINW) k_bf3_gemm(Bf3Params P) {
     constexpr int PLANE = NQ * 512;                       // bf16 per plane: NQ DMA instructions of 1 KiB (16 columns x 32 channels)
     constexpr int BUF = 2 * PLANE;
+    constexpr int NST = 2 * NTAPS;                        // MFMA steps (16 channels of one tap) per chunk
     __shared__ __attribute__((aligned(1024))) uint16_t lds[NBUF * BUF];
     const GemmParams& p = P.g;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int n0 = blockIdx.x * B3_BN;
     int b = blockIdx.z, phase = 0, sh0 = 0, dsh = 0, tapbase = 0;
     if (P.mode == GEMM_CONVT) { b = blockIdx.z / p.s; phase = blockIdx.z - b * p.s; sh0 = (phase + p.pad) / p.s; dsh = -1; tapbase = phase * NTAPS; }
     else if (P.mode == GEMM_TAPS) { sh0 = -p.pad; dsh = p.dil; }
-    constexpr int ntaps = NTAPS;
-    const int shmin = min(sh0, sh0 + (ntaps - 1) * dsh);
+    const int shmin = min(sh0, sh0 + (NTAPS - 1) * dsh);
     const int nchunks = P.Cp / B3_KC;
+    // persistent over a contiguous range of column tiles: the loader keeps streaming across tile boundaries (the next tile's first
+    // chunks land while the MFMA waves store the finished tile), the weight stream wraps around to chunk 0
+    const int tile0 = blockIdx.x * P.tpb, ntile = min(P.tpb, P.nbx - tile0);
 
     if (wave == 4) {
         // ---- loader: tile column i = input column n0 + shmin + i.  DMA instruction q moves columns 16q .. 16q+15, four lanes per column;
         // lane slot gs holds channel group gs ^ ((i >> 2) & 3) (the swizzle is on the SOURCE address, the LDS side of a DMA is lane-linear)
         const int il = lane >> 2, grp = (lane & 3) ^ ((il >> 2) & 3);
-        const size_t col0 = ((size_t)b * P.Tp + (size_t)(n0 + shmin - P.t_org + il)) * P.Cp + grp * 8;
+        const size_t col0 = ((size_t)b * P.Tp + (size_t)(tile0 * B3_BN + shmin - P.t_org + il)) * P.Cp + grp * 8;
         const uint16_t* sh = P.xh + col0;
         const uint16_t* sl = P.xl + col0;
-        const size_t qstride = (size_t)16 * P.Cp;
-        auto issue = [&](int cc, int buf) {
-            const uint16_t* h = sh + cc * B3_KC;
-            const uint16_t* l = sl + cc * B3_KC;
+        const size_t qstride = (size_t)16 * P.Cp, tstride = (size_t)B3_BN * P.Cp;
+        const int G = ntile * nchunks;                        // chunks of this block, all tiles
+        int ig = 0, icc = 0, itile = 0;                       // next chunk to issue
+        auto issue = [&]() {
+            const uint16_t* h = sh + itile * tstride + icc * B3_KC;
+            const uint16_t* l = sl + itile * tstride + icc * B3_KC;
+            const int buf = ig % NBUF;
 #pragma unroll
             for (int q = 0; q < NQ; ++q) {
                 __builtin_amdgcn_global_load_lds((gptr_t)(h + q * qstride), (lptr_t)&lds[buf * BUF + q * 512], 16, 0, 0);
                 __builtin_amdgcn_global_load_lds((gptr_t)(l + q * qstride), (lptr_t)&lds[buf * BUF + PLANE + q * 512], 16, 0, 0);
             }
+            ++ig;
+            if (++icc == nchunks) { icc = 0; ++itile; }
         };
-        for (int c = 0; c < NBUF - 1 && c < nchunks; ++c) issue(c, c);
-        for (int cc = 0; cc < nchunks; ++cc) {
-            // chunk cc must have landed; up to NBUF-2 younger chunks stay in flight
-            if (nchunks - 1 - cc >= NBUF - 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NBUF - 2) * 2 * NQ) : "memory");
+        for (int c = 0; c < NBUF - 1 && c < G; ++c) issue();
+        for (int g = 0; g < G; ++g) {
+            // chunk g must have landed; up to NBUF-2 younger chunks stay in flight
+            if (G - 1 - g >= NBUF - 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NBUF - 2) * 2 * NQ) : "memory");
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
-            if (cc + NBUF - 1 < nchunks) issue(cc + NBUF - 1, (cc + NBUF - 1) % NBUF);
+            if (ig < G) issue();
         }
         return;
     }
@@ -147,23 +161,16 @@ __global__ void __launch_bounds__(B3_THREADS) k_bf3_gemm(Bf3Params P) {
     const int wm = wave >> 1, wn = wave & 1;
     const int mt0 = blockIdx.y * 4 + wm * 2;
     if (mt0 >= P.MT32) {                                   // no rows for this wave (M <= 64 in this block row): keep the barrier count
-        for (int cc = 0; cc < nchunks; ++cc) __builtin_amdgcn_s_barrier();
+        for (int g = 0; g < ntile * nchunks; ++g) __builtin_amdgcn_s_barrier();
         return;
     }
     f32x16_t acc[2][2];
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
 
     // weight stream: step (chunk, tap, ks) -> fragments of both row tiles, hi and lo.  It runs two steps ahead of the MFMAs, across
-    // chunk boundaries (it does not depend on the staged tile).  A second row tile past M re-reads the first (its rows are never
-    // stored).  The body below is three chunks (3 * NST steps) of straight-line code: the weight registers rotate with period 3,
+    // chunk and tile boundaries (it does not depend on the staged tile).  A second row tile past M re-reads the first (its rows are
+    // never stored).  The body below is three chunks (3 * NST steps) of straight-line code: the weight registers rotate with period 3,
     // the tile-fragment registers with period 2, every index is a compile-time constant and there is no branch between the MFMAs,
     // so the waitcnt pass keeps exactly the two younger weight loads in flight (with branches in the body it fell back to vmcnt(0)).
-    constexpr int NST = 2 * NTAPS;
     const size_t tap_stride = (size_t)P.MT32 * P.KS * 1024, mt_stride = (size_t)P.KS * 1024;
     const uint16_t* wbase = P.wp + (size_t)lane * 8 + (size_t)tapbase * tap_stride + (size_t)mt0 * mt_stride;
     const size_t mt1 = (mt0 + 1 < P.MT32) ? mt_stride : 0;
@@ -171,7 +178,8 @@ __global__ void __launch_bounds__(B3_THREADS) k_bf3_gemm(Bf3Params P) {
     Bf3A aq[3];
     Bf3B bq[2];
     auto loadA = [&](Bf3A& f, int chunk, int tap, int ks) {
-        const uint16_t* q = wbase + (size_t)tap * tap_stride + (size_t)(min(chunk, nchunks - 1) * 2 + ks) * 1024;
+        if (chunk >= nchunks) chunk -= nchunks;             // the next tile starts over at chunk 0
+        const uint16_t* q = wbase + (size_t)tap * tap_stride + (size_t)(chunk * 2 + ks) * 1024;
         f.v[0][0] = *reinterpret_cast<const bf16x8_t*>(q);
         f.v[0][1] = *reinterpret_cast<const bf16x8_t*>(q + 512);
         f.v[1][0] = *reinterpret_cast<const bf16x8_t*>(q + mt1);
@@ -202,83 +210,109 @@ __global__ void __launch_bounds__(B3_THREADS) k_bf3_gemm(Bf3Params P) {
     loadA(aq[0], 0, 0, 0);
     loadA(aq[1], 0, 0, 1);
     const uint16_t* tile = lds;
-    int cc = 0;
-    for (; cc + 3 <= nchunks; cc += 3) {
-#pragma unroll
-        for (int I = 0; I < 3 * NST; ++I) {
-            const int cg = I / NST, t = I % NST;
-            if (t == 0) {
-                __builtin_amdgcn_s_barrier();
-                tile = lds + ((cc + cg) % NBUF) * BUF;
-                readB(bq[I & 1], tile, 0, 0);
-            }
-            if (t + 1 < NST) readB(bq[(I + 1) & 1], tile, (t + 1) >> 1, (t + 1) & 1);
-            const int J = I + 2;
-            loadA(aq[J % 3], cc + J / NST, (J % NST) >> 1, J & 1);
-            __builtin_amdgcn_sched_barrier(0);              // keep the prefetches HERE: the scheduler otherwise sinks them to their use
-            mfma12(aq[I % 3], bq[I & 1]);
-            __builtin_amdgcn_sched_barrier(0);
-        }
-    }
-    // tail: one or two chunks, same schedule with a runtime bound (the rotation phase is 0 again here: 3 * NST steps per group)
-    if (cc < nchunks) {
-        const int rem = (nchunks - cc) * NST;
-#pragma unroll
-        for (int I = 0; I < 2 * NST; ++I) {
-            if (I < rem) {
-                const int cg = I / NST, t = I % NST;
-                if (t == 0) {
-                    __builtin_amdgcn_s_barrier();
-                    tile = lds + ((cc + cg) % NBUF) * BUF;
-                    readB(bq[I & 1], tile, 0, 0);
-                }
-                if (t + 1 < NST) readB(bq[(I + 1) & 1], tile, (t + 1) >> 1, (t + 1) & 1);
-                const int J = I + 2;
-                loadA(aq[J % 3], cc + J / NST, (J % NST) >> 1, J & 1);
-                __builtin_amdgcn_sched_barrier(0);
-                mfma12(aq[I % 3], bq[I & 1]);
-                __builtin_amdgcn_sched_barrier(0);
-            }
-        }
-    }
-
-    // ---- epilogue (the modes of k_snac_gemm / k_conv_taps).  C/D layout: col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)
+    int gbuf = 0;                                           // ring slot of the next chunk
     const float* Xb = p.X + (size_t)b * p.Cin * p.ldx;
     const bool convt = P.mode == GEMM_CONVT, gelu = P.mode == GEMM_GELU, noise = P.mode == GEMM_NOISE;
     const float* Rr = (convt || gelu || noise) ? nullptr : p.R;
+
+    for (int ti = 0; ti < ntile; ++ti) {
 #pragma unroll
-    for (int ni = 0; ni < 2; ++ni) {
-        const int n = n0 + wn * 64 + ni * 32 + (lane & 31);
-        if (n >= p.N) continue;
-        float nz = 0.0f;
-        if (noise) {
-            if (p.noise) nz = p.noise[(size_t)b * p.N + n];
-            else if (p.noise_rng) {
-                uint64_t row = (uint64_t)(p.row_offset + (p.row_ids ? p.row_ids[b] : b));
-                uint64_t u = mis_splitmix64((p.noise_key ^ (row * 0xD1B54A32D192ED03ull)) + (uint64_t)n);
-                float u1 = ((float)(uint32_t)(u >> 40) + 0.5f) * 5.9604644775390625e-08f;
-                float u2 = ((float)(uint32_t)((u >> 16) & 0xFFFFFF) + 0.5f) * 5.9604644775390625e-08f;
-                nz = sqrtf(-2.0f * logf(u1)) * cosf(6.283185307179586f * u2);
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+        int cc = 0;
+        for (; cc + 3 <= nchunks; cc += 3) {
+#pragma unroll
+            for (int I = 0; I < 3 * NST; ++I) {
+                const int t = I % NST;
+                if (t == 0) {
+                    __builtin_amdgcn_s_barrier();
+                    tile = lds + gbuf * BUF;
+                    gbuf = gbuf + 1 == NBUF ? 0 : gbuf + 1;
+                    readB(bq[I & 1], tile, 0, 0);
+                }
+                // one scheduling region per step: the prefetches of later steps cannot sink out of it (left alone the scheduler moves
+                // them next to their use), and inside it they are spread over the shadows of the 12 MFMAs instead of running ahead
+                // of them with the matrix pipe idle: MFMA, then a weight load or a tile read with its address arithmetic
+                __builtin_amdgcn_sched_barrier(0);
+                if (t + 1 < NST) readB(bq[(I + 1) & 1], tile, (t + 1) >> 1, (t + 1) & 1);
+                const int J = I + 2;
+                loadA(aq[J % 3], cc + J / NST, (J % NST) >> 1, J & 1);
+                mfma12(aq[I % 3], bq[I & 1]);
+                B3_INTERLEAVE
+                __builtin_amdgcn_sched_barrier(0);
             }
         }
-        const int o = convt ? p.s * n + phase : n;
-        if (o >= p.Tout) continue;
-        const bool dupb = convt && n == 0 && p.dup_bias_n0;
+        // tail: one or two chunks, same schedule with a runtime bound (rotation phase 0 here: 3 * NST steps per group)
+        if (cc < nchunks) {
+            const int rem = (nchunks - cc) * NST;
 #pragma unroll
-        for (int mi = 0; mi < 2; ++mi) {
+            for (int I = 0; I < 2 * NST; ++I) {
+                if (I < rem) {
+                    const int t = I % NST;
+                    if (t == 0) {
+                        __builtin_amdgcn_s_barrier();
+                        tile = lds + gbuf * BUF;
+                        gbuf = gbuf + 1 == NBUF ? 0 : gbuf + 1;
+                        readB(bq[I & 1], tile, 0, 0);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (t + 1 < NST) readB(bq[(I + 1) & 1], tile, (t + 1) >> 1, (t + 1) & 1);
+                    const int J = I + 2;
+                    loadA(aq[J % 3], cc + J / NST, (J % NST) >> 1, J & 1);
+                    mfma12(aq[I % 3], bq[I & 1]);
+                    B3_INTERLEAVE
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+            // the next tile expects its first two steps in aq[0], aq[1]; after `rem` steps they sit at rotation rem % 3
+            const int ph = rem % 3;
+            if (ph == 1) { aq[0] = aq[1]; aq[1] = aq[2]; }
+            else if (ph == 2) { const Bf3A tmp = aq[0]; aq[0] = aq[2]; aq[1] = tmp; }
+        }
+
+        // ---- epilogue (the modes of k_snac_gemm / k_conv_taps).  C/D layout: col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)
+        const int n0 = (tile0 + ti) * B3_BN;
+        // the row offsets below are the same for every tile; left visible, LICM hoists all 32 rows' 64-bit offsets out of the tile
+        // loop and spills them (860 B of scratch per lane, written and re-read by every block: measured 1.9x slower)
+        int lane_hi = lane >> 5;
+        asm volatile("" : "+v"(lane_hi));
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int m = (mt0 + mi) * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                if (m >= p.M) continue;
-                float v = acc[mi][ni][r];
-                const float bm = p.bias ? p.bias[m] : 0.0f;
-                v += bm;
-                if (dupb) v += bm;
-                const size_t rowo = ((size_t)b * p.M + m) * p.ldy;
-                if (gelu) v = 0.5f * v * (1.0f + erff(v * 0.70710678118654752f));
-                if (Rr) { if (p.scale) v *= p.scale[m]; v += Rr[rowo + n]; }
-                if (noise) v = Xb[(size_t)m * p.ldx + n] + nz * v;
-                p.Y[rowo + o] = v;
+        for (int ni = 0; ni < 2; ++ni) {
+            const int n = n0 + wn * 64 + ni * 32 + (lane & 31);
+            if (n >= p.N) continue;
+            float nz = 0.0f;
+            if (noise) {
+                if (p.noise) nz = p.noise[(size_t)b * p.N + n];
+                else if (p.noise_rng) {
+                    uint64_t row = (uint64_t)(p.row_offset + (p.row_ids ? p.row_ids[b] : b));
+                    uint64_t u = mis_splitmix64((p.noise_key ^ (row * 0xD1B54A32D192ED03ull)) + (uint64_t)n);
+                    float u1 = ((float)(uint32_t)(u >> 40) + 0.5f) * 5.9604644775390625e-08f;
+                    float u2 = ((float)(uint32_t)((u >> 16) & 0xFFFFFF) + 0.5f) * 5.9604644775390625e-08f;
+                    nz = sqrtf(-2.0f * logf(u1)) * cosf(6.283185307179586f * u2);
+                }
+            }
+            const int o = convt ? p.s * n + phase : n;
+            if (o >= p.Tout) continue;
+            const bool dupb = convt && n == 0 && p.dup_bias_n0;
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int m = (mt0 + mi) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lane_hi;
+                    if (m >= p.M) continue;
+                    float v = acc[mi][ni][r];
+                    const float bm = p.bias ? p.bias[m] : 0.0f;
+                    v += bm;
+                    if (dupb) v += bm;
+                    const size_t rowo = ((size_t)b * p.M + m) * p.ldy;
+                    if (gelu) v = 0.5f * v * (1.0f + erff(v * 0.70710678118654752f));
+                    if (Rr) { if (p.scale) v *= p.scale[m]; v += Rr[rowo + n]; }
+                    if (noise) v = Xb[(size_t)m * p.ldx + n] + nz * v;
+                    p.Y[rowo + o] = v;
+                }
             }
         }
     }
@@ -328,8 +362,11 @@ bool launch_gemm_bf3(int mode, bool snake, const GemmParams& p_in, int batch, hi
         if ((p.s - 1 + p.pad) / p.s - p.pad / p.s > 1) return false;
     } else if (!one) return false;
     // what pays: MFMA-bound shapes.  A 1x1 conv over few channels is HBM-bound and the pre-pass would only add traffic
-    const int min_k1 = bf3_env("MIS_BF3_MIN_K1", 256), min_k = bf3_env("MIS_BF3_MIN_K", 32);
+    // (measured per dispatch, profiles/r02_codec_bf3_dispatch.txt: 1x1 over <= 512 channels and the last SNAC transposed conv, M*K = 16 K,
+    // are faster on the exact-f32 kernels; every 7-tap conv and the transposed convs from M*K = 36 K up gain 2.3 - 4x)
+    const int min_k1 = bf3_env("MIS_BF3_MIN_K1", 768), min_k = bf3_env("MIS_BF3_MIN_K", 32), min_mk = bf3_env("MIS_BF3_MIN_MK_CONVT", 32768);
     if (one ? Cin < min_k1 : Cin < min_k) return false;
+    if (mode == GEMM_CONVT && (int64_t)p.M * p.K < min_mk) return false;
     if (p.M < 32 || span > 64 || (ntaps != 1 && ntaps != 2 && ntaps != 7)) return false;
     const CodecPack::Entry& e = p.pack->get(p.AT, wtaps, Cin, p.M, s);
 
@@ -341,17 +378,25 @@ bool launch_gemm_bf3(int mode, bool snake, const GemmParams& p_in, int batch, hi
     p.pack->xh.alloc((size_t)batch * Tp * e.Cp);
     p.pack->xl.alloc((size_t)batch * Tp * e.Cp);
     const bool sn = snake && p.alpha;
-    hipLaunchKernelGGL(k_bf3_split, dim3((Tp + 63) / 64, e.Cp / 32, batch), dim3(256), 0, s, p.X, p.pack->xh.p, p.pack->xl.p,
+    hipLaunchKernelGGL(k_bf3_split, dim3((Tp + 63) / 64, (e.Cp + SP_CB - 1) / SP_CB, batch), dim3(256), 0, s, p.X, p.pack->xh.p, p.pack->xl.p,
                        sn ? p.alpha : nullptr, sn ? p.ralpha : nullptr, Cin, p.ldx, p.x_lo, p.Tin, e.Cp, Tp, t_org);
     Bf3Params P{};
     P.g = p; P.g.Cin = Cin;
     P.wp = e.wp; P.xh = p.pack->xh.p; P.xl = p.pack->xl.p;
     P.mode = mode; P.ntaps = ntaps; P.MT32 = e.MT32; P.KS = e.KS; P.Cp = e.Cp; P.Tp = Tp; P.t_org = t_org;
     const int phases = mode == GEMM_CONVT ? p.s : 1;
-    dim3 grid(nbx, (p.M + B3_BM - 1) / B3_BM, batch * phases), block(B3_THREADS);
-    if (ntaps == 1) hipLaunchKernelGGL((k_bf3_gemm<9, 4, 1>), grid, block, 0, s, P);
-    else if (ntaps == 2) hipLaunchKernelGGL((k_bf3_gemm<9, 4, 2>), grid, block, 0, s, P);
-    else if (nq == 9) hipLaunchKernelGGL((k_bf3_gemm<9, 4, 7>), grid, block, 0, s, P);
-    else hipLaunchKernelGGL((k_bf3_gemm<12, 3, 7>), grid, block, 0, s, P);
+    // column tiles per block: enough blocks for ~8 per CU, at most 16 tiles each
+    const int nby = (p.M + B3_BM - 1) / B3_BM;
+    const int64_t tiles = (int64_t)nbx * nby * batch * phases;
+    const int tpb = (int)std::max<int64_t>(1, std::min<int64_t>(bf3_env("MIS_BF3_TPB", 1), tiles / 2048));
+    P.nbx = nbx; P.tpb = tpb;
+    dim3 grid((nbx + tpb - 1) / tpb, nby, batch * phases), block(B3_THREADS);
+    // MINW 3 = two blocks (ten waves) per CU: 168 registers; the 7-tap body then spills a few address temporaries (A/B by MIS_BF3_MINW)
+    // MINW 3 = two blocks (ten waves) per CU, 168 registers: fits 1 and 2 taps; the 7-tap body would spill (measured 2.3x slower), so it
+    // runs one block per CU and relies on the persistent tile loop for overlap
+    if (ntaps == 1) hipLaunchKernelGGL((k_bf3_gemm<9, 4, 1, 3>), grid, block, 0, s, P);
+    else if (ntaps == 2) hipLaunchKernelGGL((k_bf3_gemm<9, 4, 2, 3>), grid, block, 0, s, P);
+    else if (nq == 9) hipLaunchKernelGGL((k_bf3_gemm<9, 4, 7, 2>), grid, block, 0, s, P);
+    else hipLaunchKernelGGL((k_bf3_gemm<12, 4, 7, 2>), grid, block, 0, s, P);
     return true;
 }

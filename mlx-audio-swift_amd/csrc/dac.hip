@@ -79,8 +79,8 @@ __global__ void k_dac_final(const float* __restrict__ x, float* __restrict__ out
         for (int j = 0; j < 7; ++j) {
             int ts = t + j - 3;
             if (ts < 0 || ts >= T) continue;
-            float v = xr[ts], s = sinf(ac * v);
-            acc += w[j * C + c] * (v + rc * s * s);
+            const float v = xr[ts];
+            acc += w[j * C + c] * fmaf(rc, mis_sin_sq(ac * v), v);
         }
     }
     out[(size_t)b * out_stride + t] = tanhf(acc);

@@ -23,8 +23,7 @@
 // ============================================================================ device kernels
 
 __device__ __forceinline__ float snake_f(float x, float a, float ra) {
-    float s = sinf(a * x);          // Layers.swift:44-50: x + 1/(alpha+1e-9) * sin(alpha x)^2
-    return x + ra * (s * s);
+    return fmaf(ra, mis_sin_sq(a * x), x);      // Layers.swift:44-50: x + 1/(alpha+1e-9) * sin(alpha x)^2 (mis_sin_sq: codec_kernels.h)
 }
 
 // ---- fromCodes ---------------------------------------------------------------------------------
