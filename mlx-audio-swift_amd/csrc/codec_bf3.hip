@@ -362,7 +362,7 @@ bool launch_gemm_bf3(int mode, bool snake, const GemmParams& p_in, int batch, hi
         if ((p.s - 1 + p.pad) / p.s - p.pad / p.s > 1) return false;
     } else if (!one) return false;
     // what pays: MFMA-bound shapes.  A 1x1 conv over few channels is HBM-bound and the pre-pass would only add traffic
-    // (measured per dispatch, profiles/r02_codec_bf3_dispatch.txt: 1x1 over <= 512 channels and the last SNAC transposed conv, M*K = 16 K,
+    // (measured per dispatch, profiles/r02_codec/: 1x1 over <= 512 channels and the last SNAC transposed conv, M*K = 16 K,
     // are faster on the exact-f32 kernels; every 7-tap conv and the transposed convs from M*K = 36 K up gain 2.3 - 4x)
     const int min_k1 = bf3_env("MIS_BF3_MIN_K1", 768), min_k = bf3_env("MIS_BF3_MIN_K", 32), min_mk = bf3_env("MIS_BF3_MIN_MK_CONVT", 32768);
     if (one ? Cin < min_k1 : Cin < min_k) return false;

@@ -1,7 +1,7 @@
 set -x
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out
-timeout 1500 python -m pytest tests -m gpu -q 2>&1 | grep -v "^PARITY" | tail -8
+timeout 900 python -m pytest tests/test_gpu_snac.py tests/test_gpu_dac.py tests/test_gpu_encodec.py tests/test_gpu_soprano.py tests/test_gpu_qwen3tts.py tests/test_gpu_fullwidth.py -m gpu -q -x 2>&1 | grep -v "^PARITY" | tail -5
 export TMPDIR=/tmp
 run() {  # name, workload, start kernel, env...
   name=$1; w=$2; k=$3; shift; shift; shift
@@ -11,7 +11,7 @@ run() {  # name, workload, start kernel, env...
   python tools/codec_dispatch_trace.py $f 400 > gpurun_out/dispatch_$name.txt 2>&1
   python tools/dispatch_sum.py gpurun_out/dispatch_$name.txt $k
 }
-run q3_fs q3b32 k_q3_rvq A=1
-run snac_fs snac32 k_snac_embed A=1
-timeout 300 python tools/bench_qwen3tts.py 32 100 16 > gpurun_out/q3_fs.log 2>&1; tail -1 gpurun_out/q3_fs.log
-timeout 300 python bench.py --steps 2 --warmup 1 --no-cpu-baseline > gpurun_out/bench_fs.log 2>&1; tail -1 gpurun_out/bench_fs.log | python -c "import sys,json; j=json.loads(sys.stdin.read()); print(j['value'], j['phases_ms'])"
+run q3_ep q3b32 k_q3_rvq A=1
+run q3_ep_k96 q3b32 k_q3_rvq MIS_BF3_MIN_K1=96
+run snac_ep snac32 k_snac_embed A=1
+run snac_ep_all snac32 k_snac_embed MIS_BF3_MIN_K1=128 MIS_BF3_MIN_MK_CONVT=1
