@@ -84,7 +84,7 @@ typedef struct {
     int32_t vq_strides[8];
     int32_t noise;             /* bool */
     int32_t depthwise;         /* bool; only 1 is supported (24 kHz model) */
-    int32_t attn_window_size;  /* 0 = none; only 0 is supported (24 kHz model) */
+    int32_t attn_window_size;  /* 0 = none (24 kHz model); 32: LocalMHA of the 32 / 44 kHz models (SNAC/Attention.swift; <= 64) */
 } mis_snac_config;
 
 /* SNAC.fromModelDirectory, SNACDecoder.swift:156-189: config.json + model.safetensors */

@@ -105,6 +105,72 @@ __global__ void __launch_bounds__(256) k_snac_dw(const float* __restrict__ X, fl
     }
 }
 
+// ---- LocalMHA (Attention.swift:14-94): the 32 / 44 kHz models ---------------------------------------------------------
+// LayerNorm over the channels of every column (NCT data: a thread owns one column, a wave reads 64 consecutive columns of a channel)
+__global__ void __launch_bounds__(128) k_snac_ln_ct(const float* __restrict__ x, float* __restrict__ y, const float* __restrict__ w,
+                                                    const float* __restrict__ bsh, int C, int T, float eps) {
+    const int t = blockIdx.x * 128 + threadIdx.x, b = blockIdx.y;
+    if (t >= T) return;
+    const float* xb = x + (size_t)b * C * T + t;
+    float s = 0.0f;
+    for (int c = 0; c < C; ++c) s += xb[(size_t)c * T];
+    const float mu = s / (float)C;
+    float v = 0.0f;
+    for (int c = 0; c < C; ++c) { const float d = xb[(size_t)c * T] - mu; v += d * d; }
+    const float inv = rsqrtf(v / (float)C + eps);
+    float* yb = y + (size_t)b * C * T + t;
+    for (int c = 0; c < C; ++c) yb[(size_t)c * T] = (xb[(size_t)c * T] - mu) * inv * w[c] + bsh[c];
+}
+// attention inside one window of WIN frames for one head (dim_head 64): qkv [B][3C][T] (rows: q | k | v, head h at rows h*64 ..),
+// rotary embedding of q and k over the in-window position (freqs = [n f, n f], rotate_half = [-x2, x1]; xpos off: scale 1),
+// softmax(q k^T / 8) v  ->  out [B][C][T].  Block = (window, head, batch), 256 threads.
+#define MHA_D 64
+#define MHA_MAXW 64
+__global__ void __launch_bounds__(256) k_snac_local_attn(const float* __restrict__ qkv, float* __restrict__ out, const float* __restrict__ inv_freq,
+                                                         int C, int T, int win) {
+    __shared__ float q[MHA_D][MHA_MAXW + 1], k[MHA_D][MHA_MAXW + 1], v[MHA_D][MHA_MAXW + 1], p[MHA_MAXW][MHA_MAXW + 1];
+    const int w0 = blockIdx.x * win, h = blockIdx.y, b = blockIdx.z, tid = threadIdx.x;
+    const float* base = qkv + (size_t)b * 3 * C * T;
+    for (int i = tid; i < MHA_D * win; i += 256) {
+        const int d = i / win, n = i - d * win;
+        const int dp = d < 32 ? d + 32 : d - 32;                      // rotate_half partner
+        const float sg = d < 32 ? -1.0f : 1.0f;
+        const float f = (float)n * inv_freq[d & 31];
+        const float cs = cosf(f), sn = sinf(f);
+        const size_t col = (size_t)w0 + n;
+        const float qd = base[((size_t)(h * MHA_D + d)) * T + col], qp = base[((size_t)(h * MHA_D + dp)) * T + col];
+        const float kd = base[((size_t)(C + h * MHA_D + d)) * T + col], kp = base[((size_t)(C + h * MHA_D + dp)) * T + col];
+        q[d][n] = qd * cs + sg * qp * sn;
+        k[d][n] = kd * cs + sg * kp * sn;
+        v[d][n] = base[((size_t)(2 * C + h * MHA_D + d)) * T + col];
+    }
+    __syncthreads();
+    for (int i = tid; i < win * win; i += 256) {
+        const int a = i / win, c = i - a * win;                       // query a, key c
+        float acc = 0.0f;
+#pragma unroll 8
+        for (int d = 0; d < MHA_D; ++d) acc += q[d][a] * k[d][c];
+        p[a][c] = acc * 0.125f;
+    }
+    __syncthreads();
+    if (tid < win) {                                                  // softmax over the keys of query tid
+        float m = -INFINITY;
+        for (int c = 0; c < win; ++c) m = fmaxf(m, p[tid][c]);
+        float sum = 0.0f;
+        for (int c = 0; c < win; ++c) { const float e = expf(p[tid][c] - m); p[tid][c] = e; sum += e; }
+        const float r = 1.0f / sum;
+        for (int c = 0; c < win; ++c) p[tid][c] *= r;
+    }
+    __syncthreads();
+    float* ob = out + (size_t)b * C * T;
+    for (int i = tid; i < MHA_D * win; i += 256) {
+        const int d = i / win, a = i - d * win;
+        float acc = 0.0f;
+        for (int c = 0; c < win; ++c) acc += p[a][c] * v[d][c];
+        ob[((size_t)(h * MHA_D + d)) * T + w0 + a] = acc;
+    }
+}
+
 // ---- dense contraction on f32 MFMA ----------------------------------------------------------------
 #define G_BM 64
 #define G_BN 128
@@ -510,6 +576,9 @@ struct mis_snac {
         SnakeW snake;
         ConvW down;                       // strided conv as a 3-tap conv over the phase-split tensor: A^T [3*s*cin][cout]
     };
+    // LocalMHA of the 32 / 44 kHz models (Attention.swift): decoder layer 2, encoder layer n + 1
+    struct MhaW { bool on = false; int dim = 0; size_t ln_w = 0, ln_b = 0, qkv = 0, out = 0, inv_freq = 0; };
+    MhaW dec_attn, enc_attn;
     bool has_encoder = false;
     int enc_dim = 0;
     ConvW enc_first, enc_last;            // first: [d][7] (Cin = 1); last: depthwise [C][7]
@@ -575,7 +644,7 @@ extern "C" mis_status mis_snac_create(const mis_snac_config* cfg, int device, mi
     MIS_API_BEGIN
     MIS_REQUIRE(cfg && out, MIS_ERR_INVALID_INPUT, "null argument");
     MIS_REQUIRE(cfg->depthwise == 1, MIS_ERR_INVALID_INPUT, "only depthwise SNAC decoders are supported");
-    MIS_REQUIRE(cfg->attn_window_size == 0, MIS_ERR_INVALID_INPUT, "LocalMHA SNAC variants (32/44 kHz) are not supported");
+    MIS_REQUIRE(cfg->attn_window_size >= 0 && cfg->attn_window_size <= MHA_MAXW, MIS_ERR_INVALID_INPUT, "attn_window_size must be 0 .. %d", MHA_MAXW);
     MIS_REQUIRE(cfg->n_decoder_rates >= 1 && cfg->n_decoder_rates <= 8 && cfg->n_codebooks >= 1 && cfg->n_codebooks <= 8,
                 MIS_ERR_INVALID_INPUT, "bad decoder_rates / vq_strides count");
     for (int i = 0; i < cfg->n_codebooks; ++i)
@@ -596,6 +665,10 @@ extern "C" mis_status mis_snac_create(const mis_snac_config* cfg, int device, mi
     *out = c;
     MIS_API_END
 }
+
+static int64_t mis_snac_hop_for_encoder(const mis_snac* c);
+static void snac_local_mha(const mis_snac::MhaW& m, const float* W, int win, const float* x, float* y, float* t1, float* t2, int batch, int64_t T,
+                           hipStream_t s);
 
 extern "C" void mis_snac_destroy(mis_snac* c) {
     if (!c) return;
@@ -676,9 +749,33 @@ extern "C" mis_status mis_snac_finalize(mis_snac* c) {
         }
         c->tables_off = push(tables);
     }
+    // LocalMHA parameters: norm.{weight,bias} [dim], to_qkv.weight [3 dim][dim], to_out.weight [dim][dim] (Linear, no bias), rel_pos.inv_freq [32]
+    auto push_mha = [&](const std::string& p, int64_t dim) {
+        mis_snac::MhaW m;
+        MIS_REQUIRE(dim % MHA_D == 0, MIS_ERR_INVALID_INPUT, "LocalMHA width %lld is not a multiple of the head size 64", (long long)dim);
+        m.on = true; m.dim = (int)dim;
+        m.ln_w = push(need(c, p + ".norm.weight", {dim}).v);
+        m.ln_b = push(need(c, p + ".norm.bias", {dim}).v);
+        auto lin_t = [&](const HostTensor& w, int64_t out_f, int64_t in_f) {            // Linear weight [out][in] -> A^T [in][out]
+            std::vector<float> at((size_t)in_f * out_f);
+            for (int64_t o = 0; o < out_f; ++o) for (int64_t i = 0; i < in_f; ++i) at[i * out_f + o] = w.v[o * in_f + i];
+            return at;
+        };
+        m.qkv = push(lin_t(need(c, p + ".to_qkv.weight", {3 * dim, dim}), 3 * dim, dim));
+        m.out = push(lin_t(need(c, p + ".to_out.weight", {dim, dim}), dim, dim));
+        auto fq = c->raw.find(p + ".rel_pos.inv_freq");
+        std::vector<float> inv(32);
+        if (fq != c->raw.end() && fq->second.v.size() == 32) inv = fq->second.v;
+        else for (int j = 0; j < 32; ++j) inv[j] = 1.0f / powf(10000.0f, (float)(2 * j) / 64.0f);      // SinusoidalEmbeddings.init (:105-107)
+        m.inv_freq = push(inv);
+        return m;
+    };
     const std::string L = "decoder.model.layers";
     c->stem_dw = push_dw(L + ".0", D);
     c->stem_pw = push_pw(L + ".1", cf.decoder_dim, D, true);
+    const int first_block = cf.attn_window_size > 0 ? 3 : 2;                                            // Layers.swift:395-397
+    c->dec_attn = mis_snac::MhaW{};
+    if (cf.attn_window_size > 0) c->dec_attn = push_mha(L + ".2", cf.decoder_dim);
     c->blocks.clear();
     for (int bi = 0; bi < cf.n_decoder_rates; ++bi) {
         mis_snac::Block blk;
@@ -687,7 +784,7 @@ extern "C" mis_status mis_snac_finalize(mis_snac* c) {
         MIS_REQUIRE(blk.cout >= 1, MIS_ERR_INVALID_INPUT, "decoder_dim too small for %d blocks", cf.n_decoder_rates);
         blk.stride = cf.decoder_rates[bi];
         blk.pad = (blk.stride + 1) / 2;           // ceil(stride/2), Layers.swift:294
-        std::string b = L + "." + std::to_string(2 + bi) + ".block.layers";
+        std::string b = L + "." + std::to_string(first_block + bi) + ".block.layers";
         blk.snake0 = push_snake(b + ".0.alpha", blk.cin);
         {   // transposed conv, weight_v [in, 2s, out]; per phase p: AT[p][j*Cin+ci][co] = w[ci][((p+pad)%s) + j*s][co]
             int s = blk.stride, K = 2 * s;
@@ -716,7 +813,7 @@ extern "C" mis_status mis_snac_finalize(mis_snac* c) {
         c->blocks.push_back(blk);
     }
     {
-        int n = 2 + cf.n_decoder_rates;
+        int n = first_block + cf.n_decoder_rates;
         int64_t cl = cf.decoder_dim >> cf.n_decoder_rates;
         c->fin_snake = push_snake(L + "." + std::to_string(n) + ".alpha", cl);
         std::string p = L + "." + std::to_string(n + 1);
@@ -732,7 +829,6 @@ extern "C" mis_status mis_snac_finalize(mis_snac* c) {
     auto e0 = c->raw.find(E + ".0.weight_v");
     if (e0 != c->raw.end()) {
         MIS_REQUIRE(cf.depthwise, MIS_ERR_INVALID_INPUT, "SNAC encoder: only depthwise residual units are built");
-        MIS_REQUIRE(cf.attn_window_size <= 0, MIS_ERR_INVALID_INPUT, "SNAC encoder: LocalMHA (attn_window_size) is not built");
         MIS_REQUIRE(e0->second.shape.size() == 3 && e0->second.shape[1] == 7 && e0->second.shape[2] == 1, MIS_ERR_INVALID_INPUT, "bad encoder stem");
         int64_t ch = e0->second.shape[0];
         c->enc_dim = (int)ch;
@@ -778,6 +874,8 @@ extern "C" mis_status mis_snac_finalize(mis_snac* c) {
             c->enc_blocks.push_back(eb);
         }
         MIS_REQUIRE(!c->enc_blocks.empty() && ch == D, MIS_ERR_INVALID_INPUT, "SNAC encoder output width %lld != latent_dim %lld", (long long)ch, (long long)D);
+        c->enc_attn = mis_snac::MhaW{};
+        if (cf.attn_window_size > 0) { c->enc_attn = push_mha(E + "." + std::to_string(li), D); ++li; }      // Layers.swift:339-341
         c->enc_last = push_dw(E + "." + std::to_string(li), D);
         c->vq_enc.clear();
         for (int i = 0; i < cf.n_codebooks; ++i) {
@@ -838,6 +936,7 @@ extern "C" mis_status mis_snac_encode(mis_snac* c, const float* audio, int batch
         int64_t T = Tp;
         for (auto& b : c->enc_blocks) { cap = std::max(cap, (size_t)b.cin * T); T /= b.stride; cap = std::max(cap, (size_t)b.cout * T); }
     }
+    if (c->enc_attn.on) cap = std::max(cap, (size_t)3 * D * (Tp / std::max<int64_t>(1, mis_snac_hop_for_encoder(c))));
     cap *= (size_t)batch;
     for (int i = 0; i < 3; ++i) c->enc_buf[i].alloc(cap);
     DevBuf<float> ain;
@@ -868,6 +967,10 @@ extern "C" mis_status mis_snac_encode(mis_snac* c, const float* audio, int batch
         g.M = eb.cout; g.K = 3 * eb.stride * eb.cin; g.N = (int)T; g.Tin = (int)T; g.Tout = (int)T;
         g.Cin = eb.stride * eb.cin; g.taps = 3; g.dil = 1; g.pad = 1;
         launch_gemm(GEMM_TAPS, false, g, batch, s);
+        std::swap(x, f2);
+    }
+    if (c->enc_attn.on) {                                                 // Layers.swift:339-341
+        snac_local_mha(c->enc_attn, W, cf.attn_window_size, x, /*y*/ f2, /*t1*/ f1, /*t2*/ f2, batch, T, s);
         std::swap(x, f2);
     }
     hipLaunchKernelGGL((k_snac_dw<false, false>), dim3(cdiv(T, DW_TILE), D, batch), dim3(256), 0, s, x, f1, W + c->enc_last.w, W + c->enc_last.b,
@@ -962,6 +1065,28 @@ void launch_gemm(int mode, bool snake, const GemmParams& p_in, int batch, hipStr
     else { MIS_REQUIRE(snake, MIS_ERR_GENERATION_FAILED, "convT without snake"); hipLaunchKernelGGL((k_snac_gemm<GEMM_CONVT, true>), grid, block, 0, s, p); }
 }
 
+static int64_t mis_snac_hop_for_encoder(const mis_snac* c) {
+    int64_t h = 1;
+    for (auto& b : c->enc_blocks) h *= b.stride;
+    return h;
+}
+
+// LocalMHA on x [B][C][T] (Attention.swift:31-63): LayerNorm -> to_qkv -> windowed attention -> to_out + residual.
+// t1 (>= C*T per row) and t2 (>= 3*C*T per row) are work buffers; the result lands in y.
+static void snac_local_mha(const mis_snac::MhaW& m, const float* W, int win, const float* x, float* y, float* t1, float* t2, int batch, int64_t T,
+                           hipStream_t s) {
+    MIS_REQUIRE(T % win == 0, MIS_ERR_INVALID_INPUT, "LocalMHA needs a whole number of %d-frame windows (got %lld frames)", win, (long long)T);
+    const int C = m.dim;
+    hipLaunchKernelGGL(k_snac_ln_ct, dim3(cdiv(T, 128), batch), dim3(128), 0, s, x, t1, W + m.ln_w, W + m.ln_b, C, (int)T, 1e-5f);
+    GemmParams g{};
+    g.AT = W + m.qkv; g.X = t1; g.Y = t2; g.M = 3 * C; g.K = C; g.N = (int)T; g.Tin = (int)T; g.Tout = (int)T;
+    launch_gemm(GEMM_PLAIN, false, g, batch, s);
+    hipLaunchKernelGGL(k_snac_local_attn, dim3((unsigned)(T / win), C / MHA_D, batch), dim3(256), 0, s, t2, t1, W + m.inv_freq, C, (int)T, win);
+    GemmParams o{};
+    o.AT = W + m.out; o.X = t1; o.Y = y; o.R = x; o.M = C; o.K = C; o.N = (int)T; o.Tin = (int)T; o.Tout = (int)T;
+    launch_gemm(GEMM_RESID, false, o, batch, s);
+}
+
 // Runs the decode on device pointers.  stop_after: -1 = full; 0 zq, 1 stem_dw, 2 stem_pw, 3+i block i.
 // Returns the buffer holding the stage output (for taps) and its [C, T].
 struct NoiseRng { int enabled = 0; uint64_t seed = 0; const int32_t* row_ids = nullptr; int64_t row_offset = 0; };
@@ -983,6 +1108,7 @@ static const float* snac_run(mis_snac* c, const int32_t* const* codes, int batch
             cap = std::max(cap, (size_t)(cf.decoder_dim >> (i + 1)) * (size_t)T);
         }
     }
+    if (c->dec_attn.on) cap = std::max(cap, (size_t)3 * cf.decoder_dim * T0);          // q | k | v
     cap *= (size_t)batch;
     for (int i = 0; i < 3; ++i) c->buf[i].alloc(cap);
     float *A = c->buf[0].p, *B = c->buf[1].p, *Cc = c->buf[2].p;
@@ -1008,6 +1134,11 @@ static const float* snac_run(mis_snac* c, const int32_t* const* codes, int batch
     float* x = A;        // current activation
     float* f1 = B;
     float* f2 = Cc;
+    if (c->dec_attn.on) {                                                              // Layers.swift:395-397
+        CodecPackScope exact(nullptr);                // exact-f32 contractions here: the softmax amplifies operand noise
+        snac_local_mha(c->dec_attn, W, cf.attn_window_size, A, /*y*/ Cc, /*t1*/ B, /*t2*/ Cc, batch, T0, s);
+        x = Cc; f1 = A; f2 = B;
+    }
     int64_t T = T0;
     for (size_t bi = 0; bi < c->blocks.size(); ++bi) {
         const mis_snac::Block& blk = c->blocks[bi];

@@ -66,6 +66,11 @@ class SnacConfig:
                     noise=self.noise, depthwise=self.depthwise)
 
 
+# a 32 / 44 kHz-style configuration in miniature: LocalMHA (window 32, head size 64) after the decoder stem and before the encoder's
+# last conv, four codebooks
+TINY_ATTN = dict(sampling_rate=32000, encoder_dim=8, encoder_rates=[2, 2, 2, 2], decoder_dim=128, decoder_rates=[2, 2, 2, 2],
+                 attn_window_size=32, codebook_size=64, codebook_dim=8, vq_strides=[8, 4, 2, 1], noise=True, depthwise=True)
+
 TINY = dict(encoder_dim=4, encoder_rates=[2, 2, 2, 2], decoder_dim=64, decoder_rates=[4, 2, 2, 2],
             codebook_size=64, codebook_dim=8, vq_strides=[4, 2, 1])
 
@@ -142,8 +147,7 @@ class SnacOracle:
         self.cfg = cfg
         self.dtype = np.dtype(dtype)
         self.w = {k: np.asarray(v, dtype=self.dtype) for k, v in weights.items()}
-        # LocalMHA (32/44 kHz) and the non-depthwise stem are not on the 24 kHz path (Layers.swift:376-397) and not restated
-        assert cfg.attn_window_size is None, "LocalMHA variant (32/44 kHz) not restated"
+        # the non-depthwise stem is not on the 24 / 32 / 44 kHz paths (Layers.swift:376-397) and not restated
         assert cfg.depthwise, "non-depthwise decoder stem not restated"
 
     # -- weight helpers ------------------------------------------------------
@@ -166,6 +170,49 @@ class SnacOracle:
                 zqi = np.repeat(zqi, stride, axis=2)            # (:175-184) repeat_interleave
             zq = zqi if zq is None else zq + zqi                # (:186)  0.0 + z0 + z1 + z2
         return zq.astype(self.dtype)
+
+    # -- LocalMHA (Attention.swift:14-94,99-185): the 32 / 44 kHz models ---------
+    def local_mha(self, x, p, dim_head=64):
+        """x [B, C, T] -> [B, C, T].  LayerNorm over channels, to_qkv (no bias), attention inside non-overlapping windows of
+        attn_window_size frames (full, non-causal), rotary embedding of q and k over the in-window position (SinusoidalEmbeddings
+        with useXPos false: scale = 1; freqs = [t*inv_freq, t*inv_freq], rotate_half = [-x2, x1]), scores / sqrt(d), softmax,
+        to_out (no bias), + residual."""
+        t = self.dtype.type
+        win = self.cfg.attn_window_size
+        B, C, T = x.shape
+        assert T % win == 0, "LocalMHA needs a whole number of windows (the reference's reshape fails otherwise)"
+        heads, W = C // dim_head, T // win
+        h = np.transpose(x, (0, 2, 1))                                              # [B, T, C]
+        mu = h.mean(axis=-1, keepdims=True, dtype=self.dtype)
+        var = ((h - mu) ** 2).mean(axis=-1, keepdims=True, dtype=self.dtype)
+        h = (h - mu) / np.sqrt(var + t(1e-5)) * self.w[p + ".norm.weight"] + self.w[p + ".norm.bias"]
+        qkv = h @ self.w[p + ".to_qkv.weight"].T                                    # Linear(dim, 3 dim, bias: false)
+        q, k, v = np.split(qkv, 3, axis=-1)
+
+        def rearr(a):                                                               # "b (w n) (h d) -> b h w n d"
+            return np.transpose(a.reshape(B, W, win, heads, dim_head), (0, 3, 1, 2, 4))
+        q, k, v = rearr(q), rearr(k), rearr(v)
+        inv = self.w.get(p + ".rel_pos.inv_freq")
+        if inv is None:
+            inv = (t(1.0) / np.power(t(10000.0), np.arange(0, dim_head, 2, dtype=self.dtype) / t(dim_head))).astype(self.dtype)
+        pos = np.arange(win, dtype=self.dtype)
+        fr = pos[:, None] * inv[None, :]
+        fr = np.concatenate([fr, fr], axis=-1)                                      # [n, d]
+        cos, sin = np.cos(fr).astype(self.dtype), np.sin(fr).astype(self.dtype)
+
+        def rot_half(a):
+            a1, a2 = a[..., : dim_head // 2], a[..., dim_head // 2:]
+            return np.concatenate([-a2, a1], axis=-1)
+        q = q * cos + rot_half(q) * sin
+        k = k * cos + rot_half(k) * sin
+        sc = (q @ np.swapaxes(k, -1, -2)) / t(math.sqrt(dim_head))
+        sc = sc - sc.max(axis=-1, keepdims=True)
+        pr = np.exp(sc)
+        pr = pr / pr.sum(axis=-1, keepdims=True, dtype=self.dtype)
+        o = pr @ v                                                                  # [B, h, w, n, d]
+        o = np.transpose(o, (0, 2, 3, 1, 4)).reshape(B, T, C)                       # "b h w n d -> b (w n) (h d)"
+        o = o @ self.w[p + ".to_out.weight"].T
+        return (np.transpose(o, (0, 2, 1)) + x).astype(self.dtype)
 
     # -- decoder (Layers.swift:364-421) ---------------------------------------
     def _residual_unit(self, x, p, dilation):
@@ -206,11 +253,16 @@ class SnacOracle:
         w, b = self._wn(p + ".1")
         x = conv1d_nct(x, w, b)                                            # :387
         inter["stem_pw"] = x
+        first = 2
+        if cfg.attn_window_size:                                           # :395-397
+            x = self.local_mha(x, p + ".2")
+            inter["attn"] = x
+            first = 3
         for i, s in enumerate(cfg.decoder_rates):
             nz = None if noises is None else noises[i]
-            x = self._decoder_block(x, f"{p}.{2 + i}", s, nz)              # :399-405
+            x = self._decoder_block(x, f"{p}.{first + i}", s, nz)          # :399-405
             inter[f"block{i}"] = x
-        n = 2 + len(cfg.decoder_rates)
+        n = first + len(cfg.decoder_rates)
         x = snake(x, self.w[f"{p}.{n}.alpha"])                             # :410
         w, b = self._wn(f"{p}.{n + 1}")
         x = conv1d_nct(x, w, b, padding=3)                                 # :411
@@ -238,7 +290,6 @@ class SnacOracle:
     def encoder(self, audio):
         """audio [B, 1, T] -> z [B, latent, T / hop]."""
         cfg = self.cfg
-        assert not cfg.attn_window_size, "LocalMHA encoder layer is not restated"
         p = "encoder.block.layers"
         w, b = self._wn(p + ".0")
         x = conv1d_nct(np.asarray(audio, self.dtype), w, b, padding=3)
@@ -250,6 +301,9 @@ class SnacOracle:
             w, b = self._wn(q + ".4")
             x = conv1d_nct(x, w, b, stride=s, padding=int(math.ceil(s / 2.0)))
         n = 1 + len(cfg.encoder_rates)
+        if cfg.attn_window_size:                                           # Layers.swift:339-341
+            x = self.local_mha(x, f"{p}.{n}")
+            n += 1
         w, b = self._wn(f"{p}.{n}")
         return conv1d_nct(x, w, b, padding=3, groups=x.shape[1] if cfg.depthwise else 1)
 
@@ -338,10 +392,18 @@ def make_synthetic_weights(cfg: SnacConfig, seed: int = 1234, with_encoder: bool
     p = "decoder.model.layers"
     wn_conv(p + ".0", D, 7, 1, D)                 # depthwise: reference init scale uses inChannels*k
     wn_conv(p + ".1", cfg.decoder_dim, 1, D, D)
+    first = 3 if cfg.attn_window_size else 2
+
+    def mha(prefix, dim):                         # LocalMHA parameters (Attention.swift:22-29)
+        W[prefix + ".norm.weight"] = (1.0 + synth.synth_tensor(nxt(), (dim,), 0.2)).astype(np.float32)
+        W[prefix + ".norm.bias"] = synth.synth_tensor(nxt(), (dim,), 0.1)
+        W[prefix + ".to_qkv.weight"] = synth.synth_tensor(nxt(), (3 * dim, dim), math.sqrt(3.0 / dim))
+        W[prefix + ".to_out.weight"] = synth.synth_tensor(nxt(), (dim, dim), 0.5 * math.sqrt(3.0 / dim))
+        W[prefix + ".rel_pos.inv_freq"] = (1.0 / np.power(10000.0, np.arange(0, 64, 2, dtype=np.float32) / 64.0)).astype(np.float32)
     for i, s in enumerate(cfg.decoder_rates):
         cin = cfg.decoder_dim // 2 ** i
         cout = cfg.decoder_dim // 2 ** (i + 1)
-        b = f"{p}.{2 + i}.block.layers"
+        b = f"{p}.{first + i}.block.layers"
         alpha(b + ".0.alpha", cin)
         amp = math.sqrt(3.0 / (cin * 2))          # two taps of each input reach one output
         v = synth.synth_tensor(nxt(), (cin, 2 * s, cout), amp)
@@ -359,10 +421,12 @@ def make_synthetic_weights(cfg: SnacConfig, seed: int = 1234, with_encoder: bool
             wn_conv(r + ".1", cout, 7, 1, cout)
             alpha(r + ".2.alpha", cout)
             wn_conv(r + ".3", cout, 1, cout, cout, gain=0.2)
-    n = 2 + len(cfg.decoder_rates)
+    n = first + len(cfg.decoder_rates)
     cl = cfg.decoder_dim // 2 ** len(cfg.decoder_rates)
     alpha(f"{p}.{n}.alpha", cl)
     wn_conv(f"{p}.{n + 1}", 1, 7, cl, cl, gain=0.12)
+    if cfg.attn_window_size:                      # after the other decoder keys: they keep their generator keys
+        mha(p + ".2", cfg.decoder_dim)
     if with_encoder:                      # appended after every decoder key: the decoder tensors keep their generator keys
         e = "encoder.block.layers"
         wn_conv(e + ".0", cfg.encoder_dim, 7, 1, 1, gain=3.0)
@@ -378,7 +442,11 @@ def make_synthetic_weights(cfg: SnacConfig, seed: int = 1234, with_encoder: bool
             alpha(b + ".3.alpha", c)
             wn_conv(b + ".4", 2 * c, 2 * st, c, c)
             c *= 2
-        wn_conv(f"{e}.{1 + len(cfg.encoder_rates)}", c, 7, 1 if cfg.depthwise else c, c)
+        ne = 1 + len(cfg.encoder_rates)
+        if cfg.attn_window_size:
+            mha(f"{e}.{ne}", c)
+            ne += 1
+        wn_conv(f"{e}.{ne}", c, 7, 1 if cfg.depthwise else c, c)
     return W
 
 

@@ -1,4 +1,7 @@
 """Helpers shared by the -m gpu parity tests (all calls go through the C ABI via the host mirror)."""
+import contextlib
+import os
+
 import numpy as np
 import torch
 
@@ -83,3 +86,17 @@ def logits_errors(dev_l, ref_l):
     sure = (top2[..., 1] - top2[..., 0]) > 2 * err
     agree = bool(np.array_equal(dev_l.argmax(-1)[sure], ref_l.argmax(-1)[sure]))
     return err / scale, r, int(sure.sum()), agree
+
+
+@contextlib.contextmanager
+def codec_exact_f32():
+    """Run the enclosed codec calls on the exact-f32 kernels only (MIS_CODEC_EXACT_F32 is read per launch by csrc/codec_bf3.hip)."""
+    old = os.environ.get("MIS_CODEC_EXACT_F32")
+    os.environ["MIS_CODEC_EXACT_F32"] = "1"
+    try:
+        yield
+    finally:
+        if old is None:
+            os.environ.pop("MIS_CODEC_EXACT_F32", None)
+        else:
+            os.environ["MIS_CODEC_EXACT_F32"] = old

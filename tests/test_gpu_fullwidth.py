@@ -11,7 +11,7 @@ import pytest
 import torch
 
 import mlx_audio_swift_amd as mas
-from gpu_util import lm_host_config, logits_errors, record, rms
+from gpu_util import codec_exact_f32, lm_host_config, logits_errors, record, rms
 from oracle import dac as od
 from oracle import encodec as oe
 from oracle import llama as ollama
@@ -156,7 +156,11 @@ def test_qwen3tts_06b_width_frame_loop_and_real_decoder():
     got = dev.decode_codes(cd)
     werr = float(np.abs(got - ref).max() / max(np.abs(ref).max(), 1e-3))
     assert got.shape == ref.shape == (2, 13 * 1920) and werr <= 5e-4, werr
-    record("qwen3tts_06b_width", greedy_gap_rel=worst, tol_gap=0.04, decoder_wave_max_rel=werr, tol_wave=5e-4)
+    with codec_exact_f32():                                # the same decode on the exact-f32 kernels: the split-bf16 path ran, and is close
+        ex = dev.decode_codes(cd)
+    serr = float(np.abs(got - ex).max() / max(np.abs(ex).max(), 1e-3))
+    assert not np.array_equal(got, ex) and serr <= 3e-4, serr       # observed 1.0e-4 of the clipped full-scale waveform
+    record("qwen3tts_06b_width", greedy_gap_rel=worst, tol_gap=0.04, decoder_wave_max_rel=werr, tol_wave=5e-4, split_bf16_vs_exact_f32_max_rel=serr)
 
 
 def test_snac_24khz_one_row_96_groups():
@@ -174,7 +178,12 @@ def test_snac_24khz_one_row_96_groups():
     noise32 = [np.repeat(n, 32, axis=0) for n in noise]
     got32 = dev.decode(codes32, noise32)
     assert np.array_equal(got32[0], got[0]) and np.array_equal(got32[31], got[0])
-    record("snac_24khz_96_groups", wave_rms=e, wave_max=float(np.abs(got - ref).max()), tol_rms=1e-4)
+    with codec_exact_f32():
+        ex = dev.decode(codes, noise)
+    es = rms(got, ex)
+    assert not np.array_equal(got, ex) and es < 3e-5 and rms(ex, ref) < 1e-4, es
+    record("snac_24khz_96_groups", wave_rms=e, wave_max=float(np.abs(got - ref).max()), tol_rms=1e-4, split_bf16_vs_exact_f32_rms=es,
+           exact_f32_wave_rms=rms(ex, ref))
 
 
 def test_dac_24khz_and_encodec_24khz_real_dims():
@@ -190,6 +199,10 @@ def test_dac_24khz_and_encodec_24khz_real_dims():
     got = dev.decode_from_codes(codes)
     e_dac = float(np.abs(got - ref).max() / np.abs(ref).max())
     assert got.shape == ref.shape == (2, od.num_samples(c, 25)) and e_dac <= 3e-4, e_dac
+    with codec_exact_f32():
+        ex = dev.decode_from_codes(codes)
+    s_dac = float(np.abs(got - ex).max() / np.abs(ex).max())
+    assert not np.array_equal(got, ex) and s_dac <= 3e-4, s_dac
     ec = oe.EncodecConfig()
     We = oe.make_synthetic_weights(ec)
     fields = {k: getattr(ec, k) for k in mas.EncodecConfig.__dataclass_fields__ if hasattr(ec, k)}
@@ -199,4 +212,9 @@ def test_dac_24khz_and_encodec_24khz_real_dims():
     got = edev.decode_frame(codes)
     e_enc = float(np.abs(got - ref).max() / max(np.abs(ref).max(), 1e-3))
     assert got.shape == ref.shape == (2, 75 * 320) and e_enc <= 3e-4, e_enc
-    record("dac_encodec_24khz_real_dims", dac_wave_max_rel=e_dac, encodec_wave_max_rel=e_enc, tol=3e-4)
+    with codec_exact_f32():
+        ex = edev.decode_frame(codes)
+    s_enc = float(np.abs(got - ex).max() / max(np.abs(ex).max(), 1e-3))
+    assert s_enc <= 3e-4, s_enc
+    record("dac_encodec_24khz_real_dims", dac_wave_max_rel=e_dac, encodec_wave_max_rel=e_enc, tol=3e-4, dac_split_bf16_vs_exact_f32_max_rel=s_dac,
+           encodec_split_bf16_vs_exact_f32_max_rel=s_enc)

@@ -210,3 +210,38 @@ def test_snac_encode_decode_cycle_on_the_reference_fixture():
     e = rms(wav, ref)
     assert wav.shape == ref.shape == (1, 1, 36864) and wav.shape[-1] > 0 and e < TOL, e
     record("intention_wav_snac_cycle", code_agreement=agree, wave_rms=e, tol_rms=TOL)
+
+
+def test_local_mha_variant_decode_and_encode_match_oracle():
+    """The 32 / 44 kHz model family in miniature (oracle TINY_ATTN): LocalMHA (LayerNorm, to_qkv, rotary windowed attention,
+    to_out + residual; Attention.swift:14-185) after the decoder stem and before the encoder's last conv, four codebooks."""
+    import mlx_audio_swift_amd as mas
+    ocfg = osnac.SnacConfig(**osnac.TINY_ATTN)
+    W = osnac.make_synthetic_weights(ocfg, with_encoder=True)
+    orc = osnac.SnacOracle(ocfg, W)
+    hcfg = mas.SNACConfig(**{k: getattr(ocfg, k) for k in mas.SNACConfig.__dataclass_fields__})
+    dev = mas.SNAC.from_weights(hcfg, W)
+    for B, groups in ((2, 8), (1, 4), (3, 12)):                        # 8 latent frames per coarse frame: 2, 1 and 3 windows of 32
+        codes = osnac.synthetic_codes(ocfg, B, groups, seed=7)
+        noise = osnac.synthetic_noise(ocfg, B, groups, seed=8)
+        ref, inter = orc.decoder(orc.from_codes(codes), noise, return_intermediates=True)
+        got = dev.decode(codes, noise)
+        blk0 = dev.debug_tap("block0", B)                              # the first block sits right behind the attention layer
+        assert blk0.shape == inter["block0"].shape and np.abs(blk0 - inter["block0"]).max() <= 2e-4 * np.abs(inter["block0"]).max()
+        assert got.shape == ref.shape and rms(got, ref) < 1e-4, (B, groups, rms(got, ref))
+    # a latent length that is not a whole number of windows fails like the reference's reshape, loudly
+    with pytest.raises(mas.AudioGenerationError):
+        dev.decode(osnac.synthetic_codes(ocfg, 1, 3), None)
+    rng = np.random.default_rng(5)
+    for B, n in ((2, 3000), (1, 100)):
+        audio = (0.3 * rng.standard_normal((B, n))).astype(np.float32)
+        assert dev.padded_length(n) == orc.preprocess(audio[:, None]).shape[-1]
+        codes, z = dev.encode(audio, return_latent=True)
+        zr = orc.encoder(orc.preprocess(audio[:, None]))
+        assert z.shape == zr.shape and np.abs(z - zr).max() <= 2e-4 * np.abs(zr).max()
+        rcodes, dist = orc.encode(audio[:, None], return_details=True)
+        assert len(codes) == 4
+        for g, r, d in zip(codes, rcodes, dist):
+            ds = np.sort(d, -1)
+            sure = (ds[..., 1] - ds[..., 0]) > 1e-4
+            assert g.shape == r.shape and np.array_equal(g[sure], r[sure])

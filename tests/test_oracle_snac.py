@@ -149,3 +149,56 @@ def test_encode_path_strided_conv_and_nearest_code():
     # codes decode back through fromCodes to the sum of the per-level quantised vectors
     zq = orc.from_codes(codes)
     assert zq.shape == z.shape
+
+
+def test_local_mha_matches_an_independent_torch_implementation():
+    """LocalMHA of the 32 / 44 kHz models (Attention.swift:14-185) against torch building blocks (nn.LayerNorm, F.linear,
+    F.scaled_dot_product_attention per window, rotary embedding written the complex-pair way)."""
+    import torch
+    import torch.nn.functional as F
+    from oracle import snac as osn
+    cfg = osn.SnacConfig(**osn.TINY_ATTN)
+    W = osn.make_synthetic_weights(cfg, with_encoder=True)
+    o = osn.SnacOracle(cfg, W)
+    p = "decoder.model.layers.2"
+    rng = np.random.default_rng(0)
+    B, C, T = 2, cfg.decoder_dim, 96
+    x = rng.standard_normal((B, C, T)).astype(np.float32)
+    got = o.local_mha(x, p)
+    xt = torch.from_numpy(x).transpose(1, 2)                                         # [B, T, C]
+    h = F.layer_norm(xt, (C,), torch.from_numpy(W[p + ".norm.weight"]), torch.from_numpy(W[p + ".norm.bias"]), 1e-5)
+    qkv = F.linear(h, torch.from_numpy(W[p + ".to_qkv.weight"]))
+    q, k, v = qkv.chunk(3, dim=-1)
+    win, heads = 32, C // 64
+
+    def windows(a):                                                                  # [B, T, C] -> [B, heads, T/win, win, 64]
+        return a.reshape(B, T // win, win, heads, 64).permute(0, 3, 1, 2, 4)
+    q, k, v = windows(q), windows(k), windows(v)
+    inv = 1.0 / (10000.0 ** (torch.arange(0, 64, 2).float() / 64))
+    ang = torch.arange(win).float()[:, None] * inv[None, :]                          # [win, 32]
+    rot = torch.polar(torch.ones_like(ang), ang)                                     # e^{i n f_j}: pairs (j, j + 32) as one complex number
+
+    def rope(a):
+        z = torch.complex(a[..., :32], a[..., 32:]) * rot
+        return torch.cat([z.real, z.imag], dim=-1)
+    out = F.scaled_dot_product_attention(rope(q), rope(k), v)                        # scale 1 / sqrt(64), full attention inside the window
+    out = out.permute(0, 2, 3, 1, 4).reshape(B, T, C)
+    ref = (F.linear(out, torch.from_numpy(W[p + ".to_out.weight"])).transpose(1, 2) + torch.from_numpy(x)).numpy()
+    assert got.shape == ref.shape and np.abs(got - ref).max() < 2e-5 * np.abs(ref).max()
+    # a window is self-contained: changing frames of window 2 leaves windows 0 and 1 alone
+    x2 = x.copy(); x2[:, :, 64:] += 1.0
+    assert np.array_equal(o.local_mha(x2, p)[:, :, :64], got[:, :, :64])
+
+
+def test_attention_variant_decode_and_encode_shapes():
+    from oracle import snac as osn
+    cfg = osn.SnacConfig(**osn.TINY_ATTN)
+    o = osn.SnacOracle(cfg, osn.make_synthetic_weights(cfg, with_encoder=True))
+    codes = osn.synthetic_codes(cfg, 2, 8)                                           # 8 coarse frames -> 64 latent frames = 2 windows
+    wav = o.decode(codes, osn.synthetic_noise(cfg, 2, 8))
+    assert wav.shape == (2, 1, 64 * 16) and np.abs(wav).max() <= 1.0
+    audio = (0.3 * np.random.default_rng(1).standard_normal((1, 1, 1000))).astype(np.float32)
+    pa = o.preprocess(audio)
+    assert pa.shape[-1] % (16 * 32) == 0                                             # hop 16, lcm(vq stride 8, window 32) = 32
+    c = o.encode(audio)
+    assert [ci.shape for ci in c] == [(1, pa.shape[-1] // 16 // s) for s in cfg.vq_strides]
