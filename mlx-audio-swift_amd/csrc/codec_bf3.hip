@@ -36,7 +36,7 @@ struct Bf3Params {
     const uint16_t* wp;
     const uint16_t* xh;
     const uint16_t* xl;
-    int mode, ntaps, MT32, KS, Cp, Tp, t_org, nbx, tpb;
+    int mode, ntaps, MT32, KS, Cp, Tp, t_org;
 };
 
 __device__ __forceinline__ float bf3_snake(float x, float a, float ra) { return fmaf(ra, mis_sin_sq(a * x), x); }
@@ -120,39 +120,33 @@ __global__ void __launch_bounds__(B3_THREADS, MINW) k_bf3_gemm(Bf3Params P) {
     else if (P.mode == GEMM_TAPS) { sh0 = -p.pad; dsh = p.dil; }
     const int shmin = min(sh0, sh0 + (NTAPS - 1) * dsh);
     const int nchunks = P.Cp / B3_KC;
-    // persistent over a contiguous range of column tiles: the loader keeps streaming across tile boundaries (the next tile's first
-    // chunks land while the MFMA waves store the finished tile), the weight stream wraps around to chunk 0
-    const int tile0 = blockIdx.x * P.tpb, ntile = min(P.tpb, P.nbx - tile0);
+    const int n0 = blockIdx.x * B3_BN;
 
     if (wave == 4) {
         // ---- loader: tile column i = input column n0 + shmin + i.  DMA instruction q moves columns 16q .. 16q+15, four lanes per column;
         // lane slot gs holds channel group gs ^ ((i >> 2) & 3) (the swizzle is on the SOURCE address, the LDS side of a DMA is lane-linear)
         const int il = lane >> 2, grp = (lane & 3) ^ ((il >> 2) & 3);
-        const size_t col0 = ((size_t)b * P.Tp + (size_t)(tile0 * B3_BN + shmin - P.t_org + il)) * P.Cp + grp * 8;
+        const size_t col0 = ((size_t)b * P.Tp + (size_t)(n0 + shmin - P.t_org + il)) * P.Cp + grp * 8;
         const uint16_t* sh = P.xh + col0;
         const uint16_t* sl = P.xl + col0;
-        const size_t qstride = (size_t)16 * P.Cp, tstride = (size_t)B3_BN * P.Cp;
-        const int G = ntile * nchunks;                        // chunks of this block, all tiles
-        int ig = 0, icc = 0, itile = 0;                       // next chunk to issue
-        auto issue = [&]() {
-            const uint16_t* h = sh + itile * tstride + icc * B3_KC;
-            const uint16_t* l = sl + itile * tstride + icc * B3_KC;
-            const int buf = ig % NBUF;
+        const size_t qstride = (size_t)16 * P.Cp;
+        auto issue = [&](int cc) {
+            const uint16_t* h = sh + cc * B3_KC;
+            const uint16_t* l = sl + cc * B3_KC;
+            const int buf = cc % NBUF;
 #pragma unroll
             for (int q = 0; q < NQ; ++q) {
                 __builtin_amdgcn_global_load_lds((gptr_t)(h + q * qstride), (lptr_t)&lds[buf * BUF + q * 512], 16, 0, 0);
                 __builtin_amdgcn_global_load_lds((gptr_t)(l + q * qstride), (lptr_t)&lds[buf * BUF + PLANE + q * 512], 16, 0, 0);
             }
-            ++ig;
-            if (++icc == nchunks) { icc = 0; ++itile; }
         };
-        for (int c = 0; c < NBUF - 1 && c < G; ++c) issue();
-        for (int g = 0; g < G; ++g) {
-            // chunk g must have landed; up to NBUF-2 younger chunks stay in flight
-            if (G - 1 - g >= NBUF - 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NBUF - 2) * 2 * NQ) : "memory");
+        for (int c = 0; c < NBUF - 1 && c < nchunks; ++c) issue(c);
+        for (int cc = 0; cc < nchunks; ++cc) {
+            // chunk cc must have landed; up to NBUF-2 younger chunks stay in flight
+            if (nchunks - 1 - cc >= NBUF - 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NBUF - 2) * 2 * NQ) : "memory");
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
-            if (ig < G) issue();
+            if (cc + NBUF - 1 < nchunks) issue(cc + NBUF - 1);
         }
         return;
     }
@@ -161,13 +155,13 @@ __global__ void __launch_bounds__(B3_THREADS, MINW) k_bf3_gemm(Bf3Params P) {
     const int wm = wave >> 1, wn = wave & 1;
     const int mt0 = blockIdx.y * 4 + wm * 2;
     if (mt0 >= P.MT32) {                                   // no rows for this wave (M <= 64 in this block row): keep the barrier count
-        for (int g = 0; g < ntile * nchunks; ++g) __builtin_amdgcn_s_barrier();
+        for (int cc = 0; cc < nchunks; ++cc) __builtin_amdgcn_s_barrier();
         return;
     }
     f32x16_t acc[2][2];
 
     // weight stream: step (chunk, tap, ks) -> fragments of both row tiles, hi and lo.  It runs two steps ahead of the MFMAs, across
-    // chunk and tile boundaries (it does not depend on the staged tile).  A second row tile past M re-reads the first (its rows are
+    // chunk boundaries (it does not depend on the staged tile).  A second row tile past M re-reads the first (its rows are
     // never stored).  The body below is three chunks (3 * NST steps) of straight-line code: the weight registers rotate with period 3,
     // the tile-fragment registers with period 2, every index is a compile-time constant and there is no branch between the MFMAs,
     // so the waitcnt pass keeps exactly the two younger weight loads in flight (with branches in the body it fell back to vmcnt(0)).
@@ -178,7 +172,7 @@ __global__ void __launch_bounds__(B3_THREADS, MINW) k_bf3_gemm(Bf3Params P) {
     Bf3A aq[3];
     Bf3B bq[2];
     auto loadA = [&](Bf3A& f, int chunk, int tap, int ks) {
-        if (chunk >= nchunks) chunk -= nchunks;             // the next tile starts over at chunk 0
+        chunk = min(chunk, nchunks - 1);                     // the last steps prefetch past the end: re-read the last chunk
         const uint16_t* q = wbase + (size_t)tap * tap_stride + (size_t)(chunk * 2 + ks) * 1024;
         f.v[0][0] = *reinterpret_cast<const bf16x8_t*>(q);
         f.v[0][1] = *reinterpret_cast<const bf16x8_t*>(q + 512);
@@ -215,7 +209,7 @@ __global__ void __launch_bounds__(B3_THREADS, MINW) k_bf3_gemm(Bf3Params P) {
     const bool convt = P.mode == GEMM_CONVT, gelu = P.mode == GEMM_GELU, noise = P.mode == GEMM_NOISE;
     const float* Rr = (convt || gelu || noise) ? nullptr : p.R;
 
-    for (int ti = 0; ti < ntile; ++ti) {
+    {
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -267,16 +261,11 @@ __global__ void __launch_bounds__(B3_THREADS, MINW) k_bf3_gemm(Bf3Params P) {
                     __builtin_amdgcn_sched_barrier(0);
                 }
             }
-            // the next tile expects its first two steps in aq[0], aq[1]; after `rem` steps they sit at rotation rem % 3
-            const int ph = rem % 3;
-            if (ph == 1) { aq[0] = aq[1]; aq[1] = aq[2]; }
-            else if (ph == 2) { const Bf3A tmp = aq[0]; aq[0] = aq[2]; aq[1] = tmp; }
         }
 
         // ---- epilogue (the modes of k_snac_gemm / k_conv_taps).  C/D layout: col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)
-        const int n0 = (tile0 + ti) * B3_BN;
-        // the row offsets below are the same for every tile; left visible, LICM hoists all 32 rows' 64-bit offsets out of the tile
-        // loop and spills them (860 B of scratch per lane, written and re-read by every block: measured 1.9x slower)
+        // opaque: left visible, the 32 rows' 64-bit offsets are computed ahead of the main loop and spilled (860 B of scratch per
+        // lane in the multi-tile experiment: 1.9x slower)
         int lane_hi = lane >> 5;
         asm volatile("" : "+v"(lane_hi));
 #pragma unroll
@@ -385,15 +374,10 @@ bool launch_gemm_bf3(int mode, bool snake, const GemmParams& p_in, int batch, hi
     P.wp = e.wp; P.xh = p.pack->xh.p; P.xl = p.pack->xl.p;
     P.mode = mode; P.ntaps = ntaps; P.MT32 = e.MT32; P.KS = e.KS; P.Cp = e.Cp; P.Tp = Tp; P.t_org = t_org;
     const int phases = mode == GEMM_CONVT ? p.s : 1;
-    // column tiles per block: enough blocks for ~8 per CU, at most 16 tiles each
-    const int nby = (p.M + B3_BM - 1) / B3_BM;
-    const int64_t tiles = (int64_t)nbx * nby * batch * phases;
-    const int tpb = (int)std::max<int64_t>(1, std::min<int64_t>(bf3_env("MIS_BF3_TPB", 1), tiles / 2048));
-    P.nbx = nbx; P.tpb = tpb;
-    dim3 grid((nbx + tpb - 1) / tpb, nby, batch * phases), block(B3_THREADS);
+    dim3 grid(nbx, (p.M + B3_BM - 1) / B3_BM, batch * phases), block(B3_THREADS);
     // MINW 3 = two blocks (ten waves) per CU: 168 registers; the 7-tap body then spills a few address temporaries (A/B by MIS_BF3_MINW)
     // MINW 3 = two blocks (ten waves) per CU, 168 registers: fits 1 and 2 taps; the 7-tap body would spill (measured 2.3x slower), so it
-    // runs one block per CU and relies on the persistent tile loop for overlap
+    // runs one block per CU (a persistent loop over column tiles was measured too: no gain, profiles/r02_codec/ab_record.json)
     if (ntaps == 1) hipLaunchKernelGGL((k_bf3_gemm<9, 4, 1, 3>), grid, block, 0, s, P);
     else if (ntaps == 2) hipLaunchKernelGGL((k_bf3_gemm<9, 4, 2, 3>), grid, block, 0, s, P);
     else if (nq == 9) hipLaunchKernelGGL((k_bf3_gemm<9, 4, 7, 2>), grid, block, 0, s, P);
