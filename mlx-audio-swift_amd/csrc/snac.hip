@@ -171,6 +171,119 @@ __global__ void __launch_bounds__(256) k_snac_local_attn(const float* __restrict
     }
 }
 
+// ---- fused depthwise ResidualUnit for the narrow late blocks (Layers.swift:202-231) -------------------------------------------------
+// y = x + W2 . snake2(dw7_dil(snake1(x)) + b1) + b2 for C = 64 / 128 channels in ONE pass over the tensor: as two kernels the unit
+// reads x, writes t, reads t, reads x again and writes y (five passes at 3.0-3.5 TB/s; the two late decoder blocks are HBM-bound, not
+// MFMA-bound).  Per 128-column tile and 32-channel chunk: x with its dilation halo is staged once (Snake applied on the way in), the
+// depthwise taps read it from LDS, the chunk of t goes straight into the B-operand tile of the exact-f32 MFMA contraction with the
+// chunk's rows of W2^T.  The residual is re-read at the end (L2-hot).  Same arithmetic per element as k_snac_dw + k_snac_gemm.
+#define RU_NT 128
+#define RU_KC 32
+#define RU_XS (RU_NT + 2 * DW_HALO + 2)
+template <int C>
+__global__ void __launch_bounds__(256, 2) k_snac_ru_fused(const float* __restrict__ X, float* __restrict__ Y, const float* __restrict__ w7,
+                                                          const float* __restrict__ b1, const float* __restrict__ a1, const float* __restrict__ ra1,
+                                                          const float* __restrict__ a2, const float* __restrict__ ra2,
+                                                          const float* __restrict__ AT /*[C][C]: [k][m]*/, const float* __restrict__ b2, int T, int dil) {
+    __shared__ float xs[RU_KC][RU_XS];
+    __shared__ float ts[RU_KC][RU_NT];
+    __shared__ float As[RU_KC][C];
+    constexpr int NTW = C == 128 ? 2 : 1;                 // 32-column tiles per wave (two 32-row tiles per wave in both cases)
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int n0 = blockIdx.x * RU_NT, b = blockIdx.y;
+    const int wm = C == 128 ? (wave >> 1) : 0;            // rows 64 wm ..; columns: C = 128: 64 (wave & 1) ..; C = 64: 32 wave ..
+    const int wc = C == 128 ? (wave & 1) * 64 : wave * 32;
+    const float* xb = X + (size_t)b * C * T;
+    const int halo = 3 * dil, ncols = RU_NT + 2 * halo;
+    f32x16_t acc[2][NTW];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < NTW; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+    for (int c0 = 0; c0 < C; c0 += RU_KC) {
+        __syncthreads();                                   // the previous chunk's MFMAs are done with ts / As
+        {   // x chunk with halo, Snake on the way in (zero padding AFTER Snake: snake(0) = 0).  All 24 loads of a thread are issued
+            // before the first use: lane -> column within a 64-column strip (3 strips cover 128 + 54), wave -> rows wave, wave + 4, ...
+            // (fetching the next chunk under this chunk's MFMAs was measured too: no gain at 128 channels, 8 % slower at 64)
+            float v[8][3];
+#pragma unroll
+            for (int r = 0; r < 8; ++r) {
+                const int c = c0 + wave + 4 * r;
+#pragma unroll
+                for (int sx = 0; sx < 3; ++sx) {
+                    const int j = sx * 64 + lane, t = n0 - halo + j;
+                    const bool ok = j < ncols && t >= 0 && t < T;
+                    v[r][sx] = xb[(size_t)c * T + (ok ? t : 0)];
+                    v[r][sx] = ok ? v[r][sx] : 0.0f;
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < 8; ++r) {
+                const int cc = wave + 4 * r, c = c0 + cc;
+                const float al = a1[c], ral = ra1[c];
+#pragma unroll
+                for (int sx = 0; sx < 3; ++sx) {
+                    const int j = sx * 64 + lane;
+                    if (j < RU_XS) xs[cc][j] = snake_f(v[r][sx], al, ral);
+                }
+            }
+        }
+        for (int i = tid; i < RU_KC * (C / 4); i += 256) { // rows c0 .. c0+31 of W2^T
+            const int r = i / (C / 4), m4 = (i - r * (C / 4)) * 4;
+            *reinterpret_cast<float4*>(&As[r][m4]) = *reinterpret_cast<const float4*>(AT + (size_t)(c0 + r) * C + m4);
+        }
+        __syncthreads();
+        // depthwise taps + bias + Snake -> the chunk of t.  lane -> column (consecutive lanes read consecutive LDS words: no bank
+        // conflicts), wave -> channels wave, wave + 4, ...
+#pragma unroll 2
+        for (int r = 0; r < 8; ++r) {
+            const int cc = wave + 4 * r, c = c0 + cc;
+            float wk[7];
+#pragma unroll
+            for (int k = 0; k < 7; ++k) wk[k] = w7[c * 7 + k];
+            const float bv = b1[c], ao = a2[c], rao = ra2[c];
+#pragma unroll
+            for (int hx = 0; hx < 2; ++hx) {
+                const int n = hx * 64 + lane;
+                float a = 0.0f;
+#pragma unroll
+                for (int k = 0; k < 7; ++k) a += wk[k] * xs[cc][n + k * dil];
+                a += bv;
+                ts[cc][n] = snake_f(a, ao, rao);
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int kk = 0; kk < RU_KC; kk += 2) {
+            float av[2], bv2[NTW];
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi) av[mi] = As[kk + (lane >> 5)][wm * 64 + mi * 32 + (lane & 31)];
+#pragma unroll
+            for (int ni = 0; ni < NTW; ++ni) bv2[ni] = ts[kk + (lane >> 5)][wc + ni * 32 + (lane & 31)];
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < NTW; ++ni) acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[mi], bv2[ni], acc[mi][ni], 0, 0, 0);
+        }
+    }
+    // epilogue: + bias + residual (C/D layout: col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5))
+    float* yb = Y + (size_t)b * C * T;
+#pragma unroll
+    for (int ni = 0; ni < NTW; ++ni) {
+        const int n = n0 + wc + ni * 32 + (lane & 31);
+        if (n >= T) continue;
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = wm * 64 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                yb[(size_t)m * T + n] = xb[(size_t)m * T + n] + (acc[mi][ni][r] + b2[m]);
+            }
+    }
+}
+
 // ---- dense contraction on f32 MFMA ----------------------------------------------------------------
 #define G_BM 64
 #define G_BN 128
@@ -1087,6 +1200,11 @@ static void snac_local_mha(const mis_snac::MhaW& m, const float* W, int win, con
     launch_gemm(GEMM_RESID, false, o, batch, s);
 }
 
+static bool ru_fused_enabled() {
+    const char* v = getenv("MIS_SNAC_RU_FUSED");
+    return !v || atoi(v) != 0;
+}
+
 // Runs the decode on device pointers.  stop_after: -1 = full; 0 zq, 1 stem_dw, 2 stem_pw, 3+i block i.
 // Returns the buffer holding the stage output (for taps) and its [C, T].
 struct NoiseRng { int enabled = 0; uint64_t seed = 0; const int32_t* row_ids = nullptr; int64_t row_offset = 0; };
@@ -1168,6 +1286,17 @@ static const float* snac_run(mis_snac* c, const int32_t* const* codes, int batch
         const int dils[3] = {1, 3, 9};
         for (int j = 0; j < 3; ++j) {   // ResidualUnit (Layers.swift:202-231)
             const auto& ru = blk.ru[j];
+            if ((blk.cout == 64 || blk.cout == 128) && ru_fused_enabled()) {           // HBM-bound late blocks: one pass instead of five
+                dim3 fg(cdiv(T, RU_NT), batch);
+                if (blk.cout == 128)
+                    hipLaunchKernelGGL((k_snac_ru_fused<128>), fg, dim3(256), 0, s, x, f2, W + ru.dw.w, W + ru.dw.b, W + ru.s1.a, W + ru.s1.ra,
+                                       W + ru.s2.a, W + ru.s2.ra, W + ru.pw.w, W + ru.pw.b, (int)T, dils[j]);
+                else
+                    hipLaunchKernelGGL((k_snac_ru_fused<64>), fg, dim3(256), 0, s, x, f2, W + ru.dw.w, W + ru.dw.b, W + ru.s1.a, W + ru.s1.ra,
+                                       W + ru.s2.a, W + ru.s2.ra, W + ru.pw.w, W + ru.pw.b, (int)T, dils[j]);
+                std::swap(x, f2);
+                continue;
+            }
             hipLaunchKernelGGL((k_snac_dw<true, true>), dim3(cdiv(T, DW_TILE), blk.cout, batch), dim3(256), 0, s,
                                x, f1, W + ru.dw.w, W + ru.dw.b, W + ru.s1.a, W + ru.s1.ra, W + ru.s2.a, W + ru.s2.ra,
                                blk.cout, (int)T, dils[j]);
