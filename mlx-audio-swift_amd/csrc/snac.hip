@@ -171,40 +171,59 @@ __global__ void __launch_bounds__(256) k_snac_local_attn(const float* __restrict
     }
 }
 
-// ---- fused depthwise ResidualUnit for the narrow late blocks (Layers.swift:202-231) -------------------------------------------------
-// y = x + W2 . snake2(dw7_dil(snake1(x)) + b1) + b2 for C = 64 / 128 channels in ONE pass over the tensor: as two kernels the unit
-// reads x, writes t, reads t, reads x again and writes y (five passes at 3.0-3.5 TB/s; the two late decoder blocks are HBM-bound, not
-// MFMA-bound).  Per 128-column tile and 32-channel chunk: x with its dilation halo is staged once (Snake applied on the way in), the
-// depthwise taps read it from LDS, the chunk of t goes straight into the B-operand tile of the exact-f32 MFMA contraction with the
-// chunk's rows of W2^T.  The residual is re-read at the end (L2-hot).  Same arithmetic per element as k_snac_dw + k_snac_gemm.
+// ---- fused narrow ResidualUnit tails -------------------------------------------------------------------------------------------------
+// DW = true  (SNAC, Layers.swift:202-231):  y = x + W2 . snake2(dw7_dil(snake1(x)) + b1) + b2  for C = 64 / 128 channels in ONE pass over
+//            the tensor: as two kernels the unit reads x, writes t, reads t, reads x again and writes y (five passes at 3.0-3.5 TB/s;
+//            the two late decoder blocks are HBM-bound, not MFMA-bound).
+// DW = false (Qwen3-TTS / DAC decoder units): y = r + W2 . snake(t) + b2, the 1x1 conv with Snake prologue and residual epilogue over
+//            C <= 192 channels with the WHOLE channel range in one block: the generic GEMM runs ceil(C / 64) row blocks that each
+//            re-stage (and re-Snake) the same input tile, and 96 rows fill only 1.5 of them.
+// Per 128-column tile and 32-channel chunk: the input (DW: with its dilation halo) is staged once, Snake applied on the way in; DW:
+// the depthwise taps read it from LDS; the chunk of t goes straight into the B-operand tile of the exact-f32 MFMA contraction with
+// the chunk's rows of W2^T.  The residual is read at the end (DW: L2-hot).  Same arithmetic per element as the unfused kernels.
 #define RU_NT 128
 #define RU_KC 32
 #define RU_XS (RU_NT + 2 * DW_HALO + 2)
-template <int C>
-__global__ void __launch_bounds__(256, 2) k_snac_ru_fused(const float* __restrict__ X, float* __restrict__ Y, const float* __restrict__ w7,
-                                                          const float* __restrict__ b1, const float* __restrict__ a1, const float* __restrict__ ra1,
-                                                          const float* __restrict__ a2, const float* __restrict__ ra2,
-                                                          const float* __restrict__ AT /*[C][C]: [k][m]*/, const float* __restrict__ b2, int T, int dil) {
-    __shared__ float xs[RU_KC][RU_XS];
+struct PwFusedParams {
+    const float* X; const float* R; float* Y;
+    const float *w7, *b1, *a1, *ra1;       // DW: depthwise weights [C][7], bias, Snake before the taps
+    const float *a2, *ra2;                 // Snake in front of the 1x1 conv
+    const float *AT, *b2;                  // W2^T [C][C] ([k][m]), bias
+    int T, dil, ldx, ldr, ldy;
+};
+// The body takes restrict-qualified PARAMETERS (clang ignores restrict on struct members and on locals; after inlining the parameter
+// attributes survive as scoped-noalias metadata): without them every residual / bias load of the epilogue has to wait behind the
+// previous row's store (measured: the SNAC units 2.25 -> 2.83 ms when the pointers were read from the parameter struct directly).
+struct PwFusedScalars { int T, dil, ldx, ldr, ldy; };
+template <int C, bool DW>
+__device__ __forceinline__ void pw_fused_body(const float* __restrict__ pX, const float* __restrict__ pR, float* __restrict__ pY,
+                                              const float* __restrict__ pw7, const float* __restrict__ pb1, const float* __restrict__ pa1,
+                                              const float* __restrict__ pra1, const float* __restrict__ pa2, const float* __restrict__ pra2,
+                                              const float* __restrict__ pAT, const float* __restrict__ pb2, const PwFusedScalars sc) {
+    struct { const float *X, *R; float* Y; const float *w7, *b1, *a1, *ra1, *a2, *ra2, *AT, *b2; int T, dil, ldx, ldr, ldy; } p =
+        {pX, pR, pY, pw7, pb1, pa1, pra1, pa2, pra2, pAT, pb2, sc.T, sc.dil, sc.ldx, sc.ldr, sc.ldy};
+    __shared__ float xs[DW ? RU_KC : 1][DW ? RU_XS : 1];
     __shared__ float ts[RU_KC][RU_NT];
     __shared__ float As[RU_KC][C];
-    constexpr int NTW = C == 128 ? 2 : 1;                 // 32-column tiles per wave (two 32-row tiles per wave in both cases)
+    constexpr bool SQ = C == 128;                         // 2 x 2 waves of 64 x 64; else every wave: all C rows x 32 columns
+    constexpr int MTW = SQ ? 2 : C / 32, NTW = SQ ? 2 : 1;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int n0 = blockIdx.x * RU_NT, b = blockIdx.y;
-    const int wm = C == 128 ? (wave >> 1) : 0;            // rows 64 wm ..; columns: C = 128: 64 (wave & 1) ..; C = 64: 32 wave ..
-    const int wc = C == 128 ? (wave & 1) * 64 : wave * 32;
-    const float* xb = X + (size_t)b * C * T;
-    const int halo = 3 * dil, ncols = RU_NT + 2 * halo;
-    f32x16_t acc[2][NTW];
+    const int wr = SQ ? (wave >> 1) * 64 : 0;             // first row / first column of the wave's tile
+    const int wc = SQ ? (wave & 1) * 64 : wave * 32;
+    const float* xb = p.X + (size_t)b * C * p.ldx;
+    const int T = p.T, halo = 3 * p.dil, ncols = RU_NT + 2 * halo;
+    f32x16_t acc[MTW][NTW];
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < MTW; ++i)
 #pragma unroll
         for (int j = 0; j < NTW; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
     for (int c0 = 0; c0 < C; c0 += RU_KC) {
         __syncthreads();                                   // the previous chunk's MFMAs are done with ts / As
-        {   // x chunk with halo, Snake on the way in (zero padding AFTER Snake: snake(0) = 0).  All 24 loads of a thread are issued
+        if (DW) {
+            // x chunk with halo, Snake on the way in (zero padding AFTER Snake: snake(0) = 0).  All 24 loads of a thread are issued
             // before the first use: lane -> column within a 64-column strip (3 strips cover 128 + 54), wave -> rows wave, wave + 4, ...
             // (fetching the next chunk under this chunk's MFMAs was measured too: no gain at 128 channels, 8 % slower at 64)
             float v[8][3];
@@ -215,73 +234,99 @@ __global__ void __launch_bounds__(256, 2) k_snac_ru_fused(const float* __restric
                 for (int sx = 0; sx < 3; ++sx) {
                     const int j = sx * 64 + lane, t = n0 - halo + j;
                     const bool ok = j < ncols && t >= 0 && t < T;
-                    v[r][sx] = xb[(size_t)c * T + (ok ? t : 0)];
+                    v[r][sx] = xb[(size_t)c * p.ldx + (ok ? t : 0)];
                     v[r][sx] = ok ? v[r][sx] : 0.0f;
                 }
             }
 #pragma unroll
             for (int r = 0; r < 8; ++r) {
                 const int cc = wave + 4 * r, c = c0 + cc;
-                const float al = a1[c], ral = ra1[c];
+                const float al = p.a1[c], ral = p.ra1[c];
 #pragma unroll
                 for (int sx = 0; sx < 3; ++sx) {
                     const int j = sx * 64 + lane;
                     if (j < RU_XS) xs[cc][j] = snake_f(v[r][sx], al, ral);
                 }
             }
+        } else {
+            // the chunk of the 1x1 conv's input, Snake on the way in: 16 loads per thread up front (lane -> column, wave -> rows)
+            float v[8][2];
+#pragma unroll
+            for (int r = 0; r < 8; ++r) {
+                const int c = c0 + wave + 4 * r;
+#pragma unroll
+                for (int hx = 0; hx < 2; ++hx) {
+                    const int t = n0 + hx * 64 + lane;
+                    v[r][hx] = xb[(size_t)c * p.ldx + (t < T ? t : 0)];
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < 8; ++r) {
+                const int cc = wave + 4 * r, c = c0 + cc;
+                const float al = p.a2[c], ral = p.ra2[c];
+#pragma unroll
+                for (int hx = 0; hx < 2; ++hx) ts[cc][hx * 64 + lane] = snake_f(v[r][hx], al, ral);
+            }
         }
         for (int i = tid; i < RU_KC * (C / 4); i += 256) { // rows c0 .. c0+31 of W2^T
             const int r = i / (C / 4), m4 = (i - r * (C / 4)) * 4;
-            *reinterpret_cast<float4*>(&As[r][m4]) = *reinterpret_cast<const float4*>(AT + (size_t)(c0 + r) * C + m4);
+            *reinterpret_cast<float4*>(&As[r][m4]) = *reinterpret_cast<const float4*>(p.AT + (size_t)(c0 + r) * C + m4);
         }
-        __syncthreads();
-        // depthwise taps + bias + Snake -> the chunk of t.  lane -> column (consecutive lanes read consecutive LDS words: no bank
-        // conflicts), wave -> channels wave, wave + 4, ...
+        if (DW) {
+            __syncthreads();
+            // depthwise taps + bias + Snake -> the chunk of t.  lane -> column (consecutive lanes read consecutive LDS words: no bank
+            // conflicts), wave -> channels wave, wave + 4, ...
 #pragma unroll 2
-        for (int r = 0; r < 8; ++r) {
-            const int cc = wave + 4 * r, c = c0 + cc;
-            float wk[7];
+            for (int r = 0; r < 8; ++r) {
+                const int cc = wave + 4 * r, c = c0 + cc;
+                float wk[7];
 #pragma unroll
-            for (int k = 0; k < 7; ++k) wk[k] = w7[c * 7 + k];
-            const float bv = b1[c], ao = a2[c], rao = ra2[c];
+                for (int k = 0; k < 7; ++k) wk[k] = p.w7[c * 7 + k];
+                const float bv = p.b1[c], ao = p.a2[c], rao = p.ra2[c];
 #pragma unroll
-            for (int hx = 0; hx < 2; ++hx) {
-                const int n = hx * 64 + lane;
-                float a = 0.0f;
+                for (int hx = 0; hx < 2; ++hx) {
+                    const int n = hx * 64 + lane;
+                    float a = 0.0f;
 #pragma unroll
-                for (int k = 0; k < 7; ++k) a += wk[k] * xs[cc][n + k * dil];
-                a += bv;
-                ts[cc][n] = snake_f(a, ao, rao);
+                    for (int k = 0; k < 7; ++k) a += wk[k] * xs[cc][n + k * p.dil];
+                    a += bv;
+                    ts[cc][n] = snake_f(a, ao, rao);
+                }
             }
         }
         __syncthreads();
 #pragma unroll
         for (int kk = 0; kk < RU_KC; kk += 2) {
-            float av[2], bv2[NTW];
+            float av[MTW], bv2[NTW];
 #pragma unroll
-            for (int mi = 0; mi < 2; ++mi) av[mi] = As[kk + (lane >> 5)][wm * 64 + mi * 32 + (lane & 31)];
+            for (int mi = 0; mi < MTW; ++mi) av[mi] = As[kk + (lane >> 5)][wr + mi * 32 + (lane & 31)];
 #pragma unroll
             for (int ni = 0; ni < NTW; ++ni) bv2[ni] = ts[kk + (lane >> 5)][wc + ni * 32 + (lane & 31)];
 #pragma unroll
-            for (int mi = 0; mi < 2; ++mi)
+            for (int mi = 0; mi < MTW; ++mi)
 #pragma unroll
                 for (int ni = 0; ni < NTW; ++ni) acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[mi], bv2[ni], acc[mi][ni], 0, 0, 0);
         }
     }
     // epilogue: + bias + residual (C/D layout: col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5))
-    float* yb = Y + (size_t)b * C * T;
+    const float* rb = p.R + (size_t)b * C * p.ldr;
+    float* yb = p.Y + (size_t)b * C * p.ldy;
 #pragma unroll
     for (int ni = 0; ni < NTW; ++ni) {
         const int n = n0 + wc + ni * 32 + (lane & 31);
         if (n >= T) continue;
 #pragma unroll
-        for (int mi = 0; mi < 2; ++mi)
+        for (int mi = 0; mi < MTW; ++mi)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int m = wm * 64 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                yb[(size_t)m * T + n] = xb[(size_t)m * T + n] + (acc[mi][ni][r] + b2[m]);
+                const int m = wr + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                yb[(size_t)m * p.ldy + n] = rb[(size_t)m * p.ldr + n] + (acc[mi][ni][r] + p.b2[m]);
             }
     }
+}
+template <int C, bool DW>
+__global__ void __launch_bounds__(256, 2) k_pw_fused(PwFusedParams p) {
+    pw_fused_body<C, DW>(p.X, p.R, p.Y, p.w7, p.b1, p.a1, p.ra1, p.a2, p.ra2, p.AT, p.b2, PwFusedScalars{p.T, p.dil, p.ldx, p.ldr, p.ldy});
 }
 
 // ---- dense contraction on f32 MFMA ----------------------------------------------------------------
@@ -1139,6 +1184,11 @@ void launch_dw7(const float* X, float* Y, const float* w7, const float* bias, in
                        nullptr, nullptr, nullptr, C, T, dil);
 }
 
+static bool ru_fused_enabled() {                       // MIS_CODEC_FUSED_UNITS=0: the unfused kernels (A/B)
+    const char* v = getenv("MIS_CODEC_FUSED_UNITS");
+    return !v || atoi(v) != 0;
+}
+
 // encoder pieces shared with the Descript DAC encoder (dac.hip)
 void launch_enc_first(const float* audio, float* y, const float* w, const float* bias, int batch, int C, int T, hipStream_t s) {
     hipLaunchKernelGGL(k_enc_first, dim3(cdiv(T, 256), C, batch), dim3(256), 0, s, audio, y, w, bias, C, T);
@@ -1159,6 +1209,18 @@ void launch_gemm(int mode, bool snake, const GemmParams& p_in, int batch, hipStr
     if (!p.ldx) p.ldx = p.Tin;                                          // dense [B][C][T] tensors unless the caller says otherwise
     if (!p.ldy) p.ldy = p.Tout;
     MIS_REQUIRE(p.x_lo <= 0 && p.ldx >= p.Tin, MIS_ERR_GENERATION_FAILED, "bad codec GEMM strides");
+    if (mode == GEMM_RESID && snake && p.alpha && p.R && !p.scale && p.bias && p.M == p.K && ru_fused_enabled() &&
+        (p.M == 64 || p.M == 96 || p.M == 128 || p.M == 192)) {           // narrow unit tails: whole channel range per block (k_pw_fused)
+        PwFusedParams fp{};
+        fp.X = p.X; fp.R = p.R; fp.Y = p.Y; fp.a2 = p.alpha; fp.ra2 = p.ralpha; fp.AT = p.AT; fp.b2 = p.bias;
+        fp.T = p.N; fp.dil = 0; fp.ldx = p.ldx; fp.ldr = p.ldy; fp.ldy = p.ldy;
+        dim3 fg(cdiv(p.N, RU_NT), batch);
+        if (p.M == 64) hipLaunchKernelGGL((k_pw_fused<64, false>), fg, dim3(256), 0, s, fp);
+        else if (p.M == 96) hipLaunchKernelGGL((k_pw_fused<96, false>), fg, dim3(256), 0, s, fp);
+        else if (p.M == 128) hipLaunchKernelGGL((k_pw_fused<128, false>), fg, dim3(256), 0, s, fp);
+        else hipLaunchKernelGGL((k_pw_fused<192, false>), fg, dim3(256), 0, s, fp);
+        return;
+    }
     if (launch_gemm_bf3(mode, snake, p, batch, s)) return;
     int phases = (mode == GEMM_CONVT) ? p.s : 1;
     dim3 grid(cdiv(p.N, G_BN), cdiv(p.M, G_BM), batch * phases), block(256);
@@ -1198,11 +1260,6 @@ static void snac_local_mha(const mis_snac::MhaW& m, const float* W, int win, con
     GemmParams o{};
     o.AT = W + m.out; o.X = t1; o.Y = y; o.R = x; o.M = C; o.K = C; o.N = (int)T; o.Tin = (int)T; o.Tout = (int)T;
     launch_gemm(GEMM_RESID, false, o, batch, s);
-}
-
-static bool ru_fused_enabled() {
-    const char* v = getenv("MIS_SNAC_RU_FUSED");
-    return !v || atoi(v) != 0;
 }
 
 // Runs the decode on device pointers.  stop_after: -1 = full; 0 zq, 1 stem_dw, 2 stem_pw, 3+i block i.
@@ -1287,13 +1344,13 @@ static const float* snac_run(mis_snac* c, const int32_t* const* codes, int batch
         for (int j = 0; j < 3; ++j) {   // ResidualUnit (Layers.swift:202-231)
             const auto& ru = blk.ru[j];
             if ((blk.cout == 64 || blk.cout == 128) && ru_fused_enabled()) {           // HBM-bound late blocks: one pass instead of five
+                PwFusedParams fp{};
+                fp.X = x; fp.R = x; fp.Y = f2; fp.w7 = W + ru.dw.w; fp.b1 = W + ru.dw.b; fp.a1 = W + ru.s1.a; fp.ra1 = W + ru.s1.ra;
+                fp.a2 = W + ru.s2.a; fp.ra2 = W + ru.s2.ra; fp.AT = W + ru.pw.w; fp.b2 = W + ru.pw.b;
+                fp.T = (int)T; fp.dil = dils[j]; fp.ldx = fp.ldr = fp.ldy = (int)T;
                 dim3 fg(cdiv(T, RU_NT), batch);
-                if (blk.cout == 128)
-                    hipLaunchKernelGGL((k_snac_ru_fused<128>), fg, dim3(256), 0, s, x, f2, W + ru.dw.w, W + ru.dw.b, W + ru.s1.a, W + ru.s1.ra,
-                                       W + ru.s2.a, W + ru.s2.ra, W + ru.pw.w, W + ru.pw.b, (int)T, dils[j]);
-                else
-                    hipLaunchKernelGGL((k_snac_ru_fused<64>), fg, dim3(256), 0, s, x, f2, W + ru.dw.w, W + ru.dw.b, W + ru.s1.a, W + ru.s1.ra,
-                                       W + ru.s2.a, W + ru.s2.ra, W + ru.pw.w, W + ru.pw.b, (int)T, dils[j]);
+                if (blk.cout == 128) hipLaunchKernelGGL((k_pw_fused<128, true>), fg, dim3(256), 0, s, fp);
+                else hipLaunchKernelGGL((k_pw_fused<64, true>), fg, dim3(256), 0, s, fp);
                 std::swap(x, f2);
                 continue;
             }

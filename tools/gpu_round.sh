@@ -1,7 +1,7 @@
 set -x
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out
-timeout 900 python -m pytest tests/test_gpu_snac.py "tests/test_gpu_fullwidth.py::test_snac_24khz_one_row_96_groups" -m gpu -q -x 2>&1 | grep -E "passed|failed|Error|assert" | tail -6
+timeout 900 python -m pytest tests/test_gpu_snac.py tests/test_gpu_dac.py -m gpu -q -x 2>&1 | grep -E "passed|failed|Error|assert" | tail -6
 export TMPDIR=/tmp
 run() {  # name, workload, start kernel, env...
   name=$1; w=$2; k=$3; shift; shift; shift
@@ -11,5 +11,5 @@ run() {  # name, workload, start kernel, env...
   python tools/codec_dispatch_trace.py $f 400 > gpurun_out/dispatch_$name.txt 2>&1
   python tools/dispatch_sum.py gpurun_out/dispatch_$name.txt $k
 }
-run snac_ruf2 snac32 k_snac_embed A=1
-grep "k_snac_ru_fused" gpurun_out/dispatch_snac_ruf2.txt | tail -6 | cut -c1-125
+run snac_pwf2 snac32 k_snac_embed A=1
+run q3_pwf2 q3b32 k_q3_rvq A=1
