@@ -107,8 +107,12 @@ struct Bf3B { bf16x8_t v[2][2]; };     // [n tile][hi, lo]
 #define B3_IL_M __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);
 #define B3_INTERLEAVE B3_IL_V B3_IL_V B3_IL_V B3_IL_V B3_IL_D B3_IL_D B3_IL_D B3_IL_D B3_IL_M B3_IL_M B3_IL_M B3_IL_M
 
-template <int NQ, int NBUF, int NTAPS, int MINW>
-__global__ void __launch_bounds__(B3_THREADS, MINW) k_bf3_gemm(Bf3Params P) {
+// The body takes the arrays the epilogue touches as restrict-qualified PARAMETERS: GemmParams is a struct, clang ignores restrict on
+// struct members, and without it every bias / residual load of the epilogue waits behind the previous row's store (the same effect
+// cost the fused unit kernel of snac.hip 25 %).
+template <int NQ, int NBUF, int NTAPS>
+__device__ __forceinline__ void bf3_body(const Bf3Params& P, const float* __restrict__ pX, const float* __restrict__ pR, float* __restrict__ pY,
+                                         const float* __restrict__ pbias, const float* __restrict__ pscale, const float* __restrict__ pnoise) {
     constexpr int PLANE = NQ * 512;                       // bf16 per plane: NQ DMA instructions of 1 KiB (16 columns x 32 channels)
     constexpr int BUF = 2 * PLANE;
     constexpr int NST = 2 * NTAPS;                        // MFMA steps (16 channels of one tap) per chunk
@@ -205,9 +209,9 @@ __global__ void __launch_bounds__(B3_THREADS, MINW) k_bf3_gemm(Bf3Params P) {
     loadA(aq[1], 0, 0, 1);
     const uint16_t* tile = lds;
     int gbuf = 0;                                           // ring slot of the next chunk
-    const float* Xb = p.X + (size_t)b * p.Cin * p.ldx;
+    const float* Xb = pX + (size_t)b * p.Cin * p.ldx;
     const bool convt = P.mode == GEMM_CONVT, gelu = P.mode == GEMM_GELU, noise = P.mode == GEMM_NOISE;
-    const float* Rr = (convt || gelu || noise) ? nullptr : p.R;
+    const float* Rr = (convt || gelu || noise) ? nullptr : pR;
 
     {
 #pragma unroll
@@ -274,7 +278,7 @@ __global__ void __launch_bounds__(B3_THREADS, MINW) k_bf3_gemm(Bf3Params P) {
             if (n >= p.N) continue;
             float nz = 0.0f;
             if (noise) {
-                if (p.noise) nz = p.noise[(size_t)b * p.N + n];
+                if (pnoise) nz = pnoise[(size_t)b * p.N + n];
                 else if (p.noise_rng) {
                     uint64_t row = (uint64_t)(p.row_offset + (p.row_ids ? p.row_ids[b] : b));
                     uint64_t u = mis_splitmix64((p.noise_key ^ (row * 0xD1B54A32D192ED03ull)) + (uint64_t)n);
@@ -293,18 +297,23 @@ __global__ void __launch_bounds__(B3_THREADS, MINW) k_bf3_gemm(Bf3Params P) {
                     const int m = (mt0 + mi) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lane_hi;
                     if (m >= p.M) continue;
                     float v = acc[mi][ni][r];
-                    const float bm = p.bias ? p.bias[m] : 0.0f;
+                    const float bm = pbias ? pbias[m] : 0.0f;
                     v += bm;
                     if (dupb) v += bm;
                     const size_t rowo = ((size_t)b * p.M + m) * p.ldy;
                     if (gelu) v = 0.5f * v * (1.0f + erff(v * 0.70710678118654752f));
-                    if (Rr) { if (p.scale) v *= p.scale[m]; v += Rr[rowo + n]; }
+                    if (Rr) { if (pscale) v *= pscale[m]; v += Rr[rowo + n]; }
                     if (noise) v = Xb[(size_t)m * p.ldx + n] + nz * v;
-                    p.Y[rowo + o] = v;
+                    pY[rowo + o] = v;
                 }
             }
         }
     }
+}
+
+template <int NQ, int NBUF, int NTAPS, int MINW>
+__global__ void __launch_bounds__(B3_THREADS, MINW) k_bf3_gemm(Bf3Params P) {
+    bf3_body<NQ, NBUF, NTAPS>(P, P.g.X, P.g.R, P.g.Y, P.g.bias, P.g.scale, P.g.noise);
 }
 
 // ---- host side ------------------------------------------------------------------------------------------------------------------------

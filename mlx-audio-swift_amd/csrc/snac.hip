@@ -337,8 +337,10 @@ __global__ void __launch_bounds__(256, 2) k_pw_fused(PwFusedParams p) {
 #define G_AH (G_BK / 16)              // staged A float4 per thread: rows ar + 16 h
 #define G_XH (G_BK / 8)               // staged X float4 per thread: rows xr + 8 h
 
+// (body behind restrict-qualified parameters for the arrays the epilogue touches: see k_pw_fused)
 template <int MODE, bool SNAKE>
-__global__ void __launch_bounds__(256) k_snac_gemm(GemmParams p) {
+__device__ __forceinline__ void snac_gemm_body(const GemmParams& p, const float* __restrict__ pX, const float* __restrict__ pR,
+                                               float* __restrict__ pY, const float* __restrict__ pbias, const float* __restrict__ pscale) {
     __shared__ float As[G_BK][G_BM];
     __shared__ float Xs[G_BK][G_BN];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -349,7 +351,7 @@ __global__ void __launch_bounds__(256) k_snac_gemm(GemmParams p) {
     else b = blockIdx.z;
     const int Kx = (MODE == GEMM_CONVT || MODE == GEMM_TAPS) ? p.Cin : p.K;
     const float* AT = p.AT + (size_t)phase * p.K * p.M;
-    const float* Xb = p.X + (size_t)b * Kx * p.ldx;
+    const float* Xb = pX + (size_t)b * Kx * p.ldx;
     // transposed conv phase: out o = s*n + phase takes taps j=0,1 from x[:, n + q - j]
     const int q = (MODE == GEMM_CONVT) ? (phase + p.pad) / p.s : 0;
 
@@ -455,26 +457,28 @@ __global__ void __launch_bounds__(256) k_snac_gemm(GemmParams p) {
             int m = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
             if (m >= p.M) continue;
             float v = acc[t][r];
-            if (p.bias) v += p.bias[m];
+            if (pbias) v += pbias[m];
             if (MODE == GEMM_PLAIN || MODE == GEMM_TAPS) {
-                p.Y[((size_t)b * p.M + m) * p.ldy + n] = v;
+                pY[((size_t)b * p.M + m) * p.ldy + n] = v;
             } else if (MODE == GEMM_GELU) {                            // exact-erf GELU (VocosBackbone.swift:89)
-                p.Y[((size_t)b * p.M + m) * p.ldy + n] = 0.5f * v * (1.0f + erff(v * 0.70710678118654752f));
+                pY[((size_t)b * p.M + m) * p.ldy + n] = 0.5f * v * (1.0f + erff(v * 0.70710678118654752f));
             } else if (MODE == GEMM_RESID) {
                 size_t o = ((size_t)b * p.M + m) * p.ldy + n;
-                if (p.scale) v *= p.scale[m];                          // ConvNeXt layer scale gamma (VocosBackbone.swift:92-95)
-                p.Y[o] = p.R[o] + v;                                   // Layers.swift:230
+                if (pscale) v *= pscale[m];                          // ConvNeXt layer scale gamma (VocosBackbone.swift:92-95)
+                pY[o] = pR[o] + v;                                   // Layers.swift:230
             } else if (MODE == GEMM_NOISE) {
                 size_t o = ((size_t)b * p.M + m) * p.ldy + n;
-                p.Y[o] = Xb[(size_t)m * p.ldx + n] + nzv[t] * v;       // Layers.swift:276-277
+                pY[o] = Xb[(size_t)m * p.ldx + n] + nzv[t] * v;       // Layers.swift:276-277
             } else {
                 int o = p.s * n + phase;
-                if (n == 0 && p.dup_bias_n0 && p.bias) v += p.bias[m];   // streaming overlap-add counts the bias twice (GemmParams)
-                if (o < p.Tout) p.Y[((size_t)b * p.M + m) * p.ldy + o] = v;
+                if (n == 0 && p.dup_bias_n0 && pbias) v += pbias[m];   // streaming overlap-add counts the bias twice (GemmParams)
+                if (o < p.Tout) pY[((size_t)b * p.M + m) * p.ldy + o] = v;
             }
         }
     }
 }
+template <int MODE, bool SNAKE>
+__global__ void __launch_bounds__(256) k_snac_gemm(GemmParams p) { snac_gemm_body<MODE, SNAKE>(p, p.X, p.R, p.Y, p.bias, p.scale); }
 
 // ---- encoder kernels (Layers.swift:319-360, VQ.swift:47-120) ---------------------------------------------------------
 // first layer: conv k7 "same", 1 -> C
@@ -564,13 +568,14 @@ __global__ void k_vq_residual(float* __restrict__ r, const int32_t* __restrict__
 #define CT_MAXT 7
 #define CT_BK 16                      // input channels per staged chunk (7 tap tiles of 16 x 64 + the halo tile: 43 KB of LDS)
 template <bool RESID>
-__global__ void __launch_bounds__(256) k_conv_taps(GemmParams p) {
+__device__ __forceinline__ void conv_taps_body(const GemmParams& p, const float* __restrict__ pX, const float* __restrict__ pR,
+                                               float* __restrict__ pY, const float* __restrict__ pbias, const float* __restrict__ pscale) {
     __shared__ float As[CT_MAXT][CT_BK][G_BM];
     __shared__ float Xs[CT_BK][CT_XS];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
     const int n0 = blockIdx.x * G_BN, m0 = blockIdx.y * G_BM, b = blockIdx.z;
-    const float* Xb = p.X + (size_t)b * p.Cin * p.ldx;
+    const float* Xb = pX + (size_t)b * p.Cin * p.ldx;
     const int halo = (p.taps - 1) * p.dil;
     const int c_lo = n0 - p.pad;                       // first needed input column (may be negative)
     const int a0 = (c_lo >= 0 ? c_lo : c_lo - 3) / 4 * 4;     // aligned-down staging origin
@@ -659,13 +664,15 @@ __global__ void __launch_bounds__(256) k_conv_taps(GemmParams p) {
             int m = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
             if (m >= p.M) continue;
             float v = acc[t][r];
-            if (p.bias) v += p.bias[m];
+            if (pbias) v += pbias[m];
             size_t o = ((size_t)b * p.M + m) * p.ldy + n;
-            if (RESID) { if (p.scale) v *= p.scale[m]; v += p.R[o]; }
-            p.Y[o] = v;
+            if (RESID) { if (pscale) v *= pscale[m]; v += pR[o]; }
+            pY[o] = v;
         }
     }
 }
+template <bool RESID>
+__global__ void __launch_bounds__(256) k_conv_taps(GemmParams p) { conv_taps_body<RESID>(p, p.X, p.R, p.Y, p.bias, p.scale); }
 
 // ---- final Snake -> conv k7 (C -> 1) -> tanh ----------------------------------------------------------
 #define FIN_TILE 256
