@@ -1,16 +1,8 @@
 set -x
 cd $GRAFT_REPO_ROOT
-mkdir -p gpurun_out
-timeout 900 python -m pytest tests/test_gpu_snac.py tests/test_gpu_dac.py tests/test_gpu_encodec.py tests/test_gpu_soprano.py tests/test_gpu_qwen3tts.py tests/test_gpu_fullwidth.py tests/test_gpu_whisper.py -m gpu -q -x 2>&1 | grep -E "passed|failed|Error|assert" | tail -6
-export TMPDIR=/tmp
-run() {  # name, workload, start kernel, env...
-  name=$1; w=$2; k=$3; shift; shift; shift
-  rm -rf /tmp/tr_$name
-  (cd /tmp && env "$@" timeout 300 rocprofv3 --kernel-trace --output-format csv -d /tmp/tr_$name -- python $GRAFT_REPO_ROOT/tools/pmc_codec_probe.py $w > /tmp/tr_$name.log 2>&1)
-  f=$(find /tmp/tr_$name -name "*kernel_trace.csv" | head -1)
-  python tools/codec_dispatch_trace.py $f 400 > gpurun_out/dispatch_$name.txt 2>&1
-  python tools/dispatch_sum.py gpurun_out/dispatch_$name.txt $k
-}
-run snac_rs snac32 k_snac_embed A=1
-run q3_rs q3b32 k_q3_rvq A=1
-timeout 300 python bench.py --steps 2 --warmup 1 --no-cpu-baseline > gpurun_out/bench_rs.log 2>&1; tail -1 gpurun_out/bench_rs.log | python -c "import sys,json; j=json.loads(sys.stdin.read()); print(j['value'], j['phases_ms'])"
+mkdir -p gpurun_out/final
+timeout 1500 python -m pytest tests -m gpu -q 2>&1 | grep -E "passed|failed|error" | tail -3 > gpurun_out/final/pytest_gpu.txt; cat gpurun_out/final/pytest_gpu.txt
+cp gpurun_out/parity_observed.jsonl gpurun_out/final/ 2>/dev/null
+timeout 900 python bench.py > gpurun_out/final/bench.log 2>&1; tail -1 gpurun_out/final/bench.log > gpurun_out/final/bench.json; python -c "import json; j=json.load(open('gpurun_out/final/bench.json')); print(j['value'], j['ms_per_step'], j['roofline']['frac'], j['roofline']['traffic_source']['matches_current_build'], j['phases_ms'], j['cpu_baseline']['value'])"
+timeout 300 python tools/bench_qwen3tts.py 32 100 16 > gpurun_out/final/q3_bf16.json 2>/dev/null; tail -1 gpurun_out/final/q3_bf16.json | cut -c1-600
+timeout 300 python tools/bench_soprano.py 32 > gpurun_out/final/soprano_b32.json 2>/dev/null; tail -1 gpurun_out/final/soprano_b32.json
