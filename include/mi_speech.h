@@ -496,14 +496,18 @@ typedef struct {                   /* EncodecConfig.swift:64-89 */
     int32_t n_upsampling_ratios; int32_t upsampling_ratios[8];
     int32_t n_quantizers;          /* EncodecQuantization.swift:60-64 */
     int32_t sampling_rate;
+    int32_t group_norm;            /* 1: norm_type "time_group_norm" (the 48 kHz model): GroupNorm(1 group) after every conv, in the
+                                      transposed-conv layer before the trim (EncodecLayers.swift:128-131,203-212,244-262); 0: plain convs */
 } mis_encodec_config;
 mis_status mis_encodec_create(const mis_encodec_config*, int device, mis_encodec** out);
 /* module-tree keys: quantizer.layers.N.codebook.embed, decoder.layers.N.conv.{weight [out,k,in],bias},
- * decoder.layers.1.lstm.N.{Wx,Wh,bias}, decoder.layers.N.{block.1,block.3,shortcut}.conv.*; "encoder.*" ignored */
+ * decoder.layers.1.lstm.N.{Wx,Wh,bias}, decoder.layers.N.{block.1,block.3,shortcut}.conv.*, with group_norm also
+ * <conv prefix>.norm.{weight,bias} [out]; "encoder.*" ignored */
 mis_status mis_encodec_set_tensor(mis_encodec*, const char* name, const void* data, mis_dtype dtype, const int64_t* shape, int ndim);
 mis_status mis_encodec_finalize(mis_encodec*);
 void       mis_encodec_destroy(mis_encodec*);
 int        mis_encodec_hop_length(const mis_encodec*);
+/* wav_out f32 [batch, audio_channels, T * hop] (audio_channels 1 or 2) */
 mis_status mis_encodec_decode_frame(mis_encodec*, const int32_t* codes, int batch, int n_q, int T, const float* scales, float* wav_out);
 /* stage 1 conv0, 2 LSTM block, 3 + i upsampling block i: out f32 [batch, C, T'] */
 mis_status mis_encodec_debug_tap(mis_encodec*, const int32_t* codes, int batch, int n_q, int T, int stage, float* out, int64_t capacity,

@@ -85,7 +85,7 @@ class EncodecConfigC(C.Structure):
                 ("residual_kernel_size", C.c_int32), ("use_causal_conv", C.c_int32), ("pad_reflect", C.c_int32),
                 ("last_kernel_size", C.c_int32), ("compress", C.c_int32), ("use_conv_shortcut", C.c_int32),
                 ("trim_right_ratio", C.c_float), ("n_upsampling_ratios", C.c_int32), ("upsampling_ratios", C.c_int32 * 8),
-                ("n_quantizers", C.c_int32), ("sampling_rate", C.c_int32)]
+                ("n_quantizers", C.c_int32), ("sampling_rate", C.c_int32), ("group_norm", C.c_int32)]
 
 
 class MelConfigC(C.Structure):

@@ -373,18 +373,20 @@ class EncodecConfig:
         return max(1, int((1.0 - self.overlap) * self.chunk_length))
 
     def to_c(self) -> "_lib.EncodecConfigC":
-        if self.norm_type != "weight_norm":
-            raise AudioGenerationError(3, "only norm_type 'weight_norm' Encodec models are built (no GroupNorm)")
+        if self.norm_type not in ("weight_norm", "time_group_norm"):
+            raise AudioGenerationError(3, f"unknown Encodec norm_type {self.norm_type!r}")
         return _lib.EncodecConfigC(self.audio_channels, self.num_filters, self.kernel_size, self.num_residual_layers,
                                    self.dilation_growth_rate, self.codebook_size, self.codebook_dim, self.hidden_size,
                                    self.num_lstm_layers, self.residual_kernel_size, 1 if self.use_causal_conv else 0,
                                    1 if self.pad_mode == "reflect" else 0, self.last_kernel_size, self.compress,
                                    1 if self.use_conv_shortcut else 0, float(self.trim_right_ratio), len(self.upsampling_ratios),
-                                   (C.c_int32 * 8)(*self.upsampling_ratios), self.num_quantizers, self.sampling_rate)
+                                   (C.c_int32 * 8)(*self.upsampling_ratios), self.num_quantizers, self.sampling_rate,
+                                   1 if self.norm_type == "time_group_norm" else 0)
 
 
 class Encodec:
-    """Decode side of class Encodec (Encodec/Encodec.swift:179-398): decode(audio_codes, audio_scales)."""
+    """Decode side of class Encodec (Encodec/Encodec.swift:179-398): decode(audio_codes, audio_scales); the 24 kHz (mono, causal,
+    plain convs) and the 48 kHz (stereo, non-causal, GroupNorm) model families."""
 
     def __init__(self, config: EncodecConfig, device: int = 0):
         self.config = config
@@ -412,10 +414,11 @@ class Encodec:
         return float(self.config.sampling_rate)
 
     def decode_frame(self, codes, scale=None) -> np.ndarray:
-        """decodeFrame (Encodec.swift:295-302): codes int [B, n_q, T] -> [B, T * hop]"""
+        """decodeFrame (Encodec.swift:295-302): codes int [B, n_q, T] -> [B, T * hop] (mono) or [B, channels, T * hop]"""
         cd = np.ascontiguousarray(codes, dtype=np.int32)
         B, nq, T = cd.shape
-        out = np.zeros((B, T * self.config.hop_length), np.float32)
+        ch = self.config.audio_channels
+        out = np.zeros((B, T * self.config.hop_length) if ch == 1 else (B, ch, T * self.config.hop_length), np.float32)
         sc = None if scale is None else np.ascontiguousarray(np.broadcast_to(np.asarray(scale, np.float32).reshape(-1), (B,)))
         check(_lib.lib().mis_encodec_decode_frame(self._h, cd.ctypes.data, B, nq, T, None if sc is None else sc.ctypes.data,
                                                   out.ctypes.data))
@@ -440,6 +443,13 @@ class Encodec:
         out[:, nz] /= sw[nz]
         return out
 
+    def _overlap_add(self, frames, hop_stride: int) -> np.ndarray:
+        if frames[0].ndim == 2:
+            return self.linear_overlap_add(frames, hop_stride)
+        B, ch = frames[0].shape[:2]                          # stereo: the time axis is the last one; channels ride along as rows
+        out = self.linear_overlap_add([f.reshape(B * ch, f.shape[-1]) for f in frames], hop_stride)
+        return out.reshape(B, ch, -1)
+
     def decode(self, audio_codes, audio_scales=None, padding_mask=None) -> np.ndarray:
         """decode (Encodec.swift:357-398): audio_codes [n_chunks, B, n_q, frames] -> [B, samples]"""
         ac = np.asarray(audio_codes)
@@ -449,9 +459,9 @@ class Encodec:
                 raise AudioGenerationError(3, f"Expected one frame, got {ac.shape[0]}")
             out = self.decode_frame(ac[0], scales[0])
         else:
-            out = self.linear_overlap_add([self.decode_frame(ac[i], scales[i]) for i in range(ac.shape[0])], self.config.chunk_stride or 1)
-        if padding_mask is not None and np.asarray(padding_mask).shape[1] < out.shape[1]:
-            out = out[:, : np.asarray(padding_mask).shape[1]]
+            out = self._overlap_add([self.decode_frame(ac[i], scales[i]) for i in range(ac.shape[0])], self.config.chunk_stride or 1)
+        if padding_mask is not None and np.asarray(padding_mask).shape[1] < out.shape[-1]:
+            out = out[..., : np.asarray(padding_mask).shape[1]]
         return out
 
     def debug_tap(self, codes, stage: int) -> np.ndarray:

@@ -1,4 +1,5 @@
-// encodec.hip - EnCodec (SEANet) decoder: residual-VQ codes -> waveform, float32.
+// encodec.hip - EnCodec (SEANet) decoder: residual-VQ codes -> waveform, float32.  Both model families: 24 kHz (mono, causal padding,
+// plain convs) and 48 kHz (stereo, non-causal padding, GroupNorm(1 group) after every conv - in the transposed-conv layer before the trim).
 //
 // Reference being replaced: Encodec.decodeFrame / EncodecDecoder (Sources/MLXAudioCodecs/Encodec/Encodec.swift:94-170,295-302),
 // EncodecLSTM / EncodecLSTMBlock, EncodecConv1d (causal + reflect padding), EncodecConvTranspose1dLayer, EncodecResnetBlock, ELU
@@ -26,7 +27,7 @@ struct mis_encodec {
     bool finalized = false;
     int n_q = 0, dim0 = 0;
     DevBuf<float> arena;
-    struct Lin { size_t w = 0, b = 0; int M = 0, K = 0; };
+    struct Lin { size_t w = 0, b = 0, nw = 0, nb = 0; int M = 0, K = 0; };      // nw / nb: GroupNorm weight / bias (group_norm models)
     size_t tables = 0, zeros = 0;
     Lin conv0, last;
     struct Lstm { Lin xproj; size_t wh = 0; };
@@ -37,6 +38,8 @@ struct mis_encodec {
     DevBuf<float> buf[4], hstate;
     CodecPack pack;                      // split-bf16 weight fragments + activation scratch (codec_bf3.hip)
     DevBuf<int32_t> codes_dev, sync;
+    DevBuf<double> gn_part;              // GroupNorm partial sums [batch][GN_BLOCKS][2]
+    DevBuf<float> gn_stat;               // [batch][2]: mean, 1 / sqrt(var + eps)
 };
 
 // ---------------------------------------------------------------------------- kernels
@@ -72,6 +75,49 @@ __global__ void k_encodec_scale(float* __restrict__ x, const float* __restrict__
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     int b = blockIdx.y;
     if (i < n_per_row) x[(size_t)b * n_per_row + i] *= scale[b];
+}
+
+
+// ---- GroupNorm(1 group, pytorchCompatible) over the (C, T) block of one sample (EncodecLayers.swift:128-131): two deterministic
+// reduction stages (fixed partition, fixed summation order; sums in double), then the affine apply - which also crops a column window
+// out of a wider buffer (the transposed-conv layer normalises BEFORE it trims, :244-262) and adds the residual of a resnet block.
+#define GN_BLOCKS 64
+__global__ void __launch_bounds__(256) k_gn_partial(const float* __restrict__ x, double* __restrict__ part, int64_t n) {
+    __shared__ double s1[256], s2[256];
+    const int blk = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
+    const int64_t len = (n + GN_BLOCKS - 1) / GN_BLOCKS, lo = (int64_t)blk * len, hi = lo + len < n ? lo + len : n;
+    const float* xb = x + (size_t)b * n;
+    double a = 0.0, q = 0.0;
+    for (int64_t i = lo + tid; i < hi; i += 256) { const double v = (double)xb[i]; a += v; q += v * v; }
+    s1[tid] = a; s2[tid] = q;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if (tid < o) { s1[tid] += s1[tid + o]; s2[tid] += s2[tid + o]; }
+        __syncthreads();
+    }
+    if (tid == 0) { part[((size_t)b * GN_BLOCKS + blk) * 2] = s1[0]; part[((size_t)b * GN_BLOCKS + blk) * 2 + 1] = s2[0]; }
+}
+__global__ void k_gn_final(const double* __restrict__ part, float* __restrict__ stat, double n, float eps) {
+    const int b = blockIdx.x;
+    if (threadIdx.x != 0) return;
+    double a = 0.0, q = 0.0;
+    for (int i = 0; i < GN_BLOCKS; ++i) { a += part[((size_t)b * GN_BLOCKS + i) * 2]; q += part[((size_t)b * GN_BLOCKS + i) * 2 + 1]; }
+    const double mu = a / n;
+    double var = q / n - mu * mu;
+    if (var < 0.0) var = 0.0;
+    stat[b * 2] = (float)mu;
+    stat[b * 2 + 1] = (float)(1.0 / sqrt(var + (double)eps));
+}
+// y[b][c][t] = norm(xf[b][c][off + t]) * w[c] + bsh[c] (+ R[b][c][t]); stat null: plain crop.  xf rows are ldf wide, y / R rows T.
+__global__ void k_gn_apply(const float* xf, int64_t ldf, int off, float* y, const float* __restrict__ stat, const float* __restrict__ w,
+                           const float* __restrict__ bsh, const float* R, int C, int T) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x, c = blockIdx.y, b = blockIdx.z;
+    if (t >= T) return;
+    float v = xf[((size_t)b * C + c) * ldf + off + t];
+    if (stat) v = (v - stat[b * 2]) * stat[b * 2 + 1] * w[c] + bsh[c];
+    const size_t o = ((size_t)b * C + c) * T + t;
+    if (R) v += R[o];
+    y[o] = v;
 }
 
 // LSTM recurrence (EncodecLSTM :33-61), persistent: block blk owns hidden units [blk*U, blk*U + U) = 4U gate rows of W_h
@@ -162,8 +208,8 @@ extern "C" mis_status mis_encodec_create(const mis_encodec_config* cfg, int devi
     MIS_API_BEGIN
     MIS_REQUIRE(cfg && out, MIS_ERR_INVALID_INPUT, "null argument");
     MIS_REQUIRE(cfg->n_upsampling_ratios >= 1 && cfg->n_upsampling_ratios <= 8 && cfg->num_filters >= 1 && cfg->hidden_size >= 1 &&
-                    cfg->codebook_size >= 1 && cfg->n_quantizers >= 1 && cfg->audio_channels == 1 && cfg->compress >= 1,
-                MIS_ERR_INVALID_INPUT, "bad Encodec config (mono only)");
+                    cfg->codebook_size >= 1 && cfg->n_quantizers >= 1 && (cfg->audio_channels == 1 || cfg->audio_channels == 2) && cfg->compress >= 1,
+                MIS_ERR_INVALID_INPUT, "bad Encodec config (one or two audio channels)");
     MIS_REQUIRE(cfg->kernel_size <= 7 && cfg->last_kernel_size <= 7 && cfg->residual_kernel_size <= 7, MIS_ERR_INVALID_INPUT, "kernel sizes above 7 are not built");
     int n = 0;
     HIP_CHECK(hipGetDeviceCount(&n));
@@ -231,6 +277,7 @@ extern "C" mis_status mis_encodec_finalize(mis_encodec* c) {
         std::vector<float> at((size_t)k * ci * co);
         for (int64_t o = 0; o < co; ++o) for (int64_t j = 0; j < k; ++j) for (int64_t i = 0; i < ci; ++i) at[(j * ci + i) * co + o] = w[(o * k + j) * ci + i];
         mis_encodec::Lin L; L.M = (int)co; L.K = (int)(k * ci); L.w = push(at); L.b = push(eneed(c, p + ".conv.bias", {co}));
+        if (cf.group_norm) { L.nw = push(eneed(c, p + ".norm.weight", {co})); L.nb = push(eneed(c, p + ".norm.bias", {co})); }
         return L;
     };
     {
@@ -269,6 +316,7 @@ extern "C" mis_status mis_encodec_finalize(mis_encodec* c) {
             for (int64_t ph = 0; ph < s; ++ph) for (int64_t j = 0; j < 2; ++j) for (int64_t i = 0; i < cin; ++i) for (int64_t o = 0; o < cout; ++o)
                 at[((ph * 2 + j) * cin + i) * cout + o] = w[(o * k + (ph + s * j)) * cin + i];
             U.ct.M = (int)cout; U.ct.K = (int)(2 * cin); U.ct.w = push(at); U.ct.b = push(eneed(c, p + ".conv.bias", {cout}));
+            if (cf.group_norm) { U.ct.nw = push(eneed(c, p + ".norm.weight", {cout})); U.ct.nb = push(eneed(c, p + ".norm.bias", {cout})); }
         }
         li += 2;
         dim = cout;
@@ -287,7 +335,7 @@ extern "C" mis_status mis_encodec_finalize(mis_encodec* c) {
         }
         c->ups.push_back(U);
     }
-    c->last = conv("decoder.layers." + std::to_string(li + 1), 1, cf.last_kernel_size, dim);
+    c->last = conv("decoder.layers." + std::to_string(li + 1), cf.audio_channels, cf.last_kernel_size, dim);
     c->arena.alloc(arena.size());
     HIP_CHECK(hipMemcpy(c->arena.p, arena.data(), arena.size() * 4, hipMemcpyHostToDevice));
     c->raw.clear(); c->raw_shape.clear();
@@ -312,6 +360,15 @@ static const float* encodec_run(mis_encodec* c, const int32_t* codes_dev, int nq
     }
     for (int i = 0; i < 4; ++i) c->buf[i].alloc((size_t)batch * need_elems);
     float *x = c->buf[0].p, *y = c->buf[1].p, *t1 = c->buf[2].p, *t2 = c->buf[3].p;
+    const bool gn = cf.group_norm != 0;
+    if (gn) { c->gn_part.alloc((size_t)batch * GN_BLOCKS * 2); c->gn_stat.alloc((size_t)batch * 2); }
+    // GroupNorm over the [C][ldf] block of each sample in xf, applied to the column window [off, off + T) -> y [C][T] (+ R)
+    auto group_norm = [&](const float* xf, int64_t ldf, int off, float* Y, const mis_encodec::Lin& L, const float* R, int Tn) {
+        const int64_t n = (int64_t)L.M * ldf;
+        hipLaunchKernelGGL(k_gn_partial, dim3(GN_BLOCKS, batch), dim3(256), 0, s, xf, c->gn_part.p, n);
+        hipLaunchKernelGGL(k_gn_final, dim3(batch), dim3(64), 0, s, c->gn_part.p, c->gn_stat.p, (double)n, 1e-5f);
+        hipLaunchKernelGGL(k_gn_apply, dim3(cdiv(Tn, 256), L.M, batch), dim3(256), 0, s, xf, ldf, off, Y, c->gn_stat.p, W + L.nw, W + L.nb, R, L.M, Tn);
+    };
     // EncodecConv1d (:84-214), stride 1: pad (left = k - 1 causal / split otherwise; dilation not included: as the reference), conv
     auto conv1d = [&](const mis_encodec::Lin& L, int Cin, int k, int dil, const float* X, float* Y, int Tin, int elu, const float* R) {
         const int keff = (k - 1) * dil + 1, ptotal = k - 1;
@@ -325,9 +382,10 @@ static const float* encodec_run(mis_encodec* c, const int32_t* codes_dev, int nq
             src = t2;
         }
         GemmParams g{};
-        g.AT = W + L.w; g.bias = W + L.b; g.X = src; g.Y = Y; g.R = R; g.M = L.M; g.K = L.K; g.N = Tout; g.Tin = Tp; g.Tout = Tout;
+        g.AT = W + L.w; g.bias = W + L.b; g.X = src; g.Y = Y; g.R = gn ? nullptr : R; g.M = L.M; g.K = L.K; g.N = Tout; g.Tin = Tp; g.Tout = Tout;
         g.Cin = Cin; g.taps = k; g.dil = dil; g.pad = 0;
         launch_gemm(GEMM_TAPS, false, g, batch, s);
+        if (gn) group_norm(Y, Tout, 0, Y, L, R, Tout);          // norm(conv(x)) (+ the residual, which the plain path adds in the GEMM epilogue)
         return Tout;
     };
     hipLaunchKernelGGL(k_encodec_embed, dim3(T, batch), dim3(256), 0, s, codes_dev, W + c->tables, x, nq, cf.codebook_size, cf.codebook_dim, T);
@@ -366,15 +424,28 @@ static const float* encodec_run(mis_encodec* c, const int32_t* codes_dev, int nq
     if (stage == 2) { *outC = H; *outT = Tc; return x; }
     int bi = 0;
     for (auto& U : c->ups) {
-        // ELU -> transposed conv (EncodecConvTranspose1dLayer :218-262); causal: trim k - s on the right -> length s*T
-        MIS_REQUIRE(causal && cf.trim_right_ratio == 1.0f, MIS_ERR_INVALID_INPUT, "only causal transposed convs with trim_right_ratio 1 are built");
+        // ELU -> transposed conv (EncodecConvTranspose1dLayer :218-262), kernel 2s: the full output has s * T + s samples, of which
+        // padding_total = s are trimmed - all on the right when causal (trim_right_ratio 1), s / 2 on the right otherwise
         hipLaunchKernelGGL(k_encodec_pad_act, dim3(cdiv(Tc, 256), U.cin, batch), dim3(256), 0, s, x, t1, U.cin, Tc, 0, 0, 0, 1);
         GemmParams g{};
         g.AT = W + U.ct.w; g.bias = W + U.ct.b; g.X = t1; g.Y = y; g.alpha = W + c->zeros; g.ralpha = W + c->zeros;
         g.M = U.cout; g.K = 2 * U.cin; g.N = Tc; g.Tin = Tc; g.Tout = Tc * U.s; g.s = U.s; g.pad = 0; g.Cin = U.cin;
-        launch_gemm(GEMM_CONVT, true, g, batch, s);
-        Tc *= U.s;
-        std::swap(x, y);
+        if (causal && cf.trim_right_ratio == 1.0f && !gn) {
+            launch_gemm(GEMM_CONVT, true, g, batch, s);            // the trimmed range is exactly the first s * T samples
+            Tc *= U.s;
+            std::swap(x, y);
+        } else {
+            MIS_REQUIRE(!causal || cf.trim_right_ratio == 1.0f, MIS_ERR_INVALID_INPUT, "causal transposed convs need trim_right_ratio 1");
+            const int right = causal ? U.s : U.s / 2, left = U.s - right;
+            const int Tfull = Tc * U.s + U.s;
+            g.N = Tc + 1; g.Tout = Tfull;                          // frame n = T holds the tail of the last input column
+            launch_gemm(GEMM_CONVT, true, g, batch, s);
+            Tc *= U.s;
+            // GroupNorm over the UNTRIMMED output (:244-262), then the trim; without a norm the same kernel only crops
+            if (gn) group_norm(y, Tfull, left, t1, U.ct, nullptr, Tc);
+            else hipLaunchKernelGGL(k_gn_apply, dim3(cdiv(Tc, 256), U.cout, batch), dim3(256), 0, s, y, (int64_t)Tfull, left, t1, nullptr, nullptr, nullptr, nullptr, U.cout, Tc);
+            std::swap(x, t1);
+        }
         for (auto& R : U.res) {   // EncodecResnetBlock (:266-325): shortcut(x) + conv1(ELU(conv_k(ELU(x))))
             const int hid = R.c1.M;
             int T1 = conv1d(R.c1, U.cout, cf.residual_kernel_size, R.dil, x, t1, Tc, 1, nullptr);
@@ -392,17 +463,17 @@ static const float* encodec_run(mis_encodec* c, const int32_t* codes_dev, int nq
     MIS_REQUIRE(Tc == T * hop, MIS_ERR_AUDIO_DECODE, "internal length mismatch");
     conv1d(c->last, c->ups.back().cout, cf.last_kernel_size, 1, x, wav_dev, Tc, 1, nullptr);
     HIP_CHECK(hipGetLastError());
-    *outC = 1; *outT = Tc;
+    *outC = cf.audio_channels; *outT = Tc;
     return wav_dev;
 }
 
-// decodeFrame (Encodec.swift:295-302): codes int32 [batch, n_q, T] (host or device), scales f32 [batch] or NULL -> wav [batch, T*hop]
+// decodeFrame (Encodec.swift:295-302): codes int32 [batch, n_q, T] (host or device), scales f32 [batch] or NULL -> wav [batch, channels, T*hop]
 extern "C" mis_status mis_encodec_decode_frame(mis_encodec* c, const int32_t* codes, int batch, int n_q, int T, const float* scales, float* wav_out) {
     MIS_API_BEGIN
     MIS_REQUIRE(c && codes && wav_out && batch >= 1 && T >= 1 && n_q >= 1 && n_q <= c->n_q, MIS_ERR_INVALID_INPUT, "bad argument");
     HIP_CHECK(hipSetDevice(c->device));
     hipStream_t s = c->stream;
-    const int64_t n = (int64_t)T * mis_encodec_hop_length(c);
+    const int64_t n = (int64_t)T * mis_encodec_hop_length(c) * c->cfg.audio_channels;
     c->codes_dev.alloc((size_t)batch * n_q * T);
     HIP_CHECK(hipMemcpyAsync(c->codes_dev.p, codes, (size_t)batch * n_q * T * 4, hipMemcpyDefault, s));
     DevBuf<float> wav, sc;
@@ -427,7 +498,7 @@ extern "C" mis_status mis_encodec_debug_tap(mis_encodec* c, const int32_t* codes
     c->codes_dev.alloc((size_t)batch * n_q * T);
     HIP_CHECK(hipMemcpyAsync(c->codes_dev.p, codes, (size_t)batch * n_q * T * 4, hipMemcpyDefault, s));
     DevBuf<float> wav;
-    wav.alloc((size_t)batch * T * mis_encodec_hop_length(c));
+    wav.alloc((size_t)batch * T * mis_encodec_hop_length(c) * c->cfg.audio_channels);
     int C = 0; int64_t Tt = 0;
     const float* res = encodec_run(c, c->codes_dev.p, n_q, batch, T, wav.p, stage, &C, &Tt);
     MIS_REQUIRE((int64_t)batch * C * Tt <= capacity, MIS_ERR_INVALID_INPUT, "tap buffer too small");

@@ -7,8 +7,9 @@ padding with the index rule min(pad - i, n - 1)), EncodecConvTranspose1dLayer (:
 padding_total * trim_right_ratio samples trimmed on the right when causal), EncodecResnetBlock (:266-325, conv shortcut),
 ELU (:340-350), EncodecResidualVectorQuantizer.decode (EncodecQuantization.swift:117-133: sum of codebook rows).
 The reference executes its transposed conv as scalar Swift loops over asArray copies (EncodecLayers.swift:395-420) and the LSTM
-as a Python-style per-step loop; arithmetic is plain float32.  Only norm_type "weight_norm" (no GroupNorm) is restated -
-that is the published 24 kHz model.  Layout here is [B, C, T]."""
+as a Python-style per-step loop; arithmetic is plain float32.  norm_type "weight_norm" (the 24 kHz model: plain convs) and
+"time_group_norm" (the 48 kHz stereo model: GroupNorm(1 group, pytorchCompatible) after EVERY conv and - in the transposed-conv
+layer - BEFORE the padding is trimmed, :128-131,203-212,244-262; non-causal padding split) are restated.  Layout here is [B, C, T]."""
 from __future__ import annotations
 
 import math
@@ -35,6 +36,7 @@ class EncodecConfig:                      # EncodecConfig.swift:64-89 (encodec_2
     residual_kernel_size: int = 3
     use_causal_conv: bool = True
     pad_mode: str = "reflect"
+    norm_type: str = "weight_norm"
     last_kernel_size: int = 7
     trim_right_ratio: float = 1.0
     compress: int = 2
@@ -52,6 +54,10 @@ class EncodecConfig:                      # EncodecConfig.swift:64-89 (encodec_2
         frame_rate = int(math.ceil(self.sampling_rate / self.hop_length))
         return int(1000 * max(self.target_bandwidths) / (frame_rate * 10))
 
+
+# the 48 kHz model in miniature: stereo, non-causal padding, GroupNorm after every conv
+TINY_48K = EncodecConfig(audio_channels=2, num_filters=4, codebook_size=32, codebook_dim=16, hidden_size=16, upsampling_ratios=(3, 2, 2),
+                         target_bandwidths=(1.5, 3.0), sampling_rate=1200, use_causal_conv=False, norm_type="time_group_norm")
 
 TINY = EncodecConfig(num_filters=4, codebook_size=32, codebook_dim=16, hidden_size=16, upsampling_ratios=(3, 2, 2),
                      target_bandwidths=(1.5, 3.0), sampling_rate=1200)
@@ -88,12 +94,21 @@ class EncodecOracle:
         else:
             r = ptotal // 2
             xp = pad1d(x, ptotal - r, r + extra, cfg.pad_mode)
-        return TF.conv1d(xp, self.w[p + ".conv.weight"].permute(0, 2, 1).contiguous(), self.w[p + ".conv.bias"], stride=stride,
-                         dilation=dilation)
+        return self.norm(p, TF.conv1d(xp, self.w[p + ".conv.weight"].permute(0, 2, 1).contiguous(), self.w[p + ".conv.bias"],
+                                      stride=stride, dilation=dilation))
+
+    def norm(self, p, h):
+        """GroupNorm(groupCount: 1, dimensions: C, pytorchCompatible: true) (EncodecLayers.swift:128-131): statistics over (C, T)."""
+        if self.cfg.norm_type != "time_group_norm":
+            return h
+        mu = h.mean(dim=(1, 2), keepdim=True)
+        var = ((h - mu) ** 2).mean(dim=(1, 2), keepdim=True)
+        return (h - mu) / torch.sqrt(var + 1e-5) * self.w[p + ".norm.weight"][None, :, None] + self.w[p + ".norm.bias"][None, :, None]
 
     def conv_transpose(self, p, x, k, stride):
         cfg = self.cfg
         y = TF.conv_transpose1d(x, self.w[p + ".conv.weight"].permute(2, 0, 1).contiguous(), self.w[p + ".conv.bias"], stride=stride)
+        y = self.norm(p, y)                                     # BEFORE the trim (:244-262)
         ptotal = k - stride
         right = int(math.ceil(ptotal * cfg.trim_right_ratio)) if cfg.use_causal_conv else ptotal // 2
         left = ptotal - right
@@ -151,14 +166,14 @@ class EncodecOracle:
         return self.conv(f"decoder.layers.{li + 1}", TF.elu(h), cfg.last_kernel_size)
 
     def decode_frame(self, codes, scale=None, stop_after=None):
-        """decodeFrame (:295-302): codes [B, nq, T] -> [B, T * hop] (audio_channels = 1)."""
+        """decodeFrame (:295-302): codes [B, nq, T] -> [B, T * hop] (audio_channels = 1) or [B, channels, T * hop]."""
         with torch.no_grad():
             out = self.decoder(self.quantizer_decode(codes), stop_after)
             if stop_after is not None:
                 return out.numpy()
             if scale is not None:
                 out = out * torch.as_tensor(np.asarray(scale, F)).reshape(-1, 1, 1)
-            return out[:, 0].numpy()
+            return out[:, 0].numpy() if self.cfg.audio_channels == 1 else out.numpy()
 
 
 def linear_overlap_add(frames, hop_stride):
@@ -191,6 +206,9 @@ def make_synthetic_weights(cfg: EncodecConfig, seed: int = 909, n_quantizers: in
     def conv(p, co, k, ci, gain=1.0):
         W[p + ".conv.weight"] = t((co, k, ci), gain * math.sqrt(3.0 / (k * ci)))
         W[p + ".conv.bias"] = t((co,), 0.05)
+        if cfg.norm_type == "time_group_norm":
+            W[p + ".norm.weight"] = (1.0 + t((co,), 0.3)).astype(np.float32)
+            W[p + ".norm.bias"] = t((co,), 0.1)
 
     nq = n_quantizers or cfg.num_quantizers
     for i in range(nq):

@@ -21,7 +21,13 @@ WIDE = oe.EncodecConfig(num_filters=32, codebook_size=64, codebook_dim=32, hidde
                         target_bandwidths=(8.0,), sampling_rate=1600)
 
 
-@pytest.mark.parametrize("ocfg", [oe.TINY, WIDE], ids=["tiny-1block-lstm", "wide-multiblock-lstm"])
+# the 48 kHz family at a width where the transposed convs and the k = 7 convs take the split-bf16 path as well
+WIDE_48K = oe.EncodecConfig(audio_channels=2, num_filters=32, codebook_size=64, codebook_dim=32, hidden_size=32, upsampling_ratios=(4, 2),
+                            target_bandwidths=(8.0,), sampling_rate=1600, use_causal_conv=False, norm_type="time_group_norm")
+
+
+@pytest.mark.parametrize("ocfg", [oe.TINY, WIDE, oe.TINY_48K, WIDE_48K],
+                         ids=["tiny-1block-lstm", "wide-multiblock-lstm", "48k-family-tiny", "48k-family-wide"])
 def test_decode_frame_matches_oracle(ocfg):
     orc, dev = _pair(ocfg)
     rng = np.random.default_rng(0)
@@ -36,7 +42,8 @@ def test_decode_frame_matches_oracle(ocfg):
             assert np.abs(got - ref).max() <= 3e-4 * max(np.abs(ref).max(), 1e-3), (name, B, T)
         ref = orc.decode_frame(codes, scale=[0.5] * B)
         got = dev.decode_frame(codes, scale=0.5)
-        assert got.shape == ref.shape == (B, T * ocfg.hop_length) and np.abs(got - ref).max() <= 3e-4 * max(np.abs(ref).max(), 1e-3)
+        want = (B, T * ocfg.hop_length) if ocfg.audio_channels == 1 else (B, ocfg.audio_channels, T * ocfg.hop_length)
+        assert got.shape == ref.shape == want and np.abs(got - ref).max() <= 3e-4 * max(np.abs(ref).max(), 1e-3)
     # fewer quantizers than the model holds (bandwidth selection, EncodecQuantization.swift:66-74)
     codes = rng.integers(0, ocfg.codebook_size, (1, 1, 5)).astype(np.int32)
     assert np.abs(dev.decode_frame(codes) - orc.decode_frame(codes)).max() < 1e-3
@@ -54,3 +61,14 @@ def test_chunked_decode_overlap_add():
                                    oe.make_synthetic_weights(ocfg))
     with pytest.raises(mas.AudioGenerationError):
         one.decode(chunks)                                                  # "Expected one frame" without chunking (:373-376)
+
+
+def test_chunked_stereo_decode_of_the_48k_family():
+    ocfg = oe.TINY_48K
+    orc, dev = _pair(ocfg, chunk_length_s=0.1, overlap=0.25)              # 120-sample chunks, stride 90
+    chunks = np.random.default_rng(2).integers(0, ocfg.codebook_size, (3, 2, ocfg.num_quantizers, 10)).astype(np.int32)
+    scales = [np.array([0.5, 2.0], np.float32)] * 3
+    frames = [orc.decode_frame(chunks[i], scale=scales[i]) for i in range(3)]                      # [B, 2, 120]
+    ref = np.stack([oe.linear_overlap_add([f[:, ch] for f in frames], 90) for ch in range(2)], axis=1)
+    got = dev.decode(chunks, audio_scales=scales)
+    assert got.shape == ref.shape == (2, 2, 90 * 2 + 120) and np.abs(got - ref).max() <= 3e-4 * np.abs(ref).max()

@@ -92,3 +92,44 @@ def test_decoder_and_quantizer_match_hf_transformers():
     y = o.decode_frame(codes)
     assert y.shape == (2, 11 * cfg.hop_length)
     np.testing.assert_allclose(y, y_hf[:, 0].numpy(), rtol=1e-4, atol=2e-5)
+
+
+def test_group_norm_stereo_variant_matches_hf_transformers():
+    """The 48 kHz model family (norm_type time_group_norm, non-causal padding, two audio channels) against HF EncodecModel."""
+    from transformers import EncodecConfig as HFC, EncodecModel
+    cfg = oe.TINY_48K
+    hc = HFC(audio_channels=2, num_filters=cfg.num_filters, kernel_size=cfg.kernel_size, num_residual_layers=cfg.num_residual_layers,
+             dilation_growth_rate=cfg.dilation_growth_rate, codebook_size=cfg.codebook_size, codebook_dim=cfg.codebook_dim,
+             hidden_size=cfg.hidden_size, num_lstm_layers=cfg.num_lstm_layers, residual_kernel_size=cfg.residual_kernel_size,
+             use_causal_conv=False, pad_mode="reflect", last_kernel_size=cfg.last_kernel_size, trim_right_ratio=1.0, compress=cfg.compress,
+             upsampling_ratios=list(cfg.upsampling_ratios), target_bandwidths=list(cfg.target_bandwidths),
+             sampling_rate=cfg.sampling_rate, use_conv_shortcut=True, norm_type="time_group_norm", normalize=True,
+             chunk_length_s=1.0, overlap=0.01)
+    hf = EncodecModel(hc).eval()
+    W = oe.make_synthetic_weights(cfg, seed=8)
+    sd = hf.state_dict()
+    for name in [k for k in sd if k.startswith("decoder.") and k.endswith(".conv.bias")]:
+        hp = name[: -len(".conv.bias")]
+        transposed = type(hf.get_submodule(hp)).__name__ == "EncodecConvTranspose1d"
+        w = torch.from_numpy(W[hp + ".conv.weight"])
+        sd[hp + ".conv.weight"] = w.permute(2, 0, 1).contiguous() if transposed else w.permute(0, 2, 1).contiguous()
+        sd[hp + ".conv.bias"] = torch.from_numpy(W[hp + ".conv.bias"])
+        sd[hp + ".norm.weight"] = torch.from_numpy(W[hp + ".norm.weight"])
+        sd[hp + ".norm.bias"] = torch.from_numpy(W[hp + ".norm.bias"])
+    for j in range(cfg.num_lstm_layers):
+        p = f"decoder.layers.1.lstm.{j}"
+        sd[f"decoder.layers.1.lstm.weight_ih_l{j}"] = torch.from_numpy(W[p + ".Wx"])
+        sd[f"decoder.layers.1.lstm.weight_hh_l{j}"] = torch.from_numpy(W[p + ".Wh"])
+        sd[f"decoder.layers.1.lstm.bias_ih_l{j}"] = torch.from_numpy(W[p + ".bias"])
+        sd[f"decoder.layers.1.lstm.bias_hh_l{j}"] = torch.zeros_like(sd[f"decoder.layers.1.lstm.bias_hh_l{j}"])
+    nq = cfg.num_quantizers
+    for i in range(nq):
+        sd[f"quantizer.layers.{i}.codebook.embed"] = torch.from_numpy(W[f"quantizer.layers.{i}.codebook.embed"])
+    hf.load_state_dict(sd)
+    o = oe.EncodecOracle(cfg, W)
+    codes = np.random.default_rng(4).integers(0, cfg.codebook_size, (2, nq, 13))
+    with torch.no_grad():
+        y_hf = hf.decoder(hf.quantizer.decode(torch.from_numpy(codes).transpose(0, 1)))
+    y = o.decode_frame(codes)
+    assert y.shape == (2, 2, 13 * cfg.hop_length)
+    np.testing.assert_allclose(y, y_hf.numpy(), rtol=1e-4, atol=2e-5)
