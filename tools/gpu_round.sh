@@ -1,6 +1,5 @@
 set -x
 cd $GRAFT_REPO_ROOT
-mkdir -p gpurun_out/final
-timeout 1500 python -m pytest tests -m gpu -q 2>&1 | grep -E "passed|failed|error" | tail -3 > gpurun_out/final/pytest_gpu.txt; cat gpurun_out/final/pytest_gpu.txt
-cp gpurun_out/parity_observed.jsonl gpurun_out/final/ 2>/dev/null
-python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -1
+mkdir -p gpurun_out
+timeout 600 python -m pytest tests/test_gpu_qwen3tts.py "tests/test_gpu_fullwidth.py::test_qwen3tts_06b_width_frame_loop_and_real_decoder" -m gpu -q 2>&1 | grep -E "passed|failed|Error|assert" | tail -5
+timeout 300 python tools/bench_qwen3tts.py 32 100 16 > gpurun_out/q3_norm.json 2>/dev/null; tail -1 gpurun_out/q3_norm.json | cut -c100-700
