@@ -60,6 +60,9 @@ class Qwen3TTSConfiguration:
     codec_pad_id: int = 2148
     codec_bos_id: int = 2149
     codec_language_id: dict | None = None
+    spk_id: dict | None = None              # CustomVoice: speaker name -> codec token id (int or [int, ...]: first), Qwen3TTSConfig.swift:118-147
+    spk_is_dialect: dict | None = None      # speaker name -> false | dialect name (a codec_language_id key), :153-196
+    tts_model_type: str = "base"            # "custom_voice": `voice` = "speaker[, instruction]" (Qwen3TTS.swift:361-371)
     tts_pad_token_id: int = 151671
     tts_bos_token_id: int = 151672
     tts_eos_token_id: int = 151673
@@ -88,6 +91,7 @@ class Qwen3TTSConfiguration:
                    codec_nothink_id=t.get("codec_nothink_id", 2155), codec_think_bos_id=t.get("codec_think_bos_id", 2156),
                    codec_think_eos_id=t.get("codec_think_eos_id", 2157), codec_pad_id=t.get("codec_pad_id", 2148),
                    codec_bos_id=t.get("codec_bos_id", 2149), codec_language_id=t.get("codec_language_id"),
+                   spk_id=t.get("spk_id"), spk_is_dialect=t.get("spk_is_dialect"), tts_model_type=d.get("tts_model_type", "base"),
                    tts_pad_token_id=d.get("tts_pad_token_id", 151671), tts_bos_token_id=d.get("tts_bos_token_id", 151672),
                    tts_eos_token_id=d.get("tts_eos_token_id", 151673), sample_rate=d.get("sample_rate", 24000), decoder=dec)
 
@@ -306,8 +310,25 @@ class Qwen3TTSModel:
     def samples_per_frame(self) -> int:
         return int(_lib.lib().mis_qwen3tts_samples_per_frame(self._h))
 
-    def prepare_generation_inputs(self, text: str, language: str = "auto", instruct: str | None = None) -> PreparedPrompt:
-        """prepareGenerationInputs (Qwen3TTS.swift:883-1000) without the CustomVoice speaker branch."""
+    @staticmethod
+    def parse_custom_voice_prompt(voice: str | None):
+        """parseCustomVoicePrompt (Qwen3TTS.swift:571-594): "speaker[, instruction]" -> (speaker, instruction | None); None if empty."""
+        v = (voice or "").strip()
+        if not v:
+            return None
+        if "," not in v:
+            return v, None
+        speaker, instruction = v.split(",", 1)
+        speaker, instruction = speaker.strip(), instruction.strip()
+        if not speaker:
+            return v, None
+        return speaker, (instruction or None)
+
+    def prepare_generation_inputs(self, text: str, language: str = "auto", instruct: str | None = None,
+                                  speaker: str | None = None) -> PreparedPrompt:
+        """prepareGenerationInputs (Qwen3TTS.swift:883-1000).  The CustomVoice speaker (:914-936,957-962) is the talker's input
+        embedding of the speaker's codec token, spliced between the think prefix and (pad, bos): on this side one more codec id, the
+        engine embeds it with the same table; a dialect speaker overrides the language id."""
         if self.tokenizer is None:
             raise AudioGenerationError(1, "Qwen3TTS requires the text tokenizer to be loaded")
         cfg = self.configuration
@@ -315,9 +336,17 @@ class Qwen3TTSModel:
         lang = None
         if language.lower() != "auto" and cfg.codec_language_id:
             lang = cfg.codec_language_id.get(language.lower())
+        spk_token = None
+        if speaker:
+            v = (cfg.spk_id or {}).get(speaker.lower())
+            if v is not None:                                           # SpkIdValue.intValue: the int, or the first of a list (0 if empty)
+                spk_token = (int(v[0]) if v else 0) if isinstance(v, (list, tuple)) else int(v)
+            dv = (cfg.spk_is_dialect or {}).get(speaker.lower())
+            if isinstance(dv, str) and cfg.codec_language_id and dv in cfg.codec_language_id:
+                lang = cfg.codec_language_id[dv]                          # dialect override (:927-935)
         prefix = ([cfg.codec_think_id, cfg.codec_think_bos_id, lang, cfg.codec_think_eos_id] if lang is not None
                   else [cfg.codec_nothink_id, cfg.codec_think_bos_id, cfg.codec_think_eos_id])
-        codec = prefix + [cfg.codec_pad_id, cfg.codec_bos_id]
+        codec = prefix + ([spk_token] if spk_token is not None else []) + [cfg.codec_pad_id, cfg.codec_bos_id]
         t, c = [], []
         if instruct:
             ins = list(self.tokenizer.encode(f"<|im_start|>user\n{instruct}<|im_end|>\n"))
@@ -427,9 +456,17 @@ class Qwen3TTSModel:
         VoiceDesign instruction."""
         if ref_audio is not None:
             raise AudioGenerationError(5, "in-context voice cloning needs the speech-tokenizer encoder (not built)")
-        p = self.prepare_generation_inputs(text, language or "auto", voice)
+        p = self._prepare(text, voice, language)
         out = self.generate_batch([p], generation_parameters)[0]
         return out if len(out) else np.zeros(1, np.float32)              # generatedCodes.isEmpty -> zeros([1]) (:520-522)
+
+    def _prepare(self, text, voice, language):
+        """the non-cloning branch of generate (Qwen3TTS.swift:361-371): CustomVoice models read `voice` as "speaker[, instruction]",
+        the others as the VoiceDesign instruction"""
+        if self.configuration.tts_model_type == "custom_voice":
+            cv = self.parse_custom_voice_prompt(voice)
+            return self.prepare_generation_inputs(text, language or "auto", cv[1] if cv else None, cv[0] if cv else None)
+        return self.prepare_generation_inputs(text, language or "auto", voice)
 
     # -- streamingStep / resetStreamingState (Qwen3TTSSpeechTokenizer.swift:948-1006) --------------------------------------
     def set_stream_exact(self, exact: bool):
@@ -481,5 +518,5 @@ class Qwen3TTSModel:
                         generation_parameters: Qwen3TTSGenerateParameters | None = None, streaming_interval: float = 2.0):
         """generateStream (:84-133): .token per frame and .audio chunks while generating, .info when the loop ends, then the
         remaining samples."""
-        p = self.prepare_generation_inputs(text, language or "auto", voice)
+        p = self._prepare(text, voice, language)
         yield from self.generate_stream_batch([p], generation_parameters, streaming_interval)

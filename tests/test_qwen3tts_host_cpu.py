@@ -68,3 +68,28 @@ def test_speech_tokenizer_sanitize_and_safetensors_reader_round_trip(tmp_path):
                                           {"decoder_config": {"upsample_rates": [3, 2], "codebook_dim": 160}})
     assert (cfg.talker.hidden_size, cfg.talker.num_hidden_layers, cfg.predictor.num_hidden_layers, cfg.predictor.vocab_size) == (256, 28, 3, 2048)
     assert cfg.tts_pad_token_id == 7 and cfg.decoder.upsample_rates == (3, 2) and cfg.decoder.codebook_dim == 160 and cfg.decoder.latent_dim == 1024
+
+
+def test_custom_voice_speaker_branch_and_dialect_override():
+    """CustomVoice models (Qwen3TTS.swift:361-371,914-936,957-962): `voice` = "speaker[, instruction]"; the speaker's codec token is
+    spliced between the think prefix and (pad, bos); a dialect speaker overrides the language id; unknown speakers fall through."""
+    cfg = q3.Qwen3TTSConfiguration(codec_language_id={"english": 2050, "sichuan_dialect": 2062}, tts_model_type="custom_voice",
+                                   spk_id={"ryan": 3061, "eric": [3065, 7]}, spk_is_dialect={"ryan": False, "eric": "sichuan_dialect"})
+    m = object.__new__(q3.Qwen3TTSModel)
+    m.configuration = cfg; m.tokenizer = _Tok(); m._h = None
+    assert q3.Qwen3TTSModel.parse_custom_voice_prompt(" Ryan , speak slowly ") == ("Ryan", "speak slowly")
+    assert q3.Qwen3TTSModel.parse_custom_voice_prompt("Ryan") == ("Ryan", None)
+    assert q3.Qwen3TTSModel.parse_custom_voice_prompt(", x") == (", x", None) and q3.Qwen3TTSModel.parse_custom_voice_prompt("  ") is None
+    p = m._prepare("Hi you", "Ryan", "English")
+    tail = [cfg.codec_think_id, cfg.codec_think_bos_id, 2050, cfg.codec_think_eos_id, 3061, cfg.codec_pad_id, cfg.codec_bos_id]
+    assert p.codec_ids.tolist() == [-1, -1, -1] + tail
+    ids = _Tok().encode("<|im_start|>assistant\nHi you<|im_end|>\n<|im_start|>assistant\n")
+    assert p.text_ids.tolist() == ids[:3] + [cfg.tts_pad_token_id] * (len(tail) - 2) + [cfg.tts_bos_token_id] + [ids[3]]   # padCount = prefix - 2
+    q = m._prepare("Hi you", "eric, whisper", "auto")                        # dialect speaker: language id from spk_is_dialect
+    ins = _Tok().encode("<|im_start|>user\nwhisper<|im_end|>\n")
+    assert q.codec_ids.tolist()[len(ins) + 3:] == [cfg.codec_think_id, cfg.codec_think_bos_id, 2062, cfg.codec_think_eos_id, 3065,
+                                                   cfg.codec_pad_id, cfg.codec_bos_id]
+    r = m._prepare("Hi you", "nobody", "auto")                               # unknown speaker: no splice (the reference only warns)
+    assert r.codec_ids.tolist() == [-1, -1, -1, cfg.codec_nothink_id, cfg.codec_think_bos_id, cfg.codec_think_eos_id, cfg.codec_pad_id, cfg.codec_bos_id]
+    base = q3.Qwen3TTSConfiguration.from_dict({"tts_model_type": "custom_voice", "talker_config": {"spk_id": {"a": 5}, "spk_is_dialect": {"a": False}}})
+    assert base.tts_model_type == "custom_voice" and base.spk_id == {"a": 5} and base.spk_is_dialect == {"a": False}
