@@ -153,6 +153,26 @@ __device__ static inline float wave_sum(float v) {
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
     return v;
 }
+// the same sum on the DPP network instead of six dependent ds_bpermute round trips (about 60 cycles each): two quad
+// permutes, half-row and row mirror give every lane its 16-lane row total, the four row totals are read as scalars.
+// (Other summation order than wave_sum: use one or the other consistently where bit-reproducibility across code paths matters.)
+__device__ static inline float wave_sum_dpp(float v) {
+    auto dpp_add = [](float x, int ctrl_tag) {
+        int xi = __builtin_bit_cast(int, x), yi;
+        switch (ctrl_tag) {
+            case 0: yi = __builtin_amdgcn_update_dpp(0, xi, 0xB1, 0xF, 0xF, true); break;    // quad_perm [1,0,3,2]
+            case 1: yi = __builtin_amdgcn_update_dpp(0, xi, 0x4E, 0xF, 0xF, true); break;    // quad_perm [2,3,0,1]
+            case 2: yi = __builtin_amdgcn_update_dpp(0, xi, 0x141, 0xF, 0xF, true); break;   // row_half_mirror
+            default: yi = __builtin_amdgcn_update_dpp(0, xi, 0x140, 0xF, 0xF, true); break;  // row_mirror
+        }
+        return x + __builtin_bit_cast(float, yi);
+    };
+    v = dpp_add(v, 0); v = dpp_add(v, 1); v = dpp_add(v, 2); v = dpp_add(v, 3);
+    const int vi = __builtin_bit_cast(int, v);
+    const float r0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(vi, 0)), r1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(vi, 16)),
+                r2 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(vi, 32)), r3 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(vi, 48));
+    return (r0 + r1) + (r2 + r3);
+}
 __device__ static inline float wave_max(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));

@@ -73,6 +73,12 @@ struct mis_tts {
     DevBuf<SamplerScratch> samp_scratch;
     hipGraphExec_t g_prefill = nullptr, g_decode = nullptr;
     uint64_t graph_key = 0;
+    // Infinity-Cache prefetch branch of the step chain (see k_touch, lm_kernels.hip): a second stream forked / joined with events
+    hipStream_t pf_stream = nullptr;
+    std::vector<hipEvent_t> pf_events;
+    DevBuf<uint32_t> pf_sink;
+    int pf_mask = 0, pf_blocks = 256;
+    size_t pf_cap = 0;                               // experiment: at most this many bytes per touch (0 = the whole matrix)
     bool use_graph = true;
     bool borrowed_stream = false;
     int profiling = 0;
@@ -135,6 +141,8 @@ extern "C" void mis_tts_destroy(mis_tts* c) {
     if (c->g_prefill) (void)hipGraphExecDestroy(c->g_prefill);
     if (c->g_decode) (void)hipGraphExecDestroy(c->g_decode);
     if (c->stream && !c->borrowed_stream) (void)hipStreamDestroy(c->stream);
+    for (auto e : c->pf_events) (void)hipEventDestroy(e);
+    if (c->pf_stream) (void)hipStreamDestroy(c->pf_stream);
     delete c;
 }
 
@@ -531,6 +539,16 @@ static void lm_reset(mis_tts* c, int batch, int max_context) {
     c->S_qkv = std::min(8, choose_split(c->Nqkv / 16 / c->r_part, d / 32, c->ksb_part, "MIS_S_QKV", 8));   // attention prologue: <= 8 slabs
     c->S_o = choose_split(d / 16 / c->r_part, HD / 32, c->ksb_part, "MIS_S_O");
     c->S_down = choose_split(d / 16 / c->r_part, c->ff / 32, c->ksb_part, "MIS_S_DOWN");
+    {
+        const int mask = env_int("MIS_PREFETCH", 0), blocks = std::max(1, env_int("MIS_PREFETCH_BLOCKS", 256));
+        if (mask != c->pf_mask || blocks != c->pf_blocks) destroy_graphs(c);
+        c->pf_mask = mask; c->pf_blocks = blocks;
+        c->pf_cap = (size_t)std::max(0, env_int("MIS_PREFETCH_CAP_KB", 0)) * 1024;
+        if (mask && !c->pf_stream) {
+            HIP_CHECK(hipStreamCreateWithFlags(&c->pf_stream, hipStreamNonBlocking));
+            c->pf_sink.alloc(4);
+        }
+    }
     size_t kv = (size_t)c->L * batch * c->Hkv * Smax * c->D;
     c->kcache.alloc(kv);
     c->vtcache.alloc(kv);
@@ -581,13 +599,35 @@ static void enqueue_layers(mis_tts* c, const bf16_t* table = nullptr, int table_
     hipStream_t s = c->stream;
     const int d = c->d, HD = c->H * c->D, Mpad = c->Mpad;
     const float eps = c->cfg.rms_norm_eps;
+    // prefetch branch: fork() makes the side stream depend on everything enqueued on `s` so far, so a touch forked right BEFORE
+    // launch X runs concurrently with X (and whatever follows); one join at the end of the chain.  Bits of MIS_PREFETCH:
+    //   1 o_proj weights during attention   2 down weights from glue 1 on   4 next layer's q|k|v weights during glue 2
+    //   8 this layer's cached K / V during the q|k|v GEMM   16 gate|up weights during o_proj
+    const int pf = (c->pf_stream && !c->q_qkv.on && !c->q_o.on && !c->q_gu.on && !c->q_down.on) ? c->pf_mask : 0;
+    size_t n_fork = 0;
+    auto capped = [&](size_t bytes) { return c->pf_cap ? std::min(bytes, c->pf_cap) : bytes; };
+    auto fork = [&]() {
+        if (n_fork == c->pf_events.size()) {
+            hipEvent_t e;
+            HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+            c->pf_events.push_back(e);
+        }
+        hipEvent_t e = c->pf_events[n_fork++];
+        HIP_CHECK(hipEventRecord(e, s));
+        HIP_CHECK(hipStreamWaitEvent(c->pf_stream, e, 0));
+    };
     launch_embed_rmsnorm(table ? table : c->emb.p, ids ? ids : c->ids.p, c->active.p, c->pos_cur.p, c->pos_next.p, c->norms.p,
                          c->h.p, c->x.p, d, table ? table_rows : c->V, eps, c->batch, Mpad, s);
     for (int li = 0; li < c->L; ++li) {
+        const size_t lkv = (size_t)c->batch * c->Hkv * c->Smax * c->D;
+        if (pf & 8) {
+            fork();
+            launch_touch_kv(c->kcache.p + lkv * li, c->vtcache.p + lkv * li, c->pos_cur.p, c->active.p, c->batch, c->Hkv, c->Smax, c->D,
+                            c->pf_sink.p, c->pf_stream);
+        }
         gemm_qkv(c, li, s);
         AttnParams ap{};
         ap.qkv_part = c->qkv_part.p; ap.S = c->S_qkv; ap.Mpad = Mpad; ap.Nqkv = c->Nqkv;
-        size_t lkv = (size_t)c->batch * c->Hkv * c->Smax * c->D;
         ap.kcache = c->kcache.p + lkv * li; ap.vtcache = c->vtcache.p + lkv * li;
         ap.pos = c->pos_cur.p; ap.active = c->active.p;
         ap.rope_cos = c->rope_cos.p; ap.rope_sin = c->rope_sin.p;
@@ -599,13 +639,39 @@ static void enqueue_layers(mis_tts* c, const bf16_t* table = nullptr, int table_
             ap.qk_eps = c->cfg.rms_norm_eps;
         }
         ap.rope_in_dtype = c->cfg.rope_ops_in_dtype;
+        if (pf & 1) {
+            fork();
+            launch_touch(c->wo.p + layer_o_elems(c) * li, capped(layer_o_elems(c) * 2), c->pf_blocks, c->pf_sink.p, c->pf_stream);
+        }
         launch_attn_decode(ap, c->batch, s);
+        if (pf & 16) {
+            fork();
+            launch_touch(c->wgu.p + layer_gu_elems(c) * li, capped(layer_gu_elems(c) * 2), c->pf_blocks, c->pf_sink.p, c->pf_stream);
+        }
         gemm_o(c, li, s);
+        if (pf & 2) {
+            fork();
+            launch_touch(c->wdown.p + layer_down_elems(c) * li, capped(layer_down_elems(c) * 2), c->pf_blocks, c->pf_sink.p, c->pf_stream);
+        }
         launch_reduce_residual_rmsnorm(c->part.p, c->S_o, Mpad, d, c->h.p, c->norms.p + (size_t)(2 * li + 1) * d, c->x.p, eps, s);
         gemm_gate_up(c, li, s);
         gemm_down(c, li, s);
+        if ((pf & 4) && li + 1 < c->L) {
+            fork();
+            launch_touch(c->wqkv.p + layer_qkv_elems(c) * (li + 1), capped(layer_qkv_elems(c) * 2), c->pf_blocks, c->pf_sink.p, c->pf_stream);
+        }
         const bf16_t* next_norm = c->norms.p + (size_t)(li + 1 < c->L ? 2 * (li + 1) : 2 * c->L) * d;
         launch_reduce_residual_rmsnorm(c->part.p, c->S_down, Mpad, d, c->h.p, next_norm, c->x.p, eps, s);
+    }
+    if (n_fork) {                                   // join: the side branch ends inside this chain (required by stream capture)
+        if (n_fork == c->pf_events.size()) {
+            hipEvent_t e;
+            HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+            c->pf_events.push_back(e);
+        }
+        hipEvent_t e = c->pf_events[n_fork];
+        HIP_CHECK(hipEventRecord(e, c->pf_stream));
+        HIP_CHECK(hipStreamWaitEvent(s, e, 0));
     }
 }
 static void enqueue_lm_head(mis_tts* c, const bf16_t* head = nullptr) {

@@ -38,6 +38,11 @@ void launch_gemm_skinny_q(int bits, int epi, int R, int ksb, const void* Qp, con
 void launch_pack_qweight(int bits, const uint32_t* wq, const bf16_t* scales, const bf16_t* biases, void* qdst, bf16_t* sbdst, int N, int K,
                          int tile_stride, int tile_offset, hipStream_t s);
 
+// Infinity-Cache prefetch of data a later launch of the step chain will stream (side branch of the step graph)
+void launch_touch(const void* p, size_t bytes, int blocks, void* sink, hipStream_t s);
+void launch_touch_kv(const bf16_t* kc, const bf16_t* vt, const int* pos, const uint8_t* active, int batch, int Hkv, int Smax, int D, void* sink,
+                     hipStream_t s);
+
 // batched prefill (lm_prefill.hip): M = positions x rows
 enum { PF_F32 = 0, PF_RESID = 1, PF_SILU = 2 };
 void launch_gemm_pf(int epi, const bf16_t* X, const bf16_t* Wp, void* C, int M, int N, int K, hipStream_t s);

@@ -100,6 +100,52 @@ void launch_synth_fill_bf16(bf16_t* dst, size_t n, uint64_t key, float amp, int 
     hipLaunchKernelGGL(k_synth_fill_bf16, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, dst, n, key, amp, plus_one);
 }
 
+// ============================================================================ Infinity-Cache prefetch ("touch") kernels
+//
+// The decode chain is a sequence of dependent launches; the weights (and the cached keys / values) the NEXT launches will stream
+// do not depend on anything computed in this step.  A side branch of the step graph reads them early - while a latency-bound
+// launch (glue, attention, the short split-K GEMMs) leaves HBM idle - so that they sit in the 256 MB Infinity Cache (memory-side:
+// every HBM read allocates) when their consumer starts: profiles/r02_mall_probe.txt prices the consumer at -15..23 % for the
+// split-K GEMMs.  Loads are non-temporal like the consumer's; the xor / conditional store only keeps them alive.
+typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void touch_range(const u32x4_t* __restrict__ p, size_t n16, size_t first, size_t stride, u32x4_t& acc) {
+    size_t i = first;
+    for (; i + 7 * stride < n16; i += 8 * stride) {
+        u32x4_t v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = __builtin_nontemporal_load(p + i + (size_t)u * stride);
+#pragma unroll
+        for (int u = 0; u < 8; ++u) acc ^= v[u];
+    }
+    for (; i < n16; i += stride) acc ^= __builtin_nontemporal_load(p + i);
+}
+__global__ void __launch_bounds__(256) k_touch(const u32x4_t* __restrict__ p, size_t n16, u32x4_t* __restrict__ sink) {
+    u32x4_t acc = (u32x4_t){0u, 0u, 0u, 0u};
+    touch_range(p, n16, (size_t)blockIdx.x * 256 + threadIdx.x, (size_t)gridDim.x * 256, acc);
+    if (acc.x == 0x7fc00001u && acc.y == 0x7fc00002u) sink[0] = acc;           // scratch word nobody reads
+}
+// cached keys / values of one layer: block (kv head, row) touches the tiles [0, pos / 32] the decode attention of this step will
+// read (same grid as k_attn_decode: under the observed block -> XCD mapping the lines also land in the consumer's own L2)
+__global__ void __launch_bounds__(256) k_touch_kv(const bf16_t* __restrict__ kc, const bf16_t* __restrict__ vt, const int* __restrict__ pos,
+                                                  const uint8_t* __restrict__ active, int Hkv, int Smax, int D, u32x4_t* __restrict__ sink) {
+    const int kvh = blockIdx.x, b = blockIdx.y;
+    if (!active[b]) return;
+    const size_t n16 = (size_t)((pos[b] >> 5) + 1) * 32 * D * 2 / 16;
+    const size_t base = ((size_t)(b * Hkv + kvh) * Smax) * D;
+    u32x4_t acc = (u32x4_t){0u, 0u, 0u, 0u};
+    touch_range(reinterpret_cast<const u32x4_t*>(kc + base), n16, threadIdx.x, 256, acc);
+    touch_range(reinterpret_cast<const u32x4_t*>(vt + base), n16, threadIdx.x, 256, acc);
+    if (acc.x == 0x7fc00001u && acc.y == 0x7fc00002u) sink[0] = acc;
+}
+void launch_touch(const void* p, size_t bytes, int blocks, void* sink, hipStream_t s) {
+    if (bytes < 16 || blocks < 1) return;
+    hipLaunchKernelGGL(k_touch, dim3(blocks), dim3(256), 0, s, reinterpret_cast<const u32x4_t*>(p), bytes / 16, reinterpret_cast<u32x4_t*>(sink));
+}
+void launch_touch_kv(const bf16_t* kc, const bf16_t* vt, const int* pos, const uint8_t* active, int batch, int Hkv, int Smax, int D, void* sink,
+                     hipStream_t s) {
+    hipLaunchKernelGGL(k_touch_kv, dim3(Hkv, batch), dim3(256), 0, s, kc, vt, pos, active, Hkv, Smax, D, reinterpret_cast<u32x4_t*>(sink));
+}
+
 // ============================================================================ step bookkeeping
 
 // prefill feeder: step j of a left-padded prompt matrix [B][Lmax]; row b starts at j0 = Lmax - len[b]
@@ -336,8 +382,88 @@ __global__ void __launch_bounds__(RR_THREADS) k_reduce_residual_rmsnorm(const fl
         }
     }
 }
+// The RMSNorm case again with FOUR consecutive columns per thread (N / 4 <= 1024 threads, single pass): one float4 per slab, one
+// 8-byte load each for h and the norm weight, 8-byte stores (four consecutive columns are half of a 16-byte unit of the packed
+// operand layout) - S + 2 load instructions per thread instead of 3 S + 6, and 12 waves per row instead of 16 at d = 3072.
+template <int SG>
+__global__ void __launch_bounds__(1024) k_glue4(const float* __restrict__ slabs, int S, int Mpad, int N, bf16_t* __restrict__ h,
+                                                const bf16_t* __restrict__ wnorm, bf16_t* __restrict__ x, float eps) {
+    __shared__ float red[16];
+    const int m = blockIdx.x, tid = threadIdx.x, nth = blockDim.x;
+    const int MT = gridDim.x >> 4;
+    const int c4 = tid < (N >> 2) ? tid : (N >> 2) - 1;          // clamped: threads past the row load valid addresses, results masked
+    const bool live = tid < (N >> 2);
+    // The loads are written as asm statements: hipcc splits, sinks and re-orders plain loads of `const __restrict__` data around
+    // any pin (a slab load ended up behind the wait for the others: two dependent round trips).  Volatile asm statements keep their
+    // order: S + 2 loads in flight, ONE wait naming every destination, then the math.  (hipcc does not count asm loads in its own
+    // s_waitcnt bookkeeping; the kernel has no other vector loads.)
+    unsigned long long hq, wq;
+    f32x4_t v[SG];
+    {
+        const bf16_t* hp = h + (size_t)m * N + 4 * c4;
+        const bf16_t* wp = wnorm + 4 * c4;
+        asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(hq) : "v"(hp));
+        asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(wq) : "v"(wp));
+#pragma unroll
+        for (int j = 0; j < SG; ++j) {
+            const int sj = j < S ? j : S - 1;
+            const float* sp = slabs + ((size_t)sj * Mpad + m) * N + 4 * c4;
+            asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(v[j]) : "v"(sp));
+        }
+        if constexpr (SG == 2) asm volatile("s_waitcnt vmcnt(0)" : "+v"(hq), "+v"(wq), "+v"(v[0]), "+v"(v[1]));
+        else if constexpr (SG == 4) asm volatile("s_waitcnt vmcnt(0)" : "+v"(hq), "+v"(wq), "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]));
+        else asm volatile("s_waitcnt vmcnt(0)" : "+v"(hq), "+v"(wq), "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]),
+                          "+v"(v[6]), "+v"(v[7]));
+    }
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int j = 0; j < SG; ++j) {                              // slab order 0, 1, 2, ... (fixed => deterministic)
+        const bool on = j < S;
+        acc[0] += on ? v[j][0] : 0.0f; acc[1] += on ? v[j][1] : 0.0f; acc[2] += on ? v[j][2] : 0.0f; acc[3] += on ? v[j][3] : 0.0f;
+    }
+    const uint32_t hq0 = (uint32_t)hq, hq1 = (uint32_t)(hq >> 32);
+    const float hv[4] = {bf16_to_f32((bf16_t)(hq0 & 0xffffu)), bf16_to_f32((bf16_t)(hq0 >> 16)), bf16_to_f32((bf16_t)(hq1 & 0xffffu)),
+                         bf16_to_f32((bf16_t)(hq1 >> 16))};
+    const uint32_t wq0 = (uint32_t)wq, wq1 = (uint32_t)(wq >> 32);
+    const float wv[4] = {bf16_to_f32((bf16_t)(wq0 & 0xffffu)), bf16_to_f32((bf16_t)(wq0 >> 16)), bf16_to_f32((bf16_t)(wq1 & 0xffffu)),
+                         bf16_to_f32((bf16_t)(wq1 >> 16))};
+    float hn[4], ss = 0.0f;
+    bf16_t hb[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        hn[e] = bf16_round_f32(hv[e] + bf16_round_f32(acc[e]));   // o = T(sum slabs); h = T(h + o)
+        hb[e] = f32_to_bf16(hn[e]);
+        ss += live ? hn[e] * hn[e] : 0.0f;
+    }
+    if (live) *reinterpret_cast<uint2*>(h + (size_t)m * N + 4 * c4) =
+        make_uint2((uint32_t)hb[0] | ((uint32_t)hb[1] << 16), (uint32_t)hb[2] | ((uint32_t)hb[3] << 16));
+    ss = wave_sum_dpp(ss);
+    if ((tid & 63) == 0) red[tid >> 6] = ss;
+    __syncthreads();
+    float tot = 0.0f;
+    const int nw = nth >> 6;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) tot += i < nw ? red[i] : 0.0f;
+    const float inv = 1.0f / sqrtf(tot / (float)N + eps);
+    if (live) {
+        bf16_t xb[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) xb[e] = f32_to_bf16(wv[e] * bf16_round_f32(hn[e] * inv));
+        *reinterpret_cast<uint2*>(x + xpk_index(m, 4 * c4, MT)) =
+            make_uint2((uint32_t)xb[0] | ((uint32_t)xb[1] << 16), (uint32_t)xb[2] | ((uint32_t)xb[3] << 16));
+    }
+}
+
 void launch_reduce_residual_rmsnorm(const float* slabs, int S, int Mpad, int N, bf16_t* h, const bf16_t* wnorm,
                                     bf16_t* x, float eps, hipStream_t s, const bf16_t* ln_bias) {
+    static const int v4 = getenv("MIS_GLUE_V4") ? atoi(getenv("MIS_GLUE_V4")) : 1;
+    if (v4 && !ln_bias && N % 4 == 0 && N / 4 <= 1024 && S <= 8) {
+        const int nth = ((N / 4 + 63) / 64) * 64;
+        if (S <= 2) hipLaunchKernelGGL((k_glue4<2>), dim3(Mpad), dim3(nth), 0, s, slabs, S, Mpad, N, h, wnorm, x, eps);
+        else if (S <= 4) hipLaunchKernelGGL((k_glue4<4>), dim3(Mpad), dim3(nth), 0, s, slabs, S, Mpad, N, h, wnorm, x, eps);
+        else hipLaunchKernelGGL((k_glue4<8>), dim3(Mpad), dim3(nth), 0, s, slabs, S, Mpad, N, h, wnorm, x, eps);
+        return;
+    }
     if (S <= 2) hipLaunchKernelGGL((k_reduce_residual_rmsnorm<2>), dim3(Mpad), dim3(RR_THREADS), 0, s, slabs, S, Mpad, N, h, wnorm, x, eps, ln_bias);
     else if (S <= 4) hipLaunchKernelGGL((k_reduce_residual_rmsnorm<4>), dim3(Mpad), dim3(RR_THREADS), 0, s, slabs, S, Mpad, N, h, wnorm, x, eps, ln_bias);
     else hipLaunchKernelGGL((k_reduce_residual_rmsnorm<8>), dim3(Mpad), dim3(RR_THREADS), 0, s, slabs, S, Mpad, N, h, wnorm, x, eps, ln_bias);

@@ -77,6 +77,14 @@ def record(name: str, **metrics):
         pass
 
 
+def observe(kind: str, value: float, tol: float) -> bool:
+    """Record one observed error of the running test next to its gate (name from PYTEST_CURRENT_TEST) and return value <= tol.
+    tools/parity_summary.py reduces the records to the per-test maxima kept under profiles/."""
+    name = os.environ.get("PYTEST_CURRENT_TEST", "?").split(" ")[0].split("::")[-1]
+    record(name, kind=kind, value=float(value), tol=float(tol))
+    return bool(value <= tol)
+
+
 def logits_errors(dev_l, ref_l):
     """(max abs err / max |ref|, rms err / rms ref, greedy agreement on rows whose oracle top-2 margin exceeds 2x the max error)"""
     scale = float(np.abs(ref_l).max())

@@ -10,10 +10,13 @@ import pytest
 import torch
 
 import mlx_audio_swift_amd as mas
-from gpu_util import lm_host_config, lm_pair, rms, teacher_forced
+from gpu_util import lm_host_config, lm_pair, observe, rms, teacher_forced
 from oracle import llama as ollama
 
 pytestmark = pytest.mark.gpu
+
+
+TOL_MAX, TOL_RMS = 0.04, 0.008
 
 
 def _check(pairs):
@@ -21,8 +24,8 @@ def _check(pairs):
         assert dev_l.shape == ref_l.shape
         scale = float(np.abs(ref_l).max())
         err = float(np.abs(dev_l - ref_l).max())
-        assert err <= 0.04 * scale, (err, scale)
-        assert rms(dev_l, ref_l) <= 0.008 * float(np.sqrt(np.mean(ref_l.astype(np.float64) ** 2)))
+        assert observe("logits_max_rel", err / scale, TOL_MAX), (err, scale)
+        assert observe("logits_rms_rel", rms(dev_l, ref_l) / float(np.sqrt(np.mean(ref_l.astype(np.float64) ** 2))), TOL_RMS)
         # bf16-valued logits
         t = torch.from_numpy(dev_l)
         assert torch.equal(t, t.to(torch.bfloat16).to(torch.float32))

@@ -7,7 +7,7 @@ import numpy as np
 import pytest
 
 import mlx_audio_swift_amd as mas
-from gpu_util import rms
+from gpu_util import observe, rms
 from oracle import mel as omel
 from oracle import whisper as ow
 
@@ -30,8 +30,8 @@ def _feats(B, n_mels, seed):
 
 def _check(dev, ref, max_tol, rms_tol):
     scale = float(np.abs(ref).max())
-    assert float(np.abs(dev - ref).max()) <= max_tol * scale, (float(np.abs(dev - ref).max()), scale)
-    assert rms(dev, ref) <= rms_tol * float(np.sqrt(np.mean(ref.astype(np.float64) ** 2)))
+    assert observe("max_rel", float(np.abs(dev - ref).max()) / scale, max_tol), (float(np.abs(dev - ref).max()), scale)
+    assert observe("rms_rel", rms(dev, ref) / float(np.sqrt(np.mean(ref.astype(np.float64) ** 2))), rms_tol)
 
 
 @pytest.mark.parametrize("cfg", [ow.TINY, ow.WhisperConfig(vocab_size=700, num_mel_bins=128, d_model=256, encoder_layers=1,
