@@ -30,11 +30,8 @@ struct RcclApi {
     int (*CommDestroy)(rccl_comm_t) = nullptr;
     const char* (*GetErrorString)(int) = nullptr;
 };
-RcclApi* rccl() {
-    static RcclApi api;
-    static bool tried = false;
-    if (tried) return api.handle ? &api : nullptr;
-    tried = true;
+RcclApi load_rccl() {
+    RcclApi api;
     std::vector<std::string> names;
     if (const char* p = getenv("MIS_RCCL_PATH")) names.push_back(p);
     names.push_back("librccl.so.1");
@@ -43,15 +40,18 @@ RcclApi* rccl() {
     void* h = nullptr;
     for (auto& n : names) if ((h = dlopen(n.c_str(), RTLD_NOW | RTLD_NOLOAD))) break;      // a copy the host already loaded (torch bundles one)
     if (!h) for (auto& n : names) if ((h = dlopen(n.c_str(), RTLD_NOW | RTLD_GLOBAL))) break;
-    if (!h) return nullptr;
+    if (!h) return api;
     api.GetUniqueId = (int (*)(rccl_unique_id*))dlsym(h, "ncclGetUniqueId");
     api.CommInitRank = (int (*)(rccl_comm_t*, int, rccl_unique_id, int))dlsym(h, "ncclCommInitRank");
     api.AllGather = (int (*)(const void*, void*, size_t, int, rccl_comm_t, hipStream_t))dlsym(h, "ncclAllGather");
     api.CommDestroy = (int (*)(rccl_comm_t))dlsym(h, "ncclCommDestroy");
     api.GetErrorString = (const char* (*)(int))dlsym(h, "ncclGetErrorString");
-    if (!api.GetUniqueId || !api.CommInitRank || !api.AllGather || !api.CommDestroy) return nullptr;
-    api.handle = h;
-    return &api;
+    if (api.GetUniqueId && api.CommInitRank && api.AllGather && api.CommDestroy) api.handle = h;
+    return api;
+}
+RcclApi* rccl() {
+    static RcclApi api = load_rccl();       // function-local static: initialised exactly once, concurrent callers wait for it
+    return api.handle ? &api : nullptr;
 }
 #define RCCL_CHECK(expr)                                                                                     \
     do {                                                                                                     \
@@ -121,8 +121,12 @@ extern "C" mis_status mis_comm_all_gather_pcm(mis_comm* c, const float* pcm_loca
     hipStream_t s = c->stream;
     c->lens_local.alloc(rows_local); c->lens_all.alloc((size_t)rows_local * c->world);
     HIP_CHECK(hipMemcpyAsync(c->lens_local.p, lens_local, (size_t)rows_local * 8, hipMemcpyDefault, s));
-    hipEvent_t e0, e1;
-    HIP_CHECK(hipEventCreate(&e0)); HIP_CHECK(hipEventCreate(&e1));
+    struct EventPair {                             // released on every exit path (RCCL_CHECK / HIP_CHECK throw)
+        hipEvent_t a = nullptr, b = nullptr;
+        ~EventPair() { if (a) (void)hipEventDestroy(a); if (b) (void)hipEventDestroy(b); }
+    } ev;
+    HIP_CHECK(hipEventCreate(&ev.a)); HIP_CHECK(hipEventCreate(&ev.b));
+    hipEvent_t e0 = ev.a, e1 = ev.b;
     HIP_CHECK(hipEventRecord(e0, s));
     RCCL_CHECK(rccl()->AllGather(pcm_local_dev, pcm_all_dev, (size_t)rows_local * stride, RCCL_FLOAT32, c->comm, s));
     RCCL_CHECK(rccl()->AllGather(c->lens_local.p, c->lens_all.p, (size_t)rows_local, RCCL_INT64, c->comm, s));
@@ -133,7 +137,6 @@ extern "C" mis_status mis_comm_all_gather_pcm(mis_comm* c, const float* pcm_loca
     HIP_CHECK(hipEventElapsedTime(&ms, e0, e1));
     c->last_gather_ms = ms;
     if (gather_ms) *gather_ms = ms;
-    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
     MIS_API_END
 }
 
@@ -153,6 +156,19 @@ extern "C" mis_status mis_tts_group_create(mis_tts* const* replicas, int n, mis_
             if (replicas[j] == replicas[i]) { delete g; throw MisError(MIS_ERR_INVALID_INPUT, "a handle may appear only once in a group (one in-flight call per handle)"); }
         g->reps.push_back(replicas[i]);
     }
+    // direct peer access between every pair of the group's devices: without it hipMemcpyPeerAsync stages the all-gather of
+    // mis_tts_group_generate_device through host memory instead of writing over xGMI.  (Already-enabled is not an error; a pair the
+    // platform cannot map keeps the staged path.)
+    for (int i = 0; i < n; ++i)
+        for (int j = 0; j < n; ++j) {
+            const int di = tts_device(g->reps[i]), dj = tts_device(g->reps[j]);
+            if (di == dj) continue;
+            int can = 0;
+            if (hipDeviceCanAccessPeer(&can, di, dj) != hipSuccess || !can) { (void)hipGetLastError(); continue; }
+            if (hipSetDevice(di) != hipSuccess) { (void)hipGetLastError(); continue; }
+            const hipError_t e = hipDeviceEnablePeerAccess(dj, 0);
+            if (e != hipSuccess) (void)hipGetLastError();                   // hipErrorPeerAccessAlreadyEnabled included
+        }
     *out = g;
     MIS_API_END
 }
@@ -248,8 +264,9 @@ extern "C" mis_status mis_tts_group_generate_device(mis_group* g, const int32_t*
     MIS_API_END
 }
 
-// Same, gathering to HOST memory (what a Swift host hands back as MLXArrays): each shard's rows are copied device -> pinned host
-// straight into their place of one [batch, *pcm_stride] buffer (no peer traffic is needed for a host-side gather).
+// Same, gathering to HOST memory (what a Swift host hands back as MLXArrays): every shard returns its rows in its own pinned host
+// buffer (mis_tts_generate), and the rows are then copied host -> host into their place of one [batch, *pcm_stride] buffer - one
+// extra host memcpy per row (3 MB per shard at the bench shape), no peer traffic.
 extern "C" mis_status mis_tts_group_generate(mis_group* g, const int32_t* prompt_ids, const int32_t* prompt_lens, int batch,
                                              const mis_gen_params* params, float** pcm_out, int64_t* pcm_stride, int64_t* pcm_lens,
                                              int32_t** tokens_out, int64_t* tokens_stride, int32_t* n_tokens) {

@@ -46,7 +46,8 @@ struct mis_tts {
         DevBuf<uint8_t> q;     // [L] packed codes, layer stride q_layer bytes
         DevBuf<bf16_t> sb;     // [L] packed scale / bias pairs, layer stride sb_layer elements
         size_t q_layer = 0, sb_layer = 0;
-        int bits = 0, placed = 0;
+        int bits = 0;
+        std::set<std::string> names;   // matrices that hold codes (distinct names: a duplicate set must not stand in for a missing one)
         bool bad = false, on = false;
     } q_qkv, q_o, q_gu, q_down, q_head;
 
@@ -213,7 +214,7 @@ static void place_qmatrix(mis_tts* c, const std::string& name, int64_t N, int64_
         }
         if (R.q_layer != q_layer) { R.bad = true; return; }
         launch_pack_qweight(bits, wq, sc, bi, R.q.p + q_layer * li, R.sb.p + sb_layer * li, (int)N, (int)K, tile_stride, tile_offset, s);
-        R.placed += 1;
+        R.names.insert(name);
     };
     if (name == "lm_head.weight") { put(c->q_head, 0, 1, c->V, 1, 0); return; }
     if (name.rfind("model.layers.", 0) != 0) return;
@@ -229,6 +230,13 @@ static void place_qmatrix(mis_tts* c, const std::string& name, int64_t N, int64_
     else if (rest == "mlp.gate_proj.weight") put(c->q_gu, li, c->L, 2 * c->ff, 2, 0);
     else if (rest == "mlp.up_proj.weight") put(c->q_gu, li, c->L, 2 * c->ff, 2, 1);
     else if (rest == "mlp.down_proj.weight") put(c->q_down, li, c->L, c->d, 1, 0);
+}
+
+// a matrix that arrives in a form the code-streaming kernels cannot take (dense set_tensor, 2 bit, other group sizes / scale dtypes)
+// AFTER its role already holds codes for it: only the bf16 copy was updated, so the role's codes are stale - stream the bf16 copy
+static void mark_dense_override(mis_tts* c, const std::string& name) {
+    for (mis_tts::QRole* R : {&c->q_qkv, &c->q_o, &c->q_gu, &c->q_down, &c->q_head})
+        if (R->names.count(name)) R->bad = true;
 }
 
 static bf16_t* norm_slot(mis_tts* c, const std::string& name) {
@@ -272,6 +280,7 @@ extern "C" mis_status mis_tts_set_tensor(mis_tts* c, const char* name_, const vo
         MIS_REQUIRE(ndim == 2, MIS_ERR_INVALID_INPUT, "tensor %s must be 1-D or 2-D", name.c_str());
         launch_convert_to_bf16(c->raw_staging.p, dtype, c->staging.p, n, c->stream);
         place_matrix(c, name, shape[0], shape[1]);
+        mark_dense_override(c, name);
     }
     HIP_CHECK(hipGetLastError());
     HIP_CHECK(hipStreamSynchronize(c->stream));      // staging buffers are reused by the next call
@@ -306,6 +315,7 @@ static void set_quantized_any(mis_tts* c, const std::string& name, const uint32_
     static const bool native = !(getenv("MIS_QUANT_NATIVE") && atoi(getenv("MIS_QUANT_NATIVE")) == 0);
     if (native && (bits == 8 || bits == 4) && group_size == 64 && sb_dtype == MIS_BF16 && K % 64 == 0 && (N % 16 == 0 || name == "lm_head.weight"))
         place_qmatrix(c, name, N, K, bits, (const uint32_t*)p, (const bf16_t*)ps, (const bf16_t*)pb);
+    else mark_dense_override(c, name);
     HIP_CHECK(hipGetLastError());
     HIP_CHECK(hipStreamSynchronize(c->stream));
     c->loaded.insert(name);
@@ -453,7 +463,7 @@ extern "C" mis_status mis_tts_finalize(mis_tts* c) {
     HIP_CHECK(hipStreamSynchronize(c->stream));
     {   // quantised roles: complete and uniform -> stream the codes, drop the bf16 copy
         auto decide = [&](mis_tts::QRole& R, int expected, DevBuf<bf16_t>& dense) {
-            R.on = R.bits != 0 && !R.bad && R.placed == expected;
+            R.on = R.bits != 0 && !R.bad && (int)R.names.size() == expected;
             if (R.on) dense.release();
             else { R.q.release(); R.sb.release(); R.bits = 0; }
         };

@@ -642,6 +642,7 @@ extern "C" mis_status mis_qwen3tts_decode_stream_begin(mis_qwen3tts* c, int batc
     MIS_API_BEGIN
     MIS_REQUIRE(c && batch >= 1 && max_frames >= 1 && max_chunk_frames >= 1, MIS_ERR_INVALID_INPUT, "bad argument");
     MIS_REQUIRE(c->finalized, MIS_ERR_NOT_INITIALIZED, "Qwen3-TTS model not finalized");
+    MIS_REQUIRE(q3dec_stream_pos(c->dec) < 0, MIS_ERR_INVALID_INPUT, "a streaming decode session is already open on this handle (end it first)");
     q3dec_stream_begin(c->dec, batch, max_frames, max_chunk_frames, !c->stream_exact, c->s);
     HIP_CHECK(hipStreamSynchronize(c->s));
     MIS_API_END
@@ -687,10 +688,11 @@ extern "C" mis_status mis_qwen3tts_generate(mis_qwen3tts* c, const int32_t* text
     std::deque<std::unique_ptr<Chunk>> chunks;
     DevBuf<float> wav_dev;
     hipEvent_t ev_lm = nullptr;
+    bool own_session = false;                       // the decode-stream session of the handle was opened by THIS call
     auto cleanup = [&]() {
         if (ev_lm) { (void)hipEventDestroy(ev_lm); ev_lm = nullptr; }
         for (auto& ch : chunks) if (ch->done) { (void)hipEventDestroy(ch->done); ch->done = nullptr; }
-        q3dec_stream_end(c->dec);
+        if (own_session) { q3dec_stream_end(c->dec); own_session = false; }      // never a session the host opened itself
     };
     auto emit_ready = [&](bool wait) {
         for (auto& ch : chunks) {
@@ -715,7 +717,10 @@ extern "C" mis_status mis_qwen3tts_generate(mis_qwen3tts* c, const int32_t* text
             HIP_CHECK(hipSetDevice(c->device));
             const int cap = params->max_frames;
             MIS_REQUIRE(cap >= 1, MIS_ERR_INVALID_INPUT, "max_frames must be positive");
+            MIS_REQUIRE(q3dec_stream_pos(c->dec) < 0, MIS_ERR_INVALID_INPUT,
+                        "generateStream needs the handle's decode-stream session, but the host has one open (mis_qwen3tts_decode_stream_end first)");
             q3dec_stream_begin(c->dec, batch, cap, std::min(chunk_frames, cap), !c->stream_exact, c->s_dec);
+            own_session = true;
             wav_dev.alloc((size_t)batch * std::min(chunk_frames, cap) * up);
             HIP_CHECK(hipEventCreateWithFlags(&ev_lm, hipEventDisableTiming));
             hook.chunk_frames = chunk_frames;

@@ -101,17 +101,27 @@ def stream_events(start_call, decode_event, cancel_flag=None):
 
     th = threading.Thread(target=run, daemon=True)
     th.start()
+    finished = False
     try:
         while True:
             ev = q.get()
             if isinstance(ev, tuple) and len(ev) == 3 and ev[0] is DONE:
+                finished = True                       # the C call has returned: nothing left to cancel
                 if ev[1] != _lib.MIS_OK:
                     raise AudioGenerationError(ev[1] if ev[1] >= 0 else 2, ev[2])
                 return
             yield ev
     finally:
-        flag.value = 1
-        th.join()
+        if finished:
+            th.join()
+        else:
+            # early close (GeneratorExit / an exception in the consumer): stop the worker.  A caller-supplied flag is only borrowed for
+            # that - its value is put back once the worker has returned, so a flag reused across calls does not cancel the next one
+            prev = flag.value
+            flag.value = 1
+            th.join()
+            if cancel_flag is not None:
+                flag.value = prev
 
 
 def decode_audio_event(row, kind, payload, n):

@@ -206,12 +206,16 @@ class WhisperModel:
         if eot is None or tsb is None:
             raise AudioGenerationError(3, "end-of-text / timestamp-begin ids unknown: attach a tokenizer (end_of_text_id, "
                                           "timestamp_begin_id) or set eot_id and timestamp_begin in STTGenerateParameters")
-        sup = gp.suppress_tokens if gp.suppress_tokens is not None else list(gc.get("suppress_tokens") or [])
-        bsup = gp.begin_suppress_tokens if gp.begin_suppress_tokens is not None else list(gc.get("begin_suppress_tokens") or [eot])
+        # `generationConfig?.suppressTokens ?? []`, `generationConfig?.beginSuppressTokens ?? [eot]` (:218-219): only a MISSING key takes the
+        # default - an explicit empty list in generation_config.json means "suppress nothing"
+        gsup, gbsup = gc.get("suppress_tokens"), gc.get("begin_suppress_tokens")
+        sup = gp.suppress_tokens if gp.suppress_tokens is not None else list(gsup if gsup is not None else [])
+        bsup = gp.begin_suppress_tokens if gp.begin_suppress_tokens is not None else list(gbsup if gbsup is not None else [eot])
         return replace(gp, eot_id=int(eot), timestamp_begin=int(tsb), suppress_tokens=sup, begin_suppress_tokens=bsup)
 
     def _prompt_language(self, prompt_ids, fallback):
-        """The language token sits at prompt index 1 for multilingual models (WhisperModel.swift:271-280)."""
+        """The language token sits at prompt index 1 for multilingual models (WhisperModel.swift:271-280: nil otherwise); `fallback` is the
+        caller's `detectedLanguage ?? generationParameters.language` (:81, :144)."""
         tk = self.tokenizer
         if tk is not None and getattr(tk, "is_multilingual", False) and len(prompt_ids) > 1:
             for code, tid in getattr(tk, "language_to_id", {}).items():
