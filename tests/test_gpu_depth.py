@@ -80,8 +80,11 @@ def test_orpheus_3b_full_depth_28_layers_and_error_growth():
     for L, g in growth.items():
         assert g["dev_rms"] <= FLOOR_FACTOR * g["floor_rms"] + 1e-3, (L, g)
         assert g["dev_max"] <= FLOOR_FACTOR * g["floor_max"] + 2e-3, (L, g)
-    # absolute bounds at the benchmarked depth (twice the values observed on MI355X, profiles/r03_parity_observed.json)
-    assert growth[28]["dev_rms"] <= 0.03 and growth[28]["dev_max"] <= 0.03, growth[28]
+    # absolute bounds at the benchmarked depth: twice the values observed on MI355X (profiles/r03_parity_observed.json: 28 layers
+    # rms 0.0327 / max 0.0148 against the oracle's own float64 floor of 0.0321 / 0.0129; 8 layers 0.0176 vs 0.0170; 2 layers 0.0062 vs
+    # 0.0058 - the device sits AT the floor at every depth, and the error grows like the floor does, ~ sqrt(layers))
+    assert growth[28]["dev_rms"] <= 0.066 and growth[28]["dev_max"] <= 0.03, growth[28]
+    assert growth[8]["dev_rms"] <= 0.036 and growth[2]["dev_rms"] <= 0.013, growth
 
 
 def test_batched_prefill_at_orpheus_3b_width_b32_m1024(monkeypatch):
