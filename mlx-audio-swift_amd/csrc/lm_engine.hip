@@ -74,12 +74,12 @@ struct mis_tts {
     DevBuf<SamplerScratch> samp_scratch;
     hipGraphExec_t g_prefill = nullptr, g_decode = nullptr;
     uint64_t graph_key = 0;
-    // Infinity-Cache prefetch branch of the step chain (see k_touch, lm_kernels.hip): a second stream forked / joined with events
-    hipStream_t pf_stream = nullptr;
-    std::vector<hipEvent_t> pf_events;
-    DevBuf<uint32_t> pf_sink;
-    int pf_mask = 0, pf_blocks = 256;
-    size_t pf_cap = 0;                               // experiment: at most this many bytes per touch (0 = the whole matrix)
+    // Infinity-Cache prefetch by extra blocks of the chain's own launches (touch_block, lm_kernels.hip).  KB of the upcoming matrix
+    // each carrier reads: [0] q|k|v GEMM -> o_proj(l)   [1] o_proj GEMM -> down(l)   [2] glue 1 -> down(l), continued
+    //                     [3] down GEMM -> q|k|v(l+1)   [4] glue 2 -> q|k|v(l+1), continued
+    //                     [5] decode attention (waves that run out of key tiles) -> o_proj(l), behind what [0] read
+    int pf_kb[6] = {0, 0, 0, 0, 0, 0};
+    int pf_blocks = 256;
     bool use_graph = true;
     bool borrowed_stream = false;
     int profiling = 0;
@@ -142,8 +142,6 @@ extern "C" void mis_tts_destroy(mis_tts* c) {
     if (c->g_prefill) (void)hipGraphExecDestroy(c->g_prefill);
     if (c->g_decode) (void)hipGraphExecDestroy(c->g_decode);
     if (c->stream && !c->borrowed_stream) (void)hipStreamDestroy(c->stream);
-    for (auto e : c->pf_events) (void)hipEventDestroy(e);
-    if (c->pf_stream) (void)hipStreamDestroy(c->pf_stream);
     delete c;
 }
 
@@ -549,15 +547,15 @@ static void lm_reset(mis_tts* c, int batch, int max_context) {
     c->S_qkv = std::min(8, choose_split(c->Nqkv / 16 / c->r_part, d / 32, c->ksb_part, "MIS_S_QKV", 8));   // attention prologue: <= 8 slabs
     c->S_o = choose_split(d / 16 / c->r_part, HD / 32, c->ksb_part, "MIS_S_O");
     c->S_down = choose_split(d / 16 / c->r_part, c->ff / 32, c->ksb_part, "MIS_S_DOWN");
-    {
-        const int mask = env_int("MIS_PREFETCH", 0), blocks = std::max(1, env_int("MIS_PREFETCH_BLOCKS", 256));
-        if (mask != c->pf_mask || blocks != c->pf_blocks) destroy_graphs(c);
-        c->pf_mask = mask; c->pf_blocks = blocks;
-        c->pf_cap = (size_t)std::max(0, env_int("MIS_PREFETCH_CAP_KB", 0)) * 1024;
-        if (mask && !c->pf_stream) {
-            HIP_CHECK(hipStreamCreateWithFlags(&c->pf_stream, hipStreamNonBlocking));
-            c->pf_sink.alloc(4);
-        }
+    {   // prefetch schedule (see pf_kb): MIS_PF="a,b,c,d,e" in KB, MIS_PF_BLOCKS touch blocks per carrier
+        int kb[6] = {0, 0, 0, 0, 0, 0};
+        if (const char* e = getenv("MIS_PF")) sscanf(e, "%d,%d,%d,%d,%d,%d", &kb[0], &kb[1], &kb[2], &kb[3], &kb[4], &kb[5]);
+        const int blocks = std::max(1, env_int("MIS_PF_BLOCKS", 256));
+        bool same = blocks == c->pf_blocks;
+        for (int i = 0; i < 6; ++i) same = same && kb[i] == c->pf_kb[i];
+        if (!same) destroy_graphs(c);
+        for (int i = 0; i < 6; ++i) c->pf_kb[i] = std::max(0, kb[i]);
+        c->pf_blocks = blocks;
     }
     size_t kv = (size_t)c->L * batch * c->Hkv * Smax * c->D;
     c->kcache.alloc(kv);
@@ -578,64 +576,62 @@ static void lm_reset(mis_tts* c, int batch, int max_context) {
 }
 
 // the step chain's five GEMMs: dense bf16 tiles or, for a quantised role, codes + scales (lm_qgemm.hip)
-static void gemm_qkv(mis_tts* c, size_t li, hipStream_t s) {
+static void gemm_qkv(mis_tts* c, size_t li, hipStream_t s, const GemmTouch* t = nullptr) {
     if (c->q_qkv.on) launch_gemm_skinny_q(c->q_qkv.bits, EPI_PARTIAL, c->r_part, c->ksb_part, c->q_qkv.q.p + c->q_qkv.q_layer * li, c->q_qkv.sb.p + c->q_qkv.sb_layer * li,
                                           c->x.p, c->qkv_part.p, c->Nqkv / 16, c->d / 64, c->S_qkv, c->Nqkv, c->Mpad, s);
     else launch_gemm_skinny(EPI_PARTIAL, c->r_part, c->ksb_part, c->wqkv.p + layer_qkv_elems(c) * li, c->x.p, c->qkv_part.p, c->Nqkv / 16, c->d / 32, c->S_qkv,
-                            c->Nqkv, c->Mpad, s);
+                            c->Nqkv, c->Mpad, s, nullptr, t);
 }
-static void gemm_o(mis_tts* c, size_t li, hipStream_t s) {
+static void gemm_o(mis_tts* c, size_t li, hipStream_t s, const GemmTouch* t = nullptr) {
     const int HD = c->H * c->D;
     if (c->q_o.on) launch_gemm_skinny_q(c->q_o.bits, EPI_PARTIAL, c->r_part, c->ksb_part, c->q_o.q.p + c->q_o.q_layer * li, c->q_o.sb.p + c->q_o.sb_layer * li,
                                         c->attn_out.p, c->part.p, c->d / 16, HD / 64, c->S_o, c->d, c->Mpad, s);
     else launch_gemm_skinny(EPI_PARTIAL, c->r_part, c->ksb_part, c->wo.p + layer_o_elems(c) * li, c->attn_out.p, c->part.p, c->d / 16, HD / 32, c->S_o, c->d,
-                            c->Mpad, s);
+                            c->Mpad, s, nullptr, t);
 }
 static void gemm_gate_up(mis_tts* c, size_t li, hipStream_t s) {
     if (c->q_gu.on) launch_gemm_skinny_q(c->q_gu.bits, EPI_SILU_MUL, 2, c->ksb_gu, c->q_gu.q.p + c->q_gu.q_layer * li, c->q_gu.sb.p + c->q_gu.sb_layer * li, c->x.p,
                                          c->act.p, 2 * c->ff / 16, c->d / 64, 1, c->ff, c->Mpad, s);
     else launch_gemm_skinny(EPI_SILU_MUL, 2, c->ksb_gu, c->wgu.p + layer_gu_elems(c) * li, c->x.p, c->act.p, 2 * c->ff / 16, c->d / 32, 1, c->ff, c->Mpad, s);
 }
-static void gemm_down(mis_tts* c, size_t li, hipStream_t s) {
+static void gemm_down(mis_tts* c, size_t li, hipStream_t s, const GemmTouch* t = nullptr) {
     if (c->q_down.on) launch_gemm_skinny_q(c->q_down.bits, EPI_PARTIAL, c->r_part, c->ksb_part, c->q_down.q.p + c->q_down.q_layer * li,
                                            c->q_down.sb.p + c->q_down.sb_layer * li, c->act.p, c->part.p, c->d / 16, c->ff / 64, c->S_down, c->d, c->Mpad, s);
     else launch_gemm_skinny(EPI_PARTIAL, c->r_part, c->ksb_part, c->wdown.p + layer_down_elems(c) * li, c->act.p, c->part.p, c->d / 16, c->ff / 32, c->S_down,
-                            c->d, c->Mpad, s);
+                            c->d, c->Mpad, s, nullptr, t);
 }
 
 // embed -> L x block.  Leaves x = final-norm(h) ready for lm_head.   (LlamaTTS.swift:335-345,303-310)
 // table/rows/ids: embedding source override (composite engines feed input embeddings as a [rows][d] table)
 static void enqueue_layers(mis_tts* c, const bf16_t* table = nullptr, int table_rows = 0, const int32_t* ids = nullptr) {
     hipStream_t s = c->stream;
-    const int d = c->d, HD = c->H * c->D, Mpad = c->Mpad;
+    const int d = c->d, Mpad = c->Mpad;
     const float eps = c->cfg.rms_norm_eps;
-    // prefetch branch: fork() makes the side stream depend on everything enqueued on `s` so far, so a touch forked right BEFORE
-    // launch X runs concurrently with X (and whatever follows); one join at the end of the chain.  Bits of MIS_PREFETCH:
-    //   1 o_proj weights during attention   2 down weights from glue 1 on   4 next layer's q|k|v weights during glue 2
-    //   8 this layer's cached K / V during the q|k|v GEMM   16 gate|up weights during o_proj
-    const int pf = (c->pf_stream && !c->q_qkv.on && !c->q_o.on && !c->q_gu.on && !c->q_down.on) ? c->pf_mask : 0;
-    size_t n_fork = 0;
-    auto capped = [&](size_t bytes) { return c->pf_cap ? std::min(bytes, c->pf_cap) : bytes; };
-    auto fork = [&]() {
-        if (n_fork == c->pf_events.size()) {
-            hipEvent_t e;
-            HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-            c->pf_events.push_back(e);
-        }
-        hipEvent_t e = c->pf_events[n_fork++];
-        HIP_CHECK(hipEventRecord(e, s));
-        HIP_CHECK(hipStreamWaitEvent(c->pf_stream, e, 0));
+    // prefetch carriers (pf_kb): slices of the dense bf16 matrices of this and the next layer
+    const bool pf = !c->q_qkv.on && !c->q_o.on && !c->q_down.on;
+    auto slice = [&](const bf16_t* base, size_t total_bytes, size_t off_kb, int kb) {
+        GemmTouch t;
+        const size_t off = std::min(total_bytes, off_kb * 1024);
+        t.ptr = reinterpret_cast<const char*>(base) + off;
+        t.bytes = pf ? std::min(total_bytes - off, (size_t)kb * 1024) : 0;
+        t.blocks = c->pf_blocks;
+        return t;
     };
     launch_embed_rmsnorm(table ? table : c->emb.p, ids ? ids : c->ids.p, c->active.p, c->pos_cur.p, c->pos_next.p, c->norms.p,
                          c->h.p, c->x.p, d, table ? table_rows : c->V, eps, c->batch, Mpad, s);
     for (int li = 0; li < c->L; ++li) {
         const size_t lkv = (size_t)c->batch * c->Hkv * c->Smax * c->D;
-        if (pf & 8) {
-            fork();
-            launch_touch_kv(c->kcache.p + lkv * li, c->vtcache.p + lkv * li, c->pos_cur.p, c->active.p, c->batch, c->Hkv, c->Smax, c->D,
-                            c->pf_sink.p, c->pf_stream);
-        }
-        gemm_qkv(c, li, s);
+        const bf16_t* w_o = c->wo.p + layer_o_elems(c) * li;
+        const bf16_t* w_down = c->wdown.p + layer_down_elems(c) * li;
+        const bf16_t* w_qkv_next = c->wqkv.p + layer_qkv_elems(c) * std::min(li + 1, c->L - 1);
+        const size_t b_o = layer_o_elems(c) * 2, b_down = layer_down_elems(c) * 2, b_qkv = li + 1 < c->L ? layer_qkv_elems(c) * 2 : 0;
+        const GemmTouch t_qkv = slice(w_o, b_o, 0, c->pf_kb[0]);
+        const GemmTouch t_o = slice(w_down, b_down, 0, c->pf_kb[1]);
+        const GemmTouch t_g1 = slice(w_down, b_down, c->pf_kb[1], c->pf_kb[2]);
+        const GemmTouch t_down = slice(w_qkv_next, b_qkv, 0, c->pf_kb[3]);
+        const GemmTouch t_g2 = slice(w_qkv_next, b_qkv, c->pf_kb[3], c->pf_kb[4]);
+        const GemmTouch t_att = slice(w_o, b_o, c->pf_kb[0], c->pf_kb[5]);
+        gemm_qkv(c, li, s, &t_qkv);
         AttnParams ap{};
         ap.qkv_part = c->qkv_part.p; ap.S = c->S_qkv; ap.Mpad = Mpad; ap.Nqkv = c->Nqkv;
         ap.kcache = c->kcache.p + lkv * li; ap.vtcache = c->vtcache.p + lkv * li;
@@ -649,39 +645,14 @@ static void enqueue_layers(mis_tts* c, const bf16_t* table = nullptr, int table_
             ap.qk_eps = c->cfg.rms_norm_eps;
         }
         ap.rope_in_dtype = c->cfg.rope_ops_in_dtype;
-        if (pf & 1) {
-            fork();
-            launch_touch(c->wo.p + layer_o_elems(c) * li, capped(layer_o_elems(c) * 2), c->pf_blocks, c->pf_sink.p, c->pf_stream);
-        }
+        ap.touch_ptr = t_att.bytes >= 16 ? t_att.ptr : nullptr; ap.touch_n16 = t_att.bytes / 16;
         launch_attn_decode(ap, c->batch, s);
-        if (pf & 16) {
-            fork();
-            launch_touch(c->wgu.p + layer_gu_elems(c) * li, capped(layer_gu_elems(c) * 2), c->pf_blocks, c->pf_sink.p, c->pf_stream);
-        }
-        gemm_o(c, li, s);
-        if (pf & 2) {
-            fork();
-            launch_touch(c->wdown.p + layer_down_elems(c) * li, capped(layer_down_elems(c) * 2), c->pf_blocks, c->pf_sink.p, c->pf_stream);
-        }
-        launch_reduce_residual_rmsnorm(c->part.p, c->S_o, Mpad, d, c->h.p, c->norms.p + (size_t)(2 * li + 1) * d, c->x.p, eps, s);
+        gemm_o(c, li, s, &t_o);
+        launch_reduce_residual_rmsnorm(c->part.p, c->S_o, Mpad, d, c->h.p, c->norms.p + (size_t)(2 * li + 1) * d, c->x.p, eps, s, nullptr, &t_g1);
         gemm_gate_up(c, li, s);
-        gemm_down(c, li, s);
-        if ((pf & 4) && li + 1 < c->L) {
-            fork();
-            launch_touch(c->wqkv.p + layer_qkv_elems(c) * (li + 1), capped(layer_qkv_elems(c) * 2), c->pf_blocks, c->pf_sink.p, c->pf_stream);
-        }
+        gemm_down(c, li, s, &t_down);
         const bf16_t* next_norm = c->norms.p + (size_t)(li + 1 < c->L ? 2 * (li + 1) : 2 * c->L) * d;
-        launch_reduce_residual_rmsnorm(c->part.p, c->S_down, Mpad, d, c->h.p, next_norm, c->x.p, eps, s);
-    }
-    if (n_fork) {                                   // join: the side branch ends inside this chain (required by stream capture)
-        if (n_fork == c->pf_events.size()) {
-            hipEvent_t e;
-            HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-            c->pf_events.push_back(e);
-        }
-        hipEvent_t e = c->pf_events[n_fork];
-        HIP_CHECK(hipEventRecord(e, c->pf_stream));
-        HIP_CHECK(hipStreamWaitEvent(s, e, 0));
+        launch_reduce_residual_rmsnorm(c->part.p, c->S_down, Mpad, d, c->h.p, next_norm, c->x.p, eps, s, nullptr, &t_g2);
     }
 }
 static void enqueue_lm_head(mis_tts* c, const bf16_t* head = nullptr) {

@@ -7,6 +7,9 @@ __host__ __device__ __forceinline__ size_t xpk_index(int m, int k, int MT) {
     return ((((size_t)(k >> 5) * MT + (m >> 4)) * 64) + (((k & 31) >> 3) << 4) + (m & 15)) * 8 + (k & 7);
 }
 
+// extra blocks of a step-chain launch that only read `bytes` of an upcoming weight matrix into the Infinity Cache (lm_kernels.hip)
+struct GemmTouch { const void* ptr = nullptr; size_t bytes = 0; int blocks = 0; };
+
 enum { EPI_PARTIAL = 0, EPI_BF16 = 1, EPI_SILU_MUL = 2, EPI_GELU_PACKED = 3, EPI_SILU_PACKED = 4 };
 
 void launch_convert_to_bf16(const void* src, int dtype, bf16_t* dst, size_t n, hipStream_t s);
@@ -24,24 +27,19 @@ void launch_embed_rmsnorm(const bf16_t* emb, const int32_t* ids, const uint8_t* 
                           hipStream_t s);
 // ln_bias == nullptr: RMSNorm; otherwise LayerNorm(weight wnorm, bias ln_bias)
 void launch_reduce_residual_rmsnorm(const float* slabs, int S, int Mpad, int N, bf16_t* h, const bf16_t* wnorm,
-                                    bf16_t* x, float eps, hipStream_t s, const bf16_t* ln_bias = nullptr);
+                                    bf16_t* x, float eps, hipStream_t s, const bf16_t* ln_bias = nullptr, const GemmTouch* touch = nullptr);
 // Wp packed [NT][KT][64][8]; X bf16 [Mpad][KT*32]; out: f32 slabs [S][Mpad][N_out] (EPI_PARTIAL) or bf16 [Mpad][N_out]
 // ksb = 1: each wave an independent item; ksb = 4: the block's 4 waves split the item's K range (LDS combine)
 // bias (bf16 [N], optional): added once (slab 0 / final epilogue).  EPI_GELU_PACKED: T(gelu(T(xW+b))) written
 // in the packed fragment layout (it is the next GEMM's X operand).  EPI_SILU_PACKED: h = T(xW+b), T(h * T(sigmoid(h))) packed.
 void launch_gemm_skinny(int epi, int R, int ksb, const bf16_t* Wp, const bf16_t* X, void* out, int NT, int KT, int S,
-                        int N_out, int Mpad, hipStream_t s, const bf16_t* bias = nullptr);
+                        int N_out, int Mpad, hipStream_t s, const bf16_t* bias = nullptr, const GemmTouch* touch = nullptr);
 
 // the same on MLX affine-quantised weights (lm_qgemm.hip): Qp packed codes, SB packed bf16 scale/bias pairs, G = K/64 scale groups
 void launch_gemm_skinny_q(int bits, int epi, int R, int ksb, const void* Qp, const bf16_t* SB, const bf16_t* X, void* out, int NT, int G,
                           int S, int N_out, int Mpad, hipStream_t s, const bf16_t* bias = nullptr);
 void launch_pack_qweight(int bits, const uint32_t* wq, const bf16_t* scales, const bf16_t* biases, void* qdst, bf16_t* sbdst, int N, int K,
                          int tile_stride, int tile_offset, hipStream_t s);
-
-// Infinity-Cache prefetch of data a later launch of the step chain will stream (side branch of the step graph)
-void launch_touch(const void* p, size_t bytes, int blocks, void* sink, hipStream_t s);
-void launch_touch_kv(const bf16_t* kc, const bf16_t* vt, const int* pos, const uint8_t* active, int batch, int Hkv, int Smax, int D, void* sink,
-                     hipStream_t s);
 
 // batched prefill (lm_prefill.hip): M = positions x rows
 enum { PF_F32 = 0, PF_RESID = 1, PF_SILU = 2 };
@@ -74,6 +72,11 @@ struct AttnParams {
     int H, Hkv, D, Smax;
     float scale;
     unsigned long long* dbg; // phase timestamps (MIS_ATTN_TIMING builds only), else null
+    // Infinity-Cache prefetch carried by the waves that run out of key tiles first (see touch_block, lm_kernels.hip): every block reads
+    // its 1 / gridsize share of touch_n16 16-byte units behind its tile loop, in the shadow of the partials barrier and the combine
+    const void* touch_ptr;
+    unsigned long long touch_n16;
+    unsigned int* touch_sink;   // scratch word (set by the launcher)
 };
 void launch_attn_decode(const AttnParams& p, int batch, hipStream_t s);
 

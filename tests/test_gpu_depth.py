@@ -46,7 +46,7 @@ def test_orpheus_3b_full_depth_28_layers_and_error_growth():
     gc.collect()
     o64 = _F64Oracle.__new__(_F64Oracle)
     o64.__dict__.update(o32.__dict__)                               # shares the float32 weight dict
-    B, T = 2, 48
+    B, T = 2, 40
     rng = np.random.default_rng(77)
     rows = [np.concatenate([[128259], rng.integers(0, 128000, T - 1)]).astype(np.int32) for _ in range(B)]
     growth = {}
@@ -58,18 +58,19 @@ def test_orpheus_3b_full_depth_28_layers_and_error_growth():
         del dev
         gc.collect()
         ref, ref64 = [], []
-        for o, dst in ((o32, ref), (o64, ref64)):
+        for o, dst, sel in ((o32, ref, rows), (o64, ref64, rows[:1])):      # the float64 floor on row 0 only (it re-casts every weight per call)
             o.cfg = cfg
-            o.reset(B)
-            dst.extend(x.numpy() for x in o.forward(rows))
+            o.reset(len(sel))
+            dst.extend(x.numpy() for x in o.forward(sel))
         e_max = e_rms = f_max = f_rms = 0.0
         last_rms = last_floor = 0.0
         for b in range(B):
             em, er, n_sure, agree = logits_errors(got[b], ref[b])
-            fm, fr, _, _ = logits_errors(ref64[b], ref[b])
-            e_max, e_rms, f_max, f_rms = max(e_max, em), max(e_rms, er), max(f_max, fm), max(f_rms, fr)
+            e_max, e_rms = max(e_max, em), max(e_rms, er)
             last_rms = max(last_rms, _rel_rms(got[b][-1], ref[b][-1]))
-            last_floor = max(last_floor, _rel_rms(ref64[b][-1], ref[b][-1]))
+            if b == 0:
+                f_max, f_rms, _, _ = logits_errors(ref64[0], ref[0])
+                last_floor = _rel_rms(ref64[0][-1], ref[0][-1])
             assert agree, (L, b)                                    # greedy token wherever the oracle's margin exceeds 2x the error
             assert n_sure > 0
         growth[L] = dict(dev_max=e_max, dev_rms=e_rms, floor_max=f_max, floor_rms=f_rms, dev_rms_last_pos=last_rms,
