@@ -556,6 +556,7 @@ static void lm_reset(mis_tts* c, int batch, int max_context) {
         if (!same) destroy_graphs(c);
         for (int i = 0; i < 6; ++i) c->pf_kb[i] = std::max(0, kb[i]);
         c->pf_blocks = blocks;
+        gemm_touch_prepare();
     }
     size_t kv = (size_t)c->L * batch * c->Hkv * Smax * c->D;
     c->kcache.alloc(kv);

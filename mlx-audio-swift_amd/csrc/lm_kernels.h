@@ -9,6 +9,7 @@ __host__ __device__ __forceinline__ size_t xpk_index(int m, int k, int MT) {
 
 // extra blocks of a step-chain launch that only read `bytes` of an upcoming weight matrix into the Infinity Cache (lm_kernels.hip)
 struct GemmTouch { const void* ptr = nullptr; size_t bytes = 0; int blocks = 0; };
+void gemm_touch_prepare();       // call once per device outside any stream capture before a launch carries touch blocks
 
 enum { EPI_PARTIAL = 0, EPI_BF16 = 1, EPI_SILU_MUL = 2, EPI_GELU_PACKED = 3, EPI_SILU_PACKED = 4 };
 

@@ -19,6 +19,7 @@
 #include <hip/hip_fp16.h>
 #include "common.h"
 #include <algorithm>
+#include <type_traits>
 #include "lm_kernels.h"
 
 
@@ -111,6 +112,7 @@ void launch_synth_fill_bf16(bf16_t* dst, size_t n, uint64_t key, float amp, int 
 // profiles/r03/ab1_glue4_and_graph_branch_prefetch.json).  Loads are non-temporal like the consumer's; the xor / conditional store
 // only keeps them alive.
 typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
+static unsigned int* touch_sink();
 __device__ __forceinline__ void touch_range(const u32x4_t* __restrict__ p, size_t n16, size_t first, size_t stride, u32x4_t& acc) {
     size_t i = first;
     for (; i + 7 * stride < n16; i += 8 * stride) {
@@ -128,6 +130,7 @@ __device__ __forceinline__ void touch_block(const void* __restrict__ ptr, unsign
     touch_range(reinterpret_cast<const u32x4_t*>(ptr), (size_t)n16, (size_t)tb * nth + threadIdx.x, (size_t)ntb * nth, acc);
     if (acc.x == 0x7fc00001u && acc.y == 0x7fc00002u && sink) sink[0] = acc.z ^ acc.w;      // scratch word nobody reads
 }
+void gemm_touch_prepare() { (void)touch_sink(); }       // allocate the scratch word now (hipMalloc is illegal inside a stream capture)
 static unsigned int* touch_sink() {                      // one scratch word per device, never freed
     static std::map<int, unsigned int*> sinks;
     int dev = 0;
@@ -1135,6 +1138,364 @@ __global__ void __launch_bounds__(512) k_attn_decode(AttnParams p) {
     ATT_STAMP(7);
 }
 
+// ---------------------------------------------------------------------------- decode attention, second schedule
+//
+// Same arithmetic and the same cache layout as k_attn_decode; what changes is WHEN things happen in a wave.  The phase stamps of the
+// kernel above (profiles/r01_v7_attn_phases.txt, context 431) show the stream and the math in series: a wave needs ~5 us to get its
+// 34 tile loads ACCEPTED (VMEM issue blocks while the CU's queue is full, i.e. for most of the 48 MB stream of the launch), only then
+// joins the two prologue barriers (~6 us: slab sum, RoPE, staging through LDS), and only then multiplies - ~7 us of tile math,
+// partials and combine with HBM idle.  Here
+//   * the prologue is WAVE-LOCAL: every wave sums the q slabs itself (7.5 KB from L2), redistributes them to the MFMA B layout through
+//     a private 2.5 KB LDS strip (no block barrier: LDS operations of one wave execute in order), and applies RoPE in registers - the
+//     rotation partner d +- 64 of a B-fragment element lives in the same lane.  The wave that owns the new key's tile does the same
+//     for k and v and patches them into its fragment registers; the cache append is issued last;
+//   * a wave requests ONE tile (16 loads), does its prologue while that tile is in flight, requests the next tile, and multiplies the
+//     first while the second streams: issue never blocks for long, and tile math overlaps the stream instead of following it;
+//   * the loads are asm statements with COUNTED waits (s_waitcnt vmcnt(16) = "everything but the youngest tile"): with compiler loads
+//     the wave-uniform guards around a tile request make every wait at the join conservative (vmcnt(0)), which serialises exactly
+//     the overlap wanted here.  Between the first asm load and the last counted wait the kernel issues no other vector memory
+//     operation (stores count in vmcnt on gfx9): prologue loads are asm too, the cache append and the output come after the loop.
+// Restrictions (launcher falls back to k_attn_decode otherwise): head_dim 128, self-attention with RoPE tables in float32 ops, no
+// q/k-norm, at most 4 qkv slabs, at most 32 key tiles (context <= 1024), GQA group <= 4.
+#define ATT2_MAX_J 4
+__device__ __forceinline__ void att2_issue_tile(const bf16_t* kt, const bf16_t* vt, unsigned voff, bf16x8_t (&ka)[2][4], bf16x8_t (&vb)[8]) {
+    // kt / vt: the tile's first K / V fragment (wave-uniform: SGPR base), voff = lane * 16; fragments are 1 KiB apart and the
+    // immediate offset reaches 3 KiB, hence a second base 4 KiB on.  (s_nop 4: an SGPR written by a VALU instruction - readfirstlane -
+    // needs five wait states before a VMEM instruction reads it, and hipcc pads nothing inside an asm statement.)
+    const bf16_t* kt1 = kt + 4 * 512;
+    const bf16_t* vt1 = vt + 4 * 512;
+#define ATT2_LD(DST, BASE, OFF) asm volatile("global_load_dwordx4 %0, %1, %2 offset:" #OFF : "=v"(DST) : "v"(voff), "s"(BASE))
+    asm volatile("s_nop 4\n\tglobal_load_dwordx4 %0, %1, %2" : "=v"(ka[0][0]) : "v"(voff), "s"(kt));
+    ATT2_LD(ka[0][1], kt, 1024); ATT2_LD(ka[0][2], kt, 2048); ATT2_LD(ka[0][3], kt, 3072);
+    asm volatile("s_nop 4\n\tglobal_load_dwordx4 %0, %1, %2" : "=v"(ka[1][0]) : "v"(voff), "s"(kt1));
+    ATT2_LD(ka[1][1], kt1, 1024); ATT2_LD(ka[1][2], kt1, 2048); ATT2_LD(ka[1][3], kt1, 3072);
+    asm volatile("s_nop 4\n\tglobal_load_dwordx4 %0, %1, %2" : "=v"(vb[0]) : "v"(voff), "s"(vt));
+    ATT2_LD(vb[1], vt, 1024); ATT2_LD(vb[2], vt, 2048); ATT2_LD(vb[3], vt, 3072);
+    asm volatile("s_nop 4\n\tglobal_load_dwordx4 %0, %1, %2" : "=v"(vb[4]) : "v"(voff), "s"(vt1));
+    ATT2_LD(vb[5], vt1, 1024); ATT2_LD(vb[6], vt1, 2048); ATT2_LD(vb[7], vt1, 3072);
+#undef ATT2_LD
+}
+// A counted wait is two statements: the s_waitcnt itself (register-free, so it can sit in either arm of a wave-uniform branch
+// without giving the register allocator 64 phi values to reconcile) and ONE binding statement behind the join that names every
+// register of the tile as read-write - no consumer is scheduled above it, and volatile asm statements keep their order.
+#define ATT2_VMCNT(CNT) asm volatile("s_waitcnt vmcnt(" #CNT ")" ::: "memory")
+#define ATT2_BIND_TILE(KA, VB)                                                                                               \
+    asm volatile("" : "+v"(KA[0][0]), "+v"(KA[0][1]), "+v"(KA[0][2]), "+v"(KA[0][3]), "+v"(KA[1][0]), "+v"(KA[1][1]), "+v"(KA[1][2]),  \
+                      "+v"(KA[1][3]), "+v"(VB[0]), "+v"(VB[1]), "+v"(VB[2]), "+v"(VB[3]), "+v"(VB[4]), "+v"(VB[5]), "+v"(VB[6]), "+v"(VB[7]))
+
+template <int NS>
+__global__ void __launch_bounds__(512) k_attn_decode2(AttnParams p) {
+    constexpr int D = 128;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int kvh = blockIdx.x, b = blockIdx.y;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int G = p.H / p.Hkv;
+    // LDS: per-wave strip of 7 x D floats (rows 0 .. G+1 <= 5: raw bf16-rounded q | k | v, row 6: the roped new key as bf16), then the
+    // combine buffers of k_attn_decode
+    float* strip = reinterpret_cast<float*>(smem) + (size_t)wave * 7 * D;
+    float* sm = reinterpret_cast<float*>(smem) + (size_t)ATT_WAVES * 7 * D;        // [W][16]
+    float* sl = sm + ATT_WAVES * 16;                                               // [W][16]
+    float* sO = sl + ATT_WAVES * 16;                                               // [W][G][D]
+
+    const uint32_t active_word = reinterpret_cast<const uint32_t*>(p.active)[b >> 2];
+    const unsigned char row_active = (unsigned char)((active_word >> (8 * (b & 3))) & 0xffu);
+    const int pos = p.pos[b];
+    if (!row_active) return;
+    const int kv_len = pos + 1;
+    const int n_tiles = (kv_len + 31) >> 5;
+    const int new_tile = pos >> 5;                                                  // = n_tiles - 1: the LAST tile of the wave that owns it
+    const bool owner = (new_tile & (ATT_WAVES - 1)) == wave;                        // wave-uniform
+    const int nj = wave < n_tiles ? (n_tiles - wave + ATT_WAVES - 1) / ATT_WAVES : 0;   // tiles wave, wave + 8, ... (<= ATT2_MAX_J)
+
+    bf16_t* kc = p.kcache + ((size_t)(b * p.Hkv + kvh) * p.Smax) * D;
+    bf16_t* vt = p.vtcache + ((size_t)(b * p.Hkv + kvh) * D) * p.Smax;
+    const unsigned voff = (unsigned)lane * 16u;
+    auto ktile = [&](int tile) { return kc + (size_t)tile * 32 * D; };              // 32 keys x D bf16 = 8 KiB per tile, K and V alike
+    auto vtile = [&](int tile) { return vt + (size_t)tile * 32 * D; };
+    const int h = lane & 15, g4 = lane >> 4;
+    const int pr = pos & 31;
+    const int prow = ((pr >> 3) << 2) | (pr & 3), phalf = (pr >> 2) & 1;            // the new key's place in its tile (cache tiling, header)
+    bf16_t* kro = reinterpret_cast<bf16_t*>(strip + 6 * D);
+
+    f32x4_t O[D / 16];
+    float m_run, l_run;
+
+    // Everything from the first tile request to the last tile's wait is ONE straight-line region per tile count (switch below): a
+    // register an asm load is still writing must not cross a control-flow join - at a join hipcc is free to move it with v_mov, which
+    // copies the stale value while the data lands in the old register (seen in the first version of this kernel; the audit is
+    // tools/isa_audit_attn2.py).  Hence no `if` in here: lane predicates are selects, LDS writes are unconditional (in-bounds by
+    // construction, redundant lanes write identical values), and the new key is patched at the wave's last tile, when nothing is in
+    // flight any more.
+    auto run = [&](auto tag) {
+        constexpr int NJ = decltype(tag)::value;
+        bf16x8_t kA[2][4], vA[8], kB[2][4], vB[8];
+        // ---- prologue requests (asm, in this order): the slabs of q | k | v in linear order, three 16-byte units per lane and slab
+        // (unit u = lane + 64 i holds elements 4u .. 4u+3 of the (G + 2) x D strip; units past it re-read unit 0), then the RoPE table
+        // entries this lane's B-fragment elements need: i = c 32 + (lane >> 4) 8 + e, c = 0, 1
+        const int n_unit = (G + 2) * D / 4;
+        f32x4_t sv[NS][3];
+    #pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            int u = lane + 64 * i;
+            u = u < n_unit ? u : 0;
+            const int e0 = u * 4, hh = e0 / D, d = e0 - hh * D;
+            const int col = hh < G ? (kvh * G + hh) * D + d : (hh == G ? p.H * D + kvh * D + d : p.H * D + p.Hkv * D + kvh * D + d);
+    #pragma unroll
+            for (int s = 0; s < NS; ++s) {
+                const float* sp = p.qkv_part + ((size_t)(s < p.S ? s : p.S - 1) * p.Mpad + b) * p.Nqkv + col;
+                asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(sv[s][i]) : "v"(sp));
+            }
+        }
+        f32x4_t rc[2][2], rs[2][2];
+        {
+            const float* ct = p.rope_cos + (size_t)pos * (D / 2) + g4 * 8;
+            const float* st = p.rope_sin + (size_t)pos * (D / 2) + g4 * 8;
+            asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(rc[0][0]) : "v"(ct));
+            asm volatile("global_load_dwordx4 %0, %1, off offset:16" : "=v"(rc[0][1]) : "v"(ct));
+            asm volatile("global_load_dwordx4 %0, %1, off offset:128" : "=v"(rc[1][0]) : "v"(ct));
+            asm volatile("global_load_dwordx4 %0, %1, off offset:144" : "=v"(rc[1][1]) : "v"(ct));
+            asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(rs[0][0]) : "v"(st));
+            asm volatile("global_load_dwordx4 %0, %1, off offset:16" : "=v"(rs[0][1]) : "v"(st));
+            asm volatile("global_load_dwordx4 %0, %1, off offset:128" : "=v"(rs[1][0]) : "v"(st));
+            asm volatile("global_load_dwordx4 %0, %1, off offset:144" : "=v"(rs[1][1]) : "v"(st));
+        }
+
+        if constexpr (NJ >= 1) att2_issue_tile(ktile(wave), vtile(wave), voff, kA, vA);
+        if constexpr (NJ >= 1) ATT2_VMCNT(16); else ATT2_VMCNT(0);
+        // (one binding statement; every register exactly once - a variable named twice is copied ahead of the statement, i.e. ahead
+        // of the wait)
+        asm volatile("" : "+v"(rc[0][0]), "+v"(rc[0][1]), "+v"(rc[1][0]), "+v"(rc[1][1]), "+v"(rs[0][0]), "+v"(rs[0][1]), "+v"(rs[1][0]), "+v"(rs[1][1]),
+                          "+v"(sv[0][0]), "+v"(sv[0][1]), "+v"(sv[0][2]));
+        if constexpr (NS > 1) asm volatile("" : "+v"(sv[NS > 1 ? 1 : 0][0]), "+v"(sv[NS > 1 ? 1 : 0][1]), "+v"(sv[NS > 1 ? 1 : 0][2]));
+        if constexpr (NS > 2) asm volatile("" : "+v"(sv[NS > 2 ? 2 : 0][0]), "+v"(sv[NS > 2 ? 2 : 0][1]), "+v"(sv[NS > 2 ? 2 : 0][2]));
+        if constexpr (NS > 3) asm volatile("" : "+v"(sv[NS > 3 ? 3 : 0][0]), "+v"(sv[NS > 3 ? 3 : 0][1]), "+v"(sv[NS > 3 ? 3 : 0][2]));
+        // slab sum (slab order 0, 1, ...: deterministic), T(), into the wave's strip in linear order (all 192 units are stored: rows
+        // past G + 1 hold don't-care copies of unit 0 - a lane predicate here would be a branch)
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            const int u = lane + 64 * i;
+            f32x4_t a = sv[0][i];
+#pragma unroll
+            for (int s = 1; s < NS; ++s) {
+                const f32x4_t t = a + sv[s][i];
+                a = s < p.S ? t : a;
+            }
+            *reinterpret_cast<f32x4_t*>(strip + 4 * u) = (f32x4_t){bf16_round_f32(a[0]), bf16_round_f32(a[1]), bf16_round_f32(a[2]), bf16_round_f32(a[3])};
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        // B-fragment view + RoPE in registers: lane (h, g4) holds row h, elements c 32 + g4 8 + e; pair (c, c + 2) is (i, i + D/2)
+        auto rope_row = [&](int row, bf16x8_t (&out)[4]) {
+            f32x4_t x[4][2];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                x[c][0] = *reinterpret_cast<const f32x4_t*>(strip + row * D + c * 32 + g4 * 8);
+                x[c][1] = *reinterpret_cast<const f32x4_t*>(strip + row * D + c * 32 + g4 * 8 + 4);
+            }
+#pragma unroll
+            for (int c = 0; c < 2; ++c)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const float x1 = x[c][e >> 2][e & 3], x2 = x[c + 2][e >> 2][e & 3];
+                    const float cs = rc[c][e >> 2][e & 3], sn = rs[c][e >> 2][e & 3];
+                    out[c][e] = (short)f32_to_bf16(x1 * cs - x2 * sn);
+                    out[c + 2][e] = (short)f32_to_bf16(x1 * sn + x2 * cs);
+                }
+        };
+        bf16x8_t qf[4];
+        rope_row(h < G ? h : G - 1, qf);
+        {   // (opaque pins: otherwise hipcc sinks the whole RoPE computation into an `if (h < G)` branch - a join in this region)
+            asm volatile("" : "+v"(qf[0]), "+v"(qf[1]), "+v"(qf[2]), "+v"(qf[3]));
+            const bf16x8_t zero = (bf16x8_t){0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+            for (int c = 0; c < 4; ++c) qf[c] = h < G ? qf[c] : zero;
+        }
+        {   // the roped new key, parked as bf16 in row 6 (every wave does it: a branch here would be a join; 16 lanes write each value)
+            bf16x8_t kn[4];
+            rope_row(G, kn);
+#pragma unroll
+            for (int c = 0; c < 4; ++c) *reinterpret_cast<bf16x8_t*>(kro + c * 32 + g4 * 8) = kn[c];
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+
+        // (accumulators start here, not ahead of the prologue: 32 registers less while the slabs, the tables and tile A are in flight)
+#pragma unroll
+        for (int dt = 0; dt < D / 16; ++dt) O[dt] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+        m_run = -INFINITY; l_run = 0.0f;
+        auto process = [&](int tile, const bf16x8_t (&ka)[2][4], const bf16x8_t (&vb)[8]) {      // identical math to k_attn_decode
+            const int base = tile * 32;
+            f32x4_t S0 = (f32x4_t){0.f, 0.f, 0.f, 0.f}, S1 = S0;
+#pragma unroll
+            for (int c = 0; c < D / 32; ++c) {
+                S0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ka[0][c], qf[c], S0, 0, 0, 0);
+                S1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ka[1][c], qf[c], S1, 0, 0, 0);
+            }
+            float sc[8];
+            float mx = -INFINITY;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                float v = (e < 4 ? S0[e] : S1[e - 4]) * p.scale;
+                v = (base + g4 * 8 + e < kv_len) ? v : -INFINITY;
+                sc[e] = v;
+                mx = fmaxf(mx, v);
+            }
+            mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+            float m_new = fmaxf(m_run, mx);
+            float alpha = __expf(m_run - m_new);
+            float psum = 0.0f;
+            bf16x8_t ph, pl;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                float pe = __expf(sc[e] - m_new);
+                psum += pe;
+                bf16_t hi = f32_to_bf16(pe);
+                bf16_t lo = f32_to_bf16(pe - bf16_to_f32(hi));
+                ph[e] = (short)hi;
+                pl[e] = (short)lo;
+            }
+            l_run = l_run * alpha + psum;
+            m_run = m_new;
+            float ar[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) ar[r] = __shfl(alpha, g4 * 4 + r, 64);
+#pragma unroll
+            for (int dt = 0; dt < D / 16; ++dt) {
+                f32x4_t o = O[dt];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) o[r] *= ar[r];
+                o = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ph, vb[dt], o, 0, 0, 0);
+                o = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pl, vb[dt], o, 0, 0, 0);
+                O[dt] = o;
+            }
+        };
+        // the wave's LAST tile: nothing is in flight behind it.  The owner of the new key patches it into the fragments (K row `prow`
+        // of half `phalf`, V^T column pr) and appends it to the cache (fire and forget: nothing reads it back in this launch)
+        auto last = [&](int tile, bf16x8_t (&ka)[2][4], bf16x8_t (&vb)[8]) {
+            if (owner) {
+                if ((lane & 15) == prow) {
+                    bf16x8_t* dst = reinterpret_cast<bf16x8_t*>(kc) + ((size_t)new_tile * 2 + phalf) * (D / 32) * 64 + lane;
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) {
+                        const bf16x8_t kn = *reinterpret_cast<const bf16x8_t*>(kro + c * 32 + g4 * 8);
+                        if (phalf) ka[1][c] = kn; else ka[0][c] = kn;
+                        dst[c * 64] = kn;
+                    }
+                }
+                if ((lane >> 4) == (pr >> 3)) {
+#pragma unroll
+                    for (int dt = 0; dt < 8; ++dt) {
+                        const bf16_t vn = f32_to_bf16(strip[(G + 1) * D + dt * 16 + (lane & 15)]);
+#pragma unroll
+                        for (int e = 0; e < 8; ++e)
+                            if (e == (pr & 7)) vb[dt][e] = (short)vn;
+                        vt[(((size_t)new_tile * (D / 16) + dt) * 64 + lane) * 8 + (pr & 7)] = vn;
+                    }
+                }
+            }
+            process(tile, ka, vb);
+        };
+        // buffers A, B, A, B: while tile j is multiplied tile j + 1 is in flight, tile j + 2 is requested once its buffer is free.
+        // (sched barriers: left alone the scheduler starts requesting tile j + 2 while the P.V MFMAs of tile j still read the buffer -
+        // the asm outputs then need 64 NEW registers next to the old buffer and the tile in flight, and the kernel spills.)
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (NJ >= 2) att2_issue_tile(ktile(wave + ATT_WAVES), vtile(wave + ATT_WAVES), voff, kB, vB);
+        if constexpr (NJ >= 1) {
+            if constexpr (NJ >= 2) ATT2_VMCNT(16); else ATT2_VMCNT(0);
+            ATT2_BIND_TILE(kA, vA);
+            __builtin_amdgcn_sched_barrier(0);
+            if constexpr (NJ == 1) last(wave, kA, vA); else process(wave, kA, vA);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if constexpr (NJ >= 2) {
+            if constexpr (NJ >= 3) att2_issue_tile(ktile(wave + 2 * ATT_WAVES), vtile(wave + 2 * ATT_WAVES), voff, kA, vA);
+            if constexpr (NJ >= 3) ATT2_VMCNT(16); else ATT2_VMCNT(0);
+            ATT2_BIND_TILE(kB, vB);
+            __builtin_amdgcn_sched_barrier(0);
+            if constexpr (NJ == 2) last(wave + ATT_WAVES, kB, vB); else process(wave + ATT_WAVES, kB, vB);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if constexpr (NJ >= 3) {
+            if constexpr (NJ >= 4) att2_issue_tile(ktile(wave + 3 * ATT_WAVES), vtile(wave + 3 * ATT_WAVES), voff, kB, vB);
+            if constexpr (NJ >= 4) ATT2_VMCNT(16); else ATT2_VMCNT(0);
+            ATT2_BIND_TILE(kA, vA);
+            __builtin_amdgcn_sched_barrier(0);
+            if constexpr (NJ == 3) last(wave + 2 * ATT_WAVES, kA, vA); else process(wave + 2 * ATT_WAVES, kA, vA);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if constexpr (NJ >= 4) {
+            ATT2_VMCNT(0);
+            ATT2_BIND_TILE(kB, vB);
+            __builtin_amdgcn_sched_barrier(0);
+            last(wave + 3 * ATT_WAVES, kB, vB);
+        }
+    };
+    switch (nj) {
+        case 1: run(std::integral_constant<int, 1>{}); break;
+        case 2: run(std::integral_constant<int, 2>{}); break;
+        case 3: run(std::integral_constant<int, 3>{}); break;
+        case 4: run(std::integral_constant<int, 4>{}); break;
+        default: run(std::integral_constant<int, 0>{}); break;      // a wave without a tile (context < 256): waits for its prologue loads
+    }
+    // ---- prefetch for a later launch (see k_attn_decode)
+    constexpr int ATT_TOUCH = 24;
+    u32x4_t tv[ATT_TOUCH];
+    const bool touching = p.touch_n16 != 0 && wave + ATT_WAVES >= n_tiles;
+    if (touching) {
+        const int first = n_tiles > ATT_WAVES ? n_tiles - ATT_WAVES : 0;
+        const unsigned long long nblk = (unsigned long long)gridDim.x * gridDim.y, bid = (unsigned long long)blockIdx.y * gridDim.x + blockIdx.x;
+        const unsigned long long per = (p.touch_n16 + nblk - 1) / nblk;
+        const unsigned long long lo16 = bid * per, hi16 = lo16 + per < p.touch_n16 ? lo16 + per : p.touch_n16;
+        const unsigned long long stride = (unsigned long long)(ATT_WAVES - first) * 64;
+        const u32x4_t* tp = reinterpret_cast<const u32x4_t*>(p.touch_ptr);
+#pragma unroll
+        for (int j = 0; j < ATT_TOUCH; ++j) {
+            unsigned long long i = lo16 + (unsigned long long)(wave - first) * 64 + lane + (unsigned long long)j * stride;
+            i = i < hi16 ? i : (hi16 ? hi16 - 1 : 0);
+            tv[j] = __builtin_nontemporal_load(tp + i);
+        }
+    }
+    // ---- per-wave partials -> LDS, combine (k_attn_decode)
+    l_run += __shfl_xor(l_run, 16, 64);
+    l_run += __shfl_xor(l_run, 32, 64);
+    if (g4 == 0) { sm[wave * 16 + h] = m_run; sl[wave * 16 + h] = l_run; }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        int head = g4 * 4 + r;
+        if (head < G) {
+#pragma unroll
+            for (int dt = 0; dt < D / 16; ++dt) sO[((size_t)wave * G + head) * D + dt * 16 + h] = O[dt][r];
+        }
+    }
+    __syncthreads();
+    for (int idx = tid; idx < G * D; idx += 512) {
+        int head = idx / D, d = idx - head * D;
+        float M = -INFINITY;
+#pragma unroll
+        for (int w = 0; w < ATT_WAVES; ++w) M = fmaxf(M, sm[w * 16 + head]);
+        float num = 0.0f, den = 0.0f;
+#pragma unroll
+        for (int w = 0; w < ATT_WAVES; ++w) {
+            float f = __expf(sm[w * 16 + head] - M);
+            num += f * sO[((size_t)w * G + head) * D + d];
+            den += f * sl[w * 16 + head];
+        }
+        const bf16_t ov = f32_to_bf16(num / den);
+        if (p.out_ld) p.out[(size_t)b * p.out_ld + (kvh * G + head) * D + d] = ov;
+        else p.out[xpk_index(b, (kvh * G + head) * D + d, p.Mpad >> 4)] = ov;
+    }
+    if (touching) {
+        u32x4_t acc = tv[0];
+#pragma unroll
+        for (int j = 1; j < ATT_TOUCH; ++j) acc ^= tv[j];
+        if (acc.x == 0x7fc00001u && acc.y == 0x7fc00002u && p.touch_sink) p.touch_sink[0] = acc.z ^ acc.w;
+    }
+}
+static size_t attn2_smem_bytes(int G) { return ((size_t)ATT_WAVES * 7 * 128 + 2 * ATT_WAVES * 16 + (size_t)ATT_WAVES * G * 128) * 4; }
+
 #ifdef MIS_ATTN_TIMING
 #include <string.h>
 static unsigned long long* g_attn_dbg = nullptr;
@@ -1173,6 +1534,21 @@ void launch_attn_decode(const AttnParams& p, int batch, hipStream_t s) {
     AttnParams pt = p;
     if (!pt.touch_ptr || pt.touch_n16 == 0) { pt.touch_ptr = nullptr; pt.touch_n16 = 0; pt.touch_sink = nullptr; }
     else pt.touch_sink = touch_sink();
+    {   // second schedule (k_attn_decode2) where it applies; MIS_ATTN_V2=0 keeps the first one (A/B, parity tests: read per launch)
+        const char* e = getenv("MIS_ATTN_V2");
+        const bool v2 = !(e && atoi(e) == 0);
+        if (v2 && p.D == 128 && !p.cross && p.rope_cos && !p.rope_in_dtype && !p.qnorm_w && p.S <= 4 && G <= 4 && p.Smax <= 32 * ATT_WAVES * ATT2_MAX_J &&
+            p.Smax % 32 == 0 && ((uintptr_t)p.qkv_part & 15) == 0 && p.Nqkv % 4 == 0) {
+            const size_t sm2 = attn2_smem_bytes(G);
+            switch (p.S) {
+                case 1: hipLaunchKernelGGL((k_attn_decode2<1>), grid, block, sm2, s, pt); break;
+                case 2: hipLaunchKernelGGL((k_attn_decode2<2>), grid, block, sm2, s, pt); break;
+                case 3: hipLaunchKernelGGL((k_attn_decode2<3>), grid, block, sm2, s, pt); break;
+                default: hipLaunchKernelGGL((k_attn_decode2<4>), grid, block, sm2, s, pt); break;
+            }
+            return;
+        }
+    }
 #ifdef MIS_ATTN_TIMING
     // one 16-stamp slot per enqueued launch (graph replays rewrite their slot); dumped by mis_debug_attn_timing()
     pt.dbg = g_attn_dbg ? g_attn_dbg + (size_t)(g_attn_slot++ % 4096) * 16 : nullptr;   // mis_debug_attn_timing_init() first

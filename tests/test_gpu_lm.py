@@ -185,3 +185,45 @@ def test_batched_prefill_matches_oracle_and_the_position_by_position_path(ocfg, 
     worst = [max(m_all), max(e_all), max(d_all)]
     record(f"batched_prefill_{ocfg.hidden_size}", logits_max_rel=worst[0], logits_rms_rel_worst=worst[1], logits_rms_rel_mean=float(np.mean(e_all)),
            rms_vs_sequential_worst=worst[2], rms_vs_sequential_mean=float(np.mean(d_all)), tol_max=0.04, tol_rms_mean=0.008, tol_rms_worst=0.016)
+
+
+def test_second_attention_schedule_matches_the_first_and_the_oracle(monkeypatch):
+    """k_attn_decode2 (wave-local prologue, counted waits, one tile in flight per wave while the previous one is multiplied) against
+    k_attn_decode (MIS_ATTN_V2=0, read per launch) and the oracle: the same rounding points, so the logits agree to within the bf16
+    noise of a different instruction selection (bit-identical in practice: recorded), at contexts that give the waves 0 / 1 / 2 / 3
+    tiles each (<= 256, 257..512, > 512 keys) and with the new key landing in every wave's last tile."""
+    from gpu_util import logits_errors, record
+    cfg = ollama.LlamaConfig(**{**ollama.TINY.__dict__, "num_hidden_layers": 2})
+    W, oracle, dev = lm_pair(cfg)
+    rng = np.random.default_rng(31)
+    lens = [620, 300, 41]
+    rows = [rng.integers(0, cfg.vocab_size, n).astype(np.int32) for n in lens]
+    keep = sorted({0, 1, 30, 31, 32, 33, 63, 64, 255, 256, 257, 287, 288, 299, 511, 512, 513, 543, 544, 600, 619})
+    out = {}
+    for v2 in ("0", "1"):
+        monkeypatch.setenv("MIS_ATTN_V2", v2)
+        dev.lm_reset(len(rows), 640)
+        got = {}
+        for t in range(max(lens)):
+            ids = np.asarray([r[t] if t < len(r) else 0 for r in rows], np.int32)
+            act = np.asarray([1 if t < len(r) else 0 for r in rows], np.uint8)
+            if t in keep:
+                lg = dev.lm_forward(ids, act)
+                for b in range(len(rows)):
+                    if act[b]:
+                        got[(b, t)] = lg[b].copy()
+            else:
+                dev.lm_forward(ids, act, want_logits=False)
+        out[v2] = got
+    oracle.reset(len(rows))
+    checks = [[t for t in keep if t < n] for n in lens]
+    ref = oracle.forward(rows, logit_positions=checks)
+    same = all(np.array_equal(out["0"][k], out["1"][k]) for k in out["0"])
+    worst = 0.0
+    for b in range(len(rows)):
+        d1 = np.stack([out["1"][(b, t)] for t in checks[b]]); d0 = np.stack([out["0"][(b, t)] for t in checks[b]])
+        e_max, e_rms, _, agree = logits_errors(d1, ref[b].numpy())
+        assert e_max <= TOL_MAX and e_rms <= TOL_RMS and agree, (b, e_max, e_rms)
+        worst = max(worst, float(np.abs(d1 - d0).max() / np.abs(d0).max()))
+    record("attention_second_schedule", bit_identical_to_first=bool(same), max_rel_vs_first=worst)
+    assert worst <= 0.01

@@ -1,6 +1,7 @@
 """A/B of decode-step variants on the headline workload: runs bench.py (2 timed generates, no cpu baseline) once per named
 environment setting and prints / writes value, decode ms, step ms and the per-kernel probe timings of each.
-Usage: python tools/ab_decode.py out.json name1:VAR=val,VAR2=val name2:... (the name "base" with no variables is always run first)"""
+Usage: python tools/ab_decode.py out.json name1:VAR=val+VAR2=val name2:... (variables separated by "+": values may hold commas;
+the name "base" with no variables is always run first)"""
 import json
 import os
 import subprocess
@@ -11,7 +12,7 @@ out_path = sys.argv[1]
 variants = [("base", {})]
 for spec in sys.argv[2:]:
     name, _, rest = spec.partition(":")
-    env = dict(kv.split("=", 1) for kv in rest.split(",") if kv)
+    env = dict(kv.split("=", 1) for kv in rest.split("+") if kv)
     variants.append((name, env))
 rows = []
 for name, env in variants:
