@@ -231,6 +231,22 @@ def main():
     audio_s = float(alll.sum()) / 24000.0 * args.steps
     value = audio_s / elapsed
     timing = lm.last_timing()
+    # The timed region above is frame-constrained (random weights must emit valid SNAC frames for there to be audio to count): its
+    # sampler sees a 4096-id range per step (k_samp_narrow).  A real checkpoint decodes UNCONSTRAINED - the whole 156 940-id
+    # vocabulary goes through the sampler every step (k_samp_cluster) - so one more generate of the same shape is run that way and
+    # its decode time per step is reported next to the constrained one (its tokens are not frames: no audio is counted from it).
+    unconstrained = None
+    if rank == 0:
+        gpu_ = mas.GenerateParameters(max_tokens=NEW_TOKENS, temperature=0.6, top_p=0.8, repetition_penalty=1.3,
+                                      repetition_context_size=20, seed=2024, frame_constrained=False, row_offset=row0)
+        gpu_c = gpu_.to_c()
+        for _ in range(2):                                     # first call captures the step graph of this sampler path
+            st = L.mis_tts_generate_device(lm._h, flat.ctypes.data, lens.ctypes.data, ROWS_PER_GPU, C.byref(gpu_c), None,
+                                           pcm.data_ptr(), n_samples, plens, ntok)
+            if st != 0:
+                raise RuntimeError(mas._lib.last_error())
+        tu = lm.last_timing()
+        unconstrained = {"decode_ms": tu["decode_ms"], "step_ms": tu["step_ms_avg"], "tokens_per_row_min": int(min(ntok))}
 
     result = None
     if rank == 0:
@@ -284,7 +300,13 @@ def main():
                        "new_tokens": NEW_TOKENS, "parallelism": f"utterance-dp{world}", "sampler": "T0.6 top-p0.8 rep1.3"},
             "value_per_gpu": value / world,
             "phases_ms": {"prefill": timing["prefill_ms"], "decode": timing["decode_ms"], "codec": timing["codec_ms"],
-                          "all_gather_rccl": (float(np.mean(gather_ms[-args.steps:])) if gather_ms else 0.0)},
+                          "all_gather_rccl": (float(np.mean(gather_ms[-args.steps:])) if gather_ms else 0.0),
+                          "decode_unconstrained": unconstrained["decode_ms"] if unconstrained else None},
+            "sampler": {"timed_region": "frame-constrained: 4096-id range per step, k_samp_narrow (one launch)",
+                        "unconstrained_step_ms": unconstrained["step_ms"] if unconstrained else None,
+                        "constrained_step_ms": timing["step_ms_avg"],
+                        "unconstrained": "same generate, whole 156 940-id vocabulary per step, k_samp_cluster (one launch); "
+                                         "min tokens per row %s" % (unconstrained["tokens_per_row_min"] if unconstrained else None)},
             "roofline": roofline, "cpu_baseline": cpu,
         }
         print(json.dumps(result))

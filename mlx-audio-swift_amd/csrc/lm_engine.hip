@@ -74,12 +74,6 @@ struct mis_tts {
     DevBuf<SamplerScratch> samp_scratch;
     hipGraphExec_t g_prefill = nullptr, g_decode = nullptr;
     uint64_t graph_key = 0;
-    // Infinity-Cache prefetch by extra blocks of the chain's own launches (touch_block, lm_kernels.hip).  KB of the upcoming matrix
-    // each carrier reads: [0] q|k|v GEMM -> o_proj(l)   [1] o_proj GEMM -> down(l)   [2] glue 1 -> down(l), continued
-    //                     [3] down GEMM -> q|k|v(l+1)   [4] glue 2 -> q|k|v(l+1), continued
-    //                     [5] decode attention (waves that run out of key tiles) -> o_proj(l), behind what [0] read
-    int pf_kb[6] = {0, 0, 0, 0, 0, 0};
-    int pf_blocks = 256;
     bool use_graph = true;
     bool borrowed_stream = false;
     int profiling = 0;
@@ -547,17 +541,6 @@ static void lm_reset(mis_tts* c, int batch, int max_context) {
     c->S_qkv = std::min(8, choose_split(c->Nqkv / 16 / c->r_part, d / 32, c->ksb_part, "MIS_S_QKV", 8));   // attention prologue: <= 8 slabs
     c->S_o = choose_split(d / 16 / c->r_part, HD / 32, c->ksb_part, "MIS_S_O");
     c->S_down = choose_split(d / 16 / c->r_part, c->ff / 32, c->ksb_part, "MIS_S_DOWN");
-    {   // prefetch schedule (see pf_kb): MIS_PF="a,b,c,d,e" in KB, MIS_PF_BLOCKS touch blocks per carrier
-        int kb[6] = {0, 0, 0, 0, 0, 0};
-        if (const char* e = getenv("MIS_PF")) sscanf(e, "%d,%d,%d,%d,%d,%d", &kb[0], &kb[1], &kb[2], &kb[3], &kb[4], &kb[5]);
-        const int blocks = std::max(1, env_int("MIS_PF_BLOCKS", 256));
-        bool same = blocks == c->pf_blocks;
-        for (int i = 0; i < 6; ++i) same = same && kb[i] == c->pf_kb[i];
-        if (!same) destroy_graphs(c);
-        for (int i = 0; i < 6; ++i) c->pf_kb[i] = std::max(0, kb[i]);
-        c->pf_blocks = blocks;
-        gemm_touch_prepare();
-    }
     size_t kv = (size_t)c->L * batch * c->Hkv * Smax * c->D;
     c->kcache.alloc(kv);
     c->vtcache.alloc(kv);
@@ -577,29 +560,29 @@ static void lm_reset(mis_tts* c, int batch, int max_context) {
 }
 
 // the step chain's five GEMMs: dense bf16 tiles or, for a quantised role, codes + scales (lm_qgemm.hip)
-static void gemm_qkv(mis_tts* c, size_t li, hipStream_t s, const GemmTouch* t = nullptr) {
+static void gemm_qkv(mis_tts* c, size_t li, hipStream_t s) {
     if (c->q_qkv.on) launch_gemm_skinny_q(c->q_qkv.bits, EPI_PARTIAL, c->r_part, c->ksb_part, c->q_qkv.q.p + c->q_qkv.q_layer * li, c->q_qkv.sb.p + c->q_qkv.sb_layer * li,
                                           c->x.p, c->qkv_part.p, c->Nqkv / 16, c->d / 64, c->S_qkv, c->Nqkv, c->Mpad, s);
     else launch_gemm_skinny(EPI_PARTIAL, c->r_part, c->ksb_part, c->wqkv.p + layer_qkv_elems(c) * li, c->x.p, c->qkv_part.p, c->Nqkv / 16, c->d / 32, c->S_qkv,
-                            c->Nqkv, c->Mpad, s, nullptr, t);
+                            c->Nqkv, c->Mpad, s);
 }
-static void gemm_o(mis_tts* c, size_t li, hipStream_t s, const GemmTouch* t = nullptr) {
+static void gemm_o(mis_tts* c, size_t li, hipStream_t s) {
     const int HD = c->H * c->D;
     if (c->q_o.on) launch_gemm_skinny_q(c->q_o.bits, EPI_PARTIAL, c->r_part, c->ksb_part, c->q_o.q.p + c->q_o.q_layer * li, c->q_o.sb.p + c->q_o.sb_layer * li,
                                         c->attn_out.p, c->part.p, c->d / 16, HD / 64, c->S_o, c->d, c->Mpad, s);
     else launch_gemm_skinny(EPI_PARTIAL, c->r_part, c->ksb_part, c->wo.p + layer_o_elems(c) * li, c->attn_out.p, c->part.p, c->d / 16, HD / 32, c->S_o, c->d,
-                            c->Mpad, s, nullptr, t);
+                            c->Mpad, s);
 }
 static void gemm_gate_up(mis_tts* c, size_t li, hipStream_t s) {
     if (c->q_gu.on) launch_gemm_skinny_q(c->q_gu.bits, EPI_SILU_MUL, 2, c->ksb_gu, c->q_gu.q.p + c->q_gu.q_layer * li, c->q_gu.sb.p + c->q_gu.sb_layer * li, c->x.p,
                                          c->act.p, 2 * c->ff / 16, c->d / 64, 1, c->ff, c->Mpad, s);
     else launch_gemm_skinny(EPI_SILU_MUL, 2, c->ksb_gu, c->wgu.p + layer_gu_elems(c) * li, c->x.p, c->act.p, 2 * c->ff / 16, c->d / 32, 1, c->ff, c->Mpad, s);
 }
-static void gemm_down(mis_tts* c, size_t li, hipStream_t s, const GemmTouch* t = nullptr) {
+static void gemm_down(mis_tts* c, size_t li, hipStream_t s) {
     if (c->q_down.on) launch_gemm_skinny_q(c->q_down.bits, EPI_PARTIAL, c->r_part, c->ksb_part, c->q_down.q.p + c->q_down.q_layer * li,
                                            c->q_down.sb.p + c->q_down.sb_layer * li, c->act.p, c->part.p, c->d / 16, c->ff / 64, c->S_down, c->d, c->Mpad, s);
     else launch_gemm_skinny(EPI_PARTIAL, c->r_part, c->ksb_part, c->wdown.p + layer_down_elems(c) * li, c->act.p, c->part.p, c->d / 16, c->ff / 32, c->S_down,
-                            c->d, c->Mpad, s, nullptr, t);
+                            c->d, c->Mpad, s);
 }
 
 // embed -> L x block.  Leaves x = final-norm(h) ready for lm_head.   (LlamaTTS.swift:335-345,303-310)
@@ -608,31 +591,11 @@ static void enqueue_layers(mis_tts* c, const bf16_t* table = nullptr, int table_
     hipStream_t s = c->stream;
     const int d = c->d, Mpad = c->Mpad;
     const float eps = c->cfg.rms_norm_eps;
-    // prefetch carriers (pf_kb): slices of the dense bf16 matrices of this and the next layer
-    const bool pf = !c->q_qkv.on && !c->q_o.on && !c->q_down.on;
-    auto slice = [&](const bf16_t* base, size_t total_bytes, size_t off_kb, int kb) {
-        GemmTouch t;
-        const size_t off = std::min(total_bytes, off_kb * 1024);
-        t.ptr = reinterpret_cast<const char*>(base) + off;
-        t.bytes = pf ? std::min(total_bytes - off, (size_t)kb * 1024) : 0;
-        t.blocks = c->pf_blocks;
-        return t;
-    };
     launch_embed_rmsnorm(table ? table : c->emb.p, ids ? ids : c->ids.p, c->active.p, c->pos_cur.p, c->pos_next.p, c->norms.p,
                          c->h.p, c->x.p, d, table ? table_rows : c->V, eps, c->batch, Mpad, s);
     for (int li = 0; li < c->L; ++li) {
         const size_t lkv = (size_t)c->batch * c->Hkv * c->Smax * c->D;
-        const bf16_t* w_o = c->wo.p + layer_o_elems(c) * li;
-        const bf16_t* w_down = c->wdown.p + layer_down_elems(c) * li;
-        const bf16_t* w_qkv_next = c->wqkv.p + layer_qkv_elems(c) * std::min(li + 1, c->L - 1);
-        const size_t b_o = layer_o_elems(c) * 2, b_down = layer_down_elems(c) * 2, b_qkv = li + 1 < c->L ? layer_qkv_elems(c) * 2 : 0;
-        const GemmTouch t_qkv = slice(w_o, b_o, 0, c->pf_kb[0]);
-        const GemmTouch t_o = slice(w_down, b_down, 0, c->pf_kb[1]);
-        const GemmTouch t_g1 = slice(w_down, b_down, c->pf_kb[1], c->pf_kb[2]);
-        const GemmTouch t_down = slice(w_qkv_next, b_qkv, 0, c->pf_kb[3]);
-        const GemmTouch t_g2 = slice(w_qkv_next, b_qkv, c->pf_kb[3], c->pf_kb[4]);
-        const GemmTouch t_att = slice(w_o, b_o, c->pf_kb[0], c->pf_kb[5]);
-        gemm_qkv(c, li, s, &t_qkv);
+        gemm_qkv(c, li, s);
         AttnParams ap{};
         ap.qkv_part = c->qkv_part.p; ap.S = c->S_qkv; ap.Mpad = Mpad; ap.Nqkv = c->Nqkv;
         ap.kcache = c->kcache.p + lkv * li; ap.vtcache = c->vtcache.p + lkv * li;
@@ -646,14 +609,13 @@ static void enqueue_layers(mis_tts* c, const bf16_t* table = nullptr, int table_
             ap.qk_eps = c->cfg.rms_norm_eps;
         }
         ap.rope_in_dtype = c->cfg.rope_ops_in_dtype;
-        ap.touch_ptr = t_att.bytes >= 16 ? t_att.ptr : nullptr; ap.touch_n16 = t_att.bytes / 16;
         launch_attn_decode(ap, c->batch, s);
-        gemm_o(c, li, s, &t_o);
-        launch_reduce_residual_rmsnorm(c->part.p, c->S_o, Mpad, d, c->h.p, c->norms.p + (size_t)(2 * li + 1) * d, c->x.p, eps, s, nullptr, &t_g1);
+        gemm_o(c, li, s);
+        launch_reduce_residual_rmsnorm(c->part.p, c->S_o, Mpad, d, c->h.p, c->norms.p + (size_t)(2 * li + 1) * d, c->x.p, eps, s);
         gemm_gate_up(c, li, s);
-        gemm_down(c, li, s, &t_down);
+        gemm_down(c, li, s);
         const bf16_t* next_norm = c->norms.p + (size_t)(li + 1 < c->L ? 2 * (li + 1) : 2 * c->L) * d;
-        launch_reduce_residual_rmsnorm(c->part.p, c->S_down, Mpad, d, c->h.p, next_norm, c->x.p, eps, s, nullptr, &t_g2);
+        launch_reduce_residual_rmsnorm(c->part.p, c->S_down, Mpad, d, c->h.p, next_norm, c->x.p, eps, s);
     }
 }
 static void enqueue_lm_head(mis_tts* c, const bf16_t* head = nullptr) {
@@ -897,6 +859,7 @@ extern "C" mis_status mis_sample_logits(int device, const float* logits, int bat
     HIP_CHECK(hipMemcpy(steps.p, st.data(), batch * 4, hipMemcpyHostToDevice));
     DevBuf<SamplerScratch> scratch;
     scratch.alloc(batch);
+    sampler_scratch_init(scratch.p, batch, 0);
     SamplerParams sp{};
     sp.scratch = scratch.p;
     sampler_plan(vocab, &sp.n_chunks, &sp.chunk_w);
@@ -1024,6 +987,7 @@ static void run_generate(mis_tts* c, const int32_t* prompt_ids, const int32_t* p
     HIP_CHECK(hipStreamSynchronize(s));
 
     c->samp_scratch.alloc(batch);
+    sampler_scratch_init(c->samp_scratch.p, batch, s);
     SamplerParams sp{};
     sp.scratch = c->samp_scratch.p;
     sampler_plan(c->V, &sp.n_chunks, &sp.chunk_w);

@@ -7,10 +7,6 @@ __host__ __device__ __forceinline__ size_t xpk_index(int m, int k, int MT) {
     return ((((size_t)(k >> 5) * MT + (m >> 4)) * 64) + (((k & 31) >> 3) << 4) + (m & 15)) * 8 + (k & 7);
 }
 
-// extra blocks of a step-chain launch that only read `bytes` of an upcoming weight matrix into the Infinity Cache (lm_kernels.hip)
-struct GemmTouch { const void* ptr = nullptr; size_t bytes = 0; int blocks = 0; };
-void gemm_touch_prepare();       // call once per device outside any stream capture before a launch carries touch blocks
-
 enum { EPI_PARTIAL = 0, EPI_BF16 = 1, EPI_SILU_MUL = 2, EPI_GELU_PACKED = 3, EPI_SILU_PACKED = 4 };
 
 void launch_convert_to_bf16(const void* src, int dtype, bf16_t* dst, size_t n, hipStream_t s);
@@ -28,13 +24,13 @@ void launch_embed_rmsnorm(const bf16_t* emb, const int32_t* ids, const uint8_t* 
                           hipStream_t s);
 // ln_bias == nullptr: RMSNorm; otherwise LayerNorm(weight wnorm, bias ln_bias)
 void launch_reduce_residual_rmsnorm(const float* slabs, int S, int Mpad, int N, bf16_t* h, const bf16_t* wnorm,
-                                    bf16_t* x, float eps, hipStream_t s, const bf16_t* ln_bias = nullptr, const GemmTouch* touch = nullptr);
+                                    bf16_t* x, float eps, hipStream_t s, const bf16_t* ln_bias = nullptr);
 // Wp packed [NT][KT][64][8]; X bf16 [Mpad][KT*32]; out: f32 slabs [S][Mpad][N_out] (EPI_PARTIAL) or bf16 [Mpad][N_out]
 // ksb = 1: each wave an independent item; ksb = 4: the block's 4 waves split the item's K range (LDS combine)
 // bias (bf16 [N], optional): added once (slab 0 / final epilogue).  EPI_GELU_PACKED: T(gelu(T(xW+b))) written
 // in the packed fragment layout (it is the next GEMM's X operand).  EPI_SILU_PACKED: h = T(xW+b), T(h * T(sigmoid(h))) packed.
 void launch_gemm_skinny(int epi, int R, int ksb, const bf16_t* Wp, const bf16_t* X, void* out, int NT, int KT, int S,
-                        int N_out, int Mpad, hipStream_t s, const bf16_t* bias = nullptr, const GemmTouch* touch = nullptr);
+                        int N_out, int Mpad, hipStream_t s, const bf16_t* bias = nullptr);
 
 // the same on MLX affine-quantised weights (lm_qgemm.hip): Qp packed codes, SB packed bf16 scale/bias pairs, G = K/64 scale groups
 void launch_gemm_skinny_q(int bits, int epi, int R, int ksb, const void* Qp, const bf16_t* SB, const bf16_t* X, void* out, int NT, int G,
@@ -73,11 +69,6 @@ struct AttnParams {
     int H, Hkv, D, Smax;
     float scale;
     unsigned long long* dbg; // phase timestamps (MIS_ATTN_TIMING builds only), else null
-    // Infinity-Cache prefetch carried by the waves that run out of key tiles first (see touch_block, lm_kernels.hip): every block reads
-    // its 1 / gridsize share of touch_n16 16-byte units behind its tile loop, in the shadow of the partials barrier and the combine
-    const void* touch_ptr;
-    unsigned long long touch_n16;
-    unsigned int* touch_sink;   // scratch word (set by the launcher)
 };
 void launch_attn_decode(const AttnParams& p, int batch, hipStream_t s);
 
@@ -88,7 +79,12 @@ struct SamplerScratch {             // per row, device memory
     float pmax[SAMP_MAX_CHUNKS];
     int pidx[SAMP_MAX_CHUNKS];
     unsigned bin1, kstar;
+    // k_samp_cluster (one launch, 8 blocks per row): its own exchange area - zero when the scratch is allocated (sampler_scratch_init),
+    // left zero by every launch; `sync` only ever grows
+    unsigned long long c_hist1[256], c_hist2[256], c_mass[8], c_max[8];
+    unsigned int c_sync, c_fail;
 };
+void sampler_scratch_init(SamplerScratch* scratch, int batch, hipStream_t s);
 void sampler_plan(int vocab, int* n_chunks, int* chunk_w);
 
 struct SamplerParams {

@@ -101,47 +101,10 @@ void launch_synth_fill_bf16(bf16_t* dst, size_t n, uint64_t key, float amp, int 
     hipLaunchKernelGGL(k_synth_fill_bf16, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, dst, n, key, amp, plus_one);
 }
 
-// ============================================================================ Infinity-Cache prefetch ("touch") blocks
-//
-// The decode chain is a sequence of dependent launches; the weights the NEXT launches will stream do not depend on anything
-// computed in this step.  The latency-bound launches of the chain (glue, the short split-K GEMMs) therefore carry a few EXTRA
-// blocks (block index >= the launch's own block count) that only read a slice of an upcoming weight matrix, so that it sits in the
-// 256 MB Infinity Cache (memory-side: every HBM read allocates) when its consumer starts - profiles/r02_mall_probe.txt prices the
-// consumer at -15..23 % for the split-K GEMMs.  Piggy-backing on existing launches costs no extra graph node and no cross-stream
-// edge: the same reads as a forked branch of the step graph were measured at ~16 us PER FORK on ROCm 7.2 (step 2.13 -> 2.95..4.1 ms,
-// profiles/r03/ab1_glue4_and_graph_branch_prefetch.json).  Loads are non-temporal like the consumer's; the xor / conditional store
-// only keeps them alive.
-typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
-static unsigned int* touch_sink();
-__device__ __forceinline__ void touch_range(const u32x4_t* __restrict__ p, size_t n16, size_t first, size_t stride, u32x4_t& acc) {
-    size_t i = first;
-    for (; i + 7 * stride < n16; i += 8 * stride) {
-        u32x4_t v[8];
-#pragma unroll
-        for (int u = 0; u < 8; ++u) v[u] = __builtin_nontemporal_load(p + i + (size_t)u * stride);
-#pragma unroll
-        for (int u = 0; u < 8; ++u) acc ^= v[u];
-    }
-    for (; i < n16; i += stride) acc ^= __builtin_nontemporal_load(p + i);
-}
-// body of a touch block: block `tb` of `ntb` touch blocks of `nth` threads each
-__device__ __forceinline__ void touch_block(const void* __restrict__ ptr, unsigned long long n16, int tb, int ntb, int nth, unsigned int* __restrict__ sink) {
-    u32x4_t acc = (u32x4_t){0u, 0u, 0u, 0u};
-    touch_range(reinterpret_cast<const u32x4_t*>(ptr), (size_t)n16, (size_t)tb * nth + threadIdx.x, (size_t)ntb * nth, acc);
-    if (acc.x == 0x7fc00001u && acc.y == 0x7fc00002u && sink) sink[0] = acc.z ^ acc.w;      // scratch word nobody reads
-}
-void gemm_touch_prepare() { (void)touch_sink(); }       // allocate the scratch word now (hipMalloc is illegal inside a stream capture)
-static unsigned int* touch_sink() {                      // one scratch word per device, never freed
-    static std::map<int, unsigned int*> sinks;
-    int dev = 0;
-    (void)hipGetDevice(&dev);
-    auto it = sinks.find(dev);
-    if (it != sinks.end()) return it->second;
-    unsigned int* p = nullptr;
-    if (hipMalloc((void**)&p, 64) != hipSuccess) p = nullptr;
-    sinks[dev] = p;
-    return p;
-}
+// (Round 3, measured and removed again: reading the NEXT launches' weights into the 256 MB Infinity Cache ahead of time.  As a forked
+// branch of the step graph every fork cost ~16 us on ROCm 7.2 (step 2.13 -> 2.95..4.1 ms); as extra blocks of the chain's own launches
+// - glue, split-K GEMMs, the attention waves that run out of key tiles - every schedule was slower too (2.144 -> 2.17..2.35 ms): the
+// carriers lose more than the consumers gain, the step's HBM time is conserved.  profiles/r03/ab1_*.json, ab2_*.json; DESIGN.md.)
 
 // ============================================================================ step bookkeeping
 
@@ -384,11 +347,9 @@ __global__ void __launch_bounds__(RR_THREADS) k_reduce_residual_rmsnorm(const fl
 // operand layout) - S + 2 load instructions per thread instead of 3 S + 6, and 12 waves per row instead of 16 at d = 3072.
 template <int SG>
 __global__ void __launch_bounds__(1024) k_glue4(const float* __restrict__ slabs, int S, int Mpad, int N, bf16_t* __restrict__ h,
-                                                const bf16_t* __restrict__ wnorm, bf16_t* __restrict__ x, float eps,
-                                                const void* __restrict__ tptr, unsigned long long tn16, unsigned int* __restrict__ tsink) {
+                                                const bf16_t* __restrict__ wnorm, bf16_t* __restrict__ x, float eps) {
     __shared__ float red[16];
     const int m = blockIdx.x, tid = threadIdx.x, nth = blockDim.x;
-    if (m >= Mpad) { touch_block(tptr, tn16, m - Mpad, (int)gridDim.x - Mpad, nth, tsink); return; }      // prefetch blocks (see touch_block)
     const int MT = Mpad >> 4;
     const int c4 = tid < (N >> 2) ? tid : (N >> 2) - 1;          // clamped: threads past the row load valid addresses, results masked
     const bool live = tid < (N >> 2);
@@ -454,18 +415,13 @@ __global__ void __launch_bounds__(1024) k_glue4(const float* __restrict__ slabs,
 }
 
 void launch_reduce_residual_rmsnorm(const float* slabs, int S, int Mpad, int N, bf16_t* h, const bf16_t* wnorm,
-                                    bf16_t* x, float eps, hipStream_t s, const bf16_t* ln_bias, const GemmTouch* touch) {
+                                    bf16_t* x, float eps, hipStream_t s, const bf16_t* ln_bias) {
     static const int v4 = getenv("MIS_GLUE_V4") ? atoi(getenv("MIS_GLUE_V4")) : 1;
     if (v4 && !ln_bias && N % 4 == 0 && N / 4 <= 1024 && S <= 8) {
         const int nth = ((N / 4 + 63) / 64) * 64;
-        const bool t = touch && touch->ptr && touch->bytes >= 16 && touch->blocks > 0;
-        const dim3 grid(Mpad + (t ? touch->blocks : 0));
-        const void* tp = t ? touch->ptr : nullptr;
-        const unsigned long long tn = t ? touch->bytes / 16 : 0;
-        unsigned int* sink = t ? touch_sink() : nullptr;
-        if (S <= 2) hipLaunchKernelGGL((k_glue4<2>), grid, dim3(nth), 0, s, slabs, S, Mpad, N, h, wnorm, x, eps, tp, tn, sink);
-        else if (S <= 4) hipLaunchKernelGGL((k_glue4<4>), grid, dim3(nth), 0, s, slabs, S, Mpad, N, h, wnorm, x, eps, tp, tn, sink);
-        else hipLaunchKernelGGL((k_glue4<8>), grid, dim3(nth), 0, s, slabs, S, Mpad, N, h, wnorm, x, eps, tp, tn, sink);
+        if (S <= 2) hipLaunchKernelGGL((k_glue4<2>), dim3(Mpad), dim3(nth), 0, s, slabs, S, Mpad, N, h, wnorm, x, eps);
+        else if (S <= 4) hipLaunchKernelGGL((k_glue4<4>), dim3(Mpad), dim3(nth), 0, s, slabs, S, Mpad, N, h, wnorm, x, eps);
+        else hipLaunchKernelGGL((k_glue4<8>), dim3(Mpad), dim3(nth), 0, s, slabs, S, Mpad, N, h, wnorm, x, eps);
         return;
     }
     if (S <= 2) hipLaunchKernelGGL((k_reduce_residual_rmsnorm<2>), dim3(Mpad), dim3(RR_THREADS), 0, s, slabs, S, Mpad, N, h, wnorm, x, eps, ln_bias);
@@ -582,11 +538,8 @@ __device__ __forceinline__ void gemm_epilogue(const f32x4_t (&acc)[R][MT], void*
 template <int MT, int R, int EPI, int KSB>
 __global__ void __launch_bounds__(256, 2) k_gemm_skinny(const bf16_t* __restrict__ Wp, const bf16_t* __restrict__ X,
                                                      void* __restrict__ out, int NT, int KT, int S, int n_items,
-                                                     int N_out, int Mpad, const bf16_t* __restrict__ bias, int n_main,
-                                                     const void* __restrict__ tptr, unsigned long long tn16,
-                                                     unsigned int* __restrict__ tsink) {
+                                                     int N_out, int Mpad, const bf16_t* __restrict__ bias) {
     static_assert(EPI != EPI_SILU_MUL || R == 2, "silu-mul epilogue pairs a gate tile with an up tile");
-    if ((int)blockIdx.x >= n_main) { touch_block(tptr, tn16, (int)blockIdx.x - n_main, (int)gridDim.x - n_main, 256, tsink); return; }   // prefetch blocks
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int item = (KSB == 1) ? blockIdx.x * 4 + wave : blockIdx.x;
     if (item >= n_items) return;                      // (KSB == 1: a wave of the last block may have no item)
@@ -722,18 +675,13 @@ __global__ void __launch_bounds__(256, 2) k_gemm_skinny(const bf16_t* __restrict
 
 template <int MT>
 static void launch_gemm_mt(int epi, int R, int ksb, const bf16_t* Wp, const bf16_t* X, void* out, int NT, int KT, int S,
-                           int N_out, int Mpad, const bf16_t* bias, hipStream_t s, const GemmTouch* touch) {
+                           int N_out, int Mpad, const bf16_t* bias, hipStream_t s) {
     int n_items = ((NT + R - 1) / R) * S;
-    const int n_main = ksb == 1 ? (n_items + 3) / 4 : n_items;
-    const bool t = touch && touch->ptr && touch->bytes >= 16 && touch->blocks > 0;
-    const void* tp = t ? touch->ptr : nullptr;
-    const unsigned long long tn = t ? touch->bytes / 16 : 0;
-    unsigned int* sink = t ? touch_sink() : nullptr;
-    dim3 grid(n_main + (t ? touch->blocks : 0)), block(256);
+    dim3 grid(ksb == 1 ? (n_items + 3) / 4 : n_items), block(256);
 #define GEMM_CASE(E, RR, KS)                                                                                  \
     if (epi == E && R == RR && ksb == KS) {                                                                   \
         hipLaunchKernelGGL((k_gemm_skinny<MT, RR, E, KS>), grid, block, 0, s, Wp, X, out, NT, KT, S, n_items,     \
-                           N_out, Mpad, bias, n_main, tp, tn, sink);                                              \
+                           N_out, Mpad, bias);                                                                    \
         return;                                                                                               \
     }
     GEMM_CASE(EPI_PARTIAL, 1, 1)
@@ -753,13 +701,13 @@ static void launch_gemm_mt(int epi, int R, int ksb, const bf16_t* Wp, const bf16
 }
 
 void launch_gemm_skinny(int epi, int R, int ksb, const bf16_t* Wp, const bf16_t* X, void* out, int NT, int KT, int S,
-                        int N_out, int Mpad, hipStream_t s, const bf16_t* bias, const GemmTouch* touch) {
+                        int N_out, int Mpad, hipStream_t s, const bf16_t* bias) {
     MIS_REQUIRE(epi == EPI_PARTIAL || S == 1, MIS_ERR_GENERATION_FAILED, "split-K needs the partial epilogue");
     switch (Mpad / 16) {
-        case 1: launch_gemm_mt<1>(epi, R, ksb, Wp, X, out, NT, KT, S, N_out, Mpad, bias, s, touch); break;
-        case 2: launch_gemm_mt<2>(epi, R, ksb, Wp, X, out, NT, KT, S, N_out, Mpad, bias, s, touch); break;
-        case 3: launch_gemm_mt<3>(epi, R, ksb, Wp, X, out, NT, KT, S, N_out, Mpad, bias, s, touch); break;
-        case 4: launch_gemm_mt<4>(epi, R, ksb, Wp, X, out, NT, KT, S, N_out, Mpad, bias, s, touch); break;
+        case 1: launch_gemm_mt<1>(epi, R, ksb, Wp, X, out, NT, KT, S, N_out, Mpad, bias, s); break;
+        case 2: launch_gemm_mt<2>(epi, R, ksb, Wp, X, out, NT, KT, S, N_out, Mpad, bias, s); break;
+        case 3: launch_gemm_mt<3>(epi, R, ksb, Wp, X, out, NT, KT, S, N_out, Mpad, bias, s); break;
+        case 4: launch_gemm_mt<4>(epi, R, ksb, Wp, X, out, NT, KT, S, N_out, Mpad, bias, s); break;
         default: throw MisError(MIS_ERR_INVALID_INPUT, "batch per GPU must be <= 64");
     }
 }
@@ -1079,25 +1027,6 @@ __global__ void __launch_bounds__(512) k_attn_decode(AttnParams p) {
         }
     }
     ATT_STAMP(5);
-    // ---- prefetch for a later launch (p.touch_*): the waves without a second tile are done early and HBM is running dry, so they
-    // request this block's share of an upcoming weight matrix now; the values are only consumed (xor) behind the combine below
-    constexpr int ATT_TOUCH = 24;
-    u32x4_t tv[ATT_TOUCH];
-    const bool touching = p.touch_n16 != 0 && wave + ATT_WAVES >= n_tiles;        // wave-uniform
-    if (touching) {
-        const int first = n_tiles > ATT_WAVES ? n_tiles - ATT_WAVES : 0;          // waves first .. 7 take part
-        const unsigned long long nblk = (unsigned long long)gridDim.x * gridDim.y, bid = (unsigned long long)blockIdx.y * gridDim.x + blockIdx.x;
-        const unsigned long long per = (p.touch_n16 + nblk - 1) / nblk;
-        const unsigned long long lo16 = bid * per, hi16 = lo16 + per < p.touch_n16 ? lo16 + per : p.touch_n16;
-        const unsigned long long stride = (unsigned long long)(ATT_WAVES - first) * 64;
-        const u32x4_t* tp = reinterpret_cast<const u32x4_t*>(p.touch_ptr);
-#pragma unroll
-        for (int j = 0; j < ATT_TOUCH; ++j) {
-            unsigned long long i = lo16 + (unsigned long long)(wave - first) * 64 + lane + (unsigned long long)j * stride;
-            i = i < hi16 ? i : (hi16 ? hi16 - 1 : 0);                             // clamped: a repeated line, never out of range
-            tv[j] = __builtin_nontemporal_load(tp + i);
-        }
-    }
     // ---- per-wave partials -> LDS
     l_run += __shfl_xor(l_run, 16, 64);
     l_run += __shfl_xor(l_run, 32, 64);
@@ -1128,12 +1057,6 @@ __global__ void __launch_bounds__(512) k_attn_decode(AttnParams p) {
         const bf16_t ov = f32_to_bf16(num / den);
         if (p.out_ld) p.out[(size_t)b * p.out_ld + (kvh * G + head) * D + d] = ov;            // row-major (batched prefill)
         else p.out[xpk_index(b, (kvh * G + head) * D + d, p.Mpad >> 4)] = ov;                 // packed o_proj operand
-    }
-    if (touching) {
-        u32x4_t acc = tv[0];
-#pragma unroll
-        for (int j = 1; j < ATT_TOUCH; ++j) acc ^= tv[j];
-        if (acc.x == 0x7fc00001u && acc.y == 0x7fc00002u && p.touch_sink) p.touch_sink[0] = acc.z ^ acc.w;   // scratch word nobody reads: keeps the loads
     }
     ATT_STAMP(7);
 }
@@ -1440,24 +1363,6 @@ __global__ void __launch_bounds__(512) k_attn_decode2(AttnParams p) {
         case 4: run(std::integral_constant<int, 4>{}); break;
         default: run(std::integral_constant<int, 0>{}); break;      // a wave without a tile (context < 256): waits for its prologue loads
     }
-    // ---- prefetch for a later launch (see k_attn_decode)
-    constexpr int ATT_TOUCH = 24;
-    u32x4_t tv[ATT_TOUCH];
-    const bool touching = p.touch_n16 != 0 && wave + ATT_WAVES >= n_tiles;
-    if (touching) {
-        const int first = n_tiles > ATT_WAVES ? n_tiles - ATT_WAVES : 0;
-        const unsigned long long nblk = (unsigned long long)gridDim.x * gridDim.y, bid = (unsigned long long)blockIdx.y * gridDim.x + blockIdx.x;
-        const unsigned long long per = (p.touch_n16 + nblk - 1) / nblk;
-        const unsigned long long lo16 = bid * per, hi16 = lo16 + per < p.touch_n16 ? lo16 + per : p.touch_n16;
-        const unsigned long long stride = (unsigned long long)(ATT_WAVES - first) * 64;
-        const u32x4_t* tp = reinterpret_cast<const u32x4_t*>(p.touch_ptr);
-#pragma unroll
-        for (int j = 0; j < ATT_TOUCH; ++j) {
-            unsigned long long i = lo16 + (unsigned long long)(wave - first) * 64 + lane + (unsigned long long)j * stride;
-            i = i < hi16 ? i : (hi16 ? hi16 - 1 : 0);
-            tv[j] = __builtin_nontemporal_load(tp + i);
-        }
-    }
     // ---- per-wave partials -> LDS, combine (k_attn_decode)
     l_run += __shfl_xor(l_run, 16, 64);
     l_run += __shfl_xor(l_run, 32, 64);
@@ -1486,12 +1391,6 @@ __global__ void __launch_bounds__(512) k_attn_decode2(AttnParams p) {
         const bf16_t ov = f32_to_bf16(num / den);
         if (p.out_ld) p.out[(size_t)b * p.out_ld + (kvh * G + head) * D + d] = ov;
         else p.out[xpk_index(b, (kvh * G + head) * D + d, p.Mpad >> 4)] = ov;
-    }
-    if (touching) {
-        u32x4_t acc = tv[0];
-#pragma unroll
-        for (int j = 1; j < ATT_TOUCH; ++j) acc ^= tv[j];
-        if (acc.x == 0x7fc00001u && acc.y == 0x7fc00002u && p.touch_sink) p.touch_sink[0] = acc.z ^ acc.w;
     }
 }
 static size_t attn2_smem_bytes(int G) { return ((size_t)ATT_WAVES * 7 * 128 + 2 * ATT_WAVES * 16 + (size_t)ATT_WAVES * G * 128) * 4; }
@@ -1531,9 +1430,6 @@ void launch_attn_decode(const AttnParams& p, int batch, hipStream_t s) {
     MIS_REQUIRE(((uintptr_t)p.active & 3) == 0, MIS_ERR_GENERATION_FAILED, "attention: the active-flag array must be 4-byte aligned");
     dim3 grid(p.Hkv, batch), block(512);
     const int n_el = (G + 2) * p.D;
-    AttnParams pt = p;
-    if (!pt.touch_ptr || pt.touch_n16 == 0) { pt.touch_ptr = nullptr; pt.touch_n16 = 0; pt.touch_sink = nullptr; }
-    else pt.touch_sink = touch_sink();
     {   // second schedule (k_attn_decode2) where it applies; MIS_ATTN_V2=0 keeps the first one (A/B, parity tests: read per launch)
         const char* e = getenv("MIS_ATTN_V2");
         const bool v2 = !(e && atoi(e) == 0);
@@ -1541,19 +1437,22 @@ void launch_attn_decode(const AttnParams& p, int batch, hipStream_t s) {
             p.Smax % 32 == 0 && ((uintptr_t)p.qkv_part & 15) == 0 && p.Nqkv % 4 == 0) {
             const size_t sm2 = attn2_smem_bytes(G);
             switch (p.S) {
-                case 1: hipLaunchKernelGGL((k_attn_decode2<1>), grid, block, sm2, s, pt); break;
-                case 2: hipLaunchKernelGGL((k_attn_decode2<2>), grid, block, sm2, s, pt); break;
-                case 3: hipLaunchKernelGGL((k_attn_decode2<3>), grid, block, sm2, s, pt); break;
-                default: hipLaunchKernelGGL((k_attn_decode2<4>), grid, block, sm2, s, pt); break;
+                case 1: hipLaunchKernelGGL((k_attn_decode2<1>), grid, block, sm2, s, p); break;
+                case 2: hipLaunchKernelGGL((k_attn_decode2<2>), grid, block, sm2, s, p); break;
+                case 3: hipLaunchKernelGGL((k_attn_decode2<3>), grid, block, sm2, s, p); break;
+                default: hipLaunchKernelGGL((k_attn_decode2<4>), grid, block, sm2, s, p); break;
             }
             return;
         }
     }
 #ifdef MIS_ATTN_TIMING
     // one 16-stamp slot per enqueued launch (graph replays rewrite their slot); dumped by mis_debug_attn_timing()
+    AttnParams pt = p;
     pt.dbg = g_attn_dbg ? g_attn_dbg + (size_t)(g_attn_slot++ % 4096) * 16 : nullptr;   // mis_debug_attn_timing_init() first
-#endif
     const AttnParams& p2 = pt;
+#else
+    const AttnParams& p2 = p;
+#endif
     if (p.D == 128 && n_el <= 1024) hipLaunchKernelGGL((k_attn_decode<128, 2>), grid, block, smem, s, p2);
     else if (p.D == 128) hipLaunchKernelGGL((k_attn_decode<128, 5>), grid, block, smem, s, p2);
     else if (p.D == 64 && n_el <= 1024) hipLaunchKernelGGL((k_attn_decode<64, 2>), grid, block, smem, s, p2);

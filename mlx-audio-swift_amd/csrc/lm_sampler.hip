@@ -571,6 +571,270 @@ __global__ void __launch_bounds__(SN_NT) k_samp_narrow(SamplerParams p) {
     }
 }
 
+// ---- the whole sampler in ONE launch for the full vocabulary: SC_NB = 8 blocks of 1024 threads per row, SC_PER = 20 CONSECUTIVE ids
+// per thread (8 x 1024 x 20 = 163 840 >= 156 940), every e_i in registers - no [rows][Vpad] float scratch, no kernel boundaries.
+// The 8 blocks of a row meet at four row-local barriers (max | level-1 histogram | level-2 histogram | kept mass); everything they
+// exchange is an agent-scope atomic on both sides (the per-XCD L2s are not coherent with each other; 8-byte agent atomics on both sides
+// is one of the valid hand-off forms of MI355X_MICROARCH.md), so no fences are needed: a block drains its atomics (s_waitcnt vmcnt(0)),
+// syncs, and one thread arrives on the row's counter.  The counter only grows (4 x 8 per launch); a block derives the launch's base
+// from the value it reads at entry.  Spins are bounded: a row whose partner blocks never arrive (they are always co-resident: 256
+// blocks on 256 CUs) reports through c_fail instead of hanging.  Same integers as the six-kernel path (E, Z, thr, k*, Z_K, r are
+// exact), so the token is bit-identical to oracle/sampler.py.
+#define SC_NB 8
+#define SC_NT 1024
+#define SC_PER 20
+__device__ __forceinline__ u64 sc_load(const u64* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ unsigned sc_key32(float f) { const unsigned u = __float_as_uint(f); return (u & 0x80000000u) ? ~u : (u | 0x80000000u); }
+__device__ __forceinline__ float sc_unkey32(unsigned k) { return __uint_as_float((k & 0x80000000u) ? (k & 0x7fffffffu) : ~k); }
+// row barrier: all of this block's exchange atomics are performed, then one arrival; returns false on timeout
+__device__ __forceinline__ bool sc_row_barrier(unsigned int* sync, unsigned target) {
+    __shared__ int ok;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __hip_atomic_fetch_add(sync, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        int good = 0;
+        for (int it = 0; it < (1 << 22); ++it) {
+            if ((int)(__hip_atomic_load(sync, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - target) >= 0) { good = 1; break; }
+            __builtin_amdgcn_s_sleep(2);
+        }
+        ok = good;
+    }
+    __syncthreads();
+    return ok != 0;
+}
+__global__ void __launch_bounds__(SC_NT) k_samp_cluster(SamplerParams p) {
+    __shared__ u64 hist[256];
+    __shared__ u64 sh[SC_NT / 64];
+    __shared__ u64 redk[SC_NT / 64];
+    __shared__ int pen_id[64];
+    __shared__ float pen_val[64];
+    __shared__ int n_pen;
+    __shared__ unsigned s_bin;
+    __shared__ u64 s_below;
+    __shared__ int s_token;
+    const int c = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
+    if (row_skipped(p, b)) return;                           // (row-uniform: all 8 blocks of the row take the same exit)
+    SamplerScratch* sc = p.scratch + b;
+    const int step = row_step(p, b);
+    int lo, hi;
+    allowed_range(p, step, lo, hi);
+    bf16_t* logits = p.logits + (size_t)b * p.Vpad;
+    const int my0 = (c * SC_NT + tid) * SC_PER;              // this thread's ids my0 .. my0 + SC_PER - 1
+    unsigned base = 0;
+    if (tid == 0) {
+        const unsigned v = __hip_atomic_load(&sc->c_sync, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        base = v - (v % (4u * SC_NB));                       // < 8 arrivals of this launch can have happened before this block's first
+        redk[0] = base;                                      // barrier, so rounding down to a multiple of 32 gives the launch's base
+        n_pen = 0;
+        s_token = lo < p.vocab ? lo : 0;
+        s_bin = 255; s_below = 0;
+    }
+    if (tid < 256) hist[tid] = 0;
+    __syncthreads();
+    base = (unsigned)redk[0];
+    // ---- repetition penalty (RepetitionContext.process): once per unique id of the window, bf16 arithmetic; the block that holds the
+    // id writes it back (in place, like the other sampler paths) and lists it so that the owning thread patches its register copy
+    if (p.penalty > 0.0f && p.penalty != 1.0f && p.window) {
+        const int wl = min(p.window_len[b], 64);
+        const int32_t* win = p.window + (size_t)b * p.ctx + (p.ctx - p.window_len[b]);
+        const float pen = bf16_round_f32(p.penalty);
+        if (tid < wl) {
+            const int id = win[tid];
+            bool first = id >= 0 && id < p.vocab && id / (SC_NT * SC_PER) == c;
+            for (int j = 0; j < tid; ++j) first = first && (win[j] != id);
+            if (first) {
+                const float l = bf16_to_f32(logits[id]);
+                const bf16_t v = f32_to_bf16((l < 0.0f) ? l * pen : __fdiv_rn(l, pen));
+                logits[id] = v;
+                const int slot = atomicAdd(&n_pen, 1);
+                pen_id[slot] = id; pen_val[slot] = bf16_to_f32(v);
+            }
+        }
+    }
+    // ---- this thread's ids (bf16 pairs; my0 is even and Vpad a multiple of 16, so 4-byte loads stay inside the row)
+    float l[SC_PER];
+    {
+        const uint32_t* lp = reinterpret_cast<const uint32_t*>(logits);
+        const int vp2 = p.Vpad >> 1;
+#pragma unroll
+        for (int j = 0; j < SC_PER / 2; ++j) {
+            const int w = (my0 >> 1) + j;
+            const uint32_t q = lp[w < vp2 ? w : vp2 - 1];          // clamped (ids >= hi are masked below)
+            l[2 * j] = bf16_to_f32((bf16_t)(q & 0xffffu));
+            l[2 * j + 1] = bf16_to_f32((bf16_t)(q >> 16));
+        }
+    }
+    __syncthreads();
+    {
+        const int np = n_pen;
+        for (int k = 0; k < np; ++k) {
+            const int d = pen_id[k] - my0;
+            const float v = pen_val[k];
+#pragma unroll
+            for (int j = 0; j < SC_PER; ++j) l[j] = (d == j) ? v : l[j];
+        }
+    }
+    // ---- max (first index on ties) as one comparable 64-bit key: (order-preserving float key, ~index)
+    u64 bestk = 0;
+#pragma unroll
+    for (int j = 0; j < SC_PER; ++j) {
+        const int i = my0 + j;
+        const u64 k = ((u64)sc_key32(l[j]) << 32) | (unsigned)(~(unsigned)i);
+        bestk = (i >= lo && i < hi && k > bestk) ? k : bestk;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const unsigned lo32 = __shfl_xor((unsigned)bestk, o, 64), hi32 = __shfl_xor((unsigned)(bestk >> 32), o, 64);
+        const u64 ok = ((u64)hi32 << 32) | lo32;
+        bestk = ok > bestk ? ok : bestk;
+    }
+    if ((tid & 63) == 0) redk[tid >> 6] = bestk;
+    __syncthreads();
+    if (tid == 0) {
+        u64 m = 0;
+        for (int w = 0; w < SC_NT / 64; ++w) m = redk[w] > m ? redk[w] : m;
+        __hip_atomic_store(&sc->c_max[c], m, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    bool alive = sc_row_barrier(&sc->c_sync, base + 1u * SC_NB);
+    u64 rowk = 0;
+#pragma unroll
+    for (int k = 0; k < SC_NB; ++k) { const u64 v = sc_load(&sc->c_max[k]); rowk = v > rowk ? v : rowk; }
+    const float best = rowk ? sc_unkey32((unsigned)(rowk >> 32)) : -INFINITY;
+    const int best_i = rowk ? (int)~(unsigned)rowk : 0x7fffffff;
+    if (p.temperature == 0.0f) {
+        if (tid == 0 && best_i != 0x7fffffff) s_token = best_i;
+    } else if (alive) {
+        // ---- e, E, keys
+        const float xmax = __fdiv_rn(best, p.temperature);
+        float e[SC_PER];
+#pragma unroll
+        for (int j = 0; j < SC_PER; ++j) {
+            const int i = my0 + j;
+            const float x = __fdiv_rn(l[j], p.temperature);
+            const float y = fminf(x - xmax, 0.0f);
+            e[j] = (i >= lo && i < hi) ? det_exp_dev(y) : 0.0f;
+            if ((j & 3) == 3) __builtin_amdgcn_sched_barrier(0);     // (twenty interleaved polynomial chains spill at 128 registers)
+        }
+        unsigned kstar = 0;
+        if (p.top_p > 0.0f && p.top_p < 1.0f) {
+            // level 1: mass per key >> 8 (LDS, then one agent atomic per non-empty bin)
+#pragma unroll
+            for (int j = 0; j < SC_PER; ++j) {
+                const u64 E = (u64)(e[j] * E_SCALE);
+                if (E) atomicAdd(&hist[__float_as_uint(e[j]) >> 24], E);
+            }
+            __syncthreads();
+            if (tid < 256 && hist[tid]) __hip_atomic_fetch_add(&sc->c_hist1[tid], hist[tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            alive = sc_row_barrier(&sc->c_sync, base + 2u * SC_NB) && alive;
+            u64 Z = 0;
+            u64 mine = tid < 256 ? sc_load(&sc->c_hist1[tid]) : 0;
+            u64 incl = block_scan_incl_1024(mine, sh, &Z);
+            const u64 thr = (u64)((double)(1.0f - p.top_p) * (double)Z);
+            if (tid < 256 && incl > thr && incl - mine <= thr) { s_bin = (unsigned)tid; s_below = incl - mine; }      // unique crossing
+            if (tid < 256) hist[tid] = 0;
+            __syncthreads();
+            const unsigned bin1 = s_bin;
+            const u64 below1 = s_below;
+            // level 2: mass per key & 255 inside bin1
+#pragma unroll
+            for (int j = 0; j < SC_PER; ++j) {
+                const unsigned key = __float_as_uint(e[j]) >> 16;
+                const u64 E = (u64)(e[j] * E_SCALE);
+                if (E && (key >> 8) == bin1) atomicAdd(&hist[key & 255], E);
+            }
+            __syncthreads();
+            if (tid < 256 && hist[tid]) __hip_atomic_fetch_add(&sc->c_hist2[tid], hist[tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (tid == 0) s_bin = 255;
+            alive = sc_row_barrier(&sc->c_sync, base + 3u * SC_NB) && alive;
+            mine = tid < 256 ? sc_load(&sc->c_hist2[tid]) : 0;
+            incl = block_scan_incl_1024(mine, sh, nullptr) + below1;
+            if (tid < 256 && incl > thr && incl - mine <= thr) s_bin = (unsigned)tid;
+            __syncthreads();
+            kstar = (bin1 << 8) | s_bin;
+        } else {
+            alive = sc_row_barrier(&sc->c_sync, base + 2u * SC_NB) && alive;      // keep the launch at four arrivals per block
+            alive = sc_row_barrier(&sc->c_sync, base + 3u * SC_NB) && alive;
+        }
+        // ---- kept mass in index order (consecutive ids per thread, consecutive threads, consecutive blocks), draw, inverse CDF
+        u64 mine = 0;
+#pragma unroll
+        for (int j = 0; j < SC_PER; ++j) mine += ((__float_as_uint(e[j]) >> 16) >= kstar) ? (u64)(e[j] * E_SCALE) : 0;
+        u64 Zblk = 0;
+        const u64 incl = block_scan_incl_1024(mine, sh, &Zblk);
+        if (tid == 0) __hip_atomic_store(&sc->c_mass[c], Zblk, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        alive = sc_row_barrier(&sc->c_sync, base + 4u * SC_NB) && alive;
+        u64 Zk = 0, before = 0;
+#pragma unroll
+        for (int k = 0; k < SC_NB; ++k) { const u64 v = sc_load(&sc->c_mass[k]); Zk += v; before += (k < c) ? v : 0; }
+        const u64 row = (u64)(p.row_offset + b);
+        const u64 a = p.seed ^ (0xD1B54A32D192ED03ull * (row + 1));
+        const u64 rnd = mis_splitmix64(mis_splitmix64(a) + (u64)step);
+        const u64 r = __umul64hi(rnd, Zk);
+        const u64 excl = before + incl - mine;
+        bool hit = false;
+        if (mine > 0 && r >= excl && r < excl + mine) {
+            u64 run = excl;
+#pragma unroll
+            for (int j = 0; j < SC_PER; ++j) {
+                const u64 Ek = ((__float_as_uint(e[j]) >> 16) >= kstar) ? (u64)(e[j] * E_SCALE) : 0;
+                run += Ek;
+                if (!hit && Ek && run > r) { s_token = my0 + j; hit = true; }
+            }
+        }
+        // exactly one block of the row holds r (Z_K > 0 whenever the allowed range is not empty: the maximum has e = 1); that block
+        // does the bookkeeping below.  Every block leaves the exchange area the way it found it.
+        const bool mine_blk = r >= before && r < before + Zblk;
+        __syncthreads();
+        if (tid < 256) {          // (all 8 blocks have read both histograms before anyone passed barrier 4)
+            if (c == 0) { __hip_atomic_store(&sc->c_hist1[tid], 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                          __hip_atomic_store(&sc->c_hist2[tid], 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+        }
+        if (alive && !mine_blk && Zk) return;
+        if (alive && !Zk && c != 0) return;                   // empty range: block 0 reports the fallback token
+    }
+    if (!alive) {                                             // a partner block never arrived: reported, block 0 emits the fallback token
+        if (tid == 0) __hip_atomic_store(&sc->c_fail, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (c != 0) return;
+    }
+    if (p.temperature == 0.0f && alive) {
+        // greedy: the same four arrivals, then block 0 does the bookkeeping
+        (void)sc_row_barrier(&sc->c_sync, base + 2u * SC_NB);
+        (void)sc_row_barrier(&sc->c_sync, base + 3u * SC_NB);
+        (void)sc_row_barrier(&sc->c_sync, base + 4u * SC_NB);
+        if (c != 0) return;
+    }
+    __syncthreads();
+    if (tid == 0) {      // bookkeeping of the generate loop (LlamaTTS.swift:721-738), as k_samp_pick
+        const int token = s_token;
+        if (p.tokens_out && step < p.tokens_stride) p.tokens_out[(size_t)b * p.tokens_stride + step] = token;
+        if (p.n_gen && !p.step_override) p.n_gen[b] = step + 1;
+        if (p.window && p.ctx > 0) {
+            int32_t* win = p.window + (size_t)b * p.ctx;
+            int wl = p.window_len[b];
+            if (wl < p.ctx) { wl++; p.window_len[b] = wl; }
+            for (int j = p.ctx - wl; j < p.ctx - 1; ++j) win[j] = win[j + 1];
+            win[p.ctx - 1] = token;
+        }
+        if (p.next_ids) p.next_ids[b] = token;
+        if (token == p.eos_id) {
+            if (p.active) p.active[b] = 0;
+            if (p.done_count) atomicAdd(p.done_count, 1);
+        } else {
+            if (p.all_ids) {
+                int n = p.all_len[b];
+                if (n < p.all_stride) { p.all_ids[(size_t)b * p.all_stride + n] = token; p.all_len[b] = n + 1; }
+            }
+            if (p.n_gen && !p.step_override && step + 1 >= p.max_tokens) {
+                if (p.done_count) atomicAdd(p.done_count, 1);
+            }
+        }
+    }
+}
+void sampler_scratch_init(SamplerScratch* scratch, int batch, hipStream_t s) {
+    if (scratch && batch > 0) HIP_CHECK(hipMemsetAsync(scratch, 0, (size_t)batch * sizeof(SamplerScratch), s));
+}
+
 void sampler_plan(int vocab, int* n_chunks, int* chunk_w) {
     int nc = (vocab + 4095) / 4096;
     if (nc > SAMP_MAX_CHUNKS) nc = SAMP_MAX_CHUNKS;
@@ -585,11 +849,21 @@ void launch_sampler(const SamplerParams& p, int batch, hipStream_t s) {
     MIS_REQUIRE(p.scratch && p.n_chunks >= 1 && p.n_chunks <= SAMP_MAX_CHUNKS && p.chunk_w > 0, MIS_ERR_GENERATION_FAILED,
                 "sampler scratch not configured");
     {   // narrow allowed range (every frame-constrained step; any static [lo, hi) of <= 4096 ids): the single-launch sampler
-        static const bool wide_only = getenv("MIS_SAMPLER_WIDE") && atoi(getenv("MIS_SAMPLER_WIDE")) != 0;      // A/B and parity tests
+        const char* ew = getenv("MIS_SAMPLER_WIDE");                     // A/B and parity tests (1: six kernels, 2: the one-launch cluster kernel)
+        const bool wide_only = ew && atoi(ew) != 0;
         const int hi = (p.hi <= 0 || p.hi > p.vocab) ? p.vocab : p.hi, lo = p.lo < 0 ? 0 : p.lo;
         const bool narrow = p.frame_constrained || (hi - lo <= SN_W);
         if (narrow && !wide_only && !p.logits32 && p.penalty_flavor == 0) {
             hipLaunchKernelGGL(k_samp_narrow, dim3(batch), dim3(SN_NT), 0, s, p);
+            return;
+        }
+    }
+    {   // full vocabulary in one launch (k_samp_cluster); MIS_SAMPLER_WIDE=1 keeps the six-kernel path (A/B, parity tests)
+        const char* e6 = getenv("MIS_SAMPLER_WIDE");                     // (read per launch: the parity tests switch it in-process)
+        const bool six = e6 && atoi(e6) != 0;
+        // (batch <= 32: 256 blocks, one per CU - the blocks of a row spin on each other and must be co-resident)
+        if (!six && !p.logits32 && p.penalty_flavor == 0 && p.vocab <= SC_NB * SC_NT * SC_PER && p.Vpad % 2 == 0 && p.ctx <= 64 && batch <= 32) {
+            hipLaunchKernelGGL(k_samp_cluster, dim3(SC_NB, batch), dim3(SC_NT), 0, s, p);
             return;
         }
     }

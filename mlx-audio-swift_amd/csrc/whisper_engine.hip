@@ -377,6 +377,7 @@ static void whisper_alloc_state(mis_whisper* c, int batch) {
     c->qkv_part.alloc((size_t)c->S_qkv * Mpad * 3 * d);
     c->part.alloc((size_t)std::max(std::max(c->S_o, c->S_cq), c->S_fc2) * Mpad * d);
     c->scratch.alloc(batch);
+    sampler_scratch_init(c->scratch.p, batch, c->stream);
 }
 
 static void whisper_decoder_reset(mis_whisper* c) {

@@ -295,3 +295,26 @@ def test_rccl_communicator_world1_all_gather_is_the_identity():
     torch.cuda.synchronize()
     assert torch.equal(out, x) and lens.tolist() == [1000, 7, 0] and ms >= 0.0
     comm.close()
+
+
+def test_unconstrained_generate_full_vocabulary_sampler_paths_agree(monkeypatch):
+    """Real Orpheus decoding is not frame-constrained: every step samples over the whole 156 940-id vocabulary.  The one-launch
+    sampler (k_samp_cluster) replayed inside the step graph - the same per-row exchange area step after step - returns the tokens
+    of the six-kernel path (both are pinned on the oracle in test_gpu_sampler.py)."""
+    cfg = mas.LlamaTTSConfiguration(hidden_size=256, num_hidden_layers=2, intermediate_size=512, num_attention_heads=2,
+                                    num_key_value_heads=1, head_dim=128, vocab_size=156940, rope_theta=500000.0)
+    snac_cfg = mas.SNACConfig(**SNAC_SMALL)
+    from mlx_audio_swift_amd.synthetic import snac_synthetic_weights
+    codec = mas.SNAC.from_weights(snac_cfg, snac_synthetic_weights(snac_cfg, seed=1234))
+    lm = mas.LlamaTTSModel.synthetic(cfg, codec=codec, seed=77)
+    rng = np.random.default_rng(3)
+    prompts = _prompts(rng, [9, 14, 6, 11, 8])
+    toks = {}
+    for mode, n in (("0", 40), ("1", 41)):                    # different token budgets: the step graph is captured again per mode
+        monkeypatch.setenv("MIS_SAMPLER_WIDE", mode)
+        gp = mas.GenerateParameters(max_tokens=n, temperature=0.6, top_p=0.8, repetition_penalty=1.3, seed=11, frame_constrained=False)
+        _, t = lm.generate_batch(prompts, gp, return_tokens=True)
+        toks[mode] = t
+    for r in range(len(prompts)):
+        n = min(len(toks["0"][r]), 40)
+        assert n > 0 and np.array_equal(toks["0"][r][:n], toks["1"][r][:n]), r

@@ -85,3 +85,28 @@ def test_single_launch_sampler_on_narrow_ranges_bit_exact(temp, top_p, pen):
         got = sample_logits(logits, window, wl, p, 2, lo, hi)
         ref = _oracle_tokens(logits, window, wl, p, 2, lo, hi)
         assert np.array_equal(got, ref), (lo, hi, got, ref)
+
+
+@pytest.mark.parametrize("temp,top_p,pen", [(0.6, 0.8, 1.3), (0.0, 0.8, 1.3), (1.0, 1.0, 0.0), (0.9, 0.3, 1.1), (0.7, 0.95, 1.5)])
+def test_full_vocabulary_single_launch_sampler_bit_exact(temp, top_p, pen, monkeypatch):
+    """The full 156 940-id range in ONE launch (k_samp_cluster: 8 blocks per row, four row-local barriers) against the oracle and
+    against the six-kernel path (MIS_SAMPLER_WIDE=1): same integers, same token.  32 rows = the bench's batch (256 co-resident
+    blocks); penalty windows with duplicates and with the row maximum inside; wide [lo, hi) ranges; repeated calls on the same
+    scratch (the exchange area must come back zeroed)."""
+    rng = np.random.default_rng(int(temp * 100) + int(top_p * 1000) + 5)
+    V, B, ctx = 156940, 32, 20
+    logits = bf16_round((rng.standard_normal((B, V)) * 2.0).astype(np.float32))
+    window = rng.integers(0, V, (B, ctx)).astype(np.int32)
+    window[:, -3] = window[:, -1]
+    for b in range(B):
+        window[b, 0] = int(np.argmax(logits[b]))                  # the maximum is penalised: the row max must follow
+    wl = np.asarray([20, 20, 7, 0, 1, 20] * 5 + [20, 3], np.int32)
+    p = mas.GenerateParameters(temperature=temp, top_p=top_p, repetition_penalty=pen, seed=4321, row_offset=7)
+    for step, (lo, hi) in ((0, (0, None)), (3, (0, None)), (9, (1000, 150001)), (10, (128266, 128266 + 7 * 4096))):
+        monkeypatch.setenv("MIS_SAMPLER_WIDE", "0")
+        got = sample_logits(logits, window, wl, p, step, lo, hi if hi is not None else 0)
+        monkeypatch.setenv("MIS_SAMPLER_WIDE", "1")
+        six = sample_logits(logits, window, wl, p, step, lo, hi if hi is not None else 0)
+        ref = _oracle_tokens(logits, window, wl, p, step, lo, hi)
+        assert np.array_equal(got, ref), (step, np.nonzero(got != ref)[0], got[:8], ref[:8])
+        assert np.array_equal(six, ref), step
