@@ -171,8 +171,11 @@ typedef struct {
     int32_t  repetition_context;   /* default 20 */
     uint64_t seed;                 /* mis-sampler-v1 RNG key (see csrc/lm_sampler.hip) */
     int32_t  frame_constrained;    /* 0 normal. 1 (synthetic-weight benches): step i may only emit
-                                      128266 + (i%7)*4096 + [0,4096) - all vocab entries are still
-                                      processed; EOS can then never be sampled */
+                                      128266 + (i%7)*4096 + [0,4096); EOS can then never be sampled; the
+                                      sampler only visits that range (k_samp_narrow).  2: the same
+                                      constraint through the FULL-vocabulary sampler (every id visited,
+                                      masked ones get zero mass) - the code path of an unconstrained
+                                      checkpoint, with tokens that still form valid frames */
     int64_t  row_offset;           /* global index of row 0 (RNG keyed by global row => sharding-invariant) */
     int32_t  sampler_flavor;       /* 0 mlx-lm processor/sampler (Orpheus).  1 Soprano streamGenerate (Soprano.swift:801-901):
                                       penalty window = generated tokens only, applied per occurrence in float32; the reference's
@@ -411,6 +414,7 @@ mis_status mis_qwen3tts_finalize(mis_qwen3tts*);
 void       mis_qwen3tts_destroy(mis_qwen3tts*);
 mis_tts*   mis_qwen3tts_talker(mis_qwen3tts*);            /* borrowed handle (parity taps) */
 int        mis_qwen3tts_samples_per_frame(const mis_qwen3tts*);   /* 1920 */
+int        mis_qwen3tts_num_code_groups(const mis_qwen3tts*);     /* 16: ints per frame of codes_out */
 /* Prompts as prepareGenerationInputs builds them (:883-1000): prefill position p of row b is
  * text_projection(text_embedding[text_ids[b,p]]) (text id >= 0) plus codec_embedding[codec_ids[b,p]] (codec id >= 0);
  * trailing_ids = the text ids added to the generated frames' embeddings (then tts_pad).  int32 [batch, P] / [batch, Tt].
@@ -571,6 +575,7 @@ typedef struct {
     int32_t n_suppress;
     const int32_t* begin_suppress; /* begin_suppress_tokens, first step only (default [eot]) */
     int32_t n_begin_suppress;
+    int64_t row_offset;            /* global index of row 0 (sharding): the sampler's RNG is keyed by the global row */
 } mis_stt_params;
 mis_status mis_whisper_create(const mis_whisper_config*, int device, mis_whisper** out);
 /* HF transformers key layout (model.encoder.* / model.decoder.*; conv weights [out, in, k]; proj_out ignored: tied) or the
@@ -602,6 +607,29 @@ mis_status mis_stt_whisper_generate_stream(mis_whisper*, const float* pcm, const
                                            const int32_t* prompt_ids, int n_prompt, const mis_stt_params*,
                                            mis_event_cb on_event, void* user, const volatile int* cancel_flag,
                                            int32_t** tokens_out, int64_t* tokens_stride, int32_t* n_tokens);
+
+/* ------------------------------------------------------------------------------------------
+ * Device groups for the other families ("Whisper (30 s chunks), Soprano (sentence prompts) and Qwen3-TTS rows shard the
+ * same way").  replicas[n]: one finalized handle per GPU holding the same weights.  The rows of the call are split into n contiguous
+ * blocks (mis_shard_rows), every replica runs its block on its own worker thread through the single-device entry point - with
+ * row_offset advanced by the block start, so a row's tokens / samples do not depend on n - and the results are gathered on the host
+ * in global row order.  No collective is on the critical path; outputs and ownership are those of the single-device calls.
+ * Callbacks are serialised (one at a time, any worker thread) and carry GLOBAL row indices.  Errors: the first failing shard's
+ * status, message prefixed "shard r:". */
+mis_status mis_whisper_group_generate(mis_whisper* const* replicas, int n, const float* pcm, const int64_t* lens, int batch, int64_t stride,
+                                      const int32_t* prompt_ids, int n_prompt, const mis_stt_params*,
+                                      int32_t** tokens_out, int64_t* tokens_stride, int32_t* n_tokens);
+mis_status mis_soprano_group_generate(mis_soprano* const* replicas, int n, const int32_t* prompt_ids, const int32_t* prompt_lens, int batch,
+                                      const mis_gen_params* params, float** pcm_out, int64_t* pcm_stride, int64_t* pcm_lens,
+                                      int32_t** tokens_out, int64_t* tokens_stride, int32_t* n_tokens);
+/* arguments as mis_qwen3tts_generate; with on_event and chunk_frames > 0 every replica streams its rows' chunks as they are decoded
+ * (generateStream): per-rank chunk emission, nothing is exchanged between GPUs. */
+mis_status mis_qwen3tts_group_generate(mis_qwen3tts* const* replicas, int n, const int32_t* text_ids, const int32_t* codec_ids,
+                                       const int32_t* prefill_lens, int P, const int32_t* trailing_ids, const int32_t* trailing_lens, int Tt,
+                                       int batch, const mis_qwen3tts_params* params, const int32_t* row_max_frames, float** pcm_out,
+                                       int64_t* pcm_stride, int64_t* pcm_lens, int32_t** codes_out, int64_t* codes_stride,
+                                       int32_t* n_frames, int chunk_frames, mis_event_cb on_event, void* user,
+                                       const volatile int* cancel_flag);
 
 /* diagnostics: microseconds per dependent kernel boundary in a replayed hipGraph of n trivial kernels
  * (mode 0: 1 block x 64 threads, 1: 32 x 1024, 2: 1024 x 256).  DESIGN.md quotes it as the launch floor. */

@@ -103,7 +103,7 @@ class WhisperConfigC(C.Structure):
 class SttParamsC(C.Structure):
     _fields_ = [("max_tokens", C.c_int32), ("temperature", C.c_float), ("seed", C.c_uint64), ("eot_id", C.c_int32),
                 ("timestamp_begin", C.c_int32), ("suppress", C.c_void_p), ("n_suppress", C.c_int32),
-                ("begin_suppress", C.c_void_p), ("n_begin_suppress", C.c_int32)]
+                ("begin_suppress", C.c_void_p), ("n_begin_suppress", C.c_int32), ("row_offset", C.c_int64)]
 
 
 class GroupTimingC(C.Structure):
@@ -207,6 +207,14 @@ SYMBOLS = {
     "mis_qwen3tts_destroy": (None, [_P]),
     "mis_qwen3tts_talker": (_P, [_P]),
     "mis_qwen3tts_samples_per_frame": (C.c_int, [_P]),
+    "mis_qwen3tts_num_code_groups": (C.c_int, [_P]),
+    "mis_qwen3tts_group_generate": (C.c_int, [_P, C.c_int, _P, _P, _P, C.c_int, _P, _P, C.c_int, C.c_int, C.POINTER(Qwen3TTSParamsC), _P,
+                                              C.POINTER(_P), C.POINTER(C.c_int64), _P, C.POINTER(_P), C.POINTER(C.c_int64), _P,
+                                              C.c_int, EVENT_CB, _P, _P]),
+    "mis_whisper_group_generate": (C.c_int, [_P, C.c_int, _P, _P, C.c_int, C.c_int64, _P, C.c_int, C.POINTER(SttParamsC),
+                                             C.POINTER(_P), C.POINTER(C.c_int64), _P]),
+    "mis_soprano_group_generate": (C.c_int, [_P, C.c_int, _P, _P, C.c_int, C.POINTER(GenParamsC), C.POINTER(_P), C.POINTER(C.c_int64),
+                                             _P, C.POINTER(_P), C.POINTER(C.c_int64), _P]),
     "mis_qwen3tts_generate_codes": (C.c_int, [_P, _P, _P, _P, C.c_int, _P, _P, C.c_int, C.c_int, C.POINTER(Qwen3TTSParamsC), _P,
                                               C.POINTER(_P), C.POINTER(C.c_int64), _P]),
     "mis_qwen3tts_decode": (C.c_int, [_P, _P, C.c_int, C.c_int, _P]),

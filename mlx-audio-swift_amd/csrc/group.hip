@@ -15,6 +15,7 @@
 #include <dlfcn.h>
 #include <string.h>
 #include <chrono>
+#include <mutex>
 #include <thread>
 
 // ---------------------------------------------------------------------------- RCCL (dlopen)
@@ -334,5 +335,154 @@ extern "C" mis_status mis_tts_group_last_timing(mis_group* g, mis_group_timing* 
     MIS_API_BEGIN
     MIS_REQUIRE(g && out, MIS_ERR_INVALID_INPUT, "null argument");
     *out = g->timing;
+    MIS_API_END
+}
+
+
+// ---------------------------------------------------------------------------- groups of the other families (stateless: replicas[n])
+namespace {
+struct EventRelay { mis_event_cb cb; void* user; int lo; std::mutex* mu; };
+void relay_event(void* u, int row, mis_event_kind kind, const void* payload, int64_t n) {
+    EventRelay* r = static_cast<EventRelay*>(u);
+    std::lock_guard<std::mutex> g(*r->mu);
+    r->cb(r->user, row + r->lo, kind, payload, n);
+}
+template <typename H>
+void check_replicas(H* const* replicas, int n, int batch) {
+    MIS_REQUIRE(replicas && n >= 1 && n <= 64, MIS_ERR_INVALID_INPUT, "a group needs 1..64 replicas");
+    MIS_REQUIRE(batch >= n, MIS_ERR_INVALID_INPUT, "batch %d smaller than the group (%d replicas)", batch, n);
+    for (int i = 0; i < n; ++i) {
+        MIS_REQUIRE(replicas[i], MIS_ERR_INVALID_INPUT, "null replica handle");
+        for (int j = 0; j < i; ++j) MIS_REQUIRE(replicas[j] != replicas[i], MIS_ERR_INVALID_INPUT, "a handle may appear only once in a group");
+    }
+}
+// run fn(r, lo, hi) on one thread per shard; rethrow the first failure
+template <typename F>
+void run_shards(int n, int batch, F&& fn) {
+    std::vector<ShardResult> res(n);
+    std::vector<std::thread> th;
+    for (int r = 0; r < n; ++r)
+        th.emplace_back([&, r]() {
+            int lo, hi;
+            shard_block(batch, r, n, &lo, &hi);
+            res[r].st = fn(r, lo, hi);
+            if (res[r].st != MIS_OK) res[r].err = mis_last_error();
+        });
+    for (auto& t : th) t.join();
+    for (int r = 0; r < n; ++r)
+        if (res[r].st != MIS_OK) throw MisError(res[r].st, "shard " + std::to_string(r) + ": " + res[r].err);
+}
+// rows of per-shard [rows_r, stride_r] buffers -> one pinned [batch, longest] buffer (zero padded)
+template <typename T>
+T* merge_rows(const std::vector<T*>& part, const std::vector<int64_t>& stride, int n, int batch, int64_t* longest_out) {
+    int64_t longest = 1;
+    for (int r = 0; r < n; ++r) longest = std::max(longest, stride[r]);
+    PinnedBuf<T> host((size_t)batch * longest);
+    memset(host.p, 0, (size_t)batch * longest * sizeof(T));
+    for (int r = 0; r < n; ++r) {
+        int lo, hi;
+        shard_block(batch, r, n, &lo, &hi);
+        if (!part[r]) continue;
+        for (int b = lo; b < hi; ++b) memcpy(host.p + (size_t)b * longest, part[r] + (size_t)(b - lo) * stride[r], (size_t)stride[r] * sizeof(T));
+    }
+    *longest_out = longest;
+    return host.release();
+}
+template <typename T>
+struct PartGuard {                                    // per-shard library buffers, released on every path
+    std::vector<T*> p;
+    explicit PartGuard(int n) : p(n, nullptr) {}
+    ~PartGuard() { for (auto q : p) if (q) mis_free(q); }
+};
+}   // namespace
+
+extern "C" mis_status mis_whisper_group_generate(mis_whisper* const* replicas, int n, const float* pcm, const int64_t* lens, int batch,
+                                                 int64_t stride, const int32_t* prompt_ids, int n_prompt, const mis_stt_params* sp,
+                                                 int32_t** tokens_out, int64_t* tokens_stride, int32_t* n_tokens) {
+    MIS_API_BEGIN
+    MIS_REQUIRE(pcm && lens && prompt_ids && sp && tokens_out && tokens_stride && n_tokens, MIS_ERR_INVALID_INPUT, "null argument");
+    check_replicas(replicas, n, batch);
+    PartGuard<int32_t> tok(n);
+    std::vector<int64_t> ts(n, 0);
+    run_shards(n, batch, [&](int r, int lo, int hi) {
+        mis_stt_params p = *sp;
+        p.row_offset += lo;
+        return mis_stt_whisper_generate(replicas[r], pcm + (size_t)lo * stride, lens + lo, hi - lo, stride, prompt_ids, n_prompt, &p, &tok.p[r], &ts[r],
+                                        n_tokens + lo);
+    });
+    *tokens_out = merge_rows(tok.p, ts, n, batch, tokens_stride);
+    MIS_API_END
+}
+
+extern "C" mis_status mis_soprano_group_generate(mis_soprano* const* replicas, int n, const int32_t* prompt_ids, const int32_t* prompt_lens,
+                                                 int batch, const mis_gen_params* params, float** pcm_out, int64_t* pcm_stride, int64_t* pcm_lens,
+                                                 int32_t** tokens_out, int64_t* tokens_stride, int32_t* n_tokens) {
+    MIS_API_BEGIN
+    MIS_REQUIRE(prompt_ids && prompt_lens && params && pcm_out && pcm_stride && pcm_lens, MIS_ERR_INVALID_INPUT, "null argument");
+    check_replicas(replicas, n, batch);
+    HostPrompts hp = fetch_prompts(prompt_ids, prompt_lens, batch);
+    PartGuard<float> pcm(n);
+    PartGuard<int32_t> tok(n);
+    std::vector<int64_t> ps(n, 0), ts(n, 0);
+    std::vector<int32_t> ntok(batch, 0);
+    run_shards(n, batch, [&](int r, int lo, int hi) {
+        mis_gen_params p = *params;
+        p.row_offset += lo;
+        return mis_soprano_generate(replicas[r], hp.flat.data() + hp.off[lo], hp.lens.data() + lo, hi - lo, &p, &pcm.p[r], &ps[r], pcm_lens + lo,
+                                    tokens_out ? &tok.p[r] : nullptr, tokens_out ? &ts[r] : nullptr, ntok.data() + lo);
+    });
+    *pcm_out = merge_rows(pcm.p, ps, n, batch, pcm_stride);
+    if (tokens_out) { int64_t tl = 1; *tokens_out = merge_rows(tok.p, ts, n, batch, &tl); if (tokens_stride) *tokens_stride = tl; }
+    if (n_tokens) for (int b = 0; b < batch; ++b) n_tokens[b] = ntok[b];
+    MIS_API_END
+}
+
+extern "C" mis_status mis_qwen3tts_group_generate(mis_qwen3tts* const* replicas, int n, const int32_t* text_ids, const int32_t* codec_ids,
+                                                  const int32_t* prefill_lens, int P, const int32_t* trailing_ids, const int32_t* trailing_lens,
+                                                  int Tt, int batch, const mis_qwen3tts_params* params, const int32_t* row_max_frames,
+                                                  float** pcm_out, int64_t* pcm_stride, int64_t* pcm_lens, int32_t** codes_out,
+                                                  int64_t* codes_stride, int32_t* n_frames, int chunk_frames, mis_event_cb on_event, void* user,
+                                                  const volatile int* cancel_flag) {
+    MIS_API_BEGIN
+    MIS_REQUIRE(text_ids && codec_ids && prefill_lens && trailing_lens && params && pcm_out && pcm_stride && pcm_lens, MIS_ERR_INVALID_INPUT,
+                "null argument");
+    MIS_REQUIRE(P >= 1 && Tt >= 0, MIS_ERR_INVALID_INPUT, "bad prompt sizes");
+    check_replicas(replicas, n, batch);
+    PartGuard<float> pcm(n);
+    PartGuard<int32_t> cod(n);
+    std::vector<int64_t> ps(n, 0), cs(n, 0);
+    std::vector<int32_t> nf(batch, 0);
+    std::mutex mu;
+    std::vector<EventRelay> relay(n);
+    const int Tt1 = std::max(Tt, 1);
+    run_shards(n, batch, [&](int r, int lo, int hi) {
+        mis_qwen3tts_params p = *params;
+        p.row_offset += lo;
+        relay[r] = EventRelay{on_event, user, lo, &mu};
+        return mis_qwen3tts_generate(replicas[r], text_ids + (size_t)lo * P, codec_ids + (size_t)lo * P, prefill_lens + lo, P,
+                                     trailing_ids ? trailing_ids + (size_t)lo * Tt1 : nullptr, trailing_lens + lo, Tt, hi - lo, &p,
+                                     row_max_frames ? row_max_frames + lo : nullptr, &pcm.p[r], &ps[r], pcm_lens + lo, codes_out ? &cod.p[r] : nullptr,
+                                     codes_out ? &cs[r] : nullptr, nf.data() + lo, chunk_frames, on_event ? relay_event : nullptr, &relay[r],
+                                     cancel_flag);
+    });
+    *pcm_out = merge_rows(pcm.p, ps, n, batch, pcm_stride);
+    if (codes_out) {
+        // codes rows are [frames][G]: strides are in frames, G ints per frame -> merge in units of G ints
+        int64_t longest = 1;
+        for (int r = 0; r < n; ++r) longest = std::max(longest, cs[r]);
+        const int groups = mis_qwen3tts_num_code_groups(replicas[0]);
+        PinnedBuf<int32_t> host((size_t)batch * longest * groups);
+        memset(host.p, 0, (size_t)batch * longest * groups * 4);
+        for (int r = 0; r < n; ++r) {
+            int lo, hi;
+            shard_block(batch, r, n, &lo, &hi);
+            if (!cod.p[r]) continue;
+            for (int b = lo; b < hi; ++b)
+                memcpy(host.p + (size_t)b * longest * groups, cod.p[r] + (size_t)(b - lo) * cs[r] * groups, (size_t)cs[r] * groups * 4);
+        }
+        *codes_out = host.release();
+        if (codes_stride) *codes_stride = longest;
+    }
+    if (n_frames) for (int b = 0; b < batch; ++b) n_frames[b] = nf[b];
     MIS_API_END
 }

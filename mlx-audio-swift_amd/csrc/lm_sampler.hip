@@ -852,7 +852,9 @@ void launch_sampler(const SamplerParams& p, int batch, hipStream_t s) {
         const char* ew = getenv("MIS_SAMPLER_WIDE");                     // A/B and parity tests (1: six kernels, 2: the one-launch cluster kernel)
         const bool wide_only = ew && atoi(ew) != 0;
         const int hi = (p.hi <= 0 || p.hi > p.vocab) ? p.vocab : p.hi, lo = p.lo < 0 ? 0 : p.lo;
-        const bool narrow = p.frame_constrained || (hi - lo <= SN_W);
+        // frame_constrained 2: the frame range, but through the full-vocabulary kernels (every id visited, the masked ones get e = 0) -
+        // what bench.py times as the honest stand-in for a real checkpoint's unconstrained decode
+        const bool narrow = p.frame_constrained == 1 || (!p.frame_constrained && hi - lo <= SN_W);
         if (narrow && !wide_only && !p.logits32 && p.penalty_flavor == 0) {
             hipLaunchKernelGGL(k_samp_narrow, dim3(batch), dim3(SN_NT), 0, s, p);
             return;

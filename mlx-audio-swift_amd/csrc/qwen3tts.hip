@@ -606,6 +606,7 @@ extern "C" mis_status mis_qwen3tts_sample_logits(int device, const float* logits
 
 // ---------------------------------------------------------------------------- decode / generate
 extern "C" int mis_qwen3tts_samples_per_frame(const mis_qwen3tts* c) { return c ? q3dec_total_upsample(c->dec) : 0; }
+extern "C" int mis_qwen3tts_num_code_groups(const mis_qwen3tts* c) { return c ? c->G : 0; }
 
 // Qwen3TTSSpeechTokenizerDecoder.callAsFunction / streamingStep over the whole sequence: codes int32 [batch, num_quantizers, T]
 // (host or device) -> wav f32 [batch, T * samples_per_frame]
@@ -642,7 +643,8 @@ extern "C" mis_status mis_qwen3tts_decode_stream_begin(mis_qwen3tts* c, int batc
     MIS_API_BEGIN
     MIS_REQUIRE(c && batch >= 1 && max_frames >= 1 && max_chunk_frames >= 1, MIS_ERR_INVALID_INPUT, "bad argument");
     MIS_REQUIRE(c->finalized, MIS_ERR_NOT_INITIALIZED, "Qwen3-TTS model not finalized");
-    MIS_REQUIRE(q3dec_stream_pos(c->dec) < 0, MIS_ERR_INVALID_INPUT, "a streaming decode session is already open on this handle (end it first)");
+    // (begin on an open session = resetStreamingState: the host may restart its own session at any time; what must not happen is
+    // generate / generateStream taking the session over - checked there)
     q3dec_stream_begin(c->dec, batch, max_frames, max_chunk_frames, !c->stream_exact, c->s);
     HIP_CHECK(hipStreamSynchronize(c->s));
     MIS_API_END
@@ -790,6 +792,13 @@ extern "C" mis_status mis_qwen3tts_generate(mis_qwen3tts* c, const int32_t* text
     }
     int64_t longest = 0;
     for (int b = 0; b < batch; ++b) { pcm_lens[b] = (int64_t)nf[b] * up; longest = std::max(longest, pcm_lens[b]); }
+    if (!streaming)          // decodeChunk's validLen (:223-228): frames whose first code is > 0, times the upsample rate; a shorter
+        for (int b = 0; b < batch; ++b) {       // non-zero count trims the tail (code 0 is read as padding there) - mirrored
+            int64_t valid = 0;
+            for (int f = 0; f < nf[b]; ++f) valid += codes[((size_t)b * stride + f) * G] > 0;
+            valid *= up;
+            if (valid > 0 && valid < pcm_lens[b]) pcm_lens[b] = valid;
+        }
     PinnedBuf<float> host_pin((size_t)std::max<int64_t>(longest, 1) * batch);
     float* host = host_pin.p;
     memset(host, 0, (size_t)std::max<int64_t>(longest, 1) * batch * 4);
@@ -812,10 +821,30 @@ extern "C" mis_status mis_qwen3tts_generate(mis_qwen3tts* c, const int32_t* text
             const int gb = b1 - b0;
             if (n > 0) {                                                // generatedCodes.isEmpty -> zeros([1]) (:520-522): length 0 here
                 wav.alloc((size_t)gb * n * up);
-                q3dec_decode_strided(c->dec, c->codes.p + (size_t)b0 * stride * G, (int64_t)stride * G, 1, G, gb, n, wav.p, (int64_t)n * up, c->s);
+                // decodeChunk (Qwen3TTS.swift:214-231) = streamingDecode(chunkTokens: 300) (Qwen3TTSSpeechTokenizer.swift:1070-1091):
+                // carried-state steps of 300 frames from a fresh state.  One step IS the whole-sequence decode; beyond 300 frames the
+                // reference's overlap-add counts the block biases twice right behind every 300-frame boundary (dup_bias, see
+                // q3_codec.hip) - mirrored unless mis_qwen3tts_set_stream_exact(1).  Rows of a slice share the boundaries (every row
+                // starts at frame 0) and are right-padded: causal layers, so a row's samples do not depend on the padding.
+                constexpr int kDecodeChunk = 300;
+                if (n <= kDecodeChunk) {
+                    q3dec_decode_strided(c->dec, c->codes.p + (size_t)b0 * stride * G, (int64_t)stride * G, 1, G, gb, n, wav.p, (int64_t)n * up, c->s);
+                } else {
+                    MIS_REQUIRE(q3dec_stream_pos(c->dec) < 0, MIS_ERR_INVALID_INPUT,
+                                "decoding more than 300 frames uses the handle's decode-stream session, but the host has one open");
+                    q3dec_stream_begin(c->dec, gb, n, kDecodeChunk, !c->stream_exact, c->s);
+                    try {
+                        for (int f0 = 0; f0 < n; f0 += kDecodeChunk) {
+                            const int fn = std::min(kDecodeChunk, n - f0);
+                            q3dec_stream_step(c->dec, c->codes.p + (size_t)b0 * stride * G + (size_t)f0 * G, (int64_t)stride * G, 1, G, fn,
+                                              wav.p + (size_t)f0 * up, (int64_t)n * up, c->s);
+                        }
+                    } catch (...) { q3dec_stream_end(c->dec); throw; }
+                    q3dec_stream_end(c->dec);
+                }
                 for (int r = 0; r < gb; ++r)
                     if (nf[b0 + r] > 0)
-                        HIP_CHECK(hipMemcpyAsync(host + (size_t)(b0 + r) * longest, wav.p + (size_t)r * n * up, (size_t)nf[b0 + r] * up * 4,
+                        HIP_CHECK(hipMemcpyAsync(host + (size_t)(b0 + r) * longest, wav.p + (size_t)r * n * up, (size_t)pcm_lens[b0 + r] * 4,
                                                  hipMemcpyDeviceToHost, c->s));
                 HIP_CHECK(hipStreamSynchronize(c->s));
             }
@@ -824,7 +853,7 @@ extern "C" mis_status mis_qwen3tts_generate(mis_qwen3tts* c, const int32_t* text
         }
         if (on_event)                                                   // no chunking requested: one AUDIO event per row
             for (int b = 0; b < batch; ++b)
-                if (nf[b] > 0) on_event(user, b, MIS_EVENT_AUDIO, host + (size_t)b * longest, (int64_t)nf[b] * up);
+                if (nf[b] > 0) on_event(user, b, MIS_EVENT_AUDIO, host + (size_t)b * longest, pcm_lens[b]);
     }
     if (codes_out) {
         PinnedBuf<int32_t> ch(codes.size() + 1);

@@ -627,7 +627,7 @@ static void whisper_generate_impl(mis_whisper* c, const float* pcm, const int64_
     q.logits = c->logits.p; q.e_buf = c->e_buf.p; q.Vpad = c->Vpad; q.vocab = c->V;
     q.active_in = c->active.p; q.n_gen = c->n_gen.p; q.tokens_out = c->tokens_out.p; q.tokens_stride = max_tokens;
     q.next_ids = c->ids.p; q.active = c->active.p; q.done_count = c->done_count.p;
-    q.temperature = sp->temperature > 0 ? sp->temperature : 0.0f; q.top_p = 1.0f; q.penalty = 0.0f; q.seed = sp->seed;
+    q.temperature = sp->temperature > 0 ? sp->temperature : 0.0f; q.top_p = 1.0f; q.penalty = 0.0f; q.seed = sp->seed; q.row_offset = sp->row_offset;
     q.lo = 0; q.hi = (sp->timestamp_begin > 0 && sp->timestamp_begin < c->V) ? sp->timestamp_begin : c->V;   // suppressFromIndex
     q.eos_id = sp->eot_id; q.max_tokens = max_tokens;
     PinnedBuf<int32_t> done_pin(1);

@@ -33,14 +33,14 @@ class GenerateParameters:
     repetition_penalty: float = 1.3
     repetition_context_size: int = 20
     seed: int = 0                    # engine RNG key (MLX uses its global stream)
-    frame_constrained: bool = False  # synthetic-weight benches only (see include/mi_speech.h)
+    frame_constrained: int | bool = False  # synthetic-weight benches only: 1 / True narrow sampler, 2 full-vocabulary sampler (mi_speech.h)
     row_offset: int = 0
     sampler_flavor: int = 0          # 0 mlx-lm sampler + RepetitionContext; 1 Soprano (Soprano.swift:888-901)
 
     def to_c(self) -> "_lib.GenParamsC":
         return _lib.GenParamsC(int(self.max_tokens), float(self.temperature), float(self.top_p),
                                float(self.repetition_penalty or 0.0), int(self.repetition_context_size), int(self.seed),
-                               1 if self.frame_constrained else 0, int(self.row_offset), int(self.sampler_flavor), 0)
+                               int(self.frame_constrained), int(self.row_offset), int(self.sampler_flavor), 0)
 
 
 @dataclass

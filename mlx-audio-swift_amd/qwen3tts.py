@@ -417,7 +417,7 @@ class Qwen3TTSModel:
         return buf[: B * ch.value * ln.value].reshape(B, ch.value, ln.value).copy()
 
     def generate_batch(self, prompts, generation_parameters: Qwen3TTSGenerateParameters | None = None, return_codes: bool = False,
-                       streaming_interval: float | None = None, on_audio=None):
+                       streaming_interval: float | None = None, on_audio=None, replicas=None):
         """generateVoiceDesign for a batch of prepared prompts: list of 1-D float32 PCM arrays.  With `on_audio` the decoded
         audio is also delivered in chunks of streaming_interval * 12.5 frames (Qwen3TTS.swift:394-395)."""
         gp = generation_parameters or self.default_generation_parameters
@@ -436,9 +436,15 @@ class Qwen3TTSModel:
                 on_audio(row, np.ctypeslib.as_array(C.cast(payload, C.POINTER(C.c_float)), shape=(n,)).copy())
         cbc = _lib.EVENT_CB(cb) if on_audio is not None else C.cast(None, _lib.EVENT_CB)
         keep.append(cbc)
-        check(_lib.lib().mis_qwen3tts_generate(self._h, t.ctypes.data, c.ctypes.data, pl.ctypes.data, P, tr.ctypes.data, tl.ctypes.data,
-                                               Tt, B, C.byref(gpc), caps.ctypes.data, C.byref(pcm), C.byref(stride), plens,
-                                               C.byref(codes), C.byref(cstride), nf, chunk, cbc, None, None))
+        if replicas:          # Qwen3TTSModel objects with the same weights, one per GPU: rows sharded inside the library, each replica
+            hs = (C.c_void_p * len(replicas))(*[r._h for r in replicas])          # streams its own rows' chunks (global row indices)
+            check(_lib.lib().mis_qwen3tts_group_generate(hs, len(replicas), t.ctypes.data, c.ctypes.data, pl.ctypes.data, P, tr.ctypes.data,
+                                                         tl.ctypes.data, Tt, B, C.byref(gpc), caps.ctypes.data, C.byref(pcm), C.byref(stride),
+                                                         plens, C.byref(codes), C.byref(cstride), nf, chunk, cbc, None, None))
+        else:
+            check(_lib.lib().mis_qwen3tts_generate(self._h, t.ctypes.data, c.ctypes.data, pl.ctypes.data, P, tr.ctypes.data, tl.ctypes.data,
+                                                   Tt, B, C.byref(gpc), caps.ctypes.data, C.byref(pcm), C.byref(stride), plens,
+                                                   C.byref(codes), C.byref(cstride), nf, chunk, cbc, None, None))
         try:
             arr = np.ctypeslib.as_array(C.cast(pcm, C.POINTER(C.c_float)), shape=(B, max(stride.value, 1)))
             out = [arr[b, : plens[b]].copy() for b in range(B)]

@@ -225,7 +225,7 @@ class SopranoModel:
         return np.asarray(ids, np.int32)
 
     def generate_batch(self, prompt_rows, generation_parameters: GenerateParameters | None = None,
-                       return_tokens: bool = False):
+                       return_tokens: bool = False, replicas=None):
         """One generate per tokenised sentence prompt, batched: list of 1-D float32 arrays.  More rows than the engine's
         per-call maximum run in slices of MAX_BATCH (the reference loops sentence by sentence, Soprano.swift:637-676);
         the RNG is keyed by the global row index, so slicing does not change any row."""
@@ -234,7 +234,7 @@ class SopranoModel:
             from dataclasses import replace
             outs, toks_all = [], []
             for i in range(0, len(prompt_rows), MAX_BATCH):
-                r = self.generate_batch(prompt_rows[i:i + MAX_BATCH], replace(gp, row_offset=gp.row_offset + i), return_tokens)
+                r = self.generate_batch(prompt_rows[i:i + MAX_BATCH], replace(gp, row_offset=gp.row_offset + i), return_tokens, replicas)
                 if return_tokens:
                     outs += r[0]; toks_all += r[1]
                 else:
@@ -246,9 +246,15 @@ class SopranoModel:
         gpc.sampler_flavor = 1
         pcm = C.c_void_p(); stride = C.c_int64(); plens = (C.c_int64 * B)()
         toks = C.c_void_p(); tstride = C.c_int64(); ntok = (C.c_int32 * B)()
-        check(_lib.lib().mis_soprano_generate(self._h, flat.ctypes.data, lens.ctypes.data, B, C.byref(gpc), C.byref(pcm),
-                                              C.byref(stride), plens, C.byref(toks) if return_tokens else None,
-                                              C.byref(tstride), ntok))
+        if replicas:          # SopranoModel objects with the same weights, one per GPU: rows sharded inside the library
+            hs = (C.c_void_p * len(replicas))(*[r._h for r in replicas])
+            check(_lib.lib().mis_soprano_group_generate(hs, len(replicas), flat.ctypes.data, lens.ctypes.data, B, C.byref(gpc), C.byref(pcm),
+                                                        C.byref(stride), plens, C.byref(toks) if return_tokens else None,
+                                                        C.byref(tstride), ntok))
+        else:
+            check(_lib.lib().mis_soprano_generate(self._h, flat.ctypes.data, lens.ctypes.data, B, C.byref(gpc), C.byref(pcm),
+                                                  C.byref(stride), plens, C.byref(toks) if return_tokens else None,
+                                                  C.byref(tstride), ntok))
         try:
             arr = np.ctypeslib.as_array(C.cast(pcm, C.POINTER(C.c_float)), shape=(B, max(stride.value, 1)))
             out = [arr[b, : plens[b]].copy() for b in range(B)]

@@ -169,8 +169,10 @@ class WhisperModel:
         return out
 
     # -- generate ------------------------------------------------------------------------------------
-    def transcribe_windows(self, windows, prompt_ids, params: STTGenerateParameters):
-        """transcribeChunk for a batch of <= 30 s windows: list of 1-D float arrays -> list of token-id lists."""
+    def transcribe_windows(self, windows, prompt_ids, params: STTGenerateParameters, replicas=None):
+        """transcribeChunk for a batch of <= 30 s windows: list of 1-D float arrays -> list of token-id lists.
+        replicas: WhisperModel objects holding the same weights, one per GPU (self included): the windows are sharded over them
+        inside the library (mis_whisper_group_generate) and the token ids gathered in window order."""
         B = len(windows)
         stride = max(1, max(len(w) for w in windows))
         pcm = np.zeros((B, stride), np.float32)
@@ -188,8 +190,13 @@ class WhisperModel:
                              int(params.timestamp_begin), sup.ctypes.data if len(sup) else None, len(sup),
                              bsup.ctypes.data if len(bsup) else None, len(bsup))
         toks = C.c_void_p(); ts = C.c_int64(); nt = (C.c_int32 * B)()
-        check(_lib.lib().mis_stt_whisper_generate(self._h, pcm.ctypes.data, lens.ctypes.data, B, stride, prompt.ctypes.data,
-                                                  len(prompt), C.byref(sp), C.byref(toks), C.byref(ts), nt))
+        if replicas:
+            hs = (C.c_void_p * len(replicas))(*[r._h for r in replicas])
+            check(_lib.lib().mis_whisper_group_generate(hs, len(replicas), pcm.ctypes.data, lens.ctypes.data, B, stride, prompt.ctypes.data,
+                                                        len(prompt), C.byref(sp), C.byref(toks), C.byref(ts), nt))
+        else:
+            check(_lib.lib().mis_stt_whisper_generate(self._h, pcm.ctypes.data, lens.ctypes.data, B, stride, prompt.ctypes.data,
+                                                      len(prompt), C.byref(sp), C.byref(toks), C.byref(ts), nt))
         try:
             arr = np.ctypeslib.as_array(C.cast(toks, C.POINTER(C.c_int32)), shape=(B, max(ts.value, 1)))
             return [arr[b, : nt[b]].tolist() for b in range(B)]

@@ -77,15 +77,15 @@ def test_orpheus_3b_full_depth_28_layers_and_error_growth():
                          floor_rms_last_pos=last_floor)
         record(f"orpheus3b_depth_{L}_layers", layers=L, logits_max_rel=e_max, logits_rms_rel=e_rms, oracle_f64_floor_max_rel=f_max,
                oracle_f64_floor_rms_rel=f_rms, logits_rms_rel_last_pos=last_rms, floor_rms_rel_last_pos=last_floor,
-               gate=f"dev <= {FLOOR_FACTOR} x floor (+1e-3)")
-    for L, g in growth.items():
-        assert g["dev_rms"] <= FLOOR_FACTOR * g["floor_rms"] + 1e-3, (L, g)
-        assert g["dev_max"] <= FLOOR_FACTOR * g["floor_max"] + 2e-3, (L, g)
+               gate=f"rms: dev <= {FLOOR_FACTOR} x floor (+1e-3); max: absolute")
+    for L, g in growth.items():          # (rms against the floor; the max error is one or two bf16 ulps of the largest logit on either side
+        assert g["dev_rms"] <= FLOOR_FACTOR * g["floor_rms"] + 1e-3, (L, g)       # and is bounded absolutely below)
     # absolute bounds at the benchmarked depth: twice the values observed on MI355X (profiles/r03_parity_observed.json: 28 layers
     # rms 0.0327 / max 0.0148 against the oracle's own float64 floor of 0.0321 / 0.0129; 8 layers 0.0176 vs 0.0170; 2 layers 0.0062 vs
     # 0.0058 - the device sits AT the floor at every depth, and the error grows like the floor does, ~ sqrt(layers))
     assert growth[28]["dev_rms"] <= 0.066 and growth[28]["dev_max"] <= 0.03, growth[28]
     assert growth[8]["dev_rms"] <= 0.036 and growth[2]["dev_rms"] <= 0.013, growth
+    assert growth[8]["dev_max"] <= 0.016 and growth[2]["dev_max"] <= 0.016, growth
 
 
 def test_batched_prefill_at_orpheus_3b_width_b32_m1024(monkeypatch):

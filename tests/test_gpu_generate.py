@@ -297,10 +297,12 @@ def test_rccl_communicator_world1_all_gather_is_the_identity():
     comm.close()
 
 
-def test_unconstrained_generate_full_vocabulary_sampler_paths_agree(monkeypatch):
-    """Real Orpheus decoding is not frame-constrained: every step samples over the whole 156 940-id vocabulary.  The one-launch
-    sampler (k_samp_cluster) replayed inside the step graph - the same per-row exchange area step after step - returns the tokens
-    of the six-kernel path (both are pinned on the oracle in test_gpu_sampler.py)."""
+def test_full_vocabulary_sampler_paths_agree_inside_generate(monkeypatch):
+    """Real Orpheus decoding is not frame-constrained: every step samples over the whole 156 940-id vocabulary (with random weights
+    that yields no frames at all - `No audio codes generated`, like the reference).  frame_constrained = 2 keeps the frame range but
+    sends it through the full-vocabulary kernels: the one-launch sampler (k_samp_cluster) replayed inside the step graph - the same
+    per-row exchange area step after step - returns the tokens of the six-kernel path (MIS_SAMPLER_WIDE=1) and of the narrow
+    single-launch sampler (frame_constrained = 1); all three are pinned on the oracle in test_gpu_sampler.py."""
     cfg = mas.LlamaTTSConfiguration(hidden_size=256, num_hidden_layers=2, intermediate_size=512, num_attention_heads=2,
                                     num_key_value_heads=1, head_dim=128, vocab_size=156940, rope_theta=500000.0)
     snac_cfg = mas.SNACConfig(**SNAC_SMALL)
@@ -310,11 +312,15 @@ def test_unconstrained_generate_full_vocabulary_sampler_paths_agree(monkeypatch)
     rng = np.random.default_rng(3)
     prompts = _prompts(rng, [9, 14, 6, 11, 8])
     toks = {}
-    for mode, n in (("0", 40), ("1", 41)):                    # different token budgets: the step graph is captured again per mode
-        monkeypatch.setenv("MIS_SAMPLER_WIDE", mode)
-        gp = mas.GenerateParameters(max_tokens=n, temperature=0.6, top_p=0.8, repetition_penalty=1.3, seed=11, frame_constrained=False)
+    for name, mode, fc, n in (("cluster", "0", 2, 42), ("six", "1", 2, 49), ("narrow", "0", 1, 56)):
+        monkeypatch.setenv("MIS_SAMPLER_WIDE", mode)           # (different token budgets: the step graph is captured again per path)
+        gp = mas.GenerateParameters(max_tokens=n, temperature=0.6, top_p=0.8, repetition_penalty=1.3, seed=11, frame_constrained=fc)
         _, t = lm.generate_batch(prompts, gp, return_tokens=True)
-        toks[mode] = t
+        toks[name] = t
     for r in range(len(prompts)):
-        n = min(len(toks["0"][r]), 40)
-        assert n > 0 and np.array_equal(toks["0"][r][:n], toks["1"][r][:n]), r
+        assert len(toks["cluster"][r]) == 42
+        assert np.array_equal(toks["cluster"][r], toks["six"][r][:42]) and np.array_equal(toks["cluster"][r], toks["narrow"][r][:42]), r
+    monkeypatch.setenv("MIS_SAMPLER_WIDE", "0")
+    with pytest.raises(mas.AudioGenerationError) as e:         # unconstrained + random weights: no frame survives parseOutput (:754-756)
+        lm.generate_batch(prompts, mas.GenerateParameters(max_tokens=14, temperature=0.6, top_p=0.8, repetition_penalty=1.3, seed=11))
+    assert "No audio codes" in str(e.value)

@@ -381,3 +381,60 @@ def test_from_model_directory_quantised_checkpoint_and_pytorch_layout_tokenizer(
         assert np.array_equal(a[1][r], b[1][r]) and np.array_equal(a[0][r], b[0][r])
     with pytest.raises(mas.AudioGenerationError):
         mas.Qwen3TTSModel.from_pretrained("mlx-community/Qwen3-TTS-12Hz-0.6B-Base-8bit")          # no network: local directories only
+
+
+def test_generate_beyond_300_frames_decodes_like_decode_chunk_and_trims_to_valid_len():
+    """Non-streaming generate = decodeChunk (Qwen3TTS.swift:214-231): streamingDecode(chunkTokens: 300) - carried-state steps of 300
+    frames from a fresh state, i.e. the reference's doubled block bias right behind frame 300 / 600 - followed by the validLen trim
+    (frames whose first code is > 0, times the upsample rate).  Two ragged rows past 300 frames (one past 600 would be slow on the
+    oracle: 330 and 305); the oracle decodes the ENGINE's codes the same way.  In exact mode the same call equals the
+    whole-sequence decode."""
+    cfg, dev, olm, odec = _pair()
+    rng = np.random.default_rng(8)
+    prompts = [_prompt(cfg, rng, 6, 2), _prompt(cfg, rng, 4, 3)]
+    gp = mas.Qwen3TTSGenerateParameters(max_tokens=330, temperature=0.9, top_k=50, repetition_penalty=1.05, seed=21)
+    rows = [mas.PreparedPrompt(p.text_ids, p.codec_ids, p.trailing_ids, t) for p, t in zip(prompts, (55, 51))]   # caps 6 x 55 = 330, 306
+    pcm, codes = dev.generate_batch(rows, gp, return_codes=True)
+    up = cfg.decoder.total_upsample
+    assert max(len(c) for c in codes) > 300, [len(c) for c in codes]        # (rows may end early on EOS; one at least runs past 300)
+    for r in range(2):
+        n = len(codes[r])
+        ref = _oracle_stream(odec, codes[r].T[None], [300])[0]
+        valid = int((codes[r][:, 0] > 0).sum()) * up
+        want = valid if 0 < valid < n * up else n * up
+        assert len(pcm[r]) == want, (r, len(pcm[r]), want)
+        assert np.abs(pcm[r] - ref[:want]).max() <= 5e-4 * max(np.abs(ref).max(), 1e-3)
+        if n > 300:
+            whole = odec.decode(codes[r].T[None])[0]
+            assert np.abs(ref[300 * up:300 * up + 64] - whole[300 * up:300 * up + 64]).max() > 0     # the boundary quirk is really there
+    dev.set_stream_exact(True)
+    try:
+        pcm_x, codes_x = dev.generate_batch(rows, gp, return_codes=True)
+    finally:
+        dev.set_stream_exact(False)
+    for r in range(2):
+        assert np.array_equal(codes_x[r], codes[r])
+        whole = odec.decode(codes[r].T[None])[0]
+        assert np.abs(pcm_x[r] - whole[:len(pcm_x[r])]).max() <= 5e-4 * max(np.abs(whole).max(), 1e-3)
+
+
+def test_group_of_two_logical_shards_streams_per_replica_and_returns_the_unsharded_rows():
+    """mis_qwen3tts_group_generate (BASELINE configs[4]: streaming generateStream sharded over the GPUs of a node): three rows over
+    two replicas (same weights, one GPU).  Codes and samples equal the single-handle call; with a callback every replica streams its
+    own rows' chunks under their GLOBAL row index, and a row's chunks concatenate to its pcm."""
+    cfg, dev, _, _ = _pair()
+    _, dev2, _, _ = _pair()
+    rng = np.random.default_rng(4)
+    prompts = [_prompt(cfg, rng, 7, 2), _prompt(cfg, rng, 5, 4), _prompt(cfg, rng, 6, 1)]
+    gp = mas.Qwen3TTSGenerateParameters(max_tokens=9, temperature=0.9, top_k=50, repetition_penalty=1.05, seed=5)
+    pcm, codes = dev.generate_batch(prompts, gp, return_codes=True)
+    pcm2, codes2 = dev.generate_batch(prompts, gp, return_codes=True, replicas=[dev, dev2])
+    for r in range(3):
+        assert np.array_equal(codes[r], codes2[r]) and np.array_equal(pcm[r], pcm2[r]), r
+    got = {0: [], 1: [], 2: []}
+    pcm3 = dev.generate_batch(prompts, gp, streaming_interval=0.32, on_audio=lambda row, a: got[row].append(a), replicas=[dev, dev2])
+    single = {0: [], 1: [], 2: []}
+    pcm4 = dev.generate_batch(prompts, gp, streaming_interval=0.32, on_audio=lambda row, a: single[row].append(a))
+    for r in range(3):
+        assert len(got[r]) == len(single[r]) >= 2
+        assert np.array_equal(np.concatenate(got[r]), pcm3[r]) and np.array_equal(pcm3[r], pcm4[r]), r

@@ -198,3 +198,18 @@ def test_generate_stream_event_order_and_cancel():
     with pytest.raises(mas.AudioGenerationError) as e:
         list(dev.generate_stream_batch(prompts, long_gp, cancel_flag=C.c_int(1)))
     assert e.value.case == "cancelled"
+
+
+def test_group_of_two_logical_shards_returns_the_unsharded_audio():
+    """mis_soprano_group_generate: sentence prompts sharded over two replicas (same weights, one GPU) - tokens and samples of every
+    row equal the single-handle call (sampler RNG keyed by the global row)."""
+    cfg, dev, _, _ = _pair()
+    _, dev2, _, _ = _pair()
+    rng = np.random.default_rng(2)
+    rows = [rng.integers(10, 400, n).astype(np.int32) for n in (7, 12, 5, 9, 6)]
+    gp = mas.GenerateParameters(max_tokens=6, temperature=0.7, top_p=0.95, repetition_penalty=1.5, repetition_context_size=30, seed=3,
+                                sampler_flavor=1)
+    pcm, toks = dev.generate_batch(rows, gp, return_tokens=True)
+    pcm2, toks2 = dev.generate_batch(rows, gp, return_tokens=True, replicas=[dev, dev2])
+    for r in range(len(rows)):
+        assert np.array_equal(toks[r], toks2[r]) and np.array_equal(pcm[r], pcm2[r]), r

@@ -271,3 +271,21 @@ def test_generate_stream_tokens_then_result_and_mlx_directory_loader(tmp_path):
     hf = mas.WhisperModel.from_weights(hc, W2)
     gp3 = mas.STTGenerateParameters(max_tokens=10, temperature=0.0, eot_id=599, timestamp_begin=560, suppress_tokens=[1, 2, 3])
     assert loaded.transcribe_windows(wins, prompt, gp3) == hf.transcribe_windows(wins, prompt, gp3)
+
+
+def test_group_of_two_logical_shards_returns_the_unsharded_tokens():
+    """mis_whisper_group_generate (BASELINE configs[3]: 30 s chunks sharded over the GPUs of a node): two replicas with the same
+    weights on ONE GPU stand in for two devices; five windows split 3 + 2; greedy and sampled (RNG keyed by the global window)."""
+    cfg = ow.TINY
+    a = mas.WhisperModel.synthetic(_host_cfg(cfg), seed=777)
+    b = mas.WhisperModel.synthetic(_host_cfg(cfg), seed=777)
+    rng = np.random.default_rng(14)
+    wins = [(0.1 * rng.standard_normal(16000 * n)).astype(np.float32) for n in (3, 1, 2, 4, 2)]
+    prompt = [590, 591, 592, 593]
+    for temp in (0.0, 0.8):
+        gp = mas.STTGenerateParameters(max_tokens=10, temperature=temp, seed=5, eot_id=599, timestamp_begin=560)
+        whole = a.transcribe_windows(wins, prompt, gp)
+        sharded = a.transcribe_windows(wins, prompt, gp, replicas=[a, b])
+        assert sharded == whole, temp
+    with pytest.raises(mas.AudioGenerationError):
+        a.transcribe_windows(wins[:1], prompt, gp, replicas=[a, b])          # fewer rows than replicas
