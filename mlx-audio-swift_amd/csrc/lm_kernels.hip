@@ -506,6 +506,34 @@ __device__ __forceinline__ void gemm_epilogue(const f32x4_t (&acc)[R][MT], void*
                 *reinterpret_cast<uint2*>(o + off) = v;
             }
         }
+    } else if (EPI == EPI_RESID) {
+        // residual stream updated in place by the producer (no inter-block split-K): h = T(h + T(acc [+ b]))  (LlamaTTS.swift:308-309)
+        bf16_t* o = reinterpret_cast<bf16_t*>(out);
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            int tile = ntg * R + r;
+            if (tile >= NT) continue;
+            float bv[4] = {0.f, 0.f, 0.f, 0.f};
+            if (bias) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) bv[e] = bf16_to_f32(bias[tile * 16 + nl + e]);
+            }
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+                if (mt_only >= 0 && mt != mt_only) continue;
+                const size_t off = ((size_t)mt * 16 + ml) * N_out + tile * 16 + nl;
+                const uint2 hv = *reinterpret_cast<const uint2*>(o + off);
+                const float h4[4] = {bf16_to_f32((bf16_t)(hv.x & 0xffffu)), bf16_to_f32((bf16_t)(hv.x >> 16)), bf16_to_f32((bf16_t)(hv.y & 0xffffu)),
+                                     bf16_to_f32((bf16_t)(hv.y >> 16))};
+                uint16_t res[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) res[e] = f32_to_bf16(h4[e] + bf16_round_f32(acc[r][mt][e] + bv[e]));
+                uint2 v;
+                v.x = (uint32_t)res[0] | ((uint32_t)res[1] << 16);
+                v.y = (uint32_t)res[2] | ((uint32_t)res[3] << 16);
+                *reinterpret_cast<uint2*>(o + off) = v;
+            }
+        }
     } else {   // EPI_SILU_MUL: tile 2t = gate rows, 2t+1 = up rows  (LlamaTTS.swift:283)
         bf16_t* o = reinterpret_cast<bf16_t*>(out);
 #pragma unroll
@@ -673,6 +701,176 @@ __global__ void __launch_bounds__(256, 2) k_gemm_skinny(const bf16_t* __restrict
     }
 }
 
+// ---------------------------------------------------------------------------- the same GEMM with the RMSNorm as its PROLOGUE
+//
+// Small models (hidden size <= 1024: Qwen3-TTS talker / code predictor, Soprano) spend their decode step on kernel boundaries, not on
+// bytes: ~4.8 us per launch whatever it does.  Two of a block's seven launches are the glue kernel (slab sum + residual +
+// RMSNorm).  In the fused chain both halves of it move into the neighbouring GEMMs:
+//   * the PRODUCER (o_proj / down_proj, no inter-block split-K) adds the residual in its epilogue, in place: h = T(h + T(acc))
+//     (EPI_RESID of k_gemm_skinny; nobody else touches h during that launch);
+//   * every block of the CONSUMER (q|k|v, gate|up) rebuilds its whole X operand from h in registers,
+//         x = T(w . T(h . rsqrt(mean h^2 + eps)))                          (LlamaTTS.swift:306, the glue kernel's rounding points)
+//     wave w of the block owns the k-tiles [w XT, (w+1) XT) of all Mpad rows: its 16-byte loads of h ARE the MFMA B fragments (lane
+//     (j, q) of fragment (kt, mt) holds row 16 mt + j, columns 32 kt + 8 q ..+8), the row sums of squares meet through LDS (fixed
+//     order), and the weight tiles of the wave's whole K range (XT x R KiB) are requested BEFORE that arithmetic, so the stream is
+//     in flight while the prologue computes.
+// Redundant per consumer block (64 KB of L2 reads, ~0.5 us of VALU work at hidden 1024 and 32 rows) - and a launch less, twice per
+// layer: 7 -> 5 launches.
+template <int MT, int R, int EPI, int XT>
+__global__ void __launch_bounds__(256, 2) k_gemm_norm(const bf16_t* __restrict__ Wp, const bf16_t* __restrict__ h, const bf16_t* __restrict__ wnorm,
+                                                     void* __restrict__ out, int NT, int KT, int N_out, int Mpad, float eps,
+                                                     const bf16_t* __restrict__ bias) {
+    static_assert(EPI != EPI_SILU_MUL || R == 2, "silu-mul epilogue pairs a gate tile with an up tile");
+    constexpr int KSB = 4;
+    __shared__ float rsum[KSB][MT * 16];
+    __shared__ float4 red[KSB][R * MT][64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int ntg = blockIdx.x;
+    const int d = KT * 32;
+    const int kt0 = wave * XT;                                   // this wave's k-tiles kt0 .. kt0 + XT - 1 (those >= KT contribute nothing)
+    const int j = lane & 15, q = lane >> 4;
+    // ---- weights of the whole K range of this wave: requested first
+    bf16x8_t wv[XT][R];
+#pragma unroll
+    for (int u = 0; u < XT; ++u) {
+        int kk = kt0 + u;
+        kk = kk < KT ? kk : KT - 1;
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            int tile = ntg * R + r;
+            tile = tile < NT ? tile : NT - 1;
+            wv[u][r] = __builtin_nontemporal_load(reinterpret_cast<const bf16x8_t*>(Wp) + ((size_t)tile * KT + kk) * 64 + lane);
+        }
+    }
+    // ---- the residual stream and the norm weight of the wave's columns
+    uint4 hq[XT][MT], wq[XT];
+#pragma unroll
+    for (int u = 0; u < XT; ++u) {
+        int kk = kt0 + u;
+        kk = kk < KT ? kk : KT - 1;
+        const int k0 = kk * 32 + q * 8;
+        wq[u] = *reinterpret_cast<const uint4*>(wnorm + k0);
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) hq[u][mt] = *reinterpret_cast<const uint4*>(h + (size_t)(mt * 16 + j) * d + k0);
+    }
+    // ---- row sums of squares: lane partials -> the four lanes of a row -> the four waves (LDS, fixed order)
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+        float v = 0.0f;
+#pragma unroll
+        for (int u = 0; u < XT; ++u) {
+            const uint32_t hw[4] = {hq[u][mt].x, hq[u][mt].y, hq[u][mt].z, hq[u][mt].w};
+            float t = 0.0f;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float h0 = bf16_to_f32((bf16_t)(hw[e] & 0xffffu)), h1 = bf16_to_f32((bf16_t)(hw[e] >> 16));
+                t += h0 * h0 + h1 * h1;
+            }
+            v += (kt0 + u < KT) ? t : 0.0f;
+        }
+        v += __shfl_xor(v, 16, 64);
+        v += __shfl_xor(v, 32, 64);
+        if (q == 0) rsum[wave][mt * 16 + j] = v;
+    }
+    __syncthreads();
+    // ---- x fragments in registers
+    bf16x8_t xr[XT][MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+        const float tot = ((rsum[0][mt * 16 + j] + rsum[1][mt * 16 + j]) + rsum[2][mt * 16 + j]) + rsum[3][mt * 16 + j];
+        const float inv = 1.0f / sqrtf(tot / (float)d + eps);
+#pragma unroll
+        for (int u = 0; u < XT; ++u) {
+            const uint32_t ww[4] = {wq[u].x, wq[u].y, wq[u].z, wq[u].w};
+            const uint32_t hw[4] = {hq[u][mt].x, hq[u][mt].y, hq[u][mt].z, hq[u][mt].w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float w0 = bf16_to_f32((bf16_t)(ww[e] & 0xffffu)), w1 = bf16_to_f32((bf16_t)(ww[e] >> 16));
+                const float n0 = bf16_to_f32((bf16_t)(hw[e] & 0xffffu)), n1 = bf16_to_f32((bf16_t)(hw[e] >> 16));
+                xr[u][mt][2 * e] = (short)f32_to_bf16(w0 * bf16_round_f32(n0 * inv));
+                xr[u][mt][2 * e + 1] = (short)f32_to_bf16(w1 * bf16_round_f32(n1 * inv));
+            }
+        }
+    }
+    // ---- the product over this wave's K range
+    f32x4_t acc[R][MT];
+#pragma unroll
+    for (int r = 0; r < R; ++r)
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) acc[r][mt] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int u = 0; u < XT; ++u)
+        if (kt0 + u < KT) {
+#pragma unroll
+            for (int r = 0; r < R; ++r)
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt)
+                    acc[r][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wv[u][r], xr[u][mt], acc[r][mt], 0, 0, 0);
+        }
+    // ---- in-block split-K combine (fixed order) + epilogue, as k_gemm_skinny
+#pragma unroll
+    for (int r = 0; r < R; ++r)
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+            red[wave][r * MT + mt][lane] = make_float4(acc[r][mt][0], acc[r][mt][1], acc[r][mt][2], acc[r][mt][3]);
+    __syncthreads();
+    for (int mt = wave; mt < MT; mt += KSB) {
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            float4 s0 = red[0][r * MT + mt][lane];
+#pragma unroll
+            for (int w = 1; w < KSB; ++w) {
+                float4 t = red[w][r * MT + mt][lane];
+                s0.x += t.x; s0.y += t.y; s0.z += t.z; s0.w += t.w;
+            }
+#pragma unroll
+            for (int m2 = 0; m2 < MT; ++m2)
+                if (m2 == mt) acc[r][m2] = (f32x4_t){s0.x, s0.y, s0.z, s0.w};
+        }
+        gemm_epilogue<MT, R, EPI>(acc, out, ntg, 0, NT, N_out, Mpad, lane, mt, bias);
+    }
+}
+// hidden size limit of the fused form: XT <= 8 k-tiles per wave, four waves per block (hidden size <= 1024)
+bool gemm_norm_supported(int d, int Mpad) { return d % 32 == 0 && d / 32 <= 32 && (Mpad == 16 || Mpad == 32); }
+void launch_gemm_norm(int epi, const bf16_t* Wp, const bf16_t* h, const bf16_t* wnorm, void* out, int NT, int KT, int N_out, int Mpad, float eps,
+                      hipStream_t s, const bf16_t* bias) {
+    MIS_REQUIRE(gemm_norm_supported(KT * 32, Mpad), MIS_ERR_GENERATION_FAILED, "fused norm GEMM: unsupported shape (hidden %d, rows %d)", KT * 32, Mpad);
+    const int R = 2;
+    const int xt = (KT + 3) / 4;
+    dim3 grid((NT + R - 1) / R), block(256);
+#define GN_CASE(MTV, E, XTV)                                                                                                        \
+    if (Mpad == 16 * MTV && epi == E && xt <= XTV) {                                                                                \
+        hipLaunchKernelGGL((k_gemm_norm<MTV, 2, E, XTV>), grid, block, 0, s, Wp, h, wnorm, out, NT, KT, N_out, Mpad, eps, bias);      \
+        return;                                                                                                                     \
+    }
+#define GN_EPI(MTV, XTV) GN_CASE(MTV, EPI_PARTIAL, XTV) GN_CASE(MTV, EPI_BF16, XTV) GN_CASE(MTV, EPI_SILU_MUL, XTV)
+    GN_EPI(2, 4) GN_EPI(2, 8) GN_EPI(1, 4) GN_EPI(1, 8)
+#undef GN_EPI
+#undef GN_CASE
+    throw MisError(MIS_ERR_GENERATION_FAILED, "fused norm GEMM: unsupported variant");
+}
+// x = RMSNorm(h) w as packed fragments: what is left of the glue kernel at the END of a fused chain (the final norm in front of the
+// head, read by lm_head and by the hidden-state taps)
+__global__ void __launch_bounds__(1024) k_norm_pack(const bf16_t* __restrict__ h, int Mpad, int N, const bf16_t* __restrict__ wnorm,
+                                                    bf16_t* __restrict__ x, float eps) {
+    __shared__ float red[16];
+    const int m = blockIdx.x, tid = threadIdx.x, nth = blockDim.x, MT = Mpad >> 4;
+    float ss = 0.0f;
+    for (int i = tid; i < N; i += nth) { const float hv = bf16_to_f32(h[(size_t)m * N + i]); ss += hv * hv; }
+    ss = wave_sum_dpp(ss);
+    if ((tid & 63) == 0) red[tid >> 6] = ss;
+    __syncthreads();
+    float tot = 0.0f;
+    for (int i = 0; i < (nth >> 6); ++i) tot += red[i];
+    const float inv = 1.0f / sqrtf(tot / (float)N + eps);
+    for (int i = tid; i < N; i += nth)
+        x[xpk_index(m, i, MT)] = f32_to_bf16(bf16_to_f32(wnorm[i]) * bf16_round_f32(bf16_to_f32(h[(size_t)m * N + i]) * inv));
+}
+void launch_norm_pack(const bf16_t* h, int Mpad, int N, const bf16_t* wnorm, bf16_t* x, float eps, hipStream_t s) {
+    const int nth = std::min(1024, ((N + 63) / 64) * 64);
+    hipLaunchKernelGGL(k_norm_pack, dim3(Mpad), dim3(nth), 0, s, h, Mpad, N, wnorm, x, eps);
+}
+
 template <int MT>
 static void launch_gemm_mt(int epi, int R, int ksb, const bf16_t* Wp, const bf16_t* X, void* out, int NT, int KT, int S,
                            int N_out, int Mpad, const bf16_t* bias, hipStream_t s) {
@@ -696,6 +894,8 @@ static void launch_gemm_mt(int epi, int R, int ksb, const bf16_t* Wp, const bf16
     GEMM_CASE(EPI_GELU_PACKED, 1, 4)
     GEMM_CASE(EPI_BF16, 1, 4)
     GEMM_CASE(EPI_SILU_PACKED, 2, 4)
+    GEMM_CASE(EPI_RESID, 2, 4)
+    GEMM_CASE(EPI_RESID, 1, 4)
 #undef GEMM_CASE
     throw MisError(MIS_ERR_GENERATION_FAILED, "unsupported GEMM variant");
 }

@@ -389,10 +389,18 @@ def test_generate_beyond_300_frames_decodes_like_decode_chunk_and_trims_to_valid
     (frames whose first code is > 0, times the upsample rate).  Two ragged rows past 300 frames (one past 600 would be slow on the
     oracle: 330 and 305); the oracle decodes the ENGINE's codes the same way.  In exact mode the same call equals the
     whole-sequence decode."""
-    cfg, dev, olm, odec = _pair()
+    # EOS out of reach: greedy decoding, and the EOS row of the codec head is zeroed (logit 0 against a maximum of a few sigma)
+    ocfg = oq.TINY
+    W = oq.make_synthetic_weights(ocfg)
+    Wd = oq.make_synthetic_decoder_weights(ocfg.decoder)
+    W = {k: torch.as_tensor(v).clone() for k, v in W.items()}
+    W["codec_head.weight"][ocfg.codec_eos_token_id] = 0
+    allw = {("talker." + k): v for k, v in W.items()}
+    allw.update(Wd)
+    cfg, dev, odec = ocfg, mas.Qwen3TTSModel.from_weights(_host_cfg(ocfg), allw), oq.SpeechDecoderOracle(ocfg.decoder, Wd)
     rng = np.random.default_rng(8)
     prompts = [_prompt(cfg, rng, 6, 2), _prompt(cfg, rng, 4, 3)]
-    gp = mas.Qwen3TTSGenerateParameters(max_tokens=330, temperature=0.9, top_k=50, repetition_penalty=1.05, seed=21)
+    gp = mas.Qwen3TTSGenerateParameters(max_tokens=330, temperature=0.0, repetition_penalty=1.05, seed=21)
     rows = [mas.PreparedPrompt(p.text_ids, p.codec_ids, p.trailing_ids, t) for p, t in zip(prompts, (55, 51))]   # caps 6 x 55 = 330, 306
     pcm, codes = dev.generate_batch(rows, gp, return_codes=True)
     up = cfg.decoder.total_upsample
