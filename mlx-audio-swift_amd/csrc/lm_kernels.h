@@ -39,6 +39,8 @@ bool gemm_norm_supported(int d, int Mpad);
 void launch_gemm_norm(int epi, const bf16_t* Wp, const bf16_t* h, const bf16_t* wnorm, void* out, int NT, int KT, int N_out, int Mpad, float eps,
                       hipStream_t s, const bf16_t* bias = nullptr);
 void launch_norm_pack(const bf16_t* h, int Mpad, int N, const bf16_t* wnorm, bf16_t* x, float eps, hipStream_t s);
+void launch_gemm_norm_q(int bits, int epi, const void* Qp, const bf16_t* SB, const bf16_t* h, const bf16_t* wnorm, void* out, int NT, int G, int N_out,
+                        int Mpad, float eps, hipStream_t s, const bf16_t* bias = nullptr);
 
 // the same on MLX affine-quantised weights (lm_qgemm.hip): Qp packed codes, SB packed bf16 scale/bias pairs, G = K/64 scale groups
 void launch_gemm_skinny_q(int bits, int epi, int R, int ksb, const void* Qp, const bf16_t* SB, const bf16_t* X, void* out, int NT, int G,

@@ -21,6 +21,7 @@
 #include <algorithm>
 #include <type_traits>
 #include "lm_kernels.h"
+#include "lm_gemm_norm.h"
 
 
 // ============================================================================ weight staging
@@ -564,7 +565,7 @@ __device__ __forceinline__ void gemm_epilogue(const f32x4_t (&acc)[R][MT], void*
 // than from HBM (profiles/r02_mall_probe.txt), so neither the memory nor the bytes in flight bound this launch; what is left is
 // its ramp-up and tail (the lm_head instance, 8x longer, reaches 5.8 TB/s with the same loop).
 template <int MT, int R, int EPI, int KSB>
-__global__ void __launch_bounds__(256, 2) k_gemm_skinny(const bf16_t* __restrict__ Wp, const bf16_t* __restrict__ X,
+__global__ void __launch_bounds__(KSB > 4 ? 64 * KSB : 256, KSB > 4 ? 1 : 2) k_gemm_skinny(const bf16_t* __restrict__ Wp, const bf16_t* __restrict__ X,
                                                      void* __restrict__ out, int NT, int KT, int S, int n_items,
                                                      int N_out, int Mpad, const bf16_t* __restrict__ bias) {
     static_assert(EPI != EPI_SILU_MUL || R == 2, "silu-mul epilogue pairs a gate tile with an up tile");
@@ -716,19 +717,16 @@ __global__ void __launch_bounds__(256, 2) k_gemm_skinny(const bf16_t* __restrict
 //     in flight while the prologue computes.
 // Redundant per consumer block (64 KB of L2 reads, ~0.5 us of VALU work at hidden 1024 and 32 rows) - and a launch less, twice per
 // layer: 7 -> 5 launches.
-template <int MT, int R, int EPI, int XT>
-__global__ void __launch_bounds__(256, 2) k_gemm_norm(const bf16_t* __restrict__ Wp, const bf16_t* __restrict__ h, const bf16_t* __restrict__ wnorm,
+template <int MT, int R, int EPI, int XT, int KSB>
+__global__ void __launch_bounds__(64 * KSB) k_gemm_norm(const bf16_t* __restrict__ Wp, const bf16_t* __restrict__ h, const bf16_t* __restrict__ wnorm,
                                                      void* __restrict__ out, int NT, int KT, int N_out, int Mpad, float eps,
                                                      const bf16_t* __restrict__ bias) {
     static_assert(EPI != EPI_SILU_MUL || R == 2, "silu-mul epilogue pairs a gate tile with an up tile");
-    constexpr int KSB = 4;
     __shared__ float rsum[KSB][MT * 16];
     __shared__ float4 red[KSB][R * MT][64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int ntg = blockIdx.x;
-    const int d = KT * 32;
     const int kt0 = wave * XT;                                   // this wave's k-tiles kt0 .. kt0 + XT - 1 (those >= KT contribute nothing)
-    const int j = lane & 15, q = lane >> 4;
     // ---- weights of the whole K range of this wave: requested first
     bf16x8_t wv[XT][R];
 #pragma unroll
@@ -742,56 +740,9 @@ __global__ void __launch_bounds__(256, 2) k_gemm_norm(const bf16_t* __restrict__
             wv[u][r] = __builtin_nontemporal_load(reinterpret_cast<const bf16x8_t*>(Wp) + ((size_t)tile * KT + kk) * 64 + lane);
         }
     }
-    // ---- the residual stream and the norm weight of the wave's columns
-    uint4 hq[XT][MT], wq[XT];
-#pragma unroll
-    for (int u = 0; u < XT; ++u) {
-        int kk = kt0 + u;
-        kk = kk < KT ? kk : KT - 1;
-        const int k0 = kk * 32 + q * 8;
-        wq[u] = *reinterpret_cast<const uint4*>(wnorm + k0);
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt) hq[u][mt] = *reinterpret_cast<const uint4*>(h + (size_t)(mt * 16 + j) * d + k0);
-    }
-    // ---- row sums of squares: lane partials -> the four lanes of a row -> the four waves (LDS, fixed order)
-#pragma unroll
-    for (int mt = 0; mt < MT; ++mt) {
-        float v = 0.0f;
-#pragma unroll
-        for (int u = 0; u < XT; ++u) {
-            const uint32_t hw[4] = {hq[u][mt].x, hq[u][mt].y, hq[u][mt].z, hq[u][mt].w};
-            float t = 0.0f;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const float h0 = bf16_to_f32((bf16_t)(hw[e] & 0xffffu)), h1 = bf16_to_f32((bf16_t)(hw[e] >> 16));
-                t += h0 * h0 + h1 * h1;
-            }
-            v += (kt0 + u < KT) ? t : 0.0f;
-        }
-        v += __shfl_xor(v, 16, 64);
-        v += __shfl_xor(v, 32, 64);
-        if (q == 0) rsum[wave][mt * 16 + j] = v;
-    }
-    __syncthreads();
-    // ---- x fragments in registers
+    // ---- X = RMSNorm(h) w of the wave's k-tiles, in registers (lm_gemm_norm.h)
     bf16x8_t xr[XT][MT];
-#pragma unroll
-    for (int mt = 0; mt < MT; ++mt) {
-        const float tot = ((rsum[0][mt * 16 + j] + rsum[1][mt * 16 + j]) + rsum[2][mt * 16 + j]) + rsum[3][mt * 16 + j];
-        const float inv = 1.0f / sqrtf(tot / (float)d + eps);
-#pragma unroll
-        for (int u = 0; u < XT; ++u) {
-            const uint32_t ww[4] = {wq[u].x, wq[u].y, wq[u].z, wq[u].w};
-            const uint32_t hw[4] = {hq[u][mt].x, hq[u][mt].y, hq[u][mt].z, hq[u][mt].w};
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const float w0 = bf16_to_f32((bf16_t)(ww[e] & 0xffffu)), w1 = bf16_to_f32((bf16_t)(ww[e] >> 16));
-                const float n0 = bf16_to_f32((bf16_t)(hw[e] & 0xffffu)), n1 = bf16_to_f32((bf16_t)(hw[e] >> 16));
-                xr[u][mt][2 * e] = (short)f32_to_bf16(w0 * bf16_round_f32(n0 * inv));
-                xr[u][mt][2 * e + 1] = (short)f32_to_bf16(w1 * bf16_round_f32(n1 * inv));
-            }
-        }
-    }
+    gemm_norm_prologue<MT, XT, KSB>(h, wnorm, KT, eps, kt0, lane, wave, rsum, xr);
     // ---- the product over this wave's K range
     f32x4_t acc[R][MT];
 #pragma unroll
@@ -830,22 +781,25 @@ __global__ void __launch_bounds__(256, 2) k_gemm_norm(const bf16_t* __restrict__
         gemm_epilogue<MT, R, EPI>(acc, out, ntg, 0, NT, N_out, Mpad, lane, mt, bias);
     }
 }
-// hidden size limit of the fused form: XT <= 8 k-tiles per wave, four waves per block (hidden size <= 1024)
-bool gemm_norm_supported(int d, int Mpad) { return d % 32 == 0 && d / 32 <= 32 && (Mpad == 16 || Mpad == 32); }
+// shapes of the fused form: hidden size <= 1024 (<= 4 k-tiles per wave at 8 waves), Mpad 16 / 32
+bool gemm_norm_supported(int d, int Mpad) { return d % 64 == 0 && d / 32 <= 32 && (Mpad == 16 || Mpad == 32); }
+// waves per block: 16 where the LDS combine fits (R = 1: 32 KB), else 8
 void launch_gemm_norm(int epi, const bf16_t* Wp, const bf16_t* h, const bf16_t* wnorm, void* out, int NT, int KT, int N_out, int Mpad, float eps,
                       hipStream_t s, const bf16_t* bias) {
     MIS_REQUIRE(gemm_norm_supported(KT * 32, Mpad), MIS_ERR_GENERATION_FAILED, "fused norm GEMM: unsupported shape (hidden %d, rows %d)", KT * 32, Mpad);
-    const int R = 2;
-    const int xt = (KT + 3) / 4;
-    dim3 grid((NT + R - 1) / R), block(256);
-#define GN_CASE(MTV, E, XTV)                                                                                                        \
-    if (Mpad == 16 * MTV && epi == E && xt <= XTV) {                                                                                \
-        hipLaunchKernelGGL((k_gemm_norm<MTV, 2, E, XTV>), grid, block, 0, s, Wp, h, wnorm, out, NT, KT, N_out, Mpad, eps, bias);      \
+    const bool pair = epi == EPI_SILU_MUL;                       // gate / up tiles meet in one wave: R = 2
+#define GN_CASE(MTV, RV, E, XTV, KSBV)                                                                                              \
+    if (Mpad == 16 * MTV && epi == E && (KT + KSBV - 1) / KSBV <= XTV) {                                                            \
+        hipLaunchKernelGGL((k_gemm_norm<MTV, RV, E, XTV, KSBV>), dim3((NT + RV - 1) / RV), dim3(64 * KSBV), 0, s, Wp, h, wnorm, out, NT, KT, \
+                           N_out, Mpad, eps, bias);                                                                                 \
         return;                                                                                                                     \
     }
-#define GN_EPI(MTV, XTV) GN_CASE(MTV, EPI_PARTIAL, XTV) GN_CASE(MTV, EPI_BF16, XTV) GN_CASE(MTV, EPI_SILU_MUL, XTV)
-    GN_EPI(2, 4) GN_EPI(2, 8) GN_EPI(1, 4) GN_EPI(1, 8)
-#undef GN_EPI
+    if (pair) {
+        GN_CASE(2, 2, EPI_SILU_MUL, 2, 8) GN_CASE(2, 2, EPI_SILU_MUL, 4, 8) GN_CASE(1, 2, EPI_SILU_MUL, 2, 8) GN_CASE(1, 2, EPI_SILU_MUL, 4, 8)
+    } else {
+        GN_CASE(2, 1, EPI_PARTIAL, 1, 16) GN_CASE(2, 1, EPI_PARTIAL, 2, 16) GN_CASE(1, 1, EPI_PARTIAL, 1, 16) GN_CASE(1, 1, EPI_PARTIAL, 2, 16)
+        GN_CASE(2, 1, EPI_BF16, 1, 16) GN_CASE(2, 1, EPI_BF16, 2, 16) GN_CASE(1, 1, EPI_BF16, 1, 16) GN_CASE(1, 1, EPI_BF16, 2, 16)
+    }
 #undef GN_CASE
     throw MisError(MIS_ERR_GENERATION_FAILED, "fused norm GEMM: unsupported variant");
 }
@@ -875,7 +829,7 @@ template <int MT>
 static void launch_gemm_mt(int epi, int R, int ksb, const bf16_t* Wp, const bf16_t* X, void* out, int NT, int KT, int S,
                            int N_out, int Mpad, const bf16_t* bias, hipStream_t s) {
     int n_items = ((NT + R - 1) / R) * S;
-    dim3 grid(ksb == 1 ? (n_items + 3) / 4 : n_items), block(256);
+    dim3 grid(ksb == 1 ? (n_items + 3) / 4 : n_items), block(ksb > 4 ? 64 * ksb : 256);
 #define GEMM_CASE(E, RR, KS)                                                                                  \
     if (epi == E && R == RR && ksb == KS) {                                                                   \
         hipLaunchKernelGGL((k_gemm_skinny<MT, RR, E, KS>), grid, block, 0, s, Wp, X, out, NT, KT, S, n_items,     \
@@ -896,6 +850,7 @@ static void launch_gemm_mt(int epi, int R, int ksb, const bf16_t* Wp, const bf16
     GEMM_CASE(EPI_SILU_PACKED, 2, 4)
     GEMM_CASE(EPI_RESID, 2, 4)
     GEMM_CASE(EPI_RESID, 1, 4)
+    GEMM_CASE(EPI_RESID, 1, 16)      // small-model chain: few n-tiles, no inter-block split-K -> 16 waves split K inside the block
 #undef GEMM_CASE
     throw MisError(MIS_ERR_GENERATION_FAILED, "unsupported GEMM variant");
 }
