@@ -74,7 +74,6 @@ struct mis_tts {
     DevBuf<SamplerScratch> samp_scratch;
     hipGraphExec_t g_prefill = nullptr, g_decode = nullptr;
     uint64_t graph_key = 0;
-    bool fused = false;          // 5-launch layer chain (RMSNorm in the consumer GEMM's prologue, residual in the producer's epilogue)
     bool use_graph = true;
     bool borrowed_stream = false;
     int profiling = 0;
@@ -542,13 +541,6 @@ static void lm_reset(mis_tts* c, int batch, int max_context) {
     c->S_qkv = std::min(8, choose_split(c->Nqkv / 16 / c->r_part, d / 32, c->ksb_part, "MIS_S_QKV", 8));   // attention prologue: <= 8 slabs
     c->S_o = choose_split(d / 16 / c->r_part, HD / 32, c->ksb_part, "MIS_S_O");
     c->S_down = choose_split(d / 16 / c->r_part, c->ff / 32, c->ksb_part, "MIS_S_DOWN");
-    {   // small hidden sizes: the fused chain (k_gemm_norm, lm_kernels.hip); MIS_FUSE_NORM=0 keeps the 7-launch chain (A/B, parity tests)
-        const bool want = env_int("MIS_FUSE_NORM", 1) != 0 && gemm_norm_supported(d, Mpad) && c->Nqkv % 32 == 0 && (2 * c->ff) % 32 == 0 &&
-                          HD % 64 == 0 && c->ff % 64 == 0;
-        if (want != c->fused) destroy_graphs(c);
-        c->fused = want;
-        if (c->fused) c->S_qkv = 1;
-    }
     size_t kv = (size_t)c->L * batch * c->Hkv * Smax * c->D;
     c->kcache.alloc(kv);
     c->vtcache.alloc(kv);
@@ -603,12 +595,7 @@ static void enqueue_layers(mis_tts* c, const bf16_t* table = nullptr, int table_
                          c->h.p, c->x.p, d, table ? table_rows : c->V, eps, c->batch, Mpad, s);
     for (int li = 0; li < c->L; ++li) {
         const size_t lkv = (size_t)c->batch * c->Hkv * c->Smax * c->D;
-        if (c->fused) {
-            const bf16_t* nw = c->norms.p + (size_t)(2 * li) * d;
-            if (c->q_qkv.on) launch_gemm_norm_q(c->q_qkv.bits, EPI_PARTIAL, c->q_qkv.q.p + c->q_qkv.q_layer * li, c->q_qkv.sb.p + c->q_qkv.sb_layer * li, c->h.p, nw,
-                                                c->qkv_part.p, c->Nqkv / 16, d / 64, c->Nqkv, Mpad, eps, s);
-            else launch_gemm_norm(EPI_PARTIAL, c->wqkv.p + layer_qkv_elems(c) * li, c->h.p, nw, c->qkv_part.p, c->Nqkv / 16, d / 32, c->Nqkv, Mpad, eps, s);
-        } else gemm_qkv(c, li, s);
+        gemm_qkv(c, li, s);
         AttnParams ap{};
         ap.qkv_part = c->qkv_part.p; ap.S = c->S_qkv; ap.Mpad = Mpad; ap.Nqkv = c->Nqkv;
         ap.kcache = c->kcache.p + lkv * li; ap.vtcache = c->vtcache.p + lkv * li;
@@ -623,22 +610,6 @@ static void enqueue_layers(mis_tts* c, const bf16_t* table = nullptr, int table_
         }
         ap.rope_in_dtype = c->cfg.rope_ops_in_dtype;
         launch_attn_decode(ap, c->batch, s);
-        if (c->fused) {
-            // o_proj and down_proj add the residual in place (no inter-block split-K: 16 waves split K inside a block), gate|up
-            // normalises in its prologue
-            const int HD = c->H * c->D;
-            const bf16_t* nw = c->norms.p + (size_t)(2 * li + 1) * d;
-            if (c->q_o.on) launch_gemm_skinny_q(c->q_o.bits, EPI_RESID, 1, HD / 64 >= 16 ? 16 : 4, c->q_o.q.p + c->q_o.q_layer * li, c->q_o.sb.p + c->q_o.sb_layer * li,
-                                                c->attn_out.p, c->h.p, d / 16, HD / 64, 1, d, Mpad, s);
-            else launch_gemm_skinny(EPI_RESID, 1, HD / 32 >= 32 ? 16 : 4, c->wo.p + layer_o_elems(c) * li, c->attn_out.p, c->h.p, d / 16, HD / 32, 1, d, Mpad, s);
-            if (c->q_gu.on) launch_gemm_norm_q(c->q_gu.bits, EPI_SILU_MUL, c->q_gu.q.p + c->q_gu.q_layer * li, c->q_gu.sb.p + c->q_gu.sb_layer * li, c->h.p, nw, c->act.p,
-                                               2 * c->ff / 16, d / 64, c->ff, Mpad, eps, s);
-            else launch_gemm_norm(EPI_SILU_MUL, c->wgu.p + layer_gu_elems(c) * li, c->h.p, nw, c->act.p, 2 * c->ff / 16, d / 32, c->ff, Mpad, eps, s);
-            if (c->q_down.on) launch_gemm_skinny_q(c->q_down.bits, EPI_RESID, 1, c->ff / 64 >= 16 ? 16 : 4, c->q_down.q.p + c->q_down.q_layer * li,
-                                                   c->q_down.sb.p + c->q_down.sb_layer * li, c->act.p, c->h.p, d / 16, c->ff / 64, 1, d, Mpad, s);
-            else launch_gemm_skinny(EPI_RESID, 1, c->ff / 32 >= 32 ? 16 : 4, c->wdown.p + layer_down_elems(c) * li, c->act.p, c->h.p, d / 16, c->ff / 32, 1, d, Mpad, s);
-            continue;
-        }
         gemm_o(c, li, s);
         launch_reduce_residual_rmsnorm(c->part.p, c->S_o, Mpad, d, c->h.p, c->norms.p + (size_t)(2 * li + 1) * d, c->x.p, eps, s);
         gemm_gate_up(c, li, s);
@@ -646,7 +617,6 @@ static void enqueue_layers(mis_tts* c, const bf16_t* table = nullptr, int table_
         const bf16_t* next_norm = c->norms.p + (size_t)(li + 1 < c->L ? 2 * (li + 1) : 2 * c->L) * d;
         launch_reduce_residual_rmsnorm(c->part.p, c->S_down, Mpad, d, c->h.p, next_norm, c->x.p, eps, s);
     }
-    if (c->fused) launch_norm_pack(c->h.p, Mpad, d, c->norms.p + (size_t)2 * c->L * d, c->x.p, eps, s);      // final norm: lm_head / hidden taps read x
 }
 static void enqueue_lm_head(mis_tts* c, const bf16_t* head = nullptr) {
     if (!head && c->q_head.on) {

@@ -7,7 +7,7 @@ __host__ __device__ __forceinline__ size_t xpk_index(int m, int k, int MT) {
     return ((((size_t)(k >> 5) * MT + (m >> 4)) * 64) + (((k & 31) >> 3) << 4) + (m & 15)) * 8 + (k & 7);
 }
 
-enum { EPI_PARTIAL = 0, EPI_BF16 = 1, EPI_SILU_MUL = 2, EPI_GELU_PACKED = 3, EPI_SILU_PACKED = 4, EPI_RESID = 5 };
+enum { EPI_PARTIAL = 0, EPI_BF16 = 1, EPI_SILU_MUL = 2, EPI_GELU_PACKED = 3, EPI_SILU_PACKED = 4 };
 
 void launch_convert_to_bf16(const void* src, int dtype, bf16_t* dst, size_t n, hipStream_t s);
 // MLX affine-quantised matrix (uint32 words, per-group scales / biases of dtype sb_dtype = mis_dtype) -> bf16 [N][K]
@@ -31,16 +31,6 @@ void launch_reduce_residual_rmsnorm(const float* slabs, int S, int Mpad, int N, 
 // in the packed fragment layout (it is the next GEMM's X operand).  EPI_SILU_PACKED: h = T(xW+b), T(h * T(sigmoid(h))) packed.
 void launch_gemm_skinny(int epi, int R, int ksb, const bf16_t* Wp, const bf16_t* X, void* out, int NT, int KT, int S,
                         int N_out, int Mpad, hipStream_t s, const bf16_t* bias = nullptr);
-
-// fused chain for small hidden sizes (<= 1024, Mpad 16 / 32, dense bf16 weights): the producer GEMM adds the residual in place
-// (EPI_RESID: out = the row-major bf16 residual stream h, S must be 1), the consumer rebuilds X = RMSNorm(h) w per block in registers
-// (launch_gemm_norm; epi: EPI_PARTIAL with one f32 slab, EPI_BF16, EPI_SILU_MUL); launch_norm_pack: the final norm as packed fragments
-bool gemm_norm_supported(int d, int Mpad);
-void launch_gemm_norm(int epi, const bf16_t* Wp, const bf16_t* h, const bf16_t* wnorm, void* out, int NT, int KT, int N_out, int Mpad, float eps,
-                      hipStream_t s, const bf16_t* bias = nullptr);
-void launch_norm_pack(const bf16_t* h, int Mpad, int N, const bf16_t* wnorm, bf16_t* x, float eps, hipStream_t s);
-void launch_gemm_norm_q(int bits, int epi, const void* Qp, const bf16_t* SB, const bf16_t* h, const bf16_t* wnorm, void* out, int NT, int G, int N_out,
-                        int Mpad, float eps, hipStream_t s, const bf16_t* bias = nullptr);
 
 // the same on MLX affine-quantised weights (lm_qgemm.hip): Qp packed codes, SB packed bf16 scale/bias pairs, G = K/64 scale groups
 void launch_gemm_skinny_q(int bits, int epi, int R, int ksb, const void* Qp, const bf16_t* SB, const bf16_t* X, void* out, int NT, int G,

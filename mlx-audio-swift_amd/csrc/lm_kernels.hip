@@ -21,7 +21,6 @@
 #include <algorithm>
 #include <type_traits>
 #include "lm_kernels.h"
-#include "lm_gemm_norm.h"
 
 
 // ============================================================================ weight staging
@@ -106,6 +105,11 @@ void launch_synth_fill_bf16(bf16_t* dst, size_t n, uint64_t key, float amp, int 
 // branch of the step graph every fork cost ~16 us on ROCm 7.2 (step 2.13 -> 2.95..4.1 ms); as extra blocks of the chain's own launches
 // - glue, split-K GEMMs, the attention waves that run out of key tiles - every schedule was slower too (2.144 -> 2.17..2.35 ms): the
 // carriers lose more than the consumers gain, the step's HBM time is conserved.  profiles/r03/ab1_*.json, ab2_*.json; DESIGN.md.)
+
+// (Round 3, measured and removed again: a 5-launch layer for hidden sizes <= 1024 - RMSNorm rebuilt per block in the consumer GEMM's
+// prologue, residual added in place by the producer GEMM's epilogue.  Parity-green; slower on Qwen3-TTS-0.6B (4.35-4.41 vs 3.92
+// ms/frame): the prologue costs 2.5-3 us per consumer launch (VALU work plus a block-wide reduction in front of the first MFMA) and
+// a producer without inter-block split-K keeps only 64 of 256 CUs streaming (7.2 vs 4.8 us).  profiles/r03/q3/; DESIGN.md.)
 
 // ============================================================================ step bookkeeping
 
@@ -507,34 +511,6 @@ __device__ __forceinline__ void gemm_epilogue(const f32x4_t (&acc)[R][MT], void*
                 *reinterpret_cast<uint2*>(o + off) = v;
             }
         }
-    } else if (EPI == EPI_RESID) {
-        // residual stream updated in place by the producer (no inter-block split-K): h = T(h + T(acc [+ b]))  (LlamaTTS.swift:308-309)
-        bf16_t* o = reinterpret_cast<bf16_t*>(out);
-#pragma unroll
-        for (int r = 0; r < R; ++r) {
-            int tile = ntg * R + r;
-            if (tile >= NT) continue;
-            float bv[4] = {0.f, 0.f, 0.f, 0.f};
-            if (bias) {
-#pragma unroll
-                for (int e = 0; e < 4; ++e) bv[e] = bf16_to_f32(bias[tile * 16 + nl + e]);
-            }
-#pragma unroll
-            for (int mt = 0; mt < MT; ++mt) {
-                if (mt_only >= 0 && mt != mt_only) continue;
-                const size_t off = ((size_t)mt * 16 + ml) * N_out + tile * 16 + nl;
-                const uint2 hv = *reinterpret_cast<const uint2*>(o + off);
-                const float h4[4] = {bf16_to_f32((bf16_t)(hv.x & 0xffffu)), bf16_to_f32((bf16_t)(hv.x >> 16)), bf16_to_f32((bf16_t)(hv.y & 0xffffu)),
-                                     bf16_to_f32((bf16_t)(hv.y >> 16))};
-                uint16_t res[4];
-#pragma unroll
-                for (int e = 0; e < 4; ++e) res[e] = f32_to_bf16(h4[e] + bf16_round_f32(acc[r][mt][e] + bv[e]));
-                uint2 v;
-                v.x = (uint32_t)res[0] | ((uint32_t)res[1] << 16);
-                v.y = (uint32_t)res[2] | ((uint32_t)res[3] << 16);
-                *reinterpret_cast<uint2*>(o + off) = v;
-            }
-        }
     } else {   // EPI_SILU_MUL: tile 2t = gate rows, 2t+1 = up rows  (LlamaTTS.swift:283)
         bf16_t* o = reinterpret_cast<bf16_t*>(out);
 #pragma unroll
@@ -565,7 +541,7 @@ __device__ __forceinline__ void gemm_epilogue(const f32x4_t (&acc)[R][MT], void*
 // than from HBM (profiles/r02_mall_probe.txt), so neither the memory nor the bytes in flight bound this launch; what is left is
 // its ramp-up and tail (the lm_head instance, 8x longer, reaches 5.8 TB/s with the same loop).
 template <int MT, int R, int EPI, int KSB>
-__global__ void __launch_bounds__(KSB > 4 ? 64 * KSB : 256, KSB > 4 ? 1 : 2) k_gemm_skinny(const bf16_t* __restrict__ Wp, const bf16_t* __restrict__ X,
+__global__ void __launch_bounds__(256, 2) k_gemm_skinny(const bf16_t* __restrict__ Wp, const bf16_t* __restrict__ X,
                                                      void* __restrict__ out, int NT, int KT, int S, int n_items,
                                                      int N_out, int Mpad, const bf16_t* __restrict__ bias) {
     static_assert(EPI != EPI_SILU_MUL || R == 2, "silu-mul epilogue pairs a gate tile with an up tile");
@@ -702,134 +678,11 @@ __global__ void __launch_bounds__(KSB > 4 ? 64 * KSB : 256, KSB > 4 ? 1 : 2) k_g
     }
 }
 
-// ---------------------------------------------------------------------------- the same GEMM with the RMSNorm as its PROLOGUE
-//
-// Small models (hidden size <= 1024: Qwen3-TTS talker / code predictor, Soprano) spend their decode step on kernel boundaries, not on
-// bytes: ~4.8 us per launch whatever it does.  Two of a block's seven launches are the glue kernel (slab sum + residual +
-// RMSNorm).  In the fused chain both halves of it move into the neighbouring GEMMs:
-//   * the PRODUCER (o_proj / down_proj, no inter-block split-K) adds the residual in its epilogue, in place: h = T(h + T(acc))
-//     (EPI_RESID of k_gemm_skinny; nobody else touches h during that launch);
-//   * every block of the CONSUMER (q|k|v, gate|up) rebuilds its whole X operand from h in registers,
-//         x = T(w . T(h . rsqrt(mean h^2 + eps)))                          (LlamaTTS.swift:306, the glue kernel's rounding points)
-//     wave w of the block owns the k-tiles [w XT, (w+1) XT) of all Mpad rows: its 16-byte loads of h ARE the MFMA B fragments (lane
-//     (j, q) of fragment (kt, mt) holds row 16 mt + j, columns 32 kt + 8 q ..+8), the row sums of squares meet through LDS (fixed
-//     order), and the weight tiles of the wave's whole K range (XT x R KiB) are requested BEFORE that arithmetic, so the stream is
-//     in flight while the prologue computes.
-// Redundant per consumer block (64 KB of L2 reads, ~0.5 us of VALU work at hidden 1024 and 32 rows) - and a launch less, twice per
-// layer: 7 -> 5 launches.
-template <int MT, int R, int EPI, int XT, int KSB>
-__global__ void __launch_bounds__(64 * KSB) k_gemm_norm(const bf16_t* __restrict__ Wp, const bf16_t* __restrict__ h, const bf16_t* __restrict__ wnorm,
-                                                     void* __restrict__ out, int NT, int KT, int N_out, int Mpad, float eps,
-                                                     const bf16_t* __restrict__ bias) {
-    static_assert(EPI != EPI_SILU_MUL || R == 2, "silu-mul epilogue pairs a gate tile with an up tile");
-    __shared__ float rsum[KSB][MT * 16];
-    __shared__ float4 red[KSB][R * MT][64];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int ntg = blockIdx.x;
-    const int kt0 = wave * XT;                                   // this wave's k-tiles kt0 .. kt0 + XT - 1 (those >= KT contribute nothing)
-    // ---- weights of the whole K range of this wave: requested first
-    bf16x8_t wv[XT][R];
-#pragma unroll
-    for (int u = 0; u < XT; ++u) {
-        int kk = kt0 + u;
-        kk = kk < KT ? kk : KT - 1;
-#pragma unroll
-        for (int r = 0; r < R; ++r) {
-            int tile = ntg * R + r;
-            tile = tile < NT ? tile : NT - 1;
-            wv[u][r] = __builtin_nontemporal_load(reinterpret_cast<const bf16x8_t*>(Wp) + ((size_t)tile * KT + kk) * 64 + lane);
-        }
-    }
-    // ---- X = RMSNorm(h) w of the wave's k-tiles, in registers (lm_gemm_norm.h)
-    bf16x8_t xr[XT][MT];
-    gemm_norm_prologue<MT, XT, KSB>(h, wnorm, KT, eps, kt0, lane, wave, rsum, xr);
-    // ---- the product over this wave's K range
-    f32x4_t acc[R][MT];
-#pragma unroll
-    for (int r = 0; r < R; ++r)
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt) acc[r][mt] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int u = 0; u < XT; ++u)
-        if (kt0 + u < KT) {
-#pragma unroll
-            for (int r = 0; r < R; ++r)
-#pragma unroll
-                for (int mt = 0; mt < MT; ++mt)
-                    acc[r][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wv[u][r], xr[u][mt], acc[r][mt], 0, 0, 0);
-        }
-    // ---- in-block split-K combine (fixed order) + epilogue, as k_gemm_skinny
-#pragma unroll
-    for (int r = 0; r < R; ++r)
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt)
-            red[wave][r * MT + mt][lane] = make_float4(acc[r][mt][0], acc[r][mt][1], acc[r][mt][2], acc[r][mt][3]);
-    __syncthreads();
-    for (int mt = wave; mt < MT; mt += KSB) {
-#pragma unroll
-        for (int r = 0; r < R; ++r) {
-            float4 s0 = red[0][r * MT + mt][lane];
-#pragma unroll
-            for (int w = 1; w < KSB; ++w) {
-                float4 t = red[w][r * MT + mt][lane];
-                s0.x += t.x; s0.y += t.y; s0.z += t.z; s0.w += t.w;
-            }
-#pragma unroll
-            for (int m2 = 0; m2 < MT; ++m2)
-                if (m2 == mt) acc[r][m2] = (f32x4_t){s0.x, s0.y, s0.z, s0.w};
-        }
-        gemm_epilogue<MT, R, EPI>(acc, out, ntg, 0, NT, N_out, Mpad, lane, mt, bias);
-    }
-}
-// shapes of the fused form: hidden size <= 1024 (<= 4 k-tiles per wave at 8 waves), Mpad 16 / 32
-bool gemm_norm_supported(int d, int Mpad) { return d % 64 == 0 && d / 32 <= 32 && (Mpad == 16 || Mpad == 32); }
-// waves per block: 16 where the LDS combine fits (R = 1: 32 KB), else 8
-void launch_gemm_norm(int epi, const bf16_t* Wp, const bf16_t* h, const bf16_t* wnorm, void* out, int NT, int KT, int N_out, int Mpad, float eps,
-                      hipStream_t s, const bf16_t* bias) {
-    MIS_REQUIRE(gemm_norm_supported(KT * 32, Mpad), MIS_ERR_GENERATION_FAILED, "fused norm GEMM: unsupported shape (hidden %d, rows %d)", KT * 32, Mpad);
-    const bool pair = epi == EPI_SILU_MUL;                       // gate / up tiles meet in one wave: R = 2
-#define GN_CASE(MTV, RV, E, XTV, KSBV)                                                                                              \
-    if (Mpad == 16 * MTV && epi == E && (KT + KSBV - 1) / KSBV <= XTV) {                                                            \
-        hipLaunchKernelGGL((k_gemm_norm<MTV, RV, E, XTV, KSBV>), dim3((NT + RV - 1) / RV), dim3(64 * KSBV), 0, s, Wp, h, wnorm, out, NT, KT, \
-                           N_out, Mpad, eps, bias);                                                                                 \
-        return;                                                                                                                     \
-    }
-    if (pair) {
-        GN_CASE(2, 2, EPI_SILU_MUL, 2, 8) GN_CASE(2, 2, EPI_SILU_MUL, 4, 8) GN_CASE(1, 2, EPI_SILU_MUL, 2, 8) GN_CASE(1, 2, EPI_SILU_MUL, 4, 8)
-    } else {
-        GN_CASE(2, 1, EPI_PARTIAL, 1, 16) GN_CASE(2, 1, EPI_PARTIAL, 2, 16) GN_CASE(1, 1, EPI_PARTIAL, 1, 16) GN_CASE(1, 1, EPI_PARTIAL, 2, 16)
-        GN_CASE(2, 1, EPI_BF16, 1, 16) GN_CASE(2, 1, EPI_BF16, 2, 16) GN_CASE(1, 1, EPI_BF16, 1, 16) GN_CASE(1, 1, EPI_BF16, 2, 16)
-    }
-#undef GN_CASE
-    throw MisError(MIS_ERR_GENERATION_FAILED, "fused norm GEMM: unsupported variant");
-}
-// x = RMSNorm(h) w as packed fragments: what is left of the glue kernel at the END of a fused chain (the final norm in front of the
-// head, read by lm_head and by the hidden-state taps)
-__global__ void __launch_bounds__(1024) k_norm_pack(const bf16_t* __restrict__ h, int Mpad, int N, const bf16_t* __restrict__ wnorm,
-                                                    bf16_t* __restrict__ x, float eps) {
-    __shared__ float red[16];
-    const int m = blockIdx.x, tid = threadIdx.x, nth = blockDim.x, MT = Mpad >> 4;
-    float ss = 0.0f;
-    for (int i = tid; i < N; i += nth) { const float hv = bf16_to_f32(h[(size_t)m * N + i]); ss += hv * hv; }
-    ss = wave_sum_dpp(ss);
-    if ((tid & 63) == 0) red[tid >> 6] = ss;
-    __syncthreads();
-    float tot = 0.0f;
-    for (int i = 0; i < (nth >> 6); ++i) tot += red[i];
-    const float inv = 1.0f / sqrtf(tot / (float)N + eps);
-    for (int i = tid; i < N; i += nth)
-        x[xpk_index(m, i, MT)] = f32_to_bf16(bf16_to_f32(wnorm[i]) * bf16_round_f32(bf16_to_f32(h[(size_t)m * N + i]) * inv));
-}
-void launch_norm_pack(const bf16_t* h, int Mpad, int N, const bf16_t* wnorm, bf16_t* x, float eps, hipStream_t s) {
-    const int nth = std::min(1024, ((N + 63) / 64) * 64);
-    hipLaunchKernelGGL(k_norm_pack, dim3(Mpad), dim3(nth), 0, s, h, Mpad, N, wnorm, x, eps);
-}
-
 template <int MT>
 static void launch_gemm_mt(int epi, int R, int ksb, const bf16_t* Wp, const bf16_t* X, void* out, int NT, int KT, int S,
                            int N_out, int Mpad, const bf16_t* bias, hipStream_t s) {
     int n_items = ((NT + R - 1) / R) * S;
-    dim3 grid(ksb == 1 ? (n_items + 3) / 4 : n_items), block(ksb > 4 ? 64 * ksb : 256);
+    dim3 grid(ksb == 1 ? (n_items + 3) / 4 : n_items), block(256);
 #define GEMM_CASE(E, RR, KS)                                                                                  \
     if (epi == E && R == RR && ksb == KS) {                                                                   \
         hipLaunchKernelGGL((k_gemm_skinny<MT, RR, E, KS>), grid, block, 0, s, Wp, X, out, NT, KT, S, n_items,     \
@@ -848,9 +701,6 @@ static void launch_gemm_mt(int epi, int R, int ksb, const bf16_t* Wp, const bf16
     GEMM_CASE(EPI_GELU_PACKED, 1, 4)
     GEMM_CASE(EPI_BF16, 1, 4)
     GEMM_CASE(EPI_SILU_PACKED, 2, 4)
-    GEMM_CASE(EPI_RESID, 2, 4)
-    GEMM_CASE(EPI_RESID, 1, 4)
-    GEMM_CASE(EPI_RESID, 1, 16)      // small-model chain: few n-tiles, no inter-block split-K -> 16 waves split K inside the block
 #undef GEMM_CASE
     throw MisError(MIS_ERR_GENERATION_FAILED, "unsupported GEMM variant");
 }

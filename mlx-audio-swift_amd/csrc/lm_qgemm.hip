@@ -18,7 +18,6 @@
 // Work decomposition, epilogues and the in-block split-K combine are those of k_gemm_skinny; K ranges are cut at scale groups.
 #include "common.h"
 #include "lm_kernels.h"
-#include "lm_gemm_norm.h"
 
 
 typedef unsigned int u32x2_t __attribute__((ext_vector_type(2)));
@@ -95,33 +94,6 @@ __device__ __forceinline__ void qgemm_epilogue(const f32x4_t (&acc)[R][MT], void
                 *reinterpret_cast<uint2*>(o + off) = v;
             }
         }
-    } else if (EPI == EPI_RESID) {      // h = T(h + T(acc [+ b])) in place (no inter-block split-K), see lm_kernels.hip
-        bf16_t* o = reinterpret_cast<bf16_t*>(out);
-#pragma unroll
-        for (int r = 0; r < R; ++r) {
-            int tile = ntg * R + r;
-            if (tile >= NT) continue;
-            float bv[4] = {0.f, 0.f, 0.f, 0.f};
-            if (bias) {
-#pragma unroll
-                for (int e = 0; e < 4; ++e) bv[e] = bf16_to_f32(bias[tile * 16 + nl + e]);
-            }
-#pragma unroll
-            for (int mt = 0; mt < MT; ++mt) {
-                if (mt_only >= 0 && mt != mt_only) continue;
-                const size_t off = ((size_t)mt * 16 + ml) * N_out + tile * 16 + nl;
-                const uint2 hv = *reinterpret_cast<const uint2*>(o + off);
-                float h4[4];
-                unpack_bf16x4(hv, h4);
-                uint16_t res[4];
-#pragma unroll
-                for (int e = 0; e < 4; ++e) res[e] = f32_to_bf16(h4[e] + bf16_round_f32(acc[r][mt][e] + bv[e]));
-                uint2 v;
-                v.x = (uint32_t)res[0] | ((uint32_t)res[1] << 16);
-                v.y = (uint32_t)res[2] | ((uint32_t)res[3] << 16);
-                *reinterpret_cast<uint2*>(o + off) = v;
-            }
-        }
     } else {   // EPI_SILU_MUL: tile 2t = gate rows, 2t+1 = up rows  (LlamaTTS.swift:283)
         bf16_t* o = reinterpret_cast<bf16_t*>(out);
 #pragma unroll
@@ -148,7 +120,7 @@ __device__ __forceinline__ void qgemm_epilogue(const f32x4_t (&acc)[R][MT], void
 // QGEMM_U = scale groups per register buffer: 2 (= 4 k-tiles, 196 VGPRs at MT = 2, two blocks per CU) or 1 (four blocks per CU; the
 // only one that fits without spills at MT >= 3)
 template <int MT, int R, int EPI, int KSB, int BITS, int QGEMM_U>
-__global__ void __launch_bounds__(KSB > 4 ? 64 * KSB : 256, KSB > 4 ? 1 : 2) k_gemm_skinny_q(const void* __restrict__ Qp, const bf16_t* __restrict__ SB, const bf16_t* __restrict__ X,
+__global__ void __launch_bounds__(256, 2) k_gemm_skinny_q(const void* __restrict__ Qp, const bf16_t* __restrict__ SB, const bf16_t* __restrict__ X,
                                                        void* __restrict__ out, int NT, int G, int S, int n_items, int N_out, int Mpad,
                                                        const bf16_t* __restrict__ bias) {
     static_assert(EPI != EPI_SILU_MUL || R == 2, "silu-mul epilogue pairs a gate tile with an up tile");
@@ -303,7 +275,7 @@ template <int MT, int BITS, int U>
 static void launch_qgemm_mt(int epi, int R, int ksb, const void* Qp, const bf16_t* SB, const bf16_t* X, void* out, int NT, int G, int S,
                             int N_out, int Mpad, const bf16_t* bias, hipStream_t s) {
     int n_items = ((NT + R - 1) / R) * S;
-    dim3 grid(ksb == 1 ? (n_items + 3) / 4 : n_items), block(ksb > 4 ? 64 * ksb : 256);
+    dim3 grid(ksb == 1 ? (n_items + 3) / 4 : n_items), block(256);
 #define QGEMM_CASE(E, RR, KS)                                                                                       \
     if (epi == E && R == RR && ksb == KS) {                                                                         \
         hipLaunchKernelGGL((k_gemm_skinny_q<MT, RR, E, KS, BITS, U>), grid, block, 0, s, Qp, SB, X, out, NT, G, S, n_items, \
@@ -317,10 +289,6 @@ static void launch_qgemm_mt(int epi, int R, int ksb, const void* Qp, const bf16_
     QGEMM_CASE(EPI_BF16, 2, 4)
     QGEMM_CASE(EPI_SILU_MUL, 2, 1)
     QGEMM_CASE(EPI_SILU_MUL, 2, 4)
-    QGEMM_CASE(EPI_RESID, 1, 4)
-    QGEMM_CASE(EPI_RESID, 2, 4)
-    QGEMM_CASE(EPI_RESID, 1, 16)
-    QGEMM_CASE(EPI_RESID, 1, 8)
 #undef QGEMM_CASE
     throw MisError(MIS_ERR_GENERATION_FAILED, "unsupported quantised GEMM variant");
 }
@@ -343,133 +311,6 @@ void launch_gemm_skinny_q(int bits, int epi, int R, int ksb, const void* Qp, con
         default: throw MisError(MIS_ERR_INVALID_INPUT, "batch per GPU must be <= 64");
     }
 #undef QGEMM_MT
-}
-
-// ---- the RMSNorm-prologue form of the fused small-model chain (see k_gemm_norm, lm_kernels.hip) on quantised weights: X rebuilt per
-// block in registers (lm_gemm_norm.h), the wave's whole K range (XT k-tiles = XT / 2 scale groups) of codes, scales and biases
-// requested before the prologue arithmetic, group-wise float32 scale / bias application as in k_gemm_skinny_q.
-template <int MT, int R, int EPI, int XT, int KSB, int BITS>
-__global__ void __launch_bounds__(64 * KSB) k_gemm_norm_q(const void* __restrict__ Qp, const bf16_t* __restrict__ SB, const bf16_t* __restrict__ h,
-                                                       const bf16_t* __restrict__ wnorm, void* __restrict__ out, int NT, int G, int N_out, int Mpad,
-                                                       float eps, const bf16_t* __restrict__ bias) {
-    static_assert(EPI != EPI_SILU_MUL || R == 2, "silu-mul epilogue pairs a gate tile with an up tile");
-    static_assert(XT % 2 == 0, "a wave owns whole scale groups");
-    typedef typename QTile<BITS>::type WT;
-    constexpr int XG = XT / 2;
-    __shared__ float rsum[KSB][MT * 16];
-    __shared__ float4 red[KSB][R * MT][64];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int ntg = blockIdx.x;
-    const int KT = 2 * G;
-    const int kt0 = wave * XT, g0 = wave * XG;
-    WT wv[XT][R];
-    uint2 sv[XG][R][2];
-#pragma unroll
-    for (int r = 0; r < R; ++r) {
-        int tile = ntg * R + r;
-        tile = tile < NT ? tile : NT - 1;
-        const WT* wp = reinterpret_cast<const WT*>(Qp) + (size_t)tile * KT * 64 + lane;
-        const uint2* sp = reinterpret_cast<const uint2*>(SB) + (size_t)tile * G * 8 + (lane >> 4);
-#pragma unroll
-        for (int u = 0; u < XT; ++u) {
-            int kk = kt0 + u;
-            kk = kk < KT ? kk : KT - 1;
-            wv[u][r] = __builtin_nontemporal_load(wp + (size_t)kk * 64);
-        }
-#pragma unroll
-        for (int g = 0; g < XG; ++g) {
-            int gg = g0 + g;
-            gg = gg < G ? gg : G - 1;
-            sv[g][r][0] = sp[(size_t)gg * 8];
-            sv[g][r][1] = sp[(size_t)gg * 8 + 4];
-        }
-    }
-    bf16x8_t xr[XT][MT];
-    gemm_norm_prologue<MT, XT, KSB>(h, wnorm, KT, eps, kt0, lane, wave, rsum, xr);
-    bf16x8_t ones;
-#pragma unroll
-    for (int e = 0; e < 8; ++e) ones[e] = (short)0x3F80;
-    f32x4_t acc[R][MT];
-#pragma unroll
-    for (int r = 0; r < R; ++r)
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt) acc[r][mt] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int g = 0; g < XG; ++g)
-        if (g0 + g < G) {
-            f32x4_t ag[R][MT], sx[MT];
-#pragma unroll
-            for (int mt = 0; mt < MT; ++mt) {
-                sx[mt] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-                for (int r = 0; r < R; ++r) ag[r][mt] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
-            }
-#pragma unroll
-            for (int jj = 0; jj < 2; ++jj) {
-                bf16x8_t fr[R];
-#pragma unroll
-                for (int r = 0; r < R; ++r) fr[r] = dq_codes(wv[2 * g + jj][r]);
-#pragma unroll
-                for (int mt = 0; mt < MT; ++mt) {
-                    sx[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, xr[2 * g + jj][mt], sx[mt], 0, 0, 0);
-#pragma unroll
-                    for (int r = 0; r < R; ++r) ag[r][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fr[r], xr[2 * g + jj][mt], ag[r][mt], 0, 0, 0);
-                }
-            }
-#pragma unroll
-            for (int r = 0; r < R; ++r) {
-                float sc[4], bi[4];
-                unpack_bf16x4(sv[g][r][0], sc);
-                unpack_bf16x4(sv[g][r][1], bi);
-#pragma unroll
-                for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) acc[r][mt][e] += sc[e] * ag[r][mt][e] + bi[e] * sx[mt][e];
-            }
-        }
-#pragma unroll
-    for (int r = 0; r < R; ++r)
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt)
-            red[wave][r * MT + mt][lane] = make_float4(acc[r][mt][0], acc[r][mt][1], acc[r][mt][2], acc[r][mt][3]);
-    __syncthreads();
-    for (int mt = wave; mt < MT; mt += KSB) {
-#pragma unroll
-        for (int r = 0; r < R; ++r) {
-            float4 s0 = red[0][r * MT + mt][lane];
-#pragma unroll
-            for (int w = 1; w < KSB; ++w) {
-                float4 t = red[w][r * MT + mt][lane];
-                s0.x += t.x; s0.y += t.y; s0.z += t.z; s0.w += t.w;
-            }
-#pragma unroll
-            for (int m2 = 0; m2 < MT; ++m2)
-                if (m2 == mt) acc[r][m2] = (f32x4_t){s0.x, s0.y, s0.z, s0.w};
-        }
-        qgemm_epilogue<MT, R, EPI>(acc, out, ntg, 0, NT, N_out, Mpad, lane, mt, bias);
-    }
-}
-// waves per block: a wave owns whole scale groups (XT / 2 of them); 16 waves where the group count allows it and the LDS combine fits
-void launch_gemm_norm_q(int bits, int epi, const void* Qp, const bf16_t* SB, const bf16_t* h, const bf16_t* wnorm, void* out, int NT, int G, int N_out,
-                        int Mpad, float eps, hipStream_t s, const bf16_t* bias) {
-    MIS_REQUIRE(gemm_norm_supported(G * 64, Mpad) && (bits == 8 || bits == 4), MIS_ERR_GENERATION_FAILED, "fused norm GEMM (quantised): unsupported shape");
-    const bool pair = epi == EPI_SILU_MUL;
-#define GNQ_CASE(MTV, RV, E, XTV, KSBV, B)                                                                                           \
-    if (Mpad == 16 * MTV && epi == E && bits == B && (G + KSBV - 1) / KSBV <= XTV / 2) {                                             \
-        hipLaunchKernelGGL((k_gemm_norm_q<MTV, RV, E, XTV, KSBV, B>), dim3((NT + RV - 1) / RV), dim3(64 * KSBV), 0, s, Qp, SB, h, wnorm, out, NT, \
-                           G, N_out, Mpad, eps, bias);                                                                               \
-        return;                                                                                                                      \
-    }
-#define GNQ_BITS(MTV, RV, E, XTV, KSBV) GNQ_CASE(MTV, RV, E, XTV, KSBV, 8) GNQ_CASE(MTV, RV, E, XTV, KSBV, 4)
-    if (pair) {
-        GNQ_BITS(2, 2, EPI_SILU_MUL, 2, 8) GNQ_BITS(2, 2, EPI_SILU_MUL, 4, 8) GNQ_BITS(1, 2, EPI_SILU_MUL, 2, 8) GNQ_BITS(1, 2, EPI_SILU_MUL, 4, 8)
-    } else {
-        GNQ_BITS(2, 1, EPI_PARTIAL, 2, 16) GNQ_BITS(1, 1, EPI_PARTIAL, 2, 16) GNQ_BITS(2, 1, EPI_PARTIAL, 4, 8) GNQ_BITS(1, 1, EPI_PARTIAL, 4, 8)
-        GNQ_BITS(2, 1, EPI_BF16, 2, 16) GNQ_BITS(1, 1, EPI_BF16, 2, 16) GNQ_BITS(2, 1, EPI_BF16, 4, 8) GNQ_BITS(1, 1, EPI_BF16, 4, 8)
-    }
-#undef GNQ_BITS
-#undef GNQ_CASE
-    throw MisError(MIS_ERR_GENERATION_FAILED, "fused norm GEMM (quantised): unsupported variant");
 }
 
 // ---- load-time packing: MLX layout (wq uint32 [N][K*bits/32], scales / biases bf16 [N][K/64]) -> the layouts above.

@@ -227,29 +227,3 @@ def test_second_attention_schedule_matches_the_first_and_the_oracle(monkeypatch)
         worst = max(worst, float(np.abs(d1 - d0).max() / np.abs(d0).max()))
     record("attention_second_schedule", bit_identical_to_first=bool(same), max_rel_vs_first=worst)
     assert worst <= 0.01
-
-
-@pytest.mark.parametrize("cfg,B", [(ollama.TINY, 3), (ollama.TINY_QWEN3, 20), (TINY_Q3TTS, 32), (ollama.TINY64, 5)],
-                         ids=["d768-mt1", "d512-qknorm-mt2", "qwen3tts-rope-ops-b32", "d256-head64"])
-def test_fused_norm_chain_matches_the_oracle_and_the_seven_launch_chain(cfg, B, monkeypatch):
-    """Hidden sizes <= 1024 run a 5-launch layer (RMSNorm rebuilt per block in the consumer GEMM's prologue, residual added in the
-    producer GEMM's epilogue: k_gemm_norm / EPI_RESID) instead of 7.  Same rounding points; only float32 summation orders differ (no
-    inter-block split-K, another order for the row sum of squares): both chains (MIS_FUSE_NORM read at reset) against the oracle
-    with the usual tolerance, and against each other."""
-    from gpu_util import logits_errors, record
-    W, oracle, dev = lm_pair(cfg)
-    rng = np.random.default_rng(41)
-    lens = [37 - (b * 5) % 30 for b in range(B)]
-    rows = [rng.integers(0, cfg.vocab_size, n).astype(np.int32) for n in lens]
-    out = {}
-    for mode in ("1", "0"):
-        monkeypatch.setenv("MIS_FUSE_NORM", mode)
-        out[mode] = teacher_forced(oracle, dev, rows, max_context=64)
-    worst = 0.0
-    for b in range(B):
-        for mode in ("1", "0"):
-            e_max, e_rms, _, agree = logits_errors(out[mode][b][0], out[mode][b][1])
-            assert e_max <= TOL_MAX and e_rms <= TOL_RMS and agree, (mode, b, e_max, e_rms)
-        worst = max(worst, rms(out["1"][b][0], out["0"][b][0]) / float(np.sqrt(np.mean(out["0"][b][0].astype(np.float64) ** 2))))
-    record(f"fused_norm_chain_d{cfg.hidden_size}", rms_rel_vs_seven_launch_chain=worst)
-    assert worst <= TOL_RMS
