@@ -25,7 +25,7 @@ pytestmark = pytest.mark.gpu
 def test_orpheus_3b_width_teacher_forced_b32_contexts_40_400_705():
     """Orpheus-3B per-layer shapes (d 3072, ffn 8192, 24/8 heads x 128, V 156 940, tied head), 2 layers, batch 32 = the bench's
     GEMM instantiations; ragged contexts so that attention runs 2 / 13 / 23 key tiles (incl. the second tile pair round and the
-    patched new-key tile beyond 512).  Tolerance: logits max <= 0.04 max|ref|, rms <= 0.008 rms(ref) (tests/test_gpu_lm.py)."""
+    patched new-key tile beyond 512).  Tolerance: logits max <= 0.016 max|ref|, rms <= 0.008 rms(ref) (tests/test_gpu_lm.py; observed 0.0075 / 0.0069)."""
     cfg = ollama.LlamaConfig(num_hidden_layers=2)                       # every other field = ORPHEUS_3B
     W = ollama.make_synthetic_weights(cfg, seed=4321)
     oracle = ollama.LlamaOracle(cfg, W, round="bf16")
@@ -58,10 +58,10 @@ def test_orpheus_3b_width_teacher_forced_b32_contexts_40_400_705():
         assert d.shape == r.shape
         e_max, e_rms, n_sure, agree = logits_errors(d, r)
         worst = (max(worst[0], e_max), max(worst[1], e_rms))
-        assert e_max <= 0.04 and e_rms <= 0.008, (b, e_max, e_rms)
+        assert e_max <= 0.016 and e_rms <= 0.008, (b, e_max, e_rms)
         assert agree, b
         assert torch.equal(torch.from_numpy(d), torch.from_numpy(d).bfloat16().float())          # bf16-valued logits
-    record("orpheus3b_width_b32_ctx705", logits_max_rel=worst[0], logits_rms_rel=worst[1], tol_max=0.04, tol_rms=0.008)
+    record("orpheus3b_width_b32_ctx705", logits_max_rel=worst[0], logits_rms_rel=worst[1], tol_max=0.016, tol_rms=0.008)
     # the same rows alone (B = 1 -> MT = 1 instantiation) give bit-identical logits: batching is exact
     dev.lm_reset(1, 768)
     for t in range(lens[4]):
@@ -71,7 +71,8 @@ def test_orpheus_3b_width_teacher_forced_b32_contexts_40_400_705():
 
 def test_whisper_large_v3_width_encoder_and_decoder_layer():
     """large-v3 per-layer shapes (d 1280, 20 heads x 64, ffn 5120, 128 mels, V 51 866), 1 + 1 layers.
-    Tolerance (tests/test_gpu_whisper.py): encoder max <= 0.05, rms <= 0.012; decoder logits max <= 0.05, rms <= 0.015."""
+    Tolerance (about twice the errors observed on MI355X: 0.0090 / 0.0034 / 0.0048 / 0.0041): encoder max <= 0.02, rms <= 0.008; decoder
+    logits max <= 0.012, rms <= 0.009."""
     cfg = ow.WhisperConfig(vocab_size=51866, num_mel_bins=128, d_model=1280, encoder_layers=1, encoder_attention_heads=20,
                            encoder_ffn_dim=5120, decoder_layers=1, decoder_attention_heads=20, decoder_ffn_dim=5120)
     W = ow.make_synthetic_weights(cfg, seed=777)
@@ -84,7 +85,7 @@ def test_whisper_large_v3_width_encoder_and_decoder_layer():
     enc = dev.encode(feats)
     e = [(float(np.abs(enc[b] - enc_ref[b].numpy()).max() / np.abs(enc_ref[b].numpy()).max()),
           rms(enc[b], enc_ref[b].numpy()) / float(np.sqrt(np.mean(enc_ref[b].numpy().astype(np.float64) ** 2)))) for b in range(B)]
-    assert max(x[0] for x in e) <= 0.05 and max(x[1] for x in e) <= 0.012, e
+    assert max(x[0] for x in e) <= 0.02 and max(x[1] for x in e) <= 0.008, e
     toks = np.random.default_rng(2).integers(0, cfg.vocab_size, (B, 40))
     dev.decoder_reset()
     got = [dev.decoder_forward(toks[:, t]) for t in range(40)]
@@ -94,15 +95,15 @@ def test_whisper_large_v3_width_encoder_and_decoder_layer():
         d = np.stack([g[b] for g in got]); r = ref[b].numpy()
         e_max, e_rms, n_sure, agree = logits_errors(d, r)
         worst = (max(worst[0], e_max), max(worst[1], e_rms))
-        assert e_max <= 0.05 and e_rms <= 0.015 and agree, (b, e_max, e_rms)
+        assert e_max <= 0.012 and e_rms <= 0.009 and agree, (b, e_max, e_rms)
     record("whisper_large_v3_width", enc_max_rel=max(x[0] for x in e), enc_rms_rel=max(x[1] for x in e), dec_logits_max_rel=worst[0],
-           dec_logits_rms_rel=worst[1], tol=[0.05, 0.012, 0.05, 0.015])
+           dec_logits_rms_rel=worst[1], tol=[0.02, 0.008, 0.012, 0.009])
 
 
 def test_qwen3tts_06b_width_frame_loop_and_real_decoder():
     """Qwen3-TTS-0.6B widths: talker 2 layers / predictor 1 layer at hidden 1024, 16/8 heads x 128, ffn 3072, codec vocab 3072,
     16 code groups; the speech-tokenizer decoder at its real dimensions (8 transformer layers, 1536-wide vocoder).
-    Tolerance: greedy choice within 0.04 max|logit| of the oracle's maximum (tests/test_gpu_qwen3tts.py); waveform 5e-4."""
+    Tolerance (about twice the observed 0.0051 / 9.8e-5): greedy choice within 0.012 max|logit| of the oracle's maximum; waveform 2e-4."""
     from test_gpu_qwen3tts import _host_cfg, _prompt
     base = oq.Qwen3TTSConfig()
     ocfg = oq.Qwen3TTSConfig(**{**base.__dict__,
@@ -140,13 +141,13 @@ def test_qwen3tts_06b_width_frame_loop_and_real_decoder():
             c0 = int(codes[b][f, 0])
             gap = float(l.max() - l[c0]) / float(np.abs(lg).max())
             worst = max(worst, gap)
-            assert c0 < cfg.talker.vocab_size - 1024 and gap <= 0.04, (b, f, gap)
+            assert c0 < cfg.talker.vocab_size - 1024 and gap <= 0.012, (b, f, gap)
             _, plog = olm.predictor_codes(hidden, c0, pr, b, f, forced=codes[b][f], want_logits=True)
             for i, pl in enumerate(plog):
                 ci = int(codes[b][f, i + 1])
                 g2 = float(pl.max() - pl[ci]) / float(np.abs(pl).max())
                 worst = max(worst, g2)
-                assert g2 <= 0.04, (b, f, i, g2)
+                assert g2 <= 0.012, (b, f, i, g2)
             te = trailing[f] if f < trailing.shape[0] else pad
             x = olm.next_input(te, [int(v) for v in codes[b][f]])[None]
             gen0.append(c0)
@@ -155,12 +156,12 @@ def test_qwen3tts_06b_width_frame_loop_and_real_decoder():
     ref = odec.decode(cd)
     got = dev.decode_codes(cd)
     werr = float(np.abs(got - ref).max() / max(np.abs(ref).max(), 1e-3))
-    assert got.shape == ref.shape == (2, 13 * 1920) and werr <= 5e-4, werr
+    assert got.shape == ref.shape == (2, 13 * 1920) and werr <= 2e-4, werr
     with codec_exact_f32():                                # the same decode on the exact-f32 kernels: the split-bf16 path ran, and is close
         ex = dev.decode_codes(cd)
     serr = float(np.abs(got - ex).max() / max(np.abs(ex).max(), 1e-3))
-    assert not np.array_equal(got, ex) and serr <= 3e-4, serr       # observed 1.0e-4 of the clipped full-scale waveform
-    record("qwen3tts_06b_width", greedy_gap_rel=worst, tol_gap=0.04, decoder_wave_max_rel=werr, tol_wave=5e-4, split_bf16_vs_exact_f32_max_rel=serr)
+    assert not np.array_equal(got, ex) and serr <= 2.5e-4, serr       # observed 1.0e-4 of the clipped full-scale waveform
+    record("qwen3tts_06b_width", greedy_gap_rel=worst, tol_gap=0.012, decoder_wave_max_rel=werr, tol_wave=2e-4, split_bf16_vs_exact_f32_max_rel=serr)
 
 
 def test_snac_24khz_one_row_96_groups():
@@ -172,7 +173,8 @@ def test_snac_24khz_one_row_96_groups():
     ref = oracle.decode(codes, noise)
     got = dev.decode(codes, noise)
     e = rms(got, ref)
-    assert got.shape == ref.shape == (1, 1, 96 * 2048) and e < 1e-4, e
+    assert got.shape == ref.shape == (1, 1, 96 * 2048) and e < 1e-4, e          # the north-star bound
+    assert e < 2e-5, e                                                          # twice the 8.9e-6 observed on MI355X
     # the same row inside a batch of 32 (the bench batch): bit-identical to the single-row decode
     codes32 = [np.repeat(c, 32, axis=0) for c in codes]
     noise32 = [np.repeat(n, 32, axis=0) for n in noise]
@@ -188,7 +190,7 @@ def test_snac_24khz_one_row_96_groups():
 
 def test_dac_24khz_and_encodec_24khz_real_dims():
     """Descript DAC 24 kHz (decoder_dim 1536, rates 8/5/4/2, 32 codebooks x 1024 x 8) and EnCodec 24 kHz (32 filters, hidden 128,
-    2-layer LSTM, 32 quantizers): waveform max error <= 3e-4 max|ref| (the small-config tolerance)."""
+    2-layer LSTM, 32 quantizers): waveform max error <= 1e-4 max|ref| (observed 5.0e-5 / 1.2e-5)."""
     c = od.DacConfig(n_codebooks=32, sample_rate=24000)
     W = od.make_synthetic_weights(c)
     stored = {k.replace(".outProj.", ".out_proj.").replace("decoder.model.", "decoder.model.layers."): v for k, v in W.items()}
@@ -198,11 +200,11 @@ def test_dac_24khz_and_encodec_24khz_real_dims():
     ref = orc.decode_from_codes(codes)
     got = dev.decode_from_codes(codes)
     e_dac = float(np.abs(got - ref).max() / np.abs(ref).max())
-    assert got.shape == ref.shape == (2, od.num_samples(c, 25)) and e_dac <= 3e-4, e_dac
+    assert got.shape == ref.shape == (2, od.num_samples(c, 25)) and e_dac <= 1e-4, e_dac
     with codec_exact_f32():
         ex = dev.decode_from_codes(codes)
     s_dac = float(np.abs(got - ex).max() / np.abs(ex).max())
-    assert not np.array_equal(got, ex) and s_dac <= 3e-4, s_dac
+    assert not np.array_equal(got, ex) and s_dac <= 1e-4, s_dac
     ec = oe.EncodecConfig()
     We = oe.make_synthetic_weights(ec)
     fields = {k: getattr(ec, k) for k in mas.EncodecConfig.__dataclass_fields__ if hasattr(ec, k)}
@@ -211,10 +213,10 @@ def test_dac_24khz_and_encodec_24khz_real_dims():
     ref = eo.decode_frame(codes)
     got = edev.decode_frame(codes)
     e_enc = float(np.abs(got - ref).max() / max(np.abs(ref).max(), 1e-3))
-    assert got.shape == ref.shape == (2, 75 * 320) and e_enc <= 3e-4, e_enc
+    assert got.shape == ref.shape == (2, 75 * 320) and e_enc <= 1e-4, e_enc
     with codec_exact_f32():
         ex = edev.decode_frame(codes)
     s_enc = float(np.abs(got - ex).max() / max(np.abs(ex).max(), 1e-3))
-    assert s_enc <= 3e-4, s_enc
-    record("dac_encodec_24khz_real_dims", dac_wave_max_rel=e_dac, encodec_wave_max_rel=e_enc, tol=3e-4, dac_split_bf16_vs_exact_f32_max_rel=s_dac,
+    assert s_enc <= 1e-4, s_enc
+    record("dac_encodec_24khz_real_dims", dac_wave_max_rel=e_dac, encodec_wave_max_rel=e_enc, tol=1e-4, dac_split_bf16_vs_exact_f32_max_rel=s_dac,
            encodec_split_bf16_vs_exact_f32_max_rel=s_enc)

@@ -2,7 +2,7 @@
 
 Tolerance (stated): the engine and the oracle both round to bf16 at every MLX primitive boundary but
 accumulate in different orders, so individual bf16 roundings may differ by one ulp and propagate.
-Teacher-forced logits must satisfy  max|dev - ref| <= 0.04 * max|ref|  and  rms(dev - ref) <=
+Teacher-forced logits must satisfy  max|dev - ref| <= 0.016 * max|ref| (two bf16 ulps of the largest logit; observed: one)  and  rms(dev - ref) <=
 0.008 * rms(ref), and the greedy token must agree whenever the oracle's top-2 margin exceeds that
 error bound."""
 import numpy as np
@@ -16,7 +16,7 @@ from oracle import llama as ollama
 pytestmark = pytest.mark.gpu
 
 
-TOL_MAX, TOL_RMS = 0.04, 0.008
+TOL_MAX, TOL_RMS = 0.016, 0.008          # observed on MI355X (profiles/r03_parity_observed.json): max <= 0.0078, rms <= 0.0069
 
 
 def _check(pairs):
@@ -152,7 +152,7 @@ def test_batched_prefill_matches_oracle_and_the_position_by_position_path(ocfg, 
     oracle's next-token logits, (ii) the same prompts fed position by position (MIS_PREFILL_SEQ=1: same rounding points, other float32
     summation order), and (iii) continuation: a decode step behind the batched prefill uses the caches it filled.  Ragged rows
     (left padding: a row starts when its first token arrives), 37 rows = a partial 128-row tile, prompts up to 70 tokens.
-    Tolerance: logits max <= 0.04 max|ref|; rms over the 74 (row, position) pairs: mean <= 0.008 rms(ref) (the per-row bound of the
+    Tolerance: logits max <= 0.016 max|ref|; rms over the 74 (row, position) pairs: mean <= 0.008 rms(ref) (the per-row bound of the
     other LM tests), worst <= 0.016 - single rows scatter around the bf16 noise floor (observed worst 0.007-0.011, 0.0069 for the
     decode path at Orpheus width, profiles/r02_parity_observed.json); batched and sequential prefill differ by the same amount."""
     from gpu_util import logits_errors, record
@@ -175,7 +175,7 @@ def test_batched_prefill_matches_oracle_and_the_position_by_position_path(ocfg, 
         ref = ref_all[b].numpy()
         for dv, sq, rf in ((got[b], seq[b], ref[0]), (got2[b], seq2[b], ref[1])):
             e_max, e_rms, _, agree = logits_errors(dv[None], rf[None])
-            assert e_max <= 0.04 and agree, (b, e_max)
+            assert e_max <= TOL_MAX and agree, (b, e_max)
             e_all.append(e_rms); m_all.append(e_max)
             d_all.append(float(np.sqrt(np.mean((dv - sq) ** 2)) / np.sqrt(np.mean(sq ** 2))))
     # single rows scatter around the bf16 noise floor (0.005-0.011 here, the same for the position-by-position path): bound the
@@ -184,7 +184,7 @@ def test_batched_prefill_matches_oracle_and_the_position_by_position_path(ocfg, 
     assert np.mean(d_all) <= 0.008 and np.max(d_all) <= 0.016, (np.mean(d_all), np.max(d_all))
     worst = [max(m_all), max(e_all), max(d_all)]
     record(f"batched_prefill_{ocfg.hidden_size}", logits_max_rel=worst[0], logits_rms_rel_worst=worst[1], logits_rms_rel_mean=float(np.mean(e_all)),
-           rms_vs_sequential_worst=worst[2], rms_vs_sequential_mean=float(np.mean(d_all)), tol_max=0.04, tol_rms_mean=0.008, tol_rms_worst=0.016)
+           rms_vs_sequential_worst=worst[2], rms_vs_sequential_mean=float(np.mean(d_all)), tol_max=TOL_MAX, tol_rms_mean=0.008, tol_rms_worst=0.016)
 
 
 def test_second_attention_schedule_matches_the_first_and_the_oracle(monkeypatch):

@@ -96,7 +96,7 @@ def test_native_quantised_streaming_matches_the_float32_dequant_oracle(bits, bat
     64, bf16 scales) are streamed as codes and dequantised in registers (csrc/lm_qgemm.hip).  Oracle = the LM on the float32
     weights s*q+b, NOT rounded to bf16 - what quantized_matmul computes (tests/test_oracle_mlxquant.py) - at Qwen3-TTS-0.6B talker
     widths (1024 / 3072, 16/8 heads): K = 1024 -> 16 scale groups (split-K S, 4 waves per item), K = 3072 -> 48; batch 32 / 40 / 5
-    -> MT = 2 / 3 / 1 (both register-buffer depths).  Tolerance as test_gpu_lm.py: logits max <= 0.04 max|ref|, rms <= 0.008."""
+    -> MT = 2 / 3 / 1 (both register-buffer depths).  Tolerance as test_gpu_lm.py: logits max <= 0.016 max|ref|, rms <= 0.008 (observed 0.0077 / 0.0060)."""
     from gpu_util import logits_errors, record
     W = ollama.make_synthetic_weights(QCFG, seed=99)
     m = mas.LlamaTTSModel(lm_host_config(QCFG))
@@ -121,11 +121,11 @@ def test_native_quantised_streaming_matches_the_float32_dequant_oracle(bits, bat
     for dev_l, ref_l in pairs:
         e_max, e_rms, n_sure, agree = logits_errors(dev_l, ref_l)
         worst = (max(worst[0], e_max), max(worst[1], e_rms))
-        assert e_max <= 0.04 and e_rms <= 0.008 and agree, (e_max, e_rms)
+        assert e_max <= 0.016 and e_rms <= 0.008 and agree, (e_max, e_rms)
     # how far the dequantise-at-load arithmetic (bf16-rounded weights) sits from the same device logits, for the record
     r16 = max(logits_errors(d, r)[1] for d, r in ref16)
     record(f"native_quant_{bits}bit_b{batch}", logits_max_rel=worst[0], logits_rms_rel=worst[1], rms_vs_bf16_rounded_weights=r16,
-           tol_max=0.04, tol_rms=0.008)
+           tol_max=0.016, tol_rms=0.008)
 
 
 def test_quantised_role_with_a_per_layer_override_falls_back_to_the_dense_copy():

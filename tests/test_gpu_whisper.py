@@ -1,8 +1,8 @@
 """-m gpu: Whisper encoder / decoder (HIP) vs the oracle (pinned against HF WhisperModel).
 
 Tolerance (stated): bf16 storage at every primitive boundary on both sides, different accumulation orders:
-encoder output  max|dev-ref| <= 0.05*max|ref| and rms <= 0.012*rms(ref);  teacher-forced decoder logits
-max <= 0.05*max|ref|, rms <= 0.015*rms(ref);  greedy tokens agree where the oracle's top-2 margin exceeds the error."""
+encoder output  max|dev-ref| <= 0.022*max|ref| and rms <= 0.012*rms(ref);  teacher-forced decoder logits
+max <= 0.022*max|ref|, rms <= 0.012*rms(ref) (about twice the observed 0.0106 / 0.0056);  greedy tokens agree where the oracle's top-2 margin exceeds the error."""
 import numpy as np
 import pytest
 
@@ -46,7 +46,7 @@ def test_encoder_and_teacher_forced_decoder_match_oracle(cfg):
     enc_ref = oracle.encode(feats)
     enc = dev.encode(feats)
     for b in range(B):
-        _check(enc[b], enc_ref[b].numpy(), 0.05, 0.012)
+        _check(enc[b], enc_ref[b].numpy(), 0.022, 0.012)
     rng = np.random.default_rng(2)
     toks = rng.integers(0, cfg.vocab_size, (B, 40))           # > 32 self keys: two key tiles
     dev.decoder_reset()
@@ -54,7 +54,7 @@ def test_encoder_and_teacher_forced_decoder_match_oracle(cfg):
     ref = oracle.decode([toks[0], toks[1]])
     for b in range(B):
         d = np.stack([g[b] for g in got]); r = ref[b].numpy()
-        _check(d, r, 0.05, 0.015)
+        _check(d, r, 0.022, 0.012)
         err = float(np.abs(d - r).max())
         top2 = np.sort(r, axis=1)[:, -2:]
         sure = (top2[:, 1] - top2[:, 0]) > 2 * err
