@@ -452,6 +452,48 @@ mis_status mis_qwen3tts_generate(mis_qwen3tts*, const int32_t* text_ids, const i
                                  int64_t* pcm_stride, int64_t* pcm_lens, int32_t** codes_out, int64_t* codes_stride,
                                  int32_t* n_frames, int chunk_frames, mis_event_cb on_event, void* user,
                                  const volatile int* cancel_flag);
+/* In-context voice cloning.  Replaces the reference-audio front end - extractSpeakerEmbedding (Qwen3TTS.swift:839-881:
+ * computeMelSpectrogram(24 kHz, nFft 1024, hop 256, 128 mels) -> Qwen3TTSSpeakerEncoder, Qwen3TTSSpeakerEncoder.swift:20-307) and
+ * Qwen3TTSSpeechTokenizerEncoder.encode (Qwen3TTSSpeechTokenizer.swift:792-881: Mimi SEANet encoder, causal transformer, edge-padded
+ * downsampling conv, split residual VQ) - and the ReferenceAudioContext the model keeps (:268-300): codecEmbedIcl (:249-266) rows
+ * and the speaker vector become extra prompt rows of the handle that prefill positions address by codec id. */
+typedef struct {
+    /* Qwen3TTSSpeakerEncoderConfig (Qwen3TTSConfig.swift:69-117); spk_n_blocks = entries of enc_channels, 0 = no speaker encoder */
+    int32_t spk_mel_dim, spk_enc_dim, spk_n_blocks;
+    int32_t spk_channels[8], spk_kernel_sizes[8], spk_dilations[8];
+    int32_t spk_attention_channels, spk_res2net_scale, spk_se_channels, spk_sample_rate;
+    /* Qwen3TTSTokenizerEncoderConfig (Qwen3TTSConfig.swift:388-497); enc_num_filters == 0 = the tokenizer has no encoder */
+    int32_t enc_audio_channels, enc_num_filters, enc_kernel_size, enc_last_kernel_size, enc_residual_kernel_size;
+    int32_t enc_num_residual_layers, enc_dilation_growth_rate, enc_compress;
+    int32_t enc_n_ratios, enc_upsampling_ratios[8];      /* as configured ([8,6,5,4]); the encoder applies them reversed */
+    int32_t enc_use_causal_conv, enc_use_conv_shortcut;
+    int32_t enc_hidden_size, enc_num_layers, enc_num_heads, enc_intermediate_size;
+    int32_t enc_codebook_dim, enc_codebook_size, enc_num_quantizers, enc_valid_num_quantizers, enc_sampling_rate;
+    float   enc_rope_theta, enc_frame_rate, enc_norm_eps;
+} mis_qwen3tts_reference_config;
+/* before the first set_tensor of these keys: "speaker_encoder.*" (names as Qwen3TTSSpeakerEncoder.sanitize leaves them behind the
+ * prefix, conv weights [out, k, in]) and "encoder_model.*" (Qwen3TTSSpeechTokenizer.sanitize :1093-1440) are then routed to the
+ * front end by mis_qwen3tts_set_tensor and checked by mis_qwen3tts_finalize */
+mis_status mis_qwen3tts_enable_reference(mis_qwen3tts*, const mis_qwen3tts_reference_config*);
+/* audio f32 [n_samples] mono at spk_sample_rate (host or device) -> out f32 [spk_enc_dim] */
+mis_status mis_qwen3tts_speaker_embedding(mis_qwen3tts*, const float* audio, int64_t n_samples, float* out);
+/* audio f32 [n_samples] mono at enc_sampling_rate -> *codes_out (mis_free) int32 [*n_q][*n_frames], n_q = min(valid, num_quantizers) */
+mis_status mis_qwen3tts_encode_audio(mis_qwen3tts*, const float* audio, int64_t n_samples, int32_t** codes_out, int32_t* n_q,
+                                     int32_t* n_frames);
+/* parity taps, out f32 [channels, length] (capacity floats).  kind 0 = speaker encoder: stage i < spk_n_blocks - 1 = output of
+ * blocks[i], then mfa, then asp ([2C, 1]); kind 1 = tokenizer encoder: 0 SEANet, 1 transformer, 2 downsampled latent */
+mis_status mis_qwen3tts_reference_tap(mis_qwen3tts*, int kind, const float* audio, int64_t n_samples, int stage, float* out,
+                                      int64_t capacity, int32_t* channels, int64_t* length);
+/* A reference context on the handle: codes int32 [n_q, T] (n_q <= num_code_groups) and optionally the speaker vector
+ * (f32 [hidden_size of the talker], rounded to the talker's bf16 on entry).  Its prompt rows follow the codec vocabulary: a prefill
+ * position whose codec id is vocab_size + *speaker_row reads the speaker vector, vocab_size + *first_frame_row + t reads
+ * codec_embedding[code 0 of frame t] + sum_i code_predictor.codec_embedding[i][code i+1 of frame t] (one bf16 rounding per add,
+ * codecEmbedIcl :249-266).  A non-streaming generate prepends the reference codes of a row whose prompt uses such frame rows to the
+ * generated ones before decoding and cuts the proportional head (ref frames / total frames) off the waveform (:550-563).
+ * *speaker_row = -1 without a speaker vector.  Contexts live until clear_references / destroy; at most 64. */
+mis_status mis_qwen3tts_add_reference(mis_qwen3tts*, const int32_t* codes, int n_q, int T, const float* speaker_embedding,
+                                      int speaker_dim, int32_t* speaker_row, int32_t* first_frame_row);
+mis_status mis_qwen3tts_clear_references(mis_qwen3tts*);
 /* stand-alone sampleToken (parity tests): logits f32 [batch, vocab], seen u8 [batch, vocab] or NULL */
 mis_status mis_qwen3tts_sample_logits(int device, const float* logits, int batch, int vocab, const uint8_t* seen,
                                       const mis_qwen3tts_params* params, int suppress_lo, int suppress_hi, int eos_id, int step,
@@ -524,7 +566,7 @@ mis_status mis_encodec_debug_tap(mis_encodec*, const int32_t* codes, int batch, 
  * (melFilters DSP.swift:76-168), log10, clamp to (max - 8), (x + 4) / 4.
  * ---------------------------------------------------------------------------------------- */
 typedef struct {
-    int32_t sample_rate, n_fft /* even, <= 512 */, hop_length, n_mels /* <= 256 */;
+    int32_t sample_rate, n_fft /* even, <= 2048 */, hop_length, n_mels /* <= 256 */;
     int32_t window;           /* 0 periodic Hann (WhisperAudio.swift:42-43), 1 symmetric Hann (DSP.swift:15-22) */
     int32_t mel_scale;        /* 0 HTK (DSP default), 1 Slaney (Whisper) */
     int32_t slaney_norm;      /* 1 = area normalisation (DSP.swift:155-162) */

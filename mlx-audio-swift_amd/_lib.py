@@ -67,6 +67,23 @@ class Qwen3TTSConfigC(C.Structure):
                 ("n_upsampling_ratios", C.c_int32), ("upsampling_ratios", C.c_int32 * 8), ("sample_rate", C.c_int32)]
 
 
+class Qwen3TTSReferenceConfigC(C.Structure):
+    _fields_ = [("spk_mel_dim", C.c_int32), ("spk_enc_dim", C.c_int32), ("spk_n_blocks", C.c_int32),
+                ("spk_channels", C.c_int32 * 8), ("spk_kernel_sizes", C.c_int32 * 8), ("spk_dilations", C.c_int32 * 8),
+                ("spk_attention_channels", C.c_int32), ("spk_res2net_scale", C.c_int32), ("spk_se_channels", C.c_int32),
+                ("spk_sample_rate", C.c_int32),
+                ("enc_audio_channels", C.c_int32), ("enc_num_filters", C.c_int32), ("enc_kernel_size", C.c_int32),
+                ("enc_last_kernel_size", C.c_int32), ("enc_residual_kernel_size", C.c_int32),
+                ("enc_num_residual_layers", C.c_int32), ("enc_dilation_growth_rate", C.c_int32), ("enc_compress", C.c_int32),
+                ("enc_n_ratios", C.c_int32), ("enc_upsampling_ratios", C.c_int32 * 8),
+                ("enc_use_causal_conv", C.c_int32), ("enc_use_conv_shortcut", C.c_int32),
+                ("enc_hidden_size", C.c_int32), ("enc_num_layers", C.c_int32), ("enc_num_heads", C.c_int32),
+                ("enc_intermediate_size", C.c_int32),
+                ("enc_codebook_dim", C.c_int32), ("enc_codebook_size", C.c_int32), ("enc_num_quantizers", C.c_int32),
+                ("enc_valid_num_quantizers", C.c_int32), ("enc_sampling_rate", C.c_int32),
+                ("enc_rope_theta", C.c_float), ("enc_frame_rate", C.c_float), ("enc_norm_eps", C.c_float)]
+
+
 class Qwen3TTSParamsC(C.Structure):
     _fields_ = [("max_frames", C.c_int32), ("temperature", C.c_float), ("top_p", C.c_float), ("top_k", C.c_int32),
                 ("repetition_penalty", C.c_float), ("min_p", C.c_float), ("seed", C.c_uint64), ("row_offset", C.c_int64)]
@@ -227,6 +244,13 @@ SYMBOLS = {
     "mis_qwen3tts_generate": (C.c_int, [_P, _P, _P, _P, C.c_int, _P, _P, C.c_int, C.c_int, C.POINTER(Qwen3TTSParamsC), _P,
                                         C.POINTER(_P), C.POINTER(C.c_int64), _P, C.POINTER(_P), C.POINTER(C.c_int64), _P,
                                         C.c_int, EVENT_CB, _P, _P]),
+    "mis_qwen3tts_enable_reference": (C.c_int, [_P, C.POINTER(Qwen3TTSReferenceConfigC)]),
+    "mis_qwen3tts_speaker_embedding": (C.c_int, [_P, _P, C.c_int64, _P]),
+    "mis_qwen3tts_encode_audio": (C.c_int, [_P, _P, C.c_int64, C.POINTER(_P), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
+    "mis_qwen3tts_reference_tap": (C.c_int, [_P, C.c_int, _P, C.c_int64, C.c_int, _P, C.c_int64, C.POINTER(C.c_int32),
+                                             C.POINTER(C.c_int64)]),
+    "mis_qwen3tts_add_reference": (C.c_int, [_P, _P, C.c_int, C.c_int, _P, C.c_int, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
+    "mis_qwen3tts_clear_references": (C.c_int, [_P]),
     "mis_qwen3tts_sample_logits": (C.c_int, [C.c_int, _P, C.c_int, C.c_int, _P, C.POINTER(Qwen3TTSParamsC), C.c_int, C.c_int,
                                              C.c_int, C.c_int, _P]),
     "mis_dac_create": (C.c_int, [C.POINTER(DacConfigC), C.c_int, C.POINTER(_P)]),

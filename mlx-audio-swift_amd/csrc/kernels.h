@@ -24,6 +24,7 @@ const mis_snac_config* snac_config(const mis_snac* c);
 
 // mel.hip
 void whisper_features_device(int device, const float* pcm_dev, int batch, int n_mels, float* out_dev, hipStream_t s);
+void mel_spectrogram_device(int device, const mis_mel_config& c, const float* pcm_dev, int batch, int64_t n_samples, float* out_dev, hipStream_t s);
 
 // lm_engine.hip hooks used by soprano.hip
 struct mis_tts;

@@ -149,6 +149,108 @@ __global__ void __launch_bounds__(256) k_mel_tile(MelParams p) {
     if (lane == 0 && wmax > -INFINITY) atomic_max_float(p.row_max + b, wmax);
 }
 
+// n_fft > 512 (computeMelSpectrogram(nFft: 1024) of the Qwen3-TTS speaker encoder, Qwen3TTS.swift:839-880): the frame tile no longer
+// fits LDS whole, so the DFT walks the frame in MELB_KC-sample chunks (restaged per group of 8 bin tiles: the samples are L2 hits)
+// and the filterbank contraction consumes the power spectrum 256 bins at a time; accumulators stay in registers across groups.
+#define MELB_KC 128
+__global__ void __launch_bounds__(256) k_mel_tile_big(MelParams p) {
+    __shared__ float As[MEL_FRAMES][MELB_KC + 1];
+    __shared__ float Ps[MEL_FRAMES][256 + 1];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int b = blockIdx.y, f0 = blockIdx.x * MEL_FRAMES;
+    const float* a = p.pcm + (size_t)b * p.n_samples;
+    const int pad = p.n_fft / 2;
+    const int n_btiles = p.nfp / 32, n_mtiles = p.nmp / 32;
+    const int kh = lane >> 5, col = lane & 31;
+    f32x16_t macc[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) macc[t][r] = 0.0f;
+    for (int g = 0; g < n_btiles; g += 8) {
+        f32x16_t re[2], im[2];
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { re[t][r] = 0.0f; im[t][r] = 0.0f; }
+        const int bt0 = g + wave, bt1 = g + wave + 4;
+        const bool has0 = bt0 < n_btiles, has1 = bt1 < n_btiles;
+        const float* c0 = p.cosT + (has0 ? bt0 : 0) * 32 + col;
+        const float* s0 = p.sinT + (has0 ? bt0 : 0) * 32 + col;
+        const float* c1 = p.cosT + (has1 ? bt1 : 0) * 32 + col;
+        const float* s1 = p.sinT + (has1 ? bt1 : 0) * 32 + col;
+        for (int k0 = 0; k0 < p.n_fft; k0 += MELB_KC) {
+            __syncthreads();
+            for (int idx = tid; idx < MEL_FRAMES * MELB_KC; idx += 256) {
+                const int f = idx / MELB_KC, kk = idx - f * MELB_KC, k = k0 + kk, fr = f0 + f;
+                float v = 0.0f;
+                if (fr < p.frames_total && k < p.n_fft) {
+                    const long long q = (long long)fr * p.hop + k;
+                    v = (p.raw ? (q < p.n_samples ? a[q] : 0.0f) : padded_sample(a, p.n_samples, q, pad)) * p.window[k];
+                }
+                As[f][kk] = v;
+            }
+            __syncthreads();
+            const int kn = min(MELB_KC, p.n_fft - k0);
+            if (has0) {
+#pragma unroll 4
+                for (int kk = 0; kk < kn; kk += 2) {
+                    const float av = As[col][kk + kh];
+                    const size_t row = (size_t)(k0 + kk + kh) * p.nfp;
+                    re[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, c0[row], re[0], 0, 0, 0);
+                    im[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, s0[row], im[0], 0, 0, 0);
+                    if (has1) {
+                        re[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, c1[row], re[1], 0, 0, 0);
+                        im[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, s1[row], im[1], 0, 0, 0);
+                    }
+                }
+            }
+        }
+        // power spectrum of this group -> Ps (the previous group's filterbank reads finished before the barriers above)
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            const int lt = wave + 4 * t;                              // local bin tile 0..7
+            const bool has = (g + lt) < n_btiles;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int frow = (r & 3) + 8 * (r >> 2) + 4 * kh;
+                Ps[frow][lt * 32 + col] = has ? re[t][r] * re[t][r] + im[t][r] * im[t][r] : 0.0f;
+            }
+        }
+        __syncthreads();
+        const int bins = min(256, p.nfp - g * 32);
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            const int mt = wave + 4 * t;
+            if (mt >= n_mtiles) continue;
+            const float* fp = p.filt + (size_t)g * 32 * p.nmp + mt * 32 + col;
+#pragma unroll 4
+            for (int k = 0; k < bins; k += 2) {
+                const float av = Ps[col][k + kh];
+                macc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, fp[(size_t)(k + kh) * p.nmp], macc[t], 0, 0, 0);
+            }
+        }
+    }
+    float wmax = -INFINITY;
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        const int mt = wave + 4 * t;
+        if (mt >= n_mtiles) continue;
+        const int mel = mt * 32 + col;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int fr = f0 + (r & 3) + 8 * (r >> 2) + 4 * kh;
+            if (fr < p.frames_out && mel < p.n_mels) {
+                const float v = log10f(fmaxf(macc[t][r], 1e-10f));
+                p.out[((size_t)b * p.frames_out + fr) * p.n_mels + mel] = v;
+                wmax = fmaxf(wmax, v);
+            }
+        }
+    }
+    wmax = wave_max(wmax);
+    if (lane == 0 && wmax > -INFINITY) atomic_max_float(p.row_max + b, wmax);
+}
+
 __global__ void k_mel_normalize(float* __restrict__ out, const float* __restrict__ row_max, size_t per_row, int batch) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     int b = blockIdx.y;
@@ -203,7 +305,7 @@ static MelPlan* get_plan(int device, const mis_mel_config& c) {
     std::lock_guard<std::mutex> lk(g_plan_mu);
     for (MelPlan* p : g_plans)
         if (p->device == device && memcmp(&p->cfg, &c, sizeof(c)) == 0) return p;
-    MIS_REQUIRE(c.n_fft >= 16 && c.n_fft <= 512 && (c.n_fft % 2) == 0, MIS_ERR_INVALID_INPUT, "n_fft must be even, 16..512");
+    MIS_REQUIRE(c.n_fft >= 16 && c.n_fft <= 2048 && (c.n_fft % 2) == 0, MIS_ERR_INVALID_INPUT, "n_fft must be even, 16..2048");
     MIS_REQUIRE(c.hop_length >= 1 && c.n_mels >= 1 && c.n_mels <= 256 && c.sample_rate > 0, MIS_ERR_INVALID_INPUT, "bad mel config");
     MelPlan* p = new MelPlan();
     p->cfg = c; p->device = device;
@@ -256,13 +358,21 @@ static void run_mel(int device, const mis_mel_config& c, const float* pcm_dev, i
     mp.n_samples = n_samples; mp.n_fft = c.n_fft; mp.hop = c.hop_length; mp.n_mels = c.n_mels;
     mp.nfp = pl->nfp; mp.nmp = pl->nmp; mp.frames_total = frames_total; mp.frames_out = frames_out;
     size_t smem = (size_t)MEL_FRAMES * (std::max(c.n_fft, pl->nfp) + 1) * sizeof(float);
-    MIS_REQUIRE(smem <= 64 * 1024, MIS_ERR_INVALID_INPUT, "mel tile does not fit LDS");
-    hipLaunchKernelGGL(k_mel_tile, dim3(cdiv(frames_out, MEL_FRAMES), batch), dim3(256), smem, s, mp);
+    if (c.n_fft <= 512) {
+        MIS_REQUIRE(smem <= 64 * 1024, MIS_ERR_INVALID_INPUT, "mel tile does not fit LDS");
+        hipLaunchKernelGGL(k_mel_tile, dim3(cdiv(frames_out, MEL_FRAMES), batch), dim3(256), smem, s, mp);
+    } else
+        hipLaunchKernelGGL(k_mel_tile_big, dim3(cdiv(frames_out, MEL_FRAMES), batch), dim3(256), 0, s, mp);
     size_t per_row = (size_t)frames_out * c.n_mels;
     hipLaunchKernelGGL(k_mel_normalize, dim3((unsigned)((per_row + 255) / 256), batch), dim3(256), 0, s, out_dev, rmax.p,
                        per_row, batch);
     HIP_CHECK(hipGetLastError());
     HIP_CHECK(hipStreamSynchronize(s));        // rmax is freed on return
+}
+
+// device-pointer entry for other engines (the Qwen3-TTS speaker encoder): pcm_dev [batch][n_samples] -> out_dev [batch][frames][n_mels]
+void mel_spectrogram_device(int device, const mis_mel_config& c, const float* pcm_dev, int batch, int64_t n_samples, float* out_dev, hipStream_t s) {
+    run_mel(device, c, pcm_dev, batch, n_samples, out_dev, s);
 }
 
 // device-pointer entry used by the Whisper engine: pcm_dev [batch][480000] (already padded) -> out_dev [batch][3000][n_mels]

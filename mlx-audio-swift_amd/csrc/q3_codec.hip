@@ -21,6 +21,7 @@
 #include "common.h"
 #include "kernels.h"
 #include "codec_kernels.h"
+#include "q3_kernels.h"
 
 #include <math.h>
 #include <string.h>
@@ -171,13 +172,6 @@ __global__ void k_q3_swiglu(const float* __restrict__ gu, float* __restrict__ ac
 // tensor for whole sequences (pos0 = 0), the session's cache when streaming.  One thread per query, 64 queries per block; K/V
 // tiles of 64 keys counted from key 0 are staged (K rotated) in LDS and read by all threads at the same address (broadcast), so
 // a query sees the same operation order whichever chunk it arrives in.
-struct Q3AttnArgs {
-    const float* q; int64_t q_bs; int q_ld;
-    const float* k; const float* v; int64_t kv_bs; int kv_ld;
-    float* out; int64_t o_bs; int o_ld;
-    int H, Hkv, Tq, pos0;
-    float theta, scale;
-};
 template <int D>
 __global__ void __launch_bounds__(64) k_q3_attn(Q3AttnArgs a) {
     __shared__ float Ks[D][64];
@@ -274,6 +268,18 @@ __global__ void __launch_bounds__(256) k_q3_final(const float* __restrict__ x, f
     }
     const int t = t0 + tid;
     if (t < T) out[(size_t)b * out_stride + t] = fminf(fmaxf(acc, -1.0f), 1.0f);
+}
+
+void launch_q3_attn(const Q3AttnArgs& a, int D, int batch, hipStream_t s) {
+    dim3 ag(cdiv(a.Tq, 64), a.H, batch);
+    if (D == 64) hipLaunchKernelGGL((k_q3_attn<64>), ag, dim3(64), 0, s, a);
+    else if (D == 32) hipLaunchKernelGGL((k_q3_attn<32>), ag, dim3(64), 0, s, a);
+    else if (D == 16) hipLaunchKernelGGL((k_q3_attn<16>), ag, dim3(64), 0, s, a);
+    else throw MisError(MIS_ERR_INVALID_INPUT, "attention head_dim must be 16, 32 or 64");
+}
+void launch_q3_norm_ct(const float* x, float* y, const float* w, const float* bias, int batch, int C, int Tn, int ld, float eps, int rms,
+                       hipStream_t s) {
+    hipLaunchKernelGGL(k_q3_norm_ct, dim3(cdiv(Tn, Q3N_COLS), batch), dim3(256), 0, s, x, y, w, bias, C, Tn, ld, eps, rms);
 }
 
 // ---------------------------------------------------------------------------- host: weights

@@ -41,6 +41,14 @@ struct mis_qwen3tts {
     DevBuf<int32_t> iota, tidx, cidx, plen, trail_idx, trail_len, cur_codes, codes, n_frames, frame, step_counter, done, row_max,
         ids_tmp;
     DevBuf<uint8_t> seen;
+    // in-context voice cloning: the reference-audio front end and the reference contexts of the handle (ReferenceAudioContext,
+    // Qwen3TTS.swift:268-300).  Prompt rows [n_ref_rows][d] follow the codec vocabulary in the prefill feed.
+    mis_q3ref* ref = nullptr;
+    struct RefCtx { int speaker_row = -1, frame_row0 = 0, T = 0; std::vector<int32_t> codes; /* [G][T] */ };
+    std::vector<RefCtx> refs;
+    std::vector<int> ref_row_ctx;           // row -> context index
+    DevBuf<bf16_t> ref_rows;
+    int n_ref_rows = 0;
 };
 
 // ---------------------------------------------------------------------------- kernels
@@ -69,8 +77,8 @@ __global__ void k_q3_unpack_x(const bf16_t* __restrict__ xpk, bf16_t* __restrict
 // first position).  Every position is text_proj(text_emb[t]) and/or codec_emb[c] (prepareGenerationInputs :883-1000).
 __global__ void k_q3_prefill_feed(const int32_t* __restrict__ tidx, const int32_t* __restrict__ cidx, const int32_t* __restrict__ plen,
                                   int P, int Lmax, const int* __restrict__ step_counter, const bf16_t* __restrict__ tproj,
-                                  const bf16_t* __restrict__ codec_emb, int Vc, bf16_t* __restrict__ in_emb,
-                                  uint8_t* __restrict__ active, int d, int batch) {
+                                  const bf16_t* __restrict__ codec_emb, int Vc, const bf16_t* __restrict__ ref_rows, int n_ref_rows,
+                                  bf16_t* __restrict__ in_emb, uint8_t* __restrict__ active, int d, int batch) {
     const int b = blockIdx.x;
     const int j = *step_counter;
     int idx = -1;
@@ -79,15 +87,32 @@ __global__ void k_q3_prefill_feed(const int32_t* __restrict__ tidx, const int32_
     if (threadIdx.x == 0) active[b] = on ? 1 : 0;
     const int t = on ? tidx[(size_t)b * P + idx] : -1;
     int c = on ? cidx[(size_t)b * P + idx] : -1;
-    if (c >= Vc) c = -1;
+    // ids past the codec vocabulary address the handle's reference rows (speaker vector / codecEmbedIcl frames, Qwen3TTS.swift:249-266)
+    const bf16_t* crow = nullptr;
+    if (c >= Vc) { if (c - Vc < n_ref_rows) crow = ref_rows + (size_t)(c - Vc) * d; }
+    else if (c >= 0) crow = codec_emb + (size_t)c * d;
     for (int k = threadIdx.x; k < d; k += blockDim.x) {
         float v = 0.0f;
-        if (t >= 0 && c >= 0) v = bf16_round_f32(bf16_to_f32(tproj[(size_t)t * d + k]) + bf16_to_f32(codec_emb[(size_t)c * d + k]));
+        if (t >= 0 && crow) v = bf16_round_f32(bf16_to_f32(tproj[(size_t)t * d + k]) + bf16_to_f32(crow[k]));
         else if (t >= 0) v = bf16_to_f32(tproj[(size_t)t * d + k]);
-        else if (c >= 0) v = bf16_to_f32(codec_emb[(size_t)c * d + k]);
+        else if (crow) v = bf16_to_f32(crow[k]);
         in_emb[(size_t)b * d + k] = f32_to_bf16(v);
     }
 }                                                                // the counter is bumped by a separate launch (k_q3_bump)
+
+// codecEmbedIcl rows (Qwen3TTS.swift:249-262): rows[t] = codec_emb[code 0] + sum_i pred_emb[i][code i+1], one bf16 rounding per add
+__global__ void k_q3_ref_rows(const int32_t* __restrict__ codes /*[nq][T]*/, int nq, int T, const bf16_t* __restrict__ codec_emb, int Vc,
+                              const bf16_t* const* __restrict__ pred_emb, int Vp, int d, bf16_t* __restrict__ rows) {
+    const int t = blockIdx.x;
+    for (int k = threadIdx.x; k < d; k += blockDim.x) {
+        float e = bf16_to_f32(codec_emb[(size_t)min(max(codes[t], 0), Vc - 1) * d + k]);
+        for (int i = 0; i + 1 < nq; ++i) {
+            const int ci = min(max(codes[(size_t)(i + 1) * T + t], 0), Vp - 1);
+            e = bf16_round_f32(e + bf16_to_f32(pred_emb[i][(size_t)ci * d + k]));
+        }
+        rows[(size_t)t * d + k] = f32_to_bf16(e);
+    }
+}
 
 __global__ void k_q3_bump(int* p) { if (threadIdx.x == 0 && blockIdx.x == 0) *p = *p + 1; }
 
@@ -194,6 +219,7 @@ extern "C" void mis_qwen3tts_destroy(mis_qwen3tts* c) {
     (void)hipSetDevice(c->device);
     if (c->s) (void)hipStreamSynchronize(c->s);
     if (c->s_dec) { (void)hipStreamSynchronize(c->s_dec); (void)hipStreamDestroy(c->s_dec); }
+    if (c->ref) q3ref_destroy(c->ref);
     if (c->dec) mis_q3dec_destroy(c->dec);
     if (c->pred) mis_tts_destroy(c->pred);          // borrows the talker's stream (or still owns its own if create failed early)
     if (c->talker) mis_tts_destroy(c->talker);
@@ -218,6 +244,11 @@ extern "C" mis_status mis_qwen3tts_set_tensor(mis_qwen3tts* c, const char* name_
     std::string name = name_;
     if (name.rfind("talker.", 0) == 0) name = name.substr(7);        // Qwen3TTSTalkerForConditionalGeneration.sanitize (:352-365)
     if (name.rfind("decoder.", 0) == 0) return mis_q3dec_set_tensor(c->dec, name.c_str(), data, dtype, shape, ndim);
+    if (q3ref_owns(name.c_str())) {
+        MIS_REQUIRE(c->ref, MIS_ERR_INVALID_INPUT, "tensor %s needs mis_qwen3tts_enable_reference first", name.c_str());
+        q3ref_set_tensor(c->ref, name.c_str(), data, dtype, shape, ndim);
+        return MIS_OK;
+    }
     HIP_CHECK(hipSetDevice(c->device));
     size_t n = 1;
     for (int i = 0; i < ndim; ++i) { MIS_REQUIRE(shape[i] > 0, MIS_ERR_INVALID_INPUT, "bad shape"); n *= (size_t)shape[i]; }
@@ -342,6 +373,7 @@ extern "C" mis_status mis_qwen3tts_finalize(mis_qwen3tts* c) {
     if (st == MIS_OK) st = mis_tts_finalize(c->pred);
     if (st == MIS_OK) st = mis_q3dec_finalize(c->dec);
     if (st != MIS_OK) return st;
+    if (c->ref) q3ref_finalize(c->ref);
     if (c->proj) {
         project_table(c, c->codec_emb.p, c->Vc, c->codec_emb_proj);
         for (int i = 0; i + 1 < c->G; ++i) project_table(c, c->pred_emb[i].p, c->Vp, c->pred_emb_proj[i]);
@@ -399,7 +431,7 @@ void q3_generate_codes(mis_qwen3tts* c, const int32_t* text_ids, const int32_t* 
         Lmax = std::max(Lmax, prefill_lens[b]);
         for (int p = 0; p < prefill_lens[b]; ++p) {
             int t = text_ids[(size_t)b * P + p], cc = codec_ids[(size_t)b * P + p];
-            MIS_REQUIRE(t < c->Vt && cc < c->Vc && (t >= 0 || cc >= 0), MIS_ERR_INVALID_INPUT, "row %d position %d: bad ids", b, p);
+            MIS_REQUIRE(t < c->Vt && cc < c->Vc + c->n_ref_rows && (t >= 0 || cc >= 0), MIS_ERR_INVALID_INPUT, "row %d position %d: bad ids", b, p);
             if (t >= 0) { tidx[(size_t)b * P + p] = (int)tlist.size(); tlist.push_back(t); }
             cidx[(size_t)b * P + p] = cc;
         }
@@ -453,7 +485,7 @@ void q3_generate_codes(mis_qwen3tts* c, const int32_t* text_ids, const int32_t* 
     // ---- prefill: one talker position per replay over the right-aligned prompt matrix
     auto prefill_body = [&]() {
         hipLaunchKernelGGL(k_q3_prefill_feed, dim3(Mpad), dim3(256), 0, s, c->tidx.p, c->cidx.p, c->plen.p, P, Lmax, c->step_counter.p,
-                           c->tproj.p, c->codec_emb.p, c->Vc, c->in_emb.p, tv.active, d, batch);
+                           c->tproj.p, c->codec_emb.p, c->Vc, c->ref_rows.p, c->n_ref_rows, c->in_emb.p, tv.active, d, batch);
         hipLaunchKernelGGL(k_q3_bump, dim3(1), dim3(64), 0, s, c->step_counter.p);
         tts_internal_enqueue_layers(c->talker, c->in_emb.p, Mpad, c->iota.p);
     };
@@ -607,6 +639,106 @@ extern "C" mis_status mis_qwen3tts_sample_logits(int device, const float* logits
 // ---------------------------------------------------------------------------- decode / generate
 extern "C" int mis_qwen3tts_samples_per_frame(const mis_qwen3tts* c) { return c ? q3dec_total_upsample(c->dec) : 0; }
 extern "C" int mis_qwen3tts_num_code_groups(const mis_qwen3tts* c) { return c ? c->G : 0; }
+
+// ---------------------------------------------------------------------------- in-context voice cloning: front end + reference contexts
+extern "C" mis_status mis_qwen3tts_enable_reference(mis_qwen3tts* c, const mis_qwen3tts_reference_config* cfg) {
+    MIS_API_BEGIN
+    MIS_REQUIRE(c && cfg, MIS_ERR_INVALID_INPUT, "null argument");
+    MIS_REQUIRE(!c->finalized && !c->ref, MIS_ERR_INVALID_INPUT, "enable_reference comes once, before finalize");
+    c->ref = q3ref_create(cfg, c->device, c->s);
+    MIS_API_END
+}
+// extractSpeakerEmbedding (Qwen3TTS.swift:839-881)
+extern "C" mis_status mis_qwen3tts_speaker_embedding(mis_qwen3tts* c, const float* audio, int64_t n_samples, float* out) {
+    MIS_API_BEGIN
+    MIS_REQUIRE(c && audio && out, MIS_ERR_INVALID_INPUT, "null argument");
+    MIS_REQUIRE(c->finalized && c->ref, MIS_ERR_NOT_INITIALIZED, "no reference front end on this handle (mis_qwen3tts_enable_reference)");
+    q3ref_speaker(c->ref, audio, n_samples, -1, out, q3ref_speaker_dim(c->ref), nullptr, nullptr);
+    MIS_API_END
+}
+// speechTokenizer.encode (Qwen3TTSSpeechTokenizer.swift:1052-1058 -> :868-881)
+extern "C" mis_status mis_qwen3tts_encode_audio(mis_qwen3tts* c, const float* audio, int64_t n_samples, int32_t** codes_out, int32_t* n_q,
+                                                int32_t* n_frames) {
+    MIS_API_BEGIN
+    MIS_REQUIRE(c && audio && codes_out && n_q && n_frames, MIS_ERR_INVALID_INPUT, "null argument");
+    MIS_REQUIRE(c->finalized && c->ref, MIS_ERR_NOT_INITIALIZED, "no reference front end on this handle (mis_qwen3tts_enable_reference)");
+    std::vector<int32_t> codes;
+    int nq = 0; int64_t T = 0;
+    q3ref_encode(c->ref, audio, n_samples, -1, nullptr, 0, nullptr, &T, &codes, &nq);
+    PinnedBuf<int32_t> host(codes.size() + 1);
+    memcpy(host.p, codes.data(), codes.size() * 4);
+    *codes_out = host.release(); *n_q = nq; *n_frames = (int32_t)T;
+    MIS_API_END
+}
+extern "C" mis_status mis_qwen3tts_reference_tap(mis_qwen3tts* c, int kind, const float* audio, int64_t n_samples, int stage, float* out,
+                                                 int64_t capacity, int32_t* channels, int64_t* length) {
+    MIS_API_BEGIN
+    MIS_REQUIRE(c && audio && out && channels && length && stage >= 0 && (kind == 0 || kind == 1), MIS_ERR_INVALID_INPUT, "bad argument");
+    MIS_REQUIRE(c->finalized && c->ref, MIS_ERR_NOT_INITIALIZED, "no reference front end on this handle (mis_qwen3tts_enable_reference)");
+    int C = 0; int64_t T = 0;
+    if (kind == 0) q3ref_speaker(c->ref, audio, n_samples, stage, out, capacity, &C, &T);
+    else q3ref_encode(c->ref, audio, n_samples, stage, out, capacity, &C, &T, nullptr, nullptr);
+    *channels = C; *length = T;
+    MIS_API_END
+}
+extern "C" mis_status mis_qwen3tts_add_reference(mis_qwen3tts* c, const int32_t* codes, int n_q, int T, const float* speaker_embedding,
+                                                 int speaker_dim, int32_t* speaker_row, int32_t* first_frame_row) {
+    MIS_API_BEGIN
+    MIS_REQUIRE(c && codes && speaker_row && first_frame_row, MIS_ERR_INVALID_INPUT, "null argument");
+    MIS_REQUIRE(c->finalized, MIS_ERR_NOT_INITIALIZED, "Qwen3-TTS model not finalized");
+    MIS_REQUIRE(n_q >= 1 && n_q <= c->G && T >= 1 && T <= 8192, MIS_ERR_INVALID_INPUT, "reference codes must be [1..%d, 1..8192]", c->G);
+    MIS_REQUIRE(!speaker_embedding || speaker_dim == c->d, MIS_ERR_INVALID_INPUT, "speaker vector has %d entries, the talker is %d wide", speaker_dim, c->d);
+    MIS_REQUIRE(c->refs.size() < 64, MIS_ERR_INVALID_INPUT, "too many reference contexts (mis_qwen3tts_clear_references)");
+    HIP_CHECK(hipSetDevice(c->device));
+    for (int i = 0; i < n_q * T; ++i)
+        MIS_REQUIRE(codes[i] >= 0 && codes[i] < (i < T ? c->Vc : c->Vp), MIS_ERR_INVALID_INPUT, "reference code %d out of range", codes[i]);
+    const int d = c->d, n_new = T + (speaker_embedding ? 1 : 0), n_old = c->n_ref_rows;
+    {   // grow the row table, keeping what is there
+        DevBuf<bf16_t> grown;
+        grown.alloc((size_t)(n_old + n_new) * d);
+        if (n_old) HIP_CHECK(hipMemcpyAsync(grown.p, c->ref_rows.p, (size_t)n_old * d * 2, hipMemcpyDeviceToDevice, c->s));
+        HIP_CHECK(hipStreamSynchronize(c->s));
+        std::swap(grown.p, c->ref_rows.p); std::swap(grown.n, c->ref_rows.n);
+    }
+    mis_qwen3tts::RefCtx ctx;
+    int row = n_old;
+    if (speaker_embedding) {
+        std::vector<bf16_t> sv(d);
+        for (int k = 0; k < d; ++k) sv[k] = f32_to_bf16(speaker_embedding[k]);
+        HIP_CHECK(hipMemcpyAsync(c->ref_rows.p + (size_t)row * d, sv.data(), (size_t)d * 2, hipMemcpyHostToDevice, c->s));
+        HIP_CHECK(hipStreamSynchronize(c->s));
+        ctx.speaker_row = row++;
+    }
+    ctx.frame_row0 = row; ctx.T = T;
+    ctx.codes.assign((size_t)c->G * T, 0);                           // missing groups decode as code 0
+    memcpy(ctx.codes.data(), codes, (size_t)n_q * T * 4);
+    {
+        DevBuf<int32_t> cd; DevBuf<const bf16_t*> ptabs_dev;
+        cd.alloc((size_t)n_q * T); ptabs_dev.alloc(c->G - 1);
+        std::vector<const bf16_t*> ptabs(c->G - 1);
+        for (int i = 0; i + 1 < c->G; ++i) ptabs[i] = c->pred_emb[i].p;
+        HIP_CHECK(hipMemcpyAsync(cd.p, codes, (size_t)n_q * T * 4, hipMemcpyHostToDevice, c->s));
+        HIP_CHECK(hipMemcpyAsync(ptabs_dev.p, ptabs.data(), (c->G - 1) * sizeof(void*), hipMemcpyHostToDevice, c->s));
+        hipLaunchKernelGGL(k_q3_ref_rows, dim3(T), dim3(256), 0, c->s, cd.p, n_q, T, c->codec_emb.p, c->Vc, ptabs_dev.p, c->Vp, d,
+                           c->ref_rows.p + (size_t)row * d);
+        HIP_CHECK(hipGetLastError());
+        HIP_CHECK(hipStreamSynchronize(c->s));
+    }
+    c->n_ref_rows = n_old + n_new;
+    c->ref_row_ctx.resize(c->n_ref_rows, (int)c->refs.size());
+    *speaker_row = ctx.speaker_row; *first_frame_row = ctx.frame_row0;
+    c->refs.push_back(std::move(ctx));
+    MIS_API_END
+}
+extern "C" mis_status mis_qwen3tts_clear_references(mis_qwen3tts* c) {
+    MIS_API_BEGIN
+    MIS_REQUIRE(c, MIS_ERR_INVALID_INPUT, "null handle");
+    HIP_CHECK(hipSetDevice(c->device));
+    HIP_CHECK(hipStreamSynchronize(c->s));
+    c->refs.clear(); c->ref_row_ctx.clear(); c->n_ref_rows = 0;
+    c->ref_rows.release();
+    MIS_API_END
+}
 
 // Qwen3TTSSpeechTokenizerDecoder.callAsFunction / streamingStep over the whole sequence: codes int32 [batch, num_quantizers, T]
 // (host or device) -> wav f32 [batch, T * samples_per_frame]
@@ -790,15 +922,59 @@ extern "C" mis_status mis_qwen3tts_generate(mis_qwen3tts* c, const int32_t* text
         cleanup();
         throw;
     }
+    // in-context voice cloning, non-streaming tail (Qwen3TTS.swift:547-563): a row whose prompt holds reference frame rows decodes
+    // [reference codes | generated codes] and loses the proportional head of the waveform; the streaming path decodes only what it generated
+    std::vector<int> row_ref(batch, -1), ntot(nf.begin(), nf.end());
+    std::vector<int64_t> cut(batch, 0);
+    bool any_ref = false;
+    if (!streaming && c->n_ref_rows > 0)
+        for (int b = 0; b < batch; ++b)
+            for (int p = 0; p < prefill_lens[b]; ++p) {
+                const int cc = codec_ids[(size_t)b * P + p];
+                if (cc < c->Vc) continue;
+                const int ci = c->ref_row_ctx[cc - c->Vc];
+                if (cc - c->Vc < c->refs[ci].frame_row0) continue;          // the speaker row alone does not make a row in-context
+                MIS_REQUIRE(row_ref[b] < 0 || row_ref[b] == ci, MIS_ERR_INVALID_INPUT, "row %d: prompt mixes two reference contexts", b);
+                row_ref[b] = ci; any_ref = true;
+            }
+    std::vector<int32_t> dcodes_host;
+    int dstride = stride;
+    if (any_ref) {
+        dstride = 1;
+        for (int b = 0; b < batch; ++b) {
+            if (row_ref[b] >= 0 && nf[b] > 0) ntot[b] = c->refs[row_ref[b]].T + nf[b];
+            dstride = std::max(dstride, ntot[b]);
+        }
+        dcodes_host.assign((size_t)batch * dstride * G, 0);
+        for (int b = 0; b < batch; ++b) {
+            int32_t* dst = dcodes_host.data() + (size_t)b * dstride * G;
+            int R = 0;
+            if (row_ref[b] >= 0 && nf[b] > 0) {
+                const auto& ctx = c->refs[row_ref[b]];
+                R = ctx.T;
+                for (int t = 0; t < R; ++t) for (int g = 0; g < G; ++g) dst[(size_t)t * G + g] = ctx.codes[(size_t)g * R + t];
+            }
+            memcpy(dst + (size_t)R * G, codes.data() + (size_t)b * stride * G, (size_t)nf[b] * G * 4);
+        }
+    }
+    const int32_t* dec_src_host = any_ref ? dcodes_host.data() : codes.data();
     int64_t longest = 0;
     for (int b = 0; b < batch; ++b) { pcm_lens[b] = (int64_t)nf[b] * up; longest = std::max(longest, pcm_lens[b]); }
-    if (!streaming)          // decodeChunk's validLen (:223-228): frames whose first code is > 0, times the upsample rate; a shorter
-        for (int b = 0; b < batch; ++b) {       // non-zero count trims the tail (code 0 is read as padding there) - mirrored
-            int64_t valid = 0;
-            for (int f = 0; f < nf[b]; ++f) valid += codes[((size_t)b * stride + f) * G] > 0;
+    if (!streaming) {        // decodeChunk's validLen (:223-228): frames whose first code is > 0, times the upsample rate; a shorter
+        longest = 0;         // non-zero count trims the tail (code 0 is read as padding there) - mirrored
+        for (int b = 0; b < batch; ++b) {
+            int64_t valid = 0, len = (int64_t)ntot[b] * up;
+            for (int f = 0; f < ntot[b]; ++f) valid += dec_src_host[((size_t)b * dstride + f) * G] > 0;
             valid *= up;
-            if (valid > 0 && valid < pcm_lens[b]) pcm_lens[b] = valid;
+            if (valid > 0 && valid < len) len = valid;
+            if (row_ref[b] >= 0 && ntot[b] > 0) {
+                const int64_t k = (int64_t)((double)c->refs[row_ref[b]].T / (double)std::max(ntot[b], 1) * (double)len);
+                if (k > 0 && k < len) cut[b] = k;
+            }
+            pcm_lens[b] = len - cut[b];
+            longest = std::max(longest, pcm_lens[b]);
         }
+    }
     PinnedBuf<float> host_pin((size_t)std::max<int64_t>(longest, 1) * batch);
     float* host = host_pin.p;
     memset(host, 0, (size_t)std::max<int64_t>(longest, 1) * batch * 4);
@@ -812,12 +988,19 @@ extern "C" mis_status mis_qwen3tts_generate(mis_qwen3tts* c, const int32_t* text
         chunks.clear();
     } else {
         DevBuf<float> wav;
+        DevBuf<int32_t> dcodes_dev;
+        const int32_t* dec_src = c->codes.p;
+        if (any_ref) {
+            dcodes_dev.alloc(dcodes_host.size());
+            HIP_CHECK(hipMemcpyAsync(dcodes_dev.p, dcodes_host.data(), dcodes_host.size() * 4, hipMemcpyHostToDevice, c->s));
+            dec_src = dcodes_dev.p;
+        }
         // consecutive rows decode together, right-padded to the slice's longest row (bounded by ~16 GB of activations)
         int b0 = 0;
         while (b0 < batch) {
-            int n = nf[b0], b1 = b0 + 1;
+            int n = ntot[b0], b1 = b0 + 1;
             auto fits = [&](int rows, int frames) { return (size_t)4 * 4 * 96 * (size_t)frames * up * rows <= ((size_t)16 << 30); };
-            while (b1 < batch && b1 - b0 < 64 && fits(b1 - b0 + 1, std::max(n, nf[b1]))) { n = std::max(n, nf[b1]); ++b1; }
+            while (b1 < batch && b1 - b0 < 64 && fits(b1 - b0 + 1, std::max(n, ntot[b1]))) { n = std::max(n, ntot[b1]); ++b1; }
             const int gb = b1 - b0;
             if (n > 0) {                                                // generatedCodes.isEmpty -> zeros([1]) (:520-522): length 0 here
                 wav.alloc((size_t)gb * n * up);
@@ -827,8 +1010,9 @@ extern "C" mis_status mis_qwen3tts_generate(mis_qwen3tts* c, const int32_t* text
                 // q3_codec.hip) - mirrored unless mis_qwen3tts_set_stream_exact(1).  Rows of a slice share the boundaries (every row
                 // starts at frame 0) and are right-padded: causal layers, so a row's samples do not depend on the padding.
                 constexpr int kDecodeChunk = 300;
+                const int32_t* src = dec_src + (size_t)b0 * dstride * G;
                 if (n <= kDecodeChunk) {
-                    q3dec_decode_strided(c->dec, c->codes.p + (size_t)b0 * stride * G, (int64_t)stride * G, 1, G, gb, n, wav.p, (int64_t)n * up, c->s);
+                    q3dec_decode_strided(c->dec, src, (int64_t)dstride * G, 1, G, gb, n, wav.p, (int64_t)n * up, c->s);
                 } else {
                     MIS_REQUIRE(q3dec_stream_pos(c->dec) < 0, MIS_ERR_INVALID_INPUT,
                                 "decoding more than 300 frames uses the handle's decode-stream session, but the host has one open");
@@ -836,16 +1020,15 @@ extern "C" mis_status mis_qwen3tts_generate(mis_qwen3tts* c, const int32_t* text
                     try {
                         for (int f0 = 0; f0 < n; f0 += kDecodeChunk) {
                             const int fn = std::min(kDecodeChunk, n - f0);
-                            q3dec_stream_step(c->dec, c->codes.p + (size_t)b0 * stride * G + (size_t)f0 * G, (int64_t)stride * G, 1, G, fn,
-                                              wav.p + (size_t)f0 * up, (int64_t)n * up, c->s);
+                            q3dec_stream_step(c->dec, src + (size_t)f0 * G, (int64_t)dstride * G, 1, G, fn, wav.p + (size_t)f0 * up, (int64_t)n * up, c->s);
                         }
                     } catch (...) { q3dec_stream_end(c->dec); throw; }
                     q3dec_stream_end(c->dec);
                 }
                 for (int r = 0; r < gb; ++r)
-                    if (nf[b0 + r] > 0)
-                        HIP_CHECK(hipMemcpyAsync(host + (size_t)(b0 + r) * longest, wav.p + (size_t)r * n * up, (size_t)pcm_lens[b0 + r] * 4,
-                                                 hipMemcpyDeviceToHost, c->s));
+                    if (ntot[b0 + r] > 0 && pcm_lens[b0 + r] > 0)
+                        HIP_CHECK(hipMemcpyAsync(host + (size_t)(b0 + r) * longest, wav.p + (size_t)r * n * up + cut[b0 + r],
+                                                 (size_t)pcm_lens[b0 + r] * 4, hipMemcpyDeviceToHost, c->s));
                 HIP_CHECK(hipStreamSynchronize(c->s));
             }
             if (cancel_flag && *cancel_flag) throw MisError(MIS_ERR_CANCELLED, "generation cancelled");

@@ -45,6 +45,51 @@ class Qwen3TTSDecoderConfiguration:
 
 
 @dataclass
+class Qwen3TTSSpeakerEncoderConfiguration:
+    """Qwen3TTSSpeakerEncoderConfig (Qwen3TTSConfig.swift:69-117)"""
+    mel_dim: int = 128
+    enc_dim: int = 1024
+    enc_channels: tuple = (512, 512, 512, 512, 1536)
+    enc_kernel_sizes: tuple = (5, 3, 3, 3, 1)
+    enc_dilations: tuple = (1, 2, 3, 4, 1)
+    enc_attention_channels: int = 128
+    enc_res2net_scale: int = 8
+    enc_se_channels: int = 128
+    sample_rate: int = 24000
+
+
+@dataclass
+class Qwen3TTSTokenizerEncoderConfiguration:
+    """Qwen3TTSTokenizerEncoderConfig (Qwen3TTSConfig.swift:388-497), Mimi defaults"""
+    audio_channels: int = 1
+    num_filters: int = 64
+    kernel_size: int = 7
+    last_kernel_size: int = 3
+    residual_kernel_size: int = 3
+    num_residual_layers: int = 1
+    dilation_growth_rate: int = 2
+    compress: int = 2
+    upsampling_ratios: tuple = (8, 6, 5, 4)
+    use_causal_conv: bool = True
+    use_conv_shortcut: bool = False
+    hidden_size: int = 512
+    num_hidden_layers: int = 8
+    num_attention_heads: int = 8
+    intermediate_size: int = 2048
+    rope_theta: float = 10000.0
+    norm_eps: float = 1e-5
+    sampling_rate: int = 24000
+    frame_rate: float = 12.5
+    codebook_dim: int = 256
+    codebook_size: int = 2048
+    num_quantizers: int = 32
+
+
+def _dc_from(cls, d: dict):
+    return cls(**{k: (tuple(d[k]) if isinstance(d[k], list) else d[k]) for k in cls.__dataclass_fields__ if k in d})
+
+
+@dataclass
 class Qwen3TTSConfiguration:
     """Qwen3TTSModelConfig + Qwen3TTSTalkerConfig (Qwen3TTSConfig.swift:200-305,532-583)"""
     talker: LlamaTTSConfiguration = field(default_factory=lambda: _lm(1024, 28, 3072, 16, 8, 128, 3072))
@@ -68,6 +113,11 @@ class Qwen3TTSConfiguration:
     tts_eos_token_id: int = 151673
     sample_rate: int = 24000
     decoder: Qwen3TTSDecoderConfiguration = field(default_factory=Qwen3TTSDecoderConfiguration)
+    # in-context voice cloning front end: None = not part of this checkpoint (no speaker encoder unless tts_model_type == "base",
+    # Qwen3TTS.swift:46-48; no tokenizer encoder without encoder_config, Qwen3TTSSpeechTokenizer.swift:1041-1046)
+    speaker_encoder: Qwen3TTSSpeakerEncoderConfiguration | None = None
+    tokenizer_encoder: Qwen3TTSTokenizerEncoderConfiguration | None = None
+    encoder_valid_num_quantizers: int = 16
 
     @classmethod
     def from_dict(cls, d: dict, tokenizer: dict | None = None) -> "Qwen3TTSConfiguration":
@@ -83,8 +133,10 @@ class Qwen3TTSConfiguration:
         talker.rms_norm_eps = t.get("rms_norm_eps", 1e-6); talker.rope_theta = t.get("rope_theta", 1e6)
         pred.rms_norm_eps = cp.get("rms_norm_eps", 1e-6); pred.rope_theta = cp.get("rope_theta", 1e6)
         dc = (tokenizer or {}).get("decoder_config") or {}
-        dec = Qwen3TTSDecoderConfiguration(**{k: (tuple(dc[k]) if isinstance(dc[k], list) else dc[k])
-                                              for k in Qwen3TTSDecoderConfiguration.__dataclass_fields__ if k in dc})
+        dec = _dc_from(Qwen3TTSDecoderConfiguration, dc)
+        spk = _dc_from(Qwen3TTSSpeakerEncoderConfiguration, d.get("speaker_encoder_config") or {}) if d.get("tts_model_type", "base") == "base" else None
+        ec = (tokenizer or {}).get("encoder_config")
+        enc = _dc_from(Qwen3TTSTokenizerEncoderConfiguration, ec) if ec is not None else None
         return cls(talker=talker, predictor=pred, num_code_groups=t.get("num_code_groups", 16),
                    text_hidden_size=t.get("text_hidden_size", 2048), text_vocab_size=t.get("text_vocab_size", 151936),
                    codec_eos_token_id=t.get("codec_eos_token_id", 2150), codec_think_id=t.get("codec_think_id", 2154),
@@ -93,7 +145,9 @@ class Qwen3TTSConfiguration:
                    codec_bos_id=t.get("codec_bos_id", 2149), codec_language_id=t.get("codec_language_id"),
                    spk_id=t.get("spk_id"), spk_is_dialect=t.get("spk_is_dialect"), tts_model_type=d.get("tts_model_type", "base"),
                    tts_pad_token_id=d.get("tts_pad_token_id", 151671), tts_bos_token_id=d.get("tts_bos_token_id", 151672),
-                   tts_eos_token_id=d.get("tts_eos_token_id", 151673), sample_rate=d.get("sample_rate", 24000), decoder=dec)
+                   tts_eos_token_id=d.get("tts_eos_token_id", 151673), sample_rate=d.get("sample_rate", 24000), decoder=dec,
+                   speaker_encoder=spk, tokenizer_encoder=enc,
+                   encoder_valid_num_quantizers=(tokenizer or {}).get("encoder_valid_num_quantizers", 16))
 
     def to_c(self) -> "_lib.Qwen3TTSConfigC":
         d = self.decoder
@@ -105,6 +159,30 @@ class Qwen3TTSConfiguration:
                                     d.num_attention_heads, d.num_hidden_layers, d.num_key_value_heads, d.num_quantizers,
                                     d.num_semantic_quantizers, d.rms_norm_eps, d.rope_theta, len(d.upsample_rates), ur,
                                     len(d.upsampling_ratios), up, self.sample_rate)
+
+
+    def reference_to_c(self) -> "_lib.Qwen3TTSReferenceConfigC":
+        r = _lib.Qwen3TTSReferenceConfigC()
+        sp, en = self.speaker_encoder, self.tokenizer_encoder
+        if sp is not None:
+            r.spk_mel_dim, r.spk_enc_dim, r.spk_n_blocks = sp.mel_dim, sp.enc_dim, len(sp.enc_channels)
+            r.spk_channels = (C.c_int32 * 8)(*sp.enc_channels)
+            r.spk_kernel_sizes = (C.c_int32 * 8)(*sp.enc_kernel_sizes)
+            r.spk_dilations = (C.c_int32 * 8)(*sp.enc_dilations)
+            r.spk_attention_channels, r.spk_res2net_scale = sp.enc_attention_channels, sp.enc_res2net_scale
+            r.spk_se_channels, r.spk_sample_rate = sp.enc_se_channels, sp.sample_rate
+        if en is not None:
+            r.enc_audio_channels, r.enc_num_filters, r.enc_kernel_size = en.audio_channels, en.num_filters, en.kernel_size
+            r.enc_last_kernel_size, r.enc_residual_kernel_size = en.last_kernel_size, en.residual_kernel_size
+            r.enc_num_residual_layers, r.enc_dilation_growth_rate, r.enc_compress = en.num_residual_layers, en.dilation_growth_rate, en.compress
+            r.enc_n_ratios = len(en.upsampling_ratios)
+            r.enc_upsampling_ratios = (C.c_int32 * 8)(*en.upsampling_ratios)
+            r.enc_use_causal_conv, r.enc_use_conv_shortcut = int(en.use_causal_conv), int(en.use_conv_shortcut)
+            r.enc_hidden_size, r.enc_num_layers, r.enc_num_heads = en.hidden_size, en.num_hidden_layers, en.num_attention_heads
+            r.enc_intermediate_size, r.enc_codebook_dim, r.enc_codebook_size = en.intermediate_size, en.codebook_dim, en.codebook_size
+            r.enc_num_quantizers, r.enc_valid_num_quantizers = en.num_quantizers, self.encoder_valid_num_quantizers
+            r.enc_sampling_rate, r.enc_rope_theta, r.enc_frame_rate, r.enc_norm_eps = en.sampling_rate, en.rope_theta, en.frame_rate, en.norm_eps
+        return r
 
 
 @dataclass
@@ -166,9 +244,83 @@ def sanitize_speech_tokenizer(weights: dict) -> dict:
     """Qwen3TTSSpeechTokenizer.sanitize (:1093-1440), decoder side: strip the speech_tokenizer./decoder_model. prefixes, keep the
     decoder codebooks' cluster_usage / embedding_sum (`_codebook.` -> `.codebook.`), transpose PyTorch conv weights to MLX's layout
     when the shape heuristic says they are not already (transposed convs [in, out, k] -> [out, k, in], convs [out, in, k] ->
-    [out, k, in]), rename upsample.X.Y -> upsample.X.layers.Y.  Encoder / speaker-encoder keys are dropped (not built)."""
+    [out, k, in]), rename upsample.X.Y -> upsample.X.layers.Y.  Encoder side (:1240-1370,1411-1427): the HF Mimi names
+    encoder.encoder.layers.N / encoder.encoder_transformer.layers.N / encoder.downsample / encoder.quantizer.* become the module
+    tree of Qwen3TTSSpeechTokenizerEncoder behind `encoder_model.` (conv weights always transposed to [out, k, in], q/k/v stacked
+    into in_proj, codebooks kept as cluster_usage + embedding_sum).  Speaker-encoder keys are not tokenizer weights (:1220-1222)."""
     import re
     out = {}
+    enc_qkv, enc_cb = {}, {}
+    conv_map = {0: "encoder.init_conv1d", 3: "encoder.layers.0.downsample", 6: "encoder.layers.1.downsample",
+                9: "encoder.layers.2.downsample", 12: "encoder.layers.3.downsample", 14: "encoder.final_conv1d"}
+    res_layer, res_block = {1: 0, 4: 1, 7: 2, 10: 3}, {1: 0, 3: 1}
+    tl_names = {"self_attn.out_proj.weight": "self_attn.out_proj.weight", "self_attn.o_proj.weight": "self_attn.out_proj.weight",
+                "mlp.fc1.weight": "gating.linear1.weight", "mlp.fc2.weight": "gating.linear2.weight",
+                "input_layernorm.weight": "norm1.weight", "input_layernorm.bias": "norm1.bias",
+                "post_attention_layernorm.weight": "norm2.weight", "post_attention_layernorm.bias": "norm2.bias",
+                "self_attn_layer_scale.scale": "layer_scale_1.scale", "mlp_layer_scale.scale": "layer_scale_2.scale"}
+
+    def t3(v):
+        return v.permute(0, 2, 1).contiguous() if len(v.shape) == 3 else v
+
+    def enc_group(path):
+        if "rvq_first." in path or "semantic_residual_vector_quantizer" in path:
+            return "rvq_first"
+        return "rvq_rest"
+
+    def encoder_key(k, v):
+        parts = k.split(".")
+        if k.startswith("encoder.encoder.layers."):
+            if len(parts) < 4 or not parts[3].isdigit():
+                return
+            n = int(parts[3])
+            if ".block." in k:
+                if n in res_layer and len(parts) > 5 and parts[5].isdigit() and int(parts[5]) in res_block:
+                    suffix = ".".join(parts[6:])
+                    out[f"encoder_model.encoder.layers.{res_layer[n]}.residuals.0.block.{res_block[int(parts[5])]}.conv.{suffix}"] = \
+                        t3(v) if suffix.endswith("weight") else v
+            elif n in conv_map:
+                suffix = ".".join(parts[4:])
+                out[f"encoder_model.{conv_map[n]}.conv.{suffix}"] = t3(v) if suffix.endswith("weight") else v
+            return
+        if k.startswith("encoder.encoder_transformer.layers.") or k.startswith("encoder.encoder_transformer.transformer.layers."):
+            off = 4 if (len(parts) >= 5 and parts[2] == "transformer" and parts[3] == "layers") else 3
+            if len(parts) <= off or not parts[off].isdigit():
+                return
+            li, suffix = int(parts[off]), ".".join(parts[off + 1:])
+            for nm in ("q", "k", "v"):
+                if f"self_attn.{nm}_proj.weight" in suffix:
+                    enc_qkv.setdefault(li, {})[nm] = v
+                    return
+            if "self_attn.qkv.weight" in suffix and len(v.shape) == 2:
+                if v.shape[0] % 3 == 0 and v.shape[0] > 0:
+                    h = v.shape[0] // 3
+                    enc_qkv.setdefault(li, {}).update(q=v[:h], k=v[h:2 * h], v=v[2 * h:])
+                return
+            for src, dst in tl_names.items():
+                if src in suffix:
+                    out[f"encoder_model.encoder_transformer.transformer.layers.{li}.{dst}"] = v
+                    return
+            return
+        if k.startswith("encoder.downsample."):
+            suffix = k[len("encoder.downsample."):]
+            out["encoder_model.downsample.conv.conv." + suffix] = t3(v) if suffix.endswith("weight") else v
+            return
+        if k.startswith("encoder.quantizer."):
+            rest = k[len("encoder.quantizer."):]
+            if ".codebook.embed.weight" in rest or rest.endswith("codebook.embed"):
+                return
+            if "codebook.cluster_usage" in rest or "codebook.embed_sum" in rest or "codebook.embedding_sum" in rest:
+                base = rest.rsplit(".codebook.", 1)[0]
+                enc_cb.setdefault(base, {})["cluster_usage" if "cluster_usage" in rest else "embedding_sum"] = v
+                return
+            if "codebook.initialized" in rest:
+                return
+            for proj in ("input_proj", "output_proj"):
+                if proj + ".weight" in rest:
+                    out[f"encoder_model.quantizer.{enc_group(rest)}.{proj}.weight"] = t3(v)
+            return
+
     for raw, v in weights.items():
         k = raw
         stripped = True
@@ -177,7 +329,13 @@ def sanitize_speech_tokenizer(weights: dict) -> dict:
             for pre in ("speech_tokenizer.", "encoder_model.", "decoder_model."):
                 if k.startswith(pre):
                     k = k[len(pre):]; stripped = True; break
-        if not k or k.startswith("encoder.") or "speaker_encoder" in k or "initialized" in k:
+        if not k or "speaker_encoder" in k.split("."):
+            continue
+        if k.startswith("encoder."):
+            if not isinstance(v, np.ndarray):
+                encoder_key(k, v)
+            continue
+        if "initialized" in k:
             continue
         if "_codebook.cluster_usage" in k or "_codebook.embedding_sum" in k:
             base, leaf = k.rsplit("._codebook.", 1)
@@ -192,7 +350,48 @@ def sanitize_speech_tokenizer(weights: dict) -> dict:
                 v = v.permute(0, 2, 1).contiguous()
         k = re.sub(r"upsample\.(\d+)\.(\d+)", r"upsample.\1.layers.\2", k)
         out[k] = v
+    import torch
+    for li, qkv in enc_qkv.items():
+        if all(n in qkv for n in ("q", "k", "v")):
+            out[f"encoder_model.encoder_transformer.transformer.layers.{li}.self_attn.in_proj.weight"] = torch.cat([qkv["q"], qkv["k"], qkv["v"]], 0)
+    for base, data in enc_cb.items():
+        parts = base.split(".")
+        if "cluster_usage" not in data or "embedding_sum" not in data or "layers" not in parts:
+            continue
+        i = parts.index("layers")
+        if i + 1 >= len(parts) or not parts[i + 1].isdigit():
+            continue
+        pre = f"encoder_model.quantizer.{enc_group(base)}.vq.layers.{int(parts[i + 1])}.codebook"
+        out[pre + ".cluster_usage"] = data["cluster_usage"]
+        out[pre + ".embedding_sum"] = data["embedding_sum"]
     return out
+
+
+def sanitize_speaker_encoder(weights: dict) -> dict:
+    """Qwen3TTSSpeakerEncoder.sanitize (Qwen3TTSSpeakerEncoder.swift:324-354): everything behind a `speaker_encoder` path component,
+    3-D weights transposed to [out, k, in] unless the shape heuristic says they already are; keys come back as `speaker_encoder.<rest>`."""
+    out = {}
+    for raw, v in weights.items():
+        parts = raw.split(".")
+        if "speaker_encoder" not in parts or isinstance(v, np.ndarray):
+            continue
+        rest = ".".join(parts[parts.index("speaker_encoder") + 1:])
+        if not rest:
+            continue
+        if rest.endswith(".weight") and len(v.shape) == 3 and not _mlx_conv_shape(tuple(v.shape)):
+            v = v.permute(0, 2, 1).contiguous()
+        out["speaker_encoder." + rest] = v
+    return out
+
+
+@dataclass
+class ReferenceAudioContext:
+    """ReferenceAudioContext (Qwen3TTS.swift:268-300) as the handle sees it: the speaker vector, the reference codes [n_q, T] and the
+    prompt rows they occupy behind the codec vocabulary (speaker_row = -1: no speaker vector)."""
+    speaker_embedding: np.ndarray | None
+    codes: np.ndarray
+    speaker_row: int
+    first_frame_row: int
 
 
 @dataclass
@@ -203,6 +402,7 @@ class PreparedPrompt:
     codec_ids: np.ndarray
     trailing_ids: np.ndarray
     target_token_count: int = 0
+    reference: object = None            # ReferenceAudioContext of an in-context prompt (its rows live on the model handle)
 
 
 class Qwen3TTSModel:
@@ -213,6 +413,11 @@ class Qwen3TTSModel:
         self._h = C.c_void_p()
         cc = config.to_c()
         check(_lib.lib().mis_qwen3tts_create(C.byref(cc), device, C.byref(self._h)))
+        self._ref_cache = None              # cachedReferenceAudioContext (Qwen3TTS.swift:268-300): one entry, keyed by the array object
+        self._ref_log = []                  # every context registered on the handle, in row order (replayed onto replicas)
+        if config.speaker_encoder is not None or config.tokenizer_encoder is not None:
+            rc = config.reference_to_c()
+            check(_lib.lib().mis_qwen3tts_enable_reference(self._h, C.byref(rc)))
 
     def __del__(self):
         h, self._h = getattr(self, "_h", None), None
@@ -232,8 +437,8 @@ class Qwen3TTSModel:
     def from_model_directory(cls, model_dir: str, device: int = 0) -> "Qwen3TTSModel":
         """config.json + *.safetensors (talker, `talker.` prefix stripped by sanitize :357-365; quantised paths = those with a
         `.scales` companion, group size / bits from `quantization` and its per-layer overrides :1157-1170) + speech_tokenizer/
-        (config.json, *.safetensors through `sanitize_speech_tokenizer`).  Speaker-encoder / tokenizer-encoder tensors are skipped
-        (voice cloning is not built)."""
+        (config.json, *.safetensors through `sanitize_speech_tokenizer`).  The in-context voice-cloning front end is loaded when the
+        checkpoint carries it: `speaker_encoder.*` of a base model (:1222-1236) and the tokenizer's `encoder_model.*` (encoder_config)."""
         import json
         import os
         with open(os.path.join(model_dir, "config.json")) as f:
@@ -243,11 +448,23 @@ class Qwen3TTSModel:
         if os.path.isdir(st_dir) and os.path.exists(os.path.join(st_dir, "config.json")):
             with open(os.path.join(st_dir, "config.json")) as f:
                 tj = json.load(f)
-        m = cls(Qwen3TTSConfiguration.from_dict(cj, tj), device)
         weights = {}
         for fn in sorted(os.listdir(model_dir)):
             if fn.endswith(".safetensors"):
                 weights.update(read_safetensors(os.path.join(model_dir, fn)))
+        tw = {}
+        if os.path.isdir(st_dir):
+            for fn in sorted(os.listdir(st_dir)):
+                if fn.endswith(".safetensors"):
+                    tw.update(read_safetensors(os.path.join(st_dir, fn)))
+        config = Qwen3TTSConfiguration.from_dict(cj, tj)
+        speaker = sanitize_speaker_encoder(weights)
+        tokw = sanitize_speech_tokenizer(tw)
+        if not speaker:
+            config.speaker_encoder = None
+        if not any(k.startswith("encoder_model.") for k in tokw):
+            config.tokenizer_encoder = None
+        m = cls(config, device)
         talker = {k[len("talker."):]: v for k, v in weights.items() if k.startswith("talker.")}
         quant = cj.get("quantization") or cj.get("quantization_config") or {}
         for name, arr in talker.items():
@@ -262,13 +479,11 @@ class Qwen3TTSModel:
                 m.set_tensor(name, arr)
         if not os.path.isdir(st_dir):
             raise AudioGenerationError(1, "speech_tokenizer directory not found: speech decoding unavailable")
-        tw = {}
-        for fn in sorted(os.listdir(st_dir)):
-            if fn.endswith(".safetensors"):
-                tw.update(read_safetensors(os.path.join(st_dir, fn)))
-        for name, arr in sanitize_speech_tokenizer(tw).items():
-            if name.startswith("decoder."):
+        for name, arr in tokw.items():
+            if name.startswith("decoder.") or (name.startswith("encoder_model.") and config.tokenizer_encoder is not None):
                 m.set_tensor(name, arr)
+        for name, arr in speaker.items():
+            m.set_tensor(name, arr)
         m.finalize()
         return m
 
@@ -360,6 +575,131 @@ class Qwen3TTSModel:
         return PreparedPrompt(np.asarray(t, np.int32), np.asarray(c, np.int32), np.asarray(trailing, np.int32),
                               len(self.tokenizer.encode(text)))
 
+    # -- in-context voice cloning (Qwen3TTS.swift:232-300,596-881) ------------------------------------------------------------
+    @property
+    def has_speaker_encoder(self) -> bool:
+        return self.configuration.speaker_encoder is not None
+
+    @property
+    def has_tokenizer_encoder(self) -> bool:                      # speechTokenizer.hasEncoder
+        return self.configuration.tokenizer_encoder is not None
+
+    @staticmethod
+    def _mono(ref_audio) -> np.ndarray:
+        """referenceAudioForEncoder / extractSpeakerEmbedding shapes (:240-247,:842-862): [n], [1, n] or [1, 1, n] -> the first row"""
+        a = np.asarray(ref_audio, np.float32)
+        while a.ndim > 1:
+            a = a[0]
+        return np.ascontiguousarray(a)
+
+    def extract_speaker_embedding(self, ref_audio) -> np.ndarray | None:
+        """extractSpeakerEmbedding (:839-881): log-mel (24 kHz, nFft 1024, hop 256, 128 mels) -> ECAPA-TDNN, on the device."""
+        if not self.has_speaker_encoder:
+            return None
+        a = self._mono(ref_audio)
+        out = np.zeros(self.configuration.speaker_encoder.enc_dim, np.float32)
+        check(_lib.lib().mis_qwen3tts_speaker_embedding(self._h, a.ctypes.data, len(a), out.ctypes.data))
+        return out
+
+    def encode_audio(self, ref_audio) -> np.ndarray:
+        """speechTokenizer.encode (Qwen3TTSSpeechTokenizer.swift:1052-1058): waveform -> codes int32 [valid_num_quantizers, T]."""
+        if not self.has_tokenizer_encoder:
+            raise AudioGenerationError(1, "Encoder not available for this speech tokenizer")
+        a = self._mono(ref_audio)
+        out = C.c_void_p(); nq = C.c_int32(); nf = C.c_int32()
+        check(_lib.lib().mis_qwen3tts_encode_audio(self._h, a.ctypes.data, len(a), C.byref(out), C.byref(nq), C.byref(nf)))
+        try:
+            return np.ctypeslib.as_array(C.cast(out, C.POINTER(C.c_int32)), shape=(nq.value, max(nf.value, 1)))[:, : nf.value].copy()
+        finally:
+            _lib.lib().mis_free(out)
+
+    def reference_tap(self, kind: int, ref_audio, stage: int) -> np.ndarray:
+        """parity tap of the front end: kind 0 speaker encoder, 1 tokenizer encoder -> [channels, length]"""
+        a = self._mono(ref_audio)
+        cfg = self.configuration
+        if kind == 0:
+            cap = 3 * max(cfg.speaker_encoder.enc_channels) * (len(a) // 256 + 8)
+        else:
+            cap = max(cfg.tokenizer_encoder.hidden_size * (len(a) // 2 + 8), 1 << 16)
+        buf = np.zeros(cap, np.float32)
+        ch = C.c_int32(); ln = C.c_int64()
+        check(_lib.lib().mis_qwen3tts_reference_tap(self._h, kind, a.ctypes.data, len(a), stage, buf.ctypes.data, cap, C.byref(ch), C.byref(ln)))
+        return buf[: ch.value * ln.value].reshape(ch.value, ln.value).copy()
+
+    def add_reference(self, codes, speaker_embedding=None) -> "ReferenceAudioContext":
+        """Registers reference codes [n_q, T] (+ speaker vector) on the handle: the rows prefill positions address (see
+        mis_qwen3tts_add_reference).  Qwen3TTSReferenceConditioning with precomputed tensors comes in through here as well."""
+        cd = np.ascontiguousarray(codes, np.int32)
+        sv = None if speaker_embedding is None else np.ascontiguousarray(speaker_embedding, np.float32).reshape(-1)
+        srow = C.c_int32(); frow = C.c_int32()
+        check(_lib.lib().mis_qwen3tts_add_reference(self._h, cd.ctypes.data, cd.shape[0], cd.shape[1], None if sv is None else sv.ctypes.data,
+                                                    0 if sv is None else len(sv), C.byref(srow), C.byref(frow)))
+        self._ref_log.append((cd, sv))
+        return ReferenceAudioContext(sv, cd, srow.value, frow.value)
+
+    def clear_references(self):
+        check(_lib.lib().mis_qwen3tts_clear_references(self._h))
+        self._ref_log, self._ref_cache = [], None
+
+    def reference_audio_context(self, ref_audio) -> "ReferenceAudioContext":
+        """referenceAudioContext (:268-300): speaker embedding + reference codes + their ICL rows, cached for the same array object."""
+        if self._ref_cache is not None and self._ref_cache[0] is ref_audio:
+            return self._ref_cache[1]
+        ctx = self.add_reference(self.encode_audio(ref_audio), self.extract_speaker_embedding(ref_audio))
+        self._ref_cache = (ref_audio, ctx)
+        return ctx
+
+    def prepare_reference_conditioning(self, ref_audio, ref_text: str, language: str | None = None, speaker_embedding=None):
+        """prepareReferenceConditioning (:704-751): (context, reference text ids, codec language id | None).  A caller-supplied
+        speaker vector replaces the extracted one (registered as its own context)."""
+        if self.tokenizer is None:
+            raise AudioGenerationError(1, "Qwen3TTS reference conditioning requires the text tokenizer to be loaded")
+        if not self.has_tokenizer_encoder:
+            raise AudioGenerationError(3, "Qwen3TTS reference conditioning requires a speech tokenizer encoder, but this checkpoint does not provide one.")
+        ctx = self.reference_audio_context(ref_audio)
+        if speaker_embedding is not None:
+            ctx = self.add_reference(ctx.codes, speaker_embedding)
+        lang = (language or "auto").lower()
+        ids = list(self.tokenizer.encode(f"<|im_start|>assistant\n{ref_text}<|im_end|>\n"))
+        start = min(3, len(ids))
+        ref_ids = ids[start:max(start, len(ids) - 2)]
+        lid = None
+        if lang != "auto" and self.configuration.codec_language_id:
+            lid = self.configuration.codec_language_id.get(lang)
+        return ctx, ref_ids, lid
+
+    def prepare_icl_generation_inputs(self, text: str, ref_audio=None, ref_text: str | None = None, language: str = "auto",
+                                      conditioning=None) -> PreparedPrompt:
+        """prepareICLGenerationInputs (:753-837) as (text id, codec id) positions: role, the think prefix with the speaker row,
+        [reference text + target text + tts_eos] over codec_pad, [codec_bos + the reference frames' code-sum rows] over tts_pad.
+        Everything is prefilled; the generated frames get tts_pad (trailingTextHidden = ttsPadEmbed)."""
+        if self.tokenizer is None:
+            raise AudioGenerationError(1, "Qwen3TTS request assembly requires the text tokenizer to be loaded")
+        cfg = self.configuration
+        ctx, ref_ids, lid = conditioning if conditioning is not None else self.prepare_reference_conditioning(ref_audio, ref_text, language)
+        V = cfg.talker.vocab_size
+        ids = list(self.tokenizer.encode(f"<|im_start|>assistant\n{text}<|im_end|>\n<|im_start|>assistant\n"))
+        start = min(3, len(ids))
+        target = ids[start:max(start, len(ids) - 5)]
+        prefix = ([cfg.codec_think_id, cfg.codec_think_bos_id, lid, cfg.codec_think_eos_id] if lid is not None
+                  else [cfg.codec_nothink_id, cfg.codec_think_bos_id, cfg.codec_think_eos_id])
+        codec = prefix + ([V + ctx.speaker_row] if ctx.speaker_row >= 0 else []) + [cfg.codec_pad_id, cfg.codec_bos_id]
+        t = ids[:3]; c = [-1] * len(t)
+        t += [cfg.tts_pad_token_id] * (len(codec) - 2) + [cfg.tts_bos_token_id]; c += codec[:-1]
+        body = list(ref_ids) + target + [cfg.tts_eos_token_id]
+        t += body; c += [cfg.codec_pad_id] * len(body)
+        T = ctx.codes.shape[1]
+        t += [cfg.tts_pad_token_id] * (T + 1); c += [cfg.codec_bos_id] + [V + ctx.first_frame_row + i for i in range(T)]
+        return PreparedPrompt(np.asarray(t, np.int32), np.asarray(c, np.int32), np.zeros(0, np.int32), len(self.tokenizer.encode(text)), ctx)
+
+    def _sync_references(self, replicas):
+        """replicas decode their own rows: every replica needs the contexts of this model, at the same rows"""
+        for r in replicas:
+            if r is self:
+                continue
+            for cd, sv in self._ref_log[len(r._ref_log):]:
+                r.add_reference(cd, sv)
+
     def _marshal(self, prompts):
         B = len(prompts)
         if B == 0:
@@ -437,6 +777,7 @@ class Qwen3TTSModel:
         cbc = _lib.EVENT_CB(cb) if on_audio is not None else C.cast(None, _lib.EVENT_CB)
         keep.append(cbc)
         if replicas:          # Qwen3TTSModel objects with the same weights, one per GPU: rows sharded inside the library, each replica
+            self._sync_references(replicas)
             hs = (C.c_void_p * len(replicas))(*[r._h for r in replicas])          # streams its own rows' chunks (global row indices)
             check(_lib.lib().mis_qwen3tts_group_generate(hs, len(replicas), t.ctypes.data, c.ctypes.data, pl.ctypes.data, P, tr.ctypes.data,
                                                          tl.ctypes.data, Tt, B, C.byref(gpc), caps.ctypes.data, C.byref(pcm), C.byref(stride),
@@ -460,15 +801,16 @@ class Qwen3TTSModel:
                  generation_parameters: Qwen3TTSGenerateParameters | None = None) -> np.ndarray:
         """generate(text:voice:refAudio:refText:language:generationParameters:) (Qwen3TTS.swift:60-82); `voice` is the
         VoiceDesign instruction."""
-        if ref_audio is not None:
-            raise AudioGenerationError(5, "in-context voice cloning needs the speech-tokenizer encoder (not built)")
-        p = self._prepare(text, voice, language)
+        p = self._prepare(text, voice, language, ref_audio, ref_text)
         out = self.generate_batch([p], generation_parameters)[0]
         return out if len(out) else np.zeros(1, np.float32)              # generatedCodes.isEmpty -> zeros([1]) (:520-522)
 
-    def _prepare(self, text, voice, language):
-        """the non-cloning branch of generate (Qwen3TTS.swift:361-371): CustomVoice models read `voice` as "speaker[, instruction]",
-        the others as the VoiceDesign instruction"""
+    def _prepare(self, text, voice, language, ref_audio=None, ref_text=None):
+        """the input branches of generateVoiceDesign (Qwen3TTS.swift:337-377): reference audio + text on a tokenizer with an encoder ->
+        in-context prompt; otherwise CustomVoice models read `voice` as "speaker[, instruction]", the others as the VoiceDesign
+        instruction"""
+        if ref_audio is not None and ref_text is not None and self.has_tokenizer_encoder:
+            return self.prepare_icl_generation_inputs(text, ref_audio, ref_text, language or "auto")
         if self.configuration.tts_model_type == "custom_voice":
             cv = self.parse_custom_voice_prompt(voice)
             return self.prepare_generation_inputs(text, language or "auto", cv[1] if cv else None, cv[0] if cv else None)
@@ -521,8 +863,9 @@ class Qwen3TTSModel:
         yield from stream_events(start, decode_audio_event, cancel_flag)
 
     def generate_stream(self, text: str, voice: str | None = None, language: str | None = None,
-                        generation_parameters: Qwen3TTSGenerateParameters | None = None, streaming_interval: float = 2.0):
+                        generation_parameters: Qwen3TTSGenerateParameters | None = None, streaming_interval: float = 2.0,
+                        ref_audio=None, ref_text=None):
         """generateStream (:84-133): .token per frame and .audio chunks while generating, .info when the loop ends, then the
         remaining samples."""
-        p = self._prepare(text, voice, language)
+        p = self._prepare(text, voice, language, ref_audio, ref_text)
         yield from self.generate_stream_batch([p], generation_parameters, streaming_interval)

@@ -144,7 +144,7 @@ class MimiEncoderOracle:
         with torch.no_grad():
             x = self.seanet(torch.as_tensor(np.asarray(audio, F)))
             x = self.transformer(x)
-            x = self.sconv("downsample", x, 2 * cfg.downsample_stride, stride=cfg.downsample_stride, causal=cfg.use_causal_conv, mode="edge",
+            x = self.sconv("downsample.conv", x, 2 * cfg.downsample_stride, stride=cfg.downsample_stride, causal=cfg.use_causal_conv, mode="edge",
                            bias=False)
             codes = self._rvq_encode("quantizer.rvq_first", x, 1)
             if cfg.num_quantizers > 1:
@@ -190,7 +190,7 @@ def make_synthetic_weights(cfg: MimiEncoderConfig, seed: int = 77) -> dict:
         W[p + ".gating.linear2.weight"] = t((D, cfg.intermediate_size), math.sqrt(3.0 / cfg.intermediate_size))
         W[p + ".layer_scale_1.scale"] = (0.3 + t((D,), 0.1)).astype(F)
         W[p + ".layer_scale_2.scale"] = (0.3 + t((D,), 0.1)).astype(F)
-    conv("downsample", D, 2 * cfg.downsample_stride, D, bias=False)
+    conv("downsample.conv", D, 2 * cfg.downsample_stride, D, bias=False)
     for grp, nq in (("rvq_first", 1), ("rvq_rest", cfg.num_quantizers - 1)):
         p = f"quantizer.{grp}"
         W[p + ".input_proj.weight"] = t((cfg.codebook_dim, 1, D), math.sqrt(3.0 / D))

@@ -194,15 +194,26 @@ class Qwen3TTSOracle:
     def codec_embed(self, ids):
         return self.w["model.codec_embedding.weight"][torch.as_tensor(np.asarray(ids, np.int64))]
 
-    def position_embeds(self, text_ids, codec_ids):
-        """Prefill positions as (text id | -1, codec id | -1) pairs -> [P, d] bf16-valued."""
+    def codec_embed_icl(self, ref_codes):
+        """codecEmbedIcl (Qwen3TTS.swift:249-262) without its codec_bos row: reference codes [n_q, T] -> [T, d], the talker's codec
+        embedding of code 0 plus the code predictor's embedding i of code i + 1, one model-dtype rounding per add."""
+        rc = np.asarray(ref_codes, np.int64)
+        e = self.codec_embed(rc[0])
+        for i in range(min(self.cfg.num_code_groups - 1, rc.shape[0] - 1)):
+            e = self.r(e + self.w[f"code_predictor.model.codec_embedding.{i}.weight"][torch.as_tensor(rc[i + 1])])
+        return e
+
+    def position_embeds(self, text_ids, codec_ids, extra_rows=None):
+        """Prefill positions as (text id | -1, codec id | -1) pairs -> [P, d] bf16-valued.  Codec ids past the vocabulary index
+        `extra_rows` ([n, d]: speaker vector / codecEmbedIcl rows of the in-context prompt, prepareICLGenerationInputs :753-837)."""
         out = []
+        V = self.cfg.talker.vocab_size
         for t, c in zip(text_ids, codec_ids):
             e = None
             if t >= 0:
                 e = self.text_embed([t])[0]
             if c >= 0:
-                ce = self.codec_embed([c])[0]
+                ce = self.codec_embed([c])[0] if c < V else self.r(torch.as_tensor(extra_rows[c - V], dtype=torch.float32))
                 e = ce if e is None else self.r(e + ce)
             out.append(e)
         return torch.stack(out)
@@ -240,13 +251,13 @@ class Qwen3TTSOracle:
             e = self.r(e + self.w[f"code_predictor.model.codec_embedding.{i}.weight"][c])
         return self.r(text_embed_row + e)
 
-    def generate_row(self, text_ids, codec_ids, trailing_text_ids, params, row=0, max_frames=16, forced_codes=None):
+    def generate_row(self, text_ids, codec_ids, trailing_text_ids, params, row=0, max_frames=16, forced_codes=None, extra_rows=None):
         """One utterance.  Returns (codes [n_frames, G] int, per-frame talker logits).  `forced_codes` [n, G] teacher-forces
         the sampled values (the logits are still the oracle's)."""
         cfg = self.cfg
         self.talker.reset(1)
         suppress = [t for t in range(cfg.talker.vocab_size - 1024, cfg.talker.vocab_size) if t != cfg.codec_eos_token_id]
-        x = self.position_embeds(text_ids, codec_ids)
+        x = self.position_embeds(text_ids, codec_ids, extra_rows)
         trailing = self.text_embed(trailing_text_ids) if len(trailing_text_ids) else torch.zeros(0, cfg.talker.hidden_size)
         pad = self.text_embed([cfg.tts_pad_token_id])[0]
         frames, tlogits, gen0 = [], [], []

@@ -54,7 +54,7 @@ def _hf_model(cfg, W):
         sd[q + ".input_layernorm.weight"], sd[q + ".input_layernorm.bias"] = t(p + ".norm1.weight"), t(p + ".norm1.bias")
         sd[q + ".post_attention_layernorm.weight"], sd[q + ".post_attention_layernorm.bias"] = t(p + ".norm2.weight"), t(p + ".norm2.bias")
         sd[q + ".self_attn_layer_scale.scale"], sd[q + ".mlp_layer_scale.scale"] = t(p + ".layer_scale_1.scale"), t(p + ".layer_scale_2.scale")
-    sd["downsample.conv.weight"] = t("downsample.conv.conv.weight").permute(0, 2, 1).contiguous()
+    sd["downsample.conv.weight"] = t("downsample.conv.conv.conv.weight").permute(0, 2, 1).contiguous()
     for hf_grp, o_grp, nq in (("semantic", "rvq_first", 1), ("acoustic", "rvq_rest", cfg.num_quantizers - 1)):
         hp, op = f"quantizer.{hf_grp}_residual_vector_quantizer", f"quantizer.{o_grp}"
         sd[hp + ".input_proj.weight"] = t(op + ".input_proj.weight").permute(0, 2, 1).contiguous()

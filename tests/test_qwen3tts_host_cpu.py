@@ -61,7 +61,8 @@ def test_speech_tokenizer_sanitize_and_safetensors_reader_round_trip(tmp_path):
         pt["speech_tokenizer." + k if "quantizer" in k else k] = v.contiguous()
     save_file(pt, str(tmp_path / "m.safetensors"))
     back = sanitize_speech_tokenizer(read_safetensors(str(tmp_path / "m.safetensors")))
-    assert set(back) == set(Wd)
+    assert {k for k in back if not k.startswith("encoder_model.")} == set(Wd)
+    assert tuple(back["encoder_model.encoder.init_conv1d.conv.conv.weight"].shape) == (4, 7, 1)       # encoder convs are always transposed
     for k, v in Wd.items():
         assert tuple(back[k].shape) == tuple(np.asarray(v).shape) and np.array_equal(back[k].float().numpy(), torch.as_tensor(v).float().numpy()), k
     cfg = Qwen3TTSConfiguration.from_dict({"talker_config": {"hidden_size": 256, "code_predictor_config": {"num_hidden_layers": 3}}, "tts_pad_token_id": 7},
@@ -93,3 +94,95 @@ def test_custom_voice_speaker_branch_and_dialect_override():
     assert r.codec_ids.tolist() == [-1, -1, -1, cfg.codec_nothink_id, cfg.codec_think_bos_id, cfg.codec_think_eos_id, cfg.codec_pad_id, cfg.codec_bos_id]
     base = q3.Qwen3TTSConfiguration.from_dict({"tts_model_type": "custom_voice", "talker_config": {"spk_id": {"a": 5}, "spk_is_dialect": {"a": False}}})
     assert base.tts_model_type == "custom_voice" and base.spk_id == {"a": 5} and base.spk_is_dialect == {"a": False}
+
+
+def test_encoder_side_sanitize_and_speaker_encoder_sanitize():
+    """Qwen3TTSSpeechTokenizer.sanitize, encoder side (:1099-1108,1240-1370,1411-1427): the HF Mimi names of a published speech tokenizer
+    come back as the module tree of Qwen3TTSSpeechTokenizerEncoder behind `encoder_model.` - exactly the keys and tensors of the oracle's
+    weight dict; Qwen3TTSSpeakerEncoder.sanitize (Qwen3TTSSpeakerEncoder.swift:324-354) for the x-vector net."""
+    import torch
+    from mlx_audio_swift_amd.qwen3tts import sanitize_speaker_encoder, sanitize_speech_tokenizer, Qwen3TTSConfiguration
+    from oracle import ecapa as oe
+    from oracle import mimi_encoder as om
+    cfg = om.MimiEncoderConfig(num_filters=4, hidden_size=16, num_hidden_layers=2, num_attention_heads=2, intermediate_size=32,
+                               codebook_dim=8, codebook_size=32, num_quantizers=5, valid_num_quantizers=4)
+    W = {k: torch.as_tensor(v) for k, v in om.make_synthetic_weights(cfg).items()}
+    hf = {}
+
+    def conv(hf_name, o_name, bias=True):
+        hf["encoder." + hf_name + ".conv.weight"] = W[o_name + ".conv.conv.weight"].permute(0, 2, 1).contiguous()       # PyTorch [out, in, k]
+        if bias:
+            hf["encoder." + hf_name + ".conv.bias"] = W[o_name + ".conv.conv.bias"]
+    conv("encoder.layers.0", "encoder.init_conv1d")
+    idx = 1
+    for li in range(4):
+        conv(f"encoder.layers.{idx}.block.1", f"encoder.layers.{li}.residuals.0.block.0")
+        conv(f"encoder.layers.{idx}.block.3", f"encoder.layers.{li}.residuals.0.block.1")
+        idx += 2
+        conv(f"encoder.layers.{idx}", f"encoder.layers.{li}.downsample")
+        idx += 1
+    conv(f"encoder.layers.{idx + 1}", "encoder.final_conv1d")
+    D = cfg.hidden_size
+    for li in range(cfg.num_hidden_layers):
+        p, q = f"encoder_transformer.transformer.layers.{li}", f"speech_tokenizer.encoder.encoder_transformer.layers.{li}"
+        w = W[p + ".self_attn.in_proj.weight"]
+        hf[q + ".self_attn.q_proj.weight"], hf[q + ".self_attn.k_proj.weight"], hf[q + ".self_attn.v_proj.weight"] = w[:D], w[D:2 * D], w[2 * D:]
+        hf[q + ".self_attn.o_proj.weight"] = W[p + ".self_attn.out_proj.weight"]
+        hf[q + ".mlp.fc1.weight"], hf[q + ".mlp.fc2.weight"] = W[p + ".gating.linear1.weight"], W[p + ".gating.linear2.weight"]
+        hf[q + ".input_layernorm.weight"], hf[q + ".input_layernorm.bias"] = W[p + ".norm1.weight"], W[p + ".norm1.bias"]
+        hf[q + ".post_attention_layernorm.weight"], hf[q + ".post_attention_layernorm.bias"] = W[p + ".norm2.weight"], W[p + ".norm2.bias"]
+        hf[q + ".self_attn_layer_scale.scale"], hf[q + ".mlp_layer_scale.scale"] = W[p + ".layer_scale_1.scale"], W[p + ".layer_scale_2.scale"]
+    hf["encoder.downsample.conv.weight"] = W["downsample.conv.conv.conv.weight"].permute(0, 2, 1).contiguous()
+    for hf_grp, o_grp, nq in (("semantic", "rvq_first", 1), ("acoustic", "rvq_rest", cfg.num_quantizers - 1)):
+        hp, op = f"encoder.quantizer.{hf_grp}_residual_vector_quantizer", f"quantizer.{o_grp}"
+        hf[hp + ".input_proj.weight"] = W[op + ".input_proj.weight"].permute(0, 2, 1).contiguous()
+        hf[hp + ".output_proj.weight"] = torch.zeros(cfg.hidden_size, cfg.codebook_dim, 1)
+        for i in range(nq):
+            hf[f"{hp}.layers.{i}.codebook.embed_sum"] = W[f"{op}.vq.layers.{i}.codebook.embedding_sum"]
+            hf[f"{hp}.layers.{i}.codebook.cluster_usage"] = W[f"{op}.vq.layers.{i}.codebook.cluster_usage"]
+            hf[f"{hp}.layers.{i}.codebook.initialized"] = torch.ones(1)
+    hf["speaker_encoder.fc.weight"] = torch.zeros(3, 4, 1)                      # not a tokenizer weight (:1220-1222)
+    back = sanitize_speech_tokenizer(hf)
+    enc = {k[len("encoder_model."):]: v for k, v in back.items() if k.startswith("encoder_model.") and "output_proj" not in k}
+    assert set(enc) == set(W), (set(enc) ^ set(W))
+    for k, v in W.items():
+        assert tuple(enc[k].shape) == tuple(v.shape) and torch.equal(enc[k], v), k
+    assert "encoder_model.quantizer.rvq_first.output_proj.weight" in back and not any("speaker_encoder" in k for k in back)
+    # speaker encoder: PyTorch conv layout [out, in, k] -> [out, k, in] when the heuristic says so; any prefix before `speaker_encoder`
+    ecfg = oe.EcapaConfig()
+    Ws = {k: torch.as_tensor(v) for k, v in oe.make_synthetic_weights(ecfg).items()}      # checkpoint shapes: the layout heuristic is made for them
+    raw = {}
+    for k, v in Ws.items():
+        raw["model.speaker_encoder." + k] = v.permute(0, 2, 1).contiguous() if v.ndim == 3 else v
+    raw["talker.model.norm.weight"] = torch.zeros(4)
+    sp = sanitize_speaker_encoder(raw)
+    assert set(sp) == {"speaker_encoder." + k for k in Ws}
+    for k, v in Ws.items():
+        assert tuple(sp["speaker_encoder." + k].shape) == tuple(v.shape) and torch.equal(sp["speaker_encoder." + k], v), k
+    assert all(torch.equal(v, sanitize_speaker_encoder({"speaker_encoder." + k: v})["speaker_encoder." + k]) for k, v in Ws.items())   # MLX layout stays
+    # configuration: speaker encoder only for base models, tokenizer encoder only with encoder_config
+    c = Qwen3TTSConfiguration.from_dict({"tts_model_type": "base", "speaker_encoder_config": {"enc_dim": 2048}},
+                                        {"encoder_config": {"num_filters": 32, "upsampling_ratios": [8, 6, 5, 4]}, "encoder_valid_num_quantizers": 16})
+    assert c.speaker_encoder.enc_dim == 2048 and c.speaker_encoder.enc_channels == ecfg.enc_channels
+    assert c.tokenizer_encoder.num_filters == 32 and c.tokenizer_encoder.upsampling_ratios == (8, 6, 5, 4) and c.encoder_valid_num_quantizers == 16
+    c2 = Qwen3TTSConfiguration.from_dict({"tts_model_type": "custom_voice"}, {})
+    assert c2.speaker_encoder is None and c2.tokenizer_encoder is None
+    rc = c.reference_to_c()
+    assert (rc.spk_n_blocks, rc.spk_enc_dim, rc.enc_n_ratios, rc.enc_num_filters, rc.enc_valid_num_quantizers) == (5, 2048, 4, 32, 16)
+
+
+def test_in_context_prompt_layout_without_a_device():
+    """prepareICLGenerationInputs (Qwen3TTS.swift:753-837) as (text id, codec id) positions, with a language id and without a speaker row"""
+    cfg = q3.Qwen3TTSConfiguration(codec_language_id={"english": 2050})
+    m = object.__new__(q3.Qwen3TTSModel)
+    m.configuration = cfg; m.tokenizer = _Tok(); m._h = None
+    ctx = q3.ReferenceAudioContext(None, np.zeros((16, 3), np.int32), -1, 7)
+    rid = _Tok().encode("<|im_start|>assistant\nabc<|im_end|>\n")[3:-2]
+    p = m.prepare_icl_generation_inputs("Hi you", conditioning=(ctx, rid, 2050))
+    ids = _Tok().encode("<|im_start|>assistant\nHi you<|im_end|>\n<|im_start|>assistant\n")
+    V = cfg.talker.vocab_size
+    body = rid + ids[3:-5] + [cfg.tts_eos_token_id]
+    assert p.text_ids.tolist() == ids[:3] + [cfg.tts_pad_token_id] * 4 + [cfg.tts_bos_token_id] + body + [cfg.tts_pad_token_id] * 4
+    assert p.codec_ids.tolist() == [-1] * 3 + [cfg.codec_think_id, cfg.codec_think_bos_id, 2050, cfg.codec_think_eos_id, cfg.codec_pad_id] \
+        + [cfg.codec_pad_id] * len(body) + [cfg.codec_bos_id, V + 7, V + 8, V + 9]
+    assert len(p.trailing_ids) == 0 and p.target_token_count == 6 and p.reference is ctx
