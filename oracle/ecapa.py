@@ -1,5 +1,5 @@
 """Qwen3-TTS speaker encoder (ECAPA-TDNN x-vector of the reference audio): CPU restatement of the reference.  Test infrastructure
-only; the engine side is not built yet - this module is the oracle it will be held against.
+only: the device side is csrc/q3_reference.hip, held to this module by tests/test_gpu_q3_reference.py.
 
 Follows Sources/MLXAudioTTS/Models/Qwen3TTS/Qwen3TTSSpeakerEncoder.swift: reflectPad1D (:6-16), TimeDelayNetBlock (:20-42: reflect pad
 (k-1) d / 2 on both sides, Conv1d with dilation, ReLU), Res2NetBlock (:46-96: channel chunks, chunk i > 1 gets the previous chunk's

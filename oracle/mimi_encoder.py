@@ -1,5 +1,5 @@
 """Qwen3-TTS speech-tokenizer ENCODER (reference audio -> codec codes, the in-context voice-cloning prompt): CPU restatement of the
-reference.  Test infrastructure only; the engine side is not built yet - this is the oracle it will be held to.
+reference.  Test infrastructure only: the device side is csrc/q3_reference.hip, held to this module by tests/test_gpu_q3_reference.py.
 
 Follows Qwen3TTSSpeechTokenizerEncoder (Qwen3TTSSpeechTokenizer.swift:792-881), which is the Mimi encoder of
 Sources/MLXAudioCodecs/Mimi/: StreamableConv1d (Conv.swift:171-227: padding_total = (k-1) d + 1 - stride, everything on the left when
