@@ -42,6 +42,8 @@ double tts_last_decode_ms(const mis_tts* c);
 struct TtsView { bf16_t *x, *h, *logits, *emb; int32_t *ids, *pos_next; uint8_t* active; int d, Mpad, V, Vpad, batch, finalized, L; hipStream_t stream; };
 void tts_internal_reset(mis_tts* c, int batch, int max_context);
 void tts_internal_use_stream(mis_tts* c, hipStream_t s);
+bool tts_internal_prefill_rows_ok(const mis_tts* c, int Lmax);
+void tts_internal_prefill_rows(mis_tts* c, const bf16_t* rows /*[Lmax][Mpad][d] device*/, const int32_t* lens_host, int Lmax);
 // one token position per active row: embedding rows gathered from `table` ([table_rows][d] bf16) by `ids` (device), through all
 // layers and the final norm (result: packed x of the view).  table == nullptr: the model's own embedding / id buffer.
 void tts_internal_enqueue_layers(mis_tts* c, const bf16_t* table, int table_rows, const int32_t* ids);

@@ -637,7 +637,9 @@ static bool prefill_batched_ok(const mis_tts* c, int Lmax) {
     return !off && Lmax >= 2 && !c->q_qkv.on && !c->q_o.on && !c->q_gu.on && !c->q_down.on && c->d % 64 == 0 && HD % 64 == 0 &&
            c->ff % 64 == 0 && c->d >= 128 && HD >= 128 && c->ff >= 128;
 }
-static void prefill_batched(mis_tts* c, const int32_t* prompt_mat_dev, const int32_t* lens_dev, const std::vector<int32_t>& lens, int Lmax) {
+// embed_rows != null: the [Lmax][Mpad][d] input embeddings of a composite engine replace the gather from the model's own table
+static void prefill_batched(mis_tts* c, const int32_t* prompt_mat_dev, const int32_t* lens_dev, const std::vector<int32_t>& lens, int Lmax,
+                            const bf16_t* embed_rows = nullptr) {
     hipStream_t s = c->stream;
     const int d = c->d, HD = c->H * c->D, Mpad = c->Mpad, batch = c->batch;
     const float eps = c->cfg.rms_norm_eps;
@@ -647,21 +649,29 @@ static void prefill_batched(mis_tts* c, const int32_t* prompt_mat_dev, const int
     c->pf_qkv.alloc(Mc * c->Nqkv); c->pf_pos.alloc(Mc); c->pf_on.alloc(Mc);
     HIP_CHECK(hipMemsetAsync(c->pf_attn.p, 0, Mc * HD * 2, s));             // rows of padded positions are never written by the attention
     const size_t lkv = (size_t)batch * c->Hkv * c->Smax * c->D;
+    // one launch per position fills the chip on its own once batch x kv heads reaches about half the CUs (measured: batch 32 x 8 heads,
+    // 32 positions: 14.3 ms per-position against 15.8 ms as two launches of 8192 blocks; batch 1, 350 positions: 90 -> 32 ms the other way)
+    const char* loop_env = getenv("MIS_PF_ATTN_LOOP");
+    const bool attn_loop = loop_env ? atoi(loop_env) != 0 : batch * c->Hkv >= 128;
     int t0 = 0;
     for (; t0 < Lmax; t0 += Tc) {
         const int tc = std::min(Tc, Lmax - t0);
         const int M = tc * Mpad;
-        launch_pf_embed_rmsnorm(c->emb.p, prompt_mat_dev, lens_dev, Lmax, t0, tc, batch, Mpad, c->V, c->norms.p, c->pf_h.p, c->pf_x.p,
-                                c->pf_pos.p, c->pf_on.p, d, eps, s);
+        if (embed_rows) launch_pf_rows_rmsnorm(embed_rows, lens_dev, Lmax, t0, tc, batch, Mpad, c->norms.p, c->pf_h.p, c->pf_x.p, c->pf_pos.p, c->pf_on.p, d, eps, s);
+        else launch_pf_embed_rmsnorm(c->emb.p, prompt_mat_dev, lens_dev, Lmax, t0, tc, batch, Mpad, c->V, c->norms.p, c->pf_h.p, c->pf_x.p,
+                                     c->pf_pos.p, c->pf_on.p, d, eps, s);
         for (int li = 0; li < c->L; ++li) {
             launch_gemm_pf(PF_F32, c->pf_x.p, c->wqkv.p + layer_qkv_elems(c) * li, c->pf_qkv.p, M, c->Nqkv, d, s);
-            for (int tl = 0; tl < tc; ++tl) {
+            // causal attention of the chunk: every (position, sequence) pair is a row of ONE launch.  First an append-only launch puts
+            // the roped keys and the values of all the chunk's positions into the caches, then the attention launch reads them like any
+            // earlier key (its own key is patched in registers as in the decode step).  MIS_PF_ATTN_LOOP=1 / 0 forces one launch per position / this.
+            auto attn_params = [&](int tl0) {
                 AttnParams ap{};
-                ap.qkv_part = c->pf_qkv.p + (size_t)tl * Mpad * c->Nqkv; ap.S = 1; ap.Mpad = Mpad; ap.Nqkv = c->Nqkv;
+                ap.qkv_part = c->pf_qkv.p + (size_t)tl0 * Mpad * c->Nqkv; ap.S = 1; ap.Mpad = Mpad; ap.Nqkv = c->Nqkv;
                 ap.kcache = c->kcache.p + lkv * li; ap.vtcache = c->vtcache.p + lkv * li;
-                ap.pos = c->pf_pos.p + (size_t)tl * Mpad; ap.active = c->pf_on.p + (size_t)tl * Mpad;
+                ap.pos = c->pf_pos.p + (size_t)tl0 * Mpad; ap.active = c->pf_on.p + (size_t)tl0 * Mpad;
                 ap.rope_cos = c->rope_cos.p; ap.rope_sin = c->rope_sin.p;
-                ap.out = c->pf_attn.p + (size_t)tl * Mpad * HD; ap.out_ld = HD;
+                ap.out = c->pf_attn.p + (size_t)tl0 * Mpad * HD; ap.out_ld = HD;
                 ap.H = c->H; ap.Hkv = c->Hkv; ap.D = c->D; ap.Smax = c->Smax; ap.scale = 1.0f / sqrtf((float)c->D);
                 if (c->cfg.qk_norm) {
                     ap.qnorm_w = c->qknorm.p + (size_t)(2 * li) * c->D;
@@ -669,7 +679,17 @@ static void prefill_batched(mis_tts* c, const int32_t* prompt_mat_dev, const int
                     ap.qk_eps = c->cfg.rms_norm_eps;
                 }
                 ap.rope_in_dtype = c->cfg.rope_ops_in_dtype;
-                launch_attn_decode(ap, batch, s);
+                return ap;
+            };
+            if (attn_loop) {
+                for (int tl = 0; tl < tc; ++tl) launch_attn_decode(attn_params(tl), batch, s);
+            } else {
+                AttnParams ap = attn_params(0);
+                ap.cache_rows = Mpad;
+                ap.append_only = 1;
+                launch_attn_decode(ap, tc * Mpad, s);
+                ap.append_only = 0;
+                launch_attn_decode(ap, tc * Mpad, s);
             }
             launch_gemm_pf(PF_RESID, c->pf_attn.p, c->wo.p + layer_o_elems(c) * li, c->pf_h.p, M, d, HD, s);
             launch_pf_rmsnorm(c->pf_h.p, c->norms.p + (size_t)(2 * li + 1) * d, c->pf_x.p, M, d, eps, s);
@@ -1628,6 +1648,15 @@ void tts_generate_hidden(mis_tts* c, const int32_t* prompt_ids, const int32_t* p
 
 // ---------------------------------------------------------------------------- hooks for composite engines (qwen3tts.hip)
 void tts_internal_reset(mis_tts* c, int batch, int max_context) { lm_reset(c, batch, max_context); }
+// batched prefill of right-aligned prompts given as input embeddings rows [Lmax][Mpad][d] (device; rows of positions a prompt does not
+// have are ignored): the caches then hold the prompts, the packed x of the view holds the final norm of every row's last position
+bool tts_internal_prefill_rows_ok(const mis_tts* c, int Lmax) { return prefill_batched_ok(c, Lmax); }
+void tts_internal_prefill_rows(mis_tts* c, const bf16_t* rows, const int32_t* lens_host, int Lmax) {
+    std::vector<int32_t> lens(lens_host, lens_host + c->batch);
+    c->prompt_lens.alloc(c->Mpad);
+    HIP_CHECK(hipMemcpyAsync(c->prompt_lens.p, lens.data(), (size_t)c->batch * 4, hipMemcpyHostToDevice, c->stream));
+    prefill_batched(c, nullptr, c->prompt_lens.p, lens, Lmax, rows);
+}
 void tts_internal_use_stream(mis_tts* c, hipStream_t s) {
     if (c->stream && !c->borrowed_stream && c->stream != s) { (void)hipStreamSynchronize(c->stream); (void)hipStreamDestroy(c->stream); }
     c->stream = s; c->borrowed_stream = true;

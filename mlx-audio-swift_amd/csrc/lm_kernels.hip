@@ -852,11 +852,12 @@ __global__ void __launch_bounds__(512) k_attn_decode(AttnParams p) {
     // ---- the K/V stream: the wave's first pair of tiles (32 KiB per wave) is requested now and lands while the prologue below
     // (slab reduce, q/k norm, RoPE, cache append, LDS staging, two barriers) runs - INCLUDING the tile the new key belongs to: its
     // slot is patched in registers from LDS below, so no load ever waits for this step's own cache append.
-    bf16_t* kc = p.kcache + ((size_t)(b * p.Hkv + kvh) * p.Smax) * D;
-    bf16_t* vt = p.vtcache + ((size_t)(b * p.Hkv + kvh) * D) * p.Smax;
+    const int cb = p.cache_rows ? b % p.cache_rows : b;            // batched prefill: rows are (position, sequence) pairs
+    bf16_t* kc = p.kcache + ((size_t)(cb * p.Hkv + kvh) * p.Smax) * D;
+    bf16_t* vt = p.vtcache + ((size_t)(cb * p.Hkv + kvh) * D) * p.Smax;
     const bf16x8_t* kbase = reinterpret_cast<const bf16x8_t*>(kc) + lane;
     const bf16x8_t* vbase = reinterpret_cast<const bf16x8_t*>(vt) + lane;
-    const int n_tiles = (kv_len + 31) >> 5;
+    const int n_tiles = p.append_only ? 0 : (kv_len + 31) >> 5;    // append-only launches request no tiles
     const int new_tile = p.cross ? -1 : (pos >> 5);
     bf16x8_t kA[2][D / 32], kB[2][D / 32], vA[D / 16], vB[D / 16];
     auto load_tile = [&](int tile, bf16x8_t (&ka)[2][D / 32], bf16x8_t (&vb)[D / 16]) {
@@ -935,6 +936,7 @@ __global__ void __launch_bounds__(512) k_attn_decode(AttnParams p) {
             vt[(((size_t)ptile * (D / 16) + (d >> 4)) * 64 + ((pr >> 3) << 4) + (d & 15)) * 8 + (pr & 7)] =
                 f32_to_bf16(sraw[(G + 1) * D + d]);
     __syncthreads();       // LDS q / new key visible (nobody reads this step's K/V append back from memory)
+    if (p.append_only) return;
     ATT_STAMP(4);
     // the new key (position pos) inside its tile's fragments: K row `prow` of half `phalf`, V^T column pr (see the cache tiling)
     auto patch_new_key = [&](bf16x8_t (&ka)[2][D / 32], bf16x8_t (&vb)[D / 16]) {
@@ -1438,7 +1440,7 @@ void launch_attn_decode(const AttnParams& p, int batch, hipStream_t s) {
     {   // second schedule (k_attn_decode2) where it applies; MIS_ATTN_V2=0 keeps the first one (A/B, parity tests: read per launch)
         const char* e = getenv("MIS_ATTN_V2");
         const bool v2 = !(e && atoi(e) == 0);
-        if (v2 && p.D == 128 && !p.cross && p.rope_cos && !p.rope_in_dtype && !p.qnorm_w && p.S <= 4 && G <= 4 && p.Smax <= 32 * ATT_WAVES * ATT2_MAX_J &&
+        if (v2 && !p.cache_rows && !p.append_only && p.D == 128 && !p.cross && p.rope_cos && !p.rope_in_dtype && !p.qnorm_w && p.S <= 4 && G <= 4 && p.Smax <= 32 * ATT_WAVES * ATT2_MAX_J &&
             p.Smax % 32 == 0 && ((uintptr_t)p.qkv_part & 15) == 0 && p.Nqkv % 4 == 0) {
             const size_t sm2 = attn2_smem_bytes(G);
             switch (p.S) {

@@ -63,6 +63,30 @@ __global__ void __launch_bounds__(256) k_pf_embed_rmsnorm(const bf16_t* __restri
         x[(size_t)r * d + i] = f32_to_bf16(bf16_to_f32(wnorm[i]) * bf16_round_f32(f * inv));       // T(w * T(x * rsqrt(mean + eps)))
     }
 }
+// the same for engines that feed input embeddings instead of token ids (Qwen3-TTS talker): rows [Lmax][Mpad][d] computed by the caller
+__global__ void __launch_bounds__(256) k_pf_rows_rmsnorm(const bf16_t* __restrict__ rows, const int32_t* __restrict__ lens, int Lmax, int t0, int batch,
+                                                         int Mpad, const bf16_t* __restrict__ wnorm, bf16_t* __restrict__ h, bf16_t* __restrict__ x,
+                                                         int32_t* __restrict__ pos_tab, uint8_t* __restrict__ act_tab, int d, float eps) {
+    __shared__ float red[4];
+    const int r = blockIdx.x, tl = r / Mpad, b = r - tl * Mpad, t = t0 + tl;
+    const bool row = b < batch;
+    const int len = row ? lens[b] : 0;
+    const bool on = row && t >= Lmax - len;
+    if (threadIdx.x == 0) { pos_tab[r] = on ? t - (Lmax - len) : 0; act_tab[r] = on ? 1 : 0; }
+    const bf16_t* e = rows + ((size_t)t * Mpad + b) * d;
+    float ss = 0.0f;
+    for (int i = threadIdx.x; i < d; i += 256) {
+        const bf16_t v = on ? e[i] : (bf16_t)0;
+        h[(size_t)r * d + i] = v;
+        const float f = bf16_to_f32(v);
+        ss += f * f;
+    }
+    const float inv = 1.0f / sqrtf(pf_block_sum_256(ss, red) / (float)d + eps);
+    for (int i = threadIdx.x; i < d; i += 256) {
+        const float f = on ? bf16_to_f32(e[i]) : 0.0f;
+        x[(size_t)r * d + i] = f32_to_bf16(bf16_to_f32(wnorm[i]) * bf16_round_f32(f * inv));
+    }
+}
 __global__ void __launch_bounds__(256) k_pf_rmsnorm(const bf16_t* __restrict__ h, const bf16_t* __restrict__ wnorm, bf16_t* __restrict__ x,
                                                     int d, float eps) {
     __shared__ float red[4];
@@ -219,6 +243,10 @@ void launch_pf_embed_rmsnorm(const bf16_t* emb, const int32_t* prompt, const int
                              const bf16_t* wnorm, bf16_t* h, bf16_t* x, int32_t* pos_tab, uint8_t* act_tab, int d, float eps, hipStream_t s) {
     hipLaunchKernelGGL(k_pf_embed_rmsnorm, dim3(Tc * Mpad), dim3(256), 0, s, emb, prompt, lens, Lmax, t0, batch, Mpad, vocab, wnorm, h, x, pos_tab,
                        act_tab, d, eps);
+}
+void launch_pf_rows_rmsnorm(const bf16_t* rows, const int32_t* lens, int Lmax, int t0, int Tc, int batch, int Mpad, const bf16_t* wnorm, bf16_t* h,
+                            bf16_t* x, int32_t* pos_tab, uint8_t* act_tab, int d, float eps, hipStream_t s) {
+    hipLaunchKernelGGL(k_pf_rows_rmsnorm, dim3(Tc * Mpad), dim3(256), 0, s, rows, lens, Lmax, t0, batch, Mpad, wnorm, h, x, pos_tab, act_tab, d, eps);
 }
 void launch_pf_rmsnorm(const bf16_t* h, const bf16_t* wnorm, bf16_t* x, int rows, int d, float eps, hipStream_t s) {
     hipLaunchKernelGGL(k_pf_rmsnorm, dim3(rows), dim3(256), 0, s, h, wnorm, x, d, eps);

@@ -37,7 +37,7 @@ struct mis_qwen3tts {
     DevBuf<bf16_t> text_emb, fc1, fc2, fc1_b, fc2_b, proj_w, proj_b, codec_emb, codec_emb_proj;
     DevBuf<bf16_t> pred_emb[32], pred_emb_proj[32], pred_head[32];      // num_code_groups - 1 <= 31 tables / heads
     // per-call state
-    DevBuf<bf16_t> tproj, in_emb, hid_rows, hid_proj, xpk, act;
+    DevBuf<bf16_t> tproj, in_emb, hid_rows, hid_proj, xpk, act, pf_rows;
     DevBuf<int32_t> iota, tidx, cidx, plen, trail_idx, trail_len, cur_codes, codes, n_frames, frame, step_counter, done, row_max,
         ids_tmp;
     DevBuf<uint8_t> seen;
@@ -99,6 +99,29 @@ __global__ void k_q3_prefill_feed(const int32_t* __restrict__ tidx, const int32_
         in_emb[(size_t)b * d + k] = f32_to_bf16(v);
     }
 }                                                                // the counter is bumped by a separate launch (k_q3_bump)
+
+// the whole right-aligned prompt matrix at once for the batched prefill: rows[(j * Mpad + b)] = what k_q3_prefill_feed feeds at position j
+__global__ void k_q3_prefill_rows(const int32_t* __restrict__ tidx, const int32_t* __restrict__ cidx, const int32_t* __restrict__ plen, int P,
+                                  int Lmax, const bf16_t* __restrict__ tproj, const bf16_t* __restrict__ codec_emb, int Vc,
+                                  const bf16_t* __restrict__ ref_rows, int n_ref_rows, bf16_t* __restrict__ rows, int d, int batch, int Mpad) {
+    const int b = blockIdx.x, j = blockIdx.y;
+    int idx = -1;
+    if (b < batch) idx = j - (Lmax - plen[b]);
+    const bool on = idx >= 0 && b < batch;
+    const int t = on ? tidx[(size_t)b * P + idx] : -1;
+    int c = on ? cidx[(size_t)b * P + idx] : -1;
+    const bf16_t* crow = nullptr;
+    if (c >= Vc) { if (c - Vc < n_ref_rows) crow = ref_rows + (size_t)(c - Vc) * d; }
+    else if (c >= 0) crow = codec_emb + (size_t)c * d;
+    bf16_t* out = rows + ((size_t)j * Mpad + b) * d;
+    for (int k = threadIdx.x; k < d; k += blockDim.x) {
+        float v = 0.0f;
+        if (t >= 0 && crow) v = bf16_round_f32(bf16_to_f32(tproj[(size_t)t * d + k]) + bf16_to_f32(crow[k]));
+        else if (t >= 0) v = bf16_to_f32(tproj[(size_t)t * d + k]);
+        else if (crow) v = bf16_to_f32(crow[k]);
+        out[k] = f32_to_bf16(v);
+    }
+}
 
 // codecEmbedIcl rows (Qwen3TTS.swift:249-262): rows[t] = codec_emb[code 0] + sum_i pred_emb[i][code i+1], one bf16 rounding per add
 __global__ void k_q3_ref_rows(const int32_t* __restrict__ codes /*[nq][T]*/, int nq, int T, const bf16_t* __restrict__ codec_emb, int Vc,
@@ -491,8 +514,17 @@ void q3_generate_codes(mis_qwen3tts* c, const int32_t* text_ids, const int32_t* 
     };
     hipGraphExec_t g_prefill = nullptr, g_frame = nullptr;
     try {
-        if (use_graph) capture(&g_prefill, prefill_body);
-        for (int j = 0; j < Lmax; ++j) { if (use_graph) HIP_CHECK(hipGraphLaunch(g_prefill, s)); else prefill_body(); }
+        if (tts_internal_prefill_rows_ok(c->talker, Lmax)) {
+            // all prompt positions through the talker at once (lm_prefill.hip: [positions x rows] GEMMs on the packed weights); the
+            // position-by-position graph below remains for quantised roles, odd widths and MIS_PREFILL_SEQ=1
+            c->pf_rows.alloc((size_t)Lmax * Mpad * d);
+            hipLaunchKernelGGL(k_q3_prefill_rows, dim3(Mpad, Lmax), dim3(256), 0, s, c->tidx.p, c->cidx.p, c->plen.p, P, Lmax, c->tproj.p,
+                               c->codec_emb.p, c->Vc, c->ref_rows.p, c->n_ref_rows, c->pf_rows.p, d, batch, Mpad);
+            tts_internal_prefill_rows(c->talker, c->pf_rows.p, prefill_lens, Lmax);
+        } else {
+            if (use_graph) capture(&g_prefill, prefill_body);
+            for (int j = 0; j < Lmax; ++j) { if (use_graph) HIP_CHECK(hipGraphLaunch(g_prefill, s)); else prefill_body(); }
+        }
         {
             std::vector<uint8_t> ones(Mpad, 0);
             for (int b = 0; b < batch; ++b) ones[b] = 1;

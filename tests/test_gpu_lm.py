@@ -162,8 +162,13 @@ def test_batched_prefill_matches_oracle_and_the_position_by_position_path(ocfg, 
     rows = [rng.integers(0, ocfg.vocab_size, n).astype(np.int32) for n in lens]
     nxt = rng.integers(0, ocfg.vocab_size, len(rows)).astype(np.int32)
     monkeypatch.setenv("MIS_PREFILL_SEQ", "0")
+    monkeypatch.setenv("MIS_PF_ATTN_LOOP", "0")                           # the chunk's causal attention as two launches over (position, row) pairs
     got = dev.lm_prefill(rows, max_context=96)
     got2 = dev.lm_forward(nxt)                                            # one decode step behind the prompts
+    monkeypatch.setenv("MIS_PF_ATTN_LOOP", "1")                           # ... and as one launch per position (what full batches use)
+    loop = dev.lm_prefill(rows, max_context=96)
+    loop2 = dev.lm_forward(nxt)
+    monkeypatch.delenv("MIS_PF_ATTN_LOOP")
     monkeypatch.setenv("MIS_PREFILL_SEQ", "1")
     seq = dev.lm_prefill(rows, max_context=96)
     seq2 = dev.lm_forward(nxt)
@@ -182,9 +187,12 @@ def test_batched_prefill_matches_oracle_and_the_position_by_position_path(ocfg, 
     # mean at the per-row tolerance of the other LM tests and the worst row at twice that
     assert np.mean(e_all) <= 0.008 and np.max(e_all) <= 0.016, (np.mean(e_all), np.max(e_all))
     assert np.mean(d_all) <= 0.008 and np.max(d_all) <= 0.016, (np.mean(d_all), np.max(d_all))
+    # the two attention arrangements of the batched path: same keys, same rounding points, (first / second) decode-attention schedule
+    l_all = [float(np.sqrt(np.mean((a - b) ** 2)) / np.sqrt(np.mean(b ** 2))) for a, b in zip(list(got) + list(got2), list(loop) + list(loop2))]
+    assert np.mean(l_all) <= 0.004 and np.max(l_all) <= 0.016, (np.mean(l_all), np.max(l_all))
     worst = [max(m_all), max(e_all), max(d_all)]
     record(f"batched_prefill_{ocfg.hidden_size}", logits_max_rel=worst[0], logits_rms_rel_worst=worst[1], logits_rms_rel_mean=float(np.mean(e_all)),
-           rms_vs_sequential_worst=worst[2], rms_vs_sequential_mean=float(np.mean(d_all)), tol_max=TOL_MAX, tol_rms_mean=0.008, tol_rms_worst=0.016)
+           rms_vs_sequential_worst=worst[2], rms_vs_sequential_mean=float(np.mean(d_all)), rms_pairs_vs_per_position_worst=float(np.max(l_all)), tol_max=TOL_MAX, tol_rms_mean=0.008, tol_rms_worst=0.016)
 
 
 def test_second_attention_schedule_matches_the_first_and_the_oracle(monkeypatch):

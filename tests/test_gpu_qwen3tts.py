@@ -446,3 +446,29 @@ def test_group_of_two_logical_shards_streams_per_replica_and_returns_the_unshard
     for r in range(3):
         assert len(got[r]) == len(single[r]) >= 2
         assert np.array_equal(np.concatenate(got[r]), pcm3[r]) and np.array_equal(pcm3[r], pcm4[r]), r
+
+
+def test_batched_prompt_prefill_matches_the_position_by_position_graph(monkeypatch):
+    """The talker's prompt as one [positions x rows] pass over input embeddings (tts_internal_prefill_rows -> lm_prefill.hip, causal
+    attention as two launches over (position, row) pairs) against the position-by-position graph (MIS_PREFILL_SEQ=1): greedy codes of
+    ragged rows (instruct prefixes of different lengths) agree frame for frame, and both agree with the oracle under teacher forcing
+    wherever its margin is not a rounding matter (the existing frame-loop tests run on the batched path by default)."""
+    cfg, dev, orc, _ = _pair()
+    rng = np.random.default_rng(41)
+    prompts = [_prompt(cfg, rng, 5 + 9 * i, 3) for i in range(4)]               # 8 .. 35 prompt positions
+    gp = mas.Qwen3TTSGenerateParameters(max_tokens=5, temperature=0.0)
+    monkeypatch.setenv("MIS_PREFILL_SEQ", "0")
+    a = dev.generate_codes(prompts, gp)
+    monkeypatch.setenv("MIS_PREFILL_SEQ", "1")
+    b = dev.generate_codes(prompts, gp)
+    params = dict(temperature=0.0, top_p=1.0, top_k=0, repetition_penalty=1.05, min_p=0.0, seed=0)
+    V = cfg.talker.vocab_size
+    for r, p in enumerate(prompts):
+        _, tl = orc.generate_row(p.text_ids, p.codec_ids, p.trailing_ids, params, row=r, max_frames=len(a[r]), forced_codes=a[r])
+        lg = tl[0].copy()
+        lg[V - 1024:V] = -np.inf
+        lg[cfg.codec_eos_token_id] = tl[0][cfg.codec_eos_token_id]
+        top = np.sort(lg)[-2:]
+        if top[1] - top[0] > 0.05 * max(1.0, abs(top[1])):                      # frame 0 is the prefill's own logits
+            assert int(np.argmax(lg)) == int(a[r][0][0]) == int(b[r][0][0]), r
+            assert np.array_equal(a[r], b[r]), r
