@@ -16,6 +16,7 @@
 #include <string.h>
 #include <algorithm>
 #include <chrono>
+#include <functional>
 #include <set>
 
 #define ORPHEUS_END_OF_SPEECH 128258
@@ -67,8 +68,8 @@ struct mis_tts {
         done_count, codes, n_codes, l0, l1, l2, row_map;
     DevBuf<float> pcm_tmp;
     // batched prefill (lm_prefill.hip): one chunk of positions x rows
-    DevBuf<bf16_t> pf_h, pf_x, pf_attn, pf_act;
-    DevBuf<float> pf_qkv;
+    DevBuf<bf16_t> pf_h, pf_x, pf_attn, pf_act, pf_xpk, pf_actpk;
+    DevBuf<float> pf_qkv, pf_tmp;
     DevBuf<int32_t> pf_pos;
     DevBuf<uint8_t> pf_on;
     DevBuf<SamplerScratch> samp_scratch;
@@ -634,8 +635,10 @@ static void enqueue_lm_head(mis_tts* c, const bf16_t* head = nullptr) {
 static bool prefill_batched_ok(const mis_tts* c, int Lmax) {
     const bool off = getenv("MIS_PREFILL_SEQ") && atoi(getenv("MIS_PREFILL_SEQ")) != 0;             // A/B and parity tests (read per call)
     const int HD = c->H * c->D;
-    return !off && Lmax >= 2 && !c->q_qkv.on && !c->q_o.on && !c->q_gu.on && !c->q_down.on && c->d % 64 == 0 && HD % 64 == 0 &&
-           c->ff % 64 == 0 && c->d >= 128 && HD >= 128 && c->ff >= 128;
+    // dense weights: k_gemm_pf; all four roles streamed as codes: the decode step's k_gemm_skinny_q on 64-row chunks; a mix: position by position
+    const bool dense = !c->q_qkv.on && !c->q_o.on && !c->q_gu.on && !c->q_down.on;
+    const bool coded = c->q_qkv.on && c->q_o.on && c->q_gu.on && c->q_down.on;
+    return !off && Lmax >= 2 && (dense || coded) && c->d % 64 == 0 && HD % 64 == 0 && c->ff % 64 == 0 && c->d >= 128 && HD >= 128 && c->ff >= 128;
 }
 // embed_rows != null: the [Lmax][Mpad][d] input embeddings of a composite engine replace the gather from the model's own table
 static void prefill_batched(mis_tts* c, const int32_t* prompt_mat_dev, const int32_t* lens_dev, const std::vector<int32_t>& lens, int Lmax,
@@ -643,35 +646,57 @@ static void prefill_batched(mis_tts* c, const int32_t* prompt_mat_dev, const int
     hipStream_t s = c->stream;
     const int d = c->d, HD = c->H * c->D, Mpad = c->Mpad, batch = c->batch;
     const float eps = c->cfg.rms_norm_eps;
-    const int Tc = std::min(Lmax, std::max(1, 4096 / Mpad));                 // positions per chunk: <= 4096 rows of activations
-    const size_t Mc = (size_t)Tc * Mpad;
-    c->pf_h.alloc(Mc * d); c->pf_x.alloc(Mc * d); c->pf_attn.alloc(Mc * HD); c->pf_act.alloc(Mc * c->ff);
-    c->pf_qkv.alloc(Mc * c->Nqkv); c->pf_pos.alloc(Mc); c->pf_on.alloc(Mc);
-    HIP_CHECK(hipMemsetAsync(c->pf_attn.p, 0, Mc * HD * 2, s));             // rows of padded positions are never written by the attention
-    const size_t lkv = (size_t)batch * c->Hkv * c->Smax * c->D;
-    // one launch per position fills the chip on its own once batch x kv heads reaches about half the CUs (measured: batch 32 x 8 heads,
-    // 32 positions: 14.3 ms per-position against 15.8 ms as two launches of 8192 blocks; batch 1, 350 positions: 90 -> 32 ms the other way)
+    // Causal attention of a chunk, two arrangements: one launch per position (rows = sequences) - fills the chip on its own once
+    // batch x kv heads reaches about half the CUs - or every (position, sequence) pair as a row of ONE launch: an append-only launch
+    // puts the roped keys and the values of all the chunk's positions into the caches, then the attention launch reads them like any
+    // earlier key (its own key is patched in registers as in the decode step).  Measured: batch 32 x 8 heads, 32 positions: 14.3 ms
+    // per position against 15.8 ms as pairs; batch 1, 350 positions: 90 -> 32 ms the other way.  MIS_PF_ATTN_LOOP=1 / 0 forces one.
     const char* loop_env = getenv("MIS_PF_ATTN_LOOP");
     const bool attn_loop = loop_env ? atoi(loop_env) != 0 : batch * c->Hkv >= 128;
+    // rows of the chunk: position-major, `rs` rows per position.  The pair arrangement needs no padding between positions (a batch of 1
+    // would otherwise carry 15 padding rows per position through every GEMM); the per-position one keeps Mpad (its flag words are aligned)
+    const int rs = attn_loop ? Mpad : batch;
+    const int Tc = std::min(Lmax, std::max(1, 4096 / rs));                   // positions per chunk: <= 4096 rows of activations
+    const size_t Mc = round_up((size_t)Tc * rs, 16) + Mpad;                  // GEMM rows round up to 16; the last position is read Mpad rows wide
+    c->pf_h.alloc(Mc * d); c->pf_x.alloc(Mc * d); c->pf_attn.alloc(Mc * HD);
+    c->pf_qkv.alloc(Mc * c->Nqkv); c->pf_pos.alloc(Mc); c->pf_on.alloc(Mc);
+    HIP_CHECK(hipMemsetAsync(c->pf_attn.p, 0, Mc * HD * 2, s));             // rows of padded positions are never written by the attention
+    HIP_CHECK(hipMemsetAsync(c->pf_x.p, 0, Mc * d * 2, s));                 // rows past the chunk (rounding, slack) hold zeros, not stale bits
+    HIP_CHECK(hipMemsetAsync(c->pf_h.p, 0, Mc * d * 2, s));
+    // quantised checkpoints (every role streamed as codes): each GEMM of the chunk runs the decode step's k_gemm_skinny_q on 64-row
+    // slices - rows packed into MFMA fragments first, float32 sums out, the residual add as its own small kernel; gate|up writes the
+    // packed activation its down projection reads.  The weights are streamed once per 64 rows instead of once per position.
+    const bool coded = c->q_qkv.on;
+    if (coded) { c->pf_xpk.alloc((size_t)64 * std::max(d, HD)); c->pf_actpk.alloc((size_t)64 * c->ff); c->pf_tmp.alloc((size_t)64 * d); }
+    else c->pf_act.alloc(Mc * c->ff);
+    auto q_rows = [&](int M, const std::function<void(int r0, int mp)>& body) {
+        for (int r0 = 0; r0 < M; r0 += 64) body(r0, std::min(64, M - r0));
+    };
+    auto q_partial = [&](const mis_tts::QRole& q, int li, const bf16_t* xpk, float* out, int N, int K, int mp) {
+        launch_gemm_skinny_q(q.bits, EPI_PARTIAL, c->r_part, c->ksb_part, q.q.p + q.q_layer * li, q.sb.p + q.sb_layer * li, xpk, out, N / 16, K / 64, 1, N, mp, s);
+    };
+    const size_t lkv = (size_t)batch * c->Hkv * c->Smax * c->D;
     int t0 = 0;
     for (; t0 < Lmax; t0 += Tc) {
         const int tc = std::min(Tc, Lmax - t0);
-        const int M = tc * Mpad;
-        if (embed_rows) launch_pf_rows_rmsnorm(embed_rows, lens_dev, Lmax, t0, tc, batch, Mpad, c->norms.p, c->pf_h.p, c->pf_x.p, c->pf_pos.p, c->pf_on.p, d, eps, s);
-        else launch_pf_embed_rmsnorm(c->emb.p, prompt_mat_dev, lens_dev, Lmax, t0, tc, batch, Mpad, c->V, c->norms.p, c->pf_h.p, c->pf_x.p,
+        const int Mr = tc * rs;                                              // rows that exist
+        const int M = (int)round_up((size_t)Mr, 16);                         // rows the GEMMs run over
+        if (embed_rows) launch_pf_rows_rmsnorm(embed_rows, Mpad, lens_dev, Lmax, t0, tc, batch, rs, c->norms.p, c->pf_h.p, c->pf_x.p, c->pf_pos.p, c->pf_on.p, d, eps, s);
+        else launch_pf_embed_rmsnorm(c->emb.p, prompt_mat_dev, lens_dev, Lmax, t0, tc, batch, rs, c->V, c->norms.p, c->pf_h.p, c->pf_x.p,
                                      c->pf_pos.p, c->pf_on.p, d, eps, s);
         for (int li = 0; li < c->L; ++li) {
-            launch_gemm_pf(PF_F32, c->pf_x.p, c->wqkv.p + layer_qkv_elems(c) * li, c->pf_qkv.p, M, c->Nqkv, d, s);
-            // causal attention of the chunk: every (position, sequence) pair is a row of ONE launch.  First an append-only launch puts
-            // the roped keys and the values of all the chunk's positions into the caches, then the attention launch reads them like any
-            // earlier key (its own key is patched in registers as in the decode step).  MIS_PF_ATTN_LOOP=1 / 0 forces one launch per position / this.
+            if (coded) q_rows(M, [&](int r0, int mp) {
+                launch_pf_pack_rows(c->pf_x.p + (size_t)r0 * d, c->pf_xpk.p, mp, d, s);
+                q_partial(c->q_qkv, li, c->pf_xpk.p, c->pf_qkv.p + (size_t)r0 * c->Nqkv, c->Nqkv, d, mp);
+            });
+            else launch_gemm_pf(PF_F32, c->pf_x.p, c->wqkv.p + layer_qkv_elems(c) * li, c->pf_qkv.p, M, c->Nqkv, d, s);
             auto attn_params = [&](int tl0) {
                 AttnParams ap{};
-                ap.qkv_part = c->pf_qkv.p + (size_t)tl0 * Mpad * c->Nqkv; ap.S = 1; ap.Mpad = Mpad; ap.Nqkv = c->Nqkv;
+                ap.qkv_part = c->pf_qkv.p + (size_t)tl0 * rs * c->Nqkv; ap.S = 1; ap.Mpad = Mpad; ap.Nqkv = c->Nqkv;
                 ap.kcache = c->kcache.p + lkv * li; ap.vtcache = c->vtcache.p + lkv * li;
-                ap.pos = c->pf_pos.p + (size_t)tl0 * Mpad; ap.active = c->pf_on.p + (size_t)tl0 * Mpad;
+                ap.pos = c->pf_pos.p + (size_t)tl0 * rs; ap.active = c->pf_on.p + (size_t)tl0 * rs;
                 ap.rope_cos = c->rope_cos.p; ap.rope_sin = c->rope_sin.p;
-                ap.out = c->pf_attn.p + (size_t)tl0 * Mpad * HD; ap.out_ld = HD;
+                ap.out = c->pf_attn.p + (size_t)tl0 * rs * HD; ap.out_ld = HD;
                 ap.H = c->H; ap.Hkv = c->Hkv; ap.D = c->D; ap.Smax = c->Smax; ap.scale = 1.0f / sqrtf((float)c->D);
                 if (c->cfg.qk_norm) {
                     ap.qnorm_w = c->qknorm.p + (size_t)(2 * li) * c->D;
@@ -679,27 +704,44 @@ static void prefill_batched(mis_tts* c, const int32_t* prompt_mat_dev, const int
                     ap.qk_eps = c->cfg.rms_norm_eps;
                 }
                 ap.rope_in_dtype = c->cfg.rope_ops_in_dtype;
+                ap.first_schedule = 1;          // one kernel for both arrangements: a row's logits do not depend on how many rows share the call
                 return ap;
             };
             if (attn_loop) {
                 for (int tl = 0; tl < tc; ++tl) launch_attn_decode(attn_params(tl), batch, s);
             } else {
                 AttnParams ap = attn_params(0);
-                ap.cache_rows = Mpad;
+                ap.cache_rows = rs;
                 ap.append_only = 1;
-                launch_attn_decode(ap, tc * Mpad, s);
+                launch_attn_decode(ap, Mr, s);
                 ap.append_only = 0;
-                launch_attn_decode(ap, tc * Mpad, s);
+                launch_attn_decode(ap, Mr, s);
             }
-            launch_gemm_pf(PF_RESID, c->pf_attn.p, c->wo.p + layer_o_elems(c) * li, c->pf_h.p, M, d, HD, s);
+            if (coded) q_rows(M, [&](int r0, int mp) {
+                launch_pf_pack_rows(c->pf_attn.p + (size_t)r0 * HD, c->pf_xpk.p, mp, HD, s);
+                q_partial(c->q_o, li, c->pf_xpk.p, c->pf_tmp.p, d, HD, mp);
+                launch_pf_add_resid(c->pf_h.p + (size_t)r0 * d, c->pf_tmp.p, (size_t)mp * d, s);
+            });
+            else launch_gemm_pf(PF_RESID, c->pf_attn.p, c->wo.p + layer_o_elems(c) * li, c->pf_h.p, M, d, HD, s);
             launch_pf_rmsnorm(c->pf_h.p, c->norms.p + (size_t)(2 * li + 1) * d, c->pf_x.p, M, d, eps, s);
-            launch_gemm_pf(PF_SILU, c->pf_x.p, c->wgu.p + layer_gu_elems(c) * li, c->pf_act.p, M, 2 * c->ff, d, s);
-            launch_gemm_pf(PF_RESID, c->pf_act.p, c->wdown.p + layer_down_elems(c) * li, c->pf_h.p, M, d, c->ff, s);
+            if (coded) q_rows(M, [&](int r0, int mp) {
+                launch_pf_pack_rows(c->pf_x.p + (size_t)r0 * d, c->pf_xpk.p, mp, d, s);
+                launch_gemm_skinny_q(c->q_gu.bits, EPI_SILU_MUL, 2, c->ksb_gu, c->q_gu.q.p + c->q_gu.q_layer * li, c->q_gu.sb.p + c->q_gu.sb_layer * li,
+                                     c->pf_xpk.p, c->pf_actpk.p, 2 * c->ff / 16, d / 64, 1, c->ff, mp, s);
+                q_partial(c->q_down, li, c->pf_actpk.p, c->pf_tmp.p, d, c->ff, mp);
+                launch_pf_add_resid(c->pf_h.p + (size_t)r0 * d, c->pf_tmp.p, (size_t)mp * d, s);
+            });
+            else {
+                launch_gemm_pf(PF_SILU, c->pf_x.p, c->wgu.p + layer_gu_elems(c) * li, c->pf_act.p, M, 2 * c->ff, d, s);
+                launch_gemm_pf(PF_RESID, c->pf_act.p, c->wdown.p + layer_down_elems(c) * li, c->pf_h.p, M, d, c->ff, s);
+            }
             const bf16_t* next_norm = c->norms.p + (size_t)(li + 1 < c->L ? 2 * (li + 1) : 2 * c->L) * d;
             launch_pf_rmsnorm(c->pf_h.p, next_norm, c->pf_x.p, M, d, eps, s);
         }
-        if (t0 + tc >= Lmax)                                                 // left-padded prompts: every row's last token is position Lmax - 1
-            launch_pf_pack_rows(c->pf_x.p + (size_t)(tc - 1) * Mpad * d, c->x.p, Mpad, d, s);
+        if (t0 + tc >= Lmax) {                                               // left-padded prompts: every row's last token is position Lmax - 1
+            // rows batch .. Mpad-1 of the packed x belong to no sequence: what follows the last position in pf_x (zeros, or the rounding rows)
+            launch_pf_pack_rows(c->pf_x.p + (size_t)(tc - 1) * rs * d, c->x.p, Mpad, d, s);
+        }
     }
     std::vector<int32_t> pn(Mpad, 0), pc(Mpad, 0);
     for (int b = 0; b < batch; ++b) { pn[b] = lens[b]; pc[b] = lens[b] - 1; }

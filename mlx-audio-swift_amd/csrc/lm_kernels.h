@@ -43,8 +43,9 @@ enum { PF_F32 = 0, PF_RESID = 1, PF_SILU = 2 };
 void launch_gemm_pf(int epi, const bf16_t* X, const bf16_t* Wp, void* C, int M, int N, int K, hipStream_t s);
 void launch_pf_embed_rmsnorm(const bf16_t* emb, const int32_t* prompt, const int32_t* lens, int Lmax, int t0, int Tc, int batch, int Mpad, int vocab,
                              const bf16_t* wnorm, bf16_t* h, bf16_t* x, int32_t* pos_tab, uint8_t* act_tab, int d, float eps, hipStream_t s);
-void launch_pf_rows_rmsnorm(const bf16_t* rows, const int32_t* lens, int Lmax, int t0, int Tc, int batch, int Mpad, const bf16_t* wnorm, bf16_t* h,
-                            bf16_t* x, int32_t* pos_tab, uint8_t* act_tab, int d, float eps, hipStream_t s);
+void launch_pf_add_resid(bf16_t* h, const float* part, size_t n, hipStream_t s);
+void launch_pf_rows_rmsnorm(const bf16_t* rows, int src_rows, const int32_t* lens, int Lmax, int t0, int Tc, int batch, int Mpad, const bf16_t* wnorm,
+                            bf16_t* h, bf16_t* x, int32_t* pos_tab, uint8_t* act_tab, int d, float eps, hipStream_t s);
 void launch_pf_rmsnorm(const bf16_t* h, const bf16_t* wnorm, bf16_t* x, int rows, int d, float eps, hipStream_t s);
 void launch_pf_pack_rows(const bf16_t* rows, bf16_t* xpk, int Mpad, int d, hipStream_t s);
 
@@ -75,6 +76,7 @@ struct AttnParams {
     // append_only = 1: RoPE / norm the new key and value, write them to the caches, stop (all positions of a chunk first: the second
     // launch then finds every earlier key of its own chunk in memory)
     int cache_rows, append_only;
+    int first_schedule;      // 1: never k_attn_decode2 - the prefill's two arrangements must give the same bits whatever the batch size
 };
 void launch_attn_decode(const AttnParams& p, int batch, hipStream_t s);
 

@@ -1440,7 +1440,7 @@ void launch_attn_decode(const AttnParams& p, int batch, hipStream_t s) {
     {   // second schedule (k_attn_decode2) where it applies; MIS_ATTN_V2=0 keeps the first one (A/B, parity tests: read per launch)
         const char* e = getenv("MIS_ATTN_V2");
         const bool v2 = !(e && atoi(e) == 0);
-        if (v2 && !p.cache_rows && !p.append_only && p.D == 128 && !p.cross && p.rope_cos && !p.rope_in_dtype && !p.qnorm_w && p.S <= 4 && G <= 4 && p.Smax <= 32 * ATT_WAVES * ATT2_MAX_J &&
+        if (v2 && !p.first_schedule && !p.cache_rows && !p.append_only && p.D == 128 && !p.cross && p.rope_cos && !p.rope_in_dtype && !p.qnorm_w && p.S <= 4 && G <= 4 && p.Smax <= 32 * ATT_WAVES * ATT2_MAX_J &&
             p.Smax % 32 == 0 && ((uintptr_t)p.qkv_part & 15) == 0 && p.Nqkv % 4 == 0) {
             const size_t sm2 = attn2_smem_bytes(G);
             switch (p.S) {

@@ -63,8 +63,9 @@ __global__ void __launch_bounds__(256) k_pf_embed_rmsnorm(const bf16_t* __restri
         x[(size_t)r * d + i] = f32_to_bf16(bf16_to_f32(wnorm[i]) * bf16_round_f32(f * inv));       // T(w * T(x * rsqrt(mean + eps)))
     }
 }
-// the same for engines that feed input embeddings instead of token ids (Qwen3-TTS talker): rows [Lmax][Mpad][d] computed by the caller
-__global__ void __launch_bounds__(256) k_pf_rows_rmsnorm(const bf16_t* __restrict__ rows, const int32_t* __restrict__ lens, int Lmax, int t0, int batch,
+// the same for engines that feed input embeddings instead of token ids (Qwen3-TTS talker): rows [Lmax][src_rows][d] computed by the
+// caller; `Mpad` here and in k_pf_embed_rmsnorm is the chunk's rows per position (the engine's Mpad, or the batch itself)
+__global__ void __launch_bounds__(256) k_pf_rows_rmsnorm(const bf16_t* __restrict__ rows, int src_rows, const int32_t* __restrict__ lens, int Lmax, int t0, int batch,
                                                          int Mpad, const bf16_t* __restrict__ wnorm, bf16_t* __restrict__ h, bf16_t* __restrict__ x,
                                                          int32_t* __restrict__ pos_tab, uint8_t* __restrict__ act_tab, int d, float eps) {
     __shared__ float red[4];
@@ -73,7 +74,7 @@ __global__ void __launch_bounds__(256) k_pf_rows_rmsnorm(const bf16_t* __restric
     const int len = row ? lens[b] : 0;
     const bool on = row && t >= Lmax - len;
     if (threadIdx.x == 0) { pos_tab[r] = on ? t - (Lmax - len) : 0; act_tab[r] = on ? 1 : 0; }
-    const bf16_t* e = rows + ((size_t)t * Mpad + b) * d;
+    const bf16_t* e = rows + ((size_t)t * src_rows + b) * d;                   // the caller's matrix keeps its own rows per position
     float ss = 0.0f;
     for (int i = threadIdx.x; i < d; i += 256) {
         const bf16_t v = on ? e[i] : (bf16_t)0;
@@ -244,12 +245,21 @@ void launch_pf_embed_rmsnorm(const bf16_t* emb, const int32_t* prompt, const int
     hipLaunchKernelGGL(k_pf_embed_rmsnorm, dim3(Tc * Mpad), dim3(256), 0, s, emb, prompt, lens, Lmax, t0, batch, Mpad, vocab, wnorm, h, x, pos_tab,
                        act_tab, d, eps);
 }
-void launch_pf_rows_rmsnorm(const bf16_t* rows, const int32_t* lens, int Lmax, int t0, int Tc, int batch, int Mpad, const bf16_t* wnorm, bf16_t* h,
-                            bf16_t* x, int32_t* pos_tab, uint8_t* act_tab, int d, float eps, hipStream_t s) {
-    hipLaunchKernelGGL(k_pf_rows_rmsnorm, dim3(Tc * Mpad), dim3(256), 0, s, rows, lens, Lmax, t0, batch, Mpad, wnorm, h, x, pos_tab, act_tab, d, eps);
+void launch_pf_rows_rmsnorm(const bf16_t* rows, int src_rows, const int32_t* lens, int Lmax, int t0, int Tc, int batch, int Mpad, const bf16_t* wnorm,
+                            bf16_t* h, bf16_t* x, int32_t* pos_tab, uint8_t* act_tab, int d, float eps, hipStream_t s) {
+    hipLaunchKernelGGL(k_pf_rows_rmsnorm, dim3(Tc * Mpad), dim3(256), 0, s, rows, src_rows, lens, Lmax, t0, batch, Mpad, wnorm, h, x, pos_tab, act_tab, d, eps);
 }
 void launch_pf_rmsnorm(const bf16_t* h, const bf16_t* wnorm, bf16_t* x, int rows, int d, float eps, hipStream_t s) {
     hipLaunchKernelGGL(k_pf_rmsnorm, dim3(rows), dim3(256), 0, s, h, wnorm, x, d, eps);
+}
+// h = T(h + T(part)): the residual add behind a GEMM that wrote float32 sums (quantised roles run the decode step's code-streaming
+// kernel on 64-row chunks; same rounding points as the PF_RESID epilogue and the decode step's glue)
+__global__ void k_pf_add_resid(bf16_t* __restrict__ h, const float* __restrict__ part, size_t n) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) h[i] = f32_to_bf16(bf16_to_f32(h[i]) + bf16_round_f32(part[i]));
+}
+void launch_pf_add_resid(bf16_t* h, const float* part, size_t n, hipStream_t s) {
+    hipLaunchKernelGGL(k_pf_add_resid, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, h, part, n);
 }
 void launch_pf_pack_rows(const bf16_t* rows, bf16_t* xpk, int Mpad, int d, hipStream_t s) {
     hipLaunchKernelGGL(k_pf_pack_rows, dim3(Mpad), dim3(256), 0, s, rows, xpk, d, Mpad / 16);

@@ -148,3 +148,51 @@ def test_quantised_role_with_a_per_layer_override_falls_back_to_the_dense_copy()
     rng = np.random.default_rng(1)
     rows = [rng.integers(0, CFG.vocab_size, n).astype(np.int32) for n in (9, 5)]
     _check(teacher_forced(ollama.LlamaOracle(CFG, Wd, round="bf16"), m, rows))
+
+
+@pytest.mark.parametrize("bits", [8, 4])
+def test_batched_prefill_on_code_streamed_weights(bits, monkeypatch):
+    """`model(inputIds, cache:)` on a quantised checkpoint: the [positions x rows] pass runs k_gemm_skinny_q on 64-row slices (packed
+    rows in, float32 sums out, residual add behind it) instead of falling back to one position at a time.  Against the float32-dequant
+    oracle (quantizedMatmul's arithmetic) and against the position-by-position path; a decode step continues behind it.  Ragged rows,
+    7 rows x up to 30 positions = 480 (position, row) pairs: seven 64-row slices and one of 32."""
+    from gpu_util import logits_errors, record
+    W = ollama.make_synthetic_weights(QCFG, seed=99)
+    m = mas.LlamaTTSModel(lm_host_config(QCFG))
+    W32 = {}
+    for k, v in W.items():
+        if v.ndim == 2:
+            wq, s, bia = mq.quantize(v.float().numpy(), 64, bits)
+            s16, b16 = torch.from_numpy(s).bfloat16(), torch.from_numpy(bia).bfloat16()
+            m.set_quantized_tensor(k, wq, s16, b16, 64, bits)
+            d32 = torch.from_numpy(mq.dequantize(wq, s16.float().numpy(), b16.float().numpy(), 64, bits))
+            W32[k] = d32.bfloat16() if k == "model.embed_tokens.weight" else d32
+        else:
+            m.set_tensor(k, v); W32[k] = v
+    m.finalize()
+    assert m.native_quant_bits["qkv"] == bits
+    oracle = ollama.LlamaOracle(QCFG, W32, round="bf16")
+    rng = np.random.default_rng(5)
+    lens = [30, 1, 17, 29, 2, 8, 23]
+    rows = [rng.integers(0, QCFG.vocab_size, n).astype(np.int32) for n in lens]
+    nxt = rng.integers(0, QCFG.vocab_size, len(rows)).astype(np.int32)
+    monkeypatch.setenv("MIS_PREFILL_SEQ", "0")
+    got = m.lm_prefill(rows, max_context=64)
+    got2 = m.lm_forward(nxt)
+    monkeypatch.setenv("MIS_PREFILL_SEQ", "1")
+    seq = m.lm_prefill(rows, max_context=64)
+    seq2 = m.lm_forward(nxt)
+    oracle.reset(len(rows))
+    ref_all = oracle.forward([np.concatenate([r, nxt[i:i + 1]]) for i, r in enumerate(rows)], logit_positions=[[len(r) - 1, len(r)] for r in rows])
+    e_all, d_all, m_all = [], [], []
+    for b in range(len(rows)):
+        ref = ref_all[b].numpy()
+        for dv, sq, rf in ((got[b], seq[b], ref[0]), (got2[b], seq2[b], ref[1])):
+            e_max, e_rms, _, agree = logits_errors(dv[None], rf[None])
+            assert e_max <= 0.016 and agree, (b, e_max)
+            e_all.append(e_rms); m_all.append(e_max)
+            d_all.append(float(np.sqrt(np.mean((dv - sq) ** 2)) / np.sqrt(np.mean(sq ** 2))))
+    record(f"batched_prefill_{bits}bit_codes", logits_max_rel=max(m_all), logits_rms_rel_worst=max(e_all), logits_rms_rel_mean=float(np.mean(e_all)),
+           rms_vs_sequential_worst=max(d_all), tol_max=0.016, tol_rms_mean=0.008, tol_rms_worst=0.016)
+    assert np.mean(e_all) <= 0.008 and np.max(e_all) <= 0.016, (np.mean(e_all), np.max(e_all))
+    assert np.mean(d_all) <= 0.008 and np.max(d_all) <= 0.016, (np.mean(d_all), np.max(d_all))

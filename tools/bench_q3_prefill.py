@@ -9,9 +9,15 @@ import mlx_audio_swift_amd as mas
 from mlx_audio_swift_amd.synthetic import qwen3tts_synthetic_weights
 
 cfg = mas.Qwen3TTSConfiguration(codec_eos_token_id=3071)
+BITS = int(sys.argv[1]) if len(sys.argv) > 1 else 16          # 16 = bf16 weights, 8 / 4 = every 2-D talker tensor MLX affine-quantised
 m = mas.Qwen3TTSModel(cfg)
 for name, arr in qwen3tts_synthetic_weights(cfg):
-    m.set_tensor(name, arr)
+    if BITS != 16 and arr.ndim == 2 and not name.startswith("decoder.") and arr.shape[1] % 64 == 0:
+        from mlx_audio_swift_amd.synthetic import mlx_affine_quantize
+        wq, sc, bi = mlx_affine_quantize(arr, 64, BITS)
+        m.set_quantized_tensor(name, wq, sc, bi, 64, BITS)
+    else:
+        m.set_tensor(name, arr)
 m.finalize()
 rng = np.random.default_rng(3)
 gp = mas.Qwen3TTSGenerateParameters(max_tokens=2, temperature=0.0)
@@ -34,4 +40,5 @@ for B, P in ((1, 350), (1, 40), (32, 40), (8, 350)):
         res["sequential_ms" if mode == "1" else "batched_ms"] = round(min(ts) * 1e3, 2)
         res["codes_" + mode] = [int(x) for x in codes[0][0][:4]]
     out[f"batch{B}_prompt{P}"] = res
+out["weights_bits"] = BITS
 print(json.dumps(out))
