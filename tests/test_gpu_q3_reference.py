@@ -255,3 +255,25 @@ def test_in_context_prompt_prefill_frames_and_tail():
     dev.clear_references()
     with pytest.raises(mas.AudioGenerationError):
         dev.generate_codes([p], gp)                                               # its rows are gone
+
+
+def test_in_context_rows_sharded_over_two_replicas_equal_the_single_handle():
+    """mis_qwen3tts_group_generate with in-context prompts: the reference contexts of the first model are registered on every replica in
+    the same order (Qwen3TTSModel._sync_references), each replica decodes [reference codes | generated] for its own rows.  Two replicas
+    on one GPU (same weights), three rows: in-context, plain, in-context with a second recording."""
+    dev, orc, odec, Ws, We = _model()
+    dev2, *_ = _model()
+    dev.tokenizer = _Tok()
+    xa, xb = _audio(4000, 21, 240.0), _audio(4100, 22, 240.0)
+    pa = dev.prepare_icl_generation_inputs("Hello there", xa, "ref words", "auto")
+    pq = dev.prepare_generation_inputs("Hello there", "auto", None)
+    pb = dev.prepare_icl_generation_inputs("Other words", xb, "second ref", "auto")
+    assert pb.reference is not pa.reference and pb.reference.first_frame_row > pa.reference.first_frame_row
+    gp = mas.Qwen3TTSGenerateParameters(max_tokens=5, temperature=0.8, top_k=20, seed=5)
+    one, c1 = dev.generate_batch([pa, pq, pb], gp, return_codes=True)
+    two, c2 = dev.generate_batch([pa, pq, pb], gp, return_codes=True, replicas=[dev, dev2])
+    assert len(dev2._ref_log) == len(dev._ref_log) == 2
+    for r in range(3):
+        assert np.array_equal(c1[r], c2[r]) and np.array_equal(one[r], two[r]), r
+    up = dev.samples_per_frame
+    assert len(one[1]) == len(c1[1]) * up or len(c1[1]) == 0       # the plain row is decoded on its own codes only
