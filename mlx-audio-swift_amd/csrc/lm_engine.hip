@@ -537,7 +537,10 @@ static void lm_reset(mis_tts* c, int batch, int max_context) {
     const int d = c->d, HD = c->H * c->D;
     c->ksb_part = env_int("MIS_KSB_PART", 4) == 1 ? 1 : 4;
     c->ksb_gu = env_int("MIS_KSB_GU", 4) == 1 ? 1 : 4;
-    c->ksb_head = env_int("MIS_KSB_HEAD", 1) == 4 ? 4 : 1;
+    // output projection: a big vocabulary fills the chip with one wave per tile pair (Orpheus: 4904 pairs); a codec-sized one (Qwen3-TTS
+    // 2048 / 3072 ids, Soprano) has 64-96 pairs = 16-24 blocks, each wave walking the whole K range alone: there the four waves of a
+    // block split K (10.1 -> see profiles/r03/q3_small_kernels.json).  MIS_KSB_HEAD = 1 / 4 forces one.
+    c->ksb_head = getenv("MIS_KSB_HEAD") ? (env_int("MIS_KSB_HEAD", 1) == 4 ? 4 : 1) : (c->Vpad / 32 < 1024 ? 4 : 1);
     c->r_part = env_int("MIS_R_PART", 2) == 1 ? 1 : 2;
     c->S_qkv = std::min(8, choose_split(c->Nqkv / 16 / c->r_part, d / 32, c->ksb_part, "MIS_S_QKV", 8));   // attention prologue: <= 8 slabs
     c->S_o = choose_split(d / 16 / c->r_part, HD / 32, c->ksb_part, "MIS_S_O");

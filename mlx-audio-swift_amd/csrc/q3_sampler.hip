@@ -1,6 +1,6 @@
-// q3_sampler.hip - Qwen3-TTS `sampleToken` (Qwen3TTS.swift:1003-1118) on the device, one 1024-thread block per row.
+// q3_sampler.hip - Qwen3-TTS `sampleToken` (Qwen3TTS.swift:1003-1118) on the device, one 256-thread block per row.
 //
-// The codec vocabularies are small (talker 3072, code predictor 2048), so a row's logits live in registers (4 per thread)
+// The codec vocabularies are small (talker 3072, code predictor 2048), so a row's logits live in registers (16 per thread)
 // and every selection step is a 256-bin radix pass over the 16-bit order-preserving key of the bf16 logit - exact, because a
 // bf16 value IS its 16-bit key.  Specification: oracle/qwen3tts.py::sample_token (deterministic realisation of the
 // reference's set semantics; the categorical draw is the inverse CDF on fixed-point masses of "mis-sampler-v1").
@@ -10,8 +10,8 @@
 #include "q3_kernels.h"
 
 typedef unsigned long long u64;
-#define Q3S_NT 1024
-#define Q3S_PER 4
+#define Q3S_NT 256                 // four waves: a block barrier among 4 waves costs a fraction of one among 16 (the kernel is a chain of ~25 of them)
+#define Q3S_PER 16
 #define E_SCALE 1099511627776.0f
 
 __device__ __forceinline__ float q3_det_exp(float y) {
@@ -37,18 +37,32 @@ __device__ __forceinline__ unsigned q3_key(float v) {          // order-preservi
     return (u & 0x8000u) ? (~u & 0xFFFFu) : (u | 0x8000u);
 }
 
-// inclusive scan over 256 bins (value of bin t given by threads t < 256); result left in sh[0..255]
-__device__ __forceinline__ void q3_scan256(u64 v, u64* sh) {
-    const int tid = threadIdx.x;
-    if (tid < 256) sh[tid] = v;
-    __syncthreads();
-    for (int o = 1; o < 256; o <<= 1) {
-        u64 t = (tid < 256 && tid >= o) ? sh[tid - o] : 0;
-        __syncthreads();
-        if (tid < 256) sh[tid] += t;
-        __syncthreads();
+// inclusive scan inside a wave (integer sums: exact whatever the order).  Every lane of the wave must call it.
+__device__ __forceinline__ u64 q3_wave_scan(u64 v) {
+    const int lane = threadIdx.x & 63;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const u64 t = __shfl_up(v, o, 64);
+        if (lane >= o) v += t;
     }
+    return v;
 }
+// inclusive scan over the first `n_waves` waves of the block (n_waves * 64 values, one per thread; other threads pass 0); result left in
+// sh[0 .. 64 n_waves).  Wave-level shuffles + one exchange of the wave totals: two barriers instead of two per doubling step (the
+// 256-bin and 1024-entry Hillis-Steele scans were ~60 of the kernel's ~80 block barriers, 14.9 us per launch, 16 launches per frame)
+__device__ __forceinline__ void q3_scan_waves(u64 v, u64* sh, u64* part, int n_waves) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const u64 s = q3_wave_scan(wave < n_waves ? v : 0);
+    if (wave < n_waves && lane == 63) part[wave] = s;
+    __syncthreads();
+    if (wave < n_waves) {
+        u64 off = 0;
+        for (int w = 0; w < wave; ++w) off += part[w];
+        sh[tid] = s + off;
+    }
+    __syncthreads();
+}
+__device__ __forceinline__ void q3_scan256(u64 v, u64* sh, u64* part) { q3_scan_waves(v, sh, part, 4); }
 
 // smallest bin index with sh[bin] > thr (sh ascending inclusive prefix); 256 if none.  All threads get the result.
 __device__ __forceinline__ int q3_first_above(const u64* sh, u64 thr, int* slot) {
@@ -65,6 +79,7 @@ __device__ __forceinline__ int q3_first_above(const u64* sh, u64 thr, int* slot)
 __global__ void __launch_bounds__(Q3S_NT) k_q3_sample(Q3SampleArgs a) {
     __shared__ u64 sh[Q3S_NT];
     __shared__ u64 hist[256];
+    __shared__ u64 part[Q3S_NT / 64];
     __shared__ float redf[Q3S_NT / 64];
     __shared__ int redi[Q3S_NT / 64];
     __shared__ int slot;
@@ -127,7 +142,7 @@ __global__ void __launch_bounds__(Q3S_NT) k_q3_sample(Q3SampleArgs a) {
             for (int e = 0; e < Q3S_PER; ++e)
                 if (tid * Q3S_PER + e < a.V) atomicAdd(&hist[255 - (q3_key(l[e]) >> 8)], 1ull);
             __syncthreads();
-            q3_scan256(tid < 256 ? hist[tid] : 0, sh);
+            q3_scan256(tid < 256 ? hist[tid] : 0, sh, part);
             int r1 = q3_first_above(sh, (u64)a.top_k - 1, &slot);      // first reversed bin whose cumulative count >= k
             u64 above = (r1 > 0 && r1 < 256) ? sh[r1 - 1] : 0;
             __syncthreads();
@@ -140,7 +155,7 @@ __global__ void __launch_bounds__(Q3S_NT) k_q3_sample(Q3SampleArgs a) {
                 if (tid * Q3S_PER + e < a.V && (k >> 8) == B1) atomicAdd(&hist[255 - (k & 255)], 1ull);
             }
             __syncthreads();
-            q3_scan256(tid < 256 ? hist[tid] : 0, sh);
+            q3_scan256(tid < 256 ? hist[tid] : 0, sh, part);
             int r2 = q3_first_above(sh, (u64)a.top_k - 1 - above, &slot);
             const unsigned kth = (B1 << 8) | (255u - (unsigned)r2);
 #pragma unroll
@@ -164,7 +179,7 @@ __global__ void __launch_bounds__(Q3S_NT) k_q3_sample(Q3SampleArgs a) {
             for (int e = 0; e < Q3S_PER; ++e)
                 if (E[e]) atomicAdd(&hist[q3_key(l[e]) >> 8], E[e]);
             __syncthreads();
-            q3_scan256(tid < 256 ? hist[tid] : 0, sh);
+            q3_scan256(tid < 256 ? hist[tid] : 0, sh, part);
             const u64 Z = sh[255];
             const u64 thr = (u64)((double)(1.0f - a.top_p) * (double)Z);
             int b1 = q3_first_above(sh, thr, &slot);
@@ -178,7 +193,7 @@ __global__ void __launch_bounds__(Q3S_NT) k_q3_sample(Q3SampleArgs a) {
                 if (E[e] && (int)(k >> 8) == b1) atomicAdd(&hist[k & 255], E[e]);
             }
             __syncthreads();
-            q3_scan256(tid < 256 ? hist[tid] : 0, sh);
+            q3_scan256(tid < 256 ? hist[tid] : 0, sh, part);
             int b2 = q3_first_above(sh, thr - below, &slot);
             const unsigned kstar = ((unsigned)b1 << 8) | (unsigned)(b2 & 255);
 #pragma unroll
@@ -211,14 +226,7 @@ __global__ void __launch_bounds__(Q3S_NT) k_q3_sample(Q3SampleArgs a) {
             E[e] = (tid * Q3S_PER + e < a.V) ? (u64)(ee * E_SCALE) : 0;
             loc += E[e];
         }
-        sh[tid] = loc;
-        __syncthreads();
-        for (int o = 1; o < Q3S_NT; o <<= 1) {
-            u64 t = (tid >= o) ? sh[tid - o] : 0;
-            __syncthreads();
-            sh[tid] += t;
-            __syncthreads();
-        }
+        q3_scan_waves(loc, sh, part, Q3S_NT / 64);
         const u64 Z = sh[Q3S_NT - 1];
         const u64 row = (u64)(a.row_offset + b);
         const u64 step = (u64)(*a.frame) * (u64)a.G + (u64)a.slot;

@@ -159,20 +159,24 @@ struct Q3NextArgs {
 // end of a frame: store the 16 codes, next input = text + codec_emb(code0) + sum_i pred_emb[i](code_{i+1}) with one bf16
 // rounding per add in the reference's order (Qwen3TTS.swift:464-480)
 __global__ void k_q3_next_input(Q3NextArgs a) {
+    __shared__ int cs[32];
     const int b = blockIdx.x;
     if (!a.active_a[b]) return;
     const int f = a.n_frames[b];
     const int t = (f < a.trail_len[b]) ? a.trail_idx[(size_t)b * a.Tt + f] : a.pad_row;
+    // the frame's codes once into LDS (clamped like the table lookups): the sums below then issue their G table reads back to back
+    // instead of re-reading the code before every add (26 -> see profiles/r03/q3_small_kernels.json)
+    if (threadIdx.x < a.G) {
+        const int raw = a.cur_codes[(size_t)threadIdx.x * a.Mpad + b];
+        cs[threadIdx.x] = min(raw, (threadIdx.x == 0 ? a.Vc : a.Vp) - 1);
+        a.codes[((size_t)b * a.max_frames + f) * a.G + threadIdx.x] = raw;
+    }
+    __syncthreads();
     for (int k = threadIdx.x; k < a.d; k += blockDim.x) {
-        int c0 = a.cur_codes[b];
-        float e = bf16_to_f32(a.codec_emb[(size_t)min(c0, a.Vc - 1) * a.d + k]);
-        for (int i = 0; i + 1 < a.G; ++i) {
-            int ci = min(a.cur_codes[(size_t)(i + 1) * a.Mpad + b], a.Vp - 1);
-            e = bf16_round_f32(e + bf16_to_f32(a.pred_emb[i][(size_t)ci * a.d + k]));
-        }
+        float e = bf16_to_f32(a.codec_emb[(size_t)cs[0] * a.d + k]);
+        for (int i = 0; i + 1 < a.G; ++i) e = bf16_round_f32(e + bf16_to_f32(a.pred_emb[i][(size_t)cs[i + 1] * a.d + k]));
         a.in_emb[(size_t)b * a.d + k] = f32_to_bf16(bf16_to_f32(a.tproj[(size_t)t * a.d + k]) + e);
     }
-    if (threadIdx.x < a.G) a.codes[((size_t)b * a.max_frames + f) * a.G + threadIdx.x] = a.cur_codes[(size_t)threadIdx.x * a.Mpad + b];
     if (threadIdx.x == 0) {
         a.n_frames[b] = f + 1;
         if (f + 1 >= a.row_max[b]) {                               // `for step in 0 ..< effectiveMaxTokens` (:412)
