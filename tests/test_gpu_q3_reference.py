@@ -277,3 +277,78 @@ def test_in_context_rows_sharded_over_two_replicas_equal_the_single_handle():
         assert np.array_equal(c1[r], c2[r]) and np.array_equal(one[r], two[r]), r
     up = dev.samples_per_frame
     assert len(one[1]) == len(c1[1]) * up or len(c1[1]) == 0       # the plain row is decoded on its own codes only
+
+
+class _WordTok:
+    """the reference fixture's tokenizer (Tests/MLXAudioTTSTests.swift:546-612): lower-cased whitespace words over an 18-entry vocabulary"""
+    vocab = {"<bos>": 0, "<pad>": 1, "<eos>": 2, "<unk>": 3, "<|im_start|>": 4, "<|im_end|>": 5, "assistant": 6, "user": 7, "one": 8, "two": 9,
+             "three": 10, "four": 11, "five": 12, "target": 13, "voice": 14, "prompt": 15, "sample": 16, "english": 17}
+
+    def encode(self, s):
+        import re
+        return [self.vocab.get(w, 3) for w in re.findall(r"<\|im_start\|>|<\|im_end\|>|[a-z0-9]+", s.lower())]
+
+
+def _reference_fixture(tts_model_type, include_speech_encoder, spk_id=None):
+    """makeTinyQwen3TTSModel (Tests/MLXAudioTTSTests.swift:615-687) at widths the engine takes (hidden 256 instead of 16): 3072 / 2048
+    vocabularies, two code groups, encoder_valid_num_quantizers 2, the default Mimi encoder config when `encoder_config` is present"""
+    import dataclasses
+    ocfg = oq.Qwen3TTSConfig(
+        talker=dataclasses.replace(oq.TINY.talker, vocab_size=3072), predictor=dataclasses.replace(oq.TINY.predictor, vocab_size=2048, num_hidden_layers=1),
+        num_code_groups=2, text_hidden_size=128, text_vocab_size=64, codec_eos_token_id=3050, codec_think_id=3051, codec_nothink_id=3052,
+        codec_think_bos_id=3053, codec_think_eos_id=3054, codec_pad_id=3055, codec_bos_id=3056, tts_pad_token_id=21, tts_bos_token_id=22,
+        tts_eos_token_id=23, decoder=dataclasses.replace(oq.TINY.decoder, codebook_size=2048, num_quantizers=2))
+    hc = _host_cfg(ocfg)
+    hc.codec_language_id = {"english": 3057}
+    hc.tts_model_type = tts_model_type
+    hc.spk_id = spk_id
+    W = oq.make_synthetic_weights(ocfg)
+    allw = {("talker." + k): v for k, v in W.items()}
+    allw.update(oq.make_synthetic_decoder_weights(ocfg.decoder))
+    if include_speech_encoder:
+        enc = om.MimiEncoderConfig(valid_num_quantizers=2)
+        hc.tokenizer_encoder = _enc_host(enc)
+        hc.encoder_valid_num_quantizers = 2
+        allw.update({"encoder_model." + k: v for k, v in om.make_synthetic_weights(enc).items()})
+    dev = mas.Qwen3TTSModel.from_weights(hc, allw)
+    dev.tokenizer = _WordTok()
+    return dev
+
+
+def test_reference_conditioning_pins_of_the_reference_test_suite():
+    """The reference's own Qwen3TTS suite (Tests/MLXAudioTTSTests.swift:936-1084) pins shapes and control flow, not numbers; the same pins
+    here: prepareReferenceConditioning on a voice_design model with a speech encoder (no speaker vector, codes [2, T > 0], reference text
+    ids, "english" -> codec language id 3057), generate from the prepared conditioning and through the raw refAudio / refText arguments,
+    direct and streaming (tokens > 0, one info, audio 1-D), and a custom_voice model without an encoder refusing reference conditioning."""
+    import wave
+    with wave.open("tests/golden/intention.wav", "rb") as w:
+        pcm = np.frombuffer(w.readframes(w.getnframes()), np.int16).astype(np.float32) / 32768.0
+    ref_audio = np.ascontiguousarray(pcm[:24000])                                   # loadTTSNetworkFixture(sampleRate: 24_000, maxSamples: 24_000)
+    dev = _reference_fixture("voice_design", True)
+    ctx, ref_ids, lang_id = dev.prepare_reference_conditioning(ref_audio, "one two three four five one two three four five", "English")
+    assert ctx.speaker_embedding is None and ctx.speaker_row == -1                  # #expect(conditioning.speakerEmbedding == nil)
+    assert ctx.codes.ndim == 2 and ctx.codes.shape[0] == 2 and ctx.codes.shape[1] > 0
+    assert ctx.codes.shape[1] == -(-(-(-24000 // 960)) // 2)                        # 12.5 Hz: 13 frames of one second
+    assert len(ref_ids) > 0 and lang_id == 3057                                     # resolvedLanguage "english" -> codecLanguageID 3057
+    gp = mas.Qwen3TTSGenerateParameters(max_tokens=2, temperature=0.7, top_p=0.95, repetition_penalty=1.0)
+    text = "target voice prompt one two three four five"
+    p = dev.prepare_icl_generation_inputs(text, conditioning=(ctx, ref_ids, lang_id))
+    assert p.codec_ids.tolist()[3:8] == [3051, 3053, 3057, 3054, 3055]               # think prefix with the language id, no speaker position
+    audio = dev.generate_batch([p], gp)[0]
+    assert audio.ndim == 1 and audio.shape[0] > 0
+    ev = list(dev.generate_stream_batch([p], gp, streaming_interval=0.05))
+    assert sum(isinstance(e, mas.TokenEvent) for e in ev) > 0 and sum(isinstance(e, mas.InfoEvent) for e in ev) == 1
+    last = [e for e in ev if isinstance(e, mas.AudioEvent)][-1]
+    assert last.audio.ndim == 1
+    raw = dev.generate(text, voice=None, ref_audio=ref_audio, ref_text="one two three four five one two three four five", language="English",
+                       generation_parameters=gp)
+    assert raw.ndim == 1 and raw.shape[0] > 0
+    ev2 = list(dev.generate_stream(text, None, "English", gp, 0.05, ref_audio=ref_audio, ref_text="one two three four five one two three four five"))
+    assert sum(isinstance(e, mas.TokenEvent) for e in ev2) > 0 and sum(isinstance(e, mas.InfoEvent) for e in ev2) == 1
+    # customVoiceRemainsSeparateFromReferenceConditioning (:1050-1084)
+    cv = _reference_fixture("custom_voice", False, spk_id={"ryan": 100})
+    out = cv.generate(text, voice="ryan", language="English", generation_parameters=gp)
+    assert out.ndim == 1 and out.shape[0] > 0
+    with pytest.raises(mas.AudioGenerationError) as e:
+        cv.prepare_reference_conditioning(ref_audio, "one two three four five one two three four five", "English")
+    assert e.value.case == "invalidInput"
