@@ -350,9 +350,12 @@ __global__ void __launch_bounds__(RR_THREADS) k_reduce_residual_rmsnorm(const fl
 // The RMSNorm case again with FOUR consecutive columns per thread (N / 4 <= 1024 threads, single pass): one float4 per slab, one
 // 8-byte load each for h and the norm weight, 8-byte stores (four consecutive columns are half of a 16-byte unit of the packed
 // operand layout) - S + 2 load instructions per thread instead of 3 S + 6, and 12 waves per row instead of 16 at d = 3072.
-template <int SG>
+// LN = true: LayerNorm with weight and bias instead (Whisper, WhisperLayers.swift:90-107): float32 mean and variance over the row (two
+// block sums), one rounding at the output - the arithmetic of k_reduce_residual_rmsnorm's ln_bias branch.
+template <int SG, bool LN>
 __global__ void __launch_bounds__(1024) k_glue4(const float* __restrict__ slabs, int S, int Mpad, int N, bf16_t* __restrict__ h,
-                                                const bf16_t* __restrict__ wnorm, bf16_t* __restrict__ x, float eps) {
+                                                const bf16_t* __restrict__ wnorm, bf16_t* __restrict__ x, float eps,
+                                                const bf16_t* __restrict__ ln_bias) {
     __shared__ float red[16];
     const int m = blockIdx.x, tid = threadIdx.x, nth = blockDim.x;
     const int MT = Mpad >> 4;
@@ -362,13 +365,17 @@ __global__ void __launch_bounds__(1024) k_glue4(const float* __restrict__ slabs,
     // any pin (a slab load ended up behind the wait for the others: two dependent round trips).  Volatile asm statements keep their
     // order: S + 2 loads in flight, ONE wait naming every destination, then the math.  (hipcc does not count asm loads in its own
     // s_waitcnt bookkeeping; the kernel has no other vector loads.)
-    unsigned long long hq, wq;
+    unsigned long long hq, wq, bq = 0;
     f32x4_t v[SG];
     {
         const bf16_t* hp = h + (size_t)m * N + 4 * c4;
         const bf16_t* wp = wnorm + 4 * c4;
         asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(hq) : "v"(hp));
         asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(wq) : "v"(wp));
+        if constexpr (LN) {
+            const bf16_t* bp = ln_bias + 4 * c4;
+            asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(bq) : "v"(bp));
+        }
 #pragma unroll
         for (int j = 0; j < SG; ++j) {
             const int sj = j < S ? j : S - 1;
@@ -379,6 +386,7 @@ __global__ void __launch_bounds__(1024) k_glue4(const float* __restrict__ slabs,
         else if constexpr (SG == 4) asm volatile("s_waitcnt vmcnt(0)" : "+v"(hq), "+v"(wq), "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]));
         else asm volatile("s_waitcnt vmcnt(0)" : "+v"(hq), "+v"(wq), "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]),
                           "+v"(v[6]), "+v"(v[7]));
+        if constexpr (LN) asm volatile("" : "+v"(bq));          // covered by the vmcnt(0) above (issued before it)
     }
     float acc[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -402,6 +410,41 @@ __global__ void __launch_bounds__(1024) k_glue4(const float* __restrict__ slabs,
     }
     if (live) *reinterpret_cast<uint2*>(h + (size_t)m * N + 4 * c4) =
         make_uint2((uint32_t)hb[0] | ((uint32_t)hb[1] << 16), (uint32_t)hb[2] | ((uint32_t)hb[3] << 16));
+    if constexpr (LN) {
+        float sm = 0.0f;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) sm += live ? hn[e] : 0.0f;
+        sm = wave_sum_dpp(sm);
+        if ((tid & 63) == 0) red[tid >> 6] = sm;
+        __syncthreads();
+        float tot = 0.0f;
+        const int nw = nth >> 6;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) tot += i < nw ? red[i] : 0.0f;
+        const float mean = tot / (float)N;
+        float sq = 0.0f;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { const float dl = hn[e] - mean; sq += live ? dl * dl : 0.0f; }
+        sq = wave_sum_dpp(sq);
+        __syncthreads();                                         // everyone has read the first sums
+        if ((tid & 63) == 0) red[tid >> 6] = sq;
+        __syncthreads();
+        float tq = 0.0f;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) tq += i < nw ? red[i] : 0.0f;
+        const float rstd = 1.0f / sqrtf(tq / (float)N + eps);
+        if (live) {
+            const uint32_t bq0 = (uint32_t)bq, bq1 = (uint32_t)(bq >> 32);
+            const float bv[4] = {bf16_to_f32((bf16_t)(bq0 & 0xffffu)), bf16_to_f32((bf16_t)(bq0 >> 16)), bf16_to_f32((bf16_t)(bq1 & 0xffffu)),
+                                 bf16_to_f32((bf16_t)(bq1 >> 16))};
+            bf16_t xb[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) xb[e] = f32_to_bf16((hn[e] - mean) * rstd * wv[e] + bv[e]);
+            *reinterpret_cast<uint2*>(x + xpk_index(m, 4 * c4, MT)) =
+                make_uint2((uint32_t)xb[0] | ((uint32_t)xb[1] << 16), (uint32_t)xb[2] | ((uint32_t)xb[3] << 16));
+        }
+        return;
+    }
     ss = wave_sum_dpp(ss);
     if ((tid & 63) == 0) red[tid >> 6] = ss;
     __syncthreads();
@@ -422,11 +465,17 @@ __global__ void __launch_bounds__(1024) k_glue4(const float* __restrict__ slabs,
 void launch_reduce_residual_rmsnorm(const float* slabs, int S, int Mpad, int N, bf16_t* h, const bf16_t* wnorm,
                                     bf16_t* x, float eps, hipStream_t s, const bf16_t* ln_bias) {
     static const int v4 = getenv("MIS_GLUE_V4") ? atoi(getenv("MIS_GLUE_V4")) : 1;
-    if (v4 && !ln_bias && N % 4 == 0 && N / 4 <= 1024 && S <= 8) {
+    if (v4 && N % 4 == 0 && N / 4 <= 1024 && S <= 8) {
         const int nth = ((N / 4 + 63) / 64) * 64;
-        if (S <= 2) hipLaunchKernelGGL((k_glue4<2>), dim3(Mpad), dim3(nth), 0, s, slabs, S, Mpad, N, h, wnorm, x, eps);
-        else if (S <= 4) hipLaunchKernelGGL((k_glue4<4>), dim3(Mpad), dim3(nth), 0, s, slabs, S, Mpad, N, h, wnorm, x, eps);
-        else hipLaunchKernelGGL((k_glue4<8>), dim3(Mpad), dim3(nth), 0, s, slabs, S, Mpad, N, h, wnorm, x, eps);
+        if (ln_bias) {
+            if (S <= 2) hipLaunchKernelGGL((k_glue4<2, true>), dim3(Mpad), dim3(nth), 0, s, slabs, S, Mpad, N, h, wnorm, x, eps, ln_bias);
+            else if (S <= 4) hipLaunchKernelGGL((k_glue4<4, true>), dim3(Mpad), dim3(nth), 0, s, slabs, S, Mpad, N, h, wnorm, x, eps, ln_bias);
+            else hipLaunchKernelGGL((k_glue4<8, true>), dim3(Mpad), dim3(nth), 0, s, slabs, S, Mpad, N, h, wnorm, x, eps, ln_bias);
+        } else {
+            if (S <= 2) hipLaunchKernelGGL((k_glue4<2, false>), dim3(Mpad), dim3(nth), 0, s, slabs, S, Mpad, N, h, wnorm, x, eps, ln_bias);
+            else if (S <= 4) hipLaunchKernelGGL((k_glue4<4, false>), dim3(Mpad), dim3(nth), 0, s, slabs, S, Mpad, N, h, wnorm, x, eps, ln_bias);
+            else hipLaunchKernelGGL((k_glue4<8, false>), dim3(Mpad), dim3(nth), 0, s, slabs, S, Mpad, N, h, wnorm, x, eps, ln_bias);
+        }
         return;
     }
     if (S <= 2) hipLaunchKernelGGL((k_reduce_residual_rmsnorm<2>), dim3(Mpad), dim3(RR_THREADS), 0, s, slabs, S, Mpad, N, h, wnorm, x, eps, ln_bias);
