@@ -76,8 +76,8 @@ def _tensor_args(arr):
 
 
 class SNAC:
-    """AudioCodecModel conformance (AudioCodecModel.swift:15-27): codec_sample_rate, decode_audio.
-    encode_audio (SNACDecoder.swift:120-125) is not built yet and raises audioEncodingFailed."""
+    """AudioCodecModel conformance (AudioCodecModel.swift:15-27): codec_sample_rate, encode_audio (SNACDecoder.swift:120-125, on
+    mis_snac_encode; a handle loaded without encoder tensors raises audioEncodingFailed), decode_audio."""
 
     def __init__(self, config: SNACConfig, device: int = 0, _handle=None):
         self.config = config
