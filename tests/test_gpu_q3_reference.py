@@ -321,7 +321,8 @@ def test_reference_conditioning_pins_of_the_reference_test_suite():
     ids, "english" -> codec language id 3057), generate from the prepared conditioning and through the raw refAudio / refText arguments,
     direct and streaming (tokens > 0, one info, audio 1-D), and a custom_voice model without an encoder refusing reference conditioning."""
     import wave
-    with wave.open("tests/golden/intention.wav", "rb") as w:
+    import os
+    with wave.open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "intention.wav"), "rb") as w:
         pcm = np.frombuffer(w.readframes(w.getnframes()), np.int16).astype(np.float32) / 32768.0
     ref_audio = np.ascontiguousarray(pcm[:24000])                                   # loadTTSNetworkFixture(sampleRate: 24_000, maxSamples: 24_000)
     dev = _reference_fixture("voice_design", True)
