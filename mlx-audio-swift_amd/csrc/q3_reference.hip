@@ -491,7 +491,9 @@ void q3ref_speaker(mis_q3ref* r, const float* audio, int64_t n, int stage, float
     mc.sample_rate = cf.spk_sample_rate; mc.n_fft = 1024; mc.hop_length = 256; mc.n_mels = cf.spk_mel_dim;
     mc.window = 1; mc.mel_scale = 0; mc.slaney_norm = 1; mc.drop_last_frame = 0;           // computeMelSpectrogram defaults (DSP.swift:230-273)
     const int T = (int)mis_mel_num_frames(&mc, n);
-    MIS_REQUIRE(T >= 16, MIS_ERR_INVALID_INPUT, "reference audio too short for the speaker encoder (%d mel frames)", T);
+    int max_pad = 0;                                                            // reflectPad1D needs pad < frames (:6-16 clamps; here: refuse)
+    for (int i = 0; i < cf.spk_n_blocks; ++i) max_pad = std::max(max_pad, (cf.spk_kernel_sizes[i] - 1) * cf.spk_dilations[i] / 2);
+    MIS_REQUIRE(T >= 16 && T > max_pad, MIS_ERR_INVALID_INPUT, "reference audio too short for the speaker encoder (%d mel frames)", T);
     const int nb = cf.spk_n_blocks, Cl = cf.spk_channels[nb - 1];
     int Cmax = std::max(cf.spk_mel_dim, 3 * Cl);
     for (int i = 0; i < nb; ++i) Cmax = std::max(Cmax, cf.spk_channels[i]);
@@ -554,7 +556,7 @@ void q3ref_speaker(mis_q3ref* r, const float* audio, int64_t n, int stage, float
 void q3ref_encode(mis_q3ref* r, const float* audio, int64_t n, int stage, float* out, int64_t capacity, int* oC, int64_t* oT,
                   std::vector<int32_t>* codes, int* n_q) {
     MIS_REQUIRE(r && r->finalized && r->has_enc, MIS_ERR_NOT_INITIALIZED, "this speech tokenizer has no encoder (encoder_config missing)");
-    MIS_REQUIRE(audio && n >= 1 && n <= ((int64_t)1 << 26), MIS_ERR_INVALID_INPUT, "bad reference audio length");
+    MIS_REQUIRE(audio && n >= 1 && n <= ((int64_t)1 << 25), MIS_ERR_INVALID_INPUT, "bad reference audio length (1 .. 2^25 samples)");
     HIP_CHECK(hipSetDevice(r->device));
     const mis_qwen3tts_reference_config& cf = r->cfg;
     hipStream_t s = r->s;
