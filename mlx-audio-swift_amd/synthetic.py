@@ -249,3 +249,78 @@ def mlx_affine_quantize(w, group_size: int = 64, bits: int = 8):
     for j in range(epw):
         words |= q[:, j::epw] << np.uint32(bits * j)
     return words, torch.from_numpy(scales).bfloat16(), torch.from_numpy(biases).bfloat16()
+
+
+def qwen3tts_reference_synthetic_weights(cfg, seed: int = 717):
+    """Synthetic checkpoint tensors of the in-context voice-cloning front end in the engine's key layout (`speaker_encoder.*` as
+    Qwen3TTSSpeakerEncoder.sanitize leaves them, `encoder_model.*` as Qwen3TTSSpeechTokenizer.sanitize does): for benches and tools.
+    cfg: Qwen3TTSConfiguration with speaker_encoder / tokenizer_encoder set.  Yields (name, float32 array)."""
+    key = [seed * 100000]
+
+    def t(shape, amp):
+        key[0] += 1
+        return synth_tensor(key[0], shape, amp)
+
+    def conv(p, co, k, ci, bias=True, gain=1.0):
+        yield p + ".weight", t((co, k, ci), gain * math.sqrt(3.0 / (k * ci)))
+        if bias:
+            yield p + ".bias", t((co,), 0.05)
+    sp = cfg.speaker_encoder
+    if sp is not None:
+        ch, ks = sp.enc_channels, sp.enc_kernel_sizes
+        P = "speaker_encoder."
+        yield from conv(P + "blocks.0.conv", ch[0], ks[0], sp.mel_dim, gain=1.5)
+        for i in range(1, len(ch) - 1):
+            p = f"{P}blocks.{i}"
+            w = ch[i] // sp.enc_res2net_scale
+            yield from conv(p + ".tdnn1.conv", ch[i], 1, ch[i - 1], gain=1.5)
+            for j in range(sp.enc_res2net_scale - 1):
+                yield from conv(f"{p}.res2net_block.blocks.{j}.conv", w, ks[i], w, gain=1.5)
+            yield from conv(p + ".tdnn2.conv", ch[i], 1, ch[i], gain=1.5)
+            yield from conv(p + ".se_block.conv1", sp.enc_se_channels, 1, ch[i])
+            yield from conv(p + ".se_block.conv2", ch[i], 1, sp.enc_se_channels)
+        yield from conv(P + "mfa.conv", ch[-1], ks[-1], ch[-1], gain=1.5)
+        yield from conv(P + "asp.tdnn.conv", sp.enc_attention_channels, 1, 3 * ch[-1])
+        yield from conv(P + "asp.conv", ch[-1], 1, sp.enc_attention_channels, gain=2.0)
+        yield from conv(P + "fc", sp.enc_dim, 1, 2 * ch[-1])
+    en = cfg.tokenizer_encoder
+    if en is not None:
+        P = "encoder_model."
+        nf, mult = en.num_filters, 1
+        yield from conv(P + "encoder.init_conv1d.conv.conv", nf, en.kernel_size, en.audio_channels, gain=2.0)
+        for li, ratio in enumerate(reversed(en.upsampling_ratios)):
+            p = f"{P}encoder.layers.{li}"
+            dim = mult * nf
+            for ri in range(en.num_residual_layers):
+                yield from conv(f"{p}.residuals.{ri}.block.0.conv.conv", dim // en.compress, en.residual_kernel_size, dim, gain=1.3)
+                yield from conv(f"{p}.residuals.{ri}.block.1.conv.conv", dim, 1, dim // en.compress, gain=0.7)
+                if en.use_conv_shortcut:
+                    yield from conv(f"{p}.residuals.{ri}.shortcut.conv.conv", dim, 1, dim)
+            yield from conv(p + ".downsample.conv.conv", 2 * dim, 2 * ratio, dim, gain=1.3)
+            mult *= 2
+        D, I = en.hidden_size, en.intermediate_size
+        yield from conv(P + "encoder.final_conv1d.conv.conv", D, en.last_kernel_size, mult * nf, gain=1.3)
+        for li in range(en.num_hidden_layers):
+            p = f"{P}encoder_transformer.transformer.layers.{li}"
+            for nm in ("norm1", "norm2"):
+                yield f"{p}.{nm}.weight", (1.0 + t((D,), 0.2)).astype(np.float32)
+                yield f"{p}.{nm}.bias", t((D,), 0.1)
+            yield p + ".self_attn.in_proj.weight", t((3 * D, D), math.sqrt(3.0 / D))
+            yield p + ".self_attn.out_proj.weight", t((D, D), math.sqrt(3.0 / D))
+            yield p + ".gating.linear1.weight", t((I, D), math.sqrt(3.0 / D))
+            yield p + ".gating.linear2.weight", t((D, I), math.sqrt(3.0 / I))
+            yield p + ".layer_scale_1.scale", (0.3 + t((D,), 0.1)).astype(np.float32)
+            yield p + ".layer_scale_2.scale", (0.3 + t((D,), 0.1)).astype(np.float32)
+        ds = max(1, int((en.sampling_rate / float(np.prod(en.upsampling_ratios))) / en.frame_rate))
+        yield from conv(P + "downsample.conv.conv.conv", D, 2 * ds, D, bias=False)
+        keep = min(cfg.encoder_valid_num_quantizers, en.num_quantizers)
+        for grp, nq in (("rvq_first", 1), ("rvq_rest", max(keep - 1, 0))):
+            p = f"{P}quantizer.{grp}"
+            if nq == 0:
+                continue
+            yield p + ".input_proj.weight", t((en.codebook_dim, 1, D), math.sqrt(3.0 / D))
+            for i in range(nq):
+                q = f"{p}.vq.layers.{i}.codebook"
+                usage = (1.0 + np.abs(t((en.codebook_size,), 1.0))).astype(np.float32)
+                yield q + ".cluster_usage", usage
+                yield q + ".embedding_sum", (t((en.codebook_size, en.codebook_dim), 1.0 / (i + 1)) * usage[:, None]).astype(np.float32)
