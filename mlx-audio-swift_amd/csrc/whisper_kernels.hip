@@ -260,8 +260,53 @@ __global__ void __launch_bounds__(256) k_layernorm(const bf16_t* __restrict__ x,
     for (int i = threadIdx.x; i < d; i += 256)
         y[row * d + i] = f32_to_bf16((bf16_to_f32(xr[i]) - mean) * rstd * bf16_to_f32(w[i]) + bf16_to_f32(bias[i]));
 }
+// d % 8 == 0, d <= 2048: the row lives in registers (one 16-byte piece per thread, read once), two block sums, 16-byte stores - the
+// element-wise kernel above reads the row three times with 2-byte loads (32.6 us per 12 000 x 1280 call, 1.9 TB/s)
+__global__ void __launch_bounds__(256) k_layernorm8(const bf16_t* __restrict__ x, bf16_t* __restrict__ y, const bf16_t* __restrict__ w,
+                                                    const bf16_t* __restrict__ bias, int d, float eps) {
+    __shared__ float red[4];
+    const size_t row = blockIdx.x;
+    const int tid = threadIdx.x, nch = d >> 3;
+    const bool live = tid < nch;
+    const int ch = live ? tid : 0;
+    const uint4 xq = reinterpret_cast<const uint4*>(x + row * d)[ch];
+    const uint4 wq = reinterpret_cast<const uint4*>(w)[ch];
+    const uint4 bq = reinterpret_cast<const uint4*>(bias)[ch];
+    const uint32_t xw[4] = {xq.x, xq.y, xq.z, xq.w}, ww[4] = {wq.x, wq.y, wq.z, wq.w}, bw[4] = {bq.x, bq.y, bq.z, bq.w};
+    float v[8], s = 0.0f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        v[2 * j] = bf16_to_f32((bf16_t)(xw[j] & 0xffffu)); v[2 * j + 1] = bf16_to_f32((bf16_t)(xw[j] >> 16));
+        s += live ? v[2 * j] + v[2 * j + 1] : 0.0f;
+    }
+    s = wave_sum(s);
+    if ((tid & 63) == 0) red[tid >> 6] = s;
+    __syncthreads();
+    const float mean = (red[0] + red[1] + red[2] + red[3]) / (float)d;
+    __syncthreads();
+    float q = 0.0f;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { const float t = v[e] - mean; q += live ? t * t : 0.0f; }
+    q = wave_sum(q);
+    if ((tid & 63) == 0) red[tid >> 6] = q;
+    __syncthreads();
+    const float rstd = 1.0f / sqrtf((red[0] + red[1] + red[2] + red[3]) / (float)d + eps);
+    if (live) {
+        uint32_t o[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float w0 = bf16_to_f32((bf16_t)(ww[j] & 0xffffu)), w1 = bf16_to_f32((bf16_t)(ww[j] >> 16));
+            const float b0 = bf16_to_f32((bf16_t)(bw[j] & 0xffffu)), b1 = bf16_to_f32((bf16_t)(bw[j] >> 16));
+            o[j] = (uint32_t)f32_to_bf16((v[2 * j] - mean) * rstd * w0 + b0) | ((uint32_t)f32_to_bf16((v[2 * j + 1] - mean) * rstd * w1 + b1) << 16);
+        }
+        reinterpret_cast<uint4*>(y + row * d)[ch] = make_uint4(o[0], o[1], o[2], o[3]);
+    }
+}
 void launch_layernorm(const bf16_t* x, bf16_t* y, const bf16_t* w, const bf16_t* b, int rows, int d, float eps, hipStream_t s) {
-    if (rows > 0) hipLaunchKernelGGL(k_layernorm, dim3(rows), dim3(256), 0, s, x, y, w, b, d, eps);
+    if (rows <= 0) return;
+    const bool a16 = ((((uintptr_t)x) | ((uintptr_t)y) | ((uintptr_t)w) | ((uintptr_t)b)) & 15) == 0;
+    if (d % 8 == 0 && d <= 2048 && a16) hipLaunchKernelGGL(k_layernorm8, dim3(rows), dim3(256), 0, s, x, y, w, b, d, eps);
+    else hipLaunchKernelGGL(k_layernorm, dim3(rows), dim3(256), 0, s, x, y, w, b, d, eps);
 }
 
 // ============================================================================ conv stem patches
