@@ -186,3 +186,24 @@ def test_in_context_prompt_layout_without_a_device():
     assert p.codec_ids.tolist() == [-1] * 3 + [cfg.codec_think_id, cfg.codec_think_bos_id, 2050, cfg.codec_think_eos_id, cfg.codec_pad_id] \
         + [cfg.codec_pad_id] * len(body) + [cfg.codec_bos_id, V + 7, V + 8, V + 9]
     assert len(p.trailing_ids) == 0 and p.target_token_count == 6 and p.reference is ctx
+
+
+def test_product_side_front_end_checkpoint_generator_has_the_oracles_key_set():
+    """mlx_audio_swift_amd.synthetic.qwen3tts_reference_synthetic_weights (used by tools/bench_q3_reference.py, which may not import the
+    oracle) yields exactly the tensors the engine asks for: the oracle generators' keys behind the two prefixes, kept quantizers only."""
+    from mlx_audio_swift_amd.synthetic import qwen3tts_reference_synthetic_weights
+    from oracle import ecapa as oe
+    from oracle import mimi_encoder as om
+    cfg = q3.Qwen3TTSConfiguration()
+    ec = oe.EcapaConfig(mel_dim=12, enc_dim=20, enc_channels=(16, 16, 16, 16, 48), enc_kernel_sizes=(5, 3, 3, 3, 1), enc_dilations=(1, 2, 3, 4, 1),
+                        enc_attention_channels=8, enc_res2net_scale=4, enc_se_channels=6)           # three SE-Res2Net blocks of 16 -> mfa over 48
+    cfg.speaker_encoder = q3.Qwen3TTSSpeakerEncoderConfiguration(**{k: getattr(ec, k) for k in q3.Qwen3TTSSpeakerEncoderConfiguration.__dataclass_fields__})
+    cfg.tokenizer_encoder = q3.Qwen3TTSTokenizerEncoderConfiguration(num_filters=4, hidden_size=16, num_hidden_layers=2, num_attention_heads=2, intermediate_size=32,
+                                                                    codebook_dim=8, codebook_size=32, num_quantizers=5)
+    cfg.encoder_valid_num_quantizers = 4
+    got = {n: a.shape for n, a in qwen3tts_reference_synthetic_weights(cfg)}
+    sp = {"speaker_encoder." + k: np.asarray(v).shape for k, v in oe.make_synthetic_weights(ec).items()}
+    mc = om.MimiEncoderConfig(num_filters=4, hidden_size=16, num_hidden_layers=2, num_attention_heads=2, intermediate_size=32, codebook_dim=8,
+                              codebook_size=32, num_quantizers=5, valid_num_quantizers=4)
+    en = {"encoder_model." + k: np.asarray(v).shape for k, v in om.make_synthetic_weights(mc).items() if "rvq_rest.vq.layers.3." not in k}
+    assert got == {**sp, **en}
