@@ -665,7 +665,8 @@ mis_status mis_soprano_group_generate(mis_soprano* const* replicas, int n, const
                                       const mis_gen_params* params, float** pcm_out, int64_t* pcm_stride, int64_t* pcm_lens,
                                       int32_t** tokens_out, int64_t* tokens_stride, int32_t* n_tokens);
 /* arguments as mis_qwen3tts_generate; with on_event and chunk_frames > 0 every replica streams its rows' chunks as they are decoded
- * (generateStream): per-rank chunk emission, nothing is exchanged between GPUs. */
+ * (generateStream): per-rank chunk emission, nothing is exchanged between GPUs.  In-context prompts address reference rows by codec id:
+ * register the same reference contexts, in the same order, on every replica (mis_qwen3tts_add_reference). */
 mis_status mis_qwen3tts_group_generate(mis_qwen3tts* const* replicas, int n, const int32_t* text_ids, const int32_t* codec_ids,
                                        const int32_t* prefill_lens, int P, const int32_t* trailing_ids, const int32_t* trailing_lens, int Tt,
                                        int batch, const mis_qwen3tts_params* params, const int32_t* row_max_frames, float** pcm_out,
