@@ -229,7 +229,8 @@ mis_q3ref* q3ref_create(const mis_qwen3tts_reference_config* cfg, int device, hi
     try {
         if (r->has_spk) {
             MIS_REQUIRE(cfg->spk_n_blocks >= 2 && cfg->spk_n_blocks <= 8, MIS_ERR_INVALID_INPUT, "speaker encoder: 2..8 enc_channels entries");
-            MIS_REQUIRE(cfg->spk_mel_dim >= 1 && cfg->spk_mel_dim <= 256 && cfg->spk_enc_dim >= 1 && cfg->spk_res2net_scale >= 2,
+            MIS_REQUIRE(cfg->spk_mel_dim >= 1 && cfg->spk_mel_dim <= 256 && cfg->spk_enc_dim >= 1 && cfg->spk_res2net_scale >= 2 &&
+                            cfg->spk_se_channels >= 1 && cfg->spk_attention_channels >= 1,
                         MIS_ERR_INVALID_INPUT, "bad speaker encoder dims");
             for (int i = 1; i + 1 < cfg->spk_n_blocks; ++i)
                 MIS_REQUIRE(cfg->spk_channels[i] == cfg->spk_channels[i - 1] && cfg->spk_channels[i] % cfg->spk_res2net_scale == 0,
@@ -495,7 +496,7 @@ void q3ref_speaker(mis_q3ref* r, const float* audio, int64_t n, int stage, float
     for (int i = 0; i < cf.spk_n_blocks; ++i) max_pad = std::max(max_pad, (cf.spk_kernel_sizes[i] - 1) * cf.spk_dilations[i] / 2);
     MIS_REQUIRE(T >= 16 && T > max_pad, MIS_ERR_INVALID_INPUT, "reference audio too short for the speaker encoder (%d mel frames)", T);
     const int nb = cf.spk_n_blocks, Cl = cf.spk_channels[nb - 1];
-    int Cmax = std::max(cf.spk_mel_dim, 3 * Cl);
+    int Cmax = std::max(std::max(cf.spk_mel_dim, 3 * Cl), std::max(cf.spk_se_channels, cf.spk_attention_channels));
     for (int i = 0; i < nb; ++i) Cmax = std::max(Cmax, cf.spk_channels[i]);
     DevBuf<float> ain, melTC, x0, cat, y1, y2, y3, padb, a3, vec;
     ain.alloc(n); melTC.alloc((size_t)T * cf.spk_mel_dim); x0.alloc((size_t)Cmax * T); cat.alloc((size_t)Cl * T);
