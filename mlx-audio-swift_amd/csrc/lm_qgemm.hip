@@ -271,6 +271,199 @@ __global__ void __launch_bounds__(256, 2) k_gemm_skinny_q(const void* __restrict
     }
 }
 
+// ---- one-shot arrangement (MIS_QGEMM_V2=1; MT <= 2): for launches where a wave's share of K is at most U scale groups - the split-K
+// roles of the decode step and every Qwen3-TTS-sized matrix - all loads of the wave are issued up front and the kernel is ONE memory
+// round trip instead of one per register buffer.  What pays for the registers: the MFMA operands are swapped (x fragment as the A
+// operand, codes as B: D[m][n], lane l holds n = l & 15, m = 4 (l >> 4) + e), so a lane's C/D column is one output row n and the scale
+// and bias of a group are one bf16 each per lane (2-byte loads from the same [NT][G][2][16] table) instead of four each; the wave
+// index is made scalar, so tile and K-range arithmetic and the base addresses live in SGPRs.  Groups past the wave's range are loaded
+// from its last group (clamped) and enter with scale = bias = 0: straight-line code, no load can sink behind a branch.  The
+// accumulators pass through LDS once at the end (a 16 x 16 float tile per (r, mt), written [m][n], read back as the streaming
+// kernel's lanes hold them), so the epilogues and the in-block split-K combine are shared; eight waves per item are possible here.
+// Per-element arithmetic is that of k_gemm_skinny_q; the in-block combine adds KSB partials in wave order.
+template <int MT, int R, int EPI, int KSB, int BITS, int U>
+__global__ void __launch_bounds__(KSB == 8 ? 512 : 256, 2) k_gemm_skinny_q1(const void* Qp, const bf16_t* SB, const bf16_t* X,     // not __restrict__: see the
+                                                                            void* __restrict__ out, int NT, int G, int S, int n_items, int N_out, int Mpad,   // fence below
+                                                                            const bf16_t* __restrict__ bias) {
+    static_assert(EPI != EPI_SILU_MUL || R == 2, "silu-mul epilogue pairs a gate tile with an up tile");
+    typedef typename QTile<BITS>::type WT;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int item = (KSB == 1) ? blockIdx.x * 4 + wave : blockIdx.x;
+    if (item >= n_items) return;
+    const int ntg = item / S, ks = item - ntg * S;
+    const int KT = 2 * G;
+    int g0 = (int)(((long long)G * ks) / S), g1 = (int)(((long long)G * (ks + 1)) / S);
+    if (KSB > 1) {
+        int len = g1 - g0;
+        int a = g0 + (int)(((long long)len * wave) / KSB), b = g0 + (int)(((long long)len * (wave + 1)) / KSB);
+        g0 = a; g1 = b;
+    }
+    f32x4_t acc[R][MT];
+#pragma unroll
+    for (int r = 0; r < R; ++r)
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) acc[r][mt] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+
+    if (g0 < g1) {                                         // the launcher guarantees g1 - g0 <= U
+        const WT* wp[R];
+        const uint16_t* sp[R];
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            int tile = ntg * R + r;
+            if (tile >= NT) tile = NT - 1;                 // clamp (store is skipped in the epilogue)
+            wp[r] = reinterpret_cast<const WT*>(Qp) + (size_t)tile * KT * 64 + lane;
+            sp[r] = reinterpret_cast<const uint16_t*>(SB) + (size_t)tile * G * 32 + (lane & 15);   // group g: + 32 g (scale), + 32 g + 16 (bias)
+        }
+        const bf16x8_t* xp[MT];
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) xp[mt] = reinterpret_cast<const bf16x8_t*>(X) + mt * 64 + lane;
+        bf16x8_t ones;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) ones[e] = (short)0x3F80;           // bf16 1.0
+
+        WT w[U][2][R];
+        bf16x8_t x[U][2][MT];
+        uint32_t sb[U][R][2];
+        const int glast = g1 - 1;
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            int gg = g0 + u;
+            gg = gg > glast ? glast : gg;
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+#pragma unroll
+                for (int r = 0; r < R; ++r) w[u][j][r] = __builtin_nontemporal_load(wp[r] + (size_t)(2 * gg + j) * 64);
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) x[u][j][mt] = xp[mt][(size_t)(2 * gg + j) * (MT * 64)];
+            }
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                sb[u][r][0] = sp[r][(size_t)gg * 32];
+                sb[u][r][1] = sp[r][(size_t)gg * 32 + 16];
+            }
+            __builtin_amdgcn_sched_barrier(0);             // issue order = group order (the math below waits group by group)
+        }
+        // every load is issued before the first use.  sched_barrier alone does not hold loads back (instruction selection does not
+        // order them against it, and loads through noalias read-only pointers may be moved across anything - the SLP vectoriser did):
+        // the operands are plain pointers and this fence may write memory as far as the compiler knows.
+        asm volatile("" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const bool live = g0 + u < g1;
+            // nothing that consumes a loaded value may rise above the fence (conversions and the x-only MFMA are pure and would,
+            // taking their vmcnt wait with them): every buffer register passes through an empty volatile asm here, which is also
+            // where the wait for this group's loads belongs
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+#pragma unroll
+                for (int r = 0; r < R; ++r) asm volatile("" : "+v"(w[u][j][r]));
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) asm volatile("" : "+v"(x[u][j][mt]));
+            }
+#pragma unroll
+            for (int r = 0; r < R; ++r) { asm volatile("" : "+v"(sb[u][r][0])); asm volatile("" : "+v"(sb[u][r][1])); }
+            f32x4_t ag[R][MT], sx[MT];
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+                sx[mt] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int r = 0; r < R; ++r) ag[r][mt] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+            }
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                bf16x8_t fr[R];
+#pragma unroll
+                for (int r = 0; r < R; ++r) fr[r] = dq_codes(w[u][j][r]);
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) {
+                    sx[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(x[u][j][mt], ones, sx[mt], 0, 0, 0);
+#pragma unroll
+                    for (int r = 0; r < R; ++r) ag[r][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(x[u][j][mt], fr[r], ag[r][mt], 0, 0, 0);
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                const float sc = live ? __uint_as_float(sb[u][r][0] << 16) : 0.0f;
+                const float bi = live ? __uint_as_float(sb[u][r][1] << 16) : 0.0f;
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) acc[r][mt][e] += sc * ag[r][mt][e] + bi * sx[mt][e];
+            }
+            __builtin_amdgcn_sched_barrier(0);             // groups are consumed in the order their loads were issued (vmcnt is in order)
+        }
+    }
+
+    // hand-over to the streaming kernel's lane layout: tile [m][n] floats in LDS; lane L then owns m = L & 15, n = 4 (L >> 4) .. + 3
+    __shared__ float4 red[KSB > 4 ? KSB : 4][R * MT][64];
+#pragma unroll
+    for (int r = 0; r < R; ++r)
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            float* t = reinterpret_cast<float*>(red[wave][r * MT + mt]);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) t[(4 * (lane >> 4) + e) * 16 + (lane & 15)] = acc[r][mt][e];
+        }
+    const int rd = (lane & 15) * 4 + (lane >> 4);
+    if (KSB == 1) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+        for (int r = 0; r < R; ++r)
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+                float4 v = red[wave][r * MT + mt][rd];
+                acc[r][mt] = (f32x4_t){v.x, v.y, v.z, v.w};
+            }
+        qgemm_epilogue<MT, R, EPI>(acc, out, ntg, ks, NT, N_out, Mpad, lane, -1, bias);
+    } else {
+        __syncthreads();
+        for (int mt = wave; mt < MT; mt += KSB) {
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                float4 s0 = red[0][r * MT + mt][rd];
+#pragma unroll
+                for (int wv = 1; wv < KSB; ++wv) {
+                    float4 t = red[wv][r * MT + mt][rd];
+                    s0.x += t.x; s0.y += t.y; s0.z += t.z; s0.w += t.w;
+                }
+#pragma unroll
+                for (int m2 = 0; m2 < MT; ++m2)
+                    if (m2 == mt) acc[r][m2] = (f32x4_t){s0.x, s0.y, s0.z, s0.w};
+            }
+            qgemm_epilogue<MT, R, EPI>(acc, out, ntg, ks, NT, N_out, Mpad, lane, mt, bias);
+        }
+    }
+}
+
+template <int MT, int BITS, int U>
+static void launch_qgemm1_mt(int epi, int R, int ksb, const void* Qp, const bf16_t* SB, const bf16_t* X, void* out, int NT, int G, int S,
+                             int N_out, int Mpad, const bf16_t* bias, hipStream_t s) {
+    int n_items = ((NT + R - 1) / R) * S;
+    dim3 grid(ksb == 1 ? (n_items + 3) / 4 : n_items), block(ksb == 8 ? 512 : 256);
+#define QGEMM1_CASE(E, RR, KS)                                                                                      \
+    if (epi == E && R == RR && ksb == KS) {                                                                         \
+        hipLaunchKernelGGL((k_gemm_skinny_q1<MT, RR, E, KS, BITS, U>), grid, block, 0, s, Qp, SB, X, out, NT, G, S, n_items, \
+                           N_out, Mpad, bias);                                                                      \
+        return;                                                                                                     \
+    }
+    QGEMM1_CASE(EPI_PARTIAL, 1, 4)
+    QGEMM1_CASE(EPI_PARTIAL, 1, 8)
+    QGEMM1_CASE(EPI_PARTIAL, 2, 1)
+    QGEMM1_CASE(EPI_PARTIAL, 2, 4)
+    QGEMM1_CASE(EPI_PARTIAL, 2, 8)
+    QGEMM1_CASE(EPI_BF16, 2, 1)
+    QGEMM1_CASE(EPI_BF16, 2, 4)
+    QGEMM1_CASE(EPI_BF16, 2, 8)
+    QGEMM1_CASE(EPI_SILU_MUL, 2, 1)
+    QGEMM1_CASE(EPI_SILU_MUL, 2, 4)
+    QGEMM1_CASE(EPI_SILU_MUL, 2, 8)
+#undef QGEMM1_CASE
+    throw MisError(MIS_ERR_GENERATION_FAILED, "unsupported quantised GEMM variant");
+}
+
 template <int MT, int BITS, int U>
 static void launch_qgemm_mt(int epi, int R, int ksb, const void* Qp, const bf16_t* SB, const bf16_t* X, void* out, int NT, int G, int S,
                             int N_out, int Mpad, const bf16_t* bias, hipStream_t s) {
@@ -300,6 +493,35 @@ void launch_gemm_skinny_q(int bits, int epi, int R, int ksb, const void* Qp, con
     MIS_REQUIRE(bits == 8 || bits == 4, MIS_ERR_GENERATION_FAILED, "quantised GEMM: 8 or 4 bits");
     MIS_REQUIRE(S >= 1 && S <= G, MIS_ERR_GENERATION_FAILED, "quantised GEMM: %d K slices for %d scale groups", S, G);   // a wave may get none
     static const int u_env = getenv("MIS_QGEMM_U") ? atoi(getenv("MIS_QGEMM_U")) : 2;
+    // one-shot arrangement (k_gemm_skinny_q1): off unless MIS_QGEMM_V2=1.  MIS_QGEMM_V2_PREF8=1: eight waves per item wherever that
+    // leaves each wave two to four groups; MIS_QGEMM_V2_MAXU=4: no six-group buffers
+    static const int v2 = getenv("MIS_QGEMM_V2") ? atoi(getenv("MIS_QGEMM_V2")) : 0;
+    static const int v2_pref8 = getenv("MIS_QGEMM_V2_PREF8") ? atoi(getenv("MIS_QGEMM_V2_PREF8")) : 0;
+    static const int v2_maxu = getenv("MIS_QGEMM_V2_MAXU") ? atoi(getenv("MIS_QGEMM_V2_MAXU")) : 6;
+    if (v2 && Mpad / 16 <= 2) {
+        // where a wave's K share fits a buffer of 4 or 6 scale groups - with the waves per item the caller asked for, or with eight
+        // instead of four (the in-block combine then adds eight partials); everything else streams through k_gemm_skinny_q
+        const int per_item = (G + S - 1) / S;
+        auto pw = [&](int k) { return (per_item + k - 1) / k; };
+        int k2 = 0, u2 = 0;
+        if (ksb == 1) { if (pw(1) <= 4) { k2 = 1; u2 = 4; } else if (pw(1) <= 6) { k2 = 1; u2 = 6; } }
+        else if (v2_pref8 && pw(8) <= 4 && pw(8) >= 2) { k2 = 8; u2 = 4; }
+        else if (pw(4) <= 4) { k2 = 4; u2 = 4; }
+        else if (pw(8) <= 4) { k2 = 8; u2 = 4; }
+        else if (pw(4) <= 6) { k2 = 4; u2 = 6; }
+        else if (pw(8) <= 6) { k2 = 8; u2 = 6; }
+        if (u2 > v2_maxu) u2 = 0;
+#define QGEMM1_GO(M, UU)                                                                                             \
+        { if (bits == 8) launch_qgemm1_mt<M, 8, UU>(epi, R, k2, Qp, SB, X, out, NT, G, S, N_out, Mpad, bias, s);         \
+          else launch_qgemm1_mt<M, 4, UU>(epi, R, k2, Qp, SB, X, out, NT, G, S, N_out, Mpad, bias, s);                   \
+          return; }
+#define QGEMM1_MT(M)                                                                                                 \
+        if (u2 == 4) QGEMM1_GO(M, 4)                                                                                 \
+        if (u2 == 6) QGEMM1_GO(M, 6)
+        if (Mpad / 16 == 1) { QGEMM1_MT(1) } else { QGEMM1_MT(2) }
+#undef QGEMM1_MT
+#undef QGEMM1_GO
+    }
 #define QGEMM_MT(M, UU)                                                                                              \
     if (bits == 8) launch_qgemm_mt<M, 8, UU>(epi, R, ksb, Qp, SB, X, out, NT, G, S, N_out, Mpad, bias, s);           \
     else launch_qgemm_mt<M, 4, UU>(epi, R, ksb, Qp, SB, X, out, NT, G, S, N_out, Mpad, bias, s);

@@ -1,6 +1,7 @@
 """Quantised weight-streaming GEMM (csrc/lm_qgemm.hip) at bench widths: achieved GB/s of algorithmic bytes (codes + scale/bias pairs)
 and time per launch, next to the dense bf16 kernel.  Usage: python tools/qgemm_probe.py [orpheus|qwen3] [batch]
-MIS_QGEMM_U=1|2 selects the register-buffer depth (read once per process).  Appends to gpurun_out/qgemm_probe.jsonl."""
+MIS_QGEMM_U=1|2 selects the register-buffer depth, MIS_QGEMM_V2=1 (+ MIS_QGEMM_V2_PREF8 / _MAXU) the one-shot arrangement where it
+applies (read once per process); MIS_PROBE_BITS="16,8,4" picks the weight formats.  Appends to gpurun_out/qgemm_probe.jsonl."""
 import json
 import os
 import sys
@@ -20,9 +21,11 @@ else:                             # Qwen3-TTS-0.6B talker shapes
                                     rope_scaling=None, tie_word_embeddings=False, qk_norm=True, rope_plain=True)
 names = ["qkv", "o_proj", "gate_up", "down", "lm_head"]
 rows = []
-for bits in (None, 8, 4):
+want = [int(b) for b in os.environ.get("MIS_PROBE_BITS", "16,8,4").split(",")]
+for bits in [None if b == 16 else b for b in want]:
     lm = mas.LlamaTTSModel.synthetic(cfg, seed=1, quant_bits=bits)
-    out = {"model": which_model, "batch": batch, "bits": bits or 16, "qgemm_u": os.environ.get("MIS_QGEMM_U", "2"), "native": lm.native_quant_bits}
+    out = {"model": which_model, "batch": batch, "bits": bits or 16, "qgemm_u": os.environ.get("MIS_QGEMM_U", "2"),
+           "one_shot": {k[10:].lower(): v for k, v in os.environ.items() if k.startswith("MIS_QGEMM_V2")}, "native": lm.native_quant_bits}
     for w in range(5):
         ms, by = lm.time_gemm(w, batch, iters=64)
         out[names[w]] = {"us": round(ms * 1e3, 2), "MB": round(by / 1e6, 2), "GBps": round(by / ms / 1e6, 1)}
