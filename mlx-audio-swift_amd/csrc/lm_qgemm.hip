@@ -271,7 +271,7 @@ __global__ void __launch_bounds__(256, 2) k_gemm_skinny_q(const void* __restrict
     }
 }
 
-// ---- one-shot arrangement (MIS_QGEMM_V2=1; MT <= 2): for launches where a wave's share of K is at most U scale groups - the split-K
+// ---- one-shot arrangement (MT <= 2; MIS_QGEMM_V2=0 turns it off): for launches where a wave's share of K is at most U scale groups - the split-K
 // roles of the decode step and every Qwen3-TTS-sized matrix - all loads of the wave are issued up front and the kernel is ONE memory
 // round trip instead of one per register buffer.  What pays for the registers: the MFMA operands are swapped (x fragment as the A
 // operand, codes as B: D[m][n], lane l holds n = l & 15, m = 4 (l >> 4) + e), so a lane's C/D column is one output row n and the scale
@@ -493,32 +493,29 @@ void launch_gemm_skinny_q(int bits, int epi, int R, int ksb, const void* Qp, con
     MIS_REQUIRE(bits == 8 || bits == 4, MIS_ERR_GENERATION_FAILED, "quantised GEMM: 8 or 4 bits");
     MIS_REQUIRE(S >= 1 && S <= G, MIS_ERR_GENERATION_FAILED, "quantised GEMM: %d K slices for %d scale groups", S, G);   // a wave may get none
     static const int u_env = getenv("MIS_QGEMM_U") ? atoi(getenv("MIS_QGEMM_U")) : 2;
-    // one-shot arrangement (k_gemm_skinny_q1): off unless MIS_QGEMM_V2=1.  MIS_QGEMM_V2_PREF8=1: eight waves per item wherever that
-    // leaves each wave two to four groups; MIS_QGEMM_V2_MAXU=4: no six-group buffers
-    static const int v2 = getenv("MIS_QGEMM_V2") ? atoi(getenv("MIS_QGEMM_V2")) : 0;
-    static const int v2_pref8 = getenv("MIS_QGEMM_V2_PREF8") ? atoi(getenv("MIS_QGEMM_V2_PREF8")) : 0;
+    // one-shot arrangement (k_gemm_skinny_q1): on unless MIS_QGEMM_V2=0.  MIS_QGEMM_V2_WAVES8=1: eight waves per item where four
+    // leave a wave more than six groups; MIS_QGEMM_V2_MAXU=2|4: no larger buffers
+    static const int v2 = getenv("MIS_QGEMM_V2") ? atoi(getenv("MIS_QGEMM_V2")) : 1;
+    static const int v2_waves8 = getenv("MIS_QGEMM_V2_WAVES8") ? atoi(getenv("MIS_QGEMM_V2_WAVES8")) : 0;
     static const int v2_maxu = getenv("MIS_QGEMM_V2_MAXU") ? atoi(getenv("MIS_QGEMM_V2_MAXU")) : 6;
     if (v2 && Mpad / 16 <= 2) {
-        // where a wave's K share fits a buffer of 4 or 6 scale groups - with the waves per item the caller asked for, or with eight
-        // instead of four (the in-block combine then adds eight partials); everything else streams through k_gemm_skinny_q
+        // where a wave's K share fits a buffer of 2, 4 or 6 scale groups (the smallest that holds it: groups past the share cost loads
+        // and MFMAs); everything else streams through k_gemm_skinny_q.  Eight waves per item measured worse than four on every role
+        // (profiles/r03/qgemm_one_shot.jsonl) and stay behind the switch.
         const int per_item = (G + S - 1) / S;
         auto pw = [&](int k) { return (per_item + k - 1) / k; };
-        int k2 = 0, u2 = 0;
-        if (ksb == 1) { if (pw(1) <= 4) { k2 = 1; u2 = 4; } else if (pw(1) <= 6) { k2 = 1; u2 = 6; } }
-        else if (v2_pref8 && pw(8) <= 4 && pw(8) >= 2) { k2 = 8; u2 = 4; }
-        else if (pw(4) <= 4) { k2 = 4; u2 = 4; }
-        else if (pw(8) <= 4) { k2 = 8; u2 = 4; }
-        else if (pw(4) <= 6) { k2 = 4; u2 = 6; }
-        else if (pw(8) <= 6) { k2 = 8; u2 = 6; }
-        if (u2 > v2_maxu) u2 = 0;
+        int k2 = ksb, n = pw(ksb);
+        if (n > 6 && ksb == 4 && v2_waves8 && pw(8) <= 6) { k2 = 8; n = pw(8); }
+        const int u2 = n <= 2 ? 2 : n <= 4 ? 4 : n <= 6 ? 6 : 0;
 #define QGEMM1_GO(M, UU)                                                                                             \
         { if (bits == 8) launch_qgemm1_mt<M, 8, UU>(epi, R, k2, Qp, SB, X, out, NT, G, S, N_out, Mpad, bias, s);         \
           else launch_qgemm1_mt<M, 4, UU>(epi, R, k2, Qp, SB, X, out, NT, G, S, N_out, Mpad, bias, s);                   \
           return; }
 #define QGEMM1_MT(M)                                                                                                 \
+        if (u2 == 2) QGEMM1_GO(M, 2)                                                                                 \
         if (u2 == 4) QGEMM1_GO(M, 4)                                                                                 \
         if (u2 == 6) QGEMM1_GO(M, 6)
-        if (Mpad / 16 == 1) { QGEMM1_MT(1) } else { QGEMM1_MT(2) }
+        if (u2 && u2 <= v2_maxu) { if (Mpad / 16 == 1) { QGEMM1_MT(1) } else { QGEMM1_MT(2) } }
 #undef QGEMM1_MT
 #undef QGEMM1_GO
     }

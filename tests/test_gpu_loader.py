@@ -196,3 +196,17 @@ def test_batched_prefill_on_code_streamed_weights(bits, monkeypatch):
            rms_vs_sequential_worst=max(d_all), tol_max=0.016, tol_rms_mean=0.008, tol_rms_worst=0.016)
     assert np.mean(e_all) <= 0.008 and np.max(e_all) <= 0.016, (np.mean(e_all), np.max(e_all))
     assert np.mean(d_all) <= 0.008 and np.max(d_all) <= 0.016, (np.mean(d_all), np.max(d_all))
+
+
+def test_streaming_arrangement_behind_the_switch():
+    """csrc/lm_qgemm.hip launches the one-shot arrangement (k_gemm_skinny_q1) wherever a wave's K share fits a register buffer - at
+    these widths: every role.  MIS_QGEMM_V2=0 sends the same launches through the streaming kernel (k_gemm_skinny_q), which the
+    Orpheus-sized gate/up and output projections use; the switch is read once per process, so the 8- and 4-bit batch-32 cases of the
+    oracle comparison above run again in a child interpreter with it off."""
+    import subprocess
+    import sys
+    env = dict(os.environ, MIS_QGEMM_V2="0")
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-x", "-p", "no:cacheprovider", "-k",
+                        "native_quantised and b32"], env=env, capture_output=True, text=True, timeout=600,
+                       cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    assert r.returncode == 0 and "2 passed" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
