@@ -26,6 +26,8 @@ template <> struct QTile<8> { typedef u32x2_t type; };
 template <> struct QTile<4> { typedef unsigned int type; };
 
 // 8 codes -> 8 bf16 values (exact).  (float)(byte) is v_cvt_f32_ubyteN; the pair conversion is v_cvt_pk_bf16_f32.
+// (Measured alternative: v_perm_b32 placing byte k under the exponent of 2^23, one v_pk_add_f32 per pair, then the same pack - 16
+// instead of 12 instructions per fragment and no faster anywhere: profiles/r03/qgemm_loads_vs_math.jsonl.)
 __device__ __forceinline__ bf16x8_t dq_codes(u32x2_t w) {
     bf16x8_t r;
 #pragma unroll
@@ -158,10 +160,26 @@ __global__ void __launch_bounds__(256, 2) k_gemm_skinny_q(const void* __restrict
 #pragma unroll
     for (int e = 0; e < 8; ++e) ones[e] = (short)0x3F80;               // bf16 1.0
 
+#if defined(MIS_QGEMM_ABLATE) && MIS_QGEMM_ABLATE == 2
+    WT wA[QGEMM_U][2][R] = {}, wB[QGEMM_U][2][R] = {};
+    bf16x8_t xA[QGEMM_U][2][MT] = {}, xB[QGEMM_U][2][MT] = {};
+    uint2 sA[QGEMM_U][R][2] = {}, sB[QGEMM_U][R][2] = {};
+#else
     WT wA[QGEMM_U][2][R], wB[QGEMM_U][2][R];
     bf16x8_t xA[QGEMM_U][2][MT], xB[QGEMM_U][2][MT];
     uint2 sA[QGEMM_U][R][2], sB[QGEMM_U][R][2];
+#endif
     const int glast = g1 - 1;
+#if defined(MIS_QGEMM_ABLATE) && MIS_QGEMM_ABLATE == 2   /* diagnostics build (make ablate): no loads in the K loop, registers made opaque */
+#define QG_LOAD(WBUF, XBUF, SBUF, GBASE)                                                            \
+    _Pragma("unroll") for (int u = 0; u < QGEMM_U; ++u) {                                           \
+        _Pragma("unroll") for (int j = 0; j < 2; ++j) {                                             \
+            _Pragma("unroll") for (int r = 0; r < R; ++r) asm volatile("" : "+v"(WBUF[u][j][r]));   \
+            _Pragma("unroll") for (int mt = 0; mt < MT; ++mt) asm volatile("" : "+v"(XBUF[u][j][mt])); \
+        }                                                                                           \
+        _Pragma("unroll") for (int r = 0; r < R; ++r) { asm volatile("" : "+v"(SBUF[u][r][0])); asm volatile("" : "+v"(SBUF[u][r][1])); } \
+    }
+#else
 #define QG_LOAD(WBUF, XBUF, SBUF, GBASE)                                                            \
     _Pragma("unroll") for (int u = 0; u < QGEMM_U; ++u) {                                           \
         int gg = (GBASE) + u;                                                                       \
@@ -177,6 +195,27 @@ __global__ void __launch_bounds__(256, 2) k_gemm_skinny_q(const void* __restrict
             SBUF[u][r][1] = sp[r][(size_t)gg * 8 + 4];                                              \
         }                                                                                           \
     }
+#endif
+#if defined(MIS_QGEMM_ABLATE) && MIS_QGEMM_ABLATE == 1   /* diagnostics build: loads only - every loaded register is consumed by one xor */
+#define QG_GROUP(WBUF, XBUF, SBUF, U)                                                               \
+    {                                                                                               \
+        uint32_t h = 0;                                                                             \
+        _Pragma("unroll") for (int j = 0; j < 2; ++j) {                                             \
+            _Pragma("unroll") for (int r = 0; r < R; ++r) {                                         \
+                const WT t = WBUF[U][j][r];                                                         \
+                const uint32_t* tp = reinterpret_cast<const uint32_t*>(&t);                         \
+                _Pragma("unroll") for (int e = 0; e < (int)(sizeof(WT) / 4); ++e) h ^= tp[e];       \
+            }                                                                                       \
+            _Pragma("unroll") for (int mt = 0; mt < MT; ++mt) {                                     \
+                const bf16x8_t t = XBUF[U][j][mt];                                                  \
+                const uint32_t* tp = reinterpret_cast<const uint32_t*>(&t);                         \
+                _Pragma("unroll") for (int e = 0; e < 4; ++e) h ^= tp[e];                           \
+            }                                                                                       \
+        }                                                                                           \
+        _Pragma("unroll") for (int r = 0; r < R; ++r) h ^= SBUF[U][r][0].x ^ SBUF[U][r][0].y ^ SBUF[U][r][1].x ^ SBUF[U][r][1].y; \
+        acc[0][0][0] += __uint_as_float(h & 0x007fffffu);                                           \
+    }
+#else
 #define QG_GROUP(WBUF, XBUF, SBUF, U)                                                               \
     {                                                                                               \
         f32x4_t ag[R][MT], sx[MT];                                                                  \
@@ -202,6 +241,7 @@ __global__ void __launch_bounds__(256, 2) k_gemm_skinny_q(const void* __restrict
                     acc[r][mt][e] += sc[e] * ag[r][mt][e] + bi[e] * sx[mt][e];                      \
         }                                                                                           \
     }
+#endif
 #define QG_MATH_FULL(WBUF, XBUF, SBUF)                                                              \
     _Pragma("unroll") for (int u = 0; u < QGEMM_U; ++u) QG_GROUP(WBUF, XBUF, SBUF, u)
 #define QG_MATH_TAIL(WBUF, XBUF, SBUF, GBASE)                                                       \

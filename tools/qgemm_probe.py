@@ -25,7 +25,8 @@ want = [int(b) for b in os.environ.get("MIS_PROBE_BITS", "16,8,4").split(",")]
 for bits in [None if b == 16 else b for b in want]:
     lm = mas.LlamaTTSModel.synthetic(cfg, seed=1, quant_bits=bits)
     out = {"model": which_model, "batch": batch, "bits": bits or 16, "qgemm_u": os.environ.get("MIS_QGEMM_U", "2"),
-           "one_shot": {k[10:].lower(): v for k, v in os.environ.items() if k.startswith("MIS_QGEMM_V2")}, "native": lm.native_quant_bits}
+           "one_shot": {k[10:].lower(): v for k, v in os.environ.items() if k.startswith("MIS_QGEMM_V2")},
+           "lib": os.path.basename(os.environ.get("MIS_LIB_PATH", "libmi_speech.so")), "native": lm.native_quant_bits}
     for w in range(5):
         ms, by = lm.time_gemm(w, batch, iters=64)
         out[names[w]] = {"us": round(ms * 1e3, 2), "MB": round(by / 1e6, 2), "GBps": round(by / ms / 1e6, 1)}
