@@ -328,12 +328,13 @@ __global__ void __launch_bounds__(KSB == 8 ? 512 : 256, 2) k_gemm_skinny_q1(cons
     static_assert(EPI != EPI_SILU_MUL || R == 2, "silu-mul epilogue pairs a gate tile with an up tile");
     typedef typename QTile<BITS>::type WT;
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int item = (KSB == 1) ? blockIdx.x * 4 + wave : blockIdx.x;
+    static_assert(KSB == 4 || KSB == 8, "one block per item, its waves split the item's K range");
+    const int item = blockIdx.x;
     if (item >= n_items) return;
     const int ntg = item / S, ks = item - ntg * S;
     const int KT = 2 * G;
     int g0 = (int)(((long long)G * ks) / S), g1 = (int)(((long long)G * (ks + 1)) / S);
-    if (KSB > 1) {
+    {
         int len = g1 - g0;
         int a = g0 + (int)(((long long)len * wave) / KSB), b = g0 + (int)(((long long)len * (wave + 1)) / KSB);
         g0 = a; g1 = b;
@@ -436,7 +437,7 @@ __global__ void __launch_bounds__(KSB == 8 ? 512 : 256, 2) k_gemm_skinny_q1(cons
     }
 
     // hand-over to the streaming kernel's lane layout: tile [m][n] floats in LDS; lane L then owns m = L & 15, n = 4 (L >> 4) .. + 3
-    __shared__ float4 red[KSB > 4 ? KSB : 4][R * MT][64];
+    __shared__ float4 red[KSB][R * MT][64];
 #pragma unroll
     for (int r = 0; r < R; ++r)
 #pragma unroll
@@ -446,35 +447,21 @@ __global__ void __launch_bounds__(KSB == 8 ? 512 : 256, 2) k_gemm_skinny_q1(cons
             for (int e = 0; e < 4; ++e) t[(4 * (lane >> 4) + e) * 16 + (lane & 15)] = acc[r][mt][e];
         }
     const int rd = (lane & 15) * 4 + (lane >> 4);
-    if (KSB == 1) {
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    __syncthreads();
+    for (int mt = wave; mt < MT; mt += KSB) {
 #pragma unroll
-        for (int r = 0; r < R; ++r)
+        for (int r = 0; r < R; ++r) {
+            float4 s0 = red[0][r * MT + mt][rd];
 #pragma unroll
-            for (int mt = 0; mt < MT; ++mt) {
-                float4 v = red[wave][r * MT + mt][rd];
-                acc[r][mt] = (f32x4_t){v.x, v.y, v.z, v.w};
+            for (int wv = 1; wv < KSB; ++wv) {
+                float4 t = red[wv][r * MT + mt][rd];
+                s0.x += t.x; s0.y += t.y; s0.z += t.z; s0.w += t.w;
             }
-        qgemm_epilogue<MT, R, EPI>(acc, out, ntg, ks, NT, N_out, Mpad, lane, -1, bias);
-    } else {
-        __syncthreads();
-        for (int mt = wave; mt < MT; mt += KSB) {
 #pragma unroll
-            for (int r = 0; r < R; ++r) {
-                float4 s0 = red[0][r * MT + mt][rd];
-#pragma unroll
-                for (int wv = 1; wv < KSB; ++wv) {
-                    float4 t = red[wv][r * MT + mt][rd];
-                    s0.x += t.x; s0.y += t.y; s0.z += t.z; s0.w += t.w;
-                }
-#pragma unroll
-                for (int m2 = 0; m2 < MT; ++m2)
-                    if (m2 == mt) acc[r][m2] = (f32x4_t){s0.x, s0.y, s0.z, s0.w};
-            }
-            qgemm_epilogue<MT, R, EPI>(acc, out, ntg, ks, NT, N_out, Mpad, lane, mt, bias);
+            for (int m2 = 0; m2 < MT; ++m2)
+                if (m2 == mt) acc[r][m2] = (f32x4_t){s0.x, s0.y, s0.z, s0.w};
         }
+        qgemm_epilogue<MT, R, EPI>(acc, out, ntg, ks, NT, N_out, Mpad, lane, mt, bias);
     }
 }
 
@@ -482,7 +469,7 @@ template <int MT, int BITS, int U>
 static void launch_qgemm1_mt(int epi, int R, int ksb, const void* Qp, const bf16_t* SB, const bf16_t* X, void* out, int NT, int G, int S,
                              int N_out, int Mpad, const bf16_t* bias, hipStream_t s) {
     int n_items = ((NT + R - 1) / R) * S;
-    dim3 grid(ksb == 1 ? (n_items + 3) / 4 : n_items), block(ksb == 8 ? 512 : 256);
+    dim3 grid(n_items), block(ksb == 8 ? 512 : 256);
 #define QGEMM1_CASE(E, RR, KS)                                                                                      \
     if (epi == E && R == RR && ksb == KS) {                                                                         \
         hipLaunchKernelGGL((k_gemm_skinny_q1<MT, RR, E, KS, BITS, U>), grid, block, 0, s, Qp, SB, X, out, NT, G, S, n_items, \
@@ -491,13 +478,10 @@ static void launch_qgemm1_mt(int epi, int R, int ksb, const void* Qp, const bf16
     }
     QGEMM1_CASE(EPI_PARTIAL, 1, 4)
     QGEMM1_CASE(EPI_PARTIAL, 1, 8)
-    QGEMM1_CASE(EPI_PARTIAL, 2, 1)
     QGEMM1_CASE(EPI_PARTIAL, 2, 4)
     QGEMM1_CASE(EPI_PARTIAL, 2, 8)
-    QGEMM1_CASE(EPI_BF16, 2, 1)
     QGEMM1_CASE(EPI_BF16, 2, 4)
     QGEMM1_CASE(EPI_BF16, 2, 8)
-    QGEMM1_CASE(EPI_SILU_MUL, 2, 1)
     QGEMM1_CASE(EPI_SILU_MUL, 2, 4)
     QGEMM1_CASE(EPI_SILU_MUL, 2, 8)
 #undef QGEMM1_CASE
@@ -546,7 +530,7 @@ void launch_gemm_skinny_q(int bits, int epi, int R, int ksb, const void* Qp, con
         auto pw = [&](int k) { return (per_item + k - 1) / k; };
         int k2 = ksb, n = pw(ksb);
         if (n > 6 && ksb == 4 && v2_waves8 && pw(8) <= 6) { k2 = 8; n = pw(8); }
-        const int u2 = n <= 2 ? 2 : n <= 4 ? 4 : n <= 6 ? 6 : 0;
+        const int u2 = ksb == 1 ? 0 : n <= 2 ? 2 : n <= 4 ? 4 : n <= 6 ? 6 : 0;       // one wave per item: the streaming kernel (long K shares)
 #define QGEMM1_GO(M, UU)                                                                                             \
         { if (bits == 8) launch_qgemm1_mt<M, 8, UU>(epi, R, k2, Qp, SB, X, out, NT, G, S, N_out, Mpad, bias, s);         \
           else launch_qgemm1_mt<M, 4, UU>(epi, R, k2, Qp, SB, X, out, NT, G, S, N_out, Mpad, bias, s);                   \
