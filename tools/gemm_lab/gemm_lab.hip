@@ -3,7 +3,7 @@
 // buffers and checks them against it, so that a variant is measured before anything in the (hashed) step-chain sources changes.
 //
 //   make -C tools/gemm_lab            (links against mlx-audio-swift_amd/libmi_speech.so)
-//   tools/gemm_lab/gemm_lab [rows=32] [iters=64]     -> one JSON line per (shape, variant) on stdout
+//   tools/gemm_lab/gemm_lab [rows=32] [iters=64] [shape]     -> one JSON line per (shape, variant) on stdout
 //
 // Why these two candidates:
 //   * k_lab_stream<MT, R, KSB, U>: the product's loop with R n-tiles per wave and KSB waves per item as parameters.  Every wave re-reads
@@ -18,6 +18,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <math.h>
+#include <string.h>
 #include <vector>
 
 #include "common.h"
@@ -70,15 +71,17 @@ __device__ __forceinline__ void lab_combine_store(f32x4_t (&acc)[R][MT], float4 
 }
 
 // ---------------------------------------------------------------------------- candidate 1: the streaming loop with R and KSB free
+// KSB = 1: four independent items per 256-thread block (the product's output-projection arrangement), no combine
 template <int MT, int R, int KSB, int U>
-__global__ void __launch_bounds__(KSB * 64, 2) k_lab_stream(const bf16_t* __restrict__ Wp, const bf16_t* __restrict__ X, float* __restrict__ out,
-                                                          int NT, int KT, int S, int n_items, int N_out, int Mpad) {
+__global__ void __launch_bounds__((KSB == 1 ? 4 : KSB) * 64, 2) k_lab_stream(const bf16_t* __restrict__ Wp, const bf16_t* __restrict__ X,
+                                                                           float* __restrict__ out, int NT, int KT, int S, int n_items, int N_out,
+                                                                           int Mpad) {
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int item = blockIdx.x;
+    const int item = KSB == 1 ? blockIdx.x * 4 + wave : blockIdx.x;
     if (item >= n_items) return;
     const int ntg = item / S, ks = item - ntg * S;
     int kt0 = (int)(((long long)KT * ks) / S), kt1 = (int)(((long long)KT * (ks + 1)) / S);
-    {
+    if (KSB > 1) {
         const int len = kt1 - kt0;
         const int a = kt0 + (int)(((long long)len * wave) / KSB), b = kt0 + (int)(((long long)len * (wave + 1)) / KSB);
         kt0 = a; kt1 = b;
@@ -154,8 +157,12 @@ __global__ void __launch_bounds__(KSB * 64, 2) k_lab_stream(const bf16_t* __rest
 #undef LAB_LOAD
 #undef LAB_MATH_FULL
 #undef LAB_MATH_TAIL
-    __shared__ float4 red[KSB][R * MT][64];
-    lab_combine_store<MT, R, KSB>(acc, red, out, ntg, ks, NT, N_out, Mpad, lane, wave);
+    if (KSB == 1) {
+        lab_store<MT, R>(acc, out, ntg, ks, NT, N_out, Mpad, lane, -1);
+    } else {
+        __shared__ float4 red[KSB][R * MT][64];
+        lab_combine_store<MT, R, KSB>(acc, red, out, ntg, ks, NT, N_out, Mpad, lane, wave);
+    }
 }
 
 // ---------------------------------------------------------------------------- candidate 2: one shot (wave share <= UK k-tiles)
@@ -224,7 +231,17 @@ __global__ void __launch_bounds__(KSB * 64, 2) k_lab_oneshot(const bf16_t* Wp, c
 }
 
 // ---------------------------------------------------------------------------- harness
-struct Shape { const char* name; int N, K, S; };
+struct Shape { const char* name; int N, K, S, ksb_ref; };      // S, ksb_ref: what the engine launches today (gemm_choose_split)
+
+struct Ctx {
+    Shape sh;
+    int rows, Mpad, iters, L, NT, KT;
+    size_t wn, on;
+    bf16_t *W, *X, *zero;
+    float *O0, *O1;
+    std::vector<float> ref, got;
+    hipStream_t s;
+};
 
 template <typename F>
 static double time_launches(F&& launch, int iters, hipStream_t s) {
@@ -249,67 +266,119 @@ static double max_rel_diff(const std::vector<float>& a, const std::vector<float>
     return scale > 0 ? worst / scale : worst;
 }
 
+static void report(const Ctx& c, const char* variant, double us, double err) {
+    const double mb = (double)c.wn * 2 / 1e6;
+    printf("{\"shape\": \"%s\", \"N\": %d, \"K\": %d, \"S\": %d, \"rows\": %d, \"variant\": \"%s\", \"us\": %.2f, \"MB\": %.2f, \"GBps\": %.1f, "
+           "\"max_rel_vs_product\": %.3g}\n", c.sh.name, c.sh.N, c.sh.K, c.sh.S, c.rows, variant, us, mb, mb / us * 1e3, err);
+    fflush(stdout);
+}
+
+// one launch on weight copy `layer`, checked once against the product's output, then timed
+template <typename L>
+static void check_and_time(Ctx& c, const char* label, L&& launch) {
+    LAB_CHECK(hipMemsetAsync(c.O1, 0, c.on * 4, c.s));
+    launch(0);
+    LAB_CHECK(hipGetLastError());
+    LAB_CHECK(hipMemcpyAsync(c.got.data(), c.O1, c.on * 4, hipMemcpyDeviceToHost, c.s));
+    LAB_CHECK(hipStreamSynchronize(c.s));
+    const double err = max_rel_diff(c.got, c.ref);
+    report(c, label, time_launches(launch, c.iters, c.s), err);
+}
+
+template <int MT, int R, int KSB, int U>
+static void run_stream(Ctx& c) {
+    const int S = c.sh.S, n_items = ((c.NT + R - 1) / R) * S;
+    const dim3 grid(KSB == 1 ? (n_items + 3) / 4 : n_items), block((KSB == 1 ? 4 : KSB) * 64);
+    char label[96];
+    snprintf(label, sizeof label, "stream R%d KSB%d U%d", R, KSB, U);
+    check_and_time(c, label, [&](int i) {
+        hipLaunchKernelGGL((k_lab_stream<MT, R, KSB, U>), grid, block, 0, c.s, c.W + (size_t)(i % c.L) * c.wn, c.X, c.O1, c.NT, c.KT, S, n_items,
+                           c.sh.N, c.Mpad);
+    });
+}
+
+template <int MT, int R, int KSB, int UK>
+static void run_oneshot(Ctx& c) {
+    const int S = c.sh.S, n_items = ((c.NT + R - 1) / R) * S;
+    const int share = ((c.KT + S - 1) / S + KSB - 1) / KSB;         // k-tiles of the longest wave share
+    if (share > UK) return;
+    char label[96];
+    snprintf(label, sizeof label, "one-shot R%d KSB%d UK%d", R, KSB, UK);
+    check_and_time(c, label, [&](int i) {
+        hipLaunchKernelGGL((k_lab_oneshot<MT, R, KSB, UK>), dim3(n_items), dim3(KSB * 64), 0, c.s, c.W + (size_t)(i % c.L) * c.wn, c.X, c.zero, c.O1,
+                           c.NT, c.KT, S, n_items, c.sh.N, c.Mpad);
+    });
+}
+
+template <int MT>
+static void run_shape(Ctx& c) {
+    const Shape& sh = c.sh;
+    // the product launcher on weight copy 0 is the reference of every variant
+    launch_gemm_skinny(EPI_PARTIAL, 2, sh.ksb_ref, c.W, c.X, c.O0, c.NT, c.KT, sh.S, sh.N, c.Mpad, c.s);
+    LAB_CHECK(hipMemcpyAsync(c.ref.data(), c.O0, c.on * 4, hipMemcpyDeviceToHost, c.s));
+    LAB_CHECK(hipStreamSynchronize(c.s));
+    char label[96];
+    snprintf(label, sizeof label, "product k_gemm_skinny R2 KSB%d", sh.ksb_ref);
+    report(c, label, time_launches([&](int i) {
+               launch_gemm_skinny(EPI_PARTIAL, 2, sh.ksb_ref, c.W + (size_t)(i % c.L) * c.wn, c.X, c.O0, c.NT, c.KT, sh.S, sh.N, c.Mpad, c.s); },
+               c.iters, c.s), 0.0);
+    if (sh.ksb_ref == 1) {                            // output projection: one wave per item, long K shares
+        run_stream<MT, 2, 1, 4>(c);
+        run_stream<MT, 4, 1, 3>(c);
+        run_stream<MT, 4, 1, 2>(c);
+        run_stream<MT, 8, 1, 1>(c);
+        run_stream<MT, 4, 2, 3>(c);
+        run_stream<MT, 4, 4, 3>(c);
+        return;
+    }
+    run_stream<MT, 2, 4, 4>(c);                       // the product's shape (scalar wave index)
+    run_stream<MT, 2, 2, 4>(c);
+    run_stream<MT, 2, 8, 4>(c);
+    run_stream<MT, 4, 4, 3>(c);                       // U = 4 at R = 4 spills (68 bytes of scratch)
+    run_stream<MT, 4, 4, 2>(c);
+    run_stream<MT, 4, 2, 3>(c);
+    run_stream<MT, 4, 8, 3>(c);
+    run_stream<MT, 4, 8, 2>(c);
+    run_stream<MT, 8, 4, 1>(c);
+    run_stream<MT, 8, 2, 1>(c);
+    run_stream<MT, 8, 8, 1>(c);
+    run_oneshot<MT, 2, 4, 8>(c);
+    run_oneshot<MT, 2, 4, 12>(c);
+    run_oneshot<MT, 2, 8, 8>(c);
+    run_oneshot<MT, 2, 8, 12>(c);
+    run_oneshot<MT, 4, 4, 6>(c);
+    run_oneshot<MT, 4, 8, 6>(c);
+}
+
 int main(int argc, char** argv) {
     const int rows = argc > 1 ? atoi(argv[1]) : 32, iters = argc > 2 ? atoi(argv[2]) : 64;
+    const char* only = argc > 3 ? argv[3] : nullptr;                        // optional: one shape name
     const int Mpad = (rows + 15) / 16 * 16, MT = Mpad / 16, L = 8;           // L weight copies: rotation defeats the Infinity Cache
-    if (MT != 2) { fprintf(stderr, "the lab instantiates 17..32 rows (MT = 2) only\n"); return 1; }
+    if (MT < 1 || MT > 2) { fprintf(stderr, "the lab instantiates 1..32 rows (MT = 1, 2)\n"); return 1; }
     hipStream_t s;
     LAB_CHECK(hipStreamCreate(&s));
-    const Shape shapes[] = {{"qkv", 5120, 3072, 3}, {"o_proj", 3072, 3072, 2}, {"gate_up", 16384, 3072, 1}, {"down", 3072, 8192, 8}};
+    // Orpheus-3B (hidden 3072, ffn 8192, vocabulary 156 940 padded to 156 960) and Qwen3-TTS-0.6B talker (1024 / 3072, 16 x 128 heads) shapes
+    const Shape shapes[] = {{"qkv", 5120, 3072, 3, 4}, {"o_proj", 3072, 3072, 2, 4}, {"gate_up", 16384, 3072, 1, 4}, {"down", 3072, 8192, 8, 4},
+                            {"lm_head", 156960, 3072, 1, 1},
+                            {"q3_qkv", 4096, 1024, 2, 4}, {"q3_o", 1024, 2048, 4, 4}, {"q3_gate_up", 6144, 1024, 1, 4}, {"q3_down", 1024, 3072, 6, 4},
+                            {"q3_head", 3072, 1024, 1, 4}};
     bf16_t* zero = nullptr;
     LAB_CHECK(hipMalloc(&zero, 64 * 16));
     LAB_CHECK(hipMemset(zero, 0, 64 * 16));
     for (const Shape& sh : shapes) {
-        const int NT = sh.N / 16, KT = sh.K / 32, S = sh.S;
-        const size_t wn = (size_t)sh.N * sh.K, xn = (size_t)Mpad * sh.K, on = (size_t)S * Mpad * sh.N;
-        bf16_t *W = nullptr, *X = nullptr;
-        float *O0 = nullptr, *O1 = nullptr;
-        LAB_CHECK(hipMalloc(&W, wn * 2 * L)); LAB_CHECK(hipMalloc(&X, xn * 2));
-        LAB_CHECK(hipMalloc(&O0, on * 4)); LAB_CHECK(hipMalloc(&O1, on * 4));
-        launch_synth_fill_bf16(W, wn * L, 0x1234u + sh.N, 0.02f, 0, s);
-        launch_synth_fill_bf16(X, xn, 0x9876u + sh.K, 1.0f, 0, s);
+        if (only && strcmp(only, sh.name)) continue;
+        Ctx c;
+        c.sh = sh; c.rows = rows; c.Mpad = Mpad; c.iters = iters; c.L = L; c.NT = sh.N / 16; c.KT = sh.K / 32; c.s = s; c.zero = zero;
+        c.wn = (size_t)sh.N * sh.K; c.on = (size_t)sh.S * Mpad * sh.N;
+        const size_t xn = (size_t)Mpad * sh.K;
+        LAB_CHECK(hipMalloc(&c.W, c.wn * 2 * L)); LAB_CHECK(hipMalloc(&c.X, xn * 2));
+        LAB_CHECK(hipMalloc(&c.O0, c.on * 4)); LAB_CHECK(hipMalloc(&c.O1, c.on * 4));
+        launch_synth_fill_bf16(c.W, c.wn * L, 0x1234u + sh.N, 0.02f, 0, s);
+        launch_synth_fill_bf16(c.X, xn, 0x9876u + sh.K, 1.0f, 0, s);
         LAB_CHECK(hipStreamSynchronize(s));
-        const double mb = (double)wn * 2 / 1e6;
-        std::vector<float> ref(on), got(on);
-        // the product launcher on layer 0 is the reference of every variant
-        launch_gemm_skinny(EPI_PARTIAL, 2, 4, W, X, O0, NT, KT, S, sh.N, Mpad, s);
-        LAB_CHECK(hipMemcpyAsync(ref.data(), O0, on * 4, hipMemcpyDeviceToHost, s));
-        LAB_CHECK(hipStreamSynchronize(s));
-        auto report = [&](const char* variant, double us, double err) {
-            printf("{\"shape\": \"%s\", \"N\": %d, \"K\": %d, \"S\": %d, \"rows\": %d, \"variant\": \"%s\", \"us\": %.2f, \"MB\": %.2f, \"GBps\": %.1f, "
-                   "\"max_rel_vs_product\": %.3g}\n", sh.name, sh.N, sh.K, S, rows, variant, us, mb, mb / us * 1e3, err);
-            fflush(stdout);
-        };
-        report("product k_gemm_skinny R2 KSB4", time_launches([&](int i) {
-                   launch_gemm_skinny(EPI_PARTIAL, 2, 4, W + (size_t)(i % L) * wn, X, O0, NT, KT, S, sh.N, Mpad, s); }, iters, s), 0.0);
-#define LAB_RUN(LABEL, KERNEL, RR, KSBV, ...)                                                                            \
-        {                                                                                                                \
-            const int n_items = ((NT + RR - 1) / RR) * S;                                                                \
-            LAB_CHECK(hipMemsetAsync(O1, 0, on * 4, s));                                                                 \
-            hipLaunchKernelGGL(KERNEL, dim3(n_items), dim3(KSBV * 64), 0, s, W, X, __VA_ARGS__ O1, NT, KT, S, n_items, sh.N, Mpad); \
-            LAB_CHECK(hipGetLastError());                                                                                \
-            LAB_CHECK(hipMemcpyAsync(got.data(), O1, on * 4, hipMemcpyDeviceToHost, s));                                 \
-            LAB_CHECK(hipStreamSynchronize(s));                                                                          \
-            const double err = max_rel_diff(got, ref);                                                                   \
-            report(LABEL, time_launches([&](int i) {                                                                     \
-                       hipLaunchKernelGGL(KERNEL, dim3(n_items), dim3(KSBV * 64), 0, s, W + (size_t)(i % L) * wn, X, __VA_ARGS__ O1, NT, KT, S, \
-                                          n_items, sh.N, Mpad); }, iters, s), err);                                       \
-        }
-        LAB_RUN("stream R2 KSB4 U4 (the product's shape, scalar wave index)", (k_lab_stream<2, 2, 4, 4>), 2, 4, )
-        LAB_RUN("stream R4 KSB4 U3", (k_lab_stream<2, 4, 4, 3>), 4, 4, )          /* U = 4 at R = 4 spills (68 bytes of scratch) */
-        LAB_RUN("stream R4 KSB8 U3", (k_lab_stream<2, 4, 8, 3>), 4, 8, )
-        LAB_RUN("stream R4 KSB8 U2", (k_lab_stream<2, 4, 8, 2>), 4, 8, )
-        LAB_RUN("stream R2 KSB8 U4", (k_lab_stream<2, 2, 8, 4>), 2, 8, )
-        {
-            const int share4 = ((KT + S - 1) / S + 3) / 4, share8 = ((KT + S - 1) / S + 7) / 8;     // k-tiles of the longest wave share
-            if (share4 <= 8) LAB_RUN("one-shot R2 KSB4 UK8", (k_lab_oneshot<2, 2, 4, 8>), 2, 4, zero,)
-            if (share4 <= 12 && share4 > 8) LAB_RUN("one-shot R2 KSB4 UK12", (k_lab_oneshot<2, 2, 4, 12>), 2, 4, zero,)
-            if (share8 <= 8) LAB_RUN("one-shot R2 KSB8 UK8", (k_lab_oneshot<2, 2, 8, 8>), 2, 8, zero,)
-            if (share8 <= 12 && share8 > 8) LAB_RUN("one-shot R2 KSB8 UK12", (k_lab_oneshot<2, 2, 8, 12>), 2, 8, zero,)
-            if (share8 <= 6) LAB_RUN("one-shot R4 KSB8 UK6", (k_lab_oneshot<2, 4, 8, 6>), 4, 8, zero,)
-        }
-#undef LAB_RUN
-        LAB_CHECK(hipFree(W)); LAB_CHECK(hipFree(X)); LAB_CHECK(hipFree(O0)); LAB_CHECK(hipFree(O1));
+        c.ref.resize(c.on); c.got.resize(c.on);
+        if (MT == 1) run_shape<1>(c); else run_shape<2>(c);
+        LAB_CHECK(hipFree(c.W)); LAB_CHECK(hipFree(c.X)); LAB_CHECK(hipFree(c.O0)); LAB_CHECK(hipFree(c.O1));
     }
     LAB_CHECK(hipFree(zero));
     return 0;
