@@ -56,6 +56,7 @@ struct mis_tts {
     int batch = 0, Mpad = 0, Smax = 0;
     int S_qkv = 1, S_o = 1, S_down = 1;
     int r_part = 1;                                 // n-tiles per work item of the split-K GEMMs
+    int r_gu = 2;                                   // n-tiles per wave of gate+up (4 where that still fills the chip, see lm_reset)
     int ksb_part = 4, ksb_gu = 4, ksb_head = 1;     // waves per work item (in-block split-K), see k_gemm_skinny
     DevBuf<bf16_t> kcache, vtcache;
     DevBuf<float> rope_cos, rope_sin;
@@ -542,6 +543,13 @@ static void lm_reset(mis_tts* c, int batch, int max_context) {
     // block split K (10.1 -> see profiles/r03/q3_small_kernels.json).  MIS_KSB_HEAD = 1 / 4 forces one.
     c->ksb_head = getenv("MIS_KSB_HEAD") ? (env_int("MIS_KSB_HEAD", 1) == 4 ? 4 : 1) : (c->Vpad / 32 < 1024 ? 4 : 1);
     c->r_part = env_int("MIS_R_PART", 2) == 1 ? 1 : 2;
+    // gate+up: four n-tiles per wave halve the x fragments every wave re-reads out of L2 (as many bytes as the weights at two) - 20.3 ->
+    // 17.6 us at Orpheus-3B width (profiles/r03/gemm_lab.jsonl) - where a launch still has one wave per SIMD: tile quads x 4 waves >= 4 per CU
+    {
+        const int quads = 2 * c->ff / 16 / 4;
+        const int dflt = (Mpad / 16 <= 2 && c->ksb_gu == 4 && (2 * c->ff / 16) % 4 == 0 && quads >= 256) ? 4 : 2;
+        c->r_gu = env_int("MIS_R_GU", dflt) == 4 && Mpad / 16 <= 2 && c->ksb_gu == 4 ? 4 : 2;
+    }
     c->S_qkv = std::min(8, choose_split(c->Nqkv / 16 / c->r_part, d / 32, c->ksb_part, "MIS_S_QKV", 8));   // attention prologue: <= 8 slabs
     c->S_o = choose_split(d / 16 / c->r_part, HD / 32, c->ksb_part, "MIS_S_O");
     c->S_down = choose_split(d / 16 / c->r_part, c->ff / 32, c->ksb_part, "MIS_S_DOWN");
@@ -580,7 +588,7 @@ static void gemm_o(mis_tts* c, size_t li, hipStream_t s) {
 static void gemm_gate_up(mis_tts* c, size_t li, hipStream_t s) {
     if (c->q_gu.on) launch_gemm_skinny_q(c->q_gu.bits, EPI_SILU_MUL, 2, c->ksb_gu, c->q_gu.q.p + c->q_gu.q_layer * li, c->q_gu.sb.p + c->q_gu.sb_layer * li, c->x.p,
                                          c->act.p, 2 * c->ff / 16, c->d / 64, 1, c->ff, c->Mpad, s);
-    else launch_gemm_skinny(EPI_SILU_MUL, 2, c->ksb_gu, c->wgu.p + layer_gu_elems(c) * li, c->x.p, c->act.p, 2 * c->ff / 16, c->d / 32, 1, c->ff, c->Mpad, s);
+    else launch_gemm_skinny(EPI_SILU_MUL, c->r_gu, c->ksb_gu, c->wgu.p + layer_gu_elems(c) * li, c->x.p, c->act.p, 2 * c->ff / 16, c->d / 32, 1, c->ff, c->Mpad, s);
 }
 static void gemm_down(mis_tts* c, size_t li, hipStream_t s) {
     if (c->q_down.on) launch_gemm_skinny_q(c->q_down.bits, EPI_PARTIAL, c->r_part, c->ksb_part, c->q_down.q.p + c->q_down.q_layer * li,
@@ -942,6 +950,8 @@ extern "C" mis_status mis_sample_logits(int device, const float* logits, int bat
     }
     launch_sampler(sp, batch, 0);
     HIP_CHECK(hipGetLastError());
+    MIS_REQUIRE(!sampler_check_failed(scratch.p, batch, 0), MIS_ERR_GENERATION_FAILED,
+                "sampler: a row barrier of the one-launch sampler timed out (its blocks were not co-resident)");
     HIP_CHECK(hipMemcpy(tokens_out, toks.p, batch * 4, hipMemcpyDefault));
     MIS_API_END
 }
@@ -1177,6 +1187,11 @@ static void run_generate(mis_tts* c, const int32_t* prompt_ids, const int32_t* p
         if (*done_host >= batch) break;
     }
     HIP_CHECK(hipEventRecord(ev[2], s));
+    if (sampler_check_failed(c->samp_scratch.p, batch, s)) {
+        for (auto& e : ev) (void)hipEventDestroy(e);
+        throw MisError(MIS_ERR_GENERATION_FAILED, "sampler: a row barrier of the one-launch sampler timed out (its blocks were not co-resident); "
+                                                  "MIS_SAMPLER_WIDE=1 selects the multi-launch path");
+    }
     if (cancelled) {
         for (auto& e : ev) (void)hipEventDestroy(e);
         throw MisError(MIS_ERR_CANCELLED, "generation cancelled");

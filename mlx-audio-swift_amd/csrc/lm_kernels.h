@@ -81,18 +81,26 @@ struct AttnParams {
 void launch_attn_decode(const AttnParams& p, int batch, hipStream_t s);
 
 #define SAMP_MAX_CHUNKS 64
+#define SAMP_CLUSTER_NB 8
 struct SamplerScratch {             // per row, device memory
     unsigned long long hist1[256], hist2[256], cmass[SAMP_MAX_CHUNKS];
     unsigned long long below1, Z, thr;
     float pmax[SAMP_MAX_CHUNKS];
     int pidx[SAMP_MAX_CHUNKS];
     unsigned bin1, kstar;
-    // k_samp_cluster (one launch, 8 blocks per row): its own exchange area - zero when the scratch is allocated (sampler_scratch_init),
-    // left zero by every launch; `sync` only ever grows
-    unsigned long long c_hist1[256], c_hist2[256], c_mass[8], c_max[8];
-    unsigned int c_sync, c_fail;
+    // k_samp_cluster (one launch, 8 blocks per row): the row's exchange area - one slot per block, overwritten by its owner before the
+    // barrier that releases it to the readers (nothing to zero between launches); `c_sync` only ever grows; c_fail: a row barrier timed out
+    alignas(128) unsigned long long x_hist1[SAMP_CLUSTER_NB][256];
+    alignas(128) unsigned long long x_hist2[SAMP_CLUSTER_NB][256];
+    alignas(128) unsigned long long x_max[SAMP_CLUSTER_NB];
+    alignas(128) unsigned long long x_above[SAMP_CLUSTER_NB];
+    alignas(128) unsigned int c_sync;
+    alignas(128) unsigned int c_fail;
 };
 void sampler_scratch_init(SamplerScratch* scratch, int batch, hipStream_t s);
+// true when any row of the scratch reported a timed-out row barrier of the one-launch sampler (synchronises `s`); the caller raises
+// MIS_ERR_GENERATION_FAILED and re-initialises the scratch
+bool sampler_check_failed(SamplerScratch* scratch, int batch, hipStream_t s);
 void sampler_plan(int vocab, int* n_chunks, int* chunk_w);
 
 struct SamplerParams {

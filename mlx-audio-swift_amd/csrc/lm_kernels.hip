@@ -563,23 +563,27 @@ __device__ __forceinline__ void gemm_epilogue(const f32x4_t (&acc)[R][MT], void*
     } else {   // EPI_SILU_MUL: tile 2t = gate rows, 2t+1 = up rows  (LlamaTTS.swift:283)
         bf16_t* o = reinterpret_cast<bf16_t*>(out);
 #pragma unroll
-        for (int mt = 0; mt < MT; ++mt) {
-            if (mt_only >= 0 && mt != mt_only) continue;
-            uint16_t res[4];
+        for (int p = 0; p < R / 2; ++p) {                                  // tile pair p of the item: feature tile ntg * R / 2 + p
+            if (R > 2 && (ntg * R + 2 * p + 1) >= NT) continue;            // (two tiles per item: NT is even, the item exists)
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                float g = bf16_round_f32(acc[0][mt][e]);
-                float u = bf16_round_f32(acc[R - 1][mt][e]);
-                float sg = bf16_round_f32(1.0f / (1.0f + __expf(-g)));     // T(sigmoid(g))
-                float a = bf16_round_f32(g * sg);                          // T(g * sigmoid)
-                res[e] = f32_to_bf16(a * u);                               // T(silu * up)
+            for (int mt = 0; mt < MT; ++mt) {
+                if (mt_only >= 0 && mt != mt_only) continue;
+                uint16_t res[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    float g = bf16_round_f32(acc[2 * p][mt][e]);
+                    float u = bf16_round_f32(acc[2 * p + 1][mt][e]);
+                    float sg = bf16_round_f32(1.0f / (1.0f + __expf(-g)));     // T(sigmoid(g))
+                    float a = bf16_round_f32(g * sg);                          // T(g * sigmoid)
+                    res[e] = f32_to_bf16(a * u);                               // T(silu * up)
+                }
+                // act is the down-projection's X operand: packed fragment layout (k = feature index)
+                size_t off = xpk_index(mt * 16 + ml, (ntg * (R / 2) + p) * 16 + nl, MT);
+                uint2 v;
+                v.x = (uint32_t)res[0] | ((uint32_t)res[1] << 16);
+                v.y = (uint32_t)res[2] | ((uint32_t)res[3] << 16);
+                *reinterpret_cast<uint2*>(o + off) = v;
             }
-            // act is the down-projection's X operand: packed fragment layout (k = feature index)
-            size_t off = xpk_index(mt * 16 + ml, ntg * 16 + nl, MT);
-            uint2 v;
-            v.x = (uint32_t)res[0] | ((uint32_t)res[1] << 16);
-            v.y = (uint32_t)res[2] | ((uint32_t)res[3] << 16);
-            *reinterpret_cast<uint2*>(o + off) = v;
         }
     }
 }
@@ -593,7 +597,9 @@ template <int MT, int R, int EPI, int KSB>
 __global__ void __launch_bounds__(256, 2) k_gemm_skinny(const bf16_t* __restrict__ Wp, const bf16_t* __restrict__ X,
                                                      void* __restrict__ out, int NT, int KT, int S, int n_items,
                                                      int N_out, int Mpad, const bf16_t* __restrict__ bias) {
-    static_assert(EPI != EPI_SILU_MUL || R == 2, "silu-mul epilogue pairs a gate tile with an up tile");
+    static_assert(EPI != EPI_SILU_MUL || (R & 1) == 0, "silu-mul epilogue pairs a gate tile with an up tile");
+    // k-tiles per register buffer: 4, or 3 at four n-tiles per wave (4 would spill: 2 x 4 x (4 + 2) fragments + 32 accumulators)
+    constexpr int GU = R >= 4 ? 3 : GEMM_U;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int item = (KSB == 1) ? blockIdx.x * 4 + wave : blockIdx.x;
     if (item >= n_items) return;                      // (KSB == 1: a wave of the last block may have no item)
@@ -621,17 +627,17 @@ __global__ void __launch_bounds__(256, 2) k_gemm_skinny(const bf16_t* __restrict
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) acc[r][mt] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
 
-    bf16x8_t wA[GEMM_U][R], xA[GEMM_U][MT], wB[GEMM_U][R], xB[GEMM_U][MT];
+    bf16x8_t wA[GU][R], xA[GU][MT], wB[GU][R], xB[GU][MT];
     const int klast = kt1 - 1;
 #define GEMM_LOAD_W(WBUF, KBASE)                                                                  \
-    _Pragma("unroll") for (int u = 0; u < GEMM_U; ++u) {                                           \
+    _Pragma("unroll") for (int u = 0; u < GU; ++u) {                                           \
         int kk = (KBASE) + u;                                                                      \
         kk = kk > klast ? klast : kk;               /* tail: redundant reload, MFMA is skipped */  \
         _Pragma("unroll") for (int r = 0; r < R; ++r)                                              \
             WBUF[u][r] = __builtin_nontemporal_load(wp[r] + (size_t)kk * 64);                      \
     }
 #define GEMM_LOAD_X(XBUF, KBASE)                                                                  \
-    _Pragma("unroll") for (int u = 0; u < GEMM_U; ++u) {                                           \
+    _Pragma("unroll") for (int u = 0; u < GU; ++u) {                                           \
         int kk = (KBASE) + u;                                                                      \
         kk = kk > klast ? klast : kk;                                                              \
         _Pragma("unroll") for (int mt = 0; mt < MT; ++mt)                                          \
@@ -642,14 +648,14 @@ __global__ void __launch_bounds__(256, 2) k_gemm_skinny(const bf16_t* __restrict
 /* The main loop below uses FULL and unconditional loads only: with a guard inside the loop the waitcnt pass has to assume the   */
 /* no-load path at the join and drains vmcnt far enough to stall the group just requested - one group in flight per wave.        */
 #define GEMM_MATH_FULL(WBUF, XBUF)                                                                \
-    _Pragma("unroll") for (int u = 0; u < GEMM_U; ++u) {                                           \
+    _Pragma("unroll") for (int u = 0; u < GU; ++u) {                                           \
         _Pragma("unroll") for (int r = 0; r < R; ++r)                                              \
             _Pragma("unroll") for (int mt = 0; mt < MT; ++mt)                                      \
                 acc[r][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(WBUF[u][r], XBUF[u][mt],      \
                                                                      acc[r][mt], 0, 0, 0);         \
     }
 #define GEMM_MATH_TAIL(WBUF, XBUF, KBASE)                                                         \
-    _Pragma("unroll") for (int u = 0; u < GEMM_U; ++u) {                                           \
+    _Pragma("unroll") for (int u = 0; u < GU; ++u) {                                           \
         if ((KBASE) + u < kt1) {                                                                   \
             _Pragma("unroll") for (int r = 0; r < R; ++r)                                          \
                 _Pragma("unroll") for (int mt = 0; mt < MT; ++mt)                                  \
@@ -664,29 +670,29 @@ __global__ void __launch_bounds__(256, 2) k_gemm_skinny(const bf16_t* __restrict
         // steady state: groups kt and kt + U are full and both following loads exist
         // (sched barriers: the next group is REQUESTED before the current one is waited for - left alone the scheduler sinks
         // the loads in between the MFMAs, i.e. behind the wait for the current group)
-        while (kt + 3 * GEMM_U <= kt1) {
-            GEMM_LOAD(wB, xB, kt + GEMM_U)
+        while (kt + 3 * GU <= kt1) {
+            GEMM_LOAD(wB, xB, kt + GU)
             __builtin_amdgcn_sched_barrier(0);
             GEMM_MATH_FULL(wA, xA)
             __builtin_amdgcn_sched_barrier(0);
-            GEMM_LOAD(wA, xA, kt + 2 * GEMM_U)
+            GEMM_LOAD(wA, xA, kt + 2 * GU)
             __builtin_amdgcn_sched_barrier(0);
             GEMM_MATH_FULL(wB, xB)
             __builtin_amdgcn_sched_barrier(0);
-            kt += 2 * GEMM_U;
+            kt += 2 * GU;
         }
         // tail: one to three (partial) groups left, the first of them already in buffer A
-        if (kt + GEMM_U < kt1) {
-            GEMM_LOAD(wB, xB, kt + GEMM_U)
+        if (kt + GU < kt1) {
+            GEMM_LOAD(wB, xB, kt + GU)
             __builtin_amdgcn_sched_barrier(0);
             GEMM_MATH_TAIL(wA, xA, kt)
-            if (kt + 2 * GEMM_U < kt1) {
-                GEMM_LOAD(wA, xA, kt + 2 * GEMM_U)
+            if (kt + 2 * GU < kt1) {
+                GEMM_LOAD(wA, xA, kt + 2 * GU)
                 __builtin_amdgcn_sched_barrier(0);
-                GEMM_MATH_TAIL(wB, xB, kt + GEMM_U)
-                GEMM_MATH_TAIL(wA, xA, kt + 2 * GEMM_U)
+                GEMM_MATH_TAIL(wB, xB, kt + GU)
+                GEMM_MATH_TAIL(wA, xA, kt + 2 * GU)
             } else {
-                GEMM_MATH_TAIL(wB, xB, kt + GEMM_U)
+                GEMM_MATH_TAIL(wB, xB, kt + GU)
             }
         } else {
             GEMM_MATH_TAIL(wA, xA, kt)
@@ -746,6 +752,7 @@ static void launch_gemm_mt(int epi, int R, int ksb, const bf16_t* Wp, const bf16
     GEMM_CASE(EPI_BF16, 2, 4)
     GEMM_CASE(EPI_SILU_MUL, 2, 1)
     GEMM_CASE(EPI_SILU_MUL, 2, 4)
+    if constexpr (MT <= 2) { GEMM_CASE(EPI_SILU_MUL, 4, 4) }
     GEMM_CASE(EPI_GELU_PACKED, 2, 4)
     GEMM_CASE(EPI_GELU_PACKED, 1, 4)
     GEMM_CASE(EPI_BF16, 1, 4)

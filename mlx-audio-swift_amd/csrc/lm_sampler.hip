@@ -21,6 +21,7 @@
 //   token = first i in K (index order) with prefix_K(E)_i > r
 #include "common.h"
 #include "lm_kernels.h"
+#include <vector>
 
 #define SAMP_NT 256
 #define ORPHEUS_AUDIO_OFFSET 128266
@@ -573,40 +574,63 @@ __global__ void __launch_bounds__(SN_NT) k_samp_narrow(SamplerParams p) {
 
 // ---- the whole sampler in ONE launch for the full vocabulary: SC_NB = 8 blocks of 1024 threads per row, SC_PER = 20 CONSECUTIVE ids
 // per thread (8 x 1024 x 20 = 163 840 >= 156 940), every e_i in registers - no [rows][Vpad] float scratch, no kernel boundaries.
-// The 8 blocks of a row meet at four row-local barriers (max | level-1 histogram | level-2 histogram | kept mass); everything they
-// exchange is an agent-scope atomic on both sides (the per-XCD L2s are not coherent with each other; 8-byte agent atomics on both sides
-// is one of the valid hand-off forms of MI355X_MICROARCH.md), so no fences are needed: a block drains its atomics (s_waitcnt vmcnt(0)),
-// syncs, and one thread arrives on the row's counter.  The counter only grows (4 x 8 per launch); a block derives the launch's base
-// from the value it reads at entry.  Spins are bounded: a row whose partner blocks never arrive (they are always co-resident: 256
-// blocks on 256 CUs) reports through c_fail instead of hanging.  Same integers as the six-kernel path (E, Z, thr, k*, Z_K, r are
-// exact), so the token is bit-identical to oracle/sampler.py.
+// The 8 blocks of a row meet at THREE row-local barriers:
+//   1  the block maxima                          -> row maximum
+//   2  the blocks' level-1 mass histograms       -> Z, threshold, the level-1 bin of the nucleus boundary
+//   3  the blocks' level-2 histograms inside that bin + each block's mass above the bin
+//                                                -> k*, and from the SAME slots the kept mass of every block (no fourth exchange)
+// Every block publishes into its OWN slot of the row's exchange area (256 eight-byte agent-scope stores per histogram - one coalesced
+// 2 KiB write-through instead of 256 read-modify-write atomics on a shared histogram) and nothing has to be zeroed afterwards: a slot
+// is overwritten by its owner before the barrier that lets anyone read it.  Everything exchanged is an 8-byte agent-scope atomic
+// store / load on both sides (the per-XCD L2s are not coherent with each other; that pairing is one of the valid hand-off forms of
+// MI355X_MICROARCH.md), so no fences are needed: a block drains its stores (s_waitcnt vmcnt(0)), syncs, and one thread arrives on
+// the row's counter.  The counter only grows (3 x 8 arrivals per launch); a block derives the launch's base from the value it reads
+// at entry.  Spins are bounded: a row whose partner blocks never arrive reports through c_fail instead of hanging - the host reads
+// the flags back after the decode loop (sampler_check_failed) and the launcher only picks this kernel when 8 x batch blocks fit the
+// device at once (sampler_cluster_fits).  Same integers as the six-kernel path (E, Z, thr, k*, Z_K, r are exact), so the token is
+// bit-identical to oracle/sampler.py.
+// (Round 3's version accumulated into shared histograms with agent atomics and met four times: 42.8 us per launch in the step chain.)
 #define SC_NB 8
 #define SC_NT 1024
 #define SC_PER 20
+#define SC_ARRIVALS 3
+static_assert(SC_NB == SAMP_CLUSTER_NB, "exchange slots per row (lm_kernels.h)");
 __device__ __forceinline__ u64 sc_load(const u64* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void sc_store(u64* p, u64 v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ unsigned sc_key32(float f) { const unsigned u = __float_as_uint(f); return (u & 0x80000000u) ? ~u : (u | 0x80000000u); }
 __device__ __forceinline__ float sc_unkey32(unsigned k) { return __uint_as_float((k & 0x80000000u) ? (k & 0x7fffffffu) : ~k); }
-// row barrier: all of this block's exchange atomics are performed, then one arrival; returns false on timeout
-__device__ __forceinline__ bool sc_row_barrier(unsigned int* sync, unsigned target) {
+__device__ __forceinline__ u64 wave_sum_u64(u64 v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const unsigned lo32 = __shfl_xor((unsigned)v, o, 64), hi32 = __shfl_xor((unsigned)(v >> 32), o, 64);
+        v += ((u64)hi32 << 32) | lo32;
+    }
+    return v;
+}
+// row barrier: all of this block's exchange stores are performed, then one arrival; returns false on timeout.
+// spin_limit: polls before giving up (a poll is ~0.1 us; tests force a tiny limit to exercise the failure path)
+__device__ __forceinline__ bool sc_row_barrier(unsigned int* sync, unsigned target, int spin_limit) {
     __shared__ int ok;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (threadIdx.x == 0) {
         __hip_atomic_fetch_add(sync, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         int good = 0;
-        for (int it = 0; it < (1 << 22); ++it) {
+        for (int it = 0; it < spin_limit; ++it) {
             if ((int)(__hip_atomic_load(sync, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - target) >= 0) { good = 1; break; }
-            __builtin_amdgcn_s_sleep(2);
+            __builtin_amdgcn_s_sleep(1);
         }
         ok = good;
     }
     __syncthreads();
     return ok != 0;
 }
-__global__ void __launch_bounds__(SC_NT) k_samp_cluster(SamplerParams p) {
+__global__ void __launch_bounds__(SC_NT) k_samp_cluster(SamplerParams p, int spin_limit) {
     __shared__ u64 hist[256];
     __shared__ u64 sh[SC_NT / 64];
     __shared__ u64 redk[SC_NT / 64];
+    __shared__ u64 part[4][SC_NB];
+    __shared__ u64 kept[SC_NB];
     __shared__ int pen_id[64];
     __shared__ float pen_val[64];
     __shared__ int n_pen;
@@ -624,8 +648,8 @@ __global__ void __launch_bounds__(SC_NT) k_samp_cluster(SamplerParams p) {
     unsigned base = 0;
     if (tid == 0) {
         const unsigned v = __hip_atomic_load(&sc->c_sync, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        base = v - (v % (4u * SC_NB));                       // < 8 arrivals of this launch can have happened before this block's first
-        redk[0] = base;                                      // barrier, so rounding down to a multiple of 32 gives the launch's base
+        base = v - (v % (unsigned)(SC_ARRIVALS * SC_NB));    // < 8 arrivals of this launch can have happened before this block's first
+        redk[0] = base;                                      // barrier, so rounding down to a multiple of 24 gives the launch's base
         n_pen = 0;
         s_token = lo < p.vocab ? lo : 0;
         s_bin = 255; s_below = 0;
@@ -694,17 +718,23 @@ __global__ void __launch_bounds__(SC_NT) k_samp_cluster(SamplerParams p) {
     if (tid == 0) {
         u64 m = 0;
         for (int w = 0; w < SC_NT / 64; ++w) m = redk[w] > m ? redk[w] : m;
-        __hip_atomic_store(&sc->c_max[c], m, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        sc_store(&sc->x_max[c], m);
     }
-    bool alive = sc_row_barrier(&sc->c_sync, base + 1u * SC_NB);
+    bool alive = sc_row_barrier(&sc->c_sync, base + 1u * SC_NB, spin_limit);
     u64 rowk = 0;
 #pragma unroll
-    for (int k = 0; k < SC_NB; ++k) { const u64 v = sc_load(&sc->c_max[k]); rowk = v > rowk ? v : rowk; }
+    for (int k = 0; k < SC_NB; ++k) { const u64 v = sc_load(&sc->x_max[k]); rowk = v > rowk ? v : rowk; }
     const float best = rowk ? sc_unkey32((unsigned)(rowk >> 32)) : -INFINITY;
     const int best_i = rowk ? (int)~(unsigned)rowk : 0x7fffffff;
-    if (p.temperature == 0.0f) {
-        if (tid == 0 && best_i != 0x7fffffff) s_token = best_i;
-    } else if (alive) {
+    u64 Zk = 0;
+    bool mine_blk = false;
+    if (p.temperature == 0.0f || !alive) {
+        // greedy (or a failed first barrier): the launch's remaining arrivals without waiting, block 0 does the bookkeeping
+        if (tid == 0) __hip_atomic_fetch_add(&sc->c_sync, (unsigned)(SC_ARRIVALS - 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (tid == 0 && alive && best_i != 0x7fffffff) s_token = best_i;
+        mine_blk = c == 0;
+        Zk = 1;
+    } else {
         // ---- e, E, keys
         const float xmax = __fdiv_rn(best, p.temperature);
         float e[SC_PER];
@@ -716,19 +746,23 @@ __global__ void __launch_bounds__(SC_NT) k_samp_cluster(SamplerParams p) {
             e[j] = (i >= lo && i < hi) ? det_exp_dev(y) : 0.0f;
             if ((j & 3) == 3) __builtin_amdgcn_sched_barrier(0);     // (twenty interleaved polynomial chains spill at 128 registers)
         }
-        unsigned kstar = 0;
-        if (p.top_p > 0.0f && p.top_p < 1.0f) {
-            // level 1: mass per key >> 8 (LDS, then one agent atomic per non-empty bin)
+        // level 1: this block's mass per key >> 8 -> its slot
 #pragma unroll
-            for (int j = 0; j < SC_PER; ++j) {
-                const u64 E = (u64)(e[j] * E_SCALE);
-                if (E) atomicAdd(&hist[__float_as_uint(e[j]) >> 24], E);
-            }
-            __syncthreads();
-            if (tid < 256 && hist[tid]) __hip_atomic_fetch_add(&sc->c_hist1[tid], hist[tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            alive = sc_row_barrier(&sc->c_sync, base + 2u * SC_NB) && alive;
+        for (int j = 0; j < SC_PER; ++j) {
+            const u64 E = (u64)(e[j] * E_SCALE);
+            if (E) atomicAdd(&hist[__float_as_uint(e[j]) >> 24], E);
+        }
+        __syncthreads();
+        if (tid < 256) sc_store(&sc->x_hist1[c][tid], hist[tid]);
+        alive = sc_row_barrier(&sc->c_sync, base + 2u * SC_NB, spin_limit) && alive;
+        u64 h1[SC_NB];
+        u64 mine = 0;
+#pragma unroll
+        for (int k = 0; k < SC_NB; ++k) { h1[k] = tid < 256 ? sc_load(&sc->x_hist1[k][tid]) : 0; mine += h1[k]; }
+        unsigned kstar = 0;
+        const bool nucleus = p.top_p > 0.0f && p.top_p < 1.0f;
+        if (nucleus) {
             u64 Z = 0;
-            u64 mine = tid < 256 ? sc_load(&sc->c_hist1[tid]) : 0;
             u64 incl = block_scan_incl_1024(mine, sh, &Z);
             const u64 thr = (u64)((double)(1.0f - p.top_p) * (double)Z);
             if (tid < 256 && incl > thr && incl - mine <= thr) { s_bin = (unsigned)tid; s_below = incl - mine; }      // unique crossing
@@ -736,37 +770,67 @@ __global__ void __launch_bounds__(SC_NT) k_samp_cluster(SamplerParams p) {
             __syncthreads();
             const unsigned bin1 = s_bin;
             const u64 below1 = s_below;
-            // level 2: mass per key & 255 inside bin1
+            // level 2: mass per key & 255 inside bin1, and everything above the bin (kept whatever k* turns out to be)
+            u64 above = 0;
 #pragma unroll
             for (int j = 0; j < SC_PER; ++j) {
                 const unsigned key = __float_as_uint(e[j]) >> 16;
                 const u64 E = (u64)(e[j] * E_SCALE);
                 if (E && (key >> 8) == bin1) atomicAdd(&hist[key & 255], E);
+                above += (key >> 8) > bin1 ? E : 0;
             }
+            above = wave_sum_u64(above);
+            if ((tid & 63) == 0) redk[tid >> 6] = above;
             __syncthreads();
-            if (tid < 256 && hist[tid]) __hip_atomic_fetch_add(&sc->c_hist2[tid], hist[tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (tid == 0) s_bin = 255;
-            alive = sc_row_barrier(&sc->c_sync, base + 3u * SC_NB) && alive;
-            mine = tid < 256 ? sc_load(&sc->c_hist2[tid]) : 0;
+            if (tid < 256) sc_store(&sc->x_hist2[c][tid], hist[tid]);
+            if (tid == 0) {
+                u64 t = 0;
+                for (int w = 0; w < SC_NT / 64; ++w) t += redk[w];
+                sc_store(&sc->x_above[c], t);
+                s_bin = 255;
+            }
+            alive = sc_row_barrier(&sc->c_sync, base + 3u * SC_NB, spin_limit) && alive;
+            u64 h2[SC_NB];
+            mine = 0;
+#pragma unroll
+            for (int k = 0; k < SC_NB; ++k) { h2[k] = tid < 256 ? sc_load(&sc->x_hist2[k][tid]) : 0; mine += h2[k]; }
             incl = block_scan_incl_1024(mine, sh, nullptr) + below1;
             if (tid < 256 && incl > thr && incl - mine <= thr) s_bin = (unsigned)tid;
             __syncthreads();
-            kstar = (bin1 << 8) | s_bin;
+            const unsigned bin2 = s_bin;
+            kstar = (bin1 << 8) | bin2;
+            // kept mass of every block: its mass above bin1 + its level-2 bins from k* up (threads 0..255 hold one bin of each block)
+            if (tid < 256) {
+#pragma unroll
+                for (int k = 0; k < SC_NB; ++k) {
+                    const u64 v = wave_sum_u64((unsigned)tid >= bin2 ? h2[k] : 0);
+                    if ((tid & 63) == 0) part[tid >> 6][k] = v;
+                }
+            }
+            __syncthreads();
+            if (tid < SC_NB) kept[tid] = part[0][tid] + part[1][tid] + part[2][tid] + part[3][tid] + sc_load(&sc->x_above[tid]);
         } else {
-            alive = sc_row_barrier(&sc->c_sync, base + 2u * SC_NB) && alive;      // keep the launch at four arrivals per block
-            alive = sc_row_barrier(&sc->c_sync, base + 3u * SC_NB) && alive;
+            if (tid == 0) __hip_atomic_fetch_add(&sc->c_sync, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // (three arrivals per block and launch)
+            if (tid < 256) {
+#pragma unroll
+                for (int k = 0; k < SC_NB; ++k) {
+                    const u64 v = wave_sum_u64(h1[k]);
+                    if ((tid & 63) == 0) part[tid >> 6][k] = v;
+                }
+            }
+            __syncthreads();
+            if (tid < SC_NB) kept[tid] = part[0][tid] + part[1][tid] + part[2][tid] + part[3][tid];
         }
+        __syncthreads();
+        u64 before = 0;
+#pragma unroll
+        for (int k = 0; k < SC_NB; ++k) { const u64 v = kept[k]; Zk += v; before += (k < c) ? v : 0; }
         // ---- kept mass in index order (consecutive ids per thread, consecutive threads, consecutive blocks), draw, inverse CDF
-        u64 mine = 0;
+        mine = 0;
 #pragma unroll
         for (int j = 0; j < SC_PER; ++j) mine += ((__float_as_uint(e[j]) >> 16) >= kstar) ? (u64)(e[j] * E_SCALE) : 0;
         u64 Zblk = 0;
         const u64 incl = block_scan_incl_1024(mine, sh, &Zblk);
-        if (tid == 0) __hip_atomic_store(&sc->c_mass[c], Zblk, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        alive = sc_row_barrier(&sc->c_sync, base + 4u * SC_NB) && alive;
-        u64 Zk = 0, before = 0;
-#pragma unroll
-        for (int k = 0; k < SC_NB; ++k) { const u64 v = sc_load(&sc->c_mass[k]); Zk += v; before += (k < c) ? v : 0; }
         const u64 row = (u64)(p.row_offset + b);
         const u64 a = p.seed ^ (0xD1B54A32D192ED03ull * (row + 1));
         const u64 rnd = mis_splitmix64(mis_splitmix64(a) + (u64)step);
@@ -783,27 +847,13 @@ __global__ void __launch_bounds__(SC_NT) k_samp_cluster(SamplerParams p) {
             }
         }
         // exactly one block of the row holds r (Z_K > 0 whenever the allowed range is not empty: the maximum has e = 1); that block
-        // does the bookkeeping below.  Every block leaves the exchange area the way it found it.
-        const bool mine_blk = r >= before && r < before + Zblk;
-        __syncthreads();
-        if (tid < 256) {          // (all 8 blocks have read both histograms before anyone passed barrier 4)
-            if (c == 0) { __hip_atomic_store(&sc->c_hist1[tid], 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                          __hip_atomic_store(&sc->c_hist2[tid], 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-        }
-        if (alive && !mine_blk && Zk) return;
-        if (alive && !Zk && c != 0) return;                   // empty range: block 0 reports the fallback token
+        // does the bookkeeping below.  (Zblk == kept[c]: the same integers summed two ways.)
+        mine_blk = r >= before && r < before + Zblk;
     }
     if (!alive) {                                             // a partner block never arrived: reported, block 0 emits the fallback token
         if (tid == 0) __hip_atomic_store(&sc->c_fail, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (c != 0) return;
-    }
-    if (p.temperature == 0.0f && alive) {
-        // greedy: the same four arrivals, then block 0 does the bookkeeping
-        (void)sc_row_barrier(&sc->c_sync, base + 2u * SC_NB);
-        (void)sc_row_barrier(&sc->c_sync, base + 3u * SC_NB);
-        (void)sc_row_barrier(&sc->c_sync, base + 4u * SC_NB);
-        if (c != 0) return;
-    }
+    } else if (Zk ? !mine_blk : c != 0) return;               // (empty range: block 0 reports the fallback token)
     __syncthreads();
     if (tid == 0) {      // bookkeeping of the generate loop (LlamaTTS.swift:721-738), as k_samp_pick
         const int token = s_token;
@@ -834,6 +884,31 @@ __global__ void __launch_bounds__(SC_NT) k_samp_cluster(SamplerParams p) {
 void sampler_scratch_init(SamplerScratch* scratch, int batch, hipStream_t s) {
     if (scratch && batch > 0) HIP_CHECK(hipMemsetAsync(scratch, 0, (size_t)batch * sizeof(SamplerScratch), s));
 }
+bool sampler_check_failed(SamplerScratch* scratch, int batch, hipStream_t s) {
+    if (!scratch || batch <= 0) return false;
+    std::vector<unsigned> f(batch, 0u);
+    HIP_CHECK(hipMemcpy2DAsync(f.data(), sizeof(unsigned), &scratch[0].c_fail, sizeof(SamplerScratch), sizeof(unsigned), (size_t)batch,
+                               hipMemcpyDeviceToHost, s));
+    HIP_CHECK(hipStreamSynchronize(s));
+    bool any = false;
+    for (unsigned v : f) any = any || v != 0;
+    if (any) {                                        // counters and flags back to the state a fresh scratch has
+        sampler_scratch_init(scratch, batch, s);
+        HIP_CHECK(hipStreamSynchronize(s));
+    }
+    return any;
+}
+// the one-launch sampler's 8 x batch blocks spin on each other: all of them have to be resident at once
+static bool sampler_cluster_fits(int batch) {
+    static const int capacity = [] {
+        int dev = 0, per_cu = 0;
+        hipDeviceProp_t prop{};
+        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_samp_cluster, SC_NT, 0) != hipSuccess) return 0;
+        return per_cu * prop.multiProcessorCount;
+    }();
+    return SC_NB * batch <= capacity;
+}
 
 void sampler_plan(int vocab, int* n_chunks, int* chunk_w) {
     int nc = (vocab + 4095) / 4096;
@@ -849,7 +924,7 @@ void launch_sampler(const SamplerParams& p, int batch, hipStream_t s) {
     MIS_REQUIRE(p.scratch && p.n_chunks >= 1 && p.n_chunks <= SAMP_MAX_CHUNKS && p.chunk_w > 0, MIS_ERR_GENERATION_FAILED,
                 "sampler scratch not configured");
     {   // narrow allowed range (every frame-constrained step; any static [lo, hi) of <= 4096 ids): the single-launch sampler
-        const char* ew = getenv("MIS_SAMPLER_WIDE");                     // A/B and parity tests (1: six kernels, 2: the one-launch cluster kernel)
+        const char* ew = getenv("MIS_SAMPLER_WIDE");                     // A/B and parity tests (non-zero: never the narrow kernel, and six kernels below)
         const bool wide_only = ew && atoi(ew) != 0;
         const int hi = (p.hi <= 0 || p.hi > p.vocab) ? p.vocab : p.hi, lo = p.lo < 0 ? 0 : p.lo;
         // frame_constrained 2: the frame range, but through the full-vocabulary kernels (every id visited, the masked ones get e = 0) -
@@ -863,9 +938,10 @@ void launch_sampler(const SamplerParams& p, int batch, hipStream_t s) {
     {   // full vocabulary in one launch (k_samp_cluster); MIS_SAMPLER_WIDE=1 keeps the six-kernel path (A/B, parity tests)
         const char* e6 = getenv("MIS_SAMPLER_WIDE");                     // (read per launch: the parity tests switch it in-process)
         const bool six = e6 && atoi(e6) != 0;
-        // (batch <= 32: 256 blocks, one per CU - the blocks of a row spin on each other and must be co-resident)
-        if (!six && !p.logits32 && p.penalty_flavor == 0 && p.vocab <= SC_NB * SC_NT * SC_PER && p.Vpad % 2 == 0 && p.ctx <= 64 && batch <= 32) {
-            hipLaunchKernelGGL(k_samp_cluster, dim3(SC_NB, batch), dim3(SC_NT), 0, s, p);
+        const char* es = getenv("MIS_SAMPLER_SPIN");                     // polls per row barrier before a block gives up (tests: the failure path)
+        const int spin = es && atoi(es) > 0 ? atoi(es) : (1 << 22);
+        if (!six && !p.logits32 && p.penalty_flavor == 0 && p.vocab <= SC_NB * SC_NT * SC_PER && p.Vpad % 2 == 0 && p.ctx <= 64 && sampler_cluster_fits(batch)) {
+            hipLaunchKernelGGL(k_samp_cluster, dim3(SC_NB, batch), dim3(SC_NT), 0, s, p, spin);
             return;
         }
     }

@@ -683,6 +683,8 @@ static void whisper_generate_impl(mis_whisper* c, const float* pcm, const int64_
     }
     if (gexec) (void)hipGraphExecDestroy(gexec);
     HIP_CHECK(hipGetLastError());
+    MIS_REQUIRE(!sampler_check_failed(c->scratch.p, batch, s), MIS_ERR_GENERATION_FAILED,
+                "sampler: a row barrier of the one-launch sampler timed out (its blocks were not co-resident); MIS_SAMPLER_WIDE=1 selects the multi-launch path");
     std::vector<int32_t> ng(batch), toks((size_t)batch * max_tokens);
     HIP_CHECK(hipMemcpy(ng.data(), c->n_gen.p, batch * 4, hipMemcpyDeviceToHost));
     HIP_CHECK(hipMemcpy(toks.data(), c->tokens_out.p, toks.size() * 4, hipMemcpyDeviceToHost));
