@@ -3,8 +3,9 @@
 batch 32 per GPU, bf16, synthetic weights + synthetic prompts (no checkpoints / datasets offline).
 
 A "step" = one full batched generate(): 32-token prompts -> prefill -> 672 decode steps with on-device
-sampling (T=0.6, top-p 0.8, repetition penalty 1.3 over 20 tokens; frame-constrained so that random
-weights emit valid SNAC frames - every vocabulary entry is still processed) -> parseOutput ->
+sampling (T=0.6, top-p 0.8, repetition penalty 1.3 over 20 tokens; all 156 940 vocabulary entries go through the
+sampler every step - the path of a real checkpoint - with the ids outside the step's SNAC frame slot given zero mass so that
+random weights emit valid frames: frame_constrained = 2) -> parseOutput ->
 de-interleave -> SNAC 24 kHz decode of 96 frames per row -> PCM resident in HBM (+ one RCCL all-gather of
 the PCM when N > 1, inside the library: mis_comm_all_gather_pcm).  Inputs are resident in HBM/host-pinned-free: prompts are 4 KiB.
 
@@ -178,7 +179,7 @@ def main():
     prompts = make_prompts(ROWS_PER_GPU, row0)
     flat, lens = lm._flatten(prompts)
     gp = mas.GenerateParameters(max_tokens=NEW_TOKENS, temperature=0.6, top_p=0.8, repetition_penalty=1.3,
-                                repetition_context_size=20, seed=2024, frame_constrained=True, row_offset=row0)
+                                repetition_context_size=20, seed=2024, frame_constrained=2, row_offset=row0)
     gpc = gp.to_c()
     import ctypes as C
     n_samples = codec.num_samples(NEW_TOKENS // 7)
@@ -231,23 +232,23 @@ def main():
     audio_s = float(alll.sum()) / 24000.0 * args.steps
     value = audio_s / elapsed
     timing = lm.last_timing()
-    # The timed region above is frame-constrained (random weights must emit valid SNAC frames for there to be audio to count): its
-    # sampler visits a 4096-id range per step (k_samp_narrow).  A real checkpoint decodes UNCONSTRAINED - the whole 156 940-id
-    # vocabulary goes through the sampler every step (k_samp_cluster).  frame_constrained = 2 runs exactly that code path (every id
-    # visited, masked ones get zero mass) while the tokens still form frames: the same generate is run once more that way and its
-    # decode time per step is reported next to the timed one.
-    unconstrained = None
+    # The timed region above sends the WHOLE 156 940-id vocabulary through the sampler every step (frame_constrained = 2: every id
+    # visited by k_samp_cluster, the ones outside the step's frame slot get zero mass - random weights must emit valid SNAC frames
+    # for there to be audio to count).  That is the code path of a real, unconstrained checkpoint.  A checkpoint-specific shortcut
+    # exists (frame_constrained = 1: only the 4096 ids of the slot are visited, k_samp_narrow); the same generate is run once more
+    # that way and reported beside the timed one as a secondary figure.
+    narrow = None
     if rank == 0:
-        gpu_ = mas.GenerateParameters(max_tokens=NEW_TOKENS, temperature=0.6, top_p=0.8, repetition_penalty=1.3,
-                                      repetition_context_size=20, seed=2024, frame_constrained=2, row_offset=row0)
-        gpu_c = gpu_.to_c()
+        gpn_ = mas.GenerateParameters(max_tokens=NEW_TOKENS, temperature=0.6, top_p=0.8, repetition_penalty=1.3,
+                                      repetition_context_size=20, seed=2024, frame_constrained=True, row_offset=row0)
+        gpn_c = gpn_.to_c()
         for _ in range(2):                                     # first call captures the step graph of this sampler path
-            st = L.mis_tts_generate_device(lm._h, flat.ctypes.data, lens.ctypes.data, ROWS_PER_GPU, C.byref(gpu_c), None,
+            st = L.mis_tts_generate_device(lm._h, flat.ctypes.data, lens.ctypes.data, ROWS_PER_GPU, C.byref(gpn_c), None,
                                            pcm.data_ptr(), n_samples, plens, ntok)
             if st != 0:
                 raise RuntimeError(mas._lib.last_error())
-        tu = lm.last_timing()
-        unconstrained = {"decode_ms": tu["decode_ms"], "step_ms": tu["step_ms_avg"], "tokens_per_row_min": int(min(ntok))}
+        tn = lm.last_timing()
+        narrow = {"decode_ms": tn["decode_ms"], "step_ms": tn["step_ms_avg"], "tokens_per_row_min": int(min(ntok))}
 
     result = None
     if rank == 0:
@@ -264,7 +265,7 @@ def main():
         # rocprofv3 runs, gfx950 corrections of MI355X_MICROARCH.md); tagged with the kernel source it was measured on, so a stale
         # figure is visible as such
         traffic, traffic_src = None, None
-        for cand in ("r03_pmc", "r02_pmc", "r01_pmc"):
+        for cand in ("r04_pmc", "r03_pmc", "r02_pmc", "r01_pmc"):
             try:
                 tj = json.load(open(os.path.join(ROOT, "profiles", cand, "traffic.json")))
                 traffic = tj["gate_up"]["hbm_bytes_per_launch"]
@@ -276,7 +277,7 @@ def main():
                 continue
         step_ms = timing["step_ms_avg"]
         step_GBps = timing["hbm_bytes_per_step"] / max(step_ms, 1e-9) / 1e6
-        roofline = {"bound": "hbm", "kernel": "k_gemm_skinny<MT=2,R=2,silu_mul,KSB=4> (gate+up, 100.7 MB/launch)",
+        roofline = {"bound": "hbm", "kernel": "k_gemm_skinny<MT=2,R=4,silu_mul,KSB=4,U=3> (gate+up, 100.7 MB/launch)",
                     "achieved": dom["GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": dom["GBps"] / HBM_PEAK_GBS,
                     "traffic": traffic, "traffic_source": traffic_src, "algorithmic_bytes": dom["bytes"],
                     "launch_us": dom["us"],
@@ -302,13 +303,15 @@ def main():
             "value_per_gpu": value / world,
             "phases_ms": {"prefill": timing["prefill_ms"], "decode": timing["decode_ms"], "codec": timing["codec_ms"],
                           "all_gather_rccl": (float(np.mean(gather_ms[-args.steps:])) if gather_ms else 0.0),
-                          "decode_unconstrained": unconstrained["decode_ms"] if unconstrained else None},
-            "sampler": {"timed_region": "frame-constrained: 4096-id range per step, k_samp_narrow (one launch)",
+                          "decode_frame_slot_sampler": narrow["decode_ms"] if narrow else None},
+            "sampler": {"timed_region": "full vocabulary: every one of the 156 940 ids visited by the sampler each step (k_samp_cluster, one "
+                                        "launch: the path of an unconstrained checkpoint; frame_constrained = 2 gives the ids outside the "
+                                        "step's frame slot zero mass so that the tokens form valid frames)",
                         "timed_step_ms": timing["step_ms_avg"],
-                        "full_vocabulary_step_ms": unconstrained["step_ms"] if unconstrained else None,
-                        "full_vocabulary": "the same generate with every one of the 156 940 ids visited by the sampler each step "
-                                           "(k_samp_cluster, one launch: the path of an unconstrained checkpoint; frame_constrained = 2 "
-                                           "keeps the tokens valid frames); tokens per row %s" % (unconstrained["tokens_per_row_min"] if unconstrained else None)},
+                        "frame_slot_step_ms": narrow["step_ms"] if narrow else None,
+                        "frame_slot": "secondary: the same generate with the sampler visiting only the 4096 ids of the step's frame slot "
+                                      "(k_samp_narrow, frame_constrained = 1 - a shortcut only a frame-locked checkpoint could take); "
+                                      "tokens per row %s" % (narrow["tokens_per_row_min"] if narrow else None)},
             "roofline": roofline, "cpu_baseline": cpu,
         }
         print(json.dumps(result))

@@ -58,6 +58,7 @@ struct mis_tts {
     int r_part = 1;                                 // n-tiles per work item of the split-K GEMMs
     int r_gu = 2;                                   // n-tiles per wave of gate+up (4 where that still fills the chip, see lm_reset)
     int ksb_part = 4, ksb_gu = 4, ksb_head = 1;     // waves per work item (in-block split-K), see k_gemm_skinny
+    GemmArr a_qkv, a_o, a_down, a_head;             // dense bf16 roles: the arrangement picked in lm_reset (gate+up: r_gu / ksb_gu)
     DevBuf<bf16_t> kcache, vtcache;
     DevBuf<float> rope_cos, rope_sin;
     DevBuf<int32_t> ids, pos_cur, pos_next;
@@ -74,7 +75,8 @@ struct mis_tts {
     DevBuf<int32_t> pf_pos;
     DevBuf<uint8_t> pf_on;
     DevBuf<SamplerScratch> samp_scratch;
-    hipGraphExec_t g_prefill = nullptr, g_decode = nullptr;
+    hipGraphExec_t g_prefill = nullptr, g_decode = nullptr, g_decode_n = nullptr;      // g_decode_n: graph_steps decode steps per launch
+    int graph_steps = 1;
     uint64_t graph_key = 0;
     bool use_graph = true;
     bool borrowed_stream = false;
@@ -137,6 +139,7 @@ extern "C" void mis_tts_destroy(mis_tts* c) {
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     if (c->g_prefill) (void)hipGraphExecDestroy(c->g_prefill);
     if (c->g_decode) (void)hipGraphExecDestroy(c->g_decode);
+    if (c->g_decode_n) (void)hipGraphExecDestroy(c->g_decode_n);
     if (c->stream && !c->borrowed_stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }
@@ -488,6 +491,7 @@ static int choose_split(int items, int KT, int ksb, const char* env, int s_max =
 static void destroy_graphs(mis_tts* c) {
     if (c->g_prefill) { (void)hipGraphExecDestroy(c->g_prefill); c->g_prefill = nullptr; }
     if (c->g_decode) { (void)hipGraphExecDestroy(c->g_decode); c->g_decode = nullptr; }
+    if (c->g_decode_n) { (void)hipGraphExecDestroy(c->g_decode_n); c->g_decode_n = nullptr; }
 }
 
 static void build_rope_tables(mis_tts* c) {
@@ -553,6 +557,38 @@ static void lm_reset(mis_tts* c, int batch, int max_context) {
     c->S_qkv = std::min(8, choose_split(c->Nqkv / 16 / c->r_part, d / 32, c->ksb_part, "MIS_S_QKV", 8));   // attention prologue: <= 8 slabs
     c->S_o = choose_split(d / 16 / c->r_part, HD / 32, c->ksb_part, "MIS_S_O");
     c->S_down = choose_split(d / 16 / c->r_part, c->ff / 32, c->ksb_part, "MIS_S_DOWN");
+    // Dense roles: (R, KSB, U, S) per role.  Defaults = what tools/gemm_lab measured at Orpheus-3B widths and 32 rows (profiles/r04/);
+    // four n-tiles per wave only up to 32 rows (8 accumulator tiles) and where the launch keeps every CU busy.  MIS_ARR_QKV / _O /
+    // _DOWN / _HEAD = "R,KSB,U[,S]" overrides one role (A/B).
+    {
+        const int mt = Mpad / 16;
+        auto pick = [&](const char* env, GemmArr dflt) {
+            const char* e = getenv(env);
+            GemmArr a = dflt;
+            if (e && *e) {
+                int r = 0, k = 0, u = 0, sp = 0;
+                const int n = sscanf(e, "%d,%d,%d,%d", &r, &k, &u, &sp);
+                if (n >= 3) { a.R = r; a.ksb = k; a.U = u; if (n >= 4 && sp >= 1) a.S = sp; }
+            }
+            if (a.R == 4 && mt > 2) a = dflt.R == 4 ? GemmArr{2, dflt.ksb == 2 ? 4 : dflt.ksb, 4, dflt.S} : dflt;
+            return a;
+        };
+        GemmArr q{c->r_part, c->ksb_part, 4, c->S_qkv}, o{c->r_part, c->ksb_part, 4, c->S_o}, dn{c->r_part, c->ksb_part, 4, c->S_down},
+            hd{2, c->ksb_head, 4, 1};
+        const bool tuned = env_int("MIS_ARR_TUNED", 1) != 0 && !getenv("MIS_R_PART") && !getenv("MIS_KSB_PART");
+        if (tuned && mt <= 2) {
+            // qkv: four n-tiles per wave, same K shares as before (bit-identical slabs): 8.51 -> 7.82 us
+            if ((c->Nqkv / 16) % 4 == 0 && (c->Nqkv / 16 / 4) * q.S >= 192 && c->ksb_part == 4) { q.R = 4; q.U = 2; }
+            // down projection: two waves per item (128-thread blocks) 11.8 -> 10.9 us in the lab, step 2.105 -> 2.082 ms (c2_ab.json)
+            if (c->ksb_part == 4 && c->ff / 32 >= 64) { dn.ksb = 2; }
+            // output projection of a big vocabulary: 173.5 -> 150.7 us (the four waves of a block split K)
+            if (!getenv("MIS_KSB_HEAD") && c->Vpad / 64 >= 1024) { hd.R = 4; hd.ksb = 4; hd.U = 3; }
+        }
+        c->a_qkv = pick("MIS_ARR_QKV", q); c->a_o = pick("MIS_ARR_O", o); c->a_down = pick("MIS_ARR_DOWN", dn); c->a_head = pick("MIS_ARR_HEAD", hd);
+        c->S_qkv = std::min(8, c->a_qkv.S); c->a_qkv.S = c->S_qkv;
+        c->S_o = std::min(8, c->a_o.S); c->a_o.S = c->S_o;
+        c->S_down = std::min(8, c->a_down.S); c->a_down.S = c->S_down;
+    }
     size_t kv = (size_t)c->L * batch * c->Hkv * Smax * c->D;
     c->kcache.alloc(kv);
     c->vtcache.alloc(kv);
@@ -575,15 +611,15 @@ static void lm_reset(mis_tts* c, int batch, int max_context) {
 static void gemm_qkv(mis_tts* c, size_t li, hipStream_t s) {
     if (c->q_qkv.on) launch_gemm_skinny_q(c->q_qkv.bits, EPI_PARTIAL, c->r_part, c->ksb_part, c->q_qkv.q.p + c->q_qkv.q_layer * li, c->q_qkv.sb.p + c->q_qkv.sb_layer * li,
                                           c->x.p, c->qkv_part.p, c->Nqkv / 16, c->d / 64, c->S_qkv, c->Nqkv, c->Mpad, s);
-    else launch_gemm_skinny(EPI_PARTIAL, c->r_part, c->ksb_part, c->wqkv.p + layer_qkv_elems(c) * li, c->x.p, c->qkv_part.p, c->Nqkv / 16, c->d / 32, c->S_qkv,
-                            c->Nqkv, c->Mpad, s);
+    else launch_gemm_skinny(EPI_PARTIAL, c->a_qkv.R, c->a_qkv.ksb, c->wqkv.p + layer_qkv_elems(c) * li, c->x.p, c->qkv_part.p, c->Nqkv / 16, c->d / 32, c->S_qkv,
+                            c->Nqkv, c->Mpad, s, nullptr, c->a_qkv.U);
 }
 static void gemm_o(mis_tts* c, size_t li, hipStream_t s) {
     const int HD = c->H * c->D;
     if (c->q_o.on) launch_gemm_skinny_q(c->q_o.bits, EPI_PARTIAL, c->r_part, c->ksb_part, c->q_o.q.p + c->q_o.q_layer * li, c->q_o.sb.p + c->q_o.sb_layer * li,
                                         c->attn_out.p, c->part.p, c->d / 16, HD / 64, c->S_o, c->d, c->Mpad, s);
-    else launch_gemm_skinny(EPI_PARTIAL, c->r_part, c->ksb_part, c->wo.p + layer_o_elems(c) * li, c->attn_out.p, c->part.p, c->d / 16, HD / 32, c->S_o, c->d,
-                            c->Mpad, s);
+    else launch_gemm_skinny(EPI_PARTIAL, c->a_o.R, c->a_o.ksb, c->wo.p + layer_o_elems(c) * li, c->attn_out.p, c->part.p, c->d / 16, HD / 32, c->S_o, c->d,
+                            c->Mpad, s, nullptr, c->a_o.U);
 }
 static void gemm_gate_up(mis_tts* c, size_t li, hipStream_t s) {
     if (c->q_gu.on) launch_gemm_skinny_q(c->q_gu.bits, EPI_SILU_MUL, 2, c->ksb_gu, c->q_gu.q.p + c->q_gu.q_layer * li, c->q_gu.sb.p + c->q_gu.sb_layer * li, c->x.p,
@@ -593,8 +629,8 @@ static void gemm_gate_up(mis_tts* c, size_t li, hipStream_t s) {
 static void gemm_down(mis_tts* c, size_t li, hipStream_t s) {
     if (c->q_down.on) launch_gemm_skinny_q(c->q_down.bits, EPI_PARTIAL, c->r_part, c->ksb_part, c->q_down.q.p + c->q_down.q_layer * li,
                                            c->q_down.sb.p + c->q_down.sb_layer * li, c->act.p, c->part.p, c->d / 16, c->ff / 64, c->S_down, c->d, c->Mpad, s);
-    else launch_gemm_skinny(EPI_PARTIAL, c->r_part, c->ksb_part, c->wdown.p + layer_down_elems(c) * li, c->act.p, c->part.p, c->d / 16, c->ff / 32, c->S_down,
-                            c->d, c->Mpad, s);
+    else launch_gemm_skinny(EPI_PARTIAL, c->a_down.R, c->a_down.ksb, c->wdown.p + layer_down_elems(c) * li, c->act.p, c->part.p, c->d / 16, c->ff / 32, c->S_down,
+                            c->d, c->Mpad, s, nullptr, c->a_down.U);
 }
 
 // embed -> L x block.  Leaves x = final-norm(h) ready for lm_head.   (LlamaTTS.swift:335-345,303-310)
@@ -636,8 +672,8 @@ static void enqueue_lm_head(mis_tts* c, const bf16_t* head = nullptr) {
                              c->Mpad, c->stream);
         return;
     }
-    launch_gemm_skinny(EPI_BF16, 2, c->ksb_head, head ? head : c->lm_head.p, c->x.p, c->logits.p, c->Vpad / 16, c->d / 32, 1,
-                       c->Vpad, c->Mpad, c->stream);
+    launch_gemm_skinny(EPI_BF16, c->a_head.R, c->a_head.ksb, head ? head : c->lm_head.p, c->x.p, c->logits.p, c->Vpad / 16, c->d / 32, 1,
+                       c->Vpad, c->Mpad, c->stream, nullptr, c->a_head.U);
 }
 
 // ---- the prompt in one pass per chunk of positions (LlamaTTS.swift:711; kernels and layout: lm_prefill.hip).  On return the K/V
@@ -948,10 +984,41 @@ extern "C" mis_status mis_sample_logits(int device, const float* logits, int bat
         l32.alloc((size_t)batch * Vpad);
         sp.penalty_flavor = 1; sp.top_p = 1.0f; sp.logits32 = l32.p;
     }
+    DevBuf<unsigned long long> dbg;
+    const bool want_dbg = getenv("MIS_SAMP_DBG") != nullptr;        // diagnostics: phase stamps of block (0, 0) on stderr (tools/samp_phases.py)
+    if (want_dbg) { dbg.alloc(16); dbg.zero(0); sp.dbg = dbg.p; }
     launch_sampler(sp, batch, 0);
     HIP_CHECK(hipGetLastError());
-    MIS_REQUIRE(!sampler_check_failed(scratch.p, batch, 0), MIS_ERR_GENERATION_FAILED,
-                "sampler: a row barrier of the one-launch sampler timed out (its blocks were not co-resident)");
+    if (want_dbg) {
+        hipEvent_t e0, e1;
+        HIP_CHECK(hipEventCreate(&e0)); HIP_CHECK(hipEventCreate(&e1));
+        HIP_CHECK(hipDeviceSynchronize());
+        HIP_CHECK(hipEventRecord(e0, 0));
+        for (int i = 0; i < 20; ++i) launch_sampler(sp, batch, 0);         // (stamps of the last launch stay; timing of 20 back to back)
+        HIP_CHECK(hipEventRecord(e1, 0));
+        HIP_CHECK(hipEventSynchronize(e1));
+        float ms = 0;
+        HIP_CHECK(hipEventElapsedTime(&ms, e0, e1));
+        unsigned long long st[16];
+        HIP_CHECK(hipMemcpy(st, dbg.p, sizeof(st), hipMemcpyDeviceToHost));
+        fprintf(stderr, "SAMP_DBG us_per_launch %.2f stamps", ms * 1e3 / 20);
+        for (int i = 0; i < 12; ++i) fprintf(stderr, " %llu", st[i] ? st[i] - st[0] : 0ull);
+        fprintf(stderr, "\n");
+        (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    }
+    if (sampler_check_failed(scratch.p, batch, 0)) {
+        // a row barrier of the one-launch sampler timed out (its 8 x batch blocks were not co-resident: another stream holds CUs).  This
+        // entry point owns its inputs, so it falls back instead of failing: fresh logits (the failed launch may have applied penalties
+        // in place), fresh scratch (sampler_check_failed re-initialised it), the multi-launch path
+        HIP_CHECK(hipMemset(lb.p, 0, (size_t)batch * Vpad * 2));
+        hipLaunchKernelGGL(k_f32_rows_to_bf16, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, 0, lf.p, vocab, lb.p, Vpad, batch);
+        if (ctx > 0) {                                      // (the failed launch's bookkeeping block slid the windows)
+            HIP_CHECK(hipMemcpy(win.p, window, (size_t)batch * ctx * 4, hipMemcpyDefault));
+            HIP_CHECK(hipMemcpy(wl.p, window_len, batch * 4, hipMemcpyDefault));
+        }
+        launch_sampler(sp, batch, 0, true);
+        HIP_CHECK(hipGetLastError());
+    }
     HIP_CHECK(hipMemcpy(tokens_out, toks.p, batch * 4, hipMemcpyDefault));
     MIS_API_END
 }
@@ -1098,7 +1165,9 @@ static void run_generate(mis_tts* c, const int32_t* prompt_ids, const int32_t* p
                               c->attn_out.p, c->act.p, c->logits.p, c->qkv_part.p, c->part.p, c->kcache.p, c->vtcache.p,
                               c->rope_cos.p, c->rope_sin.p, c->pos_cur.p, c->pos_next.p};
         mix(ptrs, sizeof(ptrs));
-        int ints[] = {batch, Lmax, max_tokens, c->Mpad, c->Smax, c->S_qkv, c->S_o, c->S_down, hidden_mode ? 1 : 0};
+        int ints[] = {batch, Lmax, max_tokens, c->Mpad, c->Smax, c->S_qkv, c->S_o, c->S_down, hidden_mode ? 1 : 0,
+                      c->a_qkv.R, c->a_qkv.ksb, c->a_qkv.U, c->a_o.R, c->a_o.ksb, c->a_o.U, c->a_down.R, c->a_down.ksb, c->a_down.U,
+                      c->a_head.R, c->a_head.ksb, c->a_head.U, c->r_gu, c->ksb_gu};
         mix(ints, sizeof(ints));
         const void* hp[] = {hidden_mode ? (const void*)hm->hidden->p : nullptr, hidden_mode ? (const void*)hid_count.p : nullptr};
         mix(hp, sizeof(hp));
@@ -1154,6 +1223,14 @@ static void run_generate(mis_tts* c, const int32_t* prompt_ids, const int32_t* p
     }
     // ---- decode loop (:714-744)
     if (c->use_graph && !c->g_decode) capture(&c->g_decode, decode_body);
+    // several steps per launch (MIS_GRAPH_STEPS = 2..8; default 1).  Between two hipGraphLaunch calls of the one-step graph the device
+    // idles for 8.2 us (rocprofv3 kernel trace, End of the last glue launch -> Start of the next step's lm_head, median of 2604 pairs;
+    // profiles/r04/c1_gaps.json) while kernels inside a graph follow each other without a gap - and yet eight steps per graph are
+    // SLOWER: 2.1047 against 2.0953 ms per step, five A/B runs on either side of it (profiles/r04/c2_ab.json); a 1376-node graph
+    // costs more per node than it saves at its seven removed seams.  Kept for the record and for other node counts; off by default.
+    c->graph_steps = std::max(1, std::min(env_int("MIS_GRAPH_STEPS", 1), 8));
+    if (c->use_graph && c->graph_steps > 1 && !c->g_decode_n)
+        capture(&c->g_decode_n, [&]() { for (int i = 0; i < c->graph_steps; ++i) decode_body(); });
     int steps = 0;
     const int poll = cb ? 8 : 32;
     std::vector<int32_t> host_ngen(batch, 0), host_tok;
@@ -1164,7 +1241,10 @@ static void run_generate(mis_tts* c, const int32_t* prompt_ids, const int32_t* p
     *done_host = 0;
     while (steps < max_tokens) {
         int chunk = std::min(poll, max_tokens - steps);
-        for (int i = 0; i < chunk; ++i) {
+        int i = 0;
+        if (c->use_graph && c->g_decode_n)
+            for (; i + c->graph_steps <= chunk; i += c->graph_steps) HIP_CHECK(hipGraphLaunch(c->g_decode_n, s));
+        for (; i < chunk; ++i) {
             if (c->use_graph) HIP_CHECK(hipGraphLaunch(c->g_decode, s)); else decode_body();
         }
         steps += chunk;

@@ -29,8 +29,11 @@ void launch_reduce_residual_rmsnorm(const float* slabs, int S, int Mpad, int N, 
 // ksb = 1: each wave an independent item; ksb = 4: the block's 4 waves split the item's K range (LDS combine)
 // bias (bf16 [N], optional): added once (slab 0 / final epilogue).  EPI_GELU_PACKED: T(gelu(T(xW+b))) written
 // in the packed fragment layout (it is the next GEMM's X operand).  EPI_SILU_PACKED: h = T(xW+b), T(h * T(sigmoid(h))) packed.
+// ksb = 2: 128-thread blocks, two waves per item.  U: k-tiles per register buffer (0: 4, or 3 at R = 4); R = 4 is built for <= 32 rows.
 void launch_gemm_skinny(int epi, int R, int ksb, const bf16_t* Wp, const bf16_t* X, void* out, int NT, int KT, int S,
-                        int N_out, int Mpad, hipStream_t s, const bf16_t* bias = nullptr);
+                        int N_out, int Mpad, hipStream_t s, const bf16_t* bias = nullptr, int U = 0);
+// one role's arrangement of the weight-streaming GEMM: n-tiles per wave, waves per item, k-tiles per register buffer, inter-block split
+struct GemmArr { int R = 2, ksb = 4, U = 4, S = 1; };
 
 // the same on MLX affine-quantised weights (lm_qgemm.hip): Qp packed codes, SB packed bf16 scale/bias pairs, G = K/64 scale groups
 void launch_gemm_skinny_q(int bits, int epi, int R, int ksb, const void* Qp, const bf16_t* SB, const bf16_t* X, void* out, int NT, int G,
@@ -135,5 +138,7 @@ struct SamplerParams {
     int lo, hi;              // allowed id range when not frame constrained (hi <= 0 -> vocab)
     int eos_id;
     int max_tokens;
+    unsigned long long* dbg; // diagnostics (null in the product): [16] s_memtime stamps of block (0, 0) of the one-launch sampler
 };
-void launch_sampler(const SamplerParams& p, int batch, hipStream_t s);
+// multi_launch_only: the six-kernel path whatever the range (the fall-back after a failed one-launch attempt, A/B)
+void launch_sampler(const SamplerParams& p, int batch, hipStream_t s, bool multi_launch_only = false);

@@ -20,6 +20,7 @@
 #include "common.h"
 #include <algorithm>
 #include <type_traits>
+#include <string>
 #include "lm_kernels.h"
 
 
@@ -593,13 +594,17 @@ __device__ __forceinline__ void gemm_epilogue(const f32x4_t (&acc)[R][MT], void*
 // (profiles/r02_gemm_nbuf_ab.json) - and the same kernel streams weights that already sit in the Infinity Cache only 3.5 % faster
 // than from HBM (profiles/r02_mall_probe.txt), so neither the memory nor the bytes in flight bound this launch; what is left is
 // its ramp-up and tail (the lm_head instance, 8x longer, reaches 5.8 TB/s with the same loop).
-template <int MT, int R, int EPI, int KSB>
-__global__ void __launch_bounds__(256, 2) k_gemm_skinny(const bf16_t* __restrict__ Wp, const bf16_t* __restrict__ X,
+// Round 4 (profiles/r04/gemm_lab_rows32.jsonl): the arrangement is a template parameter set - R n-tiles per wave, KSB waves per item
+// (1: four independent items per 256-thread block; 2 / 4: the block's waves split the item's K range), U k-tiles per register buffer.
+// Four n-tiles per wave halve the x fragments a wave re-reads out of L2 (as many bytes as the weights at two): gate+up 19.4 -> 17.6,
+// qkv 8.5 -> 7.8, the output projection 173.5 -> 150.7 us.
+template <int MT, int R, int EPI, int KSB, int U>
+__global__ void __launch_bounds__((KSB == 1 ? 4 : KSB) * 64, 2) k_gemm_skinny(const bf16_t* __restrict__ Wp, const bf16_t* __restrict__ X,
                                                      void* __restrict__ out, int NT, int KT, int S, int n_items,
                                                      int N_out, int Mpad, const bf16_t* __restrict__ bias) {
     static_assert(EPI != EPI_SILU_MUL || (R & 1) == 0, "silu-mul epilogue pairs a gate tile with an up tile");
-    // k-tiles per register buffer: 4, or 3 at four n-tiles per wave (4 would spill: 2 x 4 x (4 + 2) fragments + 32 accumulators)
-    constexpr int GU = R >= 4 ? 3 : GEMM_U;
+    // k-tiles per register buffer: 4 at R <= 2; 3 or 2 at four n-tiles per wave (4 would spill: 2 x 4 x (4 + 2) fragments + 32 accumulators)
+    constexpr int GU = U;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int item = (KSB == 1) ? blockIdx.x * 4 + wave : blockIdx.x;
     if (item >= n_items) return;                      // (KSB == 1: a wave of the last block may have no item)
@@ -734,41 +739,53 @@ __global__ void __launch_bounds__(256, 2) k_gemm_skinny(const bf16_t* __restrict
 }
 
 template <int MT>
-static void launch_gemm_mt(int epi, int R, int ksb, const bf16_t* Wp, const bf16_t* X, void* out, int NT, int KT, int S,
+static void launch_gemm_mt(int epi, int R, int ksb, int U, const bf16_t* Wp, const bf16_t* X, void* out, int NT, int KT, int S,
                            int N_out, int Mpad, const bf16_t* bias, hipStream_t s) {
     int n_items = ((NT + R - 1) / R) * S;
-    dim3 grid(ksb == 1 ? (n_items + 3) / 4 : n_items), block(256);
-#define GEMM_CASE(E, RR, KS)                                                                                  \
-    if (epi == E && R == RR && ksb == KS) {                                                                   \
-        hipLaunchKernelGGL((k_gemm_skinny<MT, RR, E, KS>), grid, block, 0, s, Wp, X, out, NT, KT, S, n_items,     \
+    dim3 grid(ksb == 1 ? (n_items + 3) / 4 : n_items), block((ksb == 1 ? 4 : ksb) * 64);
+#define GEMM_CASE(E, RR, KS, UU)                                                                              \
+    if (epi == E && R == RR && ksb == KS && U == UU) {                                                        \
+        hipLaunchKernelGGL((k_gemm_skinny<MT, RR, E, KS, UU>), grid, block, 0, s, Wp, X, out, NT, KT, S, n_items, \
                            N_out, Mpad, bias);                                                                    \
         return;                                                                                               \
     }
-    GEMM_CASE(EPI_PARTIAL, 1, 1)
-    GEMM_CASE(EPI_PARTIAL, 1, 4)
-    GEMM_CASE(EPI_PARTIAL, 2, 1)
-    GEMM_CASE(EPI_PARTIAL, 2, 4)
-    GEMM_CASE(EPI_BF16, 2, 1)
-    GEMM_CASE(EPI_BF16, 2, 4)
-    GEMM_CASE(EPI_SILU_MUL, 2, 1)
-    GEMM_CASE(EPI_SILU_MUL, 2, 4)
-    if constexpr (MT <= 2) { GEMM_CASE(EPI_SILU_MUL, 4, 4) }
-    GEMM_CASE(EPI_GELU_PACKED, 2, 4)
-    GEMM_CASE(EPI_GELU_PACKED, 1, 4)
-    GEMM_CASE(EPI_BF16, 1, 4)
-    GEMM_CASE(EPI_SILU_PACKED, 2, 4)
+    GEMM_CASE(EPI_PARTIAL, 1, 1, 4)
+    GEMM_CASE(EPI_PARTIAL, 1, 4, 4)
+    GEMM_CASE(EPI_PARTIAL, 2, 1, 4)
+    GEMM_CASE(EPI_PARTIAL, 2, 2, 4)
+    GEMM_CASE(EPI_PARTIAL, 2, 4, 4)
+    GEMM_CASE(EPI_BF16, 2, 1, 4)
+    GEMM_CASE(EPI_BF16, 2, 4, 4)
+    GEMM_CASE(EPI_SILU_MUL, 2, 1, 4)
+    GEMM_CASE(EPI_SILU_MUL, 2, 4, 4)
+    if constexpr (MT <= 2) {                       // four n-tiles per wave: 8 accumulator tiles, U <= 3 (no scratch up to 32 rows)
+        GEMM_CASE(EPI_SILU_MUL, 4, 4, 3)
+        GEMM_CASE(EPI_PARTIAL, 4, 4, 2)
+        GEMM_CASE(EPI_PARTIAL, 4, 4, 3)
+        GEMM_CASE(EPI_PARTIAL, 4, 2, 2)
+        GEMM_CASE(EPI_PARTIAL, 4, 2, 3)
+        GEMM_CASE(EPI_BF16, 4, 4, 3)
+        GEMM_CASE(EPI_BF16, 4, 4, 2)
+        GEMM_CASE(EPI_BF16, 4, 2, 3)
+    }
+    GEMM_CASE(EPI_GELU_PACKED, 2, 4, 4)
+    GEMM_CASE(EPI_GELU_PACKED, 1, 4, 4)
+    GEMM_CASE(EPI_BF16, 1, 4, 4)
+    GEMM_CASE(EPI_SILU_PACKED, 2, 4, 4)
 #undef GEMM_CASE
-    throw MisError(MIS_ERR_GENERATION_FAILED, "unsupported GEMM variant");
+    throw MisError(MIS_ERR_GENERATION_FAILED, "unsupported GEMM variant (epilogue " + std::to_string(epi) + ", R " + std::to_string(R) + ", KSB " +
+                                                  std::to_string(ksb) + ", U " + std::to_string(U) + ", " + std::to_string(Mpad) + " rows)");
 }
 
 void launch_gemm_skinny(int epi, int R, int ksb, const bf16_t* Wp, const bf16_t* X, void* out, int NT, int KT, int S,
-                        int N_out, int Mpad, hipStream_t s, const bf16_t* bias) {
+                        int N_out, int Mpad, hipStream_t s, const bf16_t* bias, int U) {
     MIS_REQUIRE(epi == EPI_PARTIAL || S == 1, MIS_ERR_GENERATION_FAILED, "split-K needs the partial epilogue");
+    if (U <= 0) U = R >= 4 ? 3 : GEMM_U;
     switch (Mpad / 16) {
-        case 1: launch_gemm_mt<1>(epi, R, ksb, Wp, X, out, NT, KT, S, N_out, Mpad, bias, s); break;
-        case 2: launch_gemm_mt<2>(epi, R, ksb, Wp, X, out, NT, KT, S, N_out, Mpad, bias, s); break;
-        case 3: launch_gemm_mt<3>(epi, R, ksb, Wp, X, out, NT, KT, S, N_out, Mpad, bias, s); break;
-        case 4: launch_gemm_mt<4>(epi, R, ksb, Wp, X, out, NT, KT, S, N_out, Mpad, bias, s); break;
+        case 1: launch_gemm_mt<1>(epi, R, ksb, U, Wp, X, out, NT, KT, S, N_out, Mpad, bias, s); break;
+        case 2: launch_gemm_mt<2>(epi, R, ksb, U, Wp, X, out, NT, KT, S, N_out, Mpad, bias, s); break;
+        case 3: launch_gemm_mt<3>(epi, R, ksb, U, Wp, X, out, NT, KT, S, N_out, Mpad, bias, s); break;
+        case 4: launch_gemm_mt<4>(epi, R, ksb, U, Wp, X, out, NT, KT, S, N_out, Mpad, bias, s); break;
         default: throw MisError(MIS_ERR_INVALID_INPUT, "batch per GPU must be <= 64");
     }
 }

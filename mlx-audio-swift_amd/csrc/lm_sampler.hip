@@ -594,6 +594,7 @@ __global__ void __launch_bounds__(SN_NT) k_samp_narrow(SamplerParams p) {
 #define SC_NT 1024
 #define SC_PER 20
 #define SC_ARRIVALS 3
+#define SC_STAMP(i) do { if (p.dbg && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) p.dbg[i] = __builtin_readcyclecounter(); } while (0)
 static_assert(SC_NB == SAMP_CLUSTER_NB, "exchange slots per row (lm_kernels.h)");
 __device__ __forceinline__ u64 sc_load(const u64* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ void sc_store(u64* p, u64 v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
@@ -638,6 +639,7 @@ __global__ void __launch_bounds__(SC_NT) k_samp_cluster(SamplerParams p, int spi
     __shared__ u64 s_below;
     __shared__ int s_token;
     const int c = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
+    SC_STAMP(0);
     if (row_skipped(p, b)) return;                           // (row-uniform: all 8 blocks of the row take the same exit)
     SamplerScratch* sc = p.scratch + b;
     const int step = row_step(p, b);
@@ -699,6 +701,7 @@ __global__ void __launch_bounds__(SC_NT) k_samp_cluster(SamplerParams p, int spi
             for (int j = 0; j < SC_PER; ++j) l[j] = (d == j) ? v : l[j];
         }
     }
+    SC_STAMP(1);                                             // logits loaded, penalties patched
     // ---- max (first index on ties) as one comparable 64-bit key: (order-preserving float key, ~index)
     u64 bestk = 0;
 #pragma unroll
@@ -720,7 +723,9 @@ __global__ void __launch_bounds__(SC_NT) k_samp_cluster(SamplerParams p, int spi
         for (int w = 0; w < SC_NT / 64; ++w) m = redk[w] > m ? redk[w] : m;
         sc_store(&sc->x_max[c], m);
     }
+    SC_STAMP(2);                                             // block maximum published
     bool alive = sc_row_barrier(&sc->c_sync, base + 1u * SC_NB, spin_limit);
+    SC_STAMP(3);                                             // barrier 1 passed
     u64 rowk = 0;
 #pragma unroll
     for (int k = 0; k < SC_NB; ++k) { const u64 v = sc_load(&sc->x_max[k]); rowk = v > rowk ? v : rowk; }
@@ -746,6 +751,7 @@ __global__ void __launch_bounds__(SC_NT) k_samp_cluster(SamplerParams p, int spi
             e[j] = (i >= lo && i < hi) ? det_exp_dev(y) : 0.0f;
             if ((j & 3) == 3) __builtin_amdgcn_sched_barrier(0);     // (twenty interleaved polynomial chains spill at 128 registers)
         }
+        SC_STAMP(4);                                         // e computed
         // level 1: this block's mass per key >> 8 -> its slot
 #pragma unroll
         for (int j = 0; j < SC_PER; ++j) {
@@ -753,12 +759,13 @@ __global__ void __launch_bounds__(SC_NT) k_samp_cluster(SamplerParams p, int spi
             if (E) atomicAdd(&hist[__float_as_uint(e[j]) >> 24], E);
         }
         __syncthreads();
+        SC_STAMP(5);                                         // level-1 histogram in LDS
         if (tid < 256) sc_store(&sc->x_hist1[c][tid], hist[tid]);
         alive = sc_row_barrier(&sc->c_sync, base + 2u * SC_NB, spin_limit) && alive;
-        u64 h1[SC_NB];
+        SC_STAMP(6);                                         // barrier 2 passed
         u64 mine = 0;
 #pragma unroll
-        for (int k = 0; k < SC_NB; ++k) { h1[k] = tid < 256 ? sc_load(&sc->x_hist1[k][tid]) : 0; mine += h1[k]; }
+        for (int k = 0; k < SC_NB; ++k) mine += tid < 256 ? sc_load(&sc->x_hist1[k][tid]) : 0;
         unsigned kstar = 0;
         const bool nucleus = p.top_p > 0.0f && p.top_p < 1.0f;
         if (nucleus) {
@@ -770,6 +777,7 @@ __global__ void __launch_bounds__(SC_NT) k_samp_cluster(SamplerParams p, int spi
             __syncthreads();
             const unsigned bin1 = s_bin;
             const u64 below1 = s_below;
+            SC_STAMP(7);                                     // slots read, level-1 scan done
             // level 2: mass per key & 255 inside bin1, and everything above the bin (kept whatever k* turns out to be)
             u64 above = 0;
 #pragma unroll
@@ -789,11 +797,12 @@ __global__ void __launch_bounds__(SC_NT) k_samp_cluster(SamplerParams p, int spi
                 sc_store(&sc->x_above[c], t);
                 s_bin = 255;
             }
+            SC_STAMP(8);                                     // level-2 histogram published
             alive = sc_row_barrier(&sc->c_sync, base + 3u * SC_NB, spin_limit) && alive;
-            u64 h2[SC_NB];
+            SC_STAMP(9);                                     // barrier 3 passed
             mine = 0;
 #pragma unroll
-            for (int k = 0; k < SC_NB; ++k) { h2[k] = tid < 256 ? sc_load(&sc->x_hist2[k][tid]) : 0; mine += h2[k]; }
+            for (int k = 0; k < SC_NB; ++k) mine += tid < 256 ? sc_load(&sc->x_hist2[k][tid]) : 0;
             incl = block_scan_incl_1024(mine, sh, nullptr) + below1;
             if (tid < 256 && incl > thr && incl - mine <= thr) s_bin = (unsigned)tid;
             __syncthreads();
@@ -803,7 +812,8 @@ __global__ void __launch_bounds__(SC_NT) k_samp_cluster(SamplerParams p, int spi
             if (tid < 256) {
 #pragma unroll
                 for (int k = 0; k < SC_NB; ++k) {
-                    const u64 v = wave_sum_u64((unsigned)tid >= bin2 ? h2[k] : 0);
+                    const u64 hv = sc_load(&sc->x_hist2[k][tid]);            // (read again: 16 registers less across the scan)
+                    const u64 v = wave_sum_u64((unsigned)tid >= bin2 ? hv : 0);
                     if ((tid & 63) == 0) part[tid >> 6][k] = v;
                 }
             }
@@ -811,10 +821,10 @@ __global__ void __launch_bounds__(SC_NT) k_samp_cluster(SamplerParams p, int spi
             if (tid < SC_NB) kept[tid] = part[0][tid] + part[1][tid] + part[2][tid] + part[3][tid] + sc_load(&sc->x_above[tid]);
         } else {
             if (tid == 0) __hip_atomic_fetch_add(&sc->c_sync, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // (three arrivals per block and launch)
-            if (tid < 256) {
+            if (tid < 256) {                                     // no nucleus cut: a block keeps all of its mass = the sum of its level-1 bins
 #pragma unroll
                 for (int k = 0; k < SC_NB; ++k) {
-                    const u64 v = wave_sum_u64(h1[k]);
+                    const u64 v = wave_sum_u64(sc_load(&sc->x_hist1[k][tid]));
                     if ((tid & 63) == 0) part[tid >> 6][k] = v;
                 }
             }
@@ -822,6 +832,7 @@ __global__ void __launch_bounds__(SC_NT) k_samp_cluster(SamplerParams p, int spi
             if (tid < SC_NB) kept[tid] = part[0][tid] + part[1][tid] + part[2][tid] + part[3][tid];
         }
         __syncthreads();
+        SC_STAMP(10);                                        // k* and every block's kept mass known
         u64 before = 0;
 #pragma unroll
         for (int k = 0; k < SC_NB; ++k) { const u64 v = kept[k]; Zk += v; before += (k < c) ? v : 0; }
@@ -849,6 +860,7 @@ __global__ void __launch_bounds__(SC_NT) k_samp_cluster(SamplerParams p, int spi
         // exactly one block of the row holds r (Z_K > 0 whenever the allowed range is not empty: the maximum has e = 1); that block
         // does the bookkeeping below.  (Zblk == kept[c]: the same integers summed two ways.)
         mine_blk = r >= before && r < before + Zblk;
+        SC_STAMP(11);                                        // draw located
     }
     if (!alive) {                                             // a partner block never arrived: reported, block 0 emits the fallback token
         if (tid == 0) __hip_atomic_store(&sc->c_fail, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -920,12 +932,12 @@ void sampler_plan(int vocab, int* n_chunks, int* chunk_w) {
     *chunk_w = cw;
 }
 
-void launch_sampler(const SamplerParams& p, int batch, hipStream_t s) {
+void launch_sampler(const SamplerParams& p, int batch, hipStream_t s, bool multi_launch_only) {
     MIS_REQUIRE(p.scratch && p.n_chunks >= 1 && p.n_chunks <= SAMP_MAX_CHUNKS && p.chunk_w > 0, MIS_ERR_GENERATION_FAILED,
                 "sampler scratch not configured");
     {   // narrow allowed range (every frame-constrained step; any static [lo, hi) of <= 4096 ids): the single-launch sampler
         const char* ew = getenv("MIS_SAMPLER_WIDE");                     // A/B and parity tests (non-zero: never the narrow kernel, and six kernels below)
-        const bool wide_only = ew && atoi(ew) != 0;
+        const bool wide_only = multi_launch_only || (ew && atoi(ew) != 0);
         const int hi = (p.hi <= 0 || p.hi > p.vocab) ? p.vocab : p.hi, lo = p.lo < 0 ? 0 : p.lo;
         // frame_constrained 2: the frame range, but through the full-vocabulary kernels (every id visited, the masked ones get e = 0) -
         // what bench.py times as the honest stand-in for a real checkpoint's unconstrained decode
@@ -937,9 +949,9 @@ void launch_sampler(const SamplerParams& p, int batch, hipStream_t s) {
     }
     {   // full vocabulary in one launch (k_samp_cluster); MIS_SAMPLER_WIDE=1 keeps the six-kernel path (A/B, parity tests)
         const char* e6 = getenv("MIS_SAMPLER_WIDE");                     // (read per launch: the parity tests switch it in-process)
-        const bool six = e6 && atoi(e6) != 0;
+        const bool six = multi_launch_only || (e6 && atoi(e6) != 0);
         const char* es = getenv("MIS_SAMPLER_SPIN");                     // polls per row barrier before a block gives up (tests: the failure path)
-        const int spin = es && atoi(es) > 0 ? atoi(es) : (1 << 22);
+        const int spin = es ? (atoi(es) > 0 ? atoi(es) : 0) : (1 << 22);                  // 0: every barrier times out at once
         if (!six && !p.logits32 && p.penalty_flavor == 0 && p.vocab <= SC_NB * SC_NT * SC_PER && p.Vpad % 2 == 0 && p.ctx <= 64 && sampler_cluster_fits(batch)) {
             hipLaunchKernelGGL(k_samp_cluster, dim3(SC_NB, batch), dim3(SC_NT), 0, s, p, spin);
             return;

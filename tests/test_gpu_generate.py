@@ -324,3 +324,28 @@ def test_full_vocabulary_sampler_paths_agree_inside_generate(monkeypatch):
     with pytest.raises(mas.AudioGenerationError) as e:         # unconstrained + random weights: no frame survives parseOutput (:754-756)
         lm.generate_batch(prompts, mas.GenerateParameters(max_tokens=14, temperature=0.6, top_p=0.8, repetition_penalty=1.3, seed=11))
     assert "No audio codes" in str(e.value)
+
+
+def test_one_launch_sampler_timeout_inside_generate_is_reported(monkeypatch):
+    """Inside the captured step graph there is nothing to fall back to: a timed-out row barrier of the one-launch sampler
+    (MIS_SAMPLER_SPIN=0: a block gives up without polling) is read back after the decode loop and raised as a generation failure
+    instead of returning tokens sampled from a half-exchanged state; the next generate on the same handle works."""
+    cfg = mas.LlamaTTSConfiguration(hidden_size=256, num_hidden_layers=2, intermediate_size=512, num_attention_heads=2,
+                                    num_key_value_heads=1, head_dim=128, vocab_size=156940, rope_theta=500000.0)
+    snac_cfg = mas.SNACConfig(**SNAC_SMALL)
+    from mlx_audio_swift_amd.synthetic import snac_synthetic_weights
+    codec = mas.SNAC.from_weights(snac_cfg, snac_synthetic_weights(snac_cfg, seed=1234))
+    lm = mas.LlamaTTSModel.synthetic(cfg, codec=codec, seed=77)
+    prompts = _prompts(np.random.default_rng(3), [9, 14, 6, 11, 8, 7, 12, 10])
+    gp = mas.GenerateParameters(max_tokens=21, temperature=0.6, top_p=0.8, repetition_penalty=1.3, seed=11, frame_constrained=2)
+    monkeypatch.setenv("MIS_SAMPLER_WIDE", "0")
+    _, want = lm.generate_batch(prompts, gp, return_tokens=True)
+    monkeypatch.setenv("MIS_SAMPLER_SPIN", "0")
+    gp2 = mas.GenerateParameters(max_tokens=28, temperature=0.6, top_p=0.8, repetition_penalty=1.3, seed=11, frame_constrained=2)   # (new budget: new graph)
+    with pytest.raises(mas.AudioGenerationError) as e:
+        lm.generate_batch(prompts, gp2, return_tokens=True)
+    assert "row barrier" in str(e.value)
+    monkeypatch.delenv("MIS_SAMPLER_SPIN")
+    _, again = lm.generate_batch(prompts, gp, return_tokens=True)
+    for a, b in zip(want, again):
+        assert np.array_equal(a, b)

@@ -110,3 +110,23 @@ def test_full_vocabulary_single_launch_sampler_bit_exact(temp, top_p, pen, monke
         ref = _oracle_tokens(logits, window, wl, p, step, lo, hi)
         assert np.array_equal(got, ref), (step, np.nonzero(got != ref)[0], got[:8], ref[:8])
         assert np.array_equal(six, ref), step
+
+
+def test_one_launch_sampler_timeout_falls_back_to_the_multi_launch_path(monkeypatch):
+    """The one-launch sampler's 8 blocks of a row wait for each other; MIS_SAMPLER_SPIN=0 lets a block give up without a single poll,
+    which is what a row whose partner blocks are not resident (another stream holding the CUs) looks like.  The failed rows raise
+    c_fail; the stand-alone entry point owns its inputs and falls back (fresh logits and windows, re-initialised exchange area,
+    six-kernel path): the tokens are still the oracle's.  A later call on the default limit works again (nothing is left dirty)."""
+    rng = np.random.default_rng(41)
+    V, B, ctx = 156940, 32, 20
+    logits = bf16_round((rng.standard_normal((B, V)) * 2.0).astype(np.float32))
+    window = rng.integers(0, V, (B, ctx)).astype(np.int32)
+    wl = np.full(B, 20, np.int32)
+    p = mas.GenerateParameters(temperature=0.6, top_p=0.8, repetition_penalty=1.3, seed=99, row_offset=3)
+    ref = _oracle_tokens(logits, window, wl, p, 4)
+    monkeypatch.setenv("MIS_SAMPLER_WIDE", "0")
+    monkeypatch.setenv("MIS_SAMPLER_SPIN", "0")
+    got = sample_logits(logits, window, wl, p, 4)
+    assert np.array_equal(got, ref)
+    monkeypatch.delenv("MIS_SAMPLER_SPIN")
+    assert np.array_equal(sample_logits(logits, window, wl, p, 4), ref)

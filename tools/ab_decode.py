@@ -24,7 +24,7 @@ for name, env in variants:
         j = json.loads(r.stdout.strip().splitlines()[-1])
         row = {"name": name, "env": env, "value": round(j["value"], 2), "decode_ms": round(j["phases_ms"]["decode"], 2),
                "prefill_ms": round(j["phases_ms"]["prefill"], 2), "codec_ms": round(j["phases_ms"]["codec"], 2),
-               "step_ms": round(j["roofline"]["step"]["ms"], 4),
+               "step_ms": round(j["roofline"]["step"]["ms"], 4), "frame_slot_step_ms": j["sampler"].get("frame_slot_step_ms"),
                "kernels_us": {k: v["us"] for k, v in j["roofline"]["kernels"].items()}}
     except Exception as ex:                                       # keep going: one broken variant must not lose the others
         row = {"name": name, "env": env, "error": repr(ex), "stderr": r.stderr[-600:], "stdout": r.stdout[-300:]}

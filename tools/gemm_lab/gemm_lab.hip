@@ -20,6 +20,7 @@
 #include <math.h>
 #include <string.h>
 #include <vector>
+#include <algorithm>
 
 #include "common.h"
 #include "lm_kernels.h"
@@ -239,7 +240,9 @@ struct Ctx {
     size_t wn, on;
     bf16_t *W, *X, *zero;
     float *O0, *O1;
-    std::vector<float> ref, got;
+    std::vector<float> ref, got, ref_sum;
+    int Smax = 8;
+    bool sweep_S = false;
     hipStream_t s;
 };
 
@@ -266,45 +269,60 @@ static double max_rel_diff(const std::vector<float>& a, const std::vector<float>
     return scale > 0 ? worst / scale : worst;
 }
 
-static void report(const Ctx& c, const char* variant, double us, double err) {
+static void report(const Ctx& c, const char* variant, int S, double us, double err) {
     const double mb = (double)c.wn * 2 / 1e6;
     printf("{\"shape\": \"%s\", \"N\": %d, \"K\": %d, \"S\": %d, \"rows\": %d, \"variant\": \"%s\", \"us\": %.2f, \"MB\": %.2f, \"GBps\": %.1f, "
-           "\"max_rel_vs_product\": %.3g}\n", c.sh.name, c.sh.N, c.sh.K, c.sh.S, c.rows, variant, us, mb, mb / us * 1e3, err);
+           "\"max_rel_vs_product\": %.3g}\n", c.sh.name, c.sh.N, c.sh.K, S, c.rows, variant, us, mb, mb / us * 1e3, err);
     fflush(stdout);
 }
 
-// one launch on weight copy `layer`, checked once against the product's output, then timed
+// sum of the S float32 slabs [S][Mpad][N] in slab order (what the consumer's prologue computes)
+static void slab_sum(const std::vector<float>& slabs, int S, size_t mn, std::vector<float>& out) {
+    out.assign(mn, 0.0f);
+    for (int s = 0; s < S; ++s)
+        for (size_t i = 0; i < mn; ++i) out[i] += slabs[(size_t)s * mn + i];
+}
+// one launch on weight copy `layer`, checked once against the product's output (sum over the split-K slabs: variants may use another
+// S than the product), then timed
 template <typename L>
-static void check_and_time(Ctx& c, const char* label, L&& launch) {
-    LAB_CHECK(hipMemsetAsync(c.O1, 0, c.on * 4, c.s));
+static void check_and_time(Ctx& c, const char* label, int S, L&& launch) {
+    const size_t mn = (size_t)c.Mpad * c.sh.N;
+    LAB_CHECK(hipMemsetAsync(c.O1, 0, mn * S * 4, c.s));
     launch(0);
     LAB_CHECK(hipGetLastError());
-    LAB_CHECK(hipMemcpyAsync(c.got.data(), c.O1, c.on * 4, hipMemcpyDeviceToHost, c.s));
+    c.got.resize(mn * S);
+    LAB_CHECK(hipMemcpyAsync(c.got.data(), c.O1, mn * S * 4, hipMemcpyDeviceToHost, c.s));
     LAB_CHECK(hipStreamSynchronize(c.s));
-    const double err = max_rel_diff(c.got, c.ref);
-    report(c, label, time_launches(launch, c.iters, c.s), err);
+    std::vector<float> gs;
+    slab_sum(c.got, S, mn, gs);
+    const double err = max_rel_diff(gs, c.ref_sum);
+    report(c, label, S, time_launches(launch, c.iters, c.s), err);
 }
 
 template <int MT, int R, int KSB, int U>
-static void run_stream(Ctx& c) {
-    const int S = c.sh.S, n_items = ((c.NT + R - 1) / R) * S;
+static void run_stream(Ctx& c, int S = 0) {
+    if (S <= 0) S = c.sh.S;
+    if (S > c.Smax || c.KT / (S * KSB) < 1) return;
+    const int n_items = ((c.NT + R - 1) / R) * S;
     const dim3 grid(KSB == 1 ? (n_items + 3) / 4 : n_items), block((KSB == 1 ? 4 : KSB) * 64);
     char label[96];
-    snprintf(label, sizeof label, "stream R%d KSB%d U%d", R, KSB, U);
-    check_and_time(c, label, [&](int i) {
+    snprintf(label, sizeof label, "stream R%d KSB%d U%d S%d", R, KSB, U, S);
+    check_and_time(c, label, S, [&](int i) {
         hipLaunchKernelGGL((k_lab_stream<MT, R, KSB, U>), grid, block, 0, c.s, c.W + (size_t)(i % c.L) * c.wn, c.X, c.O1, c.NT, c.KT, S, n_items,
                            c.sh.N, c.Mpad);
     });
 }
 
 template <int MT, int R, int KSB, int UK>
-static void run_oneshot(Ctx& c) {
-    const int S = c.sh.S, n_items = ((c.NT + R - 1) / R) * S;
+static void run_oneshot(Ctx& c, int S = 0) {
+    if (S <= 0) S = c.sh.S;
+    if (S > c.Smax) return;
+    const int n_items = ((c.NT + R - 1) / R) * S;
     const int share = ((c.KT + S - 1) / S + KSB - 1) / KSB;         // k-tiles of the longest wave share
-    if (share > UK) return;
+    if (share > UK || share < 1) return;
     char label[96];
-    snprintf(label, sizeof label, "one-shot R%d KSB%d UK%d", R, KSB, UK);
-    check_and_time(c, label, [&](int i) {
+    snprintf(label, sizeof label, "one-shot R%d KSB%d UK%d S%d", R, KSB, UK, S);
+    check_and_time(c, label, S, [&](int i) {
         hipLaunchKernelGGL((k_lab_oneshot<MT, R, KSB, UK>), dim3(n_items), dim3(KSB * 64), 0, c.s, c.W + (size_t)(i % c.L) * c.wn, c.X, c.zero, c.O1,
                            c.NT, c.KT, S, n_items, c.sh.N, c.Mpad);
     });
@@ -319,7 +337,8 @@ static void run_shape(Ctx& c) {
     LAB_CHECK(hipStreamSynchronize(c.s));
     char label[96];
     snprintf(label, sizeof label, "product k_gemm_skinny R2 KSB%d", sh.ksb_ref);
-    report(c, label, time_launches([&](int i) {
+    slab_sum(c.ref, sh.S, (size_t)c.Mpad * sh.N, c.ref_sum);
+    report(c, label, sh.S, time_launches([&](int i) {
                launch_gemm_skinny(EPI_PARTIAL, 2, sh.ksb_ref, c.W + (size_t)(i % c.L) * c.wn, c.X, c.O0, c.NT, c.KT, sh.S, sh.N, c.Mpad, c.s); },
                c.iters, c.s), 0.0);
     if (sh.ksb_ref == 1) {                            // output projection: one wave per item, long K shares
@@ -329,6 +348,26 @@ static void run_shape(Ctx& c) {
         run_stream<MT, 8, 1, 1>(c);
         run_stream<MT, 4, 2, 3>(c);
         run_stream<MT, 4, 4, 3>(c);
+        run_stream<MT, 4, 4, 2>(c);
+        run_stream<MT, 4, 8, 3>(c);
+        run_stream<MT, 2, 4, 4>(c);
+        run_stream<MT, 2, 2, 4>(c);
+        return;
+    }
+    if (c.sweep_S) {                                  // round 4: the split factor together with the arrangement (profiles/r04/)
+        for (int S = 1; S <= 8; ++S) {
+            if (S == 5 || S == 7) continue;
+            run_stream<MT, 2, 4, 4>(c, S);
+            run_stream<MT, 2, 2, 4>(c, S);
+            run_stream<MT, 4, 4, 3>(c, S);
+            run_stream<MT, 4, 4, 2>(c, S);
+            run_stream<MT, 4, 2, 3>(c, S);
+            run_stream<MT, 4, 2, 2>(c, S);
+            run_oneshot<MT, 2, 4, 8>(c, S);
+            run_oneshot<MT, 2, 2, 8>(c, S);
+            run_oneshot<MT, 4, 4, 6>(c, S);
+            run_oneshot<MT, 4, 2, 6>(c, S);
+        }
         return;
     }
     run_stream<MT, 2, 4, 4>(c);                       // the product's shape (scalar wave index)
@@ -369,7 +408,8 @@ int main(int argc, char** argv) {
         if (only && strcmp(only, sh.name)) continue;
         Ctx c;
         c.sh = sh; c.rows = rows; c.Mpad = Mpad; c.iters = iters; c.L = L; c.NT = sh.N / 16; c.KT = sh.K / 32; c.s = s; c.zero = zero;
-        c.wn = (size_t)sh.N * sh.K; c.on = (size_t)sh.S * Mpad * sh.N;
+        c.sweep_S = getenv("LAB_SWEEP_S") != nullptr && sh.ksb_ref != 1 && strncmp(sh.name, "q3", 2) != 0;
+        c.wn = (size_t)sh.N * sh.K; c.on = (size_t)std::max(sh.S, c.Smax) * Mpad * sh.N;
         const size_t xn = (size_t)Mpad * sh.K;
         LAB_CHECK(hipMalloc(&c.W, c.wn * 2 * L)); LAB_CHECK(hipMalloc(&c.X, xn * 2));
         LAB_CHECK(hipMalloc(&c.O0, c.on * 4)); LAB_CHECK(hipMalloc(&c.O1, c.on * 4));
