@@ -111,6 +111,114 @@ def cpu_baseline(snac_cfg_dict):
             "lm_head_s_median": med_head, "snac_s_per_1024ms": t_snac, "host_cores_available": int(avail)}
 
 
+def _lm_weight_elems(cfg):
+    """Elements of one decoder layer's four matrices (qkv, o, gate|up, down) of a Llama/Qwen3-style LM configuration."""
+    d, ff, hd = cfg.hidden_size, cfg.intermediate_size, cfg.head_dim
+    H, Hkv = cfg.num_attention_heads, cfg.num_key_value_heads
+    return (H + 2 * Hkv) * hd * d + d * H * hd + 2 * ff * d + d * ff
+
+
+def secondary_benches(device):
+    """The other single-GPU BASELINE configurations, run once each AFTER the timed region (not part of `value`): one GPU's share of
+    configs[3] (Whisper-large-v3, 8 x 30 s windows) and of configs[4] (Qwen3-TTS-0.6B as the 8-bit checkpoint, batch 32, streaming), and
+    configs[1] (Soprano-80M, batch 1).  Metric as the reference's CLI defines it (audio duration / wall time of the generate call,
+    Sources/Tools/mlx-audio-swift-tts/App.swift:168-211).  Synthetic weights of the real dimensions; each figure is the better of two
+    runs after one warm-up (graph capture, allocations).  `roofline` per entry: the bound of its dominant phase, algorithmic count /
+    time / peak (2500 TFLOP/s dense bf16 MFMA, 8000 GB/s HBM; MI355X_MICROARCH.md)."""
+    import mlx_audio_swift_amd as mas
+    from mlx_audio_swift_amd.synthetic import mlx_affine_quantize, qwen3tts_synthetic_weights
+    out = {}
+    rng = np.random.default_rng(0)
+    # ---- configs[3]: Whisper-large-v3, 8 windows of 30 s (mel -> encoder -> 4-token prompt + 96 greedy decode steps, EOT out of reach)
+    t_begin = time.perf_counter()
+    wcfg = mas.WhisperConfig(vocab_size=51866, num_mel_bins=128, d_model=1280, encoder_layers=32, encoder_attention_heads=20,
+                             encoder_ffn_dim=5120, decoder_layers=32, decoder_attention_heads=20, decoder_ffn_dim=5120)
+    wm = mas.WhisperModel.synthetic(wcfg, device=device, seed=777)
+    wins = [(0.1 * rng.standard_normal(480000)).astype(np.float32) for _ in range(8)]
+    sgp = mas.STTGenerateParameters(max_tokens=96, temperature=0.0, eot_id=-1, timestamp_begin=50365)
+    feats = mas.dsp.whisper_encoder_features(np.stack(wins), 128)
+    t_enc = t_all = 1e9
+    for rep in range(3):
+        t0 = time.perf_counter(); wm.encode(feats, want_output=False); t_enc = min(t_enc, time.perf_counter() - t0) if rep else t_enc
+        t0 = time.perf_counter(); ids = wm.transcribe_windows(wins, [50258, 50259, 50360, 50364], sgp); t_all = min(t_all, time.perf_counter() - t0) if rep else t_all
+    # encoder FLOPs per window: 32 layers x (4 d^2 + 2 d ffn) x 2 x 1500 positions + attention 2 x 2 x 1500^2 x d per layer + the two convolutions
+    d_, f_, T_ = 1280, 5120, 1500
+    enc_flops = 8 * (32 * ((4 * d_ * d_ + 2 * d_ * f_) * 2 * T_ + 4 * T_ * T_ * d_) + 2 * 3 * 128 * d_ * 3000 + 2 * 3 * d_ * d_ * T_)
+    out["whisper_large_v3_8x30s"] = {
+        "config": "BASELINE configs[3], one GPU's share: Whisper-large-v3 bf16, 8 x 30 s windows, mel + encoder + 4-token prompt + 96 decode steps",
+        "audio_s_per_s": 240.0 / t_all, "ms": t_all * 1e3, "encode_ms": t_enc * 1e3, "tokens_per_window": int(len(ids[0])),
+        "roofline": {"bound": "mfma", "phase": "encoder (32 layers, 8 x 1500 positions)", "achieved": enc_flops / t_enc / 1e12, "peak": 2500.0,
+                     "unit": "TFLOP/s", "frac": enc_flops / t_enc / 1e12 / 2500.0}}
+    wm.close()
+    del wm
+    # ---- configs[1]: Soprano-80M, batch 1, 24-token prompt, 64 new tokens ([STOP] out of reach) -> Vocos / ISTFT decoder
+    scfg = mas.SopranoConfiguration(stop_token_id=-1)
+    sm = mas.SopranoModel.synthetic(scfg, device=device, seed=4321)
+    srow = [rng.integers(4, 8000, 24).astype(np.int32)]
+    gps = mas.GenerateParameters(max_tokens=64, temperature=0.7, top_p=0.95, repetition_penalty=1.5, repetition_context_size=30, seed=7, sampler_flavor=1)
+    best = 1e9
+    for rep in range(3):
+        t0 = time.perf_counter(); pcm_s = sm.generate_batch(srow, gps); dt = time.perf_counter() - t0
+        best = min(best, dt) if rep else best
+    lmc = scfg.lm_configuration()
+    sop_bytes = 2.0 * (lmc.num_hidden_layers * _lm_weight_elems(lmc) + lmc.vocab_size * lmc.hidden_size)      # bf16 weights streamed per token
+    out["soprano_80m_b1"] = {
+        "config": "BASELINE configs[1]: Soprano-80M bf16 LM + f32 Vocos/ISTFT decoder, batch 1, 24-token prompt, 64 new tokens",
+        "audio_s_per_s": len(pcm_s[0]) / scfg.sample_rate / best, "ms": best * 1e3, "ms_per_token": best * 1e3 / 64,
+        "roofline": {"bound": "hbm", "phase": "decode step (LM weights streamed once per token; the whole generate call is the denominator)",
+                     "achieved": sop_bytes * 64 / best / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": sop_bytes * 64 / best / 1e9 / HBM_PEAK_GBS}}
+    del sm
+    # ---- configs[4]: Qwen3-TTS-0.6B as the 8-bit checkpoint (MLX affine, group 64, streamed natively), batch 32, 100 frames (8 s) per row,
+    # generateStream with streaming_interval 2.0 s (the speech-tokenizer decoder runs on a second stream while the frame loop goes on)
+    qcfg = mas.Qwen3TTSConfiguration(codec_eos_token_id=3071)
+    qm = mas.Qwen3TTSModel(qcfg, device)
+    for name, arr in qwen3tts_synthetic_weights(qcfg):
+        if arr.ndim == 2 and not name.startswith("decoder.") and arr.shape[1] % 64 == 0:
+            wq, sc, bi = mlx_affine_quantize(arr, 64, 8)
+            qm.set_quantized_tensor(name, wq, sc, bi, 64, 8)
+        else:
+            qm.set_tensor(name, arr)
+    qm.finalize()
+    prompts = []
+    for b in range(32):
+        text = rng.integers(0, 151000, 24)
+        t = list(text[:3]) + [qcfg.tts_pad_token_id] * 3 + [qcfg.tts_bos_token_id] + [int(text[3])]
+        c = [-1, -1, -1, qcfg.codec_nothink_id, qcfg.codec_think_bos_id, qcfg.codec_think_eos_id, qcfg.codec_pad_id, qcfg.codec_bos_id]
+        prompts.append(mas.PreparedPrompt(np.asarray(t, np.int32), np.asarray(c, np.int32), np.asarray(list(text[4:]) + [qcfg.tts_eos_token_id], np.int32), 0))
+    FR = 100
+    qgp = mas.Qwen3TTSGenerateParameters(max_tokens=FR, temperature=0.9, top_k=50, repetition_penalty=1.05, seed=9)
+    t_codes = t_stream = 1e9
+    t_first_best = None
+    for rep in range(3):
+        t0 = time.perf_counter(); qm.generate_codes(prompts, qgp); dt = time.perf_counter() - t0
+        t_codes = min(t_codes, dt) if rep else t_codes
+        t0 = time.perf_counter(); t_first = None; samples = 0
+        for ev in qm.generate_stream_batch(prompts, qgp, streaming_interval=2.0):
+            if isinstance(ev, mas.AudioEvent):
+                if t_first is None:
+                    t_first = time.perf_counter() - t0
+                samples += len(ev.audio)
+        dt = time.perf_counter() - t0
+        if rep and dt < t_stream:
+            t_stream, t_first_best = dt, t_first
+    # weight bytes of one frame at 8 bit (1 byte per code + 4 bytes of bf16 scale and bias per 64 codes): the talker's 28 layers + its
+    # codec head once, the code predictor's 5 layers + one of its 15 heads for each of the 15 remaining code groups
+    tk, pk = qcfg.talker, qcfg.predictor
+    q8 = 1.0 + 4.0 / 64.0
+    frame_bytes = q8 * (tk.num_hidden_layers * _lm_weight_elems(tk) + tk.vocab_size * tk.hidden_size +
+                        (qcfg.num_code_groups - 1) * (pk.num_hidden_layers * _lm_weight_elems(pk) + pk.vocab_size * pk.hidden_size))
+    out["qwen3tts_0.6b_8bit_b32_stream"] = {
+        "config": "BASELINE configs[4], one GPU's share: Qwen3-TTS-0.6B 8-bit checkpoint (native code streaming), batch 32, 100 frames = 8 s per row, "
+                  "generateStream with a 2.0 s streaming interval",
+        "audio_s_per_s": samples / qcfg.sample_rate / t_stream, "ms": t_stream * 1e3, "first_audio_ms": (t_first_best or 0.0) * 1e3,
+        "ms_per_frame": t_codes * 1e3 / FR,
+        "roofline": {"bound": "hbm", "phase": "frame loop (talker step + 15 code-predictor steps per frame)", "achieved": frame_bytes * FR / t_codes / 1e9,
+                     "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": frame_bytes * FR / t_codes / 1e9 / HBM_PEAK_GBS, "algorithmic_bytes_per_frame": frame_bytes}}
+    del qm
+    out["_wall_s"] = time.perf_counter() - t_begin
+    return out
+
+
 def kernel_source_sha1():
     """Identity of the decode-step kernels a measurement belongs to (sha1 over the step chain's sources)."""
     import hashlib
@@ -143,6 +251,7 @@ def main():
     ap.add_argument("--steps", type=int, default=2)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the secondary configurations (Whisper / Soprano / Qwen3-TTS) after the timed region")
     args = ap.parse_args()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         raise SystemExit(self_spawn(args))
@@ -314,6 +423,11 @@ def main():
                                       "tokens per row %s" % (narrow["tokens_per_row_min"] if narrow else None)},
             "roofline": roofline, "cpu_baseline": cpu,
         }
+        if world == 1 and not args.no_secondary:
+            try:
+                result["secondary"] = secondary_benches(device)
+            except Exception as ex:                              # the headline line must not be lost to a secondary configuration
+                result["secondary"] = {"error": repr(ex)}
         print(json.dumps(result))
     if world > 1:
         dist.barrier()

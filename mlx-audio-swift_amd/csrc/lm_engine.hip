@@ -577,8 +577,11 @@ static void lm_reset(mis_tts* c, int batch, int max_context) {
             hd{2, c->ksb_head, 4, 1};
         const bool tuned = env_int("MIS_ARR_TUNED", 1) != 0 && !getenv("MIS_R_PART") && !getenv("MIS_KSB_PART");
         if (tuned && mt <= 2) {
-            // qkv: four n-tiles per wave, same K shares as before (bit-identical slabs): 8.51 -> 7.82 us
-            if ((c->Nqkv / 16) % 4 == 0 && (c->Nqkv / 16 / 4) * q.S >= 192 && c->ksb_part == 4) { q.R = 4; q.U = 2; }
+            // qkv: four n-tiles per wave (the x fragments re-read half as often), two waves per item: 8.56 -> 7.71 us in the lab, step
+            // 2.125 -> 2.110 (R4 KSB4) -> 2.102 ms (R4 KSB2) on one box (profiles/r04/c4_ab.json)
+            if ((c->Nqkv / 16) % 4 == 0 && (c->Nqkv / 16 / 4) * q.S >= 192 && c->ksb_part == 4) { q.R = 4; q.ksb = 2; q.U = 2; }
+            // (attention output projection: R4 KSB2 U3 with twice the split was 6.59 -> 5.90 us in the lab and +7 us per STEP in the
+            // chain - its four slabs cost the glue launch behind it what the GEMM gained; it stays R2 KSB4 at the cost model's split)
             // down projection: two waves per item (128-thread blocks) 11.8 -> 10.9 us in the lab, step 2.105 -> 2.082 ms (c2_ab.json)
             if (c->ksb_part == 4 && c->ff / 32 >= 64) { dn.ksb = 2; }
             // output projection of a big vocabulary: 173.5 -> 150.7 us (the four waves of a block split K)

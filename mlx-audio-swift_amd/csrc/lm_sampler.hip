@@ -82,15 +82,47 @@ __device__ __forceinline__ u64 shfl_u64(u64 v, int src) {
     unsigned lo = __shfl((unsigned)v, src, 64), hi = __shfl((unsigned)(v >> 32), src, 64);
     return ((u64)hi << 32) | lo;
 }
-// inclusive scan over the 64 lanes of a wave (integers: the result does not depend on the association order)
+// 64-bit values on the DPP network: both halves moved with the same control (bound_ctrl: lanes without a source read 0)
+template <int CTRL>
+__device__ __forceinline__ u64 dpp_u64(u64 v) {
+    const unsigned lo = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(unsigned)v, CTRL, 0xF, 0xF, true);
+    const unsigned hi = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(unsigned)(v >> 32), CTRL, 0xF, 0xF, true);
+    return ((u64)hi << 32) | lo;
+}
+__device__ __forceinline__ u64 readlane_u64(u64 v, int lane) {
+    const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)v, lane), hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(v >> 32), lane);
+    return ((u64)hi << 32) | lo;
+}
+// inclusive scan over the 64 lanes of a wave (integers: the result does not depend on the association order).  Row shifts by 1, 2, 4, 8
+// scan each row of 16 lanes on the DPP network, the three row totals are read as scalars - about 30 VALU instructions instead of the six
+// dependent ds_bpermute round trips per half of the shuffle form (measured on the one-launch sampler: profiles/r04/c3_samp_phases.txt).
 __device__ __forceinline__ u64 wave_scan_incl(u64 v) {
-    const int lane = threadIdx.x & 63;
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-        u64 t = shfl_up_u64(v, o);
-        if (lane >= o) v += t;
-    }
-    return v;
+    v += dpp_u64<0x111>(v);       // row_shr:1
+    v += dpp_u64<0x112>(v);       // row_shr:2
+    v += dpp_u64<0x114>(v);       // row_shr:4
+    v += dpp_u64<0x118>(v);       // row_shr:8
+    const u64 t0 = readlane_u64(v, 15), t1 = readlane_u64(v, 31), t2 = readlane_u64(v, 47);
+    const int row = (threadIdx.x & 63) >> 4;
+    return v + (row >= 1 ? t0 : 0) + (row >= 2 ? t1 : 0) + (row >= 3 ? t2 : 0);
+}
+// sum over the 64 lanes of a wave, the same in every lane
+__device__ __forceinline__ u64 wave_sum_u64(u64 v) {
+    v += dpp_u64<0xB1>(v);        // quad_perm [1,0,3,2]
+    v += dpp_u64<0x4E>(v);        // quad_perm [2,3,0,1]
+    v += dpp_u64<0x141>(v);       // row_half_mirror
+    v += dpp_u64<0x140>(v);       // row_mirror
+    return (readlane_u64(v, 0) + readlane_u64(v, 16)) + (readlane_u64(v, 32) + readlane_u64(v, 48));
+}
+// maximum of an unsigned 32-bit key over the wave, the same in every lane
+__device__ __forceinline__ unsigned wave_max_u32(unsigned v) {
+    auto step = [](unsigned x, unsigned y) { return x > y ? x : y; };
+    v = step(v, (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xF, 0xF, true));
+    v = step(v, (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x4E, 0xF, 0xF, true));
+    v = step(v, (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x141, 0xF, 0xF, true));
+    v = step(v, (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x140, 0xF, 0xF, true));
+    const unsigned a = (unsigned)__builtin_amdgcn_readlane((int)v, 0), b = (unsigned)__builtin_amdgcn_readlane((int)v, 16),
+                   c = (unsigned)__builtin_amdgcn_readlane((int)v, 32), d = (unsigned)__builtin_amdgcn_readlane((int)v, 48);
+    return step(step(a, b), step(c, d));
 }
 // inclusive scan of 256 u64 values held one per thread: wave scans in registers + the 4 wave totals through LDS
 // (two barriers instead of the seventeen of a Hillis-Steele scan through LDS)
@@ -600,14 +632,6 @@ __device__ __forceinline__ u64 sc_load(const u64* p) { return __hip_atomic_load(
 __device__ __forceinline__ void sc_store(u64* p, u64 v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ unsigned sc_key32(float f) { const unsigned u = __float_as_uint(f); return (u & 0x80000000u) ? ~u : (u | 0x80000000u); }
 __device__ __forceinline__ float sc_unkey32(unsigned k) { return __uint_as_float((k & 0x80000000u) ? (k & 0x7fffffffu) : ~k); }
-__device__ __forceinline__ u64 wave_sum_u64(u64 v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-        const unsigned lo32 = __shfl_xor((unsigned)v, o, 64), hi32 = __shfl_xor((unsigned)(v >> 32), o, 64);
-        v += ((u64)hi32 << 32) | lo32;
-    }
-    return v;
-}
 // row barrier: all of this block's exchange stores are performed, then one arrival; returns false on timeout.
 // spin_limit: polls before giving up (a poll is ~0.1 us; tests force a tiny limit to exercise the failure path)
 __device__ __forceinline__ bool sc_row_barrier(unsigned int* sync, unsigned target, int spin_limit) {
@@ -630,10 +654,11 @@ __global__ void __launch_bounds__(SC_NT) k_samp_cluster(SamplerParams p, int spi
     __shared__ u64 hist[256];
     __shared__ u64 sh[SC_NT / 64];
     __shared__ u64 redk[SC_NT / 64];
-    __shared__ u64 part[4][SC_NB];
     __shared__ u64 kept[SC_NB];
+    __shared__ __attribute__((aligned(16))) uint32_t stage[SC_NT * SC_PER / 2];     // the block's 20 480 logits (40 KB), then the [8][256] bin table
     __shared__ int pen_id[64];
     __shared__ float pen_val[64];
+    __shared__ int swin[64];
     __shared__ int n_pen;
     __shared__ unsigned s_bin;
     __shared__ u64 s_below;
@@ -647,6 +672,23 @@ __global__ void __launch_bounds__(SC_NT) k_samp_cluster(SamplerParams p, int spi
     allowed_range(p, step, lo, hi);
     bf16_t* logits = p.logits + (size_t)b * p.Vpad;
     const int my0 = (c * SC_NT + tid) * SC_PER;              // this thread's ids my0 .. my0 + SC_PER - 1
+    // ---- this block's 20 480 logits: coalesced 16-byte loads (three per thread at most; Vpad is a multiple of 16, so the row and the
+    // block's range start 32-byte aligned; chunks past the row re-read its last one - those ids are >= hi and masked below), requested
+    // FIRST: everything up to the staging below (the launch's barrier base, the repetition window, the penalties) runs under them
+    uint4 q[3];
+    {
+        const uint4* lp = reinterpret_cast<const uint4*>(logits);
+        const int n16 = p.Vpad >> 3;                                     // 16-byte chunks in the row
+        const int c0 = c * (SC_NT * SC_PER / 8);                         // first chunk of this block
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            const int ch = c0 + tid + j * SC_NT;
+            q[j] = lp[ch < n16 ? ch : n16 - 1];
+        }
+    }
+    const bool penalise = p.penalty > 0.0f && p.penalty != 1.0f && p.window;
+    const int wl = penalise ? min(p.window_len[b], 64) : 0;
+    if (tid < wl) swin[tid] = p.window[(size_t)b * p.ctx + (p.ctx - p.window_len[b]) + tid];      // (the first-occurrence test reads it O(wl) times)
     unsigned base = 0;
     if (tid == 0) {
         const unsigned v = __hip_atomic_load(&sc->c_sync, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -661,14 +703,12 @@ __global__ void __launch_bounds__(SC_NT) k_samp_cluster(SamplerParams p, int spi
     base = (unsigned)redk[0];
     // ---- repetition penalty (RepetitionContext.process): once per unique id of the window, bf16 arithmetic; the block that holds the
     // id writes it back (in place, like the other sampler paths) and lists it so that the owning thread patches its register copy
-    if (p.penalty > 0.0f && p.penalty != 1.0f && p.window) {
-        const int wl = min(p.window_len[b], 64);
-        const int32_t* win = p.window + (size_t)b * p.ctx + (p.ctx - p.window_len[b]);
+    if (penalise) {
         const float pen = bf16_round_f32(p.penalty);
         if (tid < wl) {
-            const int id = win[tid];
+            const int id = swin[tid];
             bool first = id >= 0 && id < p.vocab && id / (SC_NT * SC_PER) == c;
-            for (int j = 0; j < tid; ++j) first = first && (win[j] != id);
+            for (int j = 0; j < tid; ++j) first = first && (swin[j] != id);
             if (first) {
                 const float l = bf16_to_f32(logits[id]);
                 const bf16_t v = f32_to_bf16((l < 0.0f) ? l * pen : __fdiv_rn(l, pen));
@@ -678,17 +718,18 @@ __global__ void __launch_bounds__(SC_NT) k_samp_cluster(SamplerParams p, int spi
             }
         }
     }
-    // ---- this thread's ids (bf16 pairs; my0 is even and Vpad a multiple of 16, so 4-byte loads stay inside the row)
+    // ---- the logits through LDS: 40 consecutive bytes per thread.  (As 4-byte loads at a 40-byte lane stride: 4.3 us for this phase.)
     float l[SC_PER];
     {
-        const uint32_t* lp = reinterpret_cast<const uint32_t*>(logits);
-        const int vp2 = p.Vpad >> 1;
 #pragma unroll
-        for (int j = 0; j < SC_PER / 2; ++j) {
-            const int w = (my0 >> 1) + j;
-            const uint32_t q = lp[w < vp2 ? w : vp2 - 1];          // clamped (ids >= hi are masked below)
-            l[2 * j] = bf16_to_f32((bf16_t)(q & 0xffffu));
-            l[2 * j + 1] = bf16_to_f32((bf16_t)(q >> 16));
+        for (int j = 0; j < 3; ++j)
+            if (tid + j * SC_NT < SC_NT * SC_PER / 8) reinterpret_cast<uint4*>(stage)[tid + j * SC_NT] = q[j];
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < SC_PER / 4; ++j) {
+            const uint2 w = *reinterpret_cast<const uint2*>(stage + tid * (SC_PER / 2) + 2 * j);
+            l[4 * j] = bf16_to_f32((bf16_t)(w.x & 0xffffu)); l[4 * j + 1] = bf16_to_f32((bf16_t)(w.x >> 16));
+            l[4 * j + 2] = bf16_to_f32((bf16_t)(w.y & 0xffffu)); l[4 * j + 3] = bf16_to_f32((bf16_t)(w.y >> 16));
         }
     }
     __syncthreads();
@@ -710,16 +751,21 @@ __global__ void __launch_bounds__(SC_NT) k_samp_cluster(SamplerParams p, int spi
         const u64 k = ((u64)sc_key32(l[j]) << 32) | (unsigned)(~(unsigned)i);
         bestk = (i >= lo && i < hi && k > bestk) ? k : bestk;
     }
+    if (p.temperature == 0.0f) {                              // greedy needs the first index of the maximum: the whole 64-bit key
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-        const unsigned lo32 = __shfl_xor((unsigned)bestk, o, 64), hi32 = __shfl_xor((unsigned)(bestk >> 32), o, 64);
-        const u64 ok = ((u64)hi32 << 32) | lo32;
-        bestk = ok > bestk ? ok : bestk;
+        for (int o = 32; o > 0; o >>= 1) {
+            const unsigned lo32 = __shfl_xor((unsigned)bestk, o, 64), hi32 = __shfl_xor((unsigned)(bestk >> 32), o, 64);
+            const u64 ok = ((u64)hi32 << 32) | lo32;
+            bestk = ok > bestk ? ok : bestk;
+        }
+    } else {                                                  // sampling needs its value only: 32 bits on the DPP network
+        bestk = (u64)wave_max_u32((unsigned)(bestk >> 32)) << 32;
     }
     if ((tid & 63) == 0) redk[tid >> 6] = bestk;
     __syncthreads();
     if (tid == 0) {
         u64 m = 0;
+#pragma unroll
         for (int w = 0; w < SC_NT / 64; ++w) m = redk[w] > m ? redk[w] : m;
         sc_store(&sc->x_max[c], m);
     }
@@ -808,28 +854,36 @@ __global__ void __launch_bounds__(SC_NT) k_samp_cluster(SamplerParams p, int spi
             __syncthreads();
             const unsigned bin2 = s_bin;
             kstar = (bin1 << 8) | bin2;
-            // kept mass of every block: its mass above bin1 + its level-2 bins from k* up (threads 0..255 hold one bin of each block)
+            // kept mass of every block: its mass above bin1 + its level-2 bins from k* up.  Threads 0..255 hold one bin of each block:
+            // the masked bins go through LDS as an [8][256] table, wave w then sums block w's row (one DPP reduction per wave instead
+            // of eight shuffle reductions in each of four waves: 5.5 -> see profiles/r04/ for this phase)
+            u64* table = reinterpret_cast<u64*>(stage);
             if (tid < 256) {
 #pragma unroll
                 for (int k = 0; k < SC_NB; ++k) {
                     const u64 hv = sc_load(&sc->x_hist2[k][tid]);            // (read again: 16 registers less across the scan)
-                    const u64 v = wave_sum_u64((unsigned)tid >= bin2 ? hv : 0);
-                    if ((tid & 63) == 0) part[tid >> 6][k] = v;
+                    table[k * 256 + tid] = (unsigned)tid >= bin2 ? hv : 0;
                 }
             }
             __syncthreads();
-            if (tid < SC_NB) kept[tid] = part[0][tid] + part[1][tid] + part[2][tid] + part[3][tid] + sc_load(&sc->x_above[tid]);
+            if (tid < SC_NB * 64) {
+                const int w = tid >> 6, ln = tid & 63;
+                const u64 v = wave_sum_u64((table[w * 256 + ln] + table[w * 256 + 64 + ln]) + (table[w * 256 + 128 + ln] + table[w * 256 + 192 + ln]));
+                if (ln == 0) kept[w] = v + sc_load(&sc->x_above[w]);
+            }
         } else {
             if (tid == 0) __hip_atomic_fetch_add(&sc->c_sync, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // (three arrivals per block and launch)
-            if (tid < 256) {                                     // no nucleus cut: a block keeps all of its mass = the sum of its level-1 bins
+            u64* table = reinterpret_cast<u64*>(stage);          // no nucleus cut: a block keeps all of its mass = the sum of its level-1 bins
+            if (tid < 256) {
 #pragma unroll
-                for (int k = 0; k < SC_NB; ++k) {
-                    const u64 v = wave_sum_u64(sc_load(&sc->x_hist1[k][tid]));
-                    if ((tid & 63) == 0) part[tid >> 6][k] = v;
-                }
+                for (int k = 0; k < SC_NB; ++k) table[k * 256 + tid] = sc_load(&sc->x_hist1[k][tid]);
             }
             __syncthreads();
-            if (tid < SC_NB) kept[tid] = part[0][tid] + part[1][tid] + part[2][tid] + part[3][tid];
+            if (tid < SC_NB * 64) {
+                const int w = tid >> 6, ln = tid & 63;
+                const u64 v = wave_sum_u64((table[w * 256 + ln] + table[w * 256 + 64 + ln]) + (table[w * 256 + 128 + ln] + table[w * 256 + 192 + ln]));
+                if (ln == 0) kept[w] = v;
+            }
         }
         __syncthreads();
         SC_STAMP(10);                                        // k* and every block's kept mass known

@@ -215,10 +215,169 @@ __global__ void __launch_bounds__(256, 2) k_gemm_big2(BigGemmParams p) {
     }
 }
 
+// ---------------------------------------------------------------------------- 256 x 256 tiles, eight waves, counted waits
+// Round 4 (tools/gemm_lab/big_lab, profiles/r04/big_lab.jsonl): at the encoder's shapes (M = 8 x 1500 rows, N, K in 1280 .. 5120) a
+// 256 x 256 x 64 tile on eight waves - one block per CU, two 64 KB LDS buffers - runs the four GEMMs of a layer in 135.7 / 44.6 / 187.6 /
+// 158.4 us against 151.2 / 52.0 / 203.9 / 181.5 for k_gemm_big2 (35-40 % of the dense bf16 MFMA peak instead of 31-35 %): each wave's
+// fragment reads feed twice the MFMAs (44 FLOP per LDS byte against 32).  The deeper rings of the same laboratory (three buffers at
+// 256 x 128 / 128 x 256) were slower.  What makes the two-buffer form work is WHEN the waves wait: the LDS-DMA of tile kt + 1 is issued
+// behind the fragment reads of tile kt and waited for with an explicit vmcnt(0) right in front of the next raw s_barrier - with compiler
+// loads hipcc puts a vmcnt(0) in front of every ds_read that follows an LDS-DMA in program order, hence asm reads (ds_read_b128, one
+// lgkmcnt(0) naming every fragment in front of the MFMAs).  Same k order and accumulators as k_gemm_big2: bit-identical C.
+__device__ __forceinline__ uint32_t bg3_lds_offset(const void* p) {
+    return (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const void*)p;
+}
+__device__ __forceinline__ bf16x8_t bg3_lds_read16(uint32_t addr) {
+    bf16x8_t v;
+    asm volatile("ds_read_b128 %0, %1" : "=v"(v) : "v"(addr) : "memory");
+    return v;
+}
+#define BG3_BM 256
+#define BG3_BN 256
+template <int EPI, int WM, int WN>
+__global__ void __launch_bounds__(512, 1) k_gemm_big3(BigGemmParams p) {
+    constexpr int NW = WM * WN;                                  // 8 waves
+    constexpr int TM = BG3_BM / WM / 16, TN = BG3_BN / WN / 16;  // 16 x 16 MFMA tiles per wave (m, n)
+    constexpr int QW = BG3_BN / 8 / NW, QX = BG3_BM / 8 / NW;    // LDS-DMA instructions per wave and tile (8 rows of 128 B each)
+    static_assert(NW == 8, "eight waves");
+    extern __shared__ __attribute__((aligned(1024))) bf16_t bg3_lds[];
+    bf16_t* Ws = bg3_lds;                                        // [2][BN * 64]
+    bf16_t* Xs = bg3_lds + (size_t)2 * BG3_BN * BG2_BK;          // [2][BM * 64]
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int n0 = blockIdx.x * BG3_BN, m0 = blockIdx.y * BG3_BM;
+    const int wn = wave / WM, wm = wave % WM;
+    f32x4_t acc[TN][TM];
+#pragma unroll
+    for (int i = 0; i < TN; ++i)
+#pragma unroll
+        for (int j = 0; j < TM; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+    const bf16_t* wsrc[QW];
+    const bf16_t* xsrc[QX];
+#pragma unroll
+    for (int q = 0; q < QW; ++q) {
+        const int r = (wave * QW + q) * 8 + (lane >> 3);
+        const int chunk = (lane & 7) ^ ((r >> 1) & 7);
+        wsrc[q] = p.W + (size_t)min(n0 + r, p.N - 1) * p.K + chunk * 8;
+    }
+#pragma unroll
+    for (int q = 0; q < QX; ++q) {
+        const int r = (wave * QX + q) * 8 + (lane >> 3);
+        const int chunk = (lane & 7) ^ ((r >> 1) & 7);
+        xsrc[q] = p.X + (size_t)min(m0 + r, p.M - 1) * p.ldx + chunk * 8;
+    }
+    auto stage = [&](int buf, int k0) {
+#pragma unroll
+        for (int q = 0; q < QW; ++q)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wsrc[q] + k0),
+                                             (__attribute__((address_space(3))) void*)&Ws[((size_t)buf * BG3_BN + (wave * QW + q) * 8) * BG2_BK], 16, 0, 0);
+#pragma unroll
+        for (int q = 0; q < QX; ++q)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(xsrc[q] + k0),
+                                             (__attribute__((address_space(3))) void*)&Xs[((size_t)buf * BG3_BM + (wave * QX + q) * 8) * BG2_BK], 16, 0, 0);
+    };
+    const int KT = p.K / BG2_BK;
+    const int sw = (lane >> 1) & 7;
+    const uint32_t ws_base = bg3_lds_offset(Ws) + (uint32_t)((wn * (BG3_BN / WN) + (lane & 15)) * BG2_BK * 2);
+    const uint32_t xs_base = bg3_lds_offset(Xs) + (uint32_t)((wm * (BG3_BM / WM) + (lane & 15)) * BG2_BK * 2);
+    stage(0, 0);
+    for (int kt = 0; kt < KT; ++kt) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // this wave's part of tile kt has landed
+        __builtin_amdgcn_s_barrier();                            // every wave's part is in LDS; the other buffer is free
+        asm volatile("" ::: "memory");
+        const int buf = kt & 1;
+        bf16x8_t a[2][TN], b[2][TM];
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            const uint32_t pos = (uint32_t)(((ks * 4 + (lane >> 4)) ^ sw) * 16);
+#pragma unroll
+            for (int i = 0; i < TN; ++i) a[ks][i] = bg3_lds_read16(ws_base + (uint32_t)((buf * BG3_BN + i * 16) * BG2_BK * 2) + pos);
+#pragma unroll
+            for (int j = 0; j < TM; ++j) b[ks][j] = bg3_lds_read16(xs_base + (uint32_t)((buf * BG3_BM + j * 16) * BG2_BK * 2) + pos);
+        }
+        // the next DMA goes into the buffer read one k-step ago; issued behind this tile's reads, it runs under its MFMAs
+        if (kt + 1 < KT) stage((kt + 1) & 1, (kt + 1) * BG2_BK);
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+#pragma unroll
+            for (int i = 0; i < TN; ++i) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a[ks][i]));      // one wait, naming every fragment
+#pragma unroll
+            for (int j = 0; j < TM; ++j) asm volatile("" : "+v"(b[ks][j]));
+#pragma unroll
+            for (int i = 0; i < TN; ++i)
+#pragma unroll
+                for (int j = 0; j < TM; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[ks][i], b[ks][j], acc[i][j], 0, 0, 0);
+        }
+    }
+    // epilogue: as k_gemm_big2 (C/D lane = column m (l & 15), rows n = 4 (l >> 4) + e)
+#pragma unroll
+    for (int i = 0; i < TN; ++i) {
+        const int n = n0 + wn * (BG3_BN / WN) + i * 16 + (lane >> 4) * 4;
+        if (n >= p.N) continue;
+        float bv[4] = {0.f, 0.f, 0.f, 0.f};
+        if (p.bias) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) bv[e] = (n + e < p.N) ? bf16_to_f32(p.bias[n + e]) : 0.0f;
+        }
+#pragma unroll
+        for (int j = 0; j < TM; ++j) {
+            const int m = m0 + wm * (BG3_BM / WM) + j * 16 + (lane & 15);
+            if (m >= p.M) continue;
+            uint16_t res[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float v = bf16_round_f32(acc[i][j][e] + bv[e]);                       // T(xW^T + b)
+                if (EPI == BG_GELU || EPI == BG_GELU_POS) v = bf16_round_f32(gelu_erf_w(v));
+                if (EPI == BG_RESID) v = bf16_round_f32(v + bf16_to_f32(p.R[(size_t)m * p.N + n + e]));
+                if (EPI == BG_GELU_POS) v = bf16_round_f32(v + bf16_to_f32(p.R[(size_t)(m % p.pos_rows) * p.N + n + e]));
+                res[e] = f32_to_bf16(v);
+            }
+            bf16_t* o = p.C + (size_t)m * p.N + n;
+            if (n + 3 < p.N) {
+                uint2 v;
+                v.x = (uint32_t)res[0] | ((uint32_t)res[1] << 16);
+                v.y = (uint32_t)res[2] | ((uint32_t)res[3] << 16);
+                *reinterpret_cast<uint2*>(o) = v;
+            } else {
+                for (int e = 0; e < 4 && n + e < p.N; ++e) o[e] = res[e];
+            }
+        }
+    }
+}
+template <int EPI, int WM, int WN>
+static bool launch_big3_one(const BigGemmParams& p, hipStream_t s) {
+    constexpr int lds_bytes = 2 * (BG3_BM + BG3_BN) * BG2_BK * 2;            // 128 KB
+    static const bool ok = hipFuncSetAttribute((const void*)k_gemm_big3<EPI, WM, WN>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes) == hipSuccess;
+    if (!ok) { (void)hipGetLastError(); return false; }
+    hipLaunchKernelGGL((k_gemm_big3<EPI, WM, WN>), dim3(cdiv(p.N, BG3_BN), cdiv(p.M, BG3_BM)), dim3(512), lds_bytes, s, p);
+    return true;
+}
+template <int EPI>
+static bool launch_big3(const BigGemmParams& p, hipStream_t s) {
+    // wave grid as measured: 2 (m) x 4 (n) for the wide / deep MLP shapes, 4 x 2 otherwise
+    return (p.N >= 4096 || p.K >= 4096) ? launch_big3_one<EPI, 2, 4>(p, s) : launch_big3_one<EPI, 4, 2>(p, s);
+}
+
 void launch_gemm_big(int epi, const BigGemmParams& p, hipStream_t s) {
     MIS_REQUIRE(p.K % BG_BK == 0 && p.ldx % 8 == 0 && p.N % 4 == 0, MIS_ERR_INVALID_INPUT, "big GEMM needs K %% 32 == 0");
     dim3 grid(cdiv(p.N, BG_BN), cdiv(p.M, BG_BM)), block(256);
     static const bool v1 = getenv("MIS_GEMM_BIG_V1") && atoi(getenv("MIS_GEMM_BIG_V1")) != 0;     // A/B: the register-staged kernel
+    {   // the 256 x 256 tile where its grid still fills most of the chip (out_proj of 8 windows: 235 blocks, 52.0 -> 44.6 us); below that the
+        // 128 x 128 kernel has four times the blocks.  MIS_GEMM_BIG3=0: never (A/B); =2: whenever the shape allows (parity tests)
+        const char* e3 = getenv("MIS_GEMM_BIG3");
+        const int mode = e3 ? atoi(e3) : 1;
+        const long blocks3 = (long)cdiv(p.N, BG3_BN) * cdiv(p.M, BG3_BM);
+        if (mode != 0 && !v1 && p.K % BG2_BK == 0 && p.K >= 2 * BG2_BK && (mode == 2 || blocks3 >= 200)) {
+            bool done = false;
+            switch (epi) {
+                case BG_NONE: done = launch_big3<BG_NONE>(p, s); break;
+                case BG_GELU: done = launch_big3<BG_GELU>(p, s); break;
+                case BG_RESID: done = launch_big3<BG_RESID>(p, s); break;
+                case BG_GELU_POS: done = launch_big3<BG_GELU_POS>(p, s); break;
+                default: throw MisError(MIS_ERR_GENERATION_FAILED, "unknown big GEMM epilogue");
+            }
+            if (done) return;
+        }
+    }
     if (!v1 && p.K % BG2_BK == 0 && p.K >= 2 * BG2_BK) {
         switch (epi) {
             case BG_NONE: hipLaunchKernelGGL((k_gemm_big2<BG_NONE>), grid, block, 0, s, p); return;

@@ -84,16 +84,21 @@ def test_whisper_large_v3_full_depth_32_plus_32_layers_and_error_growth():
     for L, g in growth.items():
         assert g["enc_rms"] <= FLOOR_FACTOR * g["enc_floor_rms"] + 2e-3, (L, g)
         assert g["dec_rms"] <= FLOOR_FACTOR * g["dec_floor_rms"] + 2e-3, (L, g)
-    # absolute bounds at the real depth (about twice the observed values, profiles/r04_parity_observed.json)
-    assert growth[32]["enc_rms"] <= 0.05 and growth[32]["dec_rms"] <= 0.06, growth[32]
-    assert growth[2]["enc_rms"] <= 0.012 and growth[2]["dec_rms"] <= 0.012, growth[2]
+    # absolute bounds, about twice what MI355X delivered (profiles/r04_parity_observed.json): 32 + 32 layers encoder rms 0.0113 / max 0.0299,
+    # decoder logits rms 0.0139 / max 0.0164 - against the oracle's own float64 floor of 0.0112 / 0.0299 and 0.0138 / 0.0164: the device
+    # sits AT the floor at every depth (8 + 8: 0.0076 vs 0.0073, 0.0086 vs 0.0086; 2 + 2: 0.0048 vs 0.0039, 0.0056 vs 0.0055)
+    assert growth[32]["enc_rms"] <= 0.023 and growth[32]["dec_rms"] <= 0.028, growth[32]
+    assert growth[32]["enc_max"] <= 0.06 and growth[32]["dec_max"] <= 0.033, growth[32]
+    assert growth[8]["enc_rms"] <= 0.016 and growth[8]["dec_rms"] <= 0.018, growth[8]
+    assert growth[2]["enc_rms"] <= 0.010 and growth[2]["dec_rms"] <= 0.012, growth[2]
 
 
 @pytest.mark.parametrize("quant", [None, 8], ids=["bf16", "8bit-checkpoint"])
 def test_qwen3tts_06b_full_depth_talker_28_predictor_5(quant):
     """Greedy choice within `tol` of the oracle's maximum for code group 0 (talker, 28 layers) and groups 1..15 (predictor, 5 layers),
-    4 frames, 2 rows; bf16 weights and the 8-bit checkpoint form.  tol: 0.03 max|logit| (the width test at 2 + 1 layers uses 0.012 and
-    observed 0.0051; the error grows ~ sqrt(layers))."""
+    4 frames, 2 rows; bf16 weights and the 8-bit checkpoint form.  tol: 0.012 max|logit| (observed on MI355X at full depth: talker 0.0
+    - the engine's choice IS the oracle's argmax in all 8 frames - predictor 0.0043 bf16 / 0.0047 8 bit; the width test at 2 + 1 layers
+    observed 0.0051 with the same bound)."""
     from test_gpu_qwen3tts import _host_cfg, _prompt
     base = oq.Qwen3TTSConfig()
     assert base.talker.num_hidden_layers == 28 and base.predictor.num_hidden_layers == 5 and base.talker.hidden_size == 1024
@@ -137,7 +142,7 @@ def test_qwen3tts_06b_full_depth_talker_28_predictor_5(quant):
     suppress = [t for t in range(cfg.talker.vocab_size - 1024, cfg.talker.vocab_size) if t != cfg.codec_eos_token_id]
     pr = dict(temperature=0.0, top_p=1.0, top_k=0, repetition_penalty=1.05, min_p=0.0, seed=1)
     worst_t = worst_p = 0.0
-    tol = 0.03
+    tol = 0.012
     for b, p in enumerate(prompts):
         olm.talker.reset(1)
         x = olm.position_embeds(p.text_ids, p.codec_ids)
@@ -169,8 +174,8 @@ def test_qwen3tts_06b_full_depth_talker_28_predictor_5(quant):
 
 def test_soprano_80m_decoder_real_dimensions():
     """Vocos decoder at Soprano-1.1's dimensions: hidden 512 -> 768-wide, 8 ConvNeXt layers (2304 intermediate, depthwise kernel 3),
-    input kernel 1, upscale 4, ISTFT head n_fft 2048 / hop 512 (2 x 1025 spectral rows per frame).  Waveform max |err| <= 2e-4 max|ref|
-    (the bound of the small-config decoder tests)."""
+    input kernel 1, upscale 4, ISTFT head n_fft 2048 / hop 512 (2 x 1025 spectral rows per frame).  Waveform max |err| <= 4e-5 max|ref|
+    (observed 1.04e-5 on MI355X; the small-config decoder tests allow 2e-4)."""
     ocfg = osop.SopranoDecoderConfig()
     assert (ocfg.decoder_num_layers, ocfg.decoder_dim, ocfg.decoder_intermediate_dim, ocfg.n_fft, ocfg.hop_length, ocfg.hidden_size) == (8, 768, 2304, 2048, 512, 512)
     LM = dataclasses.replace(ollama.TINY_QWEN3, hidden_size=512)             # the decoder's input width; the LM itself is not run here
@@ -195,5 +200,5 @@ def test_soprano_80m_decoder_real_dimensions():
         assert got.shape == ref.shape == (B, cfg.upscale * (L - 1) * cfg.hop_length)
         e = float(np.abs(got - ref).max() / np.abs(ref).max())
         worst = max(worst, e)
-        assert e <= 2e-4, (B, L, e)
-    record("soprano_80m_decoder_real_dims", wave_max_rel=worst, tol=2e-4)
+        assert e <= 4e-5, (B, L, e)
+    record("soprano_80m_decoder_real_dims", wave_max_rel=worst, tol=4e-5)

@@ -289,3 +289,23 @@ def test_group_of_two_logical_shards_returns_the_unsharded_tokens():
         assert sharded == whole, temp
     with pytest.raises(mas.AudioGenerationError):
         a.transcribe_windows(wins[:1], prompt, gp, replicas=[a, b])          # fewer rows than replicas
+
+
+def test_encoder_256x256_tile_gemm_is_bit_identical_to_the_128x128_kernel(monkeypatch):
+    """k_gemm_big3 (256 x 256 x 64 tiles, eight waves, counted waits; picked when its grid fills the chip) accumulates every output in the
+    same k order as k_gemm_big2, so forcing it on every GEMM of the encoder (MIS_GEMM_BIG3=2: conv stem with GELU / GELU + positions,
+    qkv, out_proj + residual, fc1 + GELU, fc2 + residual; ragged M = 2 x 1500 and N = 256 / 768 / 512 against 256-wide tiles) must
+    reproduce the 128 x 128 kernel's encoder output bit for bit - and with it the oracle bound of the test above."""
+    cfg = ow.WhisperConfig(vocab_size=700, num_mel_bins=128, d_model=256, encoder_layers=2, encoder_attention_heads=2, encoder_ffn_dim=512,
+                           decoder_layers=1, decoder_attention_heads=2, decoder_ffn_dim=512)
+    W, oracle, dev = _pair(cfg)
+    feats = _feats(2, cfg.num_mel_bins, 4)
+    monkeypatch.setenv("MIS_GEMM_BIG3", "0")
+    small = dev.encode(feats)
+    monkeypatch.setenv("MIS_GEMM_BIG3", "2")
+    big = dev.encode(feats)
+    assert np.array_equal(small, big)
+    oracle.reset(2)
+    ref = oracle.encode(feats)
+    for b in range(2):
+        _check(big[b], ref[b].numpy(), 0.022, 0.012)

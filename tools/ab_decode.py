@@ -18,7 +18,7 @@ rows = []
 for name, env in variants:
     e = dict(os.environ)
     e.update(env)
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--no-cpu-baseline"], env=e,
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-secondary"], env=e,
                        capture_output=True, text=True)
     try:
         j = json.loads(r.stdout.strip().splitlines()[-1])
