@@ -214,7 +214,8 @@ extern "C" mis_status mis_tts_group_generate_device(mis_group* g, const int32_t*
     MIS_API_BEGIN
     MIS_REQUIRE(g && prompt_ids && prompt_lens && params && pcm_dev && pcm_lens, MIS_ERR_INVALID_INPUT, "null argument");
     const int W = (int)g->reps.size();
-    MIS_REQUIRE(batch >= W, MIS_ERR_INVALID_INPUT, "batch %d smaller than the group (%d replicas)", batch, W);
+    MIS_REQUIRE(batch >= 1, MIS_ERR_INVALID_INPUT, "empty batch");
+    const int We = std::min(W, batch);          // replicas that get rows (a batch smaller than the group runs on its first `batch` replicas)
     for (int r = 0; r < W; ++r) MIS_REQUIRE(pcm_dev[r], MIS_ERR_INVALID_INPUT, "null PCM buffer for replica %d", r);
     HostPrompts hp = fetch_prompts(prompt_ids, prompt_lens, batch);
     std::vector<ShardResult> res(W);
@@ -222,10 +223,12 @@ extern "C" mis_status mis_tts_group_generate_device(mis_group* g, const int32_t*
     std::vector<int64_t> plens(batch, 0);
     auto t0 = std::chrono::steady_clock::now();
     std::vector<std::thread> th;
-    for (int r = 0; r < W; ++r)
+    th.reserve(We);
+    struct Joiner { std::vector<std::thread>& t; ~Joiner() { for (auto& x : t) if (x.joinable()) x.join(); } } joiner{th};
+    for (int r = 0; r < We; ++r)
         th.emplace_back([&, r]() {
             int lo, hi;
-            shard_block(batch, r, W, &lo, &hi);
+            shard_block(batch, r, We, &lo, &hi);
             mis_gen_params p = *params;
             p.row_offset += lo;
             auto a = std::chrono::steady_clock::now();
@@ -236,12 +239,12 @@ extern "C" mis_status mis_tts_group_generate_device(mis_group* g, const int32_t*
         });
     for (auto& t : th) t.join();
     auto t1 = std::chrono::steady_clock::now();
-    for (int r = 0; r < W; ++r)
+    for (int r = 0; r < We; ++r)
         if (res[r].st != MIS_OK) throw MisError(res[r].st, "shard " + std::to_string(r) + ": " + res[r].err);
     // ---- all-gather by direct peer writes: rank r's block -> every other replica's buffer, issued on r's own stream
-    for (int r = 0; r < W; ++r) {
+    for (int r = 0; r < We; ++r) {
         int lo, hi;
-        shard_block(batch, r, W, &lo, &hi);
+        shard_block(batch, r, We, &lo, &hi);
         const int dr = tts_device(g->reps[r]);
         HIP_CHECK(hipSetDevice(dr));
         hipStream_t s = tts_stream(g->reps[r]);
@@ -255,11 +258,11 @@ extern "C" mis_status mis_tts_group_generate_device(mis_group* g, const int32_t*
     }
     for (int r = 0; r < W; ++r) { HIP_CHECK(hipSetDevice(tts_device(g->reps[r]))); HIP_CHECK(hipStreamSynchronize(tts_stream(g->reps[r]))); }
     auto t2 = std::chrono::steady_clock::now();
-    g->timing.n_shards = W;
+    g->timing.n_shards = We;
     g->timing.generate_ms = std::chrono::duration<double, std::milli>(t1 - t0).count();
     g->timing.gather_ms = std::chrono::duration<double, std::milli>(t2 - t1).count();
     g->timing.slowest_shard_ms = 0;
-    for (int r = 0; r < W; ++r) g->timing.slowest_shard_ms = std::max(g->timing.slowest_shard_ms, res[r].ms);
+    for (int r = 0; r < We; ++r) g->timing.slowest_shard_ms = std::max(g->timing.slowest_shard_ms, res[r].ms);
     for (int b = 0; b < batch; ++b) pcm_lens[b] = plens[b];
     if (n_tokens) for (int b = 0; b < batch; ++b) n_tokens[b] = ntok[b];
     MIS_API_END
@@ -273,8 +276,8 @@ extern "C" mis_status mis_tts_group_generate(mis_group* g, const int32_t* prompt
                                              int32_t** tokens_out, int64_t* tokens_stride, int32_t* n_tokens) {
     MIS_API_BEGIN
     MIS_REQUIRE(g && prompt_ids && prompt_lens && params && pcm_out && pcm_stride && pcm_lens, MIS_ERR_INVALID_INPUT, "null argument");
-    const int W = (int)g->reps.size();
-    MIS_REQUIRE(batch >= W, MIS_ERR_INVALID_INPUT, "batch %d smaller than the group (%d replicas)", batch, W);
+    MIS_REQUIRE(batch >= 1, MIS_ERR_INVALID_INPUT, "empty batch");
+    const int W = std::min((int)g->reps.size(), batch);      // a batch smaller than the group runs on its first `batch` replicas
     HostPrompts hp = fetch_prompts(prompt_ids, prompt_lens, batch);
     struct Part { float* pcm = nullptr; int64_t stride = 0; int32_t* tok = nullptr; int64_t tstride = 0; };
     std::vector<Part> part(W);
@@ -283,6 +286,8 @@ extern "C" mis_status mis_tts_group_generate(mis_group* g, const int32_t* prompt
     std::vector<int64_t> plens(batch, 0);
     auto t0 = std::chrono::steady_clock::now();
     std::vector<std::thread> th;
+    th.reserve(W);
+    struct Joiner { std::vector<std::thread>& t; ~Joiner() { for (auto& x : t) if (x.joinable()) x.join(); } } joiner{th};
     for (int r = 0; r < W; ++r)
         th.emplace_back([&, r]() {
             int lo, hi;
@@ -348,19 +353,25 @@ void relay_event(void* u, int row, mis_event_kind kind, const void* payload, int
     r->cb(r->user, row + r->lo, kind, payload, n);
 }
 template <typename H>
-void check_replicas(H* const* replicas, int n, int batch) {
+int check_replicas(H* const* replicas, int n, int batch) {
     MIS_REQUIRE(replicas && n >= 1 && n <= 64, MIS_ERR_INVALID_INPUT, "a group needs 1..64 replicas");
-    MIS_REQUIRE(batch >= n, MIS_ERR_INVALID_INPUT, "batch %d smaller than the group (%d replicas)", batch, n);
+    MIS_REQUIRE(batch >= 1, MIS_ERR_INVALID_INPUT, "empty batch");
     for (int i = 0; i < n; ++i) {
         MIS_REQUIRE(replicas[i], MIS_ERR_INVALID_INPUT, "null replica handle");
         for (int j = 0; j < i; ++j) MIS_REQUIRE(replicas[j] != replicas[i], MIS_ERR_INVALID_INPUT, "a handle may appear only once in a group");
     }
+    return std::min(n, batch);          // a batch smaller than the group (the tail slice of a long request) runs on its first `batch` replicas
 }
 // run fn(r, lo, hi) on one thread per shard; rethrow the first failure
 template <typename F>
 void run_shards(int n, int batch, F&& fn) {
     std::vector<ShardResult> res(n);
     std::vector<std::thread> th;
+    th.reserve(n);
+    struct Joiner {                       // a thread constructor that throws (resource exhaustion) must not leave joinable threads behind:
+        std::vector<std::thread>& t;      // their destructors would call std::terminate
+        ~Joiner() { for (auto& x : t) if (x.joinable()) x.join(); }
+    } joiner{th};
     for (int r = 0; r < n; ++r)
         th.emplace_back([&, r]() {
             int lo, hi;
@@ -401,7 +412,7 @@ extern "C" mis_status mis_whisper_group_generate(mis_whisper* const* replicas, i
                                                  int32_t** tokens_out, int64_t* tokens_stride, int32_t* n_tokens) {
     MIS_API_BEGIN
     MIS_REQUIRE(pcm && lens && prompt_ids && sp && tokens_out && tokens_stride && n_tokens, MIS_ERR_INVALID_INPUT, "null argument");
-    check_replicas(replicas, n, batch);
+    n = check_replicas(replicas, n, batch);
     PartGuard<int32_t> tok(n);
     std::vector<int64_t> ts(n, 0);
     run_shards(n, batch, [&](int r, int lo, int hi) {
@@ -419,7 +430,7 @@ extern "C" mis_status mis_soprano_group_generate(mis_soprano* const* replicas, i
                                                  int32_t** tokens_out, int64_t* tokens_stride, int32_t* n_tokens) {
     MIS_API_BEGIN
     MIS_REQUIRE(prompt_ids && prompt_lens && params && pcm_out && pcm_stride && pcm_lens, MIS_ERR_INVALID_INPUT, "null argument");
-    check_replicas(replicas, n, batch);
+    n = check_replicas(replicas, n, batch);
     HostPrompts hp = fetch_prompts(prompt_ids, prompt_lens, batch);
     PartGuard<float> pcm(n);
     PartGuard<int32_t> tok(n);
@@ -447,7 +458,7 @@ extern "C" mis_status mis_qwen3tts_group_generate(mis_qwen3tts* const* replicas,
     MIS_REQUIRE(text_ids && codec_ids && prefill_lens && trailing_lens && params && pcm_out && pcm_stride && pcm_lens, MIS_ERR_INVALID_INPUT,
                 "null argument");
     MIS_REQUIRE(P >= 1 && Tt >= 0, MIS_ERR_INVALID_INPUT, "bad prompt sizes");
-    check_replicas(replicas, n, batch);
+    n = check_replicas(replicas, n, batch);
     PartGuard<float> pcm(n);
     PartGuard<int32_t> cod(n);
     std::vector<int64_t> ps(n, 0), cs(n, 0);

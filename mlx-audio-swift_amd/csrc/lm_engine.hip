@@ -59,6 +59,7 @@ struct mis_tts {
     int r_gu = 2;                                   // n-tiles per wave of gate+up (4 where that still fills the chip, see lm_reset)
     int ksb_part = 4, ksb_gu = 4, ksb_head = 1;     // waves per work item (in-block split-K), see k_gemm_skinny
     GemmArr a_qkv, a_o, a_down, a_head;             // dense bf16 roles: the arrangement picked in lm_reset (gate+up: r_gu / ksb_gu)
+    GemmArr qa_gu, qa_head;                         // code-streamed wide roles: (R, KSB) of k_gemm_skinny_q (MIS_QARR_GU / _HEAD = "R,KSB")
     DevBuf<bf16_t> kcache, vtcache;
     DevBuf<float> rope_cos, rope_sin;
     DevBuf<int32_t> ids, pos_cur, pos_next;
@@ -588,6 +589,24 @@ static void lm_reset(mis_tts* c, int batch, int max_context) {
             if (!getenv("MIS_KSB_HEAD") && c->Vpad / 64 >= 1024) { hd.R = 4; hd.ksb = 4; hd.U = 3; }
         }
         c->a_qkv = pick("MIS_ARR_QKV", q); c->a_o = pick("MIS_ARR_O", o); c->a_down = pick("MIS_ARR_DOWN", dn); c->a_head = pick("MIS_ARR_HEAD", hd);
+        {   // quantised checkpoints, the two wide roles (gate+up, output projection)
+            auto qpick = [&](const char* env, GemmArr dflt) {
+                const char* e = getenv(env);
+                int r = 0, k = 0;
+                if (e && sscanf(e, "%d,%d", &r, &k) == 2 && (r == 2 || r == 4) && (k == 1 || k == 4 || k == 8)) { dflt.R = r; dflt.ksb = k; }
+                if ((dflt.R == 4 || dflt.ksb == 8) && mt > 2) { dflt.R = 2; dflt.ksb = dflt.ksb == 8 ? 4 : dflt.ksb; }
+                return dflt;
+            };
+            // measured at Orpheus-3B widths, 8 bit, 32 rows (profiles/r04/c6_qgemm_arr.txt): gate+up 17.80 us as R2 KSB4, 17.37 as R4 KSB4,
+            // 16.63 as R4 KSB8 (19.32 as R2 KSB8); output projection 136.2 us as R2 KSB1, 127.5 as R4 KSB4 (148.1 as R4 KSB8)
+            GemmArr gu{2, c->ksb_gu, 0, 1}, hd{2, c->ksb_head, 0, 1};
+            if (tuned && mt <= 2) {
+                if (c->ksb_gu == 4 && (2 * c->ff / 16) % 4 == 0 && 2 * c->ff / 16 / 4 >= 256) { gu.R = 4; gu.ksb = 8; }
+                if (!getenv("MIS_KSB_HEAD") && c->Vpad / 64 >= 1024) { hd.R = 4; hd.ksb = 4; }
+            }
+            c->qa_gu = qpick("MIS_QARR_GU", gu);
+            c->qa_head = qpick("MIS_QARR_HEAD", hd);
+        }
         c->S_qkv = std::min(8, c->a_qkv.S); c->a_qkv.S = c->S_qkv;
         c->S_o = std::min(8, c->a_o.S); c->a_o.S = c->S_o;
         c->S_down = std::min(8, c->a_down.S); c->a_down.S = c->S_down;
@@ -625,7 +644,7 @@ static void gemm_o(mis_tts* c, size_t li, hipStream_t s) {
                             c->Mpad, s, nullptr, c->a_o.U);
 }
 static void gemm_gate_up(mis_tts* c, size_t li, hipStream_t s) {
-    if (c->q_gu.on) launch_gemm_skinny_q(c->q_gu.bits, EPI_SILU_MUL, 2, c->ksb_gu, c->q_gu.q.p + c->q_gu.q_layer * li, c->q_gu.sb.p + c->q_gu.sb_layer * li, c->x.p,
+    if (c->q_gu.on) launch_gemm_skinny_q(c->q_gu.bits, EPI_SILU_MUL, c->qa_gu.R, c->qa_gu.ksb, c->q_gu.q.p + c->q_gu.q_layer * li, c->q_gu.sb.p + c->q_gu.sb_layer * li, c->x.p,
                                          c->act.p, 2 * c->ff / 16, c->d / 64, 1, c->ff, c->Mpad, s);
     else launch_gemm_skinny(EPI_SILU_MUL, c->r_gu, c->ksb_gu, c->wgu.p + layer_gu_elems(c) * li, c->x.p, c->act.p, 2 * c->ff / 16, c->d / 32, 1, c->ff, c->Mpad, s);
 }
@@ -671,7 +690,7 @@ static void enqueue_layers(mis_tts* c, const bf16_t* table = nullptr, int table_
 }
 static void enqueue_lm_head(mis_tts* c, const bf16_t* head = nullptr) {
     if (!head && c->q_head.on) {
-        launch_gemm_skinny_q(c->q_head.bits, EPI_BF16, 2, c->ksb_head, c->q_head.q.p, c->q_head.sb.p, c->x.p, c->logits.p, c->Vpad / 16, c->d / 64, 1, c->Vpad,
+        launch_gemm_skinny_q(c->q_head.bits, EPI_BF16, c->qa_head.R, c->qa_head.ksb, c->q_head.q.p, c->q_head.sb.p, c->x.p, c->logits.p, c->Vpad / 16, c->d / 64, 1, c->Vpad,
                              c->Mpad, c->stream);
         return;
     }
@@ -731,6 +750,11 @@ static void prefill_batched(mis_tts* c, const int32_t* prompt_mat_dev, const int
         const int tc = std::min(Tc, Lmax - t0);
         const int Mr = tc * rs;                                              // rows that exist
         const int M = (int)round_up((size_t)Mr, 16);                         // rows the GEMMs run over
+        if (t0 > 0 && (size_t)Mr < Mc) {                                     // a shorter last chunk: the rows behind it held the previous chunk's
+            HIP_CHECK(hipMemsetAsync(c->pf_x.p + (size_t)Mr * d, 0, (Mc - Mr) * d * 2, s));       // values - zeros again, as the comments below say
+            HIP_CHECK(hipMemsetAsync(c->pf_h.p + (size_t)Mr * d, 0, (Mc - Mr) * d * 2, s));
+            HIP_CHECK(hipMemsetAsync(c->pf_attn.p + (size_t)Mr * HD, 0, (Mc - Mr) * HD * 2, s));
+        }
         if (embed_rows) launch_pf_rows_rmsnorm(embed_rows, Mpad, lens_dev, Lmax, t0, tc, batch, rs, c->norms.p, c->pf_h.p, c->pf_x.p, c->pf_pos.p, c->pf_on.p, d, eps, s);
         else launch_pf_embed_rmsnorm(c->emb.p, prompt_mat_dev, lens_dev, Lmax, t0, tc, batch, rs, c->V, c->norms.p, c->pf_h.p, c->pf_x.p,
                                      c->pf_pos.p, c->pf_on.p, d, eps, s);
@@ -1005,7 +1029,7 @@ extern "C" mis_status mis_sample_logits(int device, const float* logits, int bat
         unsigned long long st[16];
         HIP_CHECK(hipMemcpy(st, dbg.p, sizeof(st), hipMemcpyDeviceToHost));
         fprintf(stderr, "SAMP_DBG us_per_launch %.2f stamps", ms * 1e3 / 20);
-        for (int i = 0; i < 12; ++i) fprintf(stderr, " %llu", st[i] ? st[i] - st[0] : 0ull);
+        for (int i = 0; i < 14; ++i) fprintf(stderr, " %llu", st[i] ? st[i] - st[0] : 0ull);         // 12, 13: inside barriers 1 / 2, after the store drain
         fprintf(stderr, "\n");
         (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
     }
@@ -1170,7 +1194,7 @@ static void run_generate(mis_tts* c, const int32_t* prompt_ids, const int32_t* p
         mix(ptrs, sizeof(ptrs));
         int ints[] = {batch, Lmax, max_tokens, c->Mpad, c->Smax, c->S_qkv, c->S_o, c->S_down, hidden_mode ? 1 : 0,
                       c->a_qkv.R, c->a_qkv.ksb, c->a_qkv.U, c->a_o.R, c->a_o.ksb, c->a_o.U, c->a_down.R, c->a_down.ksb, c->a_down.U,
-                      c->a_head.R, c->a_head.ksb, c->a_head.U, c->r_gu, c->ksb_gu};
+                      c->a_head.R, c->a_head.ksb, c->a_head.U, c->r_gu, c->ksb_gu, c->qa_gu.R, c->qa_gu.ksb, c->qa_head.R, c->qa_head.ksb};
         mix(ints, sizeof(ints));
         const void* hp[] = {hidden_mode ? (const void*)hm->hidden->p : nullptr, hidden_mode ? (const void*)hid_count.p : nullptr};
         mix(hp, sizeof(hp));
@@ -1447,8 +1471,10 @@ static void run_generate(mis_tts* c, const int32_t* prompt_ids, const int32_t* p
     c->timing.steps = steps;
     c->timing.step_ms_avg = steps ? c->timing.decode_ms / steps : 0;
     {
-        double w = 2.0 * ((double)c->L * ((double)c->Nqkv * c->d + (double)c->d * c->H * c->D + 3.0 * (double)c->ff * c->d) +
-                          (double)c->V * c->d);
+        // bytes per weight element as streamed: 2 (bf16) or bits / 8 + 4 / 64 (codes + a bf16 scale and bias per 64 codes)
+        auto bpe = [](const mis_tts::QRole& q) { return q.on ? q.bits / 8.0 + 4.0 / 64.0 : 2.0; };
+        double w = (double)c->L * (bpe(c->q_qkv) * c->Nqkv * c->d + bpe(c->q_o) * c->d * c->H * c->D + bpe(c->q_gu) * 2.0 * c->ff * c->d +
+                                   bpe(c->q_down) * c->ff * c->d) + bpe(c->q_head) * c->V * c->d;
         double mean_ctx = Lmax + steps / 2.0;
         double kvb = (double)batch * mean_ctx * c->L * 2.0 * c->Hkv * c->D * 2.0;
         c->timing.hbm_bytes_per_step = w + kvb;

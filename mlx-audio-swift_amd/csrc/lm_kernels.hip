@@ -1516,6 +1516,9 @@ void launch_attn_decode(const AttnParams& p, int batch, hipStream_t s) {
         if (v2 && !p.first_schedule && !p.cache_rows && !p.append_only && p.D == 128 && !p.cross && p.rope_cos && !p.rope_in_dtype && !p.qnorm_w && p.S <= 4 && G <= 4 && p.Smax <= 32 * ATT_WAVES * ATT2_MAX_J &&
             p.Smax % 32 == 0 && ((uintptr_t)p.qkv_part & 15) == 0 && p.Nqkv % 4 == 0) {
             const size_t sm2 = attn2_smem_bytes(G);
+            // k_attn_decode2 is compiled for 0 .. ATT2_MAX_J key tiles per wave (its switch has no case beyond): the cache must not hold more
+            MIS_REQUIRE((p.Smax / 32 + ATT_WAVES - 1) / ATT_WAVES <= ATT2_MAX_J, MIS_ERR_GENERATION_FAILED,
+                        "attention: %d cache positions need more than %d key tiles per wave", p.Smax, ATT2_MAX_J);
             switch (p.S) {
                 case 1: hipLaunchKernelGGL((k_attn_decode2<1>), grid, block, sm2, s, p); break;
                 case 2: hipLaunchKernelGGL((k_attn_decode2<2>), grid, block, sm2, s, p); break;

@@ -96,36 +96,45 @@ __device__ __forceinline__ void qgemm_epilogue(const f32x4_t (&acc)[R][MT], void
                 *reinterpret_cast<uint2*>(o + off) = v;
             }
         }
-    } else {   // EPI_SILU_MUL: tile 2t = gate rows, 2t+1 = up rows  (LlamaTTS.swift:283)
+    } else {   // EPI_SILU_MUL: tile 2t = gate rows, 2t+1 = up rows  (LlamaTTS.swift:283); R / 2 feature tiles per item
         bf16_t* o = reinterpret_cast<bf16_t*>(out);
 #pragma unroll
-        for (int mt = 0; mt < MT; ++mt) {
-            if (mt_only >= 0 && mt != mt_only) continue;
-            uint16_t res[4];
+        for (int pr = 0; pr < R / 2; ++pr) {
+            if (R > 2 && (ntg * R + 2 * pr + 1) >= NT) continue;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                float g = bf16_round_f32(acc[0][mt][e]);
-                float u = bf16_round_f32(acc[R - 1][mt][e]);
-                float sg = bf16_round_f32(1.0f / (1.0f + __expf(-g)));
-                float a = bf16_round_f32(g * sg);
-                res[e] = f32_to_bf16(a * u);
+            for (int mt = 0; mt < MT; ++mt) {
+                if (mt_only >= 0 && mt != mt_only) continue;
+                uint16_t res[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    float g = bf16_round_f32(acc[2 * pr][mt][e]);
+                    float u = bf16_round_f32(acc[2 * pr + 1][mt][e]);
+                    float sg = bf16_round_f32(1.0f / (1.0f + __expf(-g)));
+                    float a = bf16_round_f32(g * sg);
+                    res[e] = f32_to_bf16(a * u);
+                }
+                size_t off = xpk_index(mt * 16 + ml, (ntg * (R / 2) + pr) * 16 + nl, MT);
+                uint2 v;
+                v.x = (uint32_t)res[0] | ((uint32_t)res[1] << 16);
+                v.y = (uint32_t)res[2] | ((uint32_t)res[3] << 16);
+                *reinterpret_cast<uint2*>(o + off) = v;
             }
-            size_t off = xpk_index(mt * 16 + ml, ntg * 16 + nl, MT);
-            uint2 v;
-            v.x = (uint32_t)res[0] | ((uint32_t)res[1] << 16);
-            v.y = (uint32_t)res[2] | ((uint32_t)res[3] << 16);
-            *reinterpret_cast<uint2*>(o + off) = v;
         }
     }
 }
 
 // QGEMM_U = scale groups per register buffer: 2 (= 4 k-tiles, 196 VGPRs at MT = 2, two blocks per CU) or 1 (four blocks per CU; the
 // only one that fits without spills at MT >= 3)
+// Round 4: R = 4 n-tiles per wave with KSB = 4 or 8 waves per item (8: 512-thread blocks) for the wide roles.  What the round-3
+// diagnostics (loads-only build: 17.7 of 19.0 us) did not say is WHICH loads: the bf16 laboratory of round 4 shows launch time following
+// x-fragment bytes + weight bytes alike (every wave re-reads its x fragments out of L2; R = 2 -> 4 took the bf16 gate+up from 19.4 to
+// 17.6 us) - and at 8 bit the x fragments are TWICE the code bytes at R = 2.  Four tiles per wave halve them; one scale group per
+// buffer keeps the wave under 256 registers.
 template <int MT, int R, int EPI, int KSB, int BITS, int QGEMM_U>
-__global__ void __launch_bounds__(256, 2) k_gemm_skinny_q(const void* __restrict__ Qp, const bf16_t* __restrict__ SB, const bf16_t* __restrict__ X,
+__global__ void __launch_bounds__(KSB == 8 ? 512 : 256, 2) k_gemm_skinny_q(const void* __restrict__ Qp, const bf16_t* __restrict__ SB, const bf16_t* __restrict__ X,
                                                        void* __restrict__ out, int NT, int G, int S, int n_items, int N_out, int Mpad,
                                                        const bf16_t* __restrict__ bias) {
-    static_assert(EPI != EPI_SILU_MUL || R == 2, "silu-mul epilogue pairs a gate tile with an up tile");
+    static_assert(EPI != EPI_SILU_MUL || (R & 1) == 0, "silu-mul epilogue pairs a gate tile with an up tile");
     typedef typename QTile<BITS>::type WT;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int item = (KSB == 1) ? blockIdx.x * 4 + wave : blockIdx.x;
@@ -492,7 +501,7 @@ template <int MT, int BITS, int U>
 static void launch_qgemm_mt(int epi, int R, int ksb, const void* Qp, const bf16_t* SB, const bf16_t* X, void* out, int NT, int G, int S,
                             int N_out, int Mpad, const bf16_t* bias, hipStream_t s) {
     int n_items = ((NT + R - 1) / R) * S;
-    dim3 grid(ksb == 1 ? (n_items + 3) / 4 : n_items), block(256);
+    dim3 grid(ksb == 1 ? (n_items + 3) / 4 : n_items), block(ksb == 8 ? 512 : 256);
 #define QGEMM_CASE(E, RR, KS)                                                                                       \
     if (epi == E && R == RR && ksb == KS) {                                                                         \
         hipLaunchKernelGGL((k_gemm_skinny_q<MT, RR, E, KS, BITS, U>), grid, block, 0, s, Qp, SB, X, out, NT, G, S, n_items, \
@@ -506,6 +515,18 @@ static void launch_qgemm_mt(int epi, int R, int ksb, const void* Qp, const bf16_
     QGEMM_CASE(EPI_BF16, 2, 4)
     QGEMM_CASE(EPI_SILU_MUL, 2, 1)
     QGEMM_CASE(EPI_SILU_MUL, 2, 4)
+    if constexpr (MT <= 2 && U == 1) {             // four n-tiles per wave: one scale group per buffer, <= 32 rows
+        QGEMM_CASE(EPI_SILU_MUL, 4, 4)
+        QGEMM_CASE(EPI_SILU_MUL, 4, 8)
+        QGEMM_CASE(EPI_BF16, 4, 4)
+        QGEMM_CASE(EPI_BF16, 4, 8)
+        QGEMM_CASE(EPI_PARTIAL, 4, 4)
+        QGEMM_CASE(EPI_PARTIAL, 4, 8)
+    }
+    if constexpr (MT <= 2 && U == 2) {
+        QGEMM_CASE(EPI_SILU_MUL, 2, 8)
+        QGEMM_CASE(EPI_BF16, 2, 8)
+    }
 #undef QGEMM_CASE
     throw MisError(MIS_ERR_GENERATION_FAILED, "unsupported quantised GEMM variant");
 }
@@ -522,6 +543,16 @@ void launch_gemm_skinny_q(int bits, int epi, int R, int ksb, const void* Qp, con
     static const int v2 = getenv("MIS_QGEMM_V2") ? atoi(getenv("MIS_QGEMM_V2")) : 1;
     static const int v2_waves8 = getenv("MIS_QGEMM_V2_WAVES8") ? atoi(getenv("MIS_QGEMM_V2_WAVES8")) : 0;
     static const int v2_maxu = getenv("MIS_QGEMM_V2_MAXU") ? atoi(getenv("MIS_QGEMM_V2_MAXU")) : 6;
+    if (R == 4 || ksb == 8) {                      // the wide roles' arrangement (streaming kernel only): R = 4 -> one group per buffer
+        MIS_REQUIRE(Mpad / 16 <= 2, MIS_ERR_GENERATION_FAILED, "quantised GEMM: four n-tiles per wave / eight waves per item are built for <= 32 rows");
+#define QGEMM_R4(M, UU)                                                                                              \
+        { if (bits == 8) launch_qgemm_mt<M, 8, UU>(epi, R, ksb, Qp, SB, X, out, NT, G, S, N_out, Mpad, bias, s);         \
+          else launch_qgemm_mt<M, 4, UU>(epi, R, ksb, Qp, SB, X, out, NT, G, S, N_out, Mpad, bias, s);                   \
+          return; }
+        if (R == 4) { if (Mpad / 16 == 1) QGEMM_R4(1, 1) else QGEMM_R4(2, 1) }
+        else { if (Mpad / 16 == 1) QGEMM_R4(1, 2) else QGEMM_R4(2, 2) }
+#undef QGEMM_R4
+    }
     if (v2 && Mpad / 16 <= 2) {
         // where a wave's K share fits a buffer of 2, 4 or 6 scale groups (the smallest that holds it: groups past the share cost loads
         // and MFMAs); everything else streams through k_gemm_skinny_q.  Eight waves per item measured worse than four on every role

@@ -634,10 +634,11 @@ __device__ __forceinline__ unsigned sc_key32(float f) { const unsigned u = __flo
 __device__ __forceinline__ float sc_unkey32(unsigned k) { return __uint_as_float((k & 0x80000000u) ? (k & 0x7fffffffu) : ~k); }
 // row barrier: all of this block's exchange stores are performed, then one arrival; returns false on timeout.
 // spin_limit: polls before giving up (a poll is ~0.1 us; tests force a tiny limit to exercise the failure path)
-__device__ __forceinline__ bool sc_row_barrier(unsigned int* sync, unsigned target, int spin_limit) {
+__device__ __forceinline__ bool sc_row_barrier(unsigned int* sync, unsigned target, int spin_limit, unsigned long long* dbg = nullptr) {
     __shared__ int ok;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
+    if (dbg && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) *dbg = __builtin_readcyclecounter();      // (diagnostics: stores drained, block synced)
     if (threadIdx.x == 0) {
         __hip_atomic_fetch_add(sync, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         int good = 0;
@@ -672,9 +673,20 @@ __global__ void __launch_bounds__(SC_NT) k_samp_cluster(SamplerParams p, int spi
     allowed_range(p, step, lo, hi);
     bf16_t* logits = p.logits + (size_t)b * p.Vpad;
     const int my0 = (c * SC_NT + tid) * SC_PER;              // this thread's ids my0 .. my0 + SC_PER - 1
-    // ---- this block's 20 480 logits: coalesced 16-byte loads (three per thread at most; Vpad is a multiple of 16, so the row and the
-    // block's range start 32-byte aligned; chunks past the row re-read its last one - those ids are >= hi and masked below), requested
-    // FIRST: everything up to the staging below (the launch's barrier base, the repetition window, the penalties) runs under them
+    // ---- every load of the prologue is requested before anything waits, the small ones FIRST (loads retire in order: queued behind
+    // the three 16-byte chunk loads, the window entries held the first barrier up by 2.5 us - profiles/r04/c5_samp_phases.txt): the
+    // repetition window in full (its valid part is right-aligned; how long that is comes back with it), the row's barrier counter,
+    // then this block's 20 480 logits as coalesced 16-byte loads (three per thread at most; Vpad is a multiple of 16, so the row and
+    // the block's range start 32-byte aligned; chunks past the row re-read its last one - those ids are >= hi and masked below)
+    const bool penalise = p.penalty > 0.0f && p.penalty != 1.0f && p.window;
+    // (unconditional loads on clamped addresses: a guarded load is a branch with its own vmcnt(0) at the join - one dependent round trip
+    // per guard; the counter is read by every lane of every wave - one address, one transaction per wave)
+    const int32_t* wl_src = penalise ? p.window_len + b : reinterpret_cast<const int32_t*>(&sc->c_sync);
+    const int32_t* win_src = penalise ? p.window + (size_t)b * p.ctx + (tid < p.ctx ? tid : 0) : reinterpret_cast<const int32_t*>(&sc->c_sync);
+    const int wl_raw = *wl_src;
+    const int win_raw = *win_src;
+    const unsigned sync_now = __hip_atomic_load(&sc->c_sync, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const int wlen_all = penalise ? wl_raw : 0;
     uint4 q[3];
     {
         const uint4* lp = reinterpret_cast<const uint4*>(logits);
@@ -686,12 +698,11 @@ __global__ void __launch_bounds__(SC_NT) k_samp_cluster(SamplerParams p, int spi
             q[j] = lp[ch < n16 ? ch : n16 - 1];
         }
     }
-    const bool penalise = p.penalty > 0.0f && p.penalty != 1.0f && p.window;
-    const int wl = penalise ? min(p.window_len[b], 64) : 0;
-    if (tid < wl) swin[tid] = p.window[(size_t)b * p.ctx + (p.ctx - p.window_len[b]) + tid];      // (the first-occurrence test reads it O(wl) times)
+    const int wl = min(wlen_all, 64);
+    if (penalise && tid < p.ctx && tid >= p.ctx - wlen_all && tid - (p.ctx - wlen_all) < 64) swin[tid - (p.ctx - wlen_all)] = win_raw;
     unsigned base = 0;
     if (tid == 0) {
-        const unsigned v = __hip_atomic_load(&sc->c_sync, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const unsigned v = sync_now;
         base = v - (v % (unsigned)(SC_ARRIVALS * SC_NB));    // < 8 arrivals of this launch can have happened before this block's first
         redk[0] = base;                                      // barrier, so rounding down to a multiple of 24 gives the launch's base
         n_pen = 0;
@@ -770,7 +781,7 @@ __global__ void __launch_bounds__(SC_NT) k_samp_cluster(SamplerParams p, int spi
         sc_store(&sc->x_max[c], m);
     }
     SC_STAMP(2);                                             // block maximum published
-    bool alive = sc_row_barrier(&sc->c_sync, base + 1u * SC_NB, spin_limit);
+    bool alive = sc_row_barrier(&sc->c_sync, base + 1u * SC_NB, spin_limit, p.dbg ? p.dbg + 12 : nullptr);
     SC_STAMP(3);                                             // barrier 1 passed
     u64 rowk = 0;
 #pragma unroll
@@ -807,7 +818,7 @@ __global__ void __launch_bounds__(SC_NT) k_samp_cluster(SamplerParams p, int spi
         __syncthreads();
         SC_STAMP(5);                                         // level-1 histogram in LDS
         if (tid < 256) sc_store(&sc->x_hist1[c][tid], hist[tid]);
-        alive = sc_row_barrier(&sc->c_sync, base + 2u * SC_NB, spin_limit) && alive;
+        alive = sc_row_barrier(&sc->c_sync, base + 2u * SC_NB, spin_limit, p.dbg ? p.dbg + 13 : nullptr) && alive;
         SC_STAMP(6);                                         // barrier 2 passed
         u64 mine = 0;
 #pragma unroll

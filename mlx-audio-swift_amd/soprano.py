@@ -230,11 +230,12 @@ class SopranoModel:
         per-call maximum run in slices of MAX_BATCH (the reference loops sentence by sentence, Soprano.swift:637-676);
         the RNG is keyed by the global row index, so slicing does not change any row."""
         gp = generation_parameters or self.default_generation_parameters
-        if len(prompt_rows) > MAX_BATCH:
+        per_call = MAX_BATCH * (len(replicas) if replicas else 1)            # the engine's maximum is per replica
+        if len(prompt_rows) > per_call:
             from dataclasses import replace
             outs, toks_all = [], []
-            for i in range(0, len(prompt_rows), MAX_BATCH):
-                r = self.generate_batch(prompt_rows[i:i + MAX_BATCH], replace(gp, row_offset=gp.row_offset + i), return_tokens, replicas)
+            for i in range(0, len(prompt_rows), per_call):
+                r = self.generate_batch(prompt_rows[i:i + per_call], replace(gp, row_offset=gp.row_offset + i), return_tokens, replicas)
                 if return_tokens:
                     outs += r[0]; toks_all += r[1]
                 else:

@@ -1,20 +1,16 @@
 # One GPU call that regenerates the evidence under profiles/ (run through gpurun from the repo root):
-#   full -m gpu suite, the driver's bench command, rocprofv3 kernel stats of the bench, PMC traffic + MFMA utilisation passes,
-#   secondary benches.  Outputs land in gpurun_out/final/; copy what is to be judged into profiles/.
+#   full -m gpu suite, the driver's bench command (with its secondary block), rocprofv3 kernel stats of the bench, PMC traffic passes,
+#   sampler phase stamps.  Outputs land in gpurun_out/final/; copy what is to be judged into profiles/.
 set -x
 cd ${GRAFT_REPO_ROOT:-.}
 mkdir -p gpurun_out/final
 export TMPDIR=/tmp
-[ -n "$SKIP_TESTS" ] || { timeout 1500 python -m pytest tests -m gpu -q 2>&1 | grep -E "passed|failed|error" | tail -3 > gpurun_out/final/pytest_gpu.txt; cat gpurun_out/final/pytest_gpu.txt; }
+rm -f gpurun_out/parity_observed.jsonl
+[ -n "$SKIP_TESTS" ] || { timeout 1800 python -m pytest tests -m gpu -q 2>&1 | grep -E "passed|failed|error" | tail -3 > gpurun_out/final/pytest_gpu.txt; cat gpurun_out/final/pytest_gpu.txt; }
 cp gpurun_out/parity_observed.jsonl gpurun_out/final/ 2>/dev/null
 timeout 900 python bench.py > gpurun_out/final/bench.log 2>&1; tail -1 gpurun_out/final/bench.log > gpurun_out/final/bench.json
 rm -rf /tmp/ks; (cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/ks -- python $OLDPWD/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-secondary > /tmp/ks.log 2>&1)
 cp $(find /tmp/ks -name "*kernel_stats.csv" | head -1) gpurun_out/final/bench_kernel_stats.csv
 timeout 900 bash tools/pmc_traffic.sh final > gpurun_out/final/pmc.log 2>&1; cp gpurun_out/final_pmc/traffic.json gpurun_out/final/traffic.json
 rm -rf gpurun_out/final_pmc/fetch gpurun_out/final_pmc/write
-timeout 300 python tools/bench_whisper.py > gpurun_out/final/whisper.json 2>/dev/null
-timeout 300 python tools/bench_soprano.py 32 > gpurun_out/final/soprano_b32.json 2>/dev/null
-timeout 300 python tools/bench_qwen3tts.py 32 100 16 > gpurun_out/final/q3_bf16.json 2>/dev/null
-timeout 300 python tools/bench_qwen3tts.py 32 100 8 > gpurun_out/final/q3_8bit.json 2>/dev/null
-rm -rf /tmp/pm; (cd /tmp && timeout 600 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES GRBM_GUI_ACTIVE SQ_WAVES --kernel-trace --output-format csv -d /tmp/pm -- python $OLDPWD/tools/pmc_codec_probe.py all > /tmp/pm.log 2>&1)
-python tools/pmc_mfma_reduce.py /tmp/pm gpurun_out/final/mfma_util.json > /dev/null
+timeout 120 python tools/samp_phases.py 32 2> gpurun_out/final/samp_phases.txt
