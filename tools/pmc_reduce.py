@@ -50,24 +50,18 @@ def main():
         table[k] = {"dispatches": n, "FETCH_SIZE_KiB": round(fe, 1), "WRITE_SIZE_KiB": round(wr, 1),
                     "hbm_bytes_per_launch": int(2 * fe * 1024 + wr * 1024)}
     res["kernels"] = table
-    # named entries: match by dispatch count / size where the template arguments do not identify the launch
-    for name, key in (("gate_up", "k_gemm_skinny<2, 2, 2, 4>"), ("lm_head", "k_gemm_skinny<2, 2, 1, 1>"), ("attn_decode_ctx368", "k_attn_decode"),
-                      ("reduce_residual_rmsnorm", "k_reduce_residual_rmsnorm")):
+    # named entries: the round-4 build gives every role its own instantiation k_gemm_skinny<MT, R, epilogue, KSB, U>
+    for name, key in (("gate_up", "k_gemm_skinny<2, 4, 2, 4, 3>"), ("lm_head", "k_gemm_skinny<2, 4, 1, 4, 3>"), ("qkv", "k_gemm_skinny<2, 4, 0, 2, 2>"),
+                      ("o_proj", "k_gemm_skinny<2, 2, 0, 4, 4>"), ("down", "k_gemm_skinny<2, 2, 0, 2, 4>"), ("attn_decode_ctx368", "k_attn_decode"),
+                      ("reduce_residual_rmsnorm", "k_glue4")):
         ks = [k for k in table if key in k]
         if ks:
             e = dict(table[ks[0]]); e["kernel"] = ks[0]
             if name in alg:
                 e["algorithmic_bytes_per_launch"] = alg[name]; e["ratio"] = round(e["hbm_bytes_per_launch"] / alg[name], 3)
+                if name in ("qkv", "o_proj", "down"):
+                    e["note"] = "traffic includes the f32 partial slabs written for the consumer (S x 32 x N x 4 B per launch)"
             res[name] = e
-    # the three split-K GEMMs share one instantiation (k_gemm_skinny<2,2,0,4>): report their sum against the summed algorithmic bytes
-    ks = [k for k in table if "k_gemm_skinny<2, 2, 0, 4>" in k]
-    if ks:
-        n = table[ks[0]]["dispatches"]
-        tot = table[ks[0]]["hbm_bytes_per_launch"] * n
-        a = (alg["qkv"] + alg["o_proj"] + alg["down"]) * (n / 3.0)
-        res["split_k_gemms_qkv_o_down"] = {"kernel": ks[0], "dispatches": n, "hbm_bytes_total": int(tot), "algorithmic_bytes_total": int(a),
-                                           "ratio": round(tot / a, 3),
-                                           "note": "traffic includes the f32 partial slabs written for the consumer (S x 32 x N x 4 B per launch)"}
     os.makedirs(os.path.dirname(out), exist_ok=True)
     json.dump(res, open(out, "w"), indent=1)
     print(json.dumps({k: v for k, v in res.items() if k not in ("kernels", "_how")}, indent=1))
