@@ -1013,7 +1013,7 @@ extern "C" mis_status mis_sample_logits(int device, const float* logits, int bat
     }
     DevBuf<unsigned long long> dbg;
     const bool want_dbg = getenv("MIS_SAMP_DBG") != nullptr;        // diagnostics: phase stamps of block (0, 0) on stderr (tools/samp_phases.py)
-    if (want_dbg) { dbg.alloc(16); dbg.zero(0); sp.dbg = dbg.p; }
+    if (want_dbg) { dbg.alloc(48); dbg.zero(0); sp.dbg = dbg.p; }
     launch_sampler(sp, batch, 0);
     HIP_CHECK(hipGetLastError());
     if (want_dbg) {
@@ -1026,10 +1026,15 @@ extern "C" mis_status mis_sample_logits(int device, const float* logits, int bat
         HIP_CHECK(hipEventSynchronize(e1));
         float ms = 0;
         HIP_CHECK(hipEventElapsedTime(&ms, e0, e1));
-        unsigned long long st[16];
+        unsigned long long st[48];
         HIP_CHECK(hipMemcpy(st, dbg.p, sizeof(st), hipMemcpyDeviceToHost));
         fprintf(stderr, "SAMP_DBG us_per_launch %.2f stamps", ms * 1e3 / 20);
         for (int i = 0; i < 14; ++i) fprintf(stderr, " %llu", st[i] ? st[i] - st[0] : 0ull);         // 12, 13: inside barriers 1 / 2, after the store drain
+        fprintf(stderr, " | row-0 blocks, 10 ns ticks since the earliest entry (entry, at barrier 1, past 1, past 2):");
+        unsigned long long t0w = ~0ull;
+        for (int cb = 0; cb < 8; ++cb) if (st[16 + 4 * cb] && st[16 + 4 * cb] < t0w) t0w = st[16 + 4 * cb];
+        for (int cb = 0; cb < 8; ++cb) fprintf(stderr, " [%llu %llu %llu %llu]", st[16 + 4 * cb] - t0w, st[17 + 4 * cb] - t0w, st[18 + 4 * cb] - t0w,
+                                               st[19 + 4 * cb] ? st[19 + 4 * cb] - t0w : 0ull);
         fprintf(stderr, "\n");
         (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
     }

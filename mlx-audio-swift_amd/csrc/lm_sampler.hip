@@ -627,6 +627,9 @@ __global__ void __launch_bounds__(SN_NT) k_samp_narrow(SamplerParams p) {
 #define SC_PER 20
 #define SC_ARRIVALS 3
 #define SC_STAMP(i) do { if (p.dbg && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) p.dbg[i] = __builtin_readcyclecounter(); } while (0)
+// the same for every block of row 0 on the constant 100 MHz counter (comparable across XCDs): dbg[16 + 4 c + k], k = entry / at barrier 1 /
+// past barrier 1 / past barrier 2 - who waits for whom
+#define SC_WALL(k) do { if (p.dbg && blockIdx.y == 0 && threadIdx.x == 0) p.dbg[16 + 4 * blockIdx.x + (k)] = wall_clock64(); } while (0)
 static_assert(SC_NB == SAMP_CLUSTER_NB, "exchange slots per row (lm_kernels.h)");
 __device__ __forceinline__ u64 sc_load(const u64* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ void sc_store(u64* p, u64 v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
@@ -666,6 +669,7 @@ __global__ void __launch_bounds__(SC_NT) k_samp_cluster(SamplerParams p, int spi
     __shared__ int s_token;
     const int c = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
     SC_STAMP(0);
+    SC_WALL(0);
     if (row_skipped(p, b)) return;                           // (row-uniform: all 8 blocks of the row take the same exit)
     SamplerScratch* sc = p.scratch + b;
     const int step = row_step(p, b);
@@ -781,8 +785,10 @@ __global__ void __launch_bounds__(SC_NT) k_samp_cluster(SamplerParams p, int spi
         sc_store(&sc->x_max[c], m);
     }
     SC_STAMP(2);                                             // block maximum published
+    SC_WALL(1);
     bool alive = sc_row_barrier(&sc->c_sync, base + 1u * SC_NB, spin_limit, p.dbg ? p.dbg + 12 : nullptr);
     SC_STAMP(3);                                             // barrier 1 passed
+    SC_WALL(2);
     u64 rowk = 0;
 #pragma unroll
     for (int k = 0; k < SC_NB; ++k) { const u64 v = sc_load(&sc->x_max[k]); rowk = v > rowk ? v : rowk; }
@@ -820,6 +826,7 @@ __global__ void __launch_bounds__(SC_NT) k_samp_cluster(SamplerParams p, int spi
         if (tid < 256) sc_store(&sc->x_hist1[c][tid], hist[tid]);
         alive = sc_row_barrier(&sc->c_sync, base + 2u * SC_NB, spin_limit, p.dbg ? p.dbg + 13 : nullptr) && alive;
         SC_STAMP(6);                                         // barrier 2 passed
+        SC_WALL(3);
         u64 mine = 0;
 #pragma unroll
         for (int k = 0; k < SC_NB; ++k) mine += tid < 256 ? sc_load(&sc->x_hist1[k][tid]) : 0;

@@ -15,7 +15,23 @@
 #include "common.h"
 #include "whisper_kernels.h"
 
-__device__ __forceinline__ float gelu_erf_w(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
+// GELU (erf form, WhisperLayers.swift:142-156 via MLXNN.GELU) for the encoder's big-GEMM epilogues.  erff() from the device library is
+// ~60 instructions per element once both of its range branches run in a wave - 15 us per 256 x 256 output tile, fully exposed with one
+// block per CU (k_gemm_big3<GELU> 237.7 us against 187.6 us for the same main loop without epilogue, profiles/r04/c6_whisper_kernel_stats.csv).
+// Here: erfc(|z|) = poly5(t) exp(-z^2), t = 1 / (1 + 0.3275911 |z|) (Abramowitz & Stegun 7.1.26, |error| <= 1.5e-7), branch-free, and
+// 1 + erf(z) taken as erfc(-z) for z < 0 - no cancellation on the negative side.  Against the float64 value, after the bf16 rounding
+// that follows: max |diff| 1.0e-6 of full scale, fewer mismatching roundings than the float32 0.5 x (1 + erf) form itself has.
+__device__ __forceinline__ float gelu_erf_w(float x) {
+    const float z = fabsf(x) * 0.70710678118654752f;
+    const float t = __frcp_rn(1.0f + 0.3275911f * z);
+    float p = 1.061405429f;
+    p = p * t - 1.453152027f;
+    p = p * t + 1.421413741f;
+    p = p * t - 0.284496736f;
+    p = p * t + 0.254829592f;
+    const float ec = p * t * __expf(-(z * z));            // erfc(|x| / sqrt 2)
+    return 0.5f * x * (x >= 0.0f ? 2.0f - ec : ec);
+}
 
 // ============================================================================ big GEMM
 #define BG_BM 128
@@ -323,23 +339,25 @@ __global__ void __launch_bounds__(512, 1) k_gemm_big3(BigGemmParams p) {
             const int m = m0 + wm * (BG3_BM / WM) + j * 16 + (lane & 15);
             if (m >= p.M) continue;
             uint16_t res[4];
+            float rv[4] = {0.f, 0.f, 0.f, 0.f};                                     // residual / positional row: ONE 8-byte load (N % 4 == 0)
+            if (EPI == BG_RESID || EPI == BG_GELU_POS) {
+                const size_t rrow = EPI == BG_RESID ? (size_t)m : (size_t)(m % p.pos_rows);
+                const uint2 rq = *reinterpret_cast<const uint2*>(p.R + rrow * p.N + n);
+                rv[0] = __uint_as_float(rq.x << 16); rv[1] = __uint_as_float(rq.x & 0xffff0000u);
+                rv[2] = __uint_as_float(rq.y << 16); rv[3] = __uint_as_float(rq.y & 0xffff0000u);
+            }
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 float v = bf16_round_f32(acc[i][j][e] + bv[e]);                       // T(xW^T + b)
                 if (EPI == BG_GELU || EPI == BG_GELU_POS) v = bf16_round_f32(gelu_erf_w(v));
-                if (EPI == BG_RESID) v = bf16_round_f32(v + bf16_to_f32(p.R[(size_t)m * p.N + n + e]));
-                if (EPI == BG_GELU_POS) v = bf16_round_f32(v + bf16_to_f32(p.R[(size_t)(m % p.pos_rows) * p.N + n + e]));
+                if (EPI == BG_RESID || EPI == BG_GELU_POS) v = bf16_round_f32(v + rv[e]);
                 res[e] = f32_to_bf16(v);
             }
             bf16_t* o = p.C + (size_t)m * p.N + n;
-            if (n + 3 < p.N) {
-                uint2 v;
-                v.x = (uint32_t)res[0] | ((uint32_t)res[1] << 16);
-                v.y = (uint32_t)res[2] | ((uint32_t)res[3] << 16);
-                *reinterpret_cast<uint2*>(o) = v;
-            } else {
-                for (int e = 0; e < 4 && n + e < p.N; ++e) o[e] = res[e];
-            }
+            uint2 v;
+            v.x = (uint32_t)res[0] | ((uint32_t)res[1] << 16);
+            v.y = (uint32_t)res[2] | ((uint32_t)res[3] << 16);
+            *reinterpret_cast<uint2*>(o) = v;                                       // (n < N and N % 4 == 0: the four columns exist)
         }
     }
 }

@@ -287,8 +287,8 @@ def test_group_of_two_logical_shards_returns_the_unsharded_tokens():
         whole = a.transcribe_windows(wins, prompt, gp)
         sharded = a.transcribe_windows(wins, prompt, gp, replicas=[a, b])
         assert sharded == whole, temp
-    with pytest.raises(mas.AudioGenerationError):
-        a.transcribe_windows(wins[:1], prompt, gp, replicas=[a, b])          # fewer rows than replicas
+    # fewer rows than replicas (the tail slice of a long request): the group runs them on its first `rows` replicas
+    assert a.transcribe_windows(wins[:1], prompt, gp, replicas=[a, b]) == a.transcribe_windows(wins[:1], prompt, gp)
 
 
 def test_encoder_256x256_tile_gemm_is_bit_identical_to_the_128x128_kernel(monkeypatch):
