@@ -1030,7 +1030,7 @@ extern "C" mis_status mis_sample_logits(int device, const float* logits, int bat
         HIP_CHECK(hipMemcpy(st, dbg.p, sizeof(st), hipMemcpyDeviceToHost));
         fprintf(stderr, "SAMP_DBG us_per_launch %.2f stamps", ms * 1e3 / 20);
         for (int i = 0; i < 14; ++i) fprintf(stderr, " %llu", st[i] ? st[i] - st[0] : 0ull);         // 12, 13: inside barriers 1 / 2, after the store drain
-        fprintf(stderr, " | row-0 blocks, 10 ns ticks since the earliest entry (entry, at barrier 1, past 1, past 2):");
+        fprintf(stderr, " | row-0 blocks, 10 ns ticks since the earliest entry (entry, logits loaded, at barrier 1, past 1):");
         unsigned long long t0w = ~0ull;
         for (int cb = 0; cb < 8; ++cb) if (st[16 + 4 * cb] && st[16 + 4 * cb] < t0w) t0w = st[16 + 4 * cb];
         for (int cb = 0; cb < 8; ++cb) fprintf(stderr, " [%llu %llu %llu %llu]", st[16 + 4 * cb] - t0w, st[17 + 4 * cb] - t0w, st[18 + 4 * cb] - t0w,

@@ -627,8 +627,8 @@ __global__ void __launch_bounds__(SN_NT) k_samp_narrow(SamplerParams p) {
 #define SC_PER 20
 #define SC_ARRIVALS 3
 #define SC_STAMP(i) do { if (p.dbg && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) p.dbg[i] = __builtin_readcyclecounter(); } while (0)
-// the same for every block of row 0 on the constant 100 MHz counter (comparable across XCDs): dbg[16 + 4 c + k], k = entry / at barrier 1 /
-// past barrier 1 / past barrier 2 - who waits for whom
+// the same for every block of row 0 on the constant 100 MHz counter (comparable across XCDs): dbg[16 + 4 c + k], k = entry / logits in registers /
+// at barrier 1 / past barrier 1 - who waits for whom
 #define SC_WALL(k) do { if (p.dbg && blockIdx.y == 0 && threadIdx.x == 0) p.dbg[16 + 4 * blockIdx.x + (k)] = wall_clock64(); } while (0)
 static_assert(SC_NB == SAMP_CLUSTER_NB, "exchange slots per row (lm_kernels.h)");
 __device__ __forceinline__ u64 sc_load(const u64* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
@@ -691,9 +691,10 @@ __global__ void __launch_bounds__(SC_NT) k_samp_cluster(SamplerParams p, int spi
     const int win_raw = *win_src;
     const unsigned sync_now = __hip_atomic_load(&sc->c_sync, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     const int wlen_all = penalise ? wl_raw : 0;
-    uint4 q[3];
+    typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));       // (a native vector: HIP's uint4 struct kept this array in scratch)
+    u32x4_t q[3];
     {
-        const uint4* lp = reinterpret_cast<const uint4*>(logits);
+        const u32x4_t* lp = reinterpret_cast<const u32x4_t*>(logits);
         const int n16 = p.Vpad >> 3;                                     // 16-byte chunks in the row
         const int c0 = c * (SC_NT * SC_PER / 8);                         // first chunk of this block
 #pragma unroll
@@ -738,7 +739,7 @@ __global__ void __launch_bounds__(SC_NT) k_samp_cluster(SamplerParams p, int spi
     {
 #pragma unroll
         for (int j = 0; j < 3; ++j)
-            if (tid + j * SC_NT < SC_NT * SC_PER / 8) reinterpret_cast<uint4*>(stage)[tid + j * SC_NT] = q[j];
+            if (tid + j * SC_NT < SC_NT * SC_PER / 8) reinterpret_cast<u32x4_t*>(stage)[tid + j * SC_NT] = q[j];
         __syncthreads();
 #pragma unroll
         for (int j = 0; j < SC_PER / 4; ++j) {
@@ -758,6 +759,7 @@ __global__ void __launch_bounds__(SC_NT) k_samp_cluster(SamplerParams p, int spi
         }
     }
     SC_STAMP(1);                                             // logits loaded, penalties patched
+    SC_WALL(1);
     // ---- max (first index on ties) as one comparable 64-bit key: (order-preserving float key, ~index)
     u64 bestk = 0;
 #pragma unroll
@@ -785,10 +787,10 @@ __global__ void __launch_bounds__(SC_NT) k_samp_cluster(SamplerParams p, int spi
         sc_store(&sc->x_max[c], m);
     }
     SC_STAMP(2);                                             // block maximum published
-    SC_WALL(1);
+    SC_WALL(2);
     bool alive = sc_row_barrier(&sc->c_sync, base + 1u * SC_NB, spin_limit, p.dbg ? p.dbg + 12 : nullptr);
     SC_STAMP(3);                                             // barrier 1 passed
-    SC_WALL(2);
+    SC_WALL(3);
     u64 rowk = 0;
 #pragma unroll
     for (int k = 0; k < SC_NB; ++k) { const u64 v = sc_load(&sc->x_max[k]); rowk = v > rowk ? v : rowk; }
@@ -826,7 +828,6 @@ __global__ void __launch_bounds__(SC_NT) k_samp_cluster(SamplerParams p, int spi
         if (tid < 256) sc_store(&sc->x_hist1[c][tid], hist[tid]);
         alive = sc_row_barrier(&sc->c_sync, base + 2u * SC_NB, spin_limit, p.dbg ? p.dbg + 13 : nullptr) && alive;
         SC_STAMP(6);                                         // barrier 2 passed
-        SC_WALL(3);
         u64 mine = 0;
 #pragma unroll
         for (int k = 0; k < SC_NB; ++k) mine += tid < 256 ? sc_load(&sc->x_hist1[k][tid]) : 0;
