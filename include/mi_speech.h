@@ -241,7 +241,11 @@ mis_status mis_lm_forward(mis_tts*, const int32_t* ids, const uint8_t* active, f
 mis_status mis_lm_forward_hidden(mis_tts*, const int32_t* ids, const uint8_t* active, float* logits_out, float* hidden_out);
 /* processor + sampler of the generate loop (LlamaTTS.swift:717-721) on caller-provided logits:
  * logits f32 [batch, vocab]; window [batch, ctx] (ids, right-aligned valid part = window_len[b]);
- * lo/hi: optional allowed id range (hi<=0 => vocab); tokens_out [batch].  mis-sampler-v1. */
+ * lo/hi: optional allowed id range (hi<=0 => vocab); tokens_out [batch].  mis-sampler-v1.
+ * Wide ranges run in ONE launch whose 8 blocks per row wait for each other (bounded spins); if a row's blocks were not all resident
+ * (another stream holding CUs) the time-out is detected after the launch and the call falls back to the multi-launch path on fresh
+ * inputs - the tokens are the same.  Inside mis_*_generate* (a captured graph) the same condition is reported as
+ * MIS_ERR_GENERATION_FAILED after the decode loop; MIS_SAMPLER_WIDE=1 selects the multi-launch path for such deployments. */
 mis_status mis_sample_logits(int device, const float* logits, int batch, int vocab,
                              const int32_t* window, const int32_t* window_len, int ctx,
                              const mis_gen_params* params, int step, int lo, int hi,

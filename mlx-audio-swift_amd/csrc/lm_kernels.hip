@@ -1186,7 +1186,10 @@ __device__ __forceinline__ void att2_issue_tile(const bf16_t* kt, const bf16_t* 
     asm volatile("" : "+v"(KA[0][0]), "+v"(KA[0][1]), "+v"(KA[0][2]), "+v"(KA[0][3]), "+v"(KA[1][0]), "+v"(KA[1][1]), "+v"(KA[1][2]),  \
                       "+v"(KA[1][3]), "+v"(VB[0]), "+v"(VB[1]), "+v"(VB[2]), "+v"(VB[3]), "+v"(VB[4]), "+v"(VB[5]), "+v"(VB[6]), "+v"(VB[7]))
 
-template <int NS>
+// PAIR (round 4, MIS_ATTN_PAIR=1): a wave with two or more tiles requests its first TWO tiles before the prologue instead of one - the
+// second round of requests otherwise starts only after the prologue (~3 us into the launch), behind the first 32 MB of the launch's
+// stream.  Same waits after the prologue (tile B is then simply the youngest 16 loads already).
+template <int NS, bool PAIR>
 __global__ void __launch_bounds__(512) k_attn_decode2(AttnParams p) {
     constexpr int D = 128;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -1264,7 +1267,8 @@ __global__ void __launch_bounds__(512) k_attn_decode2(AttnParams p) {
         }
 
         if constexpr (NJ >= 1) att2_issue_tile(ktile(wave), vtile(wave), voff, kA, vA);
-        if constexpr (NJ >= 1) ATT2_VMCNT(16); else ATT2_VMCNT(0);
+        if constexpr (PAIR && NJ >= 2) att2_issue_tile(ktile(wave + ATT_WAVES), vtile(wave + ATT_WAVES), voff, kB, vB);
+        if constexpr (PAIR && NJ >= 2) ATT2_VMCNT(32); else if constexpr (NJ >= 1) ATT2_VMCNT(16); else ATT2_VMCNT(0);
         // (one binding statement; every register exactly once - a variable named twice is copied ahead of the statement, i.e. ahead
         // of the wait)
         asm volatile("" : "+v"(rc[0][0]), "+v"(rc[0][1]), "+v"(rc[1][0]), "+v"(rc[1][1]), "+v"(rs[0][0]), "+v"(rs[0][1]), "+v"(rs[1][0]), "+v"(rs[1][1]),
@@ -1405,7 +1409,7 @@ __global__ void __launch_bounds__(512) k_attn_decode2(AttnParams p) {
         // (sched barriers: left alone the scheduler starts requesting tile j + 2 while the P.V MFMAs of tile j still read the buffer -
         // the asm outputs then need 64 NEW registers next to the old buffer and the tile in flight, and the kernel spills.)
         __builtin_amdgcn_sched_barrier(0);
-        if constexpr (NJ >= 2) att2_issue_tile(ktile(wave + ATT_WAVES), vtile(wave + ATT_WAVES), voff, kB, vB);
+        if constexpr (!PAIR && NJ >= 2) att2_issue_tile(ktile(wave + ATT_WAVES), vtile(wave + ATT_WAVES), voff, kB, vB);
         if constexpr (NJ >= 1) {
             if constexpr (NJ >= 2) ATT2_VMCNT(16); else ATT2_VMCNT(0);
             ATT2_BIND_TILE(kA, vA);
@@ -1519,11 +1523,19 @@ void launch_attn_decode(const AttnParams& p, int batch, hipStream_t s) {
             // k_attn_decode2 is compiled for 0 .. ATT2_MAX_J key tiles per wave (its switch has no case beyond): the cache must not hold more
             MIS_REQUIRE((p.Smax / 32 + ATT_WAVES - 1) / ATT_WAVES <= ATT2_MAX_J, MIS_ERR_GENERATION_FAILED,
                         "attention: %d cache positions need more than %d key tiles per wave", p.Smax, ATT2_MAX_J);
-            switch (p.S) {
-                case 1: hipLaunchKernelGGL((k_attn_decode2<1>), grid, block, sm2, s, p); break;
-                case 2: hipLaunchKernelGGL((k_attn_decode2<2>), grid, block, sm2, s, p); break;
-                case 3: hipLaunchKernelGGL((k_attn_decode2<3>), grid, block, sm2, s, p); break;
-                default: hipLaunchKernelGGL((k_attn_decode2<4>), grid, block, sm2, s, p); break;
+            const char* ep = getenv("MIS_ATTN_PAIR");
+            const bool pair = ep && atoi(ep) != 0;
+            if (pair) switch (p.S) {
+                case 1: hipLaunchKernelGGL((k_attn_decode2<1, true>), grid, block, sm2, s, p); break;
+                case 2: hipLaunchKernelGGL((k_attn_decode2<2, true>), grid, block, sm2, s, p); break;
+                case 3: hipLaunchKernelGGL((k_attn_decode2<3, true>), grid, block, sm2, s, p); break;
+                default: hipLaunchKernelGGL((k_attn_decode2<4, true>), grid, block, sm2, s, p); break;
+            }
+            else switch (p.S) {
+                case 1: hipLaunchKernelGGL((k_attn_decode2<1, false>), grid, block, sm2, s, p); break;
+                case 2: hipLaunchKernelGGL((k_attn_decode2<2, false>), grid, block, sm2, s, p); break;
+                case 3: hipLaunchKernelGGL((k_attn_decode2<3, false>), grid, block, sm2, s, p); break;
+                default: hipLaunchKernelGGL((k_attn_decode2<4, false>), grid, block, sm2, s, p); break;
             }
             return;
         }

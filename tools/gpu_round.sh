@@ -14,3 +14,5 @@ cp $(find /tmp/ks -name "*kernel_stats.csv" | head -1) gpurun_out/final/bench_ke
 timeout 900 bash tools/pmc_traffic.sh final > gpurun_out/final/pmc.log 2>&1; cp gpurun_out/final_pmc/traffic.json gpurun_out/final/traffic.json
 rm -rf gpurun_out/final_pmc/fetch gpurun_out/final_pmc/write
 timeout 120 python tools/samp_phases.py 32 2> gpurun_out/final/samp_phases.txt
+rm -rf /tmp/pm; (cd /tmp && timeout 600 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES GRBM_GUI_ACTIVE SQ_WAVES --kernel-trace --output-format csv -d /tmp/pm -- python $OLDPWD/tools/pmc_codec_probe.py whisper > /tmp/pm.log 2>&1)
+python tools/pmc_mfma_reduce.py /tmp/pm gpurun_out/final/whisper_mfma_util.json > /dev/null
