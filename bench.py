@@ -444,6 +444,9 @@ def main():
                                         "launch: the path of an unconstrained checkpoint; frame_constrained = 2 gives the ids outside the "
                                         "step's frame slot zero mass so that the tokens form valid frames)",
                         "timed_step_ms": timing["step_ms_avg"],
+                        "stand_in_note": "ids outside the frame slot carry zero mass and skip their histogram update: with every id live the "
+                                         "sampler launch costs 36.5 us instead of 32.9 us (tools/samp_phases.py, profiles/r04/c11_samp_phases.txt) - "
+                                         "about +3.6 us per step (0.17 %) for a real unconstrained checkpoint",
                         "frame_slot_step_ms": narrow["step_ms"] if narrow else None,
                         "frame_slot": "secondary: the same generate with the sampler visiting only the 4096 ids of the step's frame slot "
                                       "(k_samp_narrow, frame_constrained = 1 - a shortcut only a frame-locked checkpoint could take); "
