@@ -463,9 +463,101 @@ __global__ void __launch_bounds__(1024) k_glue4(const float* __restrict__ slabs,
     }
 }
 
+// The RMSNorm glue with THREE column groups per thread (N / 12 threads per row: 256 at d = 3072 - four waves instead of twelve).  The launch
+// is latency-bound (one dependent round trip, one block reduction, 32 blocks), so what a block costs before its first load is issued
+// and at its barrier counts: fewer waves to place and to meet.  Same arithmetic, same summation order per column as k_glue4 (slab
+// order 0, 1, ...); the row's sum of squares is reduced in another order (three columns groups per lane, then DPP, then four waves)
+// - a float32 sum of 3072 squares either way.  MIS_GLUE_CPT=1 keeps one group per thread (A/B).
+template <int SG>
+__global__ void __launch_bounds__(256) k_glue4x3(const float* __restrict__ slabs, int S, int Mpad, int N, bf16_t* __restrict__ h,
+                                                 const bf16_t* __restrict__ wnorm, bf16_t* __restrict__ x, float eps) {
+    __shared__ float red[4];
+    const int m = blockIdx.x, tid = threadIdx.x, nth = blockDim.x;
+    const int MT = Mpad >> 4;
+    const int ng = N >> 2;                                       // column groups of four; ng == 3 * nth (checked by the launcher)
+    unsigned long long hq[3], wq[3];
+    f32x4_t v[3][SG];
+#pragma unroll
+    for (int g = 0; g < 3; ++g) {
+        const int c4 = tid + g * nth;
+        const bf16_t* hp = h + (size_t)m * N + 4 * c4;
+        const bf16_t* wp = wnorm + 4 * c4;
+        asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(hq[g]) : "v"(hp));
+        asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(wq[g]) : "v"(wp));
+    }
+#pragma unroll
+    for (int j = 0; j < SG; ++j) {
+        const int sj = j < S ? j : S - 1;
+#pragma unroll
+        for (int g = 0; g < 3; ++g) {
+            const float* sp = slabs + ((size_t)sj * Mpad + m) * N + 4 * (tid + g * nth);
+            asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(v[g][j]) : "v"(sp));
+        }
+    }
+    // ONE wait naming every destination (volatile asm statements keep their order; hipcc does not count asm loads itself)
+#pragma unroll
+    for (int g = 0; g < 3; ++g) {
+        if (g == 0) asm volatile("s_waitcnt vmcnt(0)" : "+v"(hq[0]), "+v"(wq[0]));
+        else asm volatile("" : "+v"(hq[g]), "+v"(wq[g]));
+#pragma unroll
+        for (int j = 0; j < SG; ++j) asm volatile("" : "+v"(v[g][j]));
+    }
+    float hn[3][4], wv[3][4], ss = 0.0f;
+#pragma unroll
+    for (int g = 0; g < 3; ++g) {
+        float acc[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int j = 0; j < SG; ++j) {                           // slab order 0, 1, 2, ... (fixed => deterministic)
+            const bool on = j < S;
+            acc[0] += on ? v[g][j][0] : 0.0f; acc[1] += on ? v[g][j][1] : 0.0f; acc[2] += on ? v[g][j][2] : 0.0f; acc[3] += on ? v[g][j][3] : 0.0f;
+        }
+        const uint32_t h0 = (uint32_t)hq[g], h1 = (uint32_t)(hq[g] >> 32), w0 = (uint32_t)wq[g], w1 = (uint32_t)(wq[g] >> 32);
+        const float hv[4] = {bf16_to_f32((bf16_t)(h0 & 0xffffu)), bf16_to_f32((bf16_t)(h0 >> 16)), bf16_to_f32((bf16_t)(h1 & 0xffffu)), bf16_to_f32((bf16_t)(h1 >> 16))};
+        wv[g][0] = bf16_to_f32((bf16_t)(w0 & 0xffffu)); wv[g][1] = bf16_to_f32((bf16_t)(w0 >> 16));
+        wv[g][2] = bf16_to_f32((bf16_t)(w1 & 0xffffu)); wv[g][3] = bf16_to_f32((bf16_t)(w1 >> 16));
+        bf16_t hb[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            hn[g][e] = bf16_round_f32(hv[e] + bf16_round_f32(acc[e]));   // o = T(sum slabs); h = T(h + o)
+            hb[e] = f32_to_bf16(hn[g][e]);
+            ss += hn[g][e] * hn[g][e];
+        }
+        *reinterpret_cast<uint2*>(h + (size_t)m * N + 4 * (tid + g * nth)) =
+            make_uint2((uint32_t)hb[0] | ((uint32_t)hb[1] << 16), (uint32_t)hb[2] | ((uint32_t)hb[3] << 16));
+    }
+    ss = wave_sum_dpp(ss);
+    if ((tid & 63) == 0) red[tid >> 6] = ss;
+    __syncthreads();
+    float tot = 0.0f;
+    const int nw = nth >> 6;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) tot += i < nw ? red[i] : 0.0f;
+    const float inv = 1.0f / sqrtf(tot / (float)N + eps);
+#pragma unroll
+    for (int g = 0; g < 3; ++g) {
+        bf16_t xb[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) xb[e] = f32_to_bf16(wv[g][e] * bf16_round_f32(hn[g][e] * inv));
+        *reinterpret_cast<uint2*>(x + xpk_index(m, 4 * (tid + g * nth), MT)) =
+            make_uint2((uint32_t)xb[0] | ((uint32_t)xb[1] << 16), (uint32_t)xb[2] | ((uint32_t)xb[3] << 16));
+    }
+    (void)ng;
+}
+
 void launch_reduce_residual_rmsnorm(const float* slabs, int S, int Mpad, int N, bf16_t* h, const bf16_t* wnorm,
                                     bf16_t* x, float eps, hipStream_t s, const bf16_t* ln_bias) {
     static const int v4 = getenv("MIS_GLUE_V4") ? atoi(getenv("MIS_GLUE_V4")) : 1;
+    {   // three column groups per thread where the row divides that way into whole waves (d = 3072: 256 threads)
+        const char* ec = getenv("MIS_GLUE_CPT");
+        const bool cpt3 = !(ec && atoi(ec) == 1);
+        if (v4 && cpt3 && !ln_bias && N % 12 == 0 && (N / 12) % 64 == 0 && N / 12 <= 256 && S <= 8) {
+            const int nth = N / 12;
+            if (S <= 2) hipLaunchKernelGGL((k_glue4x3<2>), dim3(Mpad), dim3(nth), 0, s, slabs, S, Mpad, N, h, wnorm, x, eps);
+            else if (S <= 4) hipLaunchKernelGGL((k_glue4x3<4>), dim3(Mpad), dim3(nth), 0, s, slabs, S, Mpad, N, h, wnorm, x, eps);
+            else hipLaunchKernelGGL((k_glue4x3<8>), dim3(Mpad), dim3(nth), 0, s, slabs, S, Mpad, N, h, wnorm, x, eps);
+            return;
+        }
+    }
     if (v4 && N % 4 == 0 && N / 4 <= 1024 && S <= 8) {
         const int nth = ((N / 4 + 63) / 64) * 64;
         if (ln_bias) {
