@@ -463,48 +463,66 @@ __global__ void __launch_bounds__(1024) k_glue4(const float* __restrict__ slabs,
     }
 }
 
-// The RMSNorm glue with THREE column groups per thread (N / 12 threads per row: 256 at d = 3072 - four waves instead of twelve).  The launch
-// is latency-bound (one dependent round trip, one block reduction, 32 blocks), so what a block costs before its first load is issued
-// and at its barrier counts: fewer waves to place and to meet.  Same arithmetic, same summation order per column as k_glue4 (slab
-// order 0, 1, ...); the row's sum of squares is reduced in another order (three columns groups per lane, then DPP, then four waves)
-// - a float32 sum of 3072 squares either way.  MIS_GLUE_CPT=1 keeps one group per thread (A/B).
-template <int SG>
-__global__ void __launch_bounds__(256) k_glue4x3(const float* __restrict__ slabs, int S, int Mpad, int N, bf16_t* __restrict__ h,
-                                                 const bf16_t* __restrict__ wnorm, bf16_t* __restrict__ x, float eps) {
+// The glue with SEVERAL column groups per thread (round 4): CPT groups of four columns per thread, N / (4 CPT) threads per row - 256 at
+// d = 3072 (CPT = 3: four waves instead of twelve), ONE wave at d = 1024 / 1280 (CPT = 4 / 5: Qwen3-TTS, Whisper - no LDS, no block
+// barrier at all).  The launch is latency-bound (one dependent round trip, a row reduction, 32 blocks), so what a block costs before
+// its first load is issued and at its barriers counts: fewer waves to place and to meet.  Same arithmetic and the same summation order per
+// column as k_glue4 (slab order 0, 1, ...); the row statistics are reduced in another order (CPT groups per lane, DPP, then the waves) -
+// float32 sums of N terms either way.  LN = true: LayerNorm with weight and bias (Whisper, WhisperLayers.swift:90-107): float32 mean and
+// variance over the row, one rounding at the output.  MIS_GLUE_CPT=1 keeps one group per thread (A/B).
+template <int SG, int CPT, bool LN>
+__global__ void __launch_bounds__(256) k_glue_cpt(const float* __restrict__ slabs, int S, int Mpad, int N, bf16_t* __restrict__ h,
+                                                  const bf16_t* __restrict__ wnorm, bf16_t* __restrict__ x, float eps, const bf16_t* __restrict__ ln_bias) {
     __shared__ float red[4];
-    const int m = blockIdx.x, tid = threadIdx.x, nth = blockDim.x;
+    const int m = blockIdx.x, tid = threadIdx.x, nth = blockDim.x;          // N == 4 * CPT * nth (checked by the launcher)
     const int MT = Mpad >> 4;
-    const int ng = N >> 2;                                       // column groups of four; ng == 3 * nth (checked by the launcher)
-    unsigned long long hq[3], wq[3];
-    f32x4_t v[3][SG];
+    const int nw = nth >> 6;
+    unsigned long long hq[CPT], wq[CPT], bq[CPT];
+    f32x4_t v[CPT][SG];
 #pragma unroll
-    for (int g = 0; g < 3; ++g) {
+    for (int g = 0; g < CPT; ++g) {
         const int c4 = tid + g * nth;
         const bf16_t* hp = h + (size_t)m * N + 4 * c4;
         const bf16_t* wp = wnorm + 4 * c4;
         asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(hq[g]) : "v"(hp));
         asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(wq[g]) : "v"(wp));
+        if constexpr (LN) {
+            const bf16_t* bp = ln_bias + 4 * c4;
+            asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(bq[g]) : "v"(bp));
+        } else bq[g] = 0;
     }
 #pragma unroll
     for (int j = 0; j < SG; ++j) {
         const int sj = j < S ? j : S - 1;
 #pragma unroll
-        for (int g = 0; g < 3; ++g) {
+        for (int g = 0; g < CPT; ++g) {
             const float* sp = slabs + ((size_t)sj * Mpad + m) * N + 4 * (tid + g * nth);
             asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(v[g][j]) : "v"(sp));
         }
     }
-    // ONE wait naming every destination (volatile asm statements keep their order; hipcc does not count asm loads itself)
+    // ONE wait, then every destination named (volatile asm statements keep their order; hipcc does not count asm loads itself)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #pragma unroll
-    for (int g = 0; g < 3; ++g) {
-        if (g == 0) asm volatile("s_waitcnt vmcnt(0)" : "+v"(hq[0]), "+v"(wq[0]));
-        else asm volatile("" : "+v"(hq[g]), "+v"(wq[g]));
+    for (int g = 0; g < CPT; ++g) {
+        asm volatile("" : "+v"(hq[g]), "+v"(wq[g]));
+        if constexpr (LN) asm volatile("" : "+v"(bq[g]));
 #pragma unroll
         for (int j = 0; j < SG; ++j) asm volatile("" : "+v"(v[g][j]));
     }
-    float hn[3][4], wv[3][4], ss = 0.0f;
+    auto row_sum = [&](float part, bool again) {                // the same total in every thread of the block
+        part = wave_sum_dpp(part);
+        if (nw == 1) return part;
+        if (again) __syncthreads();                             // (a second use of `red`: everyone has read the first totals)
+        if ((tid & 63) == 0) red[tid >> 6] = part;
+        __syncthreads();
+        float tot = 0.0f;
 #pragma unroll
-    for (int g = 0; g < 3; ++g) {
+        for (int i = 0; i < 4; ++i) tot += i < nw ? red[i] : 0.0f;
+        return tot;
+    };
+    float hn[CPT][4], wv[CPT][4], ss = 0.0f, sm = 0.0f;
+#pragma unroll
+    for (int g = 0; g < CPT; ++g) {
         float acc[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int j = 0; j < SG; ++j) {                           // slab order 0, 1, 2, ... (fixed => deterministic)
@@ -521,41 +539,66 @@ __global__ void __launch_bounds__(256) k_glue4x3(const float* __restrict__ slabs
             hn[g][e] = bf16_round_f32(hv[e] + bf16_round_f32(acc[e]));   // o = T(sum slabs); h = T(h + o)
             hb[e] = f32_to_bf16(hn[g][e]);
             ss += hn[g][e] * hn[g][e];
+            sm += hn[g][e];
         }
         *reinterpret_cast<uint2*>(h + (size_t)m * N + 4 * (tid + g * nth)) =
             make_uint2((uint32_t)hb[0] | ((uint32_t)hb[1] << 16), (uint32_t)hb[2] | ((uint32_t)hb[3] << 16));
     }
-    ss = wave_sum_dpp(ss);
-    if ((tid & 63) == 0) red[tid >> 6] = ss;
-    __syncthreads();
-    float tot = 0.0f;
-    const int nw = nth >> 6;
+    if constexpr (LN) {
+        const float mean = row_sum(sm, false) / (float)N;
+        float sq = 0.0f;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) tot += i < nw ? red[i] : 0.0f;
-    const float inv = 1.0f / sqrtf(tot / (float)N + eps);
+        for (int g = 0; g < CPT; ++g)
 #pragma unroll
-    for (int g = 0; g < 3; ++g) {
-        bf16_t xb[4];
+            for (int e = 0; e < 4; ++e) { const float dl = hn[g][e] - mean; sq += dl * dl; }
+        const float rstd = 1.0f / sqrtf(row_sum(sq, true) / (float)N + eps);
 #pragma unroll
-        for (int e = 0; e < 4; ++e) xb[e] = f32_to_bf16(wv[g][e] * bf16_round_f32(hn[g][e] * inv));
-        *reinterpret_cast<uint2*>(x + xpk_index(m, 4 * (tid + g * nth), MT)) =
-            make_uint2((uint32_t)xb[0] | ((uint32_t)xb[1] << 16), (uint32_t)xb[2] | ((uint32_t)xb[3] << 16));
+        for (int g = 0; g < CPT; ++g) {
+            const uint32_t b0 = (uint32_t)bq[g], b1 = (uint32_t)(bq[g] >> 32);
+            const float bv[4] = {bf16_to_f32((bf16_t)(b0 & 0xffffu)), bf16_to_f32((bf16_t)(b0 >> 16)), bf16_to_f32((bf16_t)(b1 & 0xffffu)), bf16_to_f32((bf16_t)(b1 >> 16))};
+            bf16_t xb[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) xb[e] = f32_to_bf16((hn[g][e] - mean) * rstd * wv[g][e] + bv[e]);
+            *reinterpret_cast<uint2*>(x + xpk_index(m, 4 * (tid + g * nth), MT)) =
+                make_uint2((uint32_t)xb[0] | ((uint32_t)xb[1] << 16), (uint32_t)xb[2] | ((uint32_t)xb[3] << 16));
+        }
+    } else {
+        const float inv = 1.0f / sqrtf(row_sum(ss, false) / (float)N + eps);
+#pragma unroll
+        for (int g = 0; g < CPT; ++g) {
+            bf16_t xb[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) xb[e] = f32_to_bf16(wv[g][e] * bf16_round_f32(hn[g][e] * inv));
+            *reinterpret_cast<uint2*>(x + xpk_index(m, 4 * (tid + g * nth), MT)) =
+                make_uint2((uint32_t)xb[0] | ((uint32_t)xb[1] << 16), (uint32_t)xb[2] | ((uint32_t)xb[3] << 16));
+        }
     }
-    (void)ng;
+}
+template <int CPT, bool LN>
+static void launch_glue_cpt(const float* slabs, int S, int Mpad, int N, bf16_t* h, const bf16_t* wnorm, bf16_t* x, float eps, const bf16_t* ln_bias, hipStream_t s) {
+    const int nth = N / (4 * CPT);
+    if (S <= 2) hipLaunchKernelGGL((k_glue_cpt<2, CPT, LN>), dim3(Mpad), dim3(nth), 0, s, slabs, S, Mpad, N, h, wnorm, x, eps, ln_bias);
+    else if (S <= 4) hipLaunchKernelGGL((k_glue_cpt<4, CPT, LN>), dim3(Mpad), dim3(nth), 0, s, slabs, S, Mpad, N, h, wnorm, x, eps, ln_bias);
+    else hipLaunchKernelGGL((k_glue_cpt<8, CPT, LN>), dim3(Mpad), dim3(nth), 0, s, slabs, S, Mpad, N, h, wnorm, x, eps, ln_bias);
 }
 
 void launch_reduce_residual_rmsnorm(const float* slabs, int S, int Mpad, int N, bf16_t* h, const bf16_t* wnorm,
                                     bf16_t* x, float eps, hipStream_t s, const bf16_t* ln_bias) {
     static const int v4 = getenv("MIS_GLUE_V4") ? atoi(getenv("MIS_GLUE_V4")) : 1;
-    {   // three column groups per thread where the row divides that way into whole waves (d = 3072: 256 threads)
+    {   // several column groups per thread where the row divides into whole waves that way: d = 3072 -> 3 groups x 256 threads; d = 1024 /
+        // 1280 / 768 / 512 -> ONE wave of 4 / 5 / 3 / 2 groups (no LDS, no block barrier)
         const char* ec = getenv("MIS_GLUE_CPT");
-        const bool cpt3 = !(ec && atoi(ec) == 1);
-        if (v4 && cpt3 && !ln_bias && N % 12 == 0 && (N / 12) % 64 == 0 && N / 12 <= 256 && S <= 8) {
-            const int nth = N / 12;
-            if (S <= 2) hipLaunchKernelGGL((k_glue4x3<2>), dim3(Mpad), dim3(nth), 0, s, slabs, S, Mpad, N, h, wnorm, x, eps);
-            else if (S <= 4) hipLaunchKernelGGL((k_glue4x3<4>), dim3(Mpad), dim3(nth), 0, s, slabs, S, Mpad, N, h, wnorm, x, eps);
-            else hipLaunchKernelGGL((k_glue4x3<8>), dim3(Mpad), dim3(nth), 0, s, slabs, S, Mpad, N, h, wnorm, x, eps);
-            return;
+        const bool cpt_on = !(ec && atoi(ec) == 1);
+        if (v4 && cpt_on && N % 256 == 0 && S <= 8) {
+            const int g64 = N / 256;                               // column groups per lane of a single wave
+            const bool ln = ln_bias != nullptr;
+#define GLUE_CPT(C) { if (ln) launch_glue_cpt<C, true>(slabs, S, Mpad, N, h, wnorm, x, eps, ln_bias, s); else launch_glue_cpt<C, false>(slabs, S, Mpad, N, h, wnorm, x, eps, ln_bias, s); return; }
+            if (g64 == 12) GLUE_CPT(3)                              // 256 threads
+            if (g64 == 2) GLUE_CPT(2)
+            if (g64 == 3) GLUE_CPT(3)
+            if (g64 == 4) GLUE_CPT(4)
+            if (g64 == 5) GLUE_CPT(5)
+#undef GLUE_CPT
         }
     }
     if (v4 && N % 4 == 0 && N / 4 <= 1024 && S <= 8) {
