@@ -464,8 +464,7 @@ __global__ void __launch_bounds__(1024) k_glue4(const float* __restrict__ slabs,
 }
 
 // The glue with SEVERAL column groups per thread (round 4): CPT groups of four columns per thread, N / (4 CPT) threads per row - 256 at
-// d = 3072 (CPT = 3: four waves instead of twelve), ONE wave at d = 1024 / 1280 (CPT = 4 / 5: Qwen3-TTS, Whisper - no LDS, no block
-// barrier at all).  The launch is latency-bound (one dependent round trip, a row reduction, 32 blocks), so what a block costs before
+// d = 3072 (CPT = 3: four waves instead of twelve; the only dispatch - see the launcher for the single-wave forms that lost).  The launch is latency-bound (one dependent round trip, a row reduction, 32 blocks), so what a block costs before
 // its first load is issued and at its barriers counts: fewer waves to place and to meet.  Same arithmetic and the same summation order per
 // column as k_glue4 (slab order 0, 1, ...); the row statistics are reduced in another order (CPT groups per lane, DPP, then the waves) -
 // float32 sums of N terms either way.  LN = true: LayerNorm with weight and bias (Whisper, WhisperLayers.swift:90-107): float32 mean and
@@ -585,21 +584,13 @@ static void launch_glue_cpt(const float* slabs, int S, int Mpad, int N, bf16_t* 
 void launch_reduce_residual_rmsnorm(const float* slabs, int S, int Mpad, int N, bf16_t* h, const bf16_t* wnorm,
                                     bf16_t* x, float eps, hipStream_t s, const bf16_t* ln_bias) {
     static const int v4 = getenv("MIS_GLUE_V4") ? atoi(getenv("MIS_GLUE_V4")) : 1;
-    {   // several column groups per thread where the row divides into whole waves that way: d = 3072 -> 3 groups x 256 threads; d = 1024 /
-        // 1280 / 768 / 512 -> ONE wave of 4 / 5 / 3 / 2 groups (no LDS, no block barrier)
+    {   // three column groups per thread at d = 3072 (256 threads instead of 768).  The same kernel as ONE wave per row for the small
+        // models (d = 1024 / 1280: 4 / 5 groups per lane, no LDS, no barrier) measured SLOWER - Qwen3-TTS 3.86 -> 3.91 ms per frame, Whisper
+        // 243 -> 246 ms per 8 x 30 s (profiles/r04/c14_secondary_ab.txt): a single wave does not keep enough of the row in flight - and is
+        // not dispatched
         const char* ec = getenv("MIS_GLUE_CPT");
         const bool cpt_on = !(ec && atoi(ec) == 1);
-        if (v4 && cpt_on && N % 256 == 0 && S <= 8) {
-            const int g64 = N / 256;                               // column groups per lane of a single wave
-            const bool ln = ln_bias != nullptr;
-#define GLUE_CPT(C) { if (ln) launch_glue_cpt<C, true>(slabs, S, Mpad, N, h, wnorm, x, eps, ln_bias, s); else launch_glue_cpt<C, false>(slabs, S, Mpad, N, h, wnorm, x, eps, ln_bias, s); return; }
-            if (g64 == 12) GLUE_CPT(3)                              // 256 threads
-            if (g64 == 2) GLUE_CPT(2)
-            if (g64 == 3) GLUE_CPT(3)
-            if (g64 == 4) GLUE_CPT(4)
-            if (g64 == 5) GLUE_CPT(5)
-#undef GLUE_CPT
-        }
+        if (v4 && cpt_on && !ln_bias && N == 3072 && S <= 8) { launch_glue_cpt<3, false>(slabs, S, Mpad, N, h, wnorm, x, eps, ln_bias, s); return; }
     }
     if (v4 && N % 4 == 0 && N / 4 <= 1024 && S <= 8) {
         const int nth = ((N / 4 + 63) / 64) * 64;
