@@ -1199,7 +1199,8 @@ static void run_generate(mis_tts* c, const int32_t* prompt_ids, const int32_t* p
         mix(ptrs, sizeof(ptrs));
         int ints[] = {batch, Lmax, max_tokens, c->Mpad, c->Smax, c->S_qkv, c->S_o, c->S_down, hidden_mode ? 1 : 0,
                       c->a_qkv.R, c->a_qkv.ksb, c->a_qkv.U, c->a_o.R, c->a_o.ksb, c->a_o.U, c->a_down.R, c->a_down.ksb, c->a_down.U,
-                      c->a_head.R, c->a_head.ksb, c->a_head.U, c->r_gu, c->ksb_gu, c->qa_gu.R, c->qa_gu.ksb, c->qa_head.R, c->qa_head.ksb};
+                      c->a_head.R, c->a_head.ksb, c->a_head.U, c->r_gu, c->ksb_gu, c->qa_gu.R, c->qa_gu.ksb, c->qa_head.R, c->qa_head.ksb,
+                      std::max(1, std::min(env_int("MIS_GRAPH_STEPS", 1), 8))};      // (steps per captured graph: a graph of another size must not be replayed)
         mix(ints, sizeof(ints));
         const void* hp[] = {hidden_mode ? (const void*)hm->hidden->p : nullptr, hidden_mode ? (const void*)hid_count.p : nullptr};
         mix(hp, sizeof(hp));
