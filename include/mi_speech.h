@@ -685,6 +685,15 @@ mis_status mis_debug_launch_floor(int device, int n_kernels, int mode, int reps,
  * 32-wide k-tiles and `waves_per_item` waves per work item ("Split-K factor from a cost model"); no GPU needed
  * (falls back to 256 CUs when no device is visible). */
 int32_t mis_debug_choose_split(int32_t items, int32_t k_tiles, int32_t waves_per_item, int32_t s_max);
+/* diagnostics / tests: occupy compute units from ANOTHER stream - `blocks` workgroups of `threads` threads that spin (s_sleep) for
+ * `seconds` - so that launches on the library's streams find fewer CUs than the device has (the condition under which the one-launch
+ * sampler's row barriers time out and the fall-back runs).  Returns at once; mis_debug_occupy_wait() waits for the spinner and
+ * releases its stream. */
+mis_status mis_debug_occupy_cus(int device, int blocks, int threads, double seconds);
+mis_status mis_debug_occupy_wait(void);
+int32_t mis_debug_device_cus(int device);            /* compute units of a device (0 when it does not exist) */
+/* diagnostics / tests: launches of the one-launch sampler that reported a timed-out row barrier in this process so far */
+int32_t mis_debug_sampler_failures(void);
 
 #ifdef __cplusplus
 }

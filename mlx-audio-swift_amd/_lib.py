@@ -277,6 +277,10 @@ SYMBOLS = {
     "mis_encodec_debug_tap": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, C.c_int, _P, C.c_int64, C.POINTER(C.c_int32),
                                         C.POINTER(C.c_int64)]),
     "mis_debug_launch_floor": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_double)]),
+    "mis_debug_occupy_cus": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_double]),
+    "mis_debug_occupy_wait": (C.c_int, []),
+    "mis_debug_device_cus": (C.c_int32, [C.c_int]),
+    "mis_debug_sampler_failures": (C.c_int32, []),
     "mis_debug_choose_split": (C.c_int32, [C.c_int32, C.c_int32, C.c_int32, C.c_int32]),
 }
 

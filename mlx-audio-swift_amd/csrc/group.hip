@@ -497,3 +497,38 @@ extern "C" mis_status mis_qwen3tts_group_generate(mis_qwen3tts* const* replicas,
     if (n_frames) for (int b = 0; b < batch; ++b) n_frames[b] = nf[b];
     MIS_API_END
 }
+
+// ---------------------------------------------------------------------------- diagnostics: hold compute units from another stream
+// (tests of the one-launch sampler's failure path: its 8 x batch blocks wait for each other and need every one resident)
+__global__ void k_debug_spin(unsigned long long ticks_100mhz) {
+    extern __shared__ unsigned char spin_lds[];          // (96 KB requested at launch: at most ONE spinner per CU, so `blocks` CUs are held)
+    if (ticks_100mhz == ~0ull) spin_lds[threadIdx.x] = 0;
+    const unsigned long long t0 = wall_clock64();
+    while (wall_clock64() - t0 < ticks_100mhz) __builtin_amdgcn_s_sleep(64);
+}
+static hipStream_t g_occupy_stream = nullptr;
+extern "C" mis_status mis_debug_occupy_cus(int device, int blocks, int threads, double seconds) {
+    MIS_API_BEGIN
+    MIS_REQUIRE(blocks >= 1 && threads >= 64 && threads <= 1024 && threads % 64 == 0 && seconds > 0.0 && seconds <= 10.0, MIS_ERR_INVALID_INPUT, "bad argument");
+    HIP_CHECK(hipSetDevice(device));
+    if (!g_occupy_stream) HIP_CHECK(hipStreamCreateWithFlags(&g_occupy_stream, hipStreamNonBlocking));
+    static const bool lds_ok = hipFuncSetAttribute((const void*)k_debug_spin, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024) == hipSuccess;
+    MIS_REQUIRE(lds_ok, MIS_ERR_DEVICE, "cannot reserve 96 KB of LDS for the spinner");
+    hipLaunchKernelGGL(k_debug_spin, dim3(blocks), dim3(threads), 96 * 1024, g_occupy_stream, (unsigned long long)(seconds * 1e8));
+    HIP_CHECK(hipGetLastError());
+    MIS_API_END
+}
+extern "C" mis_status mis_debug_occupy_wait(void) {
+    MIS_API_BEGIN
+    if (g_occupy_stream) {
+        HIP_CHECK(hipStreamSynchronize(g_occupy_stream));
+        HIP_CHECK(hipStreamDestroy(g_occupy_stream));
+        g_occupy_stream = nullptr;
+    }
+    MIS_API_END
+}
+extern "C" int32_t mis_debug_device_cus(int device) {
+    hipDeviceProp_t prop{};
+    if (hipGetDeviceProperties(&prop, device) != hipSuccess) return 0;
+    return prop.multiProcessorCount;
+}

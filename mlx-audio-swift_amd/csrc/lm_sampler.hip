@@ -22,6 +22,7 @@
 #include "common.h"
 #include "lm_kernels.h"
 #include <vector>
+#include <atomic>
 
 #define SAMP_NT 256
 #define ORPHEUS_AUDIO_OFFSET 128266
@@ -969,6 +970,9 @@ __global__ void __launch_bounds__(SC_NT) k_samp_cluster(SamplerParams p, int spi
 void sampler_scratch_init(SamplerScratch* scratch, int batch, hipStream_t s) {
     if (scratch && batch > 0) HIP_CHECK(hipMemsetAsync(scratch, 0, (size_t)batch * sizeof(SamplerScratch), s));
 }
+// how often a launch of the one-launch sampler reported a timed-out row barrier in this process (diagnostics, tests)
+static std::atomic<int> g_sampler_failures{0};
+extern "C" int32_t mis_debug_sampler_failures(void) { return g_sampler_failures.load(); }
 bool sampler_check_failed(SamplerScratch* scratch, int batch, hipStream_t s) {
     if (!scratch || batch <= 0) return false;
     std::vector<unsigned> f(batch, 0u);
@@ -977,6 +981,7 @@ bool sampler_check_failed(SamplerScratch* scratch, int batch, hipStream_t s) {
     HIP_CHECK(hipStreamSynchronize(s));
     bool any = false;
     for (unsigned v : f) any = any || v != 0;
+    if (any) g_sampler_failures.fetch_add(1);
     if (any) {                                        // counters and flags back to the state a fresh scratch has
         sampler_scratch_init(scratch, batch, s);
         HIP_CHECK(hipStreamSynchronize(s));
