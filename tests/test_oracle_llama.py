@@ -105,3 +105,23 @@ def test_qwen3_style_variant_matches_hf_qwen3():
     b = np.concatenate([o.forward([ids[0, t:t + 1]])[0].numpy() for t in range(6, 11)])
     np.testing.assert_allclose(np.concatenate([a, b]), ref, rtol=3e-4, atol=3e-4)
     np.testing.assert_allclose(o.last_hidden.numpy()[-1], out.hidden_states[-1].numpy()[0, -1], rtol=3e-4, atol=3e-4)
+
+
+def test_orpheus_3b_width_matches_hf_fp32():
+    """The same pin at the BENCHMARKED per-layer dimensions (hidden 3072, 24 / 8 heads x 128, ffn 8192, llama3 rope scaling, tied head;
+    one layer, vocabulary cut to 20 000 rows so that the CPU suite stays quick): prefill + decode through the cache against HF's
+    LlamaForCausalLM, float32."""
+    cfg = llama.LlamaConfig(num_hidden_layers=1, vocab_size=20000)         # every other field = ORPHEUS_3B
+    assert (cfg.hidden_size, cfg.intermediate_size, cfg.num_attention_heads, cfg.num_key_value_heads, cfg.resolved_head_dim) == (3072, 8192, 24, 8, 128)
+    W = llama.make_synthetic_weights(cfg, dtype=torch.float32)
+    hf = _hf_model(cfg, W)
+    rng = np.random.default_rng(4)
+    ids = rng.integers(0, cfg.vocab_size, (1, 7))
+    with torch.no_grad():
+        ref = hf(torch.from_numpy(ids)).logits.numpy()
+    o = llama.LlamaOracle(cfg, W, round=None)
+    o.reset(1)
+    got = [o.forward([ids[0, :4]])] + [o.forward([ids[0, t:t + 1]]) for t in range(4, 7)]
+    full = np.concatenate([g[0].numpy() for g in got], 0)
+    np.testing.assert_allclose(full, ref[0], rtol=3e-4, atol=3e-4)
+    assert np.abs(ref).max() > 1.0

@@ -63,3 +63,25 @@ def test_suppress_masks_and_bf16_mode():
     assert (ea - eb).abs().max().item() < 0.05 * eb.abs().max().item()
     la, lb = a.decode([[5, 6, 7]])[0], b.decode([[5, 6, 7]])[0]
     assert (la - lb).abs().max().item() < 0.05 * lb.abs().max().item()
+
+
+def test_large_v3_width_matches_hf_fp32():
+    """The same pin at Whisper-large-v3's per-layer dimensions (d 1280, 20 heads x 64, ffn 5120, 128 mel bins; 1 + 1 layers, vocabulary
+    cut to 8 000 rows so that the CPU suite stays quick): encoder output and teacher-forced decoder logits against HF, float32."""
+    cfg = ow.WhisperConfig(vocab_size=8000, num_mel_bins=128, d_model=1280, encoder_layers=1, encoder_attention_heads=20, encoder_ffn_dim=5120,
+                           decoder_layers=1, decoder_attention_heads=20, decoder_ffn_dim=5120)
+    W = ow.make_synthetic_weights(cfg, dtype=torch.float32)
+    hf = _hf(cfg, W)
+    rng = np.random.default_rng(1)
+    feats = (rng.standard_normal((1, 3000, cfg.num_mel_bins)) * 0.5).astype(np.float32)
+    toks = rng.integers(0, cfg.vocab_size, (1, 6))
+    with torch.no_grad():
+        enc_ref = hf.model.encoder(torch.from_numpy(feats).transpose(1, 2)).last_hidden_state.numpy()
+        logits_ref = hf(input_features=torch.from_numpy(feats).transpose(1, 2), decoder_input_ids=torch.from_numpy(toks)).logits.numpy()
+    o = ow.WhisperOracle(cfg, W, round=None)
+    o.reset(1)
+    enc = o.encode(feats)
+    np.testing.assert_allclose(enc[0].numpy(), enc_ref[0], rtol=3e-4, atol=3e-4)
+    got = [o.decode([toks[0, :3]])] + [o.decode([toks[0, t:t + 1]]) for t in range(3, 6)]
+    full = np.concatenate([g[0].numpy() for g in got], 0)
+    np.testing.assert_allclose(full, logits_ref[0], rtol=5e-4, atol=5e-4)
