@@ -1,0 +1,78 @@
+"""CPU tier (no GPU): properties of the COMPILED gfx950 code that the hand-scheduled kernels rely on and that a compiler change could take
+away silently - hipcc cross-compiles here.
+
+* `k_attn_decode2` loads its K/V tiles with asm statements and counted waits that hipcc does not track: the static audit of
+  tools/isa_audit_attn2.py (no register of an in-flight load touched, no spill, no control flow with loads outstanding) must stay clean
+  for every instantiation, the `MIS_ATTN_PAIR` variants included.
+* The weight-streaming GEMMs run one or two waves per SIMD by design (R = 4: 160-230 registers): none of them, nor the glue and the
+  256 x 256 Whisper GEMM, may spill (scratch traffic sits in the same vmcnt queue as the weight stream).
+* The quantised R = 4 instantiations stay under 256 registers without scratch.
+One compile per source file (lm_kernels.hip ~40 s, the others ~15 s each)."""
+import os
+import re
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CSRC = os.path.join(ROOT, "mlx-audio-swift_amd", "csrc")
+HIPCC = "/opt/rocm/bin/hipcc"
+
+pytestmark = pytest.mark.skipif(not os.path.exists(HIPCC), reason="hipcc not installed")
+
+
+def _resource_usage(src):
+    """{mangled kernel name: {"vgprs": n, "scratch": bytes}} from -Rpass-analysis=kernel-resource-usage."""
+    r = subprocess.run([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "--cuda-device-only", "-c", os.path.join(CSRC, src), "-o", os.devnull,
+                        "-Rpass-analysis=kernel-resource-usage"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-2000:]
+    out, cur = {}, None
+    for line in r.stderr.splitlines():
+        m = re.search(r"Function Name: (\S+)", line)
+        if m:
+            cur = out.setdefault(m.group(1), {})
+            continue
+        if cur is None:
+            continue
+        m = re.search(r"remark:\s+VGPRs: (\d+)", line)
+        if m:
+            cur["vgprs"] = int(m.group(1))
+        m = re.search(r"ScratchSize \[bytes/lane\]: (\d+)", line)
+        if m:
+            cur["scratch"] = int(m.group(1))
+    return out
+
+
+def test_attention_asm_schedule_audit_is_clean():
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "isa_audit_attn2.py")], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-1000:]
+    assert r.stdout.count("0 violations") >= 8 and "violations: 0" in r.stdout        # NS = 1..4 x {one tile, two tiles up front}
+
+
+def test_step_chain_kernels_do_not_spill():
+    use = _resource_usage("lm_kernels.hip")
+    gemm = {k: v for k, v in use.items() if "k_gemm_skinny" in k}
+    assert len(gemm) >= 60                                              # MT 1..4 x the instantiated (R, epilogue, KSB, U) set
+    for k, v in gemm.items():
+        assert v["scratch"] == 0 and v["vgprs"] <= 256, (k, v)
+    r4 = [v["vgprs"] for k, v in gemm.items() if re.search(r"k_gemm_skinnyILi2ELi4E", k)]
+    assert r4 and max(r4) <= 232                                        # four n-tiles per wave at 32 rows: no pressure on the 256-register budget
+    for name in ("k_glue_cpt", "k_glue4", "k_attn_decode2", "k_embed_rmsnorm"):
+        hit = {k: v for k, v in use.items() if name in k}
+        assert hit, name
+        for k, v in hit.items():
+            assert v["scratch"] == 0, (k, v)
+
+
+def test_whisper_256_tile_gemm_and_quantised_r4_gemm_do_not_spill():
+    use = _resource_usage("whisper_kernels.hip")
+    big3 = {k: v for k, v in use.items() if "k_gemm_big3" in k}
+    assert len(big3) == 8                                               # four epilogues x two wave grids
+    for k, v in big3.items():
+        assert v["scratch"] == 0 and v["vgprs"] <= 256, (k, v)
+    useq = _resource_usage("lm_qgemm.hip")
+    q4 = {k: v for k, v in useq.items() if re.search(r"k_gemm_skinny_qILi[12]ELi4E", k)}
+    assert len(q4) >= 24
+    for k, v in q4.items():
+        assert v["scratch"] == 0 and v["vgprs"] <= 256, (k, v)
