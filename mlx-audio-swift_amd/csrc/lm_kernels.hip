@@ -1294,14 +1294,18 @@ __device__ __forceinline__ void att2_issue_tile(const bf16_t* kt, const bf16_t* 
     // needs five wait states before a VMEM instruction reads it, and hipcc pads nothing inside an asm statement.)
     const bf16_t* kt1 = kt + 4 * 512;
     const bf16_t* vt1 = vt + 4 * 512;
-#define ATT2_LD(DST, BASE, OFF) asm volatile("global_load_dwordx4 %0, %1, %2 offset:" #OFF : "=v"(DST) : "v"(voff), "s"(BASE))
-    asm volatile("s_nop 4\n\tglobal_load_dwordx4 %0, %1, %2" : "=v"(ka[0][0]) : "v"(voff), "s"(kt));
+    // non-temporal (round 4): a decode step reads every K/V tile exactly once - with the default policy the 48 MB stream of a launch
+    // displaces the x fragments and slabs the neighbouring launches share through L2.  Step 2.0809 -> 2.0580 ms over three alternating
+    // runs each, 13.0 -> 12.5 us in isolation (profiles/r04/c23_ab.json).
+#define ATT2_NT " nt"
+#define ATT2_LD(DST, BASE, OFF) asm volatile("global_load_dwordx4 %0, %1, %2 offset:" #OFF ATT2_NT : "=v"(DST) : "v"(voff), "s"(BASE))
+    asm volatile("s_nop 4\n\tglobal_load_dwordx4 %0, %1, %2" ATT2_NT : "=v"(ka[0][0]) : "v"(voff), "s"(kt));
     ATT2_LD(ka[0][1], kt, 1024); ATT2_LD(ka[0][2], kt, 2048); ATT2_LD(ka[0][3], kt, 3072);
-    asm volatile("s_nop 4\n\tglobal_load_dwordx4 %0, %1, %2" : "=v"(ka[1][0]) : "v"(voff), "s"(kt1));
+    asm volatile("s_nop 4\n\tglobal_load_dwordx4 %0, %1, %2" ATT2_NT : "=v"(ka[1][0]) : "v"(voff), "s"(kt1));
     ATT2_LD(ka[1][1], kt1, 1024); ATT2_LD(ka[1][2], kt1, 2048); ATT2_LD(ka[1][3], kt1, 3072);
-    asm volatile("s_nop 4\n\tglobal_load_dwordx4 %0, %1, %2" : "=v"(vb[0]) : "v"(voff), "s"(vt));
+    asm volatile("s_nop 4\n\tglobal_load_dwordx4 %0, %1, %2" ATT2_NT : "=v"(vb[0]) : "v"(voff), "s"(vt));
     ATT2_LD(vb[1], vt, 1024); ATT2_LD(vb[2], vt, 2048); ATT2_LD(vb[3], vt, 3072);
-    asm volatile("s_nop 4\n\tglobal_load_dwordx4 %0, %1, %2" : "=v"(vb[4]) : "v"(voff), "s"(vt1));
+    asm volatile("s_nop 4\n\tglobal_load_dwordx4 %0, %1, %2" ATT2_NT : "=v"(vb[4]) : "v"(voff), "s"(vt1));
     ATT2_LD(vb[5], vt1, 1024); ATT2_LD(vb[6], vt1, 2048); ATT2_LD(vb[7], vt1, 3072);
 #undef ATT2_LD
 }
