@@ -969,7 +969,16 @@ int gemm_choose_split(int items, int KT, int ksb, int s_max) {
 #define ATT_STAMP(i) do { } while (0)
 #endif
 
-template <int D, int NIT>
+// XS ("cross stream", round 4): the schedule for cross-attention over a LONG static cache (Whisper: 1500 keys = 47 tiles, five or six per
+// wave).  The loop below requests a pair of tiles, waits for it and multiplies - per wave two or three dependent round trips, of which
+// only the first hides behind the prologue.  With XS a wave holds TWO pairs in registers (D = 64: 4 x 32 registers): while one group is
+// multiplied the next pair streams, and the pair behind that is requested before the wait for it.  An odd tile count is taken out up
+// front (the first group is ONE tile, every later group a full pair); the code is straight-line per tile count (see the main loop for
+// why not a loop).  Tiles are multiplied in the same order as without XS - results are bit-identical.  The K/V loads are
+// non-temporal: a decode step reads each of them once (61 MB per layer at eight windows, 2 GB per step - nothing a cache can keep).
+#define ATT_XS_MIN_J 5
+#define ATT_XS_MAX_J 6
+template <int D, int NIT, bool XS = false>
 __global__ void __launch_bounds__(512) k_attn_decode(AttnParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int kvh = blockIdx.x, b = blockIdx.y;
@@ -1060,20 +1069,48 @@ __global__ void __launch_bounds__(512) k_attn_decode(AttnParams p) {
     const int n_tiles = p.append_only ? 0 : (kv_len + 31) >> 5;    // append-only launches request no tiles
     const int new_tile = p.cross ? -1 : (pos >> 5);
     bf16x8_t kA[2][D / 32], kB[2][D / 32], vA[D / 16], vB[D / 16];
+    if constexpr (XS) {                             // (an odd first group leaves B unrequested; the binding statement below names it)
+        const bf16x8_t z = (bf16x8_t){0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+        for (int c = 0; c < D / 32; ++c) { kB[0][c] = z; kB[1][c] = z; }
+#pragma unroll
+        for (int dt = 0; dt < D / 16; ++dt) vB[dt] = z;
+    }
     auto load_tile = [&](int tile, bf16x8_t (&ka)[2][D / 32], bf16x8_t (&vb)[D / 16]) {
+        if constexpr (XS) {
 #pragma unroll
-        for (int c = 0; c < D / 32; ++c) {
-            ka[0][c] = kbase[((size_t)tile * 2) * (D / 32) * 64 + c * 64];
-            ka[1][c] = kbase[((size_t)tile * 2 + 1) * (D / 32) * 64 + c * 64];
+            for (int c = 0; c < D / 32; ++c) {
+                ka[0][c] = __builtin_nontemporal_load(kbase + ((size_t)tile * 2) * (D / 32) * 64 + c * 64);
+                ka[1][c] = __builtin_nontemporal_load(kbase + ((size_t)tile * 2 + 1) * (D / 32) * 64 + c * 64);
+            }
+#pragma unroll
+            for (int dt = 0; dt < D / 16; ++dt) vb[dt] = __builtin_nontemporal_load(vbase + ((size_t)tile * (D / 16) + dt) * 64);
+        } else {
+#pragma unroll
+            for (int c = 0; c < D / 32; ++c) {
+                ka[0][c] = kbase[((size_t)tile * 2) * (D / 32) * 64 + c * 64];
+                ka[1][c] = kbase[((size_t)tile * 2 + 1) * (D / 32) * 64 + c * 64];
+            }
+#pragma unroll
+            for (int dt = 0; dt < D / 16; ++dt) vb[dt] = vbase[((size_t)tile * (D / 16) + dt) * 64];
         }
-#pragma unroll
-        for (int dt = 0; dt < D / 16; ++dt) vb[dt] = vbase[((size_t)tile * (D / 16) + dt) * 64];
     };
+    // XS: tiles of this wave (wave, wave + 8, ...); an odd count is taken out up front so that every later group is a full pair
+    // (the wave index as an SGPR: with `tid >> 6` the compiler treats every branch on it as divergent, lowers the loop below through
+    // exec masks and re-joins its arms - with a vmcnt(0) at the join)
+    const int wu = XS ? __builtin_amdgcn_readfirstlane(wave) : wave;
+    const int xs_nj = XS && wu < n_tiles ? (n_tiles - wu + ATT_WAVES - 1) / ATT_WAVES : 0;
+    const bool xs_odd = (xs_nj & 1) != 0;
     __builtin_amdgcn_sched_barrier(0);
     // wave-uniform guards: a wave without a tile requests nothing (at short contexts seven of eight waves would otherwise each
     // pull a redundant 32 KB pair through the CU's 64 B/clk return path - 2-3 us per launch on the small models)
-    if (wave < n_tiles) load_tile(wave, kA, vA);
-    if (wave + ATT_WAVES < n_tiles) load_tile(wave + ATT_WAVES, kB, vB);
+    if constexpr (XS) {
+        if (xs_nj >= 1) load_tile(wu, kA, vA);
+        if (xs_nj >= 2 && !xs_odd) load_tile(wu + ATT_WAVES, kB, vB);
+    } else {
+        if (wave < n_tiles) load_tile(wave, kA, vA);
+        if (wave + ATT_WAVES < n_tiles) load_tile(wave + ATT_WAVES, kB, vB);
+    }
     __builtin_amdgcn_sched_barrier(0);
     ATT_STAMP(2);
 #pragma unroll
@@ -1219,18 +1256,64 @@ __global__ void __launch_bounds__(512) k_attn_decode(AttnParams p) {
             O[dt] = o;
         }
     };
-    for (int tile = wave; tile < n_tiles; tile += 2 * ATT_WAVES) {
-        const int tile2 = tile + ATT_WAVES;
-        const bool has2 = tile2 < n_tiles;
-        if (tile != wave) {                                             // later pairs (the first one was requested up front)
-            load_tile(tile, kA, vA);
-            if (has2) load_tile(tile2, kB, vB);
-        }
-        if (tile == new_tile) patch_new_key(kA, vA);
-        process(tile, kA, vA);
-        if (has2) {
-            if (tile2 == new_tile) patch_new_key(kB, vB);
-            process(tile2, kB, vB);
+    if constexpr (XS) {
+        // (cross-attention: no new key to patch.)  Straight-line code per tile count (ATT_XS_MIN_J .. ATT_XS_MAX_J; the launcher checks
+        // the cache length): group 0 sits in A (/ B), the pair behind it goes to C/D, the one behind that to A/B again.  A loop over
+        // pairs was tried first: across its back-edge hipcc rotates the buffers with v_mov copies of registers whose loads are
+        // still in flight (each behind its own wait) and waits for vmcnt(0) at the header - no two pairs in flight together.
+        // A pair is REQUESTED first and the group before it multiplied behind a binding statement that names its registers: the
+        // compiler's wait for them lands there, behind the requests (vmcnt(16): "everything but the youngest pair").
+        static_assert(!XS || D == 64, "XS: two pairs of tiles in registers (D = 64)");
+#define XS_BIND(KA, VA, KB, VB)                                                                                                   \
+        asm volatile("" : "+v"(KA[0][0]), "+v"(KA[0][1]), "+v"(KA[1][0]), "+v"(KA[1][1]), "+v"(VA[0]), "+v"(VA[1]), "+v"(VA[2]), "+v"(VA[3]), \
+                          "+v"(KB[0][0]), "+v"(KB[0][1]), "+v"(KB[1][0]), "+v"(KB[1][1]), "+v"(VB[0]), "+v"(VB[1]), "+v"(VB[2]), "+v"(VB[3]) :: "memory")
+        auto xs_run = [&](auto tag) {
+            constexpr int NJ = decltype(tag)::value, W = ATT_WAVES;
+            constexpr int G0 = (NJ & 1) ? 1 : 2, P = (NJ - G0) / 2;     // tiles in group 0, full pairs behind it (0 .. 2)
+            bf16x8_t kC[2][D / 32], kD[2][D / 32], vC[D / 16], vD[D / 16];
+            const int t1 = wu + G0 * W, t2 = t1 + 2 * W;
+            if constexpr (P >= 1) {
+                load_tile(t1, kC, vC);
+                load_tile(t1 + W, kD, vD);
+                XS_BIND(kA, vA, kB, vB);
+            }
+            process(wu, kA, vA);
+            if constexpr (G0 == 2) process(wu + W, kB, vB);
+            if constexpr (P >= 1) {
+                __builtin_amdgcn_sched_barrier(0);
+                if constexpr (P >= 2) {
+                    load_tile(t2, kA, vA);
+                    load_tile(t2 + W, kB, vB);
+                }
+                XS_BIND(kC, vC, kD, vD);
+                process(t1, kC, vC);
+                process(t1 + W, kD, vD);
+            }
+            if constexpr (P >= 2) {
+                __builtin_amdgcn_sched_barrier(0);
+                XS_BIND(kA, vA, kB, vB);
+                process(t2, kA, vA);
+                process(t2 + W, kB, vB);
+            }
+        };
+        // (the launcher admits 40 .. 48 tiles: every wave has five or six - the only counts compiled, both run by every Whisper test)
+        if (xs_nj == 6) xs_run(std::integral_constant<int, 6>{});
+        else xs_run(std::integral_constant<int, 5>{});
+#undef XS_BIND
+    } else {
+        for (int tile = wave; tile < n_tiles; tile += 2 * ATT_WAVES) {
+            const int tile2 = tile + ATT_WAVES;
+            const bool has2 = tile2 < n_tiles;
+            if (tile != wave) {                                             // later pairs (the first one was requested up front)
+                load_tile(tile, kA, vA);
+                if (has2) load_tile(tile2, kB, vB);
+            }
+            if (tile == new_tile) patch_new_key(kA, vA);
+            process(tile, kA, vA);
+            if (has2) {
+                if (tile2 == new_tile) patch_new_key(kB, vB);
+                process(tile2, kB, vB);
+            }
         }
     }
     ATT_STAMP(5);
@@ -1679,8 +1762,13 @@ void launch_attn_decode(const AttnParams& p, int batch, hipStream_t s) {
 #else
     const AttnParams& p2 = p;
 #endif
+    const char* xe = getenv("MIS_ATTN_XS");                                                // 0: the pair-at-a-time loop for cross-attention too (A/B,
+    const bool xs_on = !(xe && atoi(xe) == 0);                                             // parity tests: read per launch)
     if (p.D == 128 && n_el <= 1024) hipLaunchKernelGGL((k_attn_decode<128, 2>), grid, block, smem, s, p2);
     else if (p.D == 128) hipLaunchKernelGGL((k_attn_decode<128, 5>), grid, block, smem, s, p2);
+    else if (p.D == 64 && n_el <= 1024 && p.cross && !p.append_only && !p.cache_rows && xs_on && (p.cross_len + 31) / 32 >= ATT_WAVES * ATT_XS_MIN_J &&
+             (p.cross_len + 31) / 32 <= ATT_WAVES * ATT_XS_MAX_J)
+        hipLaunchKernelGGL((k_attn_decode<64, 2, true>), grid, block, smem, s, p2);       // cross-attention: two pairs of tiles in flight
     else if (p.D == 64 && n_el <= 1024) hipLaunchKernelGGL((k_attn_decode<64, 2>), grid, block, smem, s, p2);
     else if (p.D == 64) hipLaunchKernelGGL((k_attn_decode<64, 3>), grid, block, smem, s, p2);
     else throw MisError(MIS_ERR_INVALID_INPUT, "head_dim must be 64 or 128");

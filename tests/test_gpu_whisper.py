@@ -309,3 +309,23 @@ def test_encoder_256x256_tile_gemm_is_bit_identical_to_the_128x128_kernel(monkey
     ref = oracle.encode(feats)
     for b in range(2):
         _check(big[b], ref[b].numpy(), 0.022, 0.012)
+
+
+def test_cross_attention_with_two_pairs_of_key_tiles_in_flight_is_bit_identical_to_the_pair_at_a_time_loop(monkeypatch):
+    """`k_attn_decode<64, 2, XS>` (round 4: the schedule of the cross-attention over the 1500 encoder positions - 47 key tiles, five or six per
+    wave, two pairs of them in registers, non-temporal loads) multiplies every wave's tiles in the order of the loop it replaces
+    (`MIS_ATTN_XS=0`): teacher-forced decoder logits must be equal bit for bit, every head, every step."""
+    cfg = ow.WhisperConfig(vocab_size=700, num_mel_bins=128, d_model=256, encoder_layers=1, encoder_attention_heads=4, encoder_ffn_dim=512,
+                           decoder_layers=2, decoder_attention_heads=4, decoder_ffn_dim=512)
+    W, oracle, dev = _pair(cfg)
+    B = 3
+    dev.encode(_feats(B, cfg.num_mel_bins, 6))
+    toks = np.random.default_rng(8).integers(0, cfg.vocab_size, (B, 6))
+    got = {}
+    for xs in ("0", "1"):
+        monkeypatch.setenv("MIS_ATTN_XS", xs)
+        dev.decoder_reset()
+        got[xs] = np.stack([dev.decoder_forward(toks[:, t]) for t in range(toks.shape[1])])
+    monkeypatch.delenv("MIS_ATTN_XS")
+    assert np.isfinite(got["1"]).all() and np.abs(got["1"]).max() > 0
+    assert np.array_equal(got["0"], got["1"])

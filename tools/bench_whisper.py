@@ -2,7 +2,7 @@
 mel + encoder + 4-token prompt + 96 decode steps (EOT suppressed by using an out-of-range eot id).
 argv[1] = windows per GPU (default 8); --gpus N: N replicas (one per visible GPU, same synthetic weights), N x windows sharded inside
 the library by mis_whisper_group_generate (configs[3] as worded: 64 windows over 8 GPUs)."""
-import json, os, sys, time
+import json, os, sys, time, zlib
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -29,4 +29,6 @@ for rep in range(2):
 flops_enc = 2.27e12 * (B // NG)
 print(json.dumps({"workload": f"whisper-large-v3 bf16, {B} x 30 s over {NG} GPU(s), 96 decode steps", "n_gpus": NG, "encode_ms": t_enc * 1e3,
                   "encoder_TFLOPs": flops_enc / t_enc / 1e12, "transcribe_ms": t_all * 1e3,
-                  "audio_s_per_s": 30.0 * B / t_all, "tokens": [len(i) for i in ids][:4]}))
+                  "audio_s_per_s": 30.0 * B / t_all, "tokens": [len(i) for i in ids][:4],
+                  "token_crc32": zlib.crc32(np.concatenate([np.asarray(i, np.int64) for i in ids]).tobytes()),       # A/B runs: same tokens?
+                  "MIS_ATTN_XS": os.environ.get("MIS_ATTN_XS")}))
