@@ -7,11 +7,16 @@ away silently - hipcc cross-compiles here.
 * The weight-streaming GEMMs run one or two waves per SIMD by design (R = 4: 160-230 registers): none of them, nor the glue and the
   256 x 256 Whisper GEMM, may spill (scratch traffic sits in the same vmcnt queue as the weight stream).
 * The quantised R = 4 instantiations stay under 256 registers without scratch.
+* The Whisper cross-attention schedule (`k_attn_decode<64, 2, XS>`) is plain C++ with compiler loads; what makes it fast is WHERE hipcc puts
+  its waits - a pair of key tiles is requested before the wait for the pair in front of it (`s_waitcnt vmcnt(16)` behind sixteen requests,
+  twice per tile count).  A loop form of the same code lost exactly that (vmcnt(0) at the loop header), so the property is pinned here.
 One compile per source file (lm_kernels.hip ~40 s, the others ~15 s each)."""
+import functools
 import os
 import re
 import subprocess
 import sys
+import tempfile
 
 import pytest
 
@@ -22,11 +27,16 @@ HIPCC = "/opt/rocm/bin/hipcc"
 pytestmark = pytest.mark.skipif(not os.path.exists(HIPCC), reason="hipcc not installed")
 
 
-def _resource_usage(src):
-    """{mangled kernel name: {"vgprs": n, "scratch": bytes}} from -Rpass-analysis=kernel-resource-usage."""
-    r = subprocess.run([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "--cuda-device-only", "-c", os.path.join(CSRC, src), "-o", os.devnull,
-                        "-Rpass-analysis=kernel-resource-usage"], capture_output=True, text=True)
-    assert r.returncode == 0, r.stderr[-2000:]
+@functools.lru_cache(maxsize=None)
+def _compiled(src):
+    """(assembly text, {mangled kernel name: {"vgprs": n, "scratch": bytes}}) of one source file: hipcc -S with
+    -Rpass-analysis=kernel-resource-usage, once per file and test session."""
+    with tempfile.TemporaryDirectory() as td:
+        asm = os.path.join(td, "k.s")
+        r = subprocess.run([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "--cuda-device-only", "-S", os.path.join(CSRC, src), "-o", asm,
+                            "-Rpass-analysis=kernel-resource-usage"], capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr[-2000:]
+        text = open(asm).read()
     out, cur = {}, None
     for line in r.stderr.splitlines():
         m = re.search(r"Function Name: (\S+)", line)
@@ -41,7 +51,11 @@ def _resource_usage(src):
         m = re.search(r"ScratchSize \[bytes/lane\]: (\d+)", line)
         if m:
             cur["scratch"] = int(m.group(1))
-    return out
+    return text, out
+
+
+def _resource_usage(src):
+    return _compiled(src)[1]
 
 
 def test_attention_asm_schedule_audit_is_clean():
@@ -76,3 +90,26 @@ def test_whisper_256_tile_gemm_and_quantised_r4_gemm_do_not_spill():
     assert len(q4) >= 24
     for k, v in q4.items():
         assert v["scratch"] == 0 and v["vgprs"] <= 256, (k, v)
+
+
+def test_whisper_cross_attention_keeps_two_pairs_of_key_tiles_in_flight():
+    text, use = _compiled("lm_kernels.hip")
+    name = [k for k in use if re.search(r"k_attn_decodeILi64ELi2ELb1E", k)]
+    assert len(name) == 1, name
+    assert use[name[0]]["scratch"] == 0 and use[name[0]]["vgprs"] <= 256, use[name[0]]
+    i = text.index("\n" + name[0] + ":")
+    body = text[i: text.index(".Lfunc_end", i)]
+    ins = [l.strip() for l in body.split("\n") if re.match(r"^\s+[a-z_0-9]+\b", l)]
+    # K/V requests (non-temporal 16-byte loads) since the previous vmcnt wait, at every vmcnt wait (address arithmetic sits between the loads)
+    waits, n = [], 0
+    for l in ins:
+        if l.startswith("global_load_dwordx4") and l.endswith(" nt"):
+            n += 1
+        elif l.startswith("s_waitcnt") and "vmcnt" in l:
+            waits.append((n, int(re.search(r"vmcnt\((\d+)\)", l).group(1))))
+            n = 0
+    assert sum(k for k, _ in waits) + n == 16 + 4 * 16, waits            # the first group up front (8 + 8), two pairs on either tile-count path
+    # a wait that follows a full pair of requests (sixteen loads or more since the last wait) must leave that pair outstanding: the pair is
+    # requested BEFORE the wait for the group in front of it - twice on the six-tile path, twice on the five-tile path
+    behind_pair = [w for k, w in waits if k >= 16]
+    assert len(behind_pair) == 4 and all(w >= 16 for w in behind_pair), waits
