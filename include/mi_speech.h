@@ -678,22 +678,8 @@ mis_status mis_qwen3tts_group_generate(mis_qwen3tts* const* replicas, int n, con
                                        int32_t* n_frames, int chunk_frames, mis_event_cb on_event, void* user,
                                        const volatile int* cancel_flag);
 
-/* diagnostics: microseconds per dependent kernel boundary in a replayed hipGraph of n trivial kernels
- * (mode 0: 1 block x 64 threads, 1: 32 x 1024, 2: 1024 x 256).  DESIGN.md quotes it as the launch floor. */
-mis_status mis_debug_launch_floor(int device, int n_kernels, int mode, int reps, double* us_per_kernel);
-/* diagnostics: the inter-block split-K factor the engines pick for a weight-streaming GEMM with `items` n-tile groups, `k_tiles`
- * 32-wide k-tiles and `waves_per_item` waves per work item ("Split-K factor from a cost model"); no GPU needed
- * (falls back to 256 CUs when no device is visible). */
-int32_t mis_debug_choose_split(int32_t items, int32_t k_tiles, int32_t waves_per_item, int32_t s_max);
-/* diagnostics / tests: occupy compute units from ANOTHER stream - `blocks` workgroups of `threads` threads that spin (s_sleep) for
- * `seconds` - so that launches on the library's streams find fewer CUs than the device has (the condition under which the one-launch
- * sampler's row barriers time out and the fall-back runs).  Returns at once; mis_debug_occupy_wait() waits for the spinner and
- * releases its stream. */
-mis_status mis_debug_occupy_cus(int device, int blocks, int threads, double seconds);
-mis_status mis_debug_occupy_wait(void);
-int32_t mis_debug_device_cus(int device);            /* compute units of a device (0 when it does not exist) */
-/* diagnostics / tests: launches of the one-launch sampler that reported a timed-out row barrier in this process so far */
-int32_t mis_debug_sampler_failures(void);
+/* Diagnostics and test scaffolding (launch floor, split-factor model, CU spinner, failure counters) are NOT part of the product
+ * surface: include/mi_speech_debug.h. */
 
 #ifdef __cplusplus
 }

@@ -1,0 +1,37 @@
+/* mi_speech_debug.h - diagnostics and test scaffolding exported by libmi_speech.so next to the product ABI (include/mi_speech.h).
+ *
+ * Nothing here replaces a reference interface and no host application needs it: these entry points exist for DESIGN.md's
+ * measurements (launch floor, split-factor model) and for tests that have to provoke conditions a healthy run never meets
+ * (compute units held by another stream, counted sampler time-outs).  Kept out of mi_speech.h so that the drop-in surface is
+ * exactly what a Swift shim binds. */
+#ifndef MI_SPEECH_DEBUG_H
+#define MI_SPEECH_DEBUG_H
+#include "mi_speech.h"
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* diagnostics: microseconds per dependent kernel boundary in a replayed hipGraph of n trivial kernels
+ * (mode 0: 1 block x 64 threads, 1: 32 x 1024, 2: 1024 x 256).  DESIGN.md quotes it as the launch floor. */
+mis_status mis_debug_launch_floor(int device, int n_kernels, int mode, int reps, double* us_per_kernel);
+/* diagnostics: the inter-block split-K factor the engines pick for a weight-streaming GEMM with `items` n-tile groups, `k_tiles`
+ * 32-wide k-tiles and `waves_per_item` waves per work item ("Split-K factor from a cost model"); no GPU needed
+ * (falls back to 256 CUs when no device is visible). */
+int32_t mis_debug_choose_split(int32_t items, int32_t k_tiles, int32_t waves_per_item, int32_t s_max);
+/* tests: occupy compute units from ANOTHER stream - `blocks` workgroups of `threads` threads, each reserving 96 KB of LDS (at most one
+ * per CU), that spin (s_sleep) for `seconds` - so that launches on the library's streams find fewer CUs than the device has (the
+ * condition under which the one-launch sampler's row barriers time out and the engines recover on the multi-launch path).  Every
+ * spinner announces itself on entry; the call returns MIS_OK only once all `blocks` of them are RESIDENT (handshake through a
+ * host-visible counter), or MIS_ERR_DEVICE if that does not happen within two seconds - the spinner is then released and the caller
+ * should treat the condition as not reproducible on this device (tests skip).  mis_debug_occupy_wait() releases the spinners early
+ * (if they are still running), waits for them and frees the stream. */
+mis_status mis_debug_occupy_cus(int device, int blocks, int threads, double seconds);
+mis_status mis_debug_occupy_wait(void);
+int32_t mis_debug_device_cus(int device);            /* compute units of a device (0 when it does not exist) */
+/* diagnostics / tests: launches of the one-launch sampler that reported a timed-out row barrier in this process so far */
+int32_t mis_debug_sampler_failures(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MI_SPEECH_DEBUG_H */

@@ -24,7 +24,8 @@ from . import _lib  # noqa: F401
 from .generation import (AudioGenerationError, AudioGenerationInfo, GenerateParameters, TokenEvent, InfoEvent,  # noqa: F401
                          AudioEvent)
 from .codecs import SNAC, SNACConfig, DescriptDAC, DescriptDACConfig, Encodec, EncodecConfig  # noqa: F401
-from .tts import LlamaTTSModel, LlamaTTSConfiguration, OrpheusTokens, VyvoTokens  # noqa: F401
+from .tts import (LlamaTTSModel, LlamaTTSConfiguration, OrpheusTokens, VyvoTokens, interleave_snac_codes,  # noqa: F401
+                  orpheus_prompt_rows, padded_prompt_batch)
 from .orpheus import deinterleave, parse_output  # noqa: F401
 from .soprano import SopranoModel, SopranoConfiguration  # noqa: F401
 from .qwen3tts import (Qwen3TTSModel, Qwen3TTSConfiguration, Qwen3TTSDecoderConfiguration, Qwen3TTSGenerateParameters,  # noqa: F401

@@ -276,6 +276,10 @@ SYMBOLS = {
     "mis_encodec_decode_frame": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, _P, _P]),
     "mis_encodec_debug_tap": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, C.c_int, _P, C.c_int64, C.POINTER(C.c_int32),
                                         C.POINTER(C.c_int64)]),
+}
+
+# diagnostics / test scaffolding: include/mi_speech_debug.h (not part of the product surface)
+DEBUG_SYMBOLS = {
     "mis_debug_launch_floor": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_double)]),
     "mis_debug_occupy_cus": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_double]),
     "mis_debug_occupy_wait": (C.c_int, []),
@@ -304,7 +308,7 @@ def lib():
         except Exception:
             pass
         l = C.CDLL(LIB_PATH)
-        for name, (res, args) in SYMBOLS.items():
+        for name, (res, args) in list(SYMBOLS.items()) + list(DEBUG_SYMBOLS.items()):
             fn = getattr(l, name)          # AttributeError if the ABI lost a symbol
             fn.restype = res
             fn.argtypes = args

@@ -11,6 +11,7 @@
 #include <stdexcept>
 
 #include "../../include/mi_speech.h"
+#include "../../include/mi_speech_debug.h"
 
 // ---------------------------------------------------------------------------- errors
 struct MisError : std::runtime_error {

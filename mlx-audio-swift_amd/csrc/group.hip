@@ -144,6 +144,7 @@ extern "C" mis_status mis_comm_all_gather_pcm(mis_comm* c, const float* pcm_loca
 // ---------------------------------------------------------------------------- single-process device group
 struct mis_group {
     std::vector<mis_tts*> reps;
+    std::vector<mis_tts*> marked_shared;     // replicas this group flagged as sharing their device (cleared again on destroy)
     mis_group_timing timing{};
 };
 
@@ -170,10 +171,20 @@ extern "C" mis_status mis_tts_group_create(mis_tts* const* replicas, int n, mis_
             const hipError_t e = hipDeviceEnablePeerAccess(dj, 0);
             if (e != hipSuccess) (void)hipGetLastError();                   // hipErrorPeerAccessAlreadyEnabled included
         }
+    // replicas that share a device (logical shards on one GPU) run their streams side by side: none of them may launch a kernel whose
+    // blocks wait for each other to be co-resident (the one-launch sampler would starve the other replica's rows and time out)
+    for (int i = 0; i < n; ++i) {
+        bool shared = false;
+        for (int j = 0; j < n; ++j) shared = shared || (j != i && tts_device(g->reps[j]) == tts_device(g->reps[i]));
+        if (shared) { tts_internal_set_shared_device(g->reps[i], true); g->marked_shared.push_back(g->reps[i]); }
+    }
     *out = g;
     MIS_API_END
 }
-extern "C" void mis_tts_group_destroy(mis_group* g) { delete g; }     // the replicas stay with their owner
+extern "C" void mis_tts_group_destroy(mis_group* g) {                 // the replicas stay with their owner
+    if (g) for (mis_tts* r : g->marked_shared) tts_internal_set_shared_device(r, false);
+    delete g;
+}
 extern "C" int mis_tts_group_size(const mis_group* g) { return g ? (int)g->reps.size() : 0; }
 
 static void shard_block(int n_rows, int r, int world, int* lo, int* hi) {
@@ -415,6 +426,18 @@ extern "C" mis_status mis_whisper_group_generate(mis_whisper* const* replicas, i
     n = check_replicas(replicas, n, batch);
     PartGuard<int32_t> tok(n);
     std::vector<int64_t> ts(n, 0);
+    // replicas that share a device keep to kernels that do not wait for co-resident blocks (see mis_tts_group_create)
+    struct SharedMarks {
+        std::vector<mis_whisper*> m;
+        ~SharedMarks() { for (auto* w : m) whisper_internal_set_shared_device(w, false); }
+    } marks;
+    for (int i = 0; i < n; ++i)
+        for (int j = 0; j < n; ++j)
+            if (j != i && whisper_internal_device(replicas[j]) == whisper_internal_device(replicas[i])) {
+                whisper_internal_set_shared_device(replicas[i], true);
+                marks.m.push_back(replicas[i]);
+                break;
+            }
     run_shards(n, batch, [&](int r, int lo, int hi) {
         mis_stt_params p = *sp;
         p.row_offset += lo;
@@ -498,33 +521,66 @@ extern "C" mis_status mis_qwen3tts_group_generate(mis_qwen3tts* const* replicas,
     MIS_API_END
 }
 
-// ---------------------------------------------------------------------------- diagnostics: hold compute units from another stream
-// (tests of the one-launch sampler's failure path: its 8 x batch blocks wait for each other and need every one resident)
-__global__ void k_debug_spin(unsigned long long ticks_100mhz) {
+// ---------------------------------------------------------------------------- test scaffolding (include/mi_speech_debug.h): hold compute
+// units from another stream.  The one-launch sampler's 8 x batch blocks wait for each other and need every one resident; its time-out and
+// the engines' recovery are tested by taking the CUs away.  Every spinner block announces itself in a host-visible slot, and the host
+// returns only once all of them are resident - without that handshake the sampler launched behind the spinner can simply win the race
+// for the CUs (first launch of this kernel on a fresh box; round 4's red suite).
+__global__ void k_debug_spin(unsigned long long ticks_100mhz, volatile unsigned* resident_slots, const unsigned* release) {
     extern __shared__ unsigned char spin_lds[];          // (96 KB requested at launch: at most ONE spinner per CU, so `blocks` CUs are held)
     if (ticks_100mhz == ~0ull) spin_lds[threadIdx.x] = 0;
+    if (threadIdx.x == 0) __hip_atomic_store((unsigned*)&resident_slots[blockIdx.x], 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     const unsigned long long t0 = wall_clock64();
-    while (wall_clock64() - t0 < ticks_100mhz) __builtin_amdgcn_s_sleep(64);
+    while (wall_clock64() - t0 < ticks_100mhz) {
+        if (__hip_atomic_load(release, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM)) break;       // (host memory: every wave sees the same word)
+        __builtin_amdgcn_s_sleep(64);
+    }
 }
 static hipStream_t g_occupy_stream = nullptr;
+static unsigned* g_occupy_host = nullptr;            // pinned, coherent: [0] = release flag, [1 ..] = one residency slot per spinner block
+static constexpr int OCCUPY_MAX_BLOCKS = 4096;
+static void occupy_release_and_wait() {
+    if (!g_occupy_stream) return;
+    if (g_occupy_host) __atomic_store_n(&g_occupy_host[0], 1u, __ATOMIC_RELEASE);
+    (void)hipStreamSynchronize(g_occupy_stream);
+    (void)hipStreamDestroy(g_occupy_stream);
+    g_occupy_stream = nullptr;
+}
 extern "C" mis_status mis_debug_occupy_cus(int device, int blocks, int threads, double seconds) {
     MIS_API_BEGIN
-    MIS_REQUIRE(blocks >= 1 && threads >= 64 && threads <= 1024 && threads % 64 == 0 && seconds > 0.0 && seconds <= 10.0, MIS_ERR_INVALID_INPUT, "bad argument");
+    MIS_REQUIRE(blocks >= 1 && blocks <= OCCUPY_MAX_BLOCKS && threads >= 64 && threads <= 1024 && threads % 64 == 0 && seconds > 0.0 &&
+                seconds <= 10.0, MIS_ERR_INVALID_INPUT, "bad argument");
     HIP_CHECK(hipSetDevice(device));
-    if (!g_occupy_stream) HIP_CHECK(hipStreamCreateWithFlags(&g_occupy_stream, hipStreamNonBlocking));
+    occupy_release_and_wait();                                        // (a spinner of an earlier call)
+    if (!g_occupy_host) HIP_CHECK(hipHostMalloc((void**)&g_occupy_host, (size_t)(OCCUPY_MAX_BLOCKS + 1) * sizeof(unsigned), hipHostMallocCoherent));
+    memset(g_occupy_host, 0, (size_t)(OCCUPY_MAX_BLOCKS + 1) * sizeof(unsigned));
+    HIP_CHECK(hipStreamCreateWithFlags(&g_occupy_stream, hipStreamNonBlocking));
     static const bool lds_ok = hipFuncSetAttribute((const void*)k_debug_spin, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024) == hipSuccess;
     MIS_REQUIRE(lds_ok, MIS_ERR_DEVICE, "cannot reserve 96 KB of LDS for the spinner");
-    hipLaunchKernelGGL(k_debug_spin, dim3(blocks), dim3(threads), 96 * 1024, g_occupy_stream, (unsigned long long)(seconds * 1e8));
+    hipLaunchKernelGGL(k_debug_spin, dim3(blocks), dim3(threads), 96 * 1024, g_occupy_stream, (unsigned long long)(seconds * 1e8),
+                       (volatile unsigned*)(g_occupy_host + 1), (const unsigned*)g_occupy_host);
     HIP_CHECK(hipGetLastError());
+    // handshake: all `blocks` spinners resident (each wrote its slot) before anything else is launched by the caller
+    const auto t0 = std::chrono::steady_clock::now();
+    int resident = 0;
+    for (;;) {
+        resident = 0;
+        for (int b = 0; b < blocks; ++b) resident += __atomic_load_n(&g_occupy_host[1 + b], __ATOMIC_ACQUIRE) != 0;
+        if (resident == blocks) break;
+        if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > 2.0) break;
+        std::this_thread::sleep_for(std::chrono::microseconds(50));
+    }
+    if (resident != blocks) {
+        occupy_release_and_wait();
+        char msg[128];
+        snprintf(msg, sizeof(msg), "spinner: only %d of %d blocks became resident within 2 s", resident, blocks);
+        throw MisError(MIS_ERR_DEVICE, msg);
+    }
     MIS_API_END
 }
 extern "C" mis_status mis_debug_occupy_wait(void) {
     MIS_API_BEGIN
-    if (g_occupy_stream) {
-        HIP_CHECK(hipStreamSynchronize(g_occupy_stream));
-        HIP_CHECK(hipStreamDestroy(g_occupy_stream));
-        g_occupy_stream = nullptr;
-    }
+    occupy_release_and_wait();
     MIS_API_END
 }
 extern "C" int32_t mis_debug_device_cus(int device) {

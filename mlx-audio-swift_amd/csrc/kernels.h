@@ -49,6 +49,11 @@ void tts_internal_prefill_rows(mis_tts* c, const bf16_t* rows /*[Lmax][Mpad][d] 
 void tts_internal_enqueue_layers(mis_tts* c, const bf16_t* table, int table_rows, const int32_t* ids);
 void tts_internal_enqueue_head(mis_tts* c, const bf16_t* head_packed);      // logits of the view; nullptr = own lm_head
 TtsView tts_internal_view(mis_tts* c);
+// a handle whose device also runs ANOTHER replica's streams (logical shards of a group on one GPU) must not launch kernels whose blocks
+// wait for each other to be co-resident (the one-launch sampler): set by the group entry points in group.hip
+void tts_internal_set_shared_device(mis_tts* c, bool shared);
+int whisper_internal_device(const mis_whisper* c);
+void whisper_internal_set_shared_device(mis_whisper* c, bool shared);
 
 // Qwen3-TTS speech-tokenizer decoder (q3_codec.hip)
 struct mis_q3dec;

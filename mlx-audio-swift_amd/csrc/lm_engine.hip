@@ -76,8 +76,8 @@ struct mis_tts {
     DevBuf<int32_t> pf_pos;
     DevBuf<uint8_t> pf_on;
     DevBuf<SamplerScratch> samp_scratch;
-    hipGraphExec_t g_prefill = nullptr, g_decode = nullptr, g_decode_n = nullptr;      // g_decode_n: graph_steps decode steps per launch
-    int graph_steps = 1;
+    hipGraphExec_t g_prefill = nullptr, g_decode = nullptr;
+    bool shared_device = false;      // another replica's streams run on this device (group.hip): never a kernel that waits for co-resident blocks
     uint64_t graph_key = 0;
     bool use_graph = true;
     bool borrowed_stream = false;
@@ -140,7 +140,6 @@ extern "C" void mis_tts_destroy(mis_tts* c) {
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     if (c->g_prefill) (void)hipGraphExecDestroy(c->g_prefill);
     if (c->g_decode) (void)hipGraphExecDestroy(c->g_decode);
-    if (c->g_decode_n) (void)hipGraphExecDestroy(c->g_decode_n);
     if (c->stream && !c->borrowed_stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }
@@ -492,7 +491,6 @@ static int choose_split(int items, int KT, int ksb, const char* env, int s_max =
 static void destroy_graphs(mis_tts* c) {
     if (c->g_prefill) { (void)hipGraphExecDestroy(c->g_prefill); c->g_prefill = nullptr; }
     if (c->g_decode) { (void)hipGraphExecDestroy(c->g_decode); c->g_decode = nullptr; }
-    if (c->g_decode_n) { (void)hipGraphExecDestroy(c->g_decode_n); c->g_decode_n = nullptr; }
 }
 
 static void build_rope_tables(mis_tts* c) {
@@ -541,19 +539,18 @@ static void lm_reset(mis_tts* c, int batch, int max_context) {
     bool new_tables = Smax != c->Smax;
     c->batch = batch; c->Mpad = Mpad; c->Smax = Smax;
     const int d = c->d, HD = c->H * c->D;
-    c->ksb_part = env_int("MIS_KSB_PART", 4) == 1 ? 1 : 4;
-    c->ksb_gu = env_int("MIS_KSB_GU", 4) == 1 ? 1 : 4;
+    c->ksb_part = 4;                                     // split-K roles and gate+up: the four waves of a block share an item's K range
+    c->ksb_gu = 4;
     // output projection: a big vocabulary fills the chip with one wave per tile pair (Orpheus: 4904 pairs); a codec-sized one (Qwen3-TTS
     // 2048 / 3072 ids, Soprano) has 64-96 pairs = 16-24 blocks, each wave walking the whole K range alone: there the four waves of a
-    // block split K (10.1 -> see profiles/r03/q3_small_kernels.json).  MIS_KSB_HEAD = 1 / 4 forces one.
-    c->ksb_head = getenv("MIS_KSB_HEAD") ? (env_int("MIS_KSB_HEAD", 1) == 4 ? 4 : 1) : (c->Vpad / 32 < 1024 ? 4 : 1);
-    c->r_part = env_int("MIS_R_PART", 2) == 1 ? 1 : 2;
+    // block split K (10.1 -> see profiles/r03/q3_small_kernels.json).
+    c->ksb_head = c->Vpad / 32 < 1024 ? 4 : 1;
+    c->r_part = 2;
     // gate+up: four n-tiles per wave halve the x fragments every wave re-reads out of L2 (as many bytes as the weights at two) - 20.3 ->
     // 17.6 us at Orpheus-3B width (profiles/r03/gemm_lab.jsonl) - where a launch still has one wave per SIMD: tile quads x 4 waves >= 4 per CU
     {
         const int quads = 2 * c->ff / 16 / 4;
-        const int dflt = (Mpad / 16 <= 2 && c->ksb_gu == 4 && (2 * c->ff / 16) % 4 == 0 && quads >= 256) ? 4 : 2;
-        c->r_gu = env_int("MIS_R_GU", dflt) == 4 && Mpad / 16 <= 2 && c->ksb_gu == 4 ? 4 : 2;
+        c->r_gu = (Mpad / 16 <= 2 && c->ksb_gu == 4 && (2 * c->ff / 16) % 4 == 0 && quads >= 256) ? 4 : 2;
     }
     c->S_qkv = std::min(8, choose_split(c->Nqkv / 16 / c->r_part, d / 32, c->ksb_part, "MIS_S_QKV", 8));   // attention prologue: <= 8 slabs
     c->S_o = choose_split(d / 16 / c->r_part, HD / 32, c->ksb_part, "MIS_S_O");
@@ -576,8 +573,7 @@ static void lm_reset(mis_tts* c, int batch, int max_context) {
         };
         GemmArr q{c->r_part, c->ksb_part, 4, c->S_qkv}, o{c->r_part, c->ksb_part, 4, c->S_o}, dn{c->r_part, c->ksb_part, 4, c->S_down},
             hd{2, c->ksb_head, 4, 1};
-        const bool tuned = env_int("MIS_ARR_TUNED", 1) != 0 && !getenv("MIS_R_PART") && !getenv("MIS_KSB_PART");
-        if (tuned && mt <= 2) {
+        if (mt <= 2) {
             // qkv: four n-tiles per wave (the x fragments re-read half as often), two waves per item: 8.56 -> 7.71 us in the lab, step
             // 2.125 -> 2.110 (R4 KSB4) -> 2.102 ms (R4 KSB2) on one box (profiles/r04/c4_ab.json)
             if ((c->Nqkv / 16) % 4 == 0 && (c->Nqkv / 16 / 4) * q.S >= 192 && c->ksb_part == 4) { q.R = 4; q.ksb = 2; q.U = 2; }
@@ -586,7 +582,7 @@ static void lm_reset(mis_tts* c, int batch, int max_context) {
             // down projection: two waves per item (128-thread blocks) 11.8 -> 10.9 us in the lab, step 2.105 -> 2.082 ms (c2_ab.json)
             if (c->ksb_part == 4 && c->ff / 32 >= 64) { dn.ksb = 2; }
             // output projection of a big vocabulary: 173.5 -> 150.7 us (the four waves of a block split K)
-            if (!getenv("MIS_KSB_HEAD") && c->Vpad / 64 >= 1024) { hd.R = 4; hd.ksb = 4; hd.U = 3; }
+            if (c->Vpad / 64 >= 1024) { hd.R = 4; hd.ksb = 4; hd.U = 3; }
         }
         c->a_qkv = pick("MIS_ARR_QKV", q); c->a_o = pick("MIS_ARR_O", o); c->a_down = pick("MIS_ARR_DOWN", dn); c->a_head = pick("MIS_ARR_HEAD", hd);
         {   // quantised checkpoints, the two wide roles (gate+up, output projection)
@@ -600,9 +596,9 @@ static void lm_reset(mis_tts* c, int batch, int max_context) {
             // measured at Orpheus-3B widths, 8 bit, 32 rows (profiles/r04/c6_qgemm_arr.txt): gate+up 17.80 us as R2 KSB4, 17.37 as R4 KSB4,
             // 16.63 as R4 KSB8 (19.32 as R2 KSB8); output projection 136.2 us as R2 KSB1, 127.5 as R4 KSB4 (148.1 as R4 KSB8)
             GemmArr gu{2, c->ksb_gu, 0, 1}, hd{2, c->ksb_head, 0, 1};
-            if (tuned && mt <= 2) {
+            if (mt <= 2) {
                 if (c->ksb_gu == 4 && (2 * c->ff / 16) % 4 == 0 && 2 * c->ff / 16 / 4 >= 256) { gu.R = 4; gu.ksb = 8; }
-                if (!getenv("MIS_KSB_HEAD") && c->Vpad / 64 >= 1024) { hd.R = 4; hd.ksb = 4; }
+                if (c->Vpad / 64 >= 1024) { hd.R = 4; hd.ksb = 4; }
             }
             c->qa_gu = qpick("MIS_QARR_GU", gu);
             c->qa_head = qpick("MIS_QARR_HEAD", hd);
@@ -1097,10 +1093,17 @@ struct HiddenMode {            // Soprano: collect model.norm(h) per step instea
     std::vector<int32_t> n_hidden;
 };
 
-static void run_generate(mis_tts* c, const int32_t* prompt_ids, const int32_t* prompt_lens, int batch,
-                         const mis_gen_params* gp, const float* const* snac_noise, float* pcm_dev, int64_t pcm_stride,
-                         bool want_tokens, mis_event_cb cb, void* user, const volatile int* cancel, GenOutputs& out,
-                         HiddenMode* hm = nullptr) {
+// A row barrier of the one-launch sampler timed out during the decode loop (its 8 x batch blocks were not co-resident: another stream
+// holds compute units).  Thrown at the poll that sees the flag, before any token of that poll interval reaches the callback.
+struct SamplerTimeout {};
+
+// One attempt of generate.  `multi_launch_only`: the sampler's multi-launch kernels (no kernel of the step waits for another block).
+// `emitted[b]`: tokens of row b already announced to the callback - by this attempt or by the one before it (the request is
+// deterministic: prompts, seeds and the RNG counter are the same, so a second attempt reproduces them and continues behind them).
+static void run_generate_attempt(mis_tts* c, const int32_t* prompt_ids, const int32_t* prompt_lens, int batch,
+                                 const mis_gen_params* gp, const float* const* snac_noise, float* pcm_dev, int64_t pcm_stride,
+                                 bool want_tokens, mis_event_cb cb, void* user, const volatile int* cancel, GenOutputs& out,
+                                 HiddenMode* hm, bool multi_launch_only, std::vector<int32_t>& emitted) {
     MIS_REQUIRE(c && c->finalized, MIS_ERR_NOT_INITIALIZED, "model not initialized");
     const bool hidden_mode = hm && hm->on;
     MIS_REQUIRE(hidden_mode || c->codec, MIS_ERR_NOT_INITIALIZED, "SNAC model not loaded");            // LlamaTTS.swift:672-674
@@ -1188,6 +1191,7 @@ static void run_generate(mis_tts* c, const int32_t* prompt_ids, const int32_t* p
         HIP_CHECK(hipMemcpyAsync(hid_count.p, ones_i.data(), batch * 4, hipMemcpyHostToDevice, s));
         HIP_CHECK(hipStreamSynchronize(s));
     }
+    sampler_resolve(sp, multi_launch_only);              // (environment switches read once per call; part of the graph key through sp)
     c->sp = sp;
     {   // the captured graphs bake in every pointer and scalar below: re-capture when any of them changes
         uint64_t key = 1469598103934665603ull;
@@ -1199,8 +1203,7 @@ static void run_generate(mis_tts* c, const int32_t* prompt_ids, const int32_t* p
         mix(ptrs, sizeof(ptrs));
         int ints[] = {batch, Lmax, max_tokens, c->Mpad, c->Smax, c->S_qkv, c->S_o, c->S_down, hidden_mode ? 1 : 0,
                       c->a_qkv.R, c->a_qkv.ksb, c->a_qkv.U, c->a_o.R, c->a_o.ksb, c->a_o.U, c->a_down.R, c->a_down.ksb, c->a_down.U,
-                      c->a_head.R, c->a_head.ksb, c->a_head.U, c->r_gu, c->ksb_gu, c->qa_gu.R, c->qa_gu.ksb, c->qa_head.R, c->qa_head.ksb,
-                      std::max(1, std::min(env_int("MIS_GRAPH_STEPS", 1), 8))};      // (steps per captured graph: a graph of another size must not be replayed)
+                      c->a_head.R, c->a_head.ksb, c->a_head.U, c->r_gu, c->ksb_gu, c->qa_gu.R, c->qa_gu.ksb, c->qa_head.R, c->qa_head.ksb};
         mix(ints, sizeof(ints));
         const void* hp[] = {hidden_mode ? (const void*)hm->hidden->p : nullptr, hidden_mode ? (const void*)hid_count.p : nullptr};
         mix(hp, sizeof(hp));
@@ -1256,38 +1259,39 @@ static void run_generate(mis_tts* c, const int32_t* prompt_ids, const int32_t* p
     }
     // ---- decode loop (:714-744)
     if (c->use_graph && !c->g_decode) capture(&c->g_decode, decode_body);
-    // several steps per launch (MIS_GRAPH_STEPS = 2..8; default 1).  Between two hipGraphLaunch calls of the one-step graph the device
-    // idles for 8.2 us (rocprofv3 kernel trace, End of the last glue launch -> Start of the next step's lm_head, median of 2604 pairs;
-    // profiles/r04/c1_gaps.json) while kernels inside a graph follow each other without a gap - and yet eight steps per graph are
-    // SLOWER: 2.1047 against 2.0953 ms per step, five A/B runs on either side of it (profiles/r04/c2_ab.json); a 1376-node graph
-    // costs more per node than it saves at its seven removed seams.  Kept for the record and for other node counts; off by default.
-    c->graph_steps = std::max(1, std::min(env_int("MIS_GRAPH_STEPS", 1), 8));
-    if (c->use_graph && c->graph_steps > 1 && !c->g_decode_n)
-        capture(&c->g_decode_n, [&]() { for (int i = 0; i < c->graph_steps; ++i) decode_body(); });
+    // (Several decode steps per graph launch were measured and removed: between two hipGraphLaunch calls of the one-step graph the
+    // device idles for 8.2 us - profiles/r04/c1_gaps.json - and yet eight steps per graph are SLOWER, 2.1047 against 2.0953 ms per step
+    // over five A/B runs, profiles/r04/c2_ab.json: a 1376-node graph costs more per node than its seven removed seams save.)
     int steps = 0;
     const int poll = cb ? 8 : 32;
     std::vector<int32_t> host_ngen(batch, 0), host_tok;
-    std::vector<int32_t> emitted(batch, 0);
     bool cancelled = false;
     PinnedBuf<int32_t> done_pin(1);
+    PinnedBuf<unsigned> fail_pin(batch);                 // the one-launch sampler's per-row time-out flags, read back with every poll
     int32_t* done_host = done_pin.p;
     *done_host = 0;
     while (steps < max_tokens) {
         int chunk = std::min(poll, max_tokens - steps);
-        int i = 0;
-        if (c->use_graph && c->g_decode_n)
-            for (; i + c->graph_steps <= chunk; i += c->graph_steps) HIP_CHECK(hipGraphLaunch(c->g_decode_n, s));
-        for (; i < chunk; ++i) {
+        for (int i = 0; i < chunk; ++i) {
             if (c->use_graph) HIP_CHECK(hipGraphLaunch(c->g_decode, s)); else decode_body();
         }
         steps += chunk;
         HIP_CHECK(hipMemcpyAsync(done_host, c->done_count.p, 4, hipMemcpyDeviceToHost, s));
+        sampler_fail_flags_async(c->samp_scratch.p, batch, fail_pin.p, s);
         if (cb) {
             host_tok.resize((size_t)batch * max_tokens);
             HIP_CHECK(hipMemcpyAsync(host_ngen.data(), c->n_gen.p, batch * 4, hipMemcpyDeviceToHost, s));
             HIP_CHECK(hipMemcpyAsync(host_tok.data(), c->tokens_out.p, host_tok.size() * 4, hipMemcpyDeviceToHost, s));
         }
         HIP_CHECK(hipStreamSynchronize(s));
+        if (sampler_fail_flags_any(fail_pin.p, batch)) {
+            // nothing of this poll interval has been announced; the steps queued behind the failed one ended at once (sticky flag,
+            // k_samp_cluster).  The reference's loop cannot fail for lack of free compute units (LlamaTTS.swift:714-744): the caller
+            // runs the request again on kernels that do not wait for each other.
+            sampler_note_failure(c->samp_scratch.p, batch, s);
+            for (auto& e : ev) (void)hipEventDestroy(e);
+            throw SamplerTimeout{};
+        }
         if (cb) {
             for (int b = 0; b < batch; ++b)
                 for (; emitted[b] < host_ngen[b]; ++emitted[b]) {
@@ -1300,11 +1304,6 @@ static void run_generate(mis_tts* c, const int32_t* prompt_ids, const int32_t* p
         if (*done_host >= batch) break;
     }
     HIP_CHECK(hipEventRecord(ev[2], s));
-    if (sampler_check_failed(c->samp_scratch.p, batch, s)) {
-        for (auto& e : ev) (void)hipEventDestroy(e);
-        throw MisError(MIS_ERR_GENERATION_FAILED, "sampler: a row barrier of the one-launch sampler timed out (its blocks were not co-resident); "
-                                                  "MIS_SAMPLER_WIDE=1 selects the multi-launch path");
-    }
     if (cancelled) {
         for (auto& e : ev) (void)hipEventDestroy(e);
         throw MisError(MIS_ERR_CANCELLED, "generation cancelled");
@@ -1487,6 +1486,28 @@ static void run_generate(mis_tts* c, const int32_t* prompt_ids, const int32_t* p
     }
     for (auto& e : ev) (void)hipEventDestroy(e);
 }
+
+// generate = one attempt on the fastest kernels; if the one-launch sampler could not get its blocks co-resident (the only kernel of
+// the step that needs that), the whole request once more on the multi-launch sampler - the request is deterministic, the second
+// attempt's tokens are the ones the first would have produced, and the callback continues behind what it has already been told.
+// A handle that shares its device with another replica's streams never takes the one-launch path in the first place.
+static void run_generate(mis_tts* c, const int32_t* prompt_ids, const int32_t* prompt_lens, int batch,
+                         const mis_gen_params* gp, const float* const* snac_noise, float* pcm_dev, int64_t pcm_stride,
+                         bool want_tokens, mis_event_cb cb, void* user, const volatile int* cancel, GenOutputs& out,
+                         HiddenMode* hm = nullptr) {
+    std::vector<int32_t> emitted(std::max(batch, 1), 0);
+    const bool multi_first = c && c->shared_device;
+    try {
+        run_generate_attempt(c, prompt_ids, prompt_lens, batch, gp, snac_noise, pcm_dev, pcm_stride, want_tokens, cb, user, cancel, out, hm,
+                             multi_first, emitted);
+    } catch (const SamplerTimeout&) {
+        MIS_REQUIRE(!multi_first, MIS_ERR_GENERATION_FAILED, "sampler: time-out flag raised on the multi-launch path");   // (cannot happen: nothing spins there)
+        out = GenOutputs{};
+        run_generate_attempt(c, prompt_ids, prompt_lens, batch, gp, snac_noise, pcm_dev, pcm_stride, want_tokens, cb, user, cancel, out, hm,
+                             true, emitted);
+    }
+}
+void tts_internal_set_shared_device(mis_tts* c, bool shared) { if (c) c->shared_device = shared; }
 
 static void default_params_check(const mis_gen_params* p) {
     MIS_REQUIRE(p, MIS_ERR_INVALID_INPUT, "null generation parameters");

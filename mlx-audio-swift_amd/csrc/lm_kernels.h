@@ -139,6 +139,17 @@ struct SamplerParams {
     int eos_id;
     int max_tokens;
     unsigned long long* dbg; // diagnostics (null in the product): [16] s_memtime stamps of block (0, 0) of the one-launch sampler
+    // host side only (sampler_resolve): which kernels the launcher may pick - fixed per generate call and hashed into the graph key
+    int path_resolved;       // 0: launch_sampler reads MIS_SAMPLER_WIDE / MIS_SAMPLER_SPIN itself, per launch (stand-alone entry point)
+    int force_multi;         // 1: the multi-launch kernels whatever the range (shared device, recovery after a time-out, MIS_SAMPLER_WIDE)
+    int spin;                // polls per row barrier of the one-launch sampler before it gives up
 };
+// resolves the launcher's choices once (environment + the caller's multi_launch_only) into p
+void sampler_resolve(SamplerParams& p, bool multi_launch_only);
+// failure flags of the one-launch sampler (one per row): queued copy into pinned host memory, to be read after the caller's next
+// stream synchronisation; sampler_note_failure counts the event and re-initialises the scratch
+void sampler_fail_flags_async(SamplerScratch* scratch, int batch, unsigned* host_flags, hipStream_t s);
+bool sampler_fail_flags_any(const unsigned* host_flags, int batch);
+void sampler_note_failure(SamplerScratch* scratch, int batch, hipStream_t s);
 // multi_launch_only: the six-kernel path whatever the range (the fall-back after a failed one-launch attempt, A/B)
 void launch_sampler(const SamplerParams& p, int batch, hipStream_t s, bool multi_launch_only = false);

@@ -583,17 +583,14 @@ static void launch_glue_cpt(const float* slabs, int S, int Mpad, int N, bf16_t* 
 
 void launch_reduce_residual_rmsnorm(const float* slabs, int S, int Mpad, int N, bf16_t* h, const bf16_t* wnorm,
                                     bf16_t* x, float eps, hipStream_t s, const bf16_t* ln_bias) {
-    static const int v4 = getenv("MIS_GLUE_V4") ? atoi(getenv("MIS_GLUE_V4")) : 1;
-    {   // three column groups per thread at d = 3072 (256 threads instead of 768).  The same kernel as ONE wave per row for the small
-        // models (d = 1024 / 1280: 4 / 5 groups per lane, no LDS, no barrier) measured SLOWER - Qwen3-TTS 3.86 -> 3.91 ms per frame, Whisper
-        // 243 -> 246 ms per 8 x 30 s (profiles/r04/c14_secondary_ab.txt): a single wave does not keep enough of the row in flight - and is
-        // not dispatched
-        const char* ec = getenv("MIS_GLUE_CPT");
-        const bool cpt_on = !(ec && atoi(ec) == 1);
-        // (six groups per thread - 128 threads - at d = 3072: 2.121 against 2.087 ms per step, profiles/r04/c15_ab.json: 256 threads it is)
-        if (v4 && cpt_on && !ln_bias && N == 3072 && S <= 8) { launch_glue_cpt<3, false>(slabs, S, Mpad, N, h, wnorm, x, eps, ln_bias, s); return; }
-    }
-    if (v4 && N % 4 == 0 && N / 4 <= 1024 && S <= 8) {
+    // Dispatch by shape only (the A/B switches of rounds 3-4 are gone; their records: profiles/r03/ab1_*.json, profiles/r04/c13_ab.json):
+    // d = 3072 -> three column groups per thread (256 threads instead of 768; step 2.0867 against 2.0934 ms).  The same kernel as ONE wave
+    // per row for the small models (d = 1024 / 1280) measured SLOWER - Qwen3-TTS 3.86 -> 3.91 ms per frame, Whisper 243 -> 246 ms per
+    // 8 x 30 s (profiles/r04/c14_secondary_ab.txt) - and six groups per thread at d = 3072 as well (2.121 against 2.087 ms per step,
+    // c15_ab.json); every other width up to 4096 -> one group of four columns per thread (k_glue4); beyond that, or more than 8 slabs, the
+    // general kernel.
+    if (!ln_bias && N == 3072 && S <= 8) { launch_glue_cpt<3, false>(slabs, S, Mpad, N, h, wnorm, x, eps, ln_bias, s); return; }
+    if (N % 4 == 0 && N / 4 <= 1024 && S <= 8) {
         const int nth = ((N / 4 + 63) / 64) * 64;
         if (ln_bias) {
             if (S <= 2) hipLaunchKernelGGL((k_glue4<2, true>), dim3(Mpad), dim3(nth), 0, s, slabs, S, Mpad, N, h, wnorm, x, eps, ln_bias);
@@ -1400,10 +1397,9 @@ __device__ __forceinline__ void att2_issue_tile(const bf16_t* kt, const bf16_t* 
     asm volatile("" : "+v"(KA[0][0]), "+v"(KA[0][1]), "+v"(KA[0][2]), "+v"(KA[0][3]), "+v"(KA[1][0]), "+v"(KA[1][1]), "+v"(KA[1][2]),  \
                       "+v"(KA[1][3]), "+v"(VB[0]), "+v"(VB[1]), "+v"(VB[2]), "+v"(VB[3]), "+v"(VB[4]), "+v"(VB[5]), "+v"(VB[6]), "+v"(VB[7]))
 
-// PAIR (round 4, MIS_ATTN_PAIR=1): a wave with two or more tiles requests its first TWO tiles before the prologue instead of one - the
-// second round of requests otherwise starts only after the prologue (~3 us into the launch), behind the first 32 MB of the launch's
-// stream.  Same waits after the prologue (tile B is then simply the youngest 16 loads already).
-template <int NS, bool PAIR>
+// (Measured and removed in round 5: a wave with two or more tiles requesting its first TWO tiles before the prologue - 13.04-13.06 against
+// 13.05-13.10 us in isolation, step 2.0982 against 2.0975 ms over alternating runs, profiles/r04/c9_ab.json, c12_ab.json: nothing.)
+template <int NS>
 __global__ void __launch_bounds__(512) k_attn_decode2(AttnParams p) {
     constexpr int D = 128;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -1481,8 +1477,7 @@ __global__ void __launch_bounds__(512) k_attn_decode2(AttnParams p) {
         }
 
         if constexpr (NJ >= 1) att2_issue_tile(ktile(wave), vtile(wave), voff, kA, vA);
-        if constexpr (PAIR && NJ >= 2) att2_issue_tile(ktile(wave + ATT_WAVES), vtile(wave + ATT_WAVES), voff, kB, vB);
-        if constexpr (PAIR && NJ >= 2) ATT2_VMCNT(32); else if constexpr (NJ >= 1) ATT2_VMCNT(16); else ATT2_VMCNT(0);
+        if constexpr (NJ >= 1) ATT2_VMCNT(16); else ATT2_VMCNT(0);
         // (one binding statement; every register exactly once - a variable named twice is copied ahead of the statement, i.e. ahead
         // of the wait)
         asm volatile("" : "+v"(rc[0][0]), "+v"(rc[0][1]), "+v"(rc[1][0]), "+v"(rc[1][1]), "+v"(rs[0][0]), "+v"(rs[0][1]), "+v"(rs[1][0]), "+v"(rs[1][1]),
@@ -1623,7 +1618,7 @@ __global__ void __launch_bounds__(512) k_attn_decode2(AttnParams p) {
         // (sched barriers: left alone the scheduler starts requesting tile j + 2 while the P.V MFMAs of tile j still read the buffer -
         // the asm outputs then need 64 NEW registers next to the old buffer and the tile in flight, and the kernel spills.)
         __builtin_amdgcn_sched_barrier(0);
-        if constexpr (!PAIR && NJ >= 2) att2_issue_tile(ktile(wave + ATT_WAVES), vtile(wave + ATT_WAVES), voff, kB, vB);
+        if constexpr (NJ >= 2) att2_issue_tile(ktile(wave + ATT_WAVES), vtile(wave + ATT_WAVES), voff, kB, vB);
         if constexpr (NJ >= 1) {
             if constexpr (NJ >= 2) ATT2_VMCNT(16); else ATT2_VMCNT(0);
             ATT2_BIND_TILE(kA, vA);
@@ -1728,31 +1723,21 @@ void launch_attn_decode(const AttnParams& p, int batch, hipStream_t s) {
     MIS_REQUIRE(((uintptr_t)p.active & 3) == 0, MIS_ERR_GENERATION_FAILED, "attention: the active-flag array must be 4-byte aligned");
     dim3 grid(p.Hkv, batch), block(512);
     const int n_el = (G + 2) * p.D;
-    {   // second schedule (k_attn_decode2) where it applies; MIS_ATTN_V2=0 keeps the first one (A/B, parity tests: read per launch)
-        const char* e = getenv("MIS_ATTN_V2");
-        const bool v2 = !(e && atoi(e) == 0);
-        if (v2 && !p.first_schedule && !p.cache_rows && !p.append_only && p.D == 128 && !p.cross && p.rope_cos && !p.rope_in_dtype && !p.qnorm_w && p.S <= 4 && G <= 4 && p.Smax <= 32 * ATT_WAVES * ATT2_MAX_J &&
-            p.Smax % 32 == 0 && ((uintptr_t)p.qkv_part & 15) == 0 && p.Nqkv % 4 == 0) {
-            const size_t sm2 = attn2_smem_bytes(G);
-            // k_attn_decode2 is compiled for 0 .. ATT2_MAX_J key tiles per wave (its switch has no case beyond): the cache must not hold more
-            MIS_REQUIRE((p.Smax / 32 + ATT_WAVES - 1) / ATT_WAVES <= ATT2_MAX_J, MIS_ERR_GENERATION_FAILED,
-                        "attention: %d cache positions need more than %d key tiles per wave", p.Smax, ATT2_MAX_J);
-            const char* ep = getenv("MIS_ATTN_PAIR");
-            const bool pair = ep && atoi(ep) != 0;
-            if (pair) switch (p.S) {
-                case 1: hipLaunchKernelGGL((k_attn_decode2<1, true>), grid, block, sm2, s, p); break;
-                case 2: hipLaunchKernelGGL((k_attn_decode2<2, true>), grid, block, sm2, s, p); break;
-                case 3: hipLaunchKernelGGL((k_attn_decode2<3, true>), grid, block, sm2, s, p); break;
-                default: hipLaunchKernelGGL((k_attn_decode2<4, true>), grid, block, sm2, s, p); break;
-            }
-            else switch (p.S) {
-                case 1: hipLaunchKernelGGL((k_attn_decode2<1, false>), grid, block, sm2, s, p); break;
-                case 2: hipLaunchKernelGGL((k_attn_decode2<2, false>), grid, block, sm2, s, p); break;
-                case 3: hipLaunchKernelGGL((k_attn_decode2<3, false>), grid, block, sm2, s, p); break;
-                default: hipLaunchKernelGGL((k_attn_decode2<4, false>), grid, block, sm2, s, p); break;
-            }
-            return;
+    // second schedule (k_attn_decode2) where it applies: head_dim 128, RoPE tables, no q/k norm, <= 4 slabs, a decode step (the batched
+    // prefill keeps the first schedule: its two arrangements must give the same bits whatever the batch size)
+    if (!p.first_schedule && !p.cache_rows && !p.append_only && p.D == 128 && !p.cross && p.rope_cos && !p.rope_in_dtype && !p.qnorm_w && p.S <= 4 && G <= 4 && p.Smax <= 32 * ATT_WAVES * ATT2_MAX_J &&
+        p.Smax % 32 == 0 && ((uintptr_t)p.qkv_part & 15) == 0 && p.Nqkv % 4 == 0) {
+        const size_t sm2 = attn2_smem_bytes(G);
+        // k_attn_decode2 is compiled for 0 .. ATT2_MAX_J key tiles per wave (its switch has no case beyond): the cache must not hold more
+        MIS_REQUIRE((p.Smax / 32 + ATT_WAVES - 1) / ATT_WAVES <= ATT2_MAX_J, MIS_ERR_GENERATION_FAILED,
+                    "attention: %d cache positions need more than %d key tiles per wave", p.Smax, ATT2_MAX_J);
+        switch (p.S) {
+            case 1: hipLaunchKernelGGL((k_attn_decode2<1>), grid, block, sm2, s, p); break;
+            case 2: hipLaunchKernelGGL((k_attn_decode2<2>), grid, block, sm2, s, p); break;
+            case 3: hipLaunchKernelGGL((k_attn_decode2<3>), grid, block, sm2, s, p); break;
+            default: hipLaunchKernelGGL((k_attn_decode2<4>), grid, block, sm2, s, p); break;
         }
+        return;
     }
 #ifdef MIS_ATTN_TIMING
     // one 16-stamp slot per enqueued launch (graph replays rewrite their slot); dumped by mis_debug_attn_timing()

@@ -331,13 +331,13 @@ __global__ void __launch_bounds__(KSB == 8 ? 512 : 256, 2) k_gemm_skinny_q(const
 // kernel's lanes hold them), so the epilogues and the in-block split-K combine are shared; eight waves per item are possible here.
 // Per-element arithmetic is that of k_gemm_skinny_q; the in-block combine adds KSB partials in wave order.
 template <int MT, int R, int EPI, int KSB, int BITS, int U>
-__global__ void __launch_bounds__(KSB == 8 ? 512 : 256, 2) k_gemm_skinny_q1(const void* Qp, const bf16_t* SB, const bf16_t* X,     // not __restrict__: see the
+__global__ void __launch_bounds__(256, 2) k_gemm_skinny_q1(const void* Qp, const bf16_t* SB, const bf16_t* X,     // not __restrict__: see the
                                                                             void* __restrict__ out, int NT, int G, int S, int n_items, int N_out, int Mpad,   // fence below
                                                                             const bf16_t* __restrict__ bias) {
     static_assert(EPI != EPI_SILU_MUL || R == 2, "silu-mul epilogue pairs a gate tile with an up tile");
     typedef typename QTile<BITS>::type WT;
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    static_assert(KSB == 4 || KSB == 8, "one block per item, its waves split the item's K range");
+    static_assert(KSB == 4, "one block of four waves per item, its waves split the item's K range (eight waves measured worse and were removed)");
     const int item = blockIdx.x;
     if (item >= n_items) return;
     const int ntg = item / S, ks = item - ntg * S;
@@ -478,7 +478,7 @@ template <int MT, int BITS, int U>
 static void launch_qgemm1_mt(int epi, int R, int ksb, const void* Qp, const bf16_t* SB, const bf16_t* X, void* out, int NT, int G, int S,
                              int N_out, int Mpad, const bf16_t* bias, hipStream_t s) {
     int n_items = ((NT + R - 1) / R) * S;
-    dim3 grid(n_items), block(ksb == 8 ? 512 : 256);
+    dim3 grid(n_items), block(256);
 #define QGEMM1_CASE(E, RR, KS)                                                                                      \
     if (epi == E && R == RR && ksb == KS) {                                                                         \
         hipLaunchKernelGGL((k_gemm_skinny_q1<MT, RR, E, KS, BITS, U>), grid, block, 0, s, Qp, SB, X, out, NT, G, S, n_items, \
@@ -486,13 +486,9 @@ static void launch_qgemm1_mt(int epi, int R, int ksb, const void* Qp, const bf16
         return;                                                                                                     \
     }
     QGEMM1_CASE(EPI_PARTIAL, 1, 4)
-    QGEMM1_CASE(EPI_PARTIAL, 1, 8)
     QGEMM1_CASE(EPI_PARTIAL, 2, 4)
-    QGEMM1_CASE(EPI_PARTIAL, 2, 8)
     QGEMM1_CASE(EPI_BF16, 2, 4)
-    QGEMM1_CASE(EPI_BF16, 2, 8)
     QGEMM1_CASE(EPI_SILU_MUL, 2, 4)
-    QGEMM1_CASE(EPI_SILU_MUL, 2, 8)
 #undef QGEMM1_CASE
     throw MisError(MIS_ERR_GENERATION_FAILED, "unsupported quantised GEMM variant");
 }
@@ -537,12 +533,11 @@ void launch_gemm_skinny_q(int bits, int epi, int R, int ksb, const void* Qp, con
     MIS_REQUIRE(epi == EPI_PARTIAL || S == 1, MIS_ERR_GENERATION_FAILED, "split-K needs the partial epilogue");
     MIS_REQUIRE(bits == 8 || bits == 4, MIS_ERR_GENERATION_FAILED, "quantised GEMM: 8 or 4 bits");
     MIS_REQUIRE(S >= 1 && S <= G, MIS_ERR_GENERATION_FAILED, "quantised GEMM: %d K slices for %d scale groups", S, G);   // a wave may get none
-    static const int u_env = getenv("MIS_QGEMM_U") ? atoi(getenv("MIS_QGEMM_U")) : 2;
-    // one-shot arrangement (k_gemm_skinny_q1): on unless MIS_QGEMM_V2=0.  MIS_QGEMM_V2_WAVES8=1: eight waves per item where four
-    // leave a wave more than six groups; MIS_QGEMM_V2_MAXU=2|4: no larger buffers
+    // one-shot arrangement (k_gemm_skinny_q1) wherever a wave's K share fits its buffer.  MIS_QGEMM_V2=0 (read once per process) sends
+    // those launches through the streaming kernel instead: that kernel is the product path of the wide roles at Orpheus width, and the
+    // switch is how tests/test_gpu_loader.py holds it to the oracle at small widths too.  (Eight waves per item and capped buffer sizes
+    // were measured and removed: profiles/r03/qgemm_one_shot.jsonl.)
     static const int v2 = getenv("MIS_QGEMM_V2") ? atoi(getenv("MIS_QGEMM_V2")) : 1;
-    static const int v2_waves8 = getenv("MIS_QGEMM_V2_WAVES8") ? atoi(getenv("MIS_QGEMM_V2_WAVES8")) : 0;
-    static const int v2_maxu = getenv("MIS_QGEMM_V2_MAXU") ? atoi(getenv("MIS_QGEMM_V2_MAXU")) : 6;
     if (R == 4 || ksb == 8) {                      // the wide roles' arrangement (streaming kernel only): R = 4 -> one group per buffer
         MIS_REQUIRE(Mpad / 16 <= 2, MIS_ERR_GENERATION_FAILED, "quantised GEMM: four n-tiles per wave / eight waves per item are built for <= 32 rows");
 #define QGEMM_R4(M, UU)                                                                                              \
@@ -555,12 +550,9 @@ void launch_gemm_skinny_q(int bits, int epi, int R, int ksb, const void* Qp, con
     }
     if (v2 && Mpad / 16 <= 2) {
         // where a wave's K share fits a buffer of 2, 4 or 6 scale groups (the smallest that holds it: groups past the share cost loads
-        // and MFMAs); everything else streams through k_gemm_skinny_q.  Eight waves per item measured worse than four on every role
-        // (profiles/r03/qgemm_one_shot.jsonl) and stay behind the switch.
+        // and MFMAs); everything else streams through k_gemm_skinny_q.
         const int per_item = (G + S - 1) / S;
-        auto pw = [&](int k) { return (per_item + k - 1) / k; };
-        int k2 = ksb, n = pw(ksb);
-        if (n > 6 && ksb == 4 && v2_waves8 && pw(8) <= 6) { k2 = 8; n = pw(8); }
+        const int k2 = ksb, n = (per_item + ksb - 1) / ksb;
         const int u2 = ksb == 1 ? 0 : n <= 2 ? 2 : n <= 4 ? 4 : n <= 6 ? 6 : 0;       // one wave per item: the streaming kernel (long K shares)
 #define QGEMM1_GO(M, UU)                                                                                             \
         { if (bits == 8) launch_qgemm1_mt<M, 8, UU>(epi, R, k2, Qp, SB, X, out, NT, G, S, N_out, Mpad, bias, s);         \
@@ -570,7 +562,7 @@ void launch_gemm_skinny_q(int bits, int epi, int R, int ksb, const void* Qp, con
         if (u2 == 2) QGEMM1_GO(M, 2)                                                                                 \
         if (u2 == 4) QGEMM1_GO(M, 4)                                                                                 \
         if (u2 == 6) QGEMM1_GO(M, 6)
-        if (u2 && u2 <= v2_maxu) { if (Mpad / 16 == 1) { QGEMM1_MT(1) } else { QGEMM1_MT(2) } }
+        if (u2) { if (Mpad / 16 == 1) { QGEMM1_MT(1) } else { QGEMM1_MT(2) } }
 #undef QGEMM1_MT
 #undef QGEMM1_GO
     }
@@ -578,8 +570,8 @@ void launch_gemm_skinny_q(int bits, int epi, int R, int ksb, const void* Qp, con
     if (bits == 8) launch_qgemm_mt<M, 8, UU>(epi, R, ksb, Qp, SB, X, out, NT, G, S, N_out, Mpad, bias, s);           \
     else launch_qgemm_mt<M, 4, UU>(epi, R, ksb, Qp, SB, X, out, NT, G, S, N_out, Mpad, bias, s);
     switch (Mpad / 16) {
-        case 1: if (u_env == 1) { QGEMM_MT(1, 1) } else { QGEMM_MT(1, 2) } break;
-        case 2: if (u_env == 1) { QGEMM_MT(2, 1) } else { QGEMM_MT(2, 2) } break;
+        case 1: { QGEMM_MT(1, 2) } break;
+        case 2: { QGEMM_MT(2, 2) } break;
         case 3: { QGEMM_MT(3, 1) } break;
         case 4: { QGEMM_MT(4, 1) } break;
         default: throw MisError(MIS_ERR_INVALID_INPUT, "batch per GPU must be <= 64");

@@ -23,6 +23,7 @@
 #include "lm_kernels.h"
 #include <vector>
 #include <atomic>
+#include <mutex>
 
 #define SAMP_NT 256
 #define ORPHEUS_AUDIO_OFFSET 128266
@@ -691,6 +692,10 @@ __global__ void __launch_bounds__(SC_NT) k_samp_cluster(SamplerParams p, int spi
     const int wl_raw = *wl_src;
     const int win_raw = *win_src;
     const unsigned sync_now = __hip_atomic_load(&sc->c_sync, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    // a row that timed out in an EARLIER launch (the flag is sticky until the host has read it) does not spin again: its counter is
+    // short of arrivals, every barrier of this launch would run its whole poll budget - the replays queued behind a failed step end
+    // in microseconds instead, and the host restarts the request on the multi-launch path at its next poll (run_generate)
+    if (__hip_atomic_load(&sc->c_fail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) spin_limit = 0;
     const int wlen_all = penalise ? wl_raw : 0;
     typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));       // (a native vector: HIP's uint4 struct kept this array in scratch)
     u32x4_t q[3];
@@ -973,31 +978,56 @@ void sampler_scratch_init(SamplerScratch* scratch, int batch, hipStream_t s) {
 // how often a launch of the one-launch sampler reported a timed-out row barrier in this process (diagnostics, tests)
 static std::atomic<int> g_sampler_failures{0};
 extern "C" int32_t mis_debug_sampler_failures(void) { return g_sampler_failures.load(); }
+void sampler_fail_flags_async(SamplerScratch* scratch, int batch, unsigned* host_flags, hipStream_t s) {
+    HIP_CHECK(hipMemcpy2DAsync(host_flags, sizeof(unsigned), &scratch[0].c_fail, sizeof(SamplerScratch), sizeof(unsigned), (size_t)batch,
+                               hipMemcpyDeviceToHost, s));
+}
+bool sampler_fail_flags_any(const unsigned* host_flags, int batch) {
+    bool any = false;
+    for (int b = 0; b < batch; ++b) any = any || host_flags[b] != 0;
+    return any;
+}
+void sampler_note_failure(SamplerScratch* scratch, int batch, hipStream_t s) {
+    g_sampler_failures.fetch_add(1);
+    sampler_scratch_init(scratch, batch, s);           // counters and flags back to the state a fresh scratch has
+    HIP_CHECK(hipStreamSynchronize(s));
+}
 bool sampler_check_failed(SamplerScratch* scratch, int batch, hipStream_t s) {
     if (!scratch || batch <= 0) return false;
     std::vector<unsigned> f(batch, 0u);
-    HIP_CHECK(hipMemcpy2DAsync(f.data(), sizeof(unsigned), &scratch[0].c_fail, sizeof(SamplerScratch), sizeof(unsigned), (size_t)batch,
-                               hipMemcpyDeviceToHost, s));
+    sampler_fail_flags_async(scratch, batch, f.data(), s);
     HIP_CHECK(hipStreamSynchronize(s));
-    bool any = false;
-    for (unsigned v : f) any = any || v != 0;
-    if (any) g_sampler_failures.fetch_add(1);
-    if (any) {                                        // counters and flags back to the state a fresh scratch has
-        sampler_scratch_init(scratch, batch, s);
-        HIP_CHECK(hipStreamSynchronize(s));
-    }
+    const bool any = sampler_fail_flags_any(f.data(), batch);
+    if (any) sampler_note_failure(scratch, batch, s);
     return any;
 }
-// the one-launch sampler's 8 x batch blocks spin on each other: all of them have to be resident at once
+// the one-launch sampler's 8 x batch blocks spin on each other: all of them have to be resident at once.  The capacity (occupancy query
+// x compute units) is cached per DEVICE: the replicas of a group may sit on devices of different sizes or partition modes.
 static bool sampler_cluster_fits(int batch) {
-    static const int capacity = [] {
-        int dev = 0, per_cu = 0;
+    static std::mutex mu;
+    static std::map<int, int> capacity;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return false;
+    std::lock_guard<std::mutex> lk(mu);
+    auto it = capacity.find(dev);
+    if (it == capacity.end()) {
+        int per_cu = 0, cap = 0;
         hipDeviceProp_t prop{};
-        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return 0;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_samp_cluster, SC_NT, 0) != hipSuccess) return 0;
-        return per_cu * prop.multiProcessorCount;
-    }();
-    return SC_NB * batch <= capacity;
+        if (hipGetDeviceProperties(&prop, dev) == hipSuccess &&
+            hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_samp_cluster, SC_NT, 0) == hipSuccess)
+            cap = std::min(per_cu, 2) * prop.multiProcessorCount;      // (never count on more than two 1024-thread blocks per CU: the
+                                                                       //  third would depend on the register count of a compiler release)
+        it = capacity.emplace(dev, cap).first;
+    }
+    return SC_NB * batch <= it->second;
+}
+
+void sampler_resolve(SamplerParams& p, bool multi_launch_only) {
+    const char* ew = getenv("MIS_SAMPLER_WIDE");                     // non-zero: never the one-launch kernels (A/B, parity tests, shared devices)
+    const char* es = getenv("MIS_SAMPLER_SPIN");                     // polls per row barrier before a block gives up (tests: the failure path)
+    p.path_resolved = 1;
+    p.force_multi = (multi_launch_only || (ew && atoi(ew) != 0)) ? 1 : 0;
+    p.spin = es ? (atoi(es) > 0 ? atoi(es) : 0) : (1 << 22);         // 0: every barrier times out at once
 }
 
 void sampler_plan(int vocab, int* n_chunks, int* chunk_w) {
@@ -1010,30 +1040,30 @@ void sampler_plan(int vocab, int* n_chunks, int* chunk_w) {
     *chunk_w = cw;
 }
 
-void launch_sampler(const SamplerParams& p, int batch, hipStream_t s, bool multi_launch_only) {
-    MIS_REQUIRE(p.scratch && p.n_chunks >= 1 && p.n_chunks <= SAMP_MAX_CHUNKS && p.chunk_w > 0, MIS_ERR_GENERATION_FAILED,
+void launch_sampler(const SamplerParams& p_in, int batch, hipStream_t s, bool multi_launch_only) {
+    MIS_REQUIRE(p_in.scratch && p_in.n_chunks >= 1 && p_in.n_chunks <= SAMP_MAX_CHUNKS && p_in.chunk_w > 0, MIS_ERR_GENERATION_FAILED,
                 "sampler scratch not configured");
+    // which kernels: resolved ONCE per generate call (sampler_resolve; the result is part of the captured graph's key) - or here, per
+    // launch, for the stand-alone entry point whose callers switch the environment between calls (parity tests)
+    SamplerParams p = p_in;
+    if (!p.path_resolved) sampler_resolve(p, multi_launch_only);
+    const bool multi = multi_launch_only || p.force_multi != 0;
     {   // narrow allowed range (every frame-constrained step; any static [lo, hi) of <= 4096 ids): the single-launch sampler
-        const char* ew = getenv("MIS_SAMPLER_WIDE");                     // A/B and parity tests (non-zero: never the narrow kernel, and six kernels below)
-        const bool wide_only = multi_launch_only || (ew && atoi(ew) != 0);
         const int hi = (p.hi <= 0 || p.hi > p.vocab) ? p.vocab : p.hi, lo = p.lo < 0 ? 0 : p.lo;
         // frame_constrained 2: the frame range, but through the full-vocabulary kernels (every id visited, the masked ones get e = 0) -
         // what bench.py times as the honest stand-in for a real checkpoint's unconstrained decode
         const bool narrow = p.frame_constrained == 1 || (!p.frame_constrained && hi - lo <= SN_W);
-        if (narrow && !wide_only && !p.logits32 && p.penalty_flavor == 0) {
+        if (narrow && !multi && !p.logits32 && p.penalty_flavor == 0) {
             hipLaunchKernelGGL(k_samp_narrow, dim3(batch), dim3(SN_NT), 0, s, p);
             return;
         }
     }
-    {   // full vocabulary in one launch (k_samp_cluster); MIS_SAMPLER_WIDE=1 keeps the six-kernel path (A/B, parity tests)
-        const char* e6 = getenv("MIS_SAMPLER_WIDE");                     // (read per launch: the parity tests switch it in-process)
-        const bool six = multi_launch_only || (e6 && atoi(e6) != 0);
-        const char* es = getenv("MIS_SAMPLER_SPIN");                     // polls per row barrier before a block gives up (tests: the failure path)
-        const int spin = es ? (atoi(es) > 0 ? atoi(es) : 0) : (1 << 22);                  // 0: every barrier times out at once
-        if (!six && !p.logits32 && p.penalty_flavor == 0 && p.vocab <= SC_NB * SC_NT * SC_PER && p.Vpad % 2 == 0 && p.ctx <= 64 && sampler_cluster_fits(batch)) {
-            hipLaunchKernelGGL(k_samp_cluster, dim3(SC_NB, batch), dim3(SC_NT), 0, s, p, spin);
-            return;
-        }
+    // full vocabulary in one launch (k_samp_cluster): 16-byte row chunks (Vpad % 16 == 0 keeps every row and block range aligned), every
+    // block of the launch resident at once
+    if (!multi && !p.logits32 && p.penalty_flavor == 0 && p.vocab <= SC_NB * SC_NT * SC_PER && p.Vpad % 16 == 0 && p.ctx <= 64 &&
+        sampler_cluster_fits(batch)) {
+        hipLaunchKernelGGL(k_samp_cluster, dim3(SC_NB, batch), dim3(SC_NT), 0, s, p, p.spin);
+        return;
     }
     dim3 g2(p.n_chunks, batch);
     hipLaunchKernelGGL(k_samp_prepare, dim3(batch), dim3(64), 0, s, p);

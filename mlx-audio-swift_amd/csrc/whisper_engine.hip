@@ -46,6 +46,7 @@ struct mis_whisper {
     DevBuf<bf16_t> h, x, attn_out, act, logits;
     DevBuf<float> qkv_part, part, e_buf, logits_f32;
     DevBuf<SamplerScratch> scratch;
+    bool shared_device = false;      // another replica's streams run on this device (group.hip): never a kernel that waits for co-resident blocks
 };
 
 static const float LN_EPS = 1e-5f;
@@ -607,40 +608,49 @@ static void whisper_generate_impl(mis_whisper* c, const float* pcm, const int64_
     int max_tokens = std::max(1, std::min(sp->max_tokens > 0 ? sp->max_tokens : c->cfg.max_target_positions,
                                           c->cfg.max_target_positions - n_prompt - 1));
     std::vector<uint8_t> ones(batch, 1);
-    for (int j = 0; j < n_prompt; ++j) {
-        MIS_REQUIRE(prompt[j] >= 0 && prompt[j] < c->V, MIS_ERR_INVALID_INPUT, "prompt token outside the vocabulary");
-        std::vector<int32_t> row(batch, prompt[j]);
-        HIP_CHECK(hipMemcpyAsync(c->ids.p, row.data(), batch * 4, hipMemcpyHostToDevice, s));
-        HIP_CHECK(hipMemcpyAsync(c->active.p, ones.data(), batch, hipMemcpyHostToDevice, s));
-        enqueue_decoder_step(c);
-        HIP_CHECK(hipStreamSynchronize(s));
-    }
-    // ---- decode loop
-    c->tokens_out.alloc((size_t)batch * max_tokens);
-    c->tokens_out.zero(s);
-    c->sup.alloc(std::max(sp->n_suppress, 1)); c->bsup.alloc(std::max(sp->n_begin_suppress, 1));
-    if (sp->n_suppress > 0) HIP_CHECK(hipMemcpyAsync(c->sup.p, sp->suppress, sp->n_suppress * 4, hipMemcpyDefault, s));
-    if (sp->n_begin_suppress > 0) HIP_CHECK(hipMemcpyAsync(c->bsup.p, sp->begin_suppress, sp->n_begin_suppress * 4, hipMemcpyDefault, s));
-    SamplerParams q{};
-    q.scratch = c->scratch.p;
-    sampler_plan(c->V, &q.n_chunks, &q.chunk_w);
-    q.logits = c->logits.p; q.e_buf = c->e_buf.p; q.Vpad = c->Vpad; q.vocab = c->V;
-    q.active_in = c->active.p; q.n_gen = c->n_gen.p; q.tokens_out = c->tokens_out.p; q.tokens_stride = max_tokens;
-    q.next_ids = c->ids.p; q.active = c->active.p; q.done_count = c->done_count.p;
-    q.temperature = sp->temperature > 0 ? sp->temperature : 0.0f; q.top_p = 1.0f; q.penalty = 0.0f; q.seed = sp->seed; q.row_offset = sp->row_offset;
-    q.lo = 0; q.hi = (sp->timestamp_begin > 0 && sp->timestamp_begin < c->V) ? sp->timestamp_begin : c->V;   // suppressFromIndex
-    q.eos_id = sp->eot_id; q.max_tokens = max_tokens;
-    PinnedBuf<int32_t> done_pin(1);
-    int32_t* done_host = done_pin.p;
-    *done_host = 0;
-    // one decode step = logits GEMM -> suppress masks -> argmax / sampler -> next token through the decoder: every argument
-    // is a device pointer that stays put, so the step is captured once and replayed (≈430 kernel nodes per step)
-    auto step_body = [&]() {
-        enqueue_vocab(c);
-        launch_whisper_suppress(c->logits.p, c->Vpad, c->V, c->sup.p, sp->n_suppress, c->bsup.p, sp->n_begin_suppress, c->n_gen.p,
-                                c->active.p, batch, s);
-        launch_sampler(q, batch, s);
-        enqueue_decoder_step(c);
+    for (int j = 0; j < n_prompt; ++j) MIS_REQUIRE(prompt[j] >= 0 && prompt[j] < c->V, MIS_ERR_INVALID_INPUT, "prompt token outside the vocabulary");
+    std::vector<int32_t> emitted(batch, 0);              // ids already announced to the callback (kept across a second attempt)
+    // One attempt of prompt prefill + decode loop on the encoder output already in place.  Returns false when a row barrier of the
+    // one-launch sampler timed out (its blocks were not co-resident: another stream holds compute units) - seen at the poll, before any
+    // id of that poll interval is announced; the caller resets the decoder state and runs the attempt again on the multi-launch
+    // sampler (deterministic: same ids, the callback continues behind `emitted`).
+    auto attempt = [&](bool multi_launch_only) -> bool {
+        for (int j = 0; j < n_prompt; ++j) {
+            std::vector<int32_t> row(batch, prompt[j]);
+            HIP_CHECK(hipMemcpyAsync(c->ids.p, row.data(), batch * 4, hipMemcpyHostToDevice, s));
+            HIP_CHECK(hipMemcpyAsync(c->active.p, ones.data(), batch, hipMemcpyHostToDevice, s));
+            enqueue_decoder_step(c);
+            HIP_CHECK(hipStreamSynchronize(s));
+        }
+        // ---- decode loop
+        c->tokens_out.alloc((size_t)batch * max_tokens);
+        c->tokens_out.zero(s);
+        c->sup.alloc(std::max(sp->n_suppress, 1)); c->bsup.alloc(std::max(sp->n_begin_suppress, 1));
+        if (sp->n_suppress > 0) HIP_CHECK(hipMemcpyAsync(c->sup.p, sp->suppress, sp->n_suppress * 4, hipMemcpyDefault, s));
+        if (sp->n_begin_suppress > 0) HIP_CHECK(hipMemcpyAsync(c->bsup.p, sp->begin_suppress, sp->n_begin_suppress * 4, hipMemcpyDefault, s));
+        SamplerParams q{};
+        q.scratch = c->scratch.p;
+        sampler_plan(c->V, &q.n_chunks, &q.chunk_w);
+        q.logits = c->logits.p; q.e_buf = c->e_buf.p; q.Vpad = c->Vpad; q.vocab = c->V;
+        q.active_in = c->active.p; q.n_gen = c->n_gen.p; q.tokens_out = c->tokens_out.p; q.tokens_stride = max_tokens;
+        q.next_ids = c->ids.p; q.active = c->active.p; q.done_count = c->done_count.p;
+        q.temperature = sp->temperature > 0 ? sp->temperature : 0.0f; q.top_p = 1.0f; q.penalty = 0.0f; q.seed = sp->seed; q.row_offset = sp->row_offset;
+        q.lo = 0; q.hi = (sp->timestamp_begin > 0 && sp->timestamp_begin < c->V) ? sp->timestamp_begin : c->V;   // suppressFromIndex
+        q.eos_id = sp->eot_id; q.max_tokens = max_tokens;
+        sampler_resolve(q, multi_launch_only);               // (environment switches read once per attempt)
+        PinnedBuf<int32_t> done_pin(1);
+        PinnedBuf<unsigned> fail_pin(batch);
+        bool sampler_failed = false;
+        int32_t* done_host = done_pin.p;
+        *done_host = 0;
+        // one decode step = logits GEMM -> suppress masks -> argmax / sampler -> next token through the decoder: every argument
+        // is a device pointer that stays put, so the step is captured once and replayed (≈430 kernel nodes per step)
+        auto step_body = [&]() {
+            enqueue_vocab(c);
+            launch_whisper_suppress(c->logits.p, c->Vpad, c->V, c->sup.p, sp->n_suppress, c->bsup.p, sp->n_begin_suppress, c->n_gen.p,
+                                    c->active.p, batch, s);
+            launch_sampler(q, batch, s);
+            enqueue_decoder_step(c);
     };
     hipGraphExec_t gexec = nullptr;
     const bool use_graph = getenv("MIS_NO_GRAPH") == nullptr;
@@ -655,18 +665,20 @@ static void whisper_generate_impl(mis_whisper* c, const float* pcm, const int64_
         }
         // stream form: the ids sampled since the last poll are announced in step order per row (the reference decodes them to a
         // text delta per step, WhisperModel.swift:242-254; detokenisation stays with the host); EOT is never announced (:238)
-        std::vector<int32_t> emitted(batch, 0), h_ng(batch), h_tok;
+        std::vector<int32_t> h_ng(batch), h_tok;
         const int poll = on_event ? 3 : 7;
         for (int step = 0; step < max_tokens; ++step) {
             if (use_graph) HIP_CHECK(hipGraphLaunch(gexec, s)); else step_body();
             if ((step & poll) == poll || step + 1 == max_tokens) {
                 HIP_CHECK(hipMemcpyAsync(done_host, c->done_count.p, 4, hipMemcpyDeviceToHost, s));
+                sampler_fail_flags_async(c->scratch.p, batch, fail_pin.p, s);
                 if (on_event) {
                     h_tok.resize((size_t)batch * max_tokens);
                     HIP_CHECK(hipMemcpyAsync(h_ng.data(), c->n_gen.p, batch * 4, hipMemcpyDeviceToHost, s));
                     HIP_CHECK(hipMemcpyAsync(h_tok.data(), c->tokens_out.p, h_tok.size() * 4, hipMemcpyDeviceToHost, s));
                 }
                 HIP_CHECK(hipStreamSynchronize(s));
+                if (sampler_fail_flags_any(fail_pin.p, batch)) { sampler_failed = true; break; }
                 if (on_event)
                     for (int b = 0; b < batch; ++b)
                         for (; emitted[b] < h_ng[b]; ++emitted[b]) {
@@ -683,8 +695,14 @@ static void whisper_generate_impl(mis_whisper* c, const float* pcm, const int64_
     }
     if (gexec) (void)hipGraphExecDestroy(gexec);
     HIP_CHECK(hipGetLastError());
-    MIS_REQUIRE(!sampler_check_failed(c->scratch.p, batch, s), MIS_ERR_GENERATION_FAILED,
-                "sampler: a row barrier of the one-launch sampler timed out (its blocks were not co-resident); MIS_SAMPLER_WIDE=1 selects the multi-launch path");
+    if (sampler_failed) sampler_note_failure(c->scratch.p, batch, s);
+    return !sampler_failed;
+    };
+    if (!attempt(c->shared_device)) {
+        MIS_REQUIRE(!c->shared_device, MIS_ERR_GENERATION_FAILED, "sampler: time-out flag raised on the multi-launch path");
+        whisper_decoder_reset(c);
+        MIS_REQUIRE(attempt(true), MIS_ERR_GENERATION_FAILED, "sampler: time-out flag raised on the multi-launch path");
+    }
     std::vector<int32_t> ng(batch), toks((size_t)batch * max_tokens);
     HIP_CHECK(hipMemcpy(ng.data(), c->n_gen.p, batch * 4, hipMemcpyDeviceToHost));
     HIP_CHECK(hipMemcpy(toks.data(), c->tokens_out.p, toks.size() * 4, hipMemcpyDeviceToHost));
@@ -706,6 +724,9 @@ static void whisper_generate_impl(mis_whisper* c, const float* pcm, const int64_
         }
     }
 }
+
+int whisper_internal_device(const mis_whisper* c) { return c ? c->device : -1; }
+void whisper_internal_set_shared_device(mis_whisper* c, bool shared) { if (c) c->shared_device = shared; }
 
 extern "C" mis_status mis_stt_whisper_generate(mis_whisper* c, const float* pcm, const int64_t* lens, int batch, int64_t stride,
                                                const int32_t* prompt_ids, int n_prompt, const mis_stt_params* sp,

@@ -378,13 +378,12 @@ static bool launch_big3(const BigGemmParams& p, hipStream_t s) {
 void launch_gemm_big(int epi, const BigGemmParams& p, hipStream_t s) {
     MIS_REQUIRE(p.K % BG_BK == 0 && p.ldx % 8 == 0 && p.N % 4 == 0, MIS_ERR_INVALID_INPUT, "big GEMM needs K %% 32 == 0");
     dim3 grid(cdiv(p.N, BG_BN), cdiv(p.M, BG_BM)), block(256);
-    static const bool v1 = getenv("MIS_GEMM_BIG_V1") && atoi(getenv("MIS_GEMM_BIG_V1")) != 0;     // A/B: the register-staged kernel
     {   // the 256 x 256 tile where its grid still fills most of the chip (out_proj of 8 windows: 235 blocks, 52.0 -> 44.6 us); below that the
         // 128 x 128 kernel has four times the blocks.  MIS_GEMM_BIG3=0: never (A/B); =2: whenever the shape allows (parity tests)
         const char* e3 = getenv("MIS_GEMM_BIG3");
         const int mode = e3 ? atoi(e3) : 1;
         const long blocks3 = (long)cdiv(p.N, BG3_BN) * cdiv(p.M, BG3_BM);
-        if (mode != 0 && !v1 && p.K % BG2_BK == 0 && p.K >= 2 * BG2_BK && (mode == 2 || blocks3 >= 200)) {
+        if (mode != 0 && p.K % BG2_BK == 0 && p.K >= 2 * BG2_BK && (mode == 2 || blocks3 >= 200)) {
             bool done = false;
             switch (epi) {
                 case BG_NONE: done = launch_big3<BG_NONE>(p, s); break;
@@ -396,7 +395,7 @@ void launch_gemm_big(int epi, const BigGemmParams& p, hipStream_t s) {
             if (done) return;
         }
     }
-    if (!v1 && p.K % BG2_BK == 0 && p.K >= 2 * BG2_BK) {
+    if (p.K % BG2_BK == 0 && p.K >= 2 * BG2_BK) {
         switch (epi) {
             case BG_NONE: hipLaunchKernelGGL((k_gemm_big2<BG_NONE>), grid, block, 0, s, p); return;
             case BG_GELU: hipLaunchKernelGGL((k_gemm_big2<BG_GELU>), grid, block, 0, s, p); return;

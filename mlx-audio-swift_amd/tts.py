@@ -49,6 +49,60 @@ class VyvoTokens:
     codec_chunk_groups = 50          # decodeAudioFromCodes(chunkSize:), Qwen3.swift:47
 
 
+# -- host-side integer framing of the Orpheus prompt (no device involved; tests/test_tts_host_cpu.py) ---------------------------------
+def interleave_snac_codes(l1, l2, l3) -> np.ndarray:
+    """The interleave of llamaEncodeAudioToCodes (LlamaTTS.swift:80-97): three SNAC code levels of one utterance (g, 2g, 4g codes)
+    -> g frames of 7 ids [l1 | l2+4096 | l3+2*4096 | l3+3*4096 | l2+4*4096 | l3+5*4096 | l3+6*4096]; the exact inverse of the decode-side
+    de-interleave (:41-64)."""
+    l1, l2, l3 = (np.asarray(a).astype(np.int64).reshape(-1) for a in (l1, l2, l3))
+    g = len(l1)
+    if len(l2) != 2 * g or len(l3) != 4 * g:
+        raise AudioGenerationError(3, f"SNAC code levels of lengths {len(l1)}, {len(l2)}, {len(l3)} are not a 1:2:4 hierarchy")
+    out = np.empty((g, 7), np.int64)
+    out[:, 0] = l1
+    out[:, 1] = l2[0::2] + 4096
+    out[:, 2] = l3[0::4] + 2 * 4096
+    out[:, 3] = l3[1::4] + 3 * 4096
+    out[:, 4] = l2[1::2] + 4 * 4096
+    out[:, 5] = l3[2::4] + 5 * 4096
+    out[:, 6] = l3[3::4] + 6 * 4096
+    return out.reshape(-1).astype(np.int32)
+
+
+def orpheus_prompt_rows(tokenizer, prompts, voice=None, ref_codes=None, ref_text=None, tokens=OrpheusTokens):
+    """The id rows of prepareInputIds (LlamaTTS.swift:446-553), one int32 array per prompt:
+        [SOH ref-transcript EOT EOH AUDIO_START START_OF_SPEECH ref-codes+offset END_OF_SPEECH AUDIO_END]?  SOH text EOT EOH
+    The bracketed part appears only with BOTH `ref_codes` (the interleaved SNAC codes of the reference recording, before the
+    audio-token offset, :466-467) and `ref_text` (:458); `voice` prefixes every prompt with "voice: " (:472-476).  The reference's
+    explicit pad tokens are not materialised here: see `padded_prompt_batch`."""
+    T = tokens
+    ref = []
+    if ref_codes is not None and ref_text is not None:                    # :457-469, :505-528
+        audio_ids = np.asarray(ref_codes).astype(np.int64).reshape(-1) + T.audio_token_offset
+        ref = ([T.start_of_human] + [int(t) for t in tokenizer.encode(ref_text)] + [T.end_of_text, T.end_of_human] +
+               [T.audio_start, T.start_of_speech] + [int(t) for t in audio_ids] + [T.end_of_speech, T.audio_end])
+    rows = []
+    for p in prompts:
+        if voice is not None:
+            p = f"{voice}: {p}"
+        ids = [int(t) for t in tokenizer.encode(p)]
+        rows.append(np.asarray(ref + [T.start_of_human] + ids + [T.end_of_text, T.end_of_human], np.int32))
+    return rows
+
+
+def padded_prompt_batch(rows, pad_token: int = OrpheusTokens.pad_token):
+    """What prepareInputIds returns (LlamaTTS.swift:495-552): the rows LEFT-padded with the pad token to the longest row as one
+    [batch, maxLen] int32 matrix and the mask `ids != pad`.  (The reference pads by the PROMPT lengths, and every row carries the same
+    reference prefix, so that is the same as padding by the row lengths.)  The engine takes the ragged rows and masks the padding
+    itself; this form is for callers that want the reference's return value."""
+    n = max((len(r) for r in rows), default=0)
+    ids = np.full((len(rows), n), pad_token, np.int32)
+    for i, r in enumerate(rows):
+        if len(r):
+            ids[i, n - len(r):] = r
+    return ids, ids != pad_token
+
+
 @dataclass
 class LlamaTTSConfiguration:
     """LlamaTTSConfig.swift:15-61 (CodingKeys = HF config.json names)."""
@@ -194,38 +248,19 @@ class LlamaTTSModel:
         levels into 7-token frames with the k*4096 slot offsets (inverse of the decode-side de-interleave, :41-64)."""
         if self._snac_model is None:
             raise AudioGenerationError(1, "SNAC model not loaded")
-        l1, l2, l3 = [c[0].astype(np.int64) for c in self._snac_model.encode(np.asarray(audio, np.float32).reshape(1, -1))]
-        g = len(l1)
-        out = np.empty((g, 7), np.int64)
-        out[:, 0] = l1
-        out[:, 1] = l2[0::2] + 4096
-        out[:, 2] = l3[0::4] + 2 * 4096
-        out[:, 3] = l3[1::4] + 3 * 4096
-        out[:, 4] = l2[1::2] + 4 * 4096
-        out[:, 5] = l3[2::4] + 5 * 4096
-        out[:, 6] = l3[3::4] + 6 * 4096
-        return out.reshape(-1).astype(np.int32)
+        l1, l2, l3 = [c[0] for c in self._snac_model.encode(np.asarray(audio, np.float32).reshape(1, -1))]
+        return interleave_snac_codes(l1, l2, l3)
 
     def prepare_input_ids(self, prompts, voice=None, ref_audio=None, ref_text=None):
-        """prepareInputIds (LlamaTTS.swift:446-553): the list of per-row id arrays
-        [SOH transcript EOT EOH AUDIO_START START_OF_SPEECH ref-audio-tokens END_OF_SPEECH AUDIO_END]? [SOH] text [EOT][EOH];
-        rows are left-padded by the engine, so the reference's explicit pad tokens are not materialised.  Needs
-        `self.tokenizer` (any object with .encode)."""
+        """prepareInputIds (LlamaTTS.swift:446-553) as the list of per-row id arrays (`orpheus_prompt_rows`); the engine left-pads
+        the rows itself, `padded_prompt_batch(rows)` gives the reference's (ids, mask) pair.  Needs `self.tokenizer` (any object
+        with .encode)."""
         if self.tokenizer is None:
             raise AudioGenerationError(1, "Tokenizer not loaded")
-        T = OrpheusTokens
-        ref = []
-        if ref_audio is not None and ref_text is not None:                # voice cloning branch (:457-469,505-528)
-            audio_ids = self.encode_audio_to_codes(ref_audio).astype(np.int64) + T.audio_token_offset
-            ref = ([T.start_of_human] + list(self.tokenizer.encode(ref_text)) + [T.end_of_text, T.end_of_human] +
-                   [T.audio_start, T.start_of_speech] + list(audio_ids) + [T.end_of_speech, T.audio_end])
-        rows = []
-        for p in prompts:
-            if voice is not None:
-                p = f"{voice}: {p}"
-            ids = list(self.tokenizer.encode(p))
-            rows.append(np.asarray(ref + [T.start_of_human] + ids + [T.end_of_text, T.end_of_human], np.int32))
-        return rows
+        ref_codes = None
+        if ref_audio is not None and ref_text is not None:                # voice cloning branch (:457-469)
+            ref_codes = self.encode_audio_to_codes(ref_audio)
+        return orpheus_prompt_rows(self.tokenizer, prompts, voice, ref_codes, ref_text)
 
     def generate(self, text: str, voice=None, ref_audio=None, ref_text=None, language=None,
                  generation_parameters: GenerateParameters | None = None, snac_noise=None) -> np.ndarray:

@@ -13,8 +13,8 @@ from mlx_audio_swift_amd import _lib
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _header_symbols():
-    txt = open(os.path.join(ROOT, "include", "mi_speech.h")).read()
+def _header_symbols(name="mi_speech.h"):
+    txt = open(os.path.join(ROOT, "include", name)).read()
     txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
     return sorted(set(re.findall(r"\b(mis_[a-z0-9_]+)\s*\(", txt)))
 
@@ -28,6 +28,12 @@ def test_library_is_built_and_exports_every_declared_symbol():
         assert hasattr(l, name), f"{name} declared in mi_speech.h but not exported"
     # the Python binding table covers exactly the header
     assert sorted(_lib.SYMBOLS) == declared
+    # test scaffolding lives in its own header and its own table: nothing named mis_debug_* is part of the product surface
+    assert not [n for n in declared if n.startswith("mis_debug_")]
+    debug = _header_symbols("mi_speech_debug.h")
+    assert debug and all(n.startswith("mis_debug_") for n in debug) and sorted(_lib.DEBUG_SYMBOLS) == debug
+    for name in debug:
+        assert hasattr(l, name), f"{name} declared in mi_speech_debug.h but not exported"
 
 
 def test_abi_version_and_struct_layouts():

@@ -195,11 +195,12 @@ def test_batched_prefill_matches_oracle_and_the_position_by_position_path(ocfg, 
            rms_vs_sequential_worst=worst[2], rms_vs_sequential_mean=float(np.mean(d_all)), rms_pairs_vs_per_position_worst=float(np.max(l_all)), tol_max=TOL_MAX, tol_rms_mean=0.008, tol_rms_worst=0.016)
 
 
-def test_second_attention_schedule_matches_the_first_and_the_oracle(monkeypatch):
-    """k_attn_decode2 (wave-local prologue, counted waits, one tile in flight per wave while the previous one is multiplied) against
-    k_attn_decode (MIS_ATTN_V2=0, read per launch) and the oracle: the same rounding points, so the logits agree to within the bf16
-    noise of a different instruction selection (bit-identical in practice: recorded), at contexts that give the waves 0 / 1 / 2 / 3
-    tiles each (<= 256, 257..512, > 512 keys) and with the new key landing in every wave's last tile."""
+def test_second_attention_schedule_matches_the_oracle():
+    """k_attn_decode2 (wave-local prologue, counted waits, one tile in flight per wave while the previous one is multiplied) - the decode
+    step's attention at head_dim 128 - against the oracle at contexts that give the waves 0 / 1 / 2 / 3 tiles each (<= 256, 257..512,
+    > 512 keys) and with the new key landing in every wave's last tile.  (Rounds 3-4 also held it to the first schedule through an
+    environment switch: bit-identical then, profiles/r04_parity_observed.json; the first schedule still serves the batched prefill, whose
+    tests compare the two on the same keys.)"""
     from gpu_util import logits_errors, record
     cfg = ollama.LlamaConfig(**{**ollama.TINY.__dict__, "num_hidden_layers": 2})
     W, oracle, dev = lm_pair(cfg)
@@ -207,31 +208,25 @@ def test_second_attention_schedule_matches_the_first_and_the_oracle(monkeypatch)
     lens = [620, 300, 41]
     rows = [rng.integers(0, cfg.vocab_size, n).astype(np.int32) for n in lens]
     keep = sorted({0, 1, 30, 31, 32, 33, 63, 64, 255, 256, 257, 287, 288, 299, 511, 512, 513, 543, 544, 600, 619})
-    out = {}
-    for v2 in ("0", "1"):
-        monkeypatch.setenv("MIS_ATTN_V2", v2)
-        dev.lm_reset(len(rows), 640)
-        got = {}
-        for t in range(max(lens)):
-            ids = np.asarray([r[t] if t < len(r) else 0 for r in rows], np.int32)
-            act = np.asarray([1 if t < len(r) else 0 for r in rows], np.uint8)
-            if t in keep:
-                lg = dev.lm_forward(ids, act)
-                for b in range(len(rows)):
-                    if act[b]:
-                        got[(b, t)] = lg[b].copy()
-            else:
-                dev.lm_forward(ids, act, want_logits=False)
-        out[v2] = got
+    dev.lm_reset(len(rows), 640)
+    got = {}
+    for t in range(max(lens)):
+        ids = np.asarray([r[t] if t < len(r) else 0 for r in rows], np.int32)
+        act = np.asarray([1 if t < len(r) else 0 for r in rows], np.uint8)
+        if t in keep:
+            lg = dev.lm_forward(ids, act)
+            for b in range(len(rows)):
+                if act[b]:
+                    got[(b, t)] = lg[b].copy()
+        else:
+            dev.lm_forward(ids, act, want_logits=False)
     oracle.reset(len(rows))
     checks = [[t for t in keep if t < n] for n in lens]
     ref = oracle.forward(rows, logit_positions=checks)
-    same = all(np.array_equal(out["0"][k], out["1"][k]) for k in out["0"])
-    worst = 0.0
+    worst = [0.0, 0.0]
     for b in range(len(rows)):
-        d1 = np.stack([out["1"][(b, t)] for t in checks[b]]); d0 = np.stack([out["0"][(b, t)] for t in checks[b]])
+        d1 = np.stack([got[(b, t)] for t in checks[b]])
         e_max, e_rms, _, agree = logits_errors(d1, ref[b].numpy())
         assert e_max <= TOL_MAX and e_rms <= TOL_RMS and agree, (b, e_max, e_rms)
-        worst = max(worst, float(np.abs(d1 - d0).max() / np.abs(d0).max()))
-    record("attention_second_schedule", bit_identical_to_first=bool(same), max_rel_vs_first=worst)
-    assert worst <= 0.01
+        worst = [max(worst[0], e_max), max(worst[1], e_rms)]
+    record("attention_second_schedule", logits_max_rel=worst[0], logits_rms_rel=worst[1], tol_max=TOL_MAX, tol_rms=TOL_RMS)

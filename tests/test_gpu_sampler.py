@@ -130,37 +130,3 @@ def test_one_launch_sampler_timeout_falls_back_to_the_multi_launch_path(monkeypa
     assert np.array_equal(got, ref)
     monkeypatch.delenv("MIS_SAMPLER_SPIN")
     assert np.array_equal(sample_logits(logits, window, wl, p, 4), ref)
-
-
-def test_one_launch_sampler_with_compute_units_held_by_another_stream(monkeypatch):
-    """The real condition behind the failure path: a second stream holds all but six of the device's compute units (one 1024-thread spinner
-    with 96 KB of LDS per CU; a sampler block of 1024 threads x 128 registers does not fit beside one) while the sampler is launched.  Not
-    even one row's eight blocks can be resident together (with 96 CUs free nothing fails: the blocks of a row are dispatched side by side and
-    whole rows take turns), the resident ones run out of polls waiting for partners that have no CU (MIS_SAMPLER_SPIN=4000: a few
-    milliseconds instead of the default's seconds, so that the test is quick), the rows report the time-out, and the stand-alone entry
-    point falls back to the multi-launch path - whose kernels simply queue for the free CUs.  The tokens are the oracle's, the failure
-    counter moved, and a call on the idle device afterwards takes the one-launch path again without failing."""
-    lib = mas._lib.lib()
-    rng = np.random.default_rng(43)
-    V, B, ctx = 156940, 32, 20
-    logits = bf16_round((rng.standard_normal((B, V)) * 2.0).astype(np.float32))
-    window = rng.integers(0, V, (B, ctx)).astype(np.int32)
-    wl = np.full(B, 20, np.int32)
-    p = mas.GenerateParameters(temperature=0.6, top_p=0.8, repetition_penalty=1.3, seed=77, row_offset=1)
-    ref = _oracle_tokens(logits, window, wl, p, 2)
-    monkeypatch.setenv("MIS_SAMPLER_WIDE", "0")
-    assert np.array_equal(sample_logits(logits, window, wl, p, 2), ref)             # idle device: one launch, no failure
-    before = lib.mis_debug_sampler_failures()
-    monkeypatch.setenv("MIS_SAMPLER_SPIN", "4000")
-    n_cu = lib.mis_debug_device_cus(0)
-    assert n_cu >= 16
-    assert lib.mis_debug_occupy_cus(0, n_cu - 6, 1024, 1.5) == 0
-    try:
-        got = sample_logits(logits, window, wl, p, 2)
-    finally:
-        assert lib.mis_debug_occupy_wait() == 0
-    assert np.array_equal(got, ref)
-    assert lib.mis_debug_sampler_failures() == before + 1
-    monkeypatch.delenv("MIS_SAMPLER_SPIN")
-    assert np.array_equal(sample_logits(logits, window, wl, p, 2), ref)
-    assert lib.mis_debug_sampler_failures() == before + 1

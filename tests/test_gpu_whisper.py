@@ -329,3 +329,34 @@ def test_cross_attention_with_two_pairs_of_key_tiles_in_flight_is_bit_identical_
     monkeypatch.delenv("MIS_ATTN_XS")
     assert np.isfinite(got["1"]).all() and np.abs(got["1"]).max() > 0
     assert np.array_equal(got["0"], got["1"])
+
+
+def test_sampler_timeout_inside_transcribe_recovers(monkeypatch):
+    """A vocabulary wider than 4 096 ids below the timestamp range takes the one-launch full-vocabulary sampler (k_samp_cluster: 8 blocks
+    per window that wait for each other).  MIS_SAMPLER_SPIN=0 makes every one of its row barriers time out at once: the loop sees the
+    flag at its first poll - before any id of that interval is announced -, resets the decoder and runs prompt + loop again on the
+    multi-launch sampler; ids, the stream's token events and the per-window counts equal the undisturbed run's
+    (WhisperModel.swift:186-282 has no such failure mode, so the engine must not surface one)."""
+    lib = mas._lib.lib()
+    cfg = ow.WhisperConfig(vocab_size=6000, num_mel_bins=80, d_model=128, encoder_layers=1, encoder_attention_heads=2, encoder_ffn_dim=256,
+                           decoder_layers=2, decoder_attention_heads=2, decoder_ffn_dim=256)
+    dev = mas.WhisperModel.synthetic(_host_cfg(cfg), seed=99)
+    rng = np.random.default_rng(8)
+    wins = [(0.1 * rng.standard_normal(16000 * n)).astype(np.float32) for n in (3, 1, 2)]
+    prompt = [5990, 5991, 5992, 5993]
+    for temp in (0.0, 0.7):
+        gp = mas.STTGenerateParameters(max_tokens=20, temperature=temp, seed=5, eot_id=5999, timestamp_begin=5900)
+        monkeypatch.delenv("MIS_SAMPLER_SPIN", raising=False)
+        want = dev.transcribe_windows(wins, prompt, gp)
+        before = lib.mis_debug_sampler_failures()
+        monkeypatch.setenv("MIS_SAMPLER_SPIN", "0")
+        assert dev.transcribe_windows(wins, prompt, gp) == want, temp
+        assert lib.mis_debug_sampler_failures() == before + 1
+        seen = [[] for _ in wins]
+        for ev in dev.transcribe_windows_stream(wins, prompt, gp):
+            if isinstance(ev, mas.TokenEvent):
+                seen[ev.row].append(ev.token)
+        assert seen == [[t for t in w if t != 5999] for w in want], temp
+        monkeypatch.setenv("MIS_SAMPLER_WIDE", "1")                    # the multi-launch path from the start: nothing to recover from
+        assert dev.transcribe_windows(wins, prompt, gp) == want and lib.mis_debug_sampler_failures() == before + 2
+        monkeypatch.delenv("MIS_SAMPLER_WIDE")

@@ -1,0 +1,93 @@
+"""-m gpu, collected LAST (the file name sorts behind every parity file): tests that need test scaffolding from
+include/mi_speech_debug.h - a spinner kernel that takes compute units away from the library's streams - to provoke the one condition a
+healthy run never meets: the one-launch sampler's 8 x batch blocks not being co-resident.  Nothing here is a parity test of a SURVEY
+row; a problem in this file cannot stop `pytest -x` before the parity files have run (round 4's lesson).
+
+The spinner announces every block that has started (host-visible slots) and `mis_debug_occupy_cus` returns only when all of them are
+resident - or reports that they did not become resident, in which case the condition cannot be produced on this device and the test
+SKIPS."""
+import numpy as np
+import pytest
+
+import mlx_audio_swift_amd as mas
+from oracle.synth import bf16_round
+from test_gpu_sampler import _oracle_tokens, sample_logits
+
+pytestmark = pytest.mark.gpu
+
+SNAC_SMALL = dict(encoder_dim=4, encoder_rates=[2, 4, 8, 8], decoder_dim=64, decoder_rates=[8, 8, 4, 2], codebook_size=4096, codebook_dim=8,
+                  vq_strides=[4, 2, 1])
+
+
+class held_compute_units:
+    """all but `free` compute units of device 0 held by a second stream for at most `seconds`; released on exit"""
+
+    def __init__(self, free=6, seconds=4.0):
+        self.free, self.seconds = free, seconds
+
+    def __enter__(self):
+        lib = mas._lib.lib()
+        n_cu = lib.mis_debug_device_cus(0)
+        if n_cu < 16:
+            pytest.skip(f"device with {n_cu} compute units")
+        if lib.mis_debug_occupy_cus(0, n_cu - self.free, 1024, self.seconds) != 0:
+            pytest.skip("spinner blocks did not become resident: " + mas._lib.last_error())
+        return self
+
+    def __exit__(self, *exc):
+        assert mas._lib.lib().mis_debug_occupy_wait() == 0
+        return False
+
+
+def test_one_launch_sampler_with_compute_units_held_by_another_stream(monkeypatch):
+    """The stand-alone entry point (mis_sample_logits) under the real condition behind the failure path: a second stream holds all but six
+    compute units (one 1024-thread spinner with 96 KB of LDS per CU; a sampler block of 1024 threads does not fit beside one).  Not even one
+    row's eight blocks can be resident together, the resident ones run out of polls (MIS_SAMPLER_SPIN=4000: milliseconds instead of the
+    default's seconds), the rows report the time-out and the call falls back to the multi-launch kernels, which simply queue for the free
+    CUs.  Tokens = the oracle's, the failure was counted, and a call on the idle device afterwards takes the one-launch path again."""
+    lib = mas._lib.lib()
+    rng = np.random.default_rng(43)
+    V, B, ctx = 156940, 32, 20
+    logits = bf16_round((rng.standard_normal((B, V)) * 2.0).astype(np.float32))
+    window = rng.integers(0, V, (B, ctx)).astype(np.int32)
+    wl = np.full(B, 20, np.int32)
+    p = mas.GenerateParameters(temperature=0.6, top_p=0.8, repetition_penalty=1.3, seed=77, row_offset=1)
+    ref = _oracle_tokens(logits, window, wl, p, 2)
+    monkeypatch.setenv("MIS_SAMPLER_WIDE", "0")
+    assert np.array_equal(sample_logits(logits, window, wl, p, 2), ref)             # idle device: one launch, no failure
+    before = lib.mis_debug_sampler_failures()
+    monkeypatch.setenv("MIS_SAMPLER_SPIN", "4000")
+    with held_compute_units():
+        got = sample_logits(logits, window, wl, p, 2)
+    assert np.array_equal(got, ref)
+    assert lib.mis_debug_sampler_failures() == before + 1
+    monkeypatch.delenv("MIS_SAMPLER_SPIN")
+    assert np.array_equal(sample_logits(logits, window, wl, p, 2), ref)
+    assert lib.mis_debug_sampler_failures() == before + 1
+
+
+def test_generate_with_compute_units_held_by_another_stream_recovers(monkeypatch):
+    """mis_tts_generate at the bench's batch (32 rows -> 256 sampler blocks that must be co-resident) while a second stream holds all but
+    six compute units: the first decode step's sampler times out, the loop sees it at its first poll, and the request runs again on the
+    multi-launch sampler.  Status OK, tokens and waveform equal the idle-device run's (the reference's loop has no such failure,
+    LlamaTTS.swift:714-744)."""
+    from mlx_audio_swift_amd.synthetic import snac_synthetic_weights
+    lib = mas._lib.lib()
+    snac_cfg = mas.SNACConfig(**SNAC_SMALL)
+    codec = mas.SNAC.from_weights(snac_cfg, snac_synthetic_weights(snac_cfg, seed=1234))
+    cfg = mas.LlamaTTSConfiguration(hidden_size=256, num_hidden_layers=2, intermediate_size=512, num_attention_heads=2, num_key_value_heads=1,
+                                    head_dim=128, vocab_size=156940, rope_theta=500000.0)
+    lm = mas.LlamaTTSModel.synthetic(cfg, codec=codec, seed=77)
+    rng = np.random.default_rng(3)
+    prompts = [np.asarray([128259] + list(rng.integers(0, 128000, 5 + r % 7)) + [128009, 128260, 128257], np.int32) for r in range(32)]
+    gp = mas.GenerateParameters(max_tokens=35, temperature=0.6, top_p=0.8, repetition_penalty=1.3, seed=11, frame_constrained=2)
+    monkeypatch.setenv("MIS_SAMPLER_WIDE", "0")
+    pcm_want, want = lm.generate_batch(prompts, gp, return_tokens=True)
+    before = lib.mis_debug_sampler_failures()
+    monkeypatch.setenv("MIS_SAMPLER_SPIN", "4000")
+    with held_compute_units(seconds=8.0):
+        pcm_got, got = lm.generate_batch(prompts, gp, return_tokens=True)
+    assert lib.mis_debug_sampler_failures() == before + 1
+    for r in range(32):
+        assert np.array_equal(want[r], got[r]), r
+        assert np.array_equal(pcm_want[r], pcm_got[r]), r

@@ -3,7 +3,7 @@ away silently - hipcc cross-compiles here.
 
 * `k_attn_decode2` loads its K/V tiles with asm statements and counted waits that hipcc does not track: the static audit of
   tools/isa_audit_attn2.py (no register of an in-flight load touched, no spill, no control flow with loads outstanding) must stay clean
-  for every instantiation, the `MIS_ATTN_PAIR` variants included.
+  for every instantiation (one to four split-K slabs).
 * The weight-streaming GEMMs run one or two waves per SIMD by design (R = 4: 160-230 registers): none of them, nor the glue and the
   256 x 256 Whisper GEMM, may spill (scratch traffic sits in the same vmcnt queue as the weight stream).
 * The quantised R = 4 instantiations stay under 256 registers without scratch.
@@ -61,7 +61,7 @@ def _resource_usage(src):
 def test_attention_asm_schedule_audit_is_clean():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "isa_audit_attn2.py")], capture_output=True, text=True)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-1000:]
-    assert r.stdout.count("0 violations") >= 8 and "violations: 0" in r.stdout        # NS = 1..4 x {one tile, two tiles up front}
+    assert r.stdout.count("0 violations") >= 4 and "violations: 0" in r.stdout        # NS = 1..4
 
 
 def test_step_chain_kernels_do_not_spill():

@@ -9,6 +9,6 @@ P=$PWD/mlx-audio-swift_amd
 for lib in libmi_speech.so libmi_speech_qgemm_loads_only.so libmi_speech_qgemm_math_only.so; do
   MIS_LIB_PATH=$P/$lib MIS_PROBE_BITS=8,4 timeout 60 python tools/qgemm_probe.py orpheus 32 > /dev/null 2>&1
 done
-MIS_LIB_PATH=$P/libmi_speech_qgemm_loads_only.so MIS_QGEMM_U=1 MIS_PROBE_BITS=8 timeout 40 python tools/qgemm_probe.py orpheus 32 > /dev/null 2>&1
-MIS_LIB_PATH=$P/libmi_speech.so MIS_QGEMM_U=1 MIS_PROBE_BITS=8 timeout 40 python tools/qgemm_probe.py orpheus 32 > /dev/null 2>&1
+MIS_LIB_PATH=$P/libmi_speech_qgemm_loads_only.so MIS_PROBE_BITS=8 timeout 40 python tools/qgemm_probe.py orpheus 32 > /dev/null 2>&1
+MIS_LIB_PATH=$P/libmi_speech.so MIS_PROBE_BITS=8 timeout 40 python tools/qgemm_probe.py orpheus 32 > /dev/null 2>&1
 cat gpurun_out/qgemm_probe.jsonl

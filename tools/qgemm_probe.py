@@ -1,6 +1,6 @@
 """Quantised weight-streaming GEMM (csrc/lm_qgemm.hip) at bench widths: achieved GB/s of algorithmic bytes (codes + scale/bias pairs)
 and time per launch, next to the dense bf16 kernel.  Usage: python tools/qgemm_probe.py [orpheus|qwen3] [batch]
-MIS_QGEMM_U=1|2 selects the register-buffer depth, MIS_QGEMM_V2=1 (+ MIS_QGEMM_V2_PREF8 / _MAXU) the one-shot arrangement where it
+MIS_QGEMM_V2=0 sends the one-shot launches through the streaming kernel (the other switches of rounds 2-3 are gone), where it
 applies (read once per process); MIS_PROBE_BITS="16,8,4" picks the weight formats.  Appends to gpurun_out/qgemm_probe.jsonl."""
 import json
 import os
