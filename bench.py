@@ -144,11 +144,27 @@ def secondary_benches(device, orpheus=None):
     # encoder FLOPs per window: 32 layers x (4 d^2 + 2 d ffn) x 2 x 1500 positions + attention 2 x 2 x 1500^2 x d per layer + the two convolutions
     d_, f_, T_ = 1280, 5120, 1500
     enc_flops = 8 * (32 * ((4 * d_ * d_ + 2 * d_ * f_) * 2 * T_ + 4 * T_ * T_ * d_) + 2 * 3 * 128 * d_ * 3000 + 2 * 3 * d_ * d_ * T_)
+    # decoder bytes per step (the phase that is 84 % of the wall): 32 layers x (self q|k|v + o, cross q + o, fc1 + fc2 = 6 d^2 + 2 d ffn) bf16 +
+    # the tied output projection once + the cross-attention K/V of the 8 windows (1500 keys x d x 2 x 2 B per window and layer) + the
+    # self-attention K/V read at the mean context; 4 prompt + 96 loop steps run the layers, the output projection runs in the 96 loop steps
+    n_steps = 4 + int(len(ids[0]))
+    dec_w = 2.0 * 32 * (6 * d_ * d_ + 2 * d_ * f_)
+    dec_head = 2.0 * 51866 * d_
+    dec_cross = 8 * 32 * T_ * d_ * 2 * 2.0
+    dec_self = 8 * 32 * (n_steps / 2.0) * d_ * 2 * 2.0
+    dec_bytes = n_steps * (dec_w + dec_cross + dec_self) + int(len(ids[0])) * dec_head
+    t_dec = max(t_all - t_enc, 1e-9)                       # (mel + scatter of the cross K/V included: an upper bound of the loop's time)
     out["whisper_large_v3_8x30s"] = {
         "config": "BASELINE configs[3], one GPU's share: Whisper-large-v3 bf16, 8 x 30 s windows, mel + encoder + 4-token prompt + 96 decode steps",
-        "audio_s_per_s": 240.0 / t_all, "ms": t_all * 1e3, "encode_ms": t_enc * 1e3, "tokens_per_window": int(len(ids[0])),
-        "roofline": {"bound": "mfma", "phase": "encoder (32 layers, 8 x 1500 positions)", "achieved": enc_flops / t_enc / 1e12, "peak": 2500.0,
-                     "unit": "TFLOP/s", "frac": enc_flops / t_enc / 1e12 / 2500.0}}
+        "audio_s_per_s": 240.0 / t_all, "ms": t_all * 1e3, "encode_ms": t_enc * 1e3, "decode_ms": t_dec * 1e3,
+        "decode_ms_per_step": t_dec * 1e3 / n_steps, "tokens_per_window": int(len(ids[0])),
+        # BOTH phases against their own bound: the decoder loop is most of the wall (HBM: weights + cross K/V per step), the encoder is
+        # the MFMA-bound part
+        "roofline": {"bound": "hbm", "phase": "decoder loop (4 prompt + 96 greedy steps at 8 windows: weights + cross-attention K/V streamed per step)",
+                     "achieved": dec_bytes / t_dec / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": dec_bytes / t_dec / 1e9 / HBM_PEAK_GBS,
+                     "share_of_wall": t_dec / t_all, "bytes_per_step": (dec_w + dec_cross + dec_self + dec_head)},
+        "roofline_encoder": {"bound": "mfma", "phase": "encoder (32 layers, 8 x 1500 positions)", "achieved": enc_flops / t_enc / 1e12, "peak": 2500.0,
+                             "unit": "TFLOP/s", "frac": enc_flops / t_enc / 1e12 / 2500.0, "share_of_wall": t_enc / t_all}}
     wm.close()
     del wm
     # ---- configs[1]: Soprano-80M, batch 1, 24-token prompt, 64 new tokens ([STOP] out of reach) -> Vocos / ISTFT decoder

@@ -18,8 +18,8 @@ mis_status mis_debug_launch_floor(int device, int n_kernels, int mode, int reps,
  * 32-wide k-tiles and `waves_per_item` waves per work item ("Split-K factor from a cost model"); no GPU needed
  * (falls back to 256 CUs when no device is visible). */
 int32_t mis_debug_choose_split(int32_t items, int32_t k_tiles, int32_t waves_per_item, int32_t s_max);
-/* tests: occupy compute units from ANOTHER stream - `blocks` workgroups of `threads` threads, each reserving 96 KB of LDS (at most one
- * per CU), that spin (s_sleep) for `seconds` - so that launches on the library's streams find fewer CUs than the device has (the
+/* tests: occupy compute units from ANOTHER stream - `blocks` workgroups of `threads` threads, each reserving 128 KB of the CU's 160 KB of LDS (one per CU, and
+ * nothing that needs more than 32 KB of LDS fits beside it), that spin (s_sleep) for `seconds` - so that launches on the library's streams find fewer CUs than the device has (the
  * condition under which the one-launch sampler's row barriers time out and the engines recover on the multi-launch path).  Every
  * spinner announces itself on entry; the call returns MIS_OK only once all `blocks` of them are RESIDENT (handshake through a
  * host-visible counter), or MIS_ERR_DEVICE if that does not happen within two seconds - the spinner is then released and the caller

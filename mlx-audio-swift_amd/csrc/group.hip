@@ -527,7 +527,8 @@ extern "C" mis_status mis_qwen3tts_group_generate(mis_qwen3tts* const* replicas,
 // returns only once all of them are resident - without that handshake the sampler launched behind the spinner can simply win the race
 // for the CUs (first launch of this kernel on a fresh box; round 4's red suite).
 __global__ void k_debug_spin(unsigned long long ticks_100mhz, volatile unsigned* resident_slots, const unsigned* release) {
-    extern __shared__ unsigned char spin_lds[];          // (96 KB requested at launch: at most ONE spinner per CU, so `blocks` CUs are held)
+    extern __shared__ unsigned char spin_lds[];          // (128 KB of the CU's 160 KB requested at launch: ONE spinner per CU, and no block that needs
+                                                         //  more than 32 KB of LDS - the one-launch sampler takes ~50 KB - fits beside it)
     if (ticks_100mhz == ~0ull) spin_lds[threadIdx.x] = 0;
     if (threadIdx.x == 0) __hip_atomic_store((unsigned*)&resident_slots[blockIdx.x], 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     const unsigned long long t0 = wall_clock64();
@@ -555,9 +556,9 @@ extern "C" mis_status mis_debug_occupy_cus(int device, int blocks, int threads, 
     if (!g_occupy_host) HIP_CHECK(hipHostMalloc((void**)&g_occupy_host, (size_t)(OCCUPY_MAX_BLOCKS + 1) * sizeof(unsigned), hipHostMallocCoherent));
     memset(g_occupy_host, 0, (size_t)(OCCUPY_MAX_BLOCKS + 1) * sizeof(unsigned));
     HIP_CHECK(hipStreamCreateWithFlags(&g_occupy_stream, hipStreamNonBlocking));
-    static const bool lds_ok = hipFuncSetAttribute((const void*)k_debug_spin, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024) == hipSuccess;
-    MIS_REQUIRE(lds_ok, MIS_ERR_DEVICE, "cannot reserve 96 KB of LDS for the spinner");
-    hipLaunchKernelGGL(k_debug_spin, dim3(blocks), dim3(threads), 96 * 1024, g_occupy_stream, (unsigned long long)(seconds * 1e8),
+    static const bool lds_ok = hipFuncSetAttribute((const void*)k_debug_spin, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024) == hipSuccess;
+    MIS_REQUIRE(lds_ok, MIS_ERR_DEVICE, "cannot reserve 128 KB of LDS for the spinner");
+    hipLaunchKernelGGL(k_debug_spin, dim3(blocks), dim3(threads), 128 * 1024, g_occupy_stream, (unsigned long long)(seconds * 1e8),
                        (volatile unsigned*)(g_occupy_host + 1), (const unsigned*)g_occupy_host);
     HIP_CHECK(hipGetLastError());
     // handshake: all `blocks` spinners resident (each wrote its slot) before anything else is launched by the caller
