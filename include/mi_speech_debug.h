@@ -31,6 +31,14 @@ int32_t mis_debug_device_cus(int device);            /* compute units of a devic
 /* diagnostics / tests: launches of the one-launch sampler that reported a timed-out row barrier in this process so far */
 int32_t mis_debug_sampler_failures(void);
 
+/* laboratory (round 5; csrc/token_engine.hip): a whole batch-1 request - `n_prompt` prompt positions, then `n_new` greedy steps - in ONE
+ * persistent launch on the compute units of `xcds` (1 or 2) XCDs, streaming the handle's own packed weights.  Compiled for Soprano-80M's
+ * LM widths (other shapes: MIS_ERR_INVALID_INPUT).  next_tokens[t] = arg-max id after position t (t < n_prompt + n_new; the generated
+ * ids are next_tokens[n_prompt - 1 ...]); logits_out ([n_prompt + n_new][vocab] float, bf16 values) and hidden_out ([...][hidden],
+ * the final-norm output Soprano's decoder consumes) may be NULL; ms_out = device time of the launch.  Host pointers. */
+mis_status mis_debug_token_engine(mis_tts* lm, const int32_t* prompt, int n_prompt, int n_new, int xcds, int32_t* next_tokens,
+                                  float* logits_out, float* hidden_out, double* ms_out);
+
 #ifdef __cplusplus
 }
 #endif

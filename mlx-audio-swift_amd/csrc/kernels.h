@@ -49,6 +49,16 @@ void tts_internal_prefill_rows(mis_tts* c, const bf16_t* rows /*[Lmax][Mpad][d] 
 void tts_internal_enqueue_layers(mis_tts* c, const bf16_t* table, int table_rows, const int32_t* ids);
 void tts_internal_enqueue_head(mis_tts* c, const bf16_t* head_packed);      // logits of the view; nullptr = own lm_head
 TtsView tts_internal_view(mis_tts* c);
+// the packed weights of a finalized handle, for engines that stream them in their own kernels (token_engine.hip)
+struct TtsWeightsView {
+    const bf16_t *emb, *wqkv, *wo, *wgu, *wdown, *head, *norms, *qknorm;
+    int d, L, ff, H, Hkv, D, V, Vpad, Nqkv, device, finalized, qk_norm, rope_plain, quantised;
+    float eps;
+    hipStream_t stream;
+};
+TtsWeightsView tts_internal_weights(mis_tts* c);
+// RoPE cos / sin tables [positions][D/2] for at least `max_context` positions (re-initialises the handle's per-batch state for one row)
+void tts_internal_rope_tables(mis_tts* c, int max_context, const float** cos_out, const float** sin_out);
 // a handle whose device also runs ANOTHER replica's streams (logical shards of a group on one GPU) must not launch kernels whose blocks
 // wait for each other to be co-resident (the one-launch sampler): set by the group entry points in group.hip
 void tts_internal_set_shared_device(mis_tts* c, bool shared);

@@ -1859,6 +1859,20 @@ void tts_internal_use_stream(mis_tts* c, hipStream_t s) {
 }
 void tts_internal_enqueue_layers(mis_tts* c, const bf16_t* table, int table_rows, const int32_t* ids) { enqueue_layers(c, table, table_rows, ids); }
 void tts_internal_enqueue_head(mis_tts* c, const bf16_t* head_packed) { enqueue_lm_head(c, head_packed); }
+TtsWeightsView tts_internal_weights(mis_tts* c) {
+    TtsWeightsView v{};
+    v.emb = c->emb.p; v.wqkv = c->wqkv.p; v.wo = c->wo.p; v.wgu = c->wgu.p; v.wdown = c->wdown.p;
+    v.head = c->lm_head.p; v.norms = c->norms.p; v.qknorm = c->qknorm.p;
+    v.d = c->d; v.L = c->L; v.ff = c->ff; v.H = c->H; v.Hkv = c->Hkv; v.D = c->D; v.V = c->V; v.Vpad = c->Vpad; v.Nqkv = c->Nqkv;
+    v.device = c->device; v.finalized = c->finalized ? 1 : 0; v.qk_norm = c->cfg.qk_norm ? 1 : 0; v.rope_plain = c->cfg.rope_plain ? 1 : 0;
+    v.quantised = (c->q_qkv.on || c->q_o.on || c->q_gu.on || c->q_down.on || c->q_head.on) ? 1 : 0;
+    v.eps = c->cfg.rms_norm_eps; v.stream = c->stream;
+    return v;
+}
+void tts_internal_rope_tables(mis_tts* c, int max_context, const float** cos_out, const float** sin_out) {
+    lm_reset(c, 1, max_context);
+    *cos_out = c->rope_cos.p; *sin_out = c->rope_sin.p;
+}
 TtsView tts_internal_view(mis_tts* c) {
     TtsView v{};
     v.x = c->x.p; v.h = c->h.p; v.logits = c->logits.p; v.emb = c->emb.p; v.ids = c->ids.p; v.pos_next = c->pos_next.p;

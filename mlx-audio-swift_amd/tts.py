@@ -344,6 +344,21 @@ class LlamaTTSModel:
                                                hid.ctypes.data if want_hidden else None))
         return (out, hid) if want_hidden else out
 
+    def debug_token_engine(self, prompt, n_new: int, xcds: int = 1, want_logits: bool = False, want_hidden: bool = False):
+        """Laboratory (csrc/token_engine.hip, include/mi_speech_debug.h): the whole batch-1 request - prompt positions, then n_new greedy
+        steps - in ONE persistent launch on the compute units of `xcds` XCDs.  Returns a dict: next_tokens [n_prompt + n_new] (arg-max
+        after every position), ms (device time of the launch), and logits / hidden when asked for."""
+        prompt = np.ascontiguousarray(prompt, dtype=np.int32)
+        n = len(prompt) + int(n_new)
+        nxt = np.zeros(n, np.int32)
+        lg = np.zeros((n, self.configuration.vocab_size), np.float32) if want_logits else None
+        hid = np.zeros((n, self.configuration.hidden_size), np.float32) if want_hidden else None
+        ms = C.c_double(0.0)
+        check(_lib.lib().mis_debug_token_engine(self._h, prompt.ctypes.data, len(prompt), int(n_new), int(xcds), nxt.ctypes.data,
+                                                lg.ctypes.data if want_logits else None, hid.ctypes.data if want_hidden else None,
+                                                C.byref(ms)))
+        return {"next_tokens": nxt, "ms": ms.value, "logits": lg, "hidden": hid}
+
     def last_timing(self) -> dict:
         t = _lib.TimingC()
         check(_lib.lib().mis_tts_last_timing(self._h, C.byref(t)))

@@ -1,0 +1,58 @@
+"""-m gpu: the batch-1 token engine (csrc/token_engine.hip - one persistent launch per request on the compute units of one XCD; a
+laboratory behind include/mi_speech_debug.h) against the oracle and against the product's own decode step, on the same weights.
+
+Soprano-80M's LM widths (hidden 512, ffn 2304, 4 / 1 heads x 128, q/k-norm, plain RoPE; Soprano.swift:38-199) with 2 layers and a cut
+vocabulary, so that the oracle (oracle/llama.py, pinned on HF Qwen3ForCausalLM for this variant) finishes in seconds.  Tolerances are
+the LM tests' (bf16 storage at every primitive boundary on both sides, other float32 summation orders): logits max <= 0.016 x scale,
+rms <= 0.008 x rms, greedy tokens equal wherever the oracle's top-2 margin exceeds the error."""
+import numpy as np
+import pytest
+
+import mlx_audio_swift_amd as mas
+from gpu_util import lm_pair, logits_errors, record
+from oracle import llama as ollama
+
+pytestmark = pytest.mark.gpu
+
+CFG = ollama.LlamaConfig(hidden_size=512, num_hidden_layers=2, intermediate_size=2304, num_attention_heads=4, num_key_value_heads=1,
+                         head_dim=128, vocab_size=1200, rope_theta=10000.0, rope_scaling=None, tie_word_embeddings=False, qk_norm=True,
+                         rope_plain=True, rms_norm_eps=1e-6)
+
+
+@pytest.mark.parametrize("xcds", [1, 2])
+def test_engine_logits_and_greedy_tokens_match_the_oracle_and_the_launch_chain(xcds):
+    W, oracle, dev = lm_pair(CFG)
+    rng = np.random.default_rng(7)
+    prompt = rng.integers(0, CFG.vocab_size, 40).astype(np.int32)          # > 32 positions: the score loop runs two passes
+    n_new = 24
+    out = dev.debug_token_engine(prompt, n_new, xcds=xcds, want_logits=True, want_hidden=True)
+    nxt = out["next_tokens"]
+    seq = np.concatenate([prompt, nxt[len(prompt) - 1:len(prompt) - 1 + n_new]]).astype(np.int32)       # every position the engine processed
+    assert len(seq) == len(prompt) + n_new
+    # the engine fed itself its own arg-max: position t >= n_prompt saw next_tokens[t - 1]
+    oracle.reset(1)
+    ref = oracle.forward([seq])[0].numpy()
+    e_max, e_rms, n_sure, agree = logits_errors(out["logits"], ref)
+    assert e_max <= 0.016 and e_rms <= 0.008 and agree and n_sure > 0, (e_max, e_rms, n_sure)
+    assert np.array_equal(out["logits"].argmax(1), nxt)                     # (first index on ties, like np.argmax)
+    # the hidden tap (model.norm(h), what Soprano's decoder consumes) against the oracle's
+    hid_ref = oracle.last_hidden.numpy()
+    h_rms = float(np.sqrt(np.mean((out["hidden"] - hid_ref) ** 2)) / np.sqrt(np.mean(hid_ref ** 2)))
+    assert h_rms <= 0.01, h_rms
+    # the product's launch chain on the same handle, teacher-forced with the same ids: same rounding points, other summation orders
+    dev.lm_reset(1, 128)
+    chain = np.stack([dev.lm_forward(seq[t:t + 1])[0] for t in range(len(seq))])
+    c_max, c_rms, _, c_agree = logits_errors(out["logits"], chain)
+    assert c_max <= 0.016 and c_rms <= 0.008 and c_agree, (c_max, c_rms)
+    record(f"token_engine_{xcds}xcd", logits_max_rel=e_max, logits_rms_rel=e_rms, vs_launch_chain_max_rel=c_max, vs_launch_chain_rms_rel=c_rms,
+           tol_max=0.016, tol_rms=0.008, ms_per_position=out["ms"] / len(seq))
+    # deterministic: the same request again gives the same bits
+    again = dev.debug_token_engine(prompt, n_new, xcds=xcds, want_logits=True)
+    assert np.array_equal(again["logits"], out["logits"]) and np.array_equal(again["next_tokens"], nxt)
+
+
+def test_engine_rejects_other_shapes():
+    cfg = ollama.LlamaConfig(**{**ollama.TINY_QWEN3.__dict__})
+    W, oracle, dev = lm_pair(cfg)
+    with pytest.raises(mas.AudioGenerationError):
+        dev.debug_token_engine(np.asarray([1, 2, 3], np.int32), 2)
