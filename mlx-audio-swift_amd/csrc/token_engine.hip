@@ -38,7 +38,8 @@ typedef unsigned long long u64;
 struct TeShape {
     static constexpr int d = 512, ff = 2304, H = 4, Hkv = 1, D = 128, Nqkv = (H + 2 * Hkv) * D, HD = H * D;
 };
-constexpr int TE_NT = 512, TE_NW = 8;          // threads / waves per worker
+constexpr int TE_NT = 512;                     // threads per worker: TE_VW vector waves + TE_MW matrix waves
+constexpr int TE_VW = 4, TE_MW = 4;
 constexpr int TE_CTX = 512;                    // positions per request (scores in LDS)
 constexpr int TE_XG = 1024;                    // granules per exchange buffer (4096 bf16 values)
 
@@ -52,19 +53,57 @@ struct TeParams {
     int32_t* next_tokens;       // [n_total]: arg-max after position t
     float* logits_out;          // [n_total][V] or null
     float* hidden_out;          // [n_total][d] or null (final-norm output: what Soprano's decoder consumes)
-    bf16_t* kv;                 // private K/V copies [W][L][2][TE_CTX][Hkv*D]
+    bf16_t* kv;                 // the K/V copy [L][2][TE_CTX][Hkv*D] (every worker writes the same bytes, see te_vector_role)
     u64* xbuf;                  // [2][TE_XG]
     unsigned* counter;          // monotonic arrivals
     unsigned* fail;             // set when a poll ran out (workers not co-resident)
     int xcds, spin;
+    u64* dbg;                   // diagnostics (MIS_TE_STAMPS=<position>): cycle stamps of worker 0 at the phase boundaries of layer 1 of that position
+    int dbg_token;
 };
 
 __device__ __forceinline__ unsigned te_key(float f) { const unsigned u = __float_as_uint(f); return (u & 0x80000000u) ? ~u : (u | 0x80000000u); }
+// sum over the 16 lanes of a DPP row (lanes 16 r .. 16 r + 15), result in every lane of the row: two quad permutes, half-row mirror, row
+// mirror - four VALU-rate instructions.  (__shfl_xor compiles to ds_bpermute_b32, an LDS round trip of ~64 cycles each: the score loop's
+// 128 of them per thread were 5-7 us per layer.)
+__device__ __forceinline__ float te_row16_sum(float x) {
+    int xi = __builtin_bit_cast(int, x);
+    x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, xi, 0xB1, 0xF, 0xF, true));      // quad_perm [1,0,3,2]
+    xi = __builtin_bit_cast(int, x);
+    x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, xi, 0x4E, 0xF, 0xF, true));      // quad_perm [2,3,0,1]
+    xi = __builtin_bit_cast(int, x);
+    x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, xi, 0x141, 0xF, 0xF, true));     // row_half_mirror
+    xi = __builtin_bit_cast(int, x);
+    x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, xi, 0x140, 0xF, 0xF, true));     // row_mirror
+    return x;
+}
+__device__ __forceinline__ float te_wave_max_dpp(float x) {
+    auto step = [](float v, int tag) {
+        const int vi = __builtin_bit_cast(int, v);
+        int yi;
+        switch (tag) {
+            case 0: yi = __builtin_amdgcn_update_dpp(vi, vi, 0xB1, 0xF, 0xF, false); break;
+            case 1: yi = __builtin_amdgcn_update_dpp(vi, vi, 0x4E, 0xF, 0xF, false); break;
+            case 2: yi = __builtin_amdgcn_update_dpp(vi, vi, 0x141, 0xF, 0xF, false); break;
+            default: yi = __builtin_amdgcn_update_dpp(vi, vi, 0x140, 0xF, 0xF, false); break;
+        }
+        return fmaxf(v, __builtin_bit_cast(float, yi));
+    };
+    x = step(x, 0); x = step(x, 1); x = step(x, 2); x = step(x, 3);
+    const int vi = __builtin_bit_cast(int, x);
+    const float r0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(vi, 0)), r1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(vi, 16)),
+                r2 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(vi, 32)), r3 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(vi, 48));
+    return fmaxf(fmaxf(r0, r1), fmaxf(r2, r3));
+}
+// Block barrier that waits for LDS traffic only.  __syncthreads() carries a workgroup-scope fence, i.e. s_waitcnt vmcnt(0): it would make
+// the matrix waves wait for every weight tile they have just requested for the NEXT phase.  Global-memory ordering is handled where it is
+// needed (the publishers' own s_waitcnt vmcnt(0) before an edge).
+__device__ __forceinline__ void te_sync() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
-// ---- one edge: the caller has issued its granule stores into `buf` (this edge's half of xbuf); arrive, wait for all W workers
-__device__ __forceinline__ bool te_meet(const TeParams& p, unsigned& edge, int W, int* s_ok) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
+// ---- one edge, second half: every publisher has drained its stores (and passed the barrier in front of this call); thread 0 arrives on
+// the monotonic counter and polls it (bounded) until all W workers of this edge are there
+__device__ __forceinline__ bool te_edge(const TeParams& p, unsigned& edge, int W, int* s_ok) {
+    te_sync();
     if (threadIdx.x == 0) {
         __hip_atomic_fetch_add(p.counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         const unsigned target = (unsigned)W * (edge + 1u);
@@ -75,34 +114,48 @@ __device__ __forceinline__ bool te_meet(const TeParams& p, unsigned& edge, int W
         }
         *s_ok = ok;
     }
-    __syncthreads();
+    te_sync();
     edge += 1u;
     return *s_ok != 0;
 }
-__device__ __forceinline__ u64 te_pack4(float a, float b, float c, float d) {
-    return (u64)f32_to_bf16(a) | ((u64)f32_to_bf16(b) << 16) | ((u64)f32_to_bf16(c) << 32) | ((u64)f32_to_bf16(d) << 48);
-}
 
-// ---- a worker's slice of y = W x: RMAX tile rows (ids nt[r], -1 = none), every wave takes its share of the KT k-tiles; partial sums of
-// the row-0 column land in red[wave][r][16].  All loads are issued before the first MFMA (unconditional, clamped addresses).
-template <int RMAX, int KPW>
-__device__ __forceinline__ void te_gemv(const bf16_t* __restrict__ Wp, const int KT, const int (&nt)[RMAX], const bf16_t* xb, float* red,
-                                        const int wave, const int lane) {
-    const int kt0 = wave * KT / TE_NW, kt1 = (wave + 1) * KT / TE_NW;
-    const bf16x8_t* wp = reinterpret_cast<const bf16x8_t*>(Wp);
-    bf16x8_t a[RMAX][KPW], xf[KPW];
+// ---- matrix waves.  A worker's slice of y = W x is R tile rows (ids nt[r], -1 = none); each of the TE_MW matrix waves takes a quarter of
+// the KT k-tiles of every row and holds them in registers: requested one phase AHEAD (right after the previous phase's MFMAs), so that the
+// stream runs under the vector waves' epilogue, the edge and the gather.  Loads are unconditional on clamped addresses.
+template <int R, int KPW>
+struct TeTiles { bf16x8_t a[R][KPW]; bf16x8_t wn[KPW]; };
+// Tiles FROM .. TO - 1 of the flattened list f = u R + r (all of them by default): a phase's tiles are requested in PIECES, one piece behind
+// each barrier the matrix waves pass on their way to the phase (te_matrix_role) - a wave that requests 40 tiles at once stays in the issue
+// loop for as long as the CU's memory queue is full (~4 us at one XCD's 40 GB/s per CU), and the vector waves wait for it at the next barrier.
+template <int R, int KPW, bool NORM, int FROM = 0, int TO = R * KPW>
+__device__ __forceinline__ void te_load(TeTiles<R, KPW>& T, const bf16_t* Wp, const int KT, const int (&nt)[R], const bf16_t* wnorm, const int mw,
+                                        const int lane) {
+    const int kt0 = mw * KT / TE_MW, kt1 = (mw + 1) * KT / TE_MW;
     const int klast = kt1 > kt0 ? kt1 - 1 : kt0;
+    const unsigned voff = (unsigned)lane * 16u;                      // the only per-lane part of a tile address (scalar base + 32-bit offset)
 #pragma unroll
-    for (int r = 0; r < RMAX; ++r) {
-        const int tile = nt[r] < 0 ? 0 : nt[r];
+    for (int u = 0; u < KPW; ++u) {
+        int kk = kt0 + u;
+        kk = kk > klast ? klast : kk;
+        kk = kk >= KT ? KT - 1 : kk;
 #pragma unroll
-        for (int u = 0; u < KPW; ++u) {
-            int kk = kt0 + u;
-            kk = kk > klast ? klast : kk;
-            kk = kk >= KT ? KT - 1 : kk;
-            a[r][u] = __builtin_nontemporal_load(wp + ((size_t)tile * KT + kk) * 64 + lane);
+        for (int r = 0; r < R; ++r) {
+            if (u * R + r < FROM || u * R + r >= TO) continue;
+            const int tile = nt[r] < 0 ? 0 : nt[r];
+            const char* base = reinterpret_cast<const char*>(Wp) + ((size_t)tile * KT + kk) * 1024;        // wave-uniform
+            T.a[r][u] = __builtin_nontemporal_load(reinterpret_cast<const bf16x8_t*>(base + voff));
+        }
+        if (NORM && u * R >= FROM && u * R < TO) {                                                         // the norm weights of this wave's k range
+            const char* nb = reinterpret_cast<const char*>(wnorm) + (size_t)kk * 64;
+            T.wn[u] = *reinterpret_cast<const bf16x8_t*>(nb + (unsigned)(lane >> 4) * 16u);
         }
     }
+}
+// B fragments (row 0 of the 16-row operand): lanes with (lane & 15) == 0 hold x[32 kk + 8 (lane >> 4) ..+8], everything else is zero
+template <int KPW>
+__device__ __forceinline__ void te_xfrag_bf16(bf16x8_t (&xf)[KPW], const bf16_t* xb, const int KT, const int mw, const int lane) {
+    const int kt0 = mw * KT / TE_MW, kt1 = (mw + 1) * KT / TE_MW;
+    const int klast = kt1 > kt0 ? kt1 - 1 : kt0;
     const bool row0 = (lane & 15) == 0;
     const bf16x8_t zero = {0, 0, 0, 0, 0, 0, 0, 0};
 #pragma unroll
@@ -114,310 +167,540 @@ __device__ __forceinline__ void te_gemv(const bf16_t* __restrict__ Wp, const int
         const bf16x8_t v = *reinterpret_cast<const bf16x8_t*>(xb + 32 * kk + 8 * (lane >> 4));
         xf[u] = (row0 && live) ? v : zero;
     }
-    f32x4_t acc[RMAX];
+}
+// the same from the float32 residual stream through RMSNorm: T(w * T(h * inv))
+template <int KPW>
+__device__ __forceinline__ void te_xfrag_norm(bf16x8_t (&xf)[KPW], const float* hf, const bf16x8_t (&wn)[KPW], const float inv, const int KT,
+                                              const int mw, const int lane) {
+    const int kt0 = mw * KT / TE_MW, kt1 = (mw + 1) * KT / TE_MW;
+    const int klast = kt1 > kt0 ? kt1 - 1 : kt0;
+    const bool row0 = (lane & 15) == 0;
 #pragma unroll
-    for (int r = 0; r < RMAX; ++r) acc[r] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+    for (int u = 0; u < KPW; ++u) {
+        int kk = kt0 + u;
+        const bool live = kk < kt1;
+        kk = kk > klast ? klast : kk;
+        kk = kk >= KT ? KT - 1 : kk;
+        const float* hp = hf + 32 * kk + 8 * (lane >> 4);
+        const f32x4_t h0 = *reinterpret_cast<const f32x4_t*>(hp), h1 = *reinterpret_cast<const f32x4_t*>(hp + 4);
+        bf16x8_t v;
 #pragma unroll
-    for (int u = 0; u < KPW; ++u)
-#pragma unroll
-        for (int r = 0; r < RMAX; ++r) acc[r] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[r][u], xf[u], acc[r], 0, 0, 0);
-    if (row0) {
-        const int g = lane >> 4;
-#pragma unroll
-        for (int r = 0; r < RMAX; ++r)
-            *reinterpret_cast<f32x4_t*>(red + ((size_t)(wave * RMAX + r) * 16 + 4 * g)) = acc[r];
+        for (int e = 0; e < 8; ++e) {
+            const float hv = e < 4 ? h0[e] : h1[e - 4];
+            v[e] = (short)f32_to_bf16(bf16_to_f32((bf16_t)wn[u][e]) * bf16_round_f32(hv * inv));
+        }
+        const bf16x8_t zero = {0, 0, 0, 0, 0, 0, 0, 0};
+        xf[u] = (row0 && live) ? v : zero;
     }
 }
-// sum of the eight waves' partials for element (r, i), fixed order
-template <int RMAX>
+template <int R, int KPW>
+__device__ __forceinline__ void te_mma(const TeTiles<R, KPW>& T, const bf16x8_t (&xf)[KPW], float* red, const int mw, const int lane) {
+    constexpr int RB = R > 5 ? 5 : R;                                // tile rows per block of accumulators (gate|up: 10 rows = 2 blocks - with all
+    const int g = lane >> 4;                                         //  ten live next to 176 registers of tiles the kernel spills)
+#pragma unroll
+    for (int r0 = 0; r0 < R; r0 += RB) {
+        f32x4_t acc[RB];
+#pragma unroll
+        for (int r = 0; r < RB; ++r) acc[r] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int u = 0; u < KPW; ++u)
+#pragma unroll
+            for (int r = 0; r < RB; ++r)
+                if (r0 + r < R) acc[r] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(T.a[r0 + r][u], xf[u], acc[r], 0, 0, 0);
+        if ((lane & 15) == 0) {
+#pragma unroll
+            for (int r = 0; r < RB; ++r)
+                if (r0 + r < R) *reinterpret_cast<f32x4_t*>(red + ((size_t)(mw * R + r0 + r) * 16 + 4 * g)) = acc[r];
+        }
+    }
+    // the NEXT phase's tile requests follow in program order: left to the scheduler they are hoisted above these MFMAs, and two phases'
+    // tiles (gate|up: 176 registers, down: 72) are live at once - spills into scratch, i.e. more traffic in the same vmcnt queue
+    __builtin_amdgcn_sched_barrier(0);
+}
+// sum of the matrix waves' partials for element (r, i), fixed order
+template <int R>
 __device__ __forceinline__ float te_combine(const float* red, int r, int i) {
     float s = 0.f;
 #pragma unroll
-    for (int w = 0; w < TE_NW; ++w) s += red[(size_t)(w * RMAX + r) * 16 + i];
+    for (int m = 0; m < TE_MW; ++m) s += red[(size_t)(m * R + r) * 16 + i];
     return s;
 }
 
-// block-wide sum (512 threads), result to every thread; s_red: 8 floats
-__device__ __forceinline__ float te_block_sum(float v, float* s_red, int wave, int lane) {
-    v = wave_sum(v);
-    __syncthreads();
-    if (lane == 0) s_red[wave] = v;
-    __syncthreads();
-    float t = 0.f;
-#pragma unroll
-    for (int w = 0; w < TE_NW; ++w) t += s_red[w];
-    return t;
+// LDS of one worker
+struct TeLds {
+    float* hf;          // [d] residual stream (bf16 values)
+    bf16_t* xb;         // [max(ff, H D)] attention output / activation: the plain GEMV inputs
+    float* qkvf;        // [Nqkv]
+    float* qh;          // [H][D]
+    float *knew, *vnew; // [D]
+    float* sc;          // [H][TE_CTX]
+    bf16_t *ph, *pl;    // [H][TE_CTX] probabilities of the keys before this position, bf16 hi and lo
+    bf16_t* stage;      // [R x 16] one epilogue value per thread before four of them are packed into a granule
+    float* red;         // [TE_MW][R][16] partial sums of the matrix waves
+    float* s_ss;        // [TE_VW] sum-of-squares partials of the residual stream
+    u64* s_cand;        // [TE_VW]
+    int *s_ok, *s_tok;
+};
+template <int XCDS>
+struct TeDims {
+    using S = TeShape;
+    static constexpr int W = 32 * XCDS;
+    static constexpr int R_QKV = (S::Nqkv / 16 + W - 1) / W, R_O = (S::d / 16 + W - 1) / W, P_GU = (S::ff / 16 + W - 1) / W, R_GU = 2 * P_GU;
+    static constexpr int R_HEAD = 8;                                 // tile rows of the output projection per pass
+    static constexpr int KPW_D = (S::d / 32 + TE_MW - 1) / TE_MW, KPW_HD = (S::HD / 32 + TE_MW - 1) / TE_MW, KPW_FF = (S::ff / 32 + TE_MW - 1) / TE_MW;
+    static constexpr int R_RED = R_GU > R_HEAD ? R_GU : R_HEAD;
+};
+#define TE_EDGE_OR_RETURN() do { te_sync(); te_sync(); if (!*L.s_ok) return; } while (0)      /* matrix side of te_edge */
+
+// ---------------------------------------------------------------------------- the matrix waves' program.  Every te_sync() here has its
+// partner at the same place of te_vector_role (the two programs are listed phase by phase in the same order); between barriers these
+// waves only touch their weight tiles, the GEMV inputs in LDS and `red`.
+template <int XCDS>
+__device__ __forceinline__ void te_matrix_role(const TeParams& p, const TeLds& L, const int w_in, const int mw_in, const int lane) {
+    using S = TeShape;
+    using Dm = TeDims<XCDS>;
+    constexpr int W = Dm::W, R_QKV = Dm::R_QKV, R_O = Dm::R_O, P_GU = Dm::P_GU, R_GU = Dm::R_GU, R_HEAD = Dm::R_HEAD;
+    constexpr int KPW_D = Dm::KPW_D, KPW_HD = Dm::KPW_HD, KPW_FF = Dm::KPW_FF;
+    const int NTV = p.Vpad / 16;
+    // This worker's tile rows, recomputed from an OPAQUE copy of the (scalar) worker and wave index wherever tiles are requested: every
+    // tile address is loop-invariant, and hoisted out of the layer loop the ~100 of them (64-bit each) exhaust the scalar registers,
+    // after which the compiler builds them in vector registers and the tile buffers spill.  A few SALU instructions per request instead.
+#define TE_OPAQUE_IDS() int wq = w_in, mw = mw_in; asm volatile("" : "+s"(wq), "+s"(mw))
+#define TE_ROWS_QKV(NT) int NT[R_QKV]; _Pragma("unroll") for (int r = 0; r < R_QKV; ++r) NT[r] = (wq + r * W) < S::Nqkv / 16 ? wq + r * W : -1
+#define TE_ROWS_O(NT) int NT[R_O]; _Pragma("unroll") for (int r = 0; r < R_O; ++r) NT[r] = (wq + r * W) < S::d / 16 ? wq + r * W : -1
+#define TE_ROWS_GU(NT) int NT[R_GU]; _Pragma("unroll") for (int r = 0; r < P_GU; ++r) { const int pr = wq + r * W;                       \
+        NT[2 * r] = pr < S::ff / 16 ? 2 * pr : -1; NT[2 * r + 1] = pr < S::ff / 16 ? 2 * pr + 1 : -1; }
+#define TE_ROWS_HEAD(NT, PASS) int NT[R_HEAD]; _Pragma("unroll") for (int r = 0; r < R_HEAD; ++r)                                      \
+        NT[r] = (wq + ((PASS) * R_HEAD + r) * W) < NTV ? wq + ((PASS) * R_HEAD + r) * W : -1
+    // piece k of n of a phase's N tiles
+#define TE_PIECE(N, k, n) ((N) * (k) / (n)), ((N) * ((k) + 1) / (n))
+    constexpr int N_Q = R_QKV * KPW_D, N_G = R_GU * KPW_D, N_D = R_O * KPW_FF, N_H = R_HEAD * KPW_D;
+    TeTiles<R_QKV, KPW_D> tq;
+    {
+        TE_OPAQUE_IDS();
+        TE_ROWS_QKV(nt);
+        te_load<R_QKV, KPW_D, true>(tq, p.wqkv, S::d / 32, nt, p.norms, mw, lane);
+    }
+    for (int t = 0; t < p.n_total; ++t) {
+        te_sync();                                                   // token id
+        te_sync();                                                   // embedding row + sum of squares
+        // (the layer loop is rotated by the barriers of edge 4: the output projection's first tiles are requested AFTER the loop and still
+        // ahead of the last layer's edge 4 - loaded inside the loop's last iteration they would be live across the whole loop, 144
+        // registers that the gate|up tiles need)
+        for (int li = 0; li < p.L; ++li) {
+            TeTiles<R_O, KPW_HD> to;
+            TeTiles<R_GU, KPW_D> tg;
+            TeTiles<R_O, KPW_FF> td;
+            const bf16_t* wq_l = p.wqkv + (size_t)li * S::Nqkv * S::d;
+            const bf16_t* wg_l = p.wgu + (size_t)li * 2 * S::ff * S::d;
+            const bf16_t* wd_l = p.wdown + (size_t)li * S::d * S::ff;
+            const bf16_t* n2_l = p.norms + (size_t)(2 * li + 1) * S::d;
+            if (li > 0) {   // (previous layer) edge 4 and the gather behind it; this layer's q|k|v tiles in four pieces behind its barriers
+                TE_OPAQUE_IDS();
+                TE_ROWS_QKV(nt);
+                te_load<R_QKV, KPW_D, true, TE_PIECE(N_Q, 1, 4)>(tq, wq_l, S::d / 32, nt, p.norms + (size_t)(2 * li) * S::d, mw, lane);
+                te_sync();
+                te_load<R_QKV, KPW_D, true, TE_PIECE(N_Q, 2, 4)>(tq, wq_l, S::d / 32, nt, p.norms + (size_t)(2 * li) * S::d, mw, lane);
+                te_sync();
+                if (!*L.s_ok) return;
+                te_load<R_QKV, KPW_D, true, TE_PIECE(N_Q, 3, 4)>(tq, wq_l, S::d / 32, nt, p.norms + (size_t)(2 * li) * S::d, mw, lane);
+                te_sync();                                           // residual stream gathered
+            }
+            {   // q|k|v; then o_proj's tiles and the first piece of gate|up
+                TE_OPAQUE_IDS();
+                const float inv = rsqrtf(((L.s_ss[0] + L.s_ss[1]) + (L.s_ss[2] + L.s_ss[3])) / (float)S::d + p.eps);
+                bf16x8_t xf[KPW_D];
+                te_xfrag_norm<KPW_D>(xf, L.hf, tq.wn, inv, S::d / 32, mw, lane);
+                te_mma<R_QKV, KPW_D>(tq, xf, L.red, mw, lane);
+                te_sync();                                           // red ready
+                TE_ROWS_O(nt);
+                te_load<R_O, KPW_HD, false>(to, p.wo + (size_t)li * S::d * S::HD, S::HD / 32, nt, nullptr, mw, lane);
+            }
+            {   // edge 1, the gather and the four barriers of the attention phase: gate|up's tiles in seven pieces
+                TE_OPAQUE_IDS();
+                TE_ROWS_GU(nt);
+                te_load<R_GU, KPW_D, true, TE_PIECE(N_G, 0, 7)>(tg, wg_l, S::d / 32, nt, n2_l, mw, lane);
+                te_sync();
+                te_load<R_GU, KPW_D, true, TE_PIECE(N_G, 1, 7)>(tg, wg_l, S::d / 32, nt, n2_l, mw, lane);
+                te_sync();
+                if (!*L.s_ok) return;
+                te_load<R_GU, KPW_D, true, TE_PIECE(N_G, 2, 7)>(tg, wg_l, S::d / 32, nt, n2_l, mw, lane);
+                te_sync();                                           // q|k|v gathered
+                te_load<R_GU, KPW_D, true, TE_PIECE(N_G, 3, 7)>(tg, wg_l, S::d / 32, nt, n2_l, mw, lane);
+                te_sync();                                           // q/k-norm + RoPE
+                te_load<R_GU, KPW_D, true, TE_PIECE(N_G, 4, 7)>(tg, wg_l, S::d / 32, nt, n2_l, mw, lane);
+                te_sync();                                           // scores
+                te_load<R_GU, KPW_D, true, TE_PIECE(N_G, 5, 7)>(tg, wg_l, S::d / 32, nt, n2_l, mw, lane);
+                te_sync();                                           // softmax
+                te_load<R_GU, KPW_D, true, TE_PIECE(N_G, 6, 7)>(tg, wg_l, S::d / 32, nt, n2_l, mw, lane);
+                te_sync();                                           // attention output ready
+            }
+            {   // o_proj (gate|up's 176 registers of tiles are live: nothing more can be requested before its MFMAs)
+                TE_OPAQUE_IDS();
+                bf16x8_t xf[KPW_HD];
+                te_xfrag_bf16<KPW_HD>(xf, L.xb, S::HD / 32, mw, lane);
+                te_mma<R_O, KPW_HD>(to, xf, L.red, mw, lane);
+                te_sync();                                           // red ready
+            }
+            TE_EDGE_OR_RETURN();                                     // edge 2
+            te_sync();                                               // residual stream gathered
+            {   // gate|up; then down_proj's tiles in four pieces behind edge 3 and its gather
+                TE_OPAQUE_IDS();
+                const float inv = rsqrtf(((L.s_ss[0] + L.s_ss[1]) + (L.s_ss[2] + L.s_ss[3])) / (float)S::d + p.eps);
+                bf16x8_t xf[KPW_D];
+                te_xfrag_norm<KPW_D>(xf, L.hf, tg.wn, inv, S::d / 32, mw, lane);
+                te_mma<R_GU, KPW_D>(tg, xf, L.red, mw, lane);
+                te_sync();                                           // red ready
+                TE_ROWS_O(nt);
+                te_load<R_O, KPW_FF, false, TE_PIECE(N_D, 0, 4)>(td, wd_l, S::ff / 32, nt, nullptr, mw, lane);
+                te_sync();
+                te_load<R_O, KPW_FF, false, TE_PIECE(N_D, 1, 4)>(td, wd_l, S::ff / 32, nt, nullptr, mw, lane);
+                te_sync();
+                if (!*L.s_ok) return;
+                te_load<R_O, KPW_FF, false, TE_PIECE(N_D, 2, 4)>(td, wd_l, S::ff / 32, nt, nullptr, mw, lane);
+                te_load<R_O, KPW_FF, false, TE_PIECE(N_D, 3, 4)>(td, wd_l, S::ff / 32, nt, nullptr, mw, lane);
+                te_sync();                                           // activation gathered
+            }
+            {   // down; the first piece of the next layer's q|k|v tiles (the other three: top of the loop)
+                TE_OPAQUE_IDS();
+                bf16x8_t xf[KPW_FF];
+                te_xfrag_bf16<KPW_FF>(xf, L.xb, S::ff / 32, mw, lane);
+                te_mma<R_O, KPW_FF>(td, xf, L.red, mw, lane);
+                te_sync();                                           // red ready
+                if (li + 1 < p.L) {
+                    TE_ROWS_QKV(nt);
+                    te_load<R_QKV, KPW_D, true, TE_PIECE(N_Q, 0, 4)>(tq, wq_l + (size_t)S::Nqkv * S::d, S::d / 32, nt, p.norms + (size_t)(2 * li + 2) * S::d, mw, lane);
+                }
+            }
+        }
+        {   // output projection, passes of R_HEAD tile rows; the first pass's tiles behind the barriers of the last layer's edge 4
+            TeTiles<R_HEAD, KPW_D> th;
+            int mw_h;
+            {
+                TE_OPAQUE_IDS();
+                mw_h = mw;
+                TE_ROWS_HEAD(nth, 0);
+                const bf16_t* nf = p.norms + (size_t)(2 * p.L) * S::d;
+                te_load<R_HEAD, KPW_D, true, TE_PIECE(N_H, 0, 3)>(th, p.head, S::d / 32, nth, nf, mw, lane);
+                te_sync();
+                te_load<R_HEAD, KPW_D, true, TE_PIECE(N_H, 1, 3)>(th, p.head, S::d / 32, nth, nf, mw, lane);
+                te_sync();
+                if (!*L.s_ok) return;
+                te_load<R_HEAD, KPW_D, true, TE_PIECE(N_H, 2, 3)>(th, p.head, S::d / 32, nth, nf, mw, lane);
+                te_sync();                                           // residual stream gathered
+            }
+            const float inv = rsqrtf(((L.s_ss[0] + L.s_ss[1]) + (L.s_ss[2] + L.s_ss[3])) / (float)S::d + p.eps);
+            bf16x8_t xf[KPW_D];
+            te_xfrag_norm<KPW_D>(xf, L.hf, th.wn, inv, S::d / 32, mw_h, lane);
+            for (int pass = 0; pass * R_HEAD * W < NTV; ++pass) {
+                TE_OPAQUE_IDS();
+                te_mma<R_HEAD, KPW_D>(th, xf, L.red, mw, lane);
+                te_sync();                                           // red ready
+                if ((pass + 1) * R_HEAD * W < NTV) {
+                    TE_ROWS_HEAD(nt2, pass + 1);
+                    te_load<R_HEAD, KPW_D, false>(th, p.head, S::d / 32, nt2, nullptr, mw, lane);
+                } else {
+                    TE_ROWS_QKV(nt);
+                    te_load<R_QKV, KPW_D, true>(tq, p.wqkv, S::d / 32, nt, p.norms, mw, lane);              // layer 0 of the next position
+                }
+                te_sync();                                           // red consumed
+            }
+            te_sync();                                               // candidates of the vector waves
+            TE_EDGE_OR_RETURN();                                     // edge 5
+            te_sync();                                               // candidates gathered
+        }
+    }
 }
 
+// ---------------------------------------------------------------------------- the vector waves' program (256 threads)
 template <int XCDS>
-__global__ void __launch_bounds__(TE_NT) k_token_engine(TeParams p) {
+__device__ __forceinline__ void te_vector_role(const TeParams& p, const TeLds& L, const int w, const int tid) {
     using S = TeShape;
-    constexpr int W = 32 * XCDS;
-    constexpr int R_QKV = (S::Nqkv / 16 + W - 1) / W, R_O = (S::d / 16 + W - 1) / W, P_GU = (S::ff / 16 + W - 1) / W, R_GU = 2 * P_GU;
-    constexpr int R_HEAD = 8;                                        // tile rows of the output projection per pass
-    constexpr int KPW_D = (S::d / 32 + TE_NW - 1) / TE_NW, KPW_HD = (S::HD / 32 + TE_NW - 1) / TE_NW, KPW_FF = (S::ff / 32 + TE_NW - 1) / TE_NW;
-    extern __shared__ __attribute__((aligned(16))) unsigned char te_lds_pad[];      // (requested size keeps the launch at one block per CU)
-    __shared__ __attribute__((aligned(16))) float hf[S::d];                         // residual stream (bf16 values)
-    __shared__ __attribute__((aligned(16))) bf16_t xb[S::ff > S::d ? S::ff : S::d]; // the GEMV input vector
-    __shared__ __attribute__((aligned(16))) float qkvf[S::Nqkv];
-    __shared__ __attribute__((aligned(16))) float qh[S::H][S::D];
-    __shared__ __attribute__((aligned(16))) float knew[S::Hkv * S::D], vnew[S::Hkv * S::D];
-    __shared__ __attribute__((aligned(16))) float sc[S::H][TE_CTX];
-    __shared__ __attribute__((aligned(16))) float red[TE_NW * (R_GU > R_HEAD ? R_GU : R_HEAD) * 16];
-    __shared__ float s_red[TE_NW];
-    __shared__ u64 s_cand[TE_NW];
-    __shared__ int s_ok;
-    __shared__ int s_tok;
-    if (p.n_total < 0) te_lds_pad[threadIdx.x] = 0;
-    const int b = blockIdx.x;
-    if ((b & 7) >= XCDS) return;
-    const int w = (b >> 3) * XCDS + (b & 7);
-    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    using Dm = TeDims<XCDS>;
+    constexpr int W = Dm::W, R_QKV = Dm::R_QKV, R_O = Dm::R_O, P_GU = Dm::P_GU, R_GU = Dm::R_GU, R_HEAD = Dm::R_HEAD;
+    const int wave = tid >> 6, lane = tid & 63;
+    const int NTV = p.Vpad / 16;
     unsigned edge = 0;
-    bf16_t* kv_mine = p.kv + (size_t)w * p.L * 2 * TE_CTX * (S::Hkv * S::D);
+    // ONE K/V copy for all workers, written by every one of them: the new row is computed redundantly from the same gathered q|k|v by
+    // the same instructions, so all writers store identical bytes; a worker only ever reads rows it has itself written at an earlier
+    // position (rows are 256 B = whole cache lines), so no CU can hold a stale line.  (Private copies - 32 x 17 x 2 x ctx x 256 B - do not
+    // fit the XCD's 4 MB L2: every row came from the Infinity Cache, ~2 us per round trip under the weight stream.)
+    bf16_t* kv_mine = p.kv;
     const float scale = rsqrtf((float)S::D);
-
-    for (int t = 0; t < p.n_total; ++t) {
-        // ---- token id and embedding row (every worker reads its own copy: 1 KB)
-        if (tid == 0) s_tok = t < p.n_prompt ? p.prompt[t] : s_tok;
-        __syncthreads();
-        const int tok = s_tok;
-        for (int i = tid; i < S::d; i += TE_NT) hf[i] = bf16_to_f32(p.emb[(size_t)tok * S::d + i]);
-        __syncthreads();
-        for (int li = 0; li < p.L; ++li) {
-            // ================= RMSNorm -> q|k|v slice -> edge 1
-            {
-                const bf16_t* wn = p.norms + (size_t)(2 * li) * S::d;
-                float v = tid < S::d ? hf[tid] : 0.f;
-                const float ss = te_block_sum(v * v, s_red, wave, lane);
-                const float inv = rsqrtf(ss / (float)S::d + p.eps);
-                if (tid < S::d) xb[tid] = f32_to_bf16(bf16_to_f32(wn[tid]) * bf16_round_f32(v * inv));
-                __syncthreads();
-                int nt[R_QKV];
+    float(*qh)[S::D] = reinterpret_cast<float(*)[S::D]>(L.qh);
+    float(*sc)[TE_CTX] = reinterpret_cast<float(*)[TE_CTX]>(L.sc);
+    // gather of the residual stream: 4 values per thread (tid < d / 4) + their sum of squares per wave
+    auto gather_h = [&](const u64* buf) {
+        if (tid < S::d / 4) {
+            const u64 gq = __hip_atomic_load(buf + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            float ss = 0.f;
 #pragma unroll
-                for (int r = 0; r < R_QKV; ++r) nt[r] = (w + r * W) < S::Nqkv / 16 ? w + r * W : -1;
-                te_gemv<R_QKV, KPW_D>(p.wqkv + (size_t)li * S::Nqkv * S::d, S::d / 32, nt, xb, red, wave, lane);
-                __syncthreads();
+            for (int e = 0; e < 4; ++e) { const float v = bf16_to_f32((bf16_t)(gq >> (16 * e))); L.hf[4 * tid + e] = v; ss += v * v; }
+            ss = wave_sum_dpp(ss);
+            if (lane == 0) L.s_ss[wave] = ss;
+        }
+    };
+    // One epilogue value per thread (tid < n_vals, value index tid = 16 r + i), four consecutive ones packed into a granule by the first
+    // thread of each quad through LDS (the quad sits in one wave: its own s_waitcnt orders the write before the read).  `granule_of(r)` =
+    // first granule of tile row r in the edge's vector, or -1.
+    auto publish4 = [&](u64* buf, int n_vals, float value, int first_granule) {
+        if (tid < n_vals) L.stage[tid] = f32_to_bf16(value);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if (tid < n_vals && (tid & 3) == 0 && first_granule >= 0)
+            __hip_atomic_store(buf + first_granule + ((tid & 15) >> 2), *reinterpret_cast<const u64*>(L.stage + tid), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    };
+    // residual epilogue of o_proj / down_proj: this worker's R_O x 16 outputs, T(h + T(acc))
+    auto publish_resid = [&](u64* buf) {
+        float v = 0.f;
+        int gr = -1;
+        if (tid < R_O * 16) {
+            const int r = tid >> 4, i = tid & 15, nt = w + r * W;
+            if (nt < S::d / 16) { v = L.hf[nt * 16 + i] + bf16_round_f32(te_combine<R_O>(L.red, r, i)); gr = nt * 4; }
+        }
+        publish4(buf, R_O * 16, v, gr);
+    };
+#define TE_STAMP(i) do { if (p.dbg && w == 0 && tid == 0 && t == p.dbg_token && li == 1) p.dbg[i] = __builtin_readcyclecounter(); } while (0)
+    for (int t = 0; t < p.n_total; ++t) {
+        if (tid == 0 && t < p.n_prompt) *L.s_tok = p.prompt[t];
+        te_sync();                                                   // token id
+        {
+            const int tok = *L.s_tok;
+            if (tid < S::d / 4) {
+                const u64 gq = *reinterpret_cast<const u64*>(p.emb + (size_t)tok * S::d + 4 * tid);
+                float ss = 0.f;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { const float v = bf16_to_f32((bf16_t)(gq >> (16 * e))); L.hf[4 * tid + e] = v; ss += v * v; }
+                ss = wave_sum_dpp(ss);
+                if (lane == 0) L.s_ss[wave] = ss;
+            }
+        }
+        te_sync();                                                   // embedding row + sum of squares
+        const float rope_c = p.rope_cos[(size_t)t * (S::D / 2) + lane], rope_s = p.rope_sin[(size_t)t * (S::D / 2) + lane];     // this position's row
+        for (int li = 0; li < p.L; ++li) {
+            // ================= q|k|v slice -> edge 1
+            TE_STAMP(0);
+            te_sync();                                               // red ready
+            TE_STAMP(1);
+            {
                 u64* buf = p.xbuf + (size_t)(edge & 1u) * TE_XG;
-                if (tid < R_QKV * 4) {
-                    const int r = tid >> 2, g = tid & 3;
-                    if (nt[r] >= 0)
-                        __hip_atomic_store(buf + nt[r] * 4 + g, te_pack4(te_combine<R_QKV>(red, r, 4 * g), te_combine<R_QKV>(red, r, 4 * g + 1),
-                                                                          te_combine<R_QKV>(red, r, 4 * g + 2), te_combine<R_QKV>(red, r, 4 * g + 3)),
-                                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                {
+                    float v = 0.f;
+                    int gr = -1;
+                    if (tid < R_QKV * 16) {
+                        const int r = tid >> 4, i = tid & 15, nt = w + r * W;
+                        if (nt < S::Nqkv / 16) { v = te_combine<R_QKV>(L.red, r, i); gr = nt * 4; }
+                    }
+                    publish4(buf, R_QKV * 16, v, gr);
                 }
-                if (!te_meet(p, edge, W, &s_ok)) { if (tid == 0) *p.fail = 1u; return; }
+                TE_STAMP(2);
+                if (!te_edge(p, edge, W, L.s_ok)) { if (tid == 0) *p.fail = 1u; return; }
+                TE_STAMP(3);
                 if (tid < S::Nqkv / 4) {
                     const u64 gq = __hip_atomic_load(buf + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) qkvf[4 * tid + e] = bf16_to_f32((bf16_t)(gq >> (16 * e)));
+                    for (int e = 0; e < 4; ++e) L.qkvf[4 * tid + e] = bf16_to_f32((bf16_t)(gq >> (16 * e)));
                 }
-                __syncthreads();
             }
-            // ================= q/k-norm, RoPE, attention (redundant on every worker, private K/V copy), o_proj slice -> edge 2
-            {
-                bf16_t* kc = kv_mine + ((size_t)li * 2 + 0) * TE_CTX * (S::Hkv * S::D);
-                bf16_t* vc = kv_mine + ((size_t)li * 2 + 1) * TE_CTX * (S::Hkv * S::D);
-                const int pos = t, ctx = t + 1;
-                if (wave < S::H + S::Hkv) {                                     // one wave per q head / k head: lane holds elements lane, lane + 64
-                    const bool is_k = wave >= S::H;
-                    const float* src = qkvf + (is_k ? S::HD + (wave - S::H) * S::D : wave * S::D);
-                    const bf16_t* nw = p.qknorm + (size_t)(2 * li + (is_k ? 1 : 0)) * S::D;
+            te_sync();                                               // q|k|v gathered
+            TE_STAMP(4);
+            // ================= q/k-norm, RoPE, attention (redundant on every worker, private K/V copy)
+            bf16_t* kc = kv_mine + ((size_t)li * 2 + 0) * TE_CTX * S::D;
+            bf16_t* vc = kv_mine + ((size_t)li * 2 + 1) * TE_CTX * S::D;
+            const int pos = t, ctx = t + 1;
+            {   // wave v: q head v; wave 0 also the key, wave 1 the value.  Lane holds elements lane, lane + 64 (RoPE partners)
+                const float c = rope_c, sn = rope_s;
+                for (int which = 0; which < 2; ++which) {
+                    if (which == 1 && wave != 0) break;
+                    const float* src = L.qkvf + (which ? S::HD : wave * S::D);
+                    const bf16_t* nw = p.qknorm + (size_t)(2 * li + which) * S::D;
                     const float x1 = src[lane], x2 = src[lane + 64];
-                    const float ss = wave_sum(x1 * x1 + x2 * x2);
+                    const float ss = wave_sum_dpp(x1 * x1 + x2 * x2);
                     const float inv = rsqrtf(ss / (float)S::D + p.eps);
                     const float y1 = bf16_round_f32(bf16_to_f32(nw[lane]) * bf16_round_f32(x1 * inv));
                     const float y2 = bf16_round_f32(bf16_to_f32(nw[lane + 64]) * bf16_round_f32(x2 * inv));
-                    const float c = p.rope_cos[(size_t)pos * (S::D / 2) + lane], sn = p.rope_sin[(size_t)pos * (S::D / 2) + lane];
                     const float o1 = bf16_round_f32(y1 * c - y2 * sn), o2 = bf16_round_f32(y1 * sn + y2 * c);
-                    if (is_k) {
-                        const int kh = wave - S::H;
-                        knew[kh * S::D + lane] = o1; knew[kh * S::D + lane + 64] = o2;
-                        kc[(size_t)pos * (S::Hkv * S::D) + kh * S::D + lane] = f32_to_bf16(o1);
-                        kc[(size_t)pos * (S::Hkv * S::D) + kh * S::D + lane + 64] = f32_to_bf16(o2);
+                    if (which) {
+                        L.knew[lane] = o1; L.knew[lane + 64] = o2;
+                        kc[(size_t)pos * S::D + lane] = f32_to_bf16(o1);
+                        kc[(size_t)pos * S::D + lane + 64] = f32_to_bf16(o2);
                     } else {
                         qh[wave][lane] = o1; qh[wave][lane + 64] = o2;
                     }
-                } else if (wave == S::H + S::Hkv) {                              // values: appended as they are
-                    for (int i = lane; i < S::Hkv * S::D; i += 64) {
-                        const float v = qkvf[S::HD + S::Hkv * S::D + i];
-                        vnew[i] = v;
-                        vc[(size_t)pos * (S::Hkv * S::D) + i] = f32_to_bf16(v);
+                }
+                if (wave == 1) {                                                 // values: kept TRANSPOSED [d][position] (the P.V MFMA's A operand)
+                    const float v1 = L.qkvf[S::HD + S::D + lane], v2 = L.qkvf[S::HD + S::D + lane + 64];
+                    L.vnew[lane] = v1; L.vnew[lane + 64] = v2;
+                    vc[(size_t)lane * TE_CTX + pos] = f32_to_bf16(v1);
+                    vc[(size_t)(lane + 64) * TE_CTX + pos] = f32_to_bf16(v2);
+                }
+            }
+            te_sync();
+            TE_STAMP(5);
+            {   // scores on the matrix core: D[key][head] = sum_d K[key][d] q[head][d] - A = 16 keys x 32 d straight from the row-major key
+                // cache (16 B per lane), B = q^T with the four heads in columns 0..3.  Wave v takes the key tiles v, v + 4, ...; only keys
+                // BEFORE this position come from memory (the new key is in LDS: its row is still on its way to the cache).  (The VALU form -
+                // 16 lanes per key, DPP reductions - was 4.5 us per layer at 81 keys.)
+                const int i16 = lane & 15, q4 = lane >> 4;
+                bf16x8_t qf[S::D / 32];
+#pragma unroll
+                for (int ds = 0; ds < S::D / 32; ++ds) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) qf[ds][e] = i16 < S::H ? (short)f32_to_bf16(qh[i16 < S::H ? i16 : 0][32 * ds + 8 * q4 + e]) : (short)0;
+                }
+                const int n_kt = (pos + 15) >> 4;
+                for (int kt = wave; kt < n_kt; kt += TE_VW) {
+                    int row = 16 * kt + i16;
+                    row = row < pos ? row : pos - 1;
+                    const bf16_t* kr = kc + (size_t)row * S::D + 8 * q4;
+                    bf16x8_t ka[S::D / 32];
+#pragma unroll
+                    for (int ds = 0; ds < S::D / 32; ++ds) ka[ds] = __builtin_nontemporal_load(reinterpret_cast<const bf16x8_t*>(kr + 32 * ds));
+                    f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int ds = 0; ds < S::D / 32; ++ds) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ka[ds], qf[ds], acc, 0, 0, 0);
+                    if (i16 < S::H) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const int j = 16 * kt + 4 * q4 + r;
+                            if (j < pos) sc[i16][j] = acc[r] * scale;
+                        }
                     }
                 }
-                __syncthreads();
-                // scores: 16 lanes per key (8 elements each), 32 keys per pass; the heads of a kv group share the key chunk
+                {   // the new key: head `wave`
+                    const float dsum = wave_sum_dpp(qh[wave][lane] * L.knew[lane] + qh[wave][lane + 64] * L.knew[lane + 64]);
+                    if (lane == 0) sc[wave][pos] = dsum * scale;
+                }
+            }
+            te_sync();
+            TE_STAMP(6);
+            {   // softmax of head `wave`; the probabilities of the keys before this position as bf16 hi + lo (the pair keeps float32 accuracy
+                // through the bf16 MFMA), zero up to the next multiple of 32 keys; the new key's probability stays float32 (sc[head][pos])
+                float m = -3.0e38f;
+                for (int j = lane; j < ctx; j += 64) m = fmaxf(m, sc[wave][j]);
+                m = te_wave_max_dpp(m);
+                float sum = 0.f;
+                for (int j = lane; j < ctx; j += 64) { const float e = expf(sc[wave][j] - m); sc[wave][j] = e; sum += e; }
+                sum = wave_sum_dpp(sum);
+                const float rinv = 1.0f / sum;
+                const int pend = (pos + 31) & ~31;
+                for (int j = lane; j < pend || j < ctx; j += 64) {
+                    const float pj = j < ctx ? sc[wave][j] * rinv : 0.f;
+                    if (j < ctx) sc[wave][j] = pj;
+                    if (j < pend) {
+                        const float pm = j < pos ? pj : 0.f;
+                        const bf16_t hi = f32_to_bf16(pm);
+                        L.ph[wave * TE_CTX + j] = hi;
+                        L.pl[wave * TE_CTX + j] = f32_to_bf16(pm - bf16_to_f32(hi));
+                    }
+                }
+            }
+            te_sync();
+            {   // P.V on the matrix core: D[d][head] = sum_key Vt[d][key] P[head][key] - A = 16 d x 32 keys from the transposed value cache,
+                // B = P^T (hi, then lo).  Wave v owns the d tiles 2 v, 2 v + 1 over ALL keys (no cross-wave sum); the new key joins in the
+                // epilogue from LDS.
+                const int i16 = lane & 15, q4 = lane >> 4;
+                const int n_k32 = (pos + 31) >> 5;
+                f32x4_t acc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+                for (int kt = 0; kt < n_k32; ++kt) {
+                    bf16x8_t va[2], bh, bl;
+#pragma unroll
+                    for (int n = 0; n < 2; ++n)
+                        va[n] = __builtin_nontemporal_load(reinterpret_cast<const bf16x8_t*>(vc + (size_t)(16 * (2 * wave + n) + i16) * TE_CTX + 32 * kt + 8 * q4));   // (past L1: a value line holds 64 positions, and all but the newest were written by other launches of this loop)
+                    const bf16x8_t z = {0, 0, 0, 0, 0, 0, 0, 0};
+                    bh = i16 < S::H ? *reinterpret_cast<const bf16x8_t*>(L.ph + (i16 < S::H ? i16 : 0) * TE_CTX + 32 * kt + 8 * q4) : z;
+                    bl = i16 < S::H ? *reinterpret_cast<const bf16x8_t*>(L.pl + (i16 < S::H ? i16 : 0) * TE_CTX + 32 * kt + 8 * q4) : z;
+#pragma unroll
+                    for (int n = 0; n < 2; ++n) {
+                        acc[n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(va[n], bh, acc[n], 0, 0, 0);
+                        acc[n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(va[n], bl, acc[n], 0, 0, 0);
+                    }
+                }
+                if (i16 < S::H) {
+                    const float pn = sc[i16][pos];
+#pragma unroll
+                    for (int n = 0; n < 2; ++n) {
+                        const int d0 = 16 * (2 * wave + n) + 4 * q4;
+                        bf16_t o[4];
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) o[r] = f32_to_bf16(acc[n][r] + pn * L.vnew[d0 + r]);
+                        *reinterpret_cast<u64*>(L.xb + i16 * S::D + d0) = (u64)o[0] | ((u64)o[1] << 16) | ((u64)o[2] << 32) | ((u64)o[3] << 48);
+                    }
+                }
+            }
+            te_sync();                                               // attention output ready
+            TE_STAMP(7);
+            // ================= o_proj slice, residual -> edge 2
+            te_sync();                                               // red ready
+            TE_STAMP(8);
+            {
+                u64* buf = p.xbuf + (size_t)(edge & 1u) * TE_XG;
+                publish_resid(buf);
+                TE_STAMP(9);
+                if (!te_edge(p, edge, W, L.s_ok)) { if (tid == 0) *p.fail = 1u; return; }
+                TE_STAMP(10);
+                gather_h(buf);
+            }
+            te_sync();
+            TE_STAMP(11);
+            // ================= gate|up pairs -> SwiGLU -> edge 3
+            te_sync();                                               // red ready
+            TE_STAMP(12);
+            {
+                u64* buf = p.xbuf + (size_t)(edge & 1u) * TE_XG;
                 {
-                    const int l16 = tid & 15, slot = tid >> 4;
-                    constexpr int G = S::H / S::Hkv;
-                    for (int kh = 0; kh < S::Hkv; ++kh) {
-                        float qr[G][8];
-#pragma unroll
-                        for (int g = 0; g < G; ++g)
-#pragma unroll
-                            for (int e = 0; e < 8; ++e) qr[g][e] = qh[kh * G + g][8 * l16 + e];
-                        for (int j0 = 0; j0 < ctx; j0 += TE_NT / 16) {
-                            const int j = j0 + slot;
-                            const int jc = j < ctx ? j : ctx - 1;
-                            float kf[8];
-                            if (jc == pos) {
-#pragma unroll
-                                for (int e = 0; e < 8; ++e) kf[e] = knew[kh * S::D + 8 * l16 + e];
-                            } else {
-                                const bf16x8_t kk = *reinterpret_cast<const bf16x8_t*>(kc + (size_t)jc * (S::Hkv * S::D) + kh * S::D + 8 * l16);
-#pragma unroll
-                                for (int e = 0; e < 8; ++e) kf[e] = bf16_to_f32((bf16_t)kk[e]);
-                            }
-#pragma unroll
-                            for (int g = 0; g < G; ++g) {
-                                float dsum = 0.f;
-#pragma unroll
-                                for (int e = 0; e < 8; ++e) dsum += qr[g][e] * kf[e];
-                                dsum += __shfl_xor(dsum, 1, 64); dsum += __shfl_xor(dsum, 2, 64);
-                                dsum += __shfl_xor(dsum, 4, 64); dsum += __shfl_xor(dsum, 8, 64);
-                                if (l16 == 0 && j < ctx) sc[kh * G + g][j] = dsum * scale;
-                            }
-                        }
-                    }
-                }
-                __syncthreads();
-                if (wave < S::H) {                                               // softmax of one head per wave
-                    float m = -3.0e38f;
-                    for (int j = lane; j < ctx; j += 64) m = fmaxf(m, sc[wave][j]);
-                    m = wave_max(m);
-                    float sum = 0.f;
-                    for (int j = lane; j < ctx; j += 64) { const float e = expf(sc[wave][j] - m); sc[wave][j] = e; sum += e; }
-                    sum = wave_sum(sum);
-                    const float rinv = 1.0f / sum;
-                    for (int j = lane; j < ctx; j += 64) sc[wave][j] *= rinv;
-                }
-                __syncthreads();
-                {   // P.V: thread (head, d)
-                    const int hh = tid / S::D, dd = tid % S::D, kh = hh / (S::H / S::Hkv);
-                    float acc = 0.f;
-                    const bf16_t* vcol = vc + kh * S::D + dd;
-                    int j = 0;
-                    for (; j + 4 <= pos; j += 4) {
-                        const float v0 = bf16_to_f32(vcol[(size_t)(j + 0) * (S::Hkv * S::D)]), v1 = bf16_to_f32(vcol[(size_t)(j + 1) * (S::Hkv * S::D)]);
-                        const float v2 = bf16_to_f32(vcol[(size_t)(j + 2) * (S::Hkv * S::D)]), v3 = bf16_to_f32(vcol[(size_t)(j + 3) * (S::Hkv * S::D)]);
-                        acc += sc[hh][j] * v0; acc += sc[hh][j + 1] * v1; acc += sc[hh][j + 2] * v2; acc += sc[hh][j + 3] * v3;
-                    }
-                    for (; j < pos; ++j) acc += sc[hh][j] * bf16_to_f32(vcol[(size_t)j * (S::Hkv * S::D)]);
-                    acc += sc[hh][pos] * vnew[kh * S::D + dd];
-                    xb[hh * S::D + dd] = f32_to_bf16(acc);
-                }
-                __syncthreads();
-                int nt[R_O];
-#pragma unroll
-                for (int r = 0; r < R_O; ++r) nt[r] = (w + r * W) < S::d / 16 ? w + r * W : -1;
-                te_gemv<R_O, KPW_HD>(p.wo + (size_t)li * S::d * S::HD, S::HD / 32, nt, xb, red, wave, lane);
-                __syncthreads();
-                u64* buf = p.xbuf + (size_t)(edge & 1u) * TE_XG;
-                if (tid < R_O * 4) {
-                    const int r = tid >> 2, g = tid & 3;
-                    if (nt[r] >= 0) {
-                        float o[4];
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) o[e] = hf[nt[r] * 16 + 4 * g + e] + bf16_round_f32(te_combine<R_O>(red, r, 4 * g + e));
-                        __hip_atomic_store(buf + nt[r] * 4 + g, te_pack4(o[0], o[1], o[2], o[3]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    }
-                }
-                if (!te_meet(p, edge, W, &s_ok)) { if (tid == 0) *p.fail = 1u; return; }
-                if (tid < S::d / 4) {
-                    const u64 gq = __hip_atomic_load(buf + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) hf[4 * tid + e] = bf16_to_f32((bf16_t)(gq >> (16 * e)));
-                }
-                __syncthreads();
-            }
-            // ================= RMSNorm -> gate|up pairs -> SwiGLU -> edge 3
-            {
-                const bf16_t* wn = p.norms + (size_t)(2 * li + 1) * S::d;
-                float v = tid < S::d ? hf[tid] : 0.f;
-                const float ss = te_block_sum(v * v, s_red, wave, lane);
-                const float inv = rsqrtf(ss / (float)S::d + p.eps);
-                if (tid < S::d) xb[tid] = f32_to_bf16(bf16_to_f32(wn[tid]) * bf16_round_f32(v * inv));
-                __syncthreads();
-                int nt[R_GU];
-#pragma unroll
-                for (int r = 0; r < P_GU; ++r) {
-                    const int pr = w + r * W;
-                    nt[2 * r] = pr < S::ff / 16 ? 2 * pr : -1;
-                    nt[2 * r + 1] = pr < S::ff / 16 ? 2 * pr + 1 : -1;
-                }
-                te_gemv<R_GU, KPW_D>(p.wgu + (size_t)li * 2 * S::ff * S::d, S::d / 32, nt, xb, red, wave, lane);
-                __syncthreads();
-                u64* buf = p.xbuf + (size_t)(edge & 1u) * TE_XG;
-                if (tid < P_GU * 4) {
-                    const int r = tid >> 2, g = tid & 3;
-                    if (nt[2 * r] >= 0) {
-                        float a[4];
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) {
-                            const float gt = bf16_round_f32(te_combine<R_GU>(red, 2 * r, 4 * g + e)), up = bf16_round_f32(te_combine<R_GU>(red, 2 * r + 1, 4 * g + e));
+                    float v = 0.f;
+                    int gr = -1;
+                    if (tid < P_GU * 16) {
+                        const int r = tid >> 4, i = tid & 15, pr = w + r * W;
+                        if (pr < S::ff / 16) {
+                            const float gt = bf16_round_f32(te_combine<R_GU>(L.red, 2 * r, i)), up = bf16_round_f32(te_combine<R_GU>(L.red, 2 * r + 1, i));
                             const float sg = bf16_round_f32(1.0f / (1.0f + expf(-gt)));
-                            a[e] = bf16_round_f32(gt * sg) * up;
+                            v = bf16_round_f32(gt * sg) * up;
+                            gr = pr * 4;
                         }
-                        __hip_atomic_store(buf + (nt[2 * r] >> 1) * 4 + g, te_pack4(a[0], a[1], a[2], a[3]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     }
+                    publish4(buf, P_GU * 16, v, gr);
                 }
-                if (!te_meet(p, edge, W, &s_ok)) { if (tid == 0) *p.fail = 1u; return; }
-                for (int gi = tid; gi < S::ff / 4; gi += TE_NT)
-                    *reinterpret_cast<u64*>(xb + 4 * gi) = __hip_atomic_load(buf + gi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                __syncthreads();
+                TE_STAMP(13);
+                if (!te_edge(p, edge, W, L.s_ok)) { if (tid == 0) *p.fail = 1u; return; }
+                TE_STAMP(14);
+                for (int gi = tid; gi < S::ff / 4; gi += TE_VW * 64)
+                    *reinterpret_cast<u64*>(L.xb + 4 * gi) = __hip_atomic_load(buf + gi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
+            te_sync();                                               // activation gathered
+            TE_STAMP(15);
             // ================= down_proj slice, residual -> edge 4
+            te_sync();                                               // red ready
+            TE_STAMP(16);
             {
-                int nt[R_O];
-#pragma unroll
-                for (int r = 0; r < R_O; ++r) nt[r] = (w + r * W) < S::d / 16 ? w + r * W : -1;
-                te_gemv<R_O, KPW_FF>(p.wdown + (size_t)li * S::d * S::ff, S::ff / 32, nt, xb, red, wave, lane);
-                __syncthreads();
                 u64* buf = p.xbuf + (size_t)(edge & 1u) * TE_XG;
-                if (tid < R_O * 4) {
-                    const int r = tid >> 2, g = tid & 3;
-                    if (nt[r] >= 0) {
-                        float o[4];
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) o[e] = hf[nt[r] * 16 + 4 * g + e] + bf16_round_f32(te_combine<R_O>(red, r, 4 * g + e));
-                        __hip_atomic_store(buf + nt[r] * 4 + g, te_pack4(o[0], o[1], o[2], o[3]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    }
-                }
-                if (!te_meet(p, edge, W, &s_ok)) { if (tid == 0) *p.fail = 1u; return; }
-                if (tid < S::d / 4) {
-                    const u64 gq = __hip_atomic_load(buf + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) hf[4 * tid + e] = bf16_to_f32((bf16_t)(gq >> (16 * e)));
-                }
-                __syncthreads();
+                publish_resid(buf);
+                TE_STAMP(17);
+                if (!te_edge(p, edge, W, L.s_ok)) { if (tid == 0) *p.fail = 1u; return; }
+                TE_STAMP(18);
+                gather_h(buf);
             }
+            te_sync();
+            TE_STAMP(19);
         }
-        // ================= final norm -> output projection slice -> arg-max -> edge 5
+        // ================= final norm (hidden tap) -> output projection slice -> arg-max -> edge 5
         {
-            const bf16_t* wn = p.norms + (size_t)(2 * p.L) * S::d;
-            float v = tid < S::d ? hf[tid] : 0.f;
-            const float ss = te_block_sum(v * v, s_red, wave, lane);
-            const float inv = rsqrtf(ss / (float)S::d + p.eps);
-            if (tid < S::d) {
-                const bf16_t xo = f32_to_bf16(bf16_to_f32(wn[tid]) * bf16_round_f32(v * inv));
-                xb[tid] = xo;
-                if (p.hidden_out && w == 0) p.hidden_out[(size_t)t * S::d + tid] = bf16_to_f32(xo);
-            }
-            __syncthreads();
-            const int NTV = p.Vpad / 16;
-            u64 cand = 0;
-            // (the worker's tile rows in passes of R_HEAD: 16 rows at once need 128 registers of tiles in flight and spill)
-            for (int pass = 0; pass * R_HEAD * W < NTV; ++pass) {
-                int nt[R_HEAD];
+            if (p.hidden_out && w == 0 && tid < S::d / 4) {
+                const float inv = rsqrtf(((L.s_ss[0] + L.s_ss[1]) + (L.s_ss[2] + L.s_ss[3])) / (float)S::d + p.eps);
+                const bf16_t* wn = p.norms + (size_t)(2 * p.L) * S::d;
 #pragma unroll
-                for (int r = 0; r < R_HEAD; ++r) nt[r] = (w + (pass * R_HEAD + r) * W) < NTV ? w + (pass * R_HEAD + r) * W : -1;
-                te_gemv<R_HEAD, KPW_D>(p.head, S::d / 32, nt, xb, red, wave, lane);
-                __syncthreads();
+                for (int e = 0; e < 4; ++e)
+                    p.hidden_out[(size_t)t * S::d + 4 * tid + e] = bf16_round_f32(bf16_to_f32(wn[4 * tid + e]) * bf16_round_f32(L.hf[4 * tid + e] * inv));
+            }
+            u64 cand = 0;
+            for (int pass = 0; pass * R_HEAD * W < NTV; ++pass) {
+                te_sync();                                           // red ready
                 if (tid < R_HEAD * 16) {
-                    const int r = tid >> 4, i = tid & 15;
-                    if (nt[r] >= 0) {
-                        const int n = nt[r] * 16 + i;
-                        const float lg = bf16_round_f32(te_combine<R_HEAD>(red, r, i));
+                    const int r = tid >> 4, i = tid & 15, nt = w + (pass * R_HEAD + r) * W;
+                    if (nt < NTV) {
+                        const int n = nt * 16 + i;
+                        const float lg = bf16_round_f32(te_combine<R_HEAD>(L.red, r, i));
                         if (n < p.V) {
                             if (p.logits_out) p.logits_out[(size_t)t * p.V + n] = lg;
                             const u64 c1 = ((u64)te_key(lg) << 32) | (u64)(0xffffffffu - (unsigned)n);      // highest logit, lowest id on ties
@@ -425,36 +708,72 @@ __global__ void __launch_bounds__(TE_NT) k_token_engine(TeParams p) {
                         }
                     }
                 }
-                __syncthreads();
+                te_sync();                                           // red consumed
             }
 #pragma unroll
             for (int o = 32; o > 0; o >>= 1) { const u64 other = __shfl_xor(cand, o, 64); cand = other > cand ? other : cand; }
-            if (lane == 0) s_cand[wave] = cand;
-            __syncthreads();
+            if (lane == 0) L.s_cand[wave] = cand;
+            te_sync();                                               // candidates of the vector waves
             u64* buf = p.xbuf + (size_t)(edge & 1u) * TE_XG;
             if (tid == 0) {
                 u64 best = 0;
 #pragma unroll
-                for (int q = 0; q < TE_NW; ++q) best = s_cand[q] > best ? s_cand[q] : best;
+                for (int q = 0; q < TE_VW; ++q) best = L.s_cand[q] > best ? L.s_cand[q] : best;
                 __hip_atomic_store(buf + w, best, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
-            if (!te_meet(p, edge, W, &s_ok)) { if (tid == 0) *p.fail = 1u; return; }
-            u64 c2 = tid < W ? __hip_atomic_load(buf + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (!te_edge(p, edge, W, L.s_ok)) { if (tid == 0) *p.fail = 1u; return; }
+            {
+                u64 c2 = tid < W ? __hip_atomic_load(buf + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
 #pragma unroll
-            for (int o = 32; o > 0; o >>= 1) { const u64 other = __shfl_xor(c2, o, 64); c2 = other > c2 ? other : c2; }
-            if (lane == 0) s_cand[wave] = c2;
-            __syncthreads();
+                for (int o = 32; o > 0; o >>= 1) { const u64 other = __shfl_xor(c2, o, 64); c2 = other > c2 ? other : c2; }
+                if (lane == 0) L.s_cand[wave] = c2;
+            }
+            te_sync();                                               // candidates gathered
             if (tid == 0) {
                 u64 best = 0;
 #pragma unroll
-                for (int q = 0; q < TE_NW; ++q) best = s_cand[q] > best ? s_cand[q] : best;
+                for (int q = 0; q < TE_VW; ++q) best = L.s_cand[q] > best ? L.s_cand[q] : best;
                 const int next = (int)(0xffffffffu - (unsigned)(best & 0xffffffffull));
-                s_tok = next;
+                if (t + 1 >= p.n_prompt) *L.s_tok = next;
                 if (w == 0) p.next_tokens[t] = next;
             }
-            __syncthreads();
         }
     }
+}
+
+template <int XCDS>
+__global__ void __launch_bounds__(TE_NT) k_token_engine(TeParams p) {
+    using S = TeShape;
+    using Dm = TeDims<XCDS>;
+    static_assert(S::H == TE_VW && S::Hkv == 1 && S::D == 128 && S::d / 4 <= 128 && S::Nqkv / 4 <= TE_VW * 64, "vector-wave mapping of the engine");
+    extern __shared__ __attribute__((aligned(16))) unsigned char te_lds_pad[];      // (requested size keeps the launch at one block per CU)
+    __shared__ __attribute__((aligned(16))) float hf[S::d];
+    __shared__ __attribute__((aligned(16))) bf16_t xb[S::ff > S::HD ? S::ff : S::HD];
+    __shared__ __attribute__((aligned(16))) float qkvf[S::Nqkv];
+    __shared__ __attribute__((aligned(16))) float qh[S::H * S::D];
+    __shared__ __attribute__((aligned(16))) float knew[S::D], vnew[S::D];
+    __shared__ __attribute__((aligned(16))) float sc[S::H * TE_CTX];
+    __shared__ __attribute__((aligned(16))) bf16_t ph[S::H * TE_CTX], pl[S::H * TE_CTX];
+    __shared__ __attribute__((aligned(16))) bf16_t stage[Dm::R_RED * 16];
+    __shared__ __attribute__((aligned(16))) float red[TE_MW * Dm::R_RED * 16];
+    __shared__ float s_ss[TE_VW];
+    __shared__ u64 s_cand[TE_VW];
+    __shared__ int s_ok;
+    __shared__ int s_tok;
+    if (p.n_total < 0) te_lds_pad[threadIdx.x] = 0;
+    const int b = blockIdx.x;
+    if ((b & 7) >= XCDS) return;
+    const int w = (b >> 3) * XCDS + (b & 7);
+    const int tid = threadIdx.x, wave = tid >> 6;
+    if (tid < TE_VW) s_ss[tid] = 0.f;
+    if (tid == 0) { s_ok = 1; s_tok = 0; }
+    const TeLds L{hf, xb, qkvf, qh, knew, vnew, sc, ph, pl, stage, red, s_ss, s_cand, &s_ok, &s_tok};
+    te_sync();
+    // (the wave index as a SCALAR: every tile address is then scalar base + one shared lane offset.  With a vector wave index the
+    // compiler keeps a 64-bit address pair per tile live across the layer loop - ~200 registers of addresses, everything spills)
+    if (wave >= TE_VW) te_matrix_role<XCDS>(p, L, w, __builtin_amdgcn_readfirstlane(wave - TE_VW), tid & 63);     // waves 4..7: weight tiles and MFMAs
+    else te_vector_role<XCDS>(p, L, w, tid);                                         // waves 0..3: everything else
 }
 }   // namespace
 
@@ -490,12 +809,13 @@ extern "C" mis_status mis_debug_token_engine(mis_tts* lm, const int32_t* prompt,
     DevBuf<u64> d_x;
     DevBuf<unsigned> d_sync;
     d_prompt.alloc(n_prompt); d_next.alloc(n_total);
-    d_kv.alloc((size_t)W * v.L * 2 * TE_CTX * (S::Hkv * S::D));
+    d_kv.alloc((size_t)v.L * 2 * TE_CTX * (S::Hkv * S::D));
     d_x.alloc(2 * TE_XG); d_sync.alloc(64);
     if (logits_out) d_logits.alloc((size_t)n_total * v.V);
     if (hidden_out) d_hidden.alloc((size_t)n_total * S::d);
     HIP_CHECK(hipMemcpyAsync(d_prompt.p, hp.data(), (size_t)n_prompt * 4, hipMemcpyHostToDevice, s));
     HIP_CHECK(hipMemsetAsync(d_sync.p, 0, 64 * sizeof(unsigned), s));
+    HIP_CHECK(hipMemsetAsync(d_kv.p, 0, d_kv.bytes(), s));          // (the transposed value rows are read in 32-key steps: unwritten positions x 0 must be finite)
     HIP_CHECK(hipMemsetAsync(d_x.p, 0, 2 * TE_XG * sizeof(u64), s));
     HIP_CHECK(hipMemsetAsync(d_next.p, 0, (size_t)n_total * 4, s));
     TeParams p{};
@@ -504,6 +824,13 @@ extern "C" mis_status mis_debug_token_engine(mis_tts* lm, const int32_t* prompt,
     p.prompt = d_prompt.p; p.n_prompt = n_prompt; p.n_total = n_total; p.next_tokens = d_next.p;
     p.logits_out = logits_out ? d_logits.p : nullptr; p.hidden_out = hidden_out ? d_hidden.p : nullptr;
     p.kv = d_kv.p; p.xbuf = d_x.p; p.counter = d_sync.p; p.fail = d_sync.p + 32; p.xcds = xcds; p.spin = 1 << 20;
+    DevBuf<u64> d_dbg;
+    const char* stamp_env = getenv("MIS_TE_STAMPS");
+    if (stamp_env) {
+        d_dbg.alloc(32);
+        HIP_CHECK(hipMemsetAsync(d_dbg.p, 0, 32 * 8, s));
+        p.dbg = d_dbg.p; p.dbg_token = atoi(stamp_env);
+    }
     const size_t pad = 64 * 1024;                                        // with the static arrays: more than half a CU's LDS -> one block per CU
     static bool attr_done[3] = {false, false, false};
     if (!attr_done[xcds]) {
@@ -529,5 +856,15 @@ extern "C" mis_status mis_debug_token_engine(mis_tts* lm, const int32_t* prompt,
     if (logits_out) HIP_CHECK(hipMemcpy(logits_out, d_logits.p, (size_t)n_total * v.V * 4, hipMemcpyDeviceToHost));
     if (hidden_out) HIP_CHECK(hipMemcpy(hidden_out, d_hidden.p, (size_t)n_total * S::d * 4, hipMemcpyDeviceToHost));
     if (ms_out) *ms_out = ms;
+    if (stamp_env) {
+        u64 st[32];
+        HIP_CHECK(hipMemcpy(st, d_dbg.p, sizeof(st), hipMemcpyDeviceToHost));
+        static const char* names[20] = {"layer start", "qkv: red ready", "published", "edge 1 passed", "q|k|v gathered", "q/k-norm + RoPE", "scores",
+                                        "softmax + P.V", "o: red ready", "published", "edge 2 passed", "h gathered", "gate|up: red ready", "published",
+                                        "edge 3 passed", "act gathered", "down: red ready", "published", "edge 4 passed", "h gathered"};
+        fprintf(stderr, "token engine, %d XCD(s), position %d, layer 1, worker 0 (shader cycles since layer start, delta):\n", xcds, p.dbg_token);
+        for (int i = 0; i < 20; ++i)
+            fprintf(stderr, "  %2d %-20s %8llu %6lld\n", i, names[i], (unsigned long long)(st[i] - st[0]), i ? (long long)(st[i] - st[i - 1]) : 0ll);
+    }
     MIS_API_END
 }
