@@ -30,6 +30,7 @@
 // reads the product handle's weights, so its logits are compared with the product's and the oracle's (tests/test_gpu_token_engine.py).
 #include "common.h"
 #include "kernels.h"
+#include <type_traits>
 
 namespace {
 typedef unsigned long long u64;
@@ -41,7 +42,8 @@ struct TeShape {
 constexpr int TE_NT = 512;                     // threads per worker: TE_VW vector waves + TE_MW matrix waves
 constexpr int TE_VW = 4, TE_MW = 4;
 constexpr int TE_CTX = 512;                    // positions per request (scores in LDS)
-constexpr int TE_XG = 1024;                    // granules per exchange buffer (4096 bf16 values)
+constexpr int TE_KPRE = 2, TE_VPRE = 4;        // key tiles per wave / 32-key value steps requested before the layer's first poll (128 positions)
+constexpr int TE_XG = 2048;                    // granules per exchange buffer (two bf16 values + the edge's tag each)
 
 struct TeParams {
     const bf16_t *emb, *wqkv, *wo, *wgu, *wdown, *head, *norms, *qknorm;
@@ -55,7 +57,6 @@ struct TeParams {
     float* hidden_out;          // [n_total][d] or null (final-norm output: what Soprano's decoder consumes)
     bf16_t* kv;                 // the K/V copy [L][2][TE_CTX][Hkv*D] (every worker writes the same bytes, see te_vector_role)
     u64* xbuf;                  // [2][TE_XG]
-    unsigned* counter;          // monotonic arrivals
     unsigned* fail;             // set when a poll ran out (workers not co-resident)
     int xcds, spin;
     u64* dbg;                   // diagnostics (MIS_TE_STAMPS=<position>): cycle stamps of worker 0 at the phase boundaries of layer 1 of that position
@@ -99,25 +100,6 @@ __device__ __forceinline__ float te_wave_max_dpp(float x) {
 // the matrix waves wait for every weight tile they have just requested for the NEXT phase.  Global-memory ordering is handled where it is
 // needed (the publishers' own s_waitcnt vmcnt(0) before an edge).
 __device__ __forceinline__ void te_sync() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
-
-// ---- one edge, second half: every publisher has drained its stores (and passed the barrier in front of this call); thread 0 arrives on
-// the monotonic counter and polls it (bounded) until all W workers of this edge are there
-__device__ __forceinline__ bool te_edge(const TeParams& p, unsigned& edge, int W, int* s_ok) {
-    te_sync();
-    if (threadIdx.x == 0) {
-        __hip_atomic_fetch_add(p.counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const unsigned target = (unsigned)W * (edge + 1u);
-        int ok = 0;
-        for (int it = 0; it < p.spin; ++it) {
-            if ((int)(__hip_atomic_load(p.counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - target) >= 0) { ok = 1; break; }
-            __builtin_amdgcn_s_sleep(1);
-        }
-        *s_ok = ok;
-    }
-    te_sync();
-    edge += 1u;
-    return *s_ok != 0;
-}
 
 // ---- matrix waves.  A worker's slice of y = W x is R tile rows (ids nt[r], -1 = none); each of the TE_MW matrix waves takes a quarter of
 // the KT k-tiles of every row and holds them in registers: requested one phase AHEAD (right after the previous phase's MFMAs), so that the
@@ -238,7 +220,7 @@ struct TeLds {
     bf16_t* stage;      // [R x 16] one epilogue value per thread before four of them are packed into a granule
     float* red;         // [TE_MW][R][16] partial sums of the matrix waves
     float* s_ss;        // [TE_VW] sum-of-squares partials of the residual stream
-    u64* s_cand;        // [TE_VW]
+    u64* s_cand;        // [2][TE_VW] the waves' best candidates: own slice, then all workers'
     int *s_ok, *s_tok;
 };
 template <int XCDS>
@@ -250,11 +232,12 @@ struct TeDims {
     static constexpr int KPW_D = (S::d / 32 + TE_MW - 1) / TE_MW, KPW_HD = (S::HD / 32 + TE_MW - 1) / TE_MW, KPW_FF = (S::ff / 32 + TE_MW - 1) / TE_MW;
     static constexpr int R_RED = R_GU > R_HEAD ? R_GU : R_HEAD;
 };
-#define TE_EDGE_OR_RETURN() do { te_sync(); te_sync(); if (!*L.s_ok) return; } while (0)      /* matrix side of te_edge */
-
 // ---------------------------------------------------------------------------- the matrix waves' program.  Every te_sync() here has its
 // partner at the same place of te_vector_role (the two programs are listed phase by phase in the same order); between barriers these
-// waves only touch their weight tiles, the GEMV inputs in LDS and `red`.
+// waves only touch their weight tiles, the GEMV inputs in LDS and `red`.  Where the tiles of a phase are requested: as late as the
+// registers demand (gate|up's 176 registers can only be filled once q|k|v's and before down's), and in PIECES sized to the vector waves'
+// work behind each barrier - a wave stays in the issue loop while the CU's memory queue is full (one XCD streams 40 GB/s per CU: 24 KB
+// per piece = 0.6 us), and everybody waits for it at the next barrier.
 template <int XCDS>
 __device__ __forceinline__ void te_matrix_role(const TeParams& p, const TeLds& L, const int w_in, const int mw_in, const int lane) {
     using S = TeShape;
@@ -272,9 +255,9 @@ __device__ __forceinline__ void te_matrix_role(const TeParams& p, const TeLds& L
         NT[2 * r] = pr < S::ff / 16 ? 2 * pr : -1; NT[2 * r + 1] = pr < S::ff / 16 ? 2 * pr + 1 : -1; }
 #define TE_ROWS_HEAD(NT, PASS) int NT[R_HEAD]; _Pragma("unroll") for (int r = 0; r < R_HEAD; ++r)                                      \
         NT[r] = (wq + ((PASS) * R_HEAD + r) * W) < NTV ? wq + ((PASS) * R_HEAD + r) * W : -1
-    // piece k of n of a phase's N tiles
-#define TE_PIECE(N, k, n) ((N) * (k) / (n)), ((N) * ((k) + 1) / (n))
-    constexpr int N_Q = R_QKV * KPW_D, N_G = R_GU * KPW_D, N_D = R_O * KPW_FF, N_H = R_HEAD * KPW_D;
+    // tiles [N a / 40, N b / 40) of a phase's N
+#define TE_CUT(N, a, b) ((N) * (a) / 40), ((N) * (b) / 40)
+    constexpr int N_G = R_GU * KPW_D;
     TeTiles<R_QKV, KPW_D> tq;
     {
         TE_OPAQUE_IDS();
@@ -284,29 +267,20 @@ __device__ __forceinline__ void te_matrix_role(const TeParams& p, const TeLds& L
     for (int t = 0; t < p.n_total; ++t) {
         te_sync();                                                   // token id
         te_sync();                                                   // embedding row + sum of squares
-        // (the layer loop is rotated by the barriers of edge 4: the output projection's first tiles are requested AFTER the loop and still
-        // ahead of the last layer's edge 4 - loaded inside the loop's last iteration they would be live across the whole loop, 144
+        // (the layer loop is rotated by the last barrier of edge 4: the output projection's first tiles are requested AFTER the loop and
+        // still ahead of the last layer's edge 4 - loaded inside the loop's last iteration they would be live across the whole loop, 144
         // registers that the gate|up tiles need)
         for (int li = 0; li < p.L; ++li) {
             TeTiles<R_O, KPW_HD> to;
             TeTiles<R_GU, KPW_D> tg;
             TeTiles<R_O, KPW_FF> td;
-            const bf16_t* wq_l = p.wqkv + (size_t)li * S::Nqkv * S::d;
             const bf16_t* wg_l = p.wgu + (size_t)li * 2 * S::ff * S::d;
-            const bf16_t* wd_l = p.wdown + (size_t)li * S::d * S::ff;
             const bf16_t* n2_l = p.norms + (size_t)(2 * li + 1) * S::d;
-            if (li > 0) {   // (previous layer) edge 4 and the gather behind it; this layer's q|k|v tiles in four pieces behind its barriers
-                TE_OPAQUE_IDS();
-                TE_ROWS_QKV(nt);
-                te_load<R_QKV, KPW_D, true, TE_PIECE(N_Q, 1, 4)>(tq, wq_l, S::d / 32, nt, p.norms + (size_t)(2 * li) * S::d, mw, lane);
-                te_sync();
-                te_load<R_QKV, KPW_D, true, TE_PIECE(N_Q, 2, 4)>(tq, wq_l, S::d / 32, nt, p.norms + (size_t)(2 * li) * S::d, mw, lane);
-                te_sync();
+            if (li > 0) {
+                te_sync();                                           // (previous layer) edge 4: residual stream gathered
                 if (!*L.s_ok) return;
-                te_load<R_QKV, KPW_D, true, TE_PIECE(N_Q, 3, 4)>(tq, wq_l, S::d / 32, nt, p.norms + (size_t)(2 * li) * S::d, mw, lane);
-                te_sync();                                           // residual stream gathered
             }
-            {   // q|k|v; then o_proj's tiles and the first piece of gate|up
+            {   // q|k|v; then o_proj's tiles and the first quarter of gate|up's (the vector waves publish, wait for the slowest worker and gather)
                 TE_OPAQUE_IDS();
                 const float inv = rsqrtf(((L.s_ss[0] + L.s_ss[1]) + (L.s_ss[2] + L.s_ss[3])) / (float)S::d + p.eps);
                 bf16x8_t xf[KPW_D];
@@ -315,24 +289,17 @@ __device__ __forceinline__ void te_matrix_role(const TeParams& p, const TeLds& L
                 te_sync();                                           // red ready
                 TE_ROWS_O(nt);
                 te_load<R_O, KPW_HD, false>(to, p.wo + (size_t)li * S::d * S::HD, S::HD / 32, nt, nullptr, mw, lane);
-            }
-            {   // edge 1, the gather and the four barriers of the attention phase: gate|up's tiles in seven pieces
-                TE_OPAQUE_IDS();
-                TE_ROWS_GU(nt);
-                te_load<R_GU, KPW_D, true, TE_PIECE(N_G, 0, 7)>(tg, wg_l, S::d / 32, nt, n2_l, mw, lane);
-                te_sync();
-                te_load<R_GU, KPW_D, true, TE_PIECE(N_G, 1, 7)>(tg, wg_l, S::d / 32, nt, n2_l, mw, lane);
-                te_sync();
+                TE_ROWS_GU(ng);
+                te_load<R_GU, KPW_D, true, TE_CUT(N_G, 0, 10)>(tg, wg_l, S::d / 32, ng, n2_l, mw, lane);
+                te_sync();                                           // edge 1: q|k|v gathered
                 if (!*L.s_ok) return;
-                te_load<R_GU, KPW_D, true, TE_PIECE(N_G, 2, 7)>(tg, wg_l, S::d / 32, nt, n2_l, mw, lane);
-                te_sync();                                           // q|k|v gathered
-                te_load<R_GU, KPW_D, true, TE_PIECE(N_G, 3, 7)>(tg, wg_l, S::d / 32, nt, n2_l, mw, lane);
+                te_load<R_GU, KPW_D, true, TE_CUT(N_G, 10, 16)>(tg, wg_l, S::d / 32, ng, n2_l, mw, lane);
                 te_sync();                                           // q/k-norm + RoPE
-                te_load<R_GU, KPW_D, true, TE_PIECE(N_G, 4, 7)>(tg, wg_l, S::d / 32, nt, n2_l, mw, lane);
+                te_load<R_GU, KPW_D, true, TE_CUT(N_G, 16, 28)>(tg, wg_l, S::d / 32, ng, n2_l, mw, lane);
                 te_sync();                                           // scores
-                te_load<R_GU, KPW_D, true, TE_PIECE(N_G, 5, 7)>(tg, wg_l, S::d / 32, nt, n2_l, mw, lane);
+                te_load<R_GU, KPW_D, true, TE_CUT(N_G, 28, 34)>(tg, wg_l, S::d / 32, ng, n2_l, mw, lane);
                 te_sync();                                           // softmax
-                te_load<R_GU, KPW_D, true, TE_PIECE(N_G, 6, 7)>(tg, wg_l, S::d / 32, nt, n2_l, mw, lane);
+                te_load<R_GU, KPW_D, true, TE_CUT(N_G, 34, 40)>(tg, wg_l, S::d / 32, ng, n2_l, mw, lane);
                 te_sync();                                           // attention output ready
             }
             {   // o_proj (gate|up's 176 registers of tiles are live: nothing more can be requested before its MFMAs)
@@ -342,9 +309,9 @@ __device__ __forceinline__ void te_matrix_role(const TeParams& p, const TeLds& L
                 te_mma<R_O, KPW_HD>(to, xf, L.red, mw, lane);
                 te_sync();                                           // red ready
             }
-            TE_EDGE_OR_RETURN();                                     // edge 2
-            te_sync();                                               // residual stream gathered
-            {   // gate|up; then down_proj's tiles in four pieces behind edge 3 and its gather
+            te_sync();                                               // edge 2: residual stream gathered
+            if (!*L.s_ok) return;
+            {   // gate|up; then down_proj's tiles
                 TE_OPAQUE_IDS();
                 const float inv = rsqrtf(((L.s_ss[0] + L.s_ss[1]) + (L.s_ss[2] + L.s_ss[3])) / (float)S::d + p.eps);
                 bf16x8_t xf[KPW_D];
@@ -352,16 +319,11 @@ __device__ __forceinline__ void te_matrix_role(const TeParams& p, const TeLds& L
                 te_mma<R_GU, KPW_D>(tg, xf, L.red, mw, lane);
                 te_sync();                                           // red ready
                 TE_ROWS_O(nt);
-                te_load<R_O, KPW_FF, false, TE_PIECE(N_D, 0, 4)>(td, wd_l, S::ff / 32, nt, nullptr, mw, lane);
-                te_sync();
-                te_load<R_O, KPW_FF, false, TE_PIECE(N_D, 1, 4)>(td, wd_l, S::ff / 32, nt, nullptr, mw, lane);
-                te_sync();
+                te_load<R_O, KPW_FF, false>(td, p.wdown + (size_t)li * S::d * S::ff, S::ff / 32, nt, nullptr, mw, lane);
+                te_sync();                                           // edge 3: activation gathered
                 if (!*L.s_ok) return;
-                te_load<R_O, KPW_FF, false, TE_PIECE(N_D, 2, 4)>(td, wd_l, S::ff / 32, nt, nullptr, mw, lane);
-                te_load<R_O, KPW_FF, false, TE_PIECE(N_D, 3, 4)>(td, wd_l, S::ff / 32, nt, nullptr, mw, lane);
-                te_sync();                                           // activation gathered
             }
-            {   // down; the first piece of the next layer's q|k|v tiles (the other three: top of the loop)
+            {   // down; then the next layer's q|k|v tiles
                 TE_OPAQUE_IDS();
                 bf16x8_t xf[KPW_FF];
                 te_xfrag_bf16<KPW_FF>(xf, L.xb, S::ff / 32, mw, lane);
@@ -369,25 +331,20 @@ __device__ __forceinline__ void te_matrix_role(const TeParams& p, const TeLds& L
                 te_sync();                                           // red ready
                 if (li + 1 < p.L) {
                     TE_ROWS_QKV(nt);
-                    te_load<R_QKV, KPW_D, true, TE_PIECE(N_Q, 0, 4)>(tq, wq_l + (size_t)S::Nqkv * S::d, S::d / 32, nt, p.norms + (size_t)(2 * li + 2) * S::d, mw, lane);
+                    te_load<R_QKV, KPW_D, true>(tq, p.wqkv + (size_t)(li + 1) * S::Nqkv * S::d, S::d / 32, nt, p.norms + (size_t)(2 * li + 2) * S::d, mw, lane);
                 }
             }
         }
-        {   // output projection, passes of R_HEAD tile rows; the first pass's tiles behind the barriers of the last layer's edge 4
+        {   // output projection, passes of R_HEAD tile rows; the first pass's tiles behind the last layer's down_proj
             TeTiles<R_HEAD, KPW_D> th;
             int mw_h;
             {
                 TE_OPAQUE_IDS();
                 mw_h = mw;
                 TE_ROWS_HEAD(nth, 0);
-                const bf16_t* nf = p.norms + (size_t)(2 * p.L) * S::d;
-                te_load<R_HEAD, KPW_D, true, TE_PIECE(N_H, 0, 3)>(th, p.head, S::d / 32, nth, nf, mw, lane);
-                te_sync();
-                te_load<R_HEAD, KPW_D, true, TE_PIECE(N_H, 1, 3)>(th, p.head, S::d / 32, nth, nf, mw, lane);
-                te_sync();
+                te_load<R_HEAD, KPW_D, true>(th, p.head, S::d / 32, nth, p.norms + (size_t)(2 * p.L) * S::d, mw, lane);
+                te_sync();                                           // (last layer) edge 4: residual stream gathered
                 if (!*L.s_ok) return;
-                te_load<R_HEAD, KPW_D, true, TE_PIECE(N_H, 2, 3)>(th, p.head, S::d / 32, nth, nf, mw, lane);
-                te_sync();                                           // residual stream gathered
             }
             const float inv = rsqrtf(((L.s_ss[0] + L.s_ss[1]) + (L.s_ss[2] + L.s_ss[3])) / (float)S::d + p.eps);
             bf16x8_t xf[KPW_D];
@@ -406,105 +363,164 @@ __device__ __forceinline__ void te_matrix_role(const TeParams& p, const TeLds& L
                 te_sync();                                           // red consumed
             }
             te_sync();                                               // candidates of the vector waves
-            TE_EDGE_OR_RETURN();                                     // edge 5
-            te_sync();                                               // candidates gathered
+            te_sync();                                               // edge 5: candidates gathered
+            if (!*L.s_ok) return;
         }
     }
 }
 
 // ---------------------------------------------------------------------------- the vector waves' program (256 threads)
+// An EDGE (all-to-all hand-off of one op's output vector): every value travels in a self-validating 8-byte granule {two bf16 values, the
+// edge's 32-bit tag}, written with ONE agent-scope store by its producer and polled with agent-scope loads by every consumer thread
+// that needs it (MI355X_MICROARCH.md, hand-off form R2: "granule = one naturally aligned 8-byte {data, tag}") - no counter, no drain of
+// the producer's stores, no barrier between publishing and gathering: the consumer's load that finds the tag IS the gather.  Tags count
+// edges from 1 (buffers start zeroed); two buffers alternate - a worker can only publish edge e + 2 after it has gathered all of edge
+// e + 1, which every worker publishes only after it has gathered edge e.  Polls are bounded: a time-out clears s_ok, and both programs
+// leave at the next barrier.  (Round 5's first form - values, store drain, barrier, arrival counter, poll, barrier, gather - cost
+// 3.7 + 1.9 us per edge inside the engine, three barriers of it shared with the matrix waves.)
 template <int XCDS>
 __device__ __forceinline__ void te_vector_role(const TeParams& p, const TeLds& L, const int w, const int tid) {
     using S = TeShape;
     using Dm = TeDims<XCDS>;
     constexpr int W = Dm::W, R_QKV = Dm::R_QKV, R_O = Dm::R_O, P_GU = Dm::P_GU, R_GU = Dm::R_GU, R_HEAD = Dm::R_HEAD;
+    constexpr int VT = TE_VW * 64;
     const int wave = tid >> 6, lane = tid & 63;
     const int NTV = p.Vpad / 16;
-    unsigned edge = 0;
+    unsigned edge = 0;                                               // edges passed so far; the current edge's tag is edge + 1
     // ONE K/V copy for all workers, written by every one of them: the new row is computed redundantly from the same gathered q|k|v by
-    // the same instructions, so all writers store identical bytes; a worker only ever reads rows it has itself written at an earlier
-    // position (rows are 256 B = whole cache lines), so no CU can hold a stale line.  (Private copies - 32 x 17 x 2 x ctx x 256 B - do not
-    // fit the XCD's 4 MB L2: every row came from the Infinity Cache, ~2 us per round trip under the weight stream.)
+    // the same instructions, so all writers store identical bytes, and a worker only consumes positions it has itself written at an
+    // earlier step.  (Private copies - 32 x 17 x 2 x ctx x 256 B - do not fit the XCD's 4 MB L2: every row came from the Infinity
+    // Cache, ~2 us per round trip under the weight stream.)
     bf16_t* kv_mine = p.kv;
     const float scale = rsqrtf((float)S::D);
     float(*qh)[S::D] = reinterpret_cast<float(*)[S::D]>(L.qh);
     float(*sc)[TE_CTX] = reinterpret_cast<float(*)[TE_CTX]>(L.sc);
-    // gather of the residual stream: 4 values per thread (tid < d / 4) + their sum of squares per wave
-    auto gather_h = [&](const u64* buf) {
-        if (tid < S::d / 4) {
-            const u64 gq = __hip_atomic_load(buf + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            float ss = 0.f;
+    auto granule = [&](const u64* buf, int gi, unsigned tag) -> uint32_t {         // poll granule gi until it carries `tag`; its two values
+        u64 g = __hip_atomic_load(buf + gi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        int it = 0;
+        while ((unsigned)(g >> 32) != tag) {
+            if (++it > p.spin) { *L.s_ok = 0; break; }
+            __builtin_amdgcn_s_sleep(1);
+            g = __hip_atomic_load(buf + gi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        return (uint32_t)g;
+    };
+    // the same for the NG granules tid, tid + VT, ... of a vector of n granules: all first polls in flight together (a thread that polls
+    // its granules one after the other pays a memory round trip for each: 5 for the activation vector)
+    auto granules = [&](const u64* buf, int n, unsigned tag, auto&& NGc, auto&& sink) {
+        constexpr int NG = std::remove_reference_t<decltype(NGc)>::value;
+        u64 g[NG];
 #pragma unroll
-            for (int e = 0; e < 4; ++e) { const float v = bf16_to_f32((bf16_t)(gq >> (16 * e))); L.hf[4 * tid + e] = v; ss += v * v; }
-            ss = wave_sum_dpp(ss);
-            if (lane == 0) L.s_ss[wave] = ss;
+        for (int k = 0; k < NG; ++k) { const int gi = tid + k * VT; g[k] = __hip_atomic_load(buf + (gi < n ? gi : 0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+#pragma unroll
+        for (int k = 0; k < NG; ++k) {
+            const int gi = tid + k * VT;
+            if (gi < n) {
+                uint32_t v = (uint32_t)g[k];
+                if ((unsigned)(g[k] >> 32) != tag) v = granule(buf, gi, tag);
+                sink(gi, v);
+            }
         }
     };
-    // One epilogue value per thread (tid < n_vals, value index tid = 16 r + i), four consecutive ones packed into a granule by the first
-    // thread of each quad through LDS (the quad sits in one wave: its own s_waitcnt orders the write before the read).  `granule_of(r)` =
-    // first granule of tile row r in the edge's vector, or -1.
-    auto publish4 = [&](u64* buf, int n_vals, float value, int first_granule) {
+    // One epilogue value per thread (tid < n_vals, value index tid = 16 r + i); the even thread of each pair sends both (through LDS: the
+    // pair sits in one wave, whose own s_waitcnt orders the write before the read).  first_pair = granule index of value 16 r, or -1.
+    auto publish2 = [&](u64* buf, int n_vals, float value, int first_pair, unsigned tag) {
         if (tid < n_vals) L.stage[tid] = f32_to_bf16(value);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        if (tid < n_vals && (tid & 3) == 0 && first_granule >= 0)
-            __hip_atomic_store(buf + first_granule + ((tid & 15) >> 2), *reinterpret_cast<const u64*>(L.stage + tid), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (tid < n_vals && (tid & 1) == 0 && first_pair >= 0)
+            __hip_atomic_store(buf + first_pair + ((tid & 15) >> 1), (u64)*reinterpret_cast<const uint32_t*>(L.stage + tid) | ((u64)tag << 32),
+                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    };
+    // gather of the residual stream (d values = d / 2 granules, one per thread) + its sum of squares per wave
+    auto gather_h = [&](const u64* buf, unsigned tag) {
+        float ss = 0.f;
+        if (tid < S::d / 2) {
+            const uint32_t g2 = granule(buf, tid, tag);
+            const float v0 = bf16_to_f32((bf16_t)(g2 & 0xffffu)), v1 = bf16_to_f32((bf16_t)(g2 >> 16));
+            L.hf[2 * tid] = v0; L.hf[2 * tid + 1] = v1;
+            ss = v0 * v0 + v1 * v1;
+        }
+        ss = wave_sum_dpp(ss);
+        if (lane == 0) L.s_ss[wave] = ss;
     };
     // residual epilogue of o_proj / down_proj: this worker's R_O x 16 outputs, T(h + T(acc))
-    auto publish_resid = [&](u64* buf) {
+    auto publish_resid = [&](u64* buf, unsigned tag) {
         float v = 0.f;
         int gr = -1;
         if (tid < R_O * 16) {
             const int r = tid >> 4, i = tid & 15, nt = w + r * W;
-            if (nt < S::d / 16) { v = L.hf[nt * 16 + i] + bf16_round_f32(te_combine<R_O>(L.red, r, i)); gr = nt * 4; }
+            if (nt < S::d / 16) { v = L.hf[nt * 16 + i] + bf16_round_f32(te_combine<R_O>(L.red, r, i)); gr = nt * 8; }
         }
-        publish4(buf, R_O * 16, v, gr);
+        publish2(buf, R_O * 16, v, gr, tag);
     };
 #define TE_STAMP(i) do { if (p.dbg && w == 0 && tid == 0 && t == p.dbg_token && li == 1) p.dbg[i] = __builtin_readcyclecounter(); } while (0)
+#define TE_EDGE_BUF() (p.xbuf + (size_t)(edge & 1u) * TE_XG)
     for (int t = 0; t < p.n_total; ++t) {
         if (tid == 0 && t < p.n_prompt) *L.s_tok = p.prompt[t];
         te_sync();                                                   // token id
         {
             const int tok = *L.s_tok;
-            if (tid < S::d / 4) {
-                const u64 gq = *reinterpret_cast<const u64*>(p.emb + (size_t)tok * S::d + 4 * tid);
-                float ss = 0.f;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) { const float v = bf16_to_f32((bf16_t)(gq >> (16 * e))); L.hf[4 * tid + e] = v; ss += v * v; }
-                ss = wave_sum_dpp(ss);
-                if (lane == 0) L.s_ss[wave] = ss;
+            float ss = 0.f;
+            if (tid < S::d / 2) {
+                const uint32_t g2 = *reinterpret_cast<const uint32_t*>(p.emb + (size_t)tok * S::d + 2 * tid);
+                const float v0 = bf16_to_f32((bf16_t)(g2 & 0xffffu)), v1 = bf16_to_f32((bf16_t)(g2 >> 16));
+                L.hf[2 * tid] = v0; L.hf[2 * tid + 1] = v1;
+                ss = v0 * v0 + v1 * v1;
             }
+            ss = wave_sum_dpp(ss);
+            if (lane == 0) L.s_ss[wave] = ss;
         }
         te_sync();                                                   // embedding row + sum of squares
         const float rope_c = p.rope_cos[(size_t)t * (S::D / 2) + lane], rope_s = p.rope_sin[(size_t)t * (S::D / 2) + lane];     // this position's row
         for (int li = 0; li < p.L; ++li) {
+            bf16_t nw_q[2], nw_k[2];
+            bf16x8_t kpre[TE_KPRE][S::D / 32], vpre[TE_VPRE][2];
             // ================= q|k|v slice -> edge 1
             TE_STAMP(0);
             te_sync();                                               // red ready
             TE_STAMP(1);
             {
-                u64* buf = p.xbuf + (size_t)(edge & 1u) * TE_XG;
-                {
-                    float v = 0.f;
-                    int gr = -1;
-                    if (tid < R_QKV * 16) {
-                        const int r = tid >> 4, i = tid & 15, nt = w + r * W;
-                        if (nt < S::Nqkv / 16) { v = te_combine<R_QKV>(L.red, r, i); gr = nt * 4; }
-                    }
-                    publish4(buf, R_QKV * 16, v, gr);
+                u64* buf = TE_EDGE_BUF();
+                const unsigned tag = ++edge;
+                float v = 0.f;
+                int gr = -1;
+                if (tid < R_QKV * 16) {
+                    const int r = tid >> 4, i = tid & 15, nt = w + r * W;
+                    if (nt < S::Nqkv / 16) { v = te_combine<R_QKV>(L.red, r, i); gr = nt * 8; }
                 }
+                publish2(buf, R_QKV * 16, v, gr, tag);
                 TE_STAMP(2);
-                if (!te_edge(p, edge, W, L.s_ok)) { if (tid == 0) *p.fail = 1u; return; }
-                TE_STAMP(3);
-                if (tid < S::Nqkv / 4) {
-                    const u64 gq = __hip_atomic_load(buf + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                // everything the attention phase reads from memory that does not depend on this layer's q|k|v, requested BEFORE the poll:
+                // the q/k-norm weights, this wave's first TE_KPRE key tiles, the first TE_VPRE 32-key steps of its two value tiles
+                nw_q[0] = p.qknorm[(size_t)(2 * li) * S::D + lane]; nw_q[1] = p.qknorm[(size_t)(2 * li) * S::D + lane + 64];
+                nw_k[0] = p.qknorm[(size_t)(2 * li + 1) * S::D + lane]; nw_k[1] = p.qknorm[(size_t)(2 * li + 1) * S::D + lane + 64];
+                {
+                    const int i16 = lane & 15, q4 = lane >> 4, pos = t;
+                    const bf16_t* kcl = kv_mine + ((size_t)li * 2 + 0) * TE_CTX * S::D;
+                    const bf16_t* vcl = kv_mine + ((size_t)li * 2 + 1) * TE_CTX * S::D;
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) L.qkvf[4 * tid + e] = bf16_to_f32((bf16_t)(gq >> (16 * e)));
+                    for (int k = 0; k < TE_KPRE; ++k) {
+                        int row = 16 * (wave + TE_VW * k) + i16;
+                        row = row < pos ? row : (pos > 0 ? pos - 1 : 0);
+#pragma unroll
+                        for (int ds = 0; ds < S::D / 32; ++ds)
+                            kpre[k][ds] = __builtin_nontemporal_load(reinterpret_cast<const bf16x8_t*>(kcl + (size_t)row * S::D + 8 * q4 + 32 * ds));
+                    }
+#pragma unroll
+                    for (int k = 0; k < TE_VPRE; ++k)
+#pragma unroll
+                        for (int n = 0; n < 2; ++n)   // (past L1: a value line holds 64 positions, the newest written by this CU a step ago)
+                            vpre[k][n] = __builtin_nontemporal_load(reinterpret_cast<const bf16x8_t*>(vcl + (size_t)(16 * (2 * wave + n) + i16) * TE_CTX + 32 * k + 8 * q4));
                 }
+                granules(buf, S::Nqkv / 2, tag, std::integral_constant<int, (S::Nqkv / 2 + VT - 1) / VT>{}, [&](int gi, uint32_t g2) {
+                    L.qkvf[2 * gi] = bf16_to_f32((bf16_t)(g2 & 0xffffu)); L.qkvf[2 * gi + 1] = bf16_to_f32((bf16_t)(g2 >> 16));
+                });
+                TE_STAMP(3);
             }
-            te_sync();                                               // q|k|v gathered
+            te_sync();                                               // edge 1: q|k|v gathered
+            if (!*L.s_ok) { if (tid == 0) *p.fail = 1u; return; }
             TE_STAMP(4);
-            // ================= q/k-norm, RoPE, attention (redundant on every worker, private K/V copy)
+            // ================= q/k-norm, RoPE, attention (redundant on every worker)
             bf16_t* kc = kv_mine + ((size_t)li * 2 + 0) * TE_CTX * S::D;
             bf16_t* vc = kv_mine + ((size_t)li * 2 + 1) * TE_CTX * S::D;
             const int pos = t, ctx = t + 1;
@@ -513,12 +529,11 @@ __device__ __forceinline__ void te_vector_role(const TeParams& p, const TeLds& L
                 for (int which = 0; which < 2; ++which) {
                     if (which == 1 && wave != 0) break;
                     const float* src = L.qkvf + (which ? S::HD : wave * S::D);
-                    const bf16_t* nw = p.qknorm + (size_t)(2 * li + which) * S::D;
                     const float x1 = src[lane], x2 = src[lane + 64];
                     const float ss = wave_sum_dpp(x1 * x1 + x2 * x2);
                     const float inv = rsqrtf(ss / (float)S::D + p.eps);
-                    const float y1 = bf16_round_f32(bf16_to_f32(nw[lane]) * bf16_round_f32(x1 * inv));
-                    const float y2 = bf16_round_f32(bf16_to_f32(nw[lane + 64]) * bf16_round_f32(x2 * inv));
+                    const float y1 = bf16_round_f32(bf16_to_f32(which ? nw_k[0] : nw_q[0]) * bf16_round_f32(x1 * inv));
+                    const float y2 = bf16_round_f32(bf16_to_f32(which ? nw_k[1] : nw_q[1]) * bf16_round_f32(x2 * inv));
                     const float o1 = bf16_round_f32(y1 * c - y2 * sn), o2 = bf16_round_f32(y1 * sn + y2 * c);
                     if (which) {
                         L.knew[lane] = o1; L.knew[lane + 64] = o2;
@@ -549,13 +564,7 @@ __device__ __forceinline__ void te_vector_role(const TeParams& p, const TeLds& L
                     for (int e = 0; e < 8; ++e) qf[ds][e] = i16 < S::H ? (short)f32_to_bf16(qh[i16 < S::H ? i16 : 0][32 * ds + 8 * q4 + e]) : (short)0;
                 }
                 const int n_kt = (pos + 15) >> 4;
-                for (int kt = wave; kt < n_kt; kt += TE_VW) {
-                    int row = 16 * kt + i16;
-                    row = row < pos ? row : pos - 1;
-                    const bf16_t* kr = kc + (size_t)row * S::D + 8 * q4;
-                    bf16x8_t ka[S::D / 32];
-#pragma unroll
-                    for (int ds = 0; ds < S::D / 32; ++ds) ka[ds] = __builtin_nontemporal_load(reinterpret_cast<const bf16x8_t*>(kr + 32 * ds));
+                auto score_tile = [&](int kt, const bf16x8_t (&ka)[S::D / 32]) {
                     f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                     for (int ds = 0; ds < S::D / 32; ++ds) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ka[ds], qf[ds], acc, 0, 0, 0);
@@ -566,6 +575,18 @@ __device__ __forceinline__ void te_vector_role(const TeParams& p, const TeLds& L
                             if (j < pos) sc[i16][j] = acc[r] * scale;
                         }
                     }
+                };
+#pragma unroll
+                for (int k = 0; k < TE_KPRE; ++k)
+                    if (wave + TE_VW * k < n_kt) score_tile(wave + TE_VW * k, kpre[k]);              // requested ahead of edge 1's poll
+                for (int kt = wave + TE_VW * TE_KPRE; kt < n_kt; kt += TE_VW) {                        // longer contexts: the tiles behind them
+                    int row = 16 * kt + i16;
+                    row = row < pos ? row : pos - 1;
+                    const bf16_t* kr = kc + (size_t)row * S::D + 8 * q4;
+                    bf16x8_t ka[S::D / 32];
+#pragma unroll
+                    for (int ds = 0; ds < S::D / 32; ++ds) ka[ds] = __builtin_nontemporal_load(reinterpret_cast<const bf16x8_t*>(kr + 32 * ds));
+                    score_tile(kt, ka);
                 }
                 {   // the new key: head `wave`
                     const float dsum = wave_sum_dpp(qh[wave][lane] * L.knew[lane] + qh[wave][lane + 64] * L.knew[lane + 64]);
@@ -602,19 +623,25 @@ __device__ __forceinline__ void te_vector_role(const TeParams& p, const TeLds& L
                 const int i16 = lane & 15, q4 = lane >> 4;
                 const int n_k32 = (pos + 31) >> 5;
                 f32x4_t acc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
-                for (int kt = 0; kt < n_k32; ++kt) {
-                    bf16x8_t va[2], bh, bl;
-#pragma unroll
-                    for (int n = 0; n < 2; ++n)
-                        va[n] = __builtin_nontemporal_load(reinterpret_cast<const bf16x8_t*>(vc + (size_t)(16 * (2 * wave + n) + i16) * TE_CTX + 32 * kt + 8 * q4));   // (past L1: a value line holds 64 positions, and all but the newest were written by other launches of this loop)
+                auto pv_step = [&](int kt, const bf16x8_t (&va)[2]) {
                     const bf16x8_t z = {0, 0, 0, 0, 0, 0, 0, 0};
-                    bh = i16 < S::H ? *reinterpret_cast<const bf16x8_t*>(L.ph + (i16 < S::H ? i16 : 0) * TE_CTX + 32 * kt + 8 * q4) : z;
-                    bl = i16 < S::H ? *reinterpret_cast<const bf16x8_t*>(L.pl + (i16 < S::H ? i16 : 0) * TE_CTX + 32 * kt + 8 * q4) : z;
+                    const bf16x8_t bh = i16 < S::H ? *reinterpret_cast<const bf16x8_t*>(L.ph + (i16 < S::H ? i16 : 0) * TE_CTX + 32 * kt + 8 * q4) : z;
+                    const bf16x8_t bl = i16 < S::H ? *reinterpret_cast<const bf16x8_t*>(L.pl + (i16 < S::H ? i16 : 0) * TE_CTX + 32 * kt + 8 * q4) : z;
 #pragma unroll
                     for (int n = 0; n < 2; ++n) {
                         acc[n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(va[n], bh, acc[n], 0, 0, 0);
                         acc[n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(va[n], bl, acc[n], 0, 0, 0);
                     }
+                };
+#pragma unroll
+                for (int k = 0; k < TE_VPRE; ++k)
+                    if (k < n_k32) pv_step(k, vpre[k]);                                              // requested ahead of edge 1's poll
+                for (int kt = TE_VPRE; kt < n_k32; ++kt) {
+                    bf16x8_t va[2];
+#pragma unroll
+                    for (int n = 0; n < 2; ++n)       // (past L1: a value line holds 64 positions, the newest written by this CU a step ago)
+                        va[n] = __builtin_nontemporal_load(reinterpret_cast<const bf16x8_t*>(vc + (size_t)(16 * (2 * wave + n) + i16) * TE_CTX + 32 * kt + 8 * q4));
+                    pv_step(kt, va);
                 }
                 if (i16 < S::H) {
                     const float pn = sc[i16][pos];
@@ -634,54 +661,55 @@ __device__ __forceinline__ void te_vector_role(const TeParams& p, const TeLds& L
             te_sync();                                               // red ready
             TE_STAMP(8);
             {
-                u64* buf = p.xbuf + (size_t)(edge & 1u) * TE_XG;
-                publish_resid(buf);
+                u64* buf = TE_EDGE_BUF();
+                const unsigned tag = ++edge;
+                publish_resid(buf, tag);
                 TE_STAMP(9);
-                if (!te_edge(p, edge, W, L.s_ok)) { if (tid == 0) *p.fail = 1u; return; }
+                gather_h(buf, tag);
                 TE_STAMP(10);
-                gather_h(buf);
             }
-            te_sync();
+            te_sync();                                               // edge 2: residual stream gathered
+            if (!*L.s_ok) { if (tid == 0) *p.fail = 1u; return; }
             TE_STAMP(11);
             // ================= gate|up pairs -> SwiGLU -> edge 3
             te_sync();                                               // red ready
             TE_STAMP(12);
             {
-                u64* buf = p.xbuf + (size_t)(edge & 1u) * TE_XG;
-                {
-                    float v = 0.f;
-                    int gr = -1;
-                    if (tid < P_GU * 16) {
-                        const int r = tid >> 4, i = tid & 15, pr = w + r * W;
-                        if (pr < S::ff / 16) {
-                            const float gt = bf16_round_f32(te_combine<R_GU>(L.red, 2 * r, i)), up = bf16_round_f32(te_combine<R_GU>(L.red, 2 * r + 1, i));
-                            const float sg = bf16_round_f32(1.0f / (1.0f + expf(-gt)));
-                            v = bf16_round_f32(gt * sg) * up;
-                            gr = pr * 4;
-                        }
+                u64* buf = TE_EDGE_BUF();
+                const unsigned tag = ++edge;
+                float v = 0.f;
+                int gr = -1;
+                if (tid < P_GU * 16) {
+                    const int r = tid >> 4, i = tid & 15, pr = w + r * W;
+                    if (pr < S::ff / 16) {
+                        const float gt = bf16_round_f32(te_combine<R_GU>(L.red, 2 * r, i)), up = bf16_round_f32(te_combine<R_GU>(L.red, 2 * r + 1, i));
+                        const float sg = bf16_round_f32(1.0f / (1.0f + expf(-gt)));
+                        v = bf16_round_f32(gt * sg) * up;
+                        gr = pr * 8;
                     }
-                    publish4(buf, P_GU * 16, v, gr);
                 }
+                publish2(buf, P_GU * 16, v, gr, tag);
                 TE_STAMP(13);
-                if (!te_edge(p, edge, W, L.s_ok)) { if (tid == 0) *p.fail = 1u; return; }
+                granules(buf, S::ff / 2, tag, std::integral_constant<int, (S::ff / 2 + VT - 1) / VT>{},
+                         [&](int gi, uint32_t g2) { *reinterpret_cast<uint32_t*>(L.xb + 2 * gi) = g2; });
                 TE_STAMP(14);
-                for (int gi = tid; gi < S::ff / 4; gi += TE_VW * 64)
-                    *reinterpret_cast<u64*>(L.xb + 4 * gi) = __hip_atomic_load(buf + gi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
-            te_sync();                                               // activation gathered
+            te_sync();                                               // edge 3: activation gathered
+            if (!*L.s_ok) { if (tid == 0) *p.fail = 1u; return; }
             TE_STAMP(15);
             // ================= down_proj slice, residual -> edge 4
             te_sync();                                               // red ready
             TE_STAMP(16);
             {
-                u64* buf = p.xbuf + (size_t)(edge & 1u) * TE_XG;
-                publish_resid(buf);
+                u64* buf = TE_EDGE_BUF();
+                const unsigned tag = ++edge;
+                publish_resid(buf, tag);
                 TE_STAMP(17);
-                if (!te_edge(p, edge, W, L.s_ok)) { if (tid == 0) *p.fail = 1u; return; }
+                gather_h(buf, tag);
                 TE_STAMP(18);
-                gather_h(buf);
             }
-            te_sync();
+            te_sync();                                               // edge 4: residual stream gathered
+            if (!*L.s_ok) { if (tid == 0) *p.fail = 1u; return; }
             TE_STAMP(19);
         }
         // ================= final norm (hidden tap) -> output projection slice -> arg-max -> edge 5
@@ -693,7 +721,8 @@ __device__ __forceinline__ void te_vector_role(const TeParams& p, const TeLds& L
                 for (int e = 0; e < 4; ++e)
                     p.hidden_out[(size_t)t * S::d + 4 * tid + e] = bf16_round_f32(bf16_to_f32(wn[4 * tid + e]) * bf16_round_f32(L.hf[4 * tid + e] * inv));
             }
-            u64 cand = 0;
+            // candidate = (16-bit order-preserving key of the bf16 logit) << 16 | (0xffff - id): highest logit, lowest id on ties
+            uint32_t cand = 0;
             for (int pass = 0; pass * R_HEAD * W < NTV; ++pass) {
                 te_sync();                                           // red ready
                 if (tid < R_HEAD * 16) {
@@ -703,7 +732,7 @@ __device__ __forceinline__ void te_vector_role(const TeParams& p, const TeLds& L
                         const float lg = bf16_round_f32(te_combine<R_HEAD>(L.red, r, i));
                         if (n < p.V) {
                             if (p.logits_out) p.logits_out[(size_t)t * p.V + n] = lg;
-                            const u64 c1 = ((u64)te_key(lg) << 32) | (u64)(0xffffffffu - (unsigned)n);      // highest logit, lowest id on ties
+                            const uint32_t c1 = (te_key(lg) & 0xffff0000u) | (0xffffu - (unsigned)n);
                             cand = c1 > cand ? c1 : cand;
                         }
                     }
@@ -711,30 +740,31 @@ __device__ __forceinline__ void te_vector_role(const TeParams& p, const TeLds& L
                 te_sync();                                           // red consumed
             }
 #pragma unroll
-            for (int o = 32; o > 0; o >>= 1) { const u64 other = __shfl_xor(cand, o, 64); cand = other > cand ? other : cand; }
+            for (int o = 32; o > 0; o >>= 1) { const uint32_t other = __shfl_xor(cand, o, 64); cand = other > cand ? other : cand; }
             if (lane == 0) L.s_cand[wave] = cand;
             te_sync();                                               // candidates of the vector waves
-            u64* buf = p.xbuf + (size_t)(edge & 1u) * TE_XG;
-            if (tid == 0) {
-                u64 best = 0;
-#pragma unroll
-                for (int q = 0; q < TE_VW; ++q) best = L.s_cand[q] > best ? L.s_cand[q] : best;
-                __hip_atomic_store(buf + w, best, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            if (!te_edge(p, edge, W, L.s_ok)) { if (tid == 0) *p.fail = 1u; return; }
             {
-                u64 c2 = tid < W ? __hip_atomic_load(buf + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
+                u64* buf = TE_EDGE_BUF();
+                const unsigned tag = ++edge;
+                if (tid == 0) {
+                    uint32_t best = 0;
 #pragma unroll
-                for (int o = 32; o > 0; o >>= 1) { const u64 other = __shfl_xor(c2, o, 64); c2 = other > c2 ? other : c2; }
-                if (lane == 0) L.s_cand[wave] = c2;
+                    for (int q = 0; q < TE_VW; ++q) best = (uint32_t)L.s_cand[q] > best ? (uint32_t)L.s_cand[q] : best;
+                    __hip_atomic_store(buf + w, (u64)best | ((u64)tag << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+                uint32_t c2 = tid < W ? granule(buf, tid, tag) : 0u;
+#pragma unroll
+                for (int o = 32; o > 0; o >>= 1) { const uint32_t other = __shfl_xor(c2, o, 64); c2 = other > c2 ? other : c2; }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                if (lane == 0) L.s_cand[TE_VW + wave] = c2;
             }
-            te_sync();                                               // candidates gathered
+            te_sync();                                               // edge 5: candidates gathered
+            if (!*L.s_ok) { if (tid == 0) *p.fail = 1u; return; }
             if (tid == 0) {
-                u64 best = 0;
+                uint32_t best = 0;
 #pragma unroll
-                for (int q = 0; q < TE_VW; ++q) best = L.s_cand[q] > best ? L.s_cand[q] : best;
-                const int next = (int)(0xffffffffu - (unsigned)(best & 0xffffffffull));
+                for (int q = 0; q < TE_VW; ++q) best = (uint32_t)L.s_cand[TE_VW + q] > best ? (uint32_t)L.s_cand[TE_VW + q] : best;
+                const int next = (int)(0xffffu - (best & 0xffffu));
                 if (t + 1 >= p.n_prompt) *L.s_tok = next;
                 if (w == 0) p.next_tokens[t] = next;
             }
@@ -758,7 +788,7 @@ __global__ void __launch_bounds__(TE_NT) k_token_engine(TeParams p) {
     __shared__ __attribute__((aligned(16))) bf16_t stage[Dm::R_RED * 16];
     __shared__ __attribute__((aligned(16))) float red[TE_MW * Dm::R_RED * 16];
     __shared__ float s_ss[TE_VW];
-    __shared__ u64 s_cand[TE_VW];
+    __shared__ u64 s_cand[2 * TE_VW];
     __shared__ int s_ok;
     __shared__ int s_tok;
     if (p.n_total < 0) te_lds_pad[threadIdx.x] = 0;
@@ -782,7 +812,7 @@ extern "C" mis_status mis_debug_token_engine(mis_tts* lm, const int32_t* prompt,
                                              float* logits_out, float* hidden_out, double* ms_out) {
     MIS_API_BEGIN
     MIS_REQUIRE(lm && prompt && next_tokens && n_prompt >= 1 && n_new >= 0, MIS_ERR_INVALID_INPUT, "bad argument");
-    MIS_REQUIRE(xcds == 1 || xcds == 2, MIS_ERR_INVALID_INPUT, "the engine is compiled for 1 or 2 XCDs");
+    MIS_REQUIRE(xcds == 1 || xcds == 2 || xcds == 4 || xcds == 8, MIS_ERR_INVALID_INPUT, "the engine is compiled for 1, 2, 4 or 8 XCDs");
     const TtsWeightsView v = tts_internal_weights(lm);
     using S = TeShape;
     MIS_REQUIRE(v.finalized, MIS_ERR_NOT_INITIALIZED, "model not finalized");
@@ -790,7 +820,7 @@ extern "C" mis_status mis_debug_token_engine(mis_tts* lm, const int32_t* prompt,
                 MIS_ERR_INVALID_INPUT, "the token engine is compiled for Soprano-80M's widths (d 512, ffn 2304, 4 / 1 heads x 128, q/k norm, plain RoPE, bf16)");
     const int n_total = n_prompt + n_new;
     MIS_REQUIRE(n_total <= TE_CTX, MIS_ERR_INVALID_INPUT, "at most %d positions", TE_CTX);
-    MIS_REQUIRE(S::ff / 4 <= TE_XG, MIS_ERR_INVALID_INPUT, "exchange buffer too small");
+    MIS_REQUIRE(S::ff / 2 <= TE_XG && v.V <= 65536, MIS_ERR_INVALID_INPUT, "exchange buffer too small / vocabulary above 65 536 ids");
     HIP_CHECK(hipSetDevice(v.device));
     hipDeviceProp_t prop{};
     HIP_CHECK(hipGetDeviceProperties(&prop, v.device));
@@ -823,7 +853,7 @@ extern "C" mis_status mis_debug_token_engine(mis_tts* lm, const int32_t* prompt,
     p.rope_cos = rc; p.rope_sin = rs; p.L = v.L; p.V = v.V; p.Vpad = v.Vpad; p.eps = v.eps;
     p.prompt = d_prompt.p; p.n_prompt = n_prompt; p.n_total = n_total; p.next_tokens = d_next.p;
     p.logits_out = logits_out ? d_logits.p : nullptr; p.hidden_out = hidden_out ? d_hidden.p : nullptr;
-    p.kv = d_kv.p; p.xbuf = d_x.p; p.counter = d_sync.p; p.fail = d_sync.p + 32; p.xcds = xcds; p.spin = 1 << 20;
+    p.kv = d_kv.p; p.xbuf = d_x.p; p.fail = d_sync.p + 32; p.xcds = xcds; p.spin = 1 << 20;
     DevBuf<u64> d_dbg;
     const char* stamp_env = getenv("MIS_TE_STAMPS");
     if (stamp_env) {
@@ -832,17 +862,21 @@ extern "C" mis_status mis_debug_token_engine(mis_tts* lm, const int32_t* prompt,
         p.dbg = d_dbg.p; p.dbg_token = atoi(stamp_env);
     }
     const size_t pad = 64 * 1024;                                        // with the static arrays: more than half a CU's LDS -> one block per CU
-    static bool attr_done[3] = {false, false, false};
+    static bool attr_done[9] = {};
     if (!attr_done[xcds]) {
         if (xcds == 1) HIP_CHECK(hipFuncSetAttribute((const void*)k_token_engine<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pad));
-        else HIP_CHECK(hipFuncSetAttribute((const void*)k_token_engine<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pad));
+        else if (xcds == 2) HIP_CHECK(hipFuncSetAttribute((const void*)k_token_engine<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pad));
+        else if (xcds == 4) HIP_CHECK(hipFuncSetAttribute((const void*)k_token_engine<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pad));
+        else HIP_CHECK(hipFuncSetAttribute((const void*)k_token_engine<8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pad));
         attr_done[xcds] = true;
     }
     hipEvent_t e0, e1;
     HIP_CHECK(hipEventCreate(&e0)); HIP_CHECK(hipEventCreate(&e1));
     HIP_CHECK(hipEventRecord(e0, s));
     if (xcds == 1) hipLaunchKernelGGL(k_token_engine<1>, dim3(grid), dim3(TE_NT), pad, s, p);
-    else hipLaunchKernelGGL(k_token_engine<2>, dim3(grid), dim3(TE_NT), pad, s, p);
+    else if (xcds == 2) hipLaunchKernelGGL(k_token_engine<2>, dim3(grid), dim3(TE_NT), pad, s, p);
+    else if (xcds == 4) hipLaunchKernelGGL(k_token_engine<4>, dim3(grid), dim3(TE_NT), pad, s, p);
+    else hipLaunchKernelGGL(k_token_engine<8>, dim3(grid), dim3(TE_NT), pad, s, p);
     HIP_CHECK(hipEventRecord(e1, s));
     HIP_CHECK(hipGetLastError());
     HIP_CHECK(hipStreamSynchronize(s));
@@ -859,9 +893,9 @@ extern "C" mis_status mis_debug_token_engine(mis_tts* lm, const int32_t* prompt,
     if (stamp_env) {
         u64 st[32];
         HIP_CHECK(hipMemcpy(st, d_dbg.p, sizeof(st), hipMemcpyDeviceToHost));
-        static const char* names[20] = {"layer start", "qkv: red ready", "published", "edge 1 passed", "q|k|v gathered", "q/k-norm + RoPE", "scores",
-                                        "softmax + P.V", "o: red ready", "published", "edge 2 passed", "h gathered", "gate|up: red ready", "published",
-                                        "edge 3 passed", "act gathered", "down: red ready", "published", "edge 4 passed", "h gathered"};
+        static const char* names[20] = {"layer start", "qkv: red ready", "published", "q|k|v polled in", "barrier", "q/k-norm + RoPE", "scores",
+                                        "softmax + P.V", "o: red ready", "published", "h polled in", "barrier", "gate|up: red ready", "published",
+                                        "act polled in", "barrier", "down: red ready", "published", "h polled in", "barrier"};
         fprintf(stderr, "token engine, %d XCD(s), position %d, layer 1, worker 0 (shader cycles since layer start, delta):\n", xcds, p.dbg_token);
         for (int i = 0; i < 20; ++i)
             fprintf(stderr, "  %2d %-20s %8llu %6lld\n", i, names[i], (unsigned long long)(st[i] - st[0]), i ? (long long)(st[i] - st[i - 1]) : 0ll);

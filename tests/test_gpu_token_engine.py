@@ -19,7 +19,7 @@ CFG = ollama.LlamaConfig(hidden_size=512, num_hidden_layers=2, intermediate_size
                          rope_plain=True, rms_norm_eps=1e-6)
 
 
-@pytest.mark.parametrize("xcds", [1, 2])
+@pytest.mark.parametrize("xcds", [1, 2, 4, 8])
 def test_engine_logits_and_greedy_tokens_match_the_oracle_and_the_launch_chain(xcds):
     W, oracle, dev = lm_pair(CFG)
     rng = np.random.default_rng(7)

@@ -15,7 +15,7 @@ prompt = rng.integers(4, 8000, 24).astype(np.int32)
 N_NEW = 64
 out = {"workload": "Soprano-80M LM (17 layers, d 512, ffn 2304, vocab 8192), batch 1, 24 prompt positions + 64 greedy steps, one persistent launch"}
 weights = 2.0 * (17 * (768 * 512 + 512 * 512 + 2 * 2304 * 512 + 512 * 2304) + 8192 * 512)
-for xcds in (1, 2):
+for xcds in (1, 2, 4, 8):
     best = 1e9
     toks = None
     for rep in range(4):
