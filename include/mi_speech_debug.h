@@ -31,13 +31,19 @@ int32_t mis_debug_device_cus(int device);            /* compute units of a devic
 /* diagnostics / tests: launches of the one-launch sampler that reported a timed-out row barrier in this process so far */
 int32_t mis_debug_sampler_failures(void);
 
-/* laboratory (round 5; csrc/token_engine.hip): a whole batch-1 request - `n_prompt` prompt positions, then `n_new` greedy steps - in ONE
- * persistent launch on the compute units of `xcds` (1 or 2) XCDs, streaming the handle's own packed weights.  Compiled for Soprano-80M's
- * LM widths (other shapes: MIS_ERR_INVALID_INPUT).  next_tokens[t] = arg-max id after position t (t < n_prompt + n_new; the generated
- * ids are next_tokens[n_prompt - 1 ...]); logits_out ([n_prompt + n_new][vocab] float, bf16 values) and hidden_out ([...][hidden],
- * the final-norm output Soprano's decoder consumes) may be NULL; ms_out = device time of the launch.  Host pointers. */
-mis_status mis_debug_token_engine(mis_tts* lm, const int32_t* prompt, int n_prompt, int n_new, int xcds, int32_t* next_tokens,
-                                  float* logits_out, float* hidden_out, double* ms_out);
+/* csrc/token_engine.hip (round 5): a whole batch-1 request in ONE persistent launch on the compute units of `xcds` (1, 2, 4 or 8) XCDs,
+ * streaming the handle's own packed weights; compiled for Soprano-80M's LM widths (other shapes: MIS_ERR_INVALID_INPUT).  The product
+ * reaches it through mis_soprano_generate at batch 1; this entry point is for tests and measurements.
+ *   sampling == NULL (laboratory form): `n_prompt` prompt positions, then `n_new` arg-max steps; next_tokens[t] = arg-max id after position
+ *     t for EVERY t < n_prompt + n_new, logits_out [n_prompt + n_new][vocab], hidden_out [n_prompt + n_new][hidden] (final-norm output).
+ *   sampling != NULL (generate form, the semantics of the Soprano loop, Soprano.swift:801-885): a token after the last prompt position and
+ *     after every generated one until `stop_id` or n_new ids - arg-max when sampling->temperature == 0, else "mis-sampler-v1" behind the
+ *     Soprano repetition penalty (repetition_penalty over the last repetition_context generated ids, seed, row_offset); next_tokens[t] is
+ *     set for t >= n_prompt - 1; logits_out row k = the logits the k-th token was drawn from; hidden_out row k = position n_prompt - 1 + k.
+ * counts (may be NULL): [0] positions processed, [1] ids chosen.  logits_out / hidden_out may be NULL; ms_out = device time of the launch.
+ * Host pointers. */
+mis_status mis_debug_token_engine(mis_tts* lm, const int32_t* prompt, int n_prompt, int n_new, int xcds, const mis_gen_params* sampling,
+                                  int stop_id, int32_t* next_tokens, float* logits_out, float* hidden_out, int32_t* counts, double* ms_out);
 
 #ifdef __cplusplus
 }

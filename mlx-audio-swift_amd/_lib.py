@@ -286,7 +286,7 @@ DEBUG_SYMBOLS = {
     "mis_debug_device_cus": (C.c_int32, [C.c_int]),
     "mis_debug_sampler_failures": (C.c_int32, []),
     "mis_debug_choose_split": (C.c_int32, [C.c_int32, C.c_int32, C.c_int32, C.c_int32]),
-    "mis_debug_token_engine": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, _P, _P, _P, C.POINTER(C.c_double)]),
+    "mis_debug_token_engine": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, _P, C.c_int, _P, _P, _P, _P, C.POINTER(C.c_double)]),
 }
 
 _lib = None

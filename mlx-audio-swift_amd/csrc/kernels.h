@@ -59,6 +59,28 @@ struct TtsWeightsView {
 TtsWeightsView tts_internal_weights(mis_tts* c);
 // RoPE cos / sin tables [positions][D/2] for at least `max_context` positions (re-initialises the handle's per-batch state for one row)
 void tts_internal_rope_tables(mis_tts* c, int max_context, const float** cos_out, const float** sin_out);
+// batch-1 decode engine: one persistent launch per request on the compute units of `xcds` XCDs (token_engine.hip)
+struct TokenEngineRequest {
+    const int32_t* prompt = nullptr;   // host or device
+    int n_prompt = 0, max_new = 0, xcds = 2;
+    bool generate = false;             // false: laboratory form (arg-max after every position); true: generate semantics (see token_engine_run)
+    bool sample = false;               // generate only: mis-sampler-v1 behind the Soprano flavour's penalty; false = arg-max
+    float temperature = 0.f, penalty = 0.f;
+    int win_cap = 0;
+    uint64_t seed = 0;
+    int64_t row = 0;
+    int stop_id = -1;
+    bool want_logits = false, want_hidden = false;
+    float* hidden_dev = nullptr;       // device rows [positions from the last prompt token on][hidden] written in place (else returned in `hidden`)
+};
+struct TokenEngineResult {
+    std::vector<int32_t> next_tokens;  // [n_prompt + max_new]: the id chosen after position t (positions without an output projection: 0)
+    std::vector<float> logits, hidden;
+    int n_positions = 0, n_sampled = 0, head_from = 0;
+    double ms = 0;
+};
+bool token_engine_supports(mis_tts* lm);
+void token_engine_run(mis_tts* lm, const TokenEngineRequest& rq, TokenEngineResult& out);
 // a handle whose device also runs ANOTHER replica's streams (logical shards of a group on one GPU) must not launch kernels whose blocks
 // wait for each other to be co-resident (the one-launch sampler): set by the group entry points in group.hip
 void tts_internal_set_shared_device(mis_tts* c, bool shared);

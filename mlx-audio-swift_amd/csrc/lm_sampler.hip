@@ -21,34 +21,17 @@
 //   token = first i in K (index order) with prefix_K(E)_i > r
 #include "common.h"
 #include "lm_kernels.h"
+#include "sampler_math.h"
 #include <vector>
 #include <atomic>
 #include <mutex>
 
 #define SAMP_NT 256
 #define ORPHEUS_AUDIO_OFFSET 128266
-#define E_SCALE 1099511627776.0f
 
 typedef unsigned long long u64;
 static_assert(SAMP_MAX_CHUNKS <= 64, "per-chunk quantities are reduced one per lane");
 
-__device__ __forceinline__ float det_exp_dev(float y) {
-#pragma clang fp contract(off)
-    const float LOG2E = 1.4426950408889634f;
-    float t = y * LOG2E;
-    float n = floorf(t);
-    float f = t - n;
-    float p = 0.00015403530393381608f;
-    p = p * f; p = p + 0.0013333558146428443f;
-    p = p * f; p = p + 0.009618129107628477f;
-    p = p * f; p = p + 0.05550410866482158f;
-    p = p * f; p = p + 0.2402265069591007f;
-    p = p * f; p = p + 0.6931471805599453f;
-    p = p * f; p = p + 1.0f;
-    int ni = (int)fmaxf(n, -64.0f);
-    float r = p * ldexpf(1.0f, ni);
-    return (n < -60.0f) ? 0.0f : r;
-}
 
 __device__ __forceinline__ void allowed_range(const SamplerParams& p, int step, int& lo, int& hi) {
     const int V = p.vocab;

@@ -30,7 +30,9 @@
 // reads the product handle's weights, so its logits are compared with the product's and the oracle's (tests/test_gpu_token_engine.py).
 #include "common.h"
 #include "kernels.h"
+#include "sampler_math.h"
 #include <type_traits>
+#include <string.h>
 
 namespace {
 typedef unsigned long long u64;
@@ -42,6 +44,7 @@ struct TeShape {
 constexpr int TE_NT = 512;                     // threads per worker: TE_VW vector waves + TE_MW matrix waves
 constexpr int TE_VW = 4, TE_MW = 4;
 constexpr int TE_CTX = 512;                    // positions per request (scores in LDS)
+constexpr int TE_HP = 2;                       // output-projection passes at most (vocabulary <= TE_HP x 8 x 16 x workers ids)
 constexpr int TE_KPRE = 2, TE_VPRE = 4;        // key tiles per wave / 32-key value steps requested before the layer's first poll (128 positions)
 constexpr int TE_XG = 2048;                    // granules per exchange buffer (two bf16 values + the edge's tag each)
 
@@ -59,6 +62,18 @@ struct TeParams {
     u64* xbuf;                  // [2][TE_XG]
     unsigned* fail;             // set when a poll ran out (workers not co-resident)
     int xcds, spin;
+    // which positions get an output projection and a token: [head_from, head_until) - the laboratory asks for all of them, generate for
+    // the last prompt position and every generated one but the last (whose hidden state is still wanted, not its successor)
+    int head_from, head_until;
+    // token choice: 0 = arg-max of the logits (laboratory form); 2 = arg-max behind the repetition penalty (generate at temperature 0);
+    // 1 = "mis-sampler-v1" (oracle/sampler.py) behind the Soprano flavour's repetition penalty (float32, once
+    // per occurrence among the last win_cap GENERATED ids, Soprano.swift:833-901), bit for bit what lm_sampler.hip computes
+    int sample, win_cap;
+    float temperature, penalty;
+    u64 seed;
+    long long row;              // global row index of the request (RNG key)
+    int stop_id;                // a sampled id that ends the request (-1: none)
+    int32_t* n_done;            // [2] out: positions processed, ids sampled
     u64* dbg;                   // diagnostics (MIS_TE_STAMPS=<position>): cycle stamps of worker 0 at the phase boundaries of layer 1 of that position
     int dbg_token;
 };
@@ -221,7 +236,11 @@ struct TeLds {
     float* red;         // [TE_MW][R][16] partial sums of the matrix waves
     float* s_ss;        // [TE_VW] sum-of-squares partials of the residual stream
     u64* s_cand;        // [2][TE_VW] the waves' best candidates: own slice, then all workers'
-    int *s_ok, *s_tok;
+    int *s_ok, *s_tok, *s_done;
+    u64* earr;          // [TE_HP][R_HEAD x 16] fixed-point masses of this worker's ids
+    uint32_t* tsum32;   // [2 x tiles] the mass of every 16-id tile of the vocabulary, lo / hi words
+    int* win;           // [64] + length: the repetition window (generated ids)
+    u64* s_wtot;        // [TE_VW + 2] wave totals of the tile scan; the chosen tile and the draw's remainder inside it
 };
 template <int XCDS>
 struct TeDims {
@@ -266,7 +285,9 @@ __device__ __forceinline__ void te_matrix_role(const TeParams& p, const TeLds& L
     }
     for (int t = 0; t < p.n_total; ++t) {
         te_sync();                                                   // token id
+        if (*L.s_done) return;
         te_sync();                                                   // embedding row + sum of squares
+        const bool do_head = t >= p.head_from && t < p.head_until;
         // (the layer loop is rotated by the last barrier of edge 4: the output projection's first tiles are requested AFTER the loop and
         // still ahead of the last layer's edge 4 - loaded inside the loop's last iteration they would be live across the whole loop, 144
         // registers that the gate|up tiles need)
@@ -335,7 +356,13 @@ __device__ __forceinline__ void te_matrix_role(const TeParams& p, const TeLds& L
                 }
             }
         }
-        {   // output projection, passes of R_HEAD tile rows; the first pass's tiles behind the last layer's down_proj
+        if (!do_head) {   // a prompt position: straight to the next position's first tiles
+            TE_OPAQUE_IDS();
+            TE_ROWS_QKV(nt);
+            te_load<R_QKV, KPW_D, true>(tq, p.wqkv, S::d / 32, nt, p.norms, mw, lane);
+            te_sync();                                               // (last layer) edge 4: residual stream gathered
+            if (!*L.s_ok) return;
+        } else {   // output projection, passes of R_HEAD tile rows; the first pass's tiles behind the last layer's down_proj
             TeTiles<R_HEAD, KPW_D> th;
             int mw_h;
             {
@@ -363,8 +390,19 @@ __device__ __forceinline__ void te_matrix_role(const TeParams& p, const TeLds& L
                 te_sync();                                           // red consumed
             }
             te_sync();                                               // candidates of the vector waves
-            te_sync();                                               // edge 5: candidates gathered
+            te_sync();                                               // edge 5: candidates (arg-max) / maxima (sampling) gathered
             if (!*L.s_ok) return;
+            if (p.sample == 1) {
+                te_sync();                                           // edge 6: tile masses gathered
+                if (!*L.s_ok) return;
+                te_sync(); te_sync();                                // scan of the tile masses: wave totals, the chosen tile
+                te_sync();                                           // edge 7: the token
+                if (!*L.s_ok) return;
+            } else if (p.sample == 2) {
+                te_sync();                                           // the waves' id candidates
+                te_sync();                                           // edge 6: the id
+                if (!*L.s_ok) return;
+            }
         }
     }
 }
@@ -455,9 +493,13 @@ __device__ __forceinline__ void te_vector_role(const TeParams& p, const TeLds& L
     };
 #define TE_STAMP(i) do { if (p.dbg && w == 0 && tid == 0 && t == p.dbg_token && li == 1) p.dbg[i] = __builtin_readcyclecounter(); } while (0)
 #define TE_EDGE_BUF() (p.xbuf + (size_t)(edge & 1u) * TE_XG)
+    int t_last = -1, n_sampled = 0;
     for (int t = 0; t < p.n_total; ++t) {
         if (tid == 0 && t < p.n_prompt) *L.s_tok = p.prompt[t];
         te_sync();                                                   // token id
+        if (*L.s_done) break;
+        t_last = t;
+        const bool do_head = t >= p.head_from && t < p.head_until;
         {
             const int tok = *L.s_tok;
             float ss = 0.f;
@@ -712,18 +754,25 @@ __device__ __forceinline__ void te_vector_role(const TeParams& p, const TeLds& L
             if (!*L.s_ok) { if (tid == 0) *p.fail = 1u; return; }
             TE_STAMP(19);
         }
-        // ================= final norm (hidden tap) -> output projection slice -> arg-max -> edge 5
-        {
-            if (p.hidden_out && w == 0 && tid < S::d / 4) {
-                const float inv = rsqrtf(((L.s_ss[0] + L.s_ss[1]) + (L.s_ss[2] + L.s_ss[3])) / (float)S::d + p.eps);
-                const bf16_t* wn = p.norms + (size_t)(2 * p.L) * S::d;
+        // ================= final norm (hidden tap) -> output projection slice -> token -> edges 5 (.. 7)
+        if (p.hidden_out && w == 0 && t >= p.head_from && tid < S::d / 4) {
+            const float inv = rsqrtf(((L.s_ss[0] + L.s_ss[1]) + (L.s_ss[2] + L.s_ss[3])) / (float)S::d + p.eps);
+            const bf16_t* wn = p.norms + (size_t)(2 * p.L) * S::d;
 #pragma unroll
-                for (int e = 0; e < 4; ++e)
-                    p.hidden_out[(size_t)t * S::d + 4 * tid + e] = bf16_round_f32(bf16_to_f32(wn[4 * tid + e]) * bf16_round_f32(L.hf[4 * tid + e] * inv));
-            }
-            // candidate = (16-bit order-preserving key of the bf16 logit) << 16 | (0xffff - id): highest logit, lowest id on ties
+            for (int e = 0; e < 4; ++e)
+                p.hidden_out[(size_t)(t - p.head_from) * S::d + 4 * tid + e] = bf16_round_f32(bf16_to_f32(wn[4 * tid + e]) * bf16_round_f32(L.hf[4 * tid + e] * inv));
+        }
+        if (do_head) {
+            // arg-max candidate = (16-bit order-preserving key of the bf16 logit) << 16 | (0xffff - id): highest logit, lowest id on ties;
+            // sampling candidate = the 32-bit key of the penalised float32 logit (only the maximum travels)
             uint32_t cand = 0;
-            for (int pass = 0; pass * R_HEAD * W < NTV; ++pass) {
+            float lpen[TE_HP];
+            int own_n[TE_HP];
+#pragma unroll
+            for (int k = 0; k < TE_HP; ++k) { lpen[k] = 0.f; own_n[k] = -1; }
+#pragma unroll
+            for (int pass = 0; pass < TE_HP; ++pass) {
+                if (pass * R_HEAD * W >= NTV) break;
                 te_sync();                                           // red ready
                 if (tid < R_HEAD * 16) {
                     const int r = tid >> 4, i = tid & 15, nt = w + (pass * R_HEAD + r) * W;
@@ -731,9 +780,23 @@ __device__ __forceinline__ void te_vector_role(const TeParams& p, const TeLds& L
                         const int n = nt * 16 + i;
                         const float lg = bf16_round_f32(te_combine<R_HEAD>(L.red, r, i));
                         if (n < p.V) {
-                            if (p.logits_out) p.logits_out[(size_t)t * p.V + n] = lg;
-                            const uint32_t c1 = (te_key(lg) & 0xffff0000u) | (0xffffu - (unsigned)n);
-                            cand = c1 > cand ? c1 : cand;
+                            if (p.logits_out) p.logits_out[(size_t)(t - p.head_from) * p.V + n] = lg;
+                            if (p.sample) {
+                                // Soprano applyRepetitionPenalty (Soprano.swift:888-901): float32, once PER OCCURRENCE in the window
+                                float v = lg;
+                                if (p.penalty > 0.0f && p.penalty != 1.0f) {
+                                    const int wl = L.win[64];
+                                    int mult = 0;
+                                    for (int j = 0; j < wl; ++j) mult += (L.win[j] == n);
+                                    for (int k = 0; k < mult; ++k) v = (v > 0.0f) ? __fdiv_rn(v, p.penalty) : v * p.penalty;
+                                }
+                                lpen[pass] = v; own_n[pass] = n;
+                                const uint32_t c1 = te_key(v);
+                                cand = c1 > cand ? c1 : cand;
+                            } else {
+                                const uint32_t c1 = (te_key(lg) & 0xffff0000u) | (0xffffu - (unsigned)n);
+                                cand = c1 > cand ? c1 : cand;
+                            }
                         }
                     }
                 }
@@ -743,7 +806,8 @@ __device__ __forceinline__ void te_vector_role(const TeParams& p, const TeLds& L
             for (int o = 32; o > 0; o >>= 1) { const uint32_t other = __shfl_xor(cand, o, 64); cand = other > cand ? other : cand; }
             if (lane == 0) L.s_cand[wave] = cand;
             te_sync();                                               // candidates of the vector waves
-            {
+            uint32_t best_all = 0;
+            {   // edge 5: every worker's candidate to every worker
                 u64* buf = TE_EDGE_BUF();
                 const unsigned tag = ++edge;
                 if (tid == 0) {
@@ -758,18 +822,131 @@ __device__ __forceinline__ void te_vector_role(const TeParams& p, const TeLds& L
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 if (lane == 0) L.s_cand[TE_VW + wave] = c2;
             }
-            te_sync();                                               // edge 5: candidates gathered
+            te_sync();                                               // edge 5 gathered
             if (!*L.s_ok) { if (tid == 0) *p.fail = 1u; return; }
-            if (tid == 0) {
-                uint32_t best = 0;
 #pragma unroll
-                for (int q = 0; q < TE_VW; ++q) best = (uint32_t)L.s_cand[TE_VW + q] > best ? (uint32_t)L.s_cand[TE_VW + q] : best;
-                const int next = (int)(0xffffu - (best & 0xffffu));
+            for (int q = 0; q < TE_VW; ++q) best_all = (uint32_t)L.s_cand[TE_VW + q] > best_all ? (uint32_t)L.s_cand[TE_VW + q] : best_all;
+            int next;
+            if (!p.sample) {
+                next = (int)(0xffffu - (best_all & 0xffffu));
+            } else if (p.sample == 2) {
+                // arg-max of the PENALISED float32 logits (temperature 0 in the generate form): the maximum's 32-bit key is known to
+                // everybody; the lowest id that holds it travels in a second edge
+                uint32_t c3 = 0;
+#pragma unroll
+                for (int pass = 0; pass < TE_HP; ++pass)
+                    if (own_n[pass] >= 0 && te_key(lpen[pass]) == best_all) { const uint32_t c1 = 0x10000u | (0xffffu - (unsigned)own_n[pass]); c3 = c1 > c3 ? c1 : c3; }
+#pragma unroll
+                for (int o = 32; o > 0; o >>= 1) { const uint32_t other = __shfl_xor(c3, o, 64); c3 = other > c3 ? other : c3; }
+                if (lane == 0) L.s_cand[wave] = c3;
+                te_sync();
+                u64* buf = TE_EDGE_BUF();
+                const unsigned tag = ++edge;
+                if (tid == 0) {
+                    uint32_t best = 0;
+#pragma unroll
+                    for (int q = 0; q < TE_VW; ++q) best = (uint32_t)L.s_cand[q] > best ? (uint32_t)L.s_cand[q] : best;
+                    __hip_atomic_store(buf + w, (u64)best | ((u64)tag << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+                uint32_t c2 = tid < W ? granule(buf, tid, tag) : 0u;
+#pragma unroll
+                for (int o = 32; o > 0; o >>= 1) { const uint32_t other = __shfl_xor(c2, o, 64); c2 = other > c2 ? other : c2; }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                if (lane == 0) L.s_cand[TE_VW + wave] = c2;
+                te_sync();                                           // edge 6: the id
+                if (!*L.s_ok) { if (tid == 0) *p.fail = 1u; return; }
+                uint32_t b2 = 0;
+#pragma unroll
+                for (int q = 0; q < TE_VW; ++q) b2 = (uint32_t)L.s_cand[TE_VW + q] > b2 ? (uint32_t)L.s_cand[TE_VW + q] : b2;
+                next = (int)(0xffffu - (b2 & 0xffffu));
+            } else {
+                // ---- mis-sampler-v1 over the whole vocabulary: x = fdiv(l, T), e = det_exp(min(x - max x, 0)), E = trunc(e 2^40); the draw
+                // r = mulhi64(rand64(seed, row, step), sum E) picks the first id, in id order, whose running sum of E exceeds r.  Ids are dealt
+                // to the workers in tiles of 16, so the running sum is taken over TILES first (edge 6: every tile's mass to everybody; one block
+                // scan), then inside the chosen tile by its owner (edge 7: the token to everybody).
+                const float xmax = __fdiv_rn(__uint_as_float((best_all & 0x80000000u) ? (best_all & 0x7fffffffu) : ~best_all), p.temperature);
+                u64* buf = TE_EDGE_BUF();
+                const unsigned tag = ++edge;
+#pragma unroll
+                for (int pass = 0; pass < TE_HP; ++pass) {
+                    if (pass * R_HEAD * W >= NTV) break;
+                    u64 E = 0;
+                    if (tid < R_HEAD * 16 && own_n[pass] >= 0) {
+                        const float x = __fdiv_rn(lpen[pass], p.temperature);
+                        E = (u64)(det_exp_dev(fminf(x - xmax, 0.0f)) * E_SCALE);
+                    }
+                    if (tid < R_HEAD * 16) L.earr[pass * (R_HEAD * 16) + tid] = E;
+                    // tile mass = sum over the 16 lanes of a row: E < 2^41 split into two 21-bit halves, each summed in 32 bits on the DPP network
+                    uint32_t a = (uint32_t)(E & 0x1fffffu), bb = (uint32_t)(E >> 21);
+#pragma unroll
+                    for (int o = 1; o < 16; o <<= 1) { a += __shfl_xor(a, o, 64); bb += __shfl_xor(bb, o, 64); }
+                    const u64 tile_mass = (u64)a + ((u64)bb << 21);
+                    if (tid < R_HEAD * 16 && (tid & 15) == 0) {
+                        const int nt = w + (pass * R_HEAD + (tid >> 4)) * W;
+                        if (nt < NTV) {
+                            __hip_atomic_store(buf + 2 * nt, (u64)(uint32_t)tile_mass | ((u64)tag << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            __hip_atomic_store(buf + 2 * nt + 1, (u64)(uint32_t)(tile_mass >> 32) | ((u64)tag << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        }
+                    }
+                }
+                granules(buf, 2 * NTV, tag, std::integral_constant<int, TE_XG / VT>{}, [&](int gi, uint32_t g2) { L.tsum32[gi] = g2; });
+                te_sync();                                           // edge 6: tile masses gathered
+                if (!*L.s_ok) { if (tid == 0) *p.fail = 1u; return; }
+                // scan over the tiles: thread -> tiles 2 tid, 2 tid + 1
+                const int t0i = 2 * tid, t1i = 2 * tid + 1;
+                const u64 m0 = t0i < NTV ? ((u64)L.tsum32[2 * t0i] | ((u64)L.tsum32[2 * t0i + 1] << 32)) : 0;
+                const u64 m1 = t1i < NTV ? ((u64)L.tsum32[2 * t1i] | ((u64)L.tsum32[2 * t1i + 1] << 32)) : 0;
+                u64 incl = m0 + m1;
+#pragma unroll
+                for (int o = 1; o < 64; o <<= 1) {
+                    const uint32_t ulo = __shfl_up((uint32_t)incl, o, 64), uhi = __shfl_up((uint32_t)(incl >> 32), o, 64);
+                    if (lane >= o) incl += (u64)ulo | ((u64)uhi << 32);
+                }
+                if (lane == 63) L.s_wtot[wave] = incl;
+                te_sync();
+                u64 base = 0, Z = 0;
+#pragma unroll
+                for (int q = 0; q < TE_VW; ++q) { if (q < wave) base += L.s_wtot[q]; Z += L.s_wtot[q]; }
+                const int step = t - (p.n_prompt - 1);
+                const u64 rnd = mis_splitmix64(mis_splitmix64(p.seed ^ (0xD1B54A32D192ED03ull * (u64)(p.row + 1))) + (u64)step);
+                const u64 r = __umul64hi(rnd, Z);
+                const u64 excl = base + incl - (m0 + m1);
+                if (r >= excl && r < excl + m0) { L.s_wtot[TE_VW] = (u64)t0i; L.s_wtot[TE_VW + 1] = r - excl; }
+                else if (r >= excl + m0 && r < excl + m0 + m1) { L.s_wtot[TE_VW] = (u64)t1i; L.s_wtot[TE_VW + 1] = r - excl - m0; }
+                te_sync();
+                const int tile = (int)L.s_wtot[TE_VW];
+                const u64 rin = L.s_wtot[TE_VW + 1];
+                u64* bufc = TE_EDGE_BUF();
+                const unsigned tagc = ++edge;
+                if (tile % W == w && tid == 0) {                     // the owner: inside the tile in id order
+                    const int slot = (tile - w) / W, pass = slot / R_HEAD, rr = slot % R_HEAD;
+                    u64 run = 0;
+                    int tok = 16 * tile + 15;
+                    for (int i = 0; i < 16; ++i) {
+                        run += L.earr[pass * (R_HEAD * 16) + rr * 16 + i];
+                        if (run > rin) { tok = 16 * tile + i; break; }
+                    }
+                    __hip_atomic_store(bufc, (u64)(uint32_t)tok | ((u64)tagc << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+                if (tid == 0) L.s_cand[0] = granule(bufc, 0, tagc);
+                te_sync();                                           // edge 7: the token
+                if (!*L.s_ok) { if (tid == 0) *p.fail = 1u; return; }
+                next = (int)(uint32_t)L.s_cand[0];
+            }
+            n_sampled += 1;
+            if (tid == 0) {
                 if (t + 1 >= p.n_prompt) *L.s_tok = next;
                 if (w == 0) p.next_tokens[t] = next;
+                if (p.sample && p.win_cap > 0) {                     // the window slides over the generated ids (both sampling forms)
+                    int wl = L.win[64];
+                    if (wl < p.win_cap) { L.win[wl] = next; L.win[64] = wl + 1; }
+                    else { for (int j = 0; j + 1 < wl; ++j) L.win[j] = L.win[j + 1]; L.win[wl - 1] = next; }
+                }
+                if (next == p.stop_id) *L.s_done = 1;
             }
         }
     }
+    if (w == 0 && tid == 0 && p.n_done) { p.n_done[0] = t_last + 1; p.n_done[1] = n_sampled; }
 }
 
 template <int XCDS>
@@ -791,14 +968,19 @@ __global__ void __launch_bounds__(TE_NT) k_token_engine(TeParams p) {
     __shared__ u64 s_cand[2 * TE_VW];
     __shared__ int s_ok;
     __shared__ int s_tok;
+    __shared__ int s_done;
+    __shared__ u64 earr[TE_HP * Dm::R_HEAD * 16];
+    __shared__ uint32_t tsum32[TE_XG];
+    __shared__ int win[65];
+    __shared__ u64 s_wtot[TE_VW + 2];
     if (p.n_total < 0) te_lds_pad[threadIdx.x] = 0;
     const int b = blockIdx.x;
     if ((b & 7) >= XCDS) return;
     const int w = (b >> 3) * XCDS + (b & 7);
     const int tid = threadIdx.x, wave = tid >> 6;
     if (tid < TE_VW) s_ss[tid] = 0.f;
-    if (tid == 0) { s_ok = 1; s_tok = 0; }
-    const TeLds L{hf, xb, qkvf, qh, knew, vnew, sc, ph, pl, stage, red, s_ss, s_cand, &s_ok, &s_tok};
+    if (tid == 0) { s_ok = 1; s_tok = 0; s_done = 0; win[64] = 0; }
+    const TeLds L{hf, xb, qkvf, qh, knew, vnew, sc, ph, pl, stage, red, s_ss, s_cand, &s_ok, &s_tok, &s_done, earr, tsum32, win, s_wtot};
     te_sync();
     // (the wave index as a SCALAR: every tile address is then scalar base + one shared lane offset.  With a vector wave index the
     // compiler keeps a 64-bit address pair per tile live across the layer loop - ~200 registers of addresses, everything spills)
@@ -807,20 +989,31 @@ __global__ void __launch_bounds__(TE_NT) k_token_engine(TeParams p) {
 }
 }   // namespace
 
-// ---------------------------------------------------------------------------- host side (include/mi_speech_debug.h)
-extern "C" mis_status mis_debug_token_engine(mis_tts* lm, const int32_t* prompt, int n_prompt, int n_new, int xcds, int32_t* next_tokens,
-                                             float* logits_out, float* hidden_out, double* ms_out) {
-    MIS_API_BEGIN
-    MIS_REQUIRE(lm && prompt && next_tokens && n_prompt >= 1 && n_new >= 0, MIS_ERR_INVALID_INPUT, "bad argument");
-    MIS_REQUIRE(xcds == 1 || xcds == 2 || xcds == 4 || xcds == 8, MIS_ERR_INVALID_INPUT, "the engine is compiled for 1, 2, 4 or 8 XCDs");
+// ---------------------------------------------------------------------------- host side
+bool token_engine_supports(mis_tts* lm) {
+    if (!lm) return false;
     const TtsWeightsView v = tts_internal_weights(lm);
     using S = TeShape;
-    MIS_REQUIRE(v.finalized, MIS_ERR_NOT_INITIALIZED, "model not finalized");
-    MIS_REQUIRE(v.d == S::d && v.ff == S::ff && v.H == S::H && v.Hkv == S::Hkv && v.D == S::D && v.qk_norm && v.rope_plain && !v.quantised,
-                MIS_ERR_INVALID_INPUT, "the token engine is compiled for Soprano-80M's widths (d 512, ffn 2304, 4 / 1 heads x 128, q/k norm, plain RoPE, bf16)");
-    const int n_total = n_prompt + n_new;
+    return v.finalized && v.d == S::d && v.ff == S::ff && v.H == S::H && v.Hkv == S::Hkv && v.D == S::D && v.qk_norm && v.rope_plain && !v.quantised &&
+           v.V <= 65536 && v.Vpad / 16 <= 2 * TE_VW * 64;
+}
+
+// One request.  generate == false (laboratory): arg-max after EVERY position, no stop; logits / hidden rows are indexed by position.
+// generate == true: the product's semantics (tts_generate_hidden): a token after the last prompt position and after every generated one
+// until `stop_id` or max_new ids; hidden row k = final-norm output of position n_prompt - 1 + k (row 0 = the last prompt token,
+// Soprano.swift:824-825); logits row k = the logits the k-th token was drawn from.
+void token_engine_run(mis_tts* lm, const TokenEngineRequest& rq, TokenEngineResult& out) {
+    MIS_REQUIRE(lm && rq.prompt && rq.n_prompt >= 1 && rq.max_new >= 0, MIS_ERR_INVALID_INPUT, "bad argument");
+    const int xcds = rq.xcds;
+    MIS_REQUIRE(xcds == 1 || xcds == 2 || xcds == 4 || xcds == 8, MIS_ERR_INVALID_INPUT, "the engine is compiled for 1, 2, 4 or 8 XCDs");
+    MIS_REQUIRE(token_engine_supports(lm), MIS_ERR_INVALID_INPUT,
+                "the token engine is compiled for Soprano-80M's widths (d 512, ffn 2304, 4 / 1 heads x 128, q/k norm, plain RoPE, bf16, vocabulary <= 8192)");
+    const TtsWeightsView v = tts_internal_weights(lm);
+    using S = TeShape;
+    const int n_total = rq.n_prompt + rq.max_new;
     MIS_REQUIRE(n_total <= TE_CTX, MIS_ERR_INVALID_INPUT, "at most %d positions", TE_CTX);
-    MIS_REQUIRE(S::ff / 2 <= TE_XG && v.V <= 65536, MIS_ERR_INVALID_INPUT, "exchange buffer too small / vocabulary above 65 536 ids");
+    MIS_REQUIRE(!rq.sample || (rq.temperature > 0.0f && rq.win_cap >= 0 && rq.win_cap <= 64), MIS_ERR_INVALID_INPUT, "sampling needs temperature > 0 and a window of at most 64 ids");
+    MIS_REQUIRE(v.Vpad / 16 <= TE_HP * 8 * 32 * xcds, MIS_ERR_INVALID_INPUT, "vocabulary too large for the engine's output-projection passes");
     HIP_CHECK(hipSetDevice(v.device));
     hipDeviceProp_t prop{};
     HIP_CHECK(hipGetDeviceProperties(&prop, v.device));
@@ -829,31 +1022,38 @@ extern "C" mis_status mis_debug_token_engine(mis_tts* lm, const int32_t* prompt,
     const float* rc = nullptr; const float* rs = nullptr;
     tts_internal_rope_tables(lm, n_total, &rc, &rs);                     // (builds the tables for this context length)
     hipStream_t s = v.stream;
-    const int W = 32 * xcds;
-    std::vector<int32_t> hp(n_prompt);
-    HIP_CHECK(hipMemcpy(hp.data(), prompt, (size_t)n_prompt * 4, hipMemcpyDefault));
+    std::vector<int32_t> hp(rq.n_prompt);
+    HIP_CHECK(hipMemcpy(hp.data(), rq.prompt, (size_t)rq.n_prompt * 4, hipMemcpyDefault));
     for (int t : hp) MIS_REQUIRE(t >= 0 && t < v.V, MIS_ERR_INVALID_INPUT, "prompt token %d outside the vocabulary", t);
-    DevBuf<int32_t> d_prompt, d_next;
+    const int head_from = rq.generate ? rq.n_prompt - 1 : 0;
+    const int head_until = rq.generate ? n_total - 1 : n_total;
+    const int n_rows = n_total - head_from;                              // hidden rows at most; logits rows: head_until - head_from
+    DevBuf<int32_t> d_prompt, d_next, d_done;
     DevBuf<float> d_logits, d_hidden;
     DevBuf<bf16_t> d_kv;
     DevBuf<u64> d_x;
     DevBuf<unsigned> d_sync;
-    d_prompt.alloc(n_prompt); d_next.alloc(n_total);
+    d_prompt.alloc(rq.n_prompt); d_next.alloc(n_total); d_done.alloc(2);
     d_kv.alloc((size_t)v.L * 2 * TE_CTX * (S::Hkv * S::D));
     d_x.alloc(2 * TE_XG); d_sync.alloc(64);
-    if (logits_out) d_logits.alloc((size_t)n_total * v.V);
-    if (hidden_out) d_hidden.alloc((size_t)n_total * S::d);
-    HIP_CHECK(hipMemcpyAsync(d_prompt.p, hp.data(), (size_t)n_prompt * 4, hipMemcpyHostToDevice, s));
+    if (rq.want_logits) d_logits.alloc((size_t)std::max(head_until - head_from, 1) * v.V);
+    float* hidden_dev = rq.hidden_dev;
+    if (rq.want_hidden && !hidden_dev) { d_hidden.alloc((size_t)n_rows * S::d); hidden_dev = d_hidden.p; }
+    HIP_CHECK(hipMemcpyAsync(d_prompt.p, hp.data(), (size_t)rq.n_prompt * 4, hipMemcpyHostToDevice, s));
     HIP_CHECK(hipMemsetAsync(d_sync.p, 0, 64 * sizeof(unsigned), s));
     HIP_CHECK(hipMemsetAsync(d_kv.p, 0, d_kv.bytes(), s));          // (the transposed value rows are read in 32-key steps: unwritten positions x 0 must be finite)
     HIP_CHECK(hipMemsetAsync(d_x.p, 0, 2 * TE_XG * sizeof(u64), s));
     HIP_CHECK(hipMemsetAsync(d_next.p, 0, (size_t)n_total * 4, s));
+    HIP_CHECK(hipMemsetAsync(d_done.p, 0, 8, s));
     TeParams p{};
     p.emb = v.emb; p.wqkv = v.wqkv; p.wo = v.wo; p.wgu = v.wgu; p.wdown = v.wdown; p.head = v.head; p.norms = v.norms; p.qknorm = v.qknorm;
     p.rope_cos = rc; p.rope_sin = rs; p.L = v.L; p.V = v.V; p.Vpad = v.Vpad; p.eps = v.eps;
-    p.prompt = d_prompt.p; p.n_prompt = n_prompt; p.n_total = n_total; p.next_tokens = d_next.p;
-    p.logits_out = logits_out ? d_logits.p : nullptr; p.hidden_out = hidden_out ? d_hidden.p : nullptr;
+    p.prompt = d_prompt.p; p.n_prompt = rq.n_prompt; p.n_total = n_total; p.next_tokens = d_next.p;
+    p.logits_out = rq.want_logits ? d_logits.p : nullptr; p.hidden_out = hidden_dev;
     p.kv = d_kv.p; p.xbuf = d_x.p; p.fail = d_sync.p + 32; p.xcds = xcds; p.spin = 1 << 20;
+    p.head_from = head_from; p.head_until = head_until;
+    p.sample = rq.sample ? 1 : (rq.generate ? 2 : 0); p.win_cap = rq.win_cap; p.temperature = rq.temperature; p.penalty = rq.penalty; p.seed = rq.seed; p.row = rq.row;
+    p.stop_id = rq.generate ? rq.stop_id : -1; p.n_done = d_done.p;
     DevBuf<u64> d_dbg;
     const char* stamp_env = getenv("MIS_TE_STAMPS");
     if (stamp_env) {
@@ -861,7 +1061,7 @@ extern "C" mis_status mis_debug_token_engine(mis_tts* lm, const int32_t* prompt,
         HIP_CHECK(hipMemsetAsync(d_dbg.p, 0, 32 * 8, s));
         p.dbg = d_dbg.p; p.dbg_token = atoi(stamp_env);
     }
-    const size_t pad = 64 * 1024;                                        // with the static arrays: more than half a CU's LDS -> one block per CU
+    const size_t pad = 48 * 1024;                                        // with the static arrays: more than half a CU's LDS -> one block per CU
     static bool attr_done[9] = {};
     if (!attr_done[xcds]) {
         if (xcds == 1) HIP_CHECK(hipFuncSetAttribute((const void*)k_token_engine<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pad));
@@ -886,10 +1086,19 @@ extern "C" mis_status mis_debug_token_engine(mis_tts* lm, const int32_t* prompt,
     unsigned failed = 0;
     HIP_CHECK(hipMemcpy(&failed, d_sync.p + 32, 4, hipMemcpyDeviceToHost));
     MIS_REQUIRE(!failed, MIS_ERR_GENERATION_FAILED, "token engine: an edge timed out (its workers were not co-resident)");
-    HIP_CHECK(hipMemcpy(next_tokens, d_next.p, (size_t)n_total * 4, hipMemcpyDeviceToHost));
-    if (logits_out) HIP_CHECK(hipMemcpy(logits_out, d_logits.p, (size_t)n_total * v.V * 4, hipMemcpyDeviceToHost));
-    if (hidden_out) HIP_CHECK(hipMemcpy(hidden_out, d_hidden.p, (size_t)n_total * S::d * 4, hipMemcpyDeviceToHost));
-    if (ms_out) *ms_out = ms;
+    int32_t done[2] = {0, 0};
+    HIP_CHECK(hipMemcpy(done, d_done.p, 8, hipMemcpyDeviceToHost));
+    out.n_positions = done[0]; out.n_sampled = done[1]; out.ms = ms; out.head_from = head_from;
+    out.next_tokens.assign(n_total, 0);
+    HIP_CHECK(hipMemcpy(out.next_tokens.data(), d_next.p, (size_t)n_total * 4, hipMemcpyDeviceToHost));
+    if (rq.want_logits) {
+        out.logits.assign((size_t)std::max(head_until - head_from, 1) * v.V, 0.f);
+        HIP_CHECK(hipMemcpy(out.logits.data(), d_logits.p, out.logits.size() * 4, hipMemcpyDeviceToHost));
+    }
+    if (rq.want_hidden && !rq.hidden_dev) {
+        out.hidden.assign((size_t)n_rows * S::d, 0.f);
+        HIP_CHECK(hipMemcpy(out.hidden.data(), d_hidden.p, out.hidden.size() * 4, hipMemcpyDeviceToHost));
+    }
     if (stamp_env) {
         u64 st[32];
         HIP_CHECK(hipMemcpy(st, d_dbg.p, sizeof(st), hipMemcpyDeviceToHost));
@@ -900,5 +1109,30 @@ extern "C" mis_status mis_debug_token_engine(mis_tts* lm, const int32_t* prompt,
         for (int i = 0; i < 20; ++i)
             fprintf(stderr, "  %2d %-20s %8llu %6lld\n", i, names[i], (unsigned long long)(st[i] - st[0]), i ? (long long)(st[i] - st[i - 1]) : 0ll);
     }
+}
+
+// include/mi_speech_debug.h
+extern "C" mis_status mis_debug_token_engine(mis_tts* lm, const int32_t* prompt, int n_prompt, int n_new, int xcds, const mis_gen_params* sampling,
+                                             int stop_id, int32_t* next_tokens, float* logits_out, float* hidden_out, int32_t* counts,
+                                             double* ms_out) {
+    MIS_API_BEGIN
+    MIS_REQUIRE(next_tokens, MIS_ERR_INVALID_INPUT, "null argument");
+    TokenEngineRequest rq{};
+    rq.prompt = prompt; rq.n_prompt = n_prompt; rq.max_new = n_new; rq.xcds = xcds;
+    rq.generate = sampling != nullptr;
+    if (sampling) {
+        rq.sample = sampling->temperature > 0.0f;
+        rq.temperature = sampling->temperature; rq.penalty = sampling->repetition_penalty; rq.win_cap = std::max(sampling->repetition_context, 0);
+        rq.seed = sampling->seed; rq.row = sampling->row_offset; rq.stop_id = stop_id;
+    }
+    rq.want_logits = logits_out != nullptr; rq.want_hidden = hidden_out != nullptr;
+    TokenEngineResult r;
+    token_engine_run(lm, rq, r);
+    const int n_total = n_prompt + n_new;
+    memcpy(next_tokens, r.next_tokens.data(), (size_t)n_total * 4);
+    if (logits_out) memcpy(logits_out, r.logits.data(), r.logits.size() * 4);
+    if (hidden_out) memcpy(hidden_out, r.hidden.data(), r.hidden.size() * 4);
+    if (counts) { counts[0] = r.n_positions; counts[1] = r.n_sampled; }
+    if (ms_out) *ms_out = r.ms;
     MIS_API_END
 }

@@ -344,20 +344,26 @@ class LlamaTTSModel:
                                                hid.ctypes.data if want_hidden else None))
         return (out, hid) if want_hidden else out
 
-    def debug_token_engine(self, prompt, n_new: int, xcds: int = 1, want_logits: bool = False, want_hidden: bool = False):
-        """Laboratory (csrc/token_engine.hip, include/mi_speech_debug.h): the whole batch-1 request - prompt positions, then n_new greedy
-        steps - in ONE persistent launch on the compute units of `xcds` XCDs.  Returns a dict: next_tokens [n_prompt + n_new] (arg-max
-        after every position), ms (device time of the launch), and logits / hidden when asked for."""
+    def debug_token_engine(self, prompt, n_new: int, xcds: int = 2, want_logits: bool = False, want_hidden: bool = False,
+                           sampling: GenerateParameters | None = None, stop_id: int = -1):
+        """csrc/token_engine.hip through include/mi_speech_debug.h: the whole batch-1 request in ONE persistent launch on the compute
+        units of `xcds` XCDs.  sampling=None: arg-max after every position (rows indexed by position).  sampling given: the Soprano
+        loop's semantics - rows from the last prompt position on, until stop_id or n_new ids.  Returns a dict: next_tokens, ms,
+        positions, chosen, logits / hidden when asked for."""
         prompt = np.ascontiguousarray(prompt, dtype=np.int32)
         n = len(prompt) + int(n_new)
+        rows = n if sampling is None else int(n_new) + 1
         nxt = np.zeros(n, np.int32)
-        lg = np.zeros((n, self.configuration.vocab_size), np.float32) if want_logits else None
-        hid = np.zeros((n, self.configuration.hidden_size), np.float32) if want_hidden else None
+        lg = np.zeros((rows if sampling is None else max(int(n_new), 1), self.configuration.vocab_size), np.float32) if want_logits else None
+        hid = np.zeros((rows, self.configuration.hidden_size), np.float32) if want_hidden else None
         ms = C.c_double(0.0)
-        check(_lib.lib().mis_debug_token_engine(self._h, prompt.ctypes.data, len(prompt), int(n_new), int(xcds), nxt.ctypes.data,
+        counts = (C.c_int32 * 2)()
+        gpc = sampling.to_c() if sampling is not None else None
+        check(_lib.lib().mis_debug_token_engine(self._h, prompt.ctypes.data, len(prompt), int(n_new), int(xcds),
+                                                C.byref(gpc) if gpc is not None else None, int(stop_id), nxt.ctypes.data,
                                                 lg.ctypes.data if want_logits else None, hid.ctypes.data if want_hidden else None,
-                                                C.byref(ms)))
-        return {"next_tokens": nxt, "ms": ms.value, "logits": lg, "hidden": hid}
+                                                counts, C.byref(ms)))
+        return {"next_tokens": nxt, "ms": ms.value, "logits": lg, "hidden": hid, "positions": int(counts[0]), "chosen": int(counts[1])}
 
     def last_timing(self) -> dict:
         t = _lib.TimingC()

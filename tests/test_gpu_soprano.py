@@ -213,3 +213,84 @@ def test_group_of_two_logical_shards_returns_the_unsharded_audio():
     pcm2, toks2 = dev.generate_batch(rows, gp, return_tokens=True, replicas=[dev, dev2])
     for r in range(len(rows)):
         assert np.array_equal(toks[r], toks2[r]) and np.array_equal(pcm[r], pcm2[r]), r
+
+
+def test_batch_one_generate_runs_on_the_token_engine(monkeypatch):
+    """mis_soprano_generate at batch 1 on an LM of Soprano-80M's widths (hidden 512, ffn 2304, 4 / 1 heads x 128; two layers here): the LM
+    loop is ONE persistent launch (csrc/token_engine.hip) instead of the launch chain.  Held to the same bar as the chain
+    (test_generate_greedy...): tokens = the oracle's choice under teacher forcing within the logit tolerance, audio = the oracle decoder on
+    the hidden states of (last prompt token, every generated token), [STOP] ends the row unannounced; sampling is seeded; and the chain
+    (MIS_TOKEN_ENGINE=0) on the same handle gives audio of the same length built from ITS hidden states (the two LMs agree to the logit
+    tolerance, not bit for bit: other float32 summation orders)."""
+    lm = ollama.LlamaConfig(hidden_size=512, num_hidden_layers=2, intermediate_size=2304, num_attention_heads=4, num_key_value_heads=1,
+                            head_dim=128, vocab_size=1200, rope_theta=10000.0, rope_scaling=None, tie_word_embeddings=False, qk_norm=True,
+                            rope_plain=True, rms_norm_eps=1e-6)
+    base = dict(decoder_num_layers=2, decoder_dim=96, decoder_intermediate_dim=160, hop_length=32, n_fft=128, upscale=4, input_kernel=3,
+                dw_kernel=3, token_size=128)
+
+    def build(stop):
+        cfg = mas.SopranoConfiguration(hidden_size=lm.hidden_size, num_hidden_layers=lm.num_hidden_layers, intermediate_size=lm.intermediate_size,
+                                       num_attention_heads=lm.num_attention_heads, num_key_value_heads=lm.num_key_value_heads, head_dim=lm.head_dim,
+                                       vocab_size=lm.vocab_size, rms_norm_eps=lm.rms_norm_eps, rope_theta=lm.rope_theta, tie_word_embeddings=False,
+                                       stop_token_id=stop, **base)
+        ocfg = osop.SopranoDecoderConfig(hidden_size=lm.hidden_size, **base)
+        Wd = osop.make_synthetic_weights(ocfg, seed=99)
+        Wl = ollama.make_synthetic_weights(lm, seed=4321)
+        Wall = {(k[len("model."):] if k.startswith("model.") else k): v for k, v in Wl.items()}
+        Wall.update(Wd)
+        return cfg, mas.SopranoModel.from_weights(cfg, Wall), osop.SopranoDecoderOracle(ocfg, Wd), ollama.LlamaOracle(lm, Wl, round="bf16")
+
+    cfg, dev, odec, olm = build(3)
+    lib = mas._lib.lib()
+    rng = np.random.default_rng(2)
+    prompt = rng.integers(4, lm.vocab_size, 9).astype(np.int32)
+    gp = mas.GenerateParameters(max_tokens=12, temperature=0.0, top_p=0.95, repetition_penalty=1.5, repetition_context_size=30, seed=1,
+                                sampler_flavor=1)
+    monkeypatch.delenv("MIS_TOKEN_ENGINE", raising=False)
+    pcm, toks = dev.generate_batch([prompt], gp, return_tokens=True)
+    assert len(toks[0]) == 12 and pcm[0].shape == (12 * cfg.token_size,)
+    # (1) tokens: the oracle's greedy choice under teacher forcing (penalty over the generated ids only), within the logit tolerance
+    olm.reset(1)
+    seq = list(prompt) + list(toks[0])
+    lg = olm._forward_row(0, torch.as_tensor(np.asarray(seq[:-1], np.int64))).numpy()
+    tol = 0.04 * float(np.abs(lg).max())
+    for i, t in enumerate(toks[0]):
+        l = osop.soprano_repetition_penalty(lg[len(prompt) - 1 + i], list(toks[0][:i])[-30:], 1.5)
+        assert l[t] >= l.max() - tol, i
+    # (2) audio = the oracle decoder on the engine's own hidden rows (the same request through the debug entry point gives them), and those
+    # rows = the oracle LM's under teacher forcing within 1 % rms (tests/test_gpu_token_engine.py holds them to that at more positions)
+    eng = dev.lm.debug_token_engine(prompt, 12, xcds=2, want_hidden=True, sampling=gp, stop_id=3)
+    assert np.array_equal(eng["next_tokens"][len(prompt) - 1:len(prompt) + 11], toks[0]) and eng["hidden"].shape == (13, lm.hidden_size)
+    ref = odec.decode(eng["hidden"][None])[0]
+    assert pcm[0].shape == ref.shape and np.abs(pcm[0] - ref).max() <= 2e-4 * np.abs(ref).max()
+    olm.reset(1)
+    olm._forward_row(0, torch.as_tensor(np.asarray(seq, np.int64)))
+    hid_ref = olm.last_hidden.numpy()[len(prompt) - 1:]
+    assert float(np.sqrt(np.mean((eng["hidden"] - hid_ref) ** 2)) / np.sqrt(np.mean(hid_ref ** 2))) <= 0.01
+    # (3) deterministic; the launch chain on the same handle: same length, audio close (its own hidden states)
+    pcm2, toks2 = dev.generate_batch([prompt], gp, return_tokens=True)
+    assert np.array_equal(toks2[0], toks[0]) and np.array_equal(pcm2[0], pcm[0])
+    monkeypatch.setenv("MIS_TOKEN_ENGINE", "0")
+    pcm_c, toks_c = dev.generate_batch([prompt], gp, return_tokens=True)
+    monkeypatch.delenv("MIS_TOKEN_ENGINE")
+    assert len(toks_c[0]) == 12 and pcm_c[0].shape == pcm[0].shape
+    same = int(np.sum(np.asarray(toks_c[0]) == np.asarray(toks[0])))
+    assert same >= 1 and toks_c[0][0] == toks[0][0]                          # (a near-tie may send the two LMs apart later on)
+    # (4) [STOP]: the fifth token as the stop id ends the row there, unannounced
+    stop = int(toks[0][4])
+    if stop not in toks[0][:4]:
+        cfg_s, dev_s, _, _ = build(stop)
+        pcm_s, toks_s = dev_s.generate_batch([prompt], gp, return_tokens=True)
+        assert np.array_equal(toks_s[0], toks[0][:4]) and len(pcm_s[0]) == 4 * cfg.token_size
+        ref_s = odec.decode(eng["hidden"][None, :5])[0]                        # five hidden rows: the last prompt token + four generated ones
+        want = ref_s[len(ref_s) - 4 * cfg.token_size:]                        # audio[-(n - 1) * token_size:], Soprano.swift:666-671
+        assert np.abs(pcm_s[0] - want).max() <= 2e-4 * np.abs(want).max()
+    # (5) sampling: seeded
+    gs = mas.GenerateParameters(max_tokens=10, temperature=0.7, top_p=0.95, repetition_penalty=1.5, repetition_context_size=30, seed=21,
+                                sampler_flavor=1)
+    a, ta = dev.generate_batch([prompt], gs, return_tokens=True)
+    b, tb = dev.generate_batch([prompt], gs, return_tokens=True)
+    assert np.array_equal(ta[0], tb[0]) and np.array_equal(a[0], b[0])
+    gs.seed = 22
+    c, tc = dev.generate_batch([prompt], gs, return_tokens=True)
+    assert not np.array_equal(ta[0], tc[0])

@@ -56,3 +56,46 @@ def test_engine_rejects_other_shapes():
     W, oracle, dev = lm_pair(cfg)
     with pytest.raises(mas.AudioGenerationError):
         dev.debug_token_engine(np.asarray([1, 2, 3], np.int32), 2)
+
+
+def test_generate_form_sampler_is_the_oracles_on_the_engines_own_logits():
+    """The generate form (what mis_soprano_generate runs at batch 1): a token after the last prompt position and after every generated
+    one, chosen INSIDE the persistent launch - temperature 0: arg-max behind the Soprano repetition penalty; else mis-sampler-v1 behind
+    it (three more all-to-all edges: maximum, tile masses, token).  Given the logits a token was drawn from (logits row k), the choice
+    must be oracle/sampler.py's bit for bit - the same integers as csrc/lm_sampler.hip; the hidden rows are the oracle's; a stop id ends
+    the request at once; and the number of XCDs changes nothing (same arithmetic, other placement)."""
+    from oracle import sampler as osamp
+    from oracle import soprano as osop
+    W, oracle, dev = lm_pair(CFG)
+    rng = np.random.default_rng(11)
+    prompt = rng.integers(0, CFG.vocab_size, 21).astype(np.int32)
+    n_new = 34
+    for temp in (0.0, 0.7):
+        gp = mas.GenerateParameters(max_tokens=n_new, temperature=temp, top_p=0.95, repetition_penalty=1.5, repetition_context_size=30, seed=5,
+                                    row_offset=3, sampler_flavor=1)
+        out = dev.debug_token_engine(prompt, n_new, xcds=2, want_logits=True, want_hidden=True, sampling=gp)
+        assert out["chosen"] == n_new and out["positions"] == len(prompt) + n_new
+        toks = out["next_tokens"][len(prompt) - 1:len(prompt) - 1 + n_new]
+        for k in range(n_new):
+            l = osop.soprano_repetition_penalty(out["logits"][k], list(toks[:k])[-30:], 1.5)
+            want = osamp.sample(l, temp, 1.0, 5, 3, k)
+            assert toks[k] == want, (temp, k)
+        # hidden rows: position n_prompt - 1 + k through the oracle (teacher-forced with the engine's own ids)
+        seq = np.concatenate([prompt, toks]).astype(np.int32)
+        oracle.reset(1)
+        ref_l = oracle.forward([seq])[0].numpy()
+        hid_ref = oracle.last_hidden.numpy()[len(prompt) - 1:]
+        assert out["hidden"].shape == hid_ref.shape
+        assert float(np.sqrt(np.mean((out["hidden"] - hid_ref) ** 2)) / np.sqrt(np.mean(hid_ref ** 2))) <= 0.01
+        e_max, e_rms, _, _ = logits_errors(out["logits"], ref_l[len(prompt) - 1:len(prompt) - 1 + n_new])
+        assert e_max <= 0.016 and e_rms <= 0.008, (e_max, e_rms)
+        for xcds in (1, 4):
+            other = dev.debug_token_engine(prompt, n_new, xcds=xcds, want_logits=True, sampling=gp)
+            assert np.array_equal(other["next_tokens"], out["next_tokens"]) and np.array_equal(other["logits"], out["logits"]), (temp, xcds)
+        # a stop id: the fifth chosen id (if it has not come up before) ends the request there - it is reported, nothing follows it
+        stop = int(toks[4])
+        if stop not in toks[:4]:
+            st = dev.debug_token_engine(prompt, n_new, xcds=2, want_hidden=True, sampling=gp, stop_id=stop)
+            assert st["chosen"] == 5 and st["positions"] == len(prompt) + 4
+            assert np.array_equal(st["next_tokens"][len(prompt) - 1:len(prompt) + 4], toks[:5])
+            assert np.array_equal(st["hidden"][:5], out["hidden"][:5])
