@@ -459,6 +459,18 @@ extern "C" mis_status mis_soprano_group_generate(mis_soprano* const* replicas, i
     PartGuard<int32_t> tok(n);
     std::vector<int64_t> ps(n, 0), ts(n, 0);
     std::vector<int32_t> ntok(batch, 0);
+    // replicas that share a device keep to kernels that do not wait for co-resident blocks (the batch-1 token engine; see mis_tts_group_create)
+    struct SharedMarks {
+        std::vector<mis_tts*> m;
+        ~SharedMarks() { for (auto* t : m) tts_internal_set_shared_device(t, false); }
+    } marks;
+    for (int i = 0; i < n; ++i)
+        for (int j = 0; j < n; ++j)
+            if (j != i && soprano_internal_device(replicas[j]) == soprano_internal_device(replicas[i])) {
+                tts_internal_set_shared_device(soprano_internal_lm(replicas[i]), true);
+                marks.m.push_back(soprano_internal_lm(replicas[i]));
+                break;
+            }
     run_shards(n, batch, [&](int r, int lo, int hi) {
         mis_gen_params p = *params;
         p.row_offset += lo;

@@ -84,6 +84,9 @@ void token_engine_run(mis_tts* lm, const TokenEngineRequest& rq, TokenEngineResu
 // a handle whose device also runs ANOTHER replica's streams (logical shards of a group on one GPU) must not launch kernels whose blocks
 // wait for each other to be co-resident (the one-launch sampler): set by the group entry points in group.hip
 void tts_internal_set_shared_device(mis_tts* c, bool shared);
+bool tts_internal_shared_device(const mis_tts* c);
+mis_tts* soprano_internal_lm(mis_soprano* c);
+int soprano_internal_device(const mis_soprano* c);
 int whisper_internal_device(const mis_whisper* c);
 void whisper_internal_set_shared_device(mis_whisper* c, bool shared);
 

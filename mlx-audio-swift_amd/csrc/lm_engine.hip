@@ -1508,6 +1508,7 @@ static void run_generate(mis_tts* c, const int32_t* prompt_ids, const int32_t* p
     }
 }
 void tts_internal_set_shared_device(mis_tts* c, bool shared) { if (c) c->shared_device = shared; }
+bool tts_internal_shared_device(const mis_tts* c) { return c && c->shared_device; }
 
 static void default_params_check(const mis_gen_params* p) {
     MIS_REQUIRE(p, MIS_ERR_INVALID_INPUT, "null generation parameters");

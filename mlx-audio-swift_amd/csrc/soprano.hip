@@ -338,17 +338,19 @@ static void soprano_generate_impl(mis_soprano* c, const int32_t* prompt_ids, con
     if (gp.max_tokens <= 0) gp.max_tokens = 512;                       // parameters.maxTokens ?? 512 (:635)
     std::vector<int32_t> n_hidden, ntok, toks;
     int64_t tstride = 0;
-    // One row, no per-token callback: the whole LM loop as ONE persistent launch on the compute units of two XCDs (csrc/token_engine.hip:
-    // 0.26 ms per position against the launch chain's 0.60 at Soprano-80M's widths) - same sampler arithmetic, same hidden-state rows.
+    // One row, no per-token callback: the whole LM loop as ONE persistent launch on the compute units of four XCDs (csrc/token_engine.hip:
+    // 0.26 ms per position against the launch chain's 0.60 at Soprano-80M's widths; the whole generate 28 against 38 ms) - same sampler arithmetic, same hidden-state rows.
     // MIS_TOKEN_ENGINE = 0 keeps the launch chain, 1 / 2 / 4 / 8 picks the number of XCDs.  If the engine's workers cannot be co-resident
-    // (another stream holds compute units: its bounded polls run out) the request runs on the launch chain instead.
+    // (another stream holds compute units: its bounded polls run out) the request runs on the launch chain instead; a handle that shares
+    // its device with another replica of a group (group.hip) never takes the engine.
     bool by_engine = false;
     {
         const char* e = getenv("MIS_TOKEN_ENGINE");
-        const int xcds = e ? atoi(e) : 2;
+        const int xcds = e ? atoi(e) : 4;
         int32_t len0 = 0;
         if (batch == 1) HIP_CHECK(hipMemcpy(&len0, prompt_lens, 4, hipMemcpyDefault));
-        if (batch == 1 && !on_event && (xcds == 1 || xcds == 2 || xcds == 4 || xcds == 8) && token_engine_supports(c->lm) && len0 >= 1 &&
+        if (batch == 1 && !on_event && !tts_internal_shared_device(c->lm) && (xcds == 1 || xcds == 2 || xcds == 4 || xcds == 8) &&
+            token_engine_supports(c->lm) && len0 >= 1 &&
             len0 + gp.max_tokens <= 512 && gp.repetition_context <= 64 && gp.temperature >= 0.0f) {
             TokenEngineRequest rq;
             rq.prompt = prompt_ids; rq.n_prompt = len0; rq.max_new = gp.max_tokens; rq.xcds = xcds; rq.generate = true;
@@ -434,6 +436,9 @@ static void soprano_generate_impl(mis_soprano* c, const int32_t* prompt_ids, con
     if (pcm_lens) for (int b = 0; b < batch; ++b) pcm_lens[b] = plens[b];
     if (n_tokens) for (int b = 0; b < batch; ++b) n_tokens[b] = ngen[b];
 }
+
+mis_tts* soprano_internal_lm(mis_soprano* c) { return c ? c->lm : nullptr; }
+int soprano_internal_device(const mis_soprano* c) { return c ? c->device : -1; }
 
 extern "C" mis_status mis_soprano_generate(mis_soprano* c, const int32_t* prompt_ids, const int32_t* prompt_lens, int batch,
                                            const mis_gen_params* params, float** pcm_out, int64_t* pcm_stride, int64_t* pcm_lens,
