@@ -39,7 +39,8 @@ int32_t mis_debug_sampler_failures(void);
  *   sampling != NULL (generate form, the semantics of the Soprano loop, Soprano.swift:801-885): a token after the last prompt position and
  *     after every generated one until `stop_id` or n_new ids - arg-max when sampling->temperature == 0, else "mis-sampler-v1" behind the
  *     Soprano repetition penalty (repetition_penalty over the last repetition_context generated ids, seed, row_offset); next_tokens[t] is
- *     set for t >= n_prompt - 1; logits_out row k = the logits the k-th token was drawn from; hidden_out row k = position n_prompt - 1 + k.
+ *     set for t >= n_prompt - 1 (the prompt but its last position runs through the launch chain's batched prefill, whose K/V the engine
+ *     imports - as in the product); logits_out row k = the logits the k-th token was drawn from; hidden_out row k = position n_prompt - 1 + k.
  * counts (may be NULL): [0] positions processed, [1] ids chosen.  logits_out / hidden_out may be NULL; ms_out = device time of the launch.
  * Host pointers. */
 mis_status mis_debug_token_engine(mis_tts* lm, const int32_t* prompt, int n_prompt, int n_new, int xcds, const mis_gen_params* sampling,

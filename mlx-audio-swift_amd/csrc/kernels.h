@@ -59,6 +59,12 @@ struct TtsWeightsView {
 TtsWeightsView tts_internal_weights(mis_tts* c);
 // RoPE cos / sin tables [positions][D/2] for at least `max_context` positions (re-initialises the handle's per-batch state for one row)
 void tts_internal_rope_tables(mis_tts* c, int max_context, const float** cos_out, const float** sin_out);
+// K/V of one row after the launch chain's prefill, in its tiled cache layouts (lm_kernels.hip, k_attn_decode): element (pos, d) of
+//   K: ((((pos >> 5) * 2 + ((pos & 31) >> 2 & 1)) * (D / 32) + (d >> 5)) * 64 + (((d & 31) >> 3) << 4) + ((((pos & 31) >> 3) << 2) | (pos & 3))) * 8 + (d & 7)
+//   V: ((((pos >> 5) * (D / 16) + (d >> 4)) * 64 + (((pos & 31) >> 3) << 4) + (d & 15)) * 8 + (pos & 7)
+// per (layer, kv head); layer li starts at li * layer_stride
+struct TtsKvView { const bf16_t *kcache, *vtcache; const float *rope_cos, *rope_sin; int Smax, Hkv, D; size_t layer_stride; };
+TtsKvView tts_internal_prefill_kv(mis_tts* c, const int32_t* prompt_host, int n, int max_context);
 // batch-1 decode engine: one persistent launch per request on the compute units of `xcds` XCDs (token_engine.hip)
 struct TokenEngineRequest {
     const int32_t* prompt = nullptr;   // host or device
@@ -71,6 +77,7 @@ struct TokenEngineRequest {
     int64_t row = 0;
     int stop_id = -1;
     bool want_logits = false, want_hidden = false;
+    bool prefill_by_chain = false;     // generate only: the prompt but its last position through the launch chain's batched prefill, K/V imported
     float* hidden_dev = nullptr;       // device rows [positions from the last prompt token on][hidden] written in place (else returned in `hidden`)
 };
 struct TokenEngineResult {

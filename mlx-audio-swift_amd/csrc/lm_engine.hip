@@ -1874,6 +1874,31 @@ void tts_internal_rope_tables(mis_tts* c, int max_context, const float** cos_out
     lm_reset(c, 1, max_context);
     *cos_out = c->rope_cos.p; *sin_out = c->rope_sin.p;
 }
+// The launch chain's prefill for ONE row (batched [positions x 1] pass where it applies), leaving the row's K/V in the engine's tiled caches:
+// the batch-1 token engine imports them instead of walking the prompt position by position (token_engine.hip)
+TtsKvView tts_internal_prefill_kv(mis_tts* c, const int32_t* prompt_host, int n, int max_context) {
+    MIS_REQUIRE(c && c->finalized && prompt_host && n >= 1, MIS_ERR_INVALID_INPUT, "bad argument");
+    hipStream_t s = c->stream;
+    lm_reset(c, 1, std::max(max_context, n + 1));
+    std::vector<int32_t> lens(1, n);
+    c->prompt_mat.alloc(n); c->prompt_lens.alloc(1); c->step_counter.alloc(1);
+    HIP_CHECK(hipMemcpyAsync(c->prompt_mat.p, prompt_host, (size_t)n * 4, hipMemcpyHostToDevice, s));
+    HIP_CHECK(hipMemcpyAsync(c->prompt_lens.p, lens.data(), 4, hipMemcpyHostToDevice, s));
+    c->step_counter.zero(s);
+    HIP_CHECK(hipStreamSynchronize(s));
+    if (prefill_batched_ok(c, n)) prefill_batched(c, c->prompt_mat.p, c->prompt_lens.p, lens, n);
+    else
+        for (int j = 0; j < n; ++j) {
+            launch_prefill_feed(c->prompt_mat.p, c->prompt_lens.p, n, c->step_counter.p, c->ids.p, c->active.p, 1, s);
+            enqueue_layers(c);
+        }
+    HIP_CHECK(hipGetLastError());
+    TtsKvView v{};
+    v.kcache = c->kcache.p; v.vtcache = c->vtcache.p; v.Smax = c->Smax; v.Hkv = c->Hkv; v.D = c->D;
+    v.layer_stride = (size_t)1 * c->Hkv * c->Smax * c->D;
+    v.rope_cos = c->rope_cos.p; v.rope_sin = c->rope_sin.p;
+    return v;
+}
 TtsView tts_internal_view(mis_tts* c) {
     TtsView v{};
     v.x = c->x.p; v.h = c->h.p; v.logits = c->logits.p; v.emb = c->emb.p; v.ids = c->ids.p; v.pos_next = c->pos_next.p;

@@ -358,6 +358,7 @@ static void soprano_generate_impl(mis_soprano* c, const int32_t* prompt_ids, con
             rq.win_cap = std::max(gp.repetition_context, 0); rq.seed = gp.seed; rq.row = gp.row_offset; rq.stop_id = c->cfg.stop_token_id;
             c->hidden.alloc((size_t)(gp.max_tokens + 1) * c->cfg.lm.hidden_size);
             rq.hidden_dev = c->hidden.p; rq.want_hidden = true;
+            rq.prefill_by_chain = true;                                   // the prompt (but its last position) in one batched pass of the launch chain
             TokenEngineResult r;
             try {
                 token_engine_run(c->lm, rq, r);

@@ -55,6 +55,7 @@ struct TeParams {
     float eps;
     const int32_t* prompt;
     int n_prompt, n_total;
+    int t_start;                // first position the engine walks (the K/V of the positions before it were imported from the launch chain's prefill)
     int32_t* next_tokens;       // [n_total]: arg-max after position t
     float* logits_out;          // [n_total][V] or null
     float* hidden_out;          // [n_total][d] or null (final-norm output: what Soprano's decoder consumes)
@@ -283,7 +284,7 @@ __device__ __forceinline__ void te_matrix_role(const TeParams& p, const TeLds& L
         TE_ROWS_QKV(nt);
         te_load<R_QKV, KPW_D, true>(tq, p.wqkv, S::d / 32, nt, p.norms, mw, lane);
     }
-    for (int t = 0; t < p.n_total; ++t) {
+    for (int t = p.t_start; t < p.n_total; ++t) {
         te_sync();                                                   // token id
         if (*L.s_done) return;
         te_sync();                                                   // embedding row + sum of squares
@@ -493,8 +494,8 @@ __device__ __forceinline__ void te_vector_role(const TeParams& p, const TeLds& L
     };
 #define TE_STAMP(i) do { if (p.dbg && w == 0 && tid == 0 && t == p.dbg_token && li == 1) p.dbg[i] = __builtin_readcyclecounter(); } while (0)
 #define TE_EDGE_BUF() (p.xbuf + (size_t)(edge & 1u) * TE_XG)
-    int t_last = -1, n_sampled = 0;
-    for (int t = 0; t < p.n_total; ++t) {
+    int t_last = p.t_start - 1, n_sampled = 0;
+    for (int t = p.t_start; t < p.n_total; ++t) {
         if (tid == 0 && t < p.n_prompt) *L.s_tok = p.prompt[t];
         te_sync();                                                   // token id
         if (*L.s_done) break;
@@ -987,6 +988,23 @@ __global__ void __launch_bounds__(TE_NT) k_token_engine(TeParams p) {
     if (wave >= TE_VW) te_matrix_role<XCDS>(p, L, w, __builtin_amdgcn_readfirstlane(wave - TE_VW), tid & 63);     // waves 4..7: weight tiles and MFMAs
     else te_vector_role<XCDS>(p, L, w, tid);                                         // waves 0..3: everything else
 }
+// K/V of the positions the launch chain's prefill has processed, from its tiled caches (kernels.h, TtsKvView) into the engine's copy:
+// keys row-major [position][D], values transposed [D][position]
+__global__ void k_te_import_kv(const bf16_t* __restrict__ kc_all, const bf16_t* __restrict__ vt_all, size_t layer_stride, bf16_t* __restrict__ kv,
+                               int n_pos) {
+    constexpr int D = TeShape::D;
+    const int li = blockIdx.y;
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= n_pos * D) return;
+    const int pos = idx / D, d = idx % D;
+    const bf16_t* kc = kc_all + (size_t)li * layer_stride;
+    const bf16_t* vt = vt_all + (size_t)li * layer_stride;
+    const int ptile = pos >> 5, pr = pos & 31, prow = ((pr >> 3) << 2) | (pr & 3), phalf = (pr >> 2) & 1;
+    const bf16_t kval = kc[((((size_t)ptile * 2 + phalf) * (D / 32) + (d >> 5)) * 64 + (((d & 31) >> 3) << 4) + prow) * 8 + (d & 7)];
+    const bf16_t vval = vt[(((size_t)ptile * (D / 16) + (d >> 4)) * 64 + ((pr >> 3) << 4) + (d & 15)) * 8 + (pr & 7)];
+    kv[((size_t)li * 2 + 0) * TE_CTX * D + (size_t)pos * D + d] = kval;
+    kv[((size_t)li * 2 + 1) * TE_CTX * D + (size_t)d * TE_CTX + pos] = vval;
+}
 }   // namespace
 
 // ---------------------------------------------------------------------------- host side
@@ -1020,11 +1038,21 @@ void token_engine_run(mis_tts* lm, const TokenEngineRequest& rq, TokenEngineResu
     const int grid = prop.multiProcessorCount / 8 * 8;
     MIS_REQUIRE(grid / 8 == 32, MIS_ERR_DEVICE, "the engine expects 32 compute units per XCD (found %d CUs)", prop.multiProcessorCount);
     const float* rc = nullptr; const float* rs = nullptr;
-    tts_internal_rope_tables(lm, n_total, &rc, &rs);                     // (builds the tables for this context length)
     hipStream_t s = v.stream;
     std::vector<int32_t> hp(rq.n_prompt);
     HIP_CHECK(hipMemcpy(hp.data(), rq.prompt, (size_t)rq.n_prompt * 4, hipMemcpyDefault));
     for (int t : hp) MIS_REQUIRE(t >= 0 && t < v.V, MIS_ERR_INVALID_INPUT, "prompt token %d outside the vocabulary", t);
+    // The prompt, all but its last position, through the launch chain's batched prefill (one [positions x 1] pass: ~1 ms where the engine
+    // walks 0.24 ms per position); its K/V are imported below and the engine starts at the last prompt position.
+    const int t_start = (rq.generate && rq.prefill_by_chain && rq.n_prompt >= 2) ? rq.n_prompt - 1 : 0;
+    TtsKvView kvv{};
+    if (t_start > 0) {
+        kvv = tts_internal_prefill_kv(lm, hp.data(), t_start, n_total);
+        MIS_REQUIRE(kvv.D == S::D && kvv.Hkv == S::Hkv, MIS_ERR_GENERATION_FAILED, "token engine: unexpected cache geometry");
+        rc = kvv.rope_cos; rs = kvv.rope_sin;
+    } else {
+        tts_internal_rope_tables(lm, n_total, &rc, &rs);                 // (builds the tables for this context length)
+    }
     const int head_from = rq.generate ? rq.n_prompt - 1 : 0;
     const int head_until = rq.generate ? n_total - 1 : n_total;
     const int n_rows = n_total - head_from;                              // hidden rows at most; logits rows: head_until - head_from
@@ -1045,10 +1073,13 @@ void token_engine_run(mis_tts* lm, const TokenEngineRequest& rq, TokenEngineResu
     HIP_CHECK(hipMemsetAsync(d_x.p, 0, 2 * TE_XG * sizeof(u64), s));
     HIP_CHECK(hipMemsetAsync(d_next.p, 0, (size_t)n_total * 4, s));
     HIP_CHECK(hipMemsetAsync(d_done.p, 0, 8, s));
+    if (t_start > 0)
+        hipLaunchKernelGGL(k_te_import_kv, dim3((unsigned)((t_start * S::D + 255) / 256), (unsigned)v.L), dim3(256), 0, s, kvv.kcache, kvv.vtcache,
+                           kvv.layer_stride, d_kv.p, t_start);
     TeParams p{};
     p.emb = v.emb; p.wqkv = v.wqkv; p.wo = v.wo; p.wgu = v.wgu; p.wdown = v.wdown; p.head = v.head; p.norms = v.norms; p.qknorm = v.qknorm;
     p.rope_cos = rc; p.rope_sin = rs; p.L = v.L; p.V = v.V; p.Vpad = v.Vpad; p.eps = v.eps;
-    p.prompt = d_prompt.p; p.n_prompt = rq.n_prompt; p.n_total = n_total; p.next_tokens = d_next.p;
+    p.prompt = d_prompt.p; p.n_prompt = rq.n_prompt; p.n_total = n_total; p.t_start = t_start; p.next_tokens = d_next.p;
     p.logits_out = rq.want_logits ? d_logits.p : nullptr; p.hidden_out = hidden_dev;
     p.kv = d_kv.p; p.xbuf = d_x.p; p.fail = d_sync.p + 32; p.xcds = xcds; p.spin = 1 << 20;
     p.head_from = head_from; p.head_until = head_until;
@@ -1120,6 +1151,7 @@ extern "C" mis_status mis_debug_token_engine(mis_tts* lm, const int32_t* prompt,
     TokenEngineRequest rq{};
     rq.prompt = prompt; rq.n_prompt = n_prompt; rq.max_new = n_new; rq.xcds = xcds;
     rq.generate = sampling != nullptr;
+    rq.prefill_by_chain = rq.generate;                                   // the generate form as the product runs it (mis_soprano_generate)
     if (sampling) {
         rq.sample = sampling->temperature > 0.0f;
         rq.temperature = sampling->temperature; rq.penalty = sampling->repetition_penalty; rq.win_cap = std::max(sampling->repetition_context, 0);
