@@ -351,7 +351,7 @@ static void soprano_generate_impl(mis_soprano* c, const int32_t* prompt_ids, con
         if (batch == 1) HIP_CHECK(hipMemcpy(&len0, prompt_lens, 4, hipMemcpyDefault));
         if (batch == 1 && !on_event && !tts_internal_shared_device(c->lm) && (xcds == 1 || xcds == 2 || xcds == 4 || xcds == 8) &&
             token_engine_supports(c->lm) && len0 >= 1 &&
-            len0 + gp.max_tokens <= 512 && gp.repetition_context <= 64 && gp.temperature >= 0.0f) {
+            len0 + gp.max_tokens <= 1024 && gp.repetition_context <= 64 && gp.temperature >= 0.0f) {
             TokenEngineRequest rq;
             rq.prompt = prompt_ids; rq.n_prompt = len0; rq.max_new = gp.max_tokens; rq.xcds = xcds; rq.generate = true;
             rq.sample = gp.temperature > 0.0f; rq.temperature = gp.temperature; rq.penalty = gp.repetition_penalty;

@@ -43,7 +43,7 @@ struct TeShape {
 };
 constexpr int TE_NT = 512;                     // threads per worker: TE_VW vector waves + TE_MW matrix waves
 constexpr int TE_VW = 4, TE_MW = 4;
-constexpr int TE_CTX = 512;                    // positions per request (scores in LDS)
+constexpr int TE_CTX = 1024;                   // positions per request (scores and probabilities in LDS); Soprano's default budget is 512 ids
 constexpr int TE_HP = 2;                       // output-projection passes at most (vocabulary <= TE_HP x 8 x 16 x workers ids)
 constexpr int TE_KPRE = 2, TE_VPRE = 4;        // key tiles per wave / 32-key value steps requested before the layer's first poll (128 positions)
 constexpr int TE_XG = 2048;                    // granules per exchange buffer (two bf16 values + the edge's tag each)

@@ -51,6 +51,23 @@ def test_engine_logits_and_greedy_tokens_match_the_oracle_and_the_launch_chain(x
     assert np.array_equal(again["logits"], out["logits"]) and np.array_equal(again["next_tokens"], nxt)
 
 
+def test_engine_at_contexts_beyond_the_prefetched_tiles():
+    """The attention phase requests a wave's first two key tiles and the first four 32-key value steps ahead of the layer's first poll
+    (128 positions); longer contexts take the loops behind them, and the score rows in LDS hold 1 024 positions.  300 positions here: logits
+    at the positions around every boundary (128 keys, 256 keys, the 16- and 32-key tile edges) against the oracle."""
+    W, oracle, dev = lm_pair(CFG)
+    rng = np.random.default_rng(13)
+    prompt = rng.integers(0, CFG.vocab_size, 280).astype(np.int32)
+    out = dev.debug_token_engine(prompt, 20, xcds=4, want_logits=True)
+    seq = np.concatenate([prompt, out["next_tokens"][len(prompt) - 1:len(prompt) - 1 + 20]]).astype(np.int32)
+    keep = sorted({0, 15, 16, 17, 31, 32, 33, 63, 64, 127, 128, 129, 143, 144, 145, 159, 160, 161, 255, 256, 257, 271, 272, 279, 280, 299})
+    oracle.reset(1)
+    ref = oracle.forward([seq], logit_positions=[keep])[0].numpy()
+    e_max, e_rms, n_sure, agree = logits_errors(out["logits"][keep], ref)
+    assert e_max <= 0.016 and e_rms <= 0.008 and agree and n_sure > 0, (e_max, e_rms, n_sure)
+    record("token_engine_long_context", logits_max_rel=e_max, logits_rms_rel=e_rms, tol_max=0.016, tol_rms=0.008, positions=len(seq))
+
+
 def test_engine_rejects_other_shapes():
     cfg = ollama.LlamaConfig(**{**ollama.TINY_QWEN3.__dict__})
     W, oracle, dev = lm_pair(cfg)

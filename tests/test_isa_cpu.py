@@ -113,3 +113,25 @@ def test_whisper_cross_attention_keeps_two_pairs_of_key_tiles_in_flight():
     # requested BEFORE the wait for the group in front of it - twice on the six-tile path, twice on the five-tile path
     behind_pair = [w for k, w in waits if k >= 16]
     assert len(behind_pair) == 4 and all(w >= 16 for w in behind_pair), waits
+
+
+def test_token_engine_keeps_its_tile_buffers_in_registers():
+    """csrc/token_engine.hip holds a phase's weight tiles in registers while the previous phase is still running (gate|up: 176 registers
+    per matrix wave).  Two compiler behaviours once put them into scratch - tile addresses hoisted out of the layer loop (~200 registers
+    of addresses) and the output projection's tiles live across the whole loop; the source works around both (opaque scalar ids, rotated
+    loop).  Pinned here: no scratch at all on 2 / 4 / 8 XCDs (the product's default is 4), a bounded remainder on 1 XCD (ten tile rows of
+    gate|up per worker), and the barrier the two programs meet at must not drain vector-memory loads."""
+    text, use = _compiled("token_engine.hip")
+    eng = {k: v for k, v in use.items() if "k_token_engine" in k}
+    assert len(eng) == 4, list(eng)
+    for k, v in eng.items():
+        one = "ILi1E" in k
+        assert v["vgprs"] <= 256, (k, v)
+        assert v["scratch"] <= (256 if one else 0), (k, v)
+    # te_sync() = s_waitcnt lgkmcnt(0) + s_barrier: the instruction in front of (almost) every barrier is the lgkmcnt-only wait
+    name = [k for k in eng if "ILi4E" in k][0]
+    i = text.index("\n" + name + ":")
+    body = [l.strip() for l in text[i: text.index(".Lfunc_end", i)].split("\n")]
+    waits = [body[j - 1] for j, l in enumerate(body) if l.startswith("s_barrier") and j > 0]
+    assert len(waits) >= 40
+    assert sum(1 for w_ in waits if w_.startswith("s_waitcnt") and "vmcnt" not in w_) >= 0.9 * len(waits), waits[:8]
