@@ -19,3 +19,9 @@ cp $(find /tmp/ks -name "*kernel_stats.csv" | head -1) gpurun_out/final/bench_ke
 timeout 120 python tools/samp_phases.py 32 2> gpurun_out/final/samp_phases.txt
 rm -rf /tmp/pm; (cd /tmp && timeout 600 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES GRBM_GUI_ACTIVE SQ_WAVES --kernel-trace --output-format csv -d /tmp/pm -- python $OLDPWD/tools/pmc_codec_probe.py whisper > /tmp/pm.log 2>&1)
 python tools/pmc_mfma_reduce.py /tmp/pm gpurun_out/final/whisper_mfma_util.json > /dev/null
+# configs[1] on the batch-1 token engine: kernel stats of the generate call (k_token_engine = the LM loop as one launch)
+rm -rf /tmp/ks2; (cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/ks2 -- python $OLDPWD/tools/bench_soprano.py 1 > /tmp/ks2.log 2>&1)
+cp $(find /tmp/ks2 -name "*kernel_stats.csv" | head -1) gpurun_out/final/soprano_engine_kernel_stats.csv
+timeout 200 python tools/bench_token_engine.py > gpurun_out/final/token_engine_bench.jsonl 2>/dev/null
+# identity of the sources this evidence belongs to (the box has no .git): sha1 over every source file of the product, the tests and the tools
+find mlx-audio-swift_amd include tests tools oracle bench.py __graft_entry__.py -type f \( -name "*.hip" -o -name "*.h" -o -name "*.cpp" -o -name "*.py" -o -name "*.sh" -o -name Makefile \) | sort | xargs sha1sum | sha1sum | cut -c1-16 > gpurun_out/final/source_tree_sha1.txt
