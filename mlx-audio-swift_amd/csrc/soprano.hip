@@ -58,19 +58,40 @@ __global__ void k_sop_im2col(const float* __restrict__ x, float* __restrict__ y,
     y[((size_t)b * k * C + r) * T + t] = (ts >= 0 && ts < T) ? x[((size_t)b * C + c) * T + ts] : 0.0f;
 }
 
-// LayerNorm over the CHANNEL axis of NCT data (eps 1e-6): thread = one time step, loops over C (coalesced over t)
-__global__ void k_sop_ln_ct(const float* __restrict__ x, float* __restrict__ y, const float* __restrict__ w,
-                            const float* __restrict__ bias, int C, int T, float eps) {
-    int t = blockIdx.x * blockDim.x + threadIdx.x, b = blockIdx.y;
-    if (t >= T) return;
-    const float* xb = x + (size_t)b * C * T + t;
+// LayerNorm over the CHANNEL axis of NCT data (eps 1e-6).  Block = 32 time steps x 8 channel groups: a thread walks every eighth channel
+// of its column (loads coalesced over t), the eight partial sums of a column meet in LDS in a fixed order; mean first, then the centred
+// sum of squares (two passes, as the reference's LayerNorm).  (Round 5: the first version - one thread per time step looping over all
+// 768 channels three times - took 357 us per call at one row of 257 frames, ten calls per decode = 3.6 of the 24 ms of a batch-1
+// generate, profiles/r05_final_soprano_engine_kernel_stats.csv: two blocks on a 256-CU part.)
+#define SOP_LN_TX 32
+#define SOP_LN_CG 8
+__global__ void __launch_bounds__(SOP_LN_TX * SOP_LN_CG) k_sop_ln_ct(const float* __restrict__ x, float* __restrict__ y, const float* __restrict__ w,
+                                                                      const float* __restrict__ bias, int C, int T, float eps) {
+    __shared__ float red[SOP_LN_CG][SOP_LN_TX];
+    const int tx = threadIdx.x & (SOP_LN_TX - 1), cg = threadIdx.x / SOP_LN_TX;
+    const int t = blockIdx.x * SOP_LN_TX + tx, b = blockIdx.y;
+    const bool live = t < T;
+    const float* xb = x + (size_t)b * C * T + (live ? t : 0);
     float s = 0.0f;
-    for (int c = 0; c < C; ++c) s += xb[(size_t)c * T];
-    float mean = s / (float)C, q = 0.0f;
-    for (int c = 0; c < C; ++c) { float d = xb[(size_t)c * T] - mean; q += d * d; }
-    float rstd = 1.0f / sqrtf(q / (float)C + eps);
+    for (int c = cg; c < C; c += SOP_LN_CG) s += xb[(size_t)c * T];
+    red[cg][tx] = s;
+    __syncthreads();
+    float tot = 0.0f;
+#pragma unroll
+    for (int g = 0; g < SOP_LN_CG; ++g) tot += red[g][tx];
+    const float mean = tot / (float)C;
+    __syncthreads();
+    float q = 0.0f;
+    for (int c = cg; c < C; c += SOP_LN_CG) { const float d = xb[(size_t)c * T] - mean; q += d * d; }
+    red[cg][tx] = q;
+    __syncthreads();
+    float qt = 0.0f;
+#pragma unroll
+    for (int g = 0; g < SOP_LN_CG; ++g) qt += red[g][tx];
+    const float rstd = 1.0f / sqrtf(qt / (float)C + eps);
+    if (!live) return;
     float* yb = y + (size_t)b * C * T + t;
-    for (int c = 0; c < C; ++c) yb[(size_t)c * T] = (xb[(size_t)c * T] - mean) * rstd * w[c] + bias[c];
+    for (int c = cg; c < C; c += SOP_LN_CG) yb[(size_t)c * T] = (xb[(size_t)c * T] - mean) * rstd * w[c] + bias[c];
 }
 
 // head output hh [B][n_fft+2][T] -> spec [B][2*bins][T]: rows 0..bins-1 = mag*cos(phase), bins.. = mag*sin(phase),
@@ -271,12 +292,12 @@ static void soprano_decode_device(mis_soprano* c, const float* hidden_dev, int64
     GemmParams g{};
     g.AT = W + c->embed_w; g.bias = W + c->embed_b; g.X = xin; g.Y = b; g.M = d; g.K = Kin; g.N = T; g.Tin = T; g.Tout = T;
     launch_gemm(GEMM_PLAIN, false, g, batch, s);
-    hipLaunchKernelGGL(k_sop_ln_ct, dim3(tg.x, batch), tb, 0, s, b, a, W + c->norm_w, W + c->norm_b, d, T, 1e-6f);
+    hipLaunchKernelGGL(k_sop_ln_ct, dim3(cdiv(T, SOP_LN_TX), batch), dim3(SOP_LN_TX * SOP_LN_CG), 0, s, b, a, W + c->norm_w, W + c->norm_b, d, T, 1e-6f);
     float* h = a;       // residual stream
     float* o = b;
     for (const auto& blk : c->blocks) {                                // ConvNeXtBlock, VocosBackbone.swift:64-99
         launch_dw7(h, t1, W + blk.dw, W + blk.dwb, batch, d, T, 1, s);
-        hipLaunchKernelGGL(k_sop_ln_ct, dim3(tg.x, batch), tb, 0, s, t1, t2, W + blk.lnw, W + blk.lnb, d, T, 1e-6f);
+        hipLaunchKernelGGL(k_sop_ln_ct, dim3(cdiv(T, SOP_LN_TX), batch), dim3(SOP_LN_TX * SOP_LN_CG), 0, s, t1, t2, W + blk.lnw, W + blk.lnb, d, T, 1e-6f);
         g = GemmParams{};
         g.AT = W + blk.p1; g.bias = W + blk.b1; g.X = t2; g.Y = t1; g.M = inter; g.K = d; g.N = T; g.Tin = T; g.Tout = T;
         launch_gemm(GEMM_GELU, false, g, batch, s);
@@ -286,7 +307,7 @@ static void soprano_decode_device(mis_soprano* c, const float* hidden_dev, int64
         launch_gemm(GEMM_RESID, false, g, batch, s);
         std::swap(h, o);
     }
-    hipLaunchKernelGGL(k_sop_ln_ct, dim3(tg.x, batch), tb, 0, s, h, o, W + c->fin_w, W + c->fin_b, d, T, 1e-6f);
+    hipLaunchKernelGGL(k_sop_ln_ct, dim3(cdiv(T, SOP_LN_TX), batch), dim3(SOP_LN_TX * SOP_LN_CG), 0, s, h, o, W + c->fin_w, W + c->fin_b, d, T, 1e-6f);
     g = GemmParams{};
     g.AT = W + c->head_w; g.bias = W + c->head_b; g.X = o; g.Y = t1; g.M = nf + 2; g.K = d; g.N = T; g.Tin = T; g.Tout = T;
     launch_gemm(GEMM_PLAIN, false, g, batch, s);
