@@ -1,33 +1,38 @@
-// token_engine.hip - a batch-1 decode engine for small LMs: ONE persistent launch runs every token of a request on the compute units
-// of ONE XCD.
+// token_engine.hip - a batch-1 decode engine for small LMs: ONE persistent launch runs every position of a request (the generate loop
+// with its sampler included) on the compute units of a few XCDs.
 //
 // Why (BASELINE configs[1], Soprano-80M at batch 1): the launch chain spends ~125 graph nodes x 4.7 us on a
 // token whose weights (160 MB) stream in 25 us - 0.03 of HBM.  At one row every op's output is a vector of 1-5 KB, so the per-op cost
-// is the hand-off between compute units, and that hand-off is cheap INSIDE an XCD and expensive across the chip.  Measured before this
-// was written (tools/token_engine_lab/probe.hip, profiles/r05/c2_xcd_stream_exchange_probe.json): an all-to-all edge (publish a slice,
-// arrive on a counter, poll, gather the vector) among the 32 CUs of one XCD costs 1.65 us at 1 KB / 2.29 us at 4.6 KB, among 64 / 128 /
-// 256 CUs 2.4 / 3.2 / 6.2 us; one XCD streams 1.28 TB/s out of the Infinity Cache (2.6 / 4.9 / 7.1 TB/s for 2 / 4 / 8).  Per token
-// (69 edges, 160 MB): ~131 us of stream + ~126 us of edges on ONE XCD against 24 + 441 on eight - the chip-wide form is the launch
-// chain's price again, the single-XCD form is 2-4x under it.
+// is the hand-off between compute units - a kernel boundary in the chain.  Measured before this was written
+// (tools/token_engine_lab/probe.hip, profiles/r05/c2_xcd_stream_exchange_probe.json): an all-to-all edge (publish a slice, arrive on a
+// counter, poll, gather the vector) among the 32 CUs of one XCD costs 1.65 us at 1 KB / 2.29 us at 4.6 KB, among 64 / 128 / 256 CUs
+// 2.4 / 3.2 / 6.2 us; one XCD streams 1.28 TB/s out of the Infinity Cache (2.6 / 4.9 / 7.1 TB/s for 2 / 4 / 8).  Per token (69 edges,
+// 160 MB): ~131 us of stream + ~126 us of edges on ONE XCD against 24 + 441 on eight - the chip-wide form is the launch chain's price
+// again, few XCDs are 2-4x under it.  With the edge form this file ended up with (tagged granules, below) four XCDs are the optimum:
+// 0.26 ms per position against the chain's 0.60 ("Batch-1 token engine": every version with its measurement).
 //
 // Structure.  Grid = one 512-thread block per CU; the blocks whose index mod 8 is below `xcds` are the W = 32 x xcds workers (observed
 // placement: block b runs on XCD b mod 8 - used for speed only; every hand-off below is placement-independent), the others exit.
 // Every worker holds the whole residual stream in LDS and owns a slice of the OUTPUT rows of every matrix:
 //   per layer   RMSNorm (local) -> q|k|v slice                       -> edge 1 (Nqkv values)
-//               q/k-norm, RoPE, attention over its PRIVATE K/V copy - computed redundantly by every worker (at one row it is ~50 KB
-//               of cache reads; a private copy needs no coherence protocol and saves an edge) -> o_proj slice, residual -> edge 2 (d)
+//               q/k-norm, RoPE, attention - computed REDUNDANTLY by every worker over ONE shared K/V copy that all of them write with the
+//               same bytes (no coherence protocol, no edge; ~50 KB of cache reads per layer at one row) -> o_proj slice, residual -> edge 2 (d)
 //               RMSNorm (local) -> gate|up pairs, SwiGLU             -> edge 3 (ff)
 //               down_proj slice, residual                            -> edge 4 (d)
-//   per token   final norm -> output-projection slice -> local arg-max -> edge 5 (one candidate per worker) -> next token's embedding
-// A GEMV slice runs on v_mfma_f32_16x16x32_bf16 with the engine's pre-packed weight tiles [N/16][K/32][64][8] as the A operand and the
-// input vector as row 0 of the B operand (15/16 of the matrix core idles - at one row the tile stream is the cost, not the math); the
-// eight waves of a worker split a tile row's K range and combine through LDS in a fixed order.
-// An edge = 8-byte agent-scope stores of the worker's values (bf16 x 4 per granule) into a double-buffered vector, one arrival on a
-// monotonic counter, a bounded poll, 8-byte agent-scope loads of the whole vector (MI355X_MICROARCH.md: "8-B agent atomics both sides").
+//   per token   final norm (hidden tap) -> output-projection slice -> the token: arg-max (edge 5), arg-max behind the repetition penalty
+//               (edges 5-6) or mis-sampler-v1 (edges 5-7: maximum, tile masses, token) -> next position's embedding
+// Two programs share a block (te_matrix_role, te_vector_role): waves 4-7 hold the weight tiles - a GEMV slice runs on
+// v_mfma_f32_16x16x32_bf16 with the engine's pre-packed tiles [N/16][K/32][64][8] as the A operand and the input vector as row 0 of B
+// (15/16 of the matrix core idles: at one row the tile stream is the cost, not the math), each wave a quarter of the K range, tiles
+// requested a phase ahead in pieces; waves 0-3 do the gathers, norms, attention (QK^T and P.V on the matrix core too), epilogues and
+// edges.  An edge = self-validating 8-byte granules {two bf16 values, the edge's tag}: one agent-scope store by the producer, polled by
+// the consumers (MI355X_MICROARCH.md, hand-off form R2).
 // Rounding points are the oracle's (oracle/llama.py = MLX's bf16 graph): every primitive output rounded to bf16, float32 accumulation.
 //
-// State of this file: a measured laboratory behind include/mi_speech_debug.h (greedy decoding, Soprano-80M's widths compiled in); it
-// reads the product handle's weights, so its logits are compared with the product's and the oracle's (tests/test_gpu_token_engine.py).
+// In the product: mis_soprano_generate at batch 1 (csrc/soprano.hip; prompt through the launch chain's batched prefill, its K/V
+// imported; falls back to the launch chain when the workers cannot be co-resident).  Compiled for Soprano-80M's widths (TeShape).
+// Tests: tests/test_gpu_token_engine.py (oracle and launch-chain logits, sampler bit-exact on its own logits, hidden rows, stop id,
+// long contexts, 1 / 2 / 4 / 8 XCDs), tests/test_gpu_soprano.py, tests/test_isa_cpu.py (register budget).
 #include "common.h"
 #include "kernels.h"
 #include "sampler_math.h"
