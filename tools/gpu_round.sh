@@ -6,8 +6,6 @@ cd ${GRAFT_REPO_ROOT:-.}
 mkdir -p gpurun_out/final
 export TMPDIR=/tmp
 rm -f gpurun_out/parity_observed.jsonl
-# identity of the sources this evidence belongs to (the box has no .git): sha1 over every source file of the product, the tests and the tools
-find mlx-audio-swift_amd include tests tools oracle bench.py __graft_entry__.py -type f \( -name "*.hip" -o -name "*.h" -o -name "*.cpp" -o -name "*.py" -o -name "*.sh" -o -name Makefile \) | sort | xargs sha1sum | sha1sum | cut -c1-16 > gpurun_out/final/source_tree_sha1.txt
 [ -n "$SKIP_TESTS" ] || { timeout 1800 python -m pytest tests -m gpu -q -rs --durations=8 2>&1 | grep -E "passed|failed|error|SKIPPED|s call|s setup" | tail -14 > gpurun_out/final/pytest_gpu.txt; cat gpurun_out/final/pytest_gpu.txt; }
 cp gpurun_out/parity_observed.jsonl gpurun_out/final/ 2>/dev/null
 # PMC traffic first, and installed where bench.py looks for it (on this box's copy of the repo): the bench line below then names the traffic
@@ -25,3 +23,5 @@ python tools/pmc_mfma_reduce.py /tmp/pm gpurun_out/final/whisper_mfma_util.json 
 rm -rf /tmp/ks2; (cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/ks2 -- python $OLDPWD/tools/bench_soprano.py 1 > /tmp/ks2.log 2>&1)
 cp $(find /tmp/ks2 -name "*kernel_stats.csv" | head -1) gpurun_out/final/soprano_engine_kernel_stats.csv
 timeout 200 python tools/bench_token_engine.py > gpurun_out/final/token_engine_bench.jsonl 2>/dev/null
+# identity of the sources this evidence belongs to (the box has no .git): sha1 over every source file of the product, the tests and the tools
+find mlx-audio-swift_amd include tests tools oracle bench.py __graft_entry__.py -type f \( -name "*.hip" -o -name "*.h" -o -name "*.cpp" -o -name "*.py" -o -name "*.sh" -o -name Makefile \) | sort | xargs sha1sum | sha1sum | cut -c1-16 > gpurun_out/final/source_tree_sha1.txt
