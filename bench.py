@@ -174,7 +174,7 @@ def secondary_benches(device, orpheus=None):
     gps = mas.GenerateParameters(max_tokens=64, temperature=0.7, top_p=0.95, repetition_penalty=1.5, repetition_context_size=30, seed=7, sampler_flavor=1)
     def _soprano_best():
         b = 1e9
-        for rep in range(6):                                # (one warm-up, best of five: a 20 ms call, the host's share of it varies by ~5 %)
+        for rep in range(3):
             t0 = time.perf_counter(); pcm = sm.generate_batch(srow, gps); dt = time.perf_counter() - t0
             b = min(b, dt) if rep else b
         return b, pcm

@@ -567,16 +567,7 @@ extern "C" mis_status mis_debug_occupy_cus(int device, int blocks, int threads, 
     occupy_release_and_wait();                                        // (a spinner of an earlier call)
     if (!g_occupy_host) HIP_CHECK(hipHostMalloc((void**)&g_occupy_host, (size_t)(OCCUPY_MAX_BLOCKS + 1) * sizeof(unsigned), hipHostMallocCoherent));
     memset(g_occupy_host, 0, (size_t)(OCCUPY_MAX_BLOCKS + 1) * sizeof(unsigned));
-    // a stream of its own PRIORITY class: the runtime multiplexes the streams of one priority over a few hardware queues, and a spinner that
-    // lands on the queue of the stream under test does not take CUs away from it - it simply runs in front of it (seen in long-lived test
-    // processes only: which queue a new stream gets depends on every stream the process has created before)
-    int prio_least = 0, prio_greatest = 0;
-    if (hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest) != hipSuccess || prio_greatest == prio_least ||
-        hipStreamCreateWithPriority(&g_occupy_stream, hipStreamNonBlocking, prio_greatest) != hipSuccess) {
-        (void)hipGetLastError();
-        g_occupy_stream = nullptr;
-        HIP_CHECK(hipStreamCreateWithFlags(&g_occupy_stream, hipStreamNonBlocking));
-    }
+    HIP_CHECK(hipStreamCreateWithFlags(&g_occupy_stream, hipStreamNonBlocking));
     static const bool lds_ok = hipFuncSetAttribute((const void*)k_debug_spin, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024) == hipSuccess;
     MIS_REQUIRE(lds_ok, MIS_ERR_DEVICE, "cannot reserve 128 KB of LDS for the spinner");
     hipLaunchKernelGGL(k_debug_spin, dim3(blocks), dim3(threads), 128 * 1024, g_occupy_stream, (unsigned long long)(seconds * 1e8),

@@ -76,9 +76,8 @@ def test_one_launch_sampler_with_compute_units_held_by_another_stream(monkeypatc
         held_for = time.perf_counter() - t0
     assert np.array_equal(got, ref)
     if lib.mis_debug_sampler_failures() == before and held_for >= 5.0:
-        # (seen inside full-suite runs while the spinner's stream was an ordinary one: the runtime had put it on the hardware queue of the
-        # stream under test, the sampler only launched once the spinner had run out - tokens right, nothing provoked.  The spinner now has a
-        # stream of its own priority class, group.hip; the skip stays as the safety net for runtimes without stream priorities)
+        # (seen once, inside a full-suite run: the entry point's allocations / synchronous copies were serialised behind the spinner by the
+        # runtime, the sampler only launched once the spinner had run out - tokens right, nothing provoked)
         pytest.skip(f"the call was serialised behind the spinner ({held_for:.1f} s): tokens equal, but the time-out was not provoked")
     assert lib.mis_debug_sampler_failures() == before + 1
     monkeypatch.delenv("MIS_SAMPLER_SPIN")
