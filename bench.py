@@ -86,6 +86,23 @@ def cpu_baseline(snac_cfg_dict):
             t_full.append(t1 - t0); t_head.append(t2 - t1)
     t_full, t_head = np.asarray(t_full), np.asarray(t_head)
     med_full, med_head = float(np.median(t_full)), float(np.median(t_head))
+    # Why 16 threads and not every host core: the same step timed with ALL available cores, recorded beside the
+    # 16-thread figure on every run - a batch-1 decode step is a chain of ~10 GEMVs per layer, and with one thread per core of the GPU
+    # box's host the fork/join of every GEMV costs more than its arithmetic.  The baseline is the FASTER of the two thread counts.
+    all_cores_med = None
+    if avail > cores:
+        torch.set_num_threads(avail)
+        ta = []
+        for i in range(2 + 8):
+            t0 = time.perf_counter()
+            orc.forward([[100 + i]])
+            if i >= 2:
+                ta.append(time.perf_counter() - t0)
+        all_cores_med = float(np.median(ta))
+        torch.set_num_threads(cores)
+        if all_cores_med < med_full:                                    # all cores faster on this host: use them (and say so)
+            scale = all_cores_med / med_full
+            med_full, med_head, cores = all_cores_med, med_head * scale, avail
     t_layer = max(med_full - med_head, 1e-6)
     t_token = 28 * t_layer + med_head
     spread = (float(np.percentile(t_full, 10)), float(np.percentile(t_full, 90)))
@@ -108,7 +125,10 @@ def cpu_baseline(snac_cfg_dict):
                       "(x28 layers extrapolated) + median of 3 SNAC decodes of 12 frames, %d threads of %d available cores; "
                       "per-token %.4f s, SNAC %.3f s per 1.024 s" % (warm, steps, cores, avail, t_token, t_snac),
             "step_1layer_s": {"median": med_full, "p10": spread[0], "p90": spread[1], "rel_spread": (spread[1] - spread[0]) / med_full},
-            "lm_head_s_median": med_head, "snac_s_per_1024ms": t_snac, "host_cores_available": int(avail)}
+            "lm_head_s_median": med_head, "snac_s_per_1024ms": t_snac, "host_cores_available": int(avail),
+            "threads_note": "16 threads by default: a batch-1 step is a chain of GEMVs whose fork/join over every host core costs more than the "
+                            "arithmetic; the same step with all %d cores is timed on every run (step_1layer_all_cores_s) and the faster count is used" % avail,
+            "step_1layer_all_cores_s": all_cores_med}
 
 
 def _lm_weight_elems(cfg):
@@ -178,7 +198,26 @@ def secondary_benches(device, orpheus=None):
             t0 = time.perf_counter(); pcm = sm.generate_batch(srow, gps); dt = time.perf_counter() - t0
             b = min(b, dt) if rep else b
         return b, pcm
+    def _soprano_stream_best():
+        # generateStream, the entry point the reference's CLI times (App.swift:130-138): .token events while the launch runs, then .info / .audio
+        b, first, n_tok, audio = 1e9, None, 0, None
+        for rep in range(3):
+            t0 = time.perf_counter(); t_first = None; n = 0
+            for ev in sm.generate_stream_batch(srow, gps):
+                if isinstance(ev, mas.TokenEvent):
+                    n += 1
+                    if t_first is None:
+                        t_first = time.perf_counter() - t0
+                elif isinstance(ev, mas.AudioEvent):
+                    audio = ev.audio
+            dt = time.perf_counter() - t0
+            if rep and dt < b:
+                b, first, n_tok = dt, t_first, n
+        return b, first, n_tok, audio
     best, pcm_s = _soprano_best()                           # batch 1: the LM loop is ONE persistent launch (csrc/token_engine.hip)
+    sop_path = sm.lm_path                                   # 1 = the token engine ran it (mis_soprano_lm_path)
+    stream_best, stream_first, stream_tokens, stream_audio = _soprano_stream_best()
+    stream_path = sm.lm_path
     prev = os.environ.get("MIS_TOKEN_ENGINE")
     os.environ["MIS_TOKEN_ENGINE"] = "0"                    # the same request on the launch chain (one hipGraph replay per token), for the record
     chain_best, _ = _soprano_best()
@@ -191,7 +230,13 @@ def secondary_benches(device, orpheus=None):
     out["soprano_80m_b1"] = {
         "config": "BASELINE configs[1]: Soprano-80M bf16 LM + f32 Vocos/ISTFT decoder, batch 1, 24-token prompt, 64 new tokens",
         "audio_s_per_s": len(pcm_s[0]) / scfg.sample_rate / best, "ms": best * 1e3, "ms_per_token": best * 1e3 / 64,
-        "lm_loop": "token engine: one persistent launch for the 24 prompt + 64 generated positions on the CUs of 4 XCDs (csrc/token_engine.hip)",
+        "lm_loop": "token engine: the 23 leading prompt positions in ONE batched pass of the launch chain (K/V imported), then one persistent launch for "
+                   "the last prompt position + 64 generated positions on the CUs of 4 XCDs, sampler inside (csrc/token_engine.hip)",
+        "lm_path": sop_path,
+        "generate_stream": {"audio_s_per_s": len(stream_audio) / scfg.sample_rate / stream_best, "ms": stream_best * 1e3, "first_token_ms": (stream_first or 0.0) * 1e3,
+                            "token_events": stream_tokens, "lm_path": stream_path, "same_samples_as_generate": bool(np.array_equal(stream_audio, pcm_s[0])),
+                            "note": "mis_soprano_generate_stream through the host mirror: .token events fired from host-visible memory while the "
+                                    "persistent launch runs (Soprano.swift:801-885, App.swift:130-138)"},
         "launch_chain": {"audio_s_per_s": len(pcm_s[0]) / scfg.sample_rate / chain_best, "ms": chain_best * 1e3, "ms_per_token": chain_best * 1e3 / 64},
         "roofline": {"bound": "hbm", "phase": "decode step (LM weights streamed once per token; the whole generate call is the denominator)",
                      "achieved": sop_bytes * 64 / best / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": sop_bytes * 64 / best / 1e9 / HBM_PEAK_GBS}}

@@ -364,10 +364,19 @@ mis_status mis_soprano_decode(mis_soprano*, const float* hidden, int batch, int 
 mis_status mis_soprano_generate(mis_soprano*, const int32_t* prompt_ids, const int32_t* prompt_lens, int batch,
                                 const mis_gen_params* params, float** pcm_out, int64_t* pcm_stride, int64_t* pcm_lens,
                                 int32_t** tokens_out, int64_t* tokens_stride, int32_t* n_tokens);
+/* Which program ran the LM loop of the handle's LAST generate / generateStream call: 0 = the launch chain, chosen by rule; 1 = the batch-1
+ * token engine (one persistent launch; chosen by rule: a ONE-row request - over all shards of a group call - on a bf16 checkpoint of
+ * Soprano-80M's widths, device of 8 XCDs x 32 compute units not shared with another replica, prompt + max_tokens <= 1024,
+ * repetition context <= 64; MIS_TOKEN_ENGINE=0 disables it); 2 = the launch chain AFTER the engine's workers could not be made
+ * co-resident (another stream held compute units; also written to stderr).  The two programs round at the same points but sum in other
+ * orders: ids can differ on near-ties, so the choice never depends on stream vs non-stream, only on the request (and, reported, on 2). */
+int32_t    mis_soprano_lm_path(const mis_soprano*);
 /* generateStream (Soprano.swift:693-800) for a batch of tokenised sentences: MIS_EVENT_TOKEN per sampled id while the loop runs
  * (the [STOP] token is not announced, :855-857), then per row MIS_EVENT_INFO (SopranoGenerationInfo :771-779: prompt count and
  * prefill time 0, generation count = hidden states decoded) and ONE MIS_EVENT_AUDIO (:781).  cancel_flag polled every 8 steps
- * (continuation.onTermination -> task.cancel(), :798) -> MIS_ERR_CANCELLED. */
+ * (token engine: every ~20 us, honoured at the launch's next position) (continuation.onTermination -> task.cancel(), :798)
+ * -> MIS_ERR_CANCELLED.  At one row the events are fired while ONE persistent launch runs (csrc/token_engine.hip): the ids arrive in
+ * host-visible memory, the calling thread polls them. */
 mis_status mis_soprano_generate_stream(mis_soprano*, const int32_t* prompt_ids, const int32_t* prompt_lens, int batch,
                                        const mis_gen_params* params, mis_event_cb on_event, void* user,
                                        const volatile int* cancel_flag);

@@ -212,6 +212,7 @@ SYMBOLS = {
     "mis_soprano_finalize": (C.c_int, [_P]),
     "mis_soprano_destroy": (None, [_P]),
     "mis_soprano_lm": (_P, [_P]),
+    "mis_soprano_lm_path": (C.c_int32, [_P]),
     "mis_soprano_num_samples": (C.c_int64, [_P, C.c_int]),
     "mis_soprano_decode": (C.c_int, [_P, _P, C.c_int, C.c_int, _P]),
     "mis_soprano_generate": (C.c_int, [_P, _P, _P, C.c_int, C.POINTER(GenParamsC), C.POINTER(_P), C.POINTER(C.c_int64),

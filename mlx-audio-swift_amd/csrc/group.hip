@@ -471,6 +471,13 @@ extern "C" mis_status mis_soprano_group_generate(mis_soprano* const* replicas, i
                 marks.m.push_back(soprano_internal_lm(replicas[i]));
                 break;
             }
+    // the LM program of a shard is chosen on the REQUEST's batch, not on the shard's (soprano.hip): a one-row shard of a larger batch runs
+    // the launch chain like every other row of it, so the sharded result equals the single-handle result of the same batch
+    struct GroupBatch {
+        mis_soprano* const* r; int n;
+        ~GroupBatch() { for (int i = 0; i < n; ++i) soprano_internal_set_group_batch(r[i], 0); }
+    } group_batch{replicas, n};
+    for (int i = 0; i < n; ++i) soprano_internal_set_group_batch(replicas[i], batch);
     run_shards(n, batch, [&](int r, int lo, int hi) {
         mis_gen_params p = *params;
         p.row_offset += lo;

@@ -1,6 +1,7 @@
 // kernels.h - launchers shared between translation units of libmi_speech.
 #pragma once
 #include "common.h"
+#include <functional>
 
 // orpheus_codes.hip
 void launch_orpheus_deinterleave(const int32_t* codes7, int in_stride, int batch, int groups, int32_t* l0,
@@ -66,6 +67,9 @@ void tts_internal_rope_tables(mis_tts* c, int max_context, const float** cos_out
 struct TtsKvView { const bf16_t *kcache, *vtcache; const float *rope_cos, *rope_sin; int Smax, Hkv, D; size_t layer_stride; };
 TtsKvView tts_internal_prefill_kv(mis_tts* c, const int32_t* prompt_host, int n, int max_context);
 // batch-1 decode engine: one persistent launch per request on the compute units of `xcds` XCDs (token_engine.hip)
+struct TokenEngineScratch;             // per-handle buffers of the engine (K/V copy, exchange buffers, host-visible token row), reused by every request
+TokenEngineScratch* token_engine_scratch_create();
+void token_engine_scratch_destroy(TokenEngineScratch*);
 struct TokenEngineRequest {
     const int32_t* prompt = nullptr;   // host or device
     int n_prompt = 0, max_new = 0, xcds = 2;
@@ -79,20 +83,33 @@ struct TokenEngineRequest {
     bool want_logits = false, want_hidden = false;
     bool prefill_by_chain = false;     // generate only: the prompt but its last position through the launch chain's batched prefill, K/V imported
     float* hidden_dev = nullptr;       // device rows [positions from the last prompt token on][hidden] written in place (else returned in `hidden`)
+    TokenEngineScratch* scratch = nullptr;   // null: buffers of this call only
+    // stream form (generate only): called on the CALLING thread, in order, for the k-th chosen id WHILE the launch runs (the ids land in
+    // host-visible memory one system-scope store each); cancel: polled by the host beside the ids, forwarded to the launch, which ends at
+    // its next position - token_engine_run then throws MIS_ERR_CANCELLED
+    std::function<void(int k, int32_t id)> on_token;
+    const volatile int* cancel = nullptr;
+    int spin = 0;                      // polls per granule before an edge counts as timed out (0: the default, ~1 s; MIS_TE_SPIN overrides - tests force a time-out with 0)
 };
 struct TokenEngineResult {
     std::vector<int32_t> next_tokens;  // [n_prompt + max_new]: the id chosen after position t (positions without an output projection: 0)
     std::vector<float> logits, hidden;
     int n_positions = 0, n_sampled = 0, head_from = 0;
+    int n_announced = 0;               // ids handed to on_token (also on the failure paths: what the caller has already seen)
     double ms = 0;
 };
+// shape AND device: the widths the engine is compiled for, on a device of 8 XCDs x 32 compute units (block b -> XCD b mod 8)
 bool token_engine_supports(mis_tts* lm);
+// throws MIS_ERR_GENERATION_FAILED when an edge timed out (workers not co-resident): nothing of the request is valid, the caller runs it
+// on the launch chain (if result.n_announced == 0) - and MIS_ERR_CANCELLED when rq.cancel was raised
 void token_engine_run(mis_tts* lm, const TokenEngineRequest& rq, TokenEngineResult& out);
 // a handle whose device also runs ANOTHER replica's streams (logical shards of a group on one GPU) must not launch kernels whose blocks
 // wait for each other to be co-resident (the one-launch sampler): set by the group entry points in group.hip
 void tts_internal_set_shared_device(mis_tts* c, bool shared);
 bool tts_internal_shared_device(const mis_tts* c);
 mis_tts* soprano_internal_lm(mis_soprano* c);
+void soprano_internal_set_group_batch(mis_soprano* c, int batch);   // group entry points: the request's batch over all shards (0 = leave)
+void tts_internal_set_decode_ms(mis_tts* c, double ms);
 int soprano_internal_device(const mis_soprano* c);
 int whisper_internal_device(const mis_whisper* c);
 void whisper_internal_set_shared_device(mis_whisper* c, bool shared);

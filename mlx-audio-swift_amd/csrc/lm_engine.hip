@@ -1832,6 +1832,7 @@ extern "C" mis_status mis_debug_launch_floor(int device, int n_kernels, int mode
 hipStream_t tts_stream(mis_tts* c) { return c->stream; }
 int tts_hidden_size(const mis_tts* c) { return c->d; }
 double tts_last_decode_ms(const mis_tts* c) { return c->timing.prefill_ms + c->timing.decode_ms; }
+void tts_internal_set_decode_ms(mis_tts* c, double ms) { c->timing.prefill_ms = 0; c->timing.decode_ms = ms; }
 int tts_device(const mis_tts* c) { return c->device; }
 void tts_generate_hidden(mis_tts* c, const int32_t* prompt_ids, const int32_t* prompt_lens, int batch, const mis_gen_params* gp,
                          int stop_id, DevBuf<float>& hidden, std::vector<int32_t>& n_hidden, std::vector<int32_t>& n_tokens,

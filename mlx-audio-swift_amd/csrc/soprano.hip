@@ -14,6 +14,7 @@
 #include <math.h>
 #include <string.h>
 #include <algorithm>
+#include <chrono>
 
 struct mis_soprano {
     int device = 0;
@@ -29,6 +30,9 @@ struct mis_soprano {
     DevBuf<float> buf[4];
     CodecPack pack;                      // split-bf16 weight fragments + activation scratch (codec_bf3.hip)
     DevBuf<float> hidden;
+    TokenEngineScratch* te_scratch = nullptr;   // batch-1 token engine: buffers kept between requests (token_engine.hip)
+    int group_batch = 0;                 // inside a group call: the request's batch over ALL shards (0: not in a group) - the LM program is chosen on it
+    int lm_path = 0;                     // last generate: 0 launch chain (by rule), 1 token engine, 2 launch chain after an engine time-out
 };
 
 // ---------------------------------------------------------------------------- kernels
@@ -162,6 +166,7 @@ extern "C" void mis_soprano_destroy(mis_soprano* c) {
     if (!c) return;
     if (c->lm) mis_tts_destroy(c->lm);
     (void)hipSetDevice(c->device);
+    if (c->te_scratch) token_engine_scratch_destroy(c->te_scratch);
     delete c;
 }
 extern "C" mis_tts* mis_soprano_lm(mis_soprano* c) { return c ? c->lm : nullptr; }
@@ -359,18 +364,27 @@ static void soprano_generate_impl(mis_soprano* c, const int32_t* prompt_ids, con
     if (gp.max_tokens <= 0) gp.max_tokens = 512;                       // parameters.maxTokens ?? 512 (:635)
     std::vector<int32_t> n_hidden, ntok, toks;
     int64_t tstride = 0;
-    // One row, no per-token callback: the whole LM loop as ONE persistent launch on the compute units of four XCDs (csrc/token_engine.hip:
-    // 0.26 ms per position against the launch chain's 0.60 at Soprano-80M's widths; the whole generate 28 against 38 ms) - same sampler arithmetic, same hidden-state rows.
-    // MIS_TOKEN_ENGINE = 0 keeps the launch chain, 1 / 2 / 4 / 8 picks the number of XCDs.  If the engine's workers cannot be co-resident
-    // (another stream holds compute units: its bounded polls run out) the request runs on the launch chain instead; a handle that shares
-    // its device with another replica of a group (group.hip) never takes the engine.
+    // One row: the whole LM loop as ONE persistent launch on the compute units of four XCDs (csrc/token_engine.hip: 0.26 ms per position
+    // against the launch chain's 0.60 at Soprano-80M's widths) - same sampler arithmetic, same hidden-state rows, and the same program for
+    // generate and generateStream (the ids reach host-visible memory while the launch runs; .token events are fired from there,
+    // Soprano.swift:877 - the reference's generate is itself built on streamGenerate, :801-885).
+    // WHICH program runs the LM loop is a function of the request and the handle only: the engine iff the request is ONE
+    // row (of a group call: one row over all shards), the checkpoint has the widths the engine is compiled for (TeShape: Soprano-80M,
+    // bf16 - other widths and MLX-quantised checkpoints, SopranoConfig.swift:167-190, take the launch chain at ~0.57 ms per token), the
+    // device is 8 XCDs x 32 compute units not shared with another replica, and the request fits the engine's context.
+    // MIS_TOKEN_ENGINE = 0 keeps the launch chain, 1 / 2 / 4 / 8 picks the number of XCDs.  The one run-time exception is reported, never
+    // silent: if the engine's workers cannot be co-resident (another stream holds compute units: its bounded polls run out before the
+    // first id) the request runs on the launch chain, mis_soprano_lm_path() returns 2 and a line goes to stderr - the launch chain's
+    // logits differ from the engine's in float32 summation order, so near-tie ids can differ between the two.
     bool by_engine = false;
+    c->lm_path = 0;
     {
         const char* e = getenv("MIS_TOKEN_ENGINE");
         const int xcds = e ? atoi(e) : 4;
         int32_t len0 = 0;
         if (batch == 1) HIP_CHECK(hipMemcpy(&len0, prompt_lens, 4, hipMemcpyDefault));
-        if (batch == 1 && !on_event && !tts_internal_shared_device(c->lm) && (xcds == 1 || xcds == 2 || xcds == 4 || xcds == 8) &&
+        const bool one_row_request = batch == 1 && (c->group_batch == 0 || c->group_batch == 1);
+        if (one_row_request && !tts_internal_shared_device(c->lm) && (xcds == 1 || xcds == 2 || xcds == 4 || xcds == 8) &&
             token_engine_supports(c->lm) && len0 >= 1 &&
             len0 + gp.max_tokens <= 1024 && gp.repetition_context <= 64 && gp.temperature >= 0.0f) {
             TokenEngineRequest rq;
@@ -380,19 +394,36 @@ static void soprano_generate_impl(mis_soprano* c, const int32_t* prompt_ids, con
             c->hidden.alloc((size_t)(gp.max_tokens + 1) * c->cfg.lm.hidden_size);
             rq.hidden_dev = c->hidden.p; rq.want_hidden = true;
             rq.prefill_by_chain = true;                                   // the prompt (but its last position) in one batched pass of the launch chain
+            if (!c->te_scratch) c->te_scratch = token_engine_scratch_create();
+            rq.scratch = c->te_scratch;
+            rq.cancel = cancel_flag;
+            const int stop_id = c->cfg.stop_token_id;
+            if (on_event)
+                rq.on_token = [&](int, int32_t id) {
+                    if (id == stop_id) return;                            // [STOP] ends the row unannounced (Soprano.swift:855-857)
+                    int32_t t = id;
+                    on_event(user, 0, MIS_EVENT_TOKEN, &t, 1);
+                };
             TokenEngineResult r;
+            const auto t0 = std::chrono::steady_clock::now();
             try {
                 token_engine_run(c->lm, rq, r);
                 by_engine = true;
             } catch (const MisError& err) {
-                if (err.code != MIS_ERR_GENERATION_FAILED) throw;
+                // a time-out after ids were announced cannot be taken back: the request fails (never seen: workers that were co-resident
+                // for the first edge stay resident - the launch is persistent)
+                if (err.code != MIS_ERR_GENERATION_FAILED || r.n_announced > 0) throw;
+                fprintf(stderr, "mi_speech: Soprano token engine timed out (compute units held by another stream); this request runs on the launch chain\n");
+                c->lm_path = 2;
             }
             if (by_engine) {
+                c->lm_path = 1;
                 tstride = gp.max_tokens;
                 toks.assign((size_t)gp.max_tokens, 0);
                 for (int k = 0; k < r.n_sampled; ++k) toks[k] = r.next_tokens[len0 - 1 + k];
                 ntok.assign(1, r.n_sampled);
                 n_hidden.assign(1, r.n_positions - (len0 - 1));
+                tts_internal_set_decode_ms(c->lm, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
             }
         }
     }
@@ -460,6 +491,8 @@ static void soprano_generate_impl(mis_soprano* c, const int32_t* prompt_ids, con
 }
 
 mis_tts* soprano_internal_lm(mis_soprano* c) { return c ? c->lm : nullptr; }
+void soprano_internal_set_group_batch(mis_soprano* c, int batch) { if (c) c->group_batch = batch; }
+extern "C" int32_t mis_soprano_lm_path(const mis_soprano* c) { return c ? c->lm_path : 0; }
 int soprano_internal_device(const mis_soprano* c) { return c ? c->device : -1; }
 
 extern "C" mis_status mis_soprano_generate(mis_soprano* c, const int32_t* prompt_ids, const int32_t* prompt_lens, int batch,

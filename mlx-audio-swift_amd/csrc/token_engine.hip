@@ -38,6 +38,9 @@
 #include "sampler_math.h"
 #include <type_traits>
 #include <string.h>
+#include <chrono>
+#include <mutex>
+#include <thread>
 
 namespace {
 typedef unsigned long long u64;
@@ -61,7 +64,10 @@ struct TeParams {
     const int32_t* prompt;
     int n_prompt, n_total;
     int t_start;                // first position the engine walks (the K/V of the positions before it were imported from the launch chain's prefill)
-    int32_t* next_tokens;       // [n_total]: arg-max after position t
+    int32_t* next_tokens;       // [n_total]: the id chosen after position t.  HOST-VISIBLE (pinned, coherent) memory, written with one system-scope
+                                // store per position: the host reads the ids WHILE the launch runs (generateStream's .token events, Soprano.swift:877)
+    const int* cancel;          // host-visible word or null: worker 0 reads it once per position, the value travels with edge 5 (every worker
+                                // sees the SAME value at the same position) and a non-zero value ends the request like the stop id does
     float* logits_out;          // [n_total][V] or null
     float* hidden_out;          // [n_total][d] or null (final-norm output: what Soprano's decoder consumes)
     bf16_t* kv;                 // the K/V copy [L][2][TE_CTX][Hkv*D] (every worker writes the same bytes, see te_vector_role)
@@ -242,7 +248,7 @@ struct TeLds {
     float* red;         // [TE_MW][R][16] partial sums of the matrix waves
     float* s_ss;        // [TE_VW] sum-of-squares partials of the residual stream
     u64* s_cand;        // [2][TE_VW] the waves' best candidates: own slice, then all workers'
-    int *s_ok, *s_tok, *s_done;
+    int *s_ok, *s_tok, *s_done, *s_cancel;
     u64* earr;          // [TE_HP][R_HEAD x 16] fixed-point masses of this worker's ids
     uint32_t* tsum32;   // [2 x tiles] the mass of every 16-id tile of the vocabulary, lo / hi words
     int* win;           // [64] + length: the repetition window (generated ids)
@@ -502,6 +508,9 @@ __device__ __forceinline__ void te_vector_role(const TeParams& p, const TeLds& L
     int t_last = p.t_start - 1, n_sampled = 0;
     for (int t = p.t_start; t < p.n_total; ++t) {
         if (tid == 0 && t < p.n_prompt) *L.s_tok = p.prompt[t];
+        // (requested here, consumed at edge 5 - a PCIe round trip under 17 layers of work)
+        uint32_t cancel_word = 0u;
+        if (p.cancel && w == 0 && tid == 0) cancel_word = (uint32_t)__hip_atomic_load(p.cancel, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         te_sync();                                                   // token id
         if (*L.s_done) break;
         t_last = t;
@@ -821,8 +830,14 @@ __device__ __forceinline__ void te_vector_role(const TeParams& p, const TeLds& L
 #pragma unroll
                     for (int q = 0; q < TE_VW; ++q) best = (uint32_t)L.s_cand[q] > best ? (uint32_t)L.s_cand[q] : best;
                     __hip_atomic_store(buf + w, (u64)best | ((u64)tag << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (p.cancel && w == 0)                          // granule W of this edge: the cancel word as worker 0 read it
+                        __hip_atomic_store(buf + W, (u64)cancel_word | ((u64)tag << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 }
                 uint32_t c2 = tid < W ? granule(buf, tid, tag) : 0u;
+                if (p.cancel) {                                      // polled by an idle thread where there is one (W < 256), else by thread 0 behind its own
+                    constexpr int CT = W < VT ? W : 0;
+                    if (tid == CT && granule(buf, W, tag) != 0u) *L.s_cancel = 1;
+                }
 #pragma unroll
                 for (int o = 32; o > 0; o >>= 1) { const uint32_t other = __shfl_xor(c2, o, 64); c2 = other > c2 ? other : c2; }
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -942,13 +957,13 @@ __device__ __forceinline__ void te_vector_role(const TeParams& p, const TeLds& L
             n_sampled += 1;
             if (tid == 0) {
                 if (t + 1 >= p.n_prompt) *L.s_tok = next;
-                if (w == 0) p.next_tokens[t] = next;
+                if (w == 0) __hip_atomic_store(p.next_tokens + t, next, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
                 if (p.sample && p.win_cap > 0) {                     // the window slides over the generated ids (both sampling forms)
                     int wl = L.win[64];
                     if (wl < p.win_cap) { L.win[wl] = next; L.win[64] = wl + 1; }
                     else { for (int j = 0; j + 1 < wl; ++j) L.win[j] = L.win[j + 1]; L.win[wl - 1] = next; }
                 }
-                if (next == p.stop_id) *L.s_done = 1;
+                if (next == p.stop_id || *L.s_cancel) *L.s_done = 1;
             }
         }
     }
@@ -975,6 +990,7 @@ __global__ void __launch_bounds__(TE_NT) k_token_engine(TeParams p) {
     __shared__ int s_ok;
     __shared__ int s_tok;
     __shared__ int s_done;
+    __shared__ int s_cancel;
     __shared__ u64 earr[TE_HP * Dm::R_HEAD * 16];
     __shared__ uint32_t tsum32[TE_XG];
     __shared__ int win[65];
@@ -985,8 +1001,8 @@ __global__ void __launch_bounds__(TE_NT) k_token_engine(TeParams p) {
     const int w = (b >> 3) * XCDS + (b & 7);
     const int tid = threadIdx.x, wave = tid >> 6;
     if (tid < TE_VW) s_ss[tid] = 0.f;
-    if (tid == 0) { s_ok = 1; s_tok = 0; s_done = 0; win[64] = 0; }
-    const TeLds L{hf, xb, qkvf, qh, knew, vnew, sc, ph, pl, stage, red, s_ss, s_cand, &s_ok, &s_tok, &s_done, earr, tsum32, win, s_wtot};
+    if (tid == 0) { s_ok = 1; s_tok = 0; s_done = 0; s_cancel = 0; win[64] = 0; }
+    const TeLds L{hf, xb, qkvf, qh, knew, vnew, sc, ph, pl, stage, red, s_ss, s_cand, &s_ok, &s_tok, &s_done, &s_cancel, earr, tsum32, win, s_wtot};
     te_sync();
     // (the wave index as a SCALAR: every tile address is then scalar base + one shared lane offset.  With a vector wave index the
     // compiler keeps a 64-bit address pair per tile live across the layer loop - ~200 registers of addresses, everything spills)
@@ -1013,12 +1029,47 @@ __global__ void k_te_import_kv(const bf16_t* __restrict__ kc_all, const bf16_t* 
 }   // namespace
 
 // ---------------------------------------------------------------------------- host side
+// Buffers a handle keeps between requests (every request allocated and cleared a ~9 MB K/V copy).  The token row and the
+// cancel word are pinned, coherent host memory: the launch writes / reads them with system-scope accesses while the host polls.
+struct TokenEngineScratch {
+    DevBuf<int32_t> prompt, done;
+    DevBuf<bf16_t> kv;
+    DevBuf<u64> x;
+    DevBuf<unsigned> sync;
+    int32_t* tokens_host = nullptr;    // [TE_CTX + 1]: ids, then the cancel word
+    int kv_layers = 0;
+    ~TokenEngineScratch() { if (tokens_host) (void)hipHostFree(tokens_host); }
+};
+TokenEngineScratch* token_engine_scratch_create() { return new TokenEngineScratch(); }
+void token_engine_scratch_destroy(TokenEngineScratch* s) { delete s; }
+
+namespace {
+struct TeEvents {                      // (destroyed on every path)
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    TeEvents() { HIP_CHECK(hipEventCreate(&e0)); HIP_CHECK(hipEventCreate(&e1)); }
+    ~TeEvents() { if (e0) (void)hipEventDestroy(e0); if (e1) (void)hipEventDestroy(e1); }
+};
+// 8 XCDs x 32 compute units (SPX mode of an MI355X): the worker set is "blocks with index mod 8 below xcds" of a 256-block grid, one block
+// per compute unit.  Other partition modes / parts keep the launch chain.
+bool te_device_ok(int device) {
+    static std::mutex mu;
+    static std::map<int, bool> ok;
+    std::lock_guard<std::mutex> lk(mu);
+    auto it = ok.find(device);
+    if (it != ok.end()) return it->second;
+    hipDeviceProp_t prop{};
+    const bool good = hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount == 256;
+    ok[device] = good;
+    return good;
+}
+}   // namespace
+
 bool token_engine_supports(mis_tts* lm) {
     if (!lm) return false;
     const TtsWeightsView v = tts_internal_weights(lm);
     using S = TeShape;
     return v.finalized && v.d == S::d && v.ff == S::ff && v.H == S::H && v.Hkv == S::Hkv && v.D == S::D && v.qk_norm && v.rope_plain && !v.quantised &&
-           v.V <= 65536 && v.Vpad / 16 <= 2 * TE_VW * 64;
+           v.V <= 65536 && v.Vpad / 16 <= 2 * TE_VW * 64 && te_device_ok(v.device);
 }
 
 // One request.  generate == false (laboratory): arg-max after EVERY position, no stop; logits / hidden rows are indexed by position.
@@ -1030,20 +1081,20 @@ void token_engine_run(mis_tts* lm, const TokenEngineRequest& rq, TokenEngineResu
     const int xcds = rq.xcds;
     MIS_REQUIRE(xcds == 1 || xcds == 2 || xcds == 4 || xcds == 8, MIS_ERR_INVALID_INPUT, "the engine is compiled for 1, 2, 4 or 8 XCDs");
     MIS_REQUIRE(token_engine_supports(lm), MIS_ERR_INVALID_INPUT,
-                "the token engine is compiled for Soprano-80M's widths (d 512, ffn 2304, 4 / 1 heads x 128, q/k norm, plain RoPE, bf16, vocabulary <= 8192)");
+                "the token engine is compiled for Soprano-80M's widths (d 512, ffn 2304, 4 / 1 heads x 128, q/k norm, plain RoPE, bf16, vocabulary <= 8192) "
+                "on a device of 8 XCDs x 32 compute units");
     const TtsWeightsView v = tts_internal_weights(lm);
     using S = TeShape;
     const int n_total = rq.n_prompt + rq.max_new;
     MIS_REQUIRE(n_total <= TE_CTX, MIS_ERR_INVALID_INPUT, "at most %d positions", TE_CTX);
     MIS_REQUIRE(!rq.sample || (rq.temperature > 0.0f && rq.win_cap >= 0 && rq.win_cap <= 64), MIS_ERR_INVALID_INPUT, "sampling needs temperature > 0 and a window of at most 64 ids");
     MIS_REQUIRE(v.Vpad / 16 <= TE_HP * 8 * 32 * xcds, MIS_ERR_INVALID_INPUT, "vocabulary too large for the engine's output-projection passes");
+    MIS_REQUIRE(rq.generate || (!rq.on_token && !rq.cancel), MIS_ERR_INVALID_INPUT, "token callback / cancel flag: generate form only");
     HIP_CHECK(hipSetDevice(v.device));
-    hipDeviceProp_t prop{};
-    HIP_CHECK(hipGetDeviceProperties(&prop, v.device));
-    const int grid = prop.multiProcessorCount / 8 * 8;
-    MIS_REQUIRE(grid / 8 == 32, MIS_ERR_DEVICE, "the engine expects 32 compute units per XCD (found %d CUs)", prop.multiProcessorCount);
+    const int grid = 256;
     const float* rc = nullptr; const float* rs = nullptr;
     hipStream_t s = v.stream;
+    out.n_announced = 0;
     std::vector<int32_t> hp(rq.n_prompt);
     HIP_CHECK(hipMemcpy(hp.data(), rq.prompt, (size_t)rq.n_prompt * 4, hipMemcpyDefault));
     for (int t : hp) MIS_REQUIRE(t >= 0 && t < v.V, MIS_ERR_INVALID_INPUT, "prompt token %d outside the vocabulary", t);
@@ -1061,35 +1112,45 @@ void token_engine_run(mis_tts* lm, const TokenEngineRequest& rq, TokenEngineResu
     const int head_from = rq.generate ? rq.n_prompt - 1 : 0;
     const int head_until = rq.generate ? n_total - 1 : n_total;
     const int n_rows = n_total - head_from;                              // hidden rows at most; logits rows: head_until - head_from
-    DevBuf<int32_t> d_prompt, d_next, d_done;
+    TokenEngineScratch local;
+    TokenEngineScratch& sc = rq.scratch ? *rq.scratch : local;
     DevBuf<float> d_logits, d_hidden;
-    DevBuf<bf16_t> d_kv;
-    DevBuf<u64> d_x;
-    DevBuf<unsigned> d_sync;
-    d_prompt.alloc(rq.n_prompt); d_next.alloc(n_total); d_done.alloc(2);
-    d_kv.alloc((size_t)v.L * 2 * TE_CTX * (S::Hkv * S::D));
-    d_x.alloc(2 * TE_XG); d_sync.alloc(64);
+    sc.prompt.alloc(TE_CTX); sc.done.alloc(2); sc.x.alloc(2 * TE_XG); sc.sync.alloc(64);
+    if (!sc.tokens_host)
+        HIP_CHECK(hipHostMalloc((void**)&sc.tokens_host, (TE_CTX + 1) * sizeof(int32_t), hipHostMallocMapped | hipHostMallocCoherent));
+    const size_t kv_pos = (size_t)S::Hkv * S::D;
+    // The transposed value rows are read in 32-key steps: positions this request has not written yet (x probability 0) must be finite.
+    // Cleared when allocated; what earlier requests of the handle left there are finite K/V values, and 0 x finite = 0 exactly.
+    if (sc.kv_layers != v.L) {
+        sc.kv.alloc((size_t)v.L * 2 * TE_CTX * kv_pos); sc.kv_layers = v.L;
+        HIP_CHECK(hipMemsetAsync(sc.kv.p, 0, sc.kv.bytes(), s));
+    }
     if (rq.want_logits) d_logits.alloc((size_t)std::max(head_until - head_from, 1) * v.V);
     float* hidden_dev = rq.hidden_dev;
     if (rq.want_hidden && !hidden_dev) { d_hidden.alloc((size_t)n_rows * S::d); hidden_dev = d_hidden.p; }
-    HIP_CHECK(hipMemcpyAsync(d_prompt.p, hp.data(), (size_t)rq.n_prompt * 4, hipMemcpyHostToDevice, s));
-    HIP_CHECK(hipMemsetAsync(d_sync.p, 0, 64 * sizeof(unsigned), s));
-    HIP_CHECK(hipMemsetAsync(d_kv.p, 0, d_kv.bytes(), s));          // (the transposed value rows are read in 32-key steps: unwritten positions x 0 must be finite)
-    HIP_CHECK(hipMemsetAsync(d_x.p, 0, 2 * TE_XG * sizeof(u64), s));
-    HIP_CHECK(hipMemsetAsync(d_next.p, 0, (size_t)n_total * 4, s));
-    HIP_CHECK(hipMemsetAsync(d_done.p, 0, 8, s));
+    volatile int32_t* tok_host = sc.tokens_host;
+    volatile int32_t* cancel_host = sc.tokens_host + TE_CTX;
+    for (int t = 0; t < n_total; ++t) tok_host[t] = -1;                   // (an id is >= 0: -1 = not chosen yet)
+    *cancel_host = 0;
+    HIP_CHECK(hipMemcpyAsync(sc.prompt.p, hp.data(), (size_t)rq.n_prompt * 4, hipMemcpyHostToDevice, s));
+    HIP_CHECK(hipMemsetAsync(sc.sync.p, 0, 64 * sizeof(unsigned), s));
+    HIP_CHECK(hipMemsetAsync(sc.x.p, 0, 2 * TE_XG * sizeof(u64), s));
+    HIP_CHECK(hipMemsetAsync(sc.done.p, 0, 8, s));
     if (t_start > 0)
         hipLaunchKernelGGL(k_te_import_kv, dim3((unsigned)((t_start * S::D + 255) / 256), (unsigned)v.L), dim3(256), 0, s, kvv.kcache, kvv.vtcache,
-                           kvv.layer_stride, d_kv.p, t_start);
+                           kvv.layer_stride, sc.kv.p, t_start);
     TeParams p{};
     p.emb = v.emb; p.wqkv = v.wqkv; p.wo = v.wo; p.wgu = v.wgu; p.wdown = v.wdown; p.head = v.head; p.norms = v.norms; p.qknorm = v.qknorm;
     p.rope_cos = rc; p.rope_sin = rs; p.L = v.L; p.V = v.V; p.Vpad = v.Vpad; p.eps = v.eps;
-    p.prompt = d_prompt.p; p.n_prompt = rq.n_prompt; p.n_total = n_total; p.t_start = t_start; p.next_tokens = d_next.p;
+    p.prompt = sc.prompt.p; p.n_prompt = rq.n_prompt; p.n_total = n_total; p.t_start = t_start; p.next_tokens = sc.tokens_host;
+    p.cancel = rq.cancel ? sc.tokens_host + TE_CTX : nullptr;
     p.logits_out = rq.want_logits ? d_logits.p : nullptr; p.hidden_out = hidden_dev;
-    p.kv = d_kv.p; p.xbuf = d_x.p; p.fail = d_sync.p + 32; p.xcds = xcds; p.spin = 1 << 20;
+    p.kv = sc.kv.p; p.xbuf = sc.x.p; p.fail = sc.sync.p + 32; p.xcds = xcds;
+    p.spin = rq.spin > 0 ? rq.spin : 1 << 20;
+    if (const char* e = getenv("MIS_TE_SPIN")) p.spin = std::max(atoi(e), 0);      // (tests: 0 = the first poll that misses times out)
     p.head_from = head_from; p.head_until = head_until;
     p.sample = rq.sample ? 1 : (rq.generate ? 2 : 0); p.win_cap = rq.win_cap; p.temperature = rq.temperature; p.penalty = rq.penalty; p.seed = rq.seed; p.row = rq.row;
-    p.stop_id = rq.generate ? rq.stop_id : -1; p.n_done = d_done.p;
+    p.stop_id = rq.generate ? rq.stop_id : -1; p.n_done = sc.done.p;
     DevBuf<u64> d_dbg;
     const char* stamp_env = getenv("MIS_TE_STAMPS");
     if (stamp_env) {
@@ -1098,35 +1159,54 @@ void token_engine_run(mis_tts* lm, const TokenEngineRequest& rq, TokenEngineResu
         p.dbg = d_dbg.p; p.dbg_token = atoi(stamp_env);
     }
     const size_t pad = 48 * 1024;                                        // with the static arrays: more than half a CU's LDS -> one block per CU
-    static bool attr_done[9] = {};
-    if (!attr_done[xcds]) {
-        if (xcds == 1) HIP_CHECK(hipFuncSetAttribute((const void*)k_token_engine<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pad));
-        else if (xcds == 2) HIP_CHECK(hipFuncSetAttribute((const void*)k_token_engine<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pad));
-        else if (xcds == 4) HIP_CHECK(hipFuncSetAttribute((const void*)k_token_engine<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pad));
-        else HIP_CHECK(hipFuncSetAttribute((const void*)k_token_engine<8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pad));
-        attr_done[xcds] = true;
-    }
-    hipEvent_t e0, e1;
-    HIP_CHECK(hipEventCreate(&e0)); HIP_CHECK(hipEventCreate(&e1));
-    HIP_CHECK(hipEventRecord(e0, s));
+    // (the attribute is per device and per function: set on every request - a table keyed by XCD count alone left a second device without it)
+    if (xcds == 1) HIP_CHECK(hipFuncSetAttribute((const void*)k_token_engine<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pad));
+    else if (xcds == 2) HIP_CHECK(hipFuncSetAttribute((const void*)k_token_engine<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pad));
+    else if (xcds == 4) HIP_CHECK(hipFuncSetAttribute((const void*)k_token_engine<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pad));
+    else HIP_CHECK(hipFuncSetAttribute((const void*)k_token_engine<8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pad));
+    TeEvents ev;
+    HIP_CHECK(hipEventRecord(ev.e0, s));
     if (xcds == 1) hipLaunchKernelGGL(k_token_engine<1>, dim3(grid), dim3(TE_NT), pad, s, p);
     else if (xcds == 2) hipLaunchKernelGGL(k_token_engine<2>, dim3(grid), dim3(TE_NT), pad, s, p);
     else if (xcds == 4) hipLaunchKernelGGL(k_token_engine<4>, dim3(grid), dim3(TE_NT), pad, s, p);
     else hipLaunchKernelGGL(k_token_engine<8>, dim3(grid), dim3(TE_NT), pad, s, p);
-    HIP_CHECK(hipEventRecord(e1, s));
+    HIP_CHECK(hipEventRecord(ev.e1, s));
     HIP_CHECK(hipGetLastError());
+    // ---- while the launch runs: the ids it has chosen so far, in order, to the caller; the caller's cancel flag to the launch
+    bool cancelled = false;
+    int seen = 0;                                                        // chosen ids read so far (index head_from + seen)
+    auto drain = [&]() {
+        while (head_from + seen < head_until) {
+            const int32_t id = tok_host[head_from + seen];
+            if (id < 0) break;
+            if (rq.on_token) { rq.on_token(seen, id); out.n_announced = seen + 1; }
+            seen += 1;
+            if (id == p.stop_id) break;
+        }
+    };
+    if (rq.on_token || rq.cancel) {
+        for (;;) {
+            const hipError_t q = hipEventQuery(ev.e1);
+            if (q == hipSuccess) break;
+            if (q != hipErrorNotReady) HIP_CHECK(q);
+            drain();
+            if (rq.cancel && *rq.cancel && !cancelled) { cancelled = true; *cancel_host = 1; }
+            std::this_thread::sleep_for(std::chrono::microseconds(20));
+        }
+    }
     HIP_CHECK(hipStreamSynchronize(s));
     float ms = 0;
-    HIP_CHECK(hipEventElapsedTime(&ms, e0, e1));
-    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    HIP_CHECK(hipEventElapsedTime(&ms, ev.e0, ev.e1));
     unsigned failed = 0;
-    HIP_CHECK(hipMemcpy(&failed, d_sync.p + 32, 4, hipMemcpyDeviceToHost));
+    HIP_CHECK(hipMemcpy(&failed, sc.sync.p + 32, 4, hipMemcpyDeviceToHost));
     MIS_REQUIRE(!failed, MIS_ERR_GENERATION_FAILED, "token engine: an edge timed out (its workers were not co-resident)");
+    if (cancelled || (rq.cancel && *rq.cancel)) throw MisError(MIS_ERR_CANCELLED, "generation cancelled");
+    drain();
     int32_t done[2] = {0, 0};
-    HIP_CHECK(hipMemcpy(done, d_done.p, 8, hipMemcpyDeviceToHost));
+    HIP_CHECK(hipMemcpy(done, sc.done.p, 8, hipMemcpyDeviceToHost));
     out.n_positions = done[0]; out.n_sampled = done[1]; out.ms = ms; out.head_from = head_from;
     out.next_tokens.assign(n_total, 0);
-    HIP_CHECK(hipMemcpy(out.next_tokens.data(), d_next.p, (size_t)n_total * 4, hipMemcpyDeviceToHost));
+    for (int t = 0; t < n_total; ++t) out.next_tokens[t] = tok_host[t] < 0 ? 0 : tok_host[t];
     if (rq.want_logits) {
         out.logits.assign((size_t)std::max(head_until - head_from, 1) * v.V, 0.f);
         HIP_CHECK(hipMemcpy(out.logits.data(), d_logits.p, out.logits.size() * 4, hipMemcpyDeviceToHost));

@@ -224,6 +224,12 @@ class SopranoModel:
                     ids += list(self.tokenizer.encode(chunk))
         return np.asarray(ids, np.int32)
 
+    @property
+    def lm_path(self) -> int:
+        """mis_soprano_lm_path: the program that ran the LM loop of the last call - 0 launch chain (by rule), 1 batch-1 token engine,
+        2 launch chain after the engine's workers could not be co-resident."""
+        return int(_lib.lib().mis_soprano_lm_path(self._h))
+
     def generate_batch(self, prompt_rows, generation_parameters: GenerateParameters | None = None,
                        return_tokens: bool = False, replicas=None):
         """One generate per tokenised sentence prompt, batched: list of 1-D float32 arrays.  More rows than the engine's

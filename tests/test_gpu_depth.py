@@ -37,7 +37,11 @@ def _rel_rms(a, b):
     return rms(a, b) / float(np.sqrt(np.mean(np.asarray(b, np.float64) ** 2)))
 
 
-def test_orpheus_3b_full_depth_28_layers_and_error_growth():
+@pytest.mark.parametrize("depths", [pytest.param((2, 8), id="2_and_8_layers"),
+                                    pytest.param((2, 8, 28), id="full_depth_28_layers", marks=pytest.mark.slow)])
+def test_orpheus_3b_full_depth_28_layers_and_error_growth(depths):
+    """(the 28-layer variant needs ~170 s, most of it the CPU oracle at 3B: marked slow - run on the final tree with --runslow; the default
+    set holds the device to the same floor gate at 2 and 8 layers, the growth ~ sqrt(layers) is on file from the full runs)"""
     full = ollama.LlamaConfig()                                     # ORPHEUS_3B: 28 layers
     assert full.num_hidden_layers == 28
     W = ollama.make_synthetic_weights(full, seed=4321)              # layer keys do not depend on the layer count
@@ -50,7 +54,7 @@ def test_orpheus_3b_full_depth_28_layers_and_error_growth():
     rng = np.random.default_rng(77)
     rows = [np.concatenate([[128259], rng.integers(0, 128000, T - 1)]).astype(np.int32) for _ in range(B)]
     growth = {}
-    for L in (2, 8, 28):
+    for L in depths:
         cfg = dataclasses.replace(full, num_hidden_layers=L)
         dev = mas.LlamaTTSModel.synthetic(lm_host_config(cfg), seed=4321)
         dev.lm_reset(B, 64)
@@ -83,7 +87,8 @@ def test_orpheus_3b_full_depth_28_layers_and_error_growth():
     # absolute bounds at the benchmarked depth: twice the values observed on MI355X (profiles/r03_parity_observed.json: 28 layers
     # rms 0.0327 / max 0.0148 against the oracle's own float64 floor of 0.0321 / 0.0129; 8 layers 0.0176 vs 0.0170; 2 layers 0.0062 vs
     # 0.0058 - the device sits AT the floor at every depth, and the error grows like the floor does, ~ sqrt(layers))
-    assert growth[28]["dev_rms"] <= 0.066 and growth[28]["dev_max"] <= 0.03, growth[28]
+    if 28 in growth:
+        assert growth[28]["dev_rms"] <= 0.066 and growth[28]["dev_max"] <= 0.03, growth[28]
     assert growth[8]["dev_rms"] <= 0.036 and growth[2]["dev_rms"] <= 0.013, growth
     assert growth[8]["dev_max"] <= 0.016 and growth[2]["dev_max"] <= 0.016, growth
 

@@ -10,6 +10,11 @@ test_gpu_depth.py does this for the benchmarked Orpheus-3B; here:
     against the oracle's logits under teacher forcing.
 (c) Soprano-80M (configs[1]): the Vocos decoder at its real dimensions - 8 ConvNeXt layers, dim 768 / 2304, n_fft 2048, hop 512,
     hidden 512 (SopranoConfig.swift:158-167) - waveform against oracle/soprano.py.
+(d) Soprano-80M (configs[1]): the batch-1 TOKEN ENGINE (csrc/token_engine.hip, the program that runs the LM loop of configs[1]) at the
+    LM's real shape - 17 layers, vocabulary 8 192 (the limit of token_engine_supports: at one XCD the output projection takes its
+    second pass) - 24 prompt + 64 generated positions on 1 and 4 XCDs: logits and hidden rows against oracle/llama.py under teacher
+    forcing, with the 2- and 8-layer comparison and the oracle's float64 floor beside it; and the in-launch sampler bit-exact on the
+    engine's own logits at that shape.
 Tolerances are stated per test and are about twice what MI355X delivered when the test was written (recorded with gpu_util.record)."""
 import dataclasses
 import gc
@@ -45,12 +50,16 @@ def _rel(a, b):
     return float(np.abs(np.asarray(a, np.float64) - b).max() / np.abs(b).max()), rms(a, b) / float(np.sqrt(np.mean(b ** 2)))
 
 
-def test_whisper_large_v3_full_depth_32_plus_32_layers_and_error_growth():
+@pytest.mark.parametrize("depths", [pytest.param((2, 8), id="2_and_8_layers"),
+                                    pytest.param((2, 8, 32), id="full_depth_32_plus_32_layers", marks=pytest.mark.slow)])
+def test_whisper_large_v3_full_depth_32_plus_32_layers_and_error_growth(depths):
+    """(the 32 + 32 variant needs ~140 s, most of it the CPU oracle: marked slow - run on the final tree with --runslow; the default set
+    holds the device to the same floor gate at 2 + 2 and 8 + 8 layers)"""
     T = 24
     feats = (np.random.default_rng(1).standard_normal((1, 3000, 128)) * 0.5).astype(np.float32)
     toks = np.random.default_rng(2).integers(0, 50000, (1, T))
     growth = {}
-    for L in (2, 8, 32):
+    for L in depths:
         cfg = dataclasses.replace(ow.LARGE_V3, encoder_layers=L, decoder_layers=L)
         W = ow.make_synthetic_weights(cfg, seed=777)           # (the key counter runs through the layers: one dict per depth)
         o32 = ow.WhisperOracle(cfg, W, round="bf16")
@@ -87,8 +96,9 @@ def test_whisper_large_v3_full_depth_32_plus_32_layers_and_error_growth():
     # absolute bounds, about twice what MI355X delivered (profiles/r04_parity_observed.json): 32 + 32 layers encoder rms 0.0113 / max 0.0299,
     # decoder logits rms 0.0139 / max 0.0164 - against the oracle's own float64 floor of 0.0112 / 0.0299 and 0.0138 / 0.0164: the device
     # sits AT the floor at every depth (8 + 8: 0.0076 vs 0.0073, 0.0086 vs 0.0086; 2 + 2: 0.0048 vs 0.0039, 0.0056 vs 0.0055)
-    assert growth[32]["enc_rms"] <= 0.023 and growth[32]["dec_rms"] <= 0.028, growth[32]
-    assert growth[32]["enc_max"] <= 0.06 and growth[32]["dec_max"] <= 0.033, growth[32]
+    if 32 in growth:
+        assert growth[32]["enc_rms"] <= 0.023 and growth[32]["dec_rms"] <= 0.028, growth[32]
+        assert growth[32]["enc_max"] <= 0.06 and growth[32]["dec_max"] <= 0.033, growth[32]
     assert growth[8]["enc_rms"] <= 0.016 and growth[8]["dec_rms"] <= 0.018, growth[8]
     assert growth[2]["enc_rms"] <= 0.010 and growth[2]["dec_rms"] <= 0.012, growth[2]
 
@@ -202,3 +212,91 @@ def test_soprano_80m_decoder_real_dimensions():
         worst = max(worst, e)
         assert e <= 4e-5, (B, L, e)
     record("soprano_80m_decoder_real_dims", wave_max_rel=worst, tol=4e-5)
+
+
+class _F64Llama(ollama.LlamaOracle):
+    """Same graph, same rounding points; every contraction accumulated in float64 (the noise-floor reference)."""
+
+    def linear(self, x, w):
+        return self.r((x.to(torch.float64) @ w.to(torch.float64).t()).to(torch.float32))
+
+
+SOPRANO_80M_LM = ollama.LlamaConfig(hidden_size=512, num_hidden_layers=17, intermediate_size=2304, num_attention_heads=4, num_key_value_heads=1,
+                                    head_dim=128, vocab_size=8192, rope_theta=10000.0, rope_scaling=None, tie_word_embeddings=False, qk_norm=True,
+                                    rope_plain=True, rms_norm_eps=1e-6)
+
+
+def test_token_engine_at_soprano_80m_depth_17_layers_v8192_and_error_growth():
+    """the engine had parity tests at 2 layers / V = 1 200 only.  Here the shape bench.py and the product run:
+    69 cross-CU edges per position through 17 layers, V = 8 192 (1 XCD: two output-projection passes).  Laboratory form (arg-max after
+    every position, logits and hidden rows of all 88 positions), oracle teacher-forced with the engine's own ids.  Gate like
+    test_gpu_depth.py: rms error <= FLOOR_FACTOR x the oracle's own float64-accumulation floor (+1e-3), absolute bounds at 17 layers;
+    greedy ids equal wherever the oracle's margin exceeds twice the error; 1 and 4 XCDs bit-identical."""
+    full = SOPRANO_80M_LM
+    W = ollama.make_synthetic_weights(full, seed=4321)              # layer keys do not depend on the layer count
+    o32 = ollama.LlamaOracle(full, W, round="bf16")
+    del W
+    o64 = _F64Llama.__new__(_F64Llama)
+    o64.__dict__.update(o32.__dict__)
+    rng = np.random.default_rng(23)
+    prompt = rng.integers(0, full.vocab_size, 24).astype(np.int32)
+    n_new = 64
+    growth = {}
+    for L in (2, 8, 17):
+        cfg = dataclasses.replace(full, num_hidden_layers=L)
+        dev = mas.LlamaTTSModel.synthetic(lm_host_config(cfg), seed=4321)
+        outs = {x: dev.debug_token_engine(prompt, n_new, xcds=x, want_logits=True, want_hidden=True) for x in (1, 4)}
+        del dev
+        gc.collect()
+        assert np.array_equal(outs[1]["logits"], outs[4]["logits"]) and np.array_equal(outs[1]["next_tokens"], outs[4]["next_tokens"]), L
+        assert np.array_equal(outs[1]["hidden"], outs[4]["hidden"]), L
+        out = outs[1]
+        nxt = out["next_tokens"]
+        assert np.array_equal(out["logits"].argmax(1), nxt)
+        seq = np.concatenate([prompt, nxt[len(prompt) - 1:len(prompt) - 1 + n_new]]).astype(np.int32)
+        res = {}
+        for name, o in (("ref", o32), ("floor", o64)):
+            o.cfg = cfg
+            o.reset(1)
+            lg = o.forward([seq])[0].numpy()
+            res[name] = (lg, o.last_hidden.numpy())
+        e_max, e_rms, n_sure, agree = logits_errors(out["logits"], res["ref"][0])
+        f_max, f_rms, _, _ = logits_errors(res["floor"][0], res["ref"][0])
+        h_max, h_rms = _rel(out["hidden"], res["ref"][1])
+        hf_max, hf_rms = _rel(res["floor"][1], res["ref"][1])
+        # the generated half alone (contexts 24 .. 87): where an error fed back through the engine's own ids would show
+        g_rms = rms(out["logits"][len(prompt):], res["ref"][0][len(prompt):]) / float(np.sqrt(np.mean(res["ref"][0][len(prompt):].astype(np.float64) ** 2)))
+        assert agree and n_sure > 0, (L, n_sure)
+        growth[L] = dict(dev_max=e_max, dev_rms=e_rms, floor_max=f_max, floor_rms=f_rms, hidden_max=h_max, hidden_rms=h_rms,
+                         hidden_floor_max=hf_max, hidden_floor_rms=hf_rms, dev_rms_generated_positions=g_rms, rows_with_a_sure_argmax=n_sure)
+        record(f"token_engine_soprano80m_depth_{L}_layers_v8192", layers=L, **growth[L], ms_per_position_1xcd=outs[1]["ms"] / len(seq),
+               ms_per_position_4xcd=outs[4]["ms"] / len(seq), gate=f"rms: dev <= {FLOOR_FACTOR} x floor (+1e-3); absolute at 17 layers")
+    for L, g in growth.items():
+        assert g["dev_rms"] <= FLOOR_FACTOR * g["floor_rms"] + 1e-3, (L, g)
+        assert g["hidden_rms"] <= FLOOR_FACTOR * g["hidden_floor_rms"] + 1e-3, (L, g)
+    # absolute bounds at the shipped depth (the per-row bounds of every LM test at 2 layers: max 0.016 / rms 0.008; the error grows like the
+    # floor does, ~ sqrt(layers): 17 layers ~ 3 x 2 layers)
+    assert growth[2]["dev_rms"] <= 0.008 and growth[2]["dev_max"] <= 0.016, growth[2]
+    assert growth[17]["dev_rms"] <= 0.03 and growth[17]["dev_max"] <= 0.03, growth[17]
+    assert growth[17]["hidden_rms"] <= 0.03, growth[17]
+
+
+@pytest.mark.parametrize("xcds", [1, 4])
+def test_token_engine_sampler_bit_exact_at_soprano_80m_shape(xcds):
+    """The generate form at 17 layers / V = 8 192: every id the launch chose (mis-sampler-v1 behind the Soprano penalty: edges 5-7, 1 024
+    tile-mass granules; at one XCD each worker owns ids of BOTH output-projection passes) is oracle/sampler.py's on the logits row it was
+    drawn from, and temperature 0 is the arg-max behind the penalty."""
+    from oracle import sampler as osamp
+    cfg = SOPRANO_80M_LM
+    dev = mas.LlamaTTSModel.synthetic(lm_host_config(cfg), seed=4321)
+    prompt = np.random.default_rng(29).integers(0, cfg.vocab_size, 24).astype(np.int32)
+    n_new = 64
+    for temp in (0.0, 0.3):
+        gp = mas.GenerateParameters(max_tokens=n_new, temperature=temp, top_p=0.95, repetition_penalty=1.5, repetition_context_size=30, seed=9,
+                                    row_offset=0, sampler_flavor=1)
+        out = dev.debug_token_engine(prompt, n_new, xcds=xcds, want_logits=True, sampling=gp)
+        assert out["chosen"] == n_new
+        toks = out["next_tokens"][len(prompt) - 1:len(prompt) - 1 + n_new]
+        for k in range(n_new):
+            l = osop.soprano_repetition_penalty(out["logits"][k], list(toks[:k])[-30:], 1.5)
+            assert toks[k] == osamp.sample(l, temp, 1.0, 9, 0, k), (temp, k)

@@ -215,6 +215,28 @@ def test_group_of_two_logical_shards_returns_the_unsharded_audio():
         assert np.array_equal(toks[r], toks2[r]) and np.array_equal(pcm[r], pcm2[r]), r
 
 
+ENGINE_LM = ollama.LlamaConfig(hidden_size=512, num_hidden_layers=2, intermediate_size=2304, num_attention_heads=4, num_key_value_heads=1,
+                               head_dim=128, vocab_size=1200, rope_theta=10000.0, rope_scaling=None, tie_word_embeddings=False, qk_norm=True,
+                               rope_plain=True, rms_norm_eps=1e-6)
+ENGINE_DEC = dict(decoder_num_layers=2, decoder_dim=96, decoder_intermediate_dim=160, hop_length=32, n_fft=128, upscale=4, input_kernel=3,
+                  dw_kernel=3, token_size=128)
+
+
+def _engine_pair(stop):
+    """A Soprano model whose LM has the widths the batch-1 token engine is compiled for (Soprano-80M's; two layers, cut vocabulary)."""
+    lm, base = ENGINE_LM, ENGINE_DEC
+    cfg = mas.SopranoConfiguration(hidden_size=lm.hidden_size, num_hidden_layers=lm.num_hidden_layers, intermediate_size=lm.intermediate_size,
+                                   num_attention_heads=lm.num_attention_heads, num_key_value_heads=lm.num_key_value_heads, head_dim=lm.head_dim,
+                                   vocab_size=lm.vocab_size, rms_norm_eps=lm.rms_norm_eps, rope_theta=lm.rope_theta, tie_word_embeddings=False,
+                                   stop_token_id=stop, **base)
+    ocfg = osop.SopranoDecoderConfig(hidden_size=lm.hidden_size, **base)
+    Wd = osop.make_synthetic_weights(ocfg, seed=99)
+    Wl = ollama.make_synthetic_weights(lm, seed=4321)
+    Wall = {(k[len("model."):] if k.startswith("model.") else k): v for k, v in Wl.items()}
+    Wall.update(Wd)
+    return cfg, mas.SopranoModel.from_weights(cfg, Wall), osop.SopranoDecoderOracle(ocfg, Wd), ollama.LlamaOracle(lm, Wl, round="bf16")
+
+
 def test_batch_one_generate_runs_on_the_token_engine(monkeypatch):
     """mis_soprano_generate at batch 1 on an LM of Soprano-80M's widths (hidden 512, ffn 2304, 4 / 1 heads x 128; two layers here): the LM
     loop is ONE persistent launch (csrc/token_engine.hip) instead of the launch chain.  Held to the same bar as the chain
@@ -222,24 +244,7 @@ def test_batch_one_generate_runs_on_the_token_engine(monkeypatch):
     the hidden states of (last prompt token, every generated token), [STOP] ends the row unannounced; sampling is seeded; and the chain
     (MIS_TOKEN_ENGINE=0) on the same handle gives audio of the same length built from ITS hidden states (the two LMs agree to the logit
     tolerance, not bit for bit: other float32 summation orders)."""
-    lm = ollama.LlamaConfig(hidden_size=512, num_hidden_layers=2, intermediate_size=2304, num_attention_heads=4, num_key_value_heads=1,
-                            head_dim=128, vocab_size=1200, rope_theta=10000.0, rope_scaling=None, tie_word_embeddings=False, qk_norm=True,
-                            rope_plain=True, rms_norm_eps=1e-6)
-    base = dict(decoder_num_layers=2, decoder_dim=96, decoder_intermediate_dim=160, hop_length=32, n_fft=128, upscale=4, input_kernel=3,
-                dw_kernel=3, token_size=128)
-
-    def build(stop):
-        cfg = mas.SopranoConfiguration(hidden_size=lm.hidden_size, num_hidden_layers=lm.num_hidden_layers, intermediate_size=lm.intermediate_size,
-                                       num_attention_heads=lm.num_attention_heads, num_key_value_heads=lm.num_key_value_heads, head_dim=lm.head_dim,
-                                       vocab_size=lm.vocab_size, rms_norm_eps=lm.rms_norm_eps, rope_theta=lm.rope_theta, tie_word_embeddings=False,
-                                       stop_token_id=stop, **base)
-        ocfg = osop.SopranoDecoderConfig(hidden_size=lm.hidden_size, **base)
-        Wd = osop.make_synthetic_weights(ocfg, seed=99)
-        Wl = ollama.make_synthetic_weights(lm, seed=4321)
-        Wall = {(k[len("model."):] if k.startswith("model.") else k): v for k, v in Wl.items()}
-        Wall.update(Wd)
-        return cfg, mas.SopranoModel.from_weights(cfg, Wall), osop.SopranoDecoderOracle(ocfg, Wd), ollama.LlamaOracle(lm, Wl, round="bf16")
-
+    lm, build = ENGINE_LM, _engine_pair
     cfg, dev, odec, olm = build(3)
     lib = mas._lib.lib()
     rng = np.random.default_rng(2)
@@ -248,6 +253,7 @@ def test_batch_one_generate_runs_on_the_token_engine(monkeypatch):
                                 sampler_flavor=1)
     monkeypatch.delenv("MIS_TOKEN_ENGINE", raising=False)
     pcm, toks = dev.generate_batch([prompt], gp, return_tokens=True)
+    assert dev.lm_path == 1                                                   # (mis_soprano_lm_path: the engine ran the LM loop)
     assert len(toks[0]) == 12 and pcm[0].shape == (12 * cfg.token_size,)
     # (1) tokens: the oracle's greedy choice under teacher forcing (penalty over the generated ids only), within the logit tolerance
     olm.reset(1)
@@ -272,6 +278,7 @@ def test_batch_one_generate_runs_on_the_token_engine(monkeypatch):
     assert np.array_equal(toks2[0], toks[0]) and np.array_equal(pcm2[0], pcm[0])
     monkeypatch.setenv("MIS_TOKEN_ENGINE", "0")
     pcm_c, toks_c = dev.generate_batch([prompt], gp, return_tokens=True)
+    assert dev.lm_path == 0
     monkeypatch.delenv("MIS_TOKEN_ENGINE")
     assert len(toks_c[0]) == 12 and pcm_c[0].shape == pcm[0].shape
     # (token-for-token equality of the two LM loops is not asserted: they agree to the logit tolerance, and a near-tie may send them apart)
@@ -293,3 +300,76 @@ def test_batch_one_generate_runs_on_the_token_engine(monkeypatch):
     gs.seed = 22
     c, tc = dev.generate_batch([prompt], gs, return_tokens=True)
     assert not np.array_equal(ta[0], tc[0])
+
+
+def test_batch_one_stream_runs_on_the_token_engine_and_equals_generate(monkeypatch):
+    """generateStream at ONE row (the entry point the reference's CLI times, App.swift:130-138; its generate is built on streamGenerate,
+    Soprano.swift:801-885) runs on the SAME persistent launch as generate: the ids reach host-visible memory one store each while the
+    launch runs and the calling thread fires .token from there.  Stream and non-stream: same ids, same samples (greedy and sampled);
+    the events arrive WHILE the launch runs; a cancel flag ends the launch at its next position."""
+    import ctypes as C
+    import time
+    monkeypatch.delenv("MIS_TOKEN_ENGINE", raising=False)
+    cfg, dev, _, _ = _engine_pair(3)
+    prompt = np.random.default_rng(2).integers(4, ENGINE_LM.vocab_size, 9).astype(np.int32)
+    for temp in (0.0, 0.7):
+        gp = mas.GenerateParameters(max_tokens=40, temperature=temp, top_p=0.95, repetition_penalty=1.5, repetition_context_size=30, seed=5,
+                                    sampler_flavor=1)
+        pcm, toks = dev.generate_batch([prompt], gp, return_tokens=True)
+        assert dev.lm_path == 1
+        ev = list(dev.generate_stream_batch([prompt], gp))
+        assert dev.lm_path == 1
+        assert [type(e).__name__ for e in ev] == ["TokenEvent"] * len(toks[0]) + ["InfoEvent", "AudioEvent"]
+        assert np.array_equal([e.token for e in ev if isinstance(e, mas.TokenEvent)], toks[0]), temp
+        assert np.array_equal(ev[-1].audio, pcm[0]), temp
+        assert ev[-2].info.generation_token_count == len(toks[0]) + 1 and ev[-2].info.generate_time > 0
+    # the ids are delivered while the launch runs: over a 900-position request the first and the last .token are most of the call apart
+    long_gp = mas.GenerateParameters(max_tokens=900, temperature=0.0, repetition_penalty=1.5, repetition_context_size=30, sampler_flavor=1)
+    stamps = []
+    t0 = time.perf_counter()
+    for e in dev.generate_stream_batch([prompt], long_gp):
+        stamps.append((type(e).__name__, time.perf_counter() - t0))
+    tok_t = [t for k, t in stamps if k == "TokenEvent"]
+    assert len(tok_t) >= 100
+    from gpu_util import record
+    record("soprano_stream_on_token_engine", tokens=len(tok_t), first_token_s=tok_t[0], last_token_s=tok_t[-1], call_s=stamps[-1][1])
+    assert tok_t[-1] - tok_t[0] >= 0.3 * tok_t[-1], (tok_t[0], tok_t[-1])
+    # early close -> the cancel word reaches the launch, which ends at its next position; no error surfaces, the handle stays usable
+    g = dev.generate_stream_batch([prompt], long_gp)
+    assert isinstance(next(g), mas.TokenEvent)
+    t1 = time.perf_counter()
+    g.close()
+    closed_in = time.perf_counter() - t1
+    gp = mas.GenerateParameters(max_tokens=40, temperature=0.0, top_p=0.95, repetition_penalty=1.5, repetition_context_size=30, seed=5, sampler_flavor=1)
+    pcm2, toks2 = dev.generate_batch([prompt], gp, return_tokens=True)
+    ev2 = list(dev.generate_stream_batch([prompt], gp))
+    assert np.array_equal([e.token for e in ev2 if isinstance(e, mas.TokenEvent)], toks2[0]) and np.array_equal(ev2[-1].audio, pcm2[0])
+    with pytest.raises(mas.AudioGenerationError) as err:
+        list(dev.generate_stream_batch([prompt], long_gp, cancel_flag=C.c_int(1)))
+    assert err.value.case == "cancelled"
+    record("soprano_stream_cancel_on_token_engine", close_returned_in_s=closed_in)
+
+
+def test_token_engine_time_out_falls_back_to_the_launch_chain_and_reports_it(monkeypatch):
+    """the engine -> launch-chain fall-back had no test, and was silent.  MIS_TE_SPIN=0 makes the first granule poll that misses
+    count as a time-out (what happens when another stream holds compute units and the workers cannot all be resident): the request then
+    runs on the launch chain - ids and samples equal the chain's own (MIS_TOKEN_ENGINE=0), nothing is announced twice in the stream form -
+    and mis_soprano_lm_path() says 2, not 1 or 0."""
+    cfg, dev, _, _ = _engine_pair(3)
+    prompt = np.random.default_rng(3).integers(4, ENGINE_LM.vocab_size, 11).astype(np.int32)
+    gp = mas.GenerateParameters(max_tokens=16, temperature=0.7, top_p=0.95, repetition_penalty=1.5, repetition_context_size=30, seed=8,
+                                sampler_flavor=1)
+    monkeypatch.setenv("MIS_TOKEN_ENGINE", "0")
+    pcm_c, toks_c = dev.generate_batch([prompt], gp, return_tokens=True)
+    assert dev.lm_path == 0
+    monkeypatch.delenv("MIS_TOKEN_ENGINE")
+    monkeypatch.setenv("MIS_TE_SPIN", "0")
+    pcm_f, toks_f = dev.generate_batch([prompt], gp, return_tokens=True)
+    assert dev.lm_path == 2
+    assert np.array_equal(toks_f[0], toks_c[0]) and np.array_equal(pcm_f[0], pcm_c[0])
+    ev = list(dev.generate_stream_batch([prompt], gp))
+    assert dev.lm_path == 2
+    assert np.array_equal([e.token for e in ev if isinstance(e, mas.TokenEvent)], toks_c[0]) and np.array_equal(ev[-1].audio, pcm_c[0])
+    monkeypatch.delenv("MIS_TE_SPIN")
+    pcm_e, toks_e = dev.generate_batch([prompt], gp, return_tokens=True)
+    assert dev.lm_path == 1 and len(pcm_e[0]) > 0
