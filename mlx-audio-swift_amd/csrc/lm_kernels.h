@@ -32,6 +32,13 @@ void launch_reduce_residual_rmsnorm(const float* slabs, int S, int Mpad, int N, 
 // ksb = 2: 128-thread blocks, two waves per item.  U: k-tiles per register buffer (0: 4, or 3 at R = 4); R = 4 is built for <= 32 rows.
 void launch_gemm_skinny(int epi, int R, int ksb, const bf16_t* Wp, const bf16_t* X, void* out, int NT, int KT, int S,
                         int N_out, int Mpad, hipStream_t s, const bf16_t* bias = nullptr, int U = 0);
+// The same GEMM with the residual add + LayerNorm / RMSNorm glue in its prologue (<= 16 rows, K <= 1280; see k_gemm_skinny_norm): X is rebuilt per
+// block from the producer's S_in split-K slabs [S_in][16][K] and the residual stream h_in [16][K]; h_new is written to h_out (!= h_in).
+// ln_bias == nullptr: RMSNorm.  R = 2, eight waves per item.
+bool gemm_skinny_norm_ok(int epi, int R, int KT, int S, int S_in, int Mpad, int nrows);
+void launch_gemm_skinny_norm(int epi, int R, const bf16_t* Wp, const float* slabs, int S_in, const bf16_t* h_in, bf16_t* h_out, const bf16_t* wnorm,
+                             const bf16_t* ln_bias, float eps, int nrows, void* out, int NT, int KT, int S, int N_out, int Mpad, hipStream_t s,
+                             const bf16_t* bias = nullptr);
 // one role's arrangement of the weight-streaming GEMM: n-tiles per wave, waves per item, k-tiles per register buffer, inter-block split
 struct GemmArr { int R = 2, ksb = 4, U = 4, S = 1; };
 
@@ -55,6 +62,8 @@ void launch_pf_pack_rows(const bf16_t* rows, bf16_t* xpk, int Mpad, int d, hipSt
 // split-K factor of a weight-streaming GEMM (items = n-tile groups, KT = k-tiles, ksb = waves per item), see the definition
 int gemm_choose_split(int items, int KT, int ksb, int s_max);
 
+struct AttnParams;
+bool attn_qp_ok(const AttnParams& p);
 struct AttnParams {
     const float* qkv_part;   // [S][Mpad][Nqkv]
     int S, Mpad, Nqkv;
@@ -75,6 +84,16 @@ struct AttnParams {
     int H, Hkv, D, Smax;
     float scale;
     unsigned long long* dbg; // phase timestamps (MIS_ATTN_TIMING builds only), else null
+    // cross-attention with the glue and the query projection in its prologue (qp_w != null; see attn_qp_row_gemv): q = T(W_q LN(h_new) + b),
+    // h_new = T(h_in + T(sum of the qp_S slabs [qp_S][Mpad][H D])) written to qp_h_out (!= qp_h_in) by the head-0 blocks; qkv_part / S unused
+    const bf16_t* qp_w;      // W_q packed [H D / 16][qp_KT][64][8]
+    const bf16_t* qp_bias;   // [H D] or null
+    const float* qp_slabs;
+    const bf16_t* qp_h_in;
+    bf16_t* qp_h_out;
+    const bf16_t *qp_lnw, *qp_lnb;
+    float qp_eps;
+    int qp_S, qp_KT;
     // batched prefill: the rows of a launch are (position, sequence) pairs - row r uses the caches of sequence r % cache_rows (0 = r).
     // append_only = 1: RoPE / norm the new key and value, write them to the caches, stop (all positions of a chunk first: the second
     // launch then finds every earlier key of its own chunk in memory)

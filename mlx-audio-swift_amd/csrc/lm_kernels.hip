@@ -914,6 +914,207 @@ void launch_gemm_skinny(int epi, int R, int ksb, const bf16_t* Wp, const bf16_t*
     }
 }
 
+// ============================================================================ skinny GEMM with the glue in its prologue (<= 16 rows)
+//
+// VERDICT r05 item 2 (Whisper decoder at 8 rows: three LayerNorm glue launches of 4.8 us per layer doing nothing but a norm on 8 rows).
+// At <= 16 rows the glue's whole input - the S_in split-K slabs of the producing GEMM and the residual stream - is 41 KB per slab and
+// 20 KB at d = 1280: small enough for EVERY block of the consuming GEMM to rebuild it (out of L2 / the Infinity Cache) instead of a
+// launch of its own doing it once.  Per block: the 8 waves first request their weight tiles (HBM, the long trip), then wave w rebuilds
+// row w (and w + 8): h_new = T(h + T(sum slabs)) over the WHOLE row (the statistics need it; wave-local DPP sums, no block barrier),
+// LayerNorm / RMSNorm with the glue's rounding points, and writes the columns of the block's own K range as MFMA-B fragments into LDS;
+// one barrier; MFMAs with x from LDS; the waves' partials meet in LDS like k_gemm_skinny's.  The blocks of n-tile group 0 also write
+// h_new (their K ranges cover the row) into the OTHER residual buffer - the old one is still being read by every other block.
+// Same arithmetic per element as k_glue4 (slab order 0, 1, ..; float32 statistics - summed in another order, like k_glue_cpt).
+// (At 32 rows x d = 1024 the same fold lost in round 3 - profiles/r03/q3: four times the bytes per block and a block-wide reduction in
+// front of the first MFMA; here the rows are few enough for one wave per row and the weight trip hides the prologue.)
+template <int R, int EPI, bool LN, int SG, int KW, int G>
+__global__ void __launch_bounds__(512, 1) k_gemm_skinny_norm(const bf16_t* __restrict__ Wp, const float* __restrict__ slabs, int S_in,
+                                                             const bf16_t* __restrict__ h_in, bf16_t* __restrict__ h_out,
+                                                             const bf16_t* __restrict__ wnorm, const bf16_t* __restrict__ ln_bias, float eps,
+                                                             int nrows, void* __restrict__ out, int NT, int KT, int S, int n_items, int N_out,
+                                                             const bf16_t* __restrict__ bias) {
+    constexpr int NW = 8, Mpad = 16;
+    const int N = KT * 32;                                // the norm's width = this GEMM's K
+    extern __shared__ __attribute__((aligned(16))) unsigned char gn_lds[];
+    bf16x8_t* xs = reinterpret_cast<bf16x8_t*>(gn_lds);                     // [k-tiles of the block][64] B fragments (swizzled rows)
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int item = blockIdx.x;
+    const int ntg = item / S, ks = item - ntg * S;
+    const int kb0 = (int)(((long long)KT * ks) / S), kb1 = (int)(((long long)KT * (ks + 1)) / S);
+    const int len = kb1 - kb0;
+    const int kt0 = kb0 + (len * wave) / NW, kt1 = kb0 + (len * (wave + 1)) / NW;
+    // ---- this wave's weight tiles, requested before anything else (clamped: a dead tile is multiplied by a zero fragment)
+    bf16x8_t wt[KW][R];
+#pragma unroll
+    for (int u = 0; u < KW; ++u) {
+        int kk = kt0 + u;
+        kk = kk < kb1 ? kk : kb1 - 1;
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            int tile = ntg * R + r;
+            tile = tile < NT ? tile : NT - 1;
+            wt[u][r] = __builtin_nontemporal_load(reinterpret_cast<const bf16x8_t*>(Wp) + ((size_t)tile * KT + kk) * 64 + lane);
+        }
+    }
+    // ---- the glue: wave w -> rows w, w + 8; lane -> column groups 4 (lane + 64 g) .. + 3
+#pragma unroll
+    for (int rr = 0; rr < 2; ++rr) {
+        const int m = wave + NW * rr;
+        if (m >= nrows) {                                 // padding rows: zero fragments
+            for (int g = 0; g < G; ++g) {
+                const int col = 4 * (lane + 64 * g), kt = col >> 5;
+                if (col < N && kt >= kb0 && kt < kb1) {
+                    const int k8 = (col & 31) >> 3, swz = (kt * 4 + k8) & 15;
+                    *reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(xs) + ((size_t)((kt - kb0) * 64 + k8 * 16 + (m ^ swz)) * 8 + (col & 7))) = make_uint2(0u, 0u);
+                }
+            }
+            continue;
+        }
+        uint2 hq[G], wq[G], bq[G];
+        f32x4_t v[SG][G];
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+            int col = 4 * (lane + 64 * g);
+            col = col < N ? col : N - 4;
+            hq[g] = *reinterpret_cast<const uint2*>(h_in + (size_t)m * N + col);
+            wq[g] = *reinterpret_cast<const uint2*>(wnorm + col);
+            if constexpr (LN) bq[g] = *reinterpret_cast<const uint2*>(ln_bias + col);
+#pragma unroll
+            for (int j = 0; j < SG; ++j) {
+                const int sj = j < S_in ? j : S_in - 1;
+                v[j][g] = *reinterpret_cast<const f32x4_t*>(slabs + ((size_t)sj * Mpad + m) * N + col);
+            }
+        }
+        float hn[G][4];
+        float sum = 0.f, ss = 0.f;
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+            const bool live = 4 * (lane + 64 * g) < N;
+            float acc[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int j = 0; j < SG; ++j) {                // slab order 0, 1, 2, ... (fixed => deterministic)
+                const bool on = j < S_in;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc[e] += on ? v[j][g][e] : 0.0f;
+            }
+            const float hv[4] = {bf16_to_f32((bf16_t)(hq[g].x & 0xffffu)), bf16_to_f32((bf16_t)(hq[g].x >> 16)), bf16_to_f32((bf16_t)(hq[g].y & 0xffffu)),
+                                 bf16_to_f32((bf16_t)(hq[g].y >> 16))};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                hn[g][e] = bf16_round_f32(hv[e] + bf16_round_f32(acc[e]));          // o = T(sum slabs); h = T(h + o)
+                sum += live ? hn[g][e] : 0.0f;
+                ss += live ? hn[g][e] * hn[g][e] : 0.0f;
+            }
+        }
+        float mean = 0.f, scale;
+        if constexpr (LN) {
+            mean = wave_sum_dpp(sum) / (float)N;
+            float sq = 0.f;
+#pragma unroll
+            for (int g = 0; g < G; ++g) {
+                const bool live = 4 * (lane + 64 * g) < N;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { const float dl = hn[g][e] - mean; sq += live ? dl * dl : 0.0f; }
+            }
+            scale = 1.0f / sqrtf(wave_sum_dpp(sq) / (float)N + eps);
+        } else {
+            scale = 1.0f / sqrtf(wave_sum_dpp(ss) / (float)N + eps);
+        }
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+            const int col = 4 * (lane + 64 * g), kt = col >> 5;
+            if (col < N && kt >= kb0 && kt < kb1) {
+                const float wv[4] = {bf16_to_f32((bf16_t)(wq[g].x & 0xffffu)), bf16_to_f32((bf16_t)(wq[g].x >> 16)), bf16_to_f32((bf16_t)(wq[g].y & 0xffffu)),
+                                     bf16_to_f32((bf16_t)(wq[g].y >> 16))};
+                bf16_t xb[4], hb[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    if constexpr (LN) {
+                        const float bv = bf16_to_f32((bf16_t)(e < 2 ? (bq[g].x >> (16 * e)) & 0xffffu : (bq[g].y >> (16 * (e - 2))) & 0xffffu));
+                        xb[e] = f32_to_bf16((hn[g][e] - mean) * scale * wv[e] + bv);
+                    } else {
+                        xb[e] = f32_to_bf16(wv[e] * bf16_round_f32(hn[g][e] * scale));
+                    }
+                    hb[e] = f32_to_bf16(hn[g][e]);
+                }
+                const int k8 = (col & 31) >> 3, swz = (kt * 4 + k8) & 15;
+                *reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(xs) + ((size_t)((kt - kb0) * 64 + k8 * 16 + (m ^ swz)) * 8 + (col & 7))) =
+                    make_uint2((uint32_t)xb[0] | ((uint32_t)xb[1] << 16), (uint32_t)xb[2] | ((uint32_t)xb[3] << 16));
+                if (ntg == 0)                              // the n-tile group 0 blocks (one per K slice) keep the residual stream
+                    *reinterpret_cast<uint2*>(h_out + (size_t)m * N + col) =
+                        make_uint2((uint32_t)hb[0] | ((uint32_t)hb[1] << 16), (uint32_t)hb[2] | ((uint32_t)hb[3] << 16));
+            }
+        }
+    }
+    __syncthreads();
+    // ---- MFMAs: x fragments from LDS (row m of lane l sits at l ^ swizzle inside its 16-lane group)
+    f32x4_t acc[R][1];
+#pragma unroll
+    for (int r = 0; r < R; ++r) acc[r][0] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int u = 0; u < KW; ++u) {
+        const int kt = kt0 + u;
+        const int ktc = kt < kb1 ? kt : kb1 - 1;
+        const int k8 = lane >> 4, swz = (ktc * 4 + k8) & 15;
+        bf16x8_t xf = xs[(size_t)(ktc - kb0) * 64 + k8 * 16 + ((lane & 15) ^ swz)];
+        if (kt >= kt1) xf = (bf16x8_t){0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+        for (int r = 0; r < R; ++r) acc[r][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wt[u][r], xf, acc[r][0], 0, 0, 0);
+    }
+    float4* red = reinterpret_cast<float4*>(gn_lds + (size_t)len * 64 * 16);      // [NW][R][64], behind the fragments
+#pragma unroll
+    for (int r = 0; r < R; ++r) red[(wave * R + r) * 64 + lane] = make_float4(acc[r][0][0], acc[r][0][1], acc[r][0][2], acc[r][0][3]);
+    __syncthreads();
+    if (wave == 0) {
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            float4 s0 = red[r * 64 + lane];
+#pragma unroll
+            for (int w = 1; w < NW; ++w) {                // fixed order (deterministic)
+                const float4 t = red[(w * R + r) * 64 + lane];
+                s0.x += t.x; s0.y += t.y; s0.z += t.z; s0.w += t.w;
+            }
+            acc[r][0] = (f32x4_t){s0.x, s0.y, s0.z, s0.w};
+        }
+        gemm_epilogue<1, R, EPI>(acc, out, ntg, ks, NT, N_out, Mpad, lane, -1, bias);
+    }
+}
+
+bool gemm_skinny_norm_ok(int epi, int R, int KT, int S, int S_in, int Mpad, int nrows) {
+    const int N = KT * 32;
+    return Mpad == 16 && nrows >= 1 && nrows <= 16 && R == 2 && (epi == EPI_PARTIAL || epi == EPI_GELU_PACKED) && N % 4 == 0 && N <= 1280 && S_in >= 1 &&
+           S_in <= 8 && S >= 1 && S <= KT && ((KT + S - 1) / S + 7) / 8 <= 5;
+}
+void launch_gemm_skinny_norm(int epi, int R, const bf16_t* Wp, const float* slabs, int S_in, const bf16_t* h_in, bf16_t* h_out, const bf16_t* wnorm,
+                             const bf16_t* ln_bias, float eps, int nrows, void* out, int NT, int KT, int S, int N_out, int Mpad, hipStream_t s,
+                             const bf16_t* bias) {
+    MIS_REQUIRE(gemm_skinny_norm_ok(epi, R, KT, S, S_in, Mpad, nrows), MIS_ERR_GENERATION_FAILED, "unsupported norm-in-prologue GEMM shape");
+    MIS_REQUIRE(epi == EPI_PARTIAL || S == 1, MIS_ERR_GENERATION_FAILED, "split-K needs the partial epilogue");
+    const int n_items = ((NT + R - 1) / R) * S;
+    const int len_max = (KT + S - 1) / S;                 // k-tiles of the longest block range
+    const int kw = (len_max + 7) / 8;                     // k-tiles of the longest wave range
+    const size_t lds = (size_t)len_max * 64 * 16 + (size_t)8 * R * 64 * 16;
+    const bool ln = ln_bias != nullptr;
+#define GN_CASE(E, LNB, SGv, KWv)                                                                                                         \
+    if (epi == E && ln == LNB && S_in <= SGv && kw <= KWv) {                                                                              \
+        hipLaunchKernelGGL((k_gemm_skinny_norm<2, E, LNB, SGv, KWv, 5>), dim3(n_items), dim3(512), lds, s, Wp, slabs, S_in, h_in, h_out, wnorm,  \
+                           ln_bias, eps, nrows, out, NT, KT, S, n_items, N_out, bias);                                                    \
+        return;                                                                                                                           \
+    }
+    GN_CASE(EPI_PARTIAL, true, 4, 2)
+    GN_CASE(EPI_PARTIAL, true, 8, 2)
+    GN_CASE(EPI_PARTIAL, true, 4, 5)
+    GN_CASE(EPI_PARTIAL, true, 8, 5)
+    GN_CASE(EPI_GELU_PACKED, true, 4, 5)
+    GN_CASE(EPI_GELU_PACKED, true, 8, 5)
+    GN_CASE(EPI_PARTIAL, false, 4, 2)
+    GN_CASE(EPI_PARTIAL, false, 8, 2)
+    GN_CASE(EPI_PARTIAL, false, 4, 5)
+    GN_CASE(EPI_PARTIAL, false, 8, 5)
+#undef GN_CASE
+    throw MisError(MIS_ERR_GENERATION_FAILED, "unsupported norm-in-prologue GEMM variant");
+}
+
 // Inter-block split-K factor of a weight-streaming GEMM with `items` n-tile groups and KT k-tiles.  All blocks of a launch are
 // co-resident and share their CU's load bandwidth, so the launch takes as long as the most loaded CU needs:
 //   time ~ ceil(blocks / CUs) / blocks            (the share of the weight bytes behind the busiest CU)
@@ -973,10 +1174,24 @@ int gemm_choose_split(int items, int KT, int ksb, int s_max) {
 // front (the first group is ONE tile, every later group a full pair); the code is straight-line per tile count (see the main loop for
 // why not a loop).  Tiles are multiplied in the same order as without XS - results are bit-identical.  The K/V loads are
 // non-temporal: a decode step reads each of them once (61 MB per layer at eight windows, 2 GB per step - nothing a cache can keep).
+// QP ("query projection", round 6; Whisper cross-attention at <= 16 rows): the residual add + LayerNorm glue in front of the
+// cross-attention AND its query projection run inside this kernel's prologue instead of as two launches of their own (k_glue4 4.6 us +
+// k_gemm_skinny 5.1 us per layer under the profiler).  A block is one (row, head): it needs ONE row of the glue - S_in slabs x 5 KB at
+// d = 1280, rebuilt by each of its eight waves with wave-local DPP sums (no barrier) - and 64 rows of W_q (164 KB out of L2: the eight
+// rows' blocks of a head share them).  Wave w owns k-tiles [KT w / 8, KT (w + 1) / 8): it rebuilds THAT slice of the row (<= 160 columns, one
+// group of four per lane), the row statistics meet in LDS (two raw barriers: mean, then variance - the glue's two-pass form), and it
+// multiplies its slice with the head's four n-tiles on the matrix core (B = the row as column 0); the eight partial vectors meet in LDS
+// behind the barrier the prologue has anyway.  The W_q tiles, the slice and the wave's first K/V tile are requested together, the second
+// tile behind the projection.  The head-0 blocks write h_new to the OTHER residual buffer.  Contrast with k_gemm_skinny_norm (same fold
+// on the GEMM side, measured neutral: every one of its 160-480 blocks re-reads ALL rows' slabs): a row-parallel consumer re-reads its row.
+// (First form, profiles/r06/c4: every wave rebuilt the WHOLE row and the K/V request waited behind the projection: 13.5 -> 17.8 us.)
+#define ATT_QP_KW 5
+#define ATT_QP_LDS ((size_t)ATT_WAVES * ATT_QP_KW * 32 * 2 + (size_t)ATT_WAVES * 64 * 4 + 2 * ATT_WAVES * 4)
 #define ATT_XS_MIN_J 5
 #define ATT_XS_MAX_J 6
-template <int D, int NIT, bool XS = false>
+template <int D, int NIT, bool XS = false, int QP = 0>          // QP = slabs fetched per trip by the query-projection prologue (0: off)
 __global__ void __launch_bounds__(512) k_attn_decode(AttnParams p) {
+    static_assert(QP == 0 || (XS && D == 64), "QP: the cross-attention schedule at head_dim 64");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int kvh = blockIdx.x, b = blockIdx.y;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -1007,8 +1222,38 @@ __global__ void __launch_bounds__(512) k_attn_decode(AttnParams p) {
     const int n_pro = p.cross ? G : G + 2;          // cross attention: queries only (K/V cached once per utterance)
     const int n_el = n_pro * D;
     float pv[NIT][8];                                // NIT * 512 >= (G + 2) * D
+    float* qp_part = sO + (size_t)ATT_WAVES * G * D + (size_t)ATT_WAVES * ATT_QP_KW * 16;      // [W][64] behind the waves' x strips (QP only)
+    float* qp_red = qp_part + ATT_WAVES * 64;                                                  // [2][W] row statistics
+    // QP, round trip 1: this wave's W_q tiles (k-tiles [k0, k1) of the head's four n-tiles) and its slice of the row
+    [[maybe_unused]] bf16x8_t qp_wt[QP > 0 ? ATT_QP_KW : 1][4];
+    [[maybe_unused]] uint2 qp_hq, qp_wq, qp_bq;
+    [[maybe_unused]] f32x4_t qp_v[QP > 0 ? QP : 1];
+    [[maybe_unused]] int qp_k0 = 0, qp_k1 = 0, qp_col = 0;
+    if constexpr (QP > 0) {
+        const int wq_ = __builtin_amdgcn_readfirstlane(wave);
+        const int KT = p.qp_KT, N = KT * 32;
+        qp_k0 = (KT * wq_) / ATT_WAVES; qp_k1 = (KT * (wq_ + 1)) / ATT_WAVES;
 #pragma unroll
-    for (int it = 0; it < NIT; ++it) {
+        for (int u = 0; u < ATT_QP_KW; ++u) {
+            int kk = qp_k0 + u;
+            kk = kk < KT ? kk : KT - 1;
+#pragma unroll
+            for (int r = 0; r < 4; ++r)      // (cached loads: the other rows' blocks of this head read the same tiles)
+                qp_wt[u][r] = *(reinterpret_cast<const bf16x8_t*>(p.qp_w) + ((size_t)(kvh * 4 + r) * KT + kk) * 64 + lane);
+        }
+        qp_col = 32 * qp_k0 + 4 * lane;                                  // one group of four columns per lane (<= 160 per wave)
+        const int colc = qp_col < 32 * qp_k1 ? qp_col : N - 4;
+        qp_hq = *reinterpret_cast<const uint2*>(p.qp_h_in + (size_t)b * N + colc);
+        qp_wq = *reinterpret_cast<const uint2*>(p.qp_lnw + colc);
+        qp_bq = *reinterpret_cast<const uint2*>(p.qp_lnb + colc);
+#pragma unroll
+        for (int j = 0; j < QP; ++j) {
+            const int sj = j < p.qp_S ? j : p.qp_S - 1;
+            qp_v[j] = *reinterpret_cast<const f32x4_t*>(p.qp_slabs + ((size_t)sj * p.Mpad + b) * N + colc);
+        }
+    }
+#pragma unroll
+    for (int it = 0; it < (QP > 0 ? 0 : NIT); ++it) {
         const int idx = tid + it * 512;
         int hh = idx / D, d = idx - hh * D;
         if (idx >= n_el) { hh = 0; d = 0; }          // clamped: loaded, never used
@@ -1046,8 +1291,10 @@ __global__ void __launch_bounds__(512) k_attn_decode(AttnParams p) {
     // whole first tile pair, i.e. at contexts <= 512 for the entire KV stream of the launch)
 #pragma unroll
     for (int it = 0; it < NIT; ++it) {
+        if constexpr (QP == 0) {
 #pragma unroll
-        for (int j = 0; j < 8; ++j) asm volatile("" : "+v"(pv[it][j]));
+            for (int j = 0; j < 8; ++j) asm volatile("" : "+v"(pv[it][j]));
+        }
         asm volatile("" : "+v"(rc[it]));
         asm volatile("" : "+v"(rs[it]));
     }
@@ -1101,7 +1348,82 @@ __global__ void __launch_bounds__(512) k_attn_decode(AttnParams p) {
     __builtin_amdgcn_sched_barrier(0);
     // wave-uniform guards: a wave without a tile requests nothing (at short contexts seven of eight waves would otherwise each
     // pull a redundant 32 KB pair through the CU's 64 B/clk return path - 2-3 us per launch on the small models)
-    if constexpr (XS) {
+    if constexpr (QP > 0) {
+        // the first tile UNCONDITIONALLY (the launcher admits >= ATT_XS_MIN_J tiles per wave): no join between the requests above and the
+        // projection below, so its waits count loads instead of draining them; the second tile of an even count follows the projection
+        load_tile(wu, kA, vA);
+        __builtin_amdgcn_sched_barrier(0);
+        const int N = p.qp_KT * 32;
+        const bool live = qp_col < 32 * qp_k1;
+        float acc4[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int j = 0; j < QP; ++j) {                    // slab order 0, 1, 2, ... (fixed => deterministic)
+            const bool on = j < p.qp_S;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc4[e] += on ? qp_v[j][e] : 0.0f;
+        }
+        const float hv[4] = {bf16_to_f32((bf16_t)(qp_hq.x & 0xffffu)), bf16_to_f32((bf16_t)(qp_hq.x >> 16)), bf16_to_f32((bf16_t)(qp_hq.y & 0xffffu)),
+                             bf16_to_f32((bf16_t)(qp_hq.y >> 16))};
+        float hn[4], sum = 0.f;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            hn[e] = bf16_round_f32(hv[e] + bf16_round_f32(acc4[e]));                // o = T(sum slabs); h = T(h + o)
+            sum += live ? hn[e] : 0.0f;
+        }
+        sum = wave_sum_dpp(sum);
+        if (lane == 0) qp_red[wu] = sum;
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");          // (raw: __syncthreads() would wait for the K/V tile as well)
+        float tot = 0.f;
+#pragma unroll
+        for (int w = 0; w < ATT_WAVES; ++w) tot += qp_red[w];
+        const float mean = tot / (float)N;
+        float sq = 0.f;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { const float dl = hn[e] - mean; sq += live ? dl * dl : 0.0f; }
+        sq = wave_sum_dpp(sq);
+        if (lane == 0) qp_red[ATT_WAVES + wu] = sq;
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        float tq = 0.f;
+#pragma unroll
+        for (int w = 0; w < ATT_WAVES; ++w) tq += qp_red[ATT_WAVES + w];
+        const float rstd = 1.0f / sqrtf(tq / (float)N + p.qp_eps);
+        bf16_t* xrow = reinterpret_cast<bf16_t*>(sO + (size_t)ATT_WAVES * G * D) + (size_t)wu * ATT_QP_KW * 32;
+        if (live) {
+            const float wv[4] = {bf16_to_f32((bf16_t)(qp_wq.x & 0xffffu)), bf16_to_f32((bf16_t)(qp_wq.x >> 16)), bf16_to_f32((bf16_t)(qp_wq.y & 0xffffu)),
+                                 bf16_to_f32((bf16_t)(qp_wq.y >> 16))};
+            const float bv[4] = {bf16_to_f32((bf16_t)(qp_bq.x & 0xffffu)), bf16_to_f32((bf16_t)(qp_bq.x >> 16)), bf16_to_f32((bf16_t)(qp_bq.y & 0xffffu)),
+                                 bf16_to_f32((bf16_t)(qp_bq.y >> 16))};
+            bf16_t xb[4], hb[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                xb[e] = f32_to_bf16((hn[e] - mean) * rstd * wv[e] + bv[e]);
+                hb[e] = f32_to_bf16(hn[e]);
+            }
+            *reinterpret_cast<uint2*>(xrow + 4 * lane) = make_uint2((uint32_t)xb[0] | ((uint32_t)xb[1] << 16), (uint32_t)xb[2] | ((uint32_t)xb[3] << 16));
+            if (kvh == 0)                                 // the head-0 block of the row keeps the residual stream (its waves cover the row)
+                *reinterpret_cast<uint2*>(p.qp_h_out + (size_t)b * N + qp_col) =
+                    make_uint2((uint32_t)hb[0] | ((uint32_t)hb[1] << 16), (uint32_t)hb[2] | ((uint32_t)hb[3] << 16));
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // (the strip is this wave's own: LDS operations of one wave execute in order)
+        f32x4_t qacc[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) qacc[r] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+        const bf16x8_t z = (bf16x8_t){0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+        for (int u = 0; u < ATT_QP_KW; ++u) {
+            bf16x8_t xf = *reinterpret_cast<const bf16x8_t*>(xrow + u * 32 + (lane >> 4) * 8);
+            if ((lane & 15) != 0 || qp_k0 + u >= qp_k1) xf = z;         // B = the row as column m = 0; dead k-tiles multiply zero
+#pragma unroll
+            for (int r = 0; r < 4; ++r) qacc[r] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qp_wt[u][r], xf, qacc[r], 0, 0, 0);
+        }
+        if ((lane & 15) == 0) {                               // C/D lane l, reg e: n = (l >> 4) * 4 + e, m = l & 15
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                *reinterpret_cast<float4*>(qp_part + wu * 64 + r * 16 + (lane >> 4) * 4) = make_float4(qacc[r][0], qacc[r][1], qacc[r][2], qacc[r][3]);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if (xs_nj >= 2 && !xs_odd) load_tile(wu + ATT_WAVES, kB, vB);
+    } else if constexpr (XS) {
         if (xs_nj >= 1) load_tile(wu, kA, vA);
         if (xs_nj >= 2 && !xs_odd) load_tile(wu + ATT_WAVES, kB, vB);
     } else {
@@ -1115,8 +1437,10 @@ __global__ void __launch_bounds__(512) k_attn_decode(AttnParams p) {
         const int idx = tid + it * 512;
         // unconditional (sraw is padded to NIT*512 entries; entries >= n_el hold clamped-address garbage nobody reads)
         float acc = 0.0f;
+        if constexpr (QP == 0) {
 #pragma unroll
-        for (int j = 0; j < 8; ++j) acc += (j < p.S) ? pv[it][j] : 0.0f;       // slab order 0..7 (S <= 8, checked by the launcher)
+            for (int j = 0; j < 8; ++j) acc += (j < p.S) ? pv[it][j] : 0.0f;   // slab order 0..7 (S <= 8, checked by the launcher)
+        }
         sraw[idx] = bf16_round_f32(acc);
     }
     for (int idx = tid; idx < 16 * D; idx += 512) qs[idx] = 0;
@@ -1148,6 +1472,13 @@ __global__ void __launch_bounds__(512) k_attn_decode(AttnParams p) {
         if (idx >= n_rot_el) continue;
         int hh = idx / (D / 2), i = idx - hh * (D / 2);
         float x1 = sraw[hh * D + i], x2 = sraw[hh * D + i + D / 2];
+        if constexpr (QP > 0) {                      // (cross-attention, G = 1: hh = 0) q = T(W_q x + b): the waves' partials in wave order
+            float a1 = 0.f, a2 = 0.f;
+#pragma unroll
+            for (int w = 0; w < ATT_WAVES; ++w) { a1 += qp_part[w * 64 + i]; a2 += qp_part[w * 64 + i + D / 2]; }
+            x1 = bf16_round_f32(a1 + (p.qp_bias ? bf16_to_f32(p.qp_bias[kvh * D + i]) : 0.0f));
+            x2 = bf16_round_f32(a2 + (p.qp_bias ? bf16_to_f32(p.qp_bias[kvh * D + i + D / 2]) : 0.0f));
+        }
         bf16_t r1, r2;
         if (p.rope_cos) {
             float c = rc[it], s = rs[it];
@@ -1714,12 +2045,19 @@ size_t attn_smem_bytes(int G, int D) {
     return (size_t)attn_nit(G, D) * 512 * 4 + 16 * D * 2 + D * 2 + 2 * ATT_WAVES * 16 * 4 + (size_t)ATT_WAVES * G * D * 4;
 }
 
+// the cross-attention launches whose prologue can take the LayerNorm glue and the query projection (k_attn_decode<64, 2, true, QP>)
+bool attn_qp_ok(const AttnParams& p) {
+    const char* xe = getenv("MIS_ATTN_XS");
+    return !(xe && atoi(xe) == 0) && p.cross && p.D == 64 && p.H == p.Hkv && !p.append_only && !p.cache_rows && !p.rope_cos && !p.qnorm_w &&
+           (p.cross_len + 31) / 32 >= ATT_WAVES * ATT_XS_MIN_J && (p.cross_len + 31) / 32 <= ATT_WAVES * ATT_XS_MAX_J && p.qp_KT >= 1 &&
+           (p.qp_KT + ATT_WAVES - 1) / ATT_WAVES <= ATT_QP_KW && p.qp_KT * 32 == p.H * p.D && p.qp_S >= 1 && p.qp_S <= 8;
+}
 void launch_attn_decode(const AttnParams& p, int batch, hipStream_t s) {
     int G = p.H / p.Hkv;
     MIS_REQUIRE(G >= 1 && G <= 16 && p.H % p.Hkv == 0, MIS_ERR_INVALID_INPUT, "GQA group size must be 1..16");
     size_t smem = attn_smem_bytes(G, p.D);
     MIS_REQUIRE(smem <= 64 * 1024, MIS_ERR_INVALID_INPUT, "attention LDS footprint too large");
-    MIS_REQUIRE(p.S >= 1 && p.S <= 8, MIS_ERR_GENERATION_FAILED, "attention prologue reduces at most 8 split-K slabs (got %d)", p.S);
+    MIS_REQUIRE(p.qp_w || (p.S >= 1 && p.S <= 8), MIS_ERR_GENERATION_FAILED, "attention prologue reduces at most 8 split-K slabs (got %d)", p.S);
     MIS_REQUIRE(((uintptr_t)p.active & 3) == 0, MIS_ERR_GENERATION_FAILED, "attention: the active-flag array must be 4-byte aligned");
     dim3 grid(p.Hkv, batch), block(512);
     const int n_el = (G + 2) * p.D;
@@ -1753,7 +2091,15 @@ void launch_attn_decode(const AttnParams& p, int batch, hipStream_t s) {
     else if (p.D == 128) hipLaunchKernelGGL((k_attn_decode<128, 5>), grid, block, smem, s, p2);
     else if (p.D == 64 && n_el <= 1024 && p.cross && !p.append_only && !p.cache_rows && xs_on && (p.cross_len + 31) / 32 >= ATT_WAVES * ATT_XS_MIN_J &&
              (p.cross_len + 31) / 32 <= ATT_WAVES * ATT_XS_MAX_J)
+    {
+        if (p.qp_w) {                                                                       // LayerNorm + query projection in the prologue
+            MIS_REQUIRE(attn_qp_ok(p), MIS_ERR_GENERATION_FAILED, "attention: the query-projection prologue does not apply to this launch");
+            const size_t smq = smem + ATT_QP_LDS;
+            if (p.qp_S <= 4) hipLaunchKernelGGL((k_attn_decode<64, 2, true, 4>), grid, block, smq, s, p2);
+            else hipLaunchKernelGGL((k_attn_decode<64, 2, true, 8>), grid, block, smq, s, p2);
+        } else
         hipLaunchKernelGGL((k_attn_decode<64, 2, true>), grid, block, smem, s, p2);       // cross-attention: two pairs of tiles in flight
+    }
     else if (p.D == 64 && n_el <= 1024) hipLaunchKernelGGL((k_attn_decode<64, 2>), grid, block, smem, s, p2);
     else if (p.D == 64) hipLaunchKernelGGL((k_attn_decode<64, 3>), grid, block, smem, s, p2);
     else throw MisError(MIS_ERR_INVALID_INPUT, "head_dim must be 64 or 128");

@@ -43,7 +43,7 @@ struct mis_whisper {
     DevBuf<bf16_t> cross_k, cross_v, self_k, self_v, enc_out;
     DevBuf<int32_t> ids, pos_cur, pos_next, n_gen, tokens_out, next_ids, done_count, sup, bsup;
     DevBuf<uint8_t> active;
-    DevBuf<bf16_t> h, x, attn_out, act, logits;
+    DevBuf<bf16_t> h, h2, x, attn_out, act, logits;      // h2: the other residual buffer of the folded glue (enqueue_decoder_step)
     DevBuf<float> qkv_part, part, e_buf, logits_f32;
     DevBuf<SamplerScratch> scratch;
     bool shared_device = false;      // another replica's streams run on this device (group.hip): never a kernel that waits for co-resident blocks
@@ -365,6 +365,8 @@ static void whisper_alloc_state(mis_whisper* c, int batch) {
     c->S_o = split_for(d / 16 / 2, d / 32);
     c->S_cq = c->S_o;
     c->S_fc2 = split_for(d / 16 / 2, c->cfg.decoder_ffn_dim / 32);
+    if (const char* e = getenv("MIS_WS_FC2")) c->S_fc2 = std::max(1, std::min(atoi(e), 8));        // laboratory overrides of the split factors
+    if (const char* e = getenv("MIS_WS_O")) c->S_o = c->S_cq = std::max(1, std::min(atoi(e), 8));
     size_t ck = (size_t)Ld * batch * c->Hd * c->Spad * c->D;
     c->cross_k.alloc(ck); c->cross_v.alloc(ck);
     size_t sk = (size_t)Ld * batch * c->Hd * Smax * c->D;
@@ -372,7 +374,7 @@ static void whisper_alloc_state(mis_whisper* c, int batch) {
     c->enc_out.alloc((size_t)batch * 1500 * d);
     c->ids.alloc(Mpad); c->pos_cur.alloc(Mpad); c->pos_next.alloc(Mpad); c->active.alloc(Mpad); c->n_gen.alloc(Mpad);
     c->next_ids.alloc(Mpad); c->done_count.alloc(1);
-    c->h.alloc((size_t)Mpad * d); c->x.alloc((size_t)Mpad * std::max(d, c->cfg.decoder_ffn_dim));
+    c->h.alloc((size_t)Mpad * d); c->h2.alloc((size_t)Mpad * d); c->x.alloc((size_t)Mpad * std::max(d, c->cfg.decoder_ffn_dim));
     c->attn_out.alloc((size_t)Mpad * d); c->act.alloc((size_t)Mpad * c->cfg.decoder_ffn_dim);
     c->logits.alloc((size_t)Mpad * c->Vpad); c->e_buf.alloc((size_t)Mpad * c->Vpad);
     c->qkv_part.alloc((size_t)c->S_qkv * Mpad * 3 * d);
@@ -387,7 +389,7 @@ static void whisper_decoder_reset(mis_whisper* c) {
     HIP_CHECK(hipMemsetAsync(c->self_v.p, 0, c->self_v.bytes(), s));
     c->ids.zero(s); c->pos_cur.zero(s); c->pos_next.zero(s); c->active.zero(s); c->n_gen.zero(s); c->next_ids.zero(s);
     c->done_count.zero(s);
-    c->h.zero(s); c->x.zero(s); c->attn_out.zero(s); c->act.zero(s); c->logits.zero(s);
+    c->h.zero(s); c->h2.zero(s); c->x.zero(s); c->attn_out.zero(s); c->act.zero(s); c->logits.zero(s);
     HIP_CHECK(hipStreamSynchronize(s));
 }
 
@@ -489,16 +491,42 @@ extern "C" mis_status mis_whisper_encode(mis_whisper* c, const float* features, 
 }
 
 // ---------------------------------------------------------------------------- decoder step
+// Up to 16 rows (the BASELINE share: 8 windows per GPU) the three residual + LayerNorm glue launches of a layer run inside the prologue
+// of the GEMM that consumes them (k_gemm_skinny_norm, lm_kernels.hip): 8 launches per layer instead of 11; the residual stream alternates
+// between two buffers (every block of the consumer still reads the old one while the n-tile group 0 blocks write the new one).
+// MIS_WHISPER_FOLD=0 keeps the separate glue launches (tests hold the two forms to each other); =2 fails where the fold does not apply.
+#define WHISPER_FOLD_DEFAULT 20
 static void enqueue_decoder_step(mis_whisper* c) {
     hipStream_t s = c->stream;
     const int d = c->d, fd = c->cfg.decoder_ffn_dim, Mpad = c->Mpad, H = c->Hd, D = c->D;
     const DecLayer& L0 = c->dec[0];
-    launch_whisper_embed_ln(c->emb, c->dec_pos, c->ids.p, c->active.p, c->pos_cur.p, c->pos_next.p, L0.ln1w, L0.ln1b, c->h.p,
+    // MIS_WHISPER_FOLD: bit 0 q|k|v (LayerNorm 1), bit 1 cross-attention query (LayerNorm 2), bit 2 fc1 (LayerNorm 3); bit 3: fail where a
+    // requested fold does not apply (tests)
+    const char* fe = getenv("MIS_WHISPER_FOLD");
+    const int want = fe ? atoi(fe) : WHISPER_FOLD_DEFAULT;
+    const bool f_qkv = (want & 1) && gemm_skinny_norm_ok(EPI_PARTIAL, 2, d / 32, c->S_qkv, c->S_fc2, Mpad, c->batch);
+    // bit 4: LayerNorm 2 AND the cross-attention's query projection inside the cross-attention kernel (k_attn_decode<64, 2, true, QP>)
+    AttnParams probe{};
+    probe.cross = 1; probe.cross_len = 1500; probe.D = D; probe.H = H; probe.Hkv = H; probe.qp_KT = d / 32; probe.qp_S = c->S_o;
+    const bool f_cqa = (want & 16) && Mpad == 16 && attn_qp_ok(probe);
+    const bool f_cq = !f_cqa && (want & 2) && gemm_skinny_norm_ok(EPI_PARTIAL, 2, d / 32, c->S_cq, c->S_o, Mpad, c->batch);
+    const bool f_fc1 = (want & 4) && gemm_skinny_norm_ok(EPI_GELU_PACKED, 2, d / 32, 1, c->S_o, Mpad, c->batch);
+    MIS_REQUIRE(!(want & 8) || (f_qkv == !!(want & 1) && (f_cq || f_cqa) == !!(want & 18) && f_fc1 == !!(want & 4)), MIS_ERR_GENERATION_FAILED,
+                "MIS_WHISPER_FOLD: the folded decoder step does not apply to this shape");
+    bf16_t* hcur = c->h.p;
+    bf16_t* hoth = c->h2.p;
+    launch_whisper_embed_ln(c->emb, c->dec_pos, c->ids.p, c->active.p, c->pos_cur.p, c->pos_next.p, L0.ln1w, L0.ln1b, hcur,
                             c->x.p, d, c->V, c->cfg.max_target_positions, c->batch, Mpad, s);
     for (size_t li = 0; li < c->dec.size(); ++li) {
         const DecLayer& L = c->dec[li];
         // self attention (WhisperLayers.swift:202-214)
-        launch_gemm_skinny(EPI_PARTIAL, 2, 4, L.sqkv, c->x.p, c->qkv_part.p, 3 * d / 16, d / 32, c->S_qkv, 3 * d, Mpad, s, L.sbqkv);
+        if (f_qkv && li > 0) {                             // h += fc2 of the previous layer; LayerNorm 1 of this one; q|k|v
+            launch_gemm_skinny_norm(EPI_PARTIAL, 2, L.sqkv, c->part.p, c->S_fc2, hcur, hoth, L.ln1w, L.ln1b, LN_EPS, c->batch, c->qkv_part.p, 3 * d / 16,
+                                    d / 32, c->S_qkv, 3 * d, Mpad, s, L.sbqkv);
+            std::swap(hcur, hoth);
+        } else {
+            launch_gemm_skinny(EPI_PARTIAL, 2, 4, L.sqkv, c->x.p, c->qkv_part.p, 3 * d / 16, d / 32, c->S_qkv, 3 * d, Mpad, s, L.sbqkv);
+        }
         AttnParams ap{};
         ap.qkv_part = c->qkv_part.p; ap.S = c->S_qkv; ap.Mpad = Mpad; ap.Nqkv = 3 * d;
         size_t ls = (size_t)c->batch * H * c->Smax * D;
@@ -507,9 +535,17 @@ static void enqueue_decoder_step(mis_whisper* c) {
         ap.out = c->attn_out.p; ap.H = H; ap.Hkv = H; ap.D = D; ap.Smax = c->Smax; ap.scale = 1.0f / sqrtf((float)D);
         launch_attn_decode(ap, c->batch, s);
         launch_gemm_skinny(EPI_PARTIAL, 2, 4, L.so, c->attn_out.p, c->part.p, d / 16, d / 32, c->S_o, d, Mpad, s, L.sbo);
-        launch_reduce_residual_rmsnorm(c->part.p, c->S_o, Mpad, d, c->h.p, L.ln2w, c->x.p, LN_EPS, s, L.ln2b);
         // cross attention over the cached encoder K/V (:216-243)
-        launch_gemm_skinny(EPI_PARTIAL, 2, 4, L.cq, c->x.p, c->qkv_part.p, d / 16, d / 32, c->S_cq, d, Mpad, s, L.cbq);
+        if (f_cqa) {
+            // (nothing here: the cross-attention launch below does h += self-attention output, LayerNorm 2 and q = W_q x + b itself)
+        } else if (f_cq) {
+            launch_gemm_skinny_norm(EPI_PARTIAL, 2, L.cq, c->part.p, c->S_o, hcur, hoth, L.ln2w, L.ln2b, LN_EPS, c->batch, c->qkv_part.p, d / 16, d / 32,
+                                    c->S_cq, d, Mpad, s, L.cbq);
+            std::swap(hcur, hoth);
+        } else {
+            launch_reduce_residual_rmsnorm(c->part.p, c->S_o, Mpad, d, hcur, L.ln2w, c->x.p, LN_EPS, s, L.ln2b);
+            launch_gemm_skinny(EPI_PARTIAL, 2, 4, L.cq, c->x.p, c->qkv_part.p, d / 16, d / 32, c->S_cq, d, Mpad, s, L.cbq);
+        }
         AttnParams cp{};
         cp.qkv_part = c->qkv_part.p; cp.S = c->S_cq; cp.Mpad = Mpad; cp.Nqkv = d;
         size_t cs = (size_t)c->batch * H * c->Spad * D;
@@ -517,15 +553,28 @@ static void enqueue_decoder_step(mis_whisper* c) {
         cp.pos = c->pos_cur.p; cp.active = c->active.p; cp.rope_cos = nullptr; cp.rope_sin = nullptr;
         cp.out = c->attn_out.p; cp.H = H; cp.Hkv = H; cp.D = D; cp.Smax = c->Spad; cp.scale = 1.0f / sqrtf((float)D);
         cp.cross = 1; cp.cross_len = 1500;
+        if (f_cqa) {
+            cp.qp_w = L.cq; cp.qp_bias = L.cbq; cp.qp_slabs = c->part.p; cp.qp_S = c->S_o; cp.qp_KT = d / 32; cp.qp_h_in = hcur; cp.qp_h_out = hoth;
+            cp.qp_lnw = L.ln2w; cp.qp_lnb = L.ln2b; cp.qp_eps = LN_EPS;
+            std::swap(hcur, hoth);
+        }
         launch_attn_decode(cp, c->batch, s);
         launch_gemm_skinny(EPI_PARTIAL, 2, 4, L.co, c->attn_out.p, c->part.p, d / 16, d / 32, c->S_o, d, Mpad, s, L.cbo);
-        launch_reduce_residual_rmsnorm(c->part.p, c->S_o, Mpad, d, c->h.p, L.ln3w, c->x.p, LN_EPS, s, L.ln3b);
         // MLP (:245-249)
-        launch_gemm_skinny(EPI_GELU_PACKED, 2, 4, L.fc1, c->x.p, c->act.p, fd / 16, d / 32, 1, fd, Mpad, s, L.b1);
+        if (f_fc1) {
+            launch_gemm_skinny_norm(EPI_GELU_PACKED, 2, L.fc1, c->part.p, c->S_o, hcur, hoth, L.ln3w, L.ln3b, LN_EPS, c->batch, c->act.p, fd / 16, d / 32, 1,
+                                    fd, Mpad, s, L.b1);
+            std::swap(hcur, hoth);
+        } else {
+            launch_reduce_residual_rmsnorm(c->part.p, c->S_o, Mpad, d, hcur, L.ln3w, c->x.p, LN_EPS, s, L.ln3b);
+            launch_gemm_skinny(EPI_GELU_PACKED, 2, 4, L.fc1, c->x.p, c->act.p, fd / 16, d / 32, 1, fd, Mpad, s, L.b1);
+        }
         launch_gemm_skinny(EPI_PARTIAL, 2, 4, L.fc2, c->act.p, c->part.p, d / 16, fd / 32, c->S_fc2, d, Mpad, s, L.b2);
-        const bf16_t* nw = (li + 1 < c->dec.size()) ? c->dec[li + 1].ln1w : c->dec_lnw;
-        const bf16_t* nb = (li + 1 < c->dec.size()) ? c->dec[li + 1].ln1b : c->dec_lnb;
-        launch_reduce_residual_rmsnorm(c->part.p, c->S_fc2, Mpad, d, c->h.p, nw, c->x.p, LN_EPS, s, nb);
+        if (!f_qkv || li + 1 == c->dec.size()) {            // (folded: the next layer's q|k|v launch does this; the last layer's feeds the vocabulary GEMM)
+            const bf16_t* nw = (li + 1 < c->dec.size()) ? c->dec[li + 1].ln1w : c->dec_lnw;
+            const bf16_t* nb = (li + 1 < c->dec.size()) ? c->dec[li + 1].ln1b : c->dec_lnb;
+            launch_reduce_residual_rmsnorm(c->part.p, c->S_fc2, Mpad, d, hcur, nw, c->x.p, LN_EPS, s, nb);
+        }
     }
 }
 static void enqueue_vocab(mis_whisper* c) {

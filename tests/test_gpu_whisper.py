@@ -360,3 +360,58 @@ def test_sampler_timeout_inside_transcribe_recovers(monkeypatch):
         monkeypatch.setenv("MIS_SAMPLER_WIDE", "1")                    # the multi-launch path from the start: nothing to recover from
         assert dev.transcribe_windows(wins, prompt, gp) == want and lib.mis_debug_sampler_failures() == before + 2
         monkeypatch.delenv("MIS_SAMPLER_WIDE")
+
+
+@pytest.mark.parametrize("B", [3, 8, 11, 17])
+def test_glue_folded_into_its_consumers_matches_the_separate_launches_and_the_oracle(monkeypatch, B):
+    """Round 6: up to 16 rows the residual + LayerNorm launches of a decoder layer can run in the prologue of their consumer
+    (`MIS_WHISPER_FOLD`, a bit mask): bits 0-2 = inside the q|k|v / cross-query / fc1 GEMM (`k_gemm_skinny_norm`: every block rebuilds all
+    rows from the producer's split-K slabs and the residual stream), bit 4 = LayerNorm 2 AND the cross-attention's query projection inside
+    the cross-attention kernel (`k_attn_decode<64, 2, true, QP>`: a block is one (row, head) and rebuilds only its row; the default).
+    The residual stream alternates between two buffers.  At large-v3's decoder WIDTH (d 1280, 20 heads, ffn 5120; three layers, small
+    vocabulary): every form is within the stated tolerance of the oracle and no further from the separate launches (`=0`) than that
+    (same arithmetic per element; row statistics and the query projection's K sum are float32 sums in another order).  B = 11: rows
+    8 .. 10 are a wave's SECOND row in the GEMM folds; B = 17: two m-tiles - the engine keeps the separate launches (bit 3: fail where a
+    requested fold does not apply)."""
+    cfg = ow.WhisperConfig(vocab_size=700, num_mel_bins=128, d_model=1280, encoder_layers=1, encoder_attention_heads=20, encoder_ffn_dim=1280,
+                           decoder_layers=3, decoder_attention_heads=20, decoder_ffn_dim=5120)
+    W, oracle, dev = _pair(cfg)
+    feats = _feats(B, cfg.num_mel_bins, 16)
+    dev.encode(feats)
+    T = 5
+    toks = np.random.default_rng(18).integers(0, cfg.vocab_size, (B, T))
+    modes = {"separate": "0", "gemm_folds": "15" if B <= 16 else "7", "attention_fold": "28" if B <= 16 else "20", "default": None}
+    got = {}
+    for name, fold in modes.items():
+        if fold is None:
+            monkeypatch.delenv("MIS_WHISPER_FOLD", raising=False)
+        else:
+            monkeypatch.setenv("MIS_WHISPER_FOLD", fold)
+        dev.decoder_reset()
+        got[name] = np.stack([dev.decoder_forward(toks[:, t]) for t in range(T)], axis=1)        # [B, T, V]
+    if B > 16:
+        for strict in ("15", "28"):
+            monkeypatch.setenv("MIS_WHISPER_FOLD", strict)
+            with pytest.raises(mas.AudioGenerationError):
+                dev.decoder_forward(toks[:, 0])
+    monkeypatch.delenv("MIS_WHISPER_FOLD", raising=False)
+    rows = sorted({0, B // 2, B - 1, min(8, B - 1)})
+    oracle.reset(B)
+    oracle.encode(feats)
+    ref = oracle.decode([toks[b] for b in range(B)])
+    for b in rows:
+        r = ref[b].numpy()
+        for name in modes:
+            _check(got[name][b], r, 0.022, 0.012)
+    from gpu_util import record
+    scale = float(np.abs(got["separate"]).max())
+    for name in ("gemm_folds", "attention_fold", "default"):
+        d_max = float(np.abs(got[name] - got["separate"]).max()) / scale
+        d_rms = rms(got[name], got["separate"]) / float(np.sqrt(np.mean(got["separate"].astype(np.float64) ** 2)))
+        record(f"whisper_decoder_glue_fold_b{B}_{name}", vs_separate_max_rel=d_max, vs_separate_rms_rel=d_rms, tol_max=0.022, tol_rms=0.012)
+        if B > 16:
+            assert np.array_equal(got[name], got["separate"])
+        else:
+            assert d_max <= 0.022 and d_rms <= 0.012, (name, d_max, d_rms)
+    if B <= 16:
+        assert np.array_equal(got["default"], got["attention_fold"])                              # (the default IS bits 2 and 4)
