@@ -927,6 +927,9 @@ void launch_gemm_skinny(int epi, int R, int ksb, const bf16_t* Wp, const bf16_t*
 // Same arithmetic per element as k_glue4 (slab order 0, 1, ..; float32 statistics - summed in another order, like k_glue_cpt).
 // (At 32 rows x d = 1024 the same fold lost in round 3 - profiles/r03/q3: four times the bytes per block and a block-wide reduction in
 // front of the first MFMA; here the rows are few enough for one wave per row and the weight trip hides the prologue.)
+// Measured at Whisper-large-v3's decoder (profiles/r06/c2, c3): fc1 7.0 + glue 4.6 -> 9.6 us under the profiler, transcribe -1 %: kept for
+// fc1; the q|k|v GEMM behind 8 slabs (5.1 + 4.7 -> 10.0 us) and the cross query (superseded by the fold into the attention kernel) are not
+// instantiated.
 template <int R, int EPI, bool LN, int SG, int KW, int G>
 __global__ void __launch_bounds__(512, 1) k_gemm_skinny_norm(const bf16_t* __restrict__ Wp, const float* __restrict__ slabs, int S_in,
                                                              const bf16_t* __restrict__ h_in, bf16_t* __restrict__ h_out,
@@ -1101,16 +1104,8 @@ void launch_gemm_skinny_norm(int epi, int R, const bf16_t* Wp, const float* slab
                            ln_bias, eps, nrows, out, NT, KT, S, n_items, N_out, bias);                                                    \
         return;                                                                                                                           \
     }
-    GN_CASE(EPI_PARTIAL, true, 4, 2)
-    GN_CASE(EPI_PARTIAL, true, 8, 2)
-    GN_CASE(EPI_PARTIAL, true, 4, 5)
-    GN_CASE(EPI_PARTIAL, true, 8, 5)
-    GN_CASE(EPI_GELU_PACKED, true, 4, 5)
+    GN_CASE(EPI_GELU_PACKED, true, 4, 5)                  // (the instantiations the product launches: Whisper's fc1 behind LayerNorm 3)
     GN_CASE(EPI_GELU_PACKED, true, 8, 5)
-    GN_CASE(EPI_PARTIAL, false, 4, 2)
-    GN_CASE(EPI_PARTIAL, false, 8, 2)
-    GN_CASE(EPI_PARTIAL, false, 4, 5)
-    GN_CASE(EPI_PARTIAL, false, 8, 5)
 #undef GN_CASE
     throw MisError(MIS_ERR_GENERATION_FAILED, "unsupported norm-in-prologue GEMM variant");
 }
@@ -2094,6 +2089,9 @@ void launch_attn_decode(const AttnParams& p, int batch, hipStream_t s) {
     {
         if (p.qp_w) {                                                                       // LayerNorm + query projection in the prologue
             MIS_REQUIRE(attn_qp_ok(p), MIS_ERR_GENERATION_FAILED, "attention: the query-projection prologue does not apply to this launch");
+            AttnParams pq = p2;                            // (the kernel's unconditional dummy loads - norm weights, RoPE rows - read qkv_part[0])
+            if (!pq.qkv_part) pq.qkv_part = pq.qp_slabs;
+            const AttnParams& p2 = pq;
             const size_t smq = smem + ATT_QP_LDS;
             if (p.qp_S <= 4) hipLaunchKernelGGL((k_attn_decode<64, 2, true, 4>), grid, block, smq, s, p2);
             else hipLaunchKernelGGL((k_attn_decode<64, 2, true, 8>), grid, block, smq, s, p2);

@@ -365,8 +365,6 @@ static void whisper_alloc_state(mis_whisper* c, int batch) {
     c->S_o = split_for(d / 16 / 2, d / 32);
     c->S_cq = c->S_o;
     c->S_fc2 = split_for(d / 16 / 2, c->cfg.decoder_ffn_dim / 32);
-    if (const char* e = getenv("MIS_WS_FC2")) c->S_fc2 = std::max(1, std::min(atoi(e), 8));        // laboratory overrides of the split factors
-    if (const char* e = getenv("MIS_WS_O")) c->S_o = c->S_cq = std::max(1, std::min(atoi(e), 8));
     size_t ck = (size_t)Ld * batch * c->Hd * c->Spad * c->D;
     c->cross_k.alloc(ck); c->cross_v.alloc(ck);
     size_t sk = (size_t)Ld * batch * c->Hd * Smax * c->D;
@@ -491,27 +489,28 @@ extern "C" mis_status mis_whisper_encode(mis_whisper* c, const float* features, 
 }
 
 // ---------------------------------------------------------------------------- decoder step
-// Up to 16 rows (the BASELINE share: 8 windows per GPU) the three residual + LayerNorm glue launches of a layer run inside the prologue
-// of the GEMM that consumes them (k_gemm_skinny_norm, lm_kernels.hip): 8 launches per layer instead of 11; the residual stream alternates
-// between two buffers (every block of the consumer still reads the old one while the n-tile group 0 blocks write the new one).
-// MIS_WHISPER_FOLD=0 keeps the separate glue launches (tests hold the two forms to each other); =2 fails where the fold does not apply.
+// Up to 16 rows (the BASELINE share: 8 windows per GPU) two of the three residual + LayerNorm glue launches of a layer - and one GEMM launch -
+// run inside the prologue of their consumer: 8 launches per layer instead of 11 (transcribe 228 -> 214 ms per 8 x 30 s, profiles/r06/c4, c5).
+//   bit 4 (16): h += self-attention output, LayerNorm 2 AND the cross-attention's query projection inside the cross-attention kernel
+//               (k_attn_decode<64, 2, true, QP>, lm_kernels.hip: a block is one (row, head) and rebuilds only its row);
+//   bit 2 (4):  h += cross-attention output and LayerNorm 3 inside fc1's prologue (k_gemm_skinny_norm: every block rebuilds all rows);
+//   bit 3 (8):  fail where a requested fold does not apply (tests).  MIS_WHISPER_FOLD=0 keeps the separate launches.
+// The residual stream alternates between two buffers: every block of a consumer still reads the old one while one of them writes the new.
+// Measured and not kept (profiles/r06/c3, c5): the same GEMM-side fold for q|k|v and the cross query (every one of 120-480 blocks re-reads all
+// rows' slabs: neutral to +1 %), LayerNorm 1 + q|k|v inside the SELF-attention kernel (480 KB of weights per block in three trips: the
+// kernel 5.0 -> 15.6 us against 9.6 saved; the variant is on file as c5_self_attention_qkv_fold_measured_variant.patch).
 #define WHISPER_FOLD_DEFAULT 20
 static void enqueue_decoder_step(mis_whisper* c) {
     hipStream_t s = c->stream;
     const int d = c->d, fd = c->cfg.decoder_ffn_dim, Mpad = c->Mpad, H = c->Hd, D = c->D;
     const DecLayer& L0 = c->dec[0];
-    // MIS_WHISPER_FOLD: bit 0 q|k|v (LayerNorm 1), bit 1 cross-attention query (LayerNorm 2), bit 2 fc1 (LayerNorm 3); bit 3: fail where a
-    // requested fold does not apply (tests)
     const char* fe = getenv("MIS_WHISPER_FOLD");
     const int want = fe ? atoi(fe) : WHISPER_FOLD_DEFAULT;
-    const bool f_qkv = (want & 1) && gemm_skinny_norm_ok(EPI_PARTIAL, 2, d / 32, c->S_qkv, c->S_fc2, Mpad, c->batch);
-    // bit 4: LayerNorm 2 AND the cross-attention's query projection inside the cross-attention kernel (k_attn_decode<64, 2, true, QP>)
     AttnParams probe{};
     probe.cross = 1; probe.cross_len = 1500; probe.D = D; probe.H = H; probe.Hkv = H; probe.qp_KT = d / 32; probe.qp_S = c->S_o;
     const bool f_cqa = (want & 16) && Mpad == 16 && attn_qp_ok(probe);
-    const bool f_cq = !f_cqa && (want & 2) && gemm_skinny_norm_ok(EPI_PARTIAL, 2, d / 32, c->S_cq, c->S_o, Mpad, c->batch);
     const bool f_fc1 = (want & 4) && gemm_skinny_norm_ok(EPI_GELU_PACKED, 2, d / 32, 1, c->S_o, Mpad, c->batch);
-    MIS_REQUIRE(!(want & 8) || (f_qkv == !!(want & 1) && (f_cq || f_cqa) == !!(want & 18) && f_fc1 == !!(want & 4)), MIS_ERR_GENERATION_FAILED,
+    MIS_REQUIRE(!(want & 8) || (f_cqa == !!(want & 16) && f_fc1 == !!(want & 4)), MIS_ERR_GENERATION_FAILED,
                 "MIS_WHISPER_FOLD: the folded decoder step does not apply to this shape");
     bf16_t* hcur = c->h.p;
     bf16_t* hoth = c->h2.p;
@@ -520,13 +519,7 @@ static void enqueue_decoder_step(mis_whisper* c) {
     for (size_t li = 0; li < c->dec.size(); ++li) {
         const DecLayer& L = c->dec[li];
         // self attention (WhisperLayers.swift:202-214)
-        if (f_qkv && li > 0) {                             // h += fc2 of the previous layer; LayerNorm 1 of this one; q|k|v
-            launch_gemm_skinny_norm(EPI_PARTIAL, 2, L.sqkv, c->part.p, c->S_fc2, hcur, hoth, L.ln1w, L.ln1b, LN_EPS, c->batch, c->qkv_part.p, 3 * d / 16,
-                                    d / 32, c->S_qkv, 3 * d, Mpad, s, L.sbqkv);
-            std::swap(hcur, hoth);
-        } else {
-            launch_gemm_skinny(EPI_PARTIAL, 2, 4, L.sqkv, c->x.p, c->qkv_part.p, 3 * d / 16, d / 32, c->S_qkv, 3 * d, Mpad, s, L.sbqkv);
-        }
+        launch_gemm_skinny(EPI_PARTIAL, 2, 4, L.sqkv, c->x.p, c->qkv_part.p, 3 * d / 16, d / 32, c->S_qkv, 3 * d, Mpad, s, L.sbqkv);
         AttnParams ap{};
         ap.qkv_part = c->qkv_part.p; ap.S = c->S_qkv; ap.Mpad = Mpad; ap.Nqkv = 3 * d;
         size_t ls = (size_t)c->batch * H * c->Smax * D;
@@ -536,28 +529,22 @@ static void enqueue_decoder_step(mis_whisper* c) {
         launch_attn_decode(ap, c->batch, s);
         launch_gemm_skinny(EPI_PARTIAL, 2, 4, L.so, c->attn_out.p, c->part.p, d / 16, d / 32, c->S_o, d, Mpad, s, L.sbo);
         // cross attention over the cached encoder K/V (:216-243)
-        if (f_cqa) {
-            // (nothing here: the cross-attention launch below does h += self-attention output, LayerNorm 2 and q = W_q x + b itself)
-        } else if (f_cq) {
-            launch_gemm_skinny_norm(EPI_PARTIAL, 2, L.cq, c->part.p, c->S_o, hcur, hoth, L.ln2w, L.ln2b, LN_EPS, c->batch, c->qkv_part.p, d / 16, d / 32,
-                                    c->S_cq, d, Mpad, s, L.cbq);
+        AttnParams cp{};
+        cp.Mpad = Mpad;
+        if (f_cqa) {                                       // the launch below does h += self-attention output, LayerNorm 2 and q = W_q x + b itself
+            cp.qp_w = L.cq; cp.qp_bias = L.cbq; cp.qp_slabs = c->part.p; cp.qp_S = c->S_o; cp.qp_KT = d / 32; cp.qp_h_in = hcur; cp.qp_h_out = hoth;
+            cp.qp_lnw = L.ln2w; cp.qp_lnb = L.ln2b; cp.qp_eps = LN_EPS;
             std::swap(hcur, hoth);
         } else {
             launch_reduce_residual_rmsnorm(c->part.p, c->S_o, Mpad, d, hcur, L.ln2w, c->x.p, LN_EPS, s, L.ln2b);
             launch_gemm_skinny(EPI_PARTIAL, 2, 4, L.cq, c->x.p, c->qkv_part.p, d / 16, d / 32, c->S_cq, d, Mpad, s, L.cbq);
+            cp.qkv_part = c->qkv_part.p; cp.S = c->S_cq; cp.Nqkv = d;
         }
-        AttnParams cp{};
-        cp.qkv_part = c->qkv_part.p; cp.S = c->S_cq; cp.Mpad = Mpad; cp.Nqkv = d;
         size_t cs = (size_t)c->batch * H * c->Spad * D;
         cp.kcache = c->cross_k.p + li * cs; cp.vtcache = c->cross_v.p + li * cs;
         cp.pos = c->pos_cur.p; cp.active = c->active.p; cp.rope_cos = nullptr; cp.rope_sin = nullptr;
         cp.out = c->attn_out.p; cp.H = H; cp.Hkv = H; cp.D = D; cp.Smax = c->Spad; cp.scale = 1.0f / sqrtf((float)D);
         cp.cross = 1; cp.cross_len = 1500;
-        if (f_cqa) {
-            cp.qp_w = L.cq; cp.qp_bias = L.cbq; cp.qp_slabs = c->part.p; cp.qp_S = c->S_o; cp.qp_KT = d / 32; cp.qp_h_in = hcur; cp.qp_h_out = hoth;
-            cp.qp_lnw = L.ln2w; cp.qp_lnb = L.ln2b; cp.qp_eps = LN_EPS;
-            std::swap(hcur, hoth);
-        }
         launch_attn_decode(cp, c->batch, s);
         launch_gemm_skinny(EPI_PARTIAL, 2, 4, L.co, c->attn_out.p, c->part.p, d / 16, d / 32, c->S_o, d, Mpad, s, L.cbo);
         // MLP (:245-249)
@@ -570,11 +557,9 @@ static void enqueue_decoder_step(mis_whisper* c) {
             launch_gemm_skinny(EPI_GELU_PACKED, 2, 4, L.fc1, c->x.p, c->act.p, fd / 16, d / 32, 1, fd, Mpad, s, L.b1);
         }
         launch_gemm_skinny(EPI_PARTIAL, 2, 4, L.fc2, c->act.p, c->part.p, d / 16, fd / 32, c->S_fc2, d, Mpad, s, L.b2);
-        if (!f_qkv || li + 1 == c->dec.size()) {            // (folded: the next layer's q|k|v launch does this; the last layer's feeds the vocabulary GEMM)
-            const bf16_t* nw = (li + 1 < c->dec.size()) ? c->dec[li + 1].ln1w : c->dec_lnw;
-            const bf16_t* nb = (li + 1 < c->dec.size()) ? c->dec[li + 1].ln1b : c->dec_lnb;
-            launch_reduce_residual_rmsnorm(c->part.p, c->S_fc2, Mpad, d, hcur, nw, c->x.p, LN_EPS, s, nb);
-        }
+        const bf16_t* nw = (li + 1 < c->dec.size()) ? c->dec[li + 1].ln1w : c->dec_lnw;
+        const bf16_t* nb = (li + 1 < c->dec.size()) ? c->dec[li + 1].ln1b : c->dec_lnb;
+        launch_reduce_residual_rmsnorm(c->part.p, c->S_fc2, Mpad, d, hcur, nw, c->x.p, LN_EPS, s, nb);
     }
 }
 static void enqueue_vocab(mis_whisper* c) {

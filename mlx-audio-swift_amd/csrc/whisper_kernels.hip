@@ -14,6 +14,7 @@
 //   k_attn_prefill  non-causal flash attention over the tiled K/V, 16 query rows per wave
 #include "common.h"
 #include "whisper_kernels.h"
+#include <type_traits>
 
 // GELU (erf form, WhisperLayers.swift:142-156 via MLXNN.GELU) for the encoder's big-GEMM epilogues.  erff() from the device library is
 // ~60 instructions per element once both of its range branches run in a wave - 15 us per 256 x 256 output tile, fully exposed with one
@@ -657,10 +658,148 @@ __global__ void __launch_bounds__(256) k_attn_prefill(const bf16_t* __restrict__
         }
     }
 }
+// ---- the same attention, tiled for the matrix core's appetite (round 6; VERDICT r03-r05: k_attn_prefill<64> at MfmaUtil 0.21 was the worst
+// MFMA kernel of the tree).  What the kernel above costs per 32-key tile and wave: 16 fragment loads straight from global memory, waited
+// for where they are used (no tile in flight while another is multiplied), for 12 MFMAs on 16 query rows - and every one of the 94
+// waves of a head streams the head's whole 393 KB of K/V for itself.  Here a block is 256 query rows (8 waves x 2 groups of 16): the
+// tile's K and V images (8 KB, already in fragment order - lm_kernels.hip's cache tiling) are staged ONCE per block through LDS, one
+// 16-byte piece per thread, tile t + 1 requested before tile t is multiplied (two LDS buffers, one barrier per tile); a wave reads each
+// fragment once (lane-linear ds_read_b128, conflict-free) and uses it for both of its row groups: 24 MFMAs per 8 LDS reads.  The key
+// mask is applied on the last tile only, and the running output is rescaled only when some row's maximum moved (alpha = 1 otherwise:
+// skipping the multiply is exact).  Same operations per query row in the same order as k_attn_prefill: results are bit-identical
+// (tests/test_gpu_whisper.py).  Bound after this: the softmax's VALU work (exp, the bf16 hi/lo split of P), not the matrix core.
+template <int D>
+__global__ void __launch_bounds__(512, 1) k_attn_prefill2(const bf16_t* __restrict__ q, int ldq, const bf16_t* __restrict__ kc,
+                                                          const bf16_t* __restrict__ vc, bf16_t* __restrict__ out, int ldo,
+                                                          int T, int H, int Spad, float scale) {
+    static_assert(D == 64, "one 16-byte piece of the tile's 8 KB per thread");
+    constexpr int NW = 8, QR = 32 * NW, IMG = 32 * D;                // bf16 elements of one K (or V) tile image
+    __shared__ __attribute__((aligned(16))) bf16_t kv[2][2 * IMG];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int b = blockIdx.z, h = blockIdx.y, q0 = blockIdx.x * QR + wave * 32;
+    const int j = lane & 15, g4 = lane >> 4;
+    bf16x8_t qf[2][D / 32];
+#pragma unroll
+    for (int g = 0; g < 2; ++g) {
+        const int tq = q0 + 16 * g + j;
+#pragma unroll
+        for (int c = 0; c < D / 32; ++c) {
+            if (tq < T) qf[g][c] = *reinterpret_cast<const bf16x8_t*>(q + ((size_t)b * T + tq) * ldq + h * D + c * 32 + g4 * 8);
+            else qf[g][c] = (bf16x8_t){0, 0, 0, 0, 0, 0, 0, 0};
+        }
+    }
+    const size_t base = ((size_t)b * H + h) * (size_t)Spad * D;
+    // staging: threads 0 .. 255 move the K image, 256 .. 511 the V image (IMG / 8 = 256 pieces each)
+    const uint4* src = reinterpret_cast<const uint4*>((tid < 256 ? kc : vc) + base) + (tid & 255);
+    const int dst_piece = tid;                                            // K image first, V image behind it
+    const int n_tiles = (T + 31) >> 5;
+    uint4 st = src[0];
+    *(reinterpret_cast<uint4*>(kv[0]) + dst_piece) = st;
+    __syncthreads();
+    f32x4_t O[2][D / 16];
+#pragma unroll
+    for (int g = 0; g < 2; ++g)
+#pragma unroll
+        for (int dt = 0; dt < D / 16; ++dt) O[g][dt] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+    float m_run[2] = {-INFINITY, -INFINITY}, l_run[2] = {0.0f, 0.0f};
+    auto tile_math = [&](int tile, const bf16_t* img, auto masked_tag) {
+        constexpr bool MASKED = decltype(masked_tag)::value;
+        const int kb = tile * 32;
+        const bf16x8_t* kf = reinterpret_cast<const bf16x8_t*>(img) + lane;
+        const bf16x8_t* vf = reinterpret_cast<const bf16x8_t*>(img + IMG) + lane;
+        bf16x8_t a0[D / 32], a1[D / 32], vb[D / 16];
+#pragma unroll
+        for (int c = 0; c < D / 32; ++c) { a0[c] = kf[c * 64]; a1[c] = kf[((D / 32) + c) * 64]; }
+#pragma unroll
+        for (int dt = 0; dt < D / 16; ++dt) vb[dt] = vf[dt * 64];
+#pragma unroll
+        for (int g = 0; g < 2; ++g) {
+            f32x4_t S0 = (f32x4_t){0.f, 0.f, 0.f, 0.f}, S1 = S0;
+#pragma unroll
+            for (int c = 0; c < D / 32; ++c) {
+                S0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0[c], qf[g][c], S0, 0, 0, 0);
+                S1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1[c], qf[g][c], S1, 0, 0, 0);
+            }
+            float sc[8], mx = -INFINITY;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                float v = (e < 4 ? S0[e] : S1[e - 4]) * scale;
+                if constexpr (MASKED) v = (kb + g4 * 8 + e < T) ? v : -INFINITY;
+                sc[e] = v;
+                mx = fmaxf(mx, v);
+            }
+            mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+            const float m_new = fmaxf(m_run[g], mx);
+            const float alpha = __expf(m_run[g] - m_new);
+            float psum = 0.0f;
+            bf16x8_t ph, pl;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float pe = __expf(sc[e] - m_new);
+                psum += pe;
+                const bf16_t hi = f32_to_bf16(pe);
+                const bf16_t lo = f32_to_bf16(pe - bf16_to_f32(hi));
+                ph[e] = (short)hi;
+                pl[e] = (short)lo;
+            }
+            l_run[g] = l_run[g] * alpha + psum;
+            const bool moved = m_new != m_run[g];
+            m_run[g] = m_new;
+            if (__any(moved)) {                              // (wave-uniform; alpha = exp(0) = 1 for every row otherwise)
+                float ar[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) ar[r] = __shfl(alpha, g4 * 4 + r, 64);
+#pragma unroll
+                for (int dt = 0; dt < D / 16; ++dt)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) O[g][dt][r] *= ar[r];
+            }
+#pragma unroll
+            for (int dt = 0; dt < D / 16; ++dt) {
+                f32x4_t o = O[g][dt];
+                o = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ph, vb[dt], o, 0, 0, 0);
+                o = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pl, vb[dt], o, 0, 0, 0);
+                O[g][dt] = o;
+            }
+        }
+    };
+    for (int tile = 0; tile < n_tiles; ++tile) {
+        const bool more = tile + 1 < n_tiles;
+        if (more) st = src[(size_t)(tile + 1) * (IMG / 8)];
+        if (more || (T & 31) == 0) tile_math(tile, kv[tile & 1], std::false_type{});
+        else tile_math(tile, kv[tile & 1], std::true_type{});
+        if (more) *(reinterpret_cast<uint4*>(kv[(tile + 1) & 1]) + dst_piece) = st;
+        __syncthreads();
+    }
+#pragma unroll
+    for (int g = 0; g < 2; ++g) {
+        float lr_all = l_run[g];
+        lr_all += __shfl_xor(lr_all, 16, 64);
+        lr_all += __shfl_xor(lr_all, 32, 64);
+        // O[g][dt][r]: row = query (g4*4 + r), col = d (dt*16 + j); the row's normaliser lives in lane (g4*4 + r)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float lr = __shfl(lr_all, g4 * 4 + r, 64);
+            const int tr = q0 + 16 * g + g4 * 4 + r;
+            if (tr < T) {
+#pragma unroll
+                for (int dt = 0; dt < D / 16; ++dt)
+                    out[((size_t)b * T + tr) * ldo + h * D + dt * 16 + j] = f32_to_bf16(O[g][dt][r] / lr);
+            }
+        }
+    }
+}
 void launch_attn_prefill(const bf16_t* q, int ldq, const bf16_t* kc, const bf16_t* vc, bf16_t* out, int ldo, int B, int T,
                          int H, int D, int Spad, hipStream_t s) {
-    dim3 grid(cdiv(T, 64), H, B), block(256);
     float scale = 1.0f / sqrtf((float)D);
+    const char* ve = getenv("MIS_ATTN_PREFILL_V1");                      // tests: the 16-rows-per-wave kernel (read per launch)
+    const bool v1 = ve && atoi(ve) != 0;
+    if (D == 64 && !v1 && ((uintptr_t)kc & 15) == 0 && ((uintptr_t)vc & 15) == 0) {
+        hipLaunchKernelGGL((k_attn_prefill2<64>), dim3(cdiv(T, 256), H, B), dim3(512), 0, s, q, ldq, kc, vc, out, ldo, T, H, Spad, scale);
+        return;
+    }
+    dim3 grid(cdiv(T, 64), H, B), block(256);
     if (D == 64) hipLaunchKernelGGL((k_attn_prefill<64>), grid, block, 0, s, q, ldq, kc, vc, out, ldo, T, H, Spad, scale);
     else if (D == 128) hipLaunchKernelGGL((k_attn_prefill<128>), grid, block, 0, s, q, ldq, kc, vc, out, ldo, T, H, Spad, scale);
     else throw MisError(MIS_ERR_INVALID_INPUT, "head_dim must be 64 or 128");

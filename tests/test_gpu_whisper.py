@@ -311,6 +311,24 @@ def test_encoder_256x256_tile_gemm_is_bit_identical_to_the_128x128_kernel(monkey
         _check(big[b], ref[b].numpy(), 0.022, 0.012)
 
 
+def test_encoder_attention_on_256_row_blocks_is_bit_identical_to_the_16_rows_per_wave_kernel(monkeypatch):
+    """`k_attn_prefill2` (round 6: 256 query rows per block, the K/V tile staged once per block through LDS, two row groups per wave, mask on
+    the last tile only, rescale only when a row maximum moved) performs the same operations per query row in the same order as
+    `k_attn_prefill` (`MIS_ATTN_PREFILL_V1=1`): encoder outputs must be equal bit for bit - 1500 positions = 5 full blocks + 220 rows,
+    47 key tiles of which the last is masked."""
+    cfg = ow.WhisperConfig(vocab_size=700, num_mel_bins=128, d_model=256, encoder_layers=2, encoder_attention_heads=4, encoder_ffn_dim=512,
+                           decoder_layers=1, decoder_attention_heads=4, decoder_ffn_dim=512)
+    dev = mas.WhisperModel.synthetic(_host_cfg(cfg), seed=31)
+    feats = _feats(3, cfg.num_mel_bins, 9)
+    got = {}
+    for v1 in ("1", "0"):
+        monkeypatch.setenv("MIS_ATTN_PREFILL_V1", v1)
+        got[v1] = dev.encode(feats)
+    monkeypatch.delenv("MIS_ATTN_PREFILL_V1")
+    assert np.isfinite(got["0"]).all() and np.abs(got["0"]).max() > 0
+    assert np.array_equal(got["0"], got["1"])
+
+
 def test_cross_attention_with_two_pairs_of_key_tiles_in_flight_is_bit_identical_to_the_pair_at_a_time_loop(monkeypatch):
     """`k_attn_decode<64, 2, XS>` (round 4: the schedule of the cross-attention over the 1500 encoder positions - 47 key tiles, five or six per
     wave, two pairs of them in registers, non-temporal loads) multiplies every wave's tiles in the order of the loop it replaces
@@ -364,14 +382,14 @@ def test_sampler_timeout_inside_transcribe_recovers(monkeypatch):
 
 @pytest.mark.parametrize("B", [3, 8, 11, 17])
 def test_glue_folded_into_its_consumers_matches_the_separate_launches_and_the_oracle(monkeypatch, B):
-    """Round 6: up to 16 rows the residual + LayerNorm launches of a decoder layer can run in the prologue of their consumer
-    (`MIS_WHISPER_FOLD`, a bit mask): bits 0-2 = inside the q|k|v / cross-query / fc1 GEMM (`k_gemm_skinny_norm`: every block rebuilds all
-    rows from the producer's split-K slabs and the residual stream), bit 4 = LayerNorm 2 AND the cross-attention's query projection inside
-    the cross-attention kernel (`k_attn_decode<64, 2, true, QP>`: a block is one (row, head) and rebuilds only its row; the default).
-    The residual stream alternates between two buffers.  At large-v3's decoder WIDTH (d 1280, 20 heads, ffn 5120; three layers, small
-    vocabulary): every form is within the stated tolerance of the oracle and no further from the separate launches (`=0`) than that
-    (same arithmetic per element; row statistics and the query projection's K sum are float32 sums in another order).  B = 11: rows
-    8 .. 10 are a wave's SECOND row in the GEMM folds; B = 17: two m-tiles - the engine keeps the separate launches (bit 3: fail where a
+    """Round 6: up to 16 rows two of the three residual + LayerNorm launches of a decoder layer run in the prologue of their consumer
+    (`MIS_WHISPER_FOLD`, a bit mask): bit 4 = LayerNorm 2 AND the cross-attention's query projection inside the cross-attention kernel
+    (`k_attn_decode<64, 2, true, QP>`: a block is one (row, head) and rebuilds only its row), bit 2 = LayerNorm 3 inside fc1's prologue
+    (`k_gemm_skinny_norm`: every block rebuilds all rows from the producer's split-K slabs and the residual stream); both are the
+    default.  The residual stream alternates between two buffers.  At large-v3's decoder WIDTH (d 1280, 20 heads, ffn 5120; three layers,
+    small vocabulary): every form is within the stated tolerance of the oracle and no further from the separate launches (`=0`) than
+    that (same arithmetic per element; row statistics and the query projection's K sum are float32 sums in another order).  B = 11: rows
+    8 .. 10 are a wave's SECOND row in fc1's prologue; B = 17: two m-tiles - the engine keeps the separate launches (bit 3: fail where a
     requested fold does not apply)."""
     cfg = ow.WhisperConfig(vocab_size=700, num_mel_bins=128, d_model=1280, encoder_layers=1, encoder_attention_heads=20, encoder_ffn_dim=1280,
                            decoder_layers=3, decoder_attention_heads=20, decoder_ffn_dim=5120)
@@ -380,7 +398,9 @@ def test_glue_folded_into_its_consumers_matches_the_separate_launches_and_the_or
     dev.encode(feats)
     T = 5
     toks = np.random.default_rng(18).integers(0, cfg.vocab_size, (B, T))
-    modes = {"separate": "0", "gemm_folds": "15" if B <= 16 else "7", "attention_fold": "28" if B <= 16 else "20", "default": None}
+    strict = B <= 16
+    modes = {"separate": "0", "fc1_fold": "12" if strict else "4", "attention_fold": "24" if strict else "16", "both": "28" if strict else "20",
+             "default": None}
     got = {}
     for name, fold in modes.items():
         if fold is None:
@@ -389,9 +409,9 @@ def test_glue_folded_into_its_consumers_matches_the_separate_launches_and_the_or
             monkeypatch.setenv("MIS_WHISPER_FOLD", fold)
         dev.decoder_reset()
         got[name] = np.stack([dev.decoder_forward(toks[:, t]) for t in range(T)], axis=1)        # [B, T, V]
-    if B > 16:
-        for strict in ("15", "28"):
-            monkeypatch.setenv("MIS_WHISPER_FOLD", strict)
+    if not strict:
+        for m in ("12", "24"):
+            monkeypatch.setenv("MIS_WHISPER_FOLD", m)
             with pytest.raises(mas.AudioGenerationError):
                 dev.decoder_forward(toks[:, 0])
     monkeypatch.delenv("MIS_WHISPER_FOLD", raising=False)
@@ -405,13 +425,13 @@ def test_glue_folded_into_its_consumers_matches_the_separate_launches_and_the_or
             _check(got[name][b], r, 0.022, 0.012)
     from gpu_util import record
     scale = float(np.abs(got["separate"]).max())
-    for name in ("gemm_folds", "attention_fold", "default"):
+    for name in ("fc1_fold", "attention_fold", "both", "default"):
         d_max = float(np.abs(got[name] - got["separate"]).max()) / scale
         d_rms = rms(got[name], got["separate"]) / float(np.sqrt(np.mean(got["separate"].astype(np.float64) ** 2)))
         record(f"whisper_decoder_glue_fold_b{B}_{name}", vs_separate_max_rel=d_max, vs_separate_rms_rel=d_rms, tol_max=0.022, tol_rms=0.012)
-        if B > 16:
+        if not strict:
             assert np.array_equal(got[name], got["separate"])
         else:
             assert d_max <= 0.022 and d_rms <= 0.012, (name, d_max, d_rms)
-    if B <= 16:
-        assert np.array_equal(got["default"], got["attention_fold"])                              # (the default IS bits 2 and 4)
+    if strict:
+        assert np.array_equal(got["default"], got["both"])                                        # (the default IS bits 2 and 4)
