@@ -1308,7 +1308,7 @@ __global__ void __launch_bounds__(512) k_attn_decode(AttnParams p) {
     const int n_tiles = p.append_only ? 0 : (kv_len + 31) >> 5;    // append-only launches request no tiles
     const int new_tile = p.cross ? -1 : (pos >> 5);
     bf16x8_t kA[2][D / 32], kB[2][D / 32], vA[D / 16], vB[D / 16];
-    if constexpr (XS) {                             // (an odd first group leaves B unrequested; the binding statement below names it)
+    if constexpr (XS && QP == 0) {                  // (an odd first group leaves B unrequested; the binding statement below names it)
         const bf16x8_t z = (bf16x8_t){0, 0, 0, 0, 0, 0, 0, 0};
 #pragma unroll
         for (int c = 0; c < D / 32; ++c) { kB[0][c] = z; kB[1][c] = z; }
@@ -1417,6 +1417,13 @@ __global__ void __launch_bounds__(512) k_attn_decode(AttnParams p) {
                 *reinterpret_cast<float4*>(qp_part + wu * 64 + r * 16 + (lane >> 4) * 4) = make_float4(qacc[r][0], qacc[r][1], qacc[r][2], qacc[r][3]);
         }
         __builtin_amdgcn_sched_barrier(0);
+        {                                               // (B's registers are free of the W_q tiles only now)
+            const bf16x8_t zb = (bf16x8_t){0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+            for (int c = 0; c < D / 32; ++c) { kB[0][c] = zb; kB[1][c] = zb; }
+#pragma unroll
+            for (int dt = 0; dt < D / 16; ++dt) vB[dt] = zb;
+        }
         if (xs_nj >= 2 && !xs_odd) load_tile(wu + ATT_WAVES, kB, vB);
     } else if constexpr (XS) {
         if (xs_nj >= 1) load_tile(wu, kA, vA);

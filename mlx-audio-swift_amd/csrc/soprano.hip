@@ -98,6 +98,61 @@ __global__ void __launch_bounds__(SOP_LN_TX * SOP_LN_CG) k_sop_ln_ct(const float
     for (int c = cg; c < C; c += SOP_LN_CG) yb[(size_t)c * T] = (xb[(size_t)c * T] - mean) * rstd * w[c] + bias[c];
 }
 
+// The same LayerNorm with a column's channels spread over 64 threads (16 time steps x 64 channel groups per block, <= 12 channels per thread
+// held in registers: ONE pass over memory instead of three, 17 blocks instead of 9 at 257 frames).  Round 6: the kernel above still took
+// 51 us per call at batch 1 - 96 strided loads per thread, three times - ten calls per decode = 0.5 ms of a 21 ms generate
+// (profiles/r05_final_soprano_engine_kernel_stats.csv).  Partial sums meet in LDS in a fixed order; mean first, then the centred squares.
+#define SOP_LN2_TX 16
+#define SOP_LN2_CG 64
+#define SOP_LN2_PER 12
+__global__ void __launch_bounds__(SOP_LN2_TX * SOP_LN2_CG) k_sop_ln_ct2(const float* __restrict__ x, float* __restrict__ y, const float* __restrict__ w,
+                                                                        const float* __restrict__ bias, int C, int T, float eps) {
+    __shared__ float red[SOP_LN2_CG][SOP_LN2_TX];
+    const int tx = threadIdx.x & (SOP_LN2_TX - 1), cg = threadIdx.x / SOP_LN2_TX;
+    const int t = blockIdx.x * SOP_LN2_TX + tx, b = blockIdx.y;
+    const bool live = t < T;
+    const float* xb = x + (size_t)b * C * T + (live ? t : 0);
+    float v[SOP_LN2_PER], wv[SOP_LN2_PER], bv[SOP_LN2_PER];
+    float s = 0.0f;
+#pragma unroll
+    for (int k = 0; k < SOP_LN2_PER; ++k) {
+        const int c = cg + k * SOP_LN2_CG;
+        const int cc = c < C ? c : C - 1;                 // (clamped: loaded, masked below)
+        v[k] = xb[(size_t)cc * T]; wv[k] = w[cc]; bv[k] = bias[cc];
+    }
+#pragma unroll
+    for (int k = 0; k < SOP_LN2_PER; ++k) s += (cg + k * SOP_LN2_CG < C) ? v[k] : 0.0f;
+    red[cg][tx] = s;
+    __syncthreads();
+    float tot = 0.0f;
+#pragma unroll 8
+    for (int g = 0; g < SOP_LN2_CG; ++g) tot += red[g][tx];
+    const float mean = tot / (float)C;
+    __syncthreads();
+    float q = 0.0f;
+#pragma unroll
+    for (int k = 0; k < SOP_LN2_PER; ++k) { const float d = v[k] - mean; q += (cg + k * SOP_LN2_CG < C) ? d * d : 0.0f; }
+    red[cg][tx] = q;
+    __syncthreads();
+    float qt = 0.0f;
+#pragma unroll 8
+    for (int g = 0; g < SOP_LN2_CG; ++g) qt += red[g][tx];
+    const float rstd = 1.0f / sqrtf(qt / (float)C + eps);
+    if (!live) return;
+    float* yb = y + (size_t)b * C * T + t;
+#pragma unroll
+    for (int k = 0; k < SOP_LN2_PER; ++k) {
+        const int c = cg + k * SOP_LN2_CG;
+        if (c < C) yb[(size_t)c * T] = (v[k] - mean) * rstd * wv[k] + bv[k];
+    }
+}
+static void launch_sop_ln_ct(const float* x, float* y, const float* w, const float* bias, int C, int T, int batch, hipStream_t s) {
+    if (C <= SOP_LN2_CG * SOP_LN2_PER)
+        hipLaunchKernelGGL(k_sop_ln_ct2, dim3(cdiv(T, SOP_LN2_TX), batch), dim3(SOP_LN2_TX * SOP_LN2_CG), 0, s, x, y, w, bias, C, T, 1e-6f);
+    else
+        hipLaunchKernelGGL(k_sop_ln_ct, dim3(cdiv(T, SOP_LN_TX), batch), dim3(SOP_LN_TX * SOP_LN_CG), 0, s, x, y, w, bias, C, T, 1e-6f);
+}
+
 // head output hh [B][n_fft+2][T] -> spec [B][2*bins][T]: rows 0..bins-1 = mag*cos(phase), bins.. = mag*sin(phase),
 // mag = min(exp(.), 100)   (SopranoDecoder.swift:109-122)
 __global__ void k_sop_spec(const float* __restrict__ hh, float* __restrict__ spec, int bins, int T) {
@@ -297,12 +352,12 @@ static void soprano_decode_device(mis_soprano* c, const float* hidden_dev, int64
     GemmParams g{};
     g.AT = W + c->embed_w; g.bias = W + c->embed_b; g.X = xin; g.Y = b; g.M = d; g.K = Kin; g.N = T; g.Tin = T; g.Tout = T;
     launch_gemm(GEMM_PLAIN, false, g, batch, s);
-    hipLaunchKernelGGL(k_sop_ln_ct, dim3(cdiv(T, SOP_LN_TX), batch), dim3(SOP_LN_TX * SOP_LN_CG), 0, s, b, a, W + c->norm_w, W + c->norm_b, d, T, 1e-6f);
+    launch_sop_ln_ct(b, a, W + c->norm_w, W + c->norm_b, d, T, batch, s);
     float* h = a;       // residual stream
     float* o = b;
     for (const auto& blk : c->blocks) {                                // ConvNeXtBlock, VocosBackbone.swift:64-99
         launch_dw7(h, t1, W + blk.dw, W + blk.dwb, batch, d, T, 1, s);
-        hipLaunchKernelGGL(k_sop_ln_ct, dim3(cdiv(T, SOP_LN_TX), batch), dim3(SOP_LN_TX * SOP_LN_CG), 0, s, t1, t2, W + blk.lnw, W + blk.lnb, d, T, 1e-6f);
+        launch_sop_ln_ct(t1, t2, W + blk.lnw, W + blk.lnb, d, T, batch, s);
         g = GemmParams{};
         g.AT = W + blk.p1; g.bias = W + blk.b1; g.X = t2; g.Y = t1; g.M = inter; g.K = d; g.N = T; g.Tin = T; g.Tout = T;
         launch_gemm(GEMM_GELU, false, g, batch, s);
@@ -312,7 +367,7 @@ static void soprano_decode_device(mis_soprano* c, const float* hidden_dev, int64
         launch_gemm(GEMM_RESID, false, g, batch, s);
         std::swap(h, o);
     }
-    hipLaunchKernelGGL(k_sop_ln_ct, dim3(cdiv(T, SOP_LN_TX), batch), dim3(SOP_LN_TX * SOP_LN_CG), 0, s, h, o, W + c->fin_w, W + c->fin_b, d, T, 1e-6f);
+    launch_sop_ln_ct(h, o, W + c->fin_w, W + c->fin_b, d, T, batch, s);
     g = GemmParams{};
     g.AT = W + c->head_w; g.bias = W + c->head_b; g.X = o; g.Y = t1; g.M = nf + 2; g.K = d; g.N = T; g.Tin = T; g.Tout = T;
     launch_gemm(GEMM_PLAIN, false, g, batch, s);

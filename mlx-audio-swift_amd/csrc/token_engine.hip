@@ -64,10 +64,13 @@ struct TeParams {
     const int32_t* prompt;
     int n_prompt, n_total;
     int t_start;                // first position the engine walks (the K/V of the positions before it were imported from the launch chain's prefill)
-    int32_t* next_tokens;       // [n_total]: the id chosen after position t.  HOST-VISIBLE (pinned, coherent) memory, written with one system-scope
-                                // store per position: the host reads the ids WHILE the launch runs (generateStream's .token events, Soprano.swift:877)
-    const int* cancel;          // host-visible word or null: worker 0 reads it once per position, the value travels with edge 5 (every worker
-                                // sees the SAME value at the same position) and a non-zero value ends the request like the stop id does
+    int32_t* tok_dev;           // [n_total] device memory, -1 = not chosen yet: the id chosen after position t (one agent-scope store by worker 0)
+    int32_t* next_tokens;       // [n_total] HOST-VISIBLE (pinned, coherent) copy, filled WHILE the launch runs by the relay block (te_relay): the
+                                // host reads the ids from here for generateStream's .token events (Soprano.swift:877)
+    const int* cancel;          // host-visible word or null, read by the relay block only
+    int* cancel_dev;            // device word the relay forwards it to: worker 0 reads it once per position, the value travels with edge 5
+                                // (every worker sees the SAME value at the same position) and a non-zero value ends the request like the stop id
+    unsigned* relay_done;       // device word: worker 0 has left (everything it chose is in tok_dev)
     float* logits_out;          // [n_total][V] or null
     float* hidden_out;          // [n_total][d] or null (final-norm output: what Soprano's decoder consumes)
     bf16_t* kv;                 // the K/V copy [L][2][TE_CTX][Hkv*D] (every worker writes the same bytes, see te_vector_role)
@@ -508,9 +511,9 @@ __device__ __forceinline__ void te_vector_role(const TeParams& p, const TeLds& L
     int t_last = p.t_start - 1, n_sampled = 0;
     for (int t = p.t_start; t < p.n_total; ++t) {
         if (tid == 0 && t < p.n_prompt) *L.s_tok = p.prompt[t];
-        // (requested here, consumed at edge 5 - a PCIe round trip under 17 layers of work)
+        // (requested here, consumed at edge 5; the relay block keeps the device word equal to the host's)
         uint32_t cancel_word = 0u;
-        if (p.cancel && w == 0 && tid == 0) cancel_word = (uint32_t)__hip_atomic_load(p.cancel, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        if (p.cancel && w == 0 && tid == 0) cancel_word = (uint32_t)__hip_atomic_load(p.cancel_dev, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         te_sync();                                                   // token id
         if (*L.s_done) break;
         t_last = t;
@@ -575,7 +578,7 @@ __device__ __forceinline__ void te_vector_role(const TeParams& p, const TeLds& L
                 TE_STAMP(3);
             }
             te_sync();                                               // edge 1: q|k|v gathered
-            if (!*L.s_ok) { if (tid == 0) *p.fail = 1u; return; }
+            if (!*L.s_ok) { if (tid == 0) __hip_atomic_store(p.fail, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); return; }
             TE_STAMP(4);
             // ================= q/k-norm, RoPE, attention (redundant on every worker)
             bf16_t* kc = kv_mine + ((size_t)li * 2 + 0) * TE_CTX * S::D;
@@ -726,7 +729,7 @@ __device__ __forceinline__ void te_vector_role(const TeParams& p, const TeLds& L
                 TE_STAMP(10);
             }
             te_sync();                                               // edge 2: residual stream gathered
-            if (!*L.s_ok) { if (tid == 0) *p.fail = 1u; return; }
+            if (!*L.s_ok) { if (tid == 0) __hip_atomic_store(p.fail, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); return; }
             TE_STAMP(11);
             // ================= gate|up pairs -> SwiGLU -> edge 3
             te_sync();                                               // red ready
@@ -752,7 +755,7 @@ __device__ __forceinline__ void te_vector_role(const TeParams& p, const TeLds& L
                 TE_STAMP(14);
             }
             te_sync();                                               // edge 3: activation gathered
-            if (!*L.s_ok) { if (tid == 0) *p.fail = 1u; return; }
+            if (!*L.s_ok) { if (tid == 0) __hip_atomic_store(p.fail, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); return; }
             TE_STAMP(15);
             // ================= down_proj slice, residual -> edge 4
             te_sync();                                               // red ready
@@ -766,7 +769,7 @@ __device__ __forceinline__ void te_vector_role(const TeParams& p, const TeLds& L
                 TE_STAMP(18);
             }
             te_sync();                                               // edge 4: residual stream gathered
-            if (!*L.s_ok) { if (tid == 0) *p.fail = 1u; return; }
+            if (!*L.s_ok) { if (tid == 0) __hip_atomic_store(p.fail, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); return; }
             TE_STAMP(19);
         }
         // ================= final norm (hidden tap) -> output projection slice -> token -> edges 5 (.. 7)
@@ -844,7 +847,7 @@ __device__ __forceinline__ void te_vector_role(const TeParams& p, const TeLds& L
                 if (lane == 0) L.s_cand[TE_VW + wave] = c2;
             }
             te_sync();                                               // edge 5 gathered
-            if (!*L.s_ok) { if (tid == 0) *p.fail = 1u; return; }
+            if (!*L.s_ok) { if (tid == 0) __hip_atomic_store(p.fail, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); return; }
 #pragma unroll
             for (int q = 0; q < TE_VW; ++q) best_all = (uint32_t)L.s_cand[TE_VW + q] > best_all ? (uint32_t)L.s_cand[TE_VW + q] : best_all;
             int next;
@@ -875,7 +878,7 @@ __device__ __forceinline__ void te_vector_role(const TeParams& p, const TeLds& L
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 if (lane == 0) L.s_cand[TE_VW + wave] = c2;
                 te_sync();                                           // edge 6: the id
-                if (!*L.s_ok) { if (tid == 0) *p.fail = 1u; return; }
+                if (!*L.s_ok) { if (tid == 0) __hip_atomic_store(p.fail, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); return; }
                 uint32_t b2 = 0;
 #pragma unroll
                 for (int q = 0; q < TE_VW; ++q) b2 = (uint32_t)L.s_cand[TE_VW + q] > b2 ? (uint32_t)L.s_cand[TE_VW + q] : b2;
@@ -912,7 +915,7 @@ __device__ __forceinline__ void te_vector_role(const TeParams& p, const TeLds& L
                 }
                 granules(buf, 2 * NTV, tag, std::integral_constant<int, TE_XG / VT>{}, [&](int gi, uint32_t g2) { L.tsum32[gi] = g2; });
                 te_sync();                                           // edge 6: tile masses gathered
-                if (!*L.s_ok) { if (tid == 0) *p.fail = 1u; return; }
+                if (!*L.s_ok) { if (tid == 0) __hip_atomic_store(p.fail, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); return; }
                 // scan over the tiles: thread -> tiles 2 tid, 2 tid + 1
                 const int t0i = 2 * tid, t1i = 2 * tid + 1;
                 const u64 m0 = t0i < NTV ? ((u64)L.tsum32[2 * t0i] | ((u64)L.tsum32[2 * t0i + 1] << 32)) : 0;
@@ -951,13 +954,13 @@ __device__ __forceinline__ void te_vector_role(const TeParams& p, const TeLds& L
                 }
                 if (tid == 0) L.s_cand[0] = granule(bufc, 0, tagc);
                 te_sync();                                           // edge 7: the token
-                if (!*L.s_ok) { if (tid == 0) *p.fail = 1u; return; }
+                if (!*L.s_ok) { if (tid == 0) __hip_atomic_store(p.fail, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); return; }
                 next = (int)(uint32_t)L.s_cand[0];
             }
             n_sampled += 1;
             if (tid == 0) {
                 if (t + 1 >= p.n_prompt) *L.s_tok = next;
-                if (w == 0) __hip_atomic_store(p.next_tokens + t, next, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                if (w == 0) __hip_atomic_store(p.tok_dev + t, next, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // (the relay block takes it to the host)
                 if (p.sample && p.win_cap > 0) {                     // the window slides over the generated ids (both sampling forms)
                     int wl = L.win[64];
                     if (wl < p.win_cap) { L.win[wl] = next; L.win[64] = wl + 1; }
@@ -967,7 +970,38 @@ __device__ __forceinline__ void te_vector_role(const TeParams& p, const TeLds& L
             }
         }
     }
-    if (w == 0 && tid == 0 && p.n_done) { p.n_done[0] = t_last + 1; p.n_done[1] = n_sampled; }
+    if (w == 0 && tid == 0) {
+        if (p.n_done) { p.n_done[0] = t_last + 1; p.n_done[1] = n_sampled; }
+        __threadfence();                                             // every id above is visible before the relay is told that there are no more
+        __hip_atomic_store(p.relay_done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+
+// The relay: ONE wave on a compute unit no worker uses (block 256 + xcds, i.e. on XCD `xcds`: the blocks with index mod 8 >= xcds have left).  It polls the
+// ids worker 0 publishes in device memory and copies them into the host-visible row, and polls the host's cancel word and forwards it
+// into device memory - so that no worker ever issues an access that crosses PCIe.  (Round 6, first forms: the id stored to host memory
+// by the thread that chose it - a system-scope store retires after a PCIe round trip and vmcnt retires in order, so that wave's next
+// loads, and with them every worker's first edge of the position, waited for it; then by a matrix wave behind its tile requests - 512
+// extra system-scope stores per position: 17.17 -> 17.56 -> 17.88 ms per request, profiles/r06/c7, c8.)  With 8 XCDs every compute unit
+// holds a worker and the relay only runs once they have left: the ids then arrive together at the end - still correct, not streamed.
+__device__ __forceinline__ void te_relay(const TeParams& p) {
+    if (threadIdx.x != 0) return;
+    int k = p.head_from;
+    for (long it = 0; it < (1L << 26); ++it) {                       // (bounded: ~1 us per round)
+        if (p.cancel && __hip_atomic_load(p.cancel, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0)
+            __hip_atomic_store(p.cancel_dev, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        // (read BEFORE the ids are drained: what worker 0 chose before it raised the flag is then certainly seen below)
+        const unsigned fin = __hip_atomic_load(p.relay_done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) |
+                             __hip_atomic_load(p.fail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        while (k < p.head_until) {
+            const int v = __hip_atomic_load(p.tok_dev + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (v < 0) break;
+            __hip_atomic_store(p.next_tokens + k, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            ++k;
+        }
+        if (fin) break;
+        __builtin_amdgcn_s_sleep(32);
+    }
 }
 
 template <int XCDS>
@@ -997,6 +1031,7 @@ __global__ void __launch_bounds__(TE_NT) k_token_engine(TeParams p) {
     __shared__ u64 s_wtot[TE_VW + 2];
     if (p.n_total < 0) te_lds_pad[threadIdx.x] = 0;
     const int b = blockIdx.x;
+    if (b >= 256) { if (b == 256 + XCDS) te_relay(p); return; }     // (block 256 + xcds lands on XCD `xcds`, whose compute units the workers do not use)
     if ((b & 7) >= XCDS) return;
     const int w = (b >> 3) * XCDS + (b & 7);
     const int tid = threadIdx.x, wave = tid >> 6;
@@ -1032,7 +1067,7 @@ __global__ void k_te_import_kv(const bf16_t* __restrict__ kc_all, const bf16_t* 
 // Buffers a handle keeps between requests (every request allocated and cleared a ~9 MB K/V copy).  The token row and the
 // cancel word are pinned, coherent host memory: the launch writes / reads them with system-scope accesses while the host polls.
 struct TokenEngineScratch {
-    DevBuf<int32_t> prompt, done;
+    DevBuf<int32_t> prompt, done, tokd;
     DevBuf<bf16_t> kv;
     DevBuf<u64> x;
     DevBuf<unsigned> sync;
@@ -1091,7 +1126,8 @@ void token_engine_run(mis_tts* lm, const TokenEngineRequest& rq, TokenEngineResu
     MIS_REQUIRE(v.Vpad / 16 <= TE_HP * 8 * 32 * xcds, MIS_ERR_INVALID_INPUT, "vocabulary too large for the engine's output-projection passes");
     MIS_REQUIRE(rq.generate || (!rq.on_token && !rq.cancel), MIS_ERR_INVALID_INPUT, "token callback / cancel flag: generate form only");
     HIP_CHECK(hipSetDevice(v.device));
-    const int grid = 256;
+    const int grid = 256 + xcds + 1;                                     // 256 worker slots + the relay block (te_relay) as the last one: blocks go to
+                                                                         // XCD (index mod 8), and XCD `xcds` is the first the workers leave free
     const float* rc = nullptr; const float* rs = nullptr;
     hipStream_t s = v.stream;
     out.n_announced = 0;
@@ -1115,7 +1151,7 @@ void token_engine_run(mis_tts* lm, const TokenEngineRequest& rq, TokenEngineResu
     TokenEngineScratch local;
     TokenEngineScratch& sc = rq.scratch ? *rq.scratch : local;
     DevBuf<float> d_logits, d_hidden;
-    sc.prompt.alloc(TE_CTX); sc.done.alloc(2); sc.x.alloc(2 * TE_XG); sc.sync.alloc(64);
+    sc.prompt.alloc(TE_CTX); sc.done.alloc(2); sc.tokd.alloc(TE_CTX); sc.x.alloc(2 * TE_XG); sc.sync.alloc(64);
     if (!sc.tokens_host)
         HIP_CHECK(hipHostMalloc((void**)&sc.tokens_host, (TE_CTX + 1) * sizeof(int32_t), hipHostMallocMapped | hipHostMallocCoherent));
     const size_t kv_pos = (size_t)S::Hkv * S::D;
@@ -1136,6 +1172,7 @@ void token_engine_run(mis_tts* lm, const TokenEngineRequest& rq, TokenEngineResu
     HIP_CHECK(hipMemsetAsync(sc.sync.p, 0, 64 * sizeof(unsigned), s));
     HIP_CHECK(hipMemsetAsync(sc.x.p, 0, 2 * TE_XG * sizeof(u64), s));
     HIP_CHECK(hipMemsetAsync(sc.done.p, 0, 8, s));
+    HIP_CHECK(hipMemsetAsync(sc.tokd.p, 0xFF, (size_t)TE_CTX * 4, s));                 // -1: not chosen yet
     if (t_start > 0)
         hipLaunchKernelGGL(k_te_import_kv, dim3((unsigned)((t_start * S::D + 255) / 256), (unsigned)v.L), dim3(256), 0, s, kvv.kcache, kvv.vtcache,
                            kvv.layer_stride, sc.kv.p, t_start);
@@ -1143,6 +1180,7 @@ void token_engine_run(mis_tts* lm, const TokenEngineRequest& rq, TokenEngineResu
     p.emb = v.emb; p.wqkv = v.wqkv; p.wo = v.wo; p.wgu = v.wgu; p.wdown = v.wdown; p.head = v.head; p.norms = v.norms; p.qknorm = v.qknorm;
     p.rope_cos = rc; p.rope_sin = rs; p.L = v.L; p.V = v.V; p.Vpad = v.Vpad; p.eps = v.eps;
     p.prompt = sc.prompt.p; p.n_prompt = rq.n_prompt; p.n_total = n_total; p.t_start = t_start; p.next_tokens = sc.tokens_host;
+    p.tok_dev = sc.tokd.p; p.cancel_dev = reinterpret_cast<int*>(sc.sync.p + 40); p.relay_done = sc.sync.p + 41;
     p.cancel = rq.cancel ? sc.tokens_host + TE_CTX : nullptr;
     p.logits_out = rq.want_logits ? d_logits.p : nullptr; p.hidden_out = hidden_dev;
     p.kv = sc.kv.p; p.xbuf = sc.x.p; p.fail = sc.sync.p + 32; p.xcds = xcds;
@@ -1206,7 +1244,11 @@ void token_engine_run(mis_tts* lm, const TokenEngineRequest& rq, TokenEngineResu
     HIP_CHECK(hipMemcpy(done, sc.done.p, 8, hipMemcpyDeviceToHost));
     out.n_positions = done[0]; out.n_sampled = done[1]; out.ms = ms; out.head_from = head_from;
     out.next_tokens.assign(n_total, 0);
-    for (int t = 0; t < n_total; ++t) out.next_tokens[t] = tok_host[t] < 0 ? 0 : tok_host[t];
+    HIP_CHECK(hipMemcpy(out.next_tokens.data(), sc.tokd.p, (size_t)n_total * 4, hipMemcpyDeviceToHost));
+    for (int t = 0; t < n_total; ++t) {
+        MIS_REQUIRE(out.next_tokens[t] == tok_host[t], MIS_ERR_GENERATION_FAILED, "token engine: the host-visible id row differs from the device's at position %d", t);
+        if (out.next_tokens[t] < 0) out.next_tokens[t] = 0;
+    }
     if (rq.want_logits) {
         out.logits.assign((size_t)std::max(head_until - head_from, 1) * v.V, 0.f);
         HIP_CHECK(hipMemcpy(out.logits.data(), d_logits.p, out.logits.size() * 4, hipMemcpyDeviceToHost));

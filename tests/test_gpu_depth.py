@@ -44,8 +44,11 @@ def test_orpheus_3b_full_depth_28_layers_and_error_growth(depths):
     set holds the device to the same floor gate at 2 and 8 layers, the growth ~ sqrt(layers) is on file from the full runs)"""
     full = ollama.LlamaConfig()                                     # ORPHEUS_3B: 28 layers
     assert full.num_hidden_layers == 28
-    W = ollama.make_synthetic_weights(full, seed=4321)              # layer keys do not depend on the layer count
-    o32 = ollama.LlamaOracle(full, W, round="bf16")
+    # (layer keys do not depend on the layer count: the weights of the deepest variant of this run serve the shallower ones - the
+    # 2- and 8-layer run does not build 28 layers of a 3B model on the CPU first)
+    deepest = dataclasses.replace(full, num_hidden_layers=max(depths))
+    W = ollama.make_synthetic_weights(deepest, seed=4321)
+    o32 = ollama.LlamaOracle(deepest, W, round="bf16")
     del W
     gc.collect()
     o64 = _F64Oracle.__new__(_F64Oracle)

@@ -93,26 +93,37 @@ def test_whisper_256_tile_gemm_and_quantised_r4_gemm_do_not_spill():
 
 
 def test_whisper_cross_attention_keeps_two_pairs_of_key_tiles_in_flight():
+    """k_attn_decode<64, 2, true, QP>: the plain cross-attention schedule (QP = 0) and the one with LayerNorm 2 + the query projection in
+    its prologue (QP = 4 / 8 slabs per trip, round 6) - no scratch, and on every tile-count path two pairs of K/V tiles in flight."""
     text, use = _compiled("lm_kernels.hip")
-    name = [k for k in use if re.search(r"k_attn_decodeILi64ELi2ELb1E", k)]
-    assert len(name) == 1, name
-    assert use[name[0]]["scratch"] == 0 and use[name[0]]["vgprs"] <= 256, use[name[0]]
-    i = text.index("\n" + name[0] + ":")
-    body = text[i: text.index(".Lfunc_end", i)]
-    ins = [l.strip() for l in body.split("\n") if re.match(r"^\s+[a-z_0-9]+\b", l)]
-    # K/V requests (non-temporal 16-byte loads) since the previous vmcnt wait, at every vmcnt wait (address arithmetic sits between the loads)
-    waits, n = [], 0
-    for l in ins:
-        if l.startswith("global_load_dwordx4") and l.endswith(" nt"):
-            n += 1
-        elif l.startswith("s_waitcnt") and "vmcnt" in l:
-            waits.append((n, int(re.search(r"vmcnt\((\d+)\)", l).group(1))))
-            n = 0
-    assert sum(k for k, _ in waits) + n == 16 + 4 * 16, waits            # the first group up front (8 + 8), two pairs on either tile-count path
-    # a wait that follows a full pair of requests (sixteen loads or more since the last wait) must leave that pair outstanding: the pair is
-    # requested BEFORE the wait for the group in front of it - twice on the six-tile path, twice on the five-tile path
-    behind_pair = [w for k, w in waits if k >= 16]
-    assert len(behind_pair) == 4 and all(w >= 16 for w in behind_pair), waits
+    names = sorted(k for k in use if re.search(r"k_attn_decodeILi64ELi2ELb1ELi[048]E", k))
+    assert len(names) == 3, names
+    for name in names:
+        i = text.index("\n" + name + ":")
+        body = text[i: text.index(".Lfunc_end", i)]
+        ins = [l.strip() for l in body.split("\n") if re.match(r"^\s+[a-z_0-9]+\b", l)]
+        # no vector register spilled and no scratch instruction anywhere; the projection variants park four SCALAR registers (their seven
+        # extra pointers) in vector lanes - a 20-byte frame on paper, no memory traffic
+        assert use[name]["vgprs"] <= 256 and not any("scratch_" in l for l in ins), (name, use[name])
+        assert use[name]["scratch"] == 0 or (not name.endswith("Li0EEv10AttnParams") and use[name]["scratch"] <= 32), (name, use[name])
+        # K/V requests (non-temporal 16-byte loads) since the previous vmcnt wait, at every vmcnt wait (address arithmetic sits between the loads)
+        waits, n = [], 0
+        for l in ins:
+            if l.startswith("global_load_dwordx4") and l.endswith(" nt"):
+                n += 1
+            elif l.startswith("s_waitcnt") and "vmcnt" in l:
+                waits.append((n, int(re.search(r"vmcnt\((\d+)\)", l).group(1))))
+                n = 0
+        assert sum(k for k, _ in waits) + n == 16 + 4 * 16, (name, waits)    # the first group up front (8 + 8), two pairs on either tile-count path
+        # a wait that follows a full pair of requests (sixteen loads or more since the last wait) must leave that pair outstanding: the pair is
+        # requested BEFORE the wait for the group in front of it - twice on the six-tile path, twice on the five-tile path
+        behind_pair = [w for k, w in waits if k >= 16]
+        assert len(behind_pair) == 4 and all(w >= 16 for w in behind_pair), (name, waits)
+        if not name.endswith("Li0EEv10AttnParams"):
+            # the projection prologue: its waits in front of the first MFMA count loads (the first K/V tile stays in flight behind them)
+            first_mfma = next(j for j, l in enumerate(ins) if l.startswith("v_mfma"))
+            pro = [int(re.search(r"vmcnt\((\d+)\)", l).group(1)) for l in ins[:first_mfma] if l.startswith("s_waitcnt") and "vmcnt" in l]
+            assert pro and min(pro) >= 8, (name, pro)
 
 
 def test_token_engine_keeps_its_tile_buffers_in_registers():
