@@ -498,7 +498,9 @@ extern "C" mis_status mis_whisper_encode(mis_whisper* c, const float* features, 
 // The residual stream alternates between two buffers: every block of a consumer still reads the old one while one of them writes the new.
 // Measured and not kept (profiles/r06/c3, c5): the same GEMM-side fold for q|k|v and the cross query (every one of 120-480 blocks re-reads all
 // rows' slabs: neutral to +1 %), LayerNorm 1 + q|k|v inside the SELF-attention kernel (480 KB of weights per block in three trips: the
-// kernel 5.0 -> 15.6 us against 9.6 saved; the variant is on file as c5_self_attention_qkv_fold_measured_variant.patch).
+// kernel 5.0 -> 15.6 us against 9.6 saved; the variant is on file as c5_self_attention_qkv_fold_measured_variant.patch), and the ONE-SLAB
+// arrangement (profiles/r06/c9: every producer GEMM as eight-wave items over the whole K range writing one float32 slab, so that LayerNorm 1
+// could move into q|k|v's prologue as well - 7 launches per layer, parity green, transcribe 214 -> 224 ms: fc2 at 80 blocks 5.2 -> 8.5 us).
 #define WHISPER_FOLD_DEFAULT 20
 static void enqueue_decoder_step(mis_whisper* c) {
     hipStream_t s = c->stream;
