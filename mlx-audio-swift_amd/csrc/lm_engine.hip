@@ -705,9 +705,92 @@ static bool prefill_batched_ok(const mis_tts* c, int Lmax) {
     const bool coded = c->q_qkv.on && c->q_o.on && c->q_gu.on && c->q_down.on;
     return !off && Lmax >= 2 && (dense || coded) && c->d % 64 == 0 && HD % 64 == 0 && c->ff % 64 == 0 && c->d >= 128 && HD >= 128 && c->ff >= 128;
 }
+// ---- short prompts (positions x rows <= 64, dense weights): the DECODE STEP's kernels with (position, sequence) pairs as their rows.
+// k_gemm_pf works on 128 x 128 tiles: at 23 positions of one row its o_proj / down_proj grids are 4 blocks (21 us per launch on 256 CUs,
+// profiles/r05_final_soprano_engine_kernel_stats.csv: 1.4 ms to prefill 23 positions of Soprano-80M - 7 % of a batch-1 generate).  The
+// weight-streaming GEMMs of the decode step take up to 64 rows, their glue does residual + RMSNorm and writes the packed operand, and the
+// attention kernel already has the pair arrangement (append-only launch, then every pair as a row; first schedule, like the chunked pass).
+// Same rounding points as both other prefill forms; float32 summation orders are the decode step's.  MIS_PREFILL_SMALL=0 keeps k_gemm_pf.
+__global__ void k_pf_repack_rows(const bf16_t* __restrict__ src, int MT_src, int row0, bf16_t* __restrict__ dst, int MT_dst, int d) {
+    const int m = blockIdx.x;
+    for (int k = threadIdx.x; k < d; k += blockDim.x) dst[xpk_index(m, k, MT_dst)] = src[xpk_index(row0 + m, k, MT_src)];
+}
+// WHO takes it: only the batch-1 token engine's prompt (tts_internal_prefill_kv).  The generic prefill keeps ONE arithmetic whatever the
+// batch - a row computed in a 32-row batch equals the same row computed alone or in a shard (tests/test_gpu_generate.py, the group
+// tests) - and this form sums its split-K slabs in another order than k_gemm_pf.  MIS_PREFILL_SMALL=1 forces it for every short prompt
+// (parity tests), =0 turns it off.
+static bool prefill_small_ok(const mis_tts* c, int Lmax, bool engine_prompt) {
+    const char* e = getenv("MIS_PREFILL_SMALL");
+    const bool dense = !c->q_qkv.on && !c->q_o.on && !c->q_gu.on && !c->q_down.on;
+    const bool want = e ? atoi(e) != 0 : engine_prompt;
+    return want && dense && Lmax >= 2 && Lmax * c->batch <= 64;
+}
+static void prefill_small(mis_tts* c, const int32_t* prompt_mat_dev, const int32_t* lens_dev, const std::vector<int32_t>& lens, int Lmax,
+                          const bf16_t* embed_rows) {
+    hipStream_t s = c->stream;
+    const int d = c->d, HD = c->H * c->D, Mpad = c->Mpad, batch = c->batch;
+    const float eps = c->cfg.rms_norm_eps;
+    const int Mr = Lmax * batch, Mp = (int)round_up((size_t)Mr, 16);
+    const size_t Mc = (size_t)Mp + Mpad;                                      // (the last position is repacked Mpad rows wide)
+    const int S_qkv = std::min(8, gemm_choose_split(c->Nqkv / 16 / 2, d / 32, 4, 8)), S_o = gemm_choose_split(d / 16 / 2, HD / 32, 4, 8),
+              S_down = gemm_choose_split(d / 16 / 2, c->ff / 32, 4, 8);
+    c->pf_h.alloc(Mc * d); c->pf_x.alloc(Mc * d); c->pf_xpk.alloc(Mc * d); c->pf_attn.alloc(Mc * HD); c->pf_actpk.alloc(Mc * c->ff);
+    c->pf_qkv.alloc((size_t)S_qkv * Mp * c->Nqkv); c->pf_tmp.alloc((size_t)std::max(S_o, S_down) * Mp * d);
+    c->pf_pos.alloc(Mc); c->pf_on.alloc(Mc);
+    HIP_CHECK(hipMemsetAsync(c->pf_attn.p, 0, Mc * HD * 2, s));              // rows of padded positions are never written by the attention
+    HIP_CHECK(hipMemsetAsync(c->pf_x.p, 0, Mc * d * 2, s));
+    HIP_CHECK(hipMemsetAsync(c->pf_h.p, 0, Mc * d * 2, s));
+    HIP_CHECK(hipMemsetAsync(c->pf_xpk.p, 0, Mc * d * 2, s));
+    HIP_CHECK(hipMemsetAsync(c->pf_pos.p, 0, Mc * 4, s));
+    HIP_CHECK(hipMemsetAsync(c->pf_on.p, 0, Mc, s));
+    if (embed_rows) launch_pf_rows_rmsnorm(embed_rows, Mpad, lens_dev, Lmax, 0, Lmax, batch, batch, c->norms.p, c->pf_h.p, c->pf_x.p, c->pf_pos.p, c->pf_on.p, d, eps, s);
+    else launch_pf_embed_rmsnorm(c->emb.p, prompt_mat_dev, lens_dev, Lmax, 0, Lmax, batch, batch, c->V, c->norms.p, c->pf_h.p, c->pf_x.p, c->pf_pos.p,
+                                 c->pf_on.p, d, eps, s);
+    launch_pf_pack_rows(c->pf_x.p, c->pf_xpk.p, Mp, d, s);
+    const size_t lkv = (size_t)batch * c->Hkv * c->Smax * c->D;
+    for (int li = 0; li < c->L; ++li) {
+        launch_gemm_skinny(EPI_PARTIAL, 2, 4, c->wqkv.p + layer_qkv_elems(c) * li, c->pf_xpk.p, c->pf_qkv.p, c->Nqkv / 16, d / 32, S_qkv, c->Nqkv, Mp, s);
+        AttnParams ap{};
+        ap.qkv_part = c->pf_qkv.p; ap.S = S_qkv; ap.Mpad = Mp; ap.Nqkv = c->Nqkv;
+        ap.kcache = c->kcache.p + lkv * li; ap.vtcache = c->vtcache.p + lkv * li;
+        ap.pos = c->pf_pos.p; ap.active = c->pf_on.p;
+        ap.rope_cos = c->rope_cos.p; ap.rope_sin = c->rope_sin.p;
+        ap.out = c->pf_attn.p; ap.out_ld = 0;                               // packed: the o_proj launch below is the decode step's
+        ap.H = c->H; ap.Hkv = c->Hkv; ap.D = c->D; ap.Smax = c->Smax; ap.scale = 1.0f / sqrtf((float)c->D);
+        if (c->cfg.qk_norm) {
+            ap.qnorm_w = c->qknorm.p + (size_t)(2 * li) * c->D;
+            ap.knorm_w = c->qknorm.p + (size_t)(2 * li + 1) * c->D;
+            ap.qk_eps = c->cfg.rms_norm_eps;
+        }
+        ap.rope_in_dtype = c->cfg.rope_ops_in_dtype;
+        ap.first_schedule = 1;
+        ap.cache_rows = batch;
+        ap.append_only = 1;
+        launch_attn_decode(ap, Mr, s);
+        ap.append_only = 0;
+        launch_attn_decode(ap, Mr, s);
+        launch_gemm_skinny(EPI_PARTIAL, 2, 4, c->wo.p + layer_o_elems(c) * li, c->pf_attn.p, c->pf_tmp.p, d / 16, HD / 32, S_o, d, Mp, s);
+        launch_reduce_residual_rmsnorm(c->pf_tmp.p, S_o, Mp, d, c->pf_h.p, c->norms.p + (size_t)(2 * li + 1) * d, c->pf_xpk.p, eps, s);
+        launch_gemm_skinny(EPI_SILU_MUL, 2, 4, c->wgu.p + layer_gu_elems(c) * li, c->pf_xpk.p, c->pf_actpk.p, 2 * c->ff / 16, d / 32, 1, c->ff, Mp, s);
+        launch_gemm_skinny(EPI_PARTIAL, 2, 4, c->wdown.p + layer_down_elems(c) * li, c->pf_actpk.p, c->pf_tmp.p, d / 16, c->ff / 32, S_down, d, Mp, s);
+        const bf16_t* next_norm = c->norms.p + (size_t)(li + 1 < c->L ? 2 * (li + 1) : 2 * c->L) * d;
+        launch_reduce_residual_rmsnorm(c->pf_tmp.p, S_down, Mp, d, c->pf_h.p, next_norm, c->pf_xpk.p, eps, s);
+    }
+    // left-padded prompts: every row's last token is position Lmax - 1; rows batch .. Mpad - 1 of the packed x belong to no sequence (zeros)
+    c->x.zero(s);
+    hipLaunchKernelGGL(k_pf_repack_rows, dim3(batch), dim3(256), 0, s, c->pf_xpk.p, Mp / 16, (Lmax - 1) * batch, c->x.p, Mpad / 16, d);
+    std::vector<int32_t> pn(Mpad, 0), pc(Mpad, 0);
+    for (int b = 0; b < batch; ++b) { pn[b] = lens[b]; pc[b] = lens[b] - 1; }
+    HIP_CHECK(hipMemcpyAsync(c->pos_next.p, pn.data(), (size_t)Mpad * 4, hipMemcpyHostToDevice, s));
+    HIP_CHECK(hipMemcpyAsync(c->pos_cur.p, pc.data(), (size_t)Mpad * 4, hipMemcpyHostToDevice, s));
+    HIP_CHECK(hipGetLastError());
+    HIP_CHECK(hipStreamSynchronize(s));                                      // pn / pc are host stack memory
+}
+
 // embed_rows != null: the [Lmax][Mpad][d] input embeddings of a composite engine replace the gather from the model's own table
 static void prefill_batched(mis_tts* c, const int32_t* prompt_mat_dev, const int32_t* lens_dev, const std::vector<int32_t>& lens, int Lmax,
-                            const bf16_t* embed_rows = nullptr) {
+                            const bf16_t* embed_rows = nullptr, bool engine_prompt = false) {
+    if (prefill_small_ok(c, Lmax, engine_prompt)) { prefill_small(c, prompt_mat_dev, lens_dev, lens, Lmax, embed_rows); return; }
     hipStream_t s = c->stream;
     const int d = c->d, HD = c->H * c->D, Mpad = c->Mpad, batch = c->batch;
     const float eps = c->cfg.rms_norm_eps;
@@ -1887,7 +1970,7 @@ TtsKvView tts_internal_prefill_kv(mis_tts* c, const int32_t* prompt_host, int n,
     HIP_CHECK(hipMemcpyAsync(c->prompt_lens.p, lens.data(), 4, hipMemcpyHostToDevice, s));
     c->step_counter.zero(s);
     HIP_CHECK(hipStreamSynchronize(s));
-    if (prefill_batched_ok(c, n)) prefill_batched(c, c->prompt_mat.p, c->prompt_lens.p, lens, n);
+    if (prefill_batched_ok(c, n)) prefill_batched(c, c->prompt_mat.p, c->prompt_lens.p, lens, n, nullptr, true);       // (short prompts: prefill_small)
     else
         for (int j = 0; j < n; ++j) {
             launch_prefill_feed(c->prompt_mat.p, c->prompt_lens.p, n, c->step_counter.p, c->ids.p, c->active.p, 1, s);

@@ -195,6 +195,50 @@ def test_batched_prefill_matches_oracle_and_the_position_by_position_path(ocfg, 
            rms_vs_sequential_worst=worst[2], rms_vs_sequential_mean=float(np.mean(d_all)), rms_pairs_vs_per_position_worst=float(np.max(l_all)), tol_max=TOL_MAX, tol_rms_mean=0.008, tol_rms_worst=0.016)
 
 
+@pytest.mark.parametrize("lens", [[23], [9, 4, 13], [2, 2], [16, 1, 7, 16]], ids=["1x23", "3_ragged", "2x2", "4x16_full"])
+def test_short_prompt_prefill_on_the_decode_step_kernels(lens, monkeypatch):
+    """Round 6: prompts of at most 64 (position, row) pairs run on the DECODE STEP's kernels with the pairs as rows (`prefill_small`,
+    lm_engine.hip: weight-streaming GEMMs, their glue, the attention kernel's pair arrangement) instead of the 128 x 128-tile GEMMs of the
+    chunked pass, whose grids are 4 blocks at that size - for the batch-1 token engine's prompt only (`MIS_PREFILL_SMALL=1` forces it here;
+    the generic prefill keeps one arithmetic whatever the batch).  Against the oracle (next-token logits, then a decode step behind the prompt:
+    the caches), the chunked pass (`MIS_PREFILL_SMALL=0`) and the position-by-position path; q/k-norm + plain-RoPE variant included
+    (Soprano's LM is the case this was written for: 23 prompt positions at batch 1)."""
+    from gpu_util import logits_errors, record
+    for name, cfg in (("llama", ollama.LlamaConfig(**{**ollama.TINY.__dict__, "num_hidden_layers": 2})),
+                      ("qwen3_qknorm", ollama.LlamaConfig(**{**ollama.TINY_QWEN3.__dict__, "num_hidden_layers": 2}))):
+        W, oracle, dev = lm_pair(cfg, seed=53)
+        rng = np.random.default_rng(len(lens))
+        rows = [rng.integers(0, cfg.vocab_size, n).astype(np.int32) for n in lens]
+        nxt = rng.integers(0, cfg.vocab_size, len(rows)).astype(np.int32)
+        got = {}
+        for mode, env in (("small", {"MIS_PREFILL_SEQ": "0", "MIS_PREFILL_SMALL": "1"}), ("chunked", {"MIS_PREFILL_SEQ": "0", "MIS_PREFILL_SMALL": "0"}),
+                          ("sequential", {"MIS_PREFILL_SEQ": "1"})):
+            for k in ("MIS_PREFILL_SEQ", "MIS_PREFILL_SMALL"):
+                monkeypatch.delenv(k, raising=False)
+            for k, v in env.items():
+                monkeypatch.setenv(k, v)
+            a, hid = dev.lm_prefill(rows, max_context=64, want_hidden=True)
+            got[mode] = (a, dev.lm_forward(nxt), hid)
+        for k in ("MIS_PREFILL_SEQ", "MIS_PREFILL_SMALL"):
+            monkeypatch.delenv(k, raising=False)
+        oracle.reset(len(rows))
+        ref_all = oracle.forward([np.concatenate([r, nxt[i:i + 1]]) for i, r in enumerate(rows)], logit_positions=[[len(r) - 1, len(r)] for r in rows])
+        worst = {"small": 0.0, "chunked": 0.0, "sequential": 0.0}
+        for b in range(len(rows)):
+            ref = ref_all[b].numpy()
+            for mode in worst:
+                for dv, rf in ((got[mode][0][b], ref[0]), (got[mode][1][b], ref[1])):
+                    e_max, e_rms, _, agree = logits_errors(dv[None], rf[None])
+                    assert e_max <= TOL_MAX and agree and e_rms <= 0.016, (name, mode, b, e_max, e_rms)
+                    worst[mode] = max(worst[mode], e_rms)
+        d_small_chunked = max(float(np.sqrt(np.mean((a - b) ** 2)) / np.sqrt(np.mean(b ** 2))) for a, b in zip(list(got["small"][0]) + list(got["small"][1]),
+                                                                                                                    list(got["chunked"][0]) + list(got["chunked"][1])))
+        assert d_small_chunked <= 0.016, d_small_chunked
+        assert np.abs(got["small"][2] - got["sequential"][2]).max() <= 0.02 * np.abs(got["sequential"][2]).max()       # the hidden tap of the last prompt token
+        record(f"short_prompt_prefill_{name}_{'x'.join(map(str, lens))}", rms_rel_worst_small=worst["small"], rms_rel_worst_chunked=worst["chunked"],
+               rms_rel_worst_sequential=worst["sequential"], small_vs_chunked_rms_worst=d_small_chunked, tol_max=TOL_MAX, tol_rms_row=0.016)
+
+
 def test_second_attention_schedule_matches_the_oracle():
     """k_attn_decode2 (wave-local prologue, counted waits, one tile in flight per wave while the previous one is multiplied) - the decode
     step's attention at head_dim 128 - against the oracle at contexts that give the waves 0 / 1 / 2 / 3 tiles each (<= 256, 257..512,
