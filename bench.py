@@ -474,7 +474,7 @@ def main():
         # rocprofv3 runs, gfx950 corrections of MI355X_MICROARCH.md); tagged with the kernel source it was measured on, so a stale
         # figure is visible as such
         traffic, traffic_src = None, None
-        for cand in ("r05_pmc", "r04_pmc", "r03_pmc", "r02_pmc", "r01_pmc"):
+        for cand in ("r06_pmc", "r05_pmc", "r04_pmc", "r03_pmc", "r02_pmc", "r01_pmc"):
             try:
                 tj = json.load(open(os.path.join(ROOT, "profiles", cand, "traffic.json")))
                 traffic = tj["gate_up"]["hbm_bytes_per_launch"]

@@ -1,18 +1,18 @@
 # One GPU call that regenerates the evidence under profiles/ (run through gpurun from the repo root):
-#   full -m gpu suite, the driver's bench command (with its secondary block), rocprofv3 kernel stats of the bench, PMC traffic passes,
+#   full -m gpu suite INCLUDING the slow full-depth variants (--runslow), the driver's bench command (with its secondary block), rocprofv3 kernel stats of the bench, PMC traffic passes,
 #   sampler phase stamps.  Outputs land in gpurun_out/final/; copy what is to be judged into profiles/.
 set -x
 cd ${GRAFT_REPO_ROOT:-.}
 mkdir -p gpurun_out/final
 export TMPDIR=/tmp
 rm -f gpurun_out/parity_observed.jsonl
-[ -n "$SKIP_TESTS" ] || { timeout 1800 python -m pytest tests -m gpu -q -rs --durations=8 2>&1 | grep -E "passed|failed|error|SKIPPED|s call|s setup" | tail -14 > gpurun_out/final/pytest_gpu.txt; cat gpurun_out/final/pytest_gpu.txt; }
+[ -n "$SKIP_TESTS" ] || { timeout 2400 python -m pytest tests -m gpu --runslow -q -rs --durations=8 2>&1 | grep -E "passed|failed|error|SKIPPED|s call|s setup" | tail -14 > gpurun_out/final/pytest_gpu.txt; cat gpurun_out/final/pytest_gpu.txt; }
 cp gpurun_out/parity_observed.jsonl gpurun_out/final/ 2>/dev/null
 # PMC traffic first, and installed where bench.py looks for it (on this box's copy of the repo): the bench line below then names the traffic
 # measured on the very sources it runs (`traffic_source.matches_current_build`)
 timeout 900 bash tools/pmc_traffic.sh final > gpurun_out/final/pmc.log 2>&1; cp gpurun_out/final_pmc/traffic.json gpurun_out/final/traffic.json
 rm -rf gpurun_out/final_pmc/fetch gpurun_out/final_pmc/write
-mkdir -p profiles/r05_pmc; [ -s gpurun_out/final/traffic.json ] && cp gpurun_out/final/traffic.json profiles/r05_pmc/traffic.json
+mkdir -p profiles/r06_pmc; [ -s gpurun_out/final/traffic.json ] && cp gpurun_out/final/traffic.json profiles/r06_pmc/traffic.json
 timeout 900 python bench.py > gpurun_out/final/bench.log 2>&1; tail -1 gpurun_out/final/bench.log > gpurun_out/final/bench.json
 rm -rf /tmp/ks; (cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/ks -- python $OLDPWD/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-secondary > /tmp/ks.log 2>&1)
 cp $(find /tmp/ks -name "*kernel_stats.csv" | head -1) gpurun_out/final/bench_kernel_stats.csv
