@@ -37,6 +37,9 @@ struct Bf3Params {
     const uint16_t* xh;
     const uint16_t* xl;
     int mode, ntaps, MT32, KS, Cp, Tp, t_org;
+    int ksplit;           // > 1: blockIdx.z = batch row x slice; the block contracts chunks [nchunks slice / ksplit, nchunks (slice + 1) / ksplit)
+    float* part;          //      and writes its raw float32 sums to part[slice][b][M][ldy] (k_bf3_splitk_epilogue finishes)
+    int batch;
 };
 
 __device__ __forceinline__ float bf3_snake(float x, float a, float ra) { return fmaf(ra, mis_sin_sq(a * x), x); }
@@ -119,11 +122,14 @@ __device__ __forceinline__ void bf3_body(const Bf3Params& P, const float* __rest
     __shared__ __attribute__((aligned(1024))) uint16_t lds[NBUF * BUF];
     const GemmParams& p = P.g;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    int b = blockIdx.z, phase = 0, sh0 = 0, dsh = 0, tapbase = 0;
+    int b = blockIdx.z, phase = 0, sh0 = 0, dsh = 0, tapbase = 0, slice = 0;
     if (P.mode == GEMM_CONVT) { b = blockIdx.z / p.s; phase = blockIdx.z - b * p.s; sh0 = (phase + p.pad) / p.s; dsh = -1; tapbase = phase * NTAPS; }
     else if (P.mode == GEMM_TAPS) { sh0 = -p.pad; dsh = p.dil; }
+    else if (P.ksplit > 1) { b = blockIdx.z / P.ksplit; slice = blockIdx.z - b * P.ksplit; }
     const int shmin = min(sh0, sh0 + (NTAPS - 1) * dsh);
-    const int nchunks = P.Cp / B3_KC;
+    const int nchunks_all = P.Cp / B3_KC;
+    const int c_lo = P.ksplit > 1 ? nchunks_all * slice / P.ksplit : 0;                        // this block's chunks (split-K: a slice of them)
+    const int nchunks = (P.ksplit > 1 ? nchunks_all * (slice + 1) / P.ksplit : nchunks_all) - c_lo;
     const int n0 = blockIdx.x * B3_BN;
 
     if (wave == 4) {
@@ -131,8 +137,8 @@ __device__ __forceinline__ void bf3_body(const Bf3Params& P, const float* __rest
         // lane slot gs holds channel group gs ^ ((i >> 2) & 3) (the swizzle is on the SOURCE address, the LDS side of a DMA is lane-linear)
         const int il = lane >> 2, grp = (lane & 3) ^ ((il >> 2) & 3);
         const size_t col0 = ((size_t)b * P.Tp + (size_t)(n0 + shmin - P.t_org + il)) * P.Cp + grp * 8;
-        const uint16_t* sh = P.xh + col0;
-        const uint16_t* sl = P.xl + col0;
+        const uint16_t* sh = P.xh + col0 + (size_t)c_lo * B3_KC;
+        const uint16_t* sl = P.xl + col0 + (size_t)c_lo * B3_KC;
         const size_t qstride = (size_t)16 * P.Cp;
         auto issue = [&](int cc) {
             const uint16_t* h = sh + cc * B3_KC;
@@ -170,7 +176,7 @@ __device__ __forceinline__ void bf3_body(const Bf3Params& P, const float* __rest
     // the tile-fragment registers with period 2, every index is a compile-time constant and there is no branch between the MFMAs,
     // so the waitcnt pass keeps exactly the two younger weight loads in flight (with branches in the body it fell back to vmcnt(0)).
     const size_t tap_stride = (size_t)P.MT32 * P.KS * 1024, mt_stride = (size_t)P.KS * 1024;
-    const uint16_t* wbase = P.wp + (size_t)lane * 8 + (size_t)tapbase * tap_stride + (size_t)mt0 * mt_stride;
+    const uint16_t* wbase = P.wp + (size_t)lane * 8 + (size_t)tapbase * tap_stride + (size_t)mt0 * mt_stride + (size_t)c_lo * 2 * 1024;
     const size_t mt1 = (mt0 + 1 < P.MT32) ? mt_stride : 0;
     const int ncol = wn * 64 + (lane & 31), kgrp = lane >> 5;
     Bf3A aq[3];
@@ -272,6 +278,22 @@ __device__ __forceinline__ void bf3_body(const Bf3Params& P, const float* __rest
         // lane in the multi-tile experiment: 1.9x slower)
         int lane_hi = lane >> 5;
         asm volatile("" : "+v"(lane_hi));
+        if (P.ksplit > 1) {                                  // split-K: the raw sums of this slice; k_bf3_splitk_epilogue adds the slices up
+#pragma unroll
+            for (int ni = 0; ni < 2; ++ni) {
+                const int n = n0 + wn * 64 + ni * 32 + (lane & 31);
+                if (n >= p.N) continue;
+#pragma unroll
+                for (int mi = 0; mi < 2; ++mi) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int m = (mt0 + mi) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lane_hi;
+                        if (m < p.M) P.part[(((size_t)slice * P.batch + b) * p.M + m) * p.ldy + n] = acc[mi][ni][r];
+                    }
+                }
+            }
+            return;
+        }
 #pragma unroll
         for (int ni = 0; ni < 2; ++ni) {
             const int n = n0 + wn * 64 + ni * 32 + (lane & 31);
@@ -314,6 +336,20 @@ __device__ __forceinline__ void bf3_body(const Bf3Params& P, const float* __rest
 template <int NQ, int NBUF, int NTAPS, int MINW>
 __global__ void __launch_bounds__(B3_THREADS, MINW) k_bf3_gemm(Bf3Params P) {
     bf3_body<NQ, NBUF, NTAPS>(P, P.g.X, P.g.R, P.g.Y, P.g.bias, P.g.scale, P.g.noise);
+}
+
+// split-K: Y = epilogue(sum over slices in slice order + bias) - the 1x1 modes' epilogues of bf3_body (plain / GELU / residual with scale)
+__global__ void k_bf3_splitk_epilogue(const float* __restrict__ part, int S, int batch, int mode, const float* __restrict__ bias, const float* __restrict__ scale,
+                                      const float* __restrict__ R, float* __restrict__ Y, int M, int N, int ldy) {
+    const int n = blockIdx.x * blockDim.x + threadIdx.x, m = blockIdx.y, b = blockIdx.z;
+    if (n >= N) return;
+    const size_t rowo = ((size_t)b * M + m) * ldy;
+    float v = 0.0f;
+    for (int s = 0; s < S; ++s) v += part[(((size_t)s * batch + b) * M + m) * ldy + n];
+    v += bias ? bias[m] : 0.0f;
+    if (mode == GEMM_GELU) v = 0.5f * v * (1.0f + erff(v * 0.70710678118654752f));
+    if (mode == GEMM_RESID && R) { if (scale) v *= scale[m]; v += R[rowo + n]; }
+    Y[rowo + n] = v;
 }
 
 // ---- host side ------------------------------------------------------------------------------------------------------------------------
@@ -383,11 +419,29 @@ bool launch_gemm_bf3(int mode, bool snake, const GemmParams& p_in, int batch, hi
     P.wp = e.wp; P.xh = p.pack->xh.p; P.xl = p.pack->xl.p;
     P.mode = mode; P.ntaps = ntaps; P.MT32 = e.MT32; P.KS = e.KS; P.Cp = e.Cp; P.Tp = Tp; P.t_org = t_org;
     const int phases = mode == GEMM_CONVT ? p.s : 1;
-    dim3 grid(nbx, (p.M + B3_BM - 1) / B3_BM, batch * phases), block(B3_THREADS);
+    // launch-shaped 1x1 contractions (Soprano's ConvNeXt GEMMs at 257 frames: 18 or 54 blocks per row of a 256-CU part, 60 us per launch):
+    // the K range split over blocks.  The factor is a function of the SHAPE of one batch row only (a row's bits do not depend on the batch
+    // it shares); float32 slabs, summed in slice order by k_bf3_splitk_epilogue
+    const int nchunks = e.Cp / B3_KC, per_row = nbx * ((p.M + B3_BM - 1) / B3_BM);
+    int ksplit = 1;
+    if (p.split_k_ok && ntaps == 1 && (mode == GEMM_PLAIN || mode == GEMM_GELU || mode == GEMM_RESID) && !bf3_env("MIS_BF3_NO_SPLITK", 0)) {
+        if (per_row <= 32 && nchunks >= 32) ksplit = 4;
+        else if (per_row <= 64 && nchunks >= 16) ksplit = 2;
+    }
+    if (ksplit > 1) {
+        p.pack->part.alloc((size_t)ksplit * batch * p.M * p.ldy);
+        P.ksplit = ksplit; P.part = p.pack->part.p; P.batch = batch;
+    }
+    dim3 grid(nbx, (p.M + B3_BM - 1) / B3_BM, batch * phases * ksplit), block(B3_THREADS);
     // MINW 3 = two blocks (ten waves) per CU: 168 registers; the 7-tap body then spills a few address temporaries (A/B by MIS_BF3_MINW)
     // MINW 3 = two blocks (ten waves) per CU, 168 registers: fits 1 and 2 taps; the 7-tap body would spill (measured 2.3x slower), so it
     // runs one block per CU (a persistent loop over column tiles was measured too: no gain, profiles/r02_codec/ab_record.json)
-    if (ntaps == 1) hipLaunchKernelGGL((k_bf3_gemm<9, 4, 1, 3>), grid, block, 0, s, P);
+    if (ntaps == 1) {
+        hipLaunchKernelGGL((k_bf3_gemm<9, 4, 1, 3>), grid, block, 0, s, P);
+        if (ksplit > 1)
+            hipLaunchKernelGGL(k_bf3_splitk_epilogue, dim3((p.N + 255) / 256, p.M, batch), dim3(256), 0, s, P.part, ksplit, batch, mode, p.bias, p.scale, p.R, p.Y, p.M,
+                               p.N, p.ldy);
+    }
     else if (ntaps == 2) hipLaunchKernelGGL((k_bf3_gemm<9, 4, 2, 3>), grid, block, 0, s, P);
     else if (nq == 9) hipLaunchKernelGGL((k_bf3_gemm<9, 4, 7, 2>), grid, block, 0, s, P);
     else hipLaunchKernelGGL((k_bf3_gemm<12, 4, 7, 2>), grid, block, 0, s, P);

@@ -29,6 +29,7 @@ struct CodecPack {
     struct Entry { const float* at; int ntaps, Cin, M, Cp, KS, MT32; uint16_t* wp; };
     std::vector<Entry> entries;
     DevBuf<uint16_t> xh, xl;
+    DevBuf<float> part;   // split-K slabs of launch-shaped contractions (GemmParams.split_k_ok)
     CodecPack() {}
     CodecPack(const CodecPack&) = delete;
     CodecPack& operator=(const CodecPack&) = delete;
@@ -66,6 +67,9 @@ struct GemmParams {
     int x_lo;             // lowest valid X column (<= 0): columns [x_lo, 0) hold carried history (streaming decode), zero below
     int dup_bias_n0;      // CONVT: add the bias a second time to output frame n = 0 - the reference's streaming overlap-add sums
                           // two biased outputs there (DecoderBlockUpsample.step, Qwen3TTSSpeechTokenizer.swift:553-576)
+    int split_k_ok;       // 1x1 modes on the split-bf16 path: the launch may split its K range over blocks when one batch row gives too few
+                          // blocks to fill the chip (the factor depends on the SHAPE only, never on the batch: a row's result is the same
+                          // whatever batch it shares); float32 slabs summed in slice order by a second launch that applies the epilogue
     int taps, dil;        // TAPS: dense conv, K = taps*Cin, tap j reads x[:, n - pad + j*dil] (zero outside); A^T row j*Cin + c;
                           // pad = (taps-1)*dil: causal, (taps-1)*dil/2: "same"; optional R (+scale) residual epilogue
 };

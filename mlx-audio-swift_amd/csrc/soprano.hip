@@ -360,10 +360,12 @@ static void soprano_decode_device(mis_soprano* c, const float* hidden_dev, int64
         launch_sop_ln_ct(t1, t2, W + blk.lnw, W + blk.lnb, d, T, batch, s);
         g = GemmParams{};
         g.AT = W + blk.p1; g.bias = W + blk.b1; g.X = t2; g.Y = t1; g.M = inter; g.K = d; g.N = T; g.Tin = T; g.Tout = T;
+        g.split_k_ok = 1;                                                // (a sentence is a few hundred frames: 18-54 blocks per row without it)
         launch_gemm(GEMM_GELU, false, g, batch, s);
         g = GemmParams{};
         g.AT = W + blk.p2; g.bias = W + blk.b2; g.X = t1; g.Y = o; g.R = h; g.scale = W + blk.gamma;
         g.M = d; g.K = inter; g.N = T; g.Tin = T; g.Tout = T;
+        g.split_k_ok = 1;
         launch_gemm(GEMM_RESID, false, g, batch, s);
         std::swap(h, o);
     }
